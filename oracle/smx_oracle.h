@@ -1,0 +1,53 @@
+/* oracle/smx_oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the reference algorithm for SPAdes' k-mer counting /
+ * de Bruijn construction hot path. It exists so that tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg can check the HIP product path; NOTHING under spades_amd/
+ * may include, link or call it.
+ *
+ * Parity status: PINNED. The restatement is checked (tests/test_oracle_*.py) against
+ *   - the reference's own worked byte example (kmercount.cpp:160-170),
+ *   - golden final_kmers / bucket-size fixtures produced by the REAL reference classes
+ *     (oracle/_ref/ref_kmercount, built by oracle/ref_recipe/Makefile from the sources where
+ *     they lie under /root/reference) and by the reference binaries spades-kmercount /
+ *     spades-gbuilder (tests/golden/, generator script tests/golden/make_golden.py),
+ *   - the six k=5 known-answer graph tests of src/test/debruijn/construction_test.cpp:30-64.
+ */
+#ifndef SMX_ORACLE_H
+#define SMX_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_WORDS 4 /* RtSeq = RuntimeSeq<128,uint64_t>: rtseq.hpp:768, seq_common.hpp:19-43 */
+
+/* ---- k-mer value type (rtseq.hpp) ---- */
+unsigned orc_words(unsigned K);                                   /* GetDataSize, rtseq.hpp:131-133 */
+void orc_from_string(uint64_t *w, unsigned K, const char *s);    /* init, rtseq.hpp:166-187 */
+void orc_to_string(const uint64_t *w, unsigned K, char *s);      /* str, rtseq.hpp:629-635 */
+void orc_shl(uint64_t *w, unsigned K, unsigned c);               /* operator<<=, rtseq.hpp:459-476 */
+void orc_rc(const uint64_t *w, unsigned K, uint64_t *out);       /* FastRC, rtseq.hpp:81-117 */
+int  orc_is_minimal(const uint64_t *w, unsigned K);              /* IsMinimal, rtseq.hpp:409-417 */
+int  orc_less_nucl(const uint64_t *a, const uint64_t *b, unsigned K); /* operator<, rtseq.hpp:742-750 */
+uint64_t orc_xxh3_64(const void *data, size_t len);             /* XXH3_64bits_withSeed(.,.,0), len in {8,16,24,32} */
+uint64_t orc_bucket(const uint64_t *w, unsigned K, uint64_t num_buckets); /* kmer_buckets.hpp:47-52 */
+
+/* ---- read preprocessing (longest_valid_wrapper.hpp:16-43) ---- */
+void orc_longest_valid(const char *s, size_t n, size_t *from, size_t *to);
+
+/* ---- counting (kmercount.cpp:65-83 mode 'A'; kmer_splitters.hpp:28-44 mode 'B') ----
+ * reads: concatenated ASCII, read i = bases[off[i] .. off[i+1]).
+ * Returns number of distinct records; *out is malloc'ed (caller frees with orc_free):
+ * buckets 0..B-1 concatenated, strictly increasing (w0,w1,..) inside a bucket
+ * (kmer_splitter.hpp:140-141, kmer_index_builder.hpp:346-430,190-203). bucket_sizes[B]. */
+int64_t orc_count(char mode, unsigned K, unsigned num_buckets,
+                  const char *bases, const uint64_t *off, uint64_t nreads,
+                  uint64_t **out, uint64_t *bucket_sizes);
+void orc_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
