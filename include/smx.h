@@ -1,0 +1,124 @@
+/* include/smx.h — C ABI of libspades_mi355x.so
+ *
+ * MI355X-native (gfx950) replacement for the k-mer counting / de Bruijn construction hot path of
+ * SPAdes. The reference has no C ABI for this path; its seams are C++ virtuals and on-disk files
+ * (SURVEY.md §8b). Every entry point below names the reference interface it stands in for
+ * (paths relative to /root/reference/src). INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types cross the boundary;
+ *   - every function returns 0 or one of the reference's process exit codes
+ *     (common/utils/logger/error_codes.hpp:14-20), never throws; text via smx_last_error();
+ *   - one host thread per context (thread-compatible, like one KMerDiskCounter object);
+ *   - k-mer record = ceil(K/32) little-endian uint64, nucleotide i at bits 2*(i mod 32) of word
+ *     i/32, A=0 C=1 G=2 T=3, pad bits zero (common/sequence/rtseq.hpp:131-151,379-382);
+ *   - "device" pointers are HBM addresses on the context's GPU.
+ */
+#ifndef SMX_H
+#define SMX_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smx_ctx smx_ctx;
+
+enum { /* common/utils/logger/error_codes.hpp:14-20 */
+    SMX_OK = 0,
+    SMX_INVALID_INPUT_FORMAT = 64,
+    SMX_INPUT_FILE_NOT_FOUND = 65,
+    SMX_IO_ERROR = 66,
+    SMX_INVALID_PARAMETER = 67,
+    SMX_MEMORY_LIMIT_EXCEEDED = 68,
+    SMX_DEVICE_ERROR = 70 /* HIP runtime failure (no reference equivalent) */
+};
+
+enum { /* which k-mers a read contributes */
+    SMX_MODE_ALL = 0,      /* 'A': every K-mer of read and RC(read) — spades-kmercount,
+                              projects/spades_tools/kmercount.cpp:65-83 */
+    SMX_MODE_CANONICAL = 1 /* 'B': only K-mers with IsMinimal() — construction,
+                              common/kmer_index/kmer_mph/kmer_splitters.hpp:28-44 +
+                              common/kmer_index/ph_map/storing_traits.hpp:92-101 */
+};
+
+/* ---- context ------------------------------------------------------------------------------
+ * Replaces the pair (workdir, KMerDiskCounter object): kmer_index_builder.hpp:284-304.
+ * device = HIP device ordinal; hbm_budget_bytes = 0 -> use what the device has free. */
+int smx_create(smx_ctx **out, int device, size_t hbm_budget_bytes);
+void smx_destroy(smx_ctx *ctx);
+const char *smx_last_error(const smx_ctx *ctx);
+const char *smx_version(void);
+/* Tuning / test hooks (no reference equivalent; closest is the -b buffer-size knob of
+ * kmercount.cpp:139): "leaf_cap" (records sorted per LDS leaf), "s1"/"s2" (MSD split bits). */
+int smx_set_option(smx_ctx *ctx, const char *key, int64_t value);
+
+/* ---- reads -> HBM -------------------------------------------------------------------------
+ * Replaces the read streams the splitters pull from: io::EasyStream(file, followed_by_rc=true,
+ * handle_Ns=true) (common/io/reads/io_helper.cpp:21-34) for mode A, and the binary read streams
+ * (common/io/reads/binary_streams.hpp:54-102) for mode B. Reverse complements are NOT submitted:
+ * the kernels generate them. Submissions append to the context's resident batch. */
+int smx_reads_clear(smx_ctx *ctx);
+/* ASCII reads, read i = bases[offsets[i] .. offsets[i+1]). Applies the reference's N rule on the
+ * host: each read is cut to its longest run of ACGTacgt, first one on ties
+ * (common/io/reads/longest_valid_wrapper.hpp:16-53), then 2-bit packs and uploads. */
+int smx_submit_reads_ascii(smx_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads);
+/* Already-packed reads in host memory: one 2-bit stream (layout as a k-mer record, arbitrarily
+ * long), read i occupies nucleotides [start[i], start[i]+len[i]). Mirrors Sequence::BinWrite's
+ * payload (common/sequence/sequence.hpp BinWrite: size_t len + words). */
+int smx_submit_reads_packed(smx_ctx *ctx, const uint64_t *words, uint64_t n_words,
+                            const uint64_t *start, const uint32_t *len, uint64_t n_reads);
+/* Same, but the three arrays already live in HBM (benchmark path: inputs resident before the
+ * timed region). The context borrows the pointers until smx_reads_clear()/smx_destroy();
+ * d_words must be readable for n_words + 8 words (tail pad). */
+int smx_submit_reads_device(smx_ctx *ctx, const void *d_words, uint64_t n_words,
+                            const void *d_start, const void *d_len, uint64_t n_reads);
+int smx_reads_info(const smx_ctx *ctx, uint64_t *n_reads, uint64_t *n_bases);
+
+/* ---- counting -----------------------------------------------------------------------------
+ * Replaces KMerCounter<RtSeq>::Count(num_buckets, num_threads)
+ * (common/kmer_index/kmer_mph/kmer_index_builder.hpp:273,306-332) together with the splitter it
+ * drives (KMerSplitter<RtSeq>::Split, kmer_mph/kmer_splitter.hpp:38). Result, resident in HBM:
+ * num_buckets sorted-unique runs, bucket b = mulhi64(XXH3_64(record), num_buckets)
+ * (kmer_mph/kmer_buckets.hpp:47-52), records strictly increasing as (w0,w1,..) tuples inside a
+ * bucket — i.e. exactly the bytes of the reference's bucket files kmers_XXXXXX.<b>.
+ * num_buckets: 16 for spades-kmercount (kmercount.cpp:220), 10*nthreads for construction
+ * (extension_index/kmer_extension_index_builder.hpp:75). It is an input of the ORDER, not of the
+ * parallelism. */
+int smx_count(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets);
+/* KMerDiskStorage::total_kmers / bucket_size (kmer_index_builder.hpp:139-150,176-178) */
+int smx_count_info(const smx_ctx *ctx, uint64_t *n_records, unsigned *words_per_record,
+                   uint64_t *n_kmer_instances);
+int smx_bucket_sizes(const smx_ctx *ctx, uint64_t *sizes /* [num_buckets] */);
+/* KMerDiskStorage::bucket(i) contents (kmer_index_builder.hpp:180-190) -> host memory */
+int smx_copy_bucket(const smx_ctx *ctx, unsigned bucket, void *host_dst);
+/* KMerDiskStorage::merge() (kmer_index_builder.hpp:190-203): buckets 0..B-1 concatenated =
+ * the bytes of <workdir>/final_kmers (kmercount.cpp:221-223) */
+int smx_copy_final_kmers(const smx_ctx *ctx, void *host_dst);
+int smx_write_final_kmers(const smx_ctx *ctx, const char *path);
+/* device view of the same bytes (valid until the next smx_count / smx_destroy) */
+const void *smx_device_kmers(const smx_ctx *ctx);
+
+/* ---- multi-GPU sharding ---------------------------------------------------
+ * Bucket ownership is a contiguous bucket range per rank. smx_extract_partition runs the
+ * extract + hash stage on the local read shard and groups the records by owner rank into a
+ * caller-provided HBM buffer (the caller performs the RCCL all-to-all; the library never touches
+ * the communicator). smx_count_records then sorts/uniques records the caller received. */
+int smx_extract_count(smx_ctx *ctx, unsigned K, int mode, uint64_t *n_records);
+int smx_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets, unsigned world,
+                          void *d_records, uint64_t capacity_records, uint64_t *counts /* [world] */);
+int smx_count_records(smx_ctx *ctx, unsigned K, unsigned num_buckets, const void *d_records,
+                      uint64_t n_records);
+/* first bucket owned by rank r of world (rank r owns [first(r), first(r+1))) */
+unsigned smx_rank_first_bucket(unsigned num_buckets, unsigned world, unsigned rank);
+
+/* ---- instrumentation -----------------------------------------------------------------------
+ * Per-stage GPU time of the last smx_count in milliseconds (HIP events on the library's stream).
+ * names/ms arrays of capacity cap; returns number of stages. Stands where the reference has
+ * TIME_TRACE_SCOPE("KMerDiskCounter::Split"/"::Count") (kmer_index_builder.hpp:309-324). */
+int smx_last_timings(const smx_ctx *ctx, const char **names, float *ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+"""ctypes binding of libspades_mi355x.so (include/smx.h). Fails loudly when the library is missing."""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libspades_mi355x.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "smx.h")
+
+OK = 0
+INVALID_INPUT_FORMAT, INPUT_FILE_NOT_FOUND, IO_ERROR, INVALID_PARAMETER, MEMORY_LIMIT_EXCEEDED, DEVICE_ERROR = 64, 65, 66, 67, 68, 70
+MODE_ALL, MODE_CANONICAL = 0, 1
+
+_lib = None
+
+
+def declared_symbols():
+    """Every function include/smx.h declares (used by the CPU-side export test)."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(smx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). spades_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64p, u32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    sig = {
+        "smx_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_size_t]),
+        "smx_destroy": (None, [vp]),
+        "smx_last_error": (C.c_char_p, [vp]),
+        "smx_version": (C.c_char_p, []),
+        "smx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+        "smx_reads_clear": (C.c_int, [vp]),
+        "smx_submit_reads_ascii": (C.c_int, [vp, C.c_char_p, u64p, C.c_uint64]),
+        "smx_submit_reads_packed": (C.c_int, [vp, u64p, C.c_uint64, u64p, u32p, C.c_uint64]),
+        "smx_submit_reads_device": (C.c_int, [vp, vp, C.c_uint64, vp, vp, C.c_uint64]),
+        "smx_reads_info": (C.c_int, [vp, u64p, u64p]),
+        "smx_count": (C.c_int, [vp, C.c_uint, C.c_int, C.c_uint]),
+        "smx_count_info": (C.c_int, [vp, u64p, C.POINTER(C.c_uint), u64p]),
+        "smx_bucket_sizes": (C.c_int, [vp, u64p]),
+        "smx_copy_bucket": (C.c_int, [vp, C.c_uint, vp]),
+        "smx_copy_final_kmers": (C.c_int, [vp, vp]),
+        "smx_write_final_kmers": (C.c_int, [vp, C.c_char_p]),
+        "smx_device_kmers": (vp, [vp]),
+        "smx_extract_count": (C.c_int, [vp, C.c_uint, C.c_int, u64p]),
+        "smx_extract_partition": (C.c_int, [vp, C.c_uint, C.c_int, C.c_uint, C.c_uint, vp, C.c_uint64, u64p]),
+        "smx_count_records": (C.c_int, [vp, C.c_uint, C.c_uint, vp, C.c_uint64]),
+        "smx_rank_first_bucket": (C.c_uint, [C.c_uint, C.c_uint, C.c_uint]),
+        "smx_last_timings": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

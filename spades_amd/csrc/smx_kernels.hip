@@ -1,0 +1,549 @@
+// spades_amd/csrc/smx_kernels.hip — gfx950 kernels of the k-mer counting path.
+//
+// Pipeline (one resident batch; all integer work, HBM-bound — no MFMA by design):
+//   mark     per read: set one bit per valid K-mer start in a position bitmask (reads shorter than K
+//            contribute nothing: kmer_splitters.hpp:30 / kmercount.cpp:71)
+//   L1 hist  every valid window -> record(s) -> XXH3 -> bucket -> level-1 bin; LDS histograms
+//   L1 scat  same extraction, LDS-staged multisplit so that each bin receives contiguous runs
+//   L2 hist / L2 scat   MSD refinement of every level-1 bin on the next key bits
+//   sort     one workgroup per fine bin: LDS bitonic sort by (w0,w1,..) + adjacent-unique
+//            (= pdqsort_pod + std::unique of kmer_splitter.hpp:140-141); oversized bins take the
+//            global-memory merge path (= the loser-tree merge of kmer_index_builder.hpp:357-415)
+//   compact  fine bins are already in (bucket, key) order -> concatenate uniques
+//
+// Bin order == output order: level-1 bin = bucket * 2^s1 + top s1 key bits, level-2 bin = next s2
+// key bits, so concatenating sorted fine bins yields exactly "buckets 0..B-1, each strictly
+// increasing" (kmer_index_builder.hpp:190-203).
+#include "smx_device.hpp"
+
+namespace smx {
+
+constexpr int BLK = 256;
+
+enum { SRC_READS_ALL = 0, SRC_READS_CANON = 1, SRC_RECS = 2 };
+enum { BIN_L1 = 0, BIN_L2 = 1, BIN_OWNER = 2 };
+
+struct PassArgs {
+    // reads source
+    const uint64_t *seq;
+    const uint64_t *mask;
+    uint64_t G;  // number of stream positions (nucleotides)
+    // records source
+    const void *recs;
+    const unsigned long long *seg_off;  // [nseg+1] record offsets of the input segments
+    const uint32_t *tile_start;         // [nseg+1] prefix of tiles per segment
+    uint32_t nseg;
+    uint32_t tile_recs;  // records per tile for this launch
+    // binning
+    unsigned K;
+    uint32_t num_buckets;
+    unsigned s1, s2;
+    uint32_t world;
+    uint32_t F;  // bins per segment
+    unsigned long long *hist;    // [nseg*F]
+    unsigned long long *cursor;  // [nseg*F]
+    void *out;
+};
+
+template <int NW, int BINF>
+__device__ __forceinline__ uint32_t bin_of(const Rec<NW> &x, const PassArgs &a) {
+    if constexpr (BINF == BIN_L1) {
+        uint32_t b = bucket_of(xxh3_rec<NW>(x), a.num_buckets);
+        return a.s1 ? ((b << a.s1) | (key_top32<NW>(x, a.K) >> (32 - a.s1))) : b;
+    } else if constexpr (BINF == BIN_L2) {
+        return (key_top32<NW>(x, a.K) >> (32 - a.s1 - a.s2)) & ((1u << a.s2) - 1);
+    } else {
+        uint32_t b = bucket_of(xxh3_rec<NW>(x), a.num_buckets);
+        return (uint32_t)(((uint64_t)b * a.world) / a.num_buckets);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ mark
+__global__ void k_mark_windows(const uint64_t *__restrict__ start, const uint32_t *__restrict__ len, uint64_t n,
+                               unsigned K, unsigned long long *mask, unsigned long long *total) {
+    __shared__ unsigned long long scratch[BLK / 64 + 2];
+    uint64_t r = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+    unsigned long long nwin = 0;
+    if (r < n) {
+        uint32_t l = len[r];
+        if (l >= K) {
+            nwin = l - K + 1;
+            uint64_t s = start[r], e = s + nwin - 1;
+            uint64_t fw = s >> 6, lw = e >> 6;
+            unsigned long long fm = ~0ull << (s & 63);
+            unsigned long long lm = ~0ull >> (63 - (e & 63));
+            if (fw == lw) {
+                atomicOr(&mask[fw], fm & lm);
+            } else {
+                atomicOr(&mask[fw], fm);
+                for (uint64_t w = fw + 1; w < lw; ++w) mask[w] = ~0ull;  // interior words belong to this read only
+                atomicOr(&mask[lw], lm);
+            }
+        }
+    }
+    unsigned long long tot;
+    block_excl_scan<unsigned long long>(nwin, scratch, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(total, tot);
+}
+
+// -------------------------------------------------------------------------------- record sources
+// Fills r[]/valid for this thread of tile `tile`. READS: RPT/RPP positions per thread, position =
+// tile*TP + j*BLK + tid (a wave covers 64 consecutive positions = one mask word).
+template <int NW, int SRC, int RPT>
+__device__ __forceinline__ void fetch_records(const PassArgs &a, uint64_t tile, uint64_t seg_base, uint32_t seg_n,
+                                              Rec<NW> (&r)[RPT], uint32_t &validmask) {
+    validmask = 0;
+    if constexpr (SRC == SRC_RECS) {
+        const Rec<NW> *in = (const Rec<NW> *)a.recs + seg_base;
+        const uint64_t base = tile * (uint64_t)(RPT * BLK);
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            uint64_t i = base + (uint64_t)j * BLK + threadIdx.x;
+            if (i < seg_n) {
+                r[j] = in[i];
+                validmask |= 1u << j;
+            }
+        }
+    } else {
+        constexpr int RPP = (SRC == SRC_READS_ALL) ? 2 : 1;
+        constexpr int PPT = RPT / RPP;
+        const uint64_t base = tile * (uint64_t)(PPT * BLK);
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            uint64_t g = base + (uint64_t)j * BLK + threadIdx.x;
+            bool ok = g < a.G && ((a.mask[g >> 6] >> (g & 63)) & 1);
+            if (ok) {
+                Rec<NW> x = load_window<NW>(a.seq, g, a.K);
+                Rec<NW> y = rec_rc<NW>(x, a.K);
+                if constexpr (SRC == SRC_READS_ALL) {
+                    r[2 * j] = x;
+                    r[2 * j + 1] = y;
+                    validmask |= 3u << (2 * j);
+                } else {
+                    r[j] = rc_ge<NW>(y, x) ? x : y;  // canonical representative (IsMinimal filter on read+RC stream)
+                    validmask |= 1u << j;
+                }
+            }
+        }
+    }
+}
+
+// tile -> (segment, tile index inside segment) for the records source
+__device__ __forceinline__ bool locate_tile(const PassArgs &a, uint32_t blk, uint32_t *sh, uint32_t &seg, uint32_t &tin) {
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = a.nseg;  // find seg with tile_start[seg] <= blk < tile_start[seg+1]
+        if (blk >= a.tile_start[a.nseg]) {
+            sh[0] = 0xFFFFFFFFu;
+        } else {
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (a.tile_start[mid] <= blk) lo = mid; else hi = mid;
+            }
+            sh[0] = lo;
+            sh[1] = blk - a.tile_start[lo];
+        }
+    }
+    __syncthreads();
+    seg = sh[0];
+    tin = sh[1];
+    __syncthreads();
+    return seg != 0xFFFFFFFFu;
+}
+
+// ------------------------------------------------------------------------------------------ hist
+// READS: persistent grid-stride over position tiles, one LDS histogram per workgroup, flushed once.
+// RECS:  one workgroup per (segment, tile of a.tile_recs records), flushed per tile.
+template <int NW, int SRC, int BINF, int RPT>
+__global__ void __launch_bounds__(BLK) k_hist(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lh[];
+    __shared__ uint32_t sh[2];
+    for (uint32_t i = threadIdx.x; i < a.F; i += BLK) lh[i] = 0;
+    __syncthreads();
+    if constexpr (SRC == SRC_RECS) {
+        uint32_t seg, tin;
+        if (!locate_tile(a, blockIdx.x, sh, seg, tin)) return;
+        const uint64_t sb = a.seg_off[seg];
+        const uint64_t sn = a.seg_off[seg + 1] - sb;
+        const uint64_t t0 = (uint64_t)tin * a.tile_recs;
+        const uint64_t t1 = (sn < t0 + a.tile_recs) ? sn : t0 + a.tile_recs;
+        const Rec<NW> *in = (const Rec<NW> *)a.recs + sb;
+        for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK) {
+            Rec<NW> x = in[i];
+            atomicAdd(&lh[bin_of<NW, BINF>(x, a)], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < a.F; i += BLK)
+            if (lh[i]) atomicAdd(&a.hist[(uint64_t)seg * a.F + i], (unsigned long long)lh[i]);
+    } else {
+        constexpr int RPP = (SRC == SRC_READS_ALL) ? 2 : 1;
+        constexpr int PPT = RPT / RPP;
+        const uint64_t ntiles = (a.G + (uint64_t)PPT * BLK - 1) / ((uint64_t)PPT * BLK);
+        for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            Rec<NW> r[RPT];
+            uint32_t vm;
+            fetch_records<NW, SRC, RPT>(a, tile, 0, 0, r, vm);
+#pragma unroll
+            for (int j = 0; j < RPT; ++j)
+                if (vm & (1u << j)) atomicAdd(&lh[bin_of<NW, BINF>(r[j], a)], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < a.F; i += BLK)
+            if (lh[i]) atomicAdd(&a.hist[i], (unsigned long long)lh[i]);
+    }
+}
+
+// --------------------------------------------------------------------------------------- scatter
+// LDS-staged multisplit of one tile (<= RPT*BLK records) into a.F bins of its segment.
+// LDS carve (dynamic): stage[TR*NW] u64 | ldelta[F] u64 | lhist[F] u32 | sbin[TR] u16
+template <int NW, int SRC, int BINF, int RPT>
+__global__ void __launch_bounds__(BLK) k_scatter(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    constexpr int TR = RPT * BLK;
+    uint64_t *stage = lds64;
+    uint64_t *ldelta = stage + (size_t)TR * NW;
+    uint32_t *lhist = (uint32_t *)(ldelta + a.F);
+    uint16_t *sbin = (uint16_t *)(lhist + a.F);
+    __shared__ uint32_t sh[2];
+    __shared__ uint32_t scr[BLK / 64 + 2];
+
+    uint32_t seg = 0, tin = blockIdx.x;
+    uint64_t sb = 0;
+    uint32_t sn = 0;
+    if constexpr (SRC == SRC_RECS) {
+        if (!locate_tile(a, blockIdx.x, sh, seg, tin)) return;
+        sb = a.seg_off[seg];
+        uint64_t full = a.seg_off[seg + 1] - sb;
+        // fetch_records indexes inside the segment with a 64-bit base; seg_n is only compared, clamp to u32 range per tile
+        uint64_t t0 = (uint64_t)tin * TR;
+        sb += t0;
+        sn = (uint32_t)((full - t0 < (uint64_t)TR) ? full - t0 : (uint64_t)TR);
+        tin = 0;
+    }
+    for (uint32_t i = threadIdx.x; i < a.F; i += BLK) lhist[i] = 0;
+    __syncthreads();
+
+    Rec<NW> r[RPT];
+    uint32_t vm;
+    fetch_records<NW, SRC, RPT>(a, tin, sb, sn, r, vm);
+    uint32_t packed[RPT];  // bin << 16 | slot... slot can reach TR-1 (<= 4095): 13+ bits each -> use two arrays
+    uint32_t slot[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        if (vm & (1u << j)) {
+            packed[j] = bin_of<NW, BINF>(r[j], a);
+            slot[j] = atomicAdd(&lhist[packed[j]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of lhist over F bins + global reservation
+    const uint32_t per = (a.F + BLK - 1) / BLK;
+    const uint32_t d0 = threadIdx.x * per, d1 = min(a.F, d0 + per);
+    uint32_t sum = 0;
+    for (uint32_t d = d0; d < d1; ++d) sum += lhist[d];
+    uint32_t total;
+    uint32_t run = block_excl_scan<uint32_t>(sum, scr, &total);
+    unsigned long long *cur = a.cursor + (uint64_t)seg * a.F;
+    for (uint32_t d = d0; d < d1; ++d) {
+        uint32_t c = lhist[d];
+        lhist[d] = run;
+        if (c) ldelta[d] = (uint64_t)atomicAdd(&cur[d], (unsigned long long)c) - run;
+        run += c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        if (vm & (1u << j)) {
+            uint32_t idx = lhist[packed[j]] + slot[j];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) stage[(size_t)idx * NW + w] = r[j].w[w];
+            sbin[idx] = (uint16_t)packed[j];
+        }
+    }
+    __syncthreads();
+    Rec<NW> *out = (Rec<NW> *)a.out;
+    const Rec<NW> *st = (const Rec<NW> *)stage;
+    for (uint32_t idx = threadIdx.x; idx < total; idx += BLK) out[ldelta[sbin[idx]] + idx] = st[idx];
+}
+
+// ------------------------------------------------------------------------------------------ scans
+// Single-workgroup exclusive scan (n small, e.g. level-1 histogram): out[i] = sum in[0..i), out[n] = total.
+__global__ void k_scan_small(const unsigned long long *in, unsigned long long *out, uint32_t n) {
+    __shared__ unsigned long long scr[BLK / 64 + 2];
+    const uint32_t per = (n + BLK - 1) / BLK;
+    const uint32_t d0 = min(n, threadIdx.x * per), d1 = min(n, d0 + per);
+    unsigned long long sum = 0;
+    for (uint32_t d = d0; d < d1; ++d) sum += in[d];
+    unsigned long long tot;
+    unsigned long long run = block_excl_scan<unsigned long long>(sum, scr, &tot);
+    for (uint32_t d = d0; d < d1; ++d) {
+        unsigned long long c = in[d];
+        out[d] = run;
+        run += c;
+    }
+    if (threadIdx.x == 0) out[n] = tot;
+}
+
+constexpr int SCAN_PER = 8;
+constexpr int SCAN_TILE = BLK * SCAN_PER;
+// large scan, phase 1: per-tile sums
+__global__ void k_scan_reduce(const unsigned long long *in, uint64_t n, unsigned long long *partial) {
+    __shared__ unsigned long long scr[BLK / 64 + 2];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_PER;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; ++j)
+        if (base + j < n) s += in[base + j];
+    unsigned long long tot;
+    block_excl_scan<unsigned long long>(s, scr, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+// phase 3: per-tile exclusive scan with tile offset; also writes out[n] = grand total from the last tile
+__global__ void k_scan_apply(const unsigned long long *in, uint64_t n, const unsigned long long *partial_off,
+                             unsigned long long *out) {
+    __shared__ unsigned long long scr[BLK / 64 + 2];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_PER;
+    unsigned long long v[SCAN_PER], s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; ++j) {
+        v[j] = (base + j < n) ? in[base + j] : 0;
+        s += v[j];
+    }
+    unsigned long long tot;
+    unsigned long long run = block_excl_scan<unsigned long long>(s, scr, &tot) + partial_off[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; ++j) {
+        if (base + j < n) out[base + j] = run;
+        run += v[j];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == BLK - 1) out[n] = run;
+}
+
+// tiles per segment prefix: tile_start[s] = sum_{s'<s} ceil(len(s')/tile)
+__global__ void k_tile_prefix(const unsigned long long *seg_off, uint32_t nseg, uint32_t tile, uint32_t *tile_start) {
+    __shared__ uint32_t scr[BLK / 64 + 2];
+    const uint32_t per = (nseg + BLK - 1) / BLK;
+    const uint32_t d0 = min(nseg, threadIdx.x * per), d1 = min(nseg, d0 + per);
+    uint32_t sum = 0;
+    for (uint32_t d = d0; d < d1; ++d) sum += (uint32_t)((seg_off[d + 1] - seg_off[d] + tile - 1) / tile);
+    uint32_t tot;
+    uint32_t run = block_excl_scan<uint32_t>(sum, scr, &tot);
+    for (uint32_t d = d0; d < d1; ++d) {
+        tile_start[d] = run;
+        run += (uint32_t)((seg_off[d + 1] - seg_off[d] + tile - 1) / tile);
+    }
+    if (threadIdx.x == 0) tile_start[nseg] = tot;
+}
+
+// ------------------------------------------------------------------------------------------ sort
+template <int NW>
+__device__ __forceinline__ Rec<NW> lds_get(const uint64_t *s, uint32_t i) {
+    Rec<NW> r;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) r.w[w] = s[(size_t)i * NW + w];
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ void lds_put(uint64_t *s, uint32_t i, const Rec<NW> &r) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s[(size_t)i * NW + w] = r.w[w];
+}
+
+// Normalised bitonic network (every comparator puts the smaller record at the lower index), so the
+// virtual +inf padding at indices >= n never moves and n need not be a power of two.
+template <int NW>
+__device__ void lds_bitonic_sort(uint64_t *s, uint32_t n) {
+    uint32_t N = 1;
+    while (N < n) N <<= 1;
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t t = threadIdx.x; t < (N >> 1); t += BLK) {
+            uint32_t i = (t / hk) * k + (t % hk);
+            uint32_t j = i ^ (k - 1);
+            if (j < n) {
+                Rec<NW> x = lds_get<NW>(s, i), y = lds_get<NW>(s, j);
+                if (rec_less<NW>(y, x)) {
+                    lds_put<NW>(s, i, y);
+                    lds_put<NW>(s, j, x);
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t jj = k >> 2; jj > 0; jj >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (N >> 1); t += BLK) {
+                uint32_t i = (t / jj) * (jj << 1) + (t % jj);
+                uint32_t j = i + jj;
+                if (j < n) {
+                    Rec<NW> x = lds_get<NW>(s, i), y = lds_get<NW>(s, j);
+                    if (rec_less<NW>(y, x)) {
+                        lds_put<NW>(s, i, y);
+                        lds_put<NW>(s, j, x);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// sorted LDS array -> unique records written to dst (global); returns unique count (all threads).
+template <int NW>
+__device__ uint32_t lds_unique_store(const uint64_t *s, uint32_t n, Rec<NW> *dst, uint32_t *scr) {
+    const uint32_t per = (n + BLK - 1) / BLK;
+    const uint32_t i0 = min(n, threadIdx.x * per), i1 = min(n, i0 + per);
+    uint32_t cnt = 0;
+    for (uint32_t i = i0; i < i1; ++i)
+        cnt += (i == 0) || !rec_eq<NW>(lds_get<NW>(s, i), lds_get<NW>(s, i - 1));
+    uint32_t tot;
+    uint32_t run = block_excl_scan<uint32_t>(cnt, scr, &tot);
+    for (uint32_t i = i0; i < i1; ++i) {
+        Rec<NW> x = lds_get<NW>(s, i);
+        if (i == 0 || !rec_eq<NW>(x, lds_get<NW>(s, i - 1))) dst[run++] = x;
+    }
+    return tot;
+}
+
+// One workgroup per fine bin. Bins larger than cap are queued for k_sort_big.
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned long long *off, uint32_t nbins, uint32_t cap,
+                                                    unsigned long long *ucount, uint32_t *biglist, uint32_t *bigcount) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    __shared__ uint32_t scr[BLK / 64 + 2];
+    const uint32_t b = blockIdx.x;
+    if (b >= nbins) return;
+    const uint64_t o = off[b];
+    const uint64_t n64 = off[b + 1] - o;
+    if (n64 == 0) {
+        if (threadIdx.x == 0) ucount[b] = 0;
+        return;
+    }
+    if (n64 > cap) {
+        if (threadIdx.x == 0) biglist[atomicAdd(bigcount, 1u)] = b;
+        return;
+    }
+    const uint32_t n = (uint32_t)n64;
+    Rec<NW> *g = (Rec<NW> *)buf + o;
+    for (uint32_t i = threadIdx.x; i < n; i += BLK) lds_put<NW>(lds64, i, g[i]);
+    __syncthreads();
+    lds_bitonic_sort<NW>(lds64, n);
+    uint32_t u = lds_unique_store<NW>(lds64, n, g, scr);
+    if (threadIdx.x == 0) ucount[b] = u;
+}
+
+template <int NW>
+__device__ __forceinline__ uint32_t lower_bound_g(const Rec<NW> *a, uint32_t n, const Rec<NW> &x) {  // #elements < x
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (rec_less<NW>(a[mid], x)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <int NW>
+__device__ __forceinline__ uint32_t upper_bound_g(const Rec<NW> *a, uint32_t n, const Rec<NW> &x) {  // #elements <= x
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (!rec_less<NW>(x, a[mid])) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Oversized fine bins (skewed key prefixes, poly-A ...): chunked LDS sort+unique into runs, then
+// log2(#runs) rank-merge levels through the (free) ping-pong region, then one unique pass.
+// One workgroup per oversized bin; correctness path, not a throughput path.
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_sort_big(void *buf, void *scratch, const unsigned long long *off, uint32_t cap,
+                                                  unsigned long long *ucount, const uint32_t *biglist,
+                                                  const uint32_t *bigcount, uint32_t *runlen) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    __shared__ uint32_t scr[BLK / 64 + 2];
+    __shared__ uint64_t lastrec[4];
+    for (uint32_t bi = blockIdx.x; bi < *bigcount; bi += gridDim.x) {
+        const uint32_t b = biglist[bi];
+        const uint64_t o = off[b];
+        const uint64_t n = off[b + 1] - o;
+        Rec<NW> *A = (Rec<NW> *)buf + o;
+        Rec<NW> *B = (Rec<NW> *)scratch + o;
+        uint32_t *rl = runlen + (o / cap) + b;
+        const uint32_t nch = (uint32_t)((n + cap - 1) / cap);
+        // runs: chunk c -> sorted unique at A + c*cap, length rl[c]
+        for (uint32_t c = 0; c < nch; ++c) {
+            const uint64_t c0 = (uint64_t)c * cap;
+            const uint32_t cn = (uint32_t)((n - c0 < (uint64_t)cap) ? n - c0 : (uint64_t)cap);
+            for (uint32_t i = threadIdx.x; i < cn; i += BLK) lds_put<NW>(lds64, i, A[c0 + i]);
+            __syncthreads();
+            lds_bitonic_sort<NW>(lds64, cn);
+            uint32_t u = lds_unique_store<NW>(lds64, cn, A + c0, scr);
+            if (threadIdx.x == 0) rl[c] = u;
+            __syncthreads();
+        }
+        Rec<NW> *src = A, *dst = B;
+        for (uint32_t w = 1; w < nch; w <<= 1) {
+            for (uint32_t c = 0; c < nch; c += 2 * w) {
+                const Rec<NW> *X = src + (uint64_t)c * cap;
+                const uint32_t la = rl[c];
+                const bool hasY = c + w < nch;
+                const Rec<NW> *Y = src + (uint64_t)(c + w) * cap;
+                const uint32_t lb = hasY ? rl[c + w] : 0;
+                Rec<NW> *O = dst + (uint64_t)c * cap;
+                for (uint32_t i = threadIdx.x; i < la; i += BLK) {
+                    Rec<NW> x = X[i];
+                    O[i + lower_bound_g<NW>(Y, lb, x)] = x;
+                }
+                for (uint32_t j = threadIdx.x; j < lb; j += BLK) {
+                    Rec<NW> y = Y[j];
+                    O[j + upper_bound_g<NW>(X, la, y)] = y;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) rl[c] = la + lb;
+                __syncthreads();
+            }
+            Rec<NW> *t = src;
+            src = dst;
+            dst = t;
+        }
+        // unique pass src[0..len) -> A[0..u)  (in place when src == A: writes never pass the read front)
+        const uint32_t len = rl[0];
+        uint32_t outpos = 0;
+        for (uint32_t base = 0; base < len; base += BLK) {
+            const uint32_t i = base + threadIdx.x;
+            Rec<NW> x;
+            bool keep = false;
+            if (i < len) {
+                x = src[i];
+                if (i == 0) keep = true;
+                else if (threadIdx.x == 0) keep = !rec_eq<NW>(x, *(const Rec<NW> *)lastrec);
+                else keep = !rec_eq<NW>(x, src[i - 1]);
+            }
+            uint32_t tot;
+            uint32_t rank = block_excl_scan<uint32_t>(keep ? 1u : 0u, scr, &tot);  // barriers: all reads done before writes
+            if (i < len && (threadIdx.x == BLK - 1 || i == len - 1)) *(Rec<NW> *)lastrec = x;
+            if (keep) A[outpos + rank] = x;
+            outpos += tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) ucount[b] = outpos;
+        __syncthreads();
+    }
+}
+
+// fine bins -> final output (bins are contiguous in output order)
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_compact(const void *buf, const unsigned long long *off, const unsigned long long *ucount,
+                                                 const unsigned long long *uoff, uint32_t nbins, void *out) {
+    for (uint32_t b = blockIdx.x; b < nbins; b += gridDim.x) {
+        const Rec<NW> *src = (const Rec<NW> *)buf + off[b];
+        Rec<NW> *dst = (Rec<NW> *)out + uoff[b];
+        const uint32_t u = (uint32_t)ucount[b];
+        for (uint32_t i = threadIdx.x; i < u; i += BLK) dst[i] = src[i];
+    }
+}
+
+// bucket_off[b] = uoff[b * bins_per_bucket], bucket_off[B] = total
+__global__ void k_bucket_offsets(const unsigned long long *uoff, uint32_t num_buckets, uint32_t bins_per_bucket,
+                                 unsigned long long *bucket_off) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= num_buckets) bucket_off[b] = uoff[(uint64_t)b * bins_per_bucket];
+}
+
+}  // namespace smx

@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/smx.h declares; host-side
+logic that needs no GPU (error codes, parameter checks)."""
+import os
+
+import pytest
+
+from spades_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _lib.declared_symbols()
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing
+
+
+def test_error_codes_match_reference():
+    # common/utils/logger/error_codes.hpp:14-20
+    assert (_lib.INVALID_INPUT_FORMAT, _lib.INPUT_FILE_NOT_FOUND, _lib.IO_ERROR, _lib.INVALID_PARAMETER,
+            _lib.MEMORY_LIMIT_EXCEEDED) == (64, 65, 66, 67, 68)
+
+
+def test_rank_bucket_ownership_partitions_buckets():
+    lib = _lib.load()
+    for nb in (1, 16, 30, 160, 2560):
+        for world in (1, 2, 3, 4, 8):
+            firsts = [lib.smx_rank_first_bucket(nb, world, r) for r in range(world + 1)]
+            assert firsts[0] == 0 and firsts[-1] == nb
+            assert all(a <= b for a, b in zip(firsts, firsts[1:]))
+            for b in range(nb):  # owner(b) = floor(b*world/nb) is the rank whose range holds b
+                r = b * world // nb
+                assert firsts[r] <= b < firsts[r + 1]
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from spades_amd import SmxError
+    from spades_amd.kmercount import Context
+    with pytest.raises(SmxError):
+        Context()
+
+
+def test_product_never_imports_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dp, _, fs in os.walk(os.path.join(root, "spades_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.lower() or f == "__init__.py" and "oracle" not in txt, (dp, f)
