@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: M reads/s k-mer-counted (k=55, PE150) on N x MI355X.
+
+One step = one pass of the whole hot path (mark -> extract+XXH3 bucket -> MSD partition ->
+leaf sort/unique -> compact) over one synthetic batch that is already resident in HBM.
+N=1 : smx_count on the batch.  N>1 : every rank counts its own read shard, records are
+redistributed by bucket owner with ONE RCCL all-to-all, owners sort/unique.
+Rank 0 prints ONE JSON line (contract in the task statement). cpu_baseline (rank 0, N=1 only)
+times the reference's own classes (oracle/_ref/ref_kmercount) on a bounded sample of the SAME reads.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (device memory, streams, torch.distributed: plumbing only)
+
+L = 150
+INSERT = 350
+
+
+def synth_reads_device(seed, genome_len, n_reads, dev, err=0.01, genome_seed=2):
+    """SURVEY.md §8d generator on the GPU: iid genome, PE150 pairs (read2 = RC of the far end), 1 % substitutions.
+    Returns (words int64[n_words+8], start int64[n], len int32[n], codes uint8[n, L])."""
+    assert n_reads % 32 == 0
+    gg = torch.Generator(device=dev)
+    gg.manual_seed(genome_seed)
+    genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev, generator=gg)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n_pairs = n_reads // 2
+    codes = torch.empty((n_reads, L), dtype=torch.uint8, device=dev)
+    idx = torch.arange(L, device=dev)
+    chunk = 1 << 19
+    for c0 in range(0, n_pairs, chunk):
+        c1 = min(n_pairs, c0 + chunk)
+        p = torch.randint(0, genome_len - INSERT + 1, (c1 - c0,), device=dev, generator=g)
+        codes[2 * c0:2 * c1:2] = genome[p[:, None] + idx[None, :]]
+        codes[2 * c0 + 1:2 * c1:2] = 3 - genome[(p + INSERT - 1)[:, None] - idx[None, :]]
+    for c0 in range(0, n_reads, 1 << 20):
+        blk = codes[c0:c0 + (1 << 20)]
+        e = torch.rand(blk.shape, device=dev, generator=g) < err
+        sub = torch.randint(1, 4, blk.shape, dtype=torch.uint8, device=dev, generator=g)
+        blk[:] = torch.where(e, (blk + sub) % 4, blk)
+    flat = codes.reshape(-1, 32)
+    shifts = (2 * torch.arange(32, device=dev, dtype=torch.int64))[None, :]
+    words = torch.zeros(flat.shape[0] + 8, dtype=torch.int64, device=dev)
+    for c0 in range(0, flat.shape[0], 1 << 22):
+        words[c0:c0 + (1 << 22)] = (flat[c0:c0 + (1 << 22)].to(torch.int64) << shifts).sum(dim=1)
+    start = torch.arange(n_reads, device=dev, dtype=torch.int64) * L
+    ln = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
+    return words, start, ln, codes
+
+
+def cpu_baseline(codes_sample, K, mode, nb):
+    """Reference classes (kind 'reference') when oracle/_ref exists, else the C port (kind 'port')."""
+    import numpy as np
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    arr = lut[codes_sample.cpu().numpy()]
+    n = arr.shape[0]
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_kmercount")
+    if os.path.exists(ref):
+        cores = max(1, min(os.cpu_count() or 1, 64))
+        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+            rf = os.path.join(td, "reads.txt")
+            with open(rf, "wb") as f:
+                f.write(b"\n".join(r.tobytes() for r in arr) + b"\n")
+            t0 = time.time()
+            subprocess.check_call([ref, mode, str(K), str(nb), "0", rf, os.path.join(td, "wd"), os.path.join(td, "out"), str(cores)],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dt = time.time() - t0
+        return {"value": round(n / dt / 1e6, 4), "unit": "M reads/s", "cores": cores, "kind": "reference",
+                "sample": f"first {n} reads of the bench batch, oracle/_ref/ref_kmercount (reference KMerDiskCounter, tmpfs workdir), {dt:.1f} s"}
+    from oracle import oracle
+    reads = [r.tobytes().decode() for r in arr[:50000]]
+    t0 = time.time()
+    oracle.count(reads, K, mode, nb)
+    dt = time.time() - t0
+    return {"value": round(len(reads) / dt / 1e6, 4), "unit": "M reads/s", "cores": 1, "kind": "port",
+            "sample": f"first {len(reads)} reads of the bench batch, oracle/smx_oracle.c, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=float, default=10e6, help="reads per GPU (weak scaling)")
+    ap.add_argument("--k", type=int, default=55)
+    ap.add_argument("--mode", default="A", choices=["A", "B"])
+    ap.add_argument("--buckets", type=int, default=16)
+    ap.add_argument("--genome", type=float, default=50e6)
+    ap.add_argument("--cpu-sample", type=float, default=1e6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from spades_amd import KMerDiskCounter, ReadKMerSplitter
+    from spades_amd.kmercount import Context
+    from spades_amd import dist as smx_dist
+
+    n_reads = int(args.reads) // 32 * 32
+    K, nb = args.k, args.buckets
+    nw = (K + 31) // 32
+    words, start, ln, codes = synth_reads_device(1000 + rank, int(args.genome), n_reads, dev)
+    sample = codes[:int(min(args.cpu_sample, n_reads))].clone() if rank == 0 else None
+    del codes
+    torch.cuda.synchronize()
+
+    ctx = Context(device=local_rank)
+    sp = ReadKMerSplitter(K, args.mode, ctx)
+    sp.push_back_device(words.data_ptr(), words.numel() - 8, start.data_ptr(), ln.data_ptr(), n_reads)
+    counter = KMerDiskCounter(None, sp)
+    engine = smx_dist.GpuEngine(ctx, args.mode) if world > 1 else None
+
+    def step():
+        if world == 1:
+            return counter.Count(nb)
+        return smx_dist.sharded_count(engine, K, nb, rank, world, dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        st = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    total_reads = n_reads * world
+    value = total_reads / (dt / args.steps) / 1e6
+
+    # ---- roofline of the counting pipeline (this rank), SURVEY.md §8d: B_alg = N*L/4 + 2*I*W + D*W ----
+    tm = ctx.timings()
+    kernel_ms = sum(ms for _, ms in tm)
+    inst = st.kmer_instances() if world == 1 else st["instances"]
+    distinct = st.total_kmers() if world == 1 else st["distinct"]
+    W = 8 * nw
+    b_alg = n_reads * L / 4 + 2 * inst * W + distinct * W
+    achieved = b_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    dom = max(tm, key=lambda x: x[1]) if tm else ("", 0.0)
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "kernel": "smx_count pipeline (sum of stage kernels, HIP events on the library stream)",
+                "algorithmic_bytes_per_step": int(b_alg), "kernel_ms_per_step": round(kernel_ms, 3),
+                "dominant_stage": dom[0], "dominant_stage_ms": round(dom[1], 3),
+                "stages_ms": {n: round(ms, 3) for n, ms in tm}}
+
+    out = {
+        "metric": "M reads/sec k-mer-counted (k=55, PE150)" if K == 55 else f"M reads/sec k-mer-counted (k={K}, PE150)",
+        "value": round(value, 3), "unit": "M reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"synthetic {n_reads / 1e6:g} M PE150 reads per GPU (genome {args.genome / 1e6:g} Mbp iid, 1% subst.), "
+                               f"k={K}, mode {args.mode} ({'spades-kmercount: all k-mers of read+RC' if args.mode == 'A' else 'construction: canonical (k)-mers'}), "
+                               f"{nb} buckets, inputs resident in HBM",
+                   "reads_per_gpu": n_reads, "k": K, "mode": args.mode, "num_buckets": nb,
+                   "kmer_instances": int(inst), "distinct_kmers": int(distinct),
+                   "parallelism": "1 GPU" if world == 1 else f"{world} GPUs, bucket-range owners, one RCCL all-to-all"},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sample, K, args.mode, nb)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

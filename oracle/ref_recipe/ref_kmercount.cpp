@@ -41,7 +41,7 @@ class LineSplitter : public kmers::KMerSortingSplitter<RtSeq> {
     bool canonical_only_;
     size_t bufsize_;
 
-    bool Fill(const Sequence &seq) {
+    bool Fill(const Sequence &seq, unsigned tid) {
         if (seq.size() < this->K_)
             return false;
         bool stop = false;
@@ -50,7 +50,7 @@ class LineSplitter : public kmers::KMerSortingSplitter<RtSeq> {
             kmer <<= seq[j];
             if (canonical_only_ && !kmers::StoringTypeFilter<kmers::InvertableStoring>::filter(kmer))
                 continue;
-            stop |= this->push_back_internal(kmer, 0);
+            stop |= this->push_back_internal(kmer, tid);
         }
         return stop;
     }
@@ -61,21 +61,36 @@ class LineSplitter : public kmers::KMerSortingSplitter<RtSeq> {
             : kmers::KMerSortingSplitter<RtSeq>(workdir, K), file_(std::move(file)),
               canonical_only_(canonical_only), bufsize_(bufsize) {}
 
-    RawKMers Split(size_t num_files, unsigned /*nthreads*/) override {
-        auto out = PrepareBuffers(num_files, 1, bufsize_);
+    // Like ParallelSortingSplitter::Split (kmercount.cpp:96-121): fill per-thread buffers from a
+    // batch of reads with `nthreads` workers, dump (sort+unique+append run) whenever a cell overflows.
+    RawKMers Split(size_t num_files, unsigned nthreads) override {
+        auto out = PrepareBuffers(num_files, nthreads, bufsize_);
         std::ifstream is(file_);
         std::string line;
+        std::vector<std::string> batch;
+        const size_t batch_reads = 4096 * (size_t)nthreads;
+        bool eof = false;
         size_t n = 0;
-        while (std::getline(is, line)) {
-            if (!line.empty() && line.back() == '\r') line.pop_back();
-            n += 1;
-            if (line.empty()) continue;
-            // SingleRead validates lazily; LongestValid cuts to the longest ACGT run (first on ties)
-            io::SingleRead r(std::to_string(n), line);
-            io::LongestValid(r);
-            if (r.size() == 0) continue;  // kmercount.cpp:65-83 never consults IsValid()
-            bool stop = Fill(r.sequence());
-            stop |= Fill(r.sequence(/* rc */ true));
+        while (!eof) {
+            batch.clear();
+            while (batch.size() < batch_reads) {
+                if (!std::getline(is, line)) { eof = true; break; }
+                if (!line.empty() && line.back() == '\r') line.pop_back();
+                batch.push_back(line);
+            }
+            bool stop = false;
+#           pragma omp parallel for num_threads(nthreads) reduction(|| : stop) schedule(dynamic, 256)
+            for (size_t i = 0; i < batch.size(); ++i) {
+                if (batch[i].empty()) continue;
+                // SingleRead validates lazily; LongestValid cuts to the longest ACGT run (first on ties)
+                io::SingleRead r(std::to_string(n + i), batch[i]);
+                io::LongestValid(r);
+                if (r.size() == 0) continue;  // kmercount.cpp:65-83 never consults IsValid()
+                unsigned tid = (unsigned) omp_get_thread_num();
+                stop = Fill(r.sequence(), tid) || stop;
+                stop = Fill(r.sequence(/* rc */ true), tid) || stop;
+            }
+            n += batch.size();
             if (stop) DumpBuffers(out);
         }
         DumpBuffers(out);

@@ -42,11 +42,11 @@ struct smx_ctx {
     unsigned nw = 0, K = 0, num_buckets = 0;
     std::vector<uint64_t> bucket_off;
     // tuning / test hooks
-    int64_t opt_leaf_cap = 0, opt_s1 = -1, opt_s2 = -1;
+    int64_t opt_leaf_cap = 0, opt_s1 = -1, opt_s2 = -1, opt_dbg = 0;
     // timings
     std::vector<Timing> timings;
-    std::vector<std::string> tnames;
-    std::vector<float> tms;
+    std::vector<std::string> tnames, xnames;  // last count stages / last extract_partition stages
+    std::vector<float> tms, xms;
     std::vector<void *> temps;  // allocations of the pipeline in flight
 };
 
@@ -146,8 +146,12 @@ int scan_u64(smx_ctx *ctx, const unsigned long long *in, unsigned long long *out
 
 template <int NW>
 struct Tune {
-    static constexpr int RPT = (NW == 1) ? 16 : 8;                       // records per thread in a scatter tile
-    static constexpr uint32_t CAP = (NW == 1) ? 8192 : (NW == 2 ? 4096 : 2048);  // LDS-sortable leaf
+    static constexpr int RPT = (NW <= 2) ? 16 : 8;                        // records per thread in a scatter tile
+    static constexpr uint32_t CAP = (NW == 1) ? 4096 : (NW == 2 ? 2048 : 1024);  // LDS-sortable leaf
+    static constexpr int LPT = CAP / BLK;
+    // fan-out per MSD level: runs of >= 16 records (>= 128 B) per bin and tile keep the scattered
+    // writes at streaming speed and the reservation atomics at <= 1/16 per record (tools/ubench.hip)
+    static constexpr uint32_t FMAX = RPT * BLK / 16;
 };
 
 template <int NW, int RPT>
@@ -161,7 +165,7 @@ int pass_reads(smx_ctx *ctx, int mode, bool scatter, PassArgs a, const std::vect
     constexpr int RPT = Tune<NW>::RPT;
     for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
         const ReadChunk &ch = ctx->chunks[ci];
-        if (ch.n_bases == 0) continue;
+        if (ch.n_bases == 0 || !masks[ci]) continue;
         a.seq = ch.d_words;
         a.mask = masks[ci];
         a.G = ch.n_bases;
@@ -194,15 +198,18 @@ int pass_reads(smx_ctx *ctx, int mode, bool scatter, PassArgs a, const std::vect
 }
 
 // ---- passes over records already in HBM, segmented by a.seg_off ----
+// d_tcnt / d_tstart: scratch arrays of nseg+1 u64
 template <int NW, int BINF>
-int pass_recs(smx_ctx *ctx, bool scatter, PassArgs a, uint64_t nrec, uint32_t *d_tile_start) {
+int pass_recs(smx_ctx *ctx, bool scatter, PassArgs a, uint64_t nrec, unsigned long long *d_tcnt, unsigned long long *d_tstart) {
     constexpr int RPT = Tune<NW>::RPT;
     const uint32_t tile = scatter ? RPT * BLK : 16 * RPT * BLK;
-    hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(BLK), 0, ctx->stream, a.seg_off, a.nseg, tile, d_tile_start);
+    hipLaunchKernelGGL(k_tile_counts, dim3((a.nseg + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, a.seg_off, a.nseg, tile, d_tcnt);
     HIPCHK(hipGetLastError());
-    a.tile_start = d_tile_start;
+    if (int rc = scan_u64(ctx, d_tcnt, d_tstart, a.nseg)) return rc;
+    a.tile_start = d_tstart;
     a.tile_recs = tile;
     const uint64_t grid = nrec / tile + a.nseg + 1;
+    if (grid > 0x7FFFFFFFull) return fail(ctx, SMX_INVALID_PARAMETER, "batch too large for one launch");
     if (!scatter) {
         size_t lds = (size_t)a.F * 4;
         if (int rc = set_lds(ctx, k_hist<NW, SRC_RECS, BINF, RPT>, lds)) return rc;
@@ -250,7 +257,6 @@ void clear_result(smx_ctx *ctx) {
 // The whole count: from reads (d_recs == nullptr) or from records already in HBM.
 template <int NW>
 int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in) {
-    constexpr int RPT = Tune<NW>::RPT;
     uint32_t cap = Tune<NW>::CAP;
     if (ctx->opt_leaf_cap > 0) cap = (uint32_t)std::min<int64_t>(ctx->opt_leaf_cap, cap);
     const bool from_reads = d_recs == nullptr;
@@ -272,53 +278,69 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     }
     ctx->n_instances = nrec;
     if (nrec == 0) return 0;
+    if (B > 4096) return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets=%u too large (level-1 fan-out limit 4096)", B);
 
-    // ---- choose the MSD split -------------------------------------------------------------
-    const unsigned avail = std::min(32u, 2 * K);
+    // ---- choose the MSD split: level 1 = bucket + s1 key bits, then levels of <= log2(FMAX) bits ----
+    const unsigned avail = std::min(64u, 2 * K);  // key bits visible in key_top64
     const uint64_t leaf = std::max<uint32_t>(cap / 4, 1);
     const uint64_t fneed = (nrec + leaf - 1) / leaf;
     unsigned bits = fneed > B ? ceil_log2((fneed + B - 1) / B) : 0;
-    bits = std::min(bits, avail);
-    const unsigned lb = ceil_log2(B);
-    unsigned s1 = std::min(bits, lb >= 10 ? 0u : 10u - lb);
-    while (s1 > 0 && ((uint64_t)B << s1) > 4096) --s1;
-    unsigned s2 = std::min(bits - s1, 11u);
-    if (ctx->opt_s1 >= 0) s1 = (unsigned)std::min<int64_t>(ctx->opt_s1, avail);
-    if (ctx->opt_s2 >= 0) s2 = (unsigned)std::min<int64_t>(ctx->opt_s2, avail - std::min(avail, s1));
-    if (((uint64_t)B << s1) > 4096)
-        return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets=%u too large (level-1 fan-out limit 4096)", B);
-    const uint32_t F1 = B << s1, F2 = 1u << s2;
-    const uint64_t nb = (uint64_t)F1 * F2;  // fine bins
+    bits = std::min(bits, std::min(avail, 40u));
+    unsigned fbits = 0;
+    while ((2u << fbits) <= Tune<NW>::FMAX) ++fbits;  // floor(log2(FMAX))
+    unsigned s1 = 0;
+    while (s1 < bits && ((uint64_t)B << (s1 + 1)) <= Tune<NW>::FMAX) ++s1;
+    std::vector<unsigned> lv;  // bits of levels 2..
+    if (ctx->opt_s1 >= 0 || ctx->opt_s2 >= 0) {  // test hook: explicit split
+        s1 = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_s1, 0), std::min(avail, 12u));
+        while (s1 > 0 && ((uint64_t)B << s1) > 4096) --s1;
+        unsigned s2 = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_s2, 0), std::min(avail - s1, 11u));
+        if (s2) lv.push_back(s2);
+    } else {
+        unsigned rem = bits - s1;
+        unsigned nl = (rem + fbits - 1) / fbits;
+        for (unsigned i = 0; i < nl; ++i) {
+            unsigned t = rem / (nl - i);
+            if (rem % (nl - i)) ++t;
+            lv.push_back(t);
+            rem -= t;
+        }
+    }
+    const uint32_t F1 = B << s1;
+    uint64_t nb = F1;  // fine bins after all levels
+    uint64_t nb_parent_max = F1;
+    for (unsigned t : lv) {
+        nb_parent_max = nb;
+        nb <<= t;
+    }
+    if (nb > (1ull << 31)) return fail(ctx, SMX_INVALID_PARAMETER, "batch too large: %llu fine bins", (unsigned long long)nb);
+    unsigned consumed = s1;
+    for (unsigned t : lv) consumed += t;
 
     // ---- allocations ------------------------------------------------------------------------
     Rec<NW> *bufA, *bufB;
     if (int rc = dalloc(ctx, &bufA, nrec)) return rc;
     if (int rc = dalloc(ctx, &bufB, nrec)) return rc;
-    unsigned long long *hist1, *off1, *cur1, *hist2 = nullptr, *off2 = nullptr, *cur2 = nullptr, *ucount, *uoff, *bucket_off;
-    uint32_t *tile_start, *biglist, *bigcount, *runlen;
-    if (int rc = dalloc(ctx, &hist1, F1)) return rc;
-    if (int rc = dalloc(ctx, &off1, F1 + 1)) return rc;
-    if (int rc = dalloc(ctx, &cur1, F1)) return rc;
-    if (int rc = dalloc(ctx, &tile_start, F1 + 2)) return rc;
-    if (s2) {
-        if (int rc = dalloc(ctx, &hist2, nb)) return rc;
-        if (int rc = dalloc(ctx, &off2, nb + 1)) return rc;
-        if (int rc = dalloc(ctx, &cur2, nb)) return rc;
-    }
+    unsigned long long *histA, *offA, *offB, *cur, *tcnt, *tstart, *ucount, *uoff, *bucket_off;
+    uint32_t *biglist, *bigcount, *runlen;
+    if (int rc = dalloc(ctx, &histA, nb)) return rc;
+    if (int rc = dalloc(ctx, &offA, nb + 1)) return rc;
+    if (int rc = dalloc(ctx, &offB, nb_parent_max + 1)) return rc;
+    if (int rc = dalloc(ctx, &cur, nb)) return rc;
+    if (int rc = dalloc(ctx, &tcnt, nb_parent_max + 1)) return rc;
+    if (int rc = dalloc(ctx, &tstart, nb_parent_max + 2)) return rc;
     if (int rc = dalloc(ctx, &ucount, nb)) return rc;
     if (int rc = dalloc(ctx, &uoff, nb + 1)) return rc;
     if (int rc = dalloc(ctx, &biglist, nb)) return rc;
     if (int rc = dalloc(ctx, &bigcount, 1)) return rc;
     if (int rc = dalloc(ctx, &runlen, nrec / cap + nb + 2)) return rc;
     if (int rc = dalloc(ctx, &bucket_off, B + 1)) return rc;
-    HIPCHK(hipMemsetAsync(hist1, 0, (size_t)F1 * 8, ctx->stream));
     HIPCHK(hipMemsetAsync(bigcount, 0, 4, ctx->stream));
 
     PassArgs a{};
     a.K = K;
     a.num_buckets = B;
     a.s1 = s1;
-    a.s2 = s2;
     a.world = 1;
 
     // ---- level 1 ----------------------------------------------------------------------------
@@ -330,7 +352,8 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     a.F = F1;
-    a.hist = hist1;
+    a.hist = histA;
+    HIPCHK(hipMemsetAsync(histA, 0, (size_t)F1 * 8, ctx->stream));
     tbegin(ctx, "l1_hist");
     if (from_reads) {
         if (int rc = pass_reads<NW, BIN_L1>(ctx, mode, false, a, masks)) return rc;
@@ -338,63 +361,76 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         a.recs = d_recs;
         a.seg_off = seg1;
         a.nseg = 1;
-        if (int rc = pass_recs<NW, BIN_L1>(ctx, false, a, nrec, tile_start)) return rc;
+        if (int rc = pass_recs<NW, BIN_L1>(ctx, false, a, nrec, tcnt, tstart)) return rc;
     }
     tend(ctx);
     tbegin(ctx, "l1_scan");
-    if (int rc = scan_u64(ctx, hist1, off1, F1)) return rc;
-    HIPCHK(hipMemcpyAsync(cur1, off1, (size_t)F1 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    unsigned long long *off_cur = offA, *off_other = offB;
+    if (lv.size() % 2 == 1) std::swap(off_cur, off_other);  // so that the final offsets land in offA (nb+1 entries)
+    if (int rc = scan_u64(ctx, histA, off_cur, F1)) return rc;
+    HIPCHK(hipMemcpyAsync(cur, off_cur, (size_t)F1 * 8, hipMemcpyDeviceToDevice, ctx->stream));
     tend(ctx);
-    a.cursor = cur1;
+    a.cursor = cur;
     a.out = bufA;
     tbegin(ctx, "l1_scatter");
     if (from_reads) {
         if (int rc = pass_reads<NW, BIN_L1>(ctx, mode, true, a, masks)) return rc;
     } else {
-        if (int rc = pass_recs<NW, BIN_L1>(ctx, true, a, nrec, tile_start)) return rc;
+        if (int rc = pass_recs<NW, BIN_L1>(ctx, true, a, nrec, tcnt, tstart)) return rc;
     }
     tend(ctx);
 
-    // ---- level 2 ----------------------------------------------------------------------------
+    // ---- levels 2.. -------------------------------------------------------------------------
     Rec<NW> *sortbuf = bufA, *other = bufB;
-    const unsigned long long *fine_off = off1;
-    if (s2) {
-        HIPCHK(hipMemsetAsync(hist2, 0, (size_t)nb * 8, ctx->stream));
-        a.recs = bufA;
-        a.seg_off = off1;
-        a.nseg = F1;
-        a.F = F2;
-        a.hist = hist2;
-        tbegin(ctx, "l2_hist");
-        if (int rc = pass_recs<NW, BIN_L2>(ctx, false, a, nrec, tile_start)) return rc;
+    uint64_t nseg = F1;
+    unsigned used = s1;
+    static const char *lname[3][3] = {{"l2_hist", "l2_scan", "l2_scatter"}, {"l3_hist", "l3_scan", "l3_scatter"}, {"lN_hist", "lN_scan", "lN_scatter"}};
+    for (size_t li = 0; li < lv.size(); ++li) {
+        const unsigned t = lv[li];
+        const uint64_t nchild = nseg << t;
+        const char **nm = lname[std::min<size_t>(li, 2)];
+        HIPCHK(hipMemsetAsync(histA, 0, (size_t)nchild * 8, ctx->stream));
+        a.recs = sortbuf;
+        a.seg_off = off_cur;
+        a.nseg = (uint32_t)nseg;
+        a.F = 1u << t;
+        a.shift = 64 - used - t;
+        a.hist = histA;
+        tbegin(ctx, nm[0]);
+        if (int rc = pass_recs<NW, BIN_LK>(ctx, false, a, nrec, tcnt, tstart)) return rc;
         tend(ctx);
-        tbegin(ctx, "l2_scan");
-        if (int rc = scan_u64(ctx, hist2, off2, nb)) return rc;
-        HIPCHK(hipMemcpyAsync(cur2, off2, (size_t)nb * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        tbegin(ctx, nm[1]);
+        if (int rc = scan_u64(ctx, histA, off_other, nchild)) return rc;
+        HIPCHK(hipMemcpyAsync(cur, off_other, (size_t)nchild * 8, hipMemcpyDeviceToDevice, ctx->stream));
         tend(ctx);
-        a.cursor = cur2;
-        a.out = bufB;
-        tbegin(ctx, "l2_scatter");
-        if (int rc = pass_recs<NW, BIN_L2>(ctx, true, a, nrec, tile_start)) return rc;
+        a.cursor = cur;
+        a.out = other;
+        tbegin(ctx, nm[2]);
+        if (int rc = pass_recs<NW, BIN_LK>(ctx, true, a, nrec, tcnt, tstart)) return rc;
         tend(ctx);
-        sortbuf = bufB;
-        other = bufA;
-        fine_off = off2;
+        std::swap(sortbuf, other);
+        std::swap(off_cur, off_other);
+        nseg = nchild;
+        used += t;
     }
+    const unsigned long long *fine_off = off_cur;
 
     // ---- leaf sort + unique -----------------------------------------------------------------
     {
-        size_t lds = (size_t)cap * NW * 8;
-        if (int rc = set_lds(ctx, k_sort_small<NW>, lds)) return rc;
-        if (int rc = set_lds(ctx, k_sort_big<NW>, lds)) return rc;
+        unsigned sub_bits = std::min(10u, avail - std::min(avail, consumed));
+        while (sub_bits > 0 && (1u << sub_bits) > cap) --sub_bits;
+        const unsigned sub_shift = 64 - consumed - sub_bits;
+        size_t lds = (size_t)cap * NW * 8 + (2 * (size_t)(1u << sub_bits) + 2) * 4 + cap + 16;
+        if (int rc = set_lds(ctx, k_sort_small<NW, Tune<NW>::LPT>, lds)) return rc;
+        if (int rc = set_lds(ctx, k_sort_big<NW>, (size_t)cap * NW * 8)) return rc;
         tbegin(ctx, "sort_unique");
-        hipLaunchKernelGGL((k_sort_small<NW>), dim3((unsigned)nb), dim3(BLK), lds, ctx->stream, (void *)sortbuf, fine_off,
-                           (uint32_t)nb, cap, ucount, biglist, bigcount);
+        hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3((unsigned)std::min<uint64_t>(nb, 256 * 8)), dim3(BLK), lds, ctx->stream, (void *)sortbuf,
+                           fine_off, (uint32_t)nb, cap, K, sub_bits ? sub_shift : 0u, sub_bits, ucount, biglist, bigcount, (int)ctx->opt_dbg);
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "sort_big");
-        hipLaunchKernelGGL((k_sort_big<NW>), dim3(1024), dim3(BLK), lds, ctx->stream, (void *)sortbuf, (void *)other, fine_off, cap,
-                           ucount, (const uint32_t *)biglist, (const uint32_t *)bigcount, runlen);
+        hipLaunchKernelGGL((k_sort_big<NW>), dim3(1024), dim3(BLK), (size_t)cap * NW * 8, ctx->stream, (void *)sortbuf, (void *)other,
+                           fine_off, cap, ucount, (const uint32_t *)biglist, (const uint32_t *)bigcount, runlen);
         HIPCHK(hipGetLastError());
         tend(ctx);
     }
@@ -470,16 +506,20 @@ int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsign
     a.world = world;
     a.F = world;
     a.hist = hist;
+    tbegin(ctx, "x_hist");
     if (nrec) {
         if (int rc = pass_reads<NW, BIN_OWNER>(ctx, mode, false, a, masks)) return rc;
     }
+    tend(ctx);
     if (int rc = scan_u64(ctx, hist, off, world)) return rc;
     HIPCHK(hipMemcpyAsync(cur, off, (size_t)world * 8, hipMemcpyDeviceToDevice, ctx->stream));
     a.cursor = cur;
     a.out = d_records;
+    tbegin(ctx, "x_scatter");
     if (nrec) {
         if (int rc = pass_reads<NW, BIN_OWNER>(ctx, mode, true, a, masks)) return rc;
     }
+    tend(ctx);
     std::vector<unsigned long long> h(world);
     HIPCHK(hipMemcpyAsync(h.data(), hist, (size_t)world * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -527,6 +567,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     if (!strcmp(key, "leaf_cap")) ctx->opt_leaf_cap = value;
     else if (!strcmp(key, "s1")) ctx->opt_s1 = value;
     else if (!strcmp(key, "s2")) ctx->opt_s2 = value;
+    else if (!strcmp(key, "dbg")) ctx->opt_dbg = value;
     else return fail(ctx, SMX_INVALID_PARAMETER, "unknown option %s", key);
     return SMX_OK;
 }
@@ -657,6 +698,8 @@ int smx_reads_info(const smx_ctx *ctx, uint64_t *n_reads, uint64_t *n_bases) {
 
 int smx_count(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets) {
     if (!ctx) return SMX_INVALID_PARAMETER;
+    ctx->xnames.clear();
+    ctx->xms.clear();
     return dispatch_count(ctx, K, mode, num_buckets, nullptr, 0);
 }
 
@@ -761,17 +804,36 @@ int smx_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned num_bucke
         default: rc = run_extract_partition<4>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts); break;
     }
     (void)hipStreamSynchronize(ctx->stream);
+    if (rc == 0) {
+        tcollect(ctx);
+        ctx->xnames = ctx->tnames;
+        ctx->xms = ctx->tms;
+        ctx->tnames.clear();
+        ctx->tms.clear();
+    } else {
+        for (auto &t : ctx->timings) {
+            (void)hipEventDestroy(t.e0);
+            (void)hipEventDestroy(t.e1);
+        }
+        ctx->timings.clear();
+    }
     free_temps(ctx);
     return rc;
 }
 
 int smx_last_timings(const smx_ctx *ctx, const char **names, float *ms, int cap) {
     if (!ctx) return 0;
-    int n = (int)ctx->tnames.size();
-    for (int i = 0; i < n && i < cap; ++i) {
-        if (names) names[i] = ctx->tnames[i].c_str();
-        if (ms) ms[i] = ctx->tms[i];
-    }
+    int n = 0;
+    for (size_t i = 0; i < ctx->xnames.size(); ++i, ++n)
+        if (n < cap) {
+            if (names) names[n] = ctx->xnames[i].c_str();
+            if (ms) ms[n] = ctx->xms[i];
+        }
+    for (size_t i = 0; i < ctx->tnames.size(); ++i, ++n)
+        if (n < cap) {
+            if (names) names[n] = ctx->tnames[i].c_str();
+            if (ms) ms[n] = ctx->tms[i];
+        }
     return n;
 }
 

@@ -140,12 +140,12 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t hash, uint32_t num_bucket
     return num_buckets == 1 ? 0u : (uint32_t)__umul64hi(hash, (uint64_t)num_buckets);
 }
 
-// Top 32 bits of the sort key (word 0 is the most significant word of the order; inside it the
-// HIGH bits, i.e. the LAST nucleotides it holds, are most significant — pdqsort_pod.h:725-734).
+// Top 64 bits of the sort key, left-aligned (word 0 is the most significant word of the order; inside
+// it the HIGH bits, i.e. the LAST nucleotides it holds, are most significant — pdqsort_pod.h:725-734).
+// For K < 32 the 2K key bits are shifted to the top; MSD digits are cut from this value.
 template <int NW>
-__device__ __forceinline__ uint32_t key_top32(const Rec<NW> &x, unsigned K) {
-    const unsigned nb0 = K >= 32 ? 64u : 2u * K;
-    return nb0 >= 32 ? (uint32_t)(x.w[0] >> (nb0 - 32)) : (uint32_t)(x.w[0] << (32 - nb0));
+__device__ __forceinline__ uint64_t key_top64(const Rec<NW> &x, unsigned K) {
+    return K >= 32 ? x.w[0] : (x.w[0] << (64 - 2 * K));
 }
 
 // ---- block-wide helpers (256 threads = 4 waves of 64) ------------------------------------------

@@ -21,7 +21,7 @@ namespace smx {
 constexpr int BLK = 256;
 
 enum { SRC_READS_ALL = 0, SRC_READS_CANON = 1, SRC_RECS = 2 };
-enum { BIN_L1 = 0, BIN_L2 = 1, BIN_OWNER = 2 };
+enum { BIN_L1 = 0, BIN_LK = 1, BIN_OWNER = 2 };
 
 struct PassArgs {
     // reads source
@@ -31,13 +31,14 @@ struct PassArgs {
     // records source
     const void *recs;
     const unsigned long long *seg_off;  // [nseg+1] record offsets of the input segments
-    const uint32_t *tile_start;         // [nseg+1] prefix of tiles per segment
+    const unsigned long long *tile_start;  // [nseg+1] prefix of tiles per segment
     uint32_t nseg;
     uint32_t tile_recs;  // records per tile for this launch
     // binning
     unsigned K;
     uint32_t num_buckets;
-    unsigned s1, s2;
+    unsigned s1;     // BIN_L1: key bits appended to the bucket id
+    unsigned shift;  // BIN_LK: digit = (top64 >> shift) & (F-1)
     uint32_t world;
     uint32_t F;  // bins per segment
     unsigned long long *hist;    // [nseg*F]
@@ -49,9 +50,9 @@ template <int NW, int BINF>
 __device__ __forceinline__ uint32_t bin_of(const Rec<NW> &x, const PassArgs &a) {
     if constexpr (BINF == BIN_L1) {
         uint32_t b = bucket_of(xxh3_rec<NW>(x), a.num_buckets);
-        return a.s1 ? ((b << a.s1) | (key_top32<NW>(x, a.K) >> (32 - a.s1))) : b;
-    } else if constexpr (BINF == BIN_L2) {
-        return (key_top32<NW>(x, a.K) >> (32 - a.s1 - a.s2)) & ((1u << a.s2) - 1);
+        return a.s1 ? ((b << a.s1) | (uint32_t)(key_top64<NW>(x, a.K) >> (64 - a.s1))) : b;
+    } else if constexpr (BINF == BIN_LK) {
+        return (uint32_t)(key_top64<NW>(x, a.K) >> a.shift) & (a.F - 1);
     } else {
         uint32_t b = bucket_of(xxh3_rec<NW>(x), a.num_buckets);
         return (uint32_t)(((uint64_t)b * a.world) / a.num_buckets);
@@ -129,7 +130,7 @@ __device__ __forceinline__ void fetch_records(const PassArgs &a, uint64_t tile, 
 }
 
 // tile -> (segment, tile index inside segment) for the records source
-__device__ __forceinline__ bool locate_tile(const PassArgs &a, uint32_t blk, uint32_t *sh, uint32_t &seg, uint32_t &tin) {
+__device__ __forceinline__ bool locate_tile(const PassArgs &a, uint64_t blk, uint32_t *sh, uint32_t &seg, uint32_t &tin) {
     if (threadIdx.x == 0) {
         uint32_t lo = 0, hi = a.nseg;  // find seg with tile_start[seg] <= blk < tile_start[seg+1]
         if (blk >= a.tile_start[a.nseg]) {
@@ -140,7 +141,7 @@ __device__ __forceinline__ bool locate_tile(const PassArgs &a, uint32_t blk, uin
                 if (a.tile_start[mid] <= blk) lo = mid; else hi = mid;
             }
             sh[0] = lo;
-            sh[1] = blk - a.tile_start[lo];
+            sh[1] = (uint32_t)(blk - a.tile_start[lo]);
         }
     }
     __syncthreads();
@@ -318,20 +319,10 @@ __global__ void k_scan_apply(const unsigned long long *in, uint64_t n, const uns
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == BLK - 1) out[n] = run;
 }
 
-// tiles per segment prefix: tile_start[s] = sum_{s'<s} ceil(len(s')/tile)
-__global__ void k_tile_prefix(const unsigned long long *seg_off, uint32_t nseg, uint32_t tile, uint32_t *tile_start) {
-    __shared__ uint32_t scr[BLK / 64 + 2];
-    const uint32_t per = (nseg + BLK - 1) / BLK;
-    const uint32_t d0 = min(nseg, threadIdx.x * per), d1 = min(nseg, d0 + per);
-    uint32_t sum = 0;
-    for (uint32_t d = d0; d < d1; ++d) sum += (uint32_t)((seg_off[d + 1] - seg_off[d] + tile - 1) / tile);
-    uint32_t tot;
-    uint32_t run = block_excl_scan<uint32_t>(sum, scr, &tot);
-    for (uint32_t d = d0; d < d1; ++d) {
-        tile_start[d] = run;
-        run += (uint32_t)((seg_off[d + 1] - seg_off[d] + tile - 1) / tile);
-    }
-    if (threadIdx.x == 0) tile_start[nseg] = tot;
+// tiles per segment (scanned afterwards into PassArgs::tile_start)
+__global__ void k_tile_counts(const unsigned long long *seg_off, uint32_t nseg, uint32_t tile, unsigned long long *cnt) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nseg) cnt[s] = (seg_off[s + 1] - seg_off[s] + tile - 1) / tile;
 }
 
 // ------------------------------------------------------------------------------------------ sort
@@ -402,31 +393,171 @@ __device__ uint32_t lds_unique_store(const uint64_t *s, uint32_t n, Rec<NW> *dst
     return tot;
 }
 
-// One workgroup per fine bin. Bins larger than cap are queued for k_sort_big.
+// Per-thread "insertion sort with dedup" of one small LDS range [b, e): keeps a sorted, duplicate-free
+// prefix [b, b+d) and returns d. Equal keys (coverage duplicates) cost one compare and no move;
+// the prefix never overtakes the read cursor (b+d <= i).
 template <int NW>
+__device__ __forceinline__ uint32_t lds_insertion_unique(uint64_t *s, uint32_t b, uint32_t e) {
+    uint32_t d = 0;
+    for (uint32_t i = b; i < e; ++i) {
+        Rec<NW> x = lds_get<NW>(s, i);
+        uint32_t j = b + d;
+        bool dup = false;
+        while (j > b) {
+            Rec<NW> y = lds_get<NW>(s, j - 1);
+            if (rec_less<NW>(x, y)) {
+                --j;
+            } else {
+                dup = rec_eq<NW>(x, y);
+                break;
+            }
+        }
+        if (dup) continue;
+        for (uint32_t t = b + d; t > j; --t) lds_put<NW>(s, t, lds_get<NW>(s, t - 1));
+        lds_put<NW>(s, j, x);
+        ++d;
+    }
+    return d;
+}
+
+// Leaf sort: persistent workgroups loop over fine bins (n <= cap records, all sharing their bucket
+// and the key bits consumed by the MSD levels). The leaf is split once more inside LDS on the next
+// sub_bits key bits (counting sort: LDS histogram -> scan -> placement), which leaves sub-bins of a
+// few records that single threads finish by insertion-sort-with-dedup. Skewed leaves (a sub-bin
+// above 128 records) fall back to the bitonic network + adjacent-unique. Uniques are stored in
+// place at the start of the bin's region. Bins larger than cap are queued for k_sort_big.
+template <int NW, int LPT>
 __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned long long *off, uint32_t nbins, uint32_t cap,
-                                                    unsigned long long *ucount, uint32_t *biglist, uint32_t *bigcount) {
+                                                    unsigned K, unsigned sub_shift, unsigned sub_bits,
+                                                    unsigned long long *ucount, uint32_t *biglist, uint32_t *bigcount, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     __shared__ uint32_t scr[BLK / 64 + 2];
-    const uint32_t b = blockIdx.x;
-    if (b >= nbins) return;
-    const uint64_t o = off[b];
-    const uint64_t n64 = off[b + 1] - o;
-    if (n64 == 0) {
-        if (threadIdx.x == 0) ucount[b] = 0;
-        return;
+    __shared__ uint32_t maxc;
+    const uint32_t S = 1u << sub_bits;
+    uint32_t *cnt = (uint32_t *)(lds64 + (size_t)cap * NW);  // [S+1] sub-bin offsets
+    uint32_t *dcn = cnt + S + 1;                             // [S] distinct per sub-bin -> output offsets
+    uint8_t *flg = (uint8_t *)(dcn + S);                     // [cap] first-occurrence flags
+    for (uint32_t b = blockIdx.x; b < nbins; b += gridDim.x) {
+        const uint64_t o = off[b];
+        const uint64_t n64 = off[b + 1] - o;
+        if (n64 == 0) {
+            if (threadIdx.x == 0) ucount[b] = 0;
+            continue;
+        }
+        if (n64 > cap) {
+            if (threadIdx.x == 0) biglist[atomicAdd(bigcount, 1u)] = b;
+            continue;
+        }
+        const uint32_t n = (uint32_t)n64;
+        Rec<NW> *g = (Rec<NW> *)buf + o;
+        bool bitonic = (sub_bits == 0 || n <= 64);
+        if (bitonic) {
+            for (uint32_t i = threadIdx.x; i < n; i += BLK) lds_put<NW>(lds64, i, g[i]);
+            __syncthreads();
+        } else {
+            for (uint32_t i = threadIdx.x; i <= S; i += BLK) cnt[i] = 0;
+            if (threadIdx.x == 0) maxc = 0;
+            __syncthreads();
+            Rec<NW> r[LPT];
+            uint32_t ds[LPT];  // digit << 16 | slot
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                uint32_t i = threadIdx.x + j * BLK;
+                if (i < n) {
+                    r[j] = g[i];
+                    uint32_t d = (uint32_t)(key_top64<NW>(r[j], K) >> sub_shift) & (S - 1);
+                    ds[j] = (d << 16) | atomicAdd(&cnt[d], 1u);
+                }
+            }
+            __syncthreads();
+            if (dbg == 1) continue;
+            const uint32_t per = (S + BLK - 1) / BLK;
+            const uint32_t d0 = threadIdx.x * per, d1 = min(S, d0 + per);
+            uint32_t sum = 0, mx = 0;
+            for (uint32_t d = d0; d < d1; ++d) {
+                uint32_t c = cnt[d];
+                sum += c;
+                mx = max(mx, c);
+            }
+            if (mx > 128) atomicMax(&maxc, mx);
+            uint32_t tot;
+            uint32_t run = block_excl_scan<uint32_t>(sum, scr, &tot);
+            for (uint32_t d = d0; d < d1; ++d) {
+                uint32_t c = cnt[d];
+                cnt[d] = run;
+                run += c;
+            }
+            if (threadIdx.x == 0) cnt[S] = n;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                uint32_t i = threadIdx.x + j * BLK;
+                if (i < n) lds_put<NW>(lds64, cnt[ds[j] >> 16] + (ds[j] & 0xFFFFu), r[j]);
+            }
+            __syncthreads();
+            bitonic = maxc > 128;
+            if (dbg == 2) continue;
+            if (!bitonic) {
+                // pass 1: first-occurrence flag of every placed record (one thread per record; the
+                // threads of a sub-bin read the same LDS addresses in lockstep -> broadcasts)
+                for (uint32_t i = threadIdx.x; i < S; i += BLK) dcn[i] = 0;
+                __syncthreads();
+                uint32_t fm = 0;
+#pragma unroll
+                for (int j = 0; j < LPT; ++j) {
+                    uint32_t i = threadIdx.x + j * BLK;
+                    if (i < n) {
+                        Rec<NW> x = lds_get<NW>(lds64, i);
+                        uint32_t d = (uint32_t)(key_top64<NW>(x, K) >> sub_shift) & (S - 1);
+                        bool first = true;
+                        for (uint32_t t = cnt[d]; t < i; ++t)
+                            if (rec_eq<NW>(lds_get<NW>(lds64, t), x)) {
+                                first = false;
+                                break;
+                            }
+                        flg[i] = first;
+                        if (first) {
+                            fm |= 1u << j;
+                            atomicAdd(&dcn[d], 1u);
+                        }
+                    }
+                }
+                __syncthreads();
+                uint32_t mine = 0;
+                for (uint32_t d = d0; d < d1; ++d) mine += dcn[d];
+                uint32_t total;
+                uint32_t rank = block_excl_scan<uint32_t>(mine, scr, &total);
+                for (uint32_t d = d0; d < d1; ++d) {
+                    uint32_t c = dcn[d];
+                    dcn[d] = rank;
+                    rank += c;
+                }
+                __syncthreads();
+                if (dbg == 3) continue;
+                // pass 2: rank among the distinct records of the sub-bin -> final position
+#pragma unroll
+                for (int j = 0; j < LPT; ++j) {
+                    uint32_t i = threadIdx.x + j * BLK;
+                    if (i < n && (fm & (1u << j))) {
+                        Rec<NW> x = lds_get<NW>(lds64, i);
+                        uint32_t d = (uint32_t)(key_top64<NW>(x, K) >> sub_shift) & (S - 1);
+                        uint32_t dr = 0;
+                        const uint32_t e0 = cnt[d + 1];
+                        for (uint32_t t = cnt[d]; t < e0; ++t)
+                            if (flg[t] && rec_less<NW>(lds_get<NW>(lds64, t), x)) ++dr;
+                        g[dcn[d] + dr] = x;
+                    }
+                }
+                if (threadIdx.x == 0) ucount[b] = total;
+                __syncthreads();
+                continue;
+            }
+        }
+        lds_bitonic_sort<NW>(lds64, n);
+        uint32_t u = lds_unique_store<NW>(lds64, n, g, scr);
+        if (threadIdx.x == 0) ucount[b] = u;
+        __syncthreads();
     }
-    if (n64 > cap) {
-        if (threadIdx.x == 0) biglist[atomicAdd(bigcount, 1u)] = b;
-        return;
-    }
-    const uint32_t n = (uint32_t)n64;
-    Rec<NW> *g = (Rec<NW> *)buf + o;
-    for (uint32_t i = threadIdx.x; i < n; i += BLK) lds_put<NW>(lds64, i, g[i]);
-    __syncthreads();
-    lds_bitonic_sort<NW>(lds64, n);
-    uint32_t u = lds_unique_store<NW>(lds64, n, g, scr);
-    if (threadIdx.x == 0) ucount[b] = u;
 }
 
 template <int NW>

@@ -1,0 +1,71 @@
+"""Multi-GPU sharding of the counting path: one process per GPU, bucket-range owners,
+ONE all-to-all of k-mer records over RCCL/xGMI, no other data-path collective.
+
+  local reads --extract+XXH3--> records grouped by owner rank --all_to_all_single--> owner: sort+unique
+
+Rank r owns buckets [first(r), first(r+1)), first(r) = ceil(r*B/world) (bucket = mulhi(XXH3, B) is monotone in
+the hash, so ownership is a contiguous hash range); the final file is the concatenation of the ranks' outputs.
+The engine is pluggable so that the orchestration is testable on CPU with gloo (tests inject a CPU engine
+built on the test oracle); the product engine is GpuEngine (libspades_mi355x.so), nothing else.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .kmercount import Context, _chk
+
+
+def rank_first_bucket(num_buckets: int, world: int, rank: int) -> int:
+    return (rank * num_buckets + world - 1) // world
+
+
+class GpuEngine:
+    def __init__(self, ctx: Context, mode: str):
+        self.ctx = ctx
+        self.mode = _lib.MODE_ALL if mode == "A" else _lib.MODE_CANONICAL
+
+    def alloc(self, n_words: int, dev):
+        return torch.empty(max(n_words, 1), dtype=torch.int64, device=dev)
+
+    def extract_count(self, K: int) -> int:
+        n = C.c_uint64()
+        _chk(self.ctx._h, self.ctx.lib.smx_extract_count(self.ctx._h, K, self.mode, C.byref(n)))
+        return n.value
+
+    def extract_partition(self, K: int, nb: int, world: int, buf: torch.Tensor, capacity: int):
+        counts = (C.c_uint64 * world)()
+        _chk(self.ctx._h, self.ctx.lib.smx_extract_partition(self.ctx._h, K, self.mode, nb, world, buf.data_ptr(), capacity, counts))
+        return [int(c) for c in counts]
+
+    def count_records(self, K: int, nb: int, buf: torch.Tensor, n: int):
+        h = self.ctx._h
+        _chk(h, self.ctx.lib.smx_count_records(h, K, nb, buf.data_ptr(), n))
+        nrec, nw, inst = C.c_uint64(), C.c_uint(), C.c_uint64()
+        _chk(h, self.ctx.lib.smx_count_info(h, C.byref(nrec), C.byref(nw), C.byref(inst)))
+        sizes = (C.c_uint64 * nb)()
+        _chk(h, self.ctx.lib.smx_bucket_sizes(h, sizes))
+        return {"distinct": nrec.value, "instances": inst.value, "bucket_sizes": [int(s) for s in sizes],
+                "device_ptr": int(self.ctx.lib.smx_device_kmers(h) or 0)}
+
+
+def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
+    """One step of the sharded path on this rank. Returns the owner-side result dict of the engine
+    (+ 'sent'/'received' record counts). Collective: every rank must call it."""
+    nw = (K + 31) // 32
+    n_local = engine.extract_count(K)
+    send = engine.alloc(n_local * nw, dev)
+    counts = engine.extract_partition(K, nb, world, send, n_local)
+    cnt_t = torch.tensor(counts, dtype=torch.int64, device=dev)
+    rcv_t = torch.empty_like(cnt_t)
+    dist.all_to_all_single(rcv_t, cnt_t)
+    rcounts = [int(c) for c in rcv_t.tolist()]
+    n_recv = sum(rcounts)
+    recv = engine.alloc(n_recv * nw, dev)
+    dist.all_to_all_single(recv[:n_recv * nw], send[:n_local * nw],
+                           output_split_sizes=[c * nw for c in rcounts], input_split_sizes=[c * nw for c in counts])
+    res = engine.count_records(K, nb, recv, n_recv)
+    res["sent"], res["received"] = n_local, n_recv
+    res["instances"] = n_local  # k-mer instances extracted from this rank's reads
+    return res

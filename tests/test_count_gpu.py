@@ -64,7 +64,7 @@ def test_count_vs_oracle_seeded(K, mode, nb):
     assert rec.shape == ref.shape and (rec == ref).all()
 
 
-@pytest.mark.parametrize("opts", [{"leaf_cap": 64}, {"leaf_cap": 64, "s1": 2, "s2": 3}, {"s1": 0, "s2": 0, "leaf_cap": 128},
+@pytest.mark.parametrize("opts", [{"leaf_cap": 64}, {"leaf_cap": 8}, {"leaf_cap": 4}, {"leaf_cap": 64, "s1": 2, "s2": 3}, {"s1": 0, "s2": 0, "leaf_cap": 128},
                                   {"s1": 3, "s2": 0}, {"s1": 0, "s2": 6, "leaf_cap": 256}])
 @pytest.mark.parametrize("K,mode,nb", [(21, "A", 16), (55, "B", 30), (77, "A", 16)])
 def test_multilevel_and_oversized_bins(opts, K, mode, nb):

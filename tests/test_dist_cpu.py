@@ -1,0 +1,106 @@
+"""CPU, world_size 2, gloo: the sharded orchestration (owner ranges, one all-to-all, owner-side merge) with a CPU
+engine built on the test oracle. The GPU engine shares every line of spades_amd.dist.sharded_count."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import read_lines
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """Test double for spades_amd.dist.GpuEngine: same contract, CPU tensors, oracle arithmetic."""
+
+    def __init__(self, reads, mode):
+        self.reads, self.mode = reads, mode
+        self._recs = {}
+
+    def _instances(self, K):
+        if K not in self._recs:
+            from oracle import oracle
+            out = []
+            for r in self.reads:  # every instance, duplicates kept: count each read separately and weight by multiplicity
+                a, b = oracle.longest_valid(r)
+                s = r[a:b].upper()
+                rc = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+                for t in (s, rc):
+                    for j in range(len(t) - K + 1):
+                        rec = oracle.kmer_from_string(t[j:j + K])
+                        if self.mode == "B" and not oracle.is_minimal(rec, K):
+                            continue
+                        out.append(rec)
+            self._recs[K] = np.array(out, dtype=np.uint64).reshape(-1, (K + 31) // 32)
+        return self._recs[K]
+
+    def alloc(self, n_words, dev):
+        return torch.empty(max(n_words, 1), dtype=torch.int64)
+
+    def extract_count(self, K):
+        return len(self._instances(K))
+
+    def extract_partition(self, K, nb, world, buf, capacity):
+        from oracle import oracle
+        rec = self._instances(K)
+        owner = np.array([oracle.bucket(r, K, nb) * world // nb for r in rec], dtype=np.int64)
+        order = np.argsort(owner, kind="stable")
+        flat = rec[order].reshape(-1).view(np.int64)
+        buf[:len(flat)] = torch.from_numpy(flat.copy())
+        return [int((owner == r).sum()) for r in range(world)]
+
+    def count_records(self, K, nb, buf, n):
+        from oracle import oracle
+        nw = (K + 31) // 32
+        rec = buf[:n * nw].numpy().view(np.uint64).reshape(n, nw)
+        keyed = sorted({(oracle.bucket(r, K, nb),) + tuple(int(x) for x in r) for r in rec})
+        sizes = [0] * nb
+        for k in keyed:
+            sizes[k[0]] += 1
+        self.result = np.array([k[1:] for k in keyed], dtype=np.uint64).reshape(-1, nw)
+        return {"distinct": len(keyed), "instances": n, "bucket_sizes": sizes, "device_ptr": 0}
+
+
+def _worker(rank, world, port, K, mode, nb, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spades_amd import dist as smx_dist
+    reads = read_lines("reads_small.txt")[:120]
+    eng = OracleEngine(reads[rank::world], mode)
+    res = smx_dist.sharded_count(eng, K, nb, rank, world, torch.device("cpu"))
+    q.put((rank, res["bucket_sizes"], eng.result.tobytes(), res["sent"], res["received"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K,mode,nb", [(21, "A", 16), (33, "B", 10)])
+def test_sharded_count_world2_gloo(K, mode, nb):
+    from oracle import oracle
+    from spades_amd.dist import rank_first_bucket
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, K, mode, nb, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    reads = read_lines("reads_small.txt")[:120]
+    ref, sizes = oracle.count(reads, K, mode, nb)
+    # concatenating the owners' outputs in rank order gives the reference's final_kmers bytes
+    assert b"".join(g[2] for g in got) == ref.tobytes()
+    tot = np.sum([g[1] for g in got], axis=0)
+    assert (tot == sizes).all()
+    for rank, bs, _, _, _ in got:  # each rank holds only the buckets it owns
+        lo, hi = rank_first_bucket(nb, world, rank), rank_first_bucket(nb, world, rank + 1)
+        assert all(b == 0 for i, b in enumerate(bs) if not (lo <= i < hi))
+    assert sum(g[3] for g in got) == sum(g[4] for g in got)  # every record sent is received exactly once
