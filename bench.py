@@ -52,7 +52,8 @@ def synth_reads_device(seed, genome_len, n_reads, dev, err=0.01, genome_seed=2):
     shifts = (2 * torch.arange(32, device=dev, dtype=torch.int64))[None, :]
     words = torch.zeros(flat.shape[0] + 8, dtype=torch.int64, device=dev)
     for c0 in range(0, flat.shape[0], 1 << 22):
-        words[c0:c0 + (1 << 22)] = (flat[c0:c0 + (1 << 22)].to(torch.int64) << shifts).sum(dim=1)
+        part = (flat[c0:c0 + (1 << 22)].to(torch.int64) << shifts).sum(dim=1)
+        words[c0:c0 + part.numel()] = part
     start = torch.arange(n_reads, device=dev, dtype=torch.int64) * L
     ln = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
     return words, start, ln, codes
