@@ -15,13 +15,20 @@ _LIB = os.path.join(_HERE, "libsmx_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "smx_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("smx_oracle.c", "smx_oracle_graph.c", "smx_oracle.h")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libsmx_oracle.so"])
     return _LIB
 
 
 _lib = None
+
+
+class OrcGraph(C.Structure):
+    _fields_ = [("n_kpomers", C.c_uint64), ("n_kmers", C.c_uint64), ("kmers", C.POINTER(C.c_uint64)),
+                ("masks", C.POINTER(C.c_uint8)), ("n_unitigs", C.c_uint64), ("n_loops", C.c_uint64),
+                ("unitig_off", C.POINTER(C.c_uint64)), ("unitig_seq", C.c_char_p), ("n_vertices", C.c_uint64),
+                ("n_links", C.c_uint64), ("gfa", C.c_char_p), ("gfa_len", C.c_uint64)]
 
 
 def lib():
@@ -45,6 +52,9 @@ def lib():
                                    C.POINTER(u64p), u64p]
         _lib.orc_free.argtypes = [C.c_void_p]
         _lib.orc_longest_valid.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        _lib.orc_build_graph.restype = C.POINTER(OrcGraph)
+        _lib.orc_build_graph.argtypes = [C.c_uint, C.c_uint, C.c_char_p, u64p, C.c_uint64, C.c_char_p]
+        _lib.orc_graph_free.argtypes = [C.POINTER(OrcGraph)]
     return _lib
 
 
@@ -118,3 +128,24 @@ def count_raw(bases: bytes, off: np.ndarray, K: int, mode: str = "A", num_bucket
     rec = np.ctypeslib.as_array(out, shape=(max(n, 1) * nw,))[: n * nw].copy().reshape(n, nw)
     lib().orc_free(out)
     return rec, sizes
+
+
+def build_graph(reads: Sequence[str], k: int, num_buckets: int, flavour_version: str = "SPAdes-4.3.0-dev") -> dict:
+    """spades-gbuilder restated: -> dict(kmers, masks, unitigs (list of str, reference order), n_loops, gfa (str), ...)."""
+    bases, off = concat_reads(reads)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    g = lib().orc_build_graph(k, num_buckets, bases, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off) - 1,
+                              flavour_version.encode())
+    gc = g.contents
+    nw = words(k)
+    nk = gc.n_kmers
+    kmers = np.ctypeslib.as_array(gc.kmers, shape=(max(nk, 1) * nw,))[: nk * nw].copy().reshape(nk, nw)
+    masks = np.ctypeslib.as_array(gc.masks, shape=(max(nk, 1),))[:nk].copy()
+    nu = gc.n_unitigs
+    uoff = np.ctypeslib.as_array(gc.unitig_off, shape=(nu + 1,)).copy()
+    seq = gc.unitig_seq or b""
+    unitigs = [seq[int(uoff[i]):int(uoff[i + 1])].decode() for i in range(nu)]
+    res = dict(n_kpomers=int(gc.n_kpomers), kmers=kmers, masks=masks, unitigs=unitigs, n_loops=int(gc.n_loops),
+               n_vertices=int(gc.n_vertices), n_links=int(gc.n_links), gfa=(gc.gfa or b"").decode())
+    lib().orc_graph_free(g)
+    return res

@@ -282,3 +282,9 @@ int64_t orc_count(char mode, unsigned K, unsigned num_buckets, const char *bases
 }
 
 void orc_free(void *p) { free(p); }
+
+/* shared with smx_oracle_graph.c: sort records of nwp1 words lexicographically (word 0 first) */
+void orc__sort_records(uint64_t *d, size_t n, unsigned nwp1) {
+    g_cmp_nw = nwp1 - 1;
+    if (n) qsort(d, n, nwp1 * sizeof(uint64_t), cmp_rec);
+}

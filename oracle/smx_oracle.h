@@ -47,6 +47,27 @@ int64_t orc_count(char mode, unsigned K, unsigned num_buckets,
                   uint64_t **out, uint64_t *bucket_sizes);
 void orc_free(void *p);
 
+/* ---- graph construction (spades-gbuilder path; rows a13-a19) ----
+ * reads -> canonical (k+1)-mers (B = num_buckets = 10*threads) -> canonical k-mers in k-mer-file order
+ * (kmer_extension_index_builder.hpp:83-107) -> in/out masks (:45-60, inout_mask.hpp:117-131) ->
+ * unbranching paths + perfect loops in the reference's enumeration order
+ * (debruijn_graph_constructor.hpp:184-410) -> edge/vertex ids + links (:412-568) -> GFA text
+ * (io/graph/gfa_writer.cpp:19-47,73-87,113-116). k must be odd (gbuilder.cpp:134-135). */
+typedef struct {
+    uint64_t n_kpomers, n_kmers;   /* distinct canonical (k+1)-mers / k-mers */
+    uint64_t *kmers;               /* [n_kmers * words(k)] k-mer-file order */
+    uint8_t *masks;                /* [n_kmers] InOutMask bytes BEFORE RemoveSequences */
+    uint64_t n_unitigs, n_loops;   /* loops are the last n_loops unitigs */
+    uint64_t *unitig_off;          /* [n_unitigs+1] offsets into unitig_seq */
+    char *unitig_seq;              /* ACGT, concatenated */
+    uint64_t n_vertices, n_links;
+    char *gfa;                     /* NUL-terminated GFA1 text */
+    uint64_t gfa_len;
+} orc_graph;
+orc_graph *orc_build_graph(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off,
+                           uint64_t nreads, const char *flavour_version /* e.g. "SPAdes-4.3.0-dev" */);
+void orc_graph_free(orc_graph *g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,6 +129,39 @@ def main():
                     ref = [c for c in manifest["cases"] if c["reads"] == f"reads_{name}.txt" and c["mode"] == "A" and c["K"] == K and c["num_buckets"] == 16][0]
                     assert md5(data) == ref["md5"], (name, K, "spades-kmercount binary disagrees with ref harness")
                     ref["also_verified_by"] = "spades-kmercount binary (survey build)"
+    # ---- graph fixtures: the REAL spades-gbuilder binary (GFA depends on -t: SURVEY.md finding 3) -------
+    gb = os.path.join(REF_BIN, "spades-gbuilder")
+    if os.path.exists(gb):
+        rnd = random.Random(77)
+        circle = "".join(rnd.choice("ACGT") for _ in range(400))            # perfect loop: circular genome, exact reads
+        loop_reads = [(circle + circle)[p:p + 90] for p in range(0, 400, 7)]
+        gsets = dict(datasets)
+        gsets["loop"] = (None, loop_reads)
+        gsets["mixed"] = (None, datasets["small"][1] + loop_reads)
+        for name in ("loop", "mixed"):
+            with open(os.path.join(HERE, f"reads_{name}.txt"), "w") as f:
+                f.write("\n".join(gsets[name][1]) + "\n")
+        for name, ks, ts in (("tiny", (5, 21), (1, 2)), ("small", (5, 21, 33, 55), (1, 3)), ("polyA", (21,), (1,)),
+                             ("loop", (21, 55), (1, 2)), ("mixed", (21, 33), (1, 4))):
+            reads = [r for r in gsets[name][1] if r]
+            with tempfile.TemporaryDirectory() as td:
+                fq = os.path.join(td, "r.fq")
+                with open(fq, "w") as f:
+                    for i, r in enumerate(reads):
+                        f.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n")
+                for K in ks:
+                    for T in ts:
+                        out = os.path.join(td, f"g_{K}_{T}.gfa")
+                        subprocess.check_call([gb, fq, out, "-k", str(K), "-t", str(T), "--gfa", "-tmp-dir", os.path.join(td, f"t{K}_{T}")],
+                                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                        txt = open(out).read()
+                        fn = f"graph_{name}_k{K}_t{T}.gfa"
+                        keep = len(txt) < 60000
+                        if keep:
+                            open(os.path.join(HERE, fn), "w").write(txt)
+                        manifest["cases"].append({"kind": "graph", "reads": f"reads_{name}.txt", "K": K, "threads": T, "num_buckets": 10 * T,
+                                                  "md5": md5(txt.encode()), "n_segments": txt.count("\nS\t"), "n_links": txt.count("\nL\t"),
+                                                  "file": fn if keep else None, "source": "spades-gbuilder binary (survey build), --gfa"})
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
     print(f"{len(manifest['cases'])} cases written")
 

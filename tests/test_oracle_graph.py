@@ -1,0 +1,69 @@
+"""CPU: pins the graph-construction restatement (oracle/smx_oracle_graph.c) to the reference:
+  * GFA text byte-identical to the real spades-gbuilder binary for several (dataset, k, -t) cases — the GFA
+    depends on -t through the 10*t bucket order (SURVEY.md finding 3), perfect loops included;
+  * the six k=5 known-answer tests of src/test/debruijn/construction_test.cpp:30-64 (edge sets, order-insensitive).
+"""
+import hashlib
+import os
+
+import pytest
+
+from conftest import GOLDEN, load_manifest, read_lines
+from oracle import oracle
+
+GCASES = [c for c in load_manifest()["cases"] if c["kind"] == "graph"]
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+@pytest.mark.parametrize("case", GCASES, ids=lambda c: f"{c['reads'][6:-4]}-k{c['K']}-t{c['threads']}")
+def test_gfa_matches_spades_gbuilder(case):
+    reads = [r for r in read_lines(case["reads"]) if r]
+    g = oracle.build_graph(reads, case["K"], case["num_buckets"])
+    assert g["gfa"].count("\nS\t") == case["n_segments"] and g["gfa"].count("\nL\t") == case["n_links"]
+    assert hashlib.md5(g["gfa"].encode()).hexdigest() == case["md5"]
+    if case["file"]:
+        assert g["gfa"] == open(os.path.join(GOLDEN, case["file"])).read()
+
+
+# construction_test.cpp:30-64 (AssertGraph(k, reads, etalon_edges): edge set incl. reverse complements)
+KNOWN = [
+    ("SimpleThread", ["ACAAACCACCA"], ["ACAAACCACCA"]),
+    ("SimpleThread2", ["ACAAACCACCC", "AAACCACCCAC"], ["ACAAACCACCCAC"]),
+    ("SplitThread", ["ACAAACCACCA", "ACAAACAACCC"], ["ACAAAC", "CAAACCACCA", "CAAACAACCC"]),
+    ("SplitThread2", ["ACAAACCACCA", "ACAAACAACCA"], ["AACCACCA", "ACAAAC", "CAAACCA", "CAAACAACCA"]),
+    ("Buldge", ["ACAAAACACCA", "ACAAACCACCA"], ["ACAAAACACCA", "ACAAACCACCA"]),
+    ("CondenseSimple", ["CGAAACCAC", "CGAAAACAC", "AACCACACC", "AAACACACC"], ["CGAAAACACAC", "CACACC", "CGAAACCACAC"]),
+]
+
+
+@pytest.mark.parametrize("name,reads,edges", KNOWN, ids=[k[0] for k in KNOWN])
+def test_reference_known_answer_graphs(name, reads, edges):
+    g = oracle.build_graph(reads, 5, 10)
+    got = set()
+    for u in g["unitigs"]:
+        got.add(u)
+        got.add(_rc(u))
+    want = set()
+    for e in edges:
+        want.add(e)
+        want.add(_rc(e))
+    assert got == want
+
+
+def test_unitig_invariants():
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    g = oracle.build_graph(reads, 21, 30)
+    assert all(u >= _rc(u) for u in g["unitigs"])  # every S sequence satisfies s >= RC(s)
+    # every canonical 22-mer of the reads lies on exactly one unitig (or its RC)
+    kp, _ = oracle.count(reads, 22, "B", 30)
+    seen = {}
+    for u in g["unitigs"]:
+        for i in range(len(u) - 21):
+            x = u[i:i + 22]
+            c = min(x, _rc(x))
+            seen[c] = seen.get(c, 0) + 1
+    assert len(seen) == len(kp)
+    assert all(v == 1 or k == _rc(k) for k, v in seen.items())
