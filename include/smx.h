@@ -112,6 +112,29 @@ int smx_count_records(smx_ctx *ctx, unsigned K, unsigned num_buckets, const void
 /* first bucket owned by rank r of world (rank r owns [first(r), first(r+1))) */
 unsigned smx_rank_first_bucket(unsigned num_buckets, unsigned world, unsigned rank);
 
+/* ---- de Bruijn construction (spades-gbuilder path) ---------------------------------------------
+ * smx_build_graph replaces, on the resident reads:
+ *   DeBruijnExtensionIndexBuilder::BuildExtensionIndexFromStream (canonical (k+1)-mers -> k-mers -> in/out masks;
+ *     common/kmer_index/extension_index/kmer_extension_index_builder.hpp:63-107),
+ *   UnbranchingPathExtractor::ExtractUnbranchingPathsAndLoops
+ *     (common/assembly_graph/construction/debruijn_graph_constructor.hpp:399-406),
+ *   FastGraphFromSequencesConstructor::ConstructGraph (same file :506-567).
+ * num_buckets = 10 * nthreads of the reference run being reproduced (kmer_extension_index_builder.hpp:75): the GFA
+ * of spades-gbuilder depends on it (SURVEY.md finding 3). k odd, 1 <= k < 128 (projects/spades_tools/gbuilder.cpp:130-135).
+ * After the call smx_copy_final_kmers()/smx_bucket_sizes() describe the canonical k-mer file. */
+int smx_build_graph(smx_ctx *ctx, unsigned k, unsigned num_buckets);
+/* info[8] = { #canonical (k+1)-mers, #canonical k-mers, #unitigs (incl. loops), #perfect loops, #vertices, #links
+ * (valid after a GFA was written), total unitig nucleotides, words per k-mer } */
+int smx_graph_info(const smx_ctx *ctx, uint64_t *info);
+/* k-mer file order: records [n_kmers * words] and InOutMask bytes (extension_index/inout_mask.hpp:55-221) */
+int smx_graph_copy_kmers(const smx_ctx *ctx, void *kmers_host, uint8_t *masks_host);
+/* unitigs in the reference's enumeration order: offsets [n_unitigs+1], ACGT bytes */
+int smx_graph_copy_unitigs(const smx_ctx *ctx, uint64_t *offsets, char *seq);
+/* gfa::GFAWriter::WriteSegmentsAndLinks (common/io/graph/gfa_writer.cpp); flavour_version fills "H\tsp:Z:<..>" */
+int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_version);
+/* gbuilder --unitigs (gbuilder.cpp:191-200): >EDGE_<i>_length_<len>, wrapped at 60 */
+int smx_graph_write_unitigs(smx_ctx *ctx, const char *path);
+
 /* ---- instrumentation -----------------------------------------------------------------------
  * Per-stage GPU time of the last smx_count in milliseconds (HIP events on the library's stream).
  * names/ms arrays of capacity cap; returns number of stages. Stands where the reference has

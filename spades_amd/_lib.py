@@ -54,6 +54,12 @@ def load():
         "smx_count_records": (C.c_int, [vp, C.c_uint, C.c_uint, vp, C.c_uint64]),
         "smx_rank_first_bucket": (C.c_uint, [C.c_uint, C.c_uint, C.c_uint]),
         "smx_last_timings": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
+        "smx_build_graph": (C.c_int, [vp, C.c_uint, C.c_uint]),
+        "smx_graph_info": (C.c_int, [vp, u64p]),
+        "smx_graph_copy_kmers": (C.c_int, [vp, vp, vp]),
+        "smx_graph_copy_unitigs": (C.c_int, [vp, u64p, vp]),
+        "smx_graph_write_gfa": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
+        "smx_graph_write_unitigs": (C.c_int, [vp, C.c_char_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

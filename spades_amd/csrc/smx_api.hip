@@ -2,6 +2,8 @@
 // Built by hipcc into libspades_mi355x.so; no torch / no reference headers involved.
 #include "../../include/smx.h"
 #include "smx_kernels.hip"
+#include "smx_graph.hip"
+#include "smx_graph_host.hpp"
 
 #include <algorithm>
 #include <cstdarg>
@@ -48,6 +50,14 @@ struct smx_ctx {
     std::vector<std::string> tnames, xnames;  // last count stages / last extract_partition stages
     std::vector<float> tms, xms;
     std::vector<void *> temps;  // allocations of the pipeline in flight
+    // construction state (smx_build_graph)
+    void *g_kpo = nullptr, *g_kmers = nullptr;
+    uint8_t *g_mask = nullptr;
+    uint64_t g_nkpo = 0, g_nkmers = 0;
+    unsigned g_k = 0, g_nw = 0, g_B = 0;
+    std::vector<uint64_t> g_kboff;
+    bool g_ready = false;
+    smxh::GraphHost gh;
 };
 
 namespace {
@@ -282,7 +292,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
 
     // ---- choose the MSD split: level 1 = bucket + s1 key bits, then levels of <= log2(FMAX) bits ----
     const unsigned avail = std::min(64u, 2 * K);  // key bits visible in key_top64
-    const uint64_t leaf = std::max<uint32_t>(cap / 4, 1);
+    const uint64_t leaf = std::max<uint32_t>(std::min<uint32_t>(cap / 4, 64), 1);  // wave-sortable leaves (<= 256) on average 64
     const uint64_t fneed = (nrec + leaf - 1) / leaf;
     unsigned bits = fneed > B ? ceil_log2((fneed + B - 1) / B) : 0;
     bits = std::min(bits, std::min(avail, 40u));
@@ -322,7 +332,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (int rc = dalloc(ctx, &bufA, nrec)) return rc;
     if (int rc = dalloc(ctx, &bufB, nrec)) return rc;
     unsigned long long *histA, *offA, *offB, *cur, *tcnt, *tstart, *ucount, *uoff, *bucket_off;
-    uint32_t *biglist, *bigcount, *runlen;
+    uint32_t *biglist, *bigcount, *runlen, *medlist, *medcount;
     if (int rc = dalloc(ctx, &histA, nb)) return rc;
     if (int rc = dalloc(ctx, &offA, nb + 1)) return rc;
     if (int rc = dalloc(ctx, &offB, nb_parent_max + 1)) return rc;
@@ -333,6 +343,9 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (int rc = dalloc(ctx, &uoff, nb + 1)) return rc;
     if (int rc = dalloc(ctx, &biglist, nb)) return rc;
     if (int rc = dalloc(ctx, &bigcount, 1)) return rc;
+    if (int rc = dalloc(ctx, &medlist, nb)) return rc;
+    if (int rc = dalloc(ctx, &medcount, 1)) return rc;
+    HIPCHK(hipMemsetAsync(medcount, 0, 4, ctx->stream));
     if (int rc = dalloc(ctx, &runlen, nrec / cap + nb + 2)) return rc;
     if (int rc = dalloc(ctx, &bucket_off, B + 1)) return rc;
     HIPCHK(hipMemsetAsync(bigcount, 0, 4, ctx->stream));
@@ -423,9 +436,15 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         size_t lds = (size_t)cap * NW * 8 + (2 * (size_t)(1u << sub_bits) + 2) * 4 + cap + 16;
         if (int rc = set_lds(ctx, k_sort_small<NW, Tune<NW>::LPT>, lds)) return rc;
         if (int rc = set_lds(ctx, k_sort_big<NW>, (size_t)cap * NW * 8)) return rc;
+        tbegin(ctx, "sort_wave");
+        hipLaunchKernelGGL((k_sort_wave<NW>), dim3((unsigned)std::min<uint64_t>((nb + 3) / 4, 256 * 16)), dim3(BLK), 0, ctx->stream,
+                           (void *)sortbuf, fine_off, (uint32_t)nb, cap, ucount, medlist, medcount, biglist, bigcount);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
         tbegin(ctx, "sort_unique");
-        hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3((unsigned)std::min<uint64_t>(nb, 256 * 8)), dim3(BLK), lds, ctx->stream, (void *)sortbuf,
-                           fine_off, (uint32_t)nb, cap, K, sub_bits ? sub_shift : 0u, sub_bits, ucount, biglist, bigcount, (int)ctx->opt_dbg);
+        hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 4), dim3(BLK), lds, ctx->stream, (void *)sortbuf,
+                           fine_off, (uint32_t)nb, cap, K, sub_bits ? sub_shift : 0u, sub_bits, ucount, biglist, bigcount, (int)ctx->opt_dbg,
+                           (const uint32_t *)medlist, (const uint32_t *)medcount);
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "sort_big");
@@ -437,7 +456,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     // ---- compact ----------------------------------------------------------------------------
     tbegin(ctx, "compact");
     if (int rc = scan_u64(ctx, ucount, uoff, nb)) return rc;
-    hipLaunchKernelGGL((k_compact<NW>), dim3((unsigned)std::min<uint64_t>(nb, 1u << 20)), dim3(BLK), 0, ctx->stream,
+    hipLaunchKernelGGL((k_compact_wave<NW>), dim3((unsigned)std::min<uint64_t>((nb + 3) / 4, 256 * 32)), dim3(BLK), 0, ctx->stream,
                        (const void *)sortbuf, fine_off, (const unsigned long long *)ucount, (const unsigned long long *)uoff,
                        (uint32_t)nb, (void *)other);
     HIPCHK(hipGetLastError());
@@ -528,6 +547,251 @@ int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsign
 }
 }  // namespace
 
+
+void clear_graph(smx_ctx *ctx) {
+    if (ctx->g_kpo) (void)hipFree(ctx->g_kpo);
+    if (ctx->g_kmers) {
+        if (ctx->d_result == ctx->g_kmers) ctx->d_result = nullptr;
+        (void)hipFree(ctx->g_kmers);
+    }
+    if (ctx->g_mask) (void)hipFree(ctx->g_mask);
+    ctx->g_kpo = ctx->g_kmers = nullptr;
+    ctx->g_mask = nullptr;
+    ctx->g_nkpo = ctx->g_nkmers = 0;
+    ctx->g_ready = false;
+    ctx->gh = smxh::GraphHost();
+}
+
+template <typename T>
+int d2h(smx_ctx *ctx, std::vector<T> &dst, const void *src, size_t n) {
+    dst.resize(n);
+    if (n) HIPCHK(hipMemcpy(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+template <int NW>
+int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
+    clear_graph(ctx);
+    ctx->g_k = k;
+    ctx->g_nw = NW;
+    ctx->g_B = B;
+    ctx->gh.k = k;
+    ctx->gh.eoff.assign(1, 0);
+    // ---- 1. canonical (k+1)-mers -------------------------------------------------------------
+    if (int rc = run_count<NW>(ctx, k + 1, SMX_MODE_CANONICAL, B, nullptr, 0)) return rc;
+    ctx->g_kpo = ctx->d_result_buf;
+    ctx->g_nkpo = ctx->n_records;
+    ctx->d_result_buf = ctx->d_result = nullptr;
+    free_temps(ctx, ctx->g_kpo);
+    const uint64_t nkpo = ctx->g_nkpo;
+    ctx->g_kboff.assign(B + 1, 0);
+    if (nkpo == 0) {
+        smxh::build_links(ctx->gh);
+        ctx->g_ready = true;
+        ctx->n_records = 0;
+        ctx->K = k;
+        ctx->bucket_off.assign(B + 1, 0);
+        return 0;
+    }
+    // ---- 2. canonical k-mers in k-mer-file order ----------------------------------------------
+    {
+        Rec<NW> *derived;
+        if (int rc = dalloc(ctx, &derived, 2 * nkpo)) return rc;
+        tbegin(ctx, "derive_kmers");
+        hipLaunchKernelGGL((k_derive_kmers<NW>), dim3((unsigned)std::min<uint64_t>((nkpo + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0,
+                           ctx->stream, (const void *)ctx->g_kpo, nkpo, k, (void *)derived);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, derived, 2 * nkpo)) return rc;
+        ctx->g_kmers = ctx->d_result_buf;
+        ctx->g_nkmers = ctx->n_records;
+        ctx->g_kboff = ctx->bucket_off;
+        ctx->d_result_buf = nullptr;
+        ctx->d_result = ctx->g_kmers;  // smx_copy_final_kmers() now yields the k-mer file
+        free_temps(ctx, ctx->g_kmers);
+    }
+    const uint64_t D0 = ctx->g_nkmers;
+    if (D0 >= (1ull << 31)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%llu k-mers exceed the 2^31 node-id limit", (unsigned long long)D0);
+    const unsigned grid = (unsigned)std::min<uint64_t>((2 * D0 + BLK - 1) / BLK, 1u << 16);
+    // ---- 3. extension masks ---------------------------------------------------------------------
+    unsigned long long *d_boff;
+    uint32_t *d_err;
+    if (int rc = dalloc(ctx, &d_boff, B + 1)) return rc;
+    if (int rc = dalloc(ctx, &d_err, 1)) return rc;
+    HIPCHK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    {
+        std::vector<unsigned long long> hb(ctx->g_kboff.begin(), ctx->g_kboff.end());
+        HIPCHK(hipMemcpyAsync(d_boff, hb.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    if (int rc = dalloc(ctx, &ctx->g_mask, (size_t)((D0 + 3) / 4 * 4 + 4), false)) return rc;
+    HIPCHK(hipMemsetAsync(ctx->g_mask, 0, (size_t)((D0 + 3) / 4 * 4 + 4), ctx->stream));
+    tbegin(ctx, "fill_masks");
+    hipLaunchKernelGGL((k_fill_masks<NW>), dim3((unsigned)std::min<uint64_t>((nkpo + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
+                       (const void *)ctx->g_kpo, nkpo, k, (const void *)ctx->g_kmers, (const unsigned long long *)d_boff, B,
+                       (uint32_t *)ctx->g_mask, d_err);
+    HIPCHK(hipGetLastError());
+    tend(ctx);
+    // ---- 4. successors + start de-edges -------------------------------------------------------
+    uint32_t *succ;
+    unsigned long long *ccnt, *coff;
+    if (int rc = dalloc(ctx, &succ, 2 * D0)) return rc;
+    if (int rc = dalloc(ctx, &ccnt, D0)) return rc;
+    if (int rc = dalloc(ctx, &coff, D0 + 1)) return rc;
+    tbegin(ctx, "succ");
+    hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k,
+                       (const unsigned long long *)d_boff, B, succ, d_err);
+    HIPCHK(hipGetLastError());
+    tend(ctx);
+    tbegin(ctx, "candidates");
+    hipLaunchKernelGGL(k_cand_count, dim3(grid), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, ccnt);
+    HIPCHK(hipGetLastError());
+    if (int rc = scan_u64(ctx, ccnt, coff, D0)) return rc;
+    unsigned long long C = 0;
+    HIPCHK(hipMemcpyAsync(&C, coff + D0, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    tend(ctx);
+    std::vector<unsigned long long> h_eoff;
+    uint64_t n_paths = 0;
+    uint8_t *visited;
+    if (int rc = dalloc(ctx, &visited, D0 + 1)) return rc;
+    HIPCHK(hipMemsetAsync(visited, 0, D0 + 1, ctx->stream));
+    if (C > 0) {
+        unsigned long long *cand, *len, *soff, *keeplen, *koff, *one, *eidx;
+        uint32_t *first, *last;
+        uint8_t *flags;
+        if (int rc = dalloc(ctx, &cand, C)) return rc;
+        if (int rc = dalloc(ctx, &len, C)) return rc;
+        if (int rc = dalloc(ctx, &soff, C + 1)) return rc;
+        if (int rc = dalloc(ctx, &keeplen, C)) return rc;
+        if (int rc = dalloc(ctx, &koff, C + 1)) return rc;
+        if (int rc = dalloc(ctx, &one, C)) return rc;
+        if (int rc = dalloc(ctx, &eidx, C + 1)) return rc;
+        if (int rc = dalloc(ctx, &first, C)) return rc;
+        if (int rc = dalloc(ctx, &last, C)) return rc;
+        if (int rc = dalloc(ctx, &flags, C)) return rc;
+        const unsigned cgrid = (unsigned)std::min<uint64_t>((C + BLK - 1) / BLK, 1u << 16);
+        hipLaunchKernelGGL(k_cand_expand, dim3(grid), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask,
+                           (const unsigned long long *)coff, D0, cand);
+        HIPCHK(hipGetLastError());
+        tbegin(ctx, "walk_len");
+        hipLaunchKernelGGL((k_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
+                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const uint32_t *)succ, k,
+                           (const unsigned long long *)d_boff, B, (uint64_t)(2 * D0 + 2), len, first, last, d_err);
+        HIPCHK(hipGetLastError());
+        if (int rc = scan_u64(ctx, len, soff, C)) return rc;
+        unsigned long long total = 0;
+        HIPCHK(hipMemcpyAsync(&total, soff + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        tend(ctx);
+        char *seq;
+        if (int rc = dalloc(ctx, &seq, total + 1)) return rc;
+        tbegin(ctx, "walk_write");
+        hipLaunchKernelGGL((k_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
+                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const uint32_t *)succ, k, (const uint32_t *)first,
+                           (const unsigned long long *)soff, seq, visited);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        tbegin(ctx, "keep_gather");
+        hipLaunchKernelGGL(k_keep, dim3(cgrid), dim3(BLK), 0, ctx->stream, (const char *)seq, (const unsigned long long *)soff, (uint64_t)C,
+                           keeplen, flags);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_keep_flag, dim3(cgrid), dim3(BLK), 0, ctx->stream, (const uint8_t *)flags, (uint64_t)C, one);
+        HIPCHK(hipGetLastError());
+        if (int rc = scan_u64(ctx, keeplen, koff, C)) return rc;
+        if (int rc = scan_u64(ctx, one, eidx, C)) return rc;
+        unsigned long long ktotal = 0, nkept = 0;
+        HIPCHK(hipMemcpyAsync(&ktotal, koff + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&nkept, eidx + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        char *kseq;
+        unsigned long long *eoff;
+        uint32_t *estart, *eend;
+        uint8_t *eself;
+        if (int rc = dalloc(ctx, &kseq, ktotal + 1)) return rc;
+        if (int rc = dalloc(ctx, &eoff, nkept + 1)) return rc;
+        if (int rc = dalloc(ctx, &estart, nkept + 1)) return rc;
+        if (int rc = dalloc(ctx, &eend, nkept + 1)) return rc;
+        if (int rc = dalloc(ctx, &eself, nkept + 1)) return rc;
+        hipLaunchKernelGGL(k_gather, dim3(cgrid), dim3(BLK), 0, ctx->stream, (const char *)seq, (const unsigned long long *)soff,
+                           (const unsigned long long *)koff, (const uint8_t *)flags, (const unsigned long long *)eidx,
+                           (const unsigned long long *)cand, (const uint32_t *)last, (uint64_t)C, kseq, eoff, estart, eend, eself);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        // ---- to host ----
+        n_paths = nkept;
+        if (int rc = d2h(ctx, h_eoff, eoff, nkept)) return rc;
+        ctx->gh.seq.resize(ktotal);
+        if (ktotal) HIPCHK(hipMemcpy(&ctx->gh.seq[0], kseq, ktotal, hipMemcpyDeviceToHost));
+        if (int rc = d2h(ctx, ctx->gh.estart, estart, nkept)) return rc;
+        if (int rc = d2h(ctx, ctx->gh.eend, eend, nkept)) return rc;
+        if (int rc = d2h(ctx, ctx->gh.eself, eself, nkept)) return rc;
+        ctx->gh.eoff.assign(h_eoff.begin(), h_eoff.end());
+        ctx->gh.eoff.push_back(ktotal);
+    }
+    {
+        // ---- perfect loops: non-junction k-mers on no path ----
+        uint32_t *lcount, *llist;
+        const uint32_t lcap = (uint32_t)std::min<uint64_t>(D0, 1u << 26);
+        if (int rc = dalloc(ctx, &lcount, 1)) return rc;
+        if (int rc = dalloc(ctx, &llist, lcap)) return rc;
+        HIPCHK(hipMemsetAsync(lcount, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_loop_nodes, dim3(grid), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const uint8_t *)visited, D0,
+                           lcount, llist, lcap);
+        HIPCHK(hipGetLastError());
+        uint32_t nloopk = 0;
+        HIPCHK(hipMemcpyAsync(&nloopk, lcount, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (nloopk > lcap) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%u k-mers on perfect loops exceed the host-side limit", nloopk);
+        if (nloopk) {
+            std::vector<uint32_t> ranks;
+            if (int rc = d2h(ctx, ranks, llist, nloopk)) return rc;
+            std::sort(ranks.begin(), ranks.end());  // k-mer-file order
+            HIPCHK(hipMemcpy(llist, ranks.data(), (size_t)nloopk * 4, hipMemcpyHostToDevice));
+            Rec<NW> *lk;
+            if (int rc = dalloc(ctx, &lk, nloopk)) return rc;
+            hipLaunchKernelGGL((k_gather_kmers<NW>), dim3((nloopk + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers,
+                               (const uint32_t *)llist, nloopk, (void *)lk);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            std::vector<uint64_t> hk;
+            if (int rc = d2h(ctx, hk, lk, (size_t)nloopk * NW)) return rc;
+            std::vector<uint8_t> hmask;
+            if (int rc = d2h(ctx, hmask, ctx->g_mask, (size_t)D0)) return rc;
+            std::vector<smxh::LoopNode> nodes(nloopk);
+            for (uint32_t i = 0; i < nloopk; ++i) {
+                nodes[i].rank = ranks[i];
+                nodes[i].kmer.resize(k);
+                for (unsigned j = 0; j < k; ++j) nodes[i].kmer[j] = "ACGT"[(hk[(size_t)i * NW + (j >> 5)] >> ((j & 31) << 1)) & 3];
+                nodes[i].mask = hmask[ranks[i]];
+            }
+            smxh::LoopCollector lc(nodes, k);
+            std::vector<std::string> loops;
+            lc.collect(loops);
+            // node ids must be taken from the untouched masks' k-mers: rebuild a lookup (masks were zeroed by collect)
+            for (auto &s : loops) {
+                const std::string fk = s.substr(0, k), lk2 = s.substr(s.size() - k);
+                ctx->gh.estart.push_back(lc.node_of(fk));
+                ctx->gh.eend.push_back(lc.node_of(lk2));
+                ctx->gh.eself.push_back(s == smxh::revcomp(s) ? 1 : 0);
+                ctx->gh.seq += s;
+                ctx->gh.eoff.push_back(ctx->gh.seq.size());
+            }
+            ctx->gh.n_loops = loops.size();
+        }
+    }
+    ctx->gh.n_paths = n_paths;
+    unsigned herr = 0;
+    HIPCHK(hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost));
+    if (herr) return fail(ctx, SMX_DEVICE_ERROR, "inconsistent k-mer index: %u failed lookups/walks", herr);
+    tbegin(ctx, "links_host");
+    smxh::build_links(ctx->gh);
+    tend(ctx);
+    ctx->g_ready = true;
+    return 0;
+}
+
 // ============================================================================ C ABI
 extern "C" {
 
@@ -554,6 +818,7 @@ void smx_destroy(smx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     smx_reads_clear(ctx);
+    clear_graph(ctx);
     clear_result(ctx);
     free_temps(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -819,6 +1084,89 @@ int smx_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned num_bucke
     }
     free_temps(ctx);
     return rc;
+}
+
+int smx_build_graph(smx_ctx *ctx, unsigned k, unsigned num_buckets) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    // gbuilder.cpp:130-135: MIN_K <= k < MAX_K(128), k odd
+    if (k < 1) return fail(ctx, SMX_INVALID_PARAMETER, "k-mer size %u is too low", k);
+    if (k >= 128) return fail(ctx, SMX_INVALID_PARAMETER, "k-mer size %u is too high", k);
+    if (k % 2 == 0) return fail(ctx, SMX_INVALID_PARAMETER, "k-mer size must be odd");
+    if (num_buckets < 1) return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets must be >= 1");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->xnames.clear();
+    ctx->xms.clear();
+    int rc;
+    switch ((k + 32) / 32) {  // words of k+1 (== words of k because k is odd)
+        case 1: rc = run_graph<1>(ctx, k, num_buckets); break;
+        case 2: rc = run_graph<2>(ctx, k, num_buckets); break;
+        case 3: rc = run_graph<3>(ctx, k, num_buckets); break;
+        default: rc = run_graph<4>(ctx, k, num_buckets); break;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (rc == 0) {
+        tcollect(ctx);
+    } else {
+        for (auto &t : ctx->timings) {
+            (void)hipEventDestroy(t.e0);
+            (void)hipEventDestroy(t.e1);
+        }
+        ctx->timings.clear();
+    }
+    free_temps(ctx);
+    if (rc) clear_graph(ctx);
+    return rc;
+}
+
+int smx_graph_info(const smx_ctx *ctx, uint64_t *info /* [8] */) {
+    if (!ctx || !info) return SMX_INVALID_PARAMETER;
+    if (!ctx->g_ready) return SMX_INVALID_PARAMETER;
+    info[0] = ctx->g_nkpo;
+    info[1] = ctx->g_nkmers;
+    info[2] = ctx->gh.n_edges();
+    info[3] = ctx->gh.n_loops;
+    info[4] = ctx->gh.n_vertices;
+    info[5] = ctx->gh.n_links;
+    info[6] = ctx->gh.seq.size();
+    info[7] = ctx->g_nw;
+    return SMX_OK;
+}
+
+int smx_graph_copy_kmers(const smx_ctx *cctx, void *kmers_host, uint8_t *masks_host) {
+    smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
+    if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->g_nkmers == 0) return SMX_OK;
+    if (kmers_host) HIPCHK(hipMemcpy(kmers_host, ctx->g_kmers, ctx->g_nkmers * ctx->g_nw * 8, hipMemcpyDeviceToHost));
+    if (masks_host) HIPCHK(hipMemcpy(masks_host, ctx->g_mask, ctx->g_nkmers, hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+int smx_graph_copy_unitigs(const smx_ctx *ctx, uint64_t *offsets, char *seq) {
+    if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
+    if (offsets) memcpy(offsets, ctx->gh.eoff.data(), ctx->gh.eoff.size() * 8);
+    if (seq && !ctx->gh.seq.empty()) memcpy(seq, ctx->gh.seq.data(), ctx->gh.seq.size());
+    return SMX_OK;
+}
+
+int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_version) {
+    if (!ctx || !path) return SMX_INVALID_PARAMETER;
+    if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
+    bool ok = smxh::write_gfa(ctx->gh, f, flavour_version ? flavour_version : "SPAdes-4.3.0-dev");
+    if (fclose(f) != 0) ok = false;
+    return ok ? SMX_OK : fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path);
+}
+
+int smx_graph_write_unitigs(smx_ctx *ctx, const char *path) {
+    if (!ctx || !path) return SMX_INVALID_PARAMETER;
+    if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
+    bool ok = smxh::write_unitigs_fasta(ctx->gh, f);
+    if (fclose(f) != 0) ok = false;
+    return ok ? SMX_OK : fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path);
 }
 
 int smx_last_timings(const smx_ctx *ctx, const char **names, float *ms, int cap) {

@@ -1,0 +1,274 @@
+// spades_amd/csrc/smx_graph.hip — de Bruijn construction on the device results of the counting path.
+// Included by smx_api.hip (one translation unit).
+//
+// Reference rows (paths relative to /root/reference/src/common):
+//   a13 DeBruijnKMerKMerSplitter        kmer_index/kmer_mph/kmer_splitters.hpp:138-207      -> k_derive_kmers + count
+//   a15 FillExtensionsFromIndex/InOutMask  extension_index/kmer_extension_index_builder.hpp:45-60,
+//                                           extension_index/inout_mask.hpp:92-131           -> k_fill_masks
+//   a16 UnbranchingPathExtractor        assembly_graph/construction/debruijn_graph_constructor.hpp:184-410
+//                                        -> k_succ, k_cand_*, k_walk_len, k_walk_write, k_keep, k_gather (+ host loops)
+//   a17 FastGraphFromSequencesConstructor  same file :412-568                               -> host link records
+//   a19 gfa::GFAWriter                  io/graph/gfa_writer.cpp:19-47,73-87,113-116         -> host writer
+//
+// Device layout: k-mers = the sorted-unique k-mer "file" (bucket-major, B = 10*threads), rank r = position in it
+// (stands in for the MPHF index, whose values never reach the output: debruijn_graph_constructor.hpp:540-547).
+// One byte mask per rank. A *node* is an oriented k-mer: node = 2*rank + o, o=1 meaning RC of the stored k-mer.
+#pragma once
+#include "smx_device.hpp"
+
+namespace smx {
+
+constexpr uint32_t NODE_NONE = 0xFFFFFFFFu;
+
+template <int NW>
+__device__ __forceinline__ Rec<NW> rec_shl(const Rec<NW> &x, unsigned K, unsigned c) {  // operator<<, rtseq.hpp:437-457
+    Rec<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW - 1; ++i) r.w[i] = (x.w[i] >> 2) | (x.w[i + 1] << 62);
+    r.w[NW - 1] = (x.w[NW - 1] >> 2) | ((uint64_t)c << (((K - 1) & 31) << 1));
+    return r;
+}
+// first k nucleotides of a (k+1)-mer (k and k+1 need the same number of words because k is odd)
+template <int NW>
+__device__ __forceinline__ Rec<NW> rec_prefix(const Rec<NW> &x, unsigned k) {
+    Rec<NW> r = x;
+    r.w[k >> 5] &= ~(3ull << ((k & 31) << 1));
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ Rec<NW> rec_suffix(const Rec<NW> &x) {  // nucleotides 1..k of a (k+1)-mer
+    Rec<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW - 1; ++i) r.w[i] = (x.w[i] >> 2) | (x.w[i + 1] << 62);
+    r.w[NW - 1] = x.w[NW - 1] >> 2;
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ unsigned rec_nucl(const Rec<NW> &x, unsigned i) {
+    return (unsigned)((x.w[i >> 5] >> ((i & 31) << 1)) & 3);
+}
+// canonical representative and whether the input was the non-minimal orientation
+template <int NW>
+__device__ __forceinline__ Rec<NW> rec_canon(const Rec<NW> &x, unsigned K, unsigned &is_rc) {
+    Rec<NW> y = rec_rc<NW>(x, K);
+    bool minimal = rc_ge<NW>(y, x);
+    is_rc = minimal ? 0u : 1u;
+    return minimal ? x : y;
+}
+// rank of a canonical k-mer (KMerIndex::seq_idx stand-in, kmer_index.hpp:88-100): bucket by hash, binary search
+template <int NW>
+__device__ __forceinline__ uint32_t kmer_rank(const Rec<NW> *__restrict__ kmers, const unsigned long long *__restrict__ boff,
+                                              uint32_t B, const Rec<NW> &canon) {
+    const uint32_t b = bucket_of(xxh3_rec<NW>(canon), B);
+    uint64_t lo = boff[b], hi = boff[b + 1];
+    const uint64_t end = hi;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (rec_less<NW>(kmers[mid], canon)) lo = mid + 1; else hi = mid;
+    }
+    return (lo < end && rec_eq<NW>(kmers[lo], canon)) ? (uint32_t)lo : NODE_NONE;
+}
+__device__ __forceinline__ unsigned brev8(unsigned m) { return __brev(m) >> 24; }  // InOutMask::conjugate, inout_mask.hpp:18-39,112-115
+__device__ __forceinline__ bool uniq4(unsigned m) { return m && !(m & (m - 1)); }
+__device__ __forceinline__ bool mask_junction(unsigned m) { return !uniq4(m & 15) || !uniq4((m >> 4) & 15); }  // inout_mask.hpp:157-159
+
+// a13: the 2 k-mers of every canonical (k+1)-mer, canonicalised (the RC (k+1)-mer yields the same two)
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_derive_kmers(const void *kpo_, uint64_t n, unsigned k, void *out_) {
+    const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
+    Rec<NW> *out = (Rec<NW> *)out_;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        Rec<NW> x = kpo[i];
+        unsigned f;
+        out[2 * i] = rec_canon<NW>(rec_prefix<NW>(x, k), k, f);
+        out[2 * i + 1] = rec_canon<NW>(rec_suffix<NW>(x), k, f);
+    }
+}
+
+// a15: out[prefix] |= bit(x_k), in[suffix] |= bit(x_0), positions mirrored (7-p) for non-minimal keys
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_fill_masks(const void *kpo_, uint64_t n, unsigned k, const void *kmers_,
+                                                    const unsigned long long *boff, uint32_t B, uint32_t *mask32, uint32_t *err) {
+    const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        Rec<NW> x = kpo[i];
+        const unsigned pn = rec_nucl<NW>(x, 0), nn = rec_nucl<NW>(x, k);
+        unsigned prc, src;
+        Rec<NW> p = rec_canon<NW>(rec_prefix<NW>(x, k), k, prc);
+        Rec<NW> s = rec_canon<NW>(rec_suffix<NW>(x), k, src);
+        uint32_t rp = kmer_rank<NW>(kmers, boff, B, p), rs = kmer_rank<NW>(kmers, boff, B, s);
+        if (rp == NODE_NONE || rs == NODE_NONE) {
+            atomicAdd(err, 1u);
+            continue;
+        }
+        const unsigned bp = prc ? 7 - nn : nn;
+        const unsigned bs = src ? 3 - pn : pn + 4;
+        atomicOr(&mask32[rp >> 2], (1u << bp) << ((rp & 3) * 8));
+        atomicOr(&mask32[rs >> 2], (1u << bs) << ((rs & 3) * 8));
+    }
+}
+
+// successor of every non-junction node: GetOutgoing(kwh, GetUniqueOutgoing), debruijn_graph_constructor.hpp:228-235
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t *mask, uint64_t D0, unsigned k,
+                                              const unsigned long long *boff, uint32_t B, uint32_t *succ, uint32_t *err) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
+        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        const unsigned m = mask[r];
+        if (mask_junction(m)) {
+            succ[node] = NODE_NONE;
+            continue;
+        }
+        const unsigned mo = o ? brev8(m) : m;
+        Rec<NW> x = kmers[r];
+        if (o) x = rec_rc<NW>(x, k);
+        unsigned yo;
+        Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, __ffs(mo & 15) - 1), k, yo);
+        uint32_t ry = kmer_rank<NW>(kmers, boff, B, y);
+        if (ry == NODE_NONE) atomicAdd(err, 1u);
+        succ[node] = ry == NODE_NONE ? NODE_NONE : (ry << 1) | yo;
+    }
+}
+
+// start de-edges per junction k-mer: out bits of kh, then out bits of !kh (AddStartDeEdges, :203-226)
+__global__ void k_cand_count(const uint8_t *mask, uint64_t D0, unsigned long long *cnt) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x) {
+        unsigned m = mask[r];
+        cnt[r] = mask_junction(m) ? (unsigned long long)(__popc(m & 15) + __popc(m >> 4)) : 0ull;
+    }
+}
+__global__ void k_cand_expand(const uint8_t *mask, const unsigned long long *cand_off, uint64_t D0, unsigned long long *cand) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x) {
+        unsigned m = mask[r];
+        if (!mask_junction(m)) continue;
+        unsigned long long o = cand_off[r];
+        for (unsigned c = 0; c < 4; ++c)
+            if (m & (1u << c)) cand[o++] = (r << 3) | c;
+        const unsigned mi = brev8(m);
+        for (unsigned c = 0; c < 4; ++c)
+            if (mi & (1u << c)) cand[o++] = (r << 3) | 4u | c;
+    }
+}
+
+// ConstructSequenceWithEdge (:264-273), pass 1: length and end node of every start de-edge
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_walk_len(const unsigned long long *cand, uint64_t C, const void *kmers_, const uint8_t *mask,
+                                                  const uint32_t *succ, unsigned k, const unsigned long long *boff, uint32_t B,
+                                                  uint64_t max_steps, unsigned long long *len, uint32_t *first, uint32_t *last,
+                                                  uint32_t *err) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
+        const unsigned long long cd = cand[i];
+        const uint32_t r = (uint32_t)(cd >> 3), side = (uint32_t)((cd >> 2) & 1), c = (uint32_t)(cd & 3);
+        Rec<NW> x = kmers[r];
+        if (side) x = rec_rc<NW>(x, k);
+        unsigned yo;
+        Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
+        uint32_t ry = kmer_rank<NW>(kmers, boff, B, y);
+        if (ry == NODE_NONE) {
+            atomicAdd(err, 1u);
+            len[i] = 0;
+            first[i] = last[i] = NODE_NONE;
+            continue;
+        }
+        uint32_t node = (ry << 1) | yo;
+        first[i] = node;
+        uint64_t steps = 0;
+        while (!mask_junction(mask[node >> 1])) {
+            node = succ[node];
+            if (++steps > max_steps || node == NODE_NONE) {  // cannot happen on a consistent index; never hang the GPU
+                atomicAdd(err, 1u);
+                break;
+            }
+        }
+        last[i] = node;
+        len[i] = k + 1 + steps;
+    }
+}
+
+// pass 2: write the nucleotides (ASCII) and mark every k-mer on the path (both strands share the rank) as visited
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_walk_write(const unsigned long long *cand, uint64_t C, const void *kmers_, const uint8_t *mask,
+                                                    const uint32_t *succ, unsigned k, const uint32_t *first, const unsigned long long *soff,
+                                                    char *seq, uint8_t *visited) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
+        const unsigned long long cd = cand[i];
+        const uint32_t r = (uint32_t)(cd >> 3), side = (uint32_t)((cd >> 2) & 1), c = (uint32_t)(cd & 3);
+        uint32_t node = first[i];
+        if (node == NODE_NONE) continue;
+        Rec<NW> x = kmers[r];
+        if (side) x = rec_rc<NW>(x, k);
+        char *s = seq + soff[i];
+        const unsigned long long n = soff[i + 1] - soff[i];
+        for (unsigned j = 0; j < k; ++j) s[j] = "ACGT"[rec_nucl<NW>(x, j)];
+        s[k] = "ACGT"[c];
+        visited[r] = 1;
+        unsigned long long p = k + 1;
+        while (p < n) {
+            const unsigned m = mask[node >> 1];
+            const unsigned mo = (node & 1) ? brev8(m) : m;
+            visited[node >> 1] = 1;
+            s[p++] = "ACGT"[__ffs(mo & 15) - 1];
+            node = succ[node];
+        }
+        visited[node >> 1] = 1;
+    }
+}
+
+// keep iff !(s < !s) (:305-306); also self-conjugate flag (s == !s)
+__global__ void k_keep(const char *seq, const unsigned long long *soff, uint64_t C, unsigned long long *keeplen, uint8_t *flags) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (uint64_t)gridDim.x * blockDim.x) {
+        const char *s = seq + soff[i];
+        const unsigned long long n = soff[i + 1] - soff[i];
+        int cmp = 0;  // sign of s - rc(s)
+        for (unsigned long long j = 0; j < n; ++j) {
+            const char a = s[j], b = s[n - 1 - j];
+            const char cb = b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : 'A';
+            if (a != cb) {
+                cmp = a < cb ? -1 : 1;
+                break;
+            }
+        }
+        const bool keep = n > 0 && cmp >= 0;
+        flags[i] = (uint8_t)((keep ? 1 : 0) | (cmp == 0 ? 2 : 0));
+        keeplen[i] = keep ? n : 0;
+    }
+}
+// kept candidates -> dense edge arrays
+__global__ void k_gather(const char *seq, const unsigned long long *soff, const unsigned long long *koff, const uint8_t *flags,
+                         const unsigned long long *eidx, const unsigned long long *cand, const uint32_t *last, uint64_t C,
+                         char *kseq, unsigned long long *eoff, uint32_t *estart, uint32_t *eend, uint8_t *eself) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (!(flags[i] & 1)) continue;
+        const unsigned long long e = eidx[i], n = soff[i + 1] - soff[i], o = koff[i];
+        const char *s = seq + soff[i];
+        for (unsigned long long j = 0; j < n; ++j) kseq[o + j] = s[j];
+        eoff[e] = o;
+        estart[e] = (uint32_t)(((cand[i] >> 3) << 1) | ((cand[i] >> 2) & 1));
+        eend[e] = last[i];
+        eself[e] = (flags[i] >> 1) & 1;
+    }
+}
+__global__ void k_keep_flag(const uint8_t *flags, uint64_t C, unsigned long long *one) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (uint64_t)gridDim.x * blockDim.x) one[i] = flags[i] & 1;
+}
+// k-mers left on perfect loops: non-junction and not on any extracted path (CollectLoops pass 1, :362-374)
+__global__ void k_loop_nodes(const uint8_t *mask, const uint8_t *visited, uint64_t D0, uint32_t *count, uint32_t *list, uint32_t cap) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x) {
+        if (!mask_junction(mask[r]) && !visited[r]) {
+            uint32_t p = atomicAdd(count, 1u);
+            if (p < cap) list[p] = (uint32_t)r;
+        }
+    }
+}
+template <int NW>
+__global__ void k_gather_kmers(const void *kmers_, const uint32_t *list, uint32_t n, void *out_) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    Rec<NW> *out = (Rec<NW> *)out_;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = kmers[list[i]];
+}
+
+}  // namespace smx

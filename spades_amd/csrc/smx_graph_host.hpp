@@ -1,0 +1,307 @@
+// spades_amd/csrc/smx_graph_host.hpp — host side of the construction path: the (rare, inherently serial) perfect-loop
+// collection, link records / vertex numbering, and the GFA / FASTA writers. Included by smx_api.hip.
+//
+// Reference (paths relative to /root/reference/src/common):
+//   CollectLoops / FindMinimalKMerInLoop / ConstructLoopFromVertex / SplitLoop
+//                                  assembly_graph/construction/debruijn_graph_constructor.hpp:252-293,359-397
+//   LinkRecord, ConstructGraph     same file :422-568 ; ids: assembly_graph/core/graph_core.hpp:234 (bias 3),
+//                                  out-edge lists sorted by id :199-202, IncomingEdges = conj(OutgoingEdges(conj v)) :625-628
+//   GFAWriter                      io/graph/gfa_writer.cpp:19-47,73-87,113-116
+//   unitig FASTA                   projects/spades_tools/gbuilder.cpp:191-200, io/reads/header_naming.hpp:15-21
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace smxh {
+
+struct GraphHost {
+    unsigned k = 0;
+    // edges in the reference's enumeration order (unbranching paths, then loops)
+    std::vector<uint64_t> eoff;    // [n_edges+1] offsets into seq
+    std::string seq;               // ACGT
+    std::vector<uint32_t> estart;  // node = 2*rank + rc of the first k-mer
+    std::vector<uint32_t> eend;    // node of the last k-mer
+    std::vector<uint8_t> eself;    // s == RC(s)
+    uint64_t n_paths = 0, n_loops = 0, n_vertices = 0, n_links = 0;
+    // link structure
+    struct Rec {
+        uint64_t hash_and_mask, edge;
+    };
+    std::vector<Rec> recs;
+    std::vector<size_t> vstart;  // first record of every vertex, in vertex-id order
+    size_t n_edges() const { return eoff.empty() ? 0 : eoff.size() - 1; }
+};
+
+inline char comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }
+inline std::string revcomp(const std::string &s) {
+    std::string r(s.size(), 'A');
+    for (size_t i = 0; i < s.size(); ++i) r[i] = comp(s[s.size() - 1 - i]);
+    return r;
+}
+
+// ---- perfect loops -----------------------------------------------------------------------------------
+// nodes: canonical k-mers (as strings) that are non-junction and lie on no extracted path, in k-mer-file order,
+// with their masks. All k-mers of a perfect loop are in this set, so the walk never leaves it.
+struct LoopNode {
+    uint32_t rank;
+    std::string kmer;
+    uint8_t mask;
+};
+
+inline uint8_t invert_byte(uint8_t a) {
+    uint8_t r = 0;
+    for (int i = 0; i < 8; ++i) {
+        r = (uint8_t)((r << 1) | (a & 1));
+        a >>= 1;
+    }
+    return r;
+}
+inline bool uniq4(unsigned m) { return m && !(m & (m - 1)); }
+inline unsigned uniq_nucl(unsigned m) { return m == 1 ? 0 : m == 2 ? 1 : m == 4 ? 2 : 3; }
+inline bool is_junction(uint8_t m) { return !uniq4(m & 15) || !uniq4((m >> 4) & 15); }
+
+class LoopCollector {
+    std::vector<LoopNode> &nodes_;
+    std::unordered_map<std::string, size_t> idx_;
+    unsigned k_;
+
+    // oriented mask of an oriented k-mer (InvertableStoring::get_value)
+    bool lookup(const std::string &x, size_t &i, bool &minimal) const {
+        std::string rc = revcomp(x);
+        minimal = !(rc < x);  // IsMinimal: x <= rc
+        auto it = idx_.find(minimal ? x : rc);
+        if (it == idx_.end()) return false;
+        i = it->second;
+        return true;
+    }
+    uint8_t mask_of(const std::string &x) const {
+        size_t i;
+        bool mn;
+        if (!lookup(x, i, mn)) return 0;
+        return mn ? nodes_[i].mask : invert_byte(nodes_[i].mask);
+    }
+    bool step_right(std::string &x) const {  // StepRightIfPossible(KeyWithHash&)
+        uint8_t m = mask_of(x);
+        if (uniq4(m & 15) && uniq4((m >> 4) & 15)) {
+            x = x.substr(1) + "ACGT"[uniq_nucl(m & 15)];
+            return true;
+        }
+        return false;
+    }
+    void isolate(const std::string &s) {  // RemoveSequence
+        for (size_t p = 0; p + k_ <= s.size(); ++p) {
+            size_t i;
+            bool mn;
+            if (lookup(s.substr(p, k_), i, mn)) nodes_[i].mask = 0;
+        }
+    }
+
+  public:
+    LoopCollector(std::vector<LoopNode> &nodes, unsigned k) : nodes_(nodes), k_(k) {
+        for (size_t i = 0; i < nodes.size(); ++i) idx_[nodes[i].kmer] = i;
+    }
+    uint32_t node_of(const std::string &x) const {  // 2*rank + rc
+        size_t i;
+        bool mn;
+        if (!lookup(x, i, mn)) return 0xFFFFFFFFu;
+        return (nodes_[i].rank << 1) | (mn ? 0u : 1u);
+    }
+    // appends loops (max(s, RC s) each) in the reference's order
+    void collect(std::vector<std::string> &out) {
+        const size_t n = nodes_.size();
+        for (size_t si = 0; si < n; ++si) {
+            const std::string st = nodes_[si].kmer;
+            if (is_junction(mask_of(st))) continue;  // removed by an earlier loop
+            // FindMinimalKMerInLoop: min over k-mers and their RCs by RtSeq operator< (nucleotide-lexicographic)
+            std::string minimal = std::min(st, revcomp(st));
+            std::string kh = st;
+            step_right(kh);
+            for (; kh != st; step_right(kh)) {
+                if (!(minimal < kh)) minimal = kh;
+                std::string r = revcomp(kh);
+                if (!(minimal < r)) minimal = r;
+            }
+            // ConstructLoopFromVertex: walk from `minimal` until the initial de-edge comes back
+            std::string s = minimal;
+            std::string cur = minimal;
+            step_right(cur);
+            s += cur.back();
+            const std::string i_start = minimal, i_end = cur;
+            std::string prev = cur;
+            for (;;) {
+                std::string nx = prev;
+                if (!step_right(nx)) break;
+                if (prev == i_start && nx == i_end) break;
+                s += nx.back();
+                prev = nx;
+            }
+            long split = -1;
+            for (size_t i = k_; i < s.size(); ++i) {
+                std::string kp = s.substr(i - k_, k_ + 1);
+                if (kp == revcomp(kp)) {
+                    split = (long)(i - k_);
+                    break;
+                }
+            }
+            std::vector<std::string> parts;
+            if (split < 0) parts.push_back(s);
+            else {  // SplitLoop
+                size_t pos = (size_t)split;
+                parts.push_back(s.substr(pos, k_ + 1));
+                parts.push_back(s.substr(pos + 1, (s.size() - k_) - (pos + 1)) + s.substr(0, pos + k_));
+            }
+            for (auto &p : parts) {
+                std::string rc = revcomp(p);
+                out.push_back(p < rc ? rc : p);
+                isolate(p);
+                isolate(rc);
+            }
+        }
+    }
+};
+
+// ---- link records + vertices ----------------------------------------------------------------------------
+inline void build_links(GraphHost &g) {
+    const uint64_t min_id = 3;
+    const size_t ne = g.n_edges();
+    g.recs.assign(ne * 2, GraphHost::Rec{0, 0});
+    for (size_t i = 0; i < ne; ++i) {
+        const uint64_t edge = min_id + 2 * i;
+        g.recs[2 * i] = {((uint64_t)(g.estart[i] >> 1) << 2) | ((uint64_t)(g.estart[i] & 1) << 1) | 1ull, edge};
+        if (g.eself[i]) g.recs[2 * i + 1] = {~0ull, 0};  // LinkRecord(): invalid
+        else g.recs[2 * i + 1] = {((uint64_t)(g.eend[i] >> 1) << 2) | ((uint64_t)(g.eend[i] & 1) << 1), edge};
+    }
+    auto eam = [](const GraphHost::Rec &r) { return (r.edge << 2) | (r.hash_and_mask & 3); };
+    std::sort(g.recs.begin(), g.recs.end(), [&](const GraphHost::Rec &a, const GraphHost::Rec &b) {
+        uint64_t ha = a.hash_and_mask >> 2, hb = b.hash_and_mask >> 2;
+        if (ha != hb) return ha < hb;
+        return eam(a) < eam(b);
+    });
+    g.vstart.clear();
+    for (size_t i = 0; i < g.recs.size(); ++i) {
+        const bool invalid = g.recs[i].hash_and_mask + 1 == 0 && g.recs[i].edge == 0;
+        if ((i == 0 || (g.recs[i].hash_and_mask >> 2) != (g.recs[i - 1].hash_and_mask >> 2)) && !invalid) g.vstart.push_back(i);
+    }
+    std::sort(g.vstart.begin(), g.vstart.end(), [&](size_t a, size_t b) { return eam(g.recs[a]) < eam(g.recs[b]); });
+    g.n_vertices = g.vstart.size();
+}
+
+// out-edge lists of v and conj(v) for vertex number vn (sorted by edge id)
+inline void vertex_edges(const GraphHost &g, size_t vn, uint64_t *outv, size_t &no, uint64_t *outc, size_t &nc) {
+    const uint64_t min_id = 3;
+    no = nc = 0;
+    const size_t i0 = g.vstart[vn];
+    const uint64_t h = g.recs[i0].hash_and_mask >> 2;
+    for (size_t j = i0; j < g.recs.size() && (g.recs[j].hash_and_mask >> 2) == h; ++j) {
+        const uint64_t e = g.recs[j].edge;
+        const size_t ei = (size_t)((e - min_id) >> 1);
+        const uint64_t ce = g.eself[ei] ? e : e + 1;
+        const bool is_rc = (g.recs[j].hash_and_mask >> 1) & 1, is_start = g.recs[j].hash_and_mask & 1;
+        if (is_start) {
+            if (!is_rc) outv[no++] = e; else outc[nc++] = e;
+        } else {
+            if (!is_rc) outc[nc++] = ce; else outv[no++] = ce;
+        }
+    }
+    std::sort(outv, outv + no);
+    std::sort(outc, outc + nc);
+}
+
+class BufWriter {
+    FILE *f_;
+    std::vector<char> buf_;
+    size_t n_ = 0;
+    bool ok_ = true;
+
+  public:
+    explicit BufWriter(FILE *f) : f_(f), buf_((size_t)8 << 20) {}
+    void add(const char *s, size_t n) {
+        if (n_ + n > buf_.size()) flush();
+        if (n > buf_.size()) {
+            ok_ &= fwrite(s, 1, n, f_) == n;
+            return;
+        }
+        memcpy(buf_.data() + n_, s, n);
+        n_ += n;
+    }
+    void add(const char *s) { add(s, strlen(s)); }
+    void num(uint64_t v) {
+        char t[24];
+        int n = snprintf(t, sizeof t, "%llu", (unsigned long long)v);
+        add(t, (size_t)n);
+    }
+    void flush() {
+        if (n_) ok_ &= fwrite(buf_.data(), 1, n_, f_) == n_;
+        n_ = 0;
+    }
+    bool ok() const { return ok_; }
+};
+
+// GFAWriter::WriteSegmentsAndLinks without coverage (DP:f:0, KC:i:0)
+inline bool write_gfa(GraphHost &g, FILE *f, const char *flavour_version) {
+    const uint64_t min_id = 3;
+    BufWriter w(f);
+    w.add("H\tsp:Z:");
+    w.add(flavour_version);
+    w.add("\n");
+    const size_t ne = g.n_edges();
+    for (size_t i = 0; i < ne; ++i) {
+        w.add("S\t");
+        w.num(min_id + 2 * i);
+        w.add("\t");
+        w.add(g.seq.data() + g.eoff[i], (size_t)(g.eoff[i + 1] - g.eoff[i]));
+        w.add("\tDP:f:0\tKC:i:0\n");
+    }
+    g.n_links = 0;
+    for (size_t vn = 0; vn < g.vstart.size(); ++vn) {
+        uint64_t outv[8], outc[8];
+        size_t no, nc;
+        vertex_edges(g, vn, outv, no, outc, nc);
+        for (size_t a = 0; a < nc; ++a) {
+            const uint64_t oc = outc[a];
+            const size_t ei = (size_t)((oc - min_id) >> 1);
+            const uint64_t inc = g.eself[ei] ? oc : (((oc - min_id) & 1) ? oc - 1 : oc + 1);
+            for (size_t c = 0; c < no; ++c) {
+                const uint64_t oe = outv[c];
+                const uint64_t cin = min_id + (((inc - min_id) >> 1) << 1), cout = min_id + (((oe - min_id) >> 1) << 1);
+                w.add("L\t");
+                w.num(cin);
+                w.add(inc == cin ? "\t+\t" : "\t-\t");
+                w.num(cout);
+                w.add(oe == cout ? "\t+\t" : "\t-\t");
+                w.num(g.k);
+                w.add("M\n");
+                ++g.n_links;
+            }
+        }
+    }
+    w.flush();
+    return w.ok();
+}
+
+// gbuilder --unitigs: ">EDGE_<i>_length_<len>" + sequence wrapped at 60 (gbuilder.cpp:191-200)
+inline bool write_unitigs_fasta(const GraphHost &g, FILE *f) {
+    BufWriter w(f);
+    const size_t ne = g.n_edges();
+    for (size_t i = 0; i < ne; ++i) {
+        const uint64_t len = g.eoff[i + 1] - g.eoff[i];
+        w.add(">EDGE_");
+        w.num(i + 1);
+        w.add("_length_");
+        w.num(len);
+        w.add("\n");
+        for (uint64_t p = 0; p < len; p += 60) {
+            w.add(g.seq.data() + g.eoff[i] + p, (size_t)std::min<uint64_t>(60, len - p));
+            w.add("\n");
+        }
+    }
+    w.flush();
+    return w.ok();
+}
+
+}  // namespace smxh

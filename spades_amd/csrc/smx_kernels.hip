@@ -429,7 +429,8 @@ __device__ __forceinline__ uint32_t lds_insertion_unique(uint64_t *s, uint32_t b
 template <int NW, int LPT>
 __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned long long *off, uint32_t nbins, uint32_t cap,
                                                     unsigned K, unsigned sub_shift, unsigned sub_bits,
-                                                    unsigned long long *ucount, uint32_t *biglist, uint32_t *bigcount, int dbg) {
+                                                    unsigned long long *ucount, uint32_t *biglist, uint32_t *bigcount, int dbg,
+                                                    const uint32_t *list, const uint32_t *listcount) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     __shared__ uint32_t scr[BLK / 64 + 2];
     __shared__ uint32_t maxc;
@@ -437,7 +438,9 @@ __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned lo
     uint32_t *cnt = (uint32_t *)(lds64 + (size_t)cap * NW);  // [S+1] sub-bin offsets
     uint32_t *dcn = cnt + S + 1;                             // [S] distinct per sub-bin -> output offsets
     uint8_t *flg = (uint8_t *)(dcn + S);                     // [cap] first-occurrence flags
-    for (uint32_t b = blockIdx.x; b < nbins; b += gridDim.x) {
+    const uint32_t nwork = list ? *listcount : nbins;
+    for (uint32_t bi = blockIdx.x; bi < nwork; bi += gridDim.x) {
+        const uint32_t b = list ? list[bi] : bi;
         const uint64_t o = off[b];
         const uint64_t n64 = off[b + 1] - o;
         if (n64 == 0) {
@@ -557,6 +560,150 @@ __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned lo
         uint32_t u = lds_unique_store<NW>(lds64, n, g, scr);
         if (threadIdx.x == 0) ucount[b] = u;
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------- wave-level leaf sort
+template <int NW>
+__device__ __forceinline__ Rec<NW> rec_shfl_xor(const Rec<NW> &x, int m) {
+    Rec<NW> y;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) y.w[w] = __shfl_xor((unsigned long long)x.w[w], m, 64);
+    return y;
+}
+template <int NW>
+__device__ __forceinline__ Rec<NW> rec_shfl_up1(const Rec<NW> &x) {
+    Rec<NW> y;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) y.w[w] = __shfl_up((unsigned long long)x.w[w], 1, 64);
+    return y;
+}
+template <int NW>
+__device__ __forceinline__ Rec<NW> rec_readlane63(const Rec<NW> &x) {
+    Rec<NW> y;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) y.w[w] = __shfl((unsigned long long)x.w[w], 63, 64);
+    return y;
+}
+
+// Bitonic network over 64*R records held striped in registers (element e = r*64 + lane). Compare-exchange
+// partners at distance < 64 live in another lane (cross-lane shuffle), at distance >= 64 in another register
+// of the same lane. No LDS, no barriers.
+template <int NW, int R>
+__device__ __forceinline__ void wave_bitonic(Rec<NW> (&x)[R]) {
+    const unsigned lane = threadIdx.x & 63;
+#pragma unroll
+    for (unsigned k = 2; k <= 64u * R; k <<= 1) {
+#pragma unroll
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const unsigned dj = j >> 6;
+#pragma unroll
+                for (unsigned r = 0; r < (unsigned)R; ++r) {
+                    if ((r & dj) == 0) {
+                        const unsigned r2 = r | dj;
+                        const bool asc = (((r << 6) | lane) & k) == 0;
+                        const bool sw = asc ? rec_less<NW>(x[r2], x[r]) : rec_less<NW>(x[r], x[r2]);
+                        if (sw) {
+                            Rec<NW> t = x[r];
+                            x[r] = x[r2];
+                            x[r2] = t;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (unsigned r = 0; r < (unsigned)R; ++r) {
+                    Rec<NW> y = rec_shfl_xor<NW>(x[r], (int)j);
+                    const bool lower = (lane & j) == 0;
+                    const bool asc = (((r << 6) | lane) & k) == 0;
+                    const bool keep_min = lower == asc;
+                    const bool take = keep_min ? rec_less<NW>(y, x[r]) : rec_less<NW>(x[r], y);
+                    if (take) x[r] = y;
+                }
+            }
+        }
+    }
+}
+
+// sort + unique + in-place store of one leaf of n <= 64*R records by one wave; returns the unique count.
+// Pads are all-ones records: indistinguishable from a real all-ones record, which is harmless because the first n
+// sorted positions then still hold exactly the multiset of the real records.
+template <int NW, int R>
+__device__ __forceinline__ uint32_t wave_leaf(Rec<NW> *g, uint32_t n) {
+    const unsigned lane = threadIdx.x & 63;
+    Rec<NW> x[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t e = (uint32_t)r * 64 + lane;
+        if (e < n) x[r] = g[e];
+        else {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) x[r].w[w] = ~0ull;
+        }
+    }
+    wave_bitonic<NW, R>(x);
+    uint32_t base = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t e = (uint32_t)r * 64 + lane;
+        Rec<NW> prev = rec_shfl_up1<NW>(x[r]);
+        if (r > 0) {
+            Rec<NW> p63 = rec_readlane63<NW>(x[r - 1 < 0 ? 0 : r - 1]);
+            if (lane == 0) prev = p63;
+        }
+        const bool flag = e < n && (e == 0 || !rec_eq<NW>(x[r], prev));
+        const unsigned long long bal = __ballot(flag);
+        if (flag) g[base + __popcll(bal & ((1ull << lane) - 1))] = x[r];
+        base += (uint32_t)__popcll(bal);
+    }
+    return base;
+}
+
+// One WAVE per fine bin (persistent waves). Leaves of <= 256 records are finished in registers; larger ones are
+// queued for the workgroup-level LDS kernel (<= cap) or the merge kernel (> cap).
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_sort_wave(void *buf, const unsigned long long *off, uint32_t nbins, uint32_t cap,
+                                                   unsigned long long *ucount, uint32_t *medlist, uint32_t *medcount,
+                                                   uint32_t *biglist, uint32_t *bigcount) {
+    const unsigned lane = threadIdx.x & 63;
+    const uint32_t wid = (blockIdx.x * BLK + threadIdx.x) >> 6, nwaves = (gridDim.x * BLK) >> 6;
+    for (uint32_t b = wid; b < nbins; b += nwaves) {
+        const uint64_t o = off[b];
+        const uint64_t n64 = off[b + 1] - o;
+        if (n64 == 0) {
+            if (lane == 0) ucount[b] = 0;
+            continue;
+        }
+        if (n64 > 256 || n64 > cap) {
+            if (lane == 0) {
+                if (n64 > cap) biglist[atomicAdd(bigcount, 1u)] = b;
+                else medlist[atomicAdd(medcount, 1u)] = b;
+            }
+            continue;
+        }
+        const uint32_t n = (uint32_t)n64;
+        Rec<NW> *g = (Rec<NW> *)buf + o;
+        uint32_t u;
+        if (n <= 64) u = wave_leaf<NW, 1>(g, n);
+        else if (n <= 128) u = wave_leaf<NW, 2>(g, n);
+        else u = wave_leaf<NW, 4>(g, n);
+        if (lane == 0) ucount[b] = u;
+    }
+}
+
+// fine bins -> final output, one wave per bin (bins are contiguous in output order)
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_compact_wave(const void *buf, const unsigned long long *off, const unsigned long long *ucount,
+                                                      const unsigned long long *uoff, uint32_t nbins, void *out) {
+    const unsigned lane = threadIdx.x & 63;
+    const uint32_t wid = (blockIdx.x * BLK + threadIdx.x) >> 6, nwaves = (gridDim.x * BLK) >> 6;
+    for (uint32_t b = wid; b < nbins; b += nwaves) {
+        const uint32_t u = (uint32_t)ucount[b];
+        if (u == 0) continue;
+        const Rec<NW> *src = (const Rec<NW> *)buf + off[b];
+        Rec<NW> *dst = (Rec<NW> *)out + uoff[b];
+        for (uint32_t i = lane; i < u; i += 64) dst[i] = src[i];
     }
 }
 

@@ -1,0 +1,69 @@
+"""Host-side mirror of the standalone graph builder (projects/spades_tools/gbuilder.cpp:112-245) over
+libspades_mi355x.so: reads -> extension index -> unbranching paths + perfect loops -> graph -> GFA / unitig FASTA.
+
+`threads` plays the role of the reference's -t ONLY as an input of the output order (bucket count 10*threads,
+common/kmer_index/extension_index/kmer_extension_index_builder.hpp:75); it does not control parallelism here.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .kmercount import Context, ReadKMerSplitter, SmxError, _chk
+
+
+class GraphBuilder:
+    def __init__(self, k: int, threads: int = 1, ctx: Optional[Context] = None):
+        self.k, self.threads = int(k), int(threads)
+        self.reads = ReadKMerSplitter(self.k + 1, "B", ctx)
+        self.ctx = self.reads.ctx
+        self._info = None
+
+    # -- input (same entry points as the counter's splitter) --
+    def push_back_reads(self, reads: Sequence[str]):
+        self.reads.push_back_reads(reads)
+
+    def push_back_packed(self, words, start, length):
+        self.reads.push_back_packed(words, start, length)
+
+    def push_back_device(self, d_words, n_words, d_start, d_len, n_reads):
+        self.reads.push_back_device(d_words, n_words, d_start, d_len, n_reads)
+
+    # -- steps 1-3 of gbuilder.cpp --
+    def build(self):
+        h = self.ctx._h
+        _chk(h, self.ctx.lib.smx_build_graph(h, self.k, 10 * self.threads))
+        info = (C.c_uint64 * 8)()
+        _chk(h, self.ctx.lib.smx_graph_info(h, info))
+        self._info = dict(n_kpomers=info[0], n_kmers=info[1], n_unitigs=info[2], n_loops=info[3], n_vertices=info[4],
+                          n_links=info[5], unitig_bases=info[6], words=info[7])
+        return self._info
+
+    def info(self):
+        info = (C.c_uint64 * 8)()
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_info(self.ctx._h, info))
+        self._info.update(n_links=info[5])
+        return self._info
+
+    def kmers(self):
+        n, nw = self._info["n_kmers"], self._info["words"]
+        rec = np.empty((n, nw), dtype=np.uint64)
+        masks = np.empty(n, dtype=np.uint8)
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_copy_kmers(self.ctx._h, rec.ctypes.data_as(C.c_void_p), masks.ctypes.data_as(C.c_void_p)))
+        return rec, masks
+
+    def unitigs(self) -> List[str]:
+        n = self._info["n_unitigs"]
+        off = np.zeros(n + 1, dtype=np.uint64)
+        seq = np.empty(max(self._info["unitig_bases"], 1), dtype=np.uint8)
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_copy_unitigs(self.ctx._h, off.ctypes.data_as(C.POINTER(C.c_uint64)), seq.ctypes.data_as(C.c_void_p)))
+        b = seq.tobytes()
+        return [b[int(off[i]):int(off[i + 1])].decode() for i in range(n)]
+
+    # -- step 4: outputs --
+    def write_gfa(self, path: str, flavour_version: str = "SPAdes-4.3.0-dev"):
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_write_gfa(self.ctx._h, path.encode(), flavour_version.encode()))
+
+    def write_unitigs(self, path: str):
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_write_unitigs(self.ctx._h, path.encode()))

@@ -1,0 +1,92 @@
+// spades_amd/tools/gbuilder_main.cpp — drop-in CLI for `spades-gbuilder`
+// (reference: projects/spades_tools/gbuilder.cpp:66-245; docs/standalone.md) over libspades_mi355x.so.
+//   spades-gbuilder-mi355x <fasta/fastq[.gz]> <out> [-k 21] [-t N] [-tmp-dir d] [-b n] [--unitigs|--gfa]
+// -t selects the bucket count 10*t and therefore the unitig/segment numbering of the reference run being
+// reproduced (SURVEY.md finding 3); default = the reference's default (cores/2+1 is host dependent, so 1 here).
+// Not in this build: YAML datasets, -c (coverage), --fastg, --spades.
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/smx.h"
+#include "read_input.hpp"
+
+int main(int argc, char **argv) {
+    unsigned k = 21, nthreads = 1;
+    std::string file, outfile;
+    enum { UNITIGS, GFA } mode = UNITIGS;
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto need = [&]() -> const char * {
+            if (i + 1 >= argc) {
+                fprintf(stderr, "Invalid command line arguments\n");
+                exit(SMX_INVALID_PARAMETER);
+            }
+            return argv[++i];
+        };
+        if (a == "-k") k = (unsigned)atoi(need());
+        else if (a == "-t") nthreads = (unsigned)atoi(need());
+        else if (a == "-tmp-dir" || a == "-b") (void)need();
+        else if (a == "--unitigs" || a == "-unitigs") mode = UNITIGS;
+        else if (a == "--gfa" || a == "-gfa") mode = GFA;
+        else if (a == "-c" || a == "--fastg" || a == "-fastg" || a == "--spades" || a == "-spades") {
+            fprintf(stderr, "%s is not supported by this build\n", a.c_str());
+            return SMX_INVALID_PARAMETER;
+        } else if (!a.empty() && a[0] == '-') {
+            fprintf(stderr, "Invalid command line arguments\n");
+            return SMX_INVALID_PARAMETER;
+        } else pos.push_back(a);
+    }
+    if (pos.size() != 2) {
+        fprintf(stderr, "usage: %s <dataset description (in YAML) or input FASTA file> <output filename> [-k value] [-t value] "
+                        "[-tmp-dir dir] [-b value] [--unitigs|--gfa]\n", argv[0]);
+        return SMX_INVALID_PARAMETER;
+    }
+    file = pos[0];
+    outfile = pos[1];
+    if (k < 1) { fprintf(stderr, "k-mer size %u is too low\n", k); return SMX_INVALID_PARAMETER; }
+    if (k >= 128) { fprintf(stderr, "k-mer size %u is too high\n", k); return SMX_INVALID_PARAMETER; }
+    if (k % 2 == 0) { fprintf(stderr, "k-mer size must be odd\n"); return SMX_INVALID_PARAMETER; }
+    smx_ctx *ctx = nullptr;
+    if (int rc = smx_create(&ctx, 0, 0)) {
+        fprintf(stderr, "No usable MI355X device (smx_create -> %d)\n", rc);
+        return rc;
+    }
+    printf("K-mer length set to %u\n", k);
+    int rc = 0;
+    try {
+        smxtool::ReadBatch batch;
+        bool ok = smxtool::for_each_sequence(file, [&](const std::string &s) {
+            batch.add(s);
+            if (batch.bases.size() > ((size_t)1 << 30) && !rc) {
+                rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
+                batch.clear();
+            }
+        });
+        if (!ok) {
+            fprintf(stderr, "Dataset description file: %s does not exist or is not a valid YAML file\n", file.c_str());
+            smx_destroy(ctx);
+            return SMX_INPUT_FILE_NOT_FOUND;
+        }
+        if (!rc) rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
+        if (!rc) rc = smx_build_graph(ctx, k, 10 * nthreads);
+        if (!rc) {
+            uint64_t info[8];
+            smx_graph_info(ctx, info);
+            printf("Extracting unbranching paths finished. %llu sequences extracted\n", (unsigned long long)(info[2] - info[3]));
+            printf("Collecting perfect loops finished. %llu loops collected\n", (unsigned long long)info[3]);
+            printf("Saving %s to %s\n", mode == GFA ? "graph" : "unitigs", outfile.c_str());
+            rc = mode == GFA ? smx_graph_write_gfa(ctx, outfile.c_str(), "SPAdes-4.3.0-dev") : smx_graph_write_unitigs(ctx, outfile.c_str());
+        }
+        if (rc) fprintf(stderr, "%s\n", smx_last_error(ctx));
+    } catch (const std::string &s) {
+        fprintf(stderr, "%s\n", s.c_str());
+        rc = EINTR;
+    }
+    smx_destroy(ctx);
+    if (!rc) printf("SPAdes standalone graph builder finished\n");
+    return rc;
+}

@@ -1,0 +1,105 @@
+// spades_amd/tools/kmercount_main.cpp — drop-in CLI for `spades-kmercount`
+// (reference: projects/spades_tools/kmercount.cpp:134-229; docs/standalone.md:5-45) over libspades_mi355x.so.
+//   spades-kmercount-mi355x [-k 21] [-t N] [-w dir] [-b bytes] files...   ->  <dir>/final_kmers
+// -t and -b are accepted for command-line compatibility; the result does not depend on them (SURVEY.md finding 3).
+// Exit codes follow common/utils/logger/error_codes.hpp (64-68); -d <yaml> is not supported by this clone.
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/smx.h"
+#include "read_input.hpp"
+
+static void usage(const char *a0) {
+    printf("SYNOPSIS\n        %s [-k <value>] [-t <value>] [-w <dir>] [-b <value>] [-h] [<input files>...]\n\n"
+           "DESCRIPTION\n        SPAdes k-mer counting engine (MI355X)\n\n"
+           "        Output: <output_dir>/final_kmers - unordered set of kmers in binary format. Kmers from both forward and\n"
+           "        reverse-complementary reads are taken into account.\n", a0);
+}
+
+int main(int argc, char **argv) {
+    unsigned K = 21, nthreads = 1;
+    std::string workdir = ".";
+    std::vector<std::string> input;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto need = [&](const char *what) -> const char * {
+            if (i + 1 >= argc) {
+                fprintf(stderr, "Invalid command line arguments: %s needs a value\n", what);
+                exit(SMX_INVALID_PARAMETER);
+            }
+            return argv[++i];
+        };
+        if (a == "-k" || a == "--kmer") K = (unsigned)atoi(need("-k"));
+        else if (a == "-t" || a == "--threads") nthreads = (unsigned)atoi(need("-t"));
+        else if (a == "-w" || a == "--workdir") workdir = need("-w");
+        else if (a == "-b" || a == "--bufsize") (void)need("-b");
+        else if (a == "-d" || a == "--dataset") {
+            fprintf(stderr, "-d <yaml> is not supported by this build; pass the read files directly\n");
+            return SMX_INVALID_PARAMETER;
+        } else if (a == "-h" || a == "--help") {
+            usage(argv[0]);
+            return 0;
+        } else if (!a.empty() && a[0] == '-') {
+            usage(argv[0]);
+            fprintf(stderr, "Invalid command line arguments\n");
+            return SMX_INVALID_PARAMETER;
+        } else input.push_back(a);
+    }
+    (void)nthreads;
+    if (input.empty()) {
+        fprintf(stderr, "No input files were specified\n");
+        return SMX_INVALID_PARAMETER;
+    }
+    smx_ctx *ctx = nullptr;
+    if (int rc = smx_create(&ctx, 0, 0)) {
+        fprintf(stderr, "No usable MI355X device (smx_create -> %d)\n", rc);
+        return rc;
+    }
+    printf("K-mer length set to %u\n", K);
+    try {
+        for (const auto &file : input) {
+            printf("Processing \"%s\"\n", file.c_str());
+            smxtool::ReadBatch batch;
+            int rc = 0;
+            bool ok = smxtool::for_each_sequence(file, [&](const std::string &s) {
+                batch.add(s);
+                if (batch.bases.size() > ((size_t)1 << 30) && !rc) {
+                    rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
+                    batch.clear();
+                }
+            });
+            if (!ok) {
+                fprintf(stderr, "File %s doesn't exist or can't be read!\n", file.c_str());
+                smx_destroy(ctx);
+                return SMX_INPUT_FILE_NOT_FOUND;
+            }
+            if (!rc) rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
+            if (rc) throw std::string(smx_last_error(ctx));
+        }
+        if (int rc = smx_count(ctx, K, SMX_MODE_ALL, 16)) {  // 16 buckets: kmercount.cpp:220
+            fprintf(stderr, "%s\n", smx_last_error(ctx));
+            smx_destroy(ctx);
+            return rc;
+        }
+        uint64_t n = 0;
+        smx_count_info(ctx, &n, nullptr, nullptr);
+        printf("K-mer counting done. There are %llu kmers in total.\n", (unsigned long long)n);
+        std::string out = workdir + "/final_kmers";
+        if (int rc = smx_write_final_kmers(ctx, out.c_str())) {
+            fprintf(stderr, "%s\n", smx_last_error(ctx));
+            smx_destroy(ctx);
+            return rc;
+        }
+        printf("K-mer counting done, kmers saved to \"%s\"\n", out.c_str());
+    } catch (const std::string &s) {
+        fprintf(stderr, "%s\n", s.c_str());
+        smx_destroy(ctx);
+        return EINTR;  // kmercount.cpp:226-229
+    }
+    smx_destroy(ctx);
+    return 0;
+}

@@ -1,0 +1,57 @@
+"""GPU: the C++ CLI clones (spades_amd/tools) behave like spades-kmercount / spades-gbuilder on the same files:
+same output bytes (reference goldens), same exit codes (src/test/integration/test_error_codes.py:107-272)."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT, load_manifest, read_lines
+
+pytestmark = pytest.mark.gpu
+TOOLS = os.path.join(ROOT, "spades_amd", "tools")
+KC = os.path.join(TOOLS, "spades-kmercount-mi355x")
+GB = os.path.join(TOOLS, "spades-gbuilder-mi355x")
+
+
+def _fastq(path, reads, gz=False):
+    op = gzip.open if gz else open
+    with op(path, "wt") as f:
+        for i, r in enumerate(reads):
+            if r:
+                f.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n")
+
+
+def test_kmercount_cli_matches_reference_bytes(tmp_path):
+    cases = [c for c in load_manifest()["cases"] if c["kind"] == "count" and c.get("file") and c["mode"] == "A" and c["num_buckets"] == 16]
+    reads = read_lines("reads_tiny.txt")
+    fq = str(tmp_path / "r.fq.gz")
+    _fastq(fq, reads, gz=True)
+    for c in cases:
+        wd = tmp_path / f"w{c['K']}"
+        wd.mkdir()
+        subprocess.check_call([KC, "-k", str(c["K"]), "-t", "3", "-w", str(wd), fq], stdout=subprocess.DEVNULL)
+        assert open(wd / "final_kmers", "rb").read() == open(os.path.join(GOLDEN, c["file"]), "rb").read()
+
+
+def test_gbuilder_cli_matches_reference_gfa(tmp_path):
+    for c in [c for c in load_manifest()["cases"] if c["kind"] == "graph" and c["file"] and c["reads"] in ("reads_small.txt", "reads_loop.txt")]:
+        reads = [r for r in read_lines(c["reads"]) if r]
+        fa = str(tmp_path / "r.fa")
+        with open(fa, "w") as f:
+            for i, r in enumerate(reads):
+                f.write(f">r{i}\n{r}\n")
+        out = str(tmp_path / "g.gfa")
+        subprocess.check_call([GB, fa, out, "-k", str(c["K"]), "-t", str(c["threads"]), "--gfa"], stdout=subprocess.DEVNULL)
+        assert open(out).read() == open(os.path.join(GOLDEN, c["file"])).read()
+
+
+def test_cli_exit_codes(tmp_path):
+    # error_codes.hpp:14-20 — 65 file not found, 67 invalid parameter
+    assert subprocess.call([KC, "-k", "21", "-w", str(tmp_path), "/nonexistent.fq"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 65
+    assert subprocess.call([KC, "-k", "21"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 67
+    assert subprocess.call([GB, "/nonexistent.fa", str(tmp_path / "o"), "-k", "21"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 65
+    fa = tmp_path / "r.fa"
+    fa.write_text(">a\nACGTACGTACGTACGTACGTACGTACGT\n")
+    assert subprocess.call([GB, str(fa), str(tmp_path / "o"), "-k", "22"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 67
+    assert subprocess.call([GB, str(fa), str(tmp_path / "o"), "-k", "129"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 67

@@ -77,6 +77,16 @@ def test_multilevel_and_oversized_bins(opts, K, mode, nb):
     assert rec.shape == ref.shape and (rec == ref).all()
 
 
+@pytest.mark.parametrize("K,mode,nb", [(21, "A", 16), (55, "B", 30), (77, "A", 16), (127, "B", 10)])
+def test_medium_leaves_take_the_lds_kernel(K, mode, nb):
+    """few bins with 257..cap records each -> the workgroup-level LDS counting-split kernel."""
+    from oracle import oracle
+    reads = _synth(11, 3000, 260, 150)
+    ref, rs = oracle.count(reads, K, mode, nb)
+    rec, sizes = _count(reads, K, mode, nb, {"s1": 2, "s2": 0})
+    assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
+
+
 def test_edge_inputs():
     from oracle import oracle
     for reads in ([], [""], ["N" * 50], ["ACG"], ["A" * 21], ["A" * 20 + "N" + "C" * 25, "acgtacgtacgtacgtacgtacgtacgt"]):

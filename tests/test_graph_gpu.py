@@ -1,0 +1,99 @@
+"""GPU parity: de Bruijn construction through the C ABI vs the real spades-gbuilder goldens and the oracle.
+Bit-exact: canonical k-mer file, InOutMask bytes, unitig list in the reference's order, GFA text."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_manifest, read_lines
+
+pytestmark = pytest.mark.gpu
+
+GCASES = [c for c in load_manifest()["cases"] if c["kind"] == "graph"]
+
+
+def _build(reads, k, threads, tmp_path, opts=None):
+    from spades_amd.gbuilder import GraphBuilder
+    gb = GraphBuilder(k, threads)
+    for key, v in (opts or {}).items():
+        gb.ctx.set_option(key, v)
+    gb.push_back_reads(reads)
+    info = gb.build()
+    out = os.path.join(str(tmp_path), "g.gfa")
+    gb.write_gfa(out)
+    res = dict(info=gb.info(), gfa=open(out).read(), unitigs=gb.unitigs(), kmers=gb.kmers())
+    gb.ctx.close()
+    return res
+
+
+@pytest.mark.parametrize("case", GCASES, ids=lambda c: f"{c['reads'][6:-4]}-k{c['K']}-t{c['threads']}")
+def test_gfa_matches_spades_gbuilder(case, tmp_path):
+    reads = [r for r in read_lines(case["reads"]) if r]
+    r = _build(reads, case["K"], case["threads"], tmp_path)
+    assert r["gfa"].count("\nS\t") == case["n_segments"] and r["gfa"].count("\nL\t") == case["n_links"]
+    assert hashlib.md5(r["gfa"].encode()).hexdigest() == case["md5"]
+    if case["file"]:
+        assert r["gfa"] == open(os.path.join(GOLDEN, case["file"])).read()
+
+
+def _synth(seed, glen, n, L, err=0.01, nrate=0.002, circ=False):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, glen)
+    if circ:
+        g = np.concatenate([g, g[:L]])
+    reads = []
+    for _ in range(n):
+        p = int(rng.integers(0, len(g) - L + 1))
+        r = g[p:p + L].copy()
+        e = rng.random(L) < err
+        r[e] = (r[e] + rng.integers(1, 4, int(e.sum()))) % 4
+        s = np.array(list("ACGT"))[r]
+        s[rng.random(L) < nrate] = "N"
+        reads.append("".join(s))
+    return reads
+
+
+@pytest.mark.parametrize("k,threads", [(21, 1), (21, 8), (31, 2), (33, 1), (55, 3), (63, 1), (65, 2), (77, 1), (127, 1), (5, 1), (1, 1)])
+def test_graph_vs_oracle_seeded(k, threads, tmp_path):
+    from oracle import oracle
+    reads = _synth(50 + k, 8000, 1500, 150) + _synth(9, 600, 80, 100, err=0.0, nrate=0.0, circ=True)
+    ref = oracle.build_graph(reads, k, 10 * threads)
+    r = _build(reads, k, threads, tmp_path)
+    km, masks = r["kmers"]
+    assert km.shape == ref["kmers"].shape and (km == ref["kmers"]).all()
+    assert (masks == ref["masks"]).all()
+    assert r["unitigs"] == ref["unitigs"]
+    assert r["info"]["n_loops"] == ref["n_loops"]
+    assert r["gfa"] == ref["gfa"]
+    assert r["info"]["n_vertices"] == ref["n_vertices"] and r["info"]["n_links"] == ref["n_links"]
+
+
+def test_graph_small_leaves_and_edge_inputs(tmp_path):
+    from oracle import oracle
+    reads = _synth(3, 3000, 600, 120)
+    ref = oracle.build_graph(reads, 21, 30)
+    r = _build(reads, 21, 3, tmp_path, {"leaf_cap": 16})
+    assert r["gfa"] == ref["gfa"]
+    for rd in ([], ["ACGT"], ["A" * 60], ["ACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCA"]):
+        ref = oracle.build_graph(rd, 21, 10)
+        r = _build(rd, 21, 1, tmp_path)
+        assert r["gfa"] == ref["gfa"] and r["unitigs"] == ref["unitigs"]
+
+
+def test_unitigs_fasta_and_errors(tmp_path):
+    from spades_amd import SmxError
+    from spades_amd.gbuilder import GraphBuilder
+    gb = GraphBuilder(21, 1)
+    gb.push_back_reads([r for r in read_lines("reads_small.txt") if r])
+    info = gb.build()
+    out = os.path.join(str(tmp_path), "u.fa")
+    gb.write_unitigs(out)
+    lines = open(out).read().split("\n")
+    us = gb.unitigs()
+    assert lines[0] == f">EDGE_1_length_{len(us[0])}" and lines[1] == us[0][:60]
+    assert sum(1 for l in lines if l.startswith(">")) == info["n_unitigs"]
+    bad = GraphBuilder(22, 1, gb.ctx)
+    with pytest.raises(SmxError) as e:
+        bad.build()
+    assert e.value.code == 67  # "k-mer size must be odd" -> InvalidParameter (gbuilder.cpp:134-135)
