@@ -9,7 +9,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
+#include <cstdlib>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace smx;
@@ -44,12 +47,15 @@ struct smx_ctx {
     unsigned nw = 0, K = 0, num_buckets = 0;
     std::vector<uint64_t> bucket_off;
     // tuning / test hooks
-    int64_t opt_leaf_cap = 0, opt_s1 = -1, opt_s2 = -1, opt_dbg = 0;
+    int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_dbg = 0;
     // timings
     std::vector<Timing> timings;
     std::vector<std::string> tnames, xnames;  // last count stages / last extract_partition stages
     std::vector<float> tms, xms;
     std::vector<void *> temps;  // allocations of the pipeline in flight
+    // grow-only device arena: blocks are recycled across calls (hipMalloc/hipFree of tens of GB stalls for seconds)
+    std::vector<std::pair<void *, size_t>> arena_free;  // cached blocks
+    std::unordered_map<void *, size_t> arena_size;      // every live or cached block -> bytes
     // construction state (smx_build_graph)
     void *g_kpo = nullptr, *g_kmers = nullptr;
     uint8_t *g_mask = nullptr;
@@ -80,13 +86,61 @@ int fail(smx_ctx *c, int code, const char *fmt, ...) {
                         "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);           \
     } while (0)
 
+void *arena_get(smx_ctx *ctx, size_t bytes) {
+    // best fit among cached blocks that waste at most 2x
+    size_t best = (size_t)-1, bi = 0;
+    for (size_t i = 0; i < ctx->arena_free.size(); ++i) {
+        size_t sz = ctx->arena_free[i].second;
+        if (sz >= bytes && sz <= 2 * bytes + (1u << 20) && sz < best) {
+            best = sz;
+            bi = i;
+        }
+    }
+    if (best != (size_t)-1) {
+        void *p = ctx->arena_free[bi].first;
+        ctx->arena_free.erase(ctx->arena_free.begin() + bi);
+        return p;
+    }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {  // release the cache and retry once
+        (void)hipGetLastError();
+        for (auto &b : ctx->arena_free) {
+            ctx->arena_size.erase(b.first);
+            (void)hipFree(b.first);
+        }
+        ctx->arena_free.clear();
+        e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    ctx->arena_size[q] = bytes;
+    return q;
+}
+void arena_put(smx_ctx *ctx, void *p) {
+    if (!p) return;
+    auto it = ctx->arena_size.find(p);
+    if (it == ctx->arena_size.end()) {
+        (void)hipFree(p);
+        return;
+    }
+    ctx->arena_free.emplace_back(p, it->second);
+}
+void arena_release(smx_ctx *ctx) {
+    for (auto &b : ctx->arena_free) {
+        ctx->arena_size.erase(b.first);
+        (void)hipFree(b.first);
+    }
+    ctx->arena_free.clear();
+}
+
 template <typename T>
 int dalloc(smx_ctx *ctx, T **p, size_t count, bool temp = true) {
-    void *q = nullptr;
     size_t bytes = std::max<size_t>(count * sizeof(T), 256);
-    hipError_t e = hipMalloc(&q, bytes);
-    if (e != hipSuccess)
-        return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    void *q = arena_get(ctx, bytes);
+    if (!q) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "device allocation of %zu bytes failed", bytes);
     if (temp) ctx->temps.push_back(q);
     *p = (T *)q;
     return 0;
@@ -94,9 +148,27 @@ int dalloc(smx_ctx *ctx, T **p, size_t count, bool temp = true) {
 
 void free_temps(smx_ctx *ctx, void *keep = nullptr) {
     for (void *p : ctx->temps)
-        if (p != keep) (void)hipFree(p);
+        if (p != keep) arena_put(ctx, p);
     ctx->temps.clear();
 }
+
+double wall_now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+struct WallTrace {  // SMX_DEBUG=1: host wall-clock per pipeline section (includes allocation / implicit syncs)
+    bool on;
+    double t;
+    WallTrace() : on(getenv("SMX_DEBUG") != nullptr), t(wall_now()) {}
+    void mark(smx_ctx *ctx, const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        double n = wall_now();
+        fprintf(stderr, "[smx] %-14s %8.2f ms\n", what, (n - t) * 1e3);
+        t = n;
+    }
+};
 
 void tbegin(smx_ctx *ctx, const char *name) {
     Timing t;
@@ -157,10 +229,11 @@ int scan_u64(smx_ctx *ctx, const unsigned long long *in, unsigned long long *out
 template <int NW>
 struct Tune {
     static constexpr int RPT = (NW <= 2) ? 16 : 8;                        // records per thread in a scatter tile
-    static constexpr uint32_t CAP = (NW == 1) ? 4096 : (NW == 2 ? 2048 : 1024);  // LDS-sortable leaf
+    static constexpr uint32_t CAP = (NW == 1) ? 4096 : (NW == 2 ? 2048 : 1024);  // LDS-sortable leaf (larger caps measured slower)
     static constexpr int LPT = CAP / BLK;
-    // fan-out per MSD level: runs of >= 16 records (>= 128 B) per bin and tile keep the scattered
-    // writes at streaming speed and the reservation atomics at <= 1/16 per record (tools/ubench.hip)
+    // fan-out per MSD level: runs of >= 16 records (>= 256 B) per bin and tile on average keep the scattered
+    // writes at streaming speed and the reservation atomics at <= 1/16 per record (tools/ubench.hip);
+    // 512 bins (128-B average runs) measured 1.6x slower on the level-1 scatter
     static constexpr uint32_t FMAX = RPT * BLK / 16;
 };
 
@@ -258,7 +331,7 @@ int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint6
 }
 
 void clear_result(smx_ctx *ctx) {
-    if (ctx->d_result_buf) (void)hipFree(ctx->d_result_buf);
+    if (ctx->d_result_buf) arena_put(ctx, ctx->d_result_buf);
     ctx->d_result_buf = ctx->d_result = nullptr;
     ctx->n_records = 0;
     ctx->bucket_off.clear();
@@ -276,6 +349,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     ctx->num_buckets = B;
     ctx->bucket_off.assign(B + 1, 0);
 
+    WallTrace wt;
     std::vector<uint64_t *> masks;
     uint64_t nrec = n_in;
     if (from_reads) {
@@ -292,7 +366,10 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
 
     // ---- choose the MSD split: level 1 = bucket + s1 key bits, then levels of <= log2(FMAX) bits ----
     const unsigned avail = std::min(64u, 2 * K);  // key bits visible in key_top64
-    const uint64_t leaf = std::max<uint32_t>(std::min<uint32_t>(cap / 4, 64), 1);  // wave-sortable leaves (<= 256) on average 64
+    // requested average leaf = cap/2 records (the power-of-two split then lands between cap/4 and cap/2). Measured on
+    // 10 M PE150 reads, k=55 (tools/sweep.py): 64 -> 165 ms (register sort, 4 levels), 256 -> 176, 512 -> 144, 1024 -> 127.5 ms.
+    uint64_t leaf = std::max<uint32_t>(cap / 2, 1);
+    if (ctx->opt_leaf_target > 0) leaf = (uint64_t)ctx->opt_leaf_target;
     const uint64_t fneed = (nrec + leaf - 1) / leaf;
     unsigned bits = fneed > B ? ceil_log2((fneed + B - 1) / B) : 0;
     bits = std::min(bits, std::min(avail, 40u));
@@ -332,7 +409,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (int rc = dalloc(ctx, &bufA, nrec)) return rc;
     if (int rc = dalloc(ctx, &bufB, nrec)) return rc;
     unsigned long long *histA, *offA, *offB, *cur, *tcnt, *tstart, *ucount, *uoff, *bucket_off;
-    uint32_t *biglist, *bigcount, *runlen, *medlist, *medcount;
+    uint32_t *biglist, *bigcount, *runlen, *medlist, *medcount, *smalllist, *smallcount;
     if (int rc = dalloc(ctx, &histA, nb)) return rc;
     if (int rc = dalloc(ctx, &offA, nb + 1)) return rc;
     if (int rc = dalloc(ctx, &offB, nb_parent_max + 1)) return rc;
@@ -346,9 +423,13 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (int rc = dalloc(ctx, &medlist, nb)) return rc;
     if (int rc = dalloc(ctx, &medcount, 1)) return rc;
     HIPCHK(hipMemsetAsync(medcount, 0, 4, ctx->stream));
+    if (int rc = dalloc(ctx, &smalllist, nb)) return rc;
+    if (int rc = dalloc(ctx, &smallcount, 1)) return rc;
+    HIPCHK(hipMemsetAsync(smallcount, 0, 4, ctx->stream));
     if (int rc = dalloc(ctx, &runlen, nrec / cap + nb + 2)) return rc;
     if (int rc = dalloc(ctx, &bucket_off, B + 1)) return rc;
     HIPCHK(hipMemsetAsync(bigcount, 0, 4, ctx->stream));
+    wt.mark(ctx, "mark+alloc");
 
     PassArgs a{};
     a.K = K;
@@ -393,6 +474,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     }
     tend(ctx);
 
+    wt.mark(ctx, "level1");
     // ---- levels 2.. -------------------------------------------------------------------------
     Rec<NW> *sortbuf = bufA, *other = bufB;
     uint64_t nseg = F1;
@@ -427,6 +509,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         used += t;
     }
     const unsigned long long *fine_off = off_cur;
+    wt.mark(ctx, "levels2+");
 
     // ---- leaf sort + unique -----------------------------------------------------------------
     {
@@ -436,13 +519,18 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         size_t lds = (size_t)cap * NW * 8 + (2 * (size_t)(1u << sub_bits) + 2) * 4 + cap + 16;
         if (int rc = set_lds(ctx, k_sort_small<NW, Tune<NW>::LPT>, lds)) return rc;
         if (int rc = set_lds(ctx, k_sort_big<NW>, (size_t)cap * NW * 8)) return rc;
+        tbegin(ctx, "classify");
+        hipLaunchKernelGGL(k_classify, dim3((unsigned)((nb + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, fine_off, (uint32_t)nb, cap, ucount,
+                           smalllist, smallcount, medlist, medcount, biglist, bigcount);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
         tbegin(ctx, "sort_wave");
         hipLaunchKernelGGL((k_sort_wave<NW>), dim3((unsigned)std::min<uint64_t>((nb + 3) / 4, 256 * 16)), dim3(BLK), 0, ctx->stream,
-                           (void *)sortbuf, fine_off, (uint32_t)nb, cap, ucount, medlist, medcount, biglist, bigcount);
+                           (void *)sortbuf, fine_off, ucount, (const uint32_t *)smalllist, (const uint32_t *)smallcount);
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "sort_unique");
-        hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 4), dim3(BLK), lds, ctx->stream, (void *)sortbuf,
+        hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 8), dim3(BLK), lds, ctx->stream, (void *)sortbuf,
                            fine_off, (uint32_t)nb, cap, K, sub_bits ? sub_shift : 0u, sub_bits, ucount, biglist, bigcount, (int)ctx->opt_dbg,
                            (const uint32_t *)medlist, (const uint32_t *)medcount);
         HIPCHK(hipGetLastError());
@@ -453,12 +541,18 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         HIPCHK(hipGetLastError());
         tend(ctx);
     }
+    wt.mark(ctx, "leaf sort");
     // ---- compact ----------------------------------------------------------------------------
     tbegin(ctx, "compact");
     if (int rc = scan_u64(ctx, ucount, uoff, nb)) return rc;
-    hipLaunchKernelGGL((k_compact_wave<NW>), dim3((unsigned)std::min<uint64_t>((nb + 3) / 4, 256 * 32)), dim3(BLK), 0, ctx->stream,
-                       (const void *)sortbuf, fine_off, (const unsigned long long *)ucount, (const unsigned long long *)uoff,
-                       (uint32_t)nb, (void *)other);
+    if (nrec / nb >= 128)
+        hipLaunchKernelGGL((k_compact<NW>), dim3((unsigned)std::min<uint64_t>(nb, 1u << 20)), dim3(BLK), 0, ctx->stream,
+                           (const void *)sortbuf, fine_off, (const unsigned long long *)ucount, (const unsigned long long *)uoff,
+                           (uint32_t)nb, (void *)other);
+    else
+        hipLaunchKernelGGL((k_compact_wave<NW>), dim3((unsigned)std::min<uint64_t>((nb + 3) / 4, 256 * 32)), dim3(BLK), 0, ctx->stream,
+                           (const void *)sortbuf, fine_off, (const unsigned long long *)ucount, (const unsigned long long *)uoff,
+                           (uint32_t)nb, (void *)other);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_bucket_offsets, dim3((B + 1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream,
                        (const unsigned long long *)uoff, B, (uint32_t)(nb / B), bucket_off);
@@ -471,6 +565,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     ctx->n_records = h[B];
     ctx->d_result_buf = other;
     ctx->d_result = other;
+    wt.mark(ctx, "compact");
     return 0;
 }
 
@@ -487,8 +582,10 @@ int dispatch_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d
         default: rc = run_count<4>(ctx, K, mode, B, d_recs, n_in); break;
     }
     if (rc == 0) {
+        WallTrace wt;
         tcollect(ctx);
         free_temps(ctx, ctx->d_result_buf);
+        wt.mark(ctx, "free");
     } else {
         (void)hipStreamSynchronize(ctx->stream);
         for (auto &t : ctx->timings) {
@@ -549,12 +646,12 @@ int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsign
 
 
 void clear_graph(smx_ctx *ctx) {
-    if (ctx->g_kpo) (void)hipFree(ctx->g_kpo);
+    if (ctx->g_kpo) arena_put(ctx, ctx->g_kpo);
     if (ctx->g_kmers) {
         if (ctx->d_result == ctx->g_kmers) ctx->d_result = nullptr;
-        (void)hipFree(ctx->g_kmers);
+        arena_put(ctx, ctx->g_kmers);
     }
-    if (ctx->g_mask) (void)hipFree(ctx->g_mask);
+    if (ctx->g_mask) arena_put(ctx, ctx->g_mask);
     ctx->g_kpo = ctx->g_kmers = nullptr;
     ctx->g_mask = nullptr;
     ctx->g_nkpo = ctx->g_nkmers = 0;
@@ -821,6 +918,7 @@ void smx_destroy(smx_ctx *ctx) {
     clear_graph(ctx);
     clear_result(ctx);
     free_temps(ctx);
+    arena_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -833,6 +931,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "s1")) ctx->opt_s1 = value;
     else if (!strcmp(key, "s2")) ctx->opt_s2 = value;
     else if (!strcmp(key, "dbg")) ctx->opt_dbg = value;
+    else if (!strcmp(key, "leaf_target")) ctx->opt_leaf_target = value;
     else return fail(ctx, SMX_INVALID_PARAMETER, "unknown option %s", key);
     return SMX_OK;
 }
@@ -842,9 +941,9 @@ int smx_reads_clear(smx_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto &c : ctx->chunks)
         if (c.owned) {
-            (void)hipFree(c.d_words);
-            (void)hipFree(c.d_start);
-            (void)hipFree(c.d_len);
+            arena_put(ctx, c.d_words);
+            arena_put(ctx, c.d_start);
+            arena_put(ctx, c.d_len);
         }
     ctx->chunks.clear();
     return SMX_OK;

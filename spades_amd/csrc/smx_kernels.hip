@@ -660,34 +660,36 @@ __device__ __forceinline__ uint32_t wave_leaf(Rec<NW> *g, uint32_t n) {
     return base;
 }
 
-// One WAVE per fine bin (persistent waves). Leaves of <= 256 records are finished in registers; larger ones are
-// queued for the workgroup-level LDS kernel (<= cap) or the merge kernel (> cap).
+// size classes of the fine bins: empty | small (register sort, one wave) | medium (LDS kernel) | big (merge kernel).
+// One thread per bin; the per-thread atomicAdd(.,1) is wave-aggregated by the compiler, so the three list counters
+// see one atomic per wave instead of one per bin (a single word retires only ~88 atomics/us).
+__global__ void k_classify(const unsigned long long *off, uint32_t nbins, uint32_t cap, unsigned long long *ucount,
+                           uint32_t *smalllist, uint32_t *smallcount, uint32_t *medlist, uint32_t *medcount,
+                           uint32_t *biglist, uint32_t *bigcount) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbins) return;
+    const uint64_t n = off[b + 1] - off[b];
+    if (n == 0) ucount[b] = 0;
+    else if (n > cap) biglist[atomicAdd(bigcount, 1u)] = b;
+    else if (n > 128) medlist[atomicAdd(medcount, 1u)] = b;  // R=4 register sorts cost more per record than the LDS kernel
+    else smalllist[atomicAdd(smallcount, 1u)] = b;
+}
+
+// One WAVE per small fine bin (persistent waves over the small list): <= 128 records, finished in registers.
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_sort_wave(void *buf, const unsigned long long *off, uint32_t nbins, uint32_t cap,
-                                                   unsigned long long *ucount, uint32_t *medlist, uint32_t *medcount,
-                                                   uint32_t *biglist, uint32_t *bigcount) {
+__global__ void __launch_bounds__(BLK) k_sort_wave(void *buf, const unsigned long long *off, unsigned long long *ucount,
+                                                   const uint32_t *list, const uint32_t *listcount) {
     const unsigned lane = threadIdx.x & 63;
     const uint32_t wid = (blockIdx.x * BLK + threadIdx.x) >> 6, nwaves = (gridDim.x * BLK) >> 6;
-    for (uint32_t b = wid; b < nbins; b += nwaves) {
+    const uint32_t nwork = *listcount;
+    for (uint32_t i = wid; i < nwork; i += nwaves) {
+        const uint32_t b = list[i];
         const uint64_t o = off[b];
-        const uint64_t n64 = off[b + 1] - o;
-        if (n64 == 0) {
-            if (lane == 0) ucount[b] = 0;
-            continue;
-        }
-        if (n64 > 256 || n64 > cap) {
-            if (lane == 0) {
-                if (n64 > cap) biglist[atomicAdd(bigcount, 1u)] = b;
-                else medlist[atomicAdd(medcount, 1u)] = b;
-            }
-            continue;
-        }
-        const uint32_t n = (uint32_t)n64;
+        const uint32_t n = (uint32_t)(off[b + 1] - o);
         Rec<NW> *g = (Rec<NW> *)buf + o;
         uint32_t u;
         if (n <= 64) u = wave_leaf<NW, 1>(g, n);
-        else if (n <= 128) u = wave_leaf<NW, 2>(g, n);
-        else u = wave_leaf<NW, 4>(g, n);
+        else u = wave_leaf<NW, 2>(g, n);
         if (lane == 0) ucount[b] = u;
     }
 }
