@@ -516,7 +516,9 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         unsigned sub_bits = std::min(10u, avail - std::min(avail, consumed));
         while (sub_bits > 0 && (1u << sub_bits) > cap) --sub_bits;
         const unsigned sub_shift = 64 - consumed - sub_bits;
-        size_t lds = (size_t)cap * NW * 8 + (2 * (size_t)(1u << sub_bits) + 2) * 4 + cap + 16;
+        uint32_t T = 64;
+        while (T < 2 * cap) T <<= 1;
+        size_t lds = (size_t)cap * NW * 8 + ((size_t)T + 2 * ((size_t)1 << sub_bits) + 1 + cap + 4) * 4;
         if (int rc = set_lds(ctx, k_sort_small<NW, Tune<NW>::LPT>, lds)) return rc;
         if (int rc = set_lds(ctx, k_sort_big<NW>, (size_t)cap * NW * 8)) return rc;
         tbegin(ctx, "classify");
@@ -531,7 +533,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         tend(ctx);
         tbegin(ctx, "sort_unique");
         hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 8), dim3(BLK), lds, ctx->stream, (void *)sortbuf,
-                           fine_off, (uint32_t)nb, cap, K, sub_bits ? sub_shift : 0u, sub_bits, ucount, biglist, bigcount, (int)ctx->opt_dbg,
+                           fine_off, (uint32_t)nb, cap, K, sub_bits ? sub_shift : 0u, sub_bits, T, ucount, biglist, bigcount,
                            (const uint32_t *)medlist, (const uint32_t *)medcount);
         HIPCHK(hipGetLastError());
         tend(ctx);

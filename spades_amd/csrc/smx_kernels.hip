@@ -420,24 +420,36 @@ __device__ __forceinline__ uint32_t lds_insertion_unique(uint64_t *s, uint32_t b
     return d;
 }
 
-// Leaf sort: persistent workgroups loop over fine bins (n <= cap records, all sharing their bucket
-// and the key bits consumed by the MSD levels). The leaf is split once more inside LDS on the next
-// sub_bits key bits (counting sort: LDS histogram -> scan -> placement), which leaves sub-bins of a
-// few records that single threads finish by insertion-sort-with-dedup. Skewed leaves (a sub-bin
-// above 128 records) fall back to the bitonic network + adjacent-unique. Uniques are stored in
-// place at the start of the bin's region. Bins larger than cap are queued for k_sort_big.
+// Leaf kernel for medium bins (129..cap records, all sharing their bucket and the key bits consumed by the MSD levels);
+// persistent workgroups loop over the medium list. Duplicates (coverage) are removed FIRST, by an exact LDS hash table
+// (open addressing on a 32-bit slot holding the index of the owning record; a probe that meets an occupied slot compares
+// the full key, so equal keys meet their owner and different keys move on). Only the distinct records are then ordered:
+// digit = next sub_bits key bits -> count per digit + per-digit linked list -> prefix scan -> rank = prefix[digit] +
+// #smaller keys in the digit's list (lists hold ~1 record) -> store at the final position of the bin's region.
+// Skewed leaves (a digit with > 128 distinct keys) fall back to the bitonic network + adjacent-unique.
+// LDS: stage[cap*NW] u64 | tab[T] | head[S] | cntf[S+1] | next[cap]  (u32 each)
+template <int NW>
+__device__ __forceinline__ uint32_t rec_hash32(const Rec<NW> &x) {
+    uint64_t h = x.w[0] * 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int w = 1; w < NW; ++w) h = (h ^ (h >> 29)) * 0xBF58476D1CE4E5B9ull + x.w[w] * 0x94D049BB133111EBull;
+    h ^= h >> 32;
+    return (uint32_t)h;
+}
+
 template <int NW, int LPT>
 __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned long long *off, uint32_t nbins, uint32_t cap,
-                                                    unsigned K, unsigned sub_shift, unsigned sub_bits,
-                                                    unsigned long long *ucount, uint32_t *biglist, uint32_t *bigcount, int dbg,
+                                                    unsigned K, unsigned sub_shift, unsigned sub_bits, uint32_t T,
+                                                    unsigned long long *ucount, uint32_t *biglist, uint32_t *bigcount,
                                                     const uint32_t *list, const uint32_t *listcount) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     __shared__ uint32_t scr[BLK / 64 + 2];
     __shared__ uint32_t maxc;
     const uint32_t S = 1u << sub_bits;
-    uint32_t *cnt = (uint32_t *)(lds64 + (size_t)cap * NW);  // [S+1] sub-bin offsets
-    uint32_t *dcn = cnt + S + 1;                             // [S] distinct per sub-bin -> output offsets
-    uint8_t *flg = (uint8_t *)(dcn + S);                     // [cap] first-occurrence flags
+    uint32_t *tab = (uint32_t *)(lds64 + (size_t)cap * NW);  // [T]
+    uint32_t *head = tab + T;                                // [S]
+    uint32_t *cntf = head + S;                               // [S+1]
+    uint32_t *nxt = cntf + S + 1;                            // [cap]
     const uint32_t nwork = list ? *listcount : nbins;
     for (uint32_t bi = blockIdx.x; bi < nwork; bi += gridDim.x) {
         const uint32_t b = list ? list[bi] : bi;
@@ -458,27 +470,52 @@ __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned lo
             for (uint32_t i = threadIdx.x; i < n; i += BLK) lds_put<NW>(lds64, i, g[i]);
             __syncthreads();
         } else {
-            for (uint32_t i = threadIdx.x; i <= S; i += BLK) cnt[i] = 0;
+            for (uint32_t i = threadIdx.x; i < T; i += BLK) tab[i] = 0xFFFFFFFFu;
+            for (uint32_t i = threadIdx.x; i <= S; i += BLK) {
+                cntf[i] = 0;
+                if (i < S) head[i] = 0xFFFFFFFFu;
+            }
             if (threadIdx.x == 0) maxc = 0;
-            __syncthreads();
             Rec<NW> r[LPT];
-            uint32_t ds[LPT];  // digit << 16 | slot
 #pragma unroll
             for (int j = 0; j < LPT; ++j) {
                 uint32_t i = threadIdx.x + j * BLK;
                 if (i < n) {
                     r[j] = g[i];
-                    uint32_t d = (uint32_t)(key_top64<NW>(r[j], K) >> sub_shift) & (S - 1);
-                    ds[j] = (d << 16) | atomicAdd(&cnt[d], 1u);
+                    lds_put<NW>(lds64, i, r[j]);
                 }
             }
             __syncthreads();
-            if (dbg == 1) continue;
+            uint32_t fm = 0;
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                uint32_t i = threadIdx.x + j * BLK;
+                if (i < n) {
+                    uint32_t slot = rec_hash32<NW>(r[j]) & (T - 1);
+                    bool first = false;
+                    for (;;) {
+                        uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, i);
+                        if (old == 0xFFFFFFFFu) {
+                            first = true;
+                            break;
+                        }
+                        if (rec_eq<NW>(lds_get<NW>(lds64, old), r[j])) break;  // duplicate of record `old`
+                        slot = (slot + 1) & (T - 1);
+                    }
+                    if (first) {
+                        fm |= 1u << j;
+                        const uint32_t d = (uint32_t)(key_top64<NW>(r[j], K) >> sub_shift) & (S - 1);
+                        atomicAdd(&cntf[d], 1u);
+                        nxt[i] = atomicExch(&head[d], i);
+                    }
+                }
+            }
+            __syncthreads();
             const uint32_t per = (S + BLK - 1) / BLK;
             const uint32_t d0 = threadIdx.x * per, d1 = min(S, d0 + per);
             uint32_t sum = 0, mx = 0;
             for (uint32_t d = d0; d < d1; ++d) {
-                uint32_t c = cnt[d];
+                uint32_t c = cntf[d];
                 sum += c;
                 mx = max(mx, c);
             }
@@ -486,72 +523,24 @@ __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned lo
             uint32_t tot;
             uint32_t run = block_excl_scan<uint32_t>(sum, scr, &tot);
             for (uint32_t d = d0; d < d1; ++d) {
-                uint32_t c = cnt[d];
-                cnt[d] = run;
+                uint32_t c = cntf[d];
+                cntf[d] = run;
                 run += c;
-            }
-            if (threadIdx.x == 0) cnt[S] = n;
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < LPT; ++j) {
-                uint32_t i = threadIdx.x + j * BLK;
-                if (i < n) lds_put<NW>(lds64, cnt[ds[j] >> 16] + (ds[j] & 0xFFFFu), r[j]);
             }
             __syncthreads();
             bitonic = maxc > 128;
-            if (dbg == 2) continue;
             if (!bitonic) {
-                // pass 1: first-occurrence flag of every placed record (one thread per record; the
-                // threads of a sub-bin read the same LDS addresses in lockstep -> broadcasts)
-                for (uint32_t i = threadIdx.x; i < S; i += BLK) dcn[i] = 0;
-                __syncthreads();
-                uint32_t fm = 0;
 #pragma unroll
                 for (int j = 0; j < LPT; ++j) {
-                    uint32_t i = threadIdx.x + j * BLK;
-                    if (i < n) {
-                        Rec<NW> x = lds_get<NW>(lds64, i);
-                        uint32_t d = (uint32_t)(key_top64<NW>(x, K) >> sub_shift) & (S - 1);
-                        bool first = true;
-                        for (uint32_t t = cnt[d]; t < i; ++t)
-                            if (rec_eq<NW>(lds_get<NW>(lds64, t), x)) {
-                                first = false;
-                                break;
-                            }
-                        flg[i] = first;
-                        if (first) {
-                            fm |= 1u << j;
-                            atomicAdd(&dcn[d], 1u);
-                        }
+                    if (fm & (1u << j)) {
+                        const uint32_t d = (uint32_t)(key_top64<NW>(r[j], K) >> sub_shift) & (S - 1);
+                        uint32_t smaller = 0;
+                        for (uint32_t p = head[d]; p != 0xFFFFFFFFu; p = nxt[p])
+                            smaller += rec_less<NW>(lds_get<NW>(lds64, p), r[j]) ? 1u : 0u;
+                        g[cntf[d] + smaller] = r[j];
                     }
                 }
-                __syncthreads();
-                uint32_t mine = 0;
-                for (uint32_t d = d0; d < d1; ++d) mine += dcn[d];
-                uint32_t total;
-                uint32_t rank = block_excl_scan<uint32_t>(mine, scr, &total);
-                for (uint32_t d = d0; d < d1; ++d) {
-                    uint32_t c = dcn[d];
-                    dcn[d] = rank;
-                    rank += c;
-                }
-                __syncthreads();
-                if (dbg == 3) continue;
-                // pass 2: rank among the distinct records of the sub-bin -> final position
-#pragma unroll
-                for (int j = 0; j < LPT; ++j) {
-                    uint32_t i = threadIdx.x + j * BLK;
-                    if (i < n && (fm & (1u << j))) {
-                        Rec<NW> x = lds_get<NW>(lds64, i);
-                        uint32_t d = (uint32_t)(key_top64<NW>(x, K) >> sub_shift) & (S - 1);
-                        uint32_t dr = 0;
-                        const uint32_t e0 = cnt[d + 1];
-                        for (uint32_t t = cnt[d]; t < e0; ++t)
-                            if (flg[t] && rec_less<NW>(lds_get<NW>(lds64, t), x)) ++dr;
-                        g[dcn[d] + dr] = x;
-                    }
-                }
-                if (threadIdx.x == 0) ucount[b] = total;
+                if (threadIdx.x == 0) ucount[b] = tot;
                 __syncthreads();
                 continue;
             }
