@@ -168,8 +168,17 @@ def main():
     b_alg = n_reads * L / 4 + 2 * inst * W + distinct * W
     achieved = b_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     dom = max(tm, key=lambda x: x[1]) if tm else ("", 0.0)
+    # HBM traffic per step from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, FETCH x2
+    # gfx950 correction: profiles/r01/bench_k55A_10M_pmc_hbm_traffic.csv). Only valid for the workload it was taken on.
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01", "bench_k55A_10M_pmc_hbm_traffic.csv")
+    if world == 1 and K == 55 and args.mode == "A" and n_reads == 10_000_000 and nb == 16 and os.path.exists(pmc):
+        for line in open(pmc):
+            if line.startswith("TOTAL"):
+                f = line.strip().split(",")
+                traffic = round(float(f[3]) + float(f[5]), 1)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_unit": "GB per step (PMC, profiles/r01)",
                 "kernel": "smx_count pipeline (sum of stage kernels, HIP events on the library stream)",
                 "algorithmic_bytes_per_step": int(b_alg), "kernel_ms_per_step": round(kernel_ms, 3),
                 "dominant_stage": dom[0], "dominant_stage_ms": round(dom[1], 3),
