@@ -162,6 +162,24 @@ def main():
                         manifest["cases"].append({"kind": "graph", "reads": f"reads_{name}.txt", "K": K, "threads": T, "num_buckets": 10 * T,
                                                   "md5": md5(txt.encode()), "n_segments": txt.count("\nS\t"), "n_links": txt.count("\nL\t"),
                                                   "file": fn if keep else None, "source": "spades-gbuilder binary (survey build), --gfa"})
+        # coverage (-c): DP:f / KC:i tags (CoverageHashMapBuilder + FillCoverageAndFlankingFromPHM)
+        for name, ks, ts in (("tiny", (21,), (1,)), ("small", (21, 55), (1, 3)), ("loop", (21,), (1,)), ("polyA", (21,), (1,))):
+            reads = [r for r in gsets[name][1] if r]
+            with tempfile.TemporaryDirectory() as td:
+                fq = os.path.join(td, "r.fq")
+                with open(fq, "w") as f:
+                    for i, r in enumerate(reads):
+                        f.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n")
+                for K in ks:
+                    for T in ts:
+                        out = os.path.join(td, f"gc_{K}_{T}.gfa")
+                        subprocess.check_call([gb, fq, out, "-k", str(K), "-t", str(T), "-c", "--gfa", "-tmp-dir", os.path.join(td, f"tc{K}_{T}")],
+                                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                        txt = open(out).read()
+                        fn = f"graphcov_{name}_k{K}_t{T}.gfa"
+                        open(os.path.join(HERE, fn), "w").write(txt)
+                        manifest["cases"].append({"kind": "graph_cov", "reads": f"reads_{name}.txt", "K": K, "threads": T, "num_buckets": 10 * T,
+                                                  "md5": md5(txt.encode()), "file": fn, "source": "spades-gbuilder binary (survey build), -c --gfa"})
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
     print(f"{len(manifest['cases'])} cases written")
 
