@@ -47,7 +47,7 @@ struct smx_ctx {
     unsigned nw = 0, K = 0, num_buckets = 0;
     std::vector<uint64_t> bucket_off;
     // tuning / test hooks
-    int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_dbg = 0;
+    int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_dbg = 0, opt_batch_records = 0;
     // timings
     std::vector<Timing> timings;
     std::vector<std::string> tnames, xnames;  // last count stages / last extract_partition stages
@@ -244,17 +244,20 @@ size_t scatter_lds(uint32_t F) {
 
 // ---- level-1 passes over the resident read chunks (hist or scatter) ----
 template <int NW, int BINF>
-int pass_reads(smx_ctx *ctx, int mode, bool scatter, PassArgs a, const std::vector<uint64_t *> &masks) {
+int pass_reads(smx_ctx *ctx, int mode, bool scatter, PassArgs a, const std::vector<uint64_t *> &masks,
+               const std::vector<std::pair<uint64_t, uint64_t>> *ranges = nullptr) {
     constexpr int RPT = Tune<NW>::RPT;
     for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
         const ReadChunk &ch = ctx->chunks[ci];
         if (ch.n_bases == 0 || !masks[ci]) continue;
         a.seq = ch.d_words;
         a.mask = masks[ci];
-        a.G = ch.n_bases;
+        a.g0 = ranges ? (*ranges)[ci].first : 0;
+        a.G = ranges ? (*ranges)[ci].second : ch.n_bases;
+        if (a.G <= a.g0) continue;
         const int rpp = mode == SMX_MODE_ALL ? 2 : 1;
         const uint64_t tp = (uint64_t)(RPT / rpp) * BLK;
-        const uint64_t ntiles = (a.G + tp - 1) / tp;
+        const uint64_t ntiles = (a.G - a.g0 + tp - 1) / tp;
         if (!scatter) {
             unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 4096);
             size_t lds = (size_t)a.F * 4;
@@ -307,7 +310,7 @@ int pass_recs(smx_ctx *ctx, bool scatter, PassArgs a, uint64_t nrec, unsigned lo
 }
 
 // mark valid windows of every chunk; returns total windows
-int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint64_t *total) {
+int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint64_t *total, bool temp_masks = true) {
     unsigned long long *d_total;
     if (int rc = dalloc(ctx, &d_total, 1)) return rc;
     HIPCHK(hipMemsetAsync(d_total, 0, 8, ctx->stream));
@@ -316,7 +319,7 @@ int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint6
         const ReadChunk &ch = ctx->chunks[ci];
         if (ch.n_reads == 0) continue;
         size_t mw = (size_t)(ch.n_bases / 64 + 2);
-        if (int rc = dalloc(ctx, &masks[ci], mw)) return rc;
+        if (int rc = dalloc(ctx, &masks[ci], mw, temp_masks)) return rc;
         HIPCHK(hipMemsetAsync(masks[ci], 0, mw * 8, ctx->stream));
         unsigned grid = (unsigned)((ch.n_reads + BLK - 1) / BLK);
         hipLaunchKernelGGL(k_mark_windows, dim3(grid), dim3(BLK), 0, ctx->stream, ch.d_start, ch.d_len, ch.n_reads, K,
@@ -338,8 +341,15 @@ void clear_result(smx_ctx *ctx) {
 }
 
 // The whole count: from reads (d_recs == nullptr) or from records already in HBM.
+struct ReadSel {  // which part of the resident reads one pipeline run covers
+    const std::vector<uint64_t *> *masks = nullptr;                         // precomputed window masks (else computed here)
+    const std::vector<std::pair<uint64_t, uint64_t>> *ranges = nullptr;     // per chunk position range
+    uint64_t nrec = 0;                                                      // records in the selection (when masks given)
+};
+
 template <int NW>
-int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in) {
+int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in, const ReadSel *sel = nullptr,
+              bool recs_reusable = false) {
     uint32_t cap = Tune<NW>::CAP;
     if (ctx->opt_leaf_cap > 0) cap = (uint32_t)std::min<int64_t>(ctx->opt_leaf_cap, cap);
     const bool from_reads = d_recs == nullptr;
@@ -352,7 +362,10 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     WallTrace wt;
     std::vector<uint64_t *> masks;
     uint64_t nrec = n_in;
-    if (from_reads) {
+    if (from_reads && sel && sel->masks) {
+        masks = *sel->masks;
+        nrec = sel->nrec;
+    } else if (from_reads) {
         tbegin(ctx, "mark_windows");
         uint64_t nwin = 0;
         int rc = mark_windows(ctx, K, masks, &nwin);
@@ -360,6 +373,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         if (rc) return rc;
         nrec = mode == SMX_MODE_ALL ? 2 * nwin : nwin;
     }
+    const std::vector<std::pair<uint64_t, uint64_t>> *ranges = (from_reads && sel) ? sel->ranges : nullptr;
     ctx->n_instances = nrec;
     if (nrec == 0) return 0;
     if (B > 4096) return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets=%u too large (level-1 fan-out limit 4096)", B);
@@ -407,7 +421,8 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     // ---- allocations ------------------------------------------------------------------------
     Rec<NW> *bufA, *bufB;
     if (int rc = dalloc(ctx, &bufA, nrec)) return rc;
-    if (int rc = dalloc(ctx, &bufB, nrec)) return rc;
+    if (!from_reads && recs_reusable) bufB = (Rec<NW> *)const_cast<void *>(d_recs);  // the source is dead after the level-1 scatter
+    else if (int rc = dalloc(ctx, &bufB, nrec)) return rc;
     unsigned long long *histA, *offA, *offB, *cur, *tcnt, *tstart, *ucount, *uoff, *bucket_off;
     uint32_t *biglist, *bigcount, *runlen, *medlist, *medcount, *smalllist, *smallcount;
     if (int rc = dalloc(ctx, &histA, nb)) return rc;
@@ -450,7 +465,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     HIPCHK(hipMemsetAsync(histA, 0, (size_t)F1 * 8, ctx->stream));
     tbegin(ctx, "l1_hist");
     if (from_reads) {
-        if (int rc = pass_reads<NW, BIN_L1>(ctx, mode, false, a, masks)) return rc;
+        if (int rc = pass_reads<NW, BIN_L1>(ctx, mode, false, a, masks, ranges)) return rc;
     } else {
         a.recs = d_recs;
         a.seg_off = seg1;
@@ -468,7 +483,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     a.out = bufA;
     tbegin(ctx, "l1_scatter");
     if (from_reads) {
-        if (int rc = pass_reads<NW, BIN_L1>(ctx, mode, true, a, masks)) return rc;
+        if (int rc = pass_reads<NW, BIN_L1>(ctx, mode, true, a, masks, ranges)) return rc;
     } else {
         if (int rc = pass_recs<NW, BIN_L1>(ctx, true, a, nrec, tcnt, tstart)) return rc;
     }
@@ -571,17 +586,135 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     return 0;
 }
 
+
+// Counting from the resident reads with HBM-bounded batches (the reference's dump + merge, kmer_splitter.hpp:123-170 +
+// kmer_index_builder.hpp:346-430): when two record buffers of the whole batch do not fit the budget, the position
+// space of every read chunk is cut into ranges; each range is counted on its own (sorted-unique run), and runs are
+// folded into the accumulated set by concatenation + one more pass of the same pipeline from records (= k-way
+// merge-unique; the pipeline is a sort, so equal keys of different runs meet in the same leaf).
+template <int NW>
+int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
+    std::vector<uint64_t *> masks;
+    uint64_t nwin = 0;
+    tbegin(ctx, "mark_windows");
+    int rc = mark_windows(ctx, K, masks, &nwin, /*temp_masks=*/false);
+    tend(ctx);
+    auto drop_masks = [&]() {
+        for (auto *m : masks) arena_put(ctx, m);
+    };
+    if (rc) {
+        drop_masks();
+        return rc;
+    }
+    const int rpp = mode == SMX_MODE_ALL ? 2 : 1;
+    const uint64_t nrec = nwin * rpp;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t cached = 0;
+    for (auto &b : ctx->arena_free) cached += b.second;
+    const uint64_t budget = ctx->budget ? ctx->budget : (uint64_t)((free_b + cached) * 0.92);
+    // per record: two ping-pong copies + ~1/4 record of bin bookkeeping
+    uint64_t max_batch = budget / ((uint64_t)NW * 8 * 2 + 8);
+    if (ctx->opt_batch_records > 0) max_batch = (uint64_t)ctx->opt_batch_records;
+    uint64_t nbatch = nrec ? (nrec + max_batch - 1) / max_batch : 1;
+    if (nbatch > 1) nbatch = (2 * nrec + max_batch - 1) / max_batch;  // keep half of the budget for the accumulated set + merge
+    if (nbatch <= 1) {
+        ReadSel sel;
+        sel.masks = &masks;
+        sel.nrec = nrec;
+        rc = run_count<NW>(ctx, K, mode, B, nullptr, 0, &sel);
+        drop_masks();
+        return rc;
+    }
+    void *acc = nullptr;
+    uint64_t nacc = 0;
+    unsigned long long *d_cnt = nullptr;
+    if ((rc = dalloc(ctx, &d_cnt, 1, false))) {
+        drop_masks();
+        return rc;
+    }
+    auto cleanup = [&](int code) {
+        drop_masks();
+        arena_put(ctx, d_cnt);
+        if (acc && acc != ctx->d_result_buf) arena_put(ctx, acc);
+        return code;
+    };
+    uint64_t total_inst = 0;
+    for (uint64_t bi = 0; bi < nbatch; ++bi) {
+        std::vector<std::pair<uint64_t, uint64_t>> ranges(ctx->chunks.size());
+        HIPCHK(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+        for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
+            const uint64_t G = ctx->chunks[ci].n_bases;
+            const uint64_t words = (G + 63) / 64;
+            const uint64_t w0 = words * bi / nbatch, w1 = words * (bi + 1) / nbatch;
+            ranges[ci] = {w0 * 64, std::min<uint64_t>(w1 * 64, G)};
+            if (masks[ci] && w1 > w0) {
+                hipLaunchKernelGGL(k_count_range, dim3((unsigned)std::min<uint64_t>((w1 - w0 + BLK - 1) / BLK, 4096)), dim3(BLK), 0, ctx->stream,
+                                   (const unsigned long long *)masks[ci], w0, w1, d_cnt);
+                if (hipGetLastError() != hipSuccess) return cleanup(fail(ctx, SMX_DEVICE_ERROR, "k_count_range launch failed"));
+            }
+        }
+        unsigned long long nw_b = 0;
+        if (hipMemcpyAsync(&nw_b, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return cleanup(fail(ctx, SMX_DEVICE_ERROR, "batch window count failed"));
+        ReadSel sel;
+        sel.masks = &masks;
+        sel.ranges = &ranges;
+        sel.nrec = nw_b * rpp;
+        total_inst += sel.nrec;
+        if ((rc = run_count<NW>(ctx, K, mode, B, nullptr, 0, &sel))) return cleanup(rc);
+        void *run = ctx->d_result_buf;
+        const uint64_t nrun = ctx->n_records;
+        ctx->d_result_buf = ctx->d_result = nullptr;
+        free_temps(ctx, run);
+        if (!acc) {
+            acc = run;
+            nacc = nrun;
+            continue;
+        }
+        // fold: acc U run -> acc
+        Rec<NW> *cat;
+        if ((rc = dalloc(ctx, &cat, nacc + nrun))) {
+            arena_put(ctx, run);
+            return cleanup(rc);
+        }
+        hipError_t e1 = hipMemcpyAsync(cat, acc, nacc * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream);
+        hipError_t e2 = hipMemcpyAsync(cat + nacc, run, nrun * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream);
+        hipError_t e3 = hipStreamSynchronize(ctx->stream);
+        arena_put(ctx, acc);
+        arena_put(ctx, run);
+        acc = nullptr;
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return cleanup(fail(ctx, SMX_DEVICE_ERROR, "run concatenation failed"));
+        tbegin(ctx, "merge_runs");
+        tend(ctx);
+        if ((rc = run_count<NW>(ctx, K, mode, B, cat, nacc + nrun, nullptr, /*recs_reusable=*/true))) return cleanup(rc);
+        acc = ctx->d_result_buf;
+        nacc = ctx->n_records;
+        if (bi + 1 < nbatch) {
+            ctx->d_result_buf = ctx->d_result = nullptr;
+            free_temps(ctx, acc);
+        }
+    }
+    if (ctx->d_result_buf != acc) {  // last batch was the first (cannot happen for nbatch > 1) or a fold result: install it
+        ctx->d_result_buf = ctx->d_result = acc;
+    }
+    ctx->n_instances = total_inst;
+    acc = nullptr;
+    return cleanup(0);
+}
+
 int dispatch_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in) {
     if (K < 1 || K > 128) return fail(ctx, SMX_INVALID_PARAMETER, "K=%u out of range [1,128]", K);
     if (B < 1) return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets must be >= 1");
     if (mode != SMX_MODE_ALL && mode != SMX_MODE_CANONICAL) return fail(ctx, SMX_INVALID_PARAMETER, "bad mode %d", mode);
     HIPCHK(hipSetDevice(ctx->device));
     int rc;
+    const bool reads = d_recs == nullptr;
     switch ((K + 31) / 32) {
-        case 1: rc = run_count<1>(ctx, K, mode, B, d_recs, n_in); break;
-        case 2: rc = run_count<2>(ctx, K, mode, B, d_recs, n_in); break;
-        case 3: rc = run_count<3>(ctx, K, mode, B, d_recs, n_in); break;
-        default: rc = run_count<4>(ctx, K, mode, B, d_recs, n_in); break;
+        case 1: rc = reads ? count_reads<1>(ctx, K, mode, B) : run_count<1>(ctx, K, mode, B, d_recs, n_in); break;
+        case 2: rc = reads ? count_reads<2>(ctx, K, mode, B) : run_count<2>(ctx, K, mode, B, d_recs, n_in); break;
+        case 3: rc = reads ? count_reads<3>(ctx, K, mode, B) : run_count<3>(ctx, K, mode, B, d_recs, n_in); break;
+        default: rc = reads ? count_reads<4>(ctx, K, mode, B) : run_count<4>(ctx, K, mode, B, d_recs, n_in); break;
     }
     if (rc == 0) {
         WallTrace wt;
@@ -677,7 +810,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
     ctx->gh.k = k;
     ctx->gh.eoff.assign(1, 0);
     // ---- 1. canonical (k+1)-mers -------------------------------------------------------------
-    if (int rc = run_count<NW>(ctx, k + 1, SMX_MODE_CANONICAL, B, nullptr, 0)) return rc;
+    if (int rc = count_reads<NW>(ctx, k + 1, SMX_MODE_CANONICAL, B)) return rc;
     ctx->g_kpo = ctx->d_result_buf;
     ctx->g_nkpo = ctx->n_records;
     ctx->d_result_buf = ctx->d_result = nullptr;
@@ -934,6 +1067,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "s2")) ctx->opt_s2 = value;
     else if (!strcmp(key, "dbg")) ctx->opt_dbg = value;
     else if (!strcmp(key, "leaf_target")) ctx->opt_leaf_target = value;
+    else if (!strcmp(key, "batch_records")) ctx->opt_batch_records = value;
     else return fail(ctx, SMX_INVALID_PARAMETER, "unknown option %s", key);
     return SMX_OK;
 }

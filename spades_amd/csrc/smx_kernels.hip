@@ -27,7 +27,8 @@ struct PassArgs {
     // reads source
     const uint64_t *seq;
     const uint64_t *mask;
-    uint64_t G;  // number of stream positions (nucleotides)
+    uint64_t G;   // end of the position range handled by this launch (nucleotides)
+    uint64_t g0;  // first position of the range (multiple of 64)
     // records source
     const void *recs;
     const unsigned long long *seg_off;  // [nseg+1] record offsets of the input segments
@@ -87,6 +88,16 @@ __global__ void k_mark_windows(const uint64_t *__restrict__ start, const uint32_
     if (threadIdx.x == 0 && tot) atomicAdd(total, tot);
 }
 
+// valid windows in the position range [g0, g1) of a chunk (g0, g1 multiples of 64)
+__global__ void k_count_range(const unsigned long long *mask, uint64_t w0, uint64_t w1, unsigned long long *total) {
+    __shared__ unsigned long long scratch[BLK / 64 + 2];
+    unsigned long long c = 0;
+    for (uint64_t w = w0 + (uint64_t)blockIdx.x * BLK + threadIdx.x; w < w1; w += (uint64_t)gridDim.x * BLK) c += __popcll(mask[w]);
+    unsigned long long tot;
+    block_excl_scan<unsigned long long>(c, scratch, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(total, tot);
+}
+
 // -------------------------------------------------------------------------------- record sources
 // Fills r[]/valid for this thread of tile `tile`. READS: RPT/RPP positions per thread, position =
 // tile*TP + j*BLK + tid (a wave covers 64 consecutive positions = one mask word).
@@ -108,7 +119,7 @@ __device__ __forceinline__ void fetch_records(const PassArgs &a, uint64_t tile, 
     } else {
         constexpr int RPP = (SRC == SRC_READS_ALL) ? 2 : 1;
         constexpr int PPT = RPT / RPP;
-        const uint64_t base = tile * (uint64_t)(PPT * BLK);
+        const uint64_t base = a.g0 + tile * (uint64_t)(PPT * BLK);
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             uint64_t g = base + (uint64_t)j * BLK + threadIdx.x;
@@ -178,7 +189,7 @@ __global__ void __launch_bounds__(BLK) k_hist(PassArgs a) {
     } else {
         constexpr int RPP = (SRC == SRC_READS_ALL) ? 2 : 1;
         constexpr int PPT = RPT / RPP;
-        const uint64_t ntiles = (a.G + (uint64_t)PPT * BLK - 1) / ((uint64_t)PPT * BLK);
+        const uint64_t ntiles = (a.G - a.g0 + (uint64_t)PPT * BLK - 1) / ((uint64_t)PPT * BLK);
         for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             Rec<NW> r[RPT];
             uint32_t vm;

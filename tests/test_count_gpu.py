@@ -87,6 +87,20 @@ def test_medium_leaves_take_the_lds_kernel(K, mode, nb):
     assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
 
 
+@pytest.mark.parametrize("K,mode,nb,batch", [(21, "A", 16, 100_000), (55, "A", 16, 40_000), (56, "B", 80, 30_000), (77, "B", 30, 200_000),
+                                             (21, "A", 16, 1_000)])
+def test_multi_batch_runs_are_merged(K, mode, nb, batch):
+    """HBM-bounded batches (forced tiny here): per-range sorted-unique runs folded by the same pipeline (the reference's
+    dump + loser-tree merge, kmer_splitter.hpp:123-170 / kmer_index_builder.hpp:346-430) -> same bytes as one batch."""
+    from oracle import oracle
+    reads = _synth(21, 6000, 1200, 150) + ["A" * 150] * 30
+    if batch <= 1000:
+        reads = reads[:60]
+    ref, rs = oracle.count(reads, K, mode, nb)
+    rec, sizes = _count(reads, K, mode, nb, {"batch_records": batch})
+    assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
+
+
 def test_edge_inputs():
     from oracle import oracle
     for reads in ([], [""], ["N" * 50], ["ACG"], ["A" * 21], ["A" * 20 + "N" + "C" * 25, "acgtacgtacgtacgtacgtacgtacgt"]):

@@ -75,6 +75,8 @@ def test_graph_small_leaves_and_edge_inputs(tmp_path):
     ref = oracle.build_graph(reads, 21, 30)
     r = _build(reads, 21, 3, tmp_path, {"leaf_cap": 16})
     assert r["gfa"] == ref["gfa"]
+    r = _build(reads, 21, 3, tmp_path, {"batch_records": 20000})  # multi-batch (k+1)-mer counting under the graph
+    assert r["gfa"] == ref["gfa"]
     for rd in ([], ["ACGT"], ["A" * 60], ["ACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCA"]):
         ref = oracle.build_graph(rd, 21, 10)
         r = _build(rd, 21, 1, tmp_path)
