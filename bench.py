@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--genome", type=float, default=50e6)
     ap.add_argument("--cpu-sample", type=float, default=1e6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,9 +111,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from spades_amd import KMerDiskCounter, ReadKMerSplitter
     from spades_amd.kmercount import Context
@@ -130,16 +134,16 @@ def main():
     sp = ReadKMerSplitter(K, args.mode, ctx)
     sp.push_back_device(words.data_ptr(), words.numel() - 8, start.data_ptr(), ln.data_ptr(), n_reads)
     counter = KMerDiskCounter(None, sp)
-    engine = smx_dist.GpuEngine(ctx, args.mode) if world > 1 else None
+    engine = smx_dist.GpuEngine(ctx, args.mode) if sharded else None
 
     def step():
-        if world == 1:
+        if not sharded:
             return counter.Count(nb)
         return smx_dist.sharded_count(engine, K, nb, rank, world, dev)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -151,7 +155,7 @@ def main():
         st = step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -162,8 +166,8 @@ def main():
     # ---- roofline of the counting pipeline (this rank), SURVEY.md §8d: B_alg = N*L/4 + 2*I*W + D*W ----
     tm = ctx.timings()
     kernel_ms = sum(ms for _, ms in tm)
-    inst = st.kmer_instances() if world == 1 else st["instances"]
-    distinct = st.total_kmers() if world == 1 else st["distinct"]
+    inst = st.kmer_instances() if not sharded else st["instances"]
+    distinct = st.total_kmers() if not sharded else st["distinct"]
     W = 8 * nw
     b_alg = n_reads * L / 4 + 2 * inst * W + distinct * W
     achieved = b_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -172,7 +176,7 @@ def main():
     # gfx950 correction: profiles/r01/bench_k55A_10M_pmc_hbm_traffic.csv). Only valid for the workload it was taken on.
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01", "bench_k55A_10M_pmc_hbm_traffic.csv")
-    if world == 1 and K == 55 and args.mode == "A" and n_reads == 10_000_000 and nb == 16 and os.path.exists(pmc):
+    if not sharded and K == 55 and args.mode == "A" and n_reads == 10_000_000 and nb == 16 and os.path.exists(pmc):
         for line in open(pmc):
             if line.startswith("TOTAL"):
                 f = line.strip().split(",")
@@ -194,15 +198,15 @@ def main():
                                f"{nb} buckets, inputs resident in HBM",
                    "reads_per_gpu": n_reads, "k": K, "mode": args.mode, "num_buckets": nb,
                    "kmer_instances": int(inst), "distinct_kmers": int(distinct),
-                   "parallelism": "1 GPU" if world == 1 else f"{world} GPUs, bucket-range owners, one RCCL all-to-all"},
+                   "parallelism": "1 GPU" if not sharded else f"{world} GPU(s), bucket-range owners, one RCCL all-to-all"},
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_sharded:
         out["cpu_baseline"] = cpu_baseline(sample, K, args.mode, nb)
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -17,6 +17,9 @@ from . import _lib
 from .kmercount import Context, _chk
 
 
+XCHG_LIMIT = 1 << 27  # int64 elements (1 GiB) per pair and round
+
+
 def rank_first_bucket(num_buckets: int, world: int, rank: int) -> int:
     return (rank * num_buckets + world - 1) // world
 
@@ -63,8 +66,41 @@ def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
     rcounts = [int(c) for c in rcv_t.tolist()]
     n_recv = sum(rcounts)
     recv = engine.alloc(n_recv * nw, dev)
-    dist.all_to_all_single(recv[:n_recv * nw], send[:n_local * nw],
-                           output_split_sizes=[c * nw for c in rcounts], input_split_sizes=[c * nw for c in counts])
+    # The exchange proper. Splits are capped at XCHG_LIMIT elements per (pair, round): one all_to_all_single of a
+    # 30 GB buffer (3.8 G int64 elements) silently truncates on this stack (measured: tail left untouched), so large
+    # segments go in several rounds of views (no staging copies); every pair still moves each record exactly once.
+    soff = [0]
+    for c in counts:
+        soff.append(soff[-1] + c * nw)
+    roff = [0]
+    for c in rcounts:
+        roff.append(roff[-1] + c * nw)
+    mx = torch.tensor([max(counts) * nw if counts else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    rounds = max(1, -(-int(mx.item()) // XCHG_LIMIT))
+    if rounds == 1:
+        dist.all_to_all_single(recv[:n_recv * nw], send[:n_local * nw],
+                               output_split_sizes=[c * nw for c in rcounts], input_split_sizes=[c * nw for c in counts])
+    else:
+        # grouped point-to-point rounds on views (ncclSend/ncclRecv pairs under one group on RCCL): every pair has its own
+        # xGMI link, there is no ring to serialise on, and no staging copy is needed
+        for r in range(rounds):
+            ops = []
+            for p in range(world):
+                a = min(soff[p] + r * XCHG_LIMIT, soff[p + 1])
+                b = min(a + XCHG_LIMIT, soff[p + 1])
+                c = min(roff[p] + r * XCHG_LIMIT, roff[p + 1])
+                d = min(c + XCHG_LIMIT, roff[p + 1])
+                if p == rank:
+                    recv[c:d].copy_(send[a:b])
+                    continue
+                if b > a:
+                    ops.append(dist.P2POp(dist.isend, send[a:b], p))
+                if d > c:
+                    ops.append(dist.P2POp(dist.irecv, recv[c:d], p))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
     res = engine.count_records(K, nb, recv, n_recv)
     res["sent"], res["received"] = n_local, n_recv
     res["instances"] = n_local  # k-mer instances extracted from this rank's reads

@@ -65,12 +65,14 @@ class OracleEngine:
         return {"distinct": len(keyed), "instances": n, "bucket_sizes": sizes, "device_ptr": 0}
 
 
-def _worker(rank, world, port, K, mode, nb, q):
+def _worker(rank, world, port, K, mode, nb, q, limit=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from spades_amd import dist as smx_dist
+    if limit:
+        smx_dist.XCHG_LIMIT = limit  # force the multi-round point-to-point exchange
     reads = read_lines("reads_small.txt")[:120]
     eng = OracleEngine(reads[rank::world], mode)
     res = smx_dist.sharded_count(eng, K, nb, rank, world, torch.device("cpu"))
@@ -79,15 +81,15 @@ def _worker(rank, world, port, K, mode, nb, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,mode,nb", [(21, "A", 16), (33, "B", 10)])
-def test_sharded_count_world2_gloo(K, mode, nb):
+@pytest.mark.parametrize("K,mode,nb,limit", [(21, "A", 16, None), (33, "B", 10, None), (21, "A", 16, 1000)])
+def test_sharded_count_world2_gloo(K, mode, nb, limit):
     from oracle import oracle
     from spades_amd.dist import rank_first_bucket
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, K, mode, nb, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, K, mode, nb, q, limit)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=120) for _ in range(world))
