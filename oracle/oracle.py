@@ -55,6 +55,8 @@ def lib():
         _lib.orc_build_graph.restype = C.POINTER(OrcGraph)
         _lib.orc_build_graph.argtypes = [C.c_uint, C.c_uint, C.c_char_p, u64p, C.c_uint64, C.c_char_p]
         _lib.orc_graph_free.argtypes = [C.POINTER(OrcGraph)]
+        _lib.orc_build_graph_cov.restype = C.POINTER(OrcGraph)
+        _lib.orc_build_graph_cov.argtypes = [C.c_uint, C.c_uint, C.c_char_p, u64p, C.c_uint64, C.c_char_p, C.c_int]
     return _lib
 
 
@@ -130,12 +132,12 @@ def count_raw(bases: bytes, off: np.ndarray, K: int, mode: str = "A", num_bucket
     return rec, sizes
 
 
-def build_graph(reads: Sequence[str], k: int, num_buckets: int, flavour_version: str = "SPAdes-4.3.0-dev") -> dict:
+def build_graph(reads: Sequence[str], k: int, num_buckets: int, flavour_version: str = "SPAdes-4.3.0-dev", coverage: bool = False) -> dict:
     """spades-gbuilder restated: -> dict(kmers, masks, unitigs (list of str, reference order), n_loops, gfa (str), ...)."""
     bases, off = concat_reads(reads)
     off = np.ascontiguousarray(off, dtype=np.uint64)
-    g = lib().orc_build_graph(k, num_buckets, bases, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off) - 1,
-                              flavour_version.encode())
+    g = lib().orc_build_graph_cov(k, num_buckets, bases, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off) - 1,
+                                  flavour_version.encode(), 1 if coverage else 0)
     gc = g.contents
     nw = words(k)
     nk = gc.n_kmers

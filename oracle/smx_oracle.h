@@ -66,6 +66,9 @@ typedef struct {
 } orc_graph;
 orc_graph *orc_build_graph(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off,
                            uint64_t nreads, const char *flavour_version /* e.g. "SPAdes-4.3.0-dev" */);
+/* with_cov != 0: spades-gbuilder -c (coverage_hash_map_builder.hpp:18-39, coverage_filling.hpp:46-62): DP:f / KC:i tags */
+orc_graph *orc_build_graph_cov(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off,
+                               uint64_t nreads, const char *flavour_version, int with_cov);
 void orc_graph_free(orc_graph *g);
 
 #ifdef __cplusplus

@@ -160,8 +160,14 @@ static void sb_add(sbuf *b, const char *s, size_t n) {
 static void sb_printf_u64(sbuf *b, uint64_t v) { char t[32]; int n = snprintf(t, sizeof t, "%llu", (unsigned long long)v); sb_add(b, t, (size_t)n); }
 
 /* ---------------------------------------------------------------- the whole construction */
-orc_graph *orc_build_graph(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off, uint64_t nreads,
-                           const char *flavour_version) {
+/* ASCII -> code for the coverage pass (sequence/nucl.hpp dignucl) */
+static unsigned dig(char c) {
+    if (c >= 'a' && c <= 't') c = (char)(c - 'a' + 'A');
+    return c <= 'C' ? (c == 'A' ? 0u : 1u) : (c == 'G' ? 2u : 3u);
+}
+
+orc_graph *orc_build_graph_cov(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off, uint64_t nreads,
+                               const char *flavour_version, int with_cov) {
     orc_graph *g = (orc_graph *)calloc(1, sizeof *g);
     const unsigned K1 = k + 1, nw1 = orc_words(K1), nw = orc_words(k);
     /* STEP 1a: canonical (k+1)-mers, B buckets (kmer_extension_index_builder.hpp:72-75) */
@@ -223,7 +229,6 @@ orc_graph *orc_build_graph(unsigned k, unsigned num_buckets, const char *bases, 
         ix.mask[hp.idx] |= (uint8_t)(1u << (hp.minimal ? nnucl : 7 - nnucl));
         ix.mask[hs.idx] |= (uint8_t)(1u << (hs.minimal ? pnucl + 4 : 7 - (pnucl + 4)));
     }
-    free(kpo); free(kpo_sizes);
     g->kmers = (uint64_t *)malloc((ix.n ? ix.n : 1) * nw * 8);
     memcpy(g->kmers, ix.recs, ix.n * nw * 8);
     g->masks = (uint8_t *)malloc(ix.n ? ix.n : 1);
@@ -347,13 +352,66 @@ orc_graph *orc_build_graph(unsigned k, unsigned num_buckets, const char *bases, 
     qsort(uniq, nv, sizeof *uniq, vtx_cmp);
     g->n_vertices = nv;
 
+    /* STEP 3b (-c): CoverageHashMapBuilder::FillCoverageFromStream, ph_map/coverage_hash_map_builder.hpp:18-39: every
+     * (k+1)-mer instance of the read+RC stream that is minimal increments its counter (uint32); edge raw coverage =
+     * sum over the edge's (k+1)-mers (graph_support/coverage_filling.hpp:46-62), 32-bit (core/coverage.hpp:44-65) */
+    uint32_t *ecov = (uint32_t *)calloc(seqs.n ? seqs.n : 1, 4);
+    if (with_cov && nkpo > 0) {
+        kidx kx;
+        kx.k = K1; kx.nw = nw1; kx.nb = num_buckets; kx.n = (uint64_t)nkpo; kx.recs = kpo; kx.mask = NULL;
+        kx.boff = (uint64_t *)calloc(num_buckets + 1, 8);
+        for (unsigned bb = 0; bb < num_buckets; ++bb) kx.boff[bb + 1] = kx.boff[bb] + kpo_sizes[bb];
+        uint32_t *cnt = (uint32_t *)calloc((size_t)nkpo, 4);
+        unsigned char *fw = NULL, *rc = NULL; size_t bc = 0;
+        for (uint64_t r = 0; r < nreads; ++r) {
+            const char *sq = bases + off[r]; size_t n = (size_t)(off[r + 1] - off[r]), from, to;
+            orc_longest_valid(sq, n, &from, &to);
+            size_t len = to - from;
+            if (len < K1) continue;
+            if (len > bc) { bc = len * 2; fw = (unsigned char *)realloc(fw, bc); rc = (unsigned char *)realloc(rc, bc); }
+            for (size_t i = 0; i < len; ++i) fw[i] = (unsigned char)dig(sq[from + i]);
+            seq_rc(fw, len, rc);
+            for (int strand = 0; strand < 2; ++strand) {
+                const unsigned char *t = strand ? rc : fw;
+                for (size_t j = 0; j + K1 <= len; ++j) {
+                    uint64_t w[ORC_MAX_WORDS];
+                    kmer_from_codes(t + j, K1, w);
+                    if (!orc_is_minimal(w, K1)) continue;
+                    int64_t ix2 = kidx_find(&kx, w);
+                    if (ix2 >= 0) cnt[ix2] += 1;
+                }
+            }
+        }
+        free(fw); free(rc);
+        for (size_t i = 0; i < seqs.n; ++i) {
+            uint32_t raw = 0;
+            for (size_t j = 0; j + K1 <= seqs.len[i]; ++j) {
+                uint64_t w[ORC_MAX_WORDS], wr[ORC_MAX_WORDS];
+                kmer_from_codes(seqs.seq[i] + j, K1, w);
+                const uint64_t *c = w;
+                if (!orc_is_minimal(w, K1)) { orc_rc(w, K1, wr); c = wr; }
+                int64_t ix2 = kidx_find(&kx, c);
+                if (ix2 >= 0) raw += cnt[ix2];
+            }
+            ecov[i] = raw;
+        }
+        free(cnt); free(kx.boff);
+    }
+    free(kpo); free(kpo_sizes);
+
     /* STEP 4: GFA (gfa_writer.cpp) */
     sbuf out = {0, 0, 0};
     sb_add(&out, "H\tsp:Z:", 7); sb_add(&out, flavour_version, strlen(flavour_version)); sb_add(&out, "\n", 1);
     for (size_t i = 0; i < seqs.n; ++i) { /* canonical edges in id order; without -c coverage is 0 */
         sb_add(&out, "S\t", 2); sb_printf_u64(&out, min_id + 2 * i); sb_add(&out, "\t", 1);
         sb_add(&out, g->unitig_seq + g->unitig_off[i], seqs.len[i]);
-        sb_add(&out, "\tDP:f:0\tKC:i:0\n", 15);
+        if (!with_cov) sb_add(&out, "\tDP:f:0\tKC:i:0\n", 15);
+        else { /* "DP:f:" << float(cov) (default ostream formatting = %g, precision 6) << "KC:i:" << raw */
+            char t[64];
+            double cov = (double)ecov[i] / (double)(seqs.len[i] - k);
+            int tn = snprintf(t, sizeof t, "\tDP:f:%g\tKC:i:%u\n", (double)(float)cov, ecov[i]);
+            sb_add(&out, t, (size_t)tn);
+        }
     }
     for (size_t vn = 0; vn < nv; ++vn) { /* canonical vertices in id order = vertex_num order */
         size_t i0 = uniq[vn];
@@ -383,9 +441,14 @@ orc_graph *orc_build_graph(unsigned k, unsigned num_buckets, const char *bases, 
     if (!out.d) sb_add(&out, "", 0);
     g->gfa = out.d; g->gfa_len = out.n;
     for (size_t i = 0; i < seqs.n; ++i) free(seqs.seq[i]);
-    free(seqs.seq); free(seqs.len); free(b.d); free(rcbuf); free(recs); free(uniq); free(selfconj);
+    free(seqs.seq); free(seqs.len); free(b.d); free(rcbuf); free(recs); free(uniq); free(selfconj); free(ecov);
     free(ix.recs); free(ix.boff); free(ix.mask);
     return g;
+}
+
+orc_graph *orc_build_graph(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off, uint64_t nreads,
+                           const char *flavour_version) {
+    return orc_build_graph_cov(k, num_buckets, bases, off, nreads, flavour_version, 0);
 }
 
 void orc_graph_free(orc_graph *g) {

@@ -28,6 +28,21 @@ def test_gfa_matches_spades_gbuilder(case):
         assert g["gfa"] == open(os.path.join(GOLDEN, case["file"])).read()
 
 
+CCASES = [c for c in load_manifest()["cases"] if c["kind"] == "graph_cov"]
+
+
+@pytest.mark.parametrize("case", CCASES, ids=lambda c: f"{c['reads'][6:-4]}-k{c['K']}-t{c['threads']}")
+def test_gfa_with_coverage_matches_spades_gbuilder_c(case):
+    """-c: DP:f / KC:i tags (CoverageHashMapBuilder + FillCoverageAndFlankingFromPHM)."""
+    reads = [r for r in read_lines(case["reads"]) if r]
+    g = oracle.build_graph(reads, case["K"], case["num_buckets"], coverage=True)
+    assert g["gfa"] == open(os.path.join(GOLDEN, case["file"])).read()
+
+
+# Note: construction_test.cpp:97-106 (SimpleTestEarlyPairedInfo, coverage {CCAC:4, ...}) feeds a forward-only stream
+# (no RCWrap), which neither spades-gbuilder nor this boundary can express; coverage is pinned by the real-binary goldens above.
+
+
 # construction_test.cpp:30-64 (AssertGraph(k, reads, etalon_edges): edge set incl. reverse complements)
 KNOWN = [
     ("SimpleThread", ["ACAAACCACCA"], ["ACAAACCACCA"]),
