@@ -130,6 +130,12 @@ int smx_graph_info(const smx_ctx *ctx, uint64_t *info);
 int smx_graph_copy_kmers(const smx_ctx *ctx, void *kmers_host, uint8_t *masks_host);
 /* unitigs in the reference's enumeration order: offsets [n_unitigs+1], ACGT bytes */
 int smx_graph_copy_unitigs(const smx_ctx *ctx, uint64_t *offsets, char *seq);
+/* -c of spades-gbuilder: second pass over the resident reads. Replaces CoverageHashMapBuilder::BuildIndex
+ * (common/kmer_index/ph_map/coverage_hash_map_builder.hpp:16-57) + FillCoverageAndFlankingFromPHM
+ * (common/assembly_graph/graph_support/coverage_filling.hpp:17-96): per-(k+1)-mer uint32 multiplicities over the read+RC
+ * stream, summed per edge. Afterwards smx_graph_write_gfa emits DP:f:<raw/len>  KC:i:<raw> instead of zeros. */
+int smx_graph_fill_coverage(smx_ctx *ctx);
+int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage /* [n_unitigs] */);
 /* gfa::GFAWriter::WriteSegmentsAndLinks (common/io/graph/gfa_writer.cpp); flavour_version fills "H\tsp:Z:<..>" */
 int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_version);
 /* gbuilder --unitigs (gbuilder.cpp:191-200): >EDGE_<i>_length_<len>, wrapped at 60 */

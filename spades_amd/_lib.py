@@ -59,6 +59,8 @@ def load():
         "smx_graph_copy_kmers": (C.c_int, [vp, vp, vp]),
         "smx_graph_copy_unitigs": (C.c_int, [vp, u64p, vp]),
         "smx_graph_write_gfa": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
+        "smx_graph_fill_coverage": (C.c_int, [vp]),
+        "smx_graph_copy_coverage": (C.c_int, [vp, u32p]),
         "smx_graph_write_unitigs": (C.c_int, [vp, C.c_char_p]),
     }
     for name, (res, args) in sig.items():

@@ -61,7 +61,7 @@ struct smx_ctx {
     uint8_t *g_mask = nullptr;
     uint64_t g_nkpo = 0, g_nkmers = 0;
     unsigned g_k = 0, g_nw = 0, g_B = 0;
-    std::vector<uint64_t> g_kboff;
+    std::vector<uint64_t> g_kboff, g_kpoboff;
     bool g_ready = false;
     smxh::GraphHost gh;
 };
@@ -813,6 +813,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
     if (int rc = count_reads<NW>(ctx, k + 1, SMX_MODE_CANONICAL, B)) return rc;
     ctx->g_kpo = ctx->d_result_buf;
     ctx->g_nkpo = ctx->n_records;
+    ctx->g_kpoboff = ctx->bucket_off;
     ctx->d_result_buf = ctx->d_result = nullptr;
     free_temps(ctx, ctx->g_kpo);
     const uint64_t nkpo = ctx->g_nkpo;
@@ -1021,6 +1022,53 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
     smxh::build_links(ctx->gh);
     tend(ctx);
     ctx->g_ready = true;
+    return 0;
+}
+
+
+template <int NW>
+int run_coverage(smx_ctx *ctx) {
+    const unsigned K1 = ctx->g_k + 1, B = ctx->g_B;
+    const uint64_t D1 = ctx->g_nkpo, ne = ctx->gh.n_edges();
+    ctx->gh.ecov.assign(ne, 0);
+    if (D1 == 0 || ne == 0) return 0;
+    std::vector<uint64_t *> masks;
+    uint64_t nwin = 0;
+    if (int rc = mark_windows(ctx, K1, masks, &nwin)) return rc;
+    uint32_t *cnt, *ecov;
+    unsigned long long *d_boff, *d_eoff;
+    char *d_seq;
+    if (int rc = dalloc(ctx, &cnt, D1)) return rc;
+    if (int rc = dalloc(ctx, &ecov, ne)) return rc;
+    if (int rc = dalloc(ctx, &d_boff, B + 1)) return rc;
+    if (int rc = dalloc(ctx, &d_eoff, ne + 1)) return rc;
+    if (int rc = dalloc(ctx, &d_seq, ctx->gh.seq.size() + 1)) return rc;
+    HIPCHK(hipMemsetAsync(cnt, 0, D1 * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ecov, 0, ne * 4, ctx->stream));
+    std::vector<unsigned long long> hb(ctx->g_kpoboff.begin(), ctx->g_kpoboff.end()), he(ctx->gh.eoff.begin(), ctx->gh.eoff.end());
+    HIPCHK(hipMemcpyAsync(d_boff, hb.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_eoff, he.data(), (ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_seq, ctx->gh.seq.data(), ctx->gh.seq.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    tbegin(ctx, "kpo_coverage");
+    for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
+        const ReadChunk &ch = ctx->chunks[ci];
+        if (ch.n_bases == 0 || !masks[ci]) continue;
+        hipLaunchKernelGGL((k_kpo_coverage<NW>), dim3((unsigned)std::min<uint64_t>((ch.n_bases + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0,
+                           ctx->stream, (const uint64_t *)ch.d_words, (const uint64_t *)masks[ci], ch.n_bases, K1, (const void *)ctx->g_kpo,
+                           (const unsigned long long *)d_boff, B, cnt);
+        HIPCHK(hipGetLastError());
+    }
+    tend(ctx);
+    tbegin(ctx, "edge_coverage");
+    const uint64_t total = ctx->gh.seq.size();
+    hipLaunchKernelGGL((k_edge_coverage<NW>), dim3((unsigned)std::min<uint64_t>((total + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
+                       (const char *)d_seq, (const unsigned long long *)d_eoff, ne, total, K1, (const void *)ctx->g_kpo,
+                       (const unsigned long long *)d_boff, B, (const uint32_t *)cnt, ecov);
+    HIPCHK(hipGetLastError());
+    tend(ctx);
+    HIPCHK(hipMemcpyAsync(ctx->gh.ecov.data(), ecov, ne * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -1381,6 +1429,38 @@ int smx_graph_copy_unitigs(const smx_ctx *ctx, uint64_t *offsets, char *seq) {
     if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
     if (offsets) memcpy(offsets, ctx->gh.eoff.data(), ctx->gh.eoff.size() * 8);
     if (seq && !ctx->gh.seq.empty()) memcpy(seq, ctx->gh.seq.data(), ctx->gh.seq.size());
+    return SMX_OK;
+}
+
+int smx_graph_fill_coverage(smx_ctx *ctx) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    switch (ctx->g_nw) {
+        case 1: rc = run_coverage<1>(ctx); break;
+        case 2: rc = run_coverage<2>(ctx); break;
+        case 3: rc = run_coverage<3>(ctx); break;
+        default: rc = run_coverage<4>(ctx); break;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (rc == 0) tcollect(ctx);
+    else {
+        for (auto &t : ctx->timings) {
+            (void)hipEventDestroy(t.e0);
+            (void)hipEventDestroy(t.e1);
+        }
+        ctx->timings.clear();
+        ctx->gh.ecov.clear();
+    }
+    free_temps(ctx);
+    return rc;
+}
+
+int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage) {
+    if (!ctx || !ctx->g_ready || !raw_coverage) return SMX_INVALID_PARAMETER;
+    if (ctx->gh.ecov.size() != ctx->gh.n_edges()) return SMX_INVALID_PARAMETER;
+    if (!ctx->gh.ecov.empty()) memcpy(raw_coverage, ctx->gh.ecov.data(), ctx->gh.ecov.size() * 4);
     return SMX_OK;
 }
 

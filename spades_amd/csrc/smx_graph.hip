@@ -271,4 +271,52 @@ __global__ void k_gather_kmers(const void *kmers_, const uint32_t *list, uint32_
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = kmers[list[i]];
 }
 
+// ---- coverage (-c) -----------------------------------------------------------------------------------------------
+// CoverageHashMapBuilder::FillCoverageFromStream (kmer_index/ph_map/coverage_hash_map_builder.hpp:18-39): every
+// (k+1)-mer instance of the read+RC stream whose orientation is minimal increments the counter of its canonical
+// record. One window position contributes its canonical form once — twice when the (k+1)-mer is its own reverse
+// complement (both strand instances are minimal then).
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_kpo_coverage(const uint64_t *seq, const uint64_t *mask, uint64_t G, unsigned K1,
+                                                      const void *kpo_, const unsigned long long *boff, uint32_t B, uint32_t *cnt) {
+    const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
+    for (uint64_t g = (uint64_t)blockIdx.x * BLK + threadIdx.x; g < G; g += (uint64_t)gridDim.x * BLK) {
+        if (!((mask[g >> 6] >> (g & 63)) & 1)) continue;
+        Rec<NW> x = load_window<NW>(seq, g, K1);
+        Rec<NW> y = rec_rc<NW>(x, K1);
+        const bool pal = rec_eq<NW>(x, y);
+        const Rec<NW> c = rc_ge<NW>(y, x) ? x : y;
+        const uint32_t r = kmer_rank<NW>(kpo, boff, B, c);
+        if (r != NODE_NONE) atomicAdd(&cnt[r], pal ? 2u : 1u);
+    }
+}
+
+// edge raw coverage = sum of the counters of the edge's (k+1)-mers (graph_support/coverage_filling.hpp:46-62), uint32
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_edge_coverage(const char *seq, const unsigned long long *eoff, uint64_t n_edges, uint64_t total,
+                                                       unsigned K1, const void *kpo_, const unsigned long long *boff, uint32_t B,
+                                                       const uint32_t *cnt, uint32_t *ecov) {
+    const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
+    for (uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x; p < total; p += (uint64_t)gridDim.x * BLK) {
+        uint64_t lo = 0, hi = n_edges;  // edge e with eoff[e] <= p < eoff[e+1]
+        while (hi - lo > 1) {
+            uint64_t mid = (lo + hi) >> 1;
+            if (eoff[mid] <= p) lo = mid; else hi = mid;
+        }
+        if (p + K1 > eoff[lo + 1]) continue;
+        Rec<NW> x;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) x.w[w] = 0;
+        for (unsigned j = 0; j < K1; ++j) {
+            const char ch = seq[p + j];
+            const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+            x.w[j >> 5] |= code << ((j & 31) << 1);
+        }
+        unsigned f;
+        const Rec<NW> c = rec_canon<NW>(x, K1, f);
+        const uint32_t r = kmer_rank<NW>(kpo, boff, B, c);
+        if (r != NODE_NONE) atomicAdd(&ecov[lo], cnt[r]);
+    }
+}
+
 }  // namespace smx

@@ -27,6 +27,7 @@ struct GraphHost {
     std::vector<uint32_t> estart;  // node = 2*rank + rc of the first k-mer
     std::vector<uint32_t> eend;    // node of the last k-mer
     std::vector<uint8_t> eself;    // s == RC(s)
+    std::vector<uint32_t> ecov;    // raw coverage per edge (filled by smx_graph_fill_coverage; empty = no -c)
     uint64_t n_paths = 0, n_loops = 0, n_vertices = 0, n_links = 0;
     // link structure
     struct Rec {
@@ -255,7 +256,14 @@ inline bool write_gfa(GraphHost &g, FILE *f, const char *flavour_version) {
         w.num(min_id + 2 * i);
         w.add("\t");
         w.add(g.seq.data() + g.eoff[i], (size_t)(g.eoff[i + 1] - g.eoff[i]));
-        w.add("\tDP:f:0\tKC:i:0\n");
+        if (g.ecov.size() != ne) {
+            w.add("\tDP:f:0\tKC:i:0\n");
+        } else {  // "DP:f:" << float(cov) (ostream default = %g, 6 significant digits) ; cov = raw / #(k+1)-mers
+            char t[64];
+            const double cov = (double)g.ecov[i] / (double)(g.eoff[i + 1] - g.eoff[i] - g.k);
+            int tn = snprintf(t, sizeof t, "\tDP:f:%g\tKC:i:%u\n", (double)(float)cov, g.ecov[i]);
+            w.add(t, (size_t)tn);
+        }
     }
     g.n_links = 0;
     for (size_t vn = 0; vn < g.vstart.size(); ++vn) {

@@ -61,6 +61,15 @@ class GraphBuilder:
         b = seq.tobytes()
         return [b[int(off[i]):int(off[i + 1])].decode() for i in range(n)]
 
+    def fill_coverage(self):
+        """-c: CoverageHashMapBuilder + FillCoverageAndFlankingFromPHM (gbuilder.cpp:208-219)."""
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_fill_coverage(self.ctx._h))
+
+    def raw_coverage(self) -> np.ndarray:
+        out = np.zeros(self._info["n_unitigs"], dtype=np.uint32)
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_copy_coverage(self.ctx._h, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
     # -- step 4: outputs --
     def write_gfa(self, path: str, flavour_version: str = "SPAdes-4.3.0-dev"):
         _chk(self.ctx._h, self.ctx.lib.smx_graph_write_gfa(self.ctx._h, path.encode(), flavour_version.encode()))

@@ -1,9 +1,9 @@
 // spades_amd/tools/gbuilder_main.cpp — drop-in CLI for `spades-gbuilder`
 // (reference: projects/spades_tools/gbuilder.cpp:66-245; docs/standalone.md) over libspades_mi355x.so.
-//   spades-gbuilder-mi355x <fasta/fastq[.gz]> <out> [-k 21] [-t N] [-tmp-dir d] [-b n] [--unitigs|--gfa]
+//   spades-gbuilder-mi355x <fasta/fastq[.gz]> <out> [-k 21] [-c] [-t N] [-tmp-dir d] [-b n] [--unitigs|--gfa]
 // -t selects the bucket count 10*t and therefore the unitig/segment numbering of the reference run being
 // reproduced (SURVEY.md finding 3); default = the reference's default (cores/2+1 is host dependent, so 1 here).
-// Not in this build: YAML datasets, -c (coverage), --fastg, --spades.
+// Not in this build: YAML datasets, --fastg, --spades.
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +17,7 @@ int main(int argc, char **argv) {
     unsigned k = 21, nthreads = 1;
     std::string file, outfile;
     enum { UNITIGS, GFA } mode = UNITIGS;
+    bool coverage = false;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -32,7 +33,8 @@ int main(int argc, char **argv) {
         else if (a == "-tmp-dir" || a == "-b") (void)need();
         else if (a == "--unitigs" || a == "-unitigs") mode = UNITIGS;
         else if (a == "--gfa" || a == "-gfa") mode = GFA;
-        else if (a == "-c" || a == "--fastg" || a == "-fastg" || a == "--spades" || a == "-spades") {
+        else if (a == "-c") coverage = true;
+        else if (a == "--fastg" || a == "-fastg" || a == "--spades" || a == "-spades") {
             fprintf(stderr, "%s is not supported by this build\n", a.c_str());
             return SMX_INVALID_PARAMETER;
         } else if (!a.empty() && a[0] == '-') {
@@ -73,6 +75,10 @@ int main(int argc, char **argv) {
         }
         if (!rc) rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
         if (!rc) rc = smx_build_graph(ctx, k, 10 * nthreads);
+        if (!rc && coverage && mode == GFA) {
+            printf("Filling coverage index\n");
+            rc = smx_graph_fill_coverage(ctx);
+        }
         if (!rc) {
             uint64_t info[8];
             smx_graph_info(ctx, info);

@@ -46,6 +46,15 @@ def test_gbuilder_cli_matches_reference_gfa(tmp_path):
         assert open(out).read() == open(os.path.join(GOLDEN, c["file"])).read()
 
 
+def test_gbuilder_cli_coverage_flag(tmp_path):
+    c = [c for c in load_manifest()["cases"] if c["kind"] == "graph_cov" and c["reads"] == "reads_small.txt" and c["K"] == 21 and c["threads"] == 3][0]
+    fq = str(tmp_path / "r.fq")
+    _fastq(fq, [r for r in read_lines(c["reads"]) if r])
+    out = str(tmp_path / "g.gfa")
+    subprocess.check_call([GB, fq, out, "-k", "21", "-t", "3", "-c", "--gfa"], stdout=subprocess.DEVNULL)
+    assert open(out).read() == open(os.path.join(GOLDEN, c["file"])).read()
+
+
 def test_cli_exit_codes(tmp_path):
     # error_codes.hpp:14-20 — 65 file not found, 67 invalid parameter
     assert subprocess.call([KC, "-k", "21", "-w", str(tmp_path), "/nonexistent.fq"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 65

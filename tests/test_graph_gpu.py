@@ -37,6 +37,39 @@ def test_gfa_matches_spades_gbuilder(case, tmp_path):
         assert r["gfa"] == open(os.path.join(GOLDEN, case["file"])).read()
 
 
+CCASES = [c for c in load_manifest()["cases"] if c["kind"] == "graph_cov"]
+
+
+@pytest.mark.parametrize("case", CCASES, ids=lambda c: f"{c['reads'][6:-4]}-k{c['K']}-t{c['threads']}")
+def test_gfa_with_coverage_matches_spades_gbuilder_c(case, tmp_path):
+    from spades_amd.gbuilder import GraphBuilder
+    reads = [r for r in read_lines(case["reads"]) if r]
+    gb = GraphBuilder(case["K"], case["threads"])
+    gb.push_back_reads(reads)
+    gb.build()
+    gb.fill_coverage()
+    out = os.path.join(str(tmp_path), "g.gfa")
+    gb.write_gfa(out)
+    assert open(out).read() == open(os.path.join(GOLDEN, case["file"])).read()
+    gb.ctx.close()
+
+
+def test_coverage_vs_oracle_seeded(tmp_path):
+    from oracle import oracle
+    from spades_amd.gbuilder import GraphBuilder
+    for k, threads in ((21, 2), (55, 1), (77, 1)):
+        reads = _synth(5 + k, 6000, 1500, 150) + ["ACGT" * 40] * 3 + ["A" * 100] * 5
+        ref = oracle.build_graph(reads, k, 10 * threads, coverage=True)
+        gb = GraphBuilder(k, threads)
+        gb.push_back_reads(reads)
+        gb.build()
+        gb.fill_coverage()
+        out = os.path.join(str(tmp_path), f"g{k}.gfa")
+        gb.write_gfa(out)
+        assert open(out).read() == ref["gfa"]
+        gb.ctx.close()
+
+
 def _synth(seed, glen, n, L, err=0.01, nrate=0.002, circ=False):
     rng = np.random.default_rng(seed)
     g = rng.integers(0, 4, glen)
