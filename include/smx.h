@@ -138,6 +138,9 @@ int smx_graph_fill_coverage(smx_ctx *ctx);
 int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage /* [n_unitigs] */);
 /* gfa::GFAWriter::WriteSegmentsAndLinks (common/io/graph/gfa_writer.cpp); flavour_version fills "H\tsp:Z:<..>" */
 int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_version);
+/* gbuilder --spades (gbuilder.cpp:229-230): io::binary::BasicGraphIO::Save -> <basename>.grseq (common/io/binary/graph.hpp:27-74)
+ * + <basename>.cvr (common/io/binary/coverage.hpp:23-29) — the graph_pack surface spades-core loads. */
+int smx_graph_write_spades(smx_ctx *ctx, const char *basename);
 /* gbuilder --unitigs (gbuilder.cpp:191-200): >EDGE_<i>_length_<len>, wrapped at 60 */
 int smx_graph_write_unitigs(smx_ctx *ctx, const char *path);
 

@@ -1474,6 +1474,20 @@ int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_vers
     return ok ? SMX_OK : fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path);
 }
 
+int smx_graph_write_spades(smx_ctx *ctx, const char *basename) {
+    if (!ctx || !basename) return SMX_INVALID_PARAMETER;
+    if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
+    for (int part = 0; part < 2; ++part) {
+        std::string path = std::string(basename) + (part ? ".cvr" : ".grseq");
+        FILE *f = fopen(path.c_str(), "wb");
+        if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path.c_str());
+        bool ok = part ? smxh::write_cvr(ctx->gh, f) : smxh::write_grseq(ctx->gh, f);
+        if (fclose(f) != 0) ok = false;
+        if (!ok) return fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path.c_str());
+    }
+    return SMX_OK;
+}
+
 int smx_graph_write_unitigs(smx_ctx *ctx, const char *path) {
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
     if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");

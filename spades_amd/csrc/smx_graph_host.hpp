@@ -292,6 +292,115 @@ inline bool write_gfa(GraphHost &g, FILE *f, const char *flavour_version) {
     return w.ok();
 }
 
+// ---- SPAdes internal graph format (gbuilder --spades; BasicGraphIO::Save = GraphIO + CoverageIO) ---------------------
+// io/binary/graph.hpp:27-74: ULEB128 unsigned integers (io/binary/binary.hpp impl::Encoding), raw 1-byte bool, Sequence =
+// raw size_t length + packed 2-bit words (sequence/sequence.hpp:797-830).
+//   vreserved, ereserved, link_size, vertex_cnt ; for every vertex id in increasing order: SaveVertex(v) ; for every outgoing
+//   edge e1 (sorted by id) with e1 <= conj(e1): e1, conj(e1), SaveVertex(EdgeEnd(e1)), EdgeNucls(e1) ; 0.
+//   SaveVertex(v) = v, conj(v) and, the first time either of them is met, complex=false + overlap k.
+//   vreserved = 2V + V/100, ereserved = 2E + E/100 (ConstructGraph, debruijn_graph_constructor.hpp:513,554).
+// io/binary/coverage.hpp:23-29 (.cvr): (canonical edge id, raw coverage)* 0.
+inline void put_uleb(BufWriter &w, uint64_t v) {
+    char b[10];
+    int n = 0;
+    do {
+        uint8_t byte = v & 0x7f;
+        v >>= 7;
+        if (v) byte |= 0x80;
+        b[n++] = (char)byte;
+    } while (v);
+    w.add(b, (size_t)n);
+}
+
+inline bool write_grseq(const GraphHost &g, FILE *f) {
+    const uint64_t min_id = 3;
+    const size_t ne = g.n_edges(), nv = g.vstart.size();
+    BufWriter w(f);
+    put_uleb(w, 2 * nv + nv / 100);
+    put_uleb(w, 2 * ne + ne / 100);
+    put_uleb(w, 0);
+    put_uleb(w, 2 * nv);
+    // end vertex id of every edge orientation: canonical edge i ends at v (end record, !rc) or conj(v) (rc);
+    // conj(e) ends at conj(start vertex of e)
+    std::vector<uint64_t> end_c(ne, 0), end_r(ne, 0);
+    for (size_t vn = 0; vn < nv; ++vn) {
+        const size_t i0 = g.vstart[vn];
+        const uint64_t h = g.recs[i0].hash_and_mask >> 2;
+        for (size_t j = i0; j < g.recs.size() && (g.recs[j].hash_and_mask >> 2) == h; ++j) {
+            const size_t ei = (size_t)((g.recs[j].edge - min_id) >> 1);
+            const bool is_rc = (g.recs[j].hash_and_mask >> 1) & 1, is_start = g.recs[j].hash_and_mask & 1;
+            const uint64_t v = min_id + 2 * vn, cv = v + 1;
+            if (is_start) {  // e starts at (is_rc ? cv : v)  =>  conj(e) ends at conj of that
+                end_r[ei] = is_rc ? v : cv;
+                if (g.eself[ei]) end_c[ei] = end_r[ei];
+            } else {
+                end_c[ei] = is_rc ? cv : v;
+            }
+        }
+    }
+    std::vector<uint8_t> saved(nv, 0);
+    auto save_vertex = [&](uint64_t vid) {
+        const size_t vn = (size_t)((vid - min_id) >> 1);
+        const uint64_t v = min_id + 2 * vn;
+        put_uleb(w, vid);
+        put_uleb(w, vid == v ? v + 1 : v);
+        if (saved[vn]) return;
+        const char z = 0;
+        w.add(&z, 1);  // complex = false
+        put_uleb(w, g.k);
+        saved[vn] = 1;
+    };
+    std::vector<uint64_t> words;
+    for (size_t vn = 0; vn < nv; ++vn) {
+        uint64_t outv[8], outc[8];
+        size_t no, nc;
+        vertex_edges(g, vn, outv, no, outc, nc);
+        for (int o = 0; o < 2; ++o) {
+            save_vertex(min_id + 2 * vn + o);
+            const uint64_t *lst = o ? outc : outv;
+            const size_t n = o ? nc : no;
+            for (size_t a = 0; a < n; ++a) {
+                const uint64_t e1 = lst[a];
+                const size_t ei = (size_t)((e1 - min_id) >> 1);
+                const bool canon = ((e1 - min_id) & 1) == 0;
+                if (!canon) continue;  // conj(e1) < e1
+                const uint64_t e2 = g.eself[ei] ? e1 : e1 + 1;
+                put_uleb(w, e1);
+                put_uleb(w, e2);
+                save_vertex(end_c[ei]);
+                const uint64_t len = g.eoff[ei + 1] - g.eoff[ei];
+                w.add((const char *)&len, 8);
+                words.assign((size_t)((len + 31) / 32), 0);
+                const char *sq = g.seq.data() + g.eoff[ei];
+                for (uint64_t t = 0; t < len; ++t) {
+                    const char ch = sq[t];
+                    const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+                    words[(size_t)(t >> 5)] |= code << ((t & 31) << 1);
+                }
+                // short-sequence representation (< 60 nt, sequence.hpp:196-251): the inline 2-word buffer keeps its
+                // metadata byte [size:6 | rtl:1 | is_short:1] in the top byte of word 1, and BinWrite dumps it with the data
+                if (len > 32 && len < 60) words[1] |= (uint64_t)(((len & 0x3F) << 2) | 1) << 56;  // is_short_rep: size < 60
+                w.add((const char *)words.data(), words.size() * 8);
+            }
+            put_uleb(w, 0);
+        }
+    }
+    w.flush();
+    return w.ok();
+}
+
+inline bool write_cvr(const GraphHost &g, FILE *f) {
+    BufWriter w(f);
+    const size_t ne = g.n_edges();
+    for (size_t i = 0; i < ne; ++i) {
+        put_uleb(w, 3 + 2 * i);
+        put_uleb(w, g.ecov.size() == ne ? g.ecov[i] : 0);
+    }
+    put_uleb(w, 0);
+    w.flush();
+    return w.ok();
+}
+
 // gbuilder --unitigs: ">EDGE_<i>_length_<len>" + sequence wrapped at 60 (gbuilder.cpp:191-200)
 inline bool write_unitigs_fasta(const GraphHost &g, FILE *f) {
     BufWriter w(f);

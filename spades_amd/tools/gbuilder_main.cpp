@@ -1,9 +1,9 @@
 // spades_amd/tools/gbuilder_main.cpp — drop-in CLI for `spades-gbuilder`
 // (reference: projects/spades_tools/gbuilder.cpp:66-245; docs/standalone.md) over libspades_mi355x.so.
-//   spades-gbuilder-mi355x <fasta/fastq[.gz]> <out> [-k 21] [-c] [-t N] [-tmp-dir d] [-b n] [--unitigs|--gfa]
+//   spades-gbuilder-mi355x <fasta/fastq[.gz]> <out> [-k 21] [-c] [-t N] [-tmp-dir d] [-b n] [--unitigs|--gfa|--spades]
 // -t selects the bucket count 10*t and therefore the unitig/segment numbering of the reference run being
 // reproduced (SURVEY.md finding 3); default = the reference's default (cores/2+1 is host dependent, so 1 here).
-// Not in this build: YAML datasets, --fastg, --spades.
+// Not in this build: YAML datasets, --fastg.
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +16,7 @@
 int main(int argc, char **argv) {
     unsigned k = 21, nthreads = 1;
     std::string file, outfile;
-    enum { UNITIGS, GFA } mode = UNITIGS;
+    enum { UNITIGS, GFA, SPADES } mode = UNITIGS;
     bool coverage = false;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
@@ -34,7 +34,8 @@ int main(int argc, char **argv) {
         else if (a == "--unitigs" || a == "-unitigs") mode = UNITIGS;
         else if (a == "--gfa" || a == "-gfa") mode = GFA;
         else if (a == "-c") coverage = true;
-        else if (a == "--fastg" || a == "-fastg" || a == "--spades" || a == "-spades") {
+        else if (a == "--spades" || a == "-spades") mode = SPADES;
+        else if (a == "--fastg" || a == "-fastg") {
             fprintf(stderr, "%s is not supported by this build\n", a.c_str());
             return SMX_INVALID_PARAMETER;
         } else if (!a.empty() && a[0] == '-') {
@@ -44,7 +45,7 @@ int main(int argc, char **argv) {
     }
     if (pos.size() != 2) {
         fprintf(stderr, "usage: %s <dataset description (in YAML) or input FASTA file> <output filename> [-k value] [-t value] "
-                        "[-tmp-dir dir] [-b value] [--unitigs|--gfa]\n", argv[0]);
+                        "[-tmp-dir dir] [-b value] [--unitigs|--gfa|--spades]\n", argv[0]);
         return SMX_INVALID_PARAMETER;
     }
     file = pos[0];
@@ -75,7 +76,7 @@ int main(int argc, char **argv) {
         }
         if (!rc) rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
         if (!rc) rc = smx_build_graph(ctx, k, 10 * nthreads);
-        if (!rc && coverage && mode == GFA) {
+        if (!rc && coverage && mode != UNITIGS) {
             printf("Filling coverage index\n");
             rc = smx_graph_fill_coverage(ctx);
         }
@@ -85,7 +86,8 @@ int main(int argc, char **argv) {
             printf("Extracting unbranching paths finished. %llu sequences extracted\n", (unsigned long long)(info[2] - info[3]));
             printf("Collecting perfect loops finished. %llu loops collected\n", (unsigned long long)info[3]);
             printf("Saving %s to %s\n", mode == GFA ? "graph" : "unitigs", outfile.c_str());
-            rc = mode == GFA ? smx_graph_write_gfa(ctx, outfile.c_str(), "SPAdes-4.3.0-dev") : smx_graph_write_unitigs(ctx, outfile.c_str());
+            rc = mode == GFA ? smx_graph_write_gfa(ctx, outfile.c_str(), "SPAdes-4.3.0-dev")
+                 : mode == SPADES ? smx_graph_write_spades(ctx, outfile.c_str()) : smx_graph_write_unitigs(ctx, outfile.c_str());
         }
         if (rc) fprintf(stderr, "%s\n", smx_last_error(ctx));
     } catch (const std::string &s) {

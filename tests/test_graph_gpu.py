@@ -54,6 +54,25 @@ def test_gfa_with_coverage_matches_spades_gbuilder_c(case, tmp_path):
     gb.ctx.close()
 
 
+SCASES = [c for c in load_manifest()["cases"] if c["kind"] == "graph_spades"]
+
+
+@pytest.mark.parametrize("case", SCASES, ids=lambda c: c["base"])
+def test_spades_internal_format_matches_gbuilder(case, tmp_path):
+    """--spades: .grseq + .cvr byte-identical to io::binary::BasicGraphIO::Save of the real binary."""
+    from spades_amd.gbuilder import GraphBuilder
+    gb = GraphBuilder(case["K"], case["threads"])
+    gb.push_back_reads([r for r in read_lines(case["reads"]) if r])
+    gb.build()
+    if case["coverage"]:
+        gb.fill_coverage()
+    base = os.path.join(str(tmp_path), "sp")
+    gb.write_spades(base)
+    for ext in (".grseq", ".cvr"):
+        assert open(base + ext, "rb").read() == open(os.path.join(GOLDEN, case["base"] + ext), "rb").read(), ext
+    gb.ctx.close()
+
+
 def test_coverage_vs_oracle_seeded(tmp_path):
     from oracle import oracle
     from spades_amd.gbuilder import GraphBuilder
