@@ -55,6 +55,16 @@ def test_gbuilder_cli_coverage_flag(tmp_path):
     assert open(out).read() == open(os.path.join(GOLDEN, c["file"])).read()
 
 
+def test_gbuilder_cli_spades_format(tmp_path):
+    c = [c for c in load_manifest()["cases"] if c["kind"] == "graph_spades" and c["base"] == "spades_small_k21_t3_c"][0]
+    fq = str(tmp_path / "r.fq")
+    _fastq(fq, [r for r in read_lines(c["reads"]) if r])
+    out = str(tmp_path / "sp")
+    subprocess.check_call([GB, fq, out, "-k", "21", "-t", "3", "-c", "--spades"], stdout=subprocess.DEVNULL)
+    for ext in (".grseq", ".cvr"):
+        assert open(out + ext, "rb").read() == open(os.path.join(GOLDEN, c["base"] + ext), "rb").read()
+
+
 def test_cli_exit_codes(tmp_path):
     # error_codes.hpp:14-20 — 65 file not found, 67 invalid parameter
     assert subprocess.call([KC, "-k", "21", "-w", str(tmp_path), "/nonexistent.fq"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 65
