@@ -231,6 +231,10 @@ struct Tune {
     static constexpr int RPT = (NW <= 2) ? 16 : 8;                        // records per thread in a scatter tile (RPT 8 at NW=2: L1 scatter 32.5 vs 20.6 ms)
     static constexpr uint32_t CAP = (NW == 1) ? 4096 : (NW == 2 ? 2048 : 1024);  // LDS-sortable leaf (larger caps measured slower)
     static constexpr int LPT = CAP / BLK;
+    // level 1 (extraction from reads). Measured at NW=2, 10 M reads: tiles of 2048 records 32.3 ms (64 or 256 bins alike),
+    // 4096 records 20.6 ms, 8192 records 29.2 ms -> 4096 records, 256 bins.
+    static constexpr int RPT1 = RPT;
+    static constexpr uint32_t FMAX1 = FMAX;
     // fan-out per MSD level: runs of >= 16 records (>= 256 B) per bin and tile on average keep the scattered
     // writes at streaming speed and the reservation atomics at <= 1/16 per record (tools/ubench.hip);
     // 512 bins (128-B average runs) measured 1.6x slower on the level-1 scatter
@@ -246,7 +250,7 @@ size_t scatter_lds(uint32_t F) {
 template <int NW, int BINF>
 int pass_reads(smx_ctx *ctx, int mode, bool scatter, PassArgs a, const std::vector<uint64_t *> &masks,
                const std::vector<std::pair<uint64_t, uint64_t>> *ranges = nullptr) {
-    constexpr int RPT = Tune<NW>::RPT;
+    constexpr int RPT = Tune<NW>::RPT1;
     for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
         const ReadChunk &ch = ctx->chunks[ci];
         if (ch.n_bases == 0 || !masks[ci]) continue;
@@ -390,7 +394,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     unsigned fbits = 0;
     while ((2u << fbits) <= Tune<NW>::FMAX) ++fbits;  // floor(log2(FMAX))
     unsigned s1 = 0;
-    while (s1 < bits && ((uint64_t)B << (s1 + 1)) <= Tune<NW>::FMAX) ++s1;
+    while (s1 < bits && ((uint64_t)B << (s1 + 1)) <= (from_reads ? Tune<NW>::FMAX1 : Tune<NW>::FMAX)) ++s1;
     std::vector<unsigned> lv;  // bits of levels 2..
     if (ctx->opt_s1 >= 0 || ctx->opt_s2 >= 0) {  // test hook: explicit split
         s1 = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_s1, 0), std::min(avail, 12u));
