@@ -231,14 +231,14 @@ struct Tune {
     static constexpr int RPT = (NW <= 2) ? 16 : 8;                        // records per thread in a scatter tile (RPT 8 at NW=2: L1 scatter 32.5 vs 20.6 ms)
     static constexpr uint32_t CAP = (NW == 1) ? 4096 : (NW == 2 ? 2048 : 1024);  // LDS-sortable leaf (larger caps measured slower)
     static constexpr int LPT = CAP / BLK;
-    // level 1 (extraction from reads). Measured at NW=2, 10 M reads: tiles of 2048 records 32.3 ms (64 or 256 bins alike),
-    // 4096 records 20.6 ms, 8192 records 29.2 ms -> 4096 records, 256 bins.
-    static constexpr int RPT1 = RPT;
-    static constexpr uint32_t FMAX1 = FMAX;
     // fan-out per MSD level: runs of >= 16 records (>= 256 B) per bin and tile on average keep the scattered
     // writes at streaming speed and the reservation atomics at <= 1/16 per record (tools/ubench.hip);
     // 512 bins (128-B average runs) measured 1.6x slower on the level-1 scatter
     static constexpr uint32_t FMAX = RPT * BLK / 16;
+    // level 1 (extraction from reads). Measured at NW=2, 10 M reads: tiles of 2048 records 32.3 ms (64 or 256 bins alike),
+    // 4096 records 20.6 ms, 8192 records 29.2 ms -> 4096 records, 256 bins.
+    static constexpr int RPT1 = RPT;
+    static constexpr uint32_t FMAX1 = FMAX;
 };
 
 template <int NW, int RPT>
