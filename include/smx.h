@@ -138,6 +138,8 @@ int smx_graph_fill_coverage(smx_ctx *ctx);
 int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage /* [n_unitigs] */);
 /* gfa::GFAWriter::WriteSegmentsAndLinks (common/io/graph/gfa_writer.cpp); flavour_version fills "H\tsp:Z:<..>" */
 int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_version);
+/* gbuilder --fastg (gbuilder.cpp:226-228): io::FastgWriter::WriteSegmentsAndLinks (common/io/graph/fastg_writer.cpp:21-48) */
+int smx_graph_write_fastg(smx_ctx *ctx, const char *path);
 /* gbuilder --spades (gbuilder.cpp:229-230): io::binary::BasicGraphIO::Save -> <basename>.grseq (common/io/binary/graph.hpp:27-74)
  * + <basename>.cvr (common/io/binary/coverage.hpp:23-29) — the graph_pack surface spades-core loads. */
 int smx_graph_write_spades(smx_ctx *ctx, const char *basename);

@@ -63,6 +63,7 @@ def load():
         "smx_graph_copy_coverage": (C.c_int, [vp, u32p]),
         "smx_graph_write_unitigs": (C.c_int, [vp, C.c_char_p]),
         "smx_graph_write_spades": (C.c_int, [vp, C.c_char_p]),
+        "smx_graph_write_fastg": (C.c_int, [vp, C.c_char_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

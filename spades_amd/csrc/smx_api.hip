@@ -1478,6 +1478,16 @@ int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_vers
     return ok ? SMX_OK : fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path);
 }
 
+int smx_graph_write_fastg(smx_ctx *ctx, const char *path) {
+    if (!ctx || !path) return SMX_INVALID_PARAMETER;
+    if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
+    bool ok = smxh::write_fastg(ctx->gh, f);
+    if (fclose(f) != 0) ok = false;
+    return ok ? SMX_OK : fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path);
+}
+
 int smx_graph_write_spades(smx_ctx *ctx, const char *basename) {
     if (!ctx || !basename) return SMX_INVALID_PARAMETER;
     if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");

@@ -312,6 +312,30 @@ inline void put_uleb(BufWriter &w, uint64_t v) {
     w.add(b, (size_t)n);
 }
 
+// end vertex id of every edge orientation: canonical edge i ends at v (end record, !rc) or conj(v) (rc);
+// conj(e) ends at conj(start vertex of e)   (LinkEdge, debruijn_graph_constructor.hpp:491-500)
+inline void edge_end_vertices(const GraphHost &g, std::vector<uint64_t> &end_c, std::vector<uint64_t> &end_r) {
+    const uint64_t min_id = 3;
+    const size_t ne = g.n_edges(), nv = g.vstart.size();
+    end_c.assign(ne, 0);
+    end_r.assign(ne, 0);
+    for (size_t vn = 0; vn < nv; ++vn) {
+        const size_t i0 = g.vstart[vn];
+        const uint64_t h = g.recs[i0].hash_and_mask >> 2;
+        for (size_t j = i0; j < g.recs.size() && (g.recs[j].hash_and_mask >> 2) == h; ++j) {
+            const size_t ei = (size_t)((g.recs[j].edge - min_id) >> 1);
+            const bool is_rc = (g.recs[j].hash_and_mask >> 1) & 1, is_start = g.recs[j].hash_and_mask & 1;
+            const uint64_t v = min_id + 2 * vn, cv = v + 1;
+            if (is_start) {
+                end_r[ei] = is_rc ? v : cv;
+                if (g.eself[ei]) end_c[ei] = end_r[ei];
+            } else {
+                end_c[ei] = is_rc ? cv : v;
+            }
+        }
+    }
+}
+
 inline bool write_grseq(const GraphHost &g, FILE *f) {
     const uint64_t min_id = 3;
     const size_t ne = g.n_edges(), nv = g.vstart.size();
@@ -320,24 +344,8 @@ inline bool write_grseq(const GraphHost &g, FILE *f) {
     put_uleb(w, 2 * ne + ne / 100);
     put_uleb(w, 0);
     put_uleb(w, 2 * nv);
-    // end vertex id of every edge orientation: canonical edge i ends at v (end record, !rc) or conj(v) (rc);
-    // conj(e) ends at conj(start vertex of e)
-    std::vector<uint64_t> end_c(ne, 0), end_r(ne, 0);
-    for (size_t vn = 0; vn < nv; ++vn) {
-        const size_t i0 = g.vstart[vn];
-        const uint64_t h = g.recs[i0].hash_and_mask >> 2;
-        for (size_t j = i0; j < g.recs.size() && (g.recs[j].hash_and_mask >> 2) == h; ++j) {
-            const size_t ei = (size_t)((g.recs[j].edge - min_id) >> 1);
-            const bool is_rc = (g.recs[j].hash_and_mask >> 1) & 1, is_start = g.recs[j].hash_and_mask & 1;
-            const uint64_t v = min_id + 2 * vn, cv = v + 1;
-            if (is_start) {  // e starts at (is_rc ? cv : v)  =>  conj(e) ends at conj of that
-                end_r[ei] = is_rc ? v : cv;
-                if (g.eself[ei]) end_c[ei] = end_r[ei];
-            } else {
-                end_c[ei] = is_rc ? cv : v;
-            }
-        }
-    }
+    std::vector<uint64_t> end_c, end_r;
+    edge_end_vertices(g, end_c, end_r);
     std::vector<uint8_t> saved(nv, 0);
     auto save_vertex = [&](uint64_t vid) {
         const size_t vn = (size_t)((vid - min_id) >> 1);
@@ -397,6 +405,62 @@ inline bool write_cvr(const GraphHost &g, FILE *f) {
         put_uleb(w, g.ecov.size() == ne ? g.ecov[i] : 0);
     }
     put_uleb(w, 0);
+    w.flush();
+    return w.ok();
+}
+
+// gbuilder --fastg: io::FastgWriter::WriteSegmentsAndLinks (io/graph/fastg_writer.cpp:21-48). Every edge (both orientations,
+// id order): ">" name(e) [":" names of the outgoing edges of EdgeEnd(e), as a sorted std::set<std::string>, ","-joined] ";"
+// name(e) = EDGE_<canonical id>_length_<nt>_cov_<std::to_string(double)> + "'" for the non-canonical orientation
+// (io/utils/edge_namer.hpp:31-37,72-92, io/reads/header_naming.hpp:15-25); sequence wrapped at 60.
+inline bool write_fastg(const GraphHost &g, FILE *f) {
+    const uint64_t min_id = 3;
+    const size_t ne = g.n_edges();
+    BufWriter w(f);
+    std::vector<uint64_t> end_c, end_r;
+    edge_end_vertices(g, end_c, end_r);
+    auto name = [&](uint64_t e) {
+        const size_t ei = (size_t)((e - min_id) >> 1);
+        const uint64_t len = g.eoff[ei + 1] - g.eoff[ei];
+        const double cov = g.ecov.size() == ne ? (double)g.ecov[ei] / (double)(len - g.k) : 0.0;
+        char t[96];
+        snprintf(t, sizeof t, "EDGE_%llu_length_%llu_cov_%f", (unsigned long long)(min_id + 2 * ei), (unsigned long long)len, cov);
+        std::string s(t);
+        if ((e - min_id) & 1) s += "'";
+        return s;
+    };
+    for (size_t i = 0; i < ne; ++i) {
+        for (int o = 0; o < (g.eself[i] ? 1 : 2); ++o) {
+            const uint64_t e = min_id + 2 * i + o;
+            const uint64_t endv = o ? end_r[i] : end_c[i];
+            std::vector<std::string> next;
+            if (endv >= min_id) {
+                uint64_t outv[8], outc[8];
+                size_t no, nc;
+                vertex_edges(g, (size_t)((endv - min_id) >> 1), outv, no, outc, nc);
+                const uint64_t *lst = ((endv - min_id) & 1) ? outc : outv;
+                const size_t n = ((endv - min_id) & 1) ? nc : no;
+                for (size_t a = 0; a < n; ++a) next.push_back(name(lst[a]));
+                std::sort(next.begin(), next.end());
+                next.erase(std::unique(next.begin(), next.end()), next.end());
+            }
+            w.add(">");
+            std::string hdr = name(e);
+            w.add(hdr.data(), hdr.size());
+            for (size_t a = 0; a < next.size(); ++a) {
+                w.add(a ? "," : ":");
+                w.add(next[a].data(), next[a].size());
+            }
+            w.add(";\n");
+            const uint64_t len = g.eoff[i + 1] - g.eoff[i];
+            std::string sq(g.seq.data() + g.eoff[i], (size_t)len);
+            if (o) sq = revcomp(sq);
+            for (uint64_t p = 0; p < len; p += 60) {
+                w.add(sq.data() + p, (size_t)std::min<uint64_t>(60, len - p));
+                w.add("\n");
+            }
+        }
+    }
     w.flush();
     return w.ok();
 }

@@ -74,6 +74,9 @@ class GraphBuilder:
     def write_gfa(self, path: str, flavour_version: str = "SPAdes-4.3.0-dev"):
         _chk(self.ctx._h, self.ctx.lib.smx_graph_write_gfa(self.ctx._h, path.encode(), flavour_version.encode()))
 
+    def write_fastg(self, path: str):
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_write_fastg(self.ctx._h, path.encode()))
+
     def write_spades(self, basename: str):
         """--spades: <basename>.grseq + <basename>.cvr (io::binary::BasicGraphIO::Save)."""
         _chk(self.ctx._h, self.ctx.lib.smx_graph_write_spades(self.ctx._h, basename.encode()))

@@ -1,9 +1,9 @@
 // spades_amd/tools/gbuilder_main.cpp — drop-in CLI for `spades-gbuilder`
 // (reference: projects/spades_tools/gbuilder.cpp:66-245; docs/standalone.md) over libspades_mi355x.so.
-//   spades-gbuilder-mi355x <fasta/fastq[.gz]> <out> [-k 21] [-c] [-t N] [-tmp-dir d] [-b n] [--unitigs|--gfa|--spades]
+//   spades-gbuilder-mi355x <fasta/fastq[.gz]> <out> [-k 21] [-c] [-t N] [-tmp-dir d] [-b n] [--unitigs|--fastg|--gfa|--spades]
 // -t selects the bucket count 10*t and therefore the unitig/segment numbering of the reference run being
 // reproduced (SURVEY.md finding 3); default = the reference's default (cores/2+1 is host dependent, so 1 here).
-// Not in this build: YAML datasets, --fastg.
+// Not in this build: YAML datasets.
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +16,7 @@
 int main(int argc, char **argv) {
     unsigned k = 21, nthreads = 1;
     std::string file, outfile;
-    enum { UNITIGS, GFA, SPADES } mode = UNITIGS;
+    enum { UNITIGS, GFA, SPADES, FASTG } mode = UNITIGS;
     bool coverage = false;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
@@ -35,17 +35,15 @@ int main(int argc, char **argv) {
         else if (a == "--gfa" || a == "-gfa") mode = GFA;
         else if (a == "-c") coverage = true;
         else if (a == "--spades" || a == "-spades") mode = SPADES;
-        else if (a == "--fastg" || a == "-fastg") {
-            fprintf(stderr, "%s is not supported by this build\n", a.c_str());
-            return SMX_INVALID_PARAMETER;
-        } else if (!a.empty() && a[0] == '-') {
+        else if (a == "--fastg" || a == "-fastg") mode = FASTG;
+        else if (!a.empty() && a[0] == '-') {
             fprintf(stderr, "Invalid command line arguments\n");
             return SMX_INVALID_PARAMETER;
         } else pos.push_back(a);
     }
     if (pos.size() != 2) {
         fprintf(stderr, "usage: %s <dataset description (in YAML) or input FASTA file> <output filename> [-k value] [-t value] "
-                        "[-tmp-dir dir] [-b value] [--unitigs|--gfa|--spades]\n", argv[0]);
+                        "[-tmp-dir dir] [-b value] [--unitigs|--fastg|--gfa|--spades]\n", argv[0]);
         return SMX_INVALID_PARAMETER;
     }
     file = pos[0];
@@ -87,7 +85,8 @@ int main(int argc, char **argv) {
             printf("Collecting perfect loops finished. %llu loops collected\n", (unsigned long long)info[3]);
             printf("Saving %s to %s\n", mode == GFA ? "graph" : "unitigs", outfile.c_str());
             rc = mode == GFA ? smx_graph_write_gfa(ctx, outfile.c_str(), "SPAdes-4.3.0-dev")
-                 : mode == SPADES ? smx_graph_write_spades(ctx, outfile.c_str()) : smx_graph_write_unitigs(ctx, outfile.c_str());
+                 : mode == SPADES ? smx_graph_write_spades(ctx, outfile.c_str())
+                 : mode == FASTG ? smx_graph_write_fastg(ctx, outfile.c_str()) : smx_graph_write_unitigs(ctx, outfile.c_str());
         }
         if (rc) fprintf(stderr, "%s\n", smx_last_error(ctx));
     } catch (const std::string &s) {

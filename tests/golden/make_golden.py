@@ -197,6 +197,21 @@ def main():
                     open(os.path.join(HERE, base + ext), "wb").write(open(out + ext, "rb").read())
                 manifest["cases"].append({"kind": "graph_spades", "reads": f"reads_{name}.txt", "K": K, "threads": T, "num_buckets": 10 * T,
                                           "coverage": cov, "base": base, "source": "spades-gbuilder binary (survey build), --spades"})
+        # --fastg (io/graph/fastg_writer.cpp)
+        for name, K, T, cov in (("tiny", 21, 1, False), ("small", 21, 3, True), ("loop", 21, 1, True), ("polyA", 21, 1, False)):
+            reads = [r for r in gsets[name][1] if r]
+            with tempfile.TemporaryDirectory() as td:
+                fq = os.path.join(td, "r.fq")
+                with open(fq, "w") as f:
+                    for i, r in enumerate(reads):
+                        f.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n")
+                out = os.path.join(td, "g.fastg")
+                subprocess.check_call([gb, fq, out, "-k", str(K), "-t", str(T), "--fastg", "-tmp-dir", os.path.join(td, "t")] + (["-c"] if cov else []),
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                fn = f"fastg_{name}_k{K}_t{T}{'_c' if cov else ''}.fastg"
+                open(os.path.join(HERE, fn), "w").write(open(out).read())
+                manifest["cases"].append({"kind": "graph_fastg", "reads": f"reads_{name}.txt", "K": K, "threads": T, "num_buckets": 10 * T,
+                                          "coverage": cov, "file": fn, "source": "spades-gbuilder binary (survey build), --fastg"})
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
     print(f"{len(manifest['cases'])} cases written")
 

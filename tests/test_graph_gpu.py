@@ -73,6 +73,23 @@ def test_spades_internal_format_matches_gbuilder(case, tmp_path):
     gb.ctx.close()
 
 
+FCASES = [c for c in load_manifest()["cases"] if c["kind"] == "graph_fastg"]
+
+
+@pytest.mark.parametrize("case", FCASES, ids=lambda c: c["file"])
+def test_fastg_matches_gbuilder(case, tmp_path):
+    from spades_amd.gbuilder import GraphBuilder
+    gb = GraphBuilder(case["K"], case["threads"])
+    gb.push_back_reads([r for r in read_lines(case["reads"]) if r])
+    gb.build()
+    if case["coverage"]:
+        gb.fill_coverage()
+    out = os.path.join(str(tmp_path), "g.fastg")
+    gb.write_fastg(out)
+    assert open(out).read() == open(os.path.join(GOLDEN, case["file"])).read()
+    gb.ctx.close()
+
+
 def test_coverage_vs_oracle_seeded(tmp_path):
     from oracle import oracle
     from spades_amd.gbuilder import GraphBuilder
