@@ -50,7 +50,11 @@ void smx_destroy(smx_ctx *ctx);
 const char *smx_last_error(const smx_ctx *ctx);
 const char *smx_version(void);
 /* Tuning / test hooks (no reference equivalent; closest is the -b buffer-size knob of
- * kmercount.cpp:139): "leaf_cap" (records sorted per LDS leaf), "s1"/"s2" (MSD split bits). */
+ * kmercount.cpp:139): "leaf_cap" (records sorted per LDS leaf), "s1"/"s2" (MSD split bits), "batch_records" (force HBM-bounded batches).
+ * Construction variant of spades-core (DeBruijnGraphExtentionConstructor::ConstructGraph(keep_perfect_loops),
+ * common/assembly_graph/construction/debruijn_graph_constructor.hpp:590-604; config key construction.keep_perfect_loops):
+ * "sort_edges" = 1 orders the unitigs by Sequence::RawCompare before ids are assigned (thread-independent ids),
+ * "keep_perfect_loops" = 0 drops perfect loops. Defaults (0, 1) reproduce spades-gbuilder. */
 int smx_set_option(smx_ctx *ctx, const char *key, int64_t value);
 
 /* ---- reads -> HBM -------------------------------------------------------------------------

@@ -57,6 +57,8 @@ def lib():
         _lib.orc_graph_free.argtypes = [C.POINTER(OrcGraph)]
         _lib.orc_build_graph_cov.restype = C.POINTER(OrcGraph)
         _lib.orc_build_graph_cov.argtypes = [C.c_uint, C.c_uint, C.c_char_p, u64p, C.c_uint64, C.c_char_p, C.c_int]
+        _lib.orc_build_graph_ex.restype = C.POINTER(OrcGraph)
+        _lib.orc_build_graph_ex.argtypes = [C.c_uint, C.c_uint, C.c_char_p, u64p, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_int]
     return _lib
 
 
@@ -132,12 +134,13 @@ def count_raw(bases: bytes, off: np.ndarray, K: int, mode: str = "A", num_bucket
     return rec, sizes
 
 
-def build_graph(reads: Sequence[str], k: int, num_buckets: int, flavour_version: str = "SPAdes-4.3.0-dev", coverage: bool = False) -> dict:
+def build_graph(reads: Sequence[str], k: int, num_buckets: int, flavour_version: str = "SPAdes-4.3.0-dev", coverage: bool = False,
+                sort_edges: bool = False, keep_loops: bool = True) -> dict:
     """spades-gbuilder restated: -> dict(kmers, masks, unitigs (list of str, reference order), n_loops, gfa (str), ...)."""
     bases, off = concat_reads(reads)
     off = np.ascontiguousarray(off, dtype=np.uint64)
-    g = lib().orc_build_graph_cov(k, num_buckets, bases, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off) - 1,
-                                  flavour_version.encode(), 1 if coverage else 0)
+    g = lib().orc_build_graph_ex(k, num_buckets, bases, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off) - 1,
+                                 flavour_version.encode(), 1 if coverage else 0, 1 if sort_edges else 0, 1 if keep_loops else 0)
     gc = g.contents
     nw = words(k)
     nk = gc.n_kmers

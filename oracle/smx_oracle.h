@@ -69,6 +69,11 @@ orc_graph *orc_build_graph(unsigned k, unsigned num_buckets, const char *bases, 
 /* with_cov != 0: spades-gbuilder -c (coverage_hash_map_builder.hpp:18-39, coverage_filling.hpp:46-62): DP:f / KC:i tags */
 orc_graph *orc_build_graph_cov(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off,
                                uint64_t nreads, const char *flavour_version, int with_cov);
+/* spades-core variant (DeBruijnGraphExtentionConstructor, debruijn_graph_constructor.hpp:590-604): sort_edges = unitigs
+ * ordered by Sequence::RawCompare before ids; keep_loops = keep_perfect_loops. PARITY UNPINNED for this variant: no
+ * spades-core build is available to produce a golden; the ordering rule itself is restated from sequence.hpp:605-624. */
+orc_graph *orc_build_graph_ex(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off, uint64_t nreads,
+                              const char *flavour_version, int with_cov, int sort_edges, int keep_loops);
 void orc_graph_free(orc_graph *g);
 
 #ifdef __cplusplus

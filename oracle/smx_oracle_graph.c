@@ -166,8 +166,35 @@ static unsigned dig(char c) {
     return c <= 'C' ? (c == 'A' ? 0u : 1u) : (c == 'G' ? 2u : 3u);
 }
 
+/* Sequence::RawCompare (sequence/sequence.hpp:605-624): length, then packed 64-bit words from word 0 */
+static const seqlist *g_sl;
+static int rawcmp_idx(const void *a, const void *b) {
+    size_t i = *(const size_t *)a, j = *(const size_t *)b;
+    if (g_sl->len[i] != g_sl->len[j]) return g_sl->len[i] < g_sl->len[j] ? -1 : 1;
+    size_t n = g_sl->len[i];
+    for (size_t w0 = 0; w0 < n; w0 += 32) {
+        uint64_t x = 0, y = 0;
+        for (size_t t = w0; t < n && t < w0 + 32; ++t) {
+            x |= (uint64_t)g_sl->seq[i][t] << ((t & 31) << 1);
+            y |= (uint64_t)g_sl->seq[j][t] << ((t & 31) << 1);
+        }
+        if (x != y) return x < y ? -1 : 1;
+    }
+    return 0;
+}
+
+orc_graph *orc_build_graph_ex(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off, uint64_t nreads,
+                              const char *flavour_version, int with_cov, int sort_edges, int keep_loops);
+
 orc_graph *orc_build_graph_cov(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off, uint64_t nreads,
                                const char *flavour_version, int with_cov) {
+    return orc_build_graph_ex(k, num_buckets, bases, off, nreads, flavour_version, with_cov, 0, 1);
+}
+
+/* sort_edges / keep_loops: DeBruijnGraphExtentionConstructor::ConstructGraph(keep_perfect_loops), the spades-core variant
+ * (debruijn_graph_constructor.hpp:590-604): unitigs sorted by Sequence::RawCompare before ids are assigned. */
+orc_graph *orc_build_graph_ex(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off, uint64_t nreads,
+                              const char *flavour_version, int with_cov, int sort_edges, int keep_loops) {
     orc_graph *g = (orc_graph *)calloc(1, sizeof *g);
     const unsigned K1 = k + 1, nw1 = orc_words(K1), nw = orc_words(k);
     /* STEP 1a: canonical (k+1)-mers, B buckets (kmer_extension_index_builder.hpp:72-75) */
@@ -266,7 +293,7 @@ orc_graph *orc_build_graph_cov(unsigned k, unsigned num_buckets, const char *bas
     }
     size_t n_paths = seqs.n;
     /* STEP 2c: CollectLoops, :359-397 */
-    {
+    if (keep_loops) {
         uint64_t *starts = (uint64_t *)malloc((ix.n ? ix.n : 1) * 8); size_t ns = 0;
         for (uint64_t r = 0; r < ix.n; ++r) if (!is_junction(ix.mask[r])) starts[ns++] = r;
         for (size_t si = 0; si < ns; ++si) {
@@ -313,6 +340,17 @@ orc_graph *orc_build_graph_cov(unsigned k, unsigned num_buckets, const char *bas
             }
         }
         free(starts);
+    }
+    if (sort_edges && seqs.n > 1) {
+        size_t *perm = (size_t *)malloc(seqs.n * sizeof *perm);
+        for (size_t i = 0; i < seqs.n; ++i) perm[i] = i;
+        g_sl = &seqs;
+        qsort(perm, seqs.n, sizeof *perm, rawcmp_idx);
+        unsigned char **ns = (unsigned char **)malloc(seqs.n * sizeof *ns);
+        size_t *nl = (size_t *)malloc(seqs.n * sizeof *nl);
+        for (size_t i = 0; i < seqs.n; ++i) { ns[i] = seqs.seq[perm[i]]; nl[i] = seqs.len[perm[i]]; }
+        memcpy(seqs.seq, ns, seqs.n * sizeof *ns); memcpy(seqs.len, nl, seqs.n * sizeof *nl);
+        free(ns); free(nl); free(perm);
     }
     g->n_unitigs = seqs.n; g->n_loops = seqs.n - n_paths;
     g->unitig_off = (uint64_t *)calloc(seqs.n + 1, 8);

@@ -48,6 +48,7 @@ struct smx_ctx {
     std::vector<uint64_t> bucket_off;
     // tuning / test hooks
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_dbg = 0, opt_batch_records = 0;
+    int64_t opt_sort_edges = 0, opt_keep_loops = 1;  // spades-core construction variant (debruijn_graph_constructor.hpp:590-604)
     // timings
     std::vector<Timing> timings;
     std::vector<std::string> tnames, xnames;  // last count stages / last extract_partition stages
@@ -981,7 +982,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
         HIPCHK(hipMemcpyAsync(&nloopk, lcount, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (nloopk > lcap) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%u k-mers on perfect loops exceed the host-side limit", nloopk);
-        if (nloopk) {
+        if (nloopk && ctx->opt_keep_loops) {
             std::vector<uint32_t> ranks;
             if (int rc = d2h(ctx, ranks, llist, nloopk)) return rc;
             std::sort(ranks.begin(), ranks.end());  // k-mer-file order
@@ -1023,6 +1024,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
     HIPCHK(hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost));
     if (herr) return fail(ctx, SMX_DEVICE_ERROR, "inconsistent k-mer index: %u failed lookups/walks", herr);
     tbegin(ctx, "links_host");
+    if (ctx->opt_sort_edges) smxh::sort_edges_raw(ctx->gh);
     smxh::build_links(ctx->gh);
     tend(ctx);
     ctx->g_ready = true;
@@ -1120,6 +1122,8 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "dbg")) ctx->opt_dbg = value;
     else if (!strcmp(key, "leaf_target")) ctx->opt_leaf_target = value;
     else if (!strcmp(key, "batch_records")) ctx->opt_batch_records = value;
+    else if (!strcmp(key, "sort_edges")) ctx->opt_sort_edges = value;
+    else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
     else return fail(ctx, SMX_INVALID_PARAMETER, "unknown option %s", key);
     return SMX_OK;
 }

@@ -166,6 +166,50 @@ class LoopCollector {
     }
 };
 
+// ---- spades-core edge order (DeBruijnGraphExtentionConstructor::ConstructGraph, debruijn_graph_constructor.hpp:590-604):
+// unitigs sorted by Sequence::RawCompare (sequence/sequence.hpp:605-624: length, then packed 64-bit words from word 0)
+inline void sort_edges_raw(GraphHost &g) {
+    const size_t ne = g.n_edges();
+    if (ne < 2) return;
+    std::vector<uint64_t> woff(ne + 1, 0);
+    for (size_t i = 0; i < ne; ++i) woff[i + 1] = woff[i] + (g.eoff[i + 1] - g.eoff[i] + 31) / 32;
+    std::vector<uint64_t> words(woff[ne], 0);
+    for (size_t i = 0; i < ne; ++i) {
+        const char *sq = g.seq.data() + g.eoff[i];
+        const uint64_t len = g.eoff[i + 1] - g.eoff[i];
+        for (uint64_t t = 0; t < len; ++t) {
+            const char ch = sq[t];
+            const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+            words[woff[i] + (t >> 5)] |= code << ((t & 31) << 1);
+        }
+    }
+    std::vector<size_t> perm(ne);
+    for (size_t i = 0; i < ne; ++i) perm[i] = i;
+    std::sort(perm.begin(), perm.end(), [&](size_t a, size_t b) {
+        const uint64_t la = g.eoff[a + 1] - g.eoff[a], lb = g.eoff[b + 1] - g.eoff[b];
+        if (la != lb) return la < lb;
+        const uint64_t nw = woff[a + 1] - woff[a];
+        for (uint64_t w = 0; w < nw; ++w)
+            if (words[woff[a] + w] != words[woff[b] + w]) return words[woff[a] + w] < words[woff[b] + w];
+        return false;
+    });
+    GraphHost o;
+    o.k = g.k;
+    o.eoff.assign(1, 0);
+    o.seq.reserve(g.seq.size());
+    for (size_t i = 0; i < ne; ++i) {
+        const size_t s = perm[i];
+        o.seq.append(g.seq, (size_t)g.eoff[s], (size_t)(g.eoff[s + 1] - g.eoff[s]));
+        o.eoff.push_back(o.seq.size());
+        o.estart.push_back(g.estart[s]);
+        o.eend.push_back(g.eend[s]);
+        o.eself.push_back(g.eself[s]);
+    }
+    o.n_paths = g.n_paths;
+    o.n_loops = g.n_loops;
+    g = std::move(o);
+}
+
 // ---- link records + vertices ----------------------------------------------------------------------------
 inline void build_links(GraphHost &g) {
     const uint64_t min_id = 3;

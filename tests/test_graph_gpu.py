@@ -90,6 +90,25 @@ def test_fastg_matches_gbuilder(case, tmp_path):
     gb.ctx.close()
 
 
+def test_spades_core_variant_sorted_edges(tmp_path):
+    """DeBruijnGraphExtentionConstructor order (RawCompare-sorted unitigs; thread-independent ids) vs the oracle's restatement.
+    No spades-core golden exists for this variant (parity unpinned for the order rule); invariants checked as well."""
+    from oracle import oracle
+    reads = _synth(77, 5000, 1200, 150) + _synth(9, 500, 60, 100, err=0.0, nrate=0.0, circ=True)
+    outs = []
+    for threads in (1, 4):
+        ref = oracle.build_graph(reads, 33, 10 * threads, sort_edges=True)
+        r = _build(reads, 33, threads, tmp_path, {"sort_edges": 1})
+        assert r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"]
+        outs.append(r["gfa"])
+    assert outs[0] == outs[1]  # ids no longer depend on the bucket count
+    lens = [len(u) for u in r["unitigs"]]
+    assert lens == sorted(lens)
+    ref = oracle.build_graph(reads, 33, 10, sort_edges=True, keep_loops=False)
+    r = _build(reads, 33, 1, tmp_path, {"sort_edges": 1, "keep_perfect_loops": 0})
+    assert r["gfa"] == ref["gfa"] and r["info"]["n_loops"] == 0
+
+
 def test_coverage_vs_oracle_seeded(tmp_path):
     from oracle import oracle
     from spades_amd.gbuilder import GraphBuilder
