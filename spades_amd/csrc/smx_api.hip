@@ -230,7 +230,11 @@ int scan_u64(smx_ctx *ctx, const unsigned long long *in, unsigned long long *out
 template <int NW>
 struct Tune {
     static constexpr int RPT = (NW <= 2) ? 16 : 8;                        // records per thread in a scatter tile (RPT 8 at NW=2: L1 scatter 32.5 vs 20.6 ms)
-    static constexpr uint32_t CAP = (NW == 1) ? 4096 : (NW == 2 ? 2048 : 1024);  // LDS-sortable leaf (larger caps measured slower)
+    // LDS leaf classes: CAP1 = the common class (small LDS footprint -> 3-4 workgroups per CU), CAP = 4*CAP1 for skewed bins.
+    // Sweep at 10 M reads (tools/sweep.py): k=55 cap 2048/avg 915 -> 40.6 ms, cap 1024/avg 915 -> 20.2 ms; k=21 cap 4096 -> 72.7, 2048 -> 27.9 ms
+    static constexpr uint32_t CAP1 = (NW == 1) ? 2048 : (NW == 2 ? 1024 : 512);
+    static constexpr uint32_t CAP = (NW == 1 ? 2 : 4) * CAP1;  // second class must still fit 160 KiB of LDS
+    static constexpr int LPT1 = CAP1 / BLK;
     static constexpr int LPT = CAP / BLK;
     // fan-out per MSD level: runs of >= 16 records (>= 256 B) per bin and tile on average keep the scattered
     // writes at streaming speed and the reservation atomics at <= 1/16 per record (tools/ubench.hip);
@@ -357,6 +361,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
               bool recs_reusable = false) {
     uint32_t cap = Tune<NW>::CAP;
     if (ctx->opt_leaf_cap > 0) cap = (uint32_t)std::min<int64_t>(ctx->opt_leaf_cap, cap);
+    const uint32_t cap1 = std::min<uint32_t>(Tune<NW>::CAP1, cap);
     const bool from_reads = d_recs == nullptr;
     clear_result(ctx);
     ctx->K = K;
@@ -385,9 +390,9 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
 
     // ---- choose the MSD split: level 1 = bucket + s1 key bits, then levels of <= log2(FMAX) bits ----
     const unsigned avail = std::min(64u, 2 * K);  // key bits visible in key_top64
-    // requested average leaf = cap/2 records (the power-of-two split then lands between cap/4 and cap/2). Measured on
-    // 10 M PE150 reads, k=55 (tools/sweep.py): 64 -> 165 ms (register sort, 4 levels), 256 -> 176, 512 -> 144, 1024 -> 127.5 ms.
-    uint64_t leaf = std::max<uint32_t>(cap / 2, 1);
+    // requested average leaf = 0.9 * cap1 (the power-of-two split lands the average in (0.45, 0.9] * cap1, a Poisson tail of
+    // ~1e-4 above cap1 goes to the 4x class). Larger leaves amortise the per-leaf barriers; smaller LDS raises occupancy.
+    uint64_t leaf = std::max<uint32_t>(cap1 * 9 / 10, 1);
     if (ctx->opt_leaf_target > 0) leaf = (uint64_t)ctx->opt_leaf_target;
     const uint64_t fneed = (nrec + leaf - 1) / leaf;
     unsigned bits = fneed > B ? ceil_log2((fneed + B - 1) / B) : 0;
@@ -429,7 +434,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (!from_reads && recs_reusable) bufB = (Rec<NW> *)const_cast<void *>(d_recs);  // the source is dead after the level-1 scatter
     else if (int rc = dalloc(ctx, &bufB, nrec)) return rc;
     unsigned long long *histA, *offA, *offB, *cur, *tcnt, *tstart, *ucount, *uoff, *bucket_off;
-    uint32_t *biglist, *bigcount, *runlen, *medlist, *medcount, *smalllist, *smallcount;
+    uint32_t *biglist, *bigcount, *runlen, *medlist, *medcount, *smalllist, *smallcount, *med2list, *med2count;
     if (int rc = dalloc(ctx, &histA, nb)) return rc;
     if (int rc = dalloc(ctx, &offA, nb + 1)) return rc;
     if (int rc = dalloc(ctx, &offB, nb_parent_max + 1)) return rc;
@@ -443,6 +448,9 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (int rc = dalloc(ctx, &medlist, nb)) return rc;
     if (int rc = dalloc(ctx, &medcount, 1)) return rc;
     HIPCHK(hipMemsetAsync(medcount, 0, 4, ctx->stream));
+    if (int rc = dalloc(ctx, &med2list, nb)) return rc;
+    if (int rc = dalloc(ctx, &med2count, 1)) return rc;
+    HIPCHK(hipMemsetAsync(med2count, 0, 4, ctx->stream));
     if (int rc = dalloc(ctx, &smalllist, nb)) return rc;
     if (int rc = dalloc(ctx, &smallcount, 1)) return rc;
     HIPCHK(hipMemsetAsync(smallcount, 0, 4, ctx->stream));
@@ -533,17 +541,25 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
 
     // ---- leaf sort + unique -----------------------------------------------------------------
     {
-        unsigned sub_bits = std::min(10u, avail - std::min(avail, consumed));
-        while (sub_bits > 0 && (1u << sub_bits) > cap) --sub_bits;
-        const unsigned sub_shift = 64 - consumed - sub_bits;
-        uint32_t T = 64;
-        while (T < 2 * cap) T <<= 1;
-        size_t lds = (size_t)cap * NW * 8 + ((size_t)T + 2 * ((size_t)1 << sub_bits) + 1 + cap + 4) * 4;
-        if (int rc = set_lds(ctx, k_sort_small<NW, Tune<NW>::LPT>, lds)) return rc;
+        auto leaf_geom = [&](uint32_t c, unsigned &sub_bits, unsigned &sub_shift, uint32_t &T, size_t &lds) {
+            sub_bits = std::min(10u, avail - std::min(avail, consumed));
+            while (sub_bits > 0 && (1u << sub_bits) > c) --sub_bits;
+            sub_shift = sub_bits ? 64 - consumed - sub_bits : 0;
+            T = 64;
+            while (T < 2 * c) T <<= 1;
+            lds = (size_t)c * NW * 8 + ((size_t)T + 2 * ((size_t)1 << sub_bits) + 1 + c + 4) * 4;
+        };
+        unsigned sb1, ss1, sb2, ss2;
+        uint32_t T1, T2;
+        size_t lds1, lds2;
+        leaf_geom(cap1, sb1, ss1, T1, lds1);
+        leaf_geom(cap, sb2, ss2, T2, lds2);
+        if (int rc = set_lds(ctx, k_sort_small<NW, Tune<NW>::LPT1>, lds1)) return rc;
+        if (int rc = set_lds(ctx, k_sort_small<NW, Tune<NW>::LPT>, lds2)) return rc;
         if (int rc = set_lds(ctx, k_sort_big<NW>, (size_t)cap * NW * 8)) return rc;
         tbegin(ctx, "classify");
-        hipLaunchKernelGGL(k_classify, dim3((unsigned)((nb + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, fine_off, (uint32_t)nb, cap, ucount,
-                           smalllist, smallcount, medlist, medcount, biglist, bigcount);
+        hipLaunchKernelGGL(k_classify, dim3((unsigned)((nb + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, fine_off, (uint32_t)nb, cap1, cap, ucount,
+                           smalllist, smallcount, medlist, medcount, med2list, med2count, biglist, bigcount);
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "sort_wave");
@@ -552,9 +568,15 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "sort_unique");
-        hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 8), dim3(BLK), lds, ctx->stream, (void *)sortbuf,
-                           fine_off, (uint32_t)nb, cap, K, sub_bits ? sub_shift : 0u, sub_bits, T, ucount, biglist, bigcount,
+        hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT1>), dim3(256 * 8), dim3(BLK), lds1, ctx->stream, (void *)sortbuf,
+                           fine_off, (uint32_t)nb, cap1, K, ss1, sb1, T1, ucount, biglist, bigcount,
                            (const uint32_t *)medlist, (const uint32_t *)medcount);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        tbegin(ctx, "sort_unique2");
+        hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf,
+                           fine_off, (uint32_t)nb, cap, K, ss2, sb2, T2, ucount, biglist, bigcount,
+                           (const uint32_t *)med2list, (const uint32_t *)med2count);
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "sort_big");

@@ -663,15 +663,16 @@ __device__ __forceinline__ uint32_t wave_leaf(Rec<NW> *g, uint32_t n) {
 // size classes of the fine bins: empty | small (register sort, one wave) | medium (LDS kernel) | big (merge kernel).
 // One thread per bin; the per-thread atomicAdd(.,1) is wave-aggregated by the compiler, so the three list counters
 // see one atomic per wave instead of one per bin (a single word retires only ~88 atomics/us).
-__global__ void k_classify(const unsigned long long *off, uint32_t nbins, uint32_t cap, unsigned long long *ucount,
+__global__ void k_classify(const unsigned long long *off, uint32_t nbins, uint32_t cap1, uint32_t cap2, unsigned long long *ucount,
                            uint32_t *smalllist, uint32_t *smallcount, uint32_t *medlist, uint32_t *medcount,
-                           uint32_t *biglist, uint32_t *bigcount) {
+                           uint32_t *med2list, uint32_t *med2count, uint32_t *biglist, uint32_t *bigcount) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbins) return;
     const uint64_t n = off[b + 1] - off[b];
     if (n == 0) ucount[b] = 0;
-    else if (n > cap) biglist[atomicAdd(bigcount, 1u)] = b;
-    else if (n > 128) medlist[atomicAdd(medcount, 1u)] = b;  // R=4 register sorts cost more per record than the LDS kernel
+    else if (n > cap2) biglist[atomicAdd(bigcount, 1u)] = b;
+    else if (n > cap1) med2list[atomicAdd(med2count, 1u)] = b;  // second LDS class (4x larger leaves, 1 workgroup per CU)
+    else if (n > 128) medlist[atomicAdd(medcount, 1u)] = b;     // R=4 register sorts cost more per record than the LDS kernel
     else smalllist[atomicAdd(smallcount, 1u)] = b;
 }
 
