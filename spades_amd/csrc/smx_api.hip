@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <ctime>
 #include <cstdlib>
@@ -390,43 +391,48 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
 
     // ---- choose the MSD split: level 1 = bucket + s1 key bits, then levels of <= log2(FMAX) bits ----
     const unsigned avail = std::min(64u, 2 * K);  // key bits visible in key_top64
-    // requested average leaf = 0.9 * cap1 (the power-of-two split lands the average in (0.45, 0.9] * cap1, a Poisson tail of
-    // ~1e-4 above cap1 goes to the 4x class). Larger leaves amortise the per-leaf barriers; smaller LDS raises occupancy.
-    uint64_t leaf = std::max<uint32_t>(cap1 * 9 / 10, 1);
+    // average leaf = 0.7 * cap1, hit exactly thanks to the mixed-radix fan-outs. Leaf sizes are compound-Poisson (every genomic
+    // k-mer arrives ~coverage times), sigma ~ sqrt(coverage * mean) ~ 110 at mean 716: ~3 sigma below cap1, the tail goes to the
+    // 4x class. (At mean 915 one leaf in five overflowed: sort_unique2 9.6 ms.)
+    uint64_t leaf = std::max<uint32_t>(cap1 * 7 / 10, 1);
     if (ctx->opt_leaf_target > 0) leaf = (uint64_t)ctx->opt_leaf_target;
-    const uint64_t fneed = (nrec + leaf - 1) / leaf;
-    unsigned bits = fneed > B ? ceil_log2((fneed + B - 1) / B) : 0;
-    bits = std::min(bits, std::min(avail, 40u));
-    unsigned fbits = 0;
-    while ((2u << fbits) <= Tune<NW>::FMAX) ++fbits;  // floor(log2(FMAX))
-    unsigned s1 = 0;
-    while (s1 < bits && ((uint64_t)B << (s1 + 1)) <= (from_reads ? Tune<NW>::FMAX1 : Tune<NW>::FMAX)) ++s1;
-    std::vector<unsigned> lv;  // bits of levels 2..
-    if (ctx->opt_s1 >= 0 || ctx->opt_s2 >= 0) {  // test hook: explicit split
-        s1 = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_s1, 0), std::min(avail, 12u));
+    // per-bucket key fan-out needed, realised as a mixed-radix product S1 * F2 * F3 ... (every factor <= FMAX)
+    uint64_t R = ((nrec + leaf - 1) / leaf + B - 1) / B;
+    const uint64_t rmax = 1ull << std::min(avail, 40u);  // no more key bins than key values
+    R = std::max<uint64_t>(1, std::min(R, rmax));
+    const uint32_t fmax1 = from_reads ? Tune<NW>::FMAX1 : Tune<NW>::FMAX;
+    uint32_t S1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(R, B <= fmax1 ? fmax1 / B : 1));
+    std::vector<uint32_t> lv;  // fan-outs of levels 2..
+    if (ctx->opt_s1 >= 0 || ctx->opt_s2 >= 0) {  // test hook: explicit split (powers of two)
+        unsigned s1 = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_s1, 0), std::min(avail, 12u));
         while (s1 > 0 && ((uint64_t)B << s1) > 4096) --s1;
-        unsigned s2 = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_s2, 0), std::min(avail - s1, 11u));
-        if (s2) lv.push_back(s2);
+        S1 = 1u << s1;
+        unsigned s2 = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_s2, 0), std::min(avail - std::min(avail, s1), 11u));
+        if (s2) lv.push_back(1u << s2);
     } else {
-        unsigned rem = bits - s1;
-        unsigned nl = (rem + fbits - 1) / fbits;
-        for (unsigned i = 0; i < nl; ++i) {
-            unsigned t = rem / (nl - i);
-            if (rem % (nl - i)) ++t;
-            lv.push_back(t);
-            rem -= t;
+        uint64_t rem = (R + S1 - 1) / S1;
+        while (rem > 1) {
+            unsigned nl = 1;
+            for (uint64_t capf = Tune<NW>::FMAX; capf < rem; capf *= Tune<NW>::FMAX) ++nl;
+            uint32_t F = (uint32_t)std::ceil(std::pow((double)rem, 1.0 / nl));
+            F = std::min<uint32_t>(std::max<uint32_t>(F, 2), Tune<NW>::FMAX);
+            lv.push_back(F);
+            rem = (rem + F - 1) / F;
+            if (lv.size() >= 5) break;
         }
     }
-    const uint32_t F1 = B << s1;
+    const uint32_t F1 = B * S1;
     uint64_t nb = F1;  // fine bins after all levels
     uint64_t nb_parent_max = F1;
-    for (unsigned t : lv) {
+    for (uint32_t t : lv) {
         nb_parent_max = nb;
-        nb <<= t;
+        nb *= t;
     }
     if (nb > (1ull << 31)) return fail(ctx, SMX_INVALID_PARAMETER, "batch too large: %llu fine bins", (unsigned long long)nb);
-    unsigned consumed = s1;
-    for (unsigned t : lv) consumed += t;
+    FracArgs fa{};
+    fa.n = 0;
+    if (S1 > 1) fa.f[fa.n++] = S1;
+    for (uint32_t t : lv) fa.f[fa.n++] = t;
 
     // ---- allocations ------------------------------------------------------------------------
     Rec<NW> *bufA, *bufB;
@@ -462,7 +468,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     PassArgs a{};
     a.K = K;
     a.num_buckets = B;
-    a.s1 = s1;
+    a.S1 = S1;
     a.world = 1;
 
     // ---- level 1 ----------------------------------------------------------------------------
@@ -506,18 +512,18 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     // ---- levels 2.. -------------------------------------------------------------------------
     Rec<NW> *sortbuf = bufA, *other = bufB;
     uint64_t nseg = F1;
-    unsigned used = s1;
+    a.nprev = 0;
+    if (S1 > 1) a.fprev[a.nprev++] = S1;
     static const char *lname[3][3] = {{"l2_hist", "l2_scan", "l2_scatter"}, {"l3_hist", "l3_scan", "l3_scatter"}, {"lN_hist", "lN_scan", "lN_scatter"}};
     for (size_t li = 0; li < lv.size(); ++li) {
-        const unsigned t = lv[li];
-        const uint64_t nchild = nseg << t;
+        const uint32_t t = lv[li];
+        const uint64_t nchild = nseg * t;
         const char **nm = lname[std::min<size_t>(li, 2)];
         HIPCHK(hipMemsetAsync(histA, 0, (size_t)nchild * 8, ctx->stream));
         a.recs = sortbuf;
         a.seg_off = off_cur;
         a.nseg = (uint32_t)nseg;
-        a.F = 1u << t;
-        a.shift = 64 - used - t;
+        a.F = t;
         a.hist = histA;
         tbegin(ctx, nm[0]);
         if (int rc = pass_recs<NW, BIN_LK>(ctx, false, a, nrec, tcnt, tstart)) return rc;
@@ -534,7 +540,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         std::swap(sortbuf, other);
         std::swap(off_cur, off_other);
         nseg = nchild;
-        used += t;
+        a.fprev[a.nprev++] = t;
     }
     const unsigned long long *fine_off = off_cur;
     wt.mark(ctx, "levels2+");
@@ -542,9 +548,9 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     // ---- leaf sort + unique -----------------------------------------------------------------
     {
         auto leaf_geom = [&](uint32_t c, unsigned &sub_bits, unsigned &sub_shift, uint32_t &T, size_t &lds) {
-            sub_bits = std::min(10u, avail - std::min(avail, consumed));
+            sub_bits = 10;
             while (sub_bits > 0 && (1u << sub_bits) > c) --sub_bits;
-            sub_shift = sub_bits ? 64 - consumed - sub_bits : 0;
+            sub_shift = 0;
             T = 64;
             while (T < 2 * c) T <<= 1;
             lds = (size_t)c * NW * 8 + ((size_t)T + 2 * ((size_t)1 << sub_bits) + 1 + c + 4) * 4;
@@ -569,13 +575,13 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         tend(ctx);
         tbegin(ctx, "sort_unique");
         hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT1>), dim3(256 * 8), dim3(BLK), lds1, ctx->stream, (void *)sortbuf,
-                           fine_off, (uint32_t)nb, cap1, K, ss1, sb1, T1, ucount, biglist, bigcount,
+                           fine_off, (uint32_t)nb, cap1, K, fa, sb1, T1, ucount, biglist, bigcount,
                            (const uint32_t *)medlist, (const uint32_t *)medcount);
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "sort_unique2");
         hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf,
-                           fine_off, (uint32_t)nb, cap, K, ss2, sb2, T2, ucount, biglist, bigcount,
+                           fine_off, (uint32_t)nb, cap, K, fa, sb2, T2, ucount, biglist, bigcount,
                            (const uint32_t *)med2list, (const uint32_t *)med2count);
         HIPCHK(hipGetLastError());
         tend(ctx);

@@ -11,8 +11,9 @@
 //            global-memory merge path (= the loser-tree merge of kmer_index_builder.hpp:357-415)
 //   compact  fine bins are already in (bucket, key) order -> concatenate uniques
 //
-// Bin order == output order: level-1 bin = bucket * 2^s1 + top s1 key bits, level-2 bin = next s2
-// key bits, so concatenating sorted fine bins yields exactly "buckets 0..B-1, each strictly
+// Bin order == output order: the key (top 64 bits, left aligned) is read as a fraction x in [0,1); level digits are the
+// mixed-radix expansion d1 = floor(x*S1), x' = frac(x*S1), d2 = floor(x'*F2), ... (monotone in the key, any fan-out, so the
+// average leaf size can be chosen freely), level-1 bin = bucket*S1 + d1. Concatenating sorted fine bins yields exactly "buckets 0..B-1, each strictly
 // increasing" (kmer_index_builder.hpp:190-203).
 #include "smx_device.hpp"
 
@@ -38,8 +39,9 @@ struct PassArgs {
     // binning
     unsigned K;
     uint32_t num_buckets;
-    unsigned s1;     // BIN_L1: key bits appended to the bucket id
-    unsigned shift;  // BIN_LK: digit = (top64 >> shift) & (F-1)
+    uint32_t S1;        // BIN_L1: bin = bucket * S1 + floor(keyfrac * S1)
+    uint32_t nprev;     // BIN_LK: key fan-outs already applied (S1, F2, ...), mixed radix on the key fraction
+    uint32_t fprev[6];
     uint32_t world;
     uint32_t F;  // bins per segment
     unsigned long long *hist;    // [nseg*F]
@@ -51,9 +53,11 @@ template <int NW, int BINF>
 __device__ __forceinline__ uint32_t bin_of(const Rec<NW> &x, const PassArgs &a) {
     if constexpr (BINF == BIN_L1) {
         uint32_t b = bucket_of(xxh3_rec<NW>(x), a.num_buckets);
-        return a.s1 ? ((b << a.s1) | (uint32_t)(key_top64<NW>(x, a.K) >> (64 - a.s1))) : b;
+        return a.S1 > 1 ? b * a.S1 + (uint32_t)__umul64hi(key_top64<NW>(x, a.K), (uint64_t)a.S1) : b;
     } else if constexpr (BINF == BIN_LK) {
-        return (uint32_t)(key_top64<NW>(x, a.K) >> a.shift) & (a.F - 1);
+        uint64_t f = key_top64<NW>(x, a.K);  // key as a fraction in [0,1) scaled by 2^64
+        for (uint32_t i = 0; i < a.nprev; ++i) f *= a.fprev[i];  // fractional part after each earlier digit
+        return (uint32_t)__umul64hi(f, (uint64_t)a.F);
     } else {
         uint32_t b = bucket_of(xxh3_rec<NW>(x), a.num_buckets);
         return (uint32_t)(((uint64_t)b * a.world) / a.num_buckets);
@@ -439,6 +443,17 @@ __device__ __forceinline__ uint32_t lds_insertion_unique(uint64_t *s, uint32_t b
 // #smaller keys in the digit's list (lists hold ~1 record) -> store at the final position of the bin's region.
 // Skewed leaves (a digit with > 128 distinct keys) fall back to the bitonic network + adjacent-unique.
 // LDS: stage[cap*NW] u64 | tab[T] | head[S] | cntf[S+1] | next[cap]  (u32 each)
+struct FracArgs {  // key fan-outs applied by the MSD levels (mixed radix), for the in-LDS digit of the leaf kernels
+    uint32_t n;
+    uint32_t f[6];
+};
+template <int NW>
+__device__ __forceinline__ uint32_t frac_digit(const Rec<NW> &x, unsigned K, const FracArgs &fa, uint32_t S) {
+    uint64_t f = key_top64<NW>(x, K);
+    for (uint32_t i = 0; i < fa.n; ++i) f *= fa.f[i];
+    return (uint32_t)__umul64hi(f, (uint64_t)S);
+}
+
 template <int NW>
 __device__ __forceinline__ uint32_t rec_hash32(const Rec<NW> &x) {
     uint64_t h = x.w[0] * 0x9E3779B97F4A7C15ull;
@@ -450,7 +465,7 @@ __device__ __forceinline__ uint32_t rec_hash32(const Rec<NW> &x) {
 
 template <int NW, int LPT>
 __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned long long *off, uint32_t nbins, uint32_t cap,
-                                                    unsigned K, unsigned sub_shift, unsigned sub_bits, uint32_t T,
+                                                    unsigned K, FracArgs fa, unsigned sub_bits, uint32_t T,
                                                     unsigned long long *ucount, uint32_t *biglist, uint32_t *bigcount,
                                                     const uint32_t *list, const uint32_t *listcount) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
@@ -515,7 +530,7 @@ __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned lo
                     }
                     if (first) {
                         fm |= 1u << j;
-                        const uint32_t d = (uint32_t)(key_top64<NW>(r[j], K) >> sub_shift) & (S - 1);
+                        const uint32_t d = frac_digit<NW>(r[j], K, fa, S);
                         atomicAdd(&cntf[d], 1u);
                         nxt[i] = atomicExch(&head[d], i);
                     }
@@ -544,7 +559,7 @@ __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned lo
 #pragma unroll
                 for (int j = 0; j < LPT; ++j) {
                     if (fm & (1u << j)) {
-                        const uint32_t d = (uint32_t)(key_top64<NW>(r[j], K) >> sub_shift) & (S - 1);
+                        const uint32_t d = frac_digit<NW>(r[j], K, fa, S);
                         uint32_t smaller = 0;
                         for (uint32_t p = head[d]; p != 0xFFFFFFFFu; p = nxt[p])
                             smaller += rec_less<NW>(lds_get<NW>(lds64, p), r[j]) ? 1u : 0u;
