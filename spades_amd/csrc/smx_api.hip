@@ -279,13 +279,13 @@ int pass_reads(smx_ctx *ctx, int mode, bool scatter, PassArgs a, const std::vect
                 hipLaunchKernelGGL((k_hist<NW, SRC_READS_CANON, BINF, RPT>), dim3(grid), dim3(BLK), lds, ctx->stream, a);
             }
         } else {
-            size_t lds = scatter_lds<NW, RPT>(a.F);
+            size_t lds = (size_t)a.F * 12 + (size_t)RPT * BLK * 4;
             if (mode == SMX_MODE_ALL) {
-                if (int rc = set_lds(ctx, k_scatter<NW, SRC_READS_ALL, BINF, RPT>, lds)) return rc;
-                hipLaunchKernelGGL((k_scatter<NW, SRC_READS_ALL, BINF, RPT>), dim3((unsigned)ntiles), dim3(BLK), lds, ctx->stream, a);
+                if (int rc = set_lds(ctx, k_scatter_reads<NW, SRC_READS_ALL, BINF, RPT>, lds)) return rc;
+                hipLaunchKernelGGL((k_scatter_reads<NW, SRC_READS_ALL, BINF, RPT>), dim3((unsigned)ntiles), dim3(BLK), lds, ctx->stream, a);
             } else {
-                if (int rc = set_lds(ctx, k_scatter<NW, SRC_READS_CANON, BINF, RPT>, lds)) return rc;
-                hipLaunchKernelGGL((k_scatter<NW, SRC_READS_CANON, BINF, RPT>), dim3((unsigned)ntiles), dim3(BLK), lds, ctx->stream, a);
+                if (int rc = set_lds(ctx, k_scatter_reads<NW, SRC_READS_CANON, BINF, RPT>, lds)) return rc;
+                hipLaunchKernelGGL((k_scatter_reads<NW, SRC_READS_CANON, BINF, RPT>), dim3((unsigned)ntiles), dim3(BLK), lds, ctx->stream, a);
             }
         }
         HIPCHK(hipGetLastError());

@@ -281,6 +281,85 @@ __global__ void __launch_bounds__(BLK) k_scatter(PassArgs a) {
     for (uint32_t idx = threadIdx.x; idx < total; idx += BLK) out[ldelta[sbin[idx]] + idx] = st[idx];
 }
 
+// Level-1 scatter straight from the reads. Same multisplit as k_scatter, but the LDS stage holds only a 16-bit
+// (local position, strand) tag per record instead of the record: 19 KB of LDS instead of 76 KB (8 instead of 2
+// workgroups per CU) and no record registers live across the barriers. The copy-out phase re-extracts the window
+// (L1/L2 hits) and writes the record to its reserved slot. LDS: spos[TR] u16 | sbin[TR] u16 | ldelta[F] u64 | lhist[F] u32
+template <int NW, int SRC, int BINF, int RPT>
+__global__ void __launch_bounds__(BLK) k_scatter_reads(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    constexpr int TR = RPT * BLK;
+    constexpr int RPP = (SRC == SRC_READS_ALL) ? 2 : 1;
+    constexpr int PPT = RPT / RPP;
+    uint64_t *ldelta = lds64;
+    uint32_t *lhist = (uint32_t *)(ldelta + a.F);
+    uint16_t *spos = (uint16_t *)(lhist + a.F);
+    uint16_t *sbin = spos + TR;
+    __shared__ uint32_t scr[BLK / 64 + 2];
+    for (uint32_t i = threadIdx.x; i < a.F; i += BLK) lhist[i] = 0;
+    __syncthreads();
+    const uint64_t base = a.g0 + (uint64_t)blockIdx.x * (uint64_t)(PPT * BLK);
+    uint32_t packed[RPT];  // bin << 16 | slot
+    uint32_t vm = 0;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const uint64_t g = base + (uint64_t)j * BLK + threadIdx.x;
+        const bool ok = g < a.G && ((a.mask[g >> 6] >> (g & 63)) & 1);
+        if (ok) {
+            Rec<NW> x = load_window<NW>(a.seq, g, a.K);
+            Rec<NW> y = rec_rc<NW>(x, a.K);
+            if constexpr (SRC == SRC_READS_ALL) {
+                const uint32_t b0 = bin_of<NW, BINF>(x, a), b1 = bin_of<NW, BINF>(y, a);
+                packed[2 * j] = (b0 << 16) | atomicAdd(&lhist[b0], 1u);
+                packed[2 * j + 1] = (b1 << 16) | atomicAdd(&lhist[b1], 1u);
+                vm |= 3u << (2 * j);
+            } else {
+                const Rec<NW> c = rc_ge<NW>(y, x) ? x : y;
+                const uint32_t b0 = bin_of<NW, BINF>(c, a);
+                packed[j] = (b0 << 16) | atomicAdd(&lhist[b0], 1u);
+                vm |= 1u << j;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t per = (a.F + BLK - 1) / BLK;
+    const uint32_t d0 = threadIdx.x * per, d1 = min(a.F, d0 + per);
+    uint32_t sum = 0;
+    for (uint32_t d = d0; d < d1; ++d) sum += lhist[d];
+    uint32_t total;
+    uint32_t run = block_excl_scan<uint32_t>(sum, scr, &total);
+    for (uint32_t d = d0; d < d1; ++d) {
+        uint32_t c = lhist[d];
+        lhist[d] = run;
+        if (c) ldelta[d] = (uint64_t)atomicAdd(&a.cursor[d], (unsigned long long)c) - run;
+        run += c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        if (vm & (1u << j)) {
+            const uint32_t bin = packed[j] >> 16;
+            const uint32_t idx = lhist[bin] + (packed[j] & 0xFFFFu);
+            const uint32_t lpos = (uint32_t)(j / RPP) * BLK + threadIdx.x;
+            spos[idx] = (uint16_t)((lpos << 1) | (RPP == 2 ? (j & 1) : 0));
+            sbin[idx] = (uint16_t)bin;
+        }
+    }
+    __syncthreads();
+    Rec<NW> *out = (Rec<NW> *)a.out;
+    for (uint32_t idx = threadIdx.x; idx < total; idx += BLK) {
+        const uint32_t tag = spos[idx];
+        Rec<NW> x = load_window<NW>(a.seq, base + (tag >> 1), a.K);
+        if constexpr (SRC == SRC_READS_ALL) {
+            if (tag & 1) x = rec_rc<NW>(x, a.K);
+        } else {
+            Rec<NW> y = rec_rc<NW>(x, a.K);
+            if (!rc_ge<NW>(y, x)) x = y;
+        }
+        out[ldelta[sbin[idx]] + idx] = x;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ scans
 // Single-workgroup exclusive scan (n small, e.g. level-1 histogram): out[i] = sum in[0..i), out[n] = total.
 __global__ void k_scan_small(const unsigned long long *in, unsigned long long *out, uint32_t n) {
