@@ -63,9 +63,9 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value);
  * (common/io/reads/binary_streams.hpp:54-102) for mode B. Reverse complements are NOT submitted:
  * the kernels generate them. Submissions append to the context's resident batch. */
 int smx_reads_clear(smx_ctx *ctx);
-/* ASCII reads, read i = bases[offsets[i] .. offsets[i+1]). Applies the reference's N rule on the
- * host: each read is cut to its longest run of ACGTacgt, first one on ties
- * (common/io/reads/longest_valid_wrapper.hpp:16-53), then 2-bit packs and uploads. */
+/* ASCII reads, read i = bases[offsets[i] .. offsets[i+1]). The bytes are uploaded as they are; the reference's N rule
+ * (each read is cut to its longest run of ACGTacgt, first one on ties: common/io/reads/longest_valid_wrapper.hpp:16-53)
+ * and the 2-bit packing (common/io/reads/binary_converter.cpp:83-151 keeps the same 2-bit words) run on the device. */
 int smx_submit_reads_ascii(smx_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 /* Already-packed reads in host memory: one 2-bit stream (layout as a k-mer record, arbitrarily
  * long), read i occupies nucleotides [start[i], start[i]+len[i]). Mirrors Sequence::BinWrite's

@@ -1201,54 +1201,41 @@ int smx_submit_reads_ascii(smx_ctx *ctx, const char *bases, const uint64_t *offs
     if (!ctx) return SMX_INVALID_PARAMETER;
     if (n_reads == 0) return SMX_OK;
     if (!bases || !offsets) return fail(ctx, SMX_INVALID_PARAMETER, "null read arrays");
-    // host-side read preprocessing (the reference keeps parsing / N handling on the CPU as well):
-    // longest run of ACGTacgt, first one on ties (longest_valid_wrapper.hpp:16-43)
-    auto is_nucl = [](char ch) {
-        switch (ch) {
-            case 'A': case 'C': case 'G': case 'T': case 'a': case 'c': case 'g': case 't': return true;
-            default: return false;
-        }
-    };
-    std::vector<uint64_t> start(n_reads);
-    std::vector<uint32_t> len(n_reads);
-    std::vector<uint64_t> words;
-    words.reserve((size_t)((offsets[n_reads] - offsets[0]) / 32 + 2));
-    uint64_t pos = 0, cur = 0;
-    unsigned fill = 0;
+    // Ingest on the device: the ASCII bytes and offsets are uploaded as they are (relative to offsets[0]); the longest-valid
+    // rule and the 2-bit packing run as two small kernels (k_longest_valid, k_pack_ascii). The host only checks lengths.
+    const uint64_t base0 = offsets[0], nbases = offsets[n_reads] - base0;
     for (uint64_t r = 0; r < n_reads; ++r) {
-        const char *s = bases + offsets[r];
-        const uint64_t n = offsets[r + 1] - offsets[r];
-        uint64_t best_len = 0, best_pos = 0, run = 0;
-        for (uint64_t i = 0; i <= n; ++i) {
-            if (i < n && is_nucl(s[i])) {
-                ++run;
-            } else {
-                if (run > best_len) {
-                    best_len = run;
-                    best_pos = i - run;
-                }
-                run = 0;
-            }
-        }
-        if (best_len > 0xFFFFFFFFull) return fail(ctx, SMX_INVALID_INPUT_FORMAT, "read %llu longer than 2^32-1", (unsigned long long)r);
-        start[r] = pos;
-        len[r] = (uint32_t)best_len;
-        for (uint64_t i = 0; i < best_len; ++i) {
-            char ch = s[best_pos + i];
-            uint64_t code = (ch == 'A' || ch == 'a') ? 0 : (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g') ? 2 : 3;
-            cur |= code << fill;
-            fill += 2;
-            if (fill == 64) {
-                words.push_back(cur);
-                cur = 0;
-                fill = 0;
-            }
-        }
-        pos += best_len;
+        if (offsets[r + 1] < offsets[r]) return fail(ctx, SMX_INVALID_INPUT_FORMAT, "read offsets must be non-decreasing");
+        if (offsets[r + 1] - offsets[r] > 0xFFFFFFFFull)
+            return fail(ctx, SMX_INVALID_INPUT_FORMAT, "read %llu longer than 2^32-1", (unsigned long long)r);
     }
-    if (fill) words.push_back(cur);
-    if (words.empty()) words.push_back(0);
-    return smx_submit_reads_packed(ctx, words.data(), words.size(), start.data(), len.data(), n_reads);
+    HIPCHK(hipSetDevice(ctx->device));
+    ReadChunk c;
+    c.n_reads = n_reads;
+    c.n_bases = nbases;
+    c.n_words = (nbases + 31) / 32 + 1;
+    char *d_bases;
+    unsigned long long *d_off;
+    if (int rc = dalloc(ctx, &d_bases, nbases + 1)) return rc;
+    if (int rc = dalloc(ctx, &d_off, n_reads + 1)) return rc;
+    if (int rc = dalloc(ctx, &c.d_words, c.n_words + 8, false)) return rc;
+    if (int rc = dalloc(ctx, &c.d_start, n_reads, false)) return rc;
+    if (int rc = dalloc(ctx, &c.d_len, n_reads, false)) return rc;
+    std::vector<unsigned long long> rel(n_reads + 1);
+    for (uint64_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - base0;
+    if (nbases) HIPCHK(hipMemcpyAsync(d_bases, bases + base0, nbases, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_off, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(c.d_words + c.n_words, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_longest_valid, dim3((unsigned)((n_reads + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, (const char *)d_bases,
+                       (const unsigned long long *)d_off, n_reads, c.d_start, c.d_len);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_pack_ascii, dim3((unsigned)std::min<uint64_t>((c.n_words + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
+                       (const char *)d_bases, nbases, c.d_words, c.n_words);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_temps(ctx);
+    ctx->chunks.push_back(c);
+    return SMX_OK;
 }
 
 int smx_submit_reads_device(smx_ctx *ctx, const void *d_words, uint64_t n_words, const void *d_start, const void *d_len,

@@ -64,6 +64,50 @@ __device__ __forceinline__ uint32_t bin_of(const Rec<NW> &x, const PassArgs &a) 
     }
 }
 
+// ---------------------------------------------------------------------------------------- ingest
+// ASCII reads -> 2-bit stream + (start, len) of the longest ACGTacgt run of every read, first one on ties
+// (io::LongestValid, common/io/reads/longest_valid_wrapper.hpp:16-53; dignucl, common/sequence/nucl.hpp:132-142).
+// The stream keeps every input position (non-nucleotides become 'A'); (start, len) select the valid run.
+__device__ __forceinline__ bool ascii_is_nucl(char c) {
+    return c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'a' || c == 'c' || c == 'g' || c == 't';
+}
+__global__ void k_longest_valid(const char *__restrict__ bases, const unsigned long long *__restrict__ off, uint64_t n,
+                                uint64_t *start, uint32_t *len) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint64_t b = off[r], e = off[r + 1];
+    uint64_t best_len = 0, best_pos = b, run = 0;
+    for (uint64_t i = b; i <= e; ++i) {
+        if (i < e && ascii_is_nucl(bases[i])) {
+            ++run;
+        } else {
+            if (run > best_len) {
+                best_len = run;
+                best_pos = i - run;
+            }
+            run = 0;
+        }
+    }
+    start[r] = best_pos;
+    len[r] = (uint32_t)best_len;
+}
+__global__ void k_pack_ascii(const char *__restrict__ bases, uint64_t nbases, uint64_t *words, uint64_t nwords) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t v = 0;
+        const uint64_t p0 = w * 32;
+#pragma unroll 8
+        for (unsigned j = 0; j < 32; ++j) {
+            const uint64_t p = p0 + j;
+            if (p < nbases) {
+                const char c = bases[p];
+                const uint64_t code = (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2 : (c == 'T' || c == 't') ? 3 : 0;
+                v |= code << (j << 1);
+            }
+        }
+        words[w] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ mark
 __global__ void k_mark_windows(const uint64_t *__restrict__ start, const uint32_t *__restrict__ len, uint64_t n,
                                unsigned K, unsigned long long *mask, unsigned long long *total) {
