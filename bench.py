@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--mode", default="A", choices=["A", "B"])
     ap.add_argument("--buckets", type=int, default=16)
     ap.add_argument("--genome", type=float, default=50e6)
-    ap.add_argument("--cpu-sample", type=float, default=1e6)
+    ap.add_argument("--cpu-sample", type=float, default=4e6, help="reads timed on the host with the reference classes (~10-15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
     args = ap.parse_args()

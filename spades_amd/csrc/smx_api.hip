@@ -48,7 +48,7 @@ struct smx_ctx {
     unsigned nw = 0, K = 0, num_buckets = 0;
     std::vector<uint64_t> bucket_off;
     // tuning / test hooks
-    int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_dbg = 0, opt_batch_records = 0;
+    int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;  // spades-core construction variant (debruijn_graph_constructor.hpp:590-604)
     // timings
     std::vector<Timing> timings;
@@ -547,19 +547,18 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
 
     // ---- leaf sort + unique -----------------------------------------------------------------
     {
-        auto leaf_geom = [&](uint32_t c, unsigned &sub_bits, unsigned &sub_shift, uint32_t &T, size_t &lds) {
-            sub_bits = 10;
+        auto leaf_geom = [&](uint32_t c, unsigned &sub_bits, uint32_t &T, size_t &lds) {
+            sub_bits = 10;  // 1024 in-LDS digits (512 measured the same)
             while (sub_bits > 0 && (1u << sub_bits) > c) --sub_bits;
-            sub_shift = 0;
             T = 64;
             while (T < 2 * c) T <<= 1;
             lds = (size_t)c * NW * 8 + ((size_t)T + 2 * ((size_t)1 << sub_bits) + 1 + c + 4) * 4;
         };
-        unsigned sb1, ss1, sb2, ss2;
+        unsigned sb1, sb2;
         uint32_t T1, T2;
         size_t lds1, lds2;
-        leaf_geom(cap1, sb1, ss1, T1, lds1);
-        leaf_geom(cap, sb2, ss2, T2, lds2);
+        leaf_geom(cap1, sb1, T1, lds1);
+        leaf_geom(cap, sb2, T2, lds2);
         if (int rc = set_lds(ctx, k_sort_small<NW, Tune<NW>::LPT1>, lds1)) return rc;
         if (int rc = set_lds(ctx, k_sort_small<NW, Tune<NW>::LPT>, lds2)) return rc;
         if (int rc = set_lds(ctx, k_sort_big<NW>, (size_t)cap * NW * 8)) return rc;
@@ -1147,7 +1146,6 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     if (!strcmp(key, "leaf_cap")) ctx->opt_leaf_cap = value;
     else if (!strcmp(key, "s1")) ctx->opt_s1 = value;
     else if (!strcmp(key, "s2")) ctx->opt_s2 = value;
-    else if (!strcmp(key, "dbg")) ctx->opt_dbg = value;
     else if (!strcmp(key, "leaf_target")) ctx->opt_leaf_target = value;
     else if (!strcmp(key, "batch_records")) ctx->opt_batch_records = value;
     else if (!strcmp(key, "sort_edges")) ctx->opt_sort_edges = value;
