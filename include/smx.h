@@ -150,6 +150,14 @@ int smx_graph_write_spades(smx_ctx *ctx, const char *basename);
 /* gbuilder --unitigs (gbuilder.cpp:191-200): >EDGE_<i>_length_<len>, wrapped at 60 */
 int smx_graph_write_unitigs(smx_ctx *ctx, const char *path);
 
+/* Host-only (no GPU, no context): FastGraphFromSequencesConstructor::ConstructGraph + the writers on caller-provided unitigs.
+ * offsets[n+1]/seq: ACGT unitigs in id order; start_node/end_node = 2*rank + rc of the first / last k-mer, rank being ANY injective
+ * id of the canonical k-mer (the reference uses the MPHF index only to group records: debruijn_graph_constructor.hpp:540-547);
+ * raw_coverage may be NULL; sort_edges as the option of the same name; format 0 unitig FASTA, 1 GFA, 2 FASTG, 3 .grseq+.cvr. */
+int smx_host_write_graph(unsigned k, uint64_t n_edges, const uint64_t *offsets, const char *seq, const uint32_t *start_node,
+                         const uint32_t *end_node, const uint32_t *raw_coverage, int sort_edges, int format, const char *path,
+                         const char *flavour_version);
+
 /* ---- instrumentation -----------------------------------------------------------------------
  * Per-stage GPU time of the last smx_count in milliseconds (HIP events on the library's stream).
  * names/ms arrays of capacity cap; returns number of stages. Stands where the reference has

@@ -1519,6 +1519,50 @@ int smx_graph_write_spades(smx_ctx *ctx, const char *basename) {
     return SMX_OK;
 }
 
+// Host-only entry point (no GPU, no context): links + writers on caller-provided unitigs. Lets the reference-side code reuse
+// the writers for edges it computed itself, and lets the CPU test tier cover smx_graph_host.hpp.
+int smx_host_write_graph(unsigned k, uint64_t n_edges, const uint64_t *offsets, const char *seq, const uint32_t *start_node,
+                         const uint32_t *end_node, const uint32_t *raw_coverage, int sort_edges, int format, const char *path,
+                         const char *flavour_version) {
+    if (!offsets || !path || (n_edges && (!seq || !start_node || !end_node))) return SMX_INVALID_PARAMETER;
+    smxh::GraphHost g;
+    g.k = k;
+    g.eoff.assign(offsets, offsets + n_edges + 1);
+    g.seq.assign(seq ? seq : "", (size_t)offsets[n_edges]);
+    g.estart.assign(start_node, start_node + n_edges);
+    g.eend.assign(end_node, end_node + n_edges);
+    g.eself.resize(n_edges);
+    for (uint64_t i = 0; i < n_edges; ++i) {
+        std::string s = g.seq.substr((size_t)offsets[i], (size_t)(offsets[i + 1] - offsets[i]));
+        g.eself[i] = s == smxh::revcomp(s) ? 1 : 0;
+    }
+    if (sort_edges) {
+        if (raw_coverage) return SMX_INVALID_PARAMETER;  // coverage is per edge of the given order
+        smxh::sort_edges_raw(g);
+    }
+    if (raw_coverage) g.ecov.assign(raw_coverage, raw_coverage + n_edges);
+    smxh::build_links(g);
+    bool ok = true;
+    if (format == 3) {  // .grseq + .cvr
+        for (int part = 0; part < 2 && ok; ++part) {
+            std::string p = std::string(path) + (part ? ".cvr" : ".grseq");
+            FILE *f = fopen(p.c_str(), "wb");
+            if (!f) return SMX_IO_ERROR;
+            ok = part ? smxh::write_cvr(g, f) : smxh::write_grseq(g, f);
+            if (fclose(f) != 0) ok = false;
+        }
+        return ok ? SMX_OK : SMX_IO_ERROR;
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) return SMX_IO_ERROR;
+    if (format == 0) ok = smxh::write_unitigs_fasta(g, f);
+    else if (format == 1) ok = smxh::write_gfa(g, f, flavour_version ? flavour_version : "SPAdes-4.3.0-dev");
+    else if (format == 2) ok = smxh::write_fastg(g, f);
+    else ok = false;
+    if (fclose(f) != 0) ok = false;
+    return ok ? SMX_OK : (format > 3 || format < 0 ? SMX_INVALID_PARAMETER : SMX_IO_ERROR);
+}
+
 int smx_graph_write_unitigs(smx_ctx *ctx, const char *path) {
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
     if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
