@@ -440,7 +440,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (!from_reads && recs_reusable) bufB = (Rec<NW> *)const_cast<void *>(d_recs);  // the source is dead after the level-1 scatter
     else if (int rc = dalloc(ctx, &bufB, nrec)) return rc;
     unsigned long long *histA, *offA, *offB, *cur, *tcnt, *tstart, *ucount, *uoff, *bucket_off;
-    uint32_t *biglist, *bigcount, *runlen, *medlist, *medcount, *smalllist, *smallcount, *med2list, *med2count;
+    uint32_t *biglist, *bigcount, *runlen, *medlist, *medcount, *smalllist, *smallcount, *med2list, *med2count, *fblist, *fbcount;
     if (int rc = dalloc(ctx, &histA, nb)) return rc;
     if (int rc = dalloc(ctx, &offA, nb + 1)) return rc;
     if (int rc = dalloc(ctx, &offB, nb_parent_max + 1)) return rc;
@@ -457,6 +457,9 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (int rc = dalloc(ctx, &med2list, nb)) return rc;
     if (int rc = dalloc(ctx, &med2count, 1)) return rc;
     HIPCHK(hipMemsetAsync(med2count, 0, 4, ctx->stream));
+    if (int rc = dalloc(ctx, &fblist, nb)) return rc;
+    if (int rc = dalloc(ctx, &fbcount, 1)) return rc;
+    HIPCHK(hipMemsetAsync(fbcount, 0, 4, ctx->stream));
     if (int rc = dalloc(ctx, &smalllist, nb)) return rc;
     if (int rc = dalloc(ctx, &smallcount, 1)) return rc;
     HIPCHK(hipMemsetAsync(smallcount, 0, 4, ctx->stream));
@@ -572,16 +575,33 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
                            (void *)sortbuf, fine_off, ucount, (const uint32_t *)smalllist, (const uint32_t *)smallcount);
         HIPCHK(hipGetLastError());
         tend(ctx);
+        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT1>, lds1)) return rc;
+        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT>, lds2)) return rc;
         tbegin(ctx, "sort_unique");
-        hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT1>), dim3(256 * 8), dim3(BLK), lds1, ctx->stream, (void *)sortbuf,
-                           fine_off, (uint32_t)nb, cap1, K, fa, sb1, T1, ucount, biglist, bigcount,
-                           (const uint32_t *)medlist, (const uint32_t *)medcount);
+        if (sb1 > 0) {
+            hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1>), dim3(256 * 8), dim3(BLK), lds1, ctx->stream, (void *)sortbuf, fine_off, cap1,
+                               K, fa, sb1, T1, ucount, (const uint32_t *)medlist, (const uint32_t *)medcount, fblist, fbcount);
+        } else {  // leaves too small for the digit table (test-sized caps): the general kernel takes the list directly
+            hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT1>), dim3(256 * 8), dim3(BLK), lds1, ctx->stream, (void *)sortbuf,
+                               fine_off, (uint32_t)nb, cap1, K, fa, sb1, T1, ucount, biglist, bigcount,
+                               (const uint32_t *)medlist, (const uint32_t *)medcount);
+        }
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "sort_unique2");
+        if (sb2 > 0) {
+            hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf, fine_off, cap,
+                               K, fa, sb2, T2, ucount, (const uint32_t *)med2list, (const uint32_t *)med2count, fblist, fbcount);
+        } else {
+            hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf,
+                               fine_off, (uint32_t)nb, cap, K, fa, sb2, T2, ucount, biglist, bigcount,
+                               (const uint32_t *)med2list, (const uint32_t *)med2count);
+        }
+        HIPCHK(hipGetLastError());
+        // skewed leaves left over by the fast kernel (any size <= cap): general kernel with the bitonic fallback
         hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf,
                            fine_off, (uint32_t)nb, cap, K, fa, sb2, T2, ucount, biglist, bigcount,
-                           (const uint32_t *)med2list, (const uint32_t *)med2count);
+                           (const uint32_t *)fblist, (const uint32_t *)fbcount);
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "sort_big");

@@ -184,4 +184,24 @@ __device__ __forceinline__ T block_excl_scan(T v, T *scratch, T *total) {
     return res;
 }
 
+// Workgroup barrier that orders LDS only: waits for this wave's LDS/SMEM traffic and rendezvous, but leaves global
+// loads in flight (a __syncthreads() also drains vmcnt, which would serialise a software-prefetched next tile).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T>
+__device__ __forceinline__ T block_excl_scan_lds(T v, T *scratch, T *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    T inc = wave_incl_scan(v);
+    if (lane == 63) scratch[wave] = inc;
+    lds_barrier();
+    T base = 0, tot = 0;
+    for (int i = 0; i < nw; ++i) {  // every thread sums the (few) wave totals itself: no second barrier
+        T t = scratch[i];
+        if (i < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return inc - v + base;
+}
+
 }  // namespace smx

@@ -701,6 +701,130 @@ __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned lo
     }
 }
 
+// Fast path of the medium-leaf kernel: same algorithm as k_sort_small's hash branch, but (1) the records of the NEXT leaf are
+// loaded into registers before the current one is processed and every in-leaf barrier orders LDS only (lds_barrier), so the
+// global loads stay in flight across the whole leaf; (2) no fallback code in the kernel: a skewed leaf (a digit with > 128
+// distinct keys) is left untouched and queued for k_sort_small. LDS as k_sort_small.
+template <int NW, int LPT>
+__global__ void __launch_bounds__(BLK) k_sort_hash(void *buf, const unsigned long long *off, uint32_t cap, unsigned K, FracArgs fa,
+                                                   unsigned sub_bits, uint32_t T, unsigned long long *ucount,
+                                                   const uint32_t *list, const uint32_t *listcount, uint32_t *fblist, uint32_t *fbcount) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    __shared__ uint32_t scr[BLK / 64 + 2];
+    __shared__ uint32_t maxc;
+    const uint32_t S = 1u << sub_bits;
+    uint32_t *tab = (uint32_t *)(lds64 + (size_t)cap * NW);  // [T]
+    uint32_t *head = tab + T;                                // [S]
+    uint32_t *cntf = head + S;                               // [S+1]
+    uint32_t *nxt = cntf + S + 1;                            // [cap]
+    const uint32_t nwork = *listcount;
+    uint32_t bi = blockIdx.x;
+    if (bi >= nwork) return;
+    // software pipeline: records of leaf bi are in r_n when its iteration starts
+    uint32_t b_n = list[bi];
+    uint64_t o_n = off[b_n];
+    uint32_t n_n = (uint32_t)(off[b_n + 1] - o_n);
+    Rec<NW> r_n[LPT];
+    {
+        const Rec<NW> *g = (const Rec<NW> *)buf + o_n;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            uint32_t i = threadIdx.x + j * BLK;
+            if (i < n_n) r_n[j] = g[i];
+        }
+    }
+    for (; bi < nwork; bi += gridDim.x) {
+        const uint32_t b = b_n, n = n_n;
+        Rec<NW> *g = (Rec<NW> *)buf + o_n;
+        Rec<NW> r[LPT];
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) r[j] = r_n[j];
+        for (uint32_t i = threadIdx.x; i < T; i += BLK) tab[i] = 0xFFFFFFFFu;
+        for (uint32_t i = threadIdx.x; i <= S; i += BLK) {
+            cntf[i] = 0;
+            if (i < S) head[i] = 0xFFFFFFFFu;
+        }
+        if (threadIdx.x == 0) maxc = 0;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            uint32_t i = threadIdx.x + j * BLK;
+            if (i < n) lds_put<NW>(lds64, i, r[j]);
+        }
+        // prefetch the next leaf of this workgroup (loads complete while this leaf is hashed and ranked)
+        const uint32_t bi2 = bi + gridDim.x;
+        if (bi2 < nwork) {
+            b_n = list[bi2];
+            o_n = off[b_n];
+            n_n = (uint32_t)(off[b_n + 1] - o_n);
+            const Rec<NW> *g2 = (const Rec<NW> *)buf + o_n;
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                uint32_t i = threadIdx.x + j * BLK;
+                if (i < n_n) r_n[j] = g2[i];
+            }
+        }
+        lds_barrier();
+        uint32_t fm = 0;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            uint32_t i = threadIdx.x + j * BLK;
+            if (i < n) {
+                uint32_t slot = rec_hash32<NW>(r[j]) & (T - 1);
+                bool first = false;
+                for (;;) {
+                    uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, i);
+                    if (old == 0xFFFFFFFFu) {
+                        first = true;
+                        break;
+                    }
+                    if (rec_eq<NW>(lds_get<NW>(lds64, old), r[j])) break;  // duplicate of record `old`
+                    slot = (slot + 1) & (T - 1);
+                }
+                if (first) {
+                    fm |= 1u << j;
+                    const uint32_t d = frac_digit<NW>(r[j], K, fa, S);
+                    atomicAdd(&cntf[d], 1u);
+                    nxt[i] = atomicExch(&head[d], i);
+                }
+            }
+        }
+        lds_barrier();
+        const uint32_t per = (S + BLK - 1) / BLK;
+        const uint32_t d0 = threadIdx.x * per, d1 = min(S, d0 + per);
+        uint32_t sum = 0, mx = 0;
+        for (uint32_t d = d0; d < d1; ++d) {
+            uint32_t c = cntf[d];
+            sum += c;
+            mx = max(mx, c);
+        }
+        if (mx > 128) atomicMax(&maxc, mx);
+        uint32_t tot;
+        uint32_t run = block_excl_scan_lds<uint32_t>(sum, scr, &tot);
+        for (uint32_t d = d0; d < d1; ++d) {
+            uint32_t c = cntf[d];
+            cntf[d] = run;
+            run += c;
+        }
+        lds_barrier();
+        if (maxc > 128) {
+            if (threadIdx.x == 0) fblist[atomicAdd(fbcount, 1u)] = b;  // skewed: global data untouched, k_sort_small finishes it
+        } else {
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                if (fm & (1u << j)) {
+                    const uint32_t d = frac_digit<NW>(r[j], K, fa, S);
+                    uint32_t smaller = 0;
+                    for (uint32_t p = head[d]; p != 0xFFFFFFFFu; p = nxt[p])
+                        smaller += rec_less<NW>(lds_get<NW>(lds64, p), r[j]) ? 1u : 0u;
+                    g[cntf[d] + smaller] = r[j];
+                }
+            }
+            if (threadIdx.x == 0) ucount[b] = tot;
+        }
+        lds_barrier();  // LDS tables are re-initialised by the next iteration
+    }
+}
+
 // ---------------------------------------------------------------------------------- wave-level leaf sort
 template <int NW>
 __device__ __forceinline__ Rec<NW> rec_shfl_xor(const Rec<NW> &x, int m) {
