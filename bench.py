@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--genome", type=float, default=50e6)
     ap.add_argument("--cpu-sample", type=float, default=4e6, help="reads timed on the host with the reference classes (~10-15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--construct-reads", type=float, default=2e6,
+                    help="extra (untimed for the headline): de Bruijn construction (k=55, -t 16, -c) on this many reads; 0 disables")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
     args = ap.parse_args()
 
@@ -203,6 +205,24 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_sharded:
         out["cpu_baseline"] = cpu_baseline(sample, K, args.mode, nb)
+    if rank == 0 and world == 1 and args.construct_reads > 0 and not args.force_sharded:
+        # BASELINE.json config 3 in small: count + construct + coverage on the first reads of the same batch (reported, not the metric)
+        from spades_amd.gbuilder import GraphBuilder
+        nc = int(min(args.construct_reads, n_reads)) // 32 * 32
+        gb = GraphBuilder(55, 16, ctx)
+        sp.clear()
+        gb.push_back_device(words.data_ptr(), nc * L // 32, start.data_ptr(), ln.data_ptr(), nc)
+        gb.build()  # warm-up (arena growth)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = gb.build()
+        t1 = time.perf_counter()
+        gb.fill_coverage()
+        t2 = time.perf_counter()
+        out["construct"] = {"workload": f"first {nc} reads, k=55, 160 buckets (-t 16): canonical 56-mers -> 55-mers -> masks -> unitigs -> links",
+                            "reads": nc, "build_s": round(t1 - t0, 4), "coverage_s": round(t2 - t1, 4),
+                            "M_reads_per_s": round(nc / (t1 - t0) / 1e6, 3), "n_kpomers": int(info["n_kpomers"]),
+                            "n_kmers": int(info["n_kmers"]), "n_unitigs": int(info["n_unitigs"]), "n_vertices": int(info["n_vertices"])}
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()

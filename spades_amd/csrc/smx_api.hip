@@ -853,9 +853,50 @@ int d2h(smx_ctx *ctx, std::vector<T> &dst, const void *src, size_t n) {
     return 0;
 }
 
+
+// Sort distinct 64-bit keys with the counting pipeline itself: one bucket (B = 1), K = 32 so that the whole word is the key;
+// keys are left-aligned first so that the MSD digits see a spread-out fraction. Used for the link records of the graph.
+int device_sort_u64(smx_ctx *ctx, std::vector<uint64_t> &keys) {
+    const size_t n = keys.size();
+    if (n < (1u << 16)) {  // not worth a launch sequence
+        smxh::radix_sort_u64(keys);
+        return 0;
+    }
+    uint64_t mx = 0;
+    for (uint64_t v : keys) mx |= v;
+    const int sh = mx ? __builtin_clzll(mx) : 0;
+    if (sh)
+        for (auto &v : keys) v <<= sh;
+    // save the count-result view (the k-mer file) that run_count overwrites
+    void *sv_res = ctx->d_result;
+    const uint64_t sv_n = ctx->n_records, sv_inst = ctx->n_instances;
+    const unsigned sv_nw = ctx->nw, sv_K = ctx->K, sv_B = ctx->num_buckets;
+    std::vector<uint64_t> sv_boff = ctx->bucket_off;
+    ctx->d_result = nullptr;  // non-owning view; d_result_buf is null here
+    Rec<1> *d;
+    int rc = dalloc(ctx, &d, n);
+    if (!rc && hipMemcpy(d, keys.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "key upload failed");
+    if (!rc) rc = run_count<1>(ctx, 32, SMX_MODE_ALL, 1, d, n, nullptr, /*recs_reusable=*/true);
+    if (!rc && ctx->n_records != n) rc = fail(ctx, SMX_DEVICE_ERROR, "link keys are not distinct");
+    if (!rc && hipMemcpy(keys.data(), ctx->d_result, n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "key download failed");
+    ctx->d_result_buf = nullptr;  // the result block is one of the temps
+    free_temps(ctx);
+    ctx->d_result = sv_res;
+    ctx->n_records = sv_n;
+    ctx->n_instances = sv_inst;
+    ctx->nw = sv_nw;
+    ctx->K = sv_K;
+    ctx->num_buckets = sv_B;
+    ctx->bucket_off = sv_boff;
+    if (!rc && sh)
+        for (auto &v : keys) v >>= sh;
+    return rc;
+}
+
 template <int NW>
 int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
     clear_graph(ctx);
+    WallTrace gwt;
     ctx->g_k = k;
     ctx->g_nw = NW;
     ctx->g_B = B;
@@ -895,6 +936,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
         ctx->d_result = ctx->g_kmers;  // smx_copy_final_kmers() now yields the k-mer file
         free_temps(ctx, ctx->g_kmers);
     }
+    gwt.mark(ctx, "g:counts");
     const uint64_t D0 = ctx->g_nkmers;
     if (D0 >= (1ull << 31)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%llu k-mers exceed the 2^31 node-id limit", (unsigned long long)D0);
     const unsigned grid = (unsigned)std::min<uint64_t>((2 * D0 + BLK - 1) / BLK, 1u << 16);
@@ -936,6 +978,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
     HIPCHK(hipMemcpyAsync(&C, coff + D0, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     tend(ctx);
+    gwt.mark(ctx, "g:masks+succ");
     std::vector<unsigned long long> h_eoff;
     uint64_t n_paths = 0;
     uint8_t *visited;
@@ -1004,6 +1047,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
         HIPCHK(hipGetLastError());
         tend(ctx);
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        gwt.mark(ctx, "g:walks");
         // ---- to host ----
         n_paths = nkept;
         if (int rc = d2h(ctx, h_eoff, eoff, nkept)) return rc;
@@ -1015,6 +1059,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
         ctx->gh.eoff.assign(h_eoff.begin(), h_eoff.end());
         ctx->gh.eoff.push_back(ktotal);
     }
+    gwt.mark(ctx, "g:d2h");
     {
         // ---- perfect loops: non-junction k-mers on no path ----
         uint32_t *lcount, *llist;
@@ -1070,10 +1115,16 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
     unsigned herr = 0;
     HIPCHK(hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost));
     if (herr) return fail(ctx, SMX_DEVICE_ERROR, "inconsistent k-mer index: %u failed lookups/walks", herr);
-    tbegin(ctx, "links_host");
+    gwt.mark(ctx, "g:loops");
     if (ctx->opt_sort_edges) smxh::sort_edges_raw(ctx->gh);
-    smxh::build_links(ctx->gh);
-    tend(ctx);
+    free_temps(ctx);  // walk buffers are no longer needed; the link sort reuses the arena
+    int sort_rc = 0;
+    smxh::build_links(ctx->gh, [&](std::vector<uint64_t> &keys) {
+        if (!sort_rc) sort_rc = device_sort_u64(ctx, keys);
+        if (sort_rc) smxh::radix_sort_u64(keys);
+    });
+    if (sort_rc) return sort_rc;
+    gwt.mark(ctx, "g:links");
     ctx->g_ready = true;
     return 0;
 }

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -210,8 +211,33 @@ inline void sort_edges_raw(GraphHost &g) {
     g = std::move(o);
 }
 
+// LSD radix sort of 64-bit keys, 16-bit digits, passes whose digit is constant are skipped
+inline void radix_sort_u64(std::vector<uint64_t> &a) {
+    const size_t n = a.size();
+    if (n < 2) return;
+    std::vector<uint64_t> b(n);
+    std::vector<size_t> cnt(65536);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int sh = pass * 16;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (size_t i = 0; i < n; ++i) cnt[(a[i] >> sh) & 0xFFFF]++;
+        if (cnt[(a[0] >> sh) & 0xFFFF] == n) continue;
+        size_t run = 0;
+        for (size_t d = 0; d < 65536; ++d) {
+            size_t c = cnt[d];
+            cnt[d] = run;
+            run += c;
+        }
+        for (size_t i = 0; i < n; ++i) b[cnt[(a[i] >> sh) & 0xFFFF]++] = a[i];
+        a.swap(b);
+    }
+}
+
 // ---- link records + vertices ----------------------------------------------------------------------------
-inline void build_links(GraphHost &g) {
+// sorter: sorts distinct 64-bit keys ascending (host radix sort by default; the library passes its device pipeline)
+using KeySorter = std::function<void(std::vector<uint64_t> &)>;
+
+inline void build_links(GraphHost &g, const KeySorter &sorter = radix_sort_u64) {
     const uint64_t min_id = 3;
     const size_t ne = g.n_edges();
     g.recs.assign(ne * 2, GraphHost::Rec{0, 0});
@@ -222,17 +248,55 @@ inline void build_links(GraphHost &g) {
         else g.recs[2 * i + 1] = {((uint64_t)(g.eend[i] >> 1) << 2) | ((uint64_t)(g.eend[i] & 1) << 1), edge};
     }
     auto eam = [](const GraphHost::Rec &r) { return (r.edge << 2) | (r.hash_and_mask & 3); };
-    std::sort(g.recs.begin(), g.recs.end(), [&](const GraphHost::Rec &a, const GraphHost::Rec &b) {
-        uint64_t ha = a.hash_and_mask >> 2, hb = b.hash_and_mask >> 2;
-        if (ha != hb) return ha < hb;
-        return eam(a) < eam(b);
-    });
+    // CompareByVertexKMerEdgeIdAndMask: (rank, EdgeAndMask). rank < 2^31 and edge id < 2^31, so the pair packs into one
+    // 64-bit key (rank << 33 | EdgeAndMask); invalid records (self-conjugate ends) sort last as ~0.
+    const bool packable = ne < (1ull << 29);
+    if (packable) {
+        std::vector<uint64_t> keys(g.recs.size());
+        for (size_t i = 0; i < g.recs.size(); ++i) {
+            const GraphHost::Rec &r = g.recs[i];
+            const bool invalid = r.hash_and_mask + 1 == 0 && r.edge == 0;
+            keys[i] = invalid ? ~0ull : ((r.hash_and_mask >> 2) << 33) | eam(r);
+        }
+        {  // valid keys are distinct; the invalid ones (all ~0) are set aside so that the sorter sees distinct keys only
+            size_t nvalid = 0;
+            for (size_t i = 0; i < keys.size(); ++i)
+                if (keys[i] != ~0ull) keys[nvalid++] = keys[i];
+            const size_t ninv = keys.size() - nvalid;
+            keys.resize(nvalid);
+            sorter(keys);
+            keys.resize(nvalid + ninv, ~0ull);
+        }
+        for (size_t i = 0; i < keys.size(); ++i) {
+            if (keys[i] == ~0ull) g.recs[i] = {~0ull, 0};
+            else {
+                const uint64_t e = keys[i] & ((1ull << 33) - 1);
+                g.recs[i] = {((keys[i] >> 33) << 2) | (e & 3), e >> 2};
+            }
+        }
+    } else {
+        std::sort(g.recs.begin(), g.recs.end(), [&](const GraphHost::Rec &a, const GraphHost::Rec &b) {
+            uint64_t ha = a.hash_and_mask >> 2, hb = b.hash_and_mask >> 2;
+            if (ha != hb) return ha < hb;
+            return eam(a) < eam(b);
+        });
+    }
     g.vstart.clear();
     for (size_t i = 0; i < g.recs.size(); ++i) {
         const bool invalid = g.recs[i].hash_and_mask + 1 == 0 && g.recs[i].edge == 0;
         if ((i == 0 || (g.recs[i].hash_and_mask >> 2) != (g.recs[i - 1].hash_and_mask >> 2)) && !invalid) g.vstart.push_back(i);
     }
-    std::sort(g.vstart.begin(), g.vstart.end(), [&](size_t a, size_t b) { return eam(g.recs[a]) < eam(g.recs[b]); });
+    // vertices by their smallest EdgeAndMask (unique per vertex): key = EdgeAndMask << 31 | position in vstart
+    if (packable && g.vstart.size() < (1ull << 31)) {
+        std::vector<uint64_t> keys(g.vstart.size());
+        for (size_t i = 0; i < keys.size(); ++i) keys[i] = (eam(g.recs[g.vstart[i]]) << 31) | i;
+        sorter(keys);
+        std::vector<size_t> vs(keys.size());
+        for (size_t i = 0; i < keys.size(); ++i) vs[i] = g.vstart[(size_t)(keys[i] & ((1ull << 31) - 1))];
+        g.vstart.swap(vs);
+    } else {
+        std::sort(g.vstart.begin(), g.vstart.end(), [&](size_t a, size_t b) { return eam(g.recs[a]) < eam(g.recs[b]); });
+    }
     g.n_vertices = g.vstart.size();
 }
 
@@ -277,8 +341,12 @@ class BufWriter {
     void add(const char *s) { add(s, strlen(s)); }
     void num(uint64_t v) {
         char t[24];
-        int n = snprintf(t, sizeof t, "%llu", (unsigned long long)v);
-        add(t, (size_t)n);
+        int p = 24;
+        do {
+            t[--p] = (char)('0' + v % 10);
+            v /= 10;
+        } while (v);
+        add(t + p, (size_t)(24 - p));
     }
     void flush() {
         if (n_) ok_ &= fwrite(buf_.data(), 1, n_, f_) == n_;
