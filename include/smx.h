@@ -72,6 +72,10 @@ int smx_submit_reads_ascii(smx_ctx *ctx, const char *bases, const uint64_t *offs
  * payload (common/sequence/sequence.hpp BinWrite: size_t len + words). */
 int smx_submit_reads_packed(smx_ctx *ctx, const uint64_t *words, uint64_t n_words,
                             const uint64_t *start, const uint32_t *len, uint64_t n_reads);
+/* SPAdes' own binary read format: one <prefix>.seq file written by io::ReadConverter::ConvertToBinary
+ * (common/io/reads/binary_converter.cpp:83-151, read back by common/io/reads/binary_streams.hpp:54-102) — what the
+ * Construction stage streams inside a spades.py run. Single or paired file; reads arrive already N-trimmed. */
+int smx_submit_reads_binary(smx_ctx *ctx, const char *seq_path);
 /* Same, but the three arrays already live in HBM (benchmark path: inputs resident before the
  * timed region). The context borrows the pointers until smx_reads_clear()/smx_destroy();
  * d_words must be readable for n_words + 8 words (tail pad). */

@@ -41,6 +41,7 @@ def load():
         "smx_submit_reads_ascii": (C.c_int, [vp, C.c_char_p, u64p, C.c_uint64]),
         "smx_submit_reads_packed": (C.c_int, [vp, u64p, C.c_uint64, u64p, u32p, C.c_uint64]),
         "smx_submit_reads_device": (C.c_int, [vp, vp, C.c_uint64, vp, vp, C.c_uint64]),
+        "smx_submit_reads_binary": (C.c_int, [vp, C.c_char_p]),
         "smx_reads_info": (C.c_int, [vp, u64p, u64p]),
         "smx_count": (C.c_int, [vp, C.c_uint, C.c_int, C.c_uint]),
         "smx_count_info": (C.c_int, [vp, u64p, C.POINTER(C.c_uint), u64p]),

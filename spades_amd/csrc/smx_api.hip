@@ -49,7 +49,8 @@ struct smx_ctx {
     std::vector<uint64_t> bucket_off;
     // tuning / test hooks
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
-    int64_t opt_sort_edges = 0, opt_keep_loops = 1;  // spades-core construction variant (debruijn_graph_constructor.hpp:590-604)
+    int64_t opt_sort_edges = 0, opt_keep_loops = 1;
+    int64_t opt_leaf_grid = 0, opt_leaf_tab = 0;  // tuning experiments (tools/sweep.py)  // spades-core construction variant (debruijn_graph_constructor.hpp:590-604)
     // timings
     std::vector<Timing> timings;
     std::vector<std::string> tnames, xnames;  // last count stages / last extract_partition stages
@@ -554,7 +555,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
             sub_bits = 10;  // 1024 in-LDS digits (512 measured the same)
             while (sub_bits > 0 && (1u << sub_bits) > c) --sub_bits;
             T = 64;
-            while (T < 2 * c) T <<= 1;
+            while (T < (ctx->opt_leaf_tab > 0 ? (uint32_t)ctx->opt_leaf_tab : 2u) * c) T <<= 1;
             lds = (size_t)c * NW * 8 + ((size_t)T + 2 * ((size_t)1 << sub_bits) + 1 + c + 4) * 4;
         };
         unsigned sb1, sb2;
@@ -579,7 +580,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT>, lds2)) return rc;
         tbegin(ctx, "sort_unique");
         if (sb1 > 0) {
-            hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1>), dim3(256 * 8), dim3(BLK), lds1, ctx->stream, (void *)sortbuf, fine_off, cap1,
+            hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1>), dim3(ctx->opt_leaf_grid > 0 ? (unsigned)ctx->opt_leaf_grid : 256 * 16), dim3(BLK), lds1, ctx->stream, (void *)sortbuf, fine_off, cap1,
                                K, fa, sb1, T1, ucount, (const uint32_t *)medlist, (const uint32_t *)medcount, fblist, fbcount);
         } else {  // leaves too small for the digit table (test-sized caps): the general kernel takes the list directly
             hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT1>), dim3(256 * 8), dim3(BLK), lds1, ctx->stream, (void *)sortbuf,
@@ -1220,6 +1221,8 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "leaf_target")) ctx->opt_leaf_target = value;
     else if (!strcmp(key, "batch_records")) ctx->opt_batch_records = value;
     else if (!strcmp(key, "sort_edges")) ctx->opt_sort_edges = value;
+    else if (!strcmp(key, "leaf_grid")) ctx->opt_leaf_grid = value;
+    else if (!strcmp(key, "leaf_tab")) ctx->opt_leaf_tab = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
     else return fail(ctx, SMX_INVALID_PARAMETER, "unknown option %s", key);
     return SMX_OK;
@@ -1305,6 +1308,47 @@ int smx_submit_reads_ascii(smx_ctx *ctx, const char *bases, const uint64_t *offs
     free_temps(ctx);
     ctx->chunks.push_back(c);
     return SMX_OK;
+}
+
+// SPAdes binary reads (ReadConverter::ConvertToBinary output, the input of the Construction stage inside spades.py runs):
+// ReadStreamStat header {read_count, max_len, total_len} (io/reads/read_stream.hpp:21-38), then per read
+// Sequence::BinWrite (size_t length + ceil(len/32) 2-bit words, sequence.hpp:797-830; for 32 < len < 60 the top byte of
+// word 1 carries the short-sequence metadata and is masked here), uint16 left/right offsets and a uint64 tag
+// (io/reads/single_read.hpp:317-353). Paired files are the same records, two per pair (paired_read.hpp:102-108).
+// The reads were already cut to their longest ACGT run by the converter (read_converter.cpp:107-118, handle_Ns = true).
+int smx_submit_reads_binary(smx_ctx *ctx, const char *seq_path) {
+    if (!ctx || !seq_path) return SMX_INVALID_PARAMETER;
+    FILE *f = fopen(seq_path, "rb");
+    if (!f) return fail(ctx, SMX_INPUT_FILE_NOT_FOUND, "File %s doesn't exist or can't be read!", seq_path);
+    uint64_t hdr[3];
+    if (fread(hdr, 8, 3, f) != 3) {
+        fclose(f);
+        return fail(ctx, SMX_INVALID_INPUT_FORMAT, "%s: truncated binary read header", seq_path);
+    }
+    std::vector<uint64_t> words, start;
+    std::vector<uint32_t> len;
+    for (;;) {
+        uint64_t n;
+        if (fread(&n, 8, 1, f) != 1) break;  // EOF
+        if (n > 0xFFFFFFFFull) {
+            fclose(f);
+            return fail(ctx, SMX_INVALID_INPUT_FORMAT, "%s: corrupt read length", seq_path);
+        }
+        const size_t nw = (size_t)((n + 31) / 32), w0 = words.size();
+        words.resize(w0 + nw);
+        uint16_t offs[2];
+        uint64_t tag;
+        if ((nw && fread(words.data() + w0, 8, nw, f) != nw) || fread(offs, 2, 2, f) != 2 || fread(&tag, 8, 1, f) != 1) {
+            fclose(f);
+            return fail(ctx, SMX_INVALID_INPUT_FORMAT, "%s: truncated read record", seq_path);
+        }
+        if (n & 31) words[w0 + nw - 1] &= (1ull << ((n & 31) << 1)) - 1;  // tail (and the short-sequence metadata byte)
+        start.push_back((uint64_t)w0 * 32);
+        len.push_back((uint32_t)n);
+    }
+    fclose(f);
+    if (words.empty()) words.push_back(0);
+    return smx_submit_reads_packed(ctx, words.data(), words.size(), start.data(), len.data(), start.size());
 }
 
 int smx_submit_reads_device(smx_ctx *ctx, const void *d_words, uint64_t n_words, const void *d_start, const void *d_len,

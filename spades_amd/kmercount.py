@@ -105,6 +105,10 @@ class ReadKMerSplitter:
             self.ctx._h, words.ctypes.data_as(C.POINTER(C.c_uint64)), len(words),
             start.ctypes.data_as(C.POINTER(C.c_uint64)), length.ctypes.data_as(C.POINTER(C.c_uint32)), len(start)))
 
+    def push_back_binary(self, seq_path: str):
+        """SPAdes binary reads (<prefix>.seq of io::ReadConverter::ConvertToBinary)."""
+        _chk(self.ctx._h, self.ctx.lib.smx_submit_reads_binary(self.ctx._h, seq_path.encode()))
+
     def push_back_device(self, d_words: int, n_words: int, d_start: int, d_len: int, n_reads: int):
         """HBM-resident packed reads (raw device addresses, e.g. torch tensor .data_ptr())."""
         _chk(self.ctx._h, self.ctx.lib.smx_submit_reads_device(self.ctx._h, d_words, n_words, d_start, d_len, n_reads))

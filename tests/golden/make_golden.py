@@ -197,6 +197,20 @@ def main():
                     open(os.path.join(HERE, base + ext), "wb").write(open(out + ext, "rb").read())
                 manifest["cases"].append({"kind": "graph_spades", "reads": f"reads_{name}.txt", "K": K, "threads": T, "num_buckets": 10 * T,
                                           "coverage": cov, "base": base, "source": "spades-gbuilder binary (survey build), --spades"})
+        # binary reads written by the reference's converter (kept in -tmp-dir): single_0.seq of reads_small / reads_tiny
+        import shutil
+        for name in ("small", "tiny"):
+            reads = [r for r in gsets[name][1] if r]
+            with tempfile.TemporaryDirectory() as td:
+                fq = os.path.join(td, "r.fq")
+                with open(fq, "w") as f:
+                    for i, r in enumerate(reads):
+                        f.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n")
+                subprocess.check_call([gb, fq, os.path.join(td, "o.gfa"), "-k", "21", "-t", "1", "--gfa", "-tmp-dir", os.path.join(td, "t")],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                shutil.copy(os.path.join(td, "t", "single_0.seq"), os.path.join(HERE, f"binreads_{name}_single_0.seq"))
+                manifest["cases"].append({"kind": "binary_reads", "reads": f"reads_{name}.txt", "file": f"binreads_{name}_single_0.seq",
+                                          "source": "ReadConverter::ConvertToBinary via spades-gbuilder -tmp-dir (survey build)"})
         # --fastg (io/graph/fastg_writer.cpp)
         for name, K, T, cov in (("tiny", 21, 1, False), ("small", 21, 3, True), ("loop", 21, 1, True), ("polyA", 21, 1, False)):
             reads = [r for r in gsets[name][1] if r]

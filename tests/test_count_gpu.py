@@ -131,3 +131,21 @@ def test_invalid_parameters():
     sp2 = ReadKMerSplitter(21, "A", sp.ctx)
     with pytest.raises(SmxError):
         KMerDiskCounter(None, sp2).Count(0)
+
+
+def test_spades_binary_reads_input():
+    """<prefix>.seq written by the reference's ReadConverter gives the same k-mer file as the ASCII reads it was made from."""
+    from spades_amd import KMerDiskCounter, ReadKMerSplitter
+    for c in [c for c in load_manifest()["cases"] if c["kind"] == "binary_reads"]:
+        for K, mode, nb in ((21, "A", 16), (33, "A", 16), (32, "B", 10), (55, "B", 30)):
+            gold = [g for g in CASES if g["reads"] == c["reads"] and g["K"] == K and g["mode"] == mode and g["num_buckets"] == nb][0]
+            sp = ReadKMerSplitter(K, mode)
+            sp.push_back_binary(os.path.join(GOLDEN, c["file"]))
+            st = KMerDiskCounter(None, sp).Count(nb)
+            assert hashlib.md5(st.records().tobytes()).hexdigest() == gold["md5"]
+            sp.ctx.close()
+    from spades_amd import SmxError
+    sp = ReadKMerSplitter(21, "A")
+    with pytest.raises(SmxError) as e:
+        sp.push_back_binary("/nonexistent.seq")
+    assert e.value.code == 65
