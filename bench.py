@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--construct-reads", type=float, default=2e6,
                     help="extra (untimed for the headline): de Bruijn construction (k=55, -t 16, -c) on this many reads; 0 disables")
+    ap.add_argument("--construct-sharded", action="store_true",
+                    help="with N>1 (or --force-sharded): also time spades_amd.dist.sharded_build_graph on --construct-reads reads per rank")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
     args = ap.parse_args()
 
@@ -223,6 +225,21 @@ def main():
                             "reads": nc, "build_s": round(t1 - t0, 4), "coverage_s": round(t2 - t1, 4),
                             "M_reads_per_s": round(nc / (t1 - t0) / 1e6, 3), "n_kpomers": int(info["n_kpomers"]),
                             "n_kmers": int(info["n_kmers"]), "n_unitigs": int(info["n_unitigs"]), "n_vertices": int(info["n_vertices"])}
+    if sharded and args.construct_sharded and args.construct_reads > 0:
+        # multi-GPU construction (collective): sharded (k+1)-mer count -> gather -> replicated build -> all-reduced coverage
+        nc = int(min(args.construct_reads, n_reads)) // 32 * 32
+        sp.clear()
+        sp.push_back_device(words.data_ptr(), nc * L // 32, start.data_ptr(), ln.data_ptr(), nc)
+        geng = smx_dist.GpuEngine(ctx, "B")
+        smx_dist.sharded_build_graph(geng, 55, 16, rank, world, dev, coverage=True)  # warm-up
+        sync()
+        t0 = time.perf_counter()
+        info = smx_dist.sharded_build_graph(geng, 55, 16, rank, world, dev, coverage=True)
+        sync()
+        t1 = time.perf_counter()
+        out["construct_sharded"] = {"workload": f"{nc} reads per rank x {world} ranks, k=55, 160 buckets, -c; replicated graph on every rank",
+                                    "seconds": round(t1 - t0, 4), "M_reads_per_s": round(nc * world / (t1 - t0) / 1e6, 3),
+                                    "n_kpomers": int(info["n_kpomers"]), "n_unitigs": int(info["n_unitigs"])}
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()

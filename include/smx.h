@@ -106,6 +106,8 @@ int smx_copy_final_kmers(const smx_ctx *ctx, void *host_dst);
 int smx_write_final_kmers(const smx_ctx *ctx, const char *path);
 /* device view of the same bytes (valid until the next smx_count / smx_destroy) */
 const void *smx_device_kmers(const smx_ctx *ctx);
+/* device-to-device copy of the same array into caller-owned HBM (e.g. a torch tensor about to enter a collective) */
+int smx_copy_kmers_device(const smx_ctx *ctx, void *d_dst);
 
 /* ---- multi-GPU sharding ---------------------------------------------------
  * Bucket ownership is a contiguous bucket range per rank. smx_extract_partition runs the
@@ -131,6 +133,13 @@ unsigned smx_rank_first_bucket(unsigned num_buckets, unsigned world, unsigned ra
  * of spades-gbuilder depends on it (SURVEY.md finding 3). k odd, 1 <= k < 128 (projects/spades_tools/gbuilder.cpp:130-135).
  * After the call smx_copy_final_kmers()/smx_bucket_sizes() describe the canonical k-mer file. */
 int smx_build_graph(smx_ctx *ctx, unsigned k, unsigned num_buckets);
+/* Multi-GPU construction ("replicated lookup"; precedent: hpcspades/mpi/stages/construction_mpi.cpp:343-354,
+ * count per node + merge): the same steps on a canonical (k+1)-mer file that the caller gathered from its owner ranks
+ * (HBM pointer, any order, duplicates allowed) instead of on the resident reads. The resident reads are still what
+ * smx_graph_fill_coverage counts; per-rank raw coverages add up (smx_graph_copy_coverage -> all-reduce SUM ->
+ * smx_graph_set_coverage), because edge coverage is a sum of per-(k+1)-mer counts (coverage_filling.hpp:17-55). */
+int smx_build_graph_from_records(smx_ctx *ctx, unsigned k, unsigned num_buckets, const void *d_kpomers, uint64_t n_records);
+int smx_graph_set_coverage(smx_ctx *ctx, const uint32_t *raw_coverage, uint64_t n_unitigs);
 /* info[8] = { #canonical (k+1)-mers, #canonical k-mers, #unitigs (incl. loops), #perfect loops, #vertices, #links
  * (valid after a GFA was written), total unitig nucleotides, words per k-mer } */
 int smx_graph_info(const smx_ctx *ctx, uint64_t *info);

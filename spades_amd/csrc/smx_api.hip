@@ -895,7 +895,7 @@ int device_sort_u64(smx_ctx *ctx, std::vector<uint64_t> &keys) {
 }
 
 template <int NW>
-int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
+int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullptr, uint64_t n_kpo_recs = 0) {
     clear_graph(ctx);
     WallTrace gwt;
     ctx->g_k = k;
@@ -904,7 +904,11 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B) {
     ctx->gh.k = k;
     ctx->gh.eoff.assign(1, 0);
     // ---- 1. canonical (k+1)-mers -------------------------------------------------------------
-    if (int rc = count_reads<NW>(ctx, k + 1, SMX_MODE_CANONICAL, B)) return rc;
+    if (kpo_recs) {  // multi-GPU: the (k+1)-mer file gathered from its owner ranks (any order; re-sorted here)
+        if (int rc = run_count<NW>(ctx, k + 1, SMX_MODE_ALL, B, kpo_recs, n_kpo_recs)) return rc;
+    } else {
+        if (int rc = count_reads<NW>(ctx, k + 1, SMX_MODE_CANONICAL, B)) return rc;
+    }
     ctx->g_kpo = ctx->d_result_buf;
     ctx->g_nkpo = ctx->n_records;
     ctx->g_kpoboff = ctx->bucket_off;
@@ -1505,7 +1509,7 @@ int smx_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned num_bucke
     return rc;
 }
 
-int smx_build_graph(smx_ctx *ctx, unsigned k, unsigned num_buckets) {
+static int build_graph_impl(smx_ctx *ctx, unsigned k, unsigned num_buckets, const void *recs, uint64_t nrecs) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     // gbuilder.cpp:130-135: MIN_K <= k < MAX_K(128), k odd
     if (k < 1) return fail(ctx, SMX_INVALID_PARAMETER, "k-mer size %u is too low", k);
@@ -1517,10 +1521,10 @@ int smx_build_graph(smx_ctx *ctx, unsigned k, unsigned num_buckets) {
     ctx->xms.clear();
     int rc;
     switch ((k + 32) / 32) {  // words of k+1 (== words of k because k is odd)
-        case 1: rc = run_graph<1>(ctx, k, num_buckets); break;
-        case 2: rc = run_graph<2>(ctx, k, num_buckets); break;
-        case 3: rc = run_graph<3>(ctx, k, num_buckets); break;
-        default: rc = run_graph<4>(ctx, k, num_buckets); break;
+        case 1: rc = run_graph<1>(ctx, k, num_buckets, recs, nrecs); break;
+        case 2: rc = run_graph<2>(ctx, k, num_buckets, recs, nrecs); break;
+        case 3: rc = run_graph<3>(ctx, k, num_buckets, recs, nrecs); break;
+        default: rc = run_graph<4>(ctx, k, num_buckets, recs, nrecs); break;
     }
     (void)hipStreamSynchronize(ctx->stream);
     if (rc == 0) {
@@ -1535,6 +1539,35 @@ int smx_build_graph(smx_ctx *ctx, unsigned k, unsigned num_buckets) {
     free_temps(ctx);
     if (rc) clear_graph(ctx);
     return rc;
+}
+
+int smx_build_graph(smx_ctx *ctx, unsigned k, unsigned num_buckets) { return build_graph_impl(ctx, k, num_buckets, nullptr, 0); }
+
+int smx_build_graph_from_records(smx_ctx *ctx, unsigned k, unsigned num_buckets, const void *d_kpomers, uint64_t n_records) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    if (n_records && !d_kpomers) return fail(ctx, SMX_INVALID_PARAMETER, "null records");
+    static const uint64_t dummy = 0;
+    return build_graph_impl(ctx, k, num_buckets, n_records ? d_kpomers : (const void *)&dummy, n_records);
+}
+
+int smx_graph_set_coverage(smx_ctx *ctx, const uint32_t *raw_coverage, uint64_t n_edges) {
+    if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
+    if (n_edges != ctx->gh.n_edges()) return fail(ctx, SMX_INVALID_PARAMETER, "coverage array has %llu entries, graph has %llu unitigs",
+                                                  (unsigned long long)n_edges, (unsigned long long)ctx->gh.n_edges());
+    if (n_edges && !raw_coverage) return SMX_INVALID_PARAMETER;
+    ctx->gh.ecov.assign(raw_coverage, raw_coverage + n_edges);
+    return SMX_OK;
+}
+
+int smx_copy_kmers_device(const smx_ctx *cctx, void *d_dst) {
+    smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    if (ctx->n_records == 0) return SMX_OK;
+    if (!d_dst) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(d_dst, ctx->d_result, ctx->n_records * ctx->nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SMX_OK;
 }
 
 int smx_graph_info(const smx_ctx *ctx, uint64_t *info /* [8] */) {

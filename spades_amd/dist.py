@@ -53,6 +53,32 @@ class GpuEngine:
                 "device_ptr": int(self.ctx.lib.smx_device_kmers(h) or 0)}
 
 
+    # -- construction (the compact structure is gathered and the lookup replicated) --
+    def result_tensor(self, n_words: int, dev):
+        t = torch.empty(max(n_words, 1), dtype=torch.int64, device=dev)
+        _chk(self.ctx._h, self.ctx.lib.smx_copy_kmers_device(self.ctx._h, t.data_ptr()))
+        return t
+
+    def build_graph_from_records(self, k: int, nb: int, buf: torch.Tensor, n: int):
+        h = self.ctx._h
+        _chk(h, self.ctx.lib.smx_build_graph_from_records(h, k, nb, buf.data_ptr(), n))
+        info = (C.c_uint64 * 8)()
+        _chk(h, self.ctx.lib.smx_graph_info(h, info))
+        return dict(n_kpomers=info[0], n_kmers=info[1], n_unitigs=info[2], n_loops=info[3], n_vertices=info[4],
+                    unitig_bases=info[6], words=info[7])
+
+    def local_raw_coverage(self, n_unitigs: int) -> torch.Tensor:
+        h = self.ctx._h
+        _chk(h, self.ctx.lib.smx_graph_fill_coverage(h))
+        out = torch.zeros(max(n_unitigs, 1), dtype=torch.int32)
+        _chk(h, self.ctx.lib.smx_graph_copy_coverage(h, C.cast(out.data_ptr(), C.POINTER(C.c_uint32))))
+        return out[:n_unitigs]
+
+    def set_raw_coverage(self, cov: torch.Tensor):
+        cov = cov.contiguous()
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_set_coverage(self.ctx._h, C.cast(cov.data_ptr(), C.POINTER(C.c_uint32)), cov.numel()))
+
+
 def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
     """One step of the sharded path on this rank. Returns the owner-side result dict of the engine
     (+ 'sent'/'received' record counts). Collective: every rank must call it."""
@@ -105,3 +131,46 @@ def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
     res["sent"], res["received"] = n_local, n_recv
     res["instances"] = n_local  # k-mer instances extracted from this rank's reads
     return res
+
+
+def _bcast_chunks(t: torch.Tensor, a: int, b: int, src: int):
+    """broadcast t[a:b] from rank src in rounds of XCHG_LIMIT elements (same size cap as the exchange above)"""
+    while a < b:
+        e = min(a + XCHG_LIMIT, b)
+        dist.broadcast(t[a:e], src=src)
+        a = e
+
+
+def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev, coverage: bool = False):
+    """Construction on `world` ranks (collective). Counting of the canonical (k+1)-mers is sharded exactly like
+    sharded_count; the owners' sorted-unique arrays are then all-gathered (bucket-major, so the concatenation in rank
+    order IS the (k+1)-mer file) and every rank derives the same k-mer file, masks, unitigs and links from it — the
+    replicated-lookup variant of SURVEY.md §8e (unitig walks cross owners at every step). Coverage (-c) stays sharded:
+    each rank counts its own reads against the replicated (k+1)-mer file, raw edge coverages are all-reduced (SUM mod 2^32).
+    Every rank ends with the same graph; rank 0 normally writes it. Returns the engine's graph info dict."""
+    K1, nb = k + 1, 10 * threads
+    nw = (K1 + 31) // 32
+    res = sharded_count(engine, K1, nb, rank, world, dev)
+    mine = torch.tensor([res["distinct"]], dtype=torch.int64, device=dev)
+    every = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    counts = [int(c.item()) for c in every]
+    off = [0]
+    for c in counts:
+        off.append(off[-1] + c * nw)
+    full = engine.alloc(off[-1], dev)
+    if counts[rank]:
+        full[off[rank]:off[rank + 1]].copy_(engine.result_tensor(counts[rank] * nw, dev)[:counts[rank] * nw])
+    for r in range(world):
+        _bcast_chunks(full, off[r], off[r + 1], r)
+    info = engine.build_graph_from_records(k, nb, full, sum(counts))
+    del full
+    if coverage:
+        cov = engine.local_raw_coverage(info["n_unitigs"]).to(torch.int64) & 0xFFFFFFFF
+        cov = cov.to(dev)
+        dist.all_reduce(cov, op=dist.ReduceOp.SUM)
+        cov = (cov & 0xFFFFFFFF).to("cpu")
+        cov = torch.where(cov >= 2 ** 31, cov - 2 ** 32, cov).to(torch.int32)  # uint32 bit pattern
+        engine.set_raw_coverage(cov)
+    info["kpomers_per_rank"] = counts
+    return info

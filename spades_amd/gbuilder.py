@@ -40,6 +40,11 @@ class GraphBuilder:
                           n_links=info[5], unitig_bases=info[6], words=info[7])
         return self._info
 
+    def adopt(self, info: dict):
+        """take over a graph built on this context by spades_amd.dist.sharded_build_graph"""
+        self._info = dict(info)
+        return self._info
+
     def info(self):
         info = (C.c_uint64 * 8)()
         _chk(self.ctx._h, self.ctx.lib.smx_graph_info(self.ctx._h, info))

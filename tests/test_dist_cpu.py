@@ -106,3 +106,82 @@ def test_sharded_count_world2_gloo(K, mode, nb, limit):
         lo, hi = rank_first_bucket(nb, world, rank), rank_first_bucket(nb, world, rank + 1)
         assert all(b == 0 for i, b in enumerate(bs) if not (lo <= i < hi))
     assert sum(g[3] for g in got) == sum(g[4] for g in got)  # every record sent is received exactly once
+
+
+class OracleGraphEngine(OracleEngine):
+    """adds the construction half of the GpuEngine contract (replicated graph, sharded coverage)"""
+
+    def __init__(self, reads, all_reads):
+        super().__init__(reads, "B")
+        self.all_reads = all_reads
+
+    def result_tensor(self, n_words, dev):
+        return torch.from_numpy(self.result.reshape(-1).view(np.int64).copy())
+
+    def build_graph_from_records(self, k, nb, buf, n):
+        from oracle import oracle
+        nw = (k + 1 + 31) // 32
+        self.gathered = buf[:n * nw].numpy().view(np.uint64).reshape(n, nw).copy()
+        self.k = k
+        self.g = oracle.build_graph(self.all_reads, k, nb, coverage=True)
+        return dict(n_kpomers=self.g["n_kpomers"], n_kmers=len(self.g["kmers"]), n_unitigs=len(self.g["unitigs"]),
+                    n_loops=self.g["n_loops"], n_vertices=self.g["n_vertices"], unitig_bases=0, words=nw)
+
+    def local_raw_coverage(self, n_unitigs):
+        # (k+1)-mer instances of this rank's reads (+RC), per unitig; a (k+1)-mer and its RC are the same canonical key
+        from collections import Counter
+        from oracle import oracle
+        K1 = self.k + 1
+        tr = str.maketrans("ACGT", "TGCA")
+        c = Counter()
+        for r in self.reads:
+            a, b = oracle.longest_valid(r)
+            s = r[a:b].upper()
+            for j in range(len(s) - K1 + 1):  # read + RC stream, minimal orientation counted: once per occurrence, palindromes twice
+                x = s[j:j + K1]
+                y = x[::-1].translate(tr)
+                c[min(x, y)] += 2 if x == y else 1
+        out = []
+        for u in self.g["unitigs"]:
+            out.append(sum(c[min(u[j:j + K1], u[j:j + K1][::-1].translate(tr))] for j in range(len(u) - K1 + 1)))
+        return torch.tensor(out, dtype=torch.int64).to(torch.int32)
+
+    def set_raw_coverage(self, cov):
+        self.cov = cov.numpy().astype(np.uint32)
+
+
+def _graph_worker(rank, world, port, k, threads, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spades_amd import dist as smx_dist
+    smx_dist.XCHG_LIMIT = 700  # several broadcast rounds per owner
+    reads = read_lines("reads_small.txt")[:120]
+    eng = OracleGraphEngine(reads[rank::world], reads)
+    info = smx_dist.sharded_build_graph(eng, k, threads, rank, world, torch.device("cpu"), coverage=True)
+    q.put((rank, eng.gathered.tobytes(), eng.cov.tobytes(), info["kpomers_per_rank"], eng.g["gfa"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_build_graph_world2_gloo():
+    from oracle import oracle
+    world, k, threads = 2, 21, 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, k, threads, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    reads = read_lines("reads_small.txt")[:120]
+    ref, _ = oracle.count(reads, k + 1, "B", 10 * threads)
+    kc = np.array([int(l.split("KC:i:")[1]) for l in got[0][4].splitlines() if l.startswith("S\t")], dtype=np.uint32)
+    for rank, gathered, cov, per_rank, _ in got:
+        assert gathered == ref.tobytes()  # every rank holds the reference's (k+1)-mer file
+        assert sum(per_rank) == len(ref)
+        assert (np.frombuffer(cov, dtype=np.uint32) == kc).all()  # all-reduced sharded coverage == reference KC tags
