@@ -2,6 +2,7 @@
 // Built by hipcc into libspades_mi355x.so; no torch / no reference headers involved.
 #include "../../include/smx.h"
 #include "smx_kernels.hip"
+#include "smx_superkmer.hip"
 #include "smx_graph.hip"
 #include "smx_graph_host.hpp"
 
@@ -50,6 +51,9 @@ struct smx_ctx {
     // tuning / test hooks
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;
+    int64_t opt_prededupe = -1;  // super-k-mer pre-deduplication: -1 auto, 0 off, 1 on whenever K allows it
+    int64_t opt_skm_cap = 0;     // instances per LDS dedupe chunk (0 = default)
+    int64_t opt_skm_scap = 0;    // slots staged per chunk (0 = default)
     int64_t opt_leaf_grid = 0, opt_leaf_tab = 0;  // tuning experiments (tools/sweep.py)  // spades-core construction variant (debruijn_graph_constructor.hpp:590-604)
     // timings
     std::vector<Timing> timings;
@@ -360,7 +364,7 @@ struct ReadSel {  // which part of the resident reads one pipeline run covers
 
 template <int NW>
 int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in, const ReadSel *sel = nullptr,
-              bool recs_reusable = false) {
+              bool recs_reusable = false, bool expand_rc = false) {
     uint32_t cap = Tune<NW>::CAP;
     if (ctx->opt_leaf_cap > 0) cap = (uint32_t)std::min<int64_t>(ctx->opt_leaf_cap, cap);
     const uint32_t cap1 = std::min<uint32_t>(Tune<NW>::CAP1, cap);
@@ -373,7 +377,8 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
 
     WallTrace wt;
     std::vector<uint64_t *> masks;
-    uint64_t nrec = n_in;
+    uint64_t nrec = expand_rc ? 2 * n_in : n_in;  // expand_rc: every input record also stands for its reverse complement
+    if (expand_rc) recs_reusable = false;
     if (from_reads && sel && sel->masks) {
         masks = *sel->masks;
         nrec = sel->nrec;
@@ -493,6 +498,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         a.recs = d_recs;
         a.seg_off = seg1;
         a.nseg = 1;
+        a.expand = expand_rc ? 1u : 0u;
         if (int rc = pass_recs<NW, BIN_L1>(ctx, false, a, nrec, tcnt, tstart)) return rc;
     }
     tend(ctx);
@@ -512,6 +518,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     }
     tend(ctx);
 
+    a.expand = 0;
     wt.mark(ctx, "level1");
     // ---- levels 2.. -------------------------------------------------------------------------
     Rec<NW> *sortbuf = bufA, *other = bufB;
@@ -611,6 +618,23 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         HIPCHK(hipGetLastError());
         tend(ctx);
     }
+    if (wt.on) {
+        uint32_t c[5] = {0, 0, 0, 0, 0};
+        (void)hipMemcpy(&c[0], smallcount, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&c[1], medcount, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&c[2], med2count, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&c[3], fbcount, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&c[4], bigcount, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[smx] leaves: %llu bins (F1=%u, levels=%zu) wave=%u med=%u med2=%u fallback=%u big=%u\n", (unsigned long long)nb, F1, lv.size(),
+                c[0], c[1], c[2], c[3], c[4]);
+        for (uint32_t i = 0; i < std::min<uint32_t>(c[4], 20); ++i) {
+            uint32_t bi = 0;
+            unsigned long long o[2] = {0, 0};
+            (void)hipMemcpy(&bi, biglist + i, 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(o, fine_off + bi, 16, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[smx]   big leaf: bin %u size %llu\n", bi, o[1] - o[0]);
+        }
+    }
     wt.mark(ctx, "leaf sort");
     // ---- compact ----------------------------------------------------------------------------
     tbegin(ctx, "compact");
@@ -639,6 +663,113 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     return 0;
 }
 
+
+// Super-k-mer pre-deduplication of the selected windows (smx_superkmer.hip). *out: canonical K-mers, every k-mer of the
+// selection at least once and most of them exactly once (temp buffer of nwin records), *n_out: how many.
+template <int NW>
+int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, Rec<NW> **out, uint64_t *n_out) {
+    constexpr int SW = 2 * NW;
+    const std::vector<uint64_t *> &masks = *sel.masks;
+    unsigned long long *cnt, *soff, *ocount, *cursor;
+    if (int rc = dalloc(ctx, &cnt, SKM_NKEY)) return rc;
+    if (int rc = dalloc(ctx, &soff, SKM_NKEY + 1)) return rc;
+    if (int rc = dalloc(ctx, &cursor, SKM_NKEY)) return rc;
+    if (int rc = dalloc(ctx, &ocount, 1)) return rc;
+    HIPCHK(hipMemsetAsync(cnt, 0, (size_t)SKM_NKEY * 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(ocount, 0, 8, ctx->stream));
+    SkmArgs a{};
+    a.K = K;
+    a.w = K - SKM_M + 1;
+    a.cnt = cnt;
+    auto pass = [&](int phase) -> int {
+        for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
+            const ReadChunk &ch = ctx->chunks[ci];
+            if (ch.n_bases == 0 || !masks[ci]) continue;
+            a.seq = ch.d_words;
+            a.nwords = ch.n_words;
+            a.mask = masks[ci];
+            a.g0 = sel.ranges ? (*sel.ranges)[ci].first : 0;
+            a.G = sel.ranges ? (*sel.ranges)[ci].second : ch.n_bases;
+            if (a.G <= a.g0) continue;
+            const uint64_t ntiles = (a.G - a.g0 + SKM_TP - 1) / SKM_TP;
+            const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 16);
+            if (phase == 0) hipLaunchKernelGGL((k_skm_scan<0, NW>), dim3(grid), dim3(BLK), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((k_skm_scan<1, NW>), dim3(grid), dim3(BLK), 0, ctx->stream, a);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    };
+    tbegin(ctx, "skm_count");
+    if (int rc = pass(0)) return rc;
+    tend(ctx);
+    tbegin(ctx, "skm_scan");
+    if (int rc = scan_u64(ctx, cnt, soff, SKM_NKEY)) return rc;
+    unsigned long long nslots = 0;
+    HIPCHK(hipMemcpyAsync(&nslots, soff + SKM_NKEY, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    tend(ctx);
+    uint64_t *slots;
+    if (int rc = dalloc(ctx, &slots, (size_t)nslots * SW + SW)) return rc;
+    HIPCHK(hipMemcpyAsync(cursor, soff, (size_t)SKM_NKEY * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    a.cursor = cursor;
+    a.slots = slots;
+    tbegin(ctx, "skm_scatter");
+    if (int rc = pass(1)) return rc;
+    tend(ctx);
+    if (int rc = dalloc(ctx, out, nwin + 1)) return rc;
+    uint32_t cap = 2048;
+    if (ctx->opt_skm_cap > 0) {
+        cap = 512;
+        while (cap < (uint32_t)std::min<int64_t>(ctx->opt_skm_cap, 8192)) cap <<= 1;
+    }
+    const uint32_t T = 2 * cap;
+    const uint32_t scap = std::min<uint32_t>(SKM_SCAP, ctx->opt_skm_scap > 0 ? (uint32_t)ctx->opt_skm_scap : cap / 8);  // ~12+ windows per slot on average
+    const size_t lds = (size_t)scap * SW * 8 + (size_t)T * 4 + 514 * 4 + (size_t)cap * 4 + 512 + 16;
+    if (int rc = set_lds(ctx, k_skm_dedupe<NW>, lds)) return rc;
+    const uint32_t nitems = SKM_NKEY / SKM_KEYS_PER_ITEM;
+    unsigned long long *prof = nullptr;
+    if (getenv("SMX_DEBUG")) {
+        if (int rc = dalloc(ctx, &prof, 8)) return rc;
+        HIPCHK(hipMemsetAsync(prof, 0, 64, ctx->stream));
+    }
+    tbegin(ctx, "skm_dedupe");
+    hipLaunchKernelGGL((k_skm_dedupe<NW>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
+                       (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, ocount, prof);
+    HIPCHK(hipGetLastError());
+    tend(ctx);
+    if (prof) {
+        unsigned long long hp[6];
+        HIPCHK(hipMemcpy(hp, prof, 48, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[smx] dedupe chunks=%llu slots/chunk=%.1f; 100MHz ticks per chunk: stage+clear %.1f, scan+plan %.1f, insert %.1f, output %.1f\n",
+                hp[4], hp[4] ? (double)hp[5] / hp[4] : 0.0, hp[4] ? (double)hp[0] / hp[4] : 0.0, hp[4] ? (double)hp[1] / hp[4] : 0.0,
+                hp[4] ? (double)hp[2] / hp[4] : 0.0, hp[4] ? (double)hp[3] / hp[4] : 0.0);
+    }
+    unsigned long long n = 0;
+    HIPCHK(hipMemcpyAsync(&n, ocount, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (n > nwin) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication produced %llu records from %llu windows", n, (unsigned long long)nwin);
+    *n_out = n;
+    if (getenv("SMX_DEBUG"))
+        fprintf(stderr, "[smx] prededupe: %llu windows -> %llu super-k-mers -> %llu canonical records\n", (unsigned long long)nwin, nslots, n);
+    return 0;
+}
+
+// One pipeline run over a selection of the resident reads: straight from the windows, or through the pre-dedupe stage.
+template <int NW>
+int count_selection(smx_ctx *ctx, unsigned K, int mode, unsigned B, const ReadSel &sel) {
+    const uint64_t nwin = mode == SMX_MODE_ALL ? sel.nrec / 2 : sel.nrec;
+    const bool possible = K >= 21 && K - SKM_M + 1 <= (unsigned)SKM_WMAX && nwin > 0;
+    const bool use = possible && (ctx->opt_prededupe > 0 || (ctx->opt_prededupe < 0 && nwin >= (1u << 20)));
+    if (!use) return run_count<NW>(ctx, K, mode, B, nullptr, 0, &sel);
+    Rec<NW> *recs = nullptr;
+    uint64_t n = 0;
+    if (int rc = run_prededupe<NW>(ctx, K, sel, nwin, &recs, &n)) return rc;
+    free_temps(ctx, recs);
+    ctx->temps.push_back(recs);
+    if (int rc = run_count<NW>(ctx, K, mode, B, recs, n, nullptr, false, mode == SMX_MODE_ALL)) return rc;
+    ctx->n_instances = sel.nrec;
+    return 0;
+}
 
 // Counting from the resident reads with HBM-bounded batches (the reference's dump + merge, kmer_splitter.hpp:123-170 +
 // kmer_index_builder.hpp:346-430): when two record buffers of the whole batch do not fit the budget, the position
@@ -675,7 +806,7 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
         ReadSel sel;
         sel.masks = &masks;
         sel.nrec = nrec;
-        rc = run_count<NW>(ctx, K, mode, B, nullptr, 0, &sel);
+        rc = count_selection<NW>(ctx, K, mode, B, sel);
         drop_masks();
         return rc;
     }
@@ -715,7 +846,7 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
         sel.ranges = &ranges;
         sel.nrec = nw_b * rpp;
         total_inst += sel.nrec;
-        if ((rc = run_count<NW>(ctx, K, mode, B, nullptr, 0, &sel))) return cleanup(rc);
+        if ((rc = count_selection<NW>(ctx, K, mode, B, sel))) return cleanup(rc);
         void *run = ctx->d_result_buf;
         const uint64_t nrun = ctx->n_records;
         ctx->d_result_buf = ctx->d_result = nullptr;
@@ -1227,6 +1358,9 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "sort_edges")) ctx->opt_sort_edges = value;
     else if (!strcmp(key, "leaf_grid")) ctx->opt_leaf_grid = value;
     else if (!strcmp(key, "leaf_tab")) ctx->opt_leaf_tab = value;
+    else if (!strcmp(key, "prededupe")) ctx->opt_prededupe = value;
+    else if (!strcmp(key, "skm_cap")) ctx->opt_skm_cap = value;
+    else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
     else return fail(ctx, SMX_INVALID_PARAMETER, "unknown option %s", key);
     return SMX_OK;

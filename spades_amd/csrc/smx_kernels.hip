@@ -43,6 +43,7 @@ struct PassArgs {
     uint32_t nprev;     // BIN_LK: key fan-outs already applied (S1, F2, ...), mixed radix on the key fraction
     uint32_t fprev[6];
     uint32_t world;
+    uint32_t expand;  // records source, level 1 only: instance i = record i/2, odd i = its reverse complement
     uint32_t F;  // bins per segment
     unsigned long long *hist;    // [nseg*F]
     unsigned long long *cursor;  // [nseg*F]
@@ -154,13 +155,19 @@ __device__ __forceinline__ void fetch_records(const PassArgs &a, uint64_t tile, 
                                               Rec<NW> (&r)[RPT], uint32_t &validmask) {
     validmask = 0;
     if constexpr (SRC == SRC_RECS) {
-        const Rec<NW> *in = (const Rec<NW> *)a.recs + seg_base;
+        const Rec<NW> *in = (const Rec<NW> *)a.recs;
         const uint64_t base = tile * (uint64_t)(RPT * BLK);
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             uint64_t i = base + (uint64_t)j * BLK + threadIdx.x;
             if (i < seg_n) {
-                r[j] = in[i];
+                const uint64_t gi = seg_base + i;
+                if (a.expand) {
+                    Rec<NW> x = in[gi >> 1];
+                    r[j] = (gi & 1) ? rec_rc<NW>(x, a.K) : x;
+                } else {
+                    r[j] = in[gi];
+                }
                 validmask |= 1u << j;
             }
         }
@@ -226,9 +233,16 @@ __global__ void __launch_bounds__(BLK) k_hist(PassArgs a) {
         const uint64_t sn = a.seg_off[seg + 1] - sb;
         const uint64_t t0 = (uint64_t)tin * a.tile_recs;
         const uint64_t t1 = (sn < t0 + a.tile_recs) ? sn : t0 + a.tile_recs;
-        const Rec<NW> *in = (const Rec<NW> *)a.recs + sb;
+        const Rec<NW> *in = (const Rec<NW> *)a.recs;
         for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK) {
-            Rec<NW> x = in[i];
+            const uint64_t gi = sb + i;
+            Rec<NW> x;
+            if (a.expand) {
+                x = in[gi >> 1];
+                if (gi & 1) x = rec_rc<NW>(x, a.K);
+            } else {
+                x = in[gi];
+            }
             atomicAdd(&lh[bin_of<NW, BINF>(x, a)], 1u);
         }
         __syncthreads();

@@ -1,0 +1,402 @@
+// spades_amd/csrc/smx_superkmer.hip — on-chip pre-deduplication of k-mer instances (included by smx_api.hip).
+//
+// The reference materialises every k-mer instance before it sorts and uniques them (KMerSortingSplitter buffers,
+// kmer_index/kmer_mph/kmer_splitter.hpp:55-179): I records of W bytes. On the GPU that stream is the HBM traffic of
+// every MSD level. This stage removes most duplicates BEFORE anything of size I*W exists:
+//   1. k_skm_scan   cut the valid windows of the 2-bit read stream into super-k-mers (maximal runs of consecutive
+//                   windows sharing their canonical minimizer, m = 11) and counting-sort them by minimizer key into
+//                   fixed slots of 2*NW words (<= 2K-m nucleotides + a count byte): ~1.3 bytes per instance;
+//   2. k_skm_dedupe a workgroup expands a few thousand instances of consecutive minimizer keys inside LDS, keeps one
+//                   canonical copy of each k-mer (exact hash set keyed by (slot, offset) references) and appends the
+//                   survivors to a record array in HBM.
+// All copies of a k-mer (either strand) share their canonical minimizer, hence their key, hence — unless the key is
+// cut by the LDS capacity — their workgroup. The stage is only a FILTER: the sort/unique pipeline that follows is
+// exact on any multiset, so duplicates that survive a cut cost time, never correctness, and the survivors' order
+// (atomics) does not reach the output. set(survivors) == set(canonical k-mers of the selected windows) is the only
+// contract (tests: goldens with the stage forced on).
+#pragma once
+#include "smx_device.hpp"
+
+namespace smx {
+
+constexpr unsigned SKM_M = 12;                        // minimizer length
+constexpr uint32_t SKM_NKEY = 1u << (2 * SKM_M);      // 4^12 minimizer keys
+constexpr int SKM_TP = BLK * 8;                       // window positions per tile, 8 consecutive per thread
+constexpr int SKM_WMAX = 128 - SKM_M + 1;             // windows per super-k-mer <= K - m + 1
+constexpr uint32_t SKM_SCAP = 512;                    // most slots staged per dedupe chunk (two per thread in the prefix scan)
+constexpr uint32_t SKM_KEYS_PER_ITEM = 256;
+
+struct SkmArgs {
+    const uint64_t *seq;
+    uint64_t nwords;  // words of seq that may be read
+    const uint64_t *mask;
+    uint64_t g0, G;   // windows starting outside [g0, G) are not part of this run
+    unsigned K, w;    // w = K - m + 1
+    unsigned long long *cnt;             // [NKEY] super-k-mers per key (phase 0)
+    unsigned long long *cursor;          // [NKEY] next free slot of every key, starts at its offset (phase 1)
+    uint64_t *slots;
+};
+
+// canonical m-mer -> key. The mixer is a bijection of the 22-bit space, so equal keys mean equal minimizers and the
+// key order is a pseudo-random order of the m-mers (low-complexity ones are not favoured).
+__device__ __forceinline__ uint32_t skm_key(uint32_t v) {
+    const uint32_t M = SKM_NKEY - 1;
+    uint32_t r = (uint32_t)(rev2_64((uint64_t)v) >> (64 - 2 * SKM_M)) ^ M;
+    uint32_t c = v < r ? v : r;
+    c = (c * 0x2C9277B5u) & M;
+    c ^= c >> 12;
+    c = (c * 0x1B873593u) & M;
+    c ^= c >> 14;
+    return c;
+}
+
+template <int PHASE, int NW>
+__global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
+    constexpr int SW = 2 * NW;
+    constexpr int NSW = (SKM_TP + 2 * SKM_WMAX + 64) / 32 + 2 * 4 + 4;  // staged stream words
+    constexpr int NKQ = SKM_TP + 2 * SKM_WMAX + 16;
+    __shared__ uint64_t sw[NSW];
+    __shared__ uint32_t keys[NKQ];
+    __shared__ uint64_t fw[(SKM_TP + SKM_WMAX + 64) / 64 + 3];  // break flags, bit i <-> window position p0 + i
+    __shared__ uint64_t mw[(SKM_TP + SKM_WMAX + 64) / 64 + 3];  // window-valid bits, bit i <-> position 64*mq0 + i
+    uint8_t *fb = (uint8_t *)fw;
+    const unsigned w = a.w, K = a.K;
+    const uint64_t ntiles = (a.G - a.g0 + SKM_TP - 1) / SKM_TP;
+    const int64_t nbases = (int64_t)(a.nwords * 32);
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p0 = (int64_t)(a.g0 + tile * SKM_TP);
+        const int64_t o = p0 - 1;  // origin of the local indices: qi = q - o, pi = p - o
+        const int64_t wq0 = o < 0 ? 0 : (o >> 5);
+        for (int i = threadIdx.x; i < NSW; i += BLK) sw[i] = ((uint64_t)(wq0 + i) < a.nwords) ? a.seq[wq0 + i] : 0ull;
+        const int64_t mq0 = o < 0 ? 0 : (o >> 6);
+        const int64_t mwords = (int64_t)((a.G + 63) >> 6);
+        for (int i = threadIdx.x; i < (int)(sizeof(fw) / 8); i += BLK) {
+            fw[i] = ~0ull;
+            // valid = mask bit, restricted to [g0, G) (g0 is a multiple of 64; G is cut inside its word)
+            uint64_t v = (mq0 + i < mwords) ? a.mask[mq0 + i] : 0ull;
+            const int64_t first = (mq0 + i) << 6;
+            if (first < (int64_t)a.g0) v = 0;
+            if (first + 64 > (int64_t)a.G) v = first >= (int64_t)a.G ? 0ull : (v & ((1ull << (a.G - first)) - 1));
+            mw[i] = v;
+        }
+        __syncthreads();
+        const int nq = SKM_TP + 2 * (int)w + 8;
+        for (int qi = threadIdx.x; qi < nq; qi += BLK) {
+            const int64_t q = o + qi;
+            uint32_t key = 0xFFFFFFFFu;
+            if (q >= 0 && q + (int64_t)SKM_M <= nbases) {
+                const int wi = (int)((q >> 5) - wq0);
+                const unsigned sh = (unsigned)(q & 31) << 1;
+                uint64_t v = sw[wi] >> sh;
+                if (sh > 64 - 2 * SKM_M) v |= sw[wi + 1] << (64 - sh);
+                key = skm_key((uint32_t)v & (SKM_NKEY - 1));
+            }
+            keys[qi] = key;
+        }
+        __syncthreads();
+        // minimizer position of the windows pi = b8 .. b8+8 (pi = b8 is the predecessor of the 8 owned windows)
+        uint32_t mp[8];  // minimizer positions (qi) of the 8 owned windows of the tile proper
+        uint32_t vbits = 0, bbits = 0;
+        for (int b8 = threadIdx.x * 8; b8 < SKM_TP + (int)w; b8 += BLK * 8) {
+            uint32_t ck = 0xFFFFFFFFu, cp = 0;
+            bool chave = false;
+            for (int qi = b8 + 8; qi <= b8 + (int)w - 1; ++qi) {
+                uint32_t k = keys[qi];
+                if (!chave || k < ck) {
+                    ck = k;
+                    cp = (uint32_t)qi;
+                    chave = true;
+                }
+            }
+            uint32_t lk[8], rk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                lk[j] = keys[b8 + j];
+                rk[j] = keys[b8 + (int)w + j];
+            }
+            // suffix minima of the left part (leftmost wins ties), then extend to the right
+            uint32_t sk[9], sp[9];
+            sk[8] = 0;
+            sp[8] = 0xFFFFFFFFu;  // "none"
+#pragma unroll
+            for (int j = 7; j >= 0; --j) {
+                if (sp[j + 1] == 0xFFFFFFFFu || lk[j] <= sk[j + 1]) {
+                    sk[j] = lk[j];
+                    sp[j] = (uint32_t)(b8 + j);
+                } else {
+                    sk[j] = sk[j + 1];
+                    sp[j] = sp[j + 1];
+                }
+            }
+            uint32_t m9[9];
+            uint32_t pk = 0, pp = 0xFFFFFFFFu;  // prefix minimum of the right part
+#pragma unroll
+            for (int j = 0; j <= 8; ++j) {
+                uint32_t bk = sk[j], bp = sp[j];
+                if (chave && (bp == 0xFFFFFFFFu || ck < bk)) {
+                    bk = ck;
+                    bp = cp;
+                }
+                if (pp != 0xFFFFFFFFu && (bp == 0xFFFFFFFFu || pk < bk)) {
+                    bk = pk;
+                    bp = pp;
+                }
+                m9[j] = bp;
+                if (j < 8) {
+                    if (pp == 0xFFFFFFFFu || rk[j] < pk) {
+                        pk = rk[j];
+                        pp = (uint32_t)(b8 + (int)w + j);
+                    }
+                }
+            }
+            // validity of the 9 windows and break flags of the 8 owned ones
+            uint32_t vb = 0;
+#pragma unroll
+            for (int j = 0; j <= 8; ++j) {
+                const int64_t p = o + b8 + j;
+                bool ok = p >= 0 && ((mw[(p >> 6) - mq0] >> (p & 63)) & 1);
+                vb |= (ok ? 1u : 0u) << j;
+            }
+            uint32_t brk = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bool b = !((vb >> (j + 1)) & 1) || !((vb >> j) & 1) || m9[j + 1] != m9[j];
+                brk |= (b ? 1u : 0u) << j;
+            }
+            fb[b8 >> 3] = (uint8_t)brk;
+            if (b8 < SKM_TP) {  // the owned windows of the tile proper (first trip of the loop)
+                vbits = vb >> 1;
+                bbits = brk;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mp[j] = m9[j + 1];
+            }
+        }
+        __syncthreads();
+        // one super-k-mer per owned start
+        uint32_t starts = vbits & bbits & 0xFFu;
+        const int base = threadIdx.x * 8;
+        while (starts) {
+            const int j = __ffs(starts) - 1;
+            starts &= starts - 1;
+            const int pr = base + j;  // window position relative to p0
+            // windows until the next break (a break within w positions is guaranteed: the minimizer leaves the window)
+            int nb1 = pr + 1;
+            uint32_t c = 0;
+            {
+                int wi = nb1 >> 6, bit = nb1 & 63;
+                uint64_t x = fw[wi] >> bit;
+                int acc = 0;
+                if (x == 0) {
+                    acc = 64 - bit;
+                    x = fw[wi + 1];
+                    if (x == 0) {
+                        acc += 64;
+                        x = fw[wi + 2];
+                    }
+                }
+                c = (uint32_t)(acc + (x ? __ffsll((unsigned long long)x) - 1 : 64)) + 1;
+            }
+            if (c > w) c = w;
+            uint32_t mpj = 0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t == j) mpj = mp[t];
+            const uint32_t key = keys[mpj];
+            if constexpr (PHASE == 0) {
+                atomicAdd(&a.cnt[key], 1ull);
+            } else {
+                uint64_t *dst = a.slots + atomicAdd(&a.cursor[key], 1ull) * SW;
+                const int64_t p = p0 + pr;
+                const int wi = (int)((p >> 5) - wq0);
+                const unsigned sh = (unsigned)(p & 31) << 1;
+                const unsigned nbits = 2 * (c + K - 1);
+#pragma unroll
+                for (int i = 0; i < SW; ++i) {
+                    uint64_t v = sw[wi + i] >> sh;
+                    if (sh) v |= sw[wi + i + 1] << (64 - sh);
+                    if (nbits <= 64u * i) v = 0;
+                    else if (nbits < 64u * (i + 1)) v &= (1ull << (nbits - 64u * i)) - 1;
+                    if (i == SW - 1) v |= (uint64_t)c << 56;
+                    dst[i] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// k-mer number j of a staged slot
+template <int NW>
+__device__ __forceinline__ Rec<NW> skm_extract(const uint64_t *s, unsigned j, unsigned K) {
+    Rec<NW> x;
+    const unsigned wi = j >> 5, sh = (j & 31) << 1;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        uint64_t v = s[wi + i] >> sh;
+        if (sh) v |= s[wi + i + 1] << (64 - sh);
+        x.w[i] = v;
+    }
+    const unsigned tail = (K & 31) << 1;
+    if (tail) x.w[NW - 1] &= (1ull << tail) - 1;
+    return x;
+}
+
+// One workgroup per item of SKM_KEYS_PER_ITEM consecutive minimizer keys; the item's slots are consumed in chunks of
+// whole keys holding <= cap instances (a key larger than that is cut). Per chunk: stage the slots in LDS, expand the
+// instance list (slot, offset), insert every instance into an exact hash set whose entries are 16-bit fingerprint |
+// 16-bit (slot, offset) reference (the k-mers themselves stay in the staged slots), append the winners to HBM.
+// LDS (dynamic): sl[scap*SW] u64 | tab[T] u32 | cpre[514] u32 | imap[cap] u16 | wl[cap] u16 | cl[512] u8
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__ slots, const unsigned long long *__restrict__ slot_off,
+                                                    unsigned K, uint32_t nitems, uint32_t cap, uint32_t T, uint32_t scap, void *out_,
+                                                    unsigned long long *out_count, unsigned long long *prof) {
+    constexpr int SW = 2 * NW;
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    uint64_t *sl = lds64;
+    uint32_t *tab = (uint32_t *)(sl + (size_t)scap * SW);
+    uint32_t *cpre = tab + T;
+    uint16_t *imap = (uint16_t *)(cpre + 514);
+    uint16_t *wl = imap + cap;
+    uint8_t *cl = (uint8_t *)(wl + cap);
+    __shared__ unsigned long long koff[SKM_KEYS_PER_ITEM + 1];
+    __shared__ uint32_t scr[BLK / 64 + 2];
+    __shared__ uint32_t s_take, s_ninst, s_wcount;
+    __shared__ unsigned long long s_gbase;
+    Rec<NW> *out = (Rec<NW> *)out_;
+    const unsigned lane = threadIdx.x & 63;
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;  // SMX_DEBUG: 100 MHz ticks per phase seen by thread 0
+#define SKM_T(i)                                 \
+    if (prof && threadIdx.x == 0) {              \
+        unsigned long long t1 = wall_clock64();  \
+        pt[i] += t1 - t0;                        \
+        t0 = t1;                                 \
+    }
+    if (prof && threadIdx.x == 0) t0 = wall_clock64();
+    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t <= SKM_KEYS_PER_ITEM; t += BLK) koff[t] = slot_off[(uint64_t)item * SKM_KEYS_PER_ITEM + t];
+        __syncthreads();
+        uint64_t s_cur = koff[0];
+        const uint64_t s_end = koff[SKM_KEYS_PER_ITEM];
+        while (s_cur < s_end) {
+            const uint32_t nst = (uint32_t)((s_end - s_cur < scap) ? s_end - s_cur : scap);
+            for (uint32_t i = threadIdx.x; i < nst * SW; i += BLK) {
+                uint64_t v = slots[s_cur * SW + i];
+                if (i % SW == SW - 1) {
+                    cl[i / SW] = (uint8_t)(v >> 56);
+                    v &= ~(0xFFull << 56);
+                }
+                sl[i] = v;
+            }
+            for (uint32_t i = threadIdx.x; i < T; i += BLK) tab[i] = 0xFFFFFFFFu;
+            if (threadIdx.x == 0) s_wcount = 0;
+            __syncthreads();
+            SKM_T(0)
+            {  // exclusive prefix of the window counts, two consecutive slots per thread
+                const uint32_t i0 = 2 * threadIdx.x, i1 = i0 + 1;
+                const uint32_t c0 = i0 < nst ? cl[i0] : 0, c1 = i1 < nst ? cl[i1] : 0;
+                uint32_t tot;
+                uint32_t ex = block_excl_scan<uint32_t>(c0 + c1, scr, &tot);
+                cpre[i0] = ex;
+                cpre[i1] = ex + c0;
+                if (threadIdx.x == BLK - 1) cpre[2 * BLK] = tot;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t lo = 1, hi = nst;  // largest n in [1, nst] with cpre[n] <= cap (cpre[1] <= w <= cap)
+                while (lo < hi) {
+                    uint32_t mid = (lo + hi + 1) >> 1;
+                    if (cpre[mid] <= cap) lo = mid; else hi = mid - 1;
+                }
+                uint32_t take = lo;
+                if (s_cur + take < s_end) {  // cut at the last key boundary inside the chunk, if there is one
+                    const unsigned long long x = s_cur + take;
+                    uint32_t a = 0, b = SKM_KEYS_PER_ITEM;
+                    while (a < b) {
+                        uint32_t mid = (a + b + 1) >> 1;
+                        if (koff[mid] <= x) a = mid; else b = mid - 1;
+                    }
+                    if (koff[a] > s_cur) take = (uint32_t)(koff[a] - s_cur);
+                }
+                s_take = take;
+                s_ninst = cpre[take];
+            }
+            __syncthreads();
+            const uint32_t ntake = s_take, ninst = s_ninst;
+            for (uint32_t s = threadIdx.x; s < ntake; s += BLK) {
+                const uint32_t base = cpre[s], c = cl[s];
+                for (uint32_t j = 0; j < c; ++j) imap[base + j] = (uint16_t)((s << 7) | j);
+            }
+            __syncthreads();
+            SKM_T(1)
+            for (uint32_t i0 = 0; i0 < ninst; i0 += BLK) {
+                const uint32_t i = i0 + threadIdx.x;
+                bool won = false;
+                uint32_t code = 0;
+                if (i < ninst) {
+                    code = imap[i];
+                    const Rec<NW> x = skm_extract<NW>(sl + (size_t)(code >> 7) * SW, code & 127u, K);
+                    const Rec<NW> y = rec_rc<NW>(x, K);
+                    const bool fwd = rc_ge<NW>(y, x);
+                    Rec<NW> cx;
+#pragma unroll
+                    for (int t = 0; t < NW; ++t) cx.w[t] = fwd ? x.w[t] : y.w[t];
+                    const uint32_t hh = rec_hash32<NW>(cx);
+                    uint32_t h = hh & (T - 1);
+                    const uint32_t fp = hh >> 16;
+                    const uint32_t entry = (fp << 16) | code;
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&tab[h], 0xFFFFFFFFu, entry);
+                        if (old == 0xFFFFFFFFu) {
+                            won = true;
+                            break;
+                        }
+                        if ((old >> 16) == fp) {
+                            const Rec<NW> xo = skm_extract<NW>(sl + (size_t)((old & 0xFFFFu) >> 7) * SW, old & 127u, K);
+                            if (rec_eq<NW>(xo, x) || rec_eq<NW>(xo, y)) break;  // same canonical k-mer already present
+                        }
+                        h = (h + 1) & (T - 1);
+                    }
+                }
+                const unsigned long long m = __ballot(won);
+                if (m) {
+                    const int leader = __ffsll((unsigned long long)m) - 1;
+                    uint32_t base = 0;
+                    if ((int)lane == leader) base = atomicAdd(&s_wcount, (uint32_t)__popcll(m));
+                    base = __shfl(base, leader, 64);
+                    if (won) wl[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)code;
+                }
+            }
+            __syncthreads();
+            SKM_T(2)
+            const uint32_t wcount = s_wcount;
+            if (threadIdx.x == 0) s_gbase = wcount ? atomicAdd(out_count, (unsigned long long)wcount) : 0ull;
+            __syncthreads();
+            {
+                Rec<NW> *dst = out + s_gbase;
+                for (uint32_t i = threadIdx.x; i < wcount; i += BLK) {
+                    const uint32_t code = wl[i];
+                    const Rec<NW> x = skm_extract<NW>(sl + (size_t)(code >> 7) * SW, code & 127u, K);
+                    const Rec<NW> y = rec_rc<NW>(x, K);
+                    const bool fwd = rc_ge<NW>(y, x);
+                    Rec<NW> cx;
+#pragma unroll
+                    for (int t = 0; t < NW; ++t) cx.w[t] = fwd ? x.w[t] : y.w[t];
+                    dst[i] = cx;
+                }
+            }
+            s_cur += ntake;
+            __syncthreads();
+            SKM_T(3)
+            if (prof && threadIdx.x == 0) {
+                pt[4] += 1;
+                pt[5] += ntake;
+            }
+        }
+    }
+    if (prof && threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], pt[i]);
+#undef SKM_T
+}
+
+}  // namespace smx

@@ -1,0 +1,72 @@
+"""GPU parity with the super-k-mer pre-deduplication stage forced on (it switches itself on only for >= 2^20 windows,
+so the small goldens would otherwise never see it): same bytes as the reference on every case with K >= 21."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_manifest, read_lines
+from test_count_gpu import _count, _synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = [c for c in load_manifest()["cases"] if c["kind"] == "count" and c["K"] >= 21]
+ON = {"prededupe": 1}
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['reads'][6:-4]}-{c['mode']}{c['K']}-b{c['num_buckets']}")
+def test_golden_counts_with_prededupe(case):
+    rec, sizes = _count(read_lines(case["reads"]), case["K"], case["mode"], case["num_buckets"], ON)
+    assert list(map(int, sizes)) == case["bucket_sizes"]
+    assert hashlib.md5(rec.tobytes()).hexdigest() == case["md5"]
+
+
+@pytest.mark.parametrize("K,mode,nb", [(21, "A", 16), (55, "A", 16), (22, "B", 10), (56, "B", 80), (77, "A", 16), (78, "B", 30),
+                                       (127, "A", 16), (128, "B", 20), (31, "A", 16), (32, "B", 16), (33, "A", 3), (64, "A", 1),
+                                       (65, "B", 7), (96, "A", 16), (97, "B", 5)])
+@pytest.mark.parametrize("cap", [0, 512])
+def test_seeded_vs_oracle_with_prededupe(K, mode, nb, cap):
+    """3000 reads with N runs and both strands; cap 512 cuts minimizer keys across LDS chunks (duplicates survive the
+    filter and must be removed by the pipeline behind it)."""
+    from oracle import oracle
+    reads = _synth(100 + K, 20000, 3000, 150) + ["A" * 150] * 50 + ["ACGT" * 40] * 20 + ["AC" * 75] * 20
+    ref, rs = oracle.count(reads, K, mode, nb)
+    rec, sizes = _count(reads, K, mode, nb, dict(ON, skm_cap=cap) if cap else ON)
+    assert (sizes == rs).all()
+    assert rec.shape == ref.shape and (rec == ref).all()
+
+
+@pytest.mark.parametrize("K,mode,nb,batch", [(21, "A", 16, 100_000), (55, "A", 16, 40_000), (56, "B", 80, 30_000), (77, "B", 30, 200_000)])
+def test_multi_batch_with_prededupe(K, mode, nb, batch):
+    """position-range batches: super-k-mers are cut at the range borders"""
+    from oracle import oracle
+    reads = _synth(21, 6000, 1200, 150) + ["A" * 150] * 30
+    ref, rs = oracle.count(reads, K, mode, nb)
+    rec, sizes = _count(reads, K, mode, nb, dict(ON, batch_records=batch))
+    assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
+
+
+def test_edge_inputs_with_prededupe():
+    from oracle import oracle
+    for reads in (["ACGT"], ["A" * 21], ["A" * 20 + "N" + "C" * 30], ["ACGTTGCATGCATGCAAGTCAGTCAGTTTGACN" * 3, "", "NNNN"]):
+        ref, rs = oracle.count(reads, 21, "A", 16)
+        rec, sizes = _count(reads, 21, "A", 16, ON)
+        assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
+
+
+GCASES = [c for c in load_manifest()["cases"] if c["kind"] == "graph_cov" and c["K"] >= 21]
+
+
+@pytest.mark.parametrize("case", GCASES, ids=lambda c: f"{c['reads'][6:-4]}-k{c['K']}-t{c['threads']}")
+def test_gfa_with_prededupe(case, tmp_path):
+    from spades_amd.gbuilder import GraphBuilder
+    gb = GraphBuilder(case["K"], case["threads"])
+    gb.ctx.set_option("prededupe", 1)
+    gb.push_back_reads([r for r in read_lines(case["reads"]) if r])
+    gb.build()
+    gb.fill_coverage()
+    out = os.path.join(str(tmp_path), "g.gfa")
+    gb.write_gfa(out)
+    assert open(out).read() == open(os.path.join(GOLDEN, case["file"])).read()
+    gb.ctx.close()
