@@ -679,8 +679,13 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     HIPCHK(hipMemsetAsync(ocount, 0, 8, ctx->stream));
     SkmArgs a{};
     a.K = K;
-    a.w = K - SKM_M + 1;
+    a.m = skm_m(K);
+    a.w = K - a.m + 1;
     a.cnt = cnt;
+    if (getenv("SMX_DEBUG")) {
+        if (int rc = dalloc(ctx, &a.prof, 16)) return rc;
+        HIPCHK(hipMemsetAsync(a.prof, 0, 128, ctx->stream));
+    }
     auto pass = [&](int phase) -> int {
         for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
             const ReadChunk &ch = ctx->chunks[ci];
@@ -716,6 +721,14 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     tbegin(ctx, "skm_scatter");
     if (int rc = pass(1)) return rc;
     tend(ctx);
+    if (a.prof) {
+        unsigned long long hp[16];
+        HIPCHK(hipMemcpy(hp, a.prof, 128, hipMemcpyDeviceToHost));
+        for (int ph = 0; ph < 2; ++ph)
+            fprintf(stderr, "[smx] skm_scan phase %d: tiles=%llu; ticks per tile: stage+keys %.1f, minpos+flags %.1f, emit %.1f\n", ph, hp[8 * ph + 3],
+                    hp[8 * ph + 3] ? (double)hp[8 * ph] / hp[8 * ph + 3] : 0.0, hp[8 * ph + 3] ? (double)hp[8 * ph + 1] / hp[8 * ph + 3] : 0.0,
+                    hp[8 * ph + 3] ? (double)hp[8 * ph + 2] / hp[8 * ph + 3] : 0.0);
+    }
     if (int rc = dalloc(ctx, out, nwin + 1)) return rc;
     uint32_t cap = 2048;
     if (ctx->opt_skm_cap > 0) {
@@ -758,7 +771,7 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
 template <int NW>
 int count_selection(smx_ctx *ctx, unsigned K, int mode, unsigned B, const ReadSel &sel) {
     const uint64_t nwin = mode == SMX_MODE_ALL ? sel.nrec / 2 : sel.nrec;
-    const bool possible = K >= 21 && K - SKM_M + 1 <= (unsigned)SKM_WMAX && nwin > 0;
+    const bool possible = K >= 21 && nwin > 0;
     const bool use = possible && (ctx->opt_prededupe > 0 || (ctx->opt_prededupe < 0 && nwin >= (1u << 20)));
     if (!use) return run_count<NW>(ctx, K, mode, B, nullptr, 0, &sel);
     Rec<NW> *recs = nullptr;

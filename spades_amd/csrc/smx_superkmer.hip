@@ -19,10 +19,14 @@
 
 namespace smx {
 
-constexpr unsigned SKM_M = 12;                        // minimizer length
-constexpr uint32_t SKM_NKEY = 1u << (2 * SKM_M);      // 4^12 minimizer keys
-constexpr int SKM_TP = BLK * 8;                       // window positions per tile, 8 consecutive per thread
-constexpr int SKM_WMAX = 128 - SKM_M + 1;             // windows per super-k-mer <= K - m + 1
+constexpr uint32_t SKM_NKEY = 1u << 24;               // partitions ("keys") the minimizers are hashed into
+constexpr int SKM_WMAX = 128 - 16 + 1;                // windows per super-k-mer <= K - m + 1
+// Minimizer length: long enough that an m-mer is (nearly) unique in a genome — with m = 12 every 12-mer recurs ~6 times
+// per strand of a 50 Mbp genome, the few 12-mers that win the minimizer order collect thousands of instances each and
+// most keys had to be cut (measured: +21 % surviving duplicates) — but short enough to leave >= 9 windows per super-k-mer.
+__host__ __device__ inline unsigned skm_m(unsigned K) { return K >= 25 ? 16u : K - 8u; }
+constexpr int SKM_TC = BLK * 8;                       // windows examined per tile, 8 consecutive per thread
+constexpr int SKM_TP = SKM_TC - 128;                  // windows a tile emits starts for; the rest is look-ahead (>= WMAX)
 constexpr uint32_t SKM_SCAP = 512;                    // most slots staged per dedupe chunk (two per thread in the prefix scan)
 constexpr uint32_t SKM_KEYS_PER_ITEM = 256;
 
@@ -31,38 +35,57 @@ struct SkmArgs {
     uint64_t nwords;  // words of seq that may be read
     const uint64_t *mask;
     uint64_t g0, G;   // windows starting outside [g0, G) are not part of this run
-    unsigned K, w;    // w = K - m + 1
+    unsigned K, m, w;  // w = K - m + 1
     unsigned long long *cnt;             // [NKEY] super-k-mers per key (phase 0)
     unsigned long long *cursor;          // [NKEY] next free slot of every key, starts at its offset (phase 1)
     uint64_t *slots;
+    unsigned long long *prof;            // SMX_DEBUG: ticks per phase
 };
 
-// canonical m-mer -> key. The mixer is a bijection of the 22-bit space, so equal keys mean equal minimizers and the
-// key order is a pseudo-random order of the m-mers (low-complexity ones are not favoured).
-__device__ __forceinline__ uint32_t skm_key(uint32_t v) {
-    const uint32_t M = SKM_NKEY - 1;
-    uint32_t r = (uint32_t)(rev2_64((uint64_t)v) >> (64 - 2 * SKM_M)) ^ M;
+// canonical m-mer -> order key: a bijection of 32 bits, so equal keys mean equal minimizers and the order is a
+// pseudo-random order of the m-mers (low-complexity ones are not favoured).
+__device__ __forceinline__ uint32_t skm_key(uint32_t v, unsigned m) {
+    const uint32_t M = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1);
+    uint32_t r = (uint32_t)(rev2_64((uint64_t)v) >> (64 - 2 * m)) ^ M;
     uint32_t c = v < r ? v : r;
-    c = (c * 0x2C9277B5u) & M;
-    c ^= c >> 12;
-    c = (c * 0x1B873593u) & M;
-    c ^= c >> 14;
+    c *= 0x2C9277B5u;
+    c ^= c >> 15;
+    c *= 0x1B873593u;
+    c ^= c >> 13;
     return c;
+}
+// order key -> partition: the order keys of the chosen minimizers crowd the low end of the key space by construction
+// (a minimizer IS the smallest key of its window), so the partition id is an independent mix of the same value.
+__device__ __forceinline__ uint32_t skm_part(uint32_t key) {
+    key *= 0x9E3779B1u;
+    key ^= key >> 16;
+    key *= 0x85EBCA6Bu;
+    return key >> 8;
 }
 
 template <int PHASE, int NW>
 __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
     constexpr int SW = 2 * NW;
-    constexpr int NSW = (SKM_TP + 2 * SKM_WMAX + 64) / 32 + 2 * 4 + 4;  // staged stream words
-    constexpr int NKQ = SKM_TP + 2 * SKM_WMAX + 16;
+    constexpr int NSW = (SKM_TC + SKM_WMAX + 64) / 32 + 2 * 4 + 4;  // staged stream words
+    constexpr int NKQ = SKM_TC + SKM_WMAX + 16;
+    constexpr int NFW = SKM_TC / 64 + 3;
     __shared__ uint64_t sw[NSW];
-    __shared__ uint32_t keys[NKQ];
-    __shared__ uint64_t fw[(SKM_TP + SKM_WMAX + 64) / 64 + 3];  // break flags, bit i <-> window position p0 + i
-    __shared__ uint64_t mw[(SKM_TP + SKM_WMAX + 64) / 64 + 3];  // window-valid bits, bit i <-> position 64*mq0 + i
+    __shared__ __attribute__((aligned(16))) uint32_t keys[NKQ];
+    __shared__ uint64_t fw[NFW];  // break flags, bit i <-> window position p0 + i
+    __shared__ uint64_t mw[NFW];  // window-valid bits, bit i <-> position 64*mq0 + i
     uint8_t *fb = (uint8_t *)fw;
-    const unsigned w = a.w, K = a.K;
+    const unsigned w = a.w, K = a.K, m = a.m;
+    const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1);
     const uint64_t ntiles = (a.G - a.g0 + SKM_TP - 1) / SKM_TP;
     const int64_t nbases = (int64_t)(a.nwords * 32);
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, t0 = 0;
+#define SKM_T(i)                                 \
+    if (a.prof && threadIdx.x == 0) {            \
+        unsigned long long t1 = wall_clock64();  \
+        pt[i] += t1 - t0;                        \
+        t0 = t1;                                 \
+    }
+    if (a.prof && threadIdx.x == 0) t0 = wall_clock64();
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t p0 = (int64_t)(a.g0 + tile * SKM_TP);
         const int64_t o = p0 - 1;  // origin of the local indices: qi = q - o, pi = p - o
@@ -70,7 +93,7 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
         for (int i = threadIdx.x; i < NSW; i += BLK) sw[i] = ((uint64_t)(wq0 + i) < a.nwords) ? a.seq[wq0 + i] : 0ull;
         const int64_t mq0 = o < 0 ? 0 : (o >> 6);
         const int64_t mwords = (int64_t)((a.G + 63) >> 6);
-        for (int i = threadIdx.x; i < (int)(sizeof(fw) / 8); i += BLK) {
+        for (int i = threadIdx.x; i < NFW; i += BLK) {
             fw[i] = ~0ull;
             // valid = mask bit, restricted to [g0, G) (g0 is a multiple of 64; G is cut inside its word)
             uint64_t v = (mq0 + i < mwords) ? a.mask[mq0 + i] : 0ull;
@@ -80,110 +103,104 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
             mw[i] = v;
         }
         __syncthreads();
-        const int nq = SKM_TP + 2 * (int)w + 8;
+        const int nq = SKM_TC + (int)w + 8;
         for (int qi = threadIdx.x; qi < nq; qi += BLK) {
             const int64_t q = o + qi;
             uint32_t key = 0xFFFFFFFFu;
-            if (q >= 0 && q + (int64_t)SKM_M <= nbases) {
+            if (q >= 0 && q + (int64_t)m <= nbases) {
                 const int wi = (int)((q >> 5) - wq0);
                 const unsigned sh = (unsigned)(q & 31) << 1;
-                uint64_t v = sw[wi] >> sh;
-                if (sh > 64 - 2 * SKM_M) v |= sw[wi + 1] << (64 - sh);
-                key = skm_key((uint32_t)v & (SKM_NKEY - 1));
+                const uint64_t v = (sw[wi] >> sh) | ((sw[wi + 1] << (63 - sh)) << 1);
+                key = skm_key((uint32_t)v & mmask, m);
             }
             keys[qi] = key;
         }
         __syncthreads();
-        // minimizer position of the windows pi = b8 .. b8+8 (pi = b8 is the predecessor of the 8 owned windows)
-        uint32_t mp[8];  // minimizer positions (qi) of the 8 owned windows of the tile proper
-        uint32_t vbits = 0, bbits = 0;
-        for (int b8 = threadIdx.x * 8; b8 < SKM_TP + (int)w; b8 += BLK * 8) {
-            uint32_t ck = 0xFFFFFFFFu, cp = 0;
-            bool chave = false;
-            for (int qi = b8 + 8; qi <= b8 + (int)w - 1; ++qi) {
-                uint32_t k = keys[qi];
-                if (!chave || k < ck) {
-                    ck = k;
-                    cp = (uint32_t)qi;
-                    chave = true;
-                }
+        SKM_T(0)
+        // Minimizer position (qi) of the windows pi = b8 .. b8+8: pi = b8 is the predecessor of the thread's 8 windows
+        // p0 + b8 .. p0 + b8 + 7. Window pi spans qi in [pi, pi+w-1] = L (b8+j..b8+7) + C (b8+8..b8+w-1, shared by all nine)
+        // + R (b8+w..b8+w+j-1); leftmost position wins ties.
+        const int b8 = threadIdx.x * 8;
+        uint32_t m9[9];
+        {
+            const int cend = b8 + (int)w - 1;
+            uint32_t ck = keys[b8 + 8], cp = (uint32_t)(b8 + 8);
+            for (int q4 = b8 + 8; q4 <= cend; q4 += 4) {
+                const uint4 k4 = *(const uint4 *)&keys[q4];
+                const uint32_t e0 = k4.x, e1 = q4 + 1 <= cend ? k4.y : 0xFFFFFFFFu, e2 = q4 + 2 <= cend ? k4.z : 0xFFFFFFFFu,
+                               e3 = q4 + 3 <= cend ? k4.w : 0xFFFFFFFFu;
+                if (e0 < ck) { ck = e0; cp = (uint32_t)q4; }
+                if (e1 < ck) { ck = e1; cp = (uint32_t)q4 + 1; }
+                if (e2 < ck) { ck = e2; cp = (uint32_t)q4 + 2; }
+                if (e3 < ck) { ck = e3; cp = (uint32_t)q4 + 3; }
             }
             uint32_t lk[8], rk[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                lk[j] = keys[b8 + j];
-                rk[j] = keys[b8 + (int)w + j];
+            {
+                const uint4 l0 = *(const uint4 *)&keys[b8], l1 = *(const uint4 *)&keys[b8 + 4];
+                lk[0] = l0.x; lk[1] = l0.y; lk[2] = l0.z; lk[3] = l0.w;
+                lk[4] = l1.x; lk[5] = l1.y; lk[6] = l1.z; lk[7] = l1.w;
             }
-            // suffix minima of the left part (leftmost wins ties), then extend to the right
-            uint32_t sk[9], sp[9];
-            sk[8] = 0;
-            sp[8] = 0xFFFFFFFFu;  // "none"
 #pragma unroll
-            for (int j = 7; j >= 0; --j) {
-                if (sp[j + 1] == 0xFFFFFFFFu || lk[j] <= sk[j + 1]) {
-                    sk[j] = lk[j];
-                    sp[j] = (uint32_t)(b8 + j);
-                } else {
-                    sk[j] = sk[j + 1];
-                    sp[j] = sp[j + 1];
-                }
+            for (int j = 0; j < 8; ++j) rk[j] = keys[b8 + (int)w + j];
+            uint32_t sk[8], sp[8];  // suffix minima of L
+            sk[7] = lk[7];
+            sp[7] = (uint32_t)(b8 + 7);
+#pragma unroll
+            for (int j = 6; j >= 0; --j) {
+                const bool t = lk[j] <= sk[j + 1];
+                sk[j] = t ? lk[j] : sk[j + 1];
+                sp[j] = t ? (uint32_t)(b8 + j) : sp[j + 1];
             }
-            uint32_t m9[9];
-            uint32_t pk = 0, pp = 0xFFFFFFFFu;  // prefix minimum of the right part
+            uint32_t pk = 0xFFFFFFFFu, pp = 0;  // prefix minimum of R (nothing yet: never smaller)
+            bool phave = false;
 #pragma unroll
             for (int j = 0; j <= 8; ++j) {
-                uint32_t bk = sk[j], bp = sp[j];
-                if (chave && (bp == 0xFFFFFFFFu || ck < bk)) {
-                    bk = ck;
-                    bp = cp;
+                uint32_t bk = ck, bp = cp;
+                if (j < 8 && sk[j] <= ck) {
+                    bk = sk[j];
+                    bp = sp[j];
                 }
-                if (pp != 0xFFFFFFFFu && (bp == 0xFFFFFFFFu || pk < bk)) {
+                if (phave && pk < bk) {
                     bk = pk;
                     bp = pp;
                 }
                 m9[j] = bp;
                 if (j < 8) {
-                    if (pp == 0xFFFFFFFFu || rk[j] < pk) {
+                    if (!phave || rk[j] < pk) {
                         pk = rk[j];
                         pp = (uint32_t)(b8 + (int)w + j);
+                        phave = true;
                     }
                 }
             }
-            // validity of the 9 windows and break flags of the 8 owned ones
-            uint32_t vb = 0;
-#pragma unroll
-            for (int j = 0; j <= 8; ++j) {
-                const int64_t p = o + b8 + j;
-                bool ok = p >= 0 && ((mw[(p >> 6) - mq0] >> (p & 63)) & 1);
-                vb |= (ok ? 1u : 0u) << j;
-            }
-            uint32_t brk = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bool b = !((vb >> (j + 1)) & 1) || !((vb >> j) & 1) || m9[j + 1] != m9[j];
-                brk |= (b ? 1u : 0u) << j;
-            }
-            fb[b8 >> 3] = (uint8_t)brk;
-            if (b8 < SKM_TP) {  // the owned windows of the tile proper (first trip of the loop)
-                vbits = vb >> 1;
-                bbits = brk;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) mp[j] = m9[j + 1];
-            }
         }
+        // validity of the 9 windows, break flags of the 8 owned ones
+        uint32_t vb = 0;
+#pragma unroll
+        for (int j = 0; j <= 8; ++j) {
+            const int64_t p = o + b8 + j;
+            bool ok = p >= 0 && ((mw[(p >> 6) - mq0] >> (p & 63)) & 1);
+            vb |= (ok ? 1u : 0u) << j;
+        }
+        uint32_t brk = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bool b = !((vb >> (j + 1)) & 1) || !((vb >> j) & 1) || m9[j + 1] != m9[j];
+            brk |= (b ? 1u : 0u) << j;
+        }
+        fb[b8 >> 3] = (uint8_t)brk;
         __syncthreads();
-        // one super-k-mer per owned start
-        uint32_t starts = vbits & bbits & 0xFFu;
-        const int base = threadIdx.x * 8;
+        SKM_T(1)
+        // one super-k-mer per owned start; the last SKM_TC - SKM_TP windows are only the look-ahead of the run lengths
+        uint32_t starts = b8 < SKM_TP ? ((vb >> 1) & brk & 0xFFu) : 0u;
         while (starts) {
             const int j = __ffs(starts) - 1;
             starts &= starts - 1;
-            const int pr = base + j;  // window position relative to p0
-            // windows until the next break (a break within w positions is guaranteed: the minimizer leaves the window)
-            int nb1 = pr + 1;
-            uint32_t c = 0;
+            const int pr = b8 + j;  // window position relative to p0
+            uint32_t c;             // windows until the next break (within w: the minimizer leaves the window)
             {
-                int wi = nb1 >> 6, bit = nb1 & 63;
+                const int nb1 = pr + 1;
+                const int wi = nb1 >> 6, bit = nb1 & 63;
                 uint64_t x = fw[wi] >> bit;
                 int acc = 0;
                 if (x == 0) {
@@ -200,8 +217,8 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
             uint32_t mpj = 0;
 #pragma unroll
             for (int t = 0; t < 8; ++t)
-                if (t == j) mpj = mp[t];
-            const uint32_t key = keys[mpj];
+                if (t == j) mpj = m9[t + 1];
+            const uint32_t key = skm_part(keys[mpj]);
             if constexpr (PHASE == 0) {
                 atomicAdd(&a.cnt[key], 1ull);
             } else {
@@ -222,7 +239,12 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
             }
         }
         __syncthreads();
+        SKM_T(2)
+        if (a.prof && threadIdx.x == 0) pt[3] += 1;
     }
+    if (a.prof && threadIdx.x == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd(&a.prof[8 * PHASE + i], pt[i]);
+#undef SKM_T
 }
 
 // k-mer number j of a staged slot
