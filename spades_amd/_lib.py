@@ -29,6 +29,13 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). spades_amd has no CPU fallback.")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's). Whichever copy is mapped
+    # first serves both; with the system copy first, torch later reports "No HIP GPUs are available" (measured). The Python host
+    # side shares the process with torch (device memory, streams, torch.distributed), so torch's copy goes first when torch exists.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, u64p, u32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
     sig = {

@@ -639,14 +639,22 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     // ---- compact ----------------------------------------------------------------------------
     tbegin(ctx, "compact");
     if (int rc = scan_u64(ctx, ucount, uoff, nb)) return rc;
-    if (nrec / nb >= 128)
+    unsigned long long n_unique = 0;
+    HIPCHK(hipMemcpyAsync(&n_unique, uoff + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (n_unique == nrec) {
+        // nothing was removed (the usual case behind the pre-dedupe stage): the leaves, sorted in place and contiguous, already
+        // are the bucket-major output
+        std::swap(sortbuf, other);
+    } else if (nrec / nb >= 128) {
         hipLaunchKernelGGL((k_compact<NW>), dim3((unsigned)std::min<uint64_t>(nb, 1u << 20)), dim3(BLK), 0, ctx->stream,
                            (const void *)sortbuf, fine_off, (const unsigned long long *)ucount, (const unsigned long long *)uoff,
                            (uint32_t)nb, (void *)other);
-    else
+    } else {
         hipLaunchKernelGGL((k_compact_wave<NW>), dim3((unsigned)std::min<uint64_t>((nb + 3) / 4, 256 * 32)), dim3(BLK), 0, ctx->stream,
                            (const void *)sortbuf, fine_off, (const unsigned long long *)ucount, (const unsigned long long *)uoff,
                            (uint32_t)nb, (void *)other);
+    }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_bucket_offsets, dim3((B + 1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream,
                        (const unsigned long long *)uoff, B, (uint32_t)(nb / B), bucket_off);
@@ -670,13 +678,13 @@ template <int NW>
 int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, Rec<NW> **out, uint64_t *n_out) {
     constexpr int SW = 2 * NW;
     const std::vector<uint64_t *> &masks = *sel.masks;
-    unsigned long long *cnt, *soff, *ocount, *cursor;
+    unsigned long long *cnt, *soff, *ocount, *cursor;  // ocount[0] clean, ocount[1] dirty survivors
     if (int rc = dalloc(ctx, &cnt, SKM_NKEY)) return rc;
     if (int rc = dalloc(ctx, &soff, SKM_NKEY + 1)) return rc;
     if (int rc = dalloc(ctx, &cursor, SKM_NKEY)) return rc;
-    if (int rc = dalloc(ctx, &ocount, 1)) return rc;
+    if (int rc = dalloc(ctx, &ocount, 2)) return rc;
     HIPCHK(hipMemsetAsync(cnt, 0, (size_t)SKM_NKEY * 8, ctx->stream));
-    HIPCHK(hipMemsetAsync(ocount, 0, 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(ocount, 0, 16, ctx->stream));
     SkmArgs a{};
     a.K = K;
     a.m = skm_m(K);
@@ -747,7 +755,7 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     }
     tbegin(ctx, "skm_dedupe");
     hipLaunchKernelGGL((k_skm_dedupe<NW>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
-                       (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, ocount, prof);
+                       (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)nwin, ocount, ocount + 1, prof);
     HIPCHK(hipGetLastError());
     tend(ctx);
     if (prof) {
@@ -757,13 +765,23 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
                 hp[4], hp[4] ? (double)hp[5] / hp[4] : 0.0, hp[4] ? (double)hp[0] / hp[4] : 0.0, hp[4] ? (double)hp[1] / hp[4] : 0.0,
                 hp[4] ? (double)hp[2] / hp[4] : 0.0, hp[4] ? (double)hp[3] / hp[4] : 0.0);
     }
-    unsigned long long n = 0;
-    HIPCHK(hipMemcpyAsync(&n, ocount, 8, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long nn[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(nn, ocount, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (n > nwin) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication produced %llu records from %llu windows", n, (unsigned long long)nwin);
+    if (nn[0] + nn[1] > nwin) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication produced %llu records from %llu windows", nn[0] + nn[1], (unsigned long long)nwin);
+    unsigned long long n = nn[0];
+    if (nn[1]) {  // survivors of cut keys: sort + unique them on their own, then the whole array is exactly distinct
+        if (int rc = run_count<NW>(ctx, K, SMX_MODE_ALL, 1, *out + (nwin - nn[1]), nn[1])) return rc;
+        HIPCHK(hipMemcpyAsync(*out + nn[0], ctx->d_result_buf, ctx->n_records * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        n += ctx->n_records;
+        ctx->d_result_buf = ctx->d_result = nullptr;  // stays in the temp list
+        ctx->n_records = 0;
+    }
     *n_out = n;
     if (getenv("SMX_DEBUG"))
-        fprintf(stderr, "[smx] prededupe: %llu windows -> %llu super-k-mers -> %llu canonical records\n", (unsigned long long)nwin, nslots, n);
+        fprintf(stderr, "[smx] prededupe: %llu windows -> %llu super-k-mers -> %llu canonical records (%llu from cut keys before their unique pass)\n",
+                (unsigned long long)nwin, nslots, n, nn[1]);
     return 0;
 }
 
@@ -1344,6 +1362,17 @@ int smx_create(smx_ctx **out, int device, size_t hbm_budget_bytes) {
         return SMX_DEVICE_ERROR;
     }
     *out = ctx;
+    if (const char *o = getenv("SMX_OPTS")) {  // experiments: SMX_OPTS="key=value,key=value" applied to every new context
+        std::string str(o);
+        size_t p = 0;
+        while (p < str.size()) {
+            size_t e = str.find(',', p);
+            if (e == std::string::npos) e = str.size();
+            size_t q = str.find('=', p);
+            if (q != std::string::npos && q < e) (void)smx_set_option(ctx, str.substr(p, q - p).c_str(), atoll(str.substr(q + 1, e - q - 1).c_str()));
+            p = e + 1;
+        }
+    }
     return SMX_OK;
 }
 

@@ -157,18 +157,29 @@ __device__ __forceinline__ void fetch_records(const PassArgs &a, uint64_t tile, 
     if constexpr (SRC == SRC_RECS) {
         const Rec<NW> *in = (const Rec<NW> *)a.recs;
         const uint64_t base = tile * (uint64_t)(RPT * BLK);
+        if (a.expand) {
+            // instance pair (2r, 2r+1) = record r and its reverse complement; seg_base and seg_n are even (tiles hold an even
+            // number of instances), so every thread loads RPT/2 records and emits both strands of each
+            const uint64_t rbase = (seg_base + base) >> 1;
+            const uint64_t rn = seg_n > base ? (seg_n - base) >> 1 : 0;  // records left in this tile's part of the segment
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            uint64_t i = base + (uint64_t)j * BLK + threadIdx.x;
-            if (i < seg_n) {
-                const uint64_t gi = seg_base + i;
-                if (a.expand) {
-                    Rec<NW> x = in[gi >> 1];
-                    r[j] = (gi & 1) ? rec_rc<NW>(x, a.K) : x;
-                } else {
-                    r[j] = in[gi];
+            for (int j = 0; j < RPT / 2; ++j) {
+                const uint64_t ri = (uint64_t)j * BLK + threadIdx.x;
+                if (ri < rn) {
+                    const Rec<NW> x = in[rbase + ri];
+                    r[2 * j] = x;
+                    r[2 * j + 1] = rec_rc<NW>(x, a.K);
+                    validmask |= 3u << (2 * j);
                 }
-                validmask |= 1u << j;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                uint64_t i = base + (uint64_t)j * BLK + threadIdx.x;
+                if (i < seg_n) {
+                    r[j] = in[seg_base + i];
+                    validmask |= 1u << j;
+                }
             }
         }
     } else {
@@ -234,16 +245,14 @@ __global__ void __launch_bounds__(BLK) k_hist(PassArgs a) {
         const uint64_t t0 = (uint64_t)tin * a.tile_recs;
         const uint64_t t1 = (sn < t0 + a.tile_recs) ? sn : t0 + a.tile_recs;
         const Rec<NW> *in = (const Rec<NW> *)a.recs;
-        for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK) {
-            const uint64_t gi = sb + i;
-            Rec<NW> x;
-            if (a.expand) {
-                x = in[gi >> 1];
-                if (gi & 1) x = rec_rc<NW>(x, a.K);
-            } else {
-                x = in[gi];
+        if (a.expand) {  // instances (2r, 2r+1) = record r and its reverse complement; sb, t0, t1 are even
+            for (uint64_t ri = ((sb + t0) >> 1) + threadIdx.x; ri < ((sb + t1) >> 1); ri += BLK) {
+                const Rec<NW> x = in[ri];
+                atomicAdd(&lh[bin_of<NW, BINF>(x, a)], 1u);
+                atomicAdd(&lh[bin_of<NW, BINF>(rec_rc<NW>(x, a.K), a)], 1u);
             }
-            atomicAdd(&lh[bin_of<NW, BINF>(x, a)], 1u);
+        } else {
+            for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK) atomicAdd(&lh[bin_of<NW, BINF>(in[sb + i], a)], 1u);
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < a.F; i += BLK)

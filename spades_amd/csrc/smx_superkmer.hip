@@ -271,7 +271,8 @@ __device__ __forceinline__ Rec<NW> skm_extract(const uint64_t *s, unsigned j, un
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__ slots, const unsigned long long *__restrict__ slot_off,
                                                     unsigned K, uint32_t nitems, uint32_t cap, uint32_t T, uint32_t scap, void *out_,
-                                                    unsigned long long *out_count, unsigned long long *prof) {
+                                                    unsigned long long out_cap, unsigned long long *out_count,
+                                                    unsigned long long *dirty_count, unsigned long long *prof) {
     constexpr int SW = 2 * NW;
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     uint64_t *sl = lds64;
@@ -282,7 +283,7 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
     uint8_t *cl = (uint8_t *)(wl + cap);
     __shared__ unsigned long long koff[SKM_KEYS_PER_ITEM + 1];
     __shared__ uint32_t scr[BLK / 64 + 2];
-    __shared__ uint32_t s_take, s_ninst, s_wcount;
+    __shared__ uint32_t s_take, s_nfit, s_ninst, s_wcount, s_endb;
     __shared__ unsigned long long s_gbase;
     Rec<NW> *out = (Rec<NW> *)out_;
     const unsigned lane = threadIdx.x & 63;
@@ -300,6 +301,7 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
         __syncthreads();
         uint64_t s_cur = koff[0];
         const uint64_t s_end = koff[SKM_KEYS_PER_ITEM];
+        bool on_boundary = true;  // the chunk starts with the first slot of a key
         while (s_cur < s_end) {
             const uint32_t nst = (uint32_t)((s_end - s_cur < scap) ? s_end - s_cur : scap);
             for (uint32_t i = threadIdx.x; i < nst * SW; i += BLK) {
@@ -324,24 +326,26 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                 if (threadIdx.x == BLK - 1) cpre[2 * BLK] = tot;
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t lo = 1, hi = nst;  // largest n in [1, nst] with cpre[n] <= cap (cpre[1] <= w <= cap)
-                while (lo < hi) {
-                    uint32_t mid = (lo + hi + 1) >> 1;
-                    if (cpre[mid] <= cap) lo = mid; else hi = mid - 1;
+            {  // chunk = the staged slots whose instances fit the table, cut back to the last key boundary inside if there
+               // is one (every thread tests its own candidates; exactly one matches each condition)
+                if (threadIdx.x == 0) {
+                    s_take = 0;
+                    s_endb = 0;
                 }
-                uint32_t take = lo;
-                if (s_cur + take < s_end) {  // cut at the last key boundary inside the chunk, if there is one
-                    const unsigned long long x = s_cur + take;
-                    uint32_t a = 0, b = SKM_KEYS_PER_ITEM;
-                    while (a < b) {
-                        uint32_t mid = (a + b + 1) >> 1;
-                        if (koff[mid] <= x) a = mid; else b = mid - 1;
-                    }
-                    if (koff[a] > s_cur) take = (uint32_t)(koff[a] - s_cur);
+                __syncthreads();
+                for (uint32_t n = threadIdx.x + 1; n <= nst; n += BLK)  // largest n in [1, nst] with cpre[n] <= cap
+                    if (cpre[n] <= cap && (n == nst || cpre[n + 1] > cap)) s_nfit = n;
+                __syncthreads();
+                const unsigned long long x = s_cur + s_nfit;
+                if (x < s_end)
+                    for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)  // koff[t] <= x < koff[t+1], koff[t] > s_cur
+                        if (koff[t] <= x && koff[t + 1] > x && koff[t] > s_cur) s_take = (uint32_t)(koff[t] - s_cur);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    s_endb = (x >= s_end || s_take != 0) ? 1u : 0u;  // the chunk ends with the last slot of a key
+                    if (s_take == 0) s_take = s_nfit;
+                    s_ninst = cpre[s_take];
                 }
-                s_take = take;
-                s_ninst = cpre[take];
             }
             __syncthreads();
             const uint32_t ntake = s_take, ninst = s_ninst;
@@ -392,7 +396,16 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
             __syncthreads();
             SKM_T(2)
             const uint32_t wcount = s_wcount;
-            if (threadIdx.x == 0) s_gbase = wcount ? atomicAdd(out_count, (unsigned long long)wcount) : 0ull;
+            // A chunk of whole keys holds every copy of its k-mers: its winners are exactly distinct ("clean", front of out).
+            // Winners of a key that had to be cut may recur in its other chunks ("dirty", stacked from the back of out; the
+            // host uniques that part on its own before the two are joined).
+            const bool dirty = !on_boundary || !s_endb;
+            on_boundary = s_endb != 0;
+            if (threadIdx.x == 0) {
+                if (!wcount) s_gbase = 0;
+                else if (!dirty) s_gbase = atomicAdd(out_count, (unsigned long long)wcount);
+                else s_gbase = out_cap - atomicAdd(dirty_count, (unsigned long long)wcount) - wcount;
+            }
             __syncthreads();
             {
                 Rec<NW> *dst = out + s_gbase;

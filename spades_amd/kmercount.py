@@ -58,10 +58,10 @@ class Context:
             pass
 
     def timings(self):
-        names = (C.c_char_p * 32)()
-        ms = (C.c_float * 32)()
-        n = self.lib.smx_last_timings(self._h, names, ms, 32)
-        return [(names[i].decode(), float(ms[i])) for i in range(min(n, 32))]
+        names = (C.c_char_p * 128)()
+        ms = (C.c_float * 128)()
+        n = self.lib.smx_last_timings(self._h, names, ms, 128)
+        return [(names[i].decode(), float(ms[i])) for i in range(min(n, 128))]
 
 
 class ReadKMerSplitter:

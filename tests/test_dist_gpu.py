@@ -11,13 +11,20 @@ from conftest import read_lines
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def test_sharded_path_single_rank_matches_direct_count():
     import torch
     import torch.distributed as dist
     from spades_amd import KMerDiskCounter, ReadKMerSplitter
     from spades_amd import dist as smx_dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
+    os.environ["MASTER_PORT"] = str(_free_port())
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -52,7 +59,7 @@ def test_sharded_build_graph_single_rank_nccl(tmp_path):
     from spades_amd import dist as smx_dist
     from spades_amd.gbuilder import GraphBuilder
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(30600 + os.getpid() % 1000)
+    os.environ["MASTER_PORT"] = str(_free_port())
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
