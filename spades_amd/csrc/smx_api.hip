@@ -364,7 +364,7 @@ struct ReadSel {  // which part of the resident reads one pipeline run covers
 
 template <int NW>
 int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in, const ReadSel *sel = nullptr,
-              bool recs_reusable = false, bool expand_rc = false) {
+              bool recs_reusable = false, bool expand_rc = false, bool distinct_hint = false) {
     uint32_t cap = Tune<NW>::CAP;
     if (ctx->opt_leaf_cap > 0) cap = (uint32_t)std::min<int64_t>(ctx->opt_leaf_cap, cap);
     const uint32_t cap1 = std::min<uint32_t>(Tune<NW>::CAP1, cap);
@@ -583,12 +583,21 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
                            (void *)sortbuf, fine_off, ucount, (const uint32_t *)smalllist, (const uint32_t *)smallcount);
         HIPCHK(hipGetLastError());
         tend(ctx);
-        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT1>, lds1)) return rc;
-        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT>, lds2)) return rc;
+        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT1, false>, lds1)) return rc;
+        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT, false>, lds2)) return rc;
+        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT1, true>, lds1)) return rc;
+        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT, true>, lds2)) return rc;
+        // distinct_hint: the records are expected to be distinct already (pre-dedupe stage): the leaves skip the hash set and
+        // only watch for equal records while ranking; a leaf that has some goes to the general kernel below
         tbegin(ctx, "sort_unique");
         if (sb1 > 0) {
-            hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1>), dim3(ctx->opt_leaf_grid > 0 ? (unsigned)ctx->opt_leaf_grid : 256 * 16), dim3(BLK), lds1, ctx->stream, (void *)sortbuf, fine_off, cap1,
-                               K, fa, sb1, T1, ucount, (const uint32_t *)medlist, (const uint32_t *)medcount, fblist, fbcount);
+            const dim3 grid1(ctx->opt_leaf_grid > 0 ? (unsigned)ctx->opt_leaf_grid : 256 * 16);
+            if (distinct_hint)
+                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1, true>), grid1, dim3(BLK), lds1, ctx->stream, (void *)sortbuf, fine_off, cap1, K, fa,
+                                   sb1, T1, ucount, (const uint32_t *)medlist, (const uint32_t *)medcount, fblist, fbcount);
+            else
+                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1, false>), grid1, dim3(BLK), lds1, ctx->stream, (void *)sortbuf, fine_off, cap1, K, fa,
+                                   sb1, T1, ucount, (const uint32_t *)medlist, (const uint32_t *)medcount, fblist, fbcount);
         } else {  // leaves too small for the digit table (test-sized caps): the general kernel takes the list directly
             hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT1>), dim3(256 * 8), dim3(BLK), lds1, ctx->stream, (void *)sortbuf,
                                fine_off, (uint32_t)nb, cap1, K, fa, sb1, T1, ucount, biglist, bigcount,
@@ -598,8 +607,12 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         tend(ctx);
         tbegin(ctx, "sort_unique2");
         if (sb2 > 0) {
-            hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf, fine_off, cap,
-                               K, fa, sb2, T2, ucount, (const uint32_t *)med2list, (const uint32_t *)med2count, fblist, fbcount);
+            if (distinct_hint)
+                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT, true>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf, fine_off, cap,
+                                   K, fa, sb2, T2, ucount, (const uint32_t *)med2list, (const uint32_t *)med2count, fblist, fbcount);
+            else
+                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT, false>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf, fine_off, cap,
+                                   K, fa, sb2, T2, ucount, (const uint32_t *)med2list, (const uint32_t *)med2count, fblist, fbcount);
         } else {
             hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf,
                                fine_off, (uint32_t)nb, cap, K, fa, sb2, T2, ucount, biglist, bigcount,
@@ -797,7 +810,7 @@ int count_selection(smx_ctx *ctx, unsigned K, int mode, unsigned B, const ReadSe
     if (int rc = run_prededupe<NW>(ctx, K, sel, nwin, &recs, &n)) return rc;
     free_temps(ctx, recs);
     ctx->temps.push_back(recs);
-    if (int rc = run_count<NW>(ctx, K, mode, B, recs, n, nullptr, false, mode == SMX_MODE_ALL)) return rc;
+    if (int rc = run_count<NW>(ctx, K, mode, B, recs, n, nullptr, false, mode == SMX_MODE_ALL, /*distinct_hint=*/true)) return rc;
     ctx->n_instances = sel.nrec;
     return 0;
 }

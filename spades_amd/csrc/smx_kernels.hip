@@ -728,13 +728,13 @@ __global__ void __launch_bounds__(BLK) k_sort_small(void *buf, const unsigned lo
 // loaded into registers before the current one is processed and every in-leaf barrier orders LDS only (lds_barrier), so the
 // global loads stay in flight across the whole leaf; (2) no fallback code in the kernel: a skewed leaf (a digit with > 128
 // distinct keys) is left untouched and queued for k_sort_small. LDS as k_sort_small.
-template <int NW, int LPT>
+template <int NW, int LPT, bool NODUP>
 __global__ void __launch_bounds__(BLK) k_sort_hash(void *buf, const unsigned long long *off, uint32_t cap, unsigned K, FracArgs fa,
                                                    unsigned sub_bits, uint32_t T, unsigned long long *ucount,
                                                    const uint32_t *list, const uint32_t *listcount, uint32_t *fblist, uint32_t *fbcount) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     __shared__ uint32_t scr[BLK / 64 + 2];
-    __shared__ uint32_t maxc;
+    __shared__ uint32_t maxc, dupflag;
     const uint32_t S = 1u << sub_bits;
     uint32_t *tab = (uint32_t *)(lds64 + (size_t)cap * NW);  // [T]
     uint32_t *head = tab + T;                                // [S]
@@ -762,12 +762,16 @@ __global__ void __launch_bounds__(BLK) k_sort_hash(void *buf, const unsigned lon
         Rec<NW> r[LPT];
 #pragma unroll
         for (int j = 0; j < LPT; ++j) r[j] = r_n[j];
-        for (uint32_t i = threadIdx.x; i < T; i += BLK) tab[i] = 0xFFFFFFFFu;
+        if constexpr (!NODUP)
+            for (uint32_t i = threadIdx.x; i < T; i += BLK) tab[i] = 0xFFFFFFFFu;
         for (uint32_t i = threadIdx.x; i <= S; i += BLK) {
             cntf[i] = 0;
             if (i < S) head[i] = 0xFFFFFFFFu;
         }
-        if (threadIdx.x == 0) maxc = 0;
+        if (threadIdx.x == 0) {
+            maxc = 0;
+            dupflag = 0;
+        }
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             uint32_t i = threadIdx.x + j * BLK;
@@ -792,16 +796,18 @@ __global__ void __launch_bounds__(BLK) k_sort_hash(void *buf, const unsigned lon
         for (int j = 0; j < LPT; ++j) {
             uint32_t i = threadIdx.x + j * BLK;
             if (i < n) {
-                uint32_t slot = rec_hash32<NW>(r[j]) & (T - 1);
-                bool first = false;
-                for (;;) {
-                    uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, i);
-                    if (old == 0xFFFFFFFFu) {
-                        first = true;
-                        break;
+                bool first = NODUP;  // NODUP: the caller expects distinct records; equal ones are detected while ranking
+                if constexpr (!NODUP) {
+                    uint32_t slot = rec_hash32<NW>(r[j]) & (T - 1);
+                    for (;;) {
+                        uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, i);
+                        if (old == 0xFFFFFFFFu) {
+                            first = true;
+                            break;
+                        }
+                        if (rec_eq<NW>(lds_get<NW>(lds64, old), r[j])) break;  // duplicate of record `old`
+                        slot = (slot + 1) & (T - 1);
                     }
-                    if (rec_eq<NW>(lds_get<NW>(lds64, old), r[j])) break;  // duplicate of record `old`
-                    slot = (slot + 1) & (T - 1);
                 }
                 if (first) {
                     fm |= 1u << j;
@@ -831,7 +837,7 @@ __global__ void __launch_bounds__(BLK) k_sort_hash(void *buf, const unsigned lon
         lds_barrier();
         if (maxc > 128) {
             if (threadIdx.x == 0) fblist[atomicAdd(fbcount, 1u)] = b;  // skewed: global data untouched, k_sort_small finishes it
-        } else {
+        } else if constexpr (!NODUP) {
 #pragma unroll
             for (int j = 0; j < LPT; ++j) {
                 if (fm & (1u << j)) {
@@ -843,6 +849,33 @@ __global__ void __launch_bounds__(BLK) k_sort_hash(void *buf, const unsigned lon
                 }
             }
             if (threadIdx.x == 0) ucount[b] = tot;
+        } else {
+            uint32_t pos[LPT];
+            bool dup = false;
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                if (fm & (1u << j)) {
+                    const uint32_t me = threadIdx.x + j * BLK;
+                    const uint32_t d = frac_digit<NW>(r[j], K, fa, S);
+                    uint32_t smaller = 0;
+                    for (uint32_t p = head[d]; p != 0xFFFFFFFFu; p = nxt[p]) {
+                        const Rec<NW> o = lds_get<NW>(lds64, p);
+                        smaller += rec_less<NW>(o, r[j]) ? 1u : 0u;
+                        dup |= p != me && rec_eq<NW>(o, r[j]);
+                    }
+                    pos[j] = cntf[d] + smaller;
+                }
+            }
+            if (dup) dupflag = 1;
+            lds_barrier();
+            if (dupflag) {  // not distinct after all: nothing written yet, the general kernel sorts AND uniques this leaf
+                if (threadIdx.x == 0) fblist[atomicAdd(fbcount, 1u)] = b;
+            } else {
+#pragma unroll
+                for (int j = 0; j < LPT; ++j)
+                    if (fm & (1u << j)) g[pos[j]] = r[j];
+                if (threadIdx.x == 0) ucount[b] = tot;
+            }
         }
         lds_barrier();  // LDS tables are re-initialised by the next iteration
     }

@@ -70,3 +70,21 @@ def test_gfa_with_prededupe(case, tmp_path):
     gb.write_gfa(out)
     assert open(out).read() == open(os.path.join(GOLDEN, case["file"])).read()
     gb.ctx.close()
+
+
+@pytest.mark.parametrize("K", [22, 56])
+def test_palindromes_reach_the_distinct_leaf_kernel(K):
+    """mode A with even K: a palindromic K-mer equals its reverse complement, so the RC expansion behind the pre-dedupe
+    stage emits it twice. Leaves of a few hundred records (s1/s2 forced) run the no-duplicates leaf kernel, which must notice
+    the equal pair and hand the leaf to the general sort+unique kernel."""
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    tr = str.maketrans("ACGT", "TGCA")
+    reads = _synth(33, 3000, 260, 150)
+    for _ in range(12):
+        h = "".join(rng.choice(list("ACGT"), K // 2))
+        pal = h + h[::-1].translate(tr)
+        reads.append("".join(rng.choice(list("ACGT"), 40)) + pal + "".join(rng.choice(list("ACGT"), 40)))
+    ref, rs = oracle.count(reads, K, "A", 16)
+    rec, sizes = _count(reads, K, "A", 16, {"prededupe": 1, "s1": 2, "s2": 0})
+    assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
