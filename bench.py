@@ -151,6 +151,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # setup (not a step of the measurement): let the library's device arena and torch's caching allocator reach their steady-state
+    # footprint — the first passes hipMalloc tens of GB, which stalls for tens of ms each
+    for _ in range(2 if sharded else 1):
+        st = step()
     for _ in range(args.warmup):
         st = step()
     sync()

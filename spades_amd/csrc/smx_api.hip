@@ -972,9 +972,21 @@ int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsign
     std::vector<uint64_t *> masks;
     uint64_t nwin = 0;
     if (int rc = mark_windows(ctx, K, masks, &nwin)) return rc;
-    const uint64_t nrec = mode == SMX_MODE_ALL ? 2 * nwin : nwin;
+    uint64_t nrec = mode == SMX_MODE_ALL ? 2 * nwin : nwin;
     if (nrec > capacity) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "record buffer too small: need %llu", (unsigned long long)nrec);
-    unsigned long long *hist, *off, *cur;
+    // Local pre-dedupe first ("optional local sort-unique per destination to cut volume by ~coverage"): the
+    // exchange then carries every distinct k-mer of this rank once instead of every instance.
+    Rec<NW> *recs = nullptr;
+    uint64_t n_dedup = 0;
+    const bool dedupe = K >= 21 && nwin > 0 && (ctx->opt_prededupe > 0 || (ctx->opt_prededupe < 0 && nwin >= (1u << 20)));
+    if (dedupe) {
+        ReadSel sel;
+        sel.masks = &masks;
+        sel.nrec = nrec;
+        if (int rc = run_prededupe<NW>(ctx, K, sel, nwin, &recs, &n_dedup)) return rc;
+        nrec = mode == SMX_MODE_ALL ? 2 * n_dedup : n_dedup;
+    }
+    unsigned long long *hist, *off, *cur, *seg1 = nullptr, *tcnt = nullptr, *tstart = nullptr;
     if (int rc = dalloc(ctx, &hist, world)) return rc;
     if (int rc = dalloc(ctx, &off, world + 1)) return rc;
     if (int rc = dalloc(ctx, &cur, world)) return rc;
@@ -985,9 +997,25 @@ int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsign
     a.world = world;
     a.F = world;
     a.hist = hist;
+    if (dedupe) {
+        if (int rc = dalloc(ctx, &seg1, 2)) return rc;
+        if (int rc = dalloc(ctx, &tcnt, 2)) return rc;
+        if (int rc = dalloc(ctx, &tstart, 3)) return rc;
+        unsigned long long h2[2] = {0, nrec};
+        HIPCHK(hipMemcpyAsync(seg1, h2, 16, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        a.recs = recs;
+        a.seg_off = seg1;
+        a.nseg = 1;
+        a.expand = mode == SMX_MODE_ALL ? 1u : 0u;
+    }
     tbegin(ctx, "x_hist");
     if (nrec) {
-        if (int rc = pass_reads<NW, BIN_OWNER>(ctx, mode, false, a, masks)) return rc;
+        if (dedupe) {
+            if (int rc = pass_recs<NW, BIN_OWNER>(ctx, false, a, nrec, tcnt, tstart)) return rc;
+        } else {
+            if (int rc = pass_reads<NW, BIN_OWNER>(ctx, mode, false, a, masks)) return rc;
+        }
     }
     tend(ctx);
     if (int rc = scan_u64(ctx, hist, off, world)) return rc;
@@ -996,7 +1024,11 @@ int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsign
     a.out = d_records;
     tbegin(ctx, "x_scatter");
     if (nrec) {
-        if (int rc = pass_reads<NW, BIN_OWNER>(ctx, mode, true, a, masks)) return rc;
+        if (dedupe) {
+            if (int rc = pass_recs<NW, BIN_OWNER>(ctx, true, a, nrec, tcnt, tstart)) return rc;
+        } else {
+            if (int rc = pass_reads<NW, BIN_OWNER>(ctx, mode, true, a, masks)) return rc;
+        }
     }
     tend(ctx);
     std::vector<unsigned long long> h(world);

@@ -73,6 +73,8 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t keys[NKQ];
     __shared__ uint64_t fw[NFW];  // break flags, bit i <-> window position p0 + i
     __shared__ uint64_t mw[NFW];  // window-valid bits, bit i <-> position 64*mq0 + i
+    __shared__ uint32_t slist[SKM_TP];  // starts of the tile: (window position << 12) | minimizer position
+    __shared__ uint32_t s_nstart;
     uint8_t *fb = (uint8_t *)fw;
     const unsigned w = a.w, K = a.K, m = a.m;
     const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1);
@@ -86,23 +88,38 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
         t0 = t1;                                 \
     }
     if (a.prof && threadIdx.x == 0) t0 = wall_clock64();
+    // stream / mask words of a tile, one per thread, fetched one tile ahead (the loads fly while the previous tile is scanned)
+    static_assert(NSW <= BLK && NFW <= BLK, "one staged word per thread");
+    const int64_t mwords = (int64_t)((a.G + 63) >> 6);
+    auto fetch = [&](uint64_t tile, uint64_t &rs, uint64_t &rm) {
+        const int64_t o = (int64_t)(a.g0 + tile * SKM_TP) - 1;
+        const int64_t wq0 = o < 0 ? 0 : (o >> 5), mq0 = o < 0 ? 0 : (o >> 6);
+        const int i = threadIdx.x;
+        rs = (i < NSW && (uint64_t)(wq0 + i) < a.nwords) ? a.seq[wq0 + i] : 0ull;
+        uint64_t v = 0;
+        if (i < NFW) {  // valid = mask bit, restricted to [g0, G) (g0 is a multiple of 64; G is cut inside its word)
+            v = (mq0 + i < mwords) ? a.mask[mq0 + i] : 0ull;
+            const int64_t first = (mq0 + i) << 6;
+            if (first < (int64_t)a.g0) v = 0;
+            if (first + 64 > (int64_t)a.G) v = first >= (int64_t)a.G ? 0ull : (v & ((1ull << (a.G - first)) - 1));
+        }
+        rm = v;
+    };
+    uint64_t pf_s = 0, pf_m = 0;
+    if (blockIdx.x < ntiles) fetch(blockIdx.x, pf_s, pf_m);
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t p0 = (int64_t)(a.g0 + tile * SKM_TP);
         const int64_t o = p0 - 1;  // origin of the local indices: qi = q - o, pi = p - o
         const int64_t wq0 = o < 0 ? 0 : (o >> 5);
-        for (int i = threadIdx.x; i < NSW; i += BLK) sw[i] = ((uint64_t)(wq0 + i) < a.nwords) ? a.seq[wq0 + i] : 0ull;
         const int64_t mq0 = o < 0 ? 0 : (o >> 6);
-        const int64_t mwords = (int64_t)((a.G + 63) >> 6);
-        for (int i = threadIdx.x; i < NFW; i += BLK) {
-            fw[i] = ~0ull;
-            // valid = mask bit, restricted to [g0, G) (g0 is a multiple of 64; G is cut inside its word)
-            uint64_t v = (mq0 + i < mwords) ? a.mask[mq0 + i] : 0ull;
-            const int64_t first = (mq0 + i) << 6;
-            if (first < (int64_t)a.g0) v = 0;
-            if (first + 64 > (int64_t)a.G) v = first >= (int64_t)a.G ? 0ull : (v & ((1ull << (a.G - first)) - 1));
-            mw[i] = v;
+        if (threadIdx.x < NSW) sw[threadIdx.x] = pf_s;
+        if (threadIdx.x < NFW) {
+            fw[threadIdx.x] = ~0ull;
+            mw[threadIdx.x] = pf_m;
         }
+        if (threadIdx.x == 0) s_nstart = 0;
         __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, pf_s, pf_m);
         const int nq = SKM_TC + (int)w + 8;
         for (int qi = threadIdx.x; qi < nq; qi += BLK) {
             const int64_t q = o + qi;
@@ -191,13 +208,23 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
         fb[b8 >> 3] = (uint8_t)brk;
         __syncthreads();
         SKM_T(1)
-        // one super-k-mer per owned start; the last SKM_TC - SKM_TP windows are only the look-ahead of the run lengths
-        uint32_t starts = b8 < SKM_TP ? ((vb >> 1) & brk & 0xFFu) : 0u;
-        while (starts) {
-            const int j = __ffs(starts) - 1;
-            starts &= starts - 1;
-            const int pr = b8 + j;  // window position relative to p0
-            uint32_t c;             // windows until the next break (within w: the minimizer leaves the window)
+        // one super-k-mer per owned start; the last SKM_TC - SKM_TP windows are only the look-ahead of the run lengths.
+        // The starts are first gathered into a dense list so that every lane of the emitting loop has one.
+        {
+            uint32_t starts = b8 < SKM_TP ? ((vb >> 1) & brk & 0xFFu) : 0u;
+            if (starts) {
+                uint32_t at = atomicAdd(&s_nstart, (uint32_t)__popc(starts));
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (starts & (1u << j)) slist[at++] = ((uint32_t)(b8 + j) << 12) | m9[j + 1];
+            }
+        }
+        __syncthreads();
+        const uint32_t nstart = s_nstart;
+        for (uint32_t si = threadIdx.x; si < nstart; si += BLK) {
+            const uint32_t e = slist[si];
+            const int pr = (int)(e >> 12);  // window position relative to p0
+            uint32_t c;                     // windows until the next break (within w: the minimizer leaves the window)
             {
                 const int nb1 = pr + 1;
                 const int wi = nb1 >> 6, bit = nb1 & 63;
@@ -214,11 +241,7 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
                 c = (uint32_t)(acc + (x ? __ffsll((unsigned long long)x) - 1 : 64)) + 1;
             }
             if (c > w) c = w;
-            uint32_t mpj = 0;
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-                if (t == j) mpj = m9[t + 1];
-            const uint32_t key = skm_part(keys[mpj]);
+            const uint32_t key = skm_part(keys[e & 0xFFFu]);
             if constexpr (PHASE == 0) {
                 atomicAdd(&a.cnt[key], 1ull);
             } else {

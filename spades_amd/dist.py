@@ -86,6 +86,7 @@ def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
     n_local = engine.extract_count(K)
     send = engine.alloc(n_local * nw, dev)
     counts = engine.extract_partition(K, nb, world, send, n_local)
+    n_sent = sum(counts)  # < n_local when the engine pre-dedupes its shard before the exchange
     cnt_t = torch.tensor(counts, dtype=torch.int64, device=dev)
     rcv_t = torch.empty_like(cnt_t)
     dist.all_to_all_single(rcv_t, cnt_t)
@@ -105,7 +106,7 @@ def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     rounds = max(1, -(-int(mx.item()) // XCHG_LIMIT))
     if rounds == 1:
-        dist.all_to_all_single(recv[:n_recv * nw], send[:n_local * nw],
+        dist.all_to_all_single(recv[:n_recv * nw], send[:n_sent * nw],
                                output_split_sizes=[c * nw for c in rcounts], input_split_sizes=[c * nw for c in counts])
     else:
         # grouped point-to-point rounds on views (ncclSend/ncclRecv pairs under one group on RCCL): every pair has its own
@@ -128,7 +129,7 @@ def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
     res = engine.count_records(K, nb, recv, n_recv)
-    res["sent"], res["received"] = n_local, n_recv
+    res["sent"], res["received"] = n_sent, n_recv
     res["instances"] = n_local  # k-mer instances extracted from this rank's reads
     return res
 
