@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/profile_bench.sh into the two tables kept under profiles/:
+  <dir>/kernel_stats.csv      the --stats table (as written by rocprofv3)
+  <dir>/pmc_hbm_traffic.csv   HBM GB per kernel for ONE step: FETCH_SIZE (KB) x2 (gfx950 correction, MI355X_MICROARCH.md HBM
+                               section; calibrated on a 4 GiB copy with tools/ubench) and WRITE_SIZE (KB)
+The PMC runs execute setup + 1 step = S passes of the pipeline; per-step = total / S (S = dispatches of k_mark_windows)."""
+import csv, glob, os, shutil, sys
+from collections import defaultdict
+
+d = sys.argv[1]
+
+
+def find(sub, suffix):
+    f = glob.glob(os.path.join(d, sub, "**", "*" + suffix), recursive=True)
+    return f[0] if f else None
+
+
+ks = find("kt", "kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(d, "kernel_stats.csv"))
+tot = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = find(c, "counter_collection.csv")
+    acc = defaultdict(lambda: [0, 0.0])
+    if f:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != c:
+                continue
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            acc[name][0] += 1
+            acc[name][1] += float(row["Counter_Value"])
+    tot[c] = acc
+names = sorted(set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"]), key=lambda n: -(tot["FETCH_SIZE"][n][1] * 2 + tot["WRITE_SIZE"][n][1]))
+passes = max(1, tot["FETCH_SIZE"].get("smx::k_mark_windows", [1])[0])
+with open(os.path.join(d, "pmc_hbm_traffic.csv"), "w") as o:
+    o.write("kernel,launches_per_step,FETCH_SIZE_KB(raw),fetch_GB(x2 gfx950 correction),WRITE_SIZE_KB,write_GB\n")
+    tf = tw = 0.0
+    for n in names:
+        if not n.startswith("smx::"):
+            continue
+        nl, f = tot["FETCH_SIZE"][n]
+        _, w = tot["WRITE_SIZE"][n]
+        f, w = f / passes, w / passes
+        fg, wg = f * 1024 * 2 / 1e9, w * 1024 / 1e9
+        tf += fg
+        tw += wg
+        o.write(f"{n},{nl / passes:g},{f:.0f},{fg:.2f},{w:.0f},{wg:.2f}\n")
+    o.write(f"TOTAL,,,{tf:.1f},,{tw:.1f}\n")
+print(f"passes={passes} fetch {tf:.1f} GB + write {tw:.1f} GB = {tf + tw:.1f} GB per step")
