@@ -192,12 +192,26 @@ def main():
             if line.startswith("TOTAL"):
                 f = line.strip().split(",")
                 traffic = round(float(f[3]) + float(f[5]), 1)
+    # per-stage view: algorithmic GB a stage has to move / its measured time. Behind the pre-dedupe stage the sort
+    # pipeline sees Dc = D/2 canonical records in and n2 = D (mode A) or D (mode B: Dc = D) records through its levels.
+    n2 = float(distinct)
+    dc = n2 / 2 if args.mode == "A" else n2
+    slots_b = inst / (2 if args.mode == "A" else 1) * 1.3  # ~1.3 B per canonical instance in super-k-mer slots (k=55)
+    alg = {"skm_count": n_reads * L / 4, "skm_scatter": n_reads * L / 4 + slots_b, "skm_dedupe": slots_b + dc * W,
+           "l1_hist": dc * W, "l1_scatter": dc * W + n2 * W, "l2_hist": n2 * W, "l2_scatter": 2 * n2 * W, "l3_hist": n2 * W,
+           "l3_scatter": 2 * n2 * W, "sort_unique": 2 * n2 * W}
+    stage_roofline = {}
+    if "skm_dedupe" in stages:
+        for name, b in alg.items():
+            if stages.get(name, 0) > 0.05:
+                stage_roofline[name] = {"alg_GB": round(b / 1e9, 2), "ms": round(stages[name], 3),
+                                        "TBps": round(b / (stages[name] * 1e-3) / 1e12, 2), "frac": round(b / (stages[name] * 1e-3) / 8e12, 3)}
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_unit": "GB per step (PMC, profiles/r01)",
                 "kernel": "smx_count pipeline (sum of stage kernels, HIP events on the library stream)",
                 "algorithmic_bytes_per_step": int(b_alg), "kernel_ms_per_step": round(kernel_ms, 3),
                 "dominant_stage": dom[0], "dominant_stage_ms": round(dom[1], 3),
-                "stages_ms": {n: round(ms, 3) for n, ms in stages.items()}}
+                "stages_ms": {n: round(ms, 3) for n, ms in stages.items()}, "stage_roofline": stage_roofline}
 
     out = {
         "metric": "M reads/sec k-mer-counted (k=55, PE150)" if K == 55 else f"M reads/sec k-mer-counted (k={K}, PE150)",

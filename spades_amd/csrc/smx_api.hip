@@ -51,6 +51,7 @@ struct smx_ctx {
     // tuning / test hooks
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;
+    int64_t opt_joint_hist = 1;  // fuse the level-2 histogram into the level-1 histogram pass (records source)
     int64_t opt_prededupe = -1;  // super-k-mer pre-deduplication: -1 auto, 0 off, 1 on whenever K allows it
     int64_t opt_skm_cap = 0;     // instances per LDS dedupe chunk (0 = default)
     int64_t opt_skm_scap = 0;    // slots staged per chunk (0 = default)
@@ -491,6 +492,10 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     a.F = F1;
     a.hist = histA;
     HIPCHK(hipMemsetAsync(histA, 0, (size_t)F1 * 8, ctx->stream));
+    // records source: level-1 histogram fused with the level-2 one (LDS table of F1*F2 counters) + level-1 bins cached as bytes
+    const bool joint = !from_reads && !lv.empty() && (uint64_t)F1 * lv[0] <= 24 * 1024 && F1 <= 256 && ctx->opt_joint_hist != 0;
+    unsigned long long *histJ = nullptr;
+    uint8_t *bins8 = nullptr;
     tbegin(ctx, "l1_hist");
     if (from_reads) {
         if (int rc = pass_reads<NW, BIN_L1>(ctx, mode, false, a, masks, ranges)) return rc;
@@ -499,7 +504,25 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         a.seg_off = seg1;
         a.nseg = 1;
         a.expand = expand_rc ? 1u : 0u;
-        if (int rc = pass_recs<NW, BIN_L1>(ctx, false, a, nrec, tcnt, tstart)) return rc;
+        if (joint) {
+            const uint32_t F2 = lv[0];
+            if (int rc = dalloc(ctx, &histJ, (size_t)F1 * F2)) return rc;
+            if (ctx->opt_joint_hist >= 2)
+                if (int rc = dalloc(ctx, &bins8, nrec + 16)) return rc;
+            HIPCHK(hipMemsetAsync(histJ, 0, (size_t)F1 * F2 * 8, ctx->stream));
+            PassArgs aj = a;
+            aj.hist = histJ;
+            aj.bins8 = bins8;
+            const size_t lds = (size_t)F1 * F2 * 4;
+            if (int rc = set_lds(ctx, k_hist_l1_joint<NW>, lds)) return rc;
+            hipLaunchKernelGGL((k_hist_l1_joint<NW>), dim3(256 * 2), dim3(1024), lds, ctx->stream, aj, F2, n_in);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_rowsum, dim3((F1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, (const unsigned long long *)histJ, F1, F2, histA);
+            HIPCHK(hipGetLastError());
+            a.bins8 = bins8;
+        } else {
+            if (int rc = pass_recs<NW, BIN_L1>(ctx, false, a, nrec, tcnt, tstart)) return rc;
+        }
     }
     tend(ctx);
     tbegin(ctx, "l1_scan");
@@ -519,6 +542,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     tend(ctx);
 
     a.expand = 0;
+    a.bins8 = nullptr;
     wt.mark(ctx, "level1");
     // ---- levels 2.. -------------------------------------------------------------------------
     Rec<NW> *sortbuf = bufA, *other = bufB;
@@ -530,17 +554,22 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         const uint32_t t = lv[li];
         const uint64_t nchild = nseg * t;
         const char **nm = lname[std::min<size_t>(li, 2)];
-        HIPCHK(hipMemsetAsync(histA, 0, (size_t)nchild * 8, ctx->stream));
         a.recs = sortbuf;
         a.seg_off = off_cur;
         a.nseg = (uint32_t)nseg;
         a.F = t;
         a.hist = histA;
+        const unsigned long long *hsrc = histA;
         tbegin(ctx, nm[0]);
-        if (int rc = pass_recs<NW, BIN_LK>(ctx, false, a, nrec, tcnt, tstart)) return rc;
+        if (li == 0 && joint) {
+            hsrc = histJ;  // counted together with level 1
+        } else {
+            HIPCHK(hipMemsetAsync(histA, 0, (size_t)nchild * 8, ctx->stream));
+            if (int rc = pass_recs<NW, BIN_LK>(ctx, false, a, nrec, tcnt, tstart)) return rc;
+        }
         tend(ctx);
         tbegin(ctx, nm[1]);
-        if (int rc = scan_u64(ctx, histA, off_other, nchild)) return rc;
+        if (int rc = scan_u64(ctx, hsrc, off_other, nchild)) return rc;
         HIPCHK(hipMemcpyAsync(cur, off_other, (size_t)nchild * 8, hipMemcpyDeviceToDevice, ctx->stream));
         tend(ctx);
         a.cursor = cur;
@@ -1446,6 +1475,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "leaf_grid")) ctx->opt_leaf_grid = value;
     else if (!strcmp(key, "leaf_tab")) ctx->opt_leaf_tab = value;
     else if (!strcmp(key, "prededupe")) ctx->opt_prededupe = value;
+    else if (!strcmp(key, "joint_hist")) ctx->opt_joint_hist = value;
     else if (!strcmp(key, "skm_cap")) ctx->opt_skm_cap = value;
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;

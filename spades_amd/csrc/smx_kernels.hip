@@ -44,6 +44,7 @@ struct PassArgs {
     uint32_t fprev[6];
     uint32_t world;
     uint32_t expand;  // records source, level 1 only: instance i = record i/2, odd i = its reverse complement
+    uint8_t *bins8;   // records source, level 1 only: level-1 bin of every instance, written by k_hist_l1_joint, read by k_scatter
     uint32_t F;  // bins per segment
     unsigned long long *hist;    // [nseg*F]
     unsigned long long *cursor;  // [nseg*F]
@@ -275,6 +276,48 @@ __global__ void __launch_bounds__(BLK) k_hist(PassArgs a) {
     }
 }
 
+// Level-1 histogram from records, fused with the level-2 histogram: one LDS table of F1*F2 counters per persistent workgroup
+// (bin1 * F2 + second mixed-radix digit), flushed once; the level-2 hist pass over the scattered records (one full re-read) is
+// not needed any more. Also stores the level-1 bin of every instance (u8, F1 <= 256) so that the scatter does not hash again.
+// a.F = F1, a.hist = joint histogram [F1*F2]; level-1 totals are its row sums (k_rowsum).
+template <int NW>
+__global__ void __launch_bounds__(1024) k_hist_l1_joint(PassArgs a, uint32_t F2, uint64_t n_in) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lh[];
+    const uint32_t nj = a.F * F2;
+    for (uint32_t i = threadIdx.x; i < nj; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const Rec<NW> *in = (const Rec<NW> *)a.recs;
+    const uint64_t S1 = a.S1;
+    for (uint64_t ri = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; ri < n_in; ri += (uint64_t)gridDim.x * blockDim.x) {
+        const Rec<NW> x = in[ri];
+        {
+            const uint32_t b1 = bin_of<NW, BIN_L1>(x, a);
+            uint64_t f = key_top64<NW>(x, a.K);
+            if (S1 > 1) f *= S1;
+            atomicAdd(&lh[b1 * F2 + (uint32_t)__umul64hi(f, (uint64_t)F2)], 1u);
+            if (a.bins8) a.bins8[a.expand ? 2 * ri : ri] = (uint8_t)b1;
+        }
+        if (a.expand) {
+            const Rec<NW> y = rec_rc<NW>(x, a.K);
+            const uint32_t b1 = bin_of<NW, BIN_L1>(y, a);
+            uint64_t f = key_top64<NW>(y, a.K);
+            if (S1 > 1) f *= S1;
+            atomicAdd(&lh[b1 * F2 + (uint32_t)__umul64hi(f, (uint64_t)F2)], 1u);
+            if (a.bins8) a.bins8[2 * ri + 1] = (uint8_t)b1;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nj; i += blockDim.x)
+        if (lh[i]) atomicAdd(&a.hist[i], (unsigned long long)lh[i]);
+}
+__global__ void k_rowsum(const unsigned long long *joint, uint32_t F1, uint32_t F2, unsigned long long *rows) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= F1) return;
+    unsigned long long s = 0;
+    for (uint32_t d = 0; d < F2; ++d) s += joint[(uint64_t)b * F2 + d];
+    rows[b] = s;
+}
+
 // --------------------------------------------------------------------------------------- scatter
 // LDS-staged multisplit of one tile (<= RPT*BLK records) into a.F bins of its segment.
 // LDS carve (dynamic): stage[TR*NW] u64 | ldelta[F] u64 | lhist[F] u32 | sbin[TR] u16
@@ -313,7 +356,19 @@ __global__ void __launch_bounds__(BLK) k_scatter(PassArgs a) {
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
         if (vm & (1u << j)) {
-            packed[j] = bin_of<NW, BINF>(r[j], a);
+            if (SRC == SRC_RECS && BINF == BIN_L1 && a.bins8) {  // XXH3 was paid once, in the histogram pass (same instance numbering)
+                if (a.expand) {
+                    if ((j & 1) == 0) {
+                        const uint32_t two = ((const uint16_t *)a.bins8)[(sb >> 1) + (uint64_t)(j >> 1) * BLK + threadIdx.x];
+                        packed[j] = two & 0xFFu;
+                        if (j + 1 < RPT) packed[j + 1] = two >> 8;
+                    }
+                } else {
+                    packed[j] = a.bins8[sb + (uint64_t)j * BLK + threadIdx.x];
+                }
+            } else {
+                packed[j] = bin_of<NW, BINF>(r[j], a);
+            }
             slot[j] = atomicAdd(&lhist[packed[j]], 1u);
         }
     }
