@@ -482,6 +482,82 @@ __global__ void __launch_bounds__(BLK) k_scatter_reads(PassArgs a) {
     }
 }
 
+// Level-1 scatter from records (single input segment [0, n_in), a.expand: every record also yields its reverse complement).
+// Like k_scatter_reads the LDS stage holds a 13-bit (record-in-tile, strand) tag per instance instead of the record (19 KB instead
+// of 76 KB: 8 workgroups per CU instead of 2); the copy-out re-reads the tile's records (L2 hits) and redoes the RC.
+template <int NW, int BINF, int RPT>
+__global__ void __launch_bounds__(BLK) k_scatter_recs_tag(PassArgs a, uint64_t n_in) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+    constexpr int TR = RPT * BLK;
+    uint64_t *ldelta = lds64;
+    uint32_t *lhist = (uint32_t *)(ldelta + a.F);
+    uint16_t *spos = (uint16_t *)(lhist + a.F);
+    uint16_t *sbin = spos + TR;
+    __shared__ uint32_t scr[BLK / 64 + 2];
+    for (uint32_t i = threadIdx.x; i < a.F; i += BLK) lhist[i] = 0;
+    __syncthreads();
+    const bool ex = a.expand != 0;
+    const Rec<NW> *in = (const Rec<NW> *)a.recs;
+    const uint64_t rbase = (uint64_t)blockIdx.x * (uint64_t)(ex ? TR / 2 : TR);
+    uint32_t packed[RPT];  // bin << 16 | slot
+    uint32_t vm = 0;
+    if (ex) {
+#pragma unroll
+        for (int j = 0; j < RPT / 2; ++j) {
+            const uint64_t ri = rbase + (uint64_t)j * BLK + threadIdx.x;
+            if (ri < n_in) {
+                const Rec<NW> x = in[ri];
+                const uint32_t b0 = bin_of<NW, BINF>(x, a), b1 = bin_of<NW, BINF>(rec_rc<NW>(x, a.K), a);
+                packed[2 * j] = (b0 << 16) | atomicAdd(&lhist[b0], 1u);
+                packed[2 * j + 1] = (b1 << 16) | atomicAdd(&lhist[b1], 1u);
+                vm |= 3u << (2 * j);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const uint64_t ri = rbase + (uint64_t)j * BLK + threadIdx.x;
+            if (ri < n_in) {
+                const uint32_t b0 = bin_of<NW, BINF>(in[ri], a);
+                packed[j] = (b0 << 16) | atomicAdd(&lhist[b0], 1u);
+                vm |= 1u << j;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t per = (a.F + BLK - 1) / BLK;
+    const uint32_t d0 = threadIdx.x * per, d1 = min(a.F, d0 + per);
+    uint32_t sum = 0;
+    for (uint32_t d = d0; d < d1; ++d) sum += lhist[d];
+    uint32_t total;
+    uint32_t run = block_excl_scan<uint32_t>(sum, scr, &total);
+    for (uint32_t d = d0; d < d1; ++d) {
+        uint32_t c = lhist[d];
+        lhist[d] = run;
+        if (c) ldelta[d] = (uint64_t)atomicAdd(&a.cursor[d], (unsigned long long)c) - run;
+        run += c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        if (vm & (1u << j)) {
+            const uint32_t bin = packed[j] >> 16;
+            const uint32_t idx = lhist[bin] + (packed[j] & 0xFFFFu);
+            const uint32_t lpos = (uint32_t)(ex ? j / 2 : j) * BLK + threadIdx.x;
+            spos[idx] = (uint16_t)((lpos << 1) | (ex ? (j & 1) : 0));
+            sbin[idx] = (uint16_t)bin;
+        }
+    }
+    __syncthreads();
+    Rec<NW> *out = (Rec<NW> *)a.out;
+    for (uint32_t idx = threadIdx.x; idx < total; idx += BLK) {
+        const uint32_t tag = spos[idx];
+        Rec<NW> x = in[rbase + (tag >> 1)];
+        if (tag & 1) x = rec_rc<NW>(x, a.K);
+        out[ldelta[sbin[idx]] + idx] = x;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ scans
 // Single-workgroup exclusive scan (n small, e.g. level-1 histogram): out[i] = sum in[0..i), out[n] = total.
 __global__ void k_scan_small(const unsigned long long *in, unsigned long long *out, uint32_t n) {
