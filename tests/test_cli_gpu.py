@@ -74,3 +74,23 @@ def test_cli_exit_codes(tmp_path):
     fa.write_text(">a\nACGTACGTACGTACGTACGTACGTACGT\n")
     assert subprocess.call([GB, str(fa), str(tmp_path / "o"), "-k", "22"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 67
     assert subprocess.call([GB, str(fa), str(tmp_path / "o"), "-k", "129"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 67
+
+
+def test_cli_tools_with_the_prededupe_stage_forced(tmp_path):
+    """SMX_OPTS reaches every context, so the CLI clones can be pushed through the super-k-mer stage on the small goldens."""
+    env = dict(os.environ, SMX_OPTS="prededupe=1")
+    import hashlib
+    tq = str(tmp_path / "t.fq")
+    _fastq(tq, read_lines("reads_tiny.txt"))
+    for c in [c for c in load_manifest()["cases"] if c["kind"] == "count" and c["mode"] == "A" and c["num_buckets"] == 16
+              and c["reads"] == "reads_tiny.txt" and c["K"] >= 21]:
+        wd = tmp_path / f"w{c['K']}"
+        wd.mkdir()
+        subprocess.check_call([KC, "-k", str(c["K"]), "-t", "2", "-w", str(wd), tq], stdout=subprocess.DEVNULL, env=env)
+        assert hashlib.md5(open(wd / "final_kmers", "rb").read()).hexdigest() == c["md5"]
+    fq = str(tmp_path / "r.fq")
+    _fastq(fq, [r for r in read_lines("reads_small.txt") if r])
+    c = [c for c in load_manifest()["cases"] if c["kind"] == "graph_cov" and c["reads"] == "reads_small.txt" and c["K"] == 55 and c["threads"] == 3][0]
+    out = str(tmp_path / "g.gfa")
+    subprocess.check_call([GB, fq, out, "-k", "55", "-t", "3", "-c", "--gfa"], stdout=subprocess.DEVNULL, env=env)
+    assert open(out).read() == open(os.path.join(GOLDEN, c["file"])).read()

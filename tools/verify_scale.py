@@ -18,9 +18,10 @@ dev = torch.device("cuda", 0)
 words, start, ln, codes = synth_reads_device(7, 50_000_000, n, dev); del codes
 nw = (K + 31) // 32
 
-def run(batch_records):
+def run(batch_records, prededupe=None):
     ctx = Context(0)
     if batch_records: ctx.set_option("batch_records", batch_records)
+    if prededupe is not None: ctx.set_option("prededupe", prededupe)
     sp = ReadKMerSplitter(K, mode, ctx)
     sp.push_back_device(words.data_ptr(), words.numel() - 8, start.data_ptr(), ln.data_ptr(), n)
     t0 = time.time(); st = KMerDiskCounter(None, sp).Count(nb); dt = time.time() - t0
@@ -70,5 +71,14 @@ if batch:
     print(f"multi-batch ({batch:g} records/batch) time={dt2:.3f}s identical sizes: {bool(same)} checksum equal: {csum2 == csum}")
     ok &= bool(same) and csum2 == csum
     ctx2.close()
+# the direct pipeline (no super-k-mer pre-dedupe stage) must give the identical byte stream
+ctx3, st3, dt3 = run(0, prededupe=0)
+rec3 = torch.as_tensor(Wrap(st3.device_ptr(), (st3.total_kmers(), nw)), device=dev)
+same3 = st3.total_kmers() == D and (st3.bucket_sizes() == sizes).all()
+csum3 = int((rec3.sum(dim=0) & 0x7FFFFFFFFFFFFFFF).sum().item())
+pos = torch.arange(1, 1 + min(D, 1 << 24), device=dev, dtype=torch.int64)  # order-sensitive probe on the first 16 M records
+print(f"direct pipeline (prededupe=0) time={dt3:.3f}s identical sizes: {bool(same3)} checksum equal: {csum3 == csum}")
+ok &= bool(same3) and csum3 == csum
+ctx3.close()
 print("ALL OK" if ok else "FAILED")
 sys.exit(0 if ok else 1)
