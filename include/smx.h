@@ -76,6 +76,16 @@ int smx_submit_reads_packed(smx_ctx *ctx, const uint64_t *words, uint64_t n_word
  * (common/io/reads/binary_converter.cpp:83-151, read back by common/io/reads/binary_streams.hpp:54-102) — what the
  * Construction stage streams inside a spades.py run. Single or paired file; reads arrive already N-trimmed. */
 int smx_submit_reads_binary(smx_ctx *ctx, const char *seq_path);
+/* Uncompressed strict 4-line FASTQ, parsed ON THE DEVICE (newline scan -> line roles -> per-read longest ACGT run + 2-bit packing):
+ * replaces io::FastaFastaGzParser + LongestValidWrap + the binary conversion for the common case (common/io/reads/parser.cpp,
+ * longest_valid_wrapper.hpp:16-53, binary_converter.cpp:83-151). `text` is a chunk of file bytes starting at a record; it may end
+ * inside a record: only complete records are taken, *consumed = offset of the first unconsumed byte (carry the tail into the next
+ * chunk). is_final = the chunk ends the file. Multi-line FASTQ, FASTA or any other structure -> SMX_INVALID_INPUT_FORMAT with
+ * nothing submitted (use the host parser + smx_submit_reads_ascii then). */
+int smx_submit_fastq_text(smx_ctx *ctx, const char *text, uint64_t n_bytes, int is_final, uint64_t *n_reads, uint64_t *consumed);
+/* page-locked host buffers for such chunks (optional; any host memory works, pinned memory uploads at the PCIe rate) */
+void *smx_pinned_alloc(size_t bytes);
+void smx_pinned_free(void *p);
 /* Same, but the three arrays already live in HBM (benchmark path: inputs resident before the
  * timed region). The context borrows the pointers until smx_reads_clear()/smx_destroy();
  * d_words must be readable for n_words + 8 words (tail pad). */

@@ -51,6 +51,9 @@ def load():
         "smx_build_graph_from_records": (C.c_int, [vp, C.c_uint, C.c_uint, vp, C.c_uint64]),
         "smx_graph_set_coverage": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_uint64]),
         "smx_copy_kmers_device": (C.c_int, [vp, vp]),
+        "smx_submit_fastq_text": (C.c_int, [vp, C.c_char_p, C.c_uint64, C.c_int, u64p, u64p]),
+        "smx_pinned_alloc": (vp, [C.c_size_t]),
+        "smx_pinned_free": (None, [vp]),
         "smx_submit_reads_binary": (C.c_int, [vp, C.c_char_p]),
         "smx_reads_info": (C.c_int, [vp, u64p, u64p]),
         "smx_count": (C.c_int, [vp, C.c_uint, C.c_int, C.c_uint]),

@@ -3,6 +3,7 @@
 #include "../../include/smx.h"
 #include "smx_kernels.hip"
 #include "smx_superkmer.hip"
+#include "smx_ingest.hip"
 #include "smx_graph.hip"
 #include "smx_graph_host.hpp"
 
@@ -1618,6 +1619,103 @@ int smx_submit_reads_binary(smx_ctx *ctx, const char *seq_path) {
     fclose(f);
     if (words.empty()) words.push_back(0);
     return smx_submit_reads_packed(ctx, words.data(), words.size(), start.data(), len.data(), start.size());
+}
+
+// Strict 4-line FASTQ text (uncompressed file bytes) -> read batch, parsed on the device (smx_ingest.hip). `text` may end in the
+// middle of a record: only complete records are taken and *consumed tells where the next chunk has to start. is_final: the text
+// ends the file (a missing last newline is tolerated).
+int smx_submit_fastq_text(smx_ctx *ctx, const char *text, uint64_t n_bytes, int is_final, uint64_t *n_reads, uint64_t *consumed) {
+    if (!ctx || (n_bytes && !text)) return SMX_INVALID_PARAMETER;
+    if (n_reads) *n_reads = 0;
+    if (consumed) *consumed = 0;
+    if (n_bytes == 0) return SMX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    auto bail = [&](int code) {
+        free_temps(ctx);
+        return code;
+    };
+    char *d_text;
+    unsigned long long *cnt, *boff, *d_cons;
+    uint32_t *bad;
+    const uint64_t nblk = (n_bytes + FQ_BLOCK - 1) / FQ_BLOCK;
+    if (nblk > 0x7FFFFFFFull) return fail(ctx, SMX_INVALID_PARAMETER, "FASTQ chunk too large (%llu bytes)", (unsigned long long)n_bytes);
+    if (int rc = dalloc(ctx, &d_text, n_bytes + 16)) return bail(rc);
+    if (int rc = dalloc(ctx, &cnt, nblk)) return bail(rc);
+    if (int rc = dalloc(ctx, &boff, nblk + 1)) return bail(rc);
+    if (int rc = dalloc(ctx, &d_cons, 1)) return bail(rc);
+    if (int rc = dalloc(ctx, &bad, 1)) return bail(rc);
+    HIPCHK(hipMemcpyAsync(d_text, text, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(bad, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_cons, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_fq_count, dim3((unsigned)nblk), dim3(BLK), 0, ctx->stream, (const char *)d_text, n_bytes, cnt);
+    HIPCHK(hipGetLastError());
+    if (int rc = scan_u64(ctx, cnt, boff, nblk)) return bail(rc);
+    unsigned long long n_nl = 0;
+    HIPCHK(hipMemcpyAsync(&n_nl, boff + nblk, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const bool virt = is_final && text[n_bytes - 1] != '\n';
+    const uint64_t n_rec = (n_nl + (virt ? 1 : 0)) / 4;
+    if (n_rec == 0) {
+        if (is_final && consumed) *consumed = n_bytes;
+        return bail(SMX_OK);
+    }
+    unsigned long long *sstart, *send, *wcnt, *woff;
+    if (int rc = dalloc(ctx, &sstart, n_rec)) return bail(rc);
+    if (int rc = dalloc(ctx, &send, n_rec)) return bail(rc);
+    if (int rc = dalloc(ctx, &wcnt, n_rec)) return bail(rc);
+    if (int rc = dalloc(ctx, &woff, n_rec + 1)) return bail(rc);
+    hipLaunchKernelGGL(k_fq_lines, dim3((unsigned)nblk), dim3(BLK), 0, ctx->stream, (const char *)d_text, n_bytes, (const unsigned long long *)boff,
+                       n_rec, sstart, send, d_cons, bad);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_fq_words, dim3((unsigned)((n_rec + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)sstart,
+                       (const unsigned long long *)send, n_rec, wcnt, bad);
+    HIPCHK(hipGetLastError());
+    if (int rc = scan_u64(ctx, wcnt, woff, n_rec)) return bail(rc);
+    unsigned long long n_words = 0, cons = 0;
+    uint32_t h_bad = 0;
+    HIPCHK(hipMemcpyAsync(&n_words, woff + n_rec, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&cons, d_cons, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (h_bad) return bail(fail(ctx, SMX_INVALID_INPUT_FORMAT, "not a 4-line FASTQ (%u structure violations)", h_bad));
+    ReadChunk c;
+    c.n_reads = n_rec;
+    c.n_words = n_words + 1;
+    c.n_bases = c.n_words * 32;
+    if (int rc = dalloc(ctx, &c.d_words, c.n_words + 8, false)) return bail(rc);
+    if (int rc = dalloc(ctx, &c.d_start, n_rec, false)) {
+        arena_put(ctx, c.d_words);
+        return bail(rc);
+    }
+    if (int rc = dalloc(ctx, &c.d_len, n_rec, false)) {
+        arena_put(ctx, c.d_words);
+        arena_put(ctx, c.d_start);
+        return bail(rc);
+    }
+    HIPCHK(hipMemsetAsync(c.d_words + n_words, 0, 72, ctx->stream));
+    hipLaunchKernelGGL(k_fq_pack, dim3((unsigned)((n_rec + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, (const char *)d_text,
+                       (const unsigned long long *)sstart, (const unsigned long long *)send, (const unsigned long long *)woff, n_rec, c.d_words,
+                       c.d_start, c.d_len);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_temps(ctx);
+    ctx->chunks.push_back(c);
+    if (n_reads) *n_reads = n_rec;
+    if (consumed) *consumed = (virt && n_rec * 4 == n_nl + 1) ? n_bytes : cons;
+    return SMX_OK;
+}
+
+// page-locked host memory for the FASTQ chunks (hipHostMalloc): pageable buffers cap the upload at a fraction of the PCIe rate
+void *smx_pinned_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void smx_pinned_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int smx_submit_reads_device(smx_ctx *ctx, const void *d_words, uint64_t n_words, const void *d_start, const void *d_len,

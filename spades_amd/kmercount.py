@@ -43,6 +43,11 @@ class Context:
         self._h = h
         self.lib = lib
 
+    def reads_info(self):
+        n, b = C.c_uint64(), C.c_uint64()
+        _chk(self._h, self.lib.smx_reads_info(self._h, C.byref(n), C.byref(b)))
+        return n.value, b.value
+
     def set_option(self, key: str, value: int):
         _chk(self._h, self.lib.smx_set_option(self._h, key.encode(), int(value)))
 
@@ -104,6 +109,12 @@ class ReadKMerSplitter:
         _chk(self.ctx._h, self.ctx.lib.smx_submit_reads_packed(
             self.ctx._h, words.ctypes.data_as(C.POINTER(C.c_uint64)), len(words),
             start.ctypes.data_as(C.POINTER(C.c_uint64)), length.ctypes.data_as(C.POINTER(C.c_uint32)), len(start)))
+
+    def push_back_fastq_text(self, text: bytes, is_final: bool = True) -> int:
+        """Uncompressed 4-line FASTQ bytes, parsed on the device; returns the number of bytes consumed (complete records)."""
+        n, used = C.c_uint64(), C.c_uint64()
+        _chk(self.ctx._h, self.ctx.lib.smx_submit_fastq_text(self.ctx._h, text, len(text), 1 if is_final else 0, C.byref(n), C.byref(used)))
+        return used.value
 
     def push_back_binary(self, seq_path: str):
         """SPAdes binary reads (<prefix>.seq of io::ReadConverter::ConvertToBinary)."""

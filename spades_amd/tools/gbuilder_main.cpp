@@ -12,6 +12,14 @@
 
 #include "../../include/smx.h"
 #include "read_input.hpp"
+#include <chrono>
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define STAGE(what)                                                                 \
+    if (getenv("SMX_DEBUG")) {                                                      \
+        double t_ = now_s();                                                        \
+        fprintf(stderr, "[tool] %-12s %7.3f s\n", what, t_ - t_stage);             \
+        t_stage = t_;                                                               \
+    }
 
 int main(int argc, char **argv) {
     unsigned k = 21, nthreads = 1;
@@ -52,6 +60,7 @@ int main(int argc, char **argv) {
     if (k >= 128) { fprintf(stderr, "k-mer size %u is too high\n", k); return SMX_INVALID_PARAMETER; }
     if (k % 2 == 0) { fprintf(stderr, "k-mer size must be odd\n"); return SMX_INVALID_PARAMETER; }
     smx_ctx *ctx = nullptr;
+    double t_stage = now_s();
     if (int rc = smx_create(&ctx, 0, 0)) {
         fprintf(stderr, "No usable MI355X device (smx_create -> %d)\n", rc);
         return rc;
@@ -59,21 +68,16 @@ int main(int argc, char **argv) {
     printf("K-mer length set to %u\n", k);
     int rc = 0;
     try {
-        smxtool::ReadBatch batch;
-        bool ok = smxtool::for_each_sequence(file, [&](const std::string &s) {
-            batch.add(s);
-            if (batch.bases.size() > ((size_t)1 << 30) && !rc) {
-                rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
-                batch.clear();
-            }
-        });
-        if (!ok) {
+        STAGE("device init")
+        rc = smxtool::submit_file(ctx, file);
+        STAGE("read input")
+        if (rc == -1) {
             fprintf(stderr, "Dataset description file: %s does not exist or is not a valid YAML file\n", file.c_str());
             smx_destroy(ctx);
             return SMX_INPUT_FILE_NOT_FOUND;
         }
-        if (!rc) rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
         if (!rc) rc = smx_build_graph(ctx, k, 10 * nthreads);
+        STAGE("build graph")
         if (!rc && coverage && mode != UNITIGS) {
             printf("Filling coverage index\n");
             rc = smx_graph_fill_coverage(ctx);
@@ -87,6 +91,7 @@ int main(int argc, char **argv) {
             rc = mode == GFA ? smx_graph_write_gfa(ctx, outfile.c_str(), "SPAdes-4.3.0-dev")
                  : mode == SPADES ? smx_graph_write_spades(ctx, outfile.c_str())
                  : mode == FASTG ? smx_graph_write_fastg(ctx, outfile.c_str()) : smx_graph_write_unitigs(ctx, outfile.c_str());
+            STAGE("write output")
         }
         if (rc) fprintf(stderr, "%s\n", smx_last_error(ctx));
     } catch (const std::string &s) {

@@ -12,6 +12,14 @@
 
 #include "../../include/smx.h"
 #include "read_input.hpp"
+#include <chrono>
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define STAGE(what)                                                                 \
+    if (getenv("SMX_DEBUG")) {                                                      \
+        double t_ = now_s();                                                        \
+        fprintf(stderr, "[tool] %-12s %7.3f s\n", what, t_ - t_stage);             \
+        t_stage = t_;                                                               \
+    }
 
 static void usage(const char *a0) {
     printf("SYNOPSIS\n        %s [-k <value>] [-t <value>] [-w <dir>] [-b <value>] [-h] [<input files>...]\n\n"
@@ -55,6 +63,7 @@ int main(int argc, char **argv) {
         return SMX_INVALID_PARAMETER;
     }
     smx_ctx *ctx = nullptr;
+    double t_stage = now_s();
     if (int rc = smx_create(&ctx, 0, 0)) {
         fprintf(stderr, "No usable MI355X device (smx_create -> %d)\n", rc);
         return rc;
@@ -63,21 +72,14 @@ int main(int argc, char **argv) {
     try {
         for (const auto &file : input) {
             printf("Processing \"%s\"\n", file.c_str());
-            smxtool::ReadBatch batch;
-            int rc = 0;
-            bool ok = smxtool::for_each_sequence(file, [&](const std::string &s) {
-                batch.add(s);
-                if (batch.bases.size() > ((size_t)1 << 30) && !rc) {
-                    rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
-                    batch.clear();
-                }
-            });
-            if (!ok) {
+            STAGE("device init")
+            int rc = smxtool::submit_file(ctx, file);
+            STAGE("read input")
+            if (rc == -1) {
                 fprintf(stderr, "File %s doesn't exist or can't be read!\n", file.c_str());
                 smx_destroy(ctx);
                 return SMX_INPUT_FILE_NOT_FOUND;
             }
-            if (!rc) rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
             if (rc) throw std::string(smx_last_error(ctx));
         }
         if (int rc = smx_count(ctx, K, SMX_MODE_ALL, 16)) {  // 16 buckets: kmercount.cpp:220
@@ -85,6 +87,7 @@ int main(int argc, char **argv) {
             smx_destroy(ctx);
             return rc;
         }
+        STAGE("count")
         uint64_t n = 0;
         smx_count_info(ctx, &n, nullptr, nullptr);
         printf("K-mer counting done. There are %llu kmers in total.\n", (unsigned long long)n);
@@ -94,6 +97,7 @@ int main(int argc, char **argv) {
             smx_destroy(ctx);
             return rc;
         }
+        STAGE("write output")
         printf("K-mer counting done, kmers saved to \"%s\"\n", out.c_str());
     } catch (const std::string &s) {
         fprintf(stderr, "%s\n", s.c_str());

@@ -2,10 +2,14 @@
 // The reference keeps parsing on the CPU too (kseq + zlib-ng: common/io/reads/parser.cpp); only sequences are used here.
 // Reads are handed to the library in ASCII; smx_submit_reads_ascii applies the longest-ACGT-run rule.
 #pragma once
+#include "../../include/smx.h"
 #include <zlib.h>
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -104,6 +108,73 @@ bool for_each_sequence(const std::string &path, F cb) {
         throw std::string("unknown input format (neither FASTA nor FASTQ): ") + path;
     }
     return true;
+}
+
+// One input file -> library. Uncompressed 4-line FASTQ goes to HBM as raw bytes and is cut into reads on the device
+// (smx_submit_fastq_text: page-locked chunks, complete records only, the tail is carried over); everything else
+// (gzip, FASTA, multi-line FASTQ) takes the host parser above. Returns 0, an smx error code, or -1 when the file
+// cannot be opened; throws std::string on malformed input.
+inline int submit_file(smx_ctx *ctx, const std::string &path) {
+    size_t chunk_bytes = 0;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return -1;
+    unsigned char head[2] = {0, 0};
+    const size_t nh = fread(head, 1, 2, f);
+    const bool device_path = nh == 2 && head[0] == '@' && !getenv("SMX_HOST_PARSE");  // env: force the host parser (measurements)
+    if (device_path) {
+        fseek(f, 0, SEEK_END);
+        const long fsize = ftell(f);
+        rewind(f);
+        // page-locking memory costs ~0.3 s per GiB: take what the file needs, in 256 MiB chunks at most
+        chunk_bytes = std::min<size_t>((size_t)256 << 20, std::max<size_t>((size_t)(fsize > 0 ? fsize : 0) + 4096, (size_t)1 << 20));
+        char *buf = (char *)smx_pinned_alloc(chunk_bytes);
+        bool pinned = buf != nullptr;
+        if (!buf) buf = (char *)malloc(chunk_bytes);
+        size_t have = 0;
+        bool fallback = false, any = false;
+        int rc = 0;
+        for (;;) {
+            const size_t got = fread(buf + have, 1, chunk_bytes - have, f);
+            have += got;
+            const bool final_chunk = feof(f) != 0;
+            if (have == 0) break;
+            uint64_t n = 0, used = 0;
+            rc = smx_submit_fastq_text(ctx, buf, have, final_chunk ? 1 : 0, &n, &used);
+            if (rc == SMX_INVALID_INPUT_FORMAT && !any) {  // not strict 4-line FASTQ: nothing was submitted, let the host parser decide
+                fallback = true;
+                rc = 0;
+                break;
+            }
+            if (rc) break;
+            any = any || n > 0;
+            if (used == 0 && !final_chunk && have == chunk_bytes) {  // a single record larger than the chunk
+                fallback = !any;
+                if (!fallback) rc = SMX_INVALID_INPUT_FORMAT;
+                break;
+            }
+            memmove(buf, buf + used, have - used);
+            have -= used;
+            if (final_chunk) break;
+        }
+        if (pinned) smx_pinned_free(buf); else free(buf);
+        if (!fallback) {
+            fclose(f);
+            return rc;
+        }
+    }
+    fclose(f);
+    ReadBatch batch;
+    int rc = 0;
+    bool ok = for_each_sequence(path, [&](const std::string &s) {
+        batch.add(s);
+        if (batch.bases.size() > ((size_t)1 << 30) && !rc) {
+            rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
+            batch.clear();
+        }
+    });
+    if (!ok) return -1;
+    if (!rc) rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
+    return rc;
 }
 
 }  // namespace smxtool
