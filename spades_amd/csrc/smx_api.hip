@@ -72,6 +72,13 @@ struct smx_ctx {
     uint64_t g_nkpo = 0, g_nkmers = 0;
     unsigned g_k = 0, g_nw = 0, g_B = 0;
     std::vector<uint64_t> g_kboff, g_kpoboff;
+    // fine-bin offsets of the last pipeline run (rank lookups of the construction stage), kept when want_index is set
+    bool want_index = false;
+    unsigned long long *last_idx_off = nullptr;
+    uint64_t last_idx_bins = 0;
+    uint32_t last_idx_S1 = 1;
+    std::vector<uint32_t> last_idx_f;
+    smx::RankIndex g_ix_kmers{}, g_ix_kpo{};  // .off owned by the graph state
     bool g_ready = false;
     smxh::GraphHost gh;
 };
@@ -381,6 +388,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (ctx->opt_leaf_cap > 0) cap = (uint32_t)std::min<int64_t>(ctx->opt_leaf_cap, cap);
     const uint32_t cap1 = std::min<uint32_t>(Tune<NW>::CAP1, cap);
     const bool from_reads = d_recs == nullptr;
+    ctx->last_idx_bins = 0;
     clear_result(ctx);
     ctx->K = K;
     ctx->nw = NW;
@@ -716,6 +724,15 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
                        (const unsigned long long *)uoff, B, (uint32_t)(nb / B), bucket_off);
     HIPCHK(hipGetLastError());
     tend(ctx);
+    if (ctx->want_index) {
+        if (ctx->last_idx_off) arena_put(ctx, ctx->last_idx_off);
+        ctx->last_idx_off = nullptr;
+        if (int rc = dalloc(ctx, &ctx->last_idx_off, nb + 1, false)) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->last_idx_off, uoff, (size_t)(nb + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->last_idx_bins = nb;
+        ctx->last_idx_S1 = S1;
+        ctx->last_idx_f = lv;
+    }
     std::vector<unsigned long long> h(B + 1);
     HIPCHK(hipMemcpyAsync(h.data(), bucket_off, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1090,6 +1107,10 @@ void clear_graph(smx_ctx *ctx) {
         arena_put(ctx, ctx->g_kmers);
     }
     if (ctx->g_mask) arena_put(ctx, ctx->g_mask);
+    if (ctx->g_ix_kmers.off) arena_put(ctx, (void *)ctx->g_ix_kmers.off);
+    if (ctx->g_ix_kpo.off) arena_put(ctx, (void *)ctx->g_ix_kpo.off);
+    ctx->g_ix_kmers = smx::RankIndex{};
+    ctx->g_ix_kpo = smx::RankIndex{};
     ctx->g_kpo = ctx->g_kmers = nullptr;
     ctx->g_mask = nullptr;
     ctx->g_nkpo = ctx->g_nkmers = 0;
@@ -1144,9 +1165,42 @@ int device_sort_u64(smx_ctx *ctx, std::vector<uint64_t> &keys) {
     return rc;
 }
 
+// Adopt the fine-bin offsets of the pipeline run that just produced a sorted file as its lookup index (bucket offsets if the run
+// kept none).
+int take_rank_index(smx_ctx *ctx, smx::RankIndex &ix, unsigned K, uint32_t B) {
+    ix = smx::RankIndex{};
+    ix.B = B;
+    ix.K = K;
+    ix.S1 = 1;
+    if (ctx->last_idx_off && ctx->last_idx_bins) {
+        ix.off = ctx->last_idx_off;
+        ctx->last_idx_off = nullptr;
+        ix.S1 = ctx->last_idx_S1;
+        ix.nf = (uint32_t)std::min<size_t>(ctx->last_idx_f.size(), 6);
+        for (uint32_t i = 0; i < ix.nf; ++i) ix.f[i] = ctx->last_idx_f[i];
+        return 0;
+    }
+    unsigned long long *d;
+    if (int rc = dalloc(ctx, &d, B + 1, false)) return rc;
+    std::vector<unsigned long long> hb(ctx->bucket_off.begin(), ctx->bucket_off.end());
+    hb.resize(B + 1, hb.empty() ? 0 : hb.back());
+    HIPCHK(hipMemcpy(d, hb.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice));
+    ix.off = d;
+    return 0;
+}
+
 template <int NW>
 int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullptr, uint64_t n_kpo_recs = 0) {
     clear_graph(ctx);
+    struct IndexScope {  // the pipeline keeps its fine-bin offsets only while a graph is being built
+        smx_ctx *c;
+        explicit IndexScope(smx_ctx *c_) : c(c_) { c->want_index = true; }
+        ~IndexScope() {
+            c->want_index = false;
+            if (c->last_idx_off) arena_put(c, c->last_idx_off);
+            c->last_idx_off = nullptr;
+        }
+    } index_scope(ctx);
     WallTrace gwt;
     ctx->g_k = k;
     ctx->g_nw = NW;
@@ -1162,6 +1216,8 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     ctx->g_kpo = ctx->d_result_buf;
     ctx->g_nkpo = ctx->n_records;
     ctx->g_kpoboff = ctx->bucket_off;
+    if (ctx->n_records)
+        if (int rc = take_rank_index(ctx, ctx->g_ix_kpo, k + 1, B)) return rc;
     ctx->d_result_buf = ctx->d_result = nullptr;
     free_temps(ctx, ctx->g_kpo);
     const uint64_t nkpo = ctx->g_nkpo;
@@ -1187,6 +1243,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         ctx->g_kmers = ctx->d_result_buf;
         ctx->g_nkmers = ctx->n_records;
         ctx->g_kboff = ctx->bucket_off;
+        if (int rc = take_rank_index(ctx, ctx->g_ix_kmers, k, B)) return rc;
         ctx->d_result_buf = nullptr;
         ctx->d_result = ctx->g_kmers;  // smx_copy_final_kmers() now yields the k-mer file
         free_temps(ctx, ctx->g_kmers);
@@ -1196,22 +1253,15 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     if (D0 >= (1ull << 31)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%llu k-mers exceed the 2^31 node-id limit", (unsigned long long)D0);
     const unsigned grid = (unsigned)std::min<uint64_t>((2 * D0 + BLK - 1) / BLK, 1u << 16);
     // ---- 3. extension masks ---------------------------------------------------------------------
-    unsigned long long *d_boff;
     uint32_t *d_err;
-    if (int rc = dalloc(ctx, &d_boff, B + 1)) return rc;
     if (int rc = dalloc(ctx, &d_err, 1)) return rc;
     HIPCHK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
-    {
-        std::vector<unsigned long long> hb(ctx->g_kboff.begin(), ctx->g_kboff.end());
-        HIPCHK(hipMemcpyAsync(d_boff, hb.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
+    const smx::RankIndex ixk = ctx->g_ix_kmers;
     if (int rc = dalloc(ctx, &ctx->g_mask, (size_t)((D0 + 3) / 4 * 4 + 4), false)) return rc;
     HIPCHK(hipMemsetAsync(ctx->g_mask, 0, (size_t)((D0 + 3) / 4 * 4 + 4), ctx->stream));
     tbegin(ctx, "fill_masks");
     hipLaunchKernelGGL((k_fill_masks<NW>), dim3((unsigned)std::min<uint64_t>((nkpo + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
-                       (const void *)ctx->g_kpo, nkpo, k, (const void *)ctx->g_kmers, (const unsigned long long *)d_boff, B,
-                       (uint32_t *)ctx->g_mask, d_err);
+                       (const void *)ctx->g_kpo, nkpo, k, (const void *)ctx->g_kmers, ixk, (uint32_t *)ctx->g_mask, d_err);
     HIPCHK(hipGetLastError());
     tend(ctx);
     // ---- 4. successors + start de-edges -------------------------------------------------------
@@ -1221,8 +1271,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     if (int rc = dalloc(ctx, &ccnt, D0)) return rc;
     if (int rc = dalloc(ctx, &coff, D0 + 1)) return rc;
     tbegin(ctx, "succ");
-    hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k,
-                       (const unsigned long long *)d_boff, B, succ, d_err);
+    hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, succ, d_err);
     HIPCHK(hipGetLastError());
     tend(ctx);
     tbegin(ctx, "candidates");
@@ -1259,8 +1308,8 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         HIPCHK(hipGetLastError());
         tbegin(ctx, "walk_len");
         hipLaunchKernelGGL((k_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const uint32_t *)succ, k,
-                           (const unsigned long long *)d_boff, B, (uint64_t)(2 * D0 + 2), len, first, last, d_err);
+                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const uint32_t *)succ, k, ixk,
+                           (uint64_t)(2 * D0 + 2), len, first, last, d_err);
         HIPCHK(hipGetLastError());
         if (int rc = scan_u64(ctx, len, soff, C)) return rc;
         unsigned long long total = 0;
@@ -1395,17 +1444,16 @@ int run_coverage(smx_ctx *ctx) {
     uint64_t nwin = 0;
     if (int rc = mark_windows(ctx, K1, masks, &nwin)) return rc;
     uint32_t *cnt, *ecov;
-    unsigned long long *d_boff, *d_eoff;
+    unsigned long long *d_eoff;
     char *d_seq;
     if (int rc = dalloc(ctx, &cnt, D1)) return rc;
     if (int rc = dalloc(ctx, &ecov, ne)) return rc;
-    if (int rc = dalloc(ctx, &d_boff, B + 1)) return rc;
     if (int rc = dalloc(ctx, &d_eoff, ne + 1)) return rc;
     if (int rc = dalloc(ctx, &d_seq, ctx->gh.seq.size() + 1)) return rc;
     HIPCHK(hipMemsetAsync(cnt, 0, D1 * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ecov, 0, ne * 4, ctx->stream));
-    std::vector<unsigned long long> hb(ctx->g_kpoboff.begin(), ctx->g_kpoboff.end()), he(ctx->gh.eoff.begin(), ctx->gh.eoff.end());
-    HIPCHK(hipMemcpyAsync(d_boff, hb.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<unsigned long long> he(ctx->gh.eoff.begin(), ctx->gh.eoff.end());
+    const smx::RankIndex ixp = ctx->g_ix_kpo;
     HIPCHK(hipMemcpyAsync(d_eoff, he.data(), (ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_seq, ctx->gh.seq.data(), ctx->gh.seq.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1414,16 +1462,15 @@ int run_coverage(smx_ctx *ctx) {
         const ReadChunk &ch = ctx->chunks[ci];
         if (ch.n_bases == 0 || !masks[ci]) continue;
         hipLaunchKernelGGL((k_kpo_coverage<NW>), dim3((unsigned)std::min<uint64_t>((ch.n_bases + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0,
-                           ctx->stream, (const uint64_t *)ch.d_words, (const uint64_t *)masks[ci], ch.n_bases, K1, (const void *)ctx->g_kpo,
-                           (const unsigned long long *)d_boff, B, cnt);
+                           ctx->stream, (const uint64_t *)ch.d_words, (const uint64_t *)masks[ci], ch.n_bases, K1, (const void *)ctx->g_kpo, ixp, cnt);
         HIPCHK(hipGetLastError());
     }
     tend(ctx);
     tbegin(ctx, "edge_coverage");
     const uint64_t total = ctx->gh.seq.size();
     hipLaunchKernelGGL((k_edge_coverage<NW>), dim3((unsigned)std::min<uint64_t>((total + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
-                       (const char *)d_seq, (const unsigned long long *)d_eoff, ne, total, K1, (const void *)ctx->g_kpo,
-                       (const unsigned long long *)d_boff, B, (const uint32_t *)cnt, ecov);
+                       (const char *)d_seq, (const unsigned long long *)d_eoff, ne, total, K1, (const void *)ctx->g_kpo, ixp,
+                       (const uint32_t *)cnt, ecov);
     HIPCHK(hipGetLastError());
     tend(ctx);
     HIPCHK(hipMemcpyAsync(ctx->gh.ecov.data(), ecov, ne * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -55,12 +55,27 @@ __device__ __forceinline__ Rec<NW> rec_canon(const Rec<NW> &x, unsigned K, unsig
     is_rc = minimal ? 0u : 1u;
     return minimal ? x : y;
 }
-// rank of a canonical k-mer (KMerIndex::seq_idx stand-in, kmer_index.hpp:88-100): bucket by hash, binary search
+// Where to look for a k-mer in a sorted k-mer file: the offsets of the fine bins the counting pipeline sorted it by (bucket, then
+// the mixed-radix digits of the key fraction) — a few hundred records per bin — or, without them, just the bucket offsets.
+struct RankIndex {
+    const unsigned long long *off;  // [bins + 1]
+    uint32_t B, S1, nf, f[6];
+    unsigned K;
+};
+// rank of a canonical k-mer (KMerIndex::seq_idx stand-in, kmer_index.hpp:88-100): bucket by hash, bin by key digits, binary search
 template <int NW>
-__device__ __forceinline__ uint32_t kmer_rank(const Rec<NW> *__restrict__ kmers, const unsigned long long *__restrict__ boff,
-                                              uint32_t B, const Rec<NW> &canon) {
-    const uint32_t b = bucket_of(xxh3_rec<NW>(canon), B);
-    uint64_t lo = boff[b], hi = boff[b + 1];
+__device__ __forceinline__ uint32_t kmer_rank(const Rec<NW> *__restrict__ kmers, const RankIndex &ix, const Rec<NW> &canon) {
+    uint64_t bin = bucket_of(xxh3_rec<NW>(canon), ix.B);
+    uint64_t fr = key_top64<NW>(canon, ix.K);
+    if (ix.S1 > 1) {
+        bin = bin * ix.S1 + __umul64hi(fr, (uint64_t)ix.S1);
+        fr *= ix.S1;
+    }
+    for (uint32_t i = 0; i < ix.nf; ++i) {
+        bin = bin * ix.f[i] + __umul64hi(fr, (uint64_t)ix.f[i]);
+        fr *= ix.f[i];
+    }
+    uint64_t lo = ix.off[bin], hi = ix.off[bin + 1];
     const uint64_t end = hi;
     while (lo < hi) {
         uint64_t mid = (lo + hi) >> 1;
@@ -88,7 +103,7 @@ __global__ void __launch_bounds__(BLK) k_derive_kmers(const void *kpo_, uint64_t
 // a15: out[prefix] |= bit(x_k), in[suffix] |= bit(x_0), positions mirrored (7-p) for non-minimal keys
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_fill_masks(const void *kpo_, uint64_t n, unsigned k, const void *kmers_,
-                                                    const unsigned long long *boff, uint32_t B, uint32_t *mask32, uint32_t *err) {
+                                                    RankIndex ix, uint32_t *mask32, uint32_t *err) {
     const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
@@ -97,7 +112,7 @@ __global__ void __launch_bounds__(BLK) k_fill_masks(const void *kpo_, uint64_t n
         unsigned prc, src;
         Rec<NW> p = rec_canon<NW>(rec_prefix<NW>(x, k), k, prc);
         Rec<NW> s = rec_canon<NW>(rec_suffix<NW>(x), k, src);
-        uint32_t rp = kmer_rank<NW>(kmers, boff, B, p), rs = kmer_rank<NW>(kmers, boff, B, s);
+        uint32_t rp = kmer_rank<NW>(kmers, ix, p), rs = kmer_rank<NW>(kmers, ix, s);
         if (rp == NODE_NONE || rs == NODE_NONE) {
             atomicAdd(err, 1u);
             continue;
@@ -112,7 +127,7 @@ __global__ void __launch_bounds__(BLK) k_fill_masks(const void *kpo_, uint64_t n
 // successor of every non-junction node: GetOutgoing(kwh, GetUniqueOutgoing), debruijn_graph_constructor.hpp:228-235
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t *mask, uint64_t D0, unsigned k,
-                                              const unsigned long long *boff, uint32_t B, uint32_t *succ, uint32_t *err) {
+                                              RankIndex ix, uint32_t *succ, uint32_t *err) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
         const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
@@ -126,7 +141,7 @@ __global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t 
         if (o) x = rec_rc<NW>(x, k);
         unsigned yo;
         Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, __ffs(mo & 15) - 1), k, yo);
-        uint32_t ry = kmer_rank<NW>(kmers, boff, B, y);
+        uint32_t ry = kmer_rank<NW>(kmers, ix, y);
         if (ry == NODE_NONE) atomicAdd(err, 1u);
         succ[node] = ry == NODE_NONE ? NODE_NONE : (ry << 1) | yo;
     }
@@ -155,7 +170,7 @@ __global__ void k_cand_expand(const uint8_t *mask, const unsigned long long *can
 // ConstructSequenceWithEdge (:264-273), pass 1: length and end node of every start de-edge
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_walk_len(const unsigned long long *cand, uint64_t C, const void *kmers_, const uint8_t *mask,
-                                                  const uint32_t *succ, unsigned k, const unsigned long long *boff, uint32_t B,
+                                                  const uint32_t *succ, unsigned k, RankIndex ix,
                                                   uint64_t max_steps, unsigned long long *len, uint32_t *first, uint32_t *last,
                                                   uint32_t *err) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
@@ -166,7 +181,7 @@ __global__ void __launch_bounds__(BLK) k_walk_len(const unsigned long long *cand
         if (side) x = rec_rc<NW>(x, k);
         unsigned yo;
         Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-        uint32_t ry = kmer_rank<NW>(kmers, boff, B, y);
+        uint32_t ry = kmer_rank<NW>(kmers, ix, y);
         if (ry == NODE_NONE) {
             atomicAdd(err, 1u);
             len[i] = 0;
@@ -278,7 +293,7 @@ __global__ void k_gather_kmers(const void *kmers_, const uint32_t *list, uint32_
 // complement (both strand instances are minimal then).
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_kpo_coverage(const uint64_t *seq, const uint64_t *mask, uint64_t G, unsigned K1,
-                                                      const void *kpo_, const unsigned long long *boff, uint32_t B, uint32_t *cnt) {
+                                                      const void *kpo_, RankIndex ix, uint32_t *cnt) {
     const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
     for (uint64_t g = (uint64_t)blockIdx.x * BLK + threadIdx.x; g < G; g += (uint64_t)gridDim.x * BLK) {
         if (!((mask[g >> 6] >> (g & 63)) & 1)) continue;
@@ -286,7 +301,7 @@ __global__ void __launch_bounds__(BLK) k_kpo_coverage(const uint64_t *seq, const
         Rec<NW> y = rec_rc<NW>(x, K1);
         const bool pal = rec_eq<NW>(x, y);
         const Rec<NW> c = rc_ge<NW>(y, x) ? x : y;
-        const uint32_t r = kmer_rank<NW>(kpo, boff, B, c);
+        const uint32_t r = kmer_rank<NW>(kpo, ix, c);
         if (r != NODE_NONE) atomicAdd(&cnt[r], pal ? 2u : 1u);
     }
 }
@@ -294,7 +309,7 @@ __global__ void __launch_bounds__(BLK) k_kpo_coverage(const uint64_t *seq, const
 // edge raw coverage = sum of the counters of the edge's (k+1)-mers (graph_support/coverage_filling.hpp:46-62), uint32
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_edge_coverage(const char *seq, const unsigned long long *eoff, uint64_t n_edges, uint64_t total,
-                                                       unsigned K1, const void *kpo_, const unsigned long long *boff, uint32_t B,
+                                                       unsigned K1, const void *kpo_, RankIndex ix,
                                                        const uint32_t *cnt, uint32_t *ecov) {
     const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
     for (uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x; p < total; p += (uint64_t)gridDim.x * BLK) {
@@ -314,7 +329,7 @@ __global__ void __launch_bounds__(BLK) k_edge_coverage(const char *seq, const un
         }
         unsigned f;
         const Rec<NW> c = rec_canon<NW>(x, K1, f);
-        const uint32_t r = kmer_rank<NW>(kpo, boff, B, c);
+        const uint32_t r = kmer_rank<NW>(kpo, ix, c);
         if (r != NODE_NONE) atomicAdd(&ecov[lo], cnt[r]);
     }
 }
