@@ -59,8 +59,10 @@ def synth_reads_device(seed, genome_len, n_reads, dev, err=0.01, genome_seed=2):
     return words, start, ln, codes
 
 
-def cpu_baseline(codes_sample, K, mode, nb):
-    """Reference classes (kind 'reference') when oracle/_ref exists, else the C port (kind 'port')."""
+def cpu_baseline(codes_sample, K, mode, nb, gpu_result=None):
+    """Reference classes (kind 'reference') when oracle/_ref exists, else the C port (kind 'port').
+    gpu_result(n) -> (device int64 tensor [D, nw], bucket sizes) of the GPU count of the same first n reads: when given, the
+    reference's output file is compared with it byte for byte (the checker role of oracle/_ref)."""
     import numpy as np
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     arr = lut[codes_sample.cpu().numpy()]
@@ -76,8 +78,25 @@ def cpu_baseline(codes_sample, K, mode, nb):
             subprocess.check_call([ref, mode, str(K), str(nb), "0", rf, os.path.join(td, "wd"), os.path.join(td, "out"), str(cores)],
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             dt = time.time() - t0
-        return {"value": round(n / dt / 1e6, 4), "unit": "M reads/s", "cores": cores, "kind": "reference",
-                "sample": f"first {n} reads of the bench batch, oracle/_ref/ref_kmercount (reference KMerDiskCounter, tmpfs workdir), {dt:.1f} s"}
+            parity = None
+            if gpu_result is not None:
+                import torch
+                rec = gpu_result(n).reshape(-1)  # int64 words on the device, the GPU's final_kmers of the same reads
+                out = os.path.join(td, "out")
+                same = os.path.getsize(out) == rec.numel() * 8
+                CH = 1 << 25  # words per compared chunk (256 MiB)
+                with open(out, "rb") as f:
+                    for c0 in range(0, rec.numel(), CH):
+                        if not same:
+                            break
+                        ref_chunk = torch.from_numpy(np.fromfile(f, dtype=np.int64, count=min(CH, rec.numel() - c0))).to(rec.device)
+                        same = bool(torch.equal(ref_chunk, rec[c0:c0 + ref_chunk.numel()]))
+                parity = {"bit_identical_to_reference_output": same, "compared_bytes": int(rec.numel() * 8)}
+        res = {"value": round(n / dt / 1e6, 4), "unit": "M reads/s", "cores": cores, "kind": "reference",
+               "sample": f"first {n} reads of the bench batch, oracle/_ref/ref_kmercount (reference KMerDiskCounter, tmpfs workdir), {dt:.1f} s"}
+        if parity:
+            res.update(parity)
+        return res
     from oracle import oracle
     reads = [r.tobytes().decode() for r in arr[:50000]]
     t0 = time.time()
@@ -227,7 +246,15 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_sharded:
-        out["cpu_baseline"] = cpu_baseline(sample, K, args.mode, nb)
+        def gpu_result(n):  # GPU count of the first n reads of the batch (they are the first n*L bases of the stream)
+            class Wrap:
+                def __init__(self, ptr, shape):
+                    self.__cuda_array_interface__ = {"shape": shape, "typestr": "<i8", "data": (ptr, False), "version": 2}
+            sp.clear()
+            sp.push_back_device(words.data_ptr(), n * L // 32, start.data_ptr(), ln.data_ptr(), n)
+            stn = counter.Count(nb)
+            return torch.as_tensor(Wrap(stn.device_ptr(), (stn.total_kmers(), nw)), device=dev)
+        out["cpu_baseline"] = cpu_baseline(sample, K, args.mode, nb, gpu_result if sample.shape[0] % 32 == 0 else None)
     if rank == 0 and world == 1 and args.construct_reads > 0 and not args.force_sharded:
         # BASELINE.json config 3 in small: count + construct + coverage on the first reads of the same batch (reported, not the metric)
         from spades_amd.gbuilder import GraphBuilder
