@@ -52,6 +52,7 @@ struct smx_ctx {
     // tuning / test hooks
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;
+    int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
     int64_t opt_tag_scatter = 0;  // level-1 scatter from records staging 16-bit tags instead of records: measured slower (9.1 vs 7.4 ms)
     int64_t opt_joint_hist = 1;  // fuse the level-2 histogram into the level-1 histogram pass (records source)
     int64_t opt_prededupe = -1;  // super-k-mer pre-deduplication: -1 auto, 0 off, 1 on whenever K allows it
@@ -1165,6 +1166,111 @@ int device_sort_u64(smx_ctx *ctx, std::vector<uint64_t> &keys) {
     return rc;
 }
 
+// Sort + unique 64-bit keys that are already in HBM (left-aligned) with the counting pipeline (one bucket, K = 32 so that the whole
+// word is the key). *out points into the temp list (valid until free_temps); the count-result view of the context is preserved.
+int device_sort_keys_dev(smx_ctx *ctx, void *d_keys, uint64_t n, unsigned long long **out, uint64_t *n_out) {
+    void *sv_res = ctx->d_result;
+    const uint64_t sv_n = ctx->n_records, sv_inst = ctx->n_instances;
+    const unsigned sv_nw = ctx->nw, sv_K = ctx->K, sv_B = ctx->num_buckets;
+    std::vector<uint64_t> sv_boff = ctx->bucket_off;
+    const bool sv_want = ctx->want_index;
+    ctx->want_index = false;
+    ctx->d_result = nullptr;  // non-owning view; d_result_buf is null here
+    int rc = run_count<1>(ctx, 32, SMX_MODE_ALL, 1, d_keys, n, nullptr, /*recs_reusable=*/true);
+    *out = (unsigned long long *)ctx->d_result_buf;
+    *n_out = ctx->n_records;
+    ctx->d_result_buf = nullptr;  // the result block stays in the temp list
+    ctx->d_result = sv_res;
+    ctx->n_records = sv_n;
+    ctx->n_instances = sv_inst;
+    ctx->nw = sv_nw;
+    ctx->K = sv_K;
+    ctx->num_buckets = sv_B;
+    ctx->bucket_off = sv_boff;
+    ctx->want_index = sv_want;
+    return rc;
+}
+
+// Link records and vertices of the graph on the device; fills g.recs / g.vstart / g.n_vertices exactly like smxh::build_links.
+// Returns 1 when the sizes do not fit the packed keys (the caller then takes the host path).
+int device_build_links(smx_ctx *ctx, smxh::GraphHost &g, uint64_t n_ranks) {
+    const uint64_t ne = g.n_edges();
+    if (ne == 0 || (ne < (1u << 16) && ctx->opt_device_links < 2) || ne >= (1ull << 29) || n_ranks >= (1ull << 31)) return 1;
+    uint32_t *estart, *eend;
+    uint8_t *eself;
+    unsigned long long *keys, *sorted = nullptr, *one, *vidx;
+    if (int rc = dalloc(ctx, &estart, ne)) return rc;
+    if (int rc = dalloc(ctx, &eend, ne)) return rc;
+    if (int rc = dalloc(ctx, &eself, ne)) return rc;
+    if (int rc = dalloc(ctx, &keys, 2 * ne)) return rc;
+    HIPCHK(hipMemcpyAsync(estart, g.estart.data(), ne * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(eend, g.eend.data(), ne * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(eself, g.eself.data(), ne, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t maxkey = ((n_ranks ? n_ranks - 1 : 0) << 33) | ((1ull << 33) - 1);
+    const unsigned sh = (unsigned)__builtin_clzll(maxkey | 1);
+    const unsigned g1 = (unsigned)std::min<uint64_t>((ne + BLK - 1) / BLK, 1u << 16);
+    hipLaunchKernelGGL(k_link_keys, dim3(g1), dim3(BLK), 0, ctx->stream, (const uint32_t *)estart, (const uint32_t *)eend, (const uint8_t *)eself, ne, sh,
+                       keys);
+    HIPCHK(hipGetLastError());
+    uint64_t nrec = 0;
+    if (int rc = device_sort_keys_dev(ctx, keys, 2 * ne, &sorted, &nrec)) return rc;
+    uint64_t nself = 0;
+    for (uint8_t f : g.eself) nself += f;
+    if (nrec != 2 * ne - nself) return fail(ctx, SMX_DEVICE_ERROR, "link records: %llu after sort, expected %llu", (unsigned long long)nrec,
+                                            (unsigned long long)(2 * ne - nself));
+    if (int rc = dalloc(ctx, &one, nrec)) return rc;
+    if (int rc = dalloc(ctx, &vidx, nrec + 1)) return rc;
+    const unsigned g2 = (unsigned)std::min<uint64_t>((nrec + BLK - 1) / BLK, 1u << 16);
+    hipLaunchKernelGGL(k_vertex_flags, dim3(g2), dim3(BLK), 0, ctx->stream, sorted, nrec, sh, one);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_unshift, dim3(g2), dim3(BLK), 0, ctx->stream, sorted, nrec, sh);
+    HIPCHK(hipGetLastError());
+    if (int rc = scan_u64(ctx, one, vidx, nrec)) return rc;
+    unsigned long long nv = 0;
+    HIPCHK(hipMemcpyAsync(&nv, vidx + nrec, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (nv >= (1ull << 31)) return 1;
+    unsigned long long *vpos, *vkeys, *vsorted = nullptr, *vstart;
+    if (int rc = dalloc(ctx, &vpos, nv + 1)) return rc;
+    if (int rc = dalloc(ctx, &vkeys, nv + 1)) return rc;
+    if (int rc = dalloc(ctx, &vstart, nv + 1)) return rc;
+    const uint64_t maxv = (((((3 + 2 * ne) << 2) | 3ull) << 31) | ((1ull << 31) - 1));
+    const unsigned sh2 = (unsigned)__builtin_clzll(maxv | 1);
+    hipLaunchKernelGGL(k_vertex_collect, dim3(g2), dim3(BLK), 0, ctx->stream, (const unsigned long long *)sorted, (const unsigned long long *)one,
+                       (const unsigned long long *)vidx, nrec, sh2, vpos, vkeys);
+    HIPCHK(hipGetLastError());
+    // the keys of the records are needed after the second sort: copy them out first (the pipeline reuses the arena)
+    std::vector<uint64_t> hkeys(nrec);
+    HIPCHK(hipMemcpyAsync(hkeys.data(), sorted, nrec * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint64_t nv2 = 0;
+    if (nv >= (1u << 16) || ctx->opt_device_links >= 2) {
+        if (int rc = device_sort_keys_dev(ctx, vkeys, nv, &vsorted, &nv2)) return rc;
+        if (nv2 != nv) return fail(ctx, SMX_DEVICE_ERROR, "vertex keys are not distinct");
+    } else {
+        std::vector<uint64_t> hv(nv);
+        HIPCHK(hipMemcpy(hv.data(), vkeys, nv * 8, hipMemcpyDeviceToHost));
+        smxh::radix_sort_u64(hv);
+        HIPCHK(hipMemcpy(vkeys, hv.data(), nv * 8, hipMemcpyHostToDevice));
+        vsorted = vkeys;
+    }
+    hipLaunchKernelGGL(k_vertex_permute, dim3((unsigned)std::min<uint64_t>((nv + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
+                       (const unsigned long long *)vsorted, (const unsigned long long *)vpos, (uint64_t)nv, sh2, vstart);
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned long long> hvs(nv);
+    HIPCHK(hipMemcpyAsync(hvs.data(), vstart, nv * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    g.recs.resize(2 * ne);
+    for (size_t i = 0; i < nrec; ++i) {
+        const uint64_t e = hkeys[i] & ((1ull << 33) - 1);
+        g.recs[i] = {((hkeys[i] >> 33) << 2) | (e & 3), e >> 2};
+    }
+    for (size_t i = nrec; i < 2 * ne; ++i) g.recs[i] = {~0ull, 0};
+    g.vstart.assign(hvs.begin(), hvs.end());
+    g.n_vertices = nv;
+    return 0;
+}
+
 // Adopt the fine-bin offsets of the pipeline run that just produced a sorted file as its lookup index (bucket offsets if the run
 // kept none).
 int take_rank_index(smx_ctx *ctx, smx::RankIndex &ix, unsigned K, uint32_t B) {
@@ -1422,12 +1528,17 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     gwt.mark(ctx, "g:loops");
     if (ctx->opt_sort_edges) smxh::sort_edges_raw(ctx->gh);
     free_temps(ctx);  // walk buffers are no longer needed; the link sort reuses the arena
-    int sort_rc = 0;
-    smxh::build_links(ctx->gh, [&](std::vector<uint64_t> &keys) {
-        if (!sort_rc) sort_rc = device_sort_u64(ctx, keys);
-        if (sort_rc) smxh::radix_sort_u64(keys);
-    });
-    if (sort_rc) return sort_rc;
+    int lrc = ctx->opt_device_links ? device_build_links(ctx, ctx->gh, D0) : 1;
+    free_temps(ctx);
+    if (lrc > 1) return lrc;
+    if (lrc == 1) {  // small graphs, or sizes beyond the packed keys: host link records with the device (or host) key sort
+        int sort_rc = 0;
+        smxh::build_links(ctx->gh, [&](std::vector<uint64_t> &keys) {
+            if (!sort_rc) sort_rc = device_sort_u64(ctx, keys);
+            if (sort_rc) smxh::radix_sort_u64(keys);
+        });
+        if (sort_rc) return sort_rc;
+    }
     gwt.mark(ctx, "g:links");
     ctx->g_ready = true;
     return 0;
@@ -1537,6 +1648,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "leaf_tab")) ctx->opt_leaf_tab = value;
     else if (!strcmp(key, "prededupe")) ctx->opt_prededupe = value;
     else if (!strcmp(key, "joint_hist")) ctx->opt_joint_hist = value;
+    else if (!strcmp(key, "device_links")) ctx->opt_device_links = value;
     else if (!strcmp(key, "tag_scatter")) ctx->opt_tag_scatter = value;
     else if (!strcmp(key, "skm_cap")) ctx->opt_skm_cap = value;
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;

@@ -286,6 +286,48 @@ __global__ void k_gather_kmers(const void *kmers_, const uint32_t *list, uint32_
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = kmers[list[i]];
 }
 
+// ---- link records + vertices on the device (FastGraphFromSequencesConstructor::ConstructGraph, debruijn_graph_constructor.hpp:506-567) ----
+// Record key = rank << 33 | EdgeAndMask (edge id << 2 | rc << 1 | is_start), left-shifted by sh so that the MSD digits of the
+// sorting pipeline see a spread-out fraction. The end record of a self-conjugate edge does not exist (LinkRecord() is invalid): it is
+// emitted as a copy of the start record, which the sort + unique pipeline drops.
+__global__ void k_link_keys(const uint32_t *estart, const uint32_t *eend, const uint8_t *eself, uint64_t ne, unsigned sh,
+                            unsigned long long *keys) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t edge = 3 + 2 * i;
+        const uint32_t s = estart[i], e = eend[i];
+        const unsigned long long ks = ((uint64_t)(s >> 1) << 33) | (edge << 2) | ((uint64_t)(s & 1) << 1) | 1ull;
+        const unsigned long long ke = ((uint64_t)(e >> 1) << 33) | (edge << 2) | ((uint64_t)(e & 1) << 1);
+        keys[2 * i] = ks << sh;
+        keys[2 * i + 1] = (eself[i] ? ks : ke) << sh;
+    }
+}
+// sorted keys (still shifted): un-shift in place; one[i] = 1 where a new rank (vertex) starts
+__global__ void k_vertex_flags(unsigned long long *keys, uint64_t n, unsigned sh, unsigned long long *one) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[i] >> sh;
+        const unsigned long long p = i ? keys[i - 1] >> sh : ~0ull;
+        one[i] = (i == 0 || (k >> 33) != (p >> 33)) ? 1ull : 0ull;
+    }
+}
+__global__ void k_unshift(unsigned long long *keys, uint64_t n, unsigned sh) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) keys[i] >>= sh;
+}
+// vertex v = the run of records starting at position i: vpos[v] = i, vkey[v] = smallest EdgeAndMask of the vertex << 31 | v (shifted)
+__global__ void k_vertex_collect(const unsigned long long *keys, const unsigned long long *one, const unsigned long long *vidx, uint64_t n,
+                                 unsigned sh2, unsigned long long *vpos, unsigned long long *vkeys) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (!one[i]) continue;
+        const unsigned long long v = vidx[i];
+        vpos[v] = i;
+        vkeys[v] = (((keys[i] & ((1ull << 33) - 1)) << 31) | v) << sh2;
+    }
+}
+__global__ void k_vertex_permute(const unsigned long long *vkeys_sorted, const unsigned long long *vpos, uint64_t nv, unsigned sh2,
+                                 unsigned long long *vstart) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nv; j += (uint64_t)gridDim.x * blockDim.x)
+        vstart[j] = vpos[(vkeys_sorted[j] >> sh2) & ((1ull << 31) - 1)];
+}
+
 // ---- coverage (-c) -----------------------------------------------------------------------------------------------
 // CoverageHashMapBuilder::FillCoverageFromStream (kmer_index/ph_map/coverage_hash_map_builder.hpp:18-39): every
 // (k+1)-mer instance of the read+RC stream whose orientation is minimal increments the counter of its canonical

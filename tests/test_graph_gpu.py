@@ -187,3 +187,14 @@ def test_unitigs_fasta_and_errors(tmp_path):
     with pytest.raises(SmxError) as e:
         bad.build()
     assert e.value.code == 67  # "k-mer size must be odd" -> InvalidParameter (gbuilder.cpp:134-135)
+
+
+DCASES = [c for c in load_manifest()["cases"] if c["kind"] == "graph" and c["file"]]
+
+
+@pytest.mark.parametrize("case", DCASES, ids=lambda c: f"{c['reads'][6:-4]}-k{c['K']}-t{c['threads']}")
+def test_gfa_with_link_records_built_on_the_device(case, tmp_path):
+    """device_links=2 forces the device link-record / vertex path (normally taken from 65 536 edges up) on the small goldens"""
+    reads = [r for r in read_lines(case["reads"]) if r]
+    r = _build(reads, case["K"], case["threads"], tmp_path, {"device_links": 2})
+    assert r["gfa"] == open(os.path.join(GOLDEN, case["file"])).read()

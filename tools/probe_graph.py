@@ -31,4 +31,8 @@ tm = gb.ctx.timings()
 print(f"reads={2*n_pairs} k={k} kpomers={info['n_kpomers']} kmers={info['n_kmers']} unitigs={info['n_unitigs']} loops={info['n_loops']} vertices={info['n_vertices']} wall={t1-t0:.3f}s")
 print("   " + " ".join(f"{n}={ms:.1f}" for n, ms in tm))
 t0 = time.time(); gb.write_gfa("/tmp/full.gfa"); t2 = time.time() - t0
-print(f"   gfa write {t2:.2f}s size={os.path.getsize('/tmp/full.gfa')/1e6:.1f} MB links={gb.info()['n_links']}")
+h = hashlib.md5()
+with open("/tmp/full.gfa", "rb") as f:
+    for blk in iter(lambda: f.read(1 << 24), b""):
+        h.update(blk)
+print(f"   gfa write {t2:.2f}s size={os.path.getsize('/tmp/full.gfa')/1e6:.1f} MB links={gb.info()['n_links']} md5={h.hexdigest()}")
