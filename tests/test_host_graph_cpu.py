@@ -79,3 +79,15 @@ def test_unitig_fasta_and_sorted_variant(tmp_path):
     out = str(tmp_path / "s.gfa")
     _write(g["unitigs"], 21, 1, out, sort_edges=1)  # host-side RawCompare sort of the gbuilder-ordered unitigs
     assert open(out).read() == gs["gfa"]
+
+
+@pytest.mark.parametrize("grain", ["3", "50"])
+def test_gfa_writer_blocks_on_several_threads(grain, tmp_path, monkeypatch):
+    """SMX_WRITE_GRAIN forces the block-parallel formatting path (normally used from 262 144 segments up) on a golden"""
+    monkeypatch.setenv("SMX_WRITE_GRAIN", grain)
+    case = [c for c in load_manifest()["cases"] if c["kind"] == "graph" and c["file"] == "graph_small_k21_t3.gfa"][0]
+    reads = [r for r in read_lines(case["reads"]) if r]
+    g = oracle.build_graph(reads, case["K"], case["num_buckets"])
+    out = str(tmp_path / "g.gfa")
+    _write(g["unitigs"], case["K"], 1, out)
+    assert open(out).read() == open(os.path.join(GOLDEN, case["file"])).read()
