@@ -812,10 +812,27 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
                     hp[8 * ph + 3] ? (double)hp[8 * ph + 2] / hp[8 * ph + 3] : 0.0);
     }
     if (int rc = dalloc(ctx, out, nwin + 1)) return rc;
+    // Chunk capacity of the LDS hash set: every copy of a k-mer sits in ONE partition, and a partition that does not fit a chunk is
+    // cut (its survivors need a unique pass of their own). The partition a typical super-k-mer lives in holds sum(c^2)/sum(c) slots —
+    // one genomic locus at coverage 30 is ~46 slots = ~860 instances; deeper coverage grows it linearly. 2048 instances is the fastest
+    // geometry (4 workgroups per CU; 1024: 17.7 ms, 4096: 14.0 ms, 2048: 9.6 ms at bench scale); larger only when the data need it.
     uint32_t cap = 2048;
     if (ctx->opt_skm_cap > 0) {
         cap = 512;
         while (cap < (uint32_t)std::min<int64_t>(ctx->opt_skm_cap, 8192)) cap <<= 1;
+    } else if (nslots) {
+        unsigned long long *sums;
+        if (int rc = dalloc(ctx, &sums, 2)) return rc;
+        HIPCHK(hipMemsetAsync(sums, 0, 16, ctx->stream));
+        hipLaunchKernelGGL(k_skm_moments, dim3(1024), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cnt, SKM_NKEY, sums);
+        HIPCHK(hipGetLastError());
+        unsigned long long hs[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(hs, sums, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const double typical_slots = hs[0] ? (double)hs[1] / (double)hs[0] : 0.0;
+        const double typical_inst = typical_slots * (double)nwin / (double)nslots;
+        while (cap < 8192 && typical_inst * 1.6 > cap) cap <<= 1;
+        if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] prededupe: typical partition %.0f slots = %.0f instances -> chunk capacity %u\n", typical_slots, typical_inst, cap);
     }
     const uint32_t T = 2 * cap;
     const uint32_t scap = std::min<uint32_t>(SKM_SCAP, ctx->opt_skm_scap > 0 ? (uint32_t)ctx->opt_skm_scap : cap / 8);  // ~12+ windows per slot on average

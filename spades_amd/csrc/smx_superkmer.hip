@@ -270,6 +270,24 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
 #undef SKM_T
 }
 
+// sum and sum of squares of the per-partition slot counts: sum2 / sum = the partition size a random super-k-mer lives in
+__global__ void __launch_bounds__(BLK) k_skm_moments(const unsigned long long *__restrict__ cnt, uint32_t n, unsigned long long *sums) {
+    __shared__ unsigned long long scratch[BLK / 64 + 2];
+    unsigned long long s1 = 0, s2 = 0;
+    for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+        const unsigned long long c = cnt[i];
+        s1 += c;
+        s2 += c * c;
+    }
+    unsigned long long t1, t2;
+    block_excl_scan<unsigned long long>(s1, scratch, &t1);
+    block_excl_scan<unsigned long long>(s2, scratch, &t2);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], t1);
+        atomicAdd(&sums[1], t2);
+    }
+}
+
 // k-mer number j of a staged slot
 template <int NW>
 __device__ __forceinline__ Rec<NW> skm_extract(const uint64_t *s, unsigned j, unsigned K) {

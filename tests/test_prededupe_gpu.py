@@ -88,3 +88,14 @@ def test_palindromes_reach_the_distinct_leaf_kernel(K):
     ref, rs = oracle.count(reads, K, "A", 16)
     rec, sizes = _count(reads, K, "A", 16, {"prededupe": 1, "s1": 2, "s2": 0})
     assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
+
+
+@pytest.mark.parametrize("K,mode", [(55, "A"), (56, "B"), (21, "A")])
+def test_deep_coverage_picks_a_larger_chunk(K, mode):
+    """~300x coverage of a 2 kbp genome: one minimizer partition holds thousands of instances; the stage sizes its LDS chunks from
+    the partition-size moments (and whatever is still cut goes through the extra unique pass)."""
+    from oracle import oracle
+    reads = _synth(77, 2000, 4000, 150, err=0.002, nrate=0.0)
+    ref, rs = oracle.count(reads, K, mode, 16)
+    rec, sizes = _count(reads, K, mode, 16, ON)
+    assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
