@@ -52,6 +52,7 @@ struct smx_ctx {
     // tuning / test hooks
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;
+    int64_t opt_skm_stage = 1;     // pass 0 of the super-k-mer scan stages its output so that placing it needs no second scan
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
     int64_t opt_tag_scatter = 0;  // level-1 scatter from records staging 16-bit tags instead of records: measured slower (9.1 vs 7.4 ms)
     int64_t opt_joint_hist = 1;  // fuse the level-2 histogram into the level-1 histogram pass (records source)
@@ -786,13 +787,29 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         }
         return 0;
     };
+    // staging area for the super-k-mers of pass 0 (scan order): expected 2/(w+1) starts per window, 1.5x + slack; an overflow (flag)
+    // only costs the second scan of the reads
+    unsigned long long *st_alloc = nullptr;
+    // (short runs — K < 35, w < 16 windows — make placing atomics-bound either way and the staging round trip a loss: K=21 17.9 vs 14.4 ms)
+    if (ctx->opt_skm_stage >= 2 || (ctx->opt_skm_stage == 1 && a.w >= 16)) {
+        const uint64_t blocks = 256 * 16;
+        a.stage_cap = (uint64_t)((double)nwin * 3.0 / (double)(a.w + 1)) + blocks * 4096 + 4096;
+        if (ctx->opt_skm_stage == 2) a.stage_cap = 4096;  // tests: force the overflow fallback
+        if (int rc = dalloc(ctx, &a.stage_slots, (size_t)a.stage_cap * SW)) return rc;
+        if (int rc = dalloc(ctx, &a.stage_part, (size_t)a.stage_cap)) return rc;
+        if (int rc = dalloc(ctx, &st_alloc, 2)) return rc;
+        HIPCHK(hipMemsetAsync(a.stage_part, 0xFF, (size_t)a.stage_cap * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(st_alloc, 0, 16, ctx->stream));
+        a.stage_alloc = st_alloc;
+    }
     tbegin(ctx, "skm_count");
     if (int rc = pass(0)) return rc;
     tend(ctx);
     tbegin(ctx, "skm_scan");
     if (int rc = scan_u64(ctx, cnt, soff, SKM_NKEY)) return rc;
-    unsigned long long nslots = 0;
+    unsigned long long nslots = 0, st[2] = {0, 1};
     HIPCHK(hipMemcpyAsync(&nslots, soff + SKM_NKEY, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (st_alloc) HIPCHK(hipMemcpyAsync(st, st_alloc, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     tend(ctx);
     uint64_t *slots;
@@ -801,7 +818,17 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     a.cursor = cursor;
     a.slots = slots;
     tbegin(ctx, "skm_scatter");
-    if (int rc = pass(1)) return rc;
+    if (st_alloc && st[1] == 0) {  // place the staged super-k-mers
+        const uint64_t n_stage = std::min<uint64_t>(st[0], a.stage_cap);
+        if (n_stage) {
+            hipLaunchKernelGGL((k_skm_permute<NW>), dim3((unsigned)std::min<uint64_t>((n_stage + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
+                               (const uint64_t *)a.stage_slots, (const uint32_t *)a.stage_part, n_stage, cursor, slots);
+            HIPCHK(hipGetLastError());
+        }
+    } else {
+        a.stage_slots = nullptr;
+        if (int rc = pass(1)) return rc;
+    }
     tend(ctx);
     if (a.prof) {
         unsigned long long hp[16];
@@ -1666,6 +1693,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "prededupe")) ctx->opt_prededupe = value;
     else if (!strcmp(key, "joint_hist")) ctx->opt_joint_hist = value;
     else if (!strcmp(key, "device_links")) ctx->opt_device_links = value;
+    else if (!strcmp(key, "skm_stage")) ctx->opt_skm_stage = value;
     else if (!strcmp(key, "tag_scatter")) ctx->opt_tag_scatter = value;
     else if (!strcmp(key, "skm_cap")) ctx->opt_skm_cap = value;
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;

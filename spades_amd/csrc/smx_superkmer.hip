@@ -40,6 +40,12 @@ struct SkmArgs {
     unsigned long long *cursor;          // [NKEY] next free slot of every key, starts at its offset (phase 1)
     uint64_t *slots;
     unsigned long long *prof;            // SMX_DEBUG: ticks per phase
+    // phase 0 with staging: the super-k-mers are also written out in scan order (dense, coalesced) together with their partition,
+    // so that placing them (k_skm_permute) does not have to scan the reads a second time
+    uint64_t *stage_slots;               // [stage_cap * SW] or nullptr
+    uint32_t *stage_part;                // [stage_cap], preset to 0xFFFFFFFF (= unused entry)
+    unsigned long long stage_cap;
+    unsigned long long *stage_alloc;     // [2]: next free staging entry (handed out in blocks), overflow flag
 };
 
 // canonical m-mer -> order key: a bijection of 32 bits, so equal keys mean equal minimizers and the order is a
@@ -75,7 +81,13 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
     __shared__ uint64_t mw[NFW];  // window-valid bits, bit i <-> position 64*mq0 + i
     __shared__ uint32_t slist[SKM_TP];  // starts of the tile: (window position << 12) | minimizer position
     __shared__ uint32_t s_nstart;
+    __shared__ unsigned long long s_stbase;  // staging entries of this workgroup: [s_stbase, s_stbase + s_stleft)
+    __shared__ uint32_t s_stleft;
     uint8_t *fb = (uint8_t *)fw;
+    if (threadIdx.x == 0) {
+        s_stbase = 0;
+        s_stleft = 0;
+    }
     const unsigned w = a.w, K = a.K, m = a.m;
     const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1);
     const uint64_t ntiles = (a.G - a.g0 + SKM_TP - 1) / SKM_TP;
@@ -221,6 +233,29 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
         }
         __syncthreads();
         const uint32_t nstart = s_nstart;
+        unsigned long long stage0 = ~0ull;  // first staging entry of this tile (PHASE 0 with staging)
+        if (PHASE == 0 && a.stage_slots) {
+            if (threadIdx.x == 0 && nstart) {
+                if (s_stleft < nstart) {  // next block of staging entries (the unused rest of the old one stays marked unused)
+                    constexpr uint32_t CH = 4096;  // >= SKM_TP, the most starts a tile can have
+                    const unsigned long long b = atomicAdd(&a.stage_alloc[0], (unsigned long long)CH);
+                    if (b + CH > a.stage_cap) {
+                        a.stage_alloc[1] = 1;  // overflow: the host falls back to the second scan
+                        s_stleft = 0;
+                        s_stbase = ~0ull;
+                    } else {
+                        s_stbase = b;
+                        s_stleft = CH;
+                    }
+                }
+                if (s_stbase != ~0ull) {
+                    s_stleft -= nstart;
+                    s_stbase += nstart;
+                }
+            }
+            __syncthreads();
+            stage0 = s_stbase == ~0ull ? ~0ull : s_stbase - nstart;
+        }
         for (uint32_t si = threadIdx.x; si < nstart; si += BLK) {
             const uint32_t e = slist[si];
             const int pr = (int)(e >> 12);  // window position relative to p0
@@ -242,10 +277,17 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
             }
             if (c > w) c = w;
             const uint32_t key = skm_part(keys[e & 0xFFFu]);
+            uint64_t *dst = nullptr;
             if constexpr (PHASE == 0) {
                 atomicAdd(&a.cnt[key], 1ull);
+                if (stage0 != ~0ull) {
+                    dst = a.stage_slots + (stage0 + si) * SW;
+                    a.stage_part[stage0 + si] = key;
+                }
             } else {
-                uint64_t *dst = a.slots + atomicAdd(&a.cursor[key], 1ull) * SW;
+                dst = a.slots + atomicAdd(&a.cursor[key], 1ull) * SW;
+            }
+            if (dst) {
                 const int64_t p = p0 + pr;
                 const int wi = (int)((p >> 5) - wq0);
                 const unsigned sh = (unsigned)(p & 31) << 1;
@@ -268,6 +310,23 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
     if (a.prof && threadIdx.x == 0)
         for (int i = 0; i < 4; ++i) atomicAdd(&a.prof[8 * PHASE + i], pt[i]);
 #undef SKM_T
+}
+
+// staged super-k-mers (scan order) -> their place in the partition-sorted slot array
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_skm_permute(const uint64_t *__restrict__ stage_slots, const uint32_t *__restrict__ stage_part,
+                                                     uint64_t n_stage, unsigned long long *cursor, uint64_t *slots) {
+    constexpr int SW = 2 * NW;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n_stage; i += (uint64_t)gridDim.x * BLK) {
+        const uint32_t part = stage_part[i];
+        if (part == 0xFFFFFFFFu) continue;
+        uint64_t v[SW];
+#pragma unroll
+        for (int t = 0; t < SW; ++t) v[t] = stage_slots[i * SW + t];
+        uint64_t *dst = slots + atomicAdd(&cursor[part], 1ull) * SW;
+#pragma unroll
+        for (int t = 0; t < SW; ++t) dst[t] = v[t];
+    }
 }
 
 // sum and sum of squares of the per-partition slot counts: sum2 / sum = the partition size a random super-k-mer lives in

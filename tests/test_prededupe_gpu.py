@@ -99,3 +99,14 @@ def test_deep_coverage_picks_a_larger_chunk(K, mode):
     ref, rs = oracle.count(reads, K, mode, 16)
     rec, sizes = _count(reads, K, mode, 16, ON)
     assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
+
+
+@pytest.mark.parametrize("stage", [0, 2])
+def test_staging_off_and_overflow_fall_back_to_the_second_scan(stage):
+    """skm_stage=0: two scans of the reads (count, then place); =2: a staging area of one block overflows and must fall back"""
+    from oracle import oracle
+    reads = _synth(9, 30000, 4000, 150)
+    for K, mode in ((55, "A"), (22, "B")):
+        ref, rs = oracle.count(reads, K, mode, 16)
+        rec, sizes = _count(reads, K, mode, 16, dict(ON, skm_stage=stage))
+        assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
