@@ -54,7 +54,6 @@ struct smx_ctx {
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;
     int64_t opt_skm_stage = 1;     // pass 0 of the super-k-mer scan stages its output so that placing it needs no second scan
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
-    int64_t opt_tag_scatter = 0;  // level-1 scatter from records staging 16-bit tags instead of records: measured slower (9.1 vs 7.4 ms)
     int64_t opt_joint_hist = 1;  // fuse the level-2 histogram into the level-1 histogram pass (records source)
     int64_t opt_prededupe = -1;  // super-k-mer pre-deduplication: -1 auto, 0 off, 1 on whenever K allows it
     int64_t opt_skm_cap = 0;     // instances per LDS dedupe chunk (0 = default)
@@ -327,15 +326,6 @@ int pass_recs(smx_ctx *ctx, bool scatter, PassArgs a, uint64_t nrec, unsigned lo
         size_t lds = (size_t)a.F * 4;
         if (int rc = set_lds(ctx, k_hist<NW, SRC_RECS, BINF, RPT>, lds)) return rc;
         hipLaunchKernelGGL((k_hist<NW, SRC_RECS, BINF, RPT>), dim3((unsigned)grid), dim3(BLK), lds, ctx->stream, a);
-    } else if (BINF != BIN_LK && a.nseg == 1 && ctx->opt_tag_scatter != 0) {
-        // level 1 / owner partition: one input segment, tag-staged multisplit (small LDS footprint, 8 workgroups per CU)
-        const uint64_t n_in = a.expand ? nrec / 2 : nrec;
-        const uint64_t rin = a.expand ? (uint64_t)RPT * BLK / 2 : (uint64_t)RPT * BLK;
-        const uint64_t g = (n_in + rin - 1) / rin;
-        if (g > 0x7FFFFFFFull) return fail(ctx, SMX_INVALID_PARAMETER, "batch too large for one launch");
-        size_t lds = (size_t)a.F * 12 + (size_t)RPT * BLK * 4;
-        if (int rc = set_lds(ctx, k_scatter_recs_tag<NW, BINF, RPT>, lds)) return rc;
-        if (g) hipLaunchKernelGGL((k_scatter_recs_tag<NW, BINF, RPT>), dim3((unsigned)g), dim3(BLK), lds, ctx->stream, a, n_in);
     } else {
         size_t lds = scatter_lds<NW, RPT>(a.F);
         if (int rc = set_lds(ctx, k_scatter<NW, SRC_RECS, BINF, RPT>, lds)) return rc;
@@ -513,10 +503,9 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     a.F = F1;
     a.hist = histA;
     HIPCHK(hipMemsetAsync(histA, 0, (size_t)F1 * 8, ctx->stream));
-    // records source: level-1 histogram fused with the level-2 one (LDS table of F1*F2 counters) + level-1 bins cached as bytes
+    // records source: level-1 histogram fused with the level-2 one (LDS table of F1*F2 counters)
     const bool joint = !from_reads && !lv.empty() && (uint64_t)F1 * lv[0] <= 24 * 1024 && F1 <= 256 && ctx->opt_joint_hist != 0;
     unsigned long long *histJ = nullptr;
-    uint8_t *bins8 = nullptr;
     tbegin(ctx, "l1_hist");
     if (from_reads) {
         if (int rc = pass_reads<NW, BIN_L1>(ctx, mode, false, a, masks, ranges)) return rc;
@@ -528,19 +517,15 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         if (joint) {
             const uint32_t F2 = lv[0];
             if (int rc = dalloc(ctx, &histJ, (size_t)F1 * F2)) return rc;
-            if (ctx->opt_joint_hist >= 2)
-                if (int rc = dalloc(ctx, &bins8, nrec + 16)) return rc;
             HIPCHK(hipMemsetAsync(histJ, 0, (size_t)F1 * F2 * 8, ctx->stream));
             PassArgs aj = a;
             aj.hist = histJ;
-            aj.bins8 = bins8;
             const size_t lds = (size_t)F1 * F2 * 4;
             if (int rc = set_lds(ctx, k_hist_l1_joint<NW>, lds)) return rc;
             hipLaunchKernelGGL((k_hist_l1_joint<NW>), dim3(256 * 2), dim3(1024), lds, ctx->stream, aj, F2, n_in);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_rowsum, dim3((F1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, (const unsigned long long *)histJ, F1, F2, histA);
             HIPCHK(hipGetLastError());
-            a.bins8 = bins8;
         } else {
             if (int rc = pass_recs<NW, BIN_L1>(ctx, false, a, nrec, tcnt, tstart)) return rc;
         }
@@ -563,7 +548,6 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     tend(ctx);
 
     a.expand = 0;
-    a.bins8 = nullptr;
     wt.mark(ctx, "level1");
     // ---- levels 2.. -------------------------------------------------------------------------
     Rec<NW> *sortbuf = bufA, *other = bufB;
@@ -1694,7 +1678,6 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "joint_hist")) ctx->opt_joint_hist = value;
     else if (!strcmp(key, "device_links")) ctx->opt_device_links = value;
     else if (!strcmp(key, "skm_stage")) ctx->opt_skm_stage = value;
-    else if (!strcmp(key, "tag_scatter")) ctx->opt_tag_scatter = value;
     else if (!strcmp(key, "skm_cap")) ctx->opt_skm_cap = value;
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;

@@ -44,7 +44,6 @@ struct PassArgs {
     uint32_t fprev[6];
     uint32_t world;
     uint32_t expand;  // records source, level 1 only: instance i = record i/2, odd i = its reverse complement
-    uint8_t *bins8;   // records source, level 1 only: level-1 bin of every instance, written by k_hist_l1_joint, read by k_scatter
     uint32_t F;  // bins per segment
     unsigned long long *hist;    // [nseg*F]
     unsigned long long *cursor;  // [nseg*F]
@@ -278,7 +277,7 @@ __global__ void __launch_bounds__(BLK) k_hist(PassArgs a) {
 
 // Level-1 histogram from records, fused with the level-2 histogram: one LDS table of F1*F2 counters per persistent workgroup
 // (bin1 * F2 + second mixed-radix digit), flushed once; the level-2 hist pass over the scattered records (one full re-read) is
-// not needed any more. Also stores the level-1 bin of every instance (u8, F1 <= 256) so that the scatter does not hash again.
+// not needed any more. (Caching the level-1 bins as bytes for the scatter was measured too: the byte loads cost more than re-hashing.)
 // a.F = F1, a.hist = joint histogram [F1*F2]; level-1 totals are its row sums (k_rowsum).
 template <int NW>
 __global__ void __launch_bounds__(1024) k_hist_l1_joint(PassArgs a, uint32_t F2, uint64_t n_in) {
@@ -295,7 +294,6 @@ __global__ void __launch_bounds__(1024) k_hist_l1_joint(PassArgs a, uint32_t F2,
             uint64_t f = key_top64<NW>(x, a.K);
             if (S1 > 1) f *= S1;
             atomicAdd(&lh[b1 * F2 + (uint32_t)__umul64hi(f, (uint64_t)F2)], 1u);
-            if (a.bins8) a.bins8[a.expand ? 2 * ri : ri] = (uint8_t)b1;
         }
         if (a.expand) {
             const Rec<NW> y = rec_rc<NW>(x, a.K);
@@ -303,7 +301,6 @@ __global__ void __launch_bounds__(1024) k_hist_l1_joint(PassArgs a, uint32_t F2,
             uint64_t f = key_top64<NW>(y, a.K);
             if (S1 > 1) f *= S1;
             atomicAdd(&lh[b1 * F2 + (uint32_t)__umul64hi(f, (uint64_t)F2)], 1u);
-            if (a.bins8) a.bins8[2 * ri + 1] = (uint8_t)b1;
         }
     }
     __syncthreads();
@@ -356,19 +353,7 @@ __global__ void __launch_bounds__(BLK) k_scatter(PassArgs a) {
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
         if (vm & (1u << j)) {
-            if (SRC == SRC_RECS && BINF == BIN_L1 && a.bins8) {  // XXH3 was paid once, in the histogram pass (same instance numbering)
-                if (a.expand) {
-                    if ((j & 1) == 0) {
-                        const uint32_t two = ((const uint16_t *)a.bins8)[(sb >> 1) + (uint64_t)(j >> 1) * BLK + threadIdx.x];
-                        packed[j] = two & 0xFFu;
-                        if (j + 1 < RPT) packed[j + 1] = two >> 8;
-                    }
-                } else {
-                    packed[j] = a.bins8[sb + (uint64_t)j * BLK + threadIdx.x];
-                }
-            } else {
-                packed[j] = bin_of<NW, BINF>(r[j], a);
-            }
+            packed[j] = bin_of<NW, BINF>(r[j], a);
             slot[j] = atomicAdd(&lhist[packed[j]], 1u);
         }
     }
@@ -478,82 +463,6 @@ __global__ void __launch_bounds__(BLK) k_scatter_reads(PassArgs a) {
             Rec<NW> y = rec_rc<NW>(x, a.K);
             if (!rc_ge<NW>(y, x)) x = y;
         }
-        out[ldelta[sbin[idx]] + idx] = x;
-    }
-}
-
-// Level-1 scatter from records (single input segment [0, n_in), a.expand: every record also yields its reverse complement).
-// Like k_scatter_reads the LDS stage holds a 13-bit (record-in-tile, strand) tag per instance instead of the record (19 KB instead
-// of 76 KB: 8 workgroups per CU instead of 2); the copy-out re-reads the tile's records (L2 hits) and redoes the RC.
-template <int NW, int BINF, int RPT>
-__global__ void __launch_bounds__(BLK) k_scatter_recs_tag(PassArgs a, uint64_t n_in) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    constexpr int TR = RPT * BLK;
-    uint64_t *ldelta = lds64;
-    uint32_t *lhist = (uint32_t *)(ldelta + a.F);
-    uint16_t *spos = (uint16_t *)(lhist + a.F);
-    uint16_t *sbin = spos + TR;
-    __shared__ uint32_t scr[BLK / 64 + 2];
-    for (uint32_t i = threadIdx.x; i < a.F; i += BLK) lhist[i] = 0;
-    __syncthreads();
-    const bool ex = a.expand != 0;
-    const Rec<NW> *in = (const Rec<NW> *)a.recs;
-    const uint64_t rbase = (uint64_t)blockIdx.x * (uint64_t)(ex ? TR / 2 : TR);
-    uint32_t packed[RPT];  // bin << 16 | slot
-    uint32_t vm = 0;
-    if (ex) {
-#pragma unroll
-        for (int j = 0; j < RPT / 2; ++j) {
-            const uint64_t ri = rbase + (uint64_t)j * BLK + threadIdx.x;
-            if (ri < n_in) {
-                const Rec<NW> x = in[ri];
-                const uint32_t b0 = bin_of<NW, BINF>(x, a), b1 = bin_of<NW, BINF>(rec_rc<NW>(x, a.K), a);
-                packed[2 * j] = (b0 << 16) | atomicAdd(&lhist[b0], 1u);
-                packed[2 * j + 1] = (b1 << 16) | atomicAdd(&lhist[b1], 1u);
-                vm |= 3u << (2 * j);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const uint64_t ri = rbase + (uint64_t)j * BLK + threadIdx.x;
-            if (ri < n_in) {
-                const uint32_t b0 = bin_of<NW, BINF>(in[ri], a);
-                packed[j] = (b0 << 16) | atomicAdd(&lhist[b0], 1u);
-                vm |= 1u << j;
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t per = (a.F + BLK - 1) / BLK;
-    const uint32_t d0 = threadIdx.x * per, d1 = min(a.F, d0 + per);
-    uint32_t sum = 0;
-    for (uint32_t d = d0; d < d1; ++d) sum += lhist[d];
-    uint32_t total;
-    uint32_t run = block_excl_scan<uint32_t>(sum, scr, &total);
-    for (uint32_t d = d0; d < d1; ++d) {
-        uint32_t c = lhist[d];
-        lhist[d] = run;
-        if (c) ldelta[d] = (uint64_t)atomicAdd(&a.cursor[d], (unsigned long long)c) - run;
-        run += c;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        if (vm & (1u << j)) {
-            const uint32_t bin = packed[j] >> 16;
-            const uint32_t idx = lhist[bin] + (packed[j] & 0xFFFFu);
-            const uint32_t lpos = (uint32_t)(ex ? j / 2 : j) * BLK + threadIdx.x;
-            spos[idx] = (uint16_t)((lpos << 1) | (ex ? (j & 1) : 0));
-            sbin[idx] = (uint16_t)bin;
-        }
-    }
-    __syncthreads();
-    Rec<NW> *out = (Rec<NW> *)a.out;
-    for (uint32_t idx = threadIdx.x; idx < total; idx += BLK) {
-        const uint32_t tag = spos[idx];
-        Rec<NW> x = in[rbase + (tag >> 1)];
-        if (tag & 1) x = rec_rc<NW>(x, a.K);
         out[ldelta[sbin[idx]] + idx] = x;
     }
 }
