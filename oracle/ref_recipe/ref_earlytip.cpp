@@ -1,0 +1,48 @@
+// oracle/ref_recipe/ref_earlytip.cpp — TEST INFRASTRUCTURE, not product code.
+//
+// The reference's extension index, early tip clipper and unbranching-path extractor, compiled from the sources where they lie
+// under /root/reference and driven on a one-sequence-per-line read file:
+//   canonical (k+1)-mers              KMerDiskCounter + LineSplitter (mode B)                      kmer_index_builder.hpp:284-431
+//   extension index                   DeBruijnExtensionIndexBuilder::BuildExtensionIndexFromKPOMers kmer_extension_index_builder.hpp:80-107
+//   early tip clipper (bound > 0)     EarlyTipClipperProcessor(index, bound).ClipTips()            early_simplification.hpp:38-162
+//   unitigs + perfect loops           UnbranchingPathExtractor::ExtractUnbranchingPathsAndLoops     debruijn_graph_constructor.hpp:399-406
+// This is what spades-core's Construction stage runs between "Extension index construction" and "Condensing graph"
+// (stages/construction.cpp:289-305, 345-369) with length_bound = RL - K by default.
+//
+//   ref_earlytip <k> <nthreads> <tip_length_bound|0> <reads.txt> <workdir> <out.txt>
+//   out.txt: one edge sequence per line in the extractor's order (nthreads = 1 makes the order and the clipping deterministic)
+#include "line_splitter.hpp"
+#include "kmer_index/extension_index/kmer_extension_index_builder.hpp"
+#include "assembly_graph/construction/early_simplification.hpp"
+#include "assembly_graph/construction/debruijn_graph_constructor.hpp"
+
+int main(int argc, char **argv) {
+    if (argc < 7) {
+        std::cerr << "usage: ref_earlytip <k> <nthreads> <tip_length_bound|0> <reads.txt> <workdir> <out.txt>\n";
+        return 2;
+    }
+    unsigned k = (unsigned) atoi(argv[1]);
+    unsigned nthreads = (unsigned) atoi(argv[2]);
+    size_t bound = strtoull(argv[3], nullptr, 10);
+    std::string reads = argv[4];
+    std::filesystem::path workdir = argv[5];
+    std::string outfile = argv[6];
+    omp_set_num_threads((int) nthreads);
+    create_console_logger();
+    std::filesystem::create_directories(workdir);
+    auto tmp = fs::tmp::make_temp_dir(workdir, "ref_earlytip");
+
+    kmers::DeBruijnExtensionIndex<> index(k);
+    {
+        LineSplitter splitter(workdir, k + 1, reads, /*canonical_only=*/true, 0);
+        kmers::KMerDiskCounter<RtSeq> counter(workdir, std::move(splitter));
+        auto kpomers = counter.Count(10 * nthreads, nthreads);
+        kmers::DeBruijnExtensionIndexBuilder().BuildExtensionIndexFromKPOMers(tmp, index, kpomers, nthreads, 0);
+    }
+    if (bound)
+        debruijn_graph::EarlyTipClipperProcessor(index, bound).ClipTips();
+    auto seqs = debruijn_graph::UnbranchingPathExtractor(index, k).ExtractUnbranchingPathsAndLoops(10 * nthreads);
+    std::ofstream os(outfile);
+    for (const auto &s : seqs) os << s.str() << "\n";
+    return 0;
+}

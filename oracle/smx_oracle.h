@@ -72,6 +72,9 @@ orc_graph *orc_build_graph_cov(unsigned k, unsigned num_buckets, const char *bas
 /* spades-core variant (DeBruijnGraphExtentionConstructor, debruijn_graph_constructor.hpp:590-604): sort_edges = unitigs
  * ordered by Sequence::RawCompare before ids; keep_loops = keep_perfect_loops. PARITY UNPINNED for this variant: no
  * spades-core build is available to produce a golden; the ordering rule itself is restated from sequence.hpp:605-624. */
+/* spades-core only: EarlyTipClipperProcessor(index, bound).ClipTips() between the extension index and the unitigs
+ * (early_simplification.hpp:38-162, stages/construction.cpp:289-305); 0 = off. Applies to the following orc_build_graph_* calls. */
+void orc_set_early_tip_bound(uint64_t bound);
 orc_graph *orc_build_graph_ex(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off, uint64_t nreads,
                               const char *flavour_version, int with_cov, int sort_edges, int keep_loops);
 void orc_graph_free(orc_graph *g);

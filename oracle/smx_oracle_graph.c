@@ -132,6 +132,92 @@ static void remove_sequence(kidx *ix, const unsigned char *s, size_t n) {
     for (size_t pos = ix->k; pos < n; ++pos) { h = kwh_shl(ix, &h, s[pos]); ix->mask[h.idx] = 0; }
 }
 
+/* ---------------------------------------------------------------- early tip clipper (spades-core only)
+ * EarlyTipClipperProcessor, assembly_graph/construction/early_simplification.hpp:38-162, run by the Construction stage between the
+ * extension index and the condensation (stages/construction.cpp:289-305) with length_bound = RL - K. Restated sequentially in
+ * k-mer-file order (= the reference with one thread). */
+typedef struct { int64_t *idx; size_t n, cap; } tiplist;
+static void tl_push(tiplist *t, int64_t i) {
+    if (t->n == t->cap) { t->cap = t->cap ? t->cap * 2 : 64; t->idx = (int64_t *)realloc(t->idx, t->cap * sizeof *t->idx); }
+    t->idx[t->n++] = i;
+}
+/* FindForward, :102-112: from the second k-mer of a would-be tip; leaves the list empty unless it ends in a dead end within bound */
+static void tip_find_forward(const kidx *ix, kwh kh, size_t bound, tiplist *tip) {
+    tip->n = 0;
+    for (;;) {
+        uint8_t m = get_mask(ix, &kh);
+        if (!(tip->n < bound && uniq4((m >> 4) & 15) && uniq4(m & 15))) break;
+        tl_push(tip, kh.idx);
+        kh = kwh_shl(ix, &kh, uniq_nucl(m & 15));
+    }
+    tl_push(tip, kh.idx);
+    uint8_t m = get_mask(ix, &kh);
+    if (!uniq4((m >> 4) & 15) || (m & 15) != 0) tip->n = 0; /* branching or too long */
+}
+/* RemoveForward + RemoveTips, :114-146 */
+static size_t tip_remove_forward(kidx *ix, const kwh *kh, size_t bound, tiplist tips[4]) {
+    size_t max = 0, removed = 0;
+    uint8_t m = get_mask(ix, kh);
+    for (unsigned c = 0; c < 4; ++c) {
+        tips[c].n = 0;
+        if (m & (1u << c)) {
+            kwh khc = kwh_shl(ix, kh, c);
+            tip_find_forward(ix, khc, bound, &tips[c]);
+            size_t len = tips[c].n ? tips[c].n : (size_t)-1;
+            if (len > max) max = len;
+        }
+    }
+    for (unsigned c = 0; c < 4; ++c)
+        if (tips[c].n < max) {
+            for (size_t i = 0; i < tips[c].n; ++i) ix->mask[tips[c].idx[i]] = 0; /* IsolateVertex */
+            removed += tips[c].n;
+        }
+    return removed;
+}
+/* RemoveInconsistentForwardLinks, :21-36 */
+static size_t tip_remove_inconsistent(kidx *ix, const kwh *kh) {
+    size_t count = 0;
+    uint8_t m = get_mask(ix, kh);
+    const unsigned first = nucl_at(kh->w, 0);
+    for (unsigned c = 0; c < 4; ++c) {
+        if (!(m & (1u << c))) continue;
+        kwh nx = kwh_shl(ix, kh, c);
+        uint8_t mn = get_mask(ix, &nx);
+        if (!(mn & (1u << (4 + first)))) {
+            ix->mask[kh->idx] &= (uint8_t)~(1u << (kh->minimal ? c : 7 - c)); /* DeleteOutgoing, inout_mask.hpp:133-139 */
+            ++count;
+        }
+    }
+    return count;
+}
+/* ClipTips, :52-99; returns the number of isolated k-mers */
+static size_t early_tip_clip(kidx *ix, size_t bound) {
+    tiplist tips[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    kwh *tipped = NULL; size_t nt = 0, capt = 0, removed = 0;
+    for (uint64_t r = 0; r < ix->n; ++r) {
+        kwh side[2];
+        side[0] = make_kwh(ix, ix->recs + r * ix->nw);
+        side[1] = kwh_rc(ix, &side[0]);
+        for (int sd = 0; sd < 2; ++sd) {
+            uint8_t m = get_mask(ix, &side[sd]);
+            if (__builtin_popcount(m & 15) < 2) continue;
+            size_t rm = tip_remove_forward(ix, &side[sd], bound, tips);
+            removed += rm;
+            if (rm) {
+                if (nt == capt) { capt = capt ? capt * 2 : 256; tipped = (kwh *)realloc(tipped, capt * sizeof *tipped); }
+                tipped[nt++] = side[sd];
+            }
+        }
+    }
+    for (size_t i = 0; i < nt; ++i) tip_remove_inconsistent(ix, &tipped[i]);
+    for (unsigned c = 0; c < 4; ++c) free(tips[c].idx);
+    free(tipped);
+    return removed;
+}
+/* 0 = off (spades-gbuilder); set by orc_set_early_tip_bound before orc_build_graph_* for the spades-core variant */
+static size_t g_early_tip_bound = 0;
+void orc_set_early_tip_bound(uint64_t bound) { g_early_tip_bound = (size_t)bound; }
+
 /* ---------------------------------------------------------------- link records */
 typedef struct { uint64_t hash_and_mask; uint64_t edge; } linkrec; /* debruijn_graph_constructor.hpp:422-454 */
 static uint64_t lr_hash(const linkrec *r) { return r->hash_and_mask >> 2; }
@@ -256,6 +342,7 @@ orc_graph *orc_build_graph_ex(unsigned k, unsigned num_buckets, const char *base
         ix.mask[hp.idx] |= (uint8_t)(1u << (hp.minimal ? nnucl : 7 - nnucl));
         ix.mask[hs.idx] |= (uint8_t)(1u << (hs.minimal ? pnucl + 4 : 7 - (pnucl + 4)));
     }
+    if (g_early_tip_bound) early_tip_clip(&ix, g_early_tip_bound);
     g->kmers = (uint64_t *)malloc((ix.n ? ix.n : 1) * nw * 8);
     memcpy(g->kmers, ix.recs, ix.n * nw * 8);
     g->masks = (uint8_t *)malloc(ix.n ? ix.n : 1);
