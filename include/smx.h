@@ -153,6 +153,11 @@ int smx_graph_set_coverage(smx_ctx *ctx, const uint32_t *raw_coverage, uint64_t 
 /* info[8] = { #canonical (k+1)-mers, #canonical k-mers, #unitigs (incl. loops), #perfect loops, #vertices, #links
  * (valid after a GFA was written), total unitig nucleotides, words per k-mer } */
 int smx_graph_info(const smx_ctx *ctx, uint64_t *info);
+/* spades-core's early tip clipper (Construction phase "Early tip clipping", stages/construction.cpp:289-305;
+ * EarlyTipClipperProcessor, assembly_graph/construction/early_simplification.hpp:38-162) runs inside smx_build_graph between the
+ * extension masks and the unitigs when the option "early_tip_bound" is > 0 (the reference uses RL - K). spades-gbuilder never runs it.
+ * stats[2] = { k-mers isolated, tips removed } of the last build ("<n> (k+1)-mers were removed by early tip clipper", :50). */
+int smx_graph_tip_stats(const smx_ctx *ctx, uint64_t *stats);
 /* k-mer file order: records [n_kmers * words] and InOutMask bytes (extension_index/inout_mask.hpp:55-221) */
 int smx_graph_copy_kmers(const smx_ctx *ctx, void *kmers_host, uint8_t *masks_host);
 /* unitigs in the reference's enumeration order: offsets [n_unitigs+1], ACGT bytes */

@@ -52,6 +52,7 @@ struct smx_ctx {
     // tuning / test hooks
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;
+    int64_t opt_early_tip_bound = 0;  // > 0: spades-core's early tip clipper with this length bound (RL - K there) before condensation
     int64_t opt_skm_stage = 1;     // pass 0 of the super-k-mer scan stages its output so that placing it needs no second scan
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
     int64_t opt_joint_hist = 1;  // fuse the level-2 histogram into the level-1 histogram pass (records source)
@@ -81,6 +82,7 @@ struct smx_ctx {
     std::vector<uint32_t> last_idx_f;
     smx::RankIndex g_ix_kmers{}, g_ix_kpo{};  // .off owned by the graph state
     bool g_ready = false;
+    uint64_t g_tip_kmers = 0, g_tips = 0;  // early tip clipper: k-mers isolated, tips removed
     smxh::GraphHost gh;
 };
 
@@ -1398,10 +1400,40 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
                        (const void *)ctx->g_kpo, nkpo, k, (const void *)ctx->g_kmers, ixk, (uint32_t *)ctx->g_mask, d_err);
     HIPCHK(hipGetLastError());
     tend(ctx);
-    // ---- 4. successors + start de-edges -------------------------------------------------------
     uint32_t *succ;
-    unsigned long long *ccnt, *coff;
     if (int rc = dalloc(ctx, &succ, 2 * D0)) return rc;
+    // ---- 3b. early tip clipper (spades-core variant, off for spades-gbuilder) ---------------------
+    ctx->g_tip_kmers = ctx->g_tips = 0;
+    if (ctx->opt_early_tip_bound > 0) {
+        uint8_t *isolate, *tipped;
+        unsigned long long *tstats;
+        if (int rc = dalloc(ctx, &isolate, D0 + 1)) return rc;
+        if (int rc = dalloc(ctx, &tipped, 2 * D0 + 1)) return rc;
+        if (int rc = dalloc(ctx, &tstats, 2)) return rc;
+        HIPCHK(hipMemsetAsync(isolate, 0, D0 + 1, ctx->stream));
+        HIPCHK(hipMemsetAsync(tipped, 0, 2 * D0 + 1, ctx->stream));
+        HIPCHK(hipMemsetAsync(tstats, 0, 16, ctx->stream));
+        tbegin(ctx, "early_tips");
+        hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, succ, d_err);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL((k_tip_mark<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
+                           (const uint32_t *)succ, D0, k, ixk, (uint32_t)std::min<int64_t>(ctx->opt_early_tip_bound, 0x7FFFFFFF), isolate, tipped, tstats,
+                           d_err);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_tip_apply, dim3(grid), dim3(BLK), 0, ctx->stream, ctx->g_mask, (const uint8_t *)isolate, D0);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL((k_tip_fix<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (uint32_t *)ctx->g_mask,
+                           (const uint8_t *)tipped, D0, k, ixk, d_err);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        unsigned long long hs[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(hs, tstats, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->g_tip_kmers = hs[0];
+        ctx->g_tips = hs[1];
+    }
+    // ---- 4. successors + start de-edges -------------------------------------------------------
+    unsigned long long *ccnt, *coff;
     if (int rc = dalloc(ctx, &ccnt, D0)) return rc;
     if (int rc = dalloc(ctx, &coff, D0 + 1)) return rc;
     tbegin(ctx, "succ");
@@ -1678,6 +1710,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "joint_hist")) ctx->opt_joint_hist = value;
     else if (!strcmp(key, "device_links")) ctx->opt_device_links = value;
     else if (!strcmp(key, "skm_stage")) ctx->opt_skm_stage = value;
+    else if (!strcmp(key, "early_tip_bound")) ctx->opt_early_tip_bound = value;
     else if (!strcmp(key, "skm_cap")) ctx->opt_skm_cap = value;
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
@@ -2131,6 +2164,13 @@ int smx_graph_info(const smx_ctx *ctx, uint64_t *info /* [8] */) {
     info[5] = ctx->gh.n_links;
     info[6] = ctx->gh.seq.size();
     info[7] = ctx->g_nw;
+    return SMX_OK;
+}
+
+int smx_graph_tip_stats(const smx_ctx *ctx, uint64_t *stats /* [2] */) {
+    if (!ctx || !stats || !ctx->g_ready) return SMX_INVALID_PARAMETER;
+    stats[0] = ctx->g_tip_kmers;
+    stats[1] = ctx->g_tips;
     return SMX_OK;
 }
 

@@ -147,6 +147,108 @@ __global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t 
     }
 }
 
+// ---- early tip clipper (spades-core Construction stage; EarlyTipClipperProcessor, construction/early_simplification.hpp:38-162) ----
+// One thread per oriented k-mer with >= 2 outgoing extensions (RemoveForward, :133-146). A branch is a tip if, from its first
+// k-mer, the chain of non-junction k-mers (succ[], computed on the unclipped masks) reaches a dead end with a unique incoming
+// extension within `bound` k-mers (FindForward, :102-112); tips shorter than the longest branch are removed (RemoveTips, :122-131).
+// The reference updates the masks while it iterates; the decisions do not depend on that: a tip's k-mers have unique
+// predecessors all the way back to ONE junction orientation, so no other junction ever walks them, and roots keep their phantom
+// extension bits until the clean-up pass (checked against the reference run with 1-4 threads: tests/golden/etc_*). Hence three
+// data-parallel passes: mark (reads the original masks), apply (IsolateVertex), fix (RemoveInconsistentForwardLinks, :21-36).
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_tip_mark(const void *kmers_, const uint8_t *mask, const uint32_t *succ, uint64_t D0, unsigned k,
+                                                  RankIndex ix, uint32_t bound, uint8_t *isolate, uint8_t *tipped, unsigned long long *stats,
+                                                  uint32_t *err) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
+        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        const unsigned m = mask[r];
+        const unsigned mo = o ? brev8(m) : m;
+        if (__popc(mo & 15) < 2) continue;
+        Rec<NW> x = kmers[r];
+        if (o) x = rec_rc<NW>(x, k);
+        uint32_t first[4], len[4];
+        uint32_t mx = 0;
+#pragma unroll
+        for (unsigned c = 0; c < 4; ++c) {
+            first[c] = NODE_NONE;
+            len[c] = 0;  // 0 = no branch
+            if (!(mo & (1u << c))) continue;
+            unsigned yo;
+            const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
+            const uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+            if (ry == NODE_NONE) {
+                atomicAdd(err, 1u);
+                continue;
+            }
+            uint32_t nd = (ry << 1) | yo, cnt = 0;
+            first[c] = nd;
+            while (cnt < bound && !mask_junction(mask[nd >> 1])) {
+                ++cnt;
+                nd = succ[nd];
+                if (nd == NODE_NONE) break;  // inconsistent index (reported by k_succ): never walk off the array
+            }
+            if (nd == NODE_NONE) {
+                len[c] = 0xFFFFFFFFu;
+                mx = 0xFFFFFFFFu;
+                continue;
+            }
+            ++cnt;
+            const unsigned ml = (nd & 1) ? brev8(mask[nd >> 1]) : mask[nd >> 1];
+            const bool tip = uniq4((ml >> 4) & 15) && (ml & 15) == 0;
+            len[c] = tip ? cnt : 0xFFFFFFFFu;  // branching or too long: never removed, longer than any tip
+            mx = max(mx, len[c]);
+        }
+        bool any = false;
+#pragma unroll
+        for (unsigned c = 0; c < 4; ++c) {
+            if (len[c] == 0 || len[c] == 0xFFFFFFFFu || len[c] >= mx) continue;
+            uint32_t nd = first[c];
+            for (uint32_t i = 0; i + 1 < len[c]; ++i) {
+                isolate[nd >> 1] = 1;
+                nd = succ[nd];
+            }
+            isolate[nd >> 1] = 1;
+            any = true;
+            atomicAdd(&stats[0], (unsigned long long)len[c]);
+            atomicAdd(&stats[1], 1ull);
+        }
+        if (any) tipped[node] = 1;
+    }
+}
+__global__ void k_tip_apply(uint8_t *mask, const uint8_t *isolate, uint64_t D0) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x)
+        if (isolate[r]) mask[r] = 0;
+}
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_tip_fix(const void *kmers_, uint32_t *mask32, const uint8_t *tipped, uint64_t D0, unsigned k, RankIndex ix,
+                                                 uint32_t *err) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    const uint8_t *mask = (const uint8_t *)mask32;
+    for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
+        if (!tipped[node]) continue;
+        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        const unsigned m = mask[r];
+        const unsigned mo = o ? brev8(m) : m;
+        Rec<NW> x = kmers[r];
+        if (o) x = rec_rc<NW>(x, k);
+        const unsigned firstn = rec_nucl<NW>(x, 0);
+        for (unsigned c = 0; c < 4; ++c) {
+            if (!(mo & (1u << c))) continue;
+            unsigned yo;
+            const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
+            const uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+            if (ry == NODE_NONE) {
+                atomicAdd(err, 1u);
+                continue;
+            }
+            const unsigned mn = yo ? brev8(mask[ry]) : mask[ry];
+            if (!(mn & (1u << (4 + firstn))))  // DeleteOutgoing(kh, c), inout_mask.hpp:133-139
+                atomicAnd(&mask32[r >> 2], ~((1u << (o ? 7 - c : c)) << ((r & 3) * 8)));
+        }
+    }
+}
+
 // start de-edges per junction k-mer: out bits of kh, then out bits of !kh (AddStartDeEdges, :203-226)
 __global__ void k_cand_count(const uint8_t *mask, uint64_t D0, unsigned long long *cnt) {
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x) {

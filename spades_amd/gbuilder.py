@@ -51,6 +51,12 @@ class GraphBuilder:
         self._info.update(n_links=info[5])
         return self._info
 
+    def tip_stats(self):
+        """(k-mers isolated, tips removed) by the early tip clipper of the last build (option early_tip_bound)."""
+        st = (C.c_uint64 * 2)()
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_tip_stats(self.ctx._h, st))
+        return int(st[0]), int(st[1])
+
     def kmers(self):
         n, nw = self._info["n_kmers"], self._info["words"]
         rec = np.empty((n, nw), dtype=np.uint64)

@@ -221,3 +221,35 @@ def test_multi_k_builds_on_one_resident_read_set(tmp_path):
             plain.write_gfa(gb2)
             assert open(gb2).read() == open(os.path.join(GOLDEN, "graph_small_k33_t1.gfa")).read()
     first.ctx.close()
+
+
+ECASES = [c for c in load_manifest()["cases"] if c["kind"] == "earlytip"]
+
+
+@pytest.mark.parametrize("case", ECASES, ids=lambda c: c["file"][4:-4])
+def test_early_tip_clipper_matches_reference(case, tmp_path):
+    """option early_tip_bound: spades-core's EarlyTipClipperProcessor on the extension masks before condensation; the unitig list
+    equals the one of the reference classes (oracle/_ref/ref_earlytip goldens), order included"""
+    reads = [r for r in read_lines(case["reads"]) if r]
+    r = _build(reads, case["K"], case["threads"], tmp_path, {"early_tip_bound": case["bound"]})
+    want = open(os.path.join(GOLDEN, case["file"])).read().split("\n")[:-1]
+    assert r["unitigs"] == want
+
+
+def test_early_tip_clipper_vs_oracle_seeded(tmp_path):
+    from oracle import oracle
+    from test_count_gpu import _synth
+    from spades_amd.gbuilder import GraphBuilder
+    reads = _synth(5, 30000, 6000, 150, err=0.01, nrate=0.001)
+    for k, t, bound in ((21, 2, 129), (55, 1, 95), (77, 3, 73)):
+        ref = oracle.build_graph(reads, k, 10 * t, early_tip_bound=bound)
+        plain = oracle.build_graph(reads, k, 10 * t)
+        gb = GraphBuilder(k, t)
+        gb.ctx.set_option("early_tip_bound", bound)
+        gb.push_back_reads(reads)
+        gb.build()
+        out = os.path.join(str(tmp_path), "g.gfa")
+        gb.write_gfa(out)
+        assert open(out).read() == ref["gfa"] and len(ref["unitigs"]) < len(plain["unitigs"])
+        assert gb.tip_stats()[1] > 0
+        gb.ctx.close()
