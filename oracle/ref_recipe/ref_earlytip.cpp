@@ -9,7 +9,10 @@
 // This is what spades-core's Construction stage runs between "Extension index construction" and "Condensing graph"
 // (stages/construction.cpp:289-305, 345-369) with length_bound = RL - K by default.
 //
-//   ref_earlytip <k> <nthreads> <tip_length_bound|0> <reads.txt> <workdir> <out.txt>
+//   early A/T remover (last argument "at"; RNA pipelines only, before the tip clipper):
+//                                     EarlyLowComplexityClipperProcessor(index, 0.8, 10, 200).RemoveATEdges() + RemoveATTips()
+//                                                                                                  early_simplification.hpp:164-347, construction.cpp:317-326
+//   ref_earlytip <k> <nthreads> <tip_length_bound|0> <reads.txt> <workdir> <out.txt> [at]
 //   out.txt: one edge sequence per line in the extractor's order (nthreads = 1 makes the order and the clipping deterministic)
 #include "line_splitter.hpp"
 #include "kmer_index/extension_index/kmer_extension_index_builder.hpp"
@@ -38,6 +41,11 @@ int main(int argc, char **argv) {
         kmers::KMerDiskCounter<RtSeq> counter(workdir, std::move(splitter));
         auto kpomers = counter.Count(10 * nthreads, nthreads);
         kmers::DeBruijnExtensionIndexBuilder().BuildExtensionIndexFromKPOMers(tmp, index, kpomers, nthreads, 0);
+    }
+    if (argc > 7 && std::string(argv[7]) == "at") {
+        debruijn_graph::EarlyLowComplexityClipperProcessor at_processor(index, 0.8, 10, 200);
+        at_processor.RemoveATEdges();
+        at_processor.RemoveATTips();
     }
     if (bound)
         debruijn_graph::EarlyTipClipperProcessor(index, bound).ClipTips();

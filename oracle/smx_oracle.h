@@ -75,6 +75,9 @@ orc_graph *orc_build_graph_cov(unsigned k, unsigned num_buckets, const char *bas
 /* spades-core only: EarlyTipClipperProcessor(index, bound).ClipTips() between the extension index and the unitigs
  * (early_simplification.hpp:38-162, stages/construction.cpp:289-305); 0 = off. Applies to the following orc_build_graph_* calls. */
 void orc_set_early_tip_bound(uint64_t bound);
+/* RNA pipelines only: EarlyLowComplexityClipperProcessor(index, 0.8, 10, 200).RemoveATEdges() + RemoveATTips() before the tip clipper
+ * (early_simplification.hpp:164-347, stages/construction.cpp:317-326, 446-448) */
+void orc_set_early_at_remover(int on);
 orc_graph *orc_build_graph_ex(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off, uint64_t nreads,
                               const char *flavour_version, int with_cov, int sort_edges, int keep_loops);
 void orc_graph_free(orc_graph *g);

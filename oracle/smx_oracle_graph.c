@@ -214,6 +214,101 @@ static size_t early_tip_clip(kidx *ix, size_t bound) {
     free(tipped);
     return removed;
 }
+/* ---------------------------------------------------------------- early A/T remover (RNA pipelines only)
+ * EarlyLowComplexityClipperProcessor(index, 0.8, 10, 200), early_simplification.hpp:164-347; stages/construction.cpp:317-326.
+ * math::ls(a, b) = !AlmostEquals(a, b) && a < b with the 4-ULP AlmostEquals of math/xmath.h:284-312. */
+static int dbl_almost_eq(double a, double b) {
+    int64_t x, y;
+    memcpy(&x, &a, 8); memcpy(&y, &b, 8);
+    if (x < 0) x = (int64_t)0x8000000000000000ull - x;
+    if (y < 0) y = (int64_t)0x8000000000000000ull - y;
+    int64_t d = x > y ? x - y : y - x;
+    return d <= 4;
+}
+static int dbl_ls(double a, double b) { return !dbl_almost_eq(a, b) && a < b; }
+static kwh kwh_shr(const kidx *ix, const kwh *h, unsigned c) { /* GetIncoming: kwh >> nucl = c + kmer[0..k-2] */
+    uint64_t w[ORC_MAX_WORDS] = {0, 0, 0, 0};
+    w[0] = c;
+    for (unsigned i = 0; i + 1 < ix->k; ++i) w[(i + 1) >> 5] |= (uint64_t)nucl_at(h->w, i) << (((i + 1) & 31) << 1);
+    return make_kwh(ix, w);
+}
+static void mask_del_out(kidx *ix, const kwh *h, unsigned c) { ix->mask[h->idx] &= (uint8_t)~(1u << (h->minimal ? c : 7 - c)); }
+static void mask_del_in(kidx *ix, const kwh *h, unsigned c) { ix->mask[h->idx] &= (uint8_t)~(1u << (h->minimal ? c + 4 : 7 - (c + 4))); }
+/* RemoveATEdges, :176-259 */
+static size_t at_remove_edges(kidx *ix, double ratio) {
+    typedef struct { kwh h; unsigned c; } atedge;
+    atedge *e = NULL; size_t ne = 0, cap = 0;
+    const double thr = ix->k * ratio;
+    for (uint64_t r = 0; r < ix->n; ++r) {
+        kwh side[2];
+        side[0] = make_kwh(ix, ix->recs + r * ix->nw);
+        side[1] = kwh_rc(ix, &side[0]);
+        for (int sd = 0; sd < 2; ++sd) {
+            uint8_t m = get_mask(ix, &side[sd]);
+            if (!is_junction(m)) continue;
+            size_t counts[4] = {0, 0, 0, 0}, curm = 0;
+            for (unsigned i = 0; i < ix->k; ++i) counts[nucl_at(side[sd].w, i)]++;
+            for (int t = 0; t < 4; ++t) if (counts[t] > curm) curm = counts[t];
+            if (dbl_ls((double)curm, thr)) continue;
+            for (unsigned c = 0; c < 4; ++c) {
+                if (!(m & (1u << c))) continue;
+                kwh nx = kwh_shl(ix, &side[sd], c);
+                uint8_t mn = get_mask(ix, &nx);
+                if (!is_junction(mn) && (mn & 15) != 0) continue; /* edge of length 1: next is a junction or a dead end */
+                if (ne == cap) { cap = cap ? cap * 2 : 256; e = (atedge *)realloc(e, cap * sizeof *e); }
+                e[ne].h = side[sd]; e[ne].c = c; ++ne;
+            }
+        }
+    }
+    for (size_t i = 0; i < ne; ++i) {
+        if (!(get_mask(ix, &e[i].h) & (1u << e[i].c))) continue;
+        kwh nx = kwh_shl(ix, &e[i].h, e[i].c);
+        mask_del_out(ix, &e[i].h, e[i].c);
+        mask_del_in(ix, &nx, nucl_at(e[i].h.w, 0));
+    }
+    free(e);
+    return ne;
+}
+/* RemoveATTips, :262-338 */
+static size_t at_remove_tips(kidx *ix, double ratio, size_t min_len, size_t max_len) {
+    kwh *roots = NULL; size_t nr = 0, capr = 0, removed = 0;
+    int64_t *tip = (int64_t *)malloc((max_len + 1) * sizeof *tip);
+    for (uint64_t r = 0; r < ix->n; ++r) {
+        kwh side[2];
+        side[0] = make_kwh(ix, ix->recs + r * ix->nw);
+        side[1] = kwh_rc(ix, &side[0]);
+        for (int sd = 0; sd < 2; ++sd) {
+            kwh kh = side[sd];
+            uint8_t m = get_mask(ix, &kh);
+            if ((m & 15) != 0 || !uniq4((m >> 4) & 15)) continue; /* start from tip ends */
+            size_t counts[4] = {0, 0, 0, 0}, n = 0;
+            do {
+                tip[n++] = kh.idx;
+                counts[nucl_at(kh.w, ix->k - 1)]++;
+                uint8_t mm = get_mask(ix, &kh);
+                kh = kwh_shr(ix, &kh, uniq_nucl((mm >> 4) & 15));
+            } while (n < max_len && !is_junction(get_mask(ix, &kh)));
+            uint8_t mr = get_mask(ix, &kh);
+            if (((mr >> 4) & 15) == 0 || !is_junction(mr)) continue; /* dead start, or the tip is too long */
+            for (size_t i = n - 1; i < min_len; ++i) counts[nucl_at(kh.w, ix->k - 1 - (unsigned)i)]++;
+            size_t curm = 0;
+            for (int t = 0; t < 4; ++t) if (counts[t] > curm) curm = counts[t];
+            const double thr = (double)(n > min_len ? n : min_len) * ratio;
+            if (dbl_ls((double)curm, thr)) continue;
+            if (nr == capr) { capr = capr ? capr * 2 : 256; roots = (kwh *)realloc(roots, capr * sizeof *roots); }
+            roots[nr++] = kh;
+            removed += n;
+            for (size_t i = 0; i < n; ++i) ix->mask[tip[i]] = 0;
+        }
+    }
+    for (size_t i = 0; i < nr; ++i) tip_remove_inconsistent(ix, &roots[i]);
+    free(roots);
+    free(tip);
+    return removed;
+}
+static int g_early_at = 0;
+void orc_set_early_at_remover(int on) { g_early_at = on; }
+
 /* 0 = off (spades-gbuilder); set by orc_set_early_tip_bound before orc_build_graph_* for the spades-core variant */
 static size_t g_early_tip_bound = 0;
 void orc_set_early_tip_bound(uint64_t bound) { g_early_tip_bound = (size_t)bound; }
@@ -341,6 +436,10 @@ orc_graph *orc_build_graph_ex(unsigned k, unsigned num_buckets, const char *base
         /* AddOutgoing / AddIncoming with inv_position, inout_mask.hpp:92-94,117-131 */
         ix.mask[hp.idx] |= (uint8_t)(1u << (hp.minimal ? nnucl : 7 - nnucl));
         ix.mask[hs.idx] |= (uint8_t)(1u << (hs.minimal ? pnucl + 4 : 7 - (pnucl + 4)));
+    }
+    if (g_early_at) { /* EarlyATClipper::run, construction.cpp:324-328 */
+        at_remove_edges(&ix, 0.8);
+        at_remove_tips(&ix, 0.8, 10, 200);
     }
     if (g_early_tip_bound) early_tip_clip(&ix, g_early_tip_bound);
     g->kmers = (uint64_t *)malloc((ix.n ? ix.n : 1) * nw * 8);

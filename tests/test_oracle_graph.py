@@ -92,6 +92,6 @@ def test_oracle_early_tip_clipper_matches_reference(case):
     """spades-core's EarlyTipClipperProcessor (early_simplification.hpp:38-162): the oracle's sequential restatement gives the edge
     sequences of the reference classes (oracle/_ref/ref_earlytip), in the extractor's order, also for the multi-threaded runs."""
     reads = [r for r in read_lines(case["reads"]) if r]
-    g = oracle.build_graph(reads, case["K"], case["num_buckets"], early_tip_bound=case["bound"])
+    g = oracle.build_graph(reads, case["K"], case["num_buckets"], early_tip_bound=case["bound"], early_at=bool(case.get("at")))
     want = open(os.path.join(GOLDEN, case["file"])).read().split("\n")[:-1]
     assert g["unitigs"] == want
