@@ -156,7 +156,10 @@ int smx_graph_info(const smx_ctx *ctx, uint64_t *info);
 /* spades-core's early tip clipper (Construction phase "Early tip clipping", stages/construction.cpp:289-305;
  * EarlyTipClipperProcessor, assembly_graph/construction/early_simplification.hpp:38-162) runs inside smx_build_graph between the
  * extension masks and the unitigs when the option "early_tip_bound" is > 0 (the reference uses RL - K). spades-gbuilder never runs it.
- * stats[2] = { k-mers isolated, tips removed } of the last build ("<n> (k+1)-mers were removed by early tip clipper", :50). */
+ * Option "early_at_remover" = 1 runs the early A/T remover of the RNA pipelines before it (EarlyLowComplexityClipperProcessor(index,
+ * 0.8, 10, 200).RemoveATEdges() + RemoveATTips(), early_simplification.hpp:164-347, stages/construction.cpp:317-326, 446-448).
+ * stats[4] = { k-mers isolated by the tip clipper, tips removed, length-1 A/T edges removed (counted from both ends), k-mers
+ * isolated by the A/T tip remover } of the last build. */
 int smx_graph_tip_stats(const smx_ctx *ctx, uint64_t *stats);
 /* k-mer file order: records [n_kmers * words] and InOutMask bytes (extension_index/inout_mask.hpp:55-221) */
 int smx_graph_copy_kmers(const smx_ctx *ctx, void *kmers_host, uint8_t *masks_host);

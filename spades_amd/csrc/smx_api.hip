@@ -52,6 +52,7 @@ struct smx_ctx {
     // tuning / test hooks
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;
+    int64_t opt_early_at = 0;         // 1: the early A/T remover of the RNA pipelines before the tip clipper
     int64_t opt_early_tip_bound = 0;  // > 0: spades-core's early tip clipper with this length bound (RL - K there) before condensation
     int64_t opt_skm_stage = 1;     // pass 0 of the super-k-mer scan stages its output so that placing it needs no second scan
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
@@ -83,6 +84,7 @@ struct smx_ctx {
     smx::RankIndex g_ix_kmers{}, g_ix_kpo{};  // .off owned by the graph state
     bool g_ready = false;
     uint64_t g_tip_kmers = 0, g_tips = 0;  // early tip clipper: k-mers isolated, tips removed
+    uint64_t g_at_edges = 0, g_at_tip_kmers = 0;  // early A/T remover: length-1 edges marked, tip k-mers isolated
     smxh::GraphHost gh;
 };
 
@@ -1402,6 +1404,66 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     tend(ctx);
     uint32_t *succ;
     if (int rc = dalloc(ctx, &succ, 2 * D0)) return rc;
+    // ---- 3a. early A/T remover (RNA pipelines: EarlyATClipper::run, stages/construction.cpp:317-326) --------------
+    ctx->g_at_edges = ctx->g_at_tip_kmers = 0;
+    if (ctx->opt_early_at) {
+        const double ratio = 0.8;
+        const uint32_t min_len = 10, max_len = 200;
+        // math::ls(a, b) = !AlmostEquals(a, b) && a < b (4 ULPs, math/xmath.h:284-312): thresholds as the smallest count that is NOT ls
+        auto almost_eq = [](double a, double b) {
+            int64_t x, y;
+            memcpy(&x, &a, 8);
+            memcpy(&y, &b, 8);
+            if (x < 0) x = (int64_t)0x8000000000000000ull - x;
+            if (y < 0) y = (int64_t)0x8000000000000000ull - y;
+            const int64_t d = x > y ? x - y : y - x;
+            return d <= 4;
+        };
+        auto not_less = [&](double thr) {
+            uint32_t c = 0;
+            while (!almost_eq((double)c, thr) && (double)c < thr) ++c;
+            return c;
+        };
+        const uint32_t thr_edge = not_less((double)k * ratio);
+        std::vector<uint16_t> h_thr(max_len + 2);
+        for (uint32_t n = 0; n <= max_len + 1; ++n) h_thr[n] = (uint16_t)not_less((double)std::max(n, min_len) * ratio);
+        uint8_t *atflag, *isolate, *tipped;
+        uint16_t *d_thr;
+        unsigned long long *astats;
+        if (int rc = dalloc(ctx, &atflag, 2 * D0 + 1)) return rc;
+        if (int rc = dalloc(ctx, &isolate, D0 + 1)) return rc;
+        if (int rc = dalloc(ctx, &tipped, 2 * D0 + 1)) return rc;
+        if (int rc = dalloc(ctx, &d_thr, h_thr.size())) return rc;
+        if (int rc = dalloc(ctx, &astats, 4)) return rc;
+        HIPCHK(hipMemsetAsync(atflag, 0, 2 * D0 + 1, ctx->stream));
+        HIPCHK(hipMemsetAsync(isolate, 0, D0 + 1, ctx->stream));
+        HIPCHK(hipMemsetAsync(tipped, 0, 2 * D0 + 1, ctx->stream));
+        HIPCHK(hipMemsetAsync(astats, 0, 32, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_thr, h_thr.data(), h_thr.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+        tbegin(ctx, "early_at");
+        hipLaunchKernelGGL((k_at_edges_mark<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk,
+                           thr_edge, atflag, d_err);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL((k_at_edges_apply<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (uint32_t *)ctx->g_mask, D0, k, ixk,
+                           (const uint8_t *)atflag, astats, d_err);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, succ, d_err);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL((k_at_tips_mark<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
+                           (const uint32_t *)succ, D0, k, ixk, min_len, max_len, (const uint16_t *)d_thr, isolate, tipped, astats, d_err);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_tip_apply, dim3(grid), dim3(BLK), 0, ctx->stream, ctx->g_mask, (const uint8_t *)isolate, D0);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL((k_tip_fix<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (uint32_t *)ctx->g_mask,
+                           (const uint8_t *)tipped, D0, k, ixk, d_err);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        unsigned long long hs[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(hs, astats, 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->g_at_tip_kmers = hs[0];
+        ctx->g_at_edges = hs[2];
+    }
     // ---- 3b. early tip clipper (spades-core variant, off for spades-gbuilder) ---------------------
     ctx->g_tip_kmers = ctx->g_tips = 0;
     if (ctx->opt_early_tip_bound > 0) {
@@ -1711,6 +1773,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "device_links")) ctx->opt_device_links = value;
     else if (!strcmp(key, "skm_stage")) ctx->opt_skm_stage = value;
     else if (!strcmp(key, "early_tip_bound")) ctx->opt_early_tip_bound = value;
+    else if (!strcmp(key, "early_at_remover")) ctx->opt_early_at = value;
     else if (!strcmp(key, "skm_cap")) ctx->opt_skm_cap = value;
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
@@ -2167,10 +2230,12 @@ int smx_graph_info(const smx_ctx *ctx, uint64_t *info /* [8] */) {
     return SMX_OK;
 }
 
-int smx_graph_tip_stats(const smx_ctx *ctx, uint64_t *stats /* [2] */) {
+int smx_graph_tip_stats(const smx_ctx *ctx, uint64_t *stats /* [4] */) {
     if (!ctx || !stats || !ctx->g_ready) return SMX_INVALID_PARAMETER;
     stats[0] = ctx->g_tip_kmers;
     stats[1] = ctx->g_tips;
+    stats[2] = ctx->g_at_edges;
+    stats[3] = ctx->g_at_tip_kmers;
     return SMX_OK;
 }
 

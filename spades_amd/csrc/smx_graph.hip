@@ -249,6 +249,176 @@ __global__ void __launch_bounds__(BLK) k_tip_fix(const void *kmers_, uint32_t *m
     }
 }
 
+// ---- early A/T remover (RNA pipelines; EarlyLowComplexityClipperProcessor(index, 0.8, 10, 200), early_simplification.hpp:164-347) ----
+// nucleotide counts of a k-mer
+template <int NW>
+__device__ __forceinline__ void rec_counts(const Rec<NW> &x, unsigned k, unsigned (&cnt)[4]) {
+    cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const unsigned nb = (unsigned)min((int)k - 32 * i, 32);  // nucleotides in this word
+        if ((int)nb <= 0) break;
+        const uint64_t valid = nb == 32 ? 0x5555555555555555ull : ((1ull << (2 * nb)) - 1) & 0x5555555555555555ull;
+        const uint64_t lo = x.w[i] & 0x5555555555555555ull, hi = (x.w[i] >> 1) & 0x5555555555555555ull;
+        cnt[1] += __popcll(lo & ~hi & valid);
+        cnt[2] += __popcll(hi & ~lo & valid);
+        cnt[3] += __popcll(hi & lo & valid);
+        cnt[0] += __popcll(~hi & ~lo & valid);
+    }
+}
+template <int NW>
+__device__ __forceinline__ Rec<NW> rec_shr(const Rec<NW> &x, unsigned K, unsigned c) {  // operator>>: c + kmer[0..K-2]
+    Rec<NW> r;
+#pragma unroll
+    for (int i = NW - 1; i > 0; --i) r.w[i] = (x.w[i] << 2) | (x.w[i - 1] >> 62);
+    r.w[0] = (x.w[0] << 2) | (uint64_t)c;
+    const unsigned tail = (K & 31) << 1;
+    if (tail) r.w[NW - 1] &= (1ull << tail) - 1;
+    return r;
+}
+// RemoveATEdges, :176-259, pass 1: edges of length 1 (the next k-mer is a junction or a dead end) leaving a low-complexity junction
+// k-mer (some nucleotide occurs >= thr_edge times; thr_edge = smallest count that is not math::ls than 0.8 k, computed on the host)
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_at_edges_mark(const void *kmers_, const uint8_t *mask, uint64_t D0, unsigned k, RankIndex ix,
+                                                       uint32_t thr_edge, uint8_t *atflag, uint32_t *err) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
+        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        const unsigned m = mask[r];
+        if (!mask_junction(m)) continue;
+        const unsigned mo = o ? brev8(m) : m;
+        if ((mo & 15) == 0) continue;
+        Rec<NW> x = kmers[r];
+        if (o) x = rec_rc<NW>(x, k);
+        unsigned cnt[4];
+        rec_counts<NW>(x, k, cnt);
+        if (max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3])) < thr_edge) continue;
+        unsigned fl = 0;
+        for (unsigned c = 0; c < 4; ++c) {
+            if (!(mo & (1u << c))) continue;
+            unsigned yo;
+            const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
+            const uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+            if (ry == NODE_NONE) {
+                atomicAdd(err, 1u);
+                continue;
+            }
+            const unsigned mn = yo ? brev8(mask[ry]) : mask[ry];
+            if (!mask_junction(mn) && (mn & 15) != 0) continue;
+            fl |= 1u << c;
+        }
+        if (fl) atflag[node] = (uint8_t)fl;
+    }
+}
+// pass 2: DeleteOutgoing(kh, c) + DeleteIncoming(next, kh[0]) for the marked edges (an edge marked from both of its ends clears
+// the same two bits twice)
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_at_edges_apply(const void *kmers_, uint32_t *mask32, uint64_t D0, unsigned k, RankIndex ix,
+                                                        const uint8_t *atflag, unsigned long long *stats, uint32_t *err) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
+        const unsigned fl = atflag[node];
+        if (!fl) continue;
+        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        Rec<NW> x = kmers[r];
+        if (o) x = rec_rc<NW>(x, k);
+        const unsigned firstn = rec_nucl<NW>(x, 0);
+        for (unsigned c = 0; c < 4; ++c) {
+            if (!(fl & (1u << c))) continue;
+            unsigned yo;
+            const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
+            const uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+            if (ry == NODE_NONE) {
+                atomicAdd(err, 1u);
+                continue;
+            }
+            atomicAnd(&mask32[r >> 2], ~((1u << (o ? 7 - c : c)) << ((r & 3) * 8)));
+            const unsigned p = 4 + firstn;
+            atomicAnd(&mask32[ry >> 2], ~((1u << (yo ? 7 - p : p)) << ((ry & 3) * 8)));
+            atomicAdd(&stats[2], 1ull);
+        }
+    }
+}
+// RemoveATTips, :262-338: from every dead end with a unique incoming extension walk back to the junction the tip hangs on (at most
+// max_len k-mers; succ[] of the opposite strand is the predecessor), count the last nucleotides of the tip k-mers (+ the root's up to
+// min_len), remove the tip if one nucleotide makes up >= thr_tip[max(n, min_len)] of them.
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const uint8_t *mask, const uint32_t *succ, uint64_t D0, unsigned k,
+                                                      RankIndex ix, uint32_t min_len, uint32_t max_len, const uint16_t *thr_tip,
+                                                      uint8_t *isolate, uint8_t *tipped, unsigned long long *stats, uint32_t *err) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
+        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        const unsigned m0 = mask[r];
+        const unsigned mo0 = o ? brev8(m0) : m0;
+        if ((mo0 & 15) != 0 || !uniq4((mo0 >> 4) & 15)) continue;  // start from tip ends
+        Rec<NW> x = kmers[r];
+        if (o) x = rec_rc<NW>(x, k);
+        unsigned cnt[4] = {0, 0, 0, 0};
+        uint32_t n = 0, nd = (uint32_t)node;
+        unsigned mo = mo0;
+        bool bad = false;
+        do {
+            ++n;
+            cnt[rec_nucl<NW>(x, k - 1)]++;
+            const unsigned cin = __ffs((mo >> 4) & 15) - 1;
+            x = rec_shr<NW>(x, k, cin);
+            if (n == 1) {  // the dead end is a junction k-mer: its predecessor comes from a lookup, the rest by pointer chasing
+                unsigned yo;
+                const Rec<NW> y = rec_canon<NW>(x, k, yo);
+                const uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+                if (ry == NODE_NONE) {
+                    bad = true;
+                    break;
+                }
+                nd = (ry << 1) | yo;
+            } else {
+                const uint32_t sp = succ[nd ^ 1];
+                if (sp == NODE_NONE) {
+                    bad = true;
+                    break;
+                }
+                nd = sp ^ 1;
+            }
+            const unsigned mm = mask[nd >> 1];
+            mo = (nd & 1) ? brev8(mm) : mm;
+        } while (n < max_len && !mask_junction(mo));
+        if (bad) {
+            atomicAdd(err, 1u);
+            continue;
+        }
+        if (((mo >> 4) & 15) == 0 || !mask_junction(mo)) continue;  // dead start, or the tip is too long
+        for (uint32_t i = n - 1; i < min_len; ++i) cnt[rec_nucl<NW>(x, k - 1 - i)]++;
+        const uint32_t curm = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));
+        if (curm < thr_tip[max(n, min_len)]) continue;
+        // second walk: IsolateVertex on the n tip k-mers
+        {
+            uint32_t q = (uint32_t)node;
+            Rec<NW> z = kmers[r];
+            if (o) z = rec_rc<NW>(z, k);
+            unsigned mq = mo0;
+            for (uint32_t i = 0; i < n; ++i) {
+                isolate[q >> 1] = 1;
+                if (i + 1 == n) break;
+                const unsigned cin = __ffs((mq >> 4) & 15) - 1;
+                z = rec_shr<NW>(z, k, cin);
+                if (i == 0) {
+                    unsigned yo;
+                    const Rec<NW> y = rec_canon<NW>(z, k, yo);
+                    q = (kmer_rank<NW>(kmers, ix, y) << 1) | yo;
+                } else {
+                    q = succ[q ^ 1] ^ 1;
+                }
+                const unsigned mm = mask[q >> 1];
+                mq = (q & 1) ? brev8(mm) : mm;
+            }
+        }
+        tipped[nd] = 1;
+        atomicAdd(&stats[0], (unsigned long long)n);
+        atomicAdd(&stats[1], 1ull);
+    }
+}
+
 // start de-edges per junction k-mer: out bits of kh, then out bits of !kh (AddStartDeEdges, :203-226)
 __global__ void k_cand_count(const uint8_t *mask, uint64_t D0, unsigned long long *cnt) {
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x) {

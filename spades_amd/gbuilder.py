@@ -52,10 +52,11 @@ class GraphBuilder:
         return self._info
 
     def tip_stats(self):
-        """(k-mers isolated, tips removed) by the early tip clipper of the last build (option early_tip_bound)."""
-        st = (C.c_uint64 * 2)()
+        """(k-mers isolated, tips removed) by the early tip clipper and (A/T edges, A/T tip k-mers) by the early A/T remover of the
+        last build (options early_tip_bound, early_at_remover)."""
+        st = (C.c_uint64 * 4)()
         _chk(self.ctx._h, self.ctx.lib.smx_graph_tip_stats(self.ctx._h, st))
-        return int(st[0]), int(st[1])
+        return int(st[0]), int(st[1]), int(st[2]), int(st[3])
 
     def kmers(self):
         n, nw = self._info["n_kmers"], self._info["words"]

@@ -231,7 +231,7 @@ def test_early_tip_clipper_matches_reference(case, tmp_path):
     """option early_tip_bound: spades-core's EarlyTipClipperProcessor on the extension masks before condensation; the unitig list
     equals the one of the reference classes (oracle/_ref/ref_earlytip goldens), order included"""
     reads = [r for r in read_lines(case["reads"]) if r]
-    r = _build(reads, case["K"], case["threads"], tmp_path, {"early_tip_bound": case["bound"]})
+    r = _build(reads, case["K"], case["threads"], tmp_path, {"early_tip_bound": case["bound"], "early_at_remover": int(case.get("at", 0))})
     want = open(os.path.join(GOLDEN, case["file"])).read().split("\n")[:-1]
     assert r["unitigs"] == want
 
@@ -252,4 +252,33 @@ def test_early_tip_clipper_vs_oracle_seeded(tmp_path):
         gb.write_gfa(out)
         assert open(out).read() == ref["gfa"] and len(ref["unitigs"]) < len(plain["unitigs"])
         assert gb.tip_stats()[1] > 0
+        gb.ctx.close()
+
+
+def test_early_at_remover_vs_oracle_seeded(tmp_path):
+    """RNA-pipeline variant: A/T edges + A/T tips removed, then the tip clipper; GFA identical to the oracle on a few thousand reads
+    with poly-A / low-complexity tails"""
+    from oracle import oracle
+    from test_count_gpu import _synth
+    from spades_amd.gbuilder import GraphBuilder
+    rng = np.random.default_rng(3)
+    reads = _synth(6, 20000, 4000, 150, err=0.005, nrate=0.0)
+    for i in range(400):
+        r = reads[int(rng.integers(0, 4000))]
+        cut = int(rng.integers(40, 120))
+        reads.append((r[:cut] + ["A", "T", "AT", "AAAAT"][i % 4] * 40)[:150])
+        reads.append(("A" * int(rng.integers(12, 45)) + r)[:150])
+    for k, t, bound in ((21, 1, 0), (33, 2, 117), (55, 1, 95)):
+        ref = oracle.build_graph(reads, k, 10 * t, early_tip_bound=bound, early_at=True)
+        plain = oracle.build_graph(reads, k, 10 * t, early_tip_bound=bound)
+        gb = GraphBuilder(k, t)
+        gb.ctx.set_option("early_at_remover", 1)
+        gb.ctx.set_option("early_tip_bound", bound)
+        gb.push_back_reads(reads)
+        gb.build()
+        out = os.path.join(str(tmp_path), "g.gfa")
+        gb.write_gfa(out)
+        assert open(out).read() == ref["gfa"] and ref["gfa"] != plain["gfa"]
+        st = gb.tip_stats()
+        assert st[2] > 0 or st[3] > 0
         gb.ctx.close()
