@@ -12,7 +12,9 @@
 //   early A/T remover (last argument "at"; RNA pipelines only, before the tip clipper):
 //                                     EarlyLowComplexityClipperProcessor(index, 0.8, 10, 200).RemoveATEdges() + RemoveATTips()
 //                                                                                                  early_simplification.hpp:164-347, construction.cpp:317-326
-//   ref_earlytip <k> <nthreads> <tip_length_bound|0> <reads.txt> <workdir> <out.txt> [at]
+//   spades-core edge order ("sorted" among the trailing arguments): the unitigs sorted by Sequence::RawCompare, as
+//                                     DeBruijnGraphExtentionConstructor::ConstructGraph does before ids are assigned   :590-604
+//   ref_earlytip <k> <nthreads> <tip_length_bound|0> <reads.txt> <workdir> <out.txt> [at] [sorted] [noloops]
 //   out.txt: one edge sequence per line in the extractor's order (nthreads = 1 makes the order and the clipping deterministic)
 #include "line_splitter.hpp"
 #include "kmer_index/extension_index/kmer_extension_index_builder.hpp"
@@ -42,14 +44,24 @@ int main(int argc, char **argv) {
         auto kpomers = counter.Count(10 * nthreads, nthreads);
         kmers::DeBruijnExtensionIndexBuilder().BuildExtensionIndexFromKPOMers(tmp, index, kpomers, nthreads, 0);
     }
-    if (argc > 7 && std::string(argv[7]) == "at") {
+    bool at = false, sorted = false, keep_loops = true;
+    for (int i = 7; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "at") at = true;
+        if (a == "sorted") sorted = true;
+        if (a == "noloops") keep_loops = false;
+    }
+    if (at) {
         debruijn_graph::EarlyLowComplexityClipperProcessor at_processor(index, 0.8, 10, 200);
         at_processor.RemoveATEdges();
         at_processor.RemoveATTips();
     }
     if (bound)
         debruijn_graph::EarlyTipClipperProcessor(index, bound).ClipTips();
-    auto seqs = debruijn_graph::UnbranchingPathExtractor(index, k).ExtractUnbranchingPathsAndLoops(10 * nthreads);
+    const unsigned nchunks = sorted ? 16 * nthreads : 10 * nthreads;  // :592 vs gbuilder
+    auto seqs = keep_loops ? debruijn_graph::UnbranchingPathExtractor(index, k).ExtractUnbranchingPathsAndLoops(nchunks)
+                           : debruijn_graph::UnbranchingPathExtractor(index, k).ExtractUnbranchingPaths(nchunks);
+    if (sorted) std::sort(seqs.begin(), seqs.end(), Sequence::RawCompare);
     std::ofstream os(outfile);
     for (const auto &s : seqs) os << s.str() << "\n";
     return 0;

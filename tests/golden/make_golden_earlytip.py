@@ -54,4 +54,20 @@ for name, K, T, bound, at in [("small", 21, 1, 129, 0), ("small", 21, 1, 10, 0),
                               "n_edges": data.count("\n"), "md5": hashlib.md5(data.encode()).hexdigest(), "file": fn,
                               "source": "oracle/_ref/ref_earlytip (reference EarlyTipClipperProcessor + UnbranchingPathExtractor)"})
     print(fn, data.count("\n"))
+# spades-core edge order: unitigs sorted with the reference's own Sequence::RawCompare (DeBruijnGraphExtentionConstructor, :590-604)
+manifest["cases"] = [c for c in manifest["cases"] if c["kind"] != "sorted_edges"]
+for name, K, T, loops, at, bound in [("small", 21, 1, 1, 0, 0), ("mixed", 33, 2, 1, 0, 0), ("mixed", 21, 1, 0, 0, 0), ("at", 55, 1, 1, 1, 95),
+                                     ("loop", 21, 1, 1, 0, 0), ("loop", 21, 1, 0, 0, 0), ("small", 55, 3, 1, 0, 95)]:
+    reads = os.path.join(HERE, f"reads_{name}.txt")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.txt")
+        subprocess.check_call([REF, str(K), str(T), str(bound), reads, os.path.join(td, "w"), out, "sorted"] + (["at"] if at else []) +
+                              ([] if loops else ["noloops"]), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        data = open(out).read()
+    fn = f"sorted_{name}_k{K}_t{T}_l{loops}_b{bound}{'_at' if at else ''}.txt"
+    open(os.path.join(HERE, fn), "w").write(data)
+    manifest["cases"].append({"kind": "sorted_edges", "reads": f"reads_{name}.txt", "K": K, "threads": T, "num_buckets": 10 * T, "keep_loops": loops,
+                              "at": at, "bound": bound, "n_edges": data.count("\n"), "md5": hashlib.md5(data.encode()).hexdigest(), "file": fn,
+                              "source": "oracle/_ref/ref_earlytip sorted (reference extractor + Sequence::RawCompare)"})
+    print(fn, data.count("\n"))
 json.dump(manifest, open(mf, "w"), indent=1)

@@ -91,8 +91,8 @@ def test_fastg_matches_gbuilder(case, tmp_path):
 
 
 def test_spades_core_variant_sorted_edges(tmp_path):
-    """DeBruijnGraphExtentionConstructor order (RawCompare-sorted unitigs; thread-independent ids) vs the oracle's restatement.
-    No spades-core golden exists for this variant (parity unpinned for the order rule); invariants checked as well."""
+    """DeBruijnGraphExtentionConstructor order (RawCompare-sorted unitigs; thread-independent ids) vs the oracle's restatement
+    (the order rule itself is pinned by test_spades_core_edge_order_matches_reference); invariants checked as well."""
     from oracle import oracle
     reads = _synth(77, 5000, 1200, 150) + _synth(9, 500, 60, 100, err=0.0, nrate=0.0, circ=True)
     outs = []
@@ -282,3 +282,16 @@ def test_early_at_remover_vs_oracle_seeded(tmp_path):
         st = gb.tip_stats()
         assert st[2] > 0 or st[3] > 0
         gb.ctx.close()
+
+
+SORTED_CASES = [c for c in load_manifest()["cases"] if c["kind"] == "sorted_edges"]
+
+
+@pytest.mark.parametrize("case", SORTED_CASES, ids=lambda c: c["file"][7:-4])
+def test_spades_core_edge_order_matches_reference(case, tmp_path):
+    """option sort_edges (+ keep_perfect_loops, early clippers): the unitig list equals the reference extractor's output sorted with
+    the reference's own Sequence::RawCompare (oracle/_ref/ref_earlytip ... sorted)"""
+    reads = [r for r in read_lines(case["reads"]) if r]
+    r = _build(reads, case["K"], case["threads"], tmp_path, {"sort_edges": 1, "keep_perfect_loops": case["keep_loops"],
+                                                              "early_tip_bound": case["bound"], "early_at_remover": case["at"]})
+    assert r["unitigs"] == open(os.path.join(GOLDEN, case["file"])).read().split("\n")[:-1]

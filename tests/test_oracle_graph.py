@@ -95,3 +95,16 @@ def test_oracle_early_tip_clipper_matches_reference(case):
     g = oracle.build_graph(reads, case["K"], case["num_buckets"], early_tip_bound=case["bound"], early_at=bool(case.get("at")))
     want = open(os.path.join(GOLDEN, case["file"])).read().split("\n")[:-1]
     assert g["unitigs"] == want
+
+
+SCASES = [c for c in load_manifest()["cases"] if c["kind"] == "sorted_edges"]
+
+
+@pytest.mark.parametrize("case", SCASES, ids=lambda c: c["file"][7:-4])
+def test_oracle_spades_core_edge_order_matches_reference(case):
+    """DeBruijnGraphExtentionConstructor::ConstructGraph (debruijn_graph_constructor.hpp:590-604): unitigs (with or without perfect
+    loops) sorted by the reference's own Sequence::RawCompare = the oracle's sort_edges order"""
+    reads = [r for r in read_lines(case["reads"]) if r]
+    g = oracle.build_graph(reads, case["K"], case["num_buckets"], sort_edges=True, keep_loops=bool(case["keep_loops"]),
+                           early_tip_bound=case["bound"], early_at=bool(case["at"]))
+    assert g["unitigs"] == open(os.path.join(GOLDEN, case["file"])).read().split("\n")[:-1]
