@@ -169,6 +169,8 @@ int smx_graph_copy_unitigs(const smx_ctx *ctx, uint64_t *offsets, char *seq);
  * (common/kmer_index/ph_map/coverage_hash_map_builder.hpp:16-57) + FillCoverageAndFlankingFromPHM
  * (common/assembly_graph/graph_support/coverage_filling.hpp:17-96): per-(k+1)-mer uint32 multiplicities over the read+RC
  * stream, summed per edge. Afterwards smx_graph_write_gfa emits DP:f:<raw/len>  KC:i:<raw> instead of zeros. */
+/* Reads submitted while the option "submit_contigs" is 1 (trusted contigs, contigs of the previous k) take part in the construction
+ * but are not counted here — "Has to be separate stream for not counting it in coverage" (stages/construction.cpp:108-117). */
 int smx_graph_fill_coverage(smx_ctx *ctx);
 int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage /* [n_unitigs] */);
 /* gfa::GFAWriter::WriteSegmentsAndLinks (common/io/graph/gfa_writer.cpp); flavour_version fills "H\tsp:Z:<..>" */

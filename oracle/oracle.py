@@ -135,12 +135,13 @@ def count_raw(bases: bytes, off: np.ndarray, K: int, mode: str = "A", num_bucket
 
 
 def build_graph(reads: Sequence[str], k: int, num_buckets: int, flavour_version: str = "SPAdes-4.3.0-dev", coverage: bool = False,
-                sort_edges: bool = False, keep_loops: bool = True, early_tip_bound: int = 0, early_at: bool = False) -> dict:
+                sort_edges: bool = False, keep_loops: bool = True, early_tip_bound: int = 0, early_at: bool = False, coverage_reads: int = 0) -> dict:
     """spades-gbuilder restated: -> dict(kmers, masks, unitigs (list of str, reference order), n_loops, gfa (str), ...)."""
     bases, off = concat_reads(reads)
     off = np.ascontiguousarray(off, dtype=np.uint64)
     lib().orc_set_early_tip_bound(C.c_uint64(early_tip_bound))
     lib().orc_set_early_at_remover(1 if early_at else 0)
+    lib().orc_set_coverage_reads(C.c_uint64(coverage_reads))
     g = lib().orc_build_graph_ex(k, num_buckets, bases, off.ctypes.data_as(C.POINTER(C.c_uint64)), len(off) - 1,
                                  flavour_version.encode(), 1 if coverage else 0, 1 if sort_edges else 0, 1 if keep_loops else 0)
     gc = g.contents
@@ -157,4 +158,5 @@ def build_graph(reads: Sequence[str], k: int, num_buckets: int, flavour_version:
     lib().orc_graph_free(g)
     lib().orc_set_early_tip_bound(C.c_uint64(0))
     lib().orc_set_early_at_remover(0)
+    lib().orc_set_coverage_reads(C.c_uint64(0))
     return res

@@ -78,6 +78,9 @@ void orc_set_early_tip_bound(uint64_t bound);
 /* RNA pipelines only: EarlyLowComplexityClipperProcessor(index, 0.8, 10, 200).RemoveATEdges() + RemoveATTips() before the tip clipper
  * (early_simplification.hpp:164-347, stages/construction.cpp:317-326, 446-448) */
 void orc_set_early_at_remover(int on);
+/* coverage from the first n reads only (0 = all): contigs of a previous k / trusted contigs shape the graph but are not counted
+ * (stages/construction.cpp:108-117) */
+void orc_set_coverage_reads(uint64_t n);
 orc_graph *orc_build_graph_ex(unsigned k, unsigned num_buckets, const char *bases, const uint64_t *off, uint64_t nreads,
                               const char *flavour_version, int with_cov, int sort_edges, int keep_loops);
 void orc_graph_free(orc_graph *g);

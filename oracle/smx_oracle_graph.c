@@ -308,6 +308,10 @@ static size_t at_remove_tips(kidx *ix, double ratio, size_t min_len, size_t max_
 }
 static int g_early_at = 0;
 void orc_set_early_at_remover(int on) { g_early_at = on; }
+/* spades-core: trusted / previous-k contigs take part in the construction but are "separate streams for not counting it in
+ * coverage" (stages/construction.cpp:108-117, 371-435): only the first g_cov_reads reads are counted (0 = all of them) */
+static uint64_t g_cov_reads = 0;
+void orc_set_coverage_reads(uint64_t n) { g_cov_reads = n; }
 
 /* 0 = off (spades-gbuilder); set by orc_set_early_tip_bound before orc_build_graph_* for the spades-core variant */
 static size_t g_early_tip_bound = 0;
@@ -587,7 +591,7 @@ orc_graph *orc_build_graph_ex(unsigned k, unsigned num_buckets, const char *base
         for (unsigned bb = 0; bb < num_buckets; ++bb) kx.boff[bb + 1] = kx.boff[bb] + kpo_sizes[bb];
         uint32_t *cnt = (uint32_t *)calloc((size_t)nkpo, 4);
         unsigned char *fw = NULL, *rc = NULL; size_t bc = 0;
-        for (uint64_t r = 0; r < nreads; ++r) {
+        for (uint64_t r = 0; r < (g_cov_reads ? (g_cov_reads < nreads ? g_cov_reads : nreads) : nreads); ++r) {
             const char *sq = bases + off[r]; size_t n = (size_t)(off[r + 1] - off[r]), from, to;
             orc_longest_valid(sq, n, &from, &to);
             size_t len = to - from;

@@ -28,6 +28,7 @@ struct ReadChunk {
     uint32_t *d_len = nullptr;
     uint64_t n_words = 0, n_reads = 0, n_bases = 0;
     bool owned = true;
+    bool contigs = false;  // takes part in the construction, not in the coverage (trusted / previous-k contigs)
 };
 
 struct Timing {
@@ -52,6 +53,7 @@ struct smx_ctx {
     // tuning / test hooks
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;
+    int64_t opt_submit_contigs = 0;   // reads submitted while this is 1 are contigs: construction yes, coverage no
     int64_t opt_early_at = 0;         // 1: the early A/T remover of the RNA pipelines before the tip clipper
     int64_t opt_early_tip_bound = 0;  // > 0: spades-core's early tip clipper with this length bound (RL - K there) before condensation
     int64_t opt_skm_stage = 1;     // pass 0 of the super-k-mer scan stages its output so that placing it needs no second scan
@@ -1693,7 +1695,7 @@ int run_coverage(smx_ctx *ctx) {
     tbegin(ctx, "kpo_coverage");
     for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
         const ReadChunk &ch = ctx->chunks[ci];
-        if (ch.n_bases == 0 || !masks[ci]) continue;
+        if (ch.n_bases == 0 || !masks[ci] || ch.contigs) continue;  // contigs: "separate stream for not counting it in coverage"
         hipLaunchKernelGGL((k_kpo_coverage<NW>), dim3((unsigned)std::min<uint64_t>((ch.n_bases + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0,
                            ctx->stream, (const uint64_t *)ch.d_words, (const uint64_t *)masks[ci], ch.n_bases, K1, (const void *)ctx->g_kpo, ixp, cnt);
         HIPCHK(hipGetLastError());
@@ -1774,6 +1776,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "skm_stage")) ctx->opt_skm_stage = value;
     else if (!strcmp(key, "early_tip_bound")) ctx->opt_early_tip_bound = value;
     else if (!strcmp(key, "early_at_remover")) ctx->opt_early_at = value;
+    else if (!strcmp(key, "submit_contigs")) ctx->opt_submit_contigs = value;
     else if (!strcmp(key, "skm_cap")) ctx->opt_skm_cap = value;
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
@@ -1818,6 +1821,7 @@ int smx_submit_reads_packed(smx_ctx *ctx, const uint64_t *words, uint64_t n_word
     HIPCHK(hipMemcpyAsync(c.d_start, start, n_reads * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(c.d_len, len, n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    c.contigs = ctx->opt_submit_contigs != 0;
     ctx->chunks.push_back(c);
     return SMX_OK;
 }
@@ -1859,6 +1863,7 @@ int smx_submit_reads_ascii(smx_ctx *ctx, const char *bases, const uint64_t *offs
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     free_temps(ctx);
+    c.contigs = ctx->opt_submit_contigs != 0;
     ctx->chunks.push_back(c);
     return SMX_OK;
 }
@@ -1982,6 +1987,7 @@ int smx_submit_fastq_text(smx_ctx *ctx, const char *text, uint64_t n_bytes, int 
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     free_temps(ctx);
+    c.contigs = ctx->opt_submit_contigs != 0;
     ctx->chunks.push_back(c);
     if (n_reads) *n_reads = n_rec;
     if (consumed) *consumed = (virt && n_rec * 4 == n_nl + 1) ? n_bytes : cons;
@@ -2014,6 +2020,7 @@ int smx_submit_reads_device(smx_ctx *ctx, const void *d_words, uint64_t n_words,
     c.n_reads = n_reads;
     c.n_bases = n_words * 32;
     c.owned = false;
+    c.contigs = ctx->opt_submit_contigs != 0;
     ctx->chunks.push_back(c);
     return SMX_OK;
 }

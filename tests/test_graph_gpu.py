@@ -295,3 +295,26 @@ def test_spades_core_edge_order_matches_reference(case, tmp_path):
     r = _build(reads, case["K"], case["threads"], tmp_path, {"sort_edges": 1, "keep_perfect_loops": case["keep_loops"],
                                                               "early_tip_bound": case["bound"], "early_at_remover": case["at"]})
     assert r["unitigs"] == open(os.path.join(GOLDEN, case["file"])).read().split("\n")[:-1]
+
+
+def test_previous_k_contigs_shape_the_graph_but_not_the_coverage(tmp_path):
+    """spades.py's iterative multi-k loop: the contigs of the previous k are extra streams of the construction that are not counted
+    in coverage (stages/construction.cpp:108-117, 371-435): option submit_contigs"""
+    from oracle import oracle
+    from spades_amd.gbuilder import GraphBuilder
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    contigs = [u for u in oracle.build_graph(reads, 21, 10)["unitigs"] if len(u) >= 56][:60] + ["ACGTTGCAAGGCTAGCTAGGATCGATCGGATCGATTTAGCGCGATATCGAGCTAGGGATCCGAT"]
+    for k in (33, 55):
+        ref = oracle.build_graph(reads + contigs, k, 10, coverage=True, coverage_reads=len(reads))
+        both = oracle.build_graph(reads + contigs, k, 10, coverage=True)
+        gb = GraphBuilder(k, 1)
+        gb.push_back_reads(reads)
+        gb.ctx.set_option("submit_contigs", 1)
+        gb.push_back_reads(contigs)
+        gb.ctx.set_option("submit_contigs", 0)
+        gb.build()
+        gb.fill_coverage()
+        out = os.path.join(str(tmp_path), "g.gfa")
+        gb.write_gfa(out)
+        assert open(out).read() == ref["gfa"] and ref["gfa"] != both["gfa"]
+        gb.ctx.close()
