@@ -173,6 +173,11 @@ int smx_graph_copy_unitigs(const smx_ctx *ctx, uint64_t *offsets, char *seq);
  * but are not counted here — "Has to be separate stream for not counting it in coverage" (stages/construction.cpp:108-117). */
 int smx_graph_fill_coverage(smx_ctx *ctx);
 int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage /* [n_unitigs] */);
+/* Flanking raw coverage, filled by the same pass (FillCoverageAndFlankingFromPHM, graph_support/coverage_filling.hpp:40-44,89-96;
+ * omnigraph::FlankingCoverage, detail_coverage.hpp:22-100): sum of the counters of the first `flank_range` (option, default 50 as in
+ * spades-core) (k+1)-mers of every canonical edge, and of its conjugate (= the last ones). Values restated from the reference source,
+ * not pinned by a reference run (spades-gbuilder does not compute them). */
+int smx_graph_copy_flanking(const smx_ctx *ctx, uint32_t *flank_edge /* [n_unitigs] */, uint32_t *flank_conjugate /* [n_unitigs] */);
 /* gfa::GFAWriter::WriteSegmentsAndLinks (common/io/graph/gfa_writer.cpp); flavour_version fills "H\tsp:Z:<..>" */
 int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_version);
 /* gbuilder --fastg (gbuilder.cpp:226-228): io::FastgWriter::WriteSegmentsAndLinks (common/io/graph/fastg_writer.cpp:21-48) */

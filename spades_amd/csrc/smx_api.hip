@@ -53,6 +53,7 @@ struct smx_ctx {
     // tuning / test hooks
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;
+    int64_t opt_flank_range = 50;     // FlankingCoverage averaging range ((k+1)-mers at either end of an edge)
     int64_t opt_submit_contigs = 0;   // reads submitted while this is 1 are contigs: construction yes, coverage no
     int64_t opt_early_at = 0;         // 1: the early A/T remover of the RNA pipelines before the tip clipper
     int64_t opt_early_tip_bound = 0;  // > 0: spades-core's early tip clipper with this length bound (RL - K there) before condensation
@@ -1678,15 +1679,19 @@ int run_coverage(smx_ctx *ctx) {
     std::vector<uint64_t *> masks;
     uint64_t nwin = 0;
     if (int rc = mark_windows(ctx, K1, masks, &nwin)) return rc;
-    uint32_t *cnt, *ecov;
+    uint32_t *cnt, *ecov, *fls, *fle;
     unsigned long long *d_eoff;
     char *d_seq;
     if (int rc = dalloc(ctx, &cnt, D1)) return rc;
     if (int rc = dalloc(ctx, &ecov, ne)) return rc;
+    if (int rc = dalloc(ctx, &fls, ne)) return rc;
+    if (int rc = dalloc(ctx, &fle, ne)) return rc;
     if (int rc = dalloc(ctx, &d_eoff, ne + 1)) return rc;
     if (int rc = dalloc(ctx, &d_seq, ctx->gh.seq.size() + 1)) return rc;
     HIPCHK(hipMemsetAsync(cnt, 0, D1 * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ecov, 0, ne * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(fls, 0, ne * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(fle, 0, ne * 4, ctx->stream));
     std::vector<unsigned long long> he(ctx->gh.eoff.begin(), ctx->gh.eoff.end());
     const smx::RankIndex ixp = ctx->g_ix_kpo;
     HIPCHK(hipMemcpyAsync(d_eoff, he.data(), (ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1705,10 +1710,14 @@ int run_coverage(smx_ctx *ctx) {
     const uint64_t total = ctx->gh.seq.size();
     hipLaunchKernelGGL((k_edge_coverage<NW>), dim3((unsigned)std::min<uint64_t>((total + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
                        (const char *)d_seq, (const unsigned long long *)d_eoff, ne, total, K1, (const void *)ctx->g_kpo, ixp,
-                       (const uint32_t *)cnt, ecov);
+                       (const uint32_t *)cnt, ecov, (uint32_t)std::max<int64_t>(ctx->opt_flank_range, 1), fls, fle);
     HIPCHK(hipGetLastError());
     tend(ctx);
+    ctx->gh.eflank_s.assign(ne, 0);
+    ctx->gh.eflank_e.assign(ne, 0);
     HIPCHK(hipMemcpyAsync(ctx->gh.ecov.data(), ecov, ne * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->gh.eflank_s.data(), fls, ne * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->gh.eflank_e.data(), fle, ne * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -1777,6 +1786,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "early_tip_bound")) ctx->opt_early_tip_bound = value;
     else if (!strcmp(key, "early_at_remover")) ctx->opt_early_at = value;
     else if (!strcmp(key, "submit_contigs")) ctx->opt_submit_contigs = value;
+    else if (!strcmp(key, "flank_range")) ctx->opt_flank_range = value;
     else if (!strcmp(key, "skm_cap")) ctx->opt_skm_cap = value;
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
@@ -2286,6 +2296,15 @@ int smx_graph_fill_coverage(smx_ctx *ctx) {
     }
     free_temps(ctx);
     return rc;
+}
+
+int smx_graph_copy_flanking(const smx_ctx *ctx, uint32_t *flank_edge, uint32_t *flank_conjugate) {
+    if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
+    const size_t ne = ctx->gh.n_edges();
+    if (ctx->gh.eflank_s.size() != ne || ctx->gh.eflank_e.size() != ne) return SMX_INVALID_PARAMETER;
+    if (ne && flank_edge) memcpy(flank_edge, ctx->gh.eflank_s.data(), ne * 4);
+    if (ne && flank_conjugate) memcpy(flank_conjugate, ctx->gh.eflank_e.data(), ne * 4);
+    return SMX_OK;
 }
 
 int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage) {

@@ -620,11 +620,13 @@ __global__ void __launch_bounds__(BLK) k_kpo_coverage(const uint64_t *seq, const
     }
 }
 
-// edge raw coverage = sum of the counters of the edge's (k+1)-mers (graph_support/coverage_filling.hpp:46-62), uint32
+// edge raw coverage = sum of the counters of the edge's (k+1)-mers (graph_support/coverage_filling.hpp:46-62), uint32; flanking raw
+// coverage = the same sum over the first `flank` (k+1)-mers (inc_coverage: offset < averaging_range, :40-44) of the edge (fl_s) and
+// of its conjugate, i.e. the last `flank` ones (fl_e)
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_edge_coverage(const char *seq, const unsigned long long *eoff, uint64_t n_edges, uint64_t total,
                                                        unsigned K1, const void *kpo_, RankIndex ix,
-                                                       const uint32_t *cnt, uint32_t *ecov) {
+                                                       const uint32_t *cnt, uint32_t *ecov, uint32_t flank, uint32_t *fl_s, uint32_t *fl_e) {
     const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
     for (uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x; p < total; p += (uint64_t)gridDim.x * BLK) {
         uint64_t lo = 0, hi = n_edges;  // edge e with eoff[e] <= p < eoff[e+1]
@@ -644,7 +646,13 @@ __global__ void __launch_bounds__(BLK) k_edge_coverage(const char *seq, const un
         unsigned f;
         const Rec<NW> c = rec_canon<NW>(x, K1, f);
         const uint32_t r = kmer_rank<NW>(kpo, ix, c);
-        if (r != NODE_NONE) atomicAdd(&ecov[lo], cnt[r]);
+        if (r != NODE_NONE) {
+            const uint32_t v = cnt[r];
+            atomicAdd(&ecov[lo], v);
+            const uint64_t j = p - eoff[lo], nk = eoff[lo + 1] - eoff[lo] - K1 + 1;
+            if (j < flank) atomicAdd(&fl_s[lo], v);
+            if (j + flank >= nk) atomicAdd(&fl_e[lo], v);
+        }
     }
 }
 

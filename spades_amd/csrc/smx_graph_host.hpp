@@ -32,6 +32,7 @@ struct GraphHost {
     std::vector<uint32_t> eend;    // node of the last k-mer
     std::vector<uint8_t> eself;    // s == RC(s)
     std::vector<uint32_t> ecov;    // raw coverage per edge (filled by smx_graph_fill_coverage; empty = no -c)
+    std::vector<uint32_t> eflank_s, eflank_e;  // flanking raw coverage of the edge and of its conjugate (first / last 50 (k+1)-mers)
     uint64_t n_paths = 0, n_loops = 0, n_vertices = 0, n_links = 0;
     // link structure
     struct Rec {

@@ -82,6 +82,14 @@ class GraphBuilder:
         _chk(self.ctx._h, self.ctx.lib.smx_graph_copy_coverage(self.ctx._h, out.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out
 
+    def flanking_coverage(self):
+        """(flank of every canonical edge, flank of its conjugate): raw counts over the first / last `flank_range` (k+1)-mers."""
+        a = np.zeros(self._info["n_unitigs"], dtype=np.uint32)
+        b = np.zeros(self._info["n_unitigs"], dtype=np.uint32)
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_copy_flanking(self.ctx._h, a.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                                b.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return a, b
+
     # -- step 4: outputs --
     def write_gfa(self, path: str, flavour_version: str = "SPAdes-4.3.0-dev"):
         _chk(self.ctx._h, self.ctx.lib.smx_graph_write_gfa(self.ctx._h, path.encode(), flavour_version.encode()))

@@ -318,3 +318,32 @@ def test_previous_k_contigs_shape_the_graph_but_not_the_coverage(tmp_path):
         gb.write_gfa(out)
         assert open(out).read() == ref["gfa"] and ref["gfa"] != both["gfa"]
         gb.ctx.close()
+
+
+def test_flanking_coverage_is_the_coverage_of_the_edge_ends(tmp_path):
+    """FlankingCoverage (graph_support/coverage_filling.hpp:40-44): raw counts over the first 50 (k+1)-mers of an edge and of its
+    conjugate, checked against per-(k+1)-mer counts recomputed on the host from the reads"""
+    from collections import Counter
+    from spades_amd.gbuilder import GraphBuilder
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    tr = str.maketrans("ACGT", "TGCA")
+    for k, R in ((21, 50), (55, 7)):
+        K1 = k + 1
+        c = Counter()
+        for r in reads:
+            for s in max(("".join(ch if ch in "ACGT" else " " for ch in r.upper())).split(), key=len, default="").split():
+                for j in range(len(s) - K1 + 1):
+                    x = s[j:j + K1]
+                    y = x[::-1].translate(tr)
+                    c[min(x, y)] += 2 if x == y else 1
+        gb = GraphBuilder(k, 1)
+        gb.ctx.set_option("flank_range", R)
+        gb.push_back_reads(reads)
+        gb.build()
+        gb.fill_coverage()
+        fs, fe = gb.flanking_coverage()
+        raw = gb.raw_coverage()
+        for i, u in enumerate(gb.unitigs()):
+            cnt = [c[min(u[j:j + K1], u[j:j + K1][::-1].translate(tr))] for j in range(len(u) - K1 + 1)]
+            assert raw[i] == sum(cnt) and fs[i] == sum(cnt[:R]) and fe[i] == sum(cnt[-R:])
+        gb.ctx.close()
