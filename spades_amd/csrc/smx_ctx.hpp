@@ -1,0 +1,236 @@
+// spades_amd/csrc/smx_ctx.hpp — the context behind the C ABI: resident read chunks, result view, options, grow-only device
+// arena, temp bookkeeping, stage timers (included by smx_api.hip; one translation unit).
+#pragma once
+
+namespace {
+
+struct ReadChunk {
+    uint64_t *d_words = nullptr;
+    uint64_t *d_start = nullptr;
+    uint32_t *d_len = nullptr;
+    uint64_t n_words = 0, n_reads = 0, n_bases = 0;
+    bool owned = true;
+    bool contigs = false;  // takes part in the construction, not in the coverage (trusted / previous-k contigs)
+};
+
+struct Timing {
+    std::string name;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct smx_ctx {
+    int device = 0;
+    size_t budget = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<ReadChunk> chunks;
+    // result of the last count
+    void *d_result_buf = nullptr;  // allocation holding the result
+    void *d_result = nullptr;
+    uint64_t n_records = 0, n_instances = 0;
+    unsigned nw = 0, K = 0, num_buckets = 0;
+    std::vector<uint64_t> bucket_off;
+    // tuning / test hooks
+    int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
+    int64_t opt_sort_edges = 0, opt_keep_loops = 1;
+    int64_t opt_flank_range = 50;     // FlankingCoverage averaging range ((k+1)-mers at either end of an edge)
+    int64_t opt_submit_contigs = 0;   // reads submitted while this is 1 are contigs: construction yes, coverage no
+    int64_t opt_early_at = 0;         // 1: the early A/T remover of the RNA pipelines before the tip clipper
+    int64_t opt_early_tip_bound = 0;  // > 0: spades-core's early tip clipper with this length bound (RL - K there) before condensation
+    int64_t opt_skm_stage = 1;     // pass 0 of the super-k-mer scan stages its output so that placing it needs no second scan
+    int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
+    int64_t opt_joint_hist = 1;  // fuse the level-2 histogram into the level-1 histogram pass (records source)
+    int64_t opt_prededupe = -1;  // super-k-mer pre-deduplication: -1 auto, 0 off, 1 on whenever K allows it
+    int64_t opt_skm_cap = 0;     // instances per LDS dedupe chunk (0 = default)
+    int64_t opt_skm_scap = 0;    // slots staged per chunk (0 = default)
+    int64_t opt_leaf_grid = 0, opt_leaf_tab = 0;  // tuning experiments (tools/sweep.py)  // spades-core construction variant (debruijn_graph_constructor.hpp:590-604)
+    // timings
+    std::vector<Timing> timings;
+    std::vector<std::string> tnames, xnames;  // last count stages / last extract_partition stages
+    std::vector<float> tms, xms;
+    std::vector<void *> temps;  // allocations of the pipeline in flight
+    // grow-only device arena: blocks are recycled across calls (hipMalloc/hipFree of tens of GB stalls for seconds)
+    std::vector<std::pair<void *, size_t>> arena_free;  // cached blocks
+    std::unordered_map<void *, size_t> arena_size;      // every live or cached block -> bytes
+    // construction state (smx_build_graph)
+    void *g_kpo = nullptr, *g_kmers = nullptr;
+    uint8_t *g_mask = nullptr;
+    uint64_t g_nkpo = 0, g_nkmers = 0;
+    unsigned g_k = 0, g_nw = 0, g_B = 0;
+    std::vector<uint64_t> g_kboff, g_kpoboff;
+    // fine-bin offsets of the last pipeline run (rank lookups of the construction stage), kept when want_index is set
+    bool want_index = false;
+    unsigned long long *last_idx_off = nullptr;
+    uint64_t last_idx_bins = 0;
+    uint32_t last_idx_S1 = 1;
+    std::vector<uint32_t> last_idx_f;
+    smx::RankIndex g_ix_kmers{}, g_ix_kpo{};  // .off owned by the graph state
+    bool g_ready = false;
+    uint64_t g_tip_kmers = 0, g_tips = 0;  // early tip clipper: k-mers isolated, tips removed
+    uint64_t g_at_edges = 0, g_at_tip_kmers = 0;  // early A/T remover: length-1 edges marked, tip k-mers isolated
+    smxh::GraphHost gh;
+};
+
+namespace {
+
+int fail(smx_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? SMX_MEMORY_LIMIT_EXCEEDED : SMX_DEVICE_ERROR,        \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);           \
+    } while (0)
+
+void *arena_get(smx_ctx *ctx, size_t bytes) {
+    // best fit among cached blocks that waste at most 2x
+    size_t best = (size_t)-1, bi = 0;
+    for (size_t i = 0; i < ctx->arena_free.size(); ++i) {
+        size_t sz = ctx->arena_free[i].second;
+        if (sz >= bytes && sz <= 2 * bytes + (1u << 20) && sz < best) {
+            best = sz;
+            bi = i;
+        }
+    }
+    if (best != (size_t)-1) {
+        void *p = ctx->arena_free[bi].first;
+        ctx->arena_free.erase(ctx->arena_free.begin() + bi);
+        return p;
+    }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {  // release the cache and retry once
+        (void)hipGetLastError();
+        for (auto &b : ctx->arena_free) {
+            ctx->arena_size.erase(b.first);
+            (void)hipFree(b.first);
+        }
+        ctx->arena_free.clear();
+        e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    ctx->arena_size[q] = bytes;
+    return q;
+}
+void arena_put(smx_ctx *ctx, void *p) {
+    if (!p) return;
+    auto it = ctx->arena_size.find(p);
+    if (it == ctx->arena_size.end()) {
+        (void)hipFree(p);
+        return;
+    }
+    ctx->arena_free.emplace_back(p, it->second);
+}
+void arena_release(smx_ctx *ctx) {
+    for (auto &b : ctx->arena_free) {
+        ctx->arena_size.erase(b.first);
+        (void)hipFree(b.first);
+    }
+    ctx->arena_free.clear();
+}
+
+template <typename T>
+int dalloc(smx_ctx *ctx, T **p, size_t count, bool temp = true) {
+    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    void *q = arena_get(ctx, bytes);
+    if (!q) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "device allocation of %zu bytes failed", bytes);
+    if (temp) ctx->temps.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+
+void free_temps(smx_ctx *ctx, void *keep = nullptr) {
+    for (void *p : ctx->temps)
+        if (p != keep) arena_put(ctx, p);
+    ctx->temps.clear();
+}
+
+double wall_now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+struct WallTrace {  // SMX_DEBUG=1: host wall-clock per pipeline section (includes allocation / implicit syncs)
+    bool on;
+    double t;
+    WallTrace() : on(getenv("SMX_DEBUG") != nullptr), t(wall_now()) {}
+    void mark(smx_ctx *ctx, const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        double n = wall_now();
+        fprintf(stderr, "[smx] %-14s %8.2f ms\n", what, (n - t) * 1e3);
+        t = n;
+    }
+};
+
+void tbegin(smx_ctx *ctx, const char *name) {
+    Timing t;
+    t.name = name;
+    (void)hipEventCreate(&t.e0);
+    (void)hipEventCreate(&t.e1);
+    (void)hipEventRecord(t.e0, ctx->stream);
+    ctx->timings.push_back(t);
+}
+void tend(smx_ctx *ctx) { (void)hipEventRecord(ctx->timings.back().e1, ctx->stream); }
+void tcollect(smx_ctx *ctx) {
+    ctx->tnames.clear();
+    ctx->tms.clear();
+    for (auto &t : ctx->timings) {
+        float ms = 0;
+        (void)hipEventSynchronize(t.e1);
+        (void)hipEventElapsedTime(&ms, t.e0, t.e1);
+        ctx->tnames.push_back(t.name);
+        ctx->tms.push_back(ms);
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    ctx->timings.clear();
+}
+
+unsigned ceil_log2(uint64_t v) {
+    unsigned r = 0;
+    while ((1ull << r) < v) ++r;
+    return r;
+}
+
+template <typename KernelT>
+int set_lds(smx_ctx *ctx, KernelT k, size_t bytes) {
+    if (bytes > 160 * 1024) return fail(ctx, SMX_INVALID_PARAMETER, "LDS request %zu exceeds 160 KiB", bytes);
+    if (bytes > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+// exclusive scan of n u64 values, out has n+1 entries (out[n] = total)
+int scan_u64(smx_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint64_t n) {
+    if (n <= 8192) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(BLK), 0, ctx->stream, in, out, (uint32_t)n);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    uint64_t nt = (n + SCAN_TILE - 1) / SCAN_TILE;
+    unsigned long long *partial, *poff;
+    if (int rc = dalloc(ctx, &partial, nt)) return rc;
+    if (int rc = dalloc(ctx, &poff, nt + 1)) return rc;
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nt), dim3(BLK), 0, ctx->stream, in, n, partial);
+    HIPCHK(hipGetLastError());
+    if (int rc = scan_u64(ctx, partial, poff, nt)) return rc;
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nt), dim3(BLK), 0, ctx->stream, in, n, poff, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace

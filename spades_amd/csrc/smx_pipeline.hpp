@@ -1,0 +1,889 @@
+// spades_amd/csrc/smx_pipeline.hpp — host side of the counting path: level plan + launches of the sort/unique pipeline (run_count),
+// the super-k-mer pre-dedupe stage (run_prededupe), HBM-bounded batches (count_reads) and the owner partition of the sharded path
+// (included by smx_api.hip after smx_ctx.hpp).
+#pragma once
+
+namespace {
+template <int NW>
+struct Tune {
+    static constexpr int RPT = (NW <= 2) ? 16 : 8;                        // records per thread in a scatter tile (RPT 8 at NW=2: L1 scatter 32.5 vs 20.6 ms)
+    // LDS leaf classes: CAP1 = the common class (small LDS footprint -> 3-4 workgroups per CU), CAP = 4*CAP1 for skewed bins.
+    // Sweep at 10 M reads (tools/sweep.py): k=55 cap 2048/avg 915 -> 40.6 ms, cap 1024/avg 915 -> 20.2 ms; k=21 cap 4096 -> 72.7, 2048 -> 27.9 ms
+    static constexpr uint32_t CAP1 = (NW == 1) ? 2048 : (NW == 2 ? 1024 : 512);
+    static constexpr uint32_t CAP = (NW == 1 ? 2 : 4) * CAP1;  // second class must still fit 160 KiB of LDS
+    static constexpr int LPT1 = CAP1 / BLK;
+    static constexpr int LPT = CAP / BLK;
+    // fan-out per MSD level: runs of >= 16 records (>= 256 B) per bin and tile on average keep the scattered
+    // writes at streaming speed and the reservation atomics at <= 1/16 per record (tools/ubench.hip);
+    // 512 bins (128-B average runs) measured 1.6x slower on the level-1 scatter
+    static constexpr uint32_t FMAX = RPT * BLK / 16;
+    // level 1 (extraction from reads). Measured at NW=2, 10 M reads: tiles of 2048 records 32.3 ms (64 or 256 bins alike),
+    // 4096 records 20.6 ms, 8192 records 29.2 ms -> 4096 records, 256 bins.
+    static constexpr int RPT1 = RPT;  // RPT1 = 32 with tag staging: scatter 16.4 (-0.8) but hist 7.7 ms (+1.6)
+    static constexpr uint32_t FMAX1 = FMAX;
+};
+
+template <int NW, int RPT>
+size_t scatter_lds(uint32_t F) {
+    return (size_t)RPT * BLK * NW * 8 + (size_t)F * 8 + (size_t)F * 4 + (size_t)RPT * BLK * 2;
+}
+
+// ---- level-1 passes over the resident read chunks (hist or scatter) ----
+template <int NW, int BINF>
+int pass_reads(smx_ctx *ctx, int mode, bool scatter, PassArgs a, const std::vector<uint64_t *> &masks,
+               const std::vector<std::pair<uint64_t, uint64_t>> *ranges = nullptr) {
+    constexpr int RPT = Tune<NW>::RPT1;
+    for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
+        const ReadChunk &ch = ctx->chunks[ci];
+        if (ch.n_bases == 0 || !masks[ci]) continue;
+        a.seq = ch.d_words;
+        a.mask = masks[ci];
+        a.g0 = ranges ? (*ranges)[ci].first : 0;
+        a.G = ranges ? (*ranges)[ci].second : ch.n_bases;
+        if (a.G <= a.g0) continue;
+        const int rpp = mode == SMX_MODE_ALL ? 2 : 1;
+        const uint64_t tp = (uint64_t)(RPT / rpp) * BLK;
+        const uint64_t ntiles = (a.G - a.g0 + tp - 1) / tp;
+        if (!scatter) {
+            unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 4096);
+            size_t lds = (size_t)a.F * 4;
+            if (mode == SMX_MODE_ALL) {
+                if (int rc = set_lds(ctx, k_hist<NW, SRC_READS_ALL, BINF, RPT>, lds)) return rc;
+                hipLaunchKernelGGL((k_hist<NW, SRC_READS_ALL, BINF, RPT>), dim3(grid), dim3(BLK), lds, ctx->stream, a);
+            } else {
+                if (int rc = set_lds(ctx, k_hist<NW, SRC_READS_CANON, BINF, RPT>, lds)) return rc;
+                hipLaunchKernelGGL((k_hist<NW, SRC_READS_CANON, BINF, RPT>), dim3(grid), dim3(BLK), lds, ctx->stream, a);
+            }
+        } else {
+            size_t lds = (size_t)a.F * 12 + (size_t)RPT * BLK * 4;
+            if (mode == SMX_MODE_ALL) {
+                if (int rc = set_lds(ctx, k_scatter_reads<NW, SRC_READS_ALL, BINF, RPT>, lds)) return rc;
+                hipLaunchKernelGGL((k_scatter_reads<NW, SRC_READS_ALL, BINF, RPT>), dim3((unsigned)ntiles), dim3(BLK), lds, ctx->stream, a);
+            } else {
+                if (int rc = set_lds(ctx, k_scatter_reads<NW, SRC_READS_CANON, BINF, RPT>, lds)) return rc;
+                hipLaunchKernelGGL((k_scatter_reads<NW, SRC_READS_CANON, BINF, RPT>), dim3((unsigned)ntiles), dim3(BLK), lds, ctx->stream, a);
+            }
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
+// ---- passes over records already in HBM, segmented by a.seg_off ----
+// d_tcnt / d_tstart: scratch arrays of nseg+1 u64
+template <int NW, int BINF>
+int pass_recs(smx_ctx *ctx, bool scatter, PassArgs a, uint64_t nrec, unsigned long long *d_tcnt, unsigned long long *d_tstart) {
+    constexpr int RPT = Tune<NW>::RPT;
+    const uint32_t tile = scatter ? RPT * BLK : 16 * RPT * BLK;
+    hipLaunchKernelGGL(k_tile_counts, dim3((a.nseg + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, a.seg_off, a.nseg, tile, d_tcnt);
+    HIPCHK(hipGetLastError());
+    if (int rc = scan_u64(ctx, d_tcnt, d_tstart, a.nseg)) return rc;
+    a.tile_start = d_tstart;
+    a.tile_recs = tile;
+    const uint64_t grid = nrec / tile + a.nseg + 1;
+    if (grid > 0x7FFFFFFFull) return fail(ctx, SMX_INVALID_PARAMETER, "batch too large for one launch");
+    if (!scatter) {
+        size_t lds = (size_t)a.F * 4;
+        if (int rc = set_lds(ctx, k_hist<NW, SRC_RECS, BINF, RPT>, lds)) return rc;
+        hipLaunchKernelGGL((k_hist<NW, SRC_RECS, BINF, RPT>), dim3((unsigned)grid), dim3(BLK), lds, ctx->stream, a);
+    } else {
+        size_t lds = scatter_lds<NW, RPT>(a.F);
+        if (int rc = set_lds(ctx, k_scatter<NW, SRC_RECS, BINF, RPT>, lds)) return rc;
+        hipLaunchKernelGGL((k_scatter<NW, SRC_RECS, BINF, RPT>), dim3((unsigned)grid), dim3(BLK), lds, ctx->stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// mark valid windows of every chunk; returns total windows
+int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint64_t *total, bool temp_masks = true) {
+    unsigned long long *d_total;
+    if (int rc = dalloc(ctx, &d_total, 1)) return rc;
+    HIPCHK(hipMemsetAsync(d_total, 0, 8, ctx->stream));
+    masks.assign(ctx->chunks.size(), nullptr);
+    for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
+        const ReadChunk &ch = ctx->chunks[ci];
+        if (ch.n_reads == 0) continue;
+        size_t mw = (size_t)(ch.n_bases / 64 + 2);
+        if (int rc = dalloc(ctx, &masks[ci], mw, temp_masks)) return rc;
+        HIPCHK(hipMemsetAsync(masks[ci], 0, mw * 8, ctx->stream));
+        unsigned grid = (unsigned)((ch.n_reads + BLK - 1) / BLK);
+        hipLaunchKernelGGL(k_mark_windows, dim3(grid), dim3(BLK), 0, ctx->stream, ch.d_start, ch.d_len, ch.n_reads, K,
+                           (unsigned long long *)masks[ci], d_total);
+        HIPCHK(hipGetLastError());
+    }
+    unsigned long long t = 0;
+    HIPCHK(hipMemcpyAsync(&t, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *total = t;
+    return 0;
+}
+
+void clear_result(smx_ctx *ctx) {
+    if (ctx->d_result_buf) arena_put(ctx, ctx->d_result_buf);
+    ctx->d_result_buf = ctx->d_result = nullptr;
+    ctx->n_records = 0;
+    ctx->bucket_off.clear();
+}
+
+// The whole count: from reads (d_recs == nullptr) or from records already in HBM.
+struct ReadSel {  // which part of the resident reads one pipeline run covers
+    const std::vector<uint64_t *> *masks = nullptr;                         // precomputed window masks (else computed here)
+    const std::vector<std::pair<uint64_t, uint64_t>> *ranges = nullptr;     // per chunk position range
+    uint64_t nrec = 0;                                                      // records in the selection (when masks given)
+};
+
+template <int NW>
+int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in, const ReadSel *sel = nullptr,
+              bool recs_reusable = false, bool expand_rc = false, bool distinct_hint = false) {
+    uint32_t cap = Tune<NW>::CAP;
+    if (ctx->opt_leaf_cap > 0) cap = (uint32_t)std::min<int64_t>(ctx->opt_leaf_cap, cap);
+    const uint32_t cap1 = std::min<uint32_t>(Tune<NW>::CAP1, cap);
+    const bool from_reads = d_recs == nullptr;
+    ctx->last_idx_bins = 0;
+    clear_result(ctx);
+    ctx->K = K;
+    ctx->nw = NW;
+    ctx->num_buckets = B;
+    ctx->bucket_off.assign(B + 1, 0);
+
+    WallTrace wt;
+    std::vector<uint64_t *> masks;
+    uint64_t nrec = expand_rc ? 2 * n_in : n_in;  // expand_rc: every input record also stands for its reverse complement
+    if (expand_rc) recs_reusable = false;
+    if (from_reads && sel && sel->masks) {
+        masks = *sel->masks;
+        nrec = sel->nrec;
+    } else if (from_reads) {
+        tbegin(ctx, "mark_windows");
+        uint64_t nwin = 0;
+        int rc = mark_windows(ctx, K, masks, &nwin);
+        tend(ctx);
+        if (rc) return rc;
+        nrec = mode == SMX_MODE_ALL ? 2 * nwin : nwin;
+    }
+    const std::vector<std::pair<uint64_t, uint64_t>> *ranges = (from_reads && sel) ? sel->ranges : nullptr;
+    ctx->n_instances = nrec;
+    if (nrec == 0) return 0;
+    if (B > 4096) return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets=%u too large (level-1 fan-out limit 4096)", B);
+
+    // ---- choose the MSD split: level 1 = bucket + s1 key bits, then levels of <= log2(FMAX) bits ----
+    const unsigned avail = std::min(64u, 2 * K);  // key bits visible in key_top64
+    // average leaf = 0.7 * cap1, hit exactly thanks to the mixed-radix fan-outs. Leaf sizes are compound-Poisson (every genomic
+    // k-mer arrives ~coverage times), sigma ~ sqrt(coverage * mean) ~ 110 at mean 716: ~3 sigma below cap1, the tail goes to the
+    // 4x class. (At mean 915 one leaf in five overflowed: sort_unique2 9.6 ms.)
+    uint64_t leaf = std::max<uint32_t>(cap1 * 7 / 10, 1);
+    if (ctx->opt_leaf_target > 0) leaf = (uint64_t)ctx->opt_leaf_target;
+    // per-bucket key fan-out needed, realised as a mixed-radix product S1 * F2 * F3 ... (every factor <= FMAX)
+    uint64_t R = ((nrec + leaf - 1) / leaf + B - 1) / B;
+    const uint64_t rmax = 1ull << std::min(avail, 40u);  // no more key bins than key values
+    R = std::max<uint64_t>(1, std::min(R, rmax));
+    const uint32_t fmax1 = from_reads ? Tune<NW>::FMAX1 : Tune<NW>::FMAX;
+    uint32_t S1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(R, B <= fmax1 ? fmax1 / B : 1));
+    std::vector<uint32_t> lv;  // fan-outs of levels 2..
+    if (ctx->opt_s1 >= 0 || ctx->opt_s2 >= 0) {  // test hook: explicit split (powers of two)
+        unsigned s1 = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_s1, 0), std::min(avail, 12u));
+        while (s1 > 0 && ((uint64_t)B << s1) > 4096) --s1;
+        S1 = 1u << s1;
+        unsigned s2 = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_s2, 0), std::min(avail - std::min(avail, s1), 11u));
+        if (s2) lv.push_back(1u << s2);
+    } else {
+        uint64_t rem = (R + S1 - 1) / S1;
+        while (rem > 1) {
+            unsigned nl = 1;
+            for (uint64_t capf = Tune<NW>::FMAX; capf < rem; capf *= Tune<NW>::FMAX) ++nl;
+            uint32_t F = (uint32_t)std::ceil(std::pow((double)rem, 1.0 / nl));
+            F = std::min<uint32_t>(std::max<uint32_t>(F, 2), Tune<NW>::FMAX);
+            lv.push_back(F);
+            rem = (rem + F - 1) / F;
+            if (lv.size() >= 5) break;
+        }
+    }
+    const uint32_t F1 = B * S1;
+    uint64_t nb = F1;  // fine bins after all levels
+    uint64_t nb_parent_max = F1;
+    for (uint32_t t : lv) {
+        nb_parent_max = nb;
+        nb *= t;
+    }
+    if (nb > (1ull << 31)) return fail(ctx, SMX_INVALID_PARAMETER, "batch too large: %llu fine bins", (unsigned long long)nb);
+    FracArgs fa{};
+    fa.n = 0;
+    if (S1 > 1) fa.f[fa.n++] = S1;
+    for (uint32_t t : lv) fa.f[fa.n++] = t;
+
+    // ---- allocations ------------------------------------------------------------------------
+    Rec<NW> *bufA, *bufB;
+    if (int rc = dalloc(ctx, &bufA, nrec)) return rc;
+    if (!from_reads && recs_reusable) bufB = (Rec<NW> *)const_cast<void *>(d_recs);  // the source is dead after the level-1 scatter
+    else if (int rc = dalloc(ctx, &bufB, nrec)) return rc;
+    unsigned long long *histA, *offA, *offB, *cur, *tcnt, *tstart, *ucount, *uoff, *bucket_off;
+    uint32_t *biglist, *bigcount, *runlen, *medlist, *medcount, *smalllist, *smallcount, *med2list, *med2count, *fblist, *fbcount;
+    if (int rc = dalloc(ctx, &histA, nb)) return rc;
+    if (int rc = dalloc(ctx, &offA, nb + 1)) return rc;
+    if (int rc = dalloc(ctx, &offB, nb_parent_max + 1)) return rc;
+    if (int rc = dalloc(ctx, &cur, nb)) return rc;
+    if (int rc = dalloc(ctx, &tcnt, nb_parent_max + 1)) return rc;
+    if (int rc = dalloc(ctx, &tstart, nb_parent_max + 2)) return rc;
+    if (int rc = dalloc(ctx, &ucount, nb)) return rc;
+    if (int rc = dalloc(ctx, &uoff, nb + 1)) return rc;
+    if (int rc = dalloc(ctx, &biglist, nb)) return rc;
+    if (int rc = dalloc(ctx, &bigcount, 1)) return rc;
+    if (int rc = dalloc(ctx, &medlist, nb)) return rc;
+    if (int rc = dalloc(ctx, &medcount, 1)) return rc;
+    HIPCHK(hipMemsetAsync(medcount, 0, 4, ctx->stream));
+    if (int rc = dalloc(ctx, &med2list, nb)) return rc;
+    if (int rc = dalloc(ctx, &med2count, 1)) return rc;
+    HIPCHK(hipMemsetAsync(med2count, 0, 4, ctx->stream));
+    if (int rc = dalloc(ctx, &fblist, nb)) return rc;
+    if (int rc = dalloc(ctx, &fbcount, 1)) return rc;
+    HIPCHK(hipMemsetAsync(fbcount, 0, 4, ctx->stream));
+    if (int rc = dalloc(ctx, &smalllist, nb)) return rc;
+    if (int rc = dalloc(ctx, &smallcount, 1)) return rc;
+    HIPCHK(hipMemsetAsync(smallcount, 0, 4, ctx->stream));
+    if (int rc = dalloc(ctx, &runlen, nrec / cap + nb + 2)) return rc;
+    if (int rc = dalloc(ctx, &bucket_off, B + 1)) return rc;
+    HIPCHK(hipMemsetAsync(bigcount, 0, 4, ctx->stream));
+    wt.mark(ctx, "mark+alloc");
+
+    PassArgs a{};
+    a.K = K;
+    a.num_buckets = B;
+    a.S1 = S1;
+    a.world = 1;
+
+    // ---- level 1 ----------------------------------------------------------------------------
+    unsigned long long *seg1 = nullptr;  // records source: single segment [0, nrec)
+    if (!from_reads) {
+        if (int rc = dalloc(ctx, &seg1, 2)) return rc;
+        unsigned long long h[2] = {0, nrec};
+        HIPCHK(hipMemcpyAsync(seg1, h, 16, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    a.F = F1;
+    a.hist = histA;
+    HIPCHK(hipMemsetAsync(histA, 0, (size_t)F1 * 8, ctx->stream));
+    // records source: level-1 histogram fused with the level-2 one (LDS table of F1*F2 counters)
+    const bool joint = !from_reads && !lv.empty() && (uint64_t)F1 * lv[0] <= 24 * 1024 && F1 <= 256 && ctx->opt_joint_hist != 0;
+    unsigned long long *histJ = nullptr;
+    tbegin(ctx, "l1_hist");
+    if (from_reads) {
+        if (int rc = pass_reads<NW, BIN_L1>(ctx, mode, false, a, masks, ranges)) return rc;
+    } else {
+        a.recs = d_recs;
+        a.seg_off = seg1;
+        a.nseg = 1;
+        a.expand = expand_rc ? 1u : 0u;
+        if (joint) {
+            const uint32_t F2 = lv[0];
+            if (int rc = dalloc(ctx, &histJ, (size_t)F1 * F2)) return rc;
+            HIPCHK(hipMemsetAsync(histJ, 0, (size_t)F1 * F2 * 8, ctx->stream));
+            PassArgs aj = a;
+            aj.hist = histJ;
+            const size_t lds = (size_t)F1 * F2 * 4;
+            if (int rc = set_lds(ctx, k_hist_l1_joint<NW>, lds)) return rc;
+            hipLaunchKernelGGL((k_hist_l1_joint<NW>), dim3(256 * 2), dim3(1024), lds, ctx->stream, aj, F2, n_in);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_rowsum, dim3((F1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, (const unsigned long long *)histJ, F1, F2, histA);
+            HIPCHK(hipGetLastError());
+        } else {
+            if (int rc = pass_recs<NW, BIN_L1>(ctx, false, a, nrec, tcnt, tstart)) return rc;
+        }
+    }
+    tend(ctx);
+    tbegin(ctx, "l1_scan");
+    unsigned long long *off_cur = offA, *off_other = offB;
+    if (lv.size() % 2 == 1) std::swap(off_cur, off_other);  // so that the final offsets land in offA (nb+1 entries)
+    if (int rc = scan_u64(ctx, histA, off_cur, F1)) return rc;
+    HIPCHK(hipMemcpyAsync(cur, off_cur, (size_t)F1 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    tend(ctx);
+    a.cursor = cur;
+    a.out = bufA;
+    tbegin(ctx, "l1_scatter");
+    if (from_reads) {
+        if (int rc = pass_reads<NW, BIN_L1>(ctx, mode, true, a, masks, ranges)) return rc;
+    } else {
+        if (int rc = pass_recs<NW, BIN_L1>(ctx, true, a, nrec, tcnt, tstart)) return rc;
+    }
+    tend(ctx);
+
+    a.expand = 0;
+    wt.mark(ctx, "level1");
+    // ---- levels 2.. -------------------------------------------------------------------------
+    Rec<NW> *sortbuf = bufA, *other = bufB;
+    uint64_t nseg = F1;
+    a.nprev = 0;
+    if (S1 > 1) a.fprev[a.nprev++] = S1;
+    static const char *lname[3][3] = {{"l2_hist", "l2_scan", "l2_scatter"}, {"l3_hist", "l3_scan", "l3_scatter"}, {"lN_hist", "lN_scan", "lN_scatter"}};
+    for (size_t li = 0; li < lv.size(); ++li) {
+        const uint32_t t = lv[li];
+        const uint64_t nchild = nseg * t;
+        const char **nm = lname[std::min<size_t>(li, 2)];
+        a.recs = sortbuf;
+        a.seg_off = off_cur;
+        a.nseg = (uint32_t)nseg;
+        a.F = t;
+        a.hist = histA;
+        const unsigned long long *hsrc = histA;
+        tbegin(ctx, nm[0]);
+        if (li == 0 && joint) {
+            hsrc = histJ;  // counted together with level 1
+        } else {
+            HIPCHK(hipMemsetAsync(histA, 0, (size_t)nchild * 8, ctx->stream));
+            if (int rc = pass_recs<NW, BIN_LK>(ctx, false, a, nrec, tcnt, tstart)) return rc;
+        }
+        tend(ctx);
+        tbegin(ctx, nm[1]);
+        if (int rc = scan_u64(ctx, hsrc, off_other, nchild)) return rc;
+        HIPCHK(hipMemcpyAsync(cur, off_other, (size_t)nchild * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        tend(ctx);
+        a.cursor = cur;
+        a.out = other;
+        tbegin(ctx, nm[2]);
+        if (int rc = pass_recs<NW, BIN_LK>(ctx, true, a, nrec, tcnt, tstart)) return rc;
+        tend(ctx);
+        std::swap(sortbuf, other);
+        std::swap(off_cur, off_other);
+        nseg = nchild;
+        a.fprev[a.nprev++] = t;
+    }
+    const unsigned long long *fine_off = off_cur;
+    wt.mark(ctx, "levels2+");
+
+    // ---- leaf sort + unique -----------------------------------------------------------------
+    {
+        auto leaf_geom = [&](uint32_t c, unsigned &sub_bits, uint32_t &T, size_t &lds, bool notab = false) {
+            sub_bits = 10;  // 1024 in-LDS digits (512 measured the same)
+            while (sub_bits > 0 && (1u << sub_bits) > c) --sub_bits;
+            T = 64;
+            if (!notab)
+                while (T < (ctx->opt_leaf_tab > 0 ? (uint32_t)ctx->opt_leaf_tab : 2u) * c) T <<= 1;
+            lds = (size_t)c * NW * 8 + ((size_t)T + 2 * ((size_t)1 << sub_bits) + 1 + c + 4) * 4;
+        };
+        unsigned sb1, sb2;
+        uint32_t T1, T2, T1n, T2n;
+        size_t lds1, lds2, lds1n, lds2n;  // ..n: the distinct-input kernels have no hash set; their LDS goes to more workgroups per CU
+        leaf_geom(cap1, sb1, T1, lds1);
+        leaf_geom(cap, sb2, T2, lds2);
+        leaf_geom(cap1, sb1, T1n, lds1n, true);
+        leaf_geom(cap, sb2, T2n, lds2n, true);
+        if (int rc = set_lds(ctx, k_sort_small<NW, Tune<NW>::LPT1>, lds1)) return rc;
+        if (int rc = set_lds(ctx, k_sort_small<NW, Tune<NW>::LPT>, lds2)) return rc;
+        if (int rc = set_lds(ctx, k_sort_big<NW>, (size_t)cap * NW * 8)) return rc;
+        tbegin(ctx, "classify");
+        hipLaunchKernelGGL(k_classify, dim3((unsigned)((nb + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, fine_off, (uint32_t)nb, cap1, cap, ucount,
+                           smalllist, smallcount, medlist, medcount, med2list, med2count, biglist, bigcount);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        tbegin(ctx, "sort_wave");
+        hipLaunchKernelGGL((k_sort_wave<NW>), dim3((unsigned)std::min<uint64_t>((nb + 3) / 4, 256 * 16)), dim3(BLK), 0, ctx->stream,
+                           (void *)sortbuf, fine_off, ucount, (const uint32_t *)smalllist, (const uint32_t *)smallcount);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT1, false>, lds1)) return rc;
+        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT, false>, lds2)) return rc;
+        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT1, true>, lds1n)) return rc;
+        if (int rc = set_lds(ctx, k_sort_hash<NW, Tune<NW>::LPT, true>, lds2n)) return rc;
+        // distinct_hint: the records are expected to be distinct already (pre-dedupe stage): the leaves skip the hash set and
+        // only watch for equal records while ranking; a leaf that has some goes to the general kernel below
+        tbegin(ctx, "sort_unique");
+        if (sb1 > 0) {
+            const dim3 grid1(ctx->opt_leaf_grid > 0 ? (unsigned)ctx->opt_leaf_grid : 256 * 16);
+            if (distinct_hint)
+                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1, true>), grid1, dim3(BLK), lds1n, ctx->stream, (void *)sortbuf, fine_off, cap1, K, fa,
+                                   sb1, T1n, ucount, (const uint32_t *)medlist, (const uint32_t *)medcount, fblist, fbcount);
+            else
+                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1, false>), grid1, dim3(BLK), lds1, ctx->stream, (void *)sortbuf, fine_off, cap1, K, fa,
+                                   sb1, T1, ucount, (const uint32_t *)medlist, (const uint32_t *)medcount, fblist, fbcount);
+        } else {  // leaves too small for the digit table (test-sized caps): the general kernel takes the list directly
+            hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT1>), dim3(256 * 8), dim3(BLK), lds1, ctx->stream, (void *)sortbuf,
+                               fine_off, (uint32_t)nb, cap1, K, fa, sb1, T1, ucount, biglist, bigcount,
+                               (const uint32_t *)medlist, (const uint32_t *)medcount);
+        }
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        tbegin(ctx, "sort_unique2");
+        if (sb2 > 0) {
+            if (distinct_hint)
+                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT, true>), dim3(256 * 2), dim3(BLK), lds2n, ctx->stream, (void *)sortbuf, fine_off, cap,
+                                   K, fa, sb2, T2n, ucount, (const uint32_t *)med2list, (const uint32_t *)med2count, fblist, fbcount);
+            else
+                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT, false>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf, fine_off, cap,
+                                   K, fa, sb2, T2, ucount, (const uint32_t *)med2list, (const uint32_t *)med2count, fblist, fbcount);
+        } else {
+            hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf,
+                               fine_off, (uint32_t)nb, cap, K, fa, sb2, T2, ucount, biglist, bigcount,
+                               (const uint32_t *)med2list, (const uint32_t *)med2count);
+        }
+        HIPCHK(hipGetLastError());
+        // skewed leaves left over by the fast kernel (any size <= cap): general kernel with the bitonic fallback
+        hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf,
+                           fine_off, (uint32_t)nb, cap, K, fa, sb2, T2, ucount, biglist, bigcount,
+                           (const uint32_t *)fblist, (const uint32_t *)fbcount);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        tbegin(ctx, "sort_big");
+        hipLaunchKernelGGL((k_sort_big<NW>), dim3(1024), dim3(BLK), (size_t)cap * NW * 8, ctx->stream, (void *)sortbuf, (void *)other,
+                           fine_off, cap, ucount, (const uint32_t *)biglist, (const uint32_t *)bigcount, runlen);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+    }
+    if (wt.on) {
+        uint32_t c[5] = {0, 0, 0, 0, 0};
+        (void)hipMemcpy(&c[0], smallcount, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&c[1], medcount, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&c[2], med2count, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&c[3], fbcount, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&c[4], bigcount, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[smx] leaves: %llu bins (F1=%u, levels=%zu) wave=%u med=%u med2=%u fallback=%u big=%u\n", (unsigned long long)nb, F1, lv.size(),
+                c[0], c[1], c[2], c[3], c[4]);
+        for (uint32_t i = 0; i < std::min<uint32_t>(c[4], 20); ++i) {
+            uint32_t bi = 0;
+            unsigned long long o[2] = {0, 0};
+            (void)hipMemcpy(&bi, biglist + i, 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(o, fine_off + bi, 16, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[smx]   big leaf: bin %u size %llu\n", bi, o[1] - o[0]);
+        }
+    }
+    wt.mark(ctx, "leaf sort");
+    // ---- compact ----------------------------------------------------------------------------
+    tbegin(ctx, "compact");
+    if (int rc = scan_u64(ctx, ucount, uoff, nb)) return rc;
+    unsigned long long n_unique = 0;
+    HIPCHK(hipMemcpyAsync(&n_unique, uoff + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (n_unique == nrec) {
+        // nothing was removed (the usual case behind the pre-dedupe stage): the leaves, sorted in place and contiguous, already
+        // are the bucket-major output
+        std::swap(sortbuf, other);
+    } else if (nrec / nb >= 128) {
+        hipLaunchKernelGGL((k_compact<NW>), dim3((unsigned)std::min<uint64_t>(nb, 1u << 20)), dim3(BLK), 0, ctx->stream,
+                           (const void *)sortbuf, fine_off, (const unsigned long long *)ucount, (const unsigned long long *)uoff,
+                           (uint32_t)nb, (void *)other);
+    } else {
+        hipLaunchKernelGGL((k_compact_wave<NW>), dim3((unsigned)std::min<uint64_t>((nb + 3) / 4, 256 * 32)), dim3(BLK), 0, ctx->stream,
+                           (const void *)sortbuf, fine_off, (const unsigned long long *)ucount, (const unsigned long long *)uoff,
+                           (uint32_t)nb, (void *)other);
+    }
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_bucket_offsets, dim3((B + 1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream,
+                       (const unsigned long long *)uoff, B, (uint32_t)(nb / B), bucket_off);
+    HIPCHK(hipGetLastError());
+    tend(ctx);
+    if (ctx->want_index) {
+        if (ctx->last_idx_off) arena_put(ctx, ctx->last_idx_off);
+        ctx->last_idx_off = nullptr;
+        if (int rc = dalloc(ctx, &ctx->last_idx_off, nb + 1, false)) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->last_idx_off, uoff, (size_t)(nb + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->last_idx_bins = nb;
+        ctx->last_idx_S1 = S1;
+        ctx->last_idx_f = lv;
+    }
+    std::vector<unsigned long long> h(B + 1);
+    HIPCHK(hipMemcpyAsync(h.data(), bucket_off, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (unsigned i = 0; i <= B; ++i) ctx->bucket_off[i] = h[i];
+    ctx->n_records = h[B];
+    ctx->d_result_buf = other;
+    ctx->d_result = other;
+    wt.mark(ctx, "compact");
+    return 0;
+}
+
+
+// Super-k-mer pre-deduplication of the selected windows (smx_superkmer.hip). *out: canonical K-mers, every k-mer of the
+// selection at least once and most of them exactly once (temp buffer of nwin records), *n_out: how many.
+template <int NW>
+int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, Rec<NW> **out, uint64_t *n_out) {
+    constexpr int SW = 2 * NW;
+    const std::vector<uint64_t *> &masks = *sel.masks;
+    unsigned long long *cnt, *soff, *ocount, *cursor;  // ocount[0] clean, ocount[1] dirty survivors
+    if (int rc = dalloc(ctx, &cnt, SKM_NKEY)) return rc;
+    if (int rc = dalloc(ctx, &soff, SKM_NKEY + 1)) return rc;
+    if (int rc = dalloc(ctx, &cursor, SKM_NKEY)) return rc;
+    if (int rc = dalloc(ctx, &ocount, 2)) return rc;
+    HIPCHK(hipMemsetAsync(cnt, 0, (size_t)SKM_NKEY * 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(ocount, 0, 16, ctx->stream));
+    SkmArgs a{};
+    a.K = K;
+    a.m = skm_m(K);
+    a.w = K - a.m + 1;
+    a.cnt = cnt;
+    if (getenv("SMX_DEBUG")) {
+        if (int rc = dalloc(ctx, &a.prof, 16)) return rc;
+        HIPCHK(hipMemsetAsync(a.prof, 0, 128, ctx->stream));
+    }
+    auto pass = [&](int phase) -> int {
+        for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
+            const ReadChunk &ch = ctx->chunks[ci];
+            if (ch.n_bases == 0 || !masks[ci]) continue;
+            a.seq = ch.d_words;
+            a.nwords = ch.n_words;
+            a.mask = masks[ci];
+            a.g0 = sel.ranges ? (*sel.ranges)[ci].first : 0;
+            a.G = sel.ranges ? (*sel.ranges)[ci].second : ch.n_bases;
+            if (a.G <= a.g0) continue;
+            const uint64_t ntiles = (a.G - a.g0 + SKM_TP - 1) / SKM_TP;
+            const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 16);
+            if (phase == 0) hipLaunchKernelGGL((k_skm_scan<0, NW>), dim3(grid), dim3(BLK), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((k_skm_scan<1, NW>), dim3(grid), dim3(BLK), 0, ctx->stream, a);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    };
+    // staging area for the super-k-mers of pass 0 (scan order): expected 2/(w+1) starts per window, 1.5x + slack; an overflow (flag)
+    // only costs the second scan of the reads
+    unsigned long long *st_alloc = nullptr;
+    // (short runs — K < 35, w < 16 windows — make placing atomics-bound either way and the staging round trip a loss: K=21 17.9 vs 14.4 ms)
+    if (ctx->opt_skm_stage >= 2 || (ctx->opt_skm_stage == 1 && a.w >= 16)) {
+        const uint64_t blocks = 256 * 16;
+        a.stage_cap = (uint64_t)((double)nwin * 3.0 / (double)(a.w + 1)) + blocks * 4096 + 4096;
+        if (ctx->opt_skm_stage == 2) a.stage_cap = 4096;  // tests: force the overflow fallback
+        if (int rc = dalloc(ctx, &a.stage_slots, (size_t)a.stage_cap * SW)) return rc;
+        if (int rc = dalloc(ctx, &a.stage_part, (size_t)a.stage_cap)) return rc;
+        if (int rc = dalloc(ctx, &st_alloc, 2)) return rc;
+        HIPCHK(hipMemsetAsync(a.stage_part, 0xFF, (size_t)a.stage_cap * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(st_alloc, 0, 16, ctx->stream));
+        a.stage_alloc = st_alloc;
+    }
+    tbegin(ctx, "skm_count");
+    if (int rc = pass(0)) return rc;
+    tend(ctx);
+    tbegin(ctx, "skm_scan");
+    if (int rc = scan_u64(ctx, cnt, soff, SKM_NKEY)) return rc;
+    unsigned long long nslots = 0, st[2] = {0, 1};
+    HIPCHK(hipMemcpyAsync(&nslots, soff + SKM_NKEY, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (st_alloc) HIPCHK(hipMemcpyAsync(st, st_alloc, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    tend(ctx);
+    uint64_t *slots;
+    if (int rc = dalloc(ctx, &slots, (size_t)nslots * SW + SW)) return rc;
+    HIPCHK(hipMemcpyAsync(cursor, soff, (size_t)SKM_NKEY * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    a.cursor = cursor;
+    a.slots = slots;
+    tbegin(ctx, "skm_scatter");
+    if (st_alloc && st[1] == 0) {  // place the staged super-k-mers
+        const uint64_t n_stage = std::min<uint64_t>(st[0], a.stage_cap);
+        if (n_stage) {
+            hipLaunchKernelGGL((k_skm_permute<NW>), dim3((unsigned)std::min<uint64_t>((n_stage + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
+                               (const uint64_t *)a.stage_slots, (const uint32_t *)a.stage_part, n_stage, cursor, slots);
+            HIPCHK(hipGetLastError());
+        }
+    } else {
+        a.stage_slots = nullptr;
+        if (int rc = pass(1)) return rc;
+    }
+    tend(ctx);
+    if (a.prof) {
+        unsigned long long hp[16];
+        HIPCHK(hipMemcpy(hp, a.prof, 128, hipMemcpyDeviceToHost));
+        for (int ph = 0; ph < 2; ++ph)
+            fprintf(stderr, "[smx] skm_scan phase %d: tiles=%llu; ticks per tile: stage+keys %.1f, minpos+flags %.1f, emit %.1f\n", ph, hp[8 * ph + 3],
+                    hp[8 * ph + 3] ? (double)hp[8 * ph] / hp[8 * ph + 3] : 0.0, hp[8 * ph + 3] ? (double)hp[8 * ph + 1] / hp[8 * ph + 3] : 0.0,
+                    hp[8 * ph + 3] ? (double)hp[8 * ph + 2] / hp[8 * ph + 3] : 0.0);
+    }
+    if (int rc = dalloc(ctx, out, nwin + 1)) return rc;
+    // Chunk capacity of the LDS hash set: every copy of a k-mer sits in ONE partition, and a partition that does not fit a chunk is
+    // cut (its survivors need a unique pass of their own). The partition a typical super-k-mer lives in holds sum(c^2)/sum(c) slots —
+    // one genomic locus at coverage 30 is ~46 slots = ~860 instances; deeper coverage grows it linearly. 2048 instances is the fastest
+    // geometry (4 workgroups per CU; 1024: 17.7 ms, 4096: 14.0 ms, 2048: 9.6 ms at bench scale); larger only when the data need it.
+    uint32_t cap = 2048;
+    if (ctx->opt_skm_cap > 0) {
+        cap = 512;
+        while (cap < (uint32_t)std::min<int64_t>(ctx->opt_skm_cap, 8192)) cap <<= 1;
+    } else if (nslots) {
+        unsigned long long *sums;
+        if (int rc = dalloc(ctx, &sums, 2)) return rc;
+        HIPCHK(hipMemsetAsync(sums, 0, 16, ctx->stream));
+        hipLaunchKernelGGL(k_skm_moments, dim3(1024), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cnt, SKM_NKEY, sums);
+        HIPCHK(hipGetLastError());
+        unsigned long long hs[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(hs, sums, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const double typical_slots = hs[0] ? (double)hs[1] / (double)hs[0] : 0.0;
+        const double typical_inst = typical_slots * (double)nwin / (double)nslots;
+        while (cap < 8192 && typical_inst * 1.6 > cap) cap <<= 1;
+        if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] prededupe: typical partition %.0f slots = %.0f instances -> chunk capacity %u\n", typical_slots, typical_inst, cap);
+    }
+    const uint32_t T = 2 * cap;
+    const uint32_t scap = std::min<uint32_t>(SKM_SCAP, ctx->opt_skm_scap > 0 ? (uint32_t)ctx->opt_skm_scap : cap / 8);  // ~12+ windows per slot on average
+    const size_t lds = (size_t)scap * SW * 8 + (size_t)T * 4 + 514 * 4 + (size_t)cap * 4 + 512 + 16;
+    if (int rc = set_lds(ctx, k_skm_dedupe<NW>, lds)) return rc;
+    const uint32_t nitems = SKM_NKEY / SKM_KEYS_PER_ITEM;
+    unsigned long long *prof = nullptr;
+    if (getenv("SMX_DEBUG")) {
+        if (int rc = dalloc(ctx, &prof, 8)) return rc;
+        HIPCHK(hipMemsetAsync(prof, 0, 64, ctx->stream));
+    }
+    tbegin(ctx, "skm_dedupe");
+    hipLaunchKernelGGL((k_skm_dedupe<NW>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
+                       (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)nwin, ocount, ocount + 1, prof);
+    HIPCHK(hipGetLastError());
+    tend(ctx);
+    if (prof) {
+        unsigned long long hp[6];
+        HIPCHK(hipMemcpy(hp, prof, 48, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[smx] dedupe chunks=%llu slots/chunk=%.1f; 100MHz ticks per chunk: stage+clear %.1f, scan+plan %.1f, insert %.1f, output %.1f\n",
+                hp[4], hp[4] ? (double)hp[5] / hp[4] : 0.0, hp[4] ? (double)hp[0] / hp[4] : 0.0, hp[4] ? (double)hp[1] / hp[4] : 0.0,
+                hp[4] ? (double)hp[2] / hp[4] : 0.0, hp[4] ? (double)hp[3] / hp[4] : 0.0);
+    }
+    unsigned long long nn[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(nn, ocount, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (nn[0] + nn[1] > nwin) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication produced %llu records from %llu windows", nn[0] + nn[1], (unsigned long long)nwin);
+    unsigned long long n = nn[0];
+    if (nn[1]) {  // survivors of cut keys: sort + unique them on their own, then the whole array is exactly distinct
+        if (int rc = run_count<NW>(ctx, K, SMX_MODE_ALL, 1, *out + (nwin - nn[1]), nn[1])) return rc;
+        HIPCHK(hipMemcpyAsync(*out + nn[0], ctx->d_result_buf, ctx->n_records * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        n += ctx->n_records;
+        ctx->d_result_buf = ctx->d_result = nullptr;  // stays in the temp list
+        ctx->n_records = 0;
+    }
+    *n_out = n;
+    if (getenv("SMX_DEBUG"))
+        fprintf(stderr, "[smx] prededupe: %llu windows -> %llu super-k-mers -> %llu canonical records (%llu from cut keys before their unique pass)\n",
+                (unsigned long long)nwin, nslots, n, nn[1]);
+    return 0;
+}
+
+// One pipeline run over a selection of the resident reads: straight from the windows, or through the pre-dedupe stage.
+template <int NW>
+int count_selection(smx_ctx *ctx, unsigned K, int mode, unsigned B, const ReadSel &sel) {
+    const uint64_t nwin = mode == SMX_MODE_ALL ? sel.nrec / 2 : sel.nrec;
+    const bool possible = K >= 21 && nwin > 0;
+    const bool use = possible && (ctx->opt_prededupe > 0 || (ctx->opt_prededupe < 0 && nwin >= (1u << 20)));
+    if (!use) return run_count<NW>(ctx, K, mode, B, nullptr, 0, &sel);
+    Rec<NW> *recs = nullptr;
+    uint64_t n = 0;
+    if (int rc = run_prededupe<NW>(ctx, K, sel, nwin, &recs, &n)) return rc;
+    free_temps(ctx, recs);
+    ctx->temps.push_back(recs);
+    if (int rc = run_count<NW>(ctx, K, mode, B, recs, n, nullptr, false, mode == SMX_MODE_ALL, /*distinct_hint=*/true)) return rc;
+    ctx->n_instances = sel.nrec;
+    return 0;
+}
+
+// Counting from the resident reads with HBM-bounded batches (the reference's dump + merge, kmer_splitter.hpp:123-170 +
+// kmer_index_builder.hpp:346-430): when two record buffers of the whole batch do not fit the budget, the position
+// space of every read chunk is cut into ranges; each range is counted on its own (sorted-unique run), and runs are
+// folded into the accumulated set by concatenation + one more pass of the same pipeline from records (= k-way
+// merge-unique; the pipeline is a sort, so equal keys of different runs meet in the same leaf).
+template <int NW>
+int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
+    std::vector<uint64_t *> masks;
+    uint64_t nwin = 0;
+    tbegin(ctx, "mark_windows");
+    int rc = mark_windows(ctx, K, masks, &nwin, /*temp_masks=*/false);
+    tend(ctx);
+    auto drop_masks = [&]() {
+        for (auto *m : masks) arena_put(ctx, m);
+    };
+    if (rc) {
+        drop_masks();
+        return rc;
+    }
+    const int rpp = mode == SMX_MODE_ALL ? 2 : 1;
+    const uint64_t nrec = nwin * rpp;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t cached = 0;
+    for (auto &b : ctx->arena_free) cached += b.second;
+    const uint64_t budget = ctx->budget ? ctx->budget : (uint64_t)((free_b + cached) * 0.92);
+    // per record: two ping-pong copies + ~1/4 record of bin bookkeeping
+    uint64_t max_batch = budget / ((uint64_t)NW * 8 * 2 + 8);
+    if (ctx->opt_batch_records > 0) max_batch = (uint64_t)ctx->opt_batch_records;
+    uint64_t nbatch = nrec ? (nrec + max_batch - 1) / max_batch : 1;
+    if (nbatch > 1) nbatch = (2 * nrec + max_batch - 1) / max_batch;  // keep half of the budget for the accumulated set + merge
+    if (nbatch <= 1) {
+        ReadSel sel;
+        sel.masks = &masks;
+        sel.nrec = nrec;
+        rc = count_selection<NW>(ctx, K, mode, B, sel);
+        drop_masks();
+        return rc;
+    }
+    void *acc = nullptr;
+    uint64_t nacc = 0;
+    unsigned long long *d_cnt = nullptr;
+    if ((rc = dalloc(ctx, &d_cnt, 1, false))) {
+        drop_masks();
+        return rc;
+    }
+    auto cleanup = [&](int code) {
+        drop_masks();
+        arena_put(ctx, d_cnt);
+        if (acc && acc != ctx->d_result_buf) arena_put(ctx, acc);
+        return code;
+    };
+    uint64_t total_inst = 0;
+    for (uint64_t bi = 0; bi < nbatch; ++bi) {
+        std::vector<std::pair<uint64_t, uint64_t>> ranges(ctx->chunks.size());
+        HIPCHK(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+        for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
+            const uint64_t G = ctx->chunks[ci].n_bases;
+            const uint64_t words = (G + 63) / 64;
+            const uint64_t w0 = words * bi / nbatch, w1 = words * (bi + 1) / nbatch;
+            ranges[ci] = {w0 * 64, std::min<uint64_t>(w1 * 64, G)};
+            if (masks[ci] && w1 > w0) {
+                hipLaunchKernelGGL(k_count_range, dim3((unsigned)std::min<uint64_t>((w1 - w0 + BLK - 1) / BLK, 4096)), dim3(BLK), 0, ctx->stream,
+                                   (const unsigned long long *)masks[ci], w0, w1, d_cnt);
+                if (hipGetLastError() != hipSuccess) return cleanup(fail(ctx, SMX_DEVICE_ERROR, "k_count_range launch failed"));
+            }
+        }
+        unsigned long long nw_b = 0;
+        if (hipMemcpyAsync(&nw_b, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return cleanup(fail(ctx, SMX_DEVICE_ERROR, "batch window count failed"));
+        ReadSel sel;
+        sel.masks = &masks;
+        sel.ranges = &ranges;
+        sel.nrec = nw_b * rpp;
+        total_inst += sel.nrec;
+        if ((rc = count_selection<NW>(ctx, K, mode, B, sel))) return cleanup(rc);
+        void *run = ctx->d_result_buf;
+        const uint64_t nrun = ctx->n_records;
+        ctx->d_result_buf = ctx->d_result = nullptr;
+        free_temps(ctx, run);
+        if (!acc) {
+            acc = run;
+            nacc = nrun;
+            continue;
+        }
+        // fold: acc U run -> acc
+        Rec<NW> *cat;
+        if ((rc = dalloc(ctx, &cat, nacc + nrun))) {
+            arena_put(ctx, run);
+            return cleanup(rc);
+        }
+        hipError_t e1 = hipMemcpyAsync(cat, acc, nacc * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream);
+        hipError_t e2 = hipMemcpyAsync(cat + nacc, run, nrun * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream);
+        hipError_t e3 = hipStreamSynchronize(ctx->stream);
+        arena_put(ctx, acc);
+        arena_put(ctx, run);
+        acc = nullptr;
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return cleanup(fail(ctx, SMX_DEVICE_ERROR, "run concatenation failed"));
+        tbegin(ctx, "merge_runs");
+        tend(ctx);
+        if ((rc = run_count<NW>(ctx, K, mode, B, cat, nacc + nrun, nullptr, /*recs_reusable=*/true))) return cleanup(rc);
+        acc = ctx->d_result_buf;
+        nacc = ctx->n_records;
+        if (bi + 1 < nbatch) {
+            ctx->d_result_buf = ctx->d_result = nullptr;
+            free_temps(ctx, acc);
+        }
+    }
+    if (ctx->d_result_buf != acc) {  // last batch was the first (cannot happen for nbatch > 1) or a fold result: install it
+        ctx->d_result_buf = ctx->d_result = acc;
+    }
+    ctx->n_instances = total_inst;
+    acc = nullptr;
+    return cleanup(0);
+}
+
+int dispatch_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in) {
+    if (K < 1 || K > 128) return fail(ctx, SMX_INVALID_PARAMETER, "K=%u out of range [1,128]", K);
+    if (B < 1) return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets must be >= 1");
+    if (mode != SMX_MODE_ALL && mode != SMX_MODE_CANONICAL) return fail(ctx, SMX_INVALID_PARAMETER, "bad mode %d", mode);
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    const bool reads = d_recs == nullptr;
+    switch ((K + 31) / 32) {
+        case 1: rc = reads ? count_reads<1>(ctx, K, mode, B) : run_count<1>(ctx, K, mode, B, d_recs, n_in); break;
+        case 2: rc = reads ? count_reads<2>(ctx, K, mode, B) : run_count<2>(ctx, K, mode, B, d_recs, n_in); break;
+        case 3: rc = reads ? count_reads<3>(ctx, K, mode, B) : run_count<3>(ctx, K, mode, B, d_recs, n_in); break;
+        default: rc = reads ? count_reads<4>(ctx, K, mode, B) : run_count<4>(ctx, K, mode, B, d_recs, n_in); break;
+    }
+    if (rc == 0) {
+        WallTrace wt;
+        tcollect(ctx);
+        free_temps(ctx, ctx->d_result_buf);
+        wt.mark(ctx, "free");
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto &t : ctx->timings) {
+            (void)hipEventDestroy(t.e0);
+            (void)hipEventDestroy(t.e1);
+        }
+        ctx->timings.clear();
+        free_temps(ctx);
+        ctx->d_result_buf = ctx->d_result = nullptr;
+        ctx->n_records = 0;
+    }
+    return rc;
+}
+
+}  // namespace
+
+namespace {
+template <int NW>
+int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned world, void *d_records, uint64_t capacity,
+                          uint64_t *counts) {
+    std::vector<uint64_t *> masks;
+    uint64_t nwin = 0;
+    if (int rc = mark_windows(ctx, K, masks, &nwin)) return rc;
+    uint64_t nrec = mode == SMX_MODE_ALL ? 2 * nwin : nwin;
+    if (nrec > capacity) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "record buffer too small: need %llu", (unsigned long long)nrec);
+    // Local pre-dedupe first ("optional local sort-unique per destination to cut volume by ~coverage"): the
+    // exchange then carries every distinct k-mer of this rank once instead of every instance.
+    Rec<NW> *recs = nullptr;
+    uint64_t n_dedup = 0;
+    const bool dedupe = K >= 21 && nwin > 0 && (ctx->opt_prededupe > 0 || (ctx->opt_prededupe < 0 && nwin >= (1u << 20)));
+    if (dedupe) {
+        ReadSel sel;
+        sel.masks = &masks;
+        sel.nrec = nrec;
+        if (int rc = run_prededupe<NW>(ctx, K, sel, nwin, &recs, &n_dedup)) return rc;
+        nrec = mode == SMX_MODE_ALL ? 2 * n_dedup : n_dedup;
+    }
+    unsigned long long *hist, *off, *cur, *seg1 = nullptr, *tcnt = nullptr, *tstart = nullptr;
+    if (int rc = dalloc(ctx, &hist, world)) return rc;
+    if (int rc = dalloc(ctx, &off, world + 1)) return rc;
+    if (int rc = dalloc(ctx, &cur, world)) return rc;
+    HIPCHK(hipMemsetAsync(hist, 0, (size_t)world * 8, ctx->stream));
+    PassArgs a{};
+    a.K = K;
+    a.num_buckets = B;
+    a.world = world;
+    a.F = world;
+    a.hist = hist;
+    if (dedupe) {
+        if (int rc = dalloc(ctx, &seg1, 2)) return rc;
+        if (int rc = dalloc(ctx, &tcnt, 2)) return rc;
+        if (int rc = dalloc(ctx, &tstart, 3)) return rc;
+        unsigned long long h2[2] = {0, nrec};
+        HIPCHK(hipMemcpyAsync(seg1, h2, 16, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        a.recs = recs;
+        a.seg_off = seg1;
+        a.nseg = 1;
+        a.expand = mode == SMX_MODE_ALL ? 1u : 0u;
+    }
+    tbegin(ctx, "x_hist");
+    if (nrec) {
+        if (dedupe) {
+            if (int rc = pass_recs<NW, BIN_OWNER>(ctx, false, a, nrec, tcnt, tstart)) return rc;
+        } else {
+            if (int rc = pass_reads<NW, BIN_OWNER>(ctx, mode, false, a, masks)) return rc;
+        }
+    }
+    tend(ctx);
+    if (int rc = scan_u64(ctx, hist, off, world)) return rc;
+    HIPCHK(hipMemcpyAsync(cur, off, (size_t)world * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    a.cursor = cur;
+    a.out = d_records;
+    tbegin(ctx, "x_scatter");
+    if (nrec) {
+        if (dedupe) {
+            if (int rc = pass_recs<NW, BIN_OWNER>(ctx, true, a, nrec, tcnt, tstart)) return rc;
+        } else {
+            if (int rc = pass_reads<NW, BIN_OWNER>(ctx, mode, true, a, masks)) return rc;
+        }
+    }
+    tend(ctx);
+    std::vector<unsigned long long> h(world);
+    HIPCHK(hipMemcpyAsync(h.data(), hist, (size_t)world * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (unsigned i = 0; i < world; ++i) counts[i] = h[i];
+    return 0;
+}
+}  // namespace
