@@ -81,14 +81,15 @@ def _worker(rank, world, port, K, mode, nb, q, limit=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,mode,nb,limit", [(21, "A", 16, None), (33, "B", 10, None), (21, "A", 16, 1000)])
-def test_sharded_count_world2_gloo(K, mode, nb, limit):
+@pytest.mark.parametrize("K,mode,nb,limit,world", [(21, "A", 16, None, 2), (33, "B", 10, None, 2), (21, "A", 16, 1000, 2),
+                                                   (21, "A", 16, 700, 3), (33, "B", 10, None, 4)])
+def test_sharded_count_gloo(K, mode, nb, limit, world):
+    """world 2-4 (uneven bucket ranges at 3 ranks, 10 buckets over 4 ranks), one-shot all-to-all and forced point-to-point rounds"""
     from oracle import oracle
     from spades_amd.dist import rank_first_bucket
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = 29500 + (os.getpid() % 2000) + 7 * world
     procs = [ctx.Process(target=_worker, args=(r, world, port, K, mode, nb, q, limit)) for r in range(world)]
     for p in procs:
         p.start()
