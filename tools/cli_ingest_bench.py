@@ -22,8 +22,10 @@ rec[:, 162] = 10; rec[:, 163] = ord("+"); rec[:, 164] = 10
 rec[:, 165:315] = ord("I"); rec[:, 315] = 10
 rec.tofile(fq)
 print(f"{n} reads, {os.path.getsize(fq) / 1e6:.0f} MB FASTQ")
+subprocess.check_call(["gzip", "-1", "-k", fq])
 for tool, args in (("spades-gbuilder-mi355x", [fq, os.path.join(d, "o.gfa"), "-k", "55", "-t", "16", "--gfa"]),
-                   ("spades-kmercount-mi355x", ["-k", "55", "-w", d, fq])):
+                   ("spades-kmercount-mi355x", ["-k", "55", "-w", d, fq]),
+                   ("spades-gbuilder-mi355x", [fq + ".gz", os.path.join(d, "o.gfa"), "-k", "55", "-t", "16", "--gfa"])):
     for env_extra, tag in (({}, "device FASTQ parse"), ({"SMX_HOST_PARSE": "1"}, "host parser")):
         env = dict(os.environ, **env_extra)
         exe = os.path.join(ROOT, "spades_amd", "tools", tool)
