@@ -13,6 +13,8 @@
 #include "../../include/smx.h"
 #include "read_input.hpp"
 #include <chrono>
+#include <mutex>
+#include <thread>
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define STAGE(what)                                                                 \
     if (getenv("SMX_DEBUG")) {                                                      \
@@ -70,18 +72,37 @@ int main(int argc, char **argv) {
     }
     printf("K-mer length set to %u\n", K);
     try {
-        for (const auto &file : input) {
-            printf("Processing \"%s\"\n", file.c_str());
-            STAGE("device init")
-            int rc = smxtool::submit_file(ctx, file);
-            STAGE("read input")
-            if (rc == -1) {
-                fprintf(stderr, "File %s doesn't exist or can't be read!\n", file.c_str());
+        // one host thread per input file (up to 8 at a time): reading / inflating is the slow part of the ingest and R1/R2 files are
+        // independent streams; the library calls are serialised
+        STAGE("device init")
+        std::mutex mu;
+        std::vector<int> rcs(input.size(), 0);
+        std::vector<std::string> errs(input.size());
+        for (size_t base = 0; base < input.size(); base += 8) {
+            std::vector<std::thread> th;
+            for (size_t i = base; i < std::min(input.size(), base + 8); ++i) {
+                printf("Processing \"%s\"\n", input[i].c_str());
+                th.emplace_back([&, i] {
+                    try {
+                        rcs[i] = smxtool::submit_file(ctx, input[i], &mu);
+                    } catch (const std::string &e) {
+                        rcs[i] = -2;
+                        errs[i] = e;
+                    }
+                });
+            }
+            for (auto &t : th) t.join();
+        }
+        for (size_t i = 0; i < input.size(); ++i) {
+            if (rcs[i] == -1) {
+                fprintf(stderr, "File %s doesn't exist or can't be read!\n", input[i].c_str());
                 smx_destroy(ctx);
                 return SMX_INPUT_FILE_NOT_FOUND;
             }
-            if (rc) throw std::string(smx_last_error(ctx));
+            if (rcs[i] == -2) throw errs[i];
+            if (rcs[i]) throw std::string(smx_last_error(ctx));
         }
+        STAGE("read input")
         if (int rc = smx_count(ctx, K, SMX_MODE_ALL, 16)) {  // 16 buckets: kmercount.cpp:220
             fprintf(stderr, "%s\n", smx_last_error(ctx));
             smx_destroy(ctx);

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -114,7 +115,14 @@ bool for_each_sequence(const std::string &path, F cb) {
 // (smx_submit_fastq_text: page-locked chunks, complete records only, the tail is carried over); everything else
 // (gzip, FASTA, multi-line FASTQ) takes the host parser above. Returns 0, an smx error code, or -1 when the file
 // cannot be opened; throws std::string on malformed input.
-inline int submit_file(smx_ctx *ctx, const std::string &path) {
+// mu (optional): serialises the library calls when several files are read by several host threads (a context is used by one
+// thread at a time; reading and inflating — the slow part — run in parallel).
+inline int submit_file(smx_ctx *ctx, const std::string &path, std::mutex *mu = nullptr) {
+    auto locked = [&](auto &&fn) {
+        if (!mu) return fn();
+        std::lock_guard<std::mutex> g(*mu);
+        return fn();
+    };
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return -1;
     unsigned char head[2] = {0, 0};
@@ -167,7 +175,7 @@ inline int submit_file(smx_ctx *ctx, const std::string &path) {
                 break;
             }
             uint64_t n = 0, used = 0;
-            rc = smx_submit_fastq_text(ctx, buf, have, eof ? 1 : 0, &n, &used);
+            rc = locked([&] { return smx_submit_fastq_text(ctx, buf, have, eof ? 1 : 0, &n, &used); });
             if (rc == SMX_INVALID_INPUT_FORMAT && !any) {  // not strict 4-line FASTQ: nothing was submitted, let the host parser decide
                 fallback = true;
                 rc = 0;
@@ -198,12 +206,12 @@ inline int submit_file(smx_ctx *ctx, const std::string &path) {
     bool ok = for_each_sequence(path, [&](const std::string &s) {
         batch.add(s);
         if (batch.bases.size() > ((size_t)1 << 30) && !rc) {
-            rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
+            rc = locked([&] { return smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size()); });
             batch.clear();
         }
     });
     if (!ok) return -1;
-    if (!rc) rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
+    if (!rc) rc = locked([&] { return smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size()); });
     return rc;
 }
 

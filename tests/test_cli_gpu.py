@@ -94,3 +94,20 @@ def test_cli_tools_with_the_prededupe_stage_forced(tmp_path):
     out = str(tmp_path / "g.gfa")
     subprocess.check_call([GB, fq, out, "-k", "55", "-t", "3", "-c", "--gfa"], stdout=subprocess.DEVNULL, env=env)
     assert open(out).read() == open(os.path.join(GOLDEN, c["file"])).read()
+
+
+def test_kmercount_cli_reads_several_files_in_parallel(tmp_path):
+    """R1/R2-style inputs (one gzip, one plain, one FASTA) are read by one host thread each; the k-mer file is that of all reads"""
+    from oracle import oracle
+    import hashlib
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    a, b, c = reads[0::3], reads[1::3], reads[2::3]
+    f1, f2, f3 = str(tmp_path / "a.fq.gz"), str(tmp_path / "b.fq"), str(tmp_path / "c.fa")
+    _fastq(f1, a, gz=True)
+    _fastq(f2, b)
+    with open(f3, "w") as f:
+        for i, r in enumerate(c):
+            f.write(f">c{i}\n{r}\n")
+    subprocess.check_call([KC, "-k", "33", "-w", str(tmp_path), f1, f2, f3], stdout=subprocess.DEVNULL)
+    ref, _ = oracle.count(reads, 33, "A", 16)
+    assert open(tmp_path / "final_kmers", "rb").read() == ref.tobytes()
