@@ -69,7 +69,23 @@ int main(int argc, char **argv) {
     int rc = 0;
     try {
         STAGE("device init")
-        rc = smxtool::submit_file(ctx, file);
+        std::vector<std::string> files;
+        if (file.size() > 5 && file.compare(file.size() - 5, 5, ".yaml") == 0) {  // LoadDataset, gbuilder.cpp:98-110
+            std::vector<smxtool::DatasetLibrary> libs;
+            if (!smxtool::load_dataset_yaml(file, libs)) {
+                fprintf(stderr, "Dataset description file: %s does not exist or is not a valid YAML file\n", file.c_str());
+                smx_destroy(ctx);
+                return SMX_INPUT_FILE_NOT_FOUND;
+            }
+            for (const auto &lib : libs)
+                if (lib.graph_constructable()) files.insert(files.end(), lib.files.begin(), lib.files.end());
+        } else {
+            files.push_back(file);
+        }
+        for (const auto &fn : files) {
+            rc = smxtool::submit_file(ctx, fn);
+            if (rc) break;
+        }
         STAGE("read input")
         if (rc == -1) {
             fprintf(stderr, "Dataset description file: %s does not exist or is not a valid YAML file\n", file.c_str());

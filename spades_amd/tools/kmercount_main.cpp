@@ -2,7 +2,7 @@
 // (reference: projects/spades_tools/kmercount.cpp:134-229; docs/standalone.md:5-45) over libspades_mi355x.so.
 //   spades-kmercount-mi355x [-k 21] [-t N] [-w dir] [-b bytes] files...   ->  <dir>/final_kmers
 // -t and -b are accepted for command-line compatibility; the result does not depend on them (SURVEY.md finding 3).
-// Exit codes follow common/utils/logger/error_codes.hpp (64-68); -d <yaml> is not supported by this clone.
+// Exit codes follow common/utils/logger/error_codes.hpp (64-68).
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +34,7 @@ int main(int argc, char **argv) {
     unsigned K = 21, nthreads = 1;
     std::string workdir = ".";
     std::vector<std::string> input;
+    std::string dataset;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto need = [&](const char *what) -> const char * {
@@ -47,10 +48,8 @@ int main(int argc, char **argv) {
         else if (a == "-t" || a == "--threads") nthreads = (unsigned)atoi(need("-t"));
         else if (a == "-w" || a == "--workdir") workdir = need("-w");
         else if (a == "-b" || a == "--bufsize") (void)need("-b");
-        else if (a == "-d" || a == "--dataset") {
-            fprintf(stderr, "-d <yaml> is not supported by this build; pass the read files directly\n");
-            return SMX_INVALID_PARAMETER;
-        } else if (a == "-h" || a == "--help") {
+        else if (a == "-d" || a == "--dataset") dataset = need("-d");
+        else if (a == "-h" || a == "--help") {
             usage(argv[0]);
             return 0;
         } else if (!a.empty() && a[0] == '-') {
@@ -60,6 +59,15 @@ int main(int argc, char **argv) {
         } else input.push_back(a);
     }
     (void)nthreads;
+    if (!dataset.empty()) {  // "Dataset description (in YAML), input files ignored", kmercount.cpp:141,210-214
+        std::vector<smxtool::DatasetLibrary> libs;
+        if (!smxtool::load_dataset_yaml(dataset, libs)) {
+            fprintf(stderr, "Dataset description file: %s does not exist or is not a valid YAML file\n", dataset.c_str());
+            return SMX_INPUT_FILE_NOT_FOUND;
+        }
+        input.clear();
+        for (const auto &lib : libs) input.insert(input.end(), lib.files.begin(), lib.files.end());
+    }
     if (input.empty()) {
         fprintf(stderr, "No input files were specified\n");
         return SMX_INVALID_PARAMETER;

@@ -111,6 +111,98 @@ bool for_each_sequence(const std::string &path, F cb) {
     return true;
 }
 
+// Dataset description (the YAML that spades.py writes and `spades-gbuilder <file>.yaml` / `spades-kmercount -d` read;
+// io::DataSet::load, common/library/library.cpp): a list of libraries, each a mapping with `type`, `orientation` and the read lists
+// `left reads` / `right reads` / `single reads` / `interlaced reads` / `merged reads` (block or flow sequences). Only that subset of
+// YAML is understood. Relative paths are taken from the directory of the YAML file, as the reference does.
+struct DatasetLibrary {
+    std::string type;
+    std::vector<std::string> files;
+    bool graph_constructable() const {  // SequencingLibrary::is_graph_constructable, common/library/library.hpp:197-202
+        return type == "paired-end" || type == "single" || type == "hq-mate-pairs" || type == "clouds10x";
+    }
+};
+inline bool load_dataset_yaml(const std::string &path, std::vector<DatasetLibrary> &libs) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::string text;
+    char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+    fclose(f);
+    std::string dir = path;
+    const size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    auto unquote = [](std::string v) {
+        while (!v.empty() && (v.back() == ' ' || v.back() == '\r' || v.back() == ',')) v.pop_back();
+        size_t a = 0;
+        while (a < v.size() && v[a] == ' ') ++a;
+        v = v.substr(a);
+        if (v.size() >= 2 && (v.front() == '"' || v.front() == '\'') && v.back() == v.front()) v = v.substr(1, v.size() - 2);
+        return v;
+    };
+    auto add_path = [&](DatasetLibrary &lib, const std::string &raw) {
+        std::string v = unquote(raw);
+        if (v.empty()) return;
+        if (v[0] != '/') v = dir + "/" + v;
+        lib.files.push_back(v);
+    };
+    auto is_reads_key = [](const std::string &k) {
+        return k == "left reads" || k == "right reads" || k == "single reads" || k == "interlaced reads" || k == "merged reads";
+    };
+    bool in_reads = false;
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t e = text.find('\n', pos);
+        if (e == std::string::npos) e = text.size();
+        std::string line = text.substr(pos, e - pos);
+        pos = e + 1;
+        const size_t hash = line.find(" #");
+        if (hash != std::string::npos) line = line.substr(0, hash);
+        size_t ind = 0;
+        while (ind < line.size() && line[ind] == ' ') ++ind;
+        if (ind == line.size() || line[ind] == '#') continue;
+        std::string body = line.substr(ind);
+        bool new_item = false;
+        if (body.compare(0, 2, "- ") == 0 || body == "-") {
+            if (ind == 0) {  // a new library
+                libs.emplace_back();
+                in_reads = false;
+                new_item = true;
+                body = body.size() > 2 ? body.substr(2) : std::string();
+                if (body.empty()) continue;
+            } else if (in_reads && !libs.empty()) {  // an entry of the current read list
+                add_path(libs.back(), body.substr(body.size() > 1 ? 2 : 1));
+                continue;
+            }
+        }
+        (void)new_item;
+        const size_t colon = body.find(':');
+        if (colon == std::string::npos || libs.empty()) continue;
+        const std::string key = unquote(body.substr(0, colon));
+        std::string val = body.substr(colon + 1);
+        in_reads = false;
+        if (key == "type") libs.back().type = unquote(val);
+        else if (is_reads_key(key)) {
+            const size_t lb = val.find('[');
+            if (lb != std::string::npos) {  // flow sequence on one line
+                const size_t rb = val.find(']', lb);
+                std::string inner = val.substr(lb + 1, (rb == std::string::npos ? val.size() : rb) - lb - 1);
+                size_t p = 0;
+                while (p <= inner.size()) {
+                    size_t c = inner.find(',', p);
+                    if (c == std::string::npos) c = inner.size();
+                    add_path(libs.back(), inner.substr(p, c - p));
+                    p = c + 1;
+                }
+            } else {
+                in_reads = true;
+            }
+        }
+    }
+    return true;
+}
+
 // One input file -> library. Uncompressed 4-line FASTQ goes to HBM as raw bytes and is cut into reads on the device
 // (smx_submit_fastq_text: page-locked chunks, complete records only, the tail is carried over); everything else
 // (gzip, FASTA, multi-line FASTQ) takes the host parser above. Returns 0, an smx error code, or -1 when the file

@@ -111,3 +111,26 @@ def test_kmercount_cli_reads_several_files_in_parallel(tmp_path):
     subprocess.check_call([KC, "-k", "33", "-w", str(tmp_path), f1, f2, f3], stdout=subprocess.DEVNULL)
     ref, _ = oracle.count(reads, 33, "A", 16)
     assert open(tmp_path / "final_kmers", "rb").read() == ref.tobytes()
+
+
+def test_cli_tools_take_a_dataset_yaml(tmp_path):
+    """`spades-gbuilder <dataset>.yaml` / `spades-kmercount -d <dataset>.yaml` (io::DataSet::load): libraries usable for construction
+    are read, a trusted-contigs library is skipped by gbuilder; the graph equals the reference's for the same reads"""
+    from oracle import oracle
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    os.makedirs(tmp_path / "lib")
+    _fastq(str(tmp_path / "lib" / "r1.fq.gz"), reads[0::2], gz=True)
+    _fastq(str(tmp_path / "r2.fq"), reads[1::2])
+    with open(tmp_path / "contigs.fa", "w") as f:
+        f.write(">c\n" + "ACGTTGCATTGACCAGT" * 8 + "\n")
+    y = tmp_path / "ds.yaml"
+    y.write_text(f'- orientation: "fr"\n  type: "paired-end"\n  left reads:\n  - "lib/r1.fq.gz"\n  right reads:\n  - "{tmp_path}/r2.fq"\n'
+                 f'- type: "trusted-contigs"\n  single reads:\n  - "contigs.fa"\n')
+    out = str(tmp_path / "g.gfa")
+    subprocess.check_call([GB, str(y), out, "-k", "21", "-t", "3", "-c", "--gfa"], stdout=subprocess.DEVNULL)
+    assert open(out).read() == open(os.path.join(GOLDEN, "graphcov_small_k21_t3.gfa")).read()
+    wd = tmp_path / "w"
+    wd.mkdir()
+    subprocess.check_call([KC, "-k", "21", "-w", str(wd), "-d", str(y)], stdout=subprocess.DEVNULL)
+    ref, _ = oracle.count(reads + ["ACGTTGCATTGACCAGT" * 8], 21, "A", 16)  # kmercount takes every library of the dataset
+    assert open(wd / "final_kmers", "rb").read() == ref.tobytes()
