@@ -577,7 +577,6 @@ inline bool write_cvr(const GraphHost &g, FILE *f) {
 inline bool write_fastg(const GraphHost &g, FILE *f) {
     const uint64_t min_id = 3;
     const size_t ne = g.n_edges();
-    BufWriter w(f);
     std::vector<uint64_t> end_c, end_r;
     edge_end_vertices(g, end_c, end_r);
     auto name = [&](uint64_t e) {
@@ -590,60 +589,57 @@ inline bool write_fastg(const GraphHost &g, FILE *f) {
         if ((e - min_id) & 1) s += "'";
         return s;
     };
-    for (size_t i = 0; i < ne; ++i) {
-        for (int o = 0; o < (g.eself[i] ? 1 : 2); ++o) {
-            const uint64_t e = min_id + 2 * i + o;
-            const uint64_t endv = o ? end_r[i] : end_c[i];
-            std::vector<std::string> next;
-            if (endv >= min_id) {
-                uint64_t outv[8], outc[8];
-                size_t no, nc;
-                vertex_edges(g, (size_t)((endv - min_id) >> 1), outv, no, outc, nc);
-                const uint64_t *lst = ((endv - min_id) & 1) ? outc : outv;
-                const size_t n = ((endv - min_id) & 1) ? nc : no;
-                for (size_t a = 0; a < n; ++a) next.push_back(name(lst[a]));
-                std::sort(next.begin(), next.end());
-                next.erase(std::unique(next.begin(), next.end()), next.end());
-            }
-            w.add(">");
-            std::string hdr = name(e);
-            w.add(hdr.data(), hdr.size());
-            for (size_t a = 0; a < next.size(); ++a) {
-                w.add(a ? "," : ":");
-                w.add(next[a].data(), next[a].size());
-            }
-            w.add(";\n");
-            const uint64_t len = g.eoff[i + 1] - g.eoff[i];
-            std::string sq(g.seq.data() + g.eoff[i], (size_t)len);
-            if (o) sq = revcomp(sq);
-            for (uint64_t p = 0; p < len; p += 60) {
-                w.add(sq.data() + p, (size_t)std::min<uint64_t>(60, len - p));
-                w.add("\n");
+    return parallel_write(f, ne, (size_t)1 << 15, [&](size_t b, size_t e_, std::string &out) {
+        for (size_t i = b; i < e_; ++i) {
+            for (int o = 0; o < (g.eself[i] ? 1 : 2); ++o) {
+                const uint64_t e = min_id + 2 * i + o;
+                const uint64_t endv = o ? end_r[i] : end_c[i];
+                std::vector<std::string> next;
+                if (endv >= min_id) {
+                    uint64_t outv[8], outc[8];
+                    size_t no, nc;
+                    vertex_edges(g, (size_t)((endv - min_id) >> 1), outv, no, outc, nc);
+                    const uint64_t *lst = ((endv - min_id) & 1) ? outc : outv;
+                    const size_t n = ((endv - min_id) & 1) ? nc : no;
+                    for (size_t a = 0; a < n; ++a) next.push_back(name(lst[a]));
+                    std::sort(next.begin(), next.end());
+                    next.erase(std::unique(next.begin(), next.end()), next.end());
+                }
+                out += '>';
+                out += name(e);
+                for (size_t a = 0; a < next.size(); ++a) {
+                    out += a ? ',' : ':';
+                    out += next[a];
+                }
+                out += ";\n";
+                const uint64_t len = g.eoff[i + 1] - g.eoff[i];
+                std::string sq(g.seq.data() + g.eoff[i], (size_t)len);
+                if (o) sq = revcomp(sq);
+                for (uint64_t p = 0; p < len; p += 60) {
+                    out.append(sq.data() + p, (size_t)std::min<uint64_t>(60, len - p));
+                    out += '\n';
+                }
             }
         }
-    }
-    w.flush();
-    return w.ok();
+    });
 }
 
 // gbuilder --unitigs: ">EDGE_<i>_length_<len>" + sequence wrapped at 60 (gbuilder.cpp:191-200)
 inline bool write_unitigs_fasta(const GraphHost &g, FILE *f) {
-    BufWriter w(f);
-    const size_t ne = g.n_edges();
-    for (size_t i = 0; i < ne; ++i) {
-        const uint64_t len = g.eoff[i + 1] - g.eoff[i];
-        w.add(">EDGE_");
-        w.num(i + 1);
-        w.add("_length_");
-        w.num(len);
-        w.add("\n");
-        for (uint64_t p = 0; p < len; p += 60) {
-            w.add(g.seq.data() + g.eoff[i] + p, (size_t)std::min<uint64_t>(60, len - p));
-            w.add("\n");
+    return parallel_write(f, g.n_edges(), (size_t)1 << 16, [&](size_t b, size_t e, std::string &out) {
+        for (size_t i = b; i < e; ++i) {
+            const uint64_t len = g.eoff[i + 1] - g.eoff[i];
+            out += ">EDGE_";
+            append_num(out, i + 1);
+            out += "_length_";
+            append_num(out, len);
+            out += '\n';
+            for (uint64_t p = 0; p < len; p += 60) {
+                out.append(g.seq.data() + g.eoff[i] + p, (size_t)std::min<uint64_t>(60, len - p));
+                out += '\n';
+            }
         }
-    }
-    w.flush();
-    return w.ok();
+    });
 }
 
 }  // namespace smxh

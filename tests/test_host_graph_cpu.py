@@ -91,3 +91,13 @@ def test_gfa_writer_blocks_on_several_threads(grain, tmp_path, monkeypatch):
     out = str(tmp_path / "g.gfa")
     _write(g["unitigs"], case["K"], 1, out)
     assert open(out).read() == open(os.path.join(GOLDEN, case["file"])).read()
+    fcase = [c for c in load_manifest()["cases"] if c["kind"] == "graph_fastg"][0]  # the FASTG and FASTA writers use the same block scheme
+    reads = [r for r in read_lines(fcase["reads"]) if r]
+    gf = oracle.build_graph(reads, fcase["K"], fcase["num_buckets"], coverage=bool(fcase.get("coverage")))
+    out = str(tmp_path / "g.fastg")
+    _write(gf["unitigs"], fcase["K"], 2, out, _cov_from_gfa(gf["gfa"]) if fcase.get("coverage") else None)
+    assert open(out).read() == open(os.path.join(GOLDEN, fcase["file"])).read()
+    out = str(tmp_path / "u.fa")
+    _write(gf["unitigs"], fcase["K"], 0, out)
+    want = "".join(f">EDGE_{i + 1}_length_{len(u)}\n" + "".join(u[p:p + 60] + "\n" for p in range(0, len(u), 60)) for i, u in enumerate(gf["unitigs"]))
+    assert open(out).read() == want
