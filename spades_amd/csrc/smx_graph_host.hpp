@@ -497,65 +497,97 @@ inline void edge_end_vertices(const GraphHost &g, std::vector<uint64_t> &end_c, 
     }
 }
 
+inline void put_uleb(std::string &o, uint64_t v) {
+    do {
+        uint8_t byte = v & 0x7f;
+        v >>= 7;
+        if (v) byte |= 0x80;
+        o += (char)byte;
+    } while (v);
+}
 inline bool write_grseq(const GraphHost &g, FILE *f) {
     const uint64_t min_id = 3;
     const size_t ne = g.n_edges(), nv = g.vstart.size();
-    BufWriter w(f);
-    put_uleb(w, 2 * nv + nv / 100);
-    put_uleb(w, 2 * ne + ne / 100);
-    put_uleb(w, 0);
-    put_uleb(w, 2 * nv);
+    bool ok = true;
+    {
+        std::string h;
+        put_uleb(h, 2 * nv + nv / 100);
+        put_uleb(h, 2 * ne + ne / 100);
+        put_uleb(h, 0);
+        put_uleb(h, 2 * nv);
+        ok &= fwrite(h.data(), 1, h.size(), f) == h.size();
+    }
     std::vector<uint64_t> end_c, end_r;
     edge_end_vertices(g, end_c, end_r);
-    std::vector<uint8_t> saved(nv, 0);
-    auto save_vertex = [&](uint64_t vid) {
-        const size_t vn = (size_t)((vid - min_id) >> 1);
-        const uint64_t v = min_id + 2 * vn;
-        put_uleb(w, vid);
-        put_uleb(w, vid == v ? v + 1 : v);
-        if (saved[vn]) return;
-        const char z = 0;
-        w.add(&z, 1);  // complex = false
-        put_uleb(w, g.k);
-        saved[vn] = 1;
-    };
-    std::vector<uint64_t> words;
+    // SaveVertex writes "complex = false, overlap k" the first time a vertex (either orientation) is mentioned in the traversal
+    // (vertex vn, orientation o, then the end vertices of its canonical out-edges in id order). That first mention is the vertex's
+    // own turn unless an edge of an EARLIER vertex ends in it; one serial pass finds it, the formatting then runs in blocks.
+    // mention key = ((2 vn + o) << 4) | (1 + index of the edge in the out-list), 0 for the vertex's own mention
+    std::vector<uint64_t> first(nv);
+    for (size_t vn = 0; vn < nv; ++vn) first[vn] = (uint64_t)(2 * vn) << 4;
     for (size_t vn = 0; vn < nv; ++vn) {
         uint64_t outv[8], outc[8];
         size_t no, nc;
         vertex_edges(g, vn, outv, no, outc, nc);
         for (int o = 0; o < 2; ++o) {
-            save_vertex(min_id + 2 * vn + o);
             const uint64_t *lst = o ? outc : outv;
             const size_t n = o ? nc : no;
             for (size_t a = 0; a < n; ++a) {
                 const uint64_t e1 = lst[a];
-                const size_t ei = (size_t)((e1 - min_id) >> 1);
-                const bool canon = ((e1 - min_id) & 1) == 0;
-                if (!canon) continue;  // conj(e1) < e1
-                const uint64_t e2 = g.eself[ei] ? e1 : e1 + 1;
-                put_uleb(w, e1);
-                put_uleb(w, e2);
-                save_vertex(end_c[ei]);
-                const uint64_t len = g.eoff[ei + 1] - g.eoff[ei];
-                w.add((const char *)&len, 8);
-                words.assign((size_t)((len + 31) / 32), 0);
-                const char *sq = g.seq.data() + g.eoff[ei];
-                for (uint64_t t = 0; t < len; ++t) {
-                    const char ch = sq[t];
-                    const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
-                    words[(size_t)(t >> 5)] |= code << ((t & 31) << 1);
-                }
-                // short-sequence representation (< 60 nt, sequence.hpp:196-251): the inline 2-word buffer keeps its
-                // metadata byte [size:6 | rtl:1 | is_short:1] in the top byte of word 1, and BinWrite dumps it with the data
-                if (len > 32 && len < 60) words[1] |= (uint64_t)(((len & 0x3F) << 2) | 1) << 56;  // is_short_rep: size < 60
-                w.add((const char *)words.data(), words.size() * 8);
+                if ((e1 - min_id) & 1) continue;
+                const size_t un = (size_t)((end_c[(size_t)((e1 - min_id) >> 1)] - min_id) >> 1);
+                const uint64_t key = ((uint64_t)(2 * vn + o) << 4) | (a + 1);
+                if (key < first[un]) first[un] = key;
             }
-            put_uleb(w, 0);
         }
     }
-    w.flush();
-    return w.ok();
+    ok &= parallel_write(f, nv, (size_t)1 << 15, [&](size_t vb, size_t ve, std::string &out) {
+        auto save_vertex = [&](uint64_t vid, uint64_t key) {
+            const size_t vn = (size_t)((vid - min_id) >> 1);
+            const uint64_t v = min_id + 2 * vn;
+            put_uleb(out, vid);
+            put_uleb(out, vid == v ? v + 1 : v);
+            if (key != first[vn]) return;
+            out += (char)0;  // complex = false
+            put_uleb(out, g.k);
+        };
+        std::vector<uint64_t> words;
+        for (size_t vn = vb; vn < ve; ++vn) {
+            uint64_t outv[8], outc[8];
+            size_t no, nc;
+            vertex_edges(g, vn, outv, no, outc, nc);
+            for (int o = 0; o < 2; ++o) {
+                save_vertex(min_id + 2 * vn + o, (uint64_t)(2 * vn + o) << 4);
+                const uint64_t *lst = o ? outc : outv;
+                const size_t n = o ? nc : no;
+                for (size_t a = 0; a < n; ++a) {
+                    const uint64_t e1 = lst[a];
+                    const size_t ei = (size_t)((e1 - min_id) >> 1);
+                    const bool canon = ((e1 - min_id) & 1) == 0;
+                    if (!canon) continue;  // conj(e1) < e1
+                    const uint64_t e2 = g.eself[ei] ? e1 : e1 + 1;
+                    put_uleb(out, e1);
+                    put_uleb(out, e2);
+                    save_vertex(end_c[ei], ((uint64_t)(2 * vn + o) << 4) | (a + 1));
+                    const uint64_t len = g.eoff[ei + 1] - g.eoff[ei];
+                    out.append((const char *)&len, 8);
+                    words.assign((size_t)((len + 31) / 32), 0);
+                    const char *sq = g.seq.data() + g.eoff[ei];
+                    for (uint64_t t = 0; t < len; ++t) {
+                        const char ch = sq[t];
+                        const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+                        words[(size_t)(t >> 5)] |= code << ((t & 31) << 1);
+                    }
+                    // short-sequence representation (< 60 nt, sequence.hpp:196-251): the inline 2-word buffer keeps its
+                    // metadata byte [size:6 | rtl:1 | is_short:1] in the top byte of word 1, and BinWrite dumps it with the data
+                    if (len > 32 && len < 60) words[1] |= (uint64_t)(((len & 0x3F) << 2) | 1) << 56;  // is_short_rep: size < 60
+                    out.append((const char *)words.data(), words.size() * 8);
+                }
+                put_uleb(out, 0);
+            }
+        }
+    });
+    return ok;
 }
 
 inline bool write_cvr(const GraphHost &g, FILE *f) {

@@ -97,6 +97,13 @@ def test_gfa_writer_blocks_on_several_threads(grain, tmp_path, monkeypatch):
     out = str(tmp_path / "g.fastg")
     _write(gf["unitigs"], fcase["K"], 2, out, _cov_from_gfa(gf["gfa"]) if fcase.get("coverage") else None)
     assert open(out).read() == open(os.path.join(GOLDEN, fcase["file"])).read()
+    for sc in [c for c in load_manifest()["cases"] if c["kind"] == "graph_spades"][:3]:  # .grseq: first-mention bookkeeping across blocks
+        reads = [r for r in read_lines(sc["reads"]) if r]
+        gs = oracle.build_graph(reads, sc["K"], sc["num_buckets"], coverage=bool(sc.get("coverage")))
+        base = str(tmp_path / "sp")
+        _write(gs["unitigs"], sc["K"], 3, base, _cov_from_gfa(gs["gfa"]) if sc.get("coverage") else None)
+        for ext in (".grseq", ".cvr"):
+            assert open(base + ext, "rb").read() == open(os.path.join(GOLDEN, sc["base"] + ext), "rb").read(), ext
     out = str(tmp_path / "u.fa")
     _write(gf["unitigs"], fcase["K"], 0, out)
     want = "".join(f">EDGE_{i + 1}_length_{len(u)}\n" + "".join(u[p:p + 60] + "\n" for p in range(0, len(u), 60)) for i, u in enumerate(gf["unitigs"]))
