@@ -404,23 +404,49 @@ int smx_write_final_kmers(const smx_ctx *cctx, const char *path) {
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
-    const size_t w = (size_t)ctx->nw * 8;
+    const size_t total = ctx->n_records * (size_t)ctx->nw * 8;
     const size_t chunk = (size_t)64 << 20;
-    std::vector<char> buf(std::min<size_t>(chunk, std::max<size_t>(ctx->n_records * w, 1)));
     (void)hipSetDevice(ctx->device);
-    for (size_t o = 0; o < ctx->n_records * w; o += chunk) {
-        size_t n = std::min(chunk, ctx->n_records * w - o);
-        if (hipMemcpy(buf.data(), (const char *)ctx->d_result + o, n, hipMemcpyDeviceToHost) != hipSuccess) {
-            fclose(f);
-            return fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
+    // two page-locked buffers: the read-back of chunk i+1 runs while chunk i is written
+    char *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2];
+    bool pinned = total > 0;
+    for (int i = 0; i < 2 && pinned; ++i)
+        if (hipHostMalloc((void **)&buf[i], std::min(chunk, total), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            pinned = false;
         }
-        if (fwrite(buf.data(), 1, n, f) != n) {
-            fclose(f);
-            return fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
+    int rc = SMX_OK;
+    if (pinned) {
+        for (int i = 0; i < 2; ++i) (void)hipEventCreate(&ev[i]);
+        auto issue = [&](size_t idx) {
+            const size_t o = idx * chunk, n = std::min(chunk, total - o);
+            if (hipMemcpyAsync(buf[idx & 1], (const char *)ctx->d_result + o, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+            return hipEventRecord(ev[idx & 1], ctx->stream) == hipSuccess;
+        };
+        const size_t nchunks = (total + chunk - 1) / chunk;
+        bool ok = nchunks == 0 || issue(0);
+        for (size_t i = 0; i < nchunks && ok && rc == SMX_OK; ++i) {
+            if (i + 1 < nchunks) ok = issue(i + 1);
+            if (hipEventSynchronize(ev[i & 1]) != hipSuccess) ok = false;
+            const size_t n = std::min(chunk, total - i * chunk);
+            if (ok && fwrite(buf[i & 1], 1, n, f) != n) rc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        if (!ok) rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
+        for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ev[i]);
+    } else {
+        std::vector<char> hb(std::min<size_t>(chunk, std::max<size_t>(total, 1)));
+        for (size_t o = 0; o < total && rc == SMX_OK; o += chunk) {
+            const size_t n = std::min(chunk, total - o);
+            if (hipMemcpy(hb.data(), (const char *)ctx->d_result + o, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
+            else if (fwrite(hb.data(), 1, n, f) != n) rc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
         }
     }
-    if (fclose(f) != 0) return fail(ctx, SMX_IO_ERROR, "I/O error closing %s", path);
-    return SMX_OK;
+    for (int i = 0; i < 2; ++i)
+        if (buf[i]) (void)hipHostFree(buf[i]);
+    if (fclose(f) != 0 && rc == SMX_OK) rc = fail(ctx, SMX_IO_ERROR, "I/O error closing %s", path);
+    return rc;
 }
 
 const void *smx_device_kmers(const smx_ctx *ctx) { return ctx ? ctx->d_result : nullptr; }
