@@ -173,24 +173,72 @@ class LoopCollector {
 
 // ---- spades-core edge order (DeBruijnGraphExtentionConstructor::ConstructGraph, debruijn_graph_constructor.hpp:590-604):
 // unitigs sorted by Sequence::RawCompare (sequence/sequence.hpp:605-624: length, then packed 64-bit words from word 0)
+// fn(begin, end) over [0, n) on several host threads (contiguous blocks)
+template <class Fn>
+inline void parallel_blocks(size_t n, size_t min_block, const Fn &fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt ? std::min(nt, 32u) : 1u;
+    if (const char *e = getenv("SMX_WRITE_GRAIN")) min_block = std::max<size_t>(1, (size_t)atoll(e));  // tests: force the threaded path
+    nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, n / std::max<size_t>(min_block, 1)));
+    if (nt <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt); });
+    for (auto &x : th) x.join();
+}
+// std::sort in blocks on several threads + rounds of pairwise std::inplace_merge
+template <class T, class Cmp>
+inline void parallel_sort(std::vector<T> &v, const Cmp &cmp) {
+    const size_t n = v.size();
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt ? std::min(nt, 16u) : 1u;
+    size_t min_block = (size_t)1 << 16;
+    if (const char *e = getenv("SMX_WRITE_GRAIN")) min_block = std::max<size_t>(1, (size_t)atoll(e));
+    while (nt > 1 && n / nt < min_block) nt >>= 1;
+    unsigned p2 = 1;
+    while (p2 * 2 <= nt) p2 *= 2;
+    nt = p2;
+    if (nt <= 1) {
+        std::sort(v.begin(), v.end(), cmp);
+        return;
+    }
+    std::vector<size_t> cut(nt + 1);
+    for (unsigned t = 0; t <= nt; ++t) cut[t] = n * t / nt;
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back([&, t] { std::sort(v.begin() + cut[t], v.begin() + cut[t + 1], cmp); });
+        for (auto &x : th) x.join();
+    }
+    for (unsigned w = 1; w < nt; w *= 2) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t + w < nt; t += 2 * w)
+            th.emplace_back([&, t, w] { std::inplace_merge(v.begin() + cut[t], v.begin() + cut[t + w], v.begin() + cut[std::min(nt, t + 2 * w)], cmp); });
+        for (auto &x : th) x.join();
+    }
+}
+
 inline void sort_edges_raw(GraphHost &g) {
     const size_t ne = g.n_edges();
     if (ne < 2) return;
     std::vector<uint64_t> woff(ne + 1, 0);
     for (size_t i = 0; i < ne; ++i) woff[i + 1] = woff[i] + (g.eoff[i + 1] - g.eoff[i] + 31) / 32;
     std::vector<uint64_t> words(woff[ne], 0);
-    for (size_t i = 0; i < ne; ++i) {
-        const char *sq = g.seq.data() + g.eoff[i];
-        const uint64_t len = g.eoff[i + 1] - g.eoff[i];
-        for (uint64_t t = 0; t < len; ++t) {
-            const char ch = sq[t];
-            const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
-            words[woff[i] + (t >> 5)] |= code << ((t & 31) << 1);
+    parallel_blocks(ne, (size_t)1 << 14, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const char *sq = g.seq.data() + g.eoff[i];
+            const uint64_t len = g.eoff[i + 1] - g.eoff[i];
+            for (uint64_t t = 0; t < len; ++t) {
+                const char ch = sq[t];
+                const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+                words[woff[i] + (t >> 5)] |= code << ((t & 31) << 1);
+            }
         }
-    }
+    });
     std::vector<size_t> perm(ne);
     for (size_t i = 0; i < ne; ++i) perm[i] = i;
-    std::sort(perm.begin(), perm.end(), [&](size_t a, size_t b) {
+    parallel_sort(perm, [&](size_t a, size_t b) {
         const uint64_t la = g.eoff[a + 1] - g.eoff[a], lb = g.eoff[b + 1] - g.eoff[b];
         if (la != lb) return la < lb;
         const uint64_t nw = woff[a + 1] - woff[a];
@@ -200,16 +248,21 @@ inline void sort_edges_raw(GraphHost &g) {
     });
     GraphHost o;
     o.k = g.k;
-    o.eoff.assign(1, 0);
-    o.seq.reserve(g.seq.size());
-    for (size_t i = 0; i < ne; ++i) {
-        const size_t s = perm[i];
-        o.seq.append(g.seq, (size_t)g.eoff[s], (size_t)(g.eoff[s + 1] - g.eoff[s]));
-        o.eoff.push_back(o.seq.size());
-        o.estart.push_back(g.estart[s]);
-        o.eend.push_back(g.eend[s]);
-        o.eself.push_back(g.eself[s]);
-    }
+    o.eoff.assign(ne + 1, 0);
+    for (size_t i = 0; i < ne; ++i) o.eoff[i + 1] = o.eoff[i] + (g.eoff[perm[i] + 1] - g.eoff[perm[i]]);
+    o.seq.resize(g.seq.size());
+    o.estart.resize(ne);
+    o.eend.resize(ne);
+    o.eself.resize(ne);
+    parallel_blocks(ne, (size_t)1 << 14, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const size_t s = perm[i];
+            memcpy(&o.seq[o.eoff[i]], g.seq.data() + g.eoff[s], (size_t)(g.eoff[s + 1] - g.eoff[s]));
+            o.estart[i] = g.estart[s];
+            o.eend[i] = g.eend[s];
+            o.eself[i] = g.eself[s];
+        }
+    });
     o.n_paths = g.n_paths;
     o.n_loops = g.n_loops;
     g = std::move(o);

@@ -104,6 +104,11 @@ def test_gfa_writer_blocks_on_several_threads(grain, tmp_path, monkeypatch):
         _write(gs["unitigs"], sc["K"], 3, base, _cov_from_gfa(gs["gfa"]) if sc.get("coverage") else None)
         for ext in (".grseq", ".cvr"):
             assert open(base + ext, "rb").read() == open(os.path.join(GOLDEN, sc["base"] + ext), "rb").read(), ext
+    freads = [r for r in read_lines(fcase["reads"]) if r]
+    gs = oracle.build_graph(freads, fcase["K"], fcase["num_buckets"], sort_edges=True)  # threaded RawCompare sort of the edges
+    out = str(tmp_path / "s.gfa")
+    _write(gf["unitigs"], fcase["K"], 1, out, sort_edges=1)
+    assert open(out).read() == gs["gfa"]
     out = str(tmp_path / "u.fa")
     _write(gf["unitigs"], fcase["K"], 0, out)
     want = "".join(f">EDGE_{i + 1}_length_{len(u)}\n" + "".join(u[p:p + 60] + "\n" for p in range(0, len(u), 60)) for i, u in enumerate(gf["unitigs"]))
