@@ -49,12 +49,20 @@ int smx_create(smx_ctx **out, int device, size_t hbm_budget_bytes);
 void smx_destroy(smx_ctx *ctx);
 const char *smx_last_error(const smx_ctx *ctx);
 const char *smx_version(void);
-/* Tuning / test hooks (no reference equivalent; closest is the -b buffer-size knob of
- * kmercount.cpp:139): "leaf_cap" (records sorted per LDS leaf), "s1"/"s2" (MSD split bits), "batch_records" (force HBM-bounded batches).
- * Construction variant of spades-core (DeBruijnGraphExtentionConstructor::ConstructGraph(keep_perfect_loops),
- * common/assembly_graph/construction/debruijn_graph_constructor.hpp:590-604; config key construction.keep_perfect_loops):
- * "sort_edges" = 1 orders the unitigs by Sequence::RawCompare before ids are assigned (thread-independent ids),
- * "keep_perfect_loops" = 0 drops perfect loops. Defaults (0, 1) reproduce spades-gbuilder. */
+/* Options. Behaviour switches of the reference's spades-core Construction stage (defaults reproduce spades-gbuilder):
+ *   "sort_edges" = 1          unitigs ordered by Sequence::RawCompare before ids are assigned — DeBruijnGraphExtentionConstructor::
+ *                             ConstructGraph, common/assembly_graph/construction/debruijn_graph_constructor.hpp:590-604 (thread-independent ids)
+ *   "keep_perfect_loops" = 0  drop perfect loops (config key construction.keep_perfect_loops; same function)
+ *   "early_tip_bound" = N     EarlyTipClipperProcessor(index, N) before condensation (construction/early_simplification.hpp:38-162;
+ *                             N = RL - K in the reference, stages/construction.cpp:296-301); 0 = off
+ *   "early_at_remover" = 1    EarlyLowComplexityClipperProcessor(index, 0.8, 10, 200) of the RNA pipelines (:164-347; construction.cpp:317-326)
+ *   "submit_contigs" = 1      reads submitted while set are contigs: construction yes, coverage no (construction.cpp:108-117)
+ *   "flank_range" = 50        FlankingCoverage averaging range (graph_support/detail_coverage.hpp:69-76)
+ * Engine knobs (no reference equivalent; closest is the -b buffer-size knob of kmercount.cpp:139); results never depend on them:
+ *   "prededupe" (-1 auto, 0 direct pipeline, 1 force the super-k-mer stage), "skm_cap", "skm_scap", "skm_stage" (its chunk sizes / staging),
+ *   "batch_records" (force HBM-bounded batches), "leaf_cap", "leaf_target", "leaf_grid", "leaf_tab", "s1", "s2" (leaf / MSD split geometry),
+ *   "joint_hist" (level-2 histogram counted with level 1), "device_links" (0 host, 1 device from 65 536 edges, 2 always).
+ * SMX_OPTS="key=value,..." in the environment applies options to every new context. */
 int smx_set_option(smx_ctx *ctx, const char *key, int64_t value);
 
 /* ---- reads -> HBM -------------------------------------------------------------------------
