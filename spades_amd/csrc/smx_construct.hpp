@@ -246,7 +246,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
                            ctx->stream, (const void *)ctx->g_kpo, nkpo, k, (void *)derived);
         HIPCHK(hipGetLastError());
         tend(ctx);
-        if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, derived, 2 * nkpo)) return rc;
+        if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, derived, 2 * nkpo, nullptr, /*recs_reusable=*/true)) return rc;
         ctx->g_kmers = ctx->d_result_buf;
         ctx->g_nkmers = ctx->n_records;
         ctx->g_kboff = ctx->bucket_off;
