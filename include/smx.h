@@ -200,8 +200,8 @@ int smx_graph_write_unitigs(smx_ctx *ctx, const char *path);
  * offsets[n+1]/seq: ACGT unitigs in id order; start_node/end_node = 2*rank + rc of the first / last k-mer, rank being ANY injective
  * id of the canonical k-mer (the reference uses the MPHF index only to group records: debruijn_graph_constructor.hpp:540-547);
  * raw_coverage may be NULL; sort_edges as the option of the same name; format 0 unitig FASTA, 1 GFA, 2 FASTG, 3 .grseq+.cvr. */
-int smx_host_write_graph(unsigned k, uint64_t n_edges, const uint64_t *offsets, const char *seq, const uint32_t *start_node,
-                         const uint32_t *end_node, const uint32_t *raw_coverage, int sort_edges, int format, const char *path,
+int smx_host_write_graph(unsigned k, uint64_t n_edges, const uint64_t *offsets, const char *seq, const uint64_t *start_node,
+                         const uint64_t *end_node, const uint32_t *raw_coverage, int sort_edges, int format, const char *path,
                          const char *flavour_version);
 
 /* ---- instrumentation -----------------------------------------------------------------------

@@ -80,7 +80,7 @@ def load():
         "smx_graph_write_unitigs": (C.c_int, [vp, C.c_char_p]),
         "smx_graph_write_spades": (C.c_int, [vp, C.c_char_p]),
         "smx_graph_write_fastg": (C.c_int, [vp, C.c_char_p]),
-        "smx_host_write_graph": (C.c_int, [C.c_uint, C.c_uint64, u64p, C.c_char_p, u32p, u32p, u32p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
+        "smx_host_write_graph": (C.c_int, [C.c_uint, C.c_uint64, u64p, C.c_char_p, u64p, u64p, u32p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -92,6 +92,8 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "skm_cap")) ctx->opt_skm_cap = value;
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
+    else if (!strcmp(key, "derive_batches")) ctx->opt_derive_batches = value;
+    else if (!strcmp(key, "keep_kpo")) ctx->opt_keep_kpo = value;
     else return fail(ctx, SMX_INVALID_PARAMETER, "unknown option %s", key);
     return SMX_OK;
 }
@@ -543,8 +545,8 @@ int smx_build_graph_from_records(smx_ctx *ctx, unsigned k, unsigned num_buckets,
 
 int smx_graph_set_coverage(smx_ctx *ctx, const uint32_t *raw_coverage, uint64_t n_edges) {
     if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
-    if (n_edges != ctx->gh.n_edges()) return fail(ctx, SMX_INVALID_PARAMETER, "coverage array has %llu entries, graph has %llu unitigs",
-                                                  (unsigned long long)n_edges, (unsigned long long)ctx->gh.n_edges());
+    if (n_edges != ctx->g_ne) return fail(ctx, SMX_INVALID_PARAMETER, "coverage array has %llu entries, graph has %llu unitigs",
+                                          (unsigned long long)n_edges, (unsigned long long)ctx->g_ne);
     if (n_edges && !raw_coverage) return SMX_INVALID_PARAMETER;
     ctx->gh.ecov.assign(raw_coverage, raw_coverage + n_edges);
     return SMX_OK;
@@ -566,11 +568,11 @@ int smx_graph_info(const smx_ctx *ctx, uint64_t *info /* [8] */) {
     if (!ctx->g_ready) return SMX_INVALID_PARAMETER;
     info[0] = ctx->g_nkpo;
     info[1] = ctx->g_nkmers;
-    info[2] = ctx->gh.n_edges();
-    info[3] = ctx->gh.n_loops;
-    info[4] = ctx->gh.n_vertices;
+    info[2] = ctx->g_ne;
+    info[3] = ctx->g_nloops;
+    info[4] = ctx->g_links_dev ? ctx->g_nv : ctx->gh.n_vertices;
     info[5] = ctx->gh.n_links;
-    info[6] = ctx->gh.seq.size();
+    info[6] = ctx->g_nbases;
     info[7] = ctx->g_nw;
     return SMX_OK;
 }
@@ -594,8 +596,11 @@ int smx_graph_copy_kmers(const smx_ctx *cctx, void *kmers_host, uint8_t *masks_h
     return SMX_OK;
 }
 
-int smx_graph_copy_unitigs(const smx_ctx *ctx, uint64_t *offsets, char *seq) {
+int smx_graph_copy_unitigs(const smx_ctx *cctx, uint64_t *offsets, char *seq) {
+    smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
     if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int rc = materialize_host(ctx)) return rc;
     if (offsets) memcpy(offsets, ctx->gh.eoff.data(), ctx->gh.eoff.size() * 8);
     if (seq && !ctx->gh.seq.empty()) memcpy(seq, ctx->gh.seq.data(), ctx->gh.seq.size());
     return SMX_OK;
@@ -628,7 +633,7 @@ int smx_graph_fill_coverage(smx_ctx *ctx) {
 
 int smx_graph_copy_flanking(const smx_ctx *ctx, uint32_t *flank_edge, uint32_t *flank_conjugate) {
     if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
-    const size_t ne = ctx->gh.n_edges();
+    const size_t ne = ctx->g_ne;
     if (ctx->gh.eflank_s.size() != ne || ctx->gh.eflank_e.size() != ne) return SMX_INVALID_PARAMETER;
     if (ne && flank_edge) memcpy(flank_edge, ctx->gh.eflank_s.data(), ne * 4);
     if (ne && flank_conjugate) memcpy(flank_conjugate, ctx->gh.eflank_e.data(), ne * 4);
@@ -637,7 +642,7 @@ int smx_graph_copy_flanking(const smx_ctx *ctx, uint32_t *flank_edge, uint32_t *
 
 int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage) {
     if (!ctx || !ctx->g_ready || !raw_coverage) return SMX_INVALID_PARAMETER;
-    if (ctx->gh.ecov.size() != ctx->gh.n_edges()) return SMX_INVALID_PARAMETER;
+    if (ctx->gh.ecov.size() != ctx->g_ne) return SMX_INVALID_PARAMETER;
     if (!ctx->gh.ecov.empty()) memcpy(raw_coverage, ctx->gh.ecov.data(), ctx->gh.ecov.size() * 4);
     return SMX_OK;
 }
@@ -645,6 +650,8 @@ int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage) {
 int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_version) {
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
     if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
+    (void)hipSetDevice(ctx->device);
+    if (int rc = materialize_host(ctx)) return rc;
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
     bool ok = smxh::write_gfa(ctx->gh, f, flavour_version ? flavour_version : "SPAdes-4.3.0-dev");
@@ -655,6 +662,8 @@ int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_vers
 int smx_graph_write_fastg(smx_ctx *ctx, const char *path) {
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
     if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
+    (void)hipSetDevice(ctx->device);
+    if (int rc = materialize_host(ctx)) return rc;
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
     bool ok = smxh::write_fastg(ctx->gh, f);
@@ -665,6 +674,8 @@ int smx_graph_write_fastg(smx_ctx *ctx, const char *path) {
 int smx_graph_write_spades(smx_ctx *ctx, const char *basename) {
     if (!ctx || !basename) return SMX_INVALID_PARAMETER;
     if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
+    (void)hipSetDevice(ctx->device);
+    if (int rc = materialize_host(ctx)) return rc;
     for (int part = 0; part < 2; ++part) {
         std::string path = std::string(basename) + (part ? ".cvr" : ".grseq");
         FILE *f = fopen(path.c_str(), "wb");
@@ -678,8 +689,8 @@ int smx_graph_write_spades(smx_ctx *ctx, const char *basename) {
 
 // Host-only entry point (no GPU, no context): links + writers on caller-provided unitigs. Lets the reference-side code reuse
 // the writers for edges it computed itself, and lets the CPU test tier cover smx_graph_host.hpp.
-int smx_host_write_graph(unsigned k, uint64_t n_edges, const uint64_t *offsets, const char *seq, const uint32_t *start_node,
-                         const uint32_t *end_node, const uint32_t *raw_coverage, int sort_edges, int format, const char *path,
+int smx_host_write_graph(unsigned k, uint64_t n_edges, const uint64_t *offsets, const char *seq, const uint64_t *start_node,
+                         const uint64_t *end_node, const uint32_t *raw_coverage, int sort_edges, int format, const char *path,
                          const char *flavour_version) {
     if (!offsets || !path || (n_edges && (!seq || !start_node || !end_node))) return SMX_INVALID_PARAMETER;
     smxh::GraphHost g;
@@ -723,6 +734,8 @@ int smx_host_write_graph(unsigned k, uint64_t n_edges, const uint64_t *offsets, 
 int smx_graph_write_unitigs(smx_ctx *ctx, const char *path) {
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
     if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
+    (void)hipSetDevice(ctx->device);
+    if (int rc = materialize_host(ctx)) return rc;
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
     bool ok = smxh::write_unitigs_fasta(ctx->gh, f);

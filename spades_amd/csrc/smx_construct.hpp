@@ -1,22 +1,60 @@
-// spades_amd/csrc/smx_construct.hpp — host side of the construction path: rank indexes, link records / vertices on the device,
-// run_graph (masks, early clippers, successors, walks, loops) and run_coverage (included by smx_api.hip after smx_pipeline.hpp).
+// spades_amd/csrc/smx_construct.hpp — host side of the construction path: rank directories, the k-mer file from the (k+1)-mer file
+// (whole or in bucket ranges), run_graph (masks + successors, early clippers, walks, loops, link records / vertices on the device),
+// the lazily filled host mirror of the graph, and run_coverage (included by smx_api.hip after smx_pipeline.hpp).
+//
+// The graph stays in HBM: unitigs 2-bit packed (the reference's Sequence word layout) with word-aligned starts, edge arrays in
+// the reference's enumeration order, sorted link records and the vertex order. The host mirror (smxh::GraphHost, what the
+// writers format) is filled the first time something asks for it. Ranks and node ids are 64-bit (size_t in the reference,
+// debruijn_graph_constructor.hpp:399-406,506-567).
 #pragma once
 
+void drop_device_graph(smx_ctx *ctx) {
+    arena_put(ctx, ctx->g_uwords);
+    arena_put(ctx, ctx->g_eoffw);
+    arena_put(ctx, ctx->g_elen);
+    arena_put(ctx, ctx->g_estart);
+    arena_put(ctx, ctx->g_eend);
+    arena_put(ctx, ctx->g_eself);
+    arena_put(ctx, ctx->g_lrecs);
+    arena_put(ctx, ctx->g_vstart);
+    ctx->g_uwords = nullptr;
+    ctx->g_eoffw = ctx->g_elen = nullptr;
+    ctx->g_estart = ctx->g_eend = nullptr;
+    ctx->g_eself = nullptr;
+    ctx->g_lrecs = nullptr;
+    ctx->g_vstart = nullptr;
+    ctx->g_nlrec = ctx->g_nv = 0;
+    ctx->g_links_dev = false;
+    ctx->g_dev_valid = false;
+}
+
+void drop_rank_dir(smx_ctx *ctx, smx::RankDir &ix) {
+    arena_put(ctx, (void *)ix.dir);
+    arena_put(ctx, (void *)ix.boff);
+    ix = smx::RankDir{};
+}
+
+void drop_kpo(smx_ctx *ctx) {
+    arena_put(ctx, ctx->g_kpo);
+    ctx->g_kpo = nullptr;
+    drop_rank_dir(ctx, ctx->g_dir_kpo);
+}
+
 void clear_graph(smx_ctx *ctx) {
-    if (ctx->g_kpo) arena_put(ctx, ctx->g_kpo);
+    drop_kpo(ctx);
     if (ctx->g_kmers) {
         if (ctx->d_result == ctx->g_kmers) ctx->d_result = nullptr;
         arena_put(ctx, ctx->g_kmers);
     }
-    if (ctx->g_mask) arena_put(ctx, ctx->g_mask);
-    if (ctx->g_ix_kmers.off) arena_put(ctx, (void *)ctx->g_ix_kmers.off);
-    if (ctx->g_ix_kpo.off) arena_put(ctx, (void *)ctx->g_ix_kpo.off);
-    ctx->g_ix_kmers = smx::RankIndex{};
-    ctx->g_ix_kpo = smx::RankIndex{};
-    ctx->g_kpo = ctx->g_kmers = nullptr;
+    arena_put(ctx, ctx->g_mask);
+    drop_rank_dir(ctx, ctx->g_dir_kmers);
+    drop_device_graph(ctx);
+    ctx->g_kmers = nullptr;
     ctx->g_mask = nullptr;
     ctx->g_nkpo = ctx->g_nkmers = 0;
+    ctx->g_ne = ctx->g_nuwords = ctx->g_nbases = ctx->g_npaths = ctx->g_nloops = 0;
     ctx->g_ready = false;
+    ctx->g_host_valid = false;
     ctx->gh = smxh::GraphHost();
 }
 
@@ -27,9 +65,8 @@ int d2h(smx_ctx *ctx, std::vector<T> &dst, const void *src, size_t n) {
     return 0;
 }
 
-
-// Sort distinct 64-bit keys with the counting pipeline itself: one bucket (B = 1), K = 32 so that the whole word is the key;
-// keys are left-aligned first so that the MSD digits see a spread-out fraction. Used for the link records of the graph.
+// Sort distinct 64-bit keys that the host holds with the counting pipeline itself: one bucket (B = 1), K = 32 so that the whole word
+// is the key; keys are left-aligned first so that the MSD digits see a spread-out fraction (host link path of mid-sized graphs).
 int device_sort_u64(smx_ctx *ctx, std::vector<uint64_t> &keys) {
     const size_t n = keys.size();
     if (n < (1u << 16)) {  // not worth a launch sequence
@@ -67,18 +104,17 @@ int device_sort_u64(smx_ctx *ctx, std::vector<uint64_t> &keys) {
     return rc;
 }
 
-// Sort + unique 64-bit keys that are already in HBM (left-aligned) with the counting pipeline (one bucket, K = 32 so that the whole
-// word is the key). *out points into the temp list (valid until free_temps); the count-result view of the context is preserved.
-int device_sort_keys_dev(smx_ctx *ctx, void *d_keys, uint64_t n, unsigned long long **out, uint64_t *n_out) {
+// Sort + unique two-word records (w0, w1) that are already in HBM with the counting pipeline (one bucket, K = 64: the record is
+// its own key, word 0 most significant). *out points into the temp list (valid until free_temps); the count-result view of the
+// context is preserved.
+int device_sort_recs2(smx_ctx *ctx, void *d_keys, uint64_t n, Rec<2> **out, uint64_t *n_out) {
     void *sv_res = ctx->d_result;
     const uint64_t sv_n = ctx->n_records, sv_inst = ctx->n_instances;
     const unsigned sv_nw = ctx->nw, sv_K = ctx->K, sv_B = ctx->num_buckets;
     std::vector<uint64_t> sv_boff = ctx->bucket_off;
-    const bool sv_want = ctx->want_index;
-    ctx->want_index = false;
     ctx->d_result = nullptr;  // non-owning view; d_result_buf is null here
-    int rc = run_count<1>(ctx, 32, SMX_MODE_ALL, 1, d_keys, n, nullptr, /*recs_reusable=*/true);
-    *out = (unsigned long long *)ctx->d_result_buf;
+    int rc = run_count<2>(ctx, 64, SMX_MODE_ALL, 1, d_keys, n, nullptr, /*recs_reusable=*/true);
+    *out = (Rec<2> *)ctx->d_result_buf;
     *n_out = ctx->n_records;
     ctx->d_result_buf = nullptr;  // the result block stays in the temp list
     ctx->d_result = sv_res;
@@ -88,126 +124,291 @@ int device_sort_keys_dev(smx_ctx *ctx, void *d_keys, uint64_t n, unsigned long l
     ctx->K = sv_K;
     ctx->num_buckets = sv_B;
     ctx->bucket_off = sv_boff;
-    ctx->want_index = sv_want;
     return rc;
 }
 
-// Link records and vertices of the graph on the device; fills g.recs / g.vstart / g.n_vertices exactly like smxh::build_links.
-// Returns 1 when the sizes do not fit the packed keys (the caller then takes the host path).
-int device_build_links(smx_ctx *ctx, smxh::GraphHost &g, uint64_t n_ranks) {
-    const uint64_t ne = g.n_edges();
-    if (ne == 0 || (ne < (1u << 16) && ctx->opt_device_links < 2) || ne >= (1ull << 29) || n_ranks >= (1ull << 31)) return 1;
-    uint32_t *estart, *eend;
-    uint8_t *eself;
-    unsigned long long *keys, *sorted = nullptr, *one, *vidx;
-    if (int rc = dalloc(ctx, &estart, ne)) return rc;
-    if (int rc = dalloc(ctx, &eend, ne)) return rc;
-    if (int rc = dalloc(ctx, &eself, ne)) return rc;
+unsigned grid_for(uint64_t n, unsigned cap = 1u << 16) { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + BLK - 1) / BLK, cap)); }
+
+// Link records and vertices of the graph on the device, from the edge arrays in HBM: g_lrecs (sorted records) and g_vstart
+// (first record of every vertex, in vertex-id order).
+int device_build_links(smx_ctx *ctx, uint64_t n_ranks) {
+    const uint64_t ne = ctx->g_ne;
+    Rec<2> *keys, *sorted = nullptr;
     if (int rc = dalloc(ctx, &keys, 2 * ne)) return rc;
-    HIPCHK(hipMemcpyAsync(estart, g.estart.data(), ne * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(eend, g.eend.data(), ne * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(eself, g.eself.data(), ne, hipMemcpyHostToDevice, ctx->stream));
-    const uint64_t maxkey = ((n_ranks ? n_ranks - 1 : 0) << 33) | ((1ull << 33) - 1);
-    const unsigned sh = (unsigned)__builtin_clzll(maxkey | 1);
-    const unsigned g1 = (unsigned)std::min<uint64_t>((ne + BLK - 1) / BLK, 1u << 16);
-    hipLaunchKernelGGL(k_link_keys, dim3(g1), dim3(BLK), 0, ctx->stream, (const uint32_t *)estart, (const uint32_t *)eend, (const uint8_t *)eself, ne, sh,
-                       keys);
+    const unsigned sh = (unsigned)__builtin_clzll((n_ranks ? n_ranks - 1 : 0) | 1);
+    hipLaunchKernelGGL(k_link_keys, dim3(grid_for(ne)), dim3(BLK), 0, ctx->stream, (const node_t *)ctx->g_estart, (const node_t *)ctx->g_eend,
+                       (const uint8_t *)ctx->g_eself, ne, sh, keys);
     HIPCHK(hipGetLastError());
     uint64_t nrec = 0;
-    if (int rc = device_sort_keys_dev(ctx, keys, 2 * ne, &sorted, &nrec)) return rc;
-    uint64_t nself = 0;
-    for (uint8_t f : g.eself) nself += f;
-    if (nrec != 2 * ne - nself) return fail(ctx, SMX_DEVICE_ERROR, "link records: %llu after sort, expected %llu", (unsigned long long)nrec,
-                                            (unsigned long long)(2 * ne - nself));
+    if (int rc = device_sort_recs2(ctx, keys, 2 * ne, &sorted, &nrec)) return rc;
+    if (nrec == 0 || nrec > 2 * ne) return fail(ctx, SMX_DEVICE_ERROR, "link records: %llu after sort from %llu edges", (unsigned long long)nrec, (unsigned long long)ne);
+    unsigned long long *one, *vidx;
     if (int rc = dalloc(ctx, &one, nrec)) return rc;
     if (int rc = dalloc(ctx, &vidx, nrec + 1)) return rc;
-    const unsigned g2 = (unsigned)std::min<uint64_t>((nrec + BLK - 1) / BLK, 1u << 16);
-    hipLaunchKernelGGL(k_vertex_flags, dim3(g2), dim3(BLK), 0, ctx->stream, sorted, nrec, sh, one);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_unshift, dim3(g2), dim3(BLK), 0, ctx->stream, sorted, nrec, sh);
+    hipLaunchKernelGGL(k_vertex_flags, dim3(grid_for(nrec)), dim3(BLK), 0, ctx->stream, (const Rec<2> *)sorted, nrec, one);
     HIPCHK(hipGetLastError());
     if (int rc = scan_u64(ctx, one, vidx, nrec)) return rc;
     unsigned long long nv = 0;
     HIPCHK(hipMemcpyAsync(&nv, vidx + nrec, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (nv >= (1ull << 31)) return 1;
-    unsigned long long *vpos, *vkeys, *vsorted = nullptr, *vstart;
+    // the sorted records become part of the graph before the second sort reuses the arena
+    Rec<2> *lrecs;
+    if (int rc = dalloc(ctx, &lrecs, nrec, false)) return rc;
+    ctx->g_lrecs = lrecs;
+    HIPCHK(hipMemcpyAsync(lrecs, sorted, nrec * sizeof(Rec<2>), hipMemcpyDeviceToDevice, ctx->stream));
+    unsigned long long *vpos, *vstart;
+    Rec<2> *vkeys, *vsorted = nullptr;
     if (int rc = dalloc(ctx, &vpos, nv + 1)) return rc;
     if (int rc = dalloc(ctx, &vkeys, nv + 1)) return rc;
-    if (int rc = dalloc(ctx, &vstart, nv + 1)) return rc;
-    const uint64_t maxv = (((((3 + 2 * ne) << 2) | 3ull) << 31) | ((1ull << 31) - 1));
-    const unsigned sh2 = (unsigned)__builtin_clzll(maxv | 1);
-    hipLaunchKernelGGL(k_vertex_collect, dim3(g2), dim3(BLK), 0, ctx->stream, (const unsigned long long *)sorted, (const unsigned long long *)one,
+    if (int rc = dalloc(ctx, &vstart, nv + 1, false)) return rc;
+    ctx->g_vstart = vstart;
+    const unsigned sh2 = (unsigned)__builtin_clzll((((3 + 2 * ne) << 2) | 3ull) | 1);
+    hipLaunchKernelGGL(k_vertex_collect, dim3(grid_for(nrec)), dim3(BLK), 0, ctx->stream, (const Rec<2> *)lrecs, (const unsigned long long *)one,
                        (const unsigned long long *)vidx, nrec, sh2, vpos, vkeys);
     HIPCHK(hipGetLastError());
-    // the keys of the records are needed after the second sort: copy them out first (the pipeline reuses the arena)
-    std::vector<uint64_t> hkeys(nrec);
-    HIPCHK(hipMemcpyAsync(hkeys.data(), sorted, nrec * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
     uint64_t nv2 = 0;
-    if (nv >= (1u << 16) || ctx->opt_device_links >= 2) {
-        if (int rc = device_sort_keys_dev(ctx, vkeys, nv, &vsorted, &nv2)) return rc;
-        if (nv2 != nv) return fail(ctx, SMX_DEVICE_ERROR, "vertex keys are not distinct");
-    } else {
-        std::vector<uint64_t> hv(nv);
-        HIPCHK(hipMemcpy(hv.data(), vkeys, nv * 8, hipMemcpyDeviceToHost));
-        smxh::radix_sort_u64(hv);
-        HIPCHK(hipMemcpy(vkeys, hv.data(), nv * 8, hipMemcpyHostToDevice));
-        vsorted = vkeys;
-    }
-    hipLaunchKernelGGL(k_vertex_permute, dim3((unsigned)std::min<uint64_t>((nv + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
-                       (const unsigned long long *)vsorted, (const unsigned long long *)vpos, (uint64_t)nv, sh2, vstart);
+    if (int rc = device_sort_recs2(ctx, vkeys, nv, &vsorted, &nv2)) return rc;
+    if (nv2 != nv) return fail(ctx, SMX_DEVICE_ERROR, "vertex keys are not distinct");
+    hipLaunchKernelGGL(k_vertex_permute, dim3(grid_for(nv)), dim3(BLK), 0, ctx->stream, (const Rec<2> *)vsorted, (const unsigned long long *)vpos,
+                       (uint64_t)nv, vstart);
     HIPCHK(hipGetLastError());
-    std::vector<unsigned long long> hvs(nv);
-    HIPCHK(hipMemcpyAsync(hvs.data(), vstart, nv * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    g.recs.resize(2 * ne);
-    for (size_t i = 0; i < nrec; ++i) {
-        const uint64_t e = hkeys[i] & ((1ull << 33) - 1);
-        g.recs[i] = {((hkeys[i] >> 33) << 2) | (e & 3), e >> 2};
-    }
-    for (size_t i = nrec; i < 2 * ne; ++i) g.recs[i] = {~0ull, 0};
-    g.vstart.assign(hvs.begin(), hvs.end());
-    g.n_vertices = nv;
+    ctx->g_nlrec = nrec;
+    ctx->g_nv = nv;
+    ctx->g_lsh = sh;
+    ctx->g_links_dev = true;
     return 0;
 }
 
-// Adopt the fine-bin offsets of the pipeline run that just produced a sorted file as its lookup index (bucket offsets if the run
-// kept none).
-int take_rank_index(smx_ctx *ctx, smx::RankIndex &ix, unsigned K, uint32_t B) {
-    ix = smx::RankIndex{};
+// Rank directory of a sorted file whose bucket offsets the host knows.
+template <int NW>
+int build_rank_dir(smx_ctx *ctx, const void *recs, uint64_t n, const std::vector<uint64_t> &boff, uint32_t B, unsigned K, smx::RankDir &ix) {
+    drop_rank_dir(ctx, ix);
+    uint64_t mx = 0;
+    for (uint32_t b = 0; b < B; ++b) mx = std::max(mx, boff[b + 1] - boff[b]);
+    if (mx >= (1ull << 32)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "a bucket of %llu records exceeds the directory's 32-bit offsets (use more buckets)", (unsigned long long)mx);
+    const uint64_t sb = std::min<uint64_t>(std::max<uint64_t>(1, (n / B + 1) / 2), 1ull << 30);
+    unsigned long long *d_boff;
+    uint32_t *dir;
+    if (int rc = dalloc(ctx, &d_boff, (size_t)B + 1, false)) return rc;
+    ix.boff = d_boff;
+    if (int rc = dalloc(ctx, &dir, (size_t)B * (sb + 1), false)) return rc;
+    ix.dir = dir;
     ix.B = B;
+    ix.SB = (uint32_t)sb;
     ix.K = K;
-    ix.S1 = 1;
-    if (ctx->last_idx_off && ctx->last_idx_bins) {
-        ix.off = ctx->last_idx_off;
-        ctx->last_idx_off = nullptr;
-        ix.S1 = ctx->last_idx_S1;
-        ix.nf = (uint32_t)std::min<size_t>(ctx->last_idx_f.size(), 6);
-        for (uint32_t i = 0; i < ix.nf; ++i) ix.f[i] = ctx->last_idx_f[i];
+    std::vector<unsigned long long> hb(boff.begin(), boff.begin() + B + 1);
+    HIPCHK(hipMemcpyAsync(d_boff, hb.data(), ((size_t)B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(dir, 0, (size_t)B * (sb + 1) * 4, ctx->stream));
+    if (n) {
+        hipLaunchKernelGGL((k_dir_fill<NW>), dim3(grid_for(n)), dim3(BLK), 0, ctx->stream, recs, n, ix, dir);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // hb goes out of scope
+    return 0;
+}
+
+// ---- 2. canonical k-mers in k-mer-file order (DeBruijnKMerKMerSplitter + KMerDiskCounter, kmer_splitters.hpp:138-207) ----
+// Whole: 2 derived records per (k+1)-mer through the pipeline at once. In bucket ranges when that does not fit HBM (or on request):
+// the buckets of the k-mer file are disjoint, so the sorted-unique output of a range is final and only has to be appended.
+template <int NW>
+int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B) {
+    const uint64_t nkpo = ctx->g_nkpo;
+    const size_t W = (size_t)NW * 8;
+    const size_t avail = arena_avail(ctx);
+    const size_t need_whole = (size_t)(4.25 * (double)nkpo * (double)W) + ((size_t)64 << 20);
+    const bool whole = ctx->opt_derive_batches > 1 ? false : (ctx->opt_derive_batches == 1 || need_whole <= avail);
+    if (whole) {
+        Rec<NW> *derived;
+        if (int rc = dalloc(ctx, &derived, 2 * nkpo)) return rc;
+        tbegin(ctx, "derive_kmers");
+        hipLaunchKernelGGL((k_derive_kmers<NW>), dim3(grid_for(nkpo)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kpo, nkpo, k, (void *)derived);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, derived, 2 * nkpo, nullptr, /*recs_reusable=*/true)) return rc;
+        ctx->g_kmers = ctx->d_result_buf;
+        detach_temp(ctx, ctx->g_kmers);
+        ctx->g_nkmers = ctx->n_records;
+        ctx->g_kboff = ctx->bucket_off;
+        ctx->d_result_buf = nullptr;
+        free_temps(ctx);
         return 0;
     }
-    unsigned long long *d;
-    if (int rc = dalloc(ctx, &d, B + 1, false)) return rc;
-    std::vector<unsigned long long> hb(ctx->bucket_off.begin(), ctx->bucket_off.end());
-    hb.resize(B + 1, hb.empty() ? 0 : hb.back());
-    HIPCHK(hipMemcpy(d, hb.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice));
-    ix.off = d;
+    if (B > 12 * 1024) return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets=%u too large for the bucket histogram", B);
+    unsigned long long *d_hist, *d_count;
+    if (int rc = dalloc(ctx, &d_hist, B)) return rc;
+    if (int rc = dalloc(ctx, &d_count, 1)) return rc;
+    HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)B * 8, ctx->stream));
+    tbegin(ctx, "derive_hist");
+    hipLaunchKernelGGL((k_derive_hist<NW>), dim3(grid_for(nkpo, 4096)), dim3(BLK), (size_t)B * 4, ctx->stream, (const void *)ctx->g_kpo, nkpo, k, B, d_hist);
+    HIPCHK(hipGetLastError());
+    tend(ctx);
+    std::vector<unsigned long long> h(B);
+    HIPCHK(hipMemcpyAsync(h.data(), d_hist, (size_t)B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // the k-mer file: a graph has about as many k-mers as (k+1)-mers; grown (copy) in the rare case it has more
+    uint64_t cap = std::min<uint64_t>(2 * nkpo, nkpo + nkpo / 8 + (1u << 20));
+    Rec<NW> *file;
+    if (int rc = dalloc(ctx, &file, cap, false)) return rc;
+    ctx->g_kmers = file;
+    uint64_t max_batch = (uint64_t)((double)arena_avail(ctx) / (2.25 * (double)W));
+    if (ctx->opt_derive_batches > 1) max_batch = (2 * nkpo + ctx->opt_derive_batches - 1) / ctx->opt_derive_batches;
+    uint64_t used = 0, remaining = 2 * nkpo;
+    ctx->g_kboff.assign(B + 1, 0);
+    for (uint32_t b0 = 0; b0 < B;) {
+        uint32_t b1 = b0;
+        uint64_t sum = 0;
+        while (b1 < B && (b1 == b0 || sum + h[b1] <= max_batch)) sum += h[b1++];
+        if (sum > max_batch && ctx->opt_derive_batches <= 1)
+            return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "bucket %u alone holds %llu derived k-mers: more than HBM has room to sort (use more buckets)", b0, (unsigned long long)sum);
+        if (sum) {
+            Rec<NW> *derived;
+            if (int rc = dalloc(ctx, &derived, sum)) return rc;
+            HIPCHK(hipMemsetAsync(d_count, 0, 8, ctx->stream));
+            tbegin(ctx, "derive_kmers");
+            hipLaunchKernelGGL((k_derive_range<NW>), dim3(grid_for(nkpo, 256 * 32)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kpo, nkpo, k, B, b0, b1,
+                               (void *)derived, d_count);
+            HIPCHK(hipGetLastError());
+            tend(ctx);
+            if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, derived, sum, nullptr, /*recs_reusable=*/true)) return rc;
+            const uint64_t nres = ctx->n_records;
+            remaining -= sum;
+            if (used + nres > cap) {
+                const uint64_t ncap = used + nres + remaining;
+                Rec<NW> *bigger;
+                if (int rc = dalloc(ctx, &bigger, ncap, false)) return rc;
+                HIPCHK(hipMemcpyAsync(bigger, file, used * W, hipMemcpyDeviceToDevice, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                arena_put(ctx, file);
+                ctx->g_kmers = file = bigger;
+                cap = ncap;
+            }
+            HIPCHK(hipMemcpyAsync(file + used, ctx->d_result_buf, nres * W, hipMemcpyDeviceToDevice, ctx->stream));
+            for (uint32_t b = b0; b < b1; ++b) ctx->g_kboff[b + 1] = used + ctx->bucket_off[b + 1];
+            used += nres;
+            ctx->d_result_buf = ctx->d_result = nullptr;  // one of the temps
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            void *keep[2] = {d_hist, d_count};
+            std::vector<void *> rest;
+            for (void *p : ctx->temps) {
+                if (p == keep[0] || p == keep[1]) rest.push_back(p);
+                else arena_put(ctx, p);
+            }
+            ctx->temps = rest;
+        } else {
+            for (uint32_t b = b0; b < b1; ++b) ctx->g_kboff[b + 1] = used;
+        }
+        b0 = b1;
+    }
+    ctx->g_nkmers = used;
+    // the count-result view of the context describes the k-mer file (smx_copy_final_kmers, smx_bucket_sizes)
+    ctx->n_records = used;
+    ctx->bucket_off = ctx->g_kboff;
+    ctx->K = k;
+    ctx->nw = NW;
+    ctx->num_buckets = B;
+    free_temps(ctx);
+    return 0;
+}
+
+// ---- host mirror of the device graph -----------------------------------------------------------------------------------------
+// 2-bit words -> ACGT, several threads
+inline void unpack_unitigs(const uint64_t *words, const unsigned long long *eoffw, const uint64_t *eoff, size_t ne, char *seq) {
+    smxh::parallel_blocks(ne, (size_t)1 << 12, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const uint64_t *w = words + eoffw[i];
+            char *s = seq + eoff[i];
+            const uint64_t len = eoff[i + 1] - eoff[i];
+            for (uint64_t t = 0; t < len; ++t) s[t] = "ACGT"[(w[t >> 5] >> ((t & 31) << 1)) & 3];
+        }
+    });
+}
+
+int materialize_host(smx_ctx *ctx) {
+    if (ctx->g_host_valid) return 0;
+    smxh::GraphHost &g = ctx->gh;
+    const uint64_t ne = ctx->g_ne;
+    std::vector<unsigned long long> eoffw, elen;
+    if (int rc = d2h(ctx, eoffw, ctx->g_eoffw, ne)) return rc;
+    if (int rc = d2h(ctx, elen, ctx->g_elen, ne)) return rc;
+    g.eoff.assign(ne + 1, 0);
+    for (uint64_t i = 0; i < ne; ++i) g.eoff[i + 1] = g.eoff[i] + elen[i];
+    {
+        std::vector<uint64_t> words;
+        if (int rc = d2h(ctx, words, ctx->g_uwords, ctx->g_nuwords)) return rc;
+        g.seq.resize(g.eoff[ne]);
+        if (ne) unpack_unitigs(words.data(), eoffw.data(), g.eoff.data(), ne, &g.seq[0]);
+    }
+    if (int rc = d2h(ctx, g.estart, ctx->g_estart, ne)) return rc;
+    if (int rc = d2h(ctx, g.eend, ctx->g_eend, ne)) return rc;
+    if (int rc = d2h(ctx, g.eself, ctx->g_eself, ne)) return rc;
+    g.n_paths = ctx->g_npaths;
+    g.n_loops = ctx->g_nloops;
+    if (ctx->g_links_dev) {
+        std::vector<Rec<2>> lr;
+        if (int rc = d2h(ctx, lr, ctx->g_lrecs, ctx->g_nlrec)) return rc;
+        std::vector<unsigned long long> vs;
+        if (int rc = d2h(ctx, vs, ctx->g_vstart, ctx->g_nv)) return rc;
+        g.recs.resize(2 * ne);
+        const unsigned sh = ctx->g_lsh;
+        const size_t nrec = lr.size();
+        smxh::parallel_blocks(nrec, (size_t)1 << 16, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) g.recs[i] = {((lr[i].w[0] >> sh) << 2) | (lr[i].w[1] & 3), lr[i].w[1] >> 2};
+        });
+        for (size_t i = nrec; i < 2 * ne; ++i) g.recs[i] = {~0ull, 0};  // the missing end records of self-conjugate edges
+        g.vstart.assign(vs.begin(), vs.end());
+        g.n_vertices = ctx->g_nv;
+    }
+    ctx->g_host_valid = true;
+    return 0;
+}
+
+// host -> device (after a host-side reordering of the edges): packed unitigs + edge arrays
+int upload_graph(smx_ctx *ctx) {
+    drop_device_graph(ctx);
+    const smxh::GraphHost &g = ctx->gh;
+    const uint64_t ne = g.n_edges();
+    std::vector<unsigned long long> eoffw(ne + 1, 0), elen(ne);
+    for (uint64_t i = 0; i < ne; ++i) {
+        elen[i] = g.eoff[i + 1] - g.eoff[i];
+        eoffw[i + 1] = eoffw[i] + (elen[i] + 31) / 32;
+    }
+    std::vector<uint64_t> words(eoffw[ne] + 8, 0);
+    smxh::parallel_blocks(ne, (size_t)1 << 12, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const char *s = g.seq.data() + g.eoff[i];
+            uint64_t *w = words.data() + eoffw[i];
+            for (uint64_t t = 0; t < elen[i]; ++t) {
+                const char ch = s[t];
+                const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+                w[t >> 5] |= code << ((t & 31) << 1);
+            }
+        }
+    });
+    if (int rc = dalloc(ctx, &ctx->g_uwords, words.size(), false)) return rc;
+    if (int rc = dalloc(ctx, &ctx->g_eoffw, ne + 1, false)) return rc;
+    if (int rc = dalloc(ctx, &ctx->g_elen, ne + 1, false)) return rc;
+    if (int rc = dalloc(ctx, &ctx->g_estart, ne + 1, false)) return rc;
+    if (int rc = dalloc(ctx, &ctx->g_eend, ne + 1, false)) return rc;
+    if (int rc = dalloc(ctx, &ctx->g_eself, ne + 1, false)) return rc;
+    HIPCHK(hipMemcpy(ctx->g_uwords, words.data(), words.size() * 8, hipMemcpyHostToDevice));
+    if (ne) {
+        HIPCHK(hipMemcpy(ctx->g_eoffw, eoffw.data(), ne * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->g_elen, elen.data(), ne * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->g_estart, g.estart.data(), ne * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->g_eend, g.eend.data(), ne * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->g_eself, g.eself.data(), ne, hipMemcpyHostToDevice));
+    }
+    ctx->g_ne = ne;
+    ctx->g_nuwords = eoffw[ne];
+    ctx->g_nbases = g.eoff[ne];
+    ctx->g_dev_valid = true;
     return 0;
 }
 
 template <int NW>
 int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullptr, uint64_t n_kpo_recs = 0) {
     clear_graph(ctx);
-    struct IndexScope {  // the pipeline keeps its fine-bin offsets only while a graph is being built
-        smx_ctx *c;
-        explicit IndexScope(smx_ctx *c_) : c(c_) { c->want_index = true; }
-        ~IndexScope() {
-            c->want_index = false;
-            if (c->last_idx_off) arena_put(c, c->last_idx_off);
-            c->last_idx_off = nullptr;
-        }
-    } index_scope(ctx);
     WallTrace gwt;
     ctx->g_k = k;
     ctx->g_nw = NW;
@@ -221,16 +422,16 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         if (int rc = count_reads<NW>(ctx, k + 1, SMX_MODE_CANONICAL, B)) return rc;
     }
     ctx->g_kpo = ctx->d_result_buf;
+    detach_temp(ctx, ctx->g_kpo);
+    ctx->d_result_buf = ctx->d_result = nullptr;
+    free_temps(ctx);
     ctx->g_nkpo = ctx->n_records;
     ctx->g_kpoboff = ctx->bucket_off;
-    if (ctx->n_records)
-        if (int rc = take_rank_index(ctx, ctx->g_ix_kpo, k + 1, B)) return rc;
-    ctx->d_result_buf = ctx->d_result = nullptr;
-    free_temps(ctx, ctx->g_kpo);
     const uint64_t nkpo = ctx->g_nkpo;
     ctx->g_kboff.assign(B + 1, 0);
+    gwt.mark(ctx, "g:kpo count");
     if (nkpo == 0) {
-        smxh::build_links(ctx->gh);
+        ctx->g_host_valid = true;  // the empty graph
         ctx->g_ready = true;
         ctx->n_records = 0;
         ctx->K = k;
@@ -238,44 +439,44 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         return 0;
     }
     // ---- 2. canonical k-mers in k-mer-file order ----------------------------------------------
-    {
-        Rec<NW> *derived;
-        if (int rc = dalloc(ctx, &derived, 2 * nkpo)) return rc;
-        tbegin(ctx, "derive_kmers");
-        hipLaunchKernelGGL((k_derive_kmers<NW>), dim3((unsigned)std::min<uint64_t>((nkpo + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0,
-                           ctx->stream, (const void *)ctx->g_kpo, nkpo, k, (void *)derived);
-        HIPCHK(hipGetLastError());
-        tend(ctx);
-        if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, derived, 2 * nkpo, nullptr, /*recs_reusable=*/true)) return rc;
-        ctx->g_kmers = ctx->d_result_buf;
-        ctx->g_nkmers = ctx->n_records;
-        ctx->g_kboff = ctx->bucket_off;
-        if (int rc = take_rank_index(ctx, ctx->g_ix_kmers, k, B)) return rc;
-        ctx->d_result_buf = nullptr;
-        ctx->d_result = ctx->g_kmers;  // smx_copy_final_kmers() now yields the k-mer file
-        free_temps(ctx, ctx->g_kmers);
-    }
-    gwt.mark(ctx, "g:counts");
+    if (int rc = derive_kmer_file<NW>(ctx, k, B)) return rc;
+    ctx->d_result = ctx->g_kmers;  // smx_copy_final_kmers() now yields the k-mer file
+    gwt.mark(ctx, "g:kmer file");
     const uint64_t D0 = ctx->g_nkmers;
-    if (D0 >= (1ull << 31)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%llu k-mers exceed the 2^31 node-id limit", (unsigned long long)D0);
-    const unsigned grid = (unsigned)std::min<uint64_t>((2 * D0 + BLK - 1) / BLK, 1u << 16);
-    // ---- 3. extension masks ---------------------------------------------------------------------
+    if (D0 >= (1ull << 60)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%llu k-mers exceed the node-id range", (unsigned long long)D0);
+    const unsigned grid = grid_for(2 * D0);
+    tbegin(ctx, "rank_dir");
+    if (int rc = build_rank_dir<NW>(ctx, ctx->g_kmers, D0, ctx->g_kboff, B, k, ctx->g_dir_kmers)) return rc;
+    tend(ctx);
+    // ---- 3. extension masks + successors --------------------------------------------------------
     uint32_t *d_err;
     if (int rc = dalloc(ctx, &d_err, 1)) return rc;
     HIPCHK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
-    const smx::RankIndex ixk = ctx->g_ix_kmers;
-    if (int rc = dalloc(ctx, &ctx->g_mask, (size_t)((D0 + 3) / 4 * 4 + 4), false)) return rc;
-    HIPCHK(hipMemsetAsync(ctx->g_mask, 0, (size_t)((D0 + 3) / 4 * 4 + 4), ctx->stream));
+    const smx::RankDir ixk = ctx->g_dir_kmers;
+    const size_t mask_bytes = (size_t)((D0 + 7) / 8 * 8 + 8);
+    if (int rc = dalloc(ctx, &ctx->g_mask, mask_bytes, false)) return rc;
+    HIPCHK(hipMemsetAsync(ctx->g_mask, 0, mask_bytes, ctx->stream));
+    node_t *succ;
+    if (int rc = dalloc(ctx, &succ, 2 * D0)) return rc;
     tbegin(ctx, "fill_masks");
-    hipLaunchKernelGGL((k_fill_masks<NW>), dim3((unsigned)std::min<uint64_t>((nkpo + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
-                       (const void *)ctx->g_kpo, nkpo, k, (const void *)ctx->g_kmers, ixk, (uint32_t *)ctx->g_mask, d_err);
+    hipLaunchKernelGGL((k_fill_masks<NW>), dim3(grid_for(nkpo)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kpo, nkpo, k, (const void *)ctx->g_kmers,
+                       ixk, (uint32_t *)ctx->g_mask, succ, d_err);
     HIPCHK(hipGetLastError());
     tend(ctx);
-    uint32_t *succ;
-    if (int rc = dalloc(ctx, &succ, 2 * D0)) return rc;
+    {
+        // the (k+1)-mer file is only needed again by -c; when HBM is short it goes now and the coverage pass recounts it
+        const size_t later = (size_t)D0 * 40;  // visited + candidate and edge arrays of the walks, generously
+        const bool keep = ctx->opt_keep_kpo > 0 || (ctx->opt_keep_kpo < 0 && arena_avail(ctx) > later);
+        if (!keep) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            drop_kpo(ctx);
+        }
+    }
+    bool clipped = false;
     // ---- 3a. early A/T remover (RNA pipelines: EarlyATClipper::run, stages/construction.cpp:317-326) --------------
     ctx->g_at_edges = ctx->g_at_tip_kmers = 0;
     if (ctx->opt_early_at) {
+        clipped = true;
         const double ratio = 0.8;
         const uint32_t min_len = 10, max_len = 200;
         // math::ls(a, b) = !AlmostEquals(a, b) && a < b (4 ULPs, math/xmath.h:284-312): thresholds as the smallest count that is NOT ls
@@ -319,7 +520,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, succ, d_err);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL((k_at_tips_mark<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const uint32_t *)succ, D0, k, ixk, min_len, max_len, (const uint16_t *)d_thr, isolate, tipped, astats, d_err);
+                           (const node_t *)succ, D0, k, ixk, min_len, max_len, (const uint16_t *)d_thr, isolate, tipped, astats, d_err);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_tip_apply, dim3(grid), dim3(BLK), 0, ctx->stream, ctx->g_mask, (const uint8_t *)isolate, D0);
         HIPCHK(hipGetLastError());
@@ -336,6 +537,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     // ---- 3b. early tip clipper (spades-core variant, off for spades-gbuilder) ---------------------
     ctx->g_tip_kmers = ctx->g_tips = 0;
     if (ctx->opt_early_tip_bound > 0) {
+        clipped = true;
         uint8_t *isolate, *tipped;
         unsigned long long *tstats;
         if (int rc = dalloc(ctx, &isolate, D0 + 1)) return rc;
@@ -348,7 +550,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, succ, d_err);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL((k_tip_mark<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const uint32_t *)succ, D0, k, ixk, (uint32_t)std::min<int64_t>(ctx->opt_early_tip_bound, 0x7FFFFFFF), isolate, tipped, tstats,
+                           (const node_t *)succ, D0, k, ixk, (uint32_t)std::min<int64_t>(ctx->opt_early_tip_bound, 0x7FFFFFFF), isolate, tipped, tstats,
                            d_err);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_tip_apply, dim3(grid), dim3(BLK), 0, ctx->stream, ctx->g_mask, (const uint8_t *)isolate, D0);
@@ -363,224 +565,326 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         ctx->g_tip_kmers = hs[0];
         ctx->g_tips = hs[1];
     }
-    // ---- 4. successors + start de-edges -------------------------------------------------------
-    unsigned long long *ccnt, *coff;
-    if (int rc = dalloc(ctx, &ccnt, D0)) return rc;
-    if (int rc = dalloc(ctx, &coff, D0 + 1)) return rc;
-    tbegin(ctx, "succ");
-    hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, succ, d_err);
-    HIPCHK(hipGetLastError());
-    tend(ctx);
+    if (clipped) {  // the successor table has to describe the clipped masks
+        tbegin(ctx, "succ");
+        hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, succ, d_err);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+    }
+    // ---- 4. start de-edges -----------------------------------------------------------------------
+    const uint64_t ntiles = (D0 + CAND_TILE - 1) / CAND_TILE;
+    unsigned long long *tcnt, *toff;
+    if (int rc = dalloc(ctx, &tcnt, ntiles)) return rc;
+    if (int rc = dalloc(ctx, &toff, ntiles + 1)) return rc;
     tbegin(ctx, "candidates");
-    hipLaunchKernelGGL(k_cand_count, dim3(grid), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, ccnt);
+    hipLaunchKernelGGL(k_cand_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, tcnt);
     HIPCHK(hipGetLastError());
-    if (int rc = scan_u64(ctx, ccnt, coff, D0)) return rc;
+    if (int rc = scan_u64(ctx, tcnt, toff, ntiles)) return rc;
     unsigned long long C = 0;
-    HIPCHK(hipMemcpyAsync(&C, coff + D0, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&C, toff + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     tend(ctx);
     gwt.mark(ctx, "g:masks+succ");
-    std::vector<unsigned long long> h_eoff;
-    uint64_t n_paths = 0;
     uint8_t *visited;
-    if (int rc = dalloc(ctx, &visited, D0 + 1)) return rc;
-    HIPCHK(hipMemsetAsync(visited, 0, D0 + 1, ctx->stream));
+    if (int rc = dalloc(ctx, &visited, D0 + 8)) return rc;
+    HIPCHK(hipMemsetAsync(visited, 0, D0 + 8, ctx->stream));
+    uint64_t nkept = 0, ktotalw = 0;
     if (C > 0) {
-        unsigned long long *cand, *len, *soff, *keeplen, *koff, *one, *eidx;
-        uint32_t *first, *last;
+        unsigned long long *cand, *len, *kw, *one;
+        node_t *first, *last;
         uint8_t *flags;
         if (int rc = dalloc(ctx, &cand, C)) return rc;
         if (int rc = dalloc(ctx, &len, C)) return rc;
-        if (int rc = dalloc(ctx, &soff, C + 1)) return rc;
-        if (int rc = dalloc(ctx, &keeplen, C)) return rc;
-        if (int rc = dalloc(ctx, &koff, C + 1)) return rc;
-        if (int rc = dalloc(ctx, &one, C)) return rc;
-        if (int rc = dalloc(ctx, &eidx, C + 1)) return rc;
+        if (int rc = dalloc(ctx, &kw, C + 1)) return rc;
+        if (int rc = dalloc(ctx, &one, C + 1)) return rc;
         if (int rc = dalloc(ctx, &first, C)) return rc;
         if (int rc = dalloc(ctx, &last, C)) return rc;
         if (int rc = dalloc(ctx, &flags, C)) return rc;
-        const unsigned cgrid = (unsigned)std::min<uint64_t>((C + BLK - 1) / BLK, 1u << 16);
-        hipLaunchKernelGGL(k_cand_expand, dim3(grid), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask,
-                           (const unsigned long long *)coff, D0, cand);
+        const unsigned cgrid = grid_for(C);
+        hipLaunchKernelGGL(k_cand_expand, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask,
+                           (const unsigned long long *)toff, D0, cand);
         HIPCHK(hipGetLastError());
         tbegin(ctx, "walk_len");
         hipLaunchKernelGGL((k_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const uint32_t *)succ, k, ixk,
-                           (uint64_t)(2 * D0 + 2), len, first, last, d_err);
+                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const node_t *)succ, k, ixk,
+                           (uint64_t)(2 * D0), len, first, last, d_err);
         HIPCHK(hipGetLastError());
-        if (int rc = scan_u64(ctx, len, soff, C)) return rc;
-        unsigned long long total = 0;
-        HIPCHK(hipMemcpyAsync(&total, soff + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+        tend(ctx);
+        tbegin(ctx, "keep");
+        hipLaunchKernelGGL((k_keep<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
+                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const node_t *)succ, k, (const unsigned long long *)len,
+                           (const node_t *)first, (const node_t *)last, flags, kw, one);
+        HIPCHK(hipGetLastError());
+        // word offsets and edge indices of the kept paths (scans in place: kw -> woff, one -> eidx)
+        if (int rc = scan_u64(ctx, kw, kw, C)) return rc;
+        if (int rc = scan_u64(ctx, one, one, C)) return rc;
+        unsigned long long tw = 0, nk = 0;
+        HIPCHK(hipMemcpyAsync(&tw, kw + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&nk, one + C, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         tend(ctx);
-        char *seq;
-        if (int rc = dalloc(ctx, &seq, total + 1)) return rc;
+        nkept = nk;
+        ktotalw = tw;
+        if (int rc = dalloc(ctx, &ctx->g_uwords, ktotalw + 8, false)) return rc;
+        if (int rc = dalloc(ctx, &ctx->g_eoffw, nkept + 1, false)) return rc;
+        if (int rc = dalloc(ctx, &ctx->g_elen, nkept + 1, false)) return rc;
+        if (int rc = dalloc(ctx, &ctx->g_estart, nkept + 1, false)) return rc;
+        if (int rc = dalloc(ctx, &ctx->g_eend, nkept + 1, false)) return rc;
+        if (int rc = dalloc(ctx, &ctx->g_eself, nkept + 1, false)) return rc;
+        HIPCHK(hipMemsetAsync(ctx->g_uwords + ktotalw, 0, 64, ctx->stream));
         tbegin(ctx, "walk_write");
         hipLaunchKernelGGL((k_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const uint32_t *)succ, k, (const uint32_t *)first,
-                           (const unsigned long long *)soff, seq, visited);
+                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const node_t *)succ, k, (const unsigned long long *)len,
+                           (const node_t *)first, (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw,
+                           (const unsigned long long *)one, ctx->g_uwords, ctx->g_eoffw, ctx->g_elen, ctx->g_estart, ctx->g_eend, ctx->g_eself, visited);
         HIPCHK(hipGetLastError());
         tend(ctx);
-        tbegin(ctx, "keep_gather");
-        hipLaunchKernelGGL(k_keep, dim3(cgrid), dim3(BLK), 0, ctx->stream, (const char *)seq, (const unsigned long long *)soff, (uint64_t)C,
-                           keeplen, flags);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_keep_flag, dim3(cgrid), dim3(BLK), 0, ctx->stream, (const uint8_t *)flags, (uint64_t)C, one);
-        HIPCHK(hipGetLastError());
-        if (int rc = scan_u64(ctx, keeplen, koff, C)) return rc;
-        if (int rc = scan_u64(ctx, one, eidx, C)) return rc;
-        unsigned long long ktotal = 0, nkept = 0;
-        HIPCHK(hipMemcpyAsync(&ktotal, koff + C, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(&nkept, eidx + C, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        char *kseq;
-        unsigned long long *eoff;
-        uint32_t *estart, *eend;
-        uint8_t *eself;
-        if (int rc = dalloc(ctx, &kseq, ktotal + 1)) return rc;
-        if (int rc = dalloc(ctx, &eoff, nkept + 1)) return rc;
-        if (int rc = dalloc(ctx, &estart, nkept + 1)) return rc;
-        if (int rc = dalloc(ctx, &eend, nkept + 1)) return rc;
-        if (int rc = dalloc(ctx, &eself, nkept + 1)) return rc;
-        hipLaunchKernelGGL(k_gather, dim3(cgrid), dim3(BLK), 0, ctx->stream, (const char *)seq, (const unsigned long long *)soff,
-                           (const unsigned long long *)koff, (const uint8_t *)flags, (const unsigned long long *)eidx,
-                           (const unsigned long long *)cand, (const uint32_t *)last, (uint64_t)C, kseq, eoff, estart, eend, eself);
-        HIPCHK(hipGetLastError());
-        tend(ctx);
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        gwt.mark(ctx, "g:walks");
-        // ---- to host ----
-        n_paths = nkept;
-        if (int rc = d2h(ctx, h_eoff, eoff, nkept)) return rc;
-        ctx->gh.seq.resize(ktotal);
-        if (ktotal) HIPCHK(hipMemcpy(&ctx->gh.seq[0], kseq, ktotal, hipMemcpyDeviceToHost));
-        if (int rc = d2h(ctx, ctx->gh.estart, estart, nkept)) return rc;
-        if (int rc = d2h(ctx, ctx->gh.eend, eend, nkept)) return rc;
-        if (int rc = d2h(ctx, ctx->gh.eself, eself, nkept)) return rc;
-        ctx->gh.eoff.assign(h_eoff.begin(), h_eoff.end());
-        ctx->gh.eoff.push_back(ktotal);
+    } else {
+        if (int rc = dalloc(ctx, &ctx->g_uwords, 8, false)) return rc;
+        if (int rc = dalloc(ctx, &ctx->g_eoffw, 1, false)) return rc;
+        if (int rc = dalloc(ctx, &ctx->g_elen, 1, false)) return rc;
+        if (int rc = dalloc(ctx, &ctx->g_estart, 1, false)) return rc;
+        if (int rc = dalloc(ctx, &ctx->g_eend, 1, false)) return rc;
+        if (int rc = dalloc(ctx, &ctx->g_eself, 1, false)) return rc;
+        HIPCHK(hipMemsetAsync(ctx->g_uwords, 0, 64, ctx->stream));
     }
-    gwt.mark(ctx, "g:d2h");
+    ctx->g_ne = ctx->g_npaths = nkept;
+    ctx->g_nuwords = ktotalw;
+    gwt.mark(ctx, "g:walks");
     {
-        // ---- perfect loops: non-junction k-mers on no path ----
-        uint32_t *lcount, *llist;
-        const uint32_t lcap = (uint32_t)std::min<uint64_t>(D0, 1u << 26);
-        if (int rc = dalloc(ctx, &lcount, 1)) return rc;
-        if (int rc = dalloc(ctx, &llist, lcap)) return rc;
-        HIPCHK(hipMemsetAsync(lcount, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(k_loop_nodes, dim3(grid), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const uint8_t *)visited, D0,
-                           lcount, llist, lcap);
+        // ---- perfect loops: non-junction k-mers on no path (CollectLoops, :359-397; serial in the reference too) ----
+        unsigned long long *lcount;
+        if (int rc = dalloc(ctx, &lcount, 2)) return rc;
+        HIPCHK(hipMemsetAsync(lcount, 0, 16, ctx->stream));
+        hipLaunchKernelGGL(k_loop_count, dim3(grid_for(D0, 4096)), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const uint8_t *)visited, D0, lcount);
         HIPCHK(hipGetLastError());
-        uint32_t nloopk = 0;
-        HIPCHK(hipMemcpyAsync(&nloopk, lcount, 4, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long nloopk = 0;
+        HIPCHK(hipMemcpyAsync(&nloopk, lcount, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (nloopk > lcap) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%u k-mers on perfect loops exceed the host-side limit", nloopk);
         if (nloopk && ctx->opt_keep_loops) {
-            std::vector<uint32_t> ranks;
+            unsigned long long *llist;
+            if (int rc = dalloc(ctx, &llist, nloopk)) return rc;
+            hipLaunchKernelGGL(k_loop_list, dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const uint8_t *)visited, D0,
+                               lcount + 1, llist, nloopk);
+            HIPCHK(hipGetLastError());
+            std::vector<unsigned long long> ranks;
             if (int rc = d2h(ctx, ranks, llist, nloopk)) return rc;
             std::sort(ranks.begin(), ranks.end());  // k-mer-file order
-            HIPCHK(hipMemcpy(llist, ranks.data(), (size_t)nloopk * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(llist, ranks.data(), (size_t)nloopk * 8, hipMemcpyHostToDevice));
             Rec<NW> *lk;
+            uint8_t *lm;
             if (int rc = dalloc(ctx, &lk, nloopk)) return rc;
-            hipLaunchKernelGGL((k_gather_kmers<NW>), dim3((nloopk + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers,
-                               (const uint32_t *)llist, nloopk, (void *)lk);
+            if (int rc = dalloc(ctx, &lm, nloopk)) return rc;
+            hipLaunchKernelGGL((k_gather_kmers<NW>), dim3(grid_for(nloopk)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers,
+                               (const uint8_t *)ctx->g_mask, (const unsigned long long *)llist, (uint64_t)nloopk, (void *)lk, lm);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(ctx->stream));
             std::vector<uint64_t> hk;
             if (int rc = d2h(ctx, hk, lk, (size_t)nloopk * NW)) return rc;
             std::vector<uint8_t> hmask;
-            if (int rc = d2h(ctx, hmask, ctx->g_mask, (size_t)D0)) return rc;
+            if (int rc = d2h(ctx, hmask, lm, (size_t)nloopk)) return rc;
             std::vector<smxh::LoopNode> nodes(nloopk);
-            for (uint32_t i = 0; i < nloopk; ++i) {
+            for (uint64_t i = 0; i < nloopk; ++i) {
                 nodes[i].rank = ranks[i];
                 nodes[i].kmer.resize(k);
                 for (unsigned j = 0; j < k; ++j) nodes[i].kmer[j] = "ACGT"[(hk[(size_t)i * NW + (j >> 5)] >> ((j & 31) << 1)) & 3];
-                nodes[i].mask = hmask[ranks[i]];
+                nodes[i].mask = hmask[i];
             }
             smxh::LoopCollector lc(nodes, k);
             std::vector<std::string> loops;
             lc.collect(loops);
-            // node ids must be taken from the untouched masks' k-mers: rebuild a lookup (masks were zeroed by collect)
-            for (auto &s : loops) {
-                const std::string fk = s.substr(0, k), lk2 = s.substr(s.size() - k);
-                ctx->gh.estart.push_back(lc.node_of(fk));
-                ctx->gh.eend.push_back(lc.node_of(lk2));
-                ctx->gh.eself.push_back(s == smxh::revcomp(s) ? 1 : 0);
-                ctx->gh.seq += s;
-                ctx->gh.eoff.push_back(ctx->gh.seq.size());
+            // the loops are appended to the device graph: bigger arrays, old content copied, loop edges uploaded
+            const uint64_t nl = loops.size();
+            if (nl) {
+                std::vector<unsigned long long> l_offw(nl), l_len(nl), l_start(nl), l_end(nl);
+                std::vector<uint8_t> l_self(nl);
+                std::vector<uint64_t> lwords;
+                for (uint64_t i = 0; i < nl; ++i) {
+                    const std::string &s = loops[i];
+                    l_offw[i] = ktotalw + lwords.size();
+                    l_len[i] = s.size();
+                    // node ids must be taken from the untouched masks' k-mers (collect() zeroed the masks, not the index)
+                    l_start[i] = lc.node_of(s.substr(0, k));
+                    l_end[i] = lc.node_of(s.substr(s.size() - k));
+                    l_self[i] = s == smxh::revcomp(s) ? 1 : 0;
+                    const size_t w0 = lwords.size();
+                    lwords.resize(w0 + (s.size() + 31) / 32, 0);
+                    for (size_t t = 0; t < s.size(); ++t) {
+                        const char ch = s[t];
+                        const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+                        lwords[w0 + (t >> 5)] |= code << ((t & 31) << 1);
+                    }
+                }
+                const uint64_t ne2 = nkept + nl, tw2 = ktotalw + lwords.size();
+                uint64_t *uw2;
+                unsigned long long *eo2, *el2;
+                node_t *es2, *ee2;
+                uint8_t *sf2;
+                if (int rc = dalloc(ctx, &uw2, tw2 + 8, false)) return rc;
+                if (int rc = dalloc(ctx, &eo2, ne2 + 1, false)) return rc;
+                if (int rc = dalloc(ctx, &el2, ne2 + 1, false)) return rc;
+                if (int rc = dalloc(ctx, &es2, ne2 + 1, false)) return rc;
+                if (int rc = dalloc(ctx, &ee2, ne2 + 1, false)) return rc;
+                if (int rc = dalloc(ctx, &sf2, ne2 + 1, false)) return rc;
+                hipError_t e = hipSuccess;
+                auto cp = [&](void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+                    if (bytes && e == hipSuccess) e = hipMemcpy(dst, src, bytes, kind);
+                };
+                cp(uw2, ctx->g_uwords, ktotalw * 8, hipMemcpyDeviceToDevice);
+                cp(uw2 + ktotalw, lwords.data(), lwords.size() * 8, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemset(uw2 + tw2, 0, 64);
+                cp(eo2, ctx->g_eoffw, nkept * 8, hipMemcpyDeviceToDevice);
+                cp(eo2 + nkept, l_offw.data(), nl * 8, hipMemcpyHostToDevice);
+                cp(el2, ctx->g_elen, nkept * 8, hipMemcpyDeviceToDevice);
+                cp(el2 + nkept, l_len.data(), nl * 8, hipMemcpyHostToDevice);
+                cp(es2, ctx->g_estart, nkept * 8, hipMemcpyDeviceToDevice);
+                cp(es2 + nkept, l_start.data(), nl * 8, hipMemcpyHostToDevice);
+                cp(ee2, ctx->g_eend, nkept * 8, hipMemcpyDeviceToDevice);
+                cp(ee2 + nkept, l_end.data(), nl * 8, hipMemcpyHostToDevice);
+                cp(sf2, ctx->g_eself, nkept, hipMemcpyDeviceToDevice);
+                cp(sf2 + nkept, l_self.data(), nl, hipMemcpyHostToDevice);
+                arena_put(ctx, ctx->g_uwords);
+                arena_put(ctx, ctx->g_eoffw);
+                arena_put(ctx, ctx->g_elen);
+                arena_put(ctx, ctx->g_estart);
+                arena_put(ctx, ctx->g_eend);
+                arena_put(ctx, ctx->g_eself);
+                ctx->g_uwords = uw2;
+                ctx->g_eoffw = eo2;
+                ctx->g_elen = el2;
+                ctx->g_estart = es2;
+                ctx->g_eend = ee2;
+                ctx->g_eself = sf2;
+                if (e != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "appending the perfect loops failed: %s", hipGetErrorString(e));
+                ctx->g_ne = ne2;
+                ctx->g_nuwords = tw2;
+                ctx->g_nloops = nl;
             }
-            ctx->gh.n_loops = loops.size();
         }
     }
-    ctx->gh.n_paths = n_paths;
     unsigned herr = 0;
     HIPCHK(hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost));
     if (herr) return fail(ctx, SMX_DEVICE_ERROR, "inconsistent k-mer index: %u failed lookups/walks", herr);
     gwt.mark(ctx, "g:loops");
-    if (ctx->opt_sort_edges) smxh::sort_edges_raw(ctx->gh);
     free_temps(ctx);  // walk buffers are no longer needed; the link sort reuses the arena
-    int lrc = ctx->opt_device_links ? device_build_links(ctx, ctx->gh, D0) : 1;
-    free_temps(ctx);
-    if (lrc > 1) return lrc;
-    if (lrc == 1) {  // small graphs, or sizes beyond the packed keys: host link records with the device (or host) key sort
+    ctx->g_dev_valid = true;
+    {
+        // total nucleotides (graph info) without a device pass: elen is summed where the host mirror is built; keep a device sum here
+        unsigned long long *one1, *tot;
+        const uint64_t ne = ctx->g_ne;
+        if (int rc = dalloc(ctx, &one1, ne + 1)) return rc;
+        (void)tot;
+        if (ne) {
+            if (int rc = scan_u64(ctx, ctx->g_elen, one1, ne)) return rc;
+            unsigned long long nb = 0;
+            HIPCHK(hipMemcpyAsync(&nb, one1 + ne, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            ctx->g_nbases = nb;
+        } else {
+            ctx->g_nbases = 0;
+        }
+        free_temps(ctx);
+    }
+    // ---- 5. link records + vertices ---------------------------------------------------------------
+    const bool host_links = ctx->opt_sort_edges || ctx->g_ne == 0 || ctx->opt_device_links == 0 || (ctx->g_ne < (1u << 16) && ctx->opt_device_links < 2);
+    if (host_links) {
+        if (int rc = materialize_host(ctx)) return rc;
+        if (ctx->opt_sort_edges) {
+            smxh::sort_edges_raw(ctx->gh);
+            if (int rc = upload_graph(ctx)) return rc;  // the device copy follows the new edge order (coverage walks it)
+        }
         int sort_rc = 0;
         smxh::build_links(ctx->gh, [&](std::vector<uint64_t> &keys) {
             if (!sort_rc) sort_rc = device_sort_u64(ctx, keys);
             if (sort_rc) smxh::radix_sort_u64(keys);
         });
         if (sort_rc) return sort_rc;
+    } else {
+        if (int rc = device_build_links(ctx, D0)) return rc;
+        free_temps(ctx);
     }
     gwt.mark(ctx, "g:links");
     ctx->g_ready = true;
     return 0;
 }
 
-
+// -c: per-(k+1)-mer multiplicities over the resident reads, summed per edge (and over the edge flanks)
 template <int NW>
 int run_coverage(smx_ctx *ctx) {
     const unsigned K1 = ctx->g_k + 1, B = ctx->g_B;
-    const uint64_t D1 = ctx->g_nkpo, ne = ctx->gh.n_edges();
+    const uint64_t D1 = ctx->g_nkpo, ne = ctx->g_ne;
     ctx->gh.ecov.assign(ne, 0);
+    ctx->gh.eflank_s.assign(ne, 0);
+    ctx->gh.eflank_e.assign(ne, 0);
     if (D1 == 0 || ne == 0) return 0;
+    if (!ctx->g_dev_valid)
+        if (int rc = upload_graph(ctx)) return rc;
+    if (!ctx->g_kpo) {  // dropped to make room for the walks: count the canonical (k+1)-mers again
+        void *sv_res = ctx->d_result;
+        const uint64_t sv_n = ctx->n_records;
+        const unsigned sv_K = ctx->K;
+        std::vector<uint64_t> sv_boff = ctx->bucket_off;
+        ctx->d_result = nullptr;
+        if (int rc = count_reads<NW>(ctx, K1, SMX_MODE_CANONICAL, B)) return rc;
+        if (ctx->n_records != D1) return fail(ctx, SMX_DEVICE_ERROR, "recount of the (k+1)-mers gave %llu records, the graph was built from %llu",
+                                              (unsigned long long)ctx->n_records, (unsigned long long)D1);
+        ctx->g_kpo = ctx->d_result_buf;
+        detach_temp(ctx, ctx->g_kpo);
+        ctx->d_result_buf = nullptr;
+        ctx->d_result = sv_res;
+        ctx->n_records = sv_n;
+        ctx->K = sv_K;
+        ctx->bucket_off = sv_boff;
+        ctx->n_instances = 0;
+        free_temps(ctx);
+    }
+    if (!ctx->g_dir_kpo.dir)
+        if (int rc = build_rank_dir<NW>(ctx, ctx->g_kpo, D1, ctx->g_kpoboff, B, K1, ctx->g_dir_kpo)) return rc;
     std::vector<uint64_t *> masks;
     uint64_t nwin = 0;
     if (int rc = mark_windows(ctx, K1, masks, &nwin)) return rc;
     uint32_t *cnt, *ecov, *fls, *fle;
-    unsigned long long *d_eoff;
-    char *d_seq;
     if (int rc = dalloc(ctx, &cnt, D1)) return rc;
     if (int rc = dalloc(ctx, &ecov, ne)) return rc;
     if (int rc = dalloc(ctx, &fls, ne)) return rc;
     if (int rc = dalloc(ctx, &fle, ne)) return rc;
-    if (int rc = dalloc(ctx, &d_eoff, ne + 1)) return rc;
-    if (int rc = dalloc(ctx, &d_seq, ctx->gh.seq.size() + 1)) return rc;
     HIPCHK(hipMemsetAsync(cnt, 0, D1 * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ecov, 0, ne * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(fls, 0, ne * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(fle, 0, ne * 4, ctx->stream));
-    std::vector<unsigned long long> he(ctx->gh.eoff.begin(), ctx->gh.eoff.end());
-    const smx::RankIndex ixp = ctx->g_ix_kpo;
-    HIPCHK(hipMemcpyAsync(d_eoff, he.data(), (ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_seq, ctx->gh.seq.data(), ctx->gh.seq.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const smx::RankDir ixp = ctx->g_dir_kpo;
     tbegin(ctx, "kpo_coverage");
     for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
         const ReadChunk &ch = ctx->chunks[ci];
         if (ch.n_bases == 0 || !masks[ci] || ch.contigs) continue;  // contigs: "separate stream for not counting it in coverage"
-        hipLaunchKernelGGL((k_kpo_coverage<NW>), dim3((unsigned)std::min<uint64_t>((ch.n_bases + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0,
+        hipLaunchKernelGGL((k_kpo_coverage<NW>), dim3(grid_for(ch.n_bases)), dim3(BLK), 0,
                            ctx->stream, (const uint64_t *)ch.d_words, (const uint64_t *)masks[ci], ch.n_bases, K1, (const void *)ctx->g_kpo, ixp, cnt);
         HIPCHK(hipGetLastError());
     }
     tend(ctx);
+    // the unitigs as a read batch: (k+1)-mer windows marked the same way
     tbegin(ctx, "edge_coverage");
-    const uint64_t total = ctx->gh.seq.size();
-    hipLaunchKernelGGL((k_edge_coverage<NW>), dim3((unsigned)std::min<uint64_t>((total + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
-                       (const char *)d_seq, (const unsigned long long *)d_eoff, ne, total, K1, (const void *)ctx->g_kpo, ixp,
+    const uint64_t G = ctx->g_nuwords * 32;
+    uint64_t *ustart, *wmask;
+    uint32_t *ulen;
+    unsigned long long *d_total;
+    if (int rc = dalloc(ctx, &ustart, ne)) return rc;
+    if (int rc = dalloc(ctx, &ulen, ne)) return rc;
+    if (int rc = dalloc(ctx, &wmask, G / 64 + 2)) return rc;
+    if (int rc = dalloc(ctx, &d_total, 1)) return rc;
+    HIPCHK(hipMemsetAsync(wmask, 0, (G / 64 + 2) * 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_total, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_edge_as_reads, dim3(grid_for(ne)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)ctx->g_eoffw,
+                       (const unsigned long long *)ctx->g_elen, ne, ustart, ulen);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_mark_windows, dim3((unsigned)((ne + BLK - 1) / BLK)), dim3(BLK), 0, ctx->stream, (const uint64_t *)ustart, (const uint32_t *)ulen, ne, K1,
+                       (unsigned long long *)wmask, d_total);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL((k_edge_coverage<NW>), dim3(grid_for(G)), dim3(BLK), 0, ctx->stream, (const uint64_t *)ctx->g_uwords, (const uint64_t *)wmask,
+                       (const unsigned long long *)ctx->g_eoffw, (const unsigned long long *)ctx->g_elen, ne, G, K1, (const void *)ctx->g_kpo, ixp,
                        (const uint32_t *)cnt, ecov, (uint32_t)std::max<int64_t>(ctx->opt_flank_range, 1), fls, fle);
     HIPCHK(hipGetLastError());
     tend(ctx);
-    ctx->gh.eflank_s.assign(ne, 0);
-    ctx->gh.eflank_e.assign(ne, 0);
     HIPCHK(hipMemcpyAsync(ctx->gh.ecov.data(), ecov, ne * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->gh.eflank_s.data(), fls, ne * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->gh.eflank_e.data(), fle, ne * 4, hipMemcpyDeviceToHost, ctx->stream));

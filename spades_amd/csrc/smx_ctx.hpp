@@ -41,6 +41,8 @@ struct smx_ctx {
     int64_t opt_early_tip_bound = 0;  // > 0: spades-core's early tip clipper with this length bound (RL - K there) before condensation
     int64_t opt_skm_stage = 1;     // pass 0 of the super-k-mer scan stages its output so that placing it needs no second scan
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
+    int64_t opt_derive_batches = 0;  // > 1: derive the k-mer file in this many bucket ranges (tests; 0 = as HBM requires)
+    int64_t opt_keep_kpo = -1;       // keep the (k+1)-mer file after the masks are filled: -1 = if HBM allows, 0 = drop (coverage recounts)
     int64_t opt_joint_hist = 1;  // fuse the level-2 histogram into the level-1 histogram pass (records source)
     int64_t opt_prededupe = -1;  // super-k-mer pre-deduplication: -1 auto, 0 off, 1 on whenever K allows it
     int64_t opt_skm_cap = 0;     // instances per LDS dedupe chunk (0 = default)
@@ -54,20 +56,29 @@ struct smx_ctx {
     // grow-only device arena: blocks are recycled across calls (hipMalloc/hipFree of tens of GB stalls for seconds)
     std::vector<std::pair<void *, size_t>> arena_free;  // cached blocks
     std::unordered_map<void *, size_t> arena_size;      // every live or cached block -> bytes
+    size_t arena_live = 0;                              // bytes handed out and not yet returned
     // construction state (smx_build_graph)
     void *g_kpo = nullptr, *g_kmers = nullptr;
     uint8_t *g_mask = nullptr;
     uint64_t g_nkpo = 0, g_nkmers = 0;
     unsigned g_k = 0, g_nw = 0, g_B = 0;
     std::vector<uint64_t> g_kboff, g_kpoboff;
-    // fine-bin offsets of the last pipeline run (rank lookups of the construction stage), kept when want_index is set
-    bool want_index = false;
-    unsigned long long *last_idx_off = nullptr;
-    uint64_t last_idx_bins = 0;
-    uint32_t last_idx_S1 = 1;
-    std::vector<uint32_t> last_idx_f;
-    smx::RankIndex g_ix_kmers{}, g_ix_kpo{};  // .off owned by the graph state
+    smx::RankDir g_dir_kmers{}, g_dir_kpo{};  // .dir / .boff owned by the graph state
     bool g_ready = false;
+    // the graph itself, resident in HBM (unitigs 2-bit packed, word-aligned starts; edges in the reference's enumeration order)
+    uint64_t *g_uwords = nullptr;                          // [g_nuwords + 8]
+    unsigned long long *g_eoffw = nullptr, *g_elen = nullptr;  // [g_ne] word offset / nucleotides of every unitig
+    smx::node_t *g_estart = nullptr, *g_eend = nullptr;    // [g_ne] node of the first / last k-mer
+    uint8_t *g_eself = nullptr;                            // [g_ne] s == RC(s)
+    uint64_t g_ne = 0, g_nuwords = 0, g_nbases = 0, g_npaths = 0, g_nloops = 0;
+    smx::Rec<2> *g_lrecs = nullptr;                        // sorted link records (rank << g_lsh, EdgeAndMask), [g_nlrec]
+    unsigned long long *g_vstart = nullptr;                // first record of every vertex, in vertex-id order, [g_nv]
+    uint64_t g_nlrec = 0, g_nv = 0;
+    unsigned g_lsh = 0;
+    bool g_links_dev = false;   // link records / vertices live in g_lrecs / g_vstart (else gh holds them)
+    bool g_host_valid = false;  // gh mirrors the device graph
+    bool g_dev_valid = false;   // the device arrays above describe the graph (false after a host-side edge sort until re-uploaded)
+    void *g_kpo_block = nullptr;  // allocation behind g_kpo
     uint64_t g_tip_kmers = 0, g_tips = 0;  // early tip clipper: k-mers isolated, tips removed
     uint64_t g_at_edges = 0, g_at_tip_kmers = 0;  // early A/T remover: length-1 edges marked, tip k-mers isolated
     smxh::GraphHost gh;
@@ -106,6 +117,7 @@ void *arena_get(smx_ctx *ctx, size_t bytes) {
     if (best != (size_t)-1) {
         void *p = ctx->arena_free[bi].first;
         ctx->arena_free.erase(ctx->arena_free.begin() + bi);
+        ctx->arena_live += best;
         return p;
     }
     void *q = nullptr;
@@ -124,6 +136,7 @@ void *arena_get(smx_ctx *ctx, size_t bytes) {
         }
     }
     ctx->arena_size[q] = bytes;
+    ctx->arena_live += bytes;
     return q;
 }
 void arena_put(smx_ctx *ctx, void *p) {
@@ -133,7 +146,20 @@ void arena_put(smx_ctx *ctx, void *p) {
         (void)hipFree(p);
         return;
     }
+    for (auto &b : ctx->arena_free)
+        if (b.first == p) return;  // already returned (an error path released it twice): one owner only
     ctx->arena_free.emplace_back(p, it->second);
+    ctx->arena_live -= std::min(ctx->arena_live, it->second);
+}
+// HBM still obtainable for new allocations: what the device has free plus the cached blocks (or what is left of the caller's budget)
+size_t arena_avail(smx_ctx *ctx) {
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t cached = 0;
+    for (auto &b : ctx->arena_free) cached += b.second;
+    const size_t dev = (size_t)((double)(free_b + cached) * 0.94);
+    if (!ctx->budget) return dev;
+    return std::min(dev, ctx->budget > ctx->arena_live ? ctx->budget - ctx->arena_live : (size_t)0);
 }
 void arena_release(smx_ctx *ctx) {
     for (auto &b : ctx->arena_free) {
@@ -151,6 +177,15 @@ int dalloc(smx_ctx *ctx, T **p, size_t count, bool temp = true) {
     if (temp) ctx->temps.push_back(q);
     *p = (T *)q;
     return 0;
+}
+
+// a temp becomes a long-lived block of its new owner (count result, graph state)
+void detach_temp(smx_ctx *ctx, void *p) {
+    for (size_t i = 0; i < ctx->temps.size(); ++i)
+        if (ctx->temps[i] == p) {
+            ctx->temps.erase(ctx->temps.begin() + i);
+            return;
+        }
 }
 
 void free_temps(smx_ctx *ctx, void *keep = nullptr) {

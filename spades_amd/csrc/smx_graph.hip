@@ -2,23 +2,26 @@
 // Included by smx_api.hip (one translation unit).
 //
 // Reference rows (paths relative to /root/reference/src/common):
-//   a13 DeBruijnKMerKMerSplitter        kmer_index/kmer_mph/kmer_splitters.hpp:138-207      -> k_derive_kmers + count
+//   a13 DeBruijnKMerKMerSplitter        kmer_index/kmer_mph/kmer_splitters.hpp:138-207      -> k_derive_* + count
+//   a14 KMerIndex / PerfectHashMap      kmer_index/kmer_mph/kmer_index.hpp:88-100           -> RankDir + kmer_rank
 //   a15 FillExtensionsFromIndex/InOutMask  extension_index/kmer_extension_index_builder.hpp:45-60,
 //                                           extension_index/inout_mask.hpp:92-131           -> k_fill_masks
 //   a16 UnbranchingPathExtractor        assembly_graph/construction/debruijn_graph_constructor.hpp:184-410
-//                                        -> k_succ, k_cand_*, k_walk_len, k_walk_write, k_keep, k_gather (+ host loops)
-//   a17 FastGraphFromSequencesConstructor  same file :412-568                               -> host link records
-//   a19 gfa::GFAWriter                  io/graph/gfa_writer.cpp:19-47,73-87,113-116         -> host writer
+//                                        -> k_cand_*, k_walk_len, k_keep, k_walk_write (+ host loops)
+//   a17 FastGraphFromSequencesConstructor  same file :412-568                               -> k_link_keys, k_vertex_*
+//   a20 coverage                         ph_map/coverage_hash_map_builder.hpp:16-57, graph_support/coverage_filling.hpp:17-96
 //
 // Device layout: k-mers = the sorted-unique k-mer "file" (bucket-major, B = 10*threads), rank r = position in it
-// (stands in for the MPHF index, whose values never reach the output: debruijn_graph_constructor.hpp:540-547).
-// One byte mask per rank. A *node* is an oriented k-mer: node = 2*rank + o, o=1 meaning RC of the stored k-mer.
+// (stands in for the MPHF index, whose values never reach the output: debruijn_graph_constructor.hpp:540-547; size_t there,
+// 64 bits here). One byte mask per rank. A *node* is an oriented k-mer: node = 2*rank + o, o=1 meaning RC of the stored k-mer.
+// Unitigs leave the walk kernels 2-bit packed (the RtSeq / Sequence word layout), every unitig starting on a word boundary.
 #pragma once
 #include "smx_device.hpp"
 
 namespace smx {
 
-constexpr uint32_t NODE_NONE = 0xFFFFFFFFu;
+typedef unsigned long long node_t;
+constexpr node_t NODE_NONE = ~0ull;
 
 template <int NW>
 __device__ __forceinline__ Rec<NW> rec_shl(const Rec<NW> &x, unsigned K, unsigned c) {  // operator<<, rtseq.hpp:437-457
@@ -55,37 +58,105 @@ __device__ __forceinline__ Rec<NW> rec_canon(const Rec<NW> &x, unsigned K, unsig
     is_rc = minimal ? 0u : 1u;
     return minimal ? x : y;
 }
-// Where to look for a k-mer in a sorted k-mer file: the offsets of the fine bins the counting pipeline sorted it by (bucket, then
-// the mixed-radix digits of the key fraction) — a few hundred records per bin — or, without them, just the bucket offsets.
-struct RankIndex {
-    const unsigned long long *off;  // [bins + 1]
-    uint32_t B, S1, nf, f[6];
+// nucleotide-lexicographic compare, nucleotide 0 first (RtSeq operator<, rtseq.hpp:742-750; Sequence operator<, sequence.hpp:592-600)
+template <int NW>
+__device__ __forceinline__ int rec_lex_cmp(const Rec<NW> &a, const Rec<NW> &b) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const uint64_t d = a.w[i] ^ b.w[i];
+        if (d) {
+            const unsigned pos = (unsigned)__builtin_ctzll(d) & ~1u;
+            return ((a.w[i] >> pos) & 3) < ((b.w[i] >> pos) & 3) ? -1 : 1;
+        }
+    }
+    return 0;
+}
+
+// ---- rank directory -----------------------------------------------------------------------------------------------------------
+// Where a canonical k-mer sits in a sorted k-mer file (KMerIndex::seq_idx stand-in, kmer_index.hpp:88-100). Inside a bucket the
+// records ascend by key, so slot = floor(key_fraction * SB) ascends too: dir[b][s] = first record of bucket b whose slot is >= s
+// (relative to the bucket start; SB + 1 entries per bucket, the last one = bucket size). With SB ~ half the records of a bucket a
+// lookup is one hash, one 8-byte directory read and a scan of ~2 adjacent records — two dependent HBM reads instead of the
+// ~10 of a binary search over the bucket.
+struct RankDir {
+    const uint32_t *dir;             // [B * (SB + 1)]
+    const unsigned long long *boff;  // [B + 1] bucket offsets of the file
+    uint32_t B, SB;
     unsigned K;
 };
-// rank of a canonical k-mer (KMerIndex::seq_idx stand-in, kmer_index.hpp:88-100): bucket by hash, bin by key digits, binary search
 template <int NW>
-__device__ __forceinline__ uint32_t kmer_rank(const Rec<NW> *__restrict__ kmers, const RankIndex &ix, const Rec<NW> &canon) {
-    uint64_t bin = bucket_of(xxh3_rec<NW>(canon), ix.B);
-    uint64_t fr = key_top64<NW>(canon, ix.K);
-    if (ix.S1 > 1) {
-        bin = bin * ix.S1 + __umul64hi(fr, (uint64_t)ix.S1);
-        fr *= ix.S1;
-    }
-    for (uint32_t i = 0; i < ix.nf; ++i) {
-        bin = bin * ix.f[i] + __umul64hi(fr, (uint64_t)ix.f[i]);
-        fr *= ix.f[i];
-    }
-    uint64_t lo = ix.off[bin], hi = ix.off[bin + 1];
+__device__ __forceinline__ uint64_t dir_slot(const Rec<NW> &x, const RankDir &ix) {
+    return __umul64hi(key_top64<NW>(x, ix.K), (uint64_t)ix.SB);
+}
+template <int NW>
+__device__ __forceinline__ node_t kmer_rank(const Rec<NW> *__restrict__ kmers, const RankDir &ix, const Rec<NW> &canon) {
+    const uint32_t b = bucket_of(xxh3_rec<NW>(canon), ix.B);
+    const uint32_t *d = ix.dir + (uint64_t)b * (ix.SB + 1) + dir_slot<NW>(canon, ix);
+    const uint64_t base = ix.boff[b];
+    uint64_t lo = base + d[0], hi = base + d[1];
     const uint64_t end = hi;
-    while (lo < hi) {
-        uint64_t mid = (lo + hi) >> 1;
+    while (hi - lo > 8) {  // crowded slot (skewed keys): halve first (lower bound: the answer stays in [lo, hi])
+        const uint64_t mid = (lo + hi) >> 1;
         if (rec_less<NW>(kmers[mid], canon)) lo = mid + 1; else hi = mid;
     }
-    return (lo < end && rec_eq<NW>(kmers[lo], canon)) ? (uint32_t)lo : NODE_NONE;
+    for (; lo < end; ++lo) {
+        const Rec<NW> r = kmers[lo];
+        if (!rec_less<NW>(r, canon)) return rec_eq<NW>(r, canon) ? lo : NODE_NONE;
+    }
+    return NODE_NONE;
 }
+// Directory of a sorted file. One record per lane; a record that opens new slots writes their entries, long gaps are filled by
+// the whole wave (low-complexity data leaves most slots of a bucket empty).
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_dir_fill(const void *kmers_, uint64_t n, RankDir ix, uint32_t *dir) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n; base += (uint64_t)gridDim.x * BLK) {
+        const uint64_t i = base + threadIdx.x;
+        uint32_t *d = dir;
+        uint64_t t0 = 0, t1 = 0;  // entries [t0, t1) get `val`
+        uint32_t val = 0;
+        uint64_t u0 = 0, u1 = 0;  // last record of a bucket: entries [u0, u1) get val + 1
+        if (i < n) {
+            const Rec<NW> x = kmers[i];
+            const uint32_t b = bucket_of(xxh3_rec<NW>(x), ix.B);
+            const uint64_t s = dir_slot<NW>(x, ix), bs = ix.boff[b];
+            d = dir + (uint64_t)b * (ix.SB + 1);
+            val = (uint32_t)(i - bs);
+            t0 = i == bs ? 0 : dir_slot<NW>(kmers[i - 1], ix) + 1;
+            t1 = s + 1;
+            if (i + 1 == ix.boff[b + 1]) {
+                u0 = s + 1;
+                u1 = (uint64_t)ix.SB + 1;
+            }
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint64_t a0 = pass ? u0 : t0, a1 = pass ? u1 : t1;
+            const uint32_t v = pass ? val + 1 : val;
+            const bool big = a1 > a0 + 8;
+            if (!big)
+                for (uint64_t t = a0; t < a1; ++t) d[t] = v;
+            unsigned long long m = __ballot(big);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                uint32_t *dd = (uint32_t *)__shfl((unsigned long long)(uintptr_t)d, src, 64);
+                const uint64_t b0 = __shfl((unsigned long long)a0, src, 64), b1 = __shfl((unsigned long long)a1, src, 64);
+                const uint32_t vv = __shfl(v, src, 64);
+                for (uint64_t t = b0 + lane; t < b1; t += 64) dd[t] = vv;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned brev8(unsigned m) { return __brev(m) >> 24; }  // InOutMask::conjugate, inout_mask.hpp:18-39,112-115
 __device__ __forceinline__ bool uniq4(unsigned m) { return m && !(m & (m - 1)); }
 __device__ __forceinline__ bool mask_junction(unsigned m) { return !uniq4(m & 15) || !uniq4((m >> 4) & 15); }  // inout_mask.hpp:157-159
+template <int NW>
+__device__ __forceinline__ Rec<NW> node_kmer(const Rec<NW> *__restrict__ kmers, node_t node, unsigned k) {  // oriented k-mer of a node
+    const Rec<NW> x = kmers[node >> 1];
+    return (node & 1) ? rec_rc<NW>(x, k) : x;
+}
 
 // a13: the 2 k-mers of every canonical (k+1)-mer, canonicalised (the RC (k+1)-mer yields the same two)
 template <int NW>
@@ -99,11 +170,63 @@ __global__ void __launch_bounds__(BLK) k_derive_kmers(const void *kpo_, uint64_t
         out[2 * i + 1] = rec_canon<NW>(rec_suffix<NW>(x), k, f);
     }
 }
+// The same step when 4 record buffers of the whole (k+1)-mer file do not fit HBM: the k-mer file is produced one bucket range at a
+// time. The buckets of the k-mer file are disjoint by construction, so each range is final on its own (no merge of runs).
+// k_derive_hist: how many derived k-mers land in every bucket (decides the ranges); k_derive_range: emit those of [b0, b1).
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_derive_hist(const void *kpo_, uint64_t n, unsigned k, uint32_t B, unsigned long long *hist) {
+    extern __shared__ uint32_t lh[];
+    const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
+    for (uint32_t t = threadIdx.x; t < B; t += BLK) lh[t] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        const Rec<NW> x = kpo[i];
+        unsigned f;
+        atomicAdd(&lh[bucket_of(xxh3_rec<NW>(rec_canon<NW>(rec_prefix<NW>(x, k), k, f)), B)], 1u);
+        atomicAdd(&lh[bucket_of(xxh3_rec<NW>(rec_canon<NW>(rec_suffix<NW>(x), k, f)), B)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < B; t += BLK)
+        if (lh[t]) atomicAdd(&hist[t], (unsigned long long)lh[t]);
+}
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_derive_range(const void *kpo_, uint64_t n, unsigned k, uint32_t B, uint32_t b0, uint32_t b1,
+                                                      void *out_, unsigned long long *count) {
+    __shared__ uint32_t scratch[BLK / 64 + 2];
+    __shared__ unsigned long long s_base;
+    const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
+    Rec<NW> *out = (Rec<NW> *)out_;
+    for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n; base += (uint64_t)gridDim.x * BLK) {
+        const uint64_t i = base + threadIdx.x;
+        Rec<NW> p, s;
+        bool kp = false, ks = false;
+        if (i < n) {
+            const Rec<NW> x = kpo[i];
+            unsigned f;
+            p = rec_canon<NW>(rec_prefix<NW>(x, k), k, f);
+            s = rec_canon<NW>(rec_suffix<NW>(x), k, f);
+            const uint32_t bp = bucket_of(xxh3_rec<NW>(p), B), bs = bucket_of(xxh3_rec<NW>(s), B);
+            kp = bp >= b0 && bp < b1;
+            ks = bs >= b0 && bs < b1;
+        }
+        uint32_t tot;
+        const uint32_t off = block_excl_scan<uint32_t>((kp ? 1u : 0u) + (ks ? 1u : 0u), scratch, &tot);
+        if (threadIdx.x == 0) s_base = tot ? atomicAdd(count, (unsigned long long)tot) : 0ull;
+        __syncthreads();
+        unsigned long long o = s_base + off;
+        if (kp) out[o++] = p;
+        if (ks) out[o] = s;
+        __syncthreads();
+    }
+}
 
-// a15: out[prefix] |= bit(x_k), in[suffix] |= bit(x_0), positions mirrored (7-p) for non-minimal keys
+// a15: out[prefix] |= bit(x_k), in[suffix] |= bit(x_0), positions mirrored (7-p) for non-minimal keys. The two rank lookups also
+// tell where the de Bruijn edge x leads: succ[P] = S and, on the other strand, succ[S^1] = P^1 (P, S = the oriented prefix / suffix
+// nodes). A node with a unique outgoing extension is written by exactly one (k+1)-mer, so its entry is exact; entries of nodes with
+// several outgoing extensions are written more than once and are never read (the walks stop at junctions).
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_fill_masks(const void *kpo_, uint64_t n, unsigned k, const void *kmers_,
-                                                    RankIndex ix, uint32_t *mask32, uint32_t *err) {
+                                                    RankDir ix, uint32_t *mask32, node_t *succ, uint32_t *err) {
     const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
@@ -112,7 +235,7 @@ __global__ void __launch_bounds__(BLK) k_fill_masks(const void *kpo_, uint64_t n
         unsigned prc, src;
         Rec<NW> p = rec_canon<NW>(rec_prefix<NW>(x, k), k, prc);
         Rec<NW> s = rec_canon<NW>(rec_suffix<NW>(x), k, src);
-        uint32_t rp = kmer_rank<NW>(kmers, ix, p), rs = kmer_rank<NW>(kmers, ix, s);
+        const node_t rp = kmer_rank<NW>(kmers, ix, p), rs = kmer_rank<NW>(kmers, ix, s);
         if (rp == NODE_NONE || rs == NODE_NONE) {
             atomicAdd(err, 1u);
             continue;
@@ -121,16 +244,23 @@ __global__ void __launch_bounds__(BLK) k_fill_masks(const void *kpo_, uint64_t n
         const unsigned bs = src ? 3 - pn : pn + 4;
         atomicOr(&mask32[rp >> 2], (1u << bp) << ((rp & 3) * 8));
         atomicOr(&mask32[rs >> 2], (1u << bs) << ((rs & 3) * 8));
+        if (succ) {
+            const node_t P = (rp << 1) | prc, S = (rs << 1) | src;
+            succ[P] = S;
+            succ[S ^ 1] = P ^ 1;
+        }
     }
 }
 
-// successor of every non-junction node: GetOutgoing(kwh, GetUniqueOutgoing), debruijn_graph_constructor.hpp:228-235
+// successor of every non-junction node by lookup: GetOutgoing(kwh, GetUniqueOutgoing), debruijn_graph_constructor.hpp:228-235.
+// Used after the early clippers changed the masks (the table k_fill_masks left behind describes the unclipped index).
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t *mask, uint64_t D0, unsigned k,
-                                              RankIndex ix, uint32_t *succ, uint32_t *err) {
+                                              RankDir ix, node_t *succ, uint32_t *err) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
-        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        const uint64_t r = node >> 1;
+        const unsigned o = (unsigned)(node & 1);
         const unsigned m = mask[r];
         if (mask_junction(m)) {
             succ[node] = NODE_NONE;
@@ -141,7 +271,7 @@ __global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t 
         if (o) x = rec_rc<NW>(x, k);
         unsigned yo;
         Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, __ffs(mo & 15) - 1), k, yo);
-        uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+        const node_t ry = kmer_rank<NW>(kmers, ix, y);
         if (ry == NODE_NONE) atomicAdd(err, 1u);
         succ[node] = ry == NODE_NONE ? NODE_NONE : (ry << 1) | yo;
     }
@@ -156,18 +286,20 @@ __global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t 
 // extension bits until the clean-up pass (checked against the reference run with 1-4 threads: tests/golden/etc_*). Hence three
 // data-parallel passes: mark (reads the original masks), apply (IsolateVertex), fix (RemoveInconsistentForwardLinks, :21-36).
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_tip_mark(const void *kmers_, const uint8_t *mask, const uint32_t *succ, uint64_t D0, unsigned k,
-                                                  RankIndex ix, uint32_t bound, uint8_t *isolate, uint8_t *tipped, unsigned long long *stats,
+__global__ void __launch_bounds__(BLK) k_tip_mark(const void *kmers_, const uint8_t *mask, const node_t *succ, uint64_t D0, unsigned k,
+                                                  RankDir ix, uint32_t bound, uint8_t *isolate, uint8_t *tipped, unsigned long long *stats,
                                                   uint32_t *err) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
-        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        const uint64_t r = node >> 1;
+        const unsigned o = (unsigned)(node & 1);
         const unsigned m = mask[r];
         const unsigned mo = o ? brev8(m) : m;
         if (__popc(mo & 15) < 2) continue;
         Rec<NW> x = kmers[r];
         if (o) x = rec_rc<NW>(x, k);
-        uint32_t first[4], len[4];
+        node_t first[4];
+        uint32_t len[4];
         uint32_t mx = 0;
 #pragma unroll
         for (unsigned c = 0; c < 4; ++c) {
@@ -176,12 +308,13 @@ __global__ void __launch_bounds__(BLK) k_tip_mark(const void *kmers_, const uint
             if (!(mo & (1u << c))) continue;
             unsigned yo;
             const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-            const uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+            const node_t ry = kmer_rank<NW>(kmers, ix, y);
             if (ry == NODE_NONE) {
                 atomicAdd(err, 1u);
                 continue;
             }
-            uint32_t nd = (ry << 1) | yo, cnt = 0;
+            node_t nd = (ry << 1) | yo;
+            uint32_t cnt = 0;
             first[c] = nd;
             while (cnt < bound && !mask_junction(mask[nd >> 1])) {
                 ++cnt;
@@ -203,7 +336,7 @@ __global__ void __launch_bounds__(BLK) k_tip_mark(const void *kmers_, const uint
 #pragma unroll
         for (unsigned c = 0; c < 4; ++c) {
             if (len[c] == 0 || len[c] == 0xFFFFFFFFu || len[c] >= mx) continue;
-            uint32_t nd = first[c];
+            node_t nd = first[c];
             for (uint32_t i = 0; i + 1 < len[c]; ++i) {
                 isolate[nd >> 1] = 1;
                 nd = succ[nd];
@@ -221,13 +354,14 @@ __global__ void k_tip_apply(uint8_t *mask, const uint8_t *isolate, uint64_t D0) 
         if (isolate[r]) mask[r] = 0;
 }
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_tip_fix(const void *kmers_, uint32_t *mask32, const uint8_t *tipped, uint64_t D0, unsigned k, RankIndex ix,
+__global__ void __launch_bounds__(BLK) k_tip_fix(const void *kmers_, uint32_t *mask32, const uint8_t *tipped, uint64_t D0, unsigned k, RankDir ix,
                                                  uint32_t *err) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     const uint8_t *mask = (const uint8_t *)mask32;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
         if (!tipped[node]) continue;
-        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        const uint64_t r = node >> 1;
+        const unsigned o = (unsigned)(node & 1);
         const unsigned m = mask[r];
         const unsigned mo = o ? brev8(m) : m;
         Rec<NW> x = kmers[r];
@@ -237,7 +371,7 @@ __global__ void __launch_bounds__(BLK) k_tip_fix(const void *kmers_, uint32_t *m
             if (!(mo & (1u << c))) continue;
             unsigned yo;
             const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-            const uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+            const node_t ry = kmer_rank<NW>(kmers, ix, y);
             if (ry == NODE_NONE) {
                 atomicAdd(err, 1u);
                 continue;
@@ -279,11 +413,12 @@ __device__ __forceinline__ Rec<NW> rec_shr(const Rec<NW> &x, unsigned K, unsigne
 // RemoveATEdges, :176-259, pass 1: edges of length 1 (the next k-mer is a junction or a dead end) leaving a low-complexity junction
 // k-mer (some nucleotide occurs >= thr_edge times; thr_edge = smallest count that is not math::ls than 0.8 k, computed on the host)
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_at_edges_mark(const void *kmers_, const uint8_t *mask, uint64_t D0, unsigned k, RankIndex ix,
+__global__ void __launch_bounds__(BLK) k_at_edges_mark(const void *kmers_, const uint8_t *mask, uint64_t D0, unsigned k, RankDir ix,
                                                        uint32_t thr_edge, uint8_t *atflag, uint32_t *err) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
-        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        const uint64_t r = node >> 1;
+        const unsigned o = (unsigned)(node & 1);
         const unsigned m = mask[r];
         if (!mask_junction(m)) continue;
         const unsigned mo = o ? brev8(m) : m;
@@ -298,7 +433,7 @@ __global__ void __launch_bounds__(BLK) k_at_edges_mark(const void *kmers_, const
             if (!(mo & (1u << c))) continue;
             unsigned yo;
             const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-            const uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+            const node_t ry = kmer_rank<NW>(kmers, ix, y);
             if (ry == NODE_NONE) {
                 atomicAdd(err, 1u);
                 continue;
@@ -313,13 +448,14 @@ __global__ void __launch_bounds__(BLK) k_at_edges_mark(const void *kmers_, const
 // pass 2: DeleteOutgoing(kh, c) + DeleteIncoming(next, kh[0]) for the marked edges (an edge marked from both of its ends clears
 // the same two bits twice)
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_at_edges_apply(const void *kmers_, uint32_t *mask32, uint64_t D0, unsigned k, RankIndex ix,
+__global__ void __launch_bounds__(BLK) k_at_edges_apply(const void *kmers_, uint32_t *mask32, uint64_t D0, unsigned k, RankDir ix,
                                                         const uint8_t *atflag, unsigned long long *stats, uint32_t *err) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
         const unsigned fl = atflag[node];
         if (!fl) continue;
-        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        const uint64_t r = node >> 1;
+        const unsigned o = (unsigned)(node & 1);
         Rec<NW> x = kmers[r];
         if (o) x = rec_rc<NW>(x, k);
         const unsigned firstn = rec_nucl<NW>(x, 0);
@@ -327,7 +463,7 @@ __global__ void __launch_bounds__(BLK) k_at_edges_apply(const void *kmers_, uint
             if (!(fl & (1u << c))) continue;
             unsigned yo;
             const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-            const uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+            const node_t ry = kmer_rank<NW>(kmers, ix, y);
             if (ry == NODE_NONE) {
                 atomicAdd(err, 1u);
                 continue;
@@ -343,19 +479,21 @@ __global__ void __launch_bounds__(BLK) k_at_edges_apply(const void *kmers_, uint
 // max_len k-mers; succ[] of the opposite strand is the predecessor), count the last nucleotides of the tip k-mers (+ the root's up to
 // min_len), remove the tip if one nucleotide makes up >= thr_tip[max(n, min_len)] of them.
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const uint8_t *mask, const uint32_t *succ, uint64_t D0, unsigned k,
-                                                      RankIndex ix, uint32_t min_len, uint32_t max_len, const uint16_t *thr_tip,
+__global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const uint8_t *mask, const node_t *succ, uint64_t D0, unsigned k,
+                                                      RankDir ix, uint32_t min_len, uint32_t max_len, const uint16_t *thr_tip,
                                                       uint8_t *isolate, uint8_t *tipped, unsigned long long *stats, uint32_t *err) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
-        const uint32_t r = (uint32_t)(node >> 1), o = (uint32_t)(node & 1);
+        const uint64_t r = node >> 1;
+        const unsigned o = (unsigned)(node & 1);
         const unsigned m0 = mask[r];
         const unsigned mo0 = o ? brev8(m0) : m0;
         if ((mo0 & 15) != 0 || !uniq4((mo0 >> 4) & 15)) continue;  // start from tip ends
         Rec<NW> x = kmers[r];
         if (o) x = rec_rc<NW>(x, k);
         unsigned cnt[4] = {0, 0, 0, 0};
-        uint32_t n = 0, nd = (uint32_t)node;
+        uint32_t n = 0;
+        node_t nd = node;
         unsigned mo = mo0;
         bool bad = false;
         do {
@@ -366,14 +504,14 @@ __global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const 
             if (n == 1) {  // the dead end is a junction k-mer: its predecessor comes from a lookup, the rest by pointer chasing
                 unsigned yo;
                 const Rec<NW> y = rec_canon<NW>(x, k, yo);
-                const uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+                const node_t ry = kmer_rank<NW>(kmers, ix, y);
                 if (ry == NODE_NONE) {
                     bad = true;
                     break;
                 }
                 nd = (ry << 1) | yo;
             } else {
-                const uint32_t sp = succ[nd ^ 1];
+                const node_t sp = succ[nd ^ 1];
                 if (sp == NODE_NONE) {
                     bad = true;
                     break;
@@ -393,7 +531,7 @@ __global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const 
         if (curm < thr_tip[max(n, min_len)]) continue;
         // second walk: IsolateVertex on the n tip k-mers
         {
-            uint32_t q = (uint32_t)node;
+            node_t q = node;
             Rec<NW> z = kmers[r];
             if (o) z = rec_rc<NW>(z, k);
             unsigned mq = mo0;
@@ -419,185 +557,245 @@ __global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const 
     }
 }
 
-// start de-edges per junction k-mer: out bits of kh, then out bits of !kh (AddStartDeEdges, :203-226)
-__global__ void k_cand_count(const uint8_t *mask, uint64_t D0, unsigned long long *cnt) {
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x) {
-        unsigned m = mask[r];
-        cnt[r] = mask_junction(m) ? (unsigned long long)(__popc(m & 15) + __popc(m >> 4)) : 0ull;
-    }
+// start de-edges per junction k-mer: out bits of kh, then out bits of !kh (AddStartDeEdges, :203-226), in k-mer-file order.
+// Tiles of CAND_TILE ranks (8 consecutive ranks per thread): per-tile totals, a scan over the tiles, then every tile places its own.
+constexpr int CAND_PER = 8;
+constexpr int CAND_TILE = BLK * CAND_PER;
+__device__ __forceinline__ unsigned cand_of_mask(unsigned m) { return mask_junction(m) ? (unsigned)(__popc(m & 15) + __popc(m >> 4)) : 0u; }
+__global__ void __launch_bounds__(BLK) k_cand_tiles(const uint8_t *mask, uint64_t D0, unsigned long long *tcnt) {
+    __shared__ uint32_t scratch[BLK / 64 + 2];
+    const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
+    uint32_t c = 0;
+    for (int j = 0; j < CAND_PER; ++j)
+        if (r0 + j < D0) c += cand_of_mask(mask[r0 + j]);
+    uint32_t tot;
+    block_excl_scan<uint32_t>(c, scratch, &tot);
+    if (threadIdx.x == 0) tcnt[blockIdx.x] = tot;
 }
-__global__ void k_cand_expand(const uint8_t *mask, const unsigned long long *cand_off, uint64_t D0, unsigned long long *cand) {
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x) {
-        unsigned m = mask[r];
+__global__ void __launch_bounds__(BLK) k_cand_expand(const uint8_t *mask, const unsigned long long *toff, uint64_t D0, unsigned long long *cand) {
+    __shared__ uint32_t scratch[BLK / 64 + 2];
+    const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
+    uint32_t c = 0;
+    for (int j = 0; j < CAND_PER; ++j)
+        if (r0 + j < D0) c += cand_of_mask(mask[r0 + j]);
+    uint32_t tot;
+    unsigned long long o = toff[blockIdx.x] + block_excl_scan<uint32_t>(c, scratch, &tot);
+    for (int j = 0; j < CAND_PER; ++j) {
+        const uint64_t r = r0 + j;
+        if (r >= D0) break;
+        const unsigned m = mask[r];
         if (!mask_junction(m)) continue;
-        unsigned long long o = cand_off[r];
-        for (unsigned c = 0; c < 4; ++c)
-            if (m & (1u << c)) cand[o++] = (r << 3) | c;
+        for (unsigned cc = 0; cc < 4; ++cc)
+            if (m & (1u << cc)) cand[o++] = (r << 3) | cc;
         const unsigned mi = brev8(m);
-        for (unsigned c = 0; c < 4; ++c)
-            if (mi & (1u << c)) cand[o++] = (r << 3) | 4u | c;
+        for (unsigned cc = 0; cc < 4; ++cc)
+            if (mi & (1u << cc)) cand[o++] = (r << 3) | 4u | cc;
     }
 }
 
 // ConstructSequenceWithEdge (:264-273), pass 1: length and end node of every start de-edge
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_walk_len(const unsigned long long *cand, uint64_t C, const void *kmers_, const uint8_t *mask,
-                                                  const uint32_t *succ, unsigned k, RankIndex ix,
-                                                  uint64_t max_steps, unsigned long long *len, uint32_t *first, uint32_t *last,
+                                                  const node_t *succ, unsigned k, RankDir ix,
+                                                  uint64_t n_nodes, unsigned long long *len, node_t *first, node_t *last,
                                                   uint32_t *err) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         const unsigned long long cd = cand[i];
-        const uint32_t r = (uint32_t)(cd >> 3), side = (uint32_t)((cd >> 2) & 1), c = (uint32_t)(cd & 3);
-        Rec<NW> x = kmers[r];
-        if (side) x = rec_rc<NW>(x, k);
+        const unsigned c = (unsigned)(cd & 3);
+        const Rec<NW> x = node_kmer<NW>(kmers, cd >> 2, k);  // cd >> 2 = 2 * rank + side
         unsigned yo;
         Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-        uint32_t ry = kmer_rank<NW>(kmers, ix, y);
+        const node_t ry = kmer_rank<NW>(kmers, ix, y);
         if (ry == NODE_NONE) {
             atomicAdd(err, 1u);
             len[i] = 0;
             first[i] = last[i] = NODE_NONE;
             continue;
         }
-        uint32_t node = (ry << 1) | yo;
+        node_t node = (ry << 1) | yo;
         first[i] = node;
         uint64_t steps = 0;
         while (!mask_junction(mask[node >> 1])) {
             node = succ[node];
-            if (++steps > max_steps || node == NODE_NONE) {  // cannot happen on a consistent index; never hang the GPU
+            if (++steps > n_nodes || node >= n_nodes) {  // cannot happen on a consistent index; never hang the GPU or leave the arrays
                 atomicAdd(err, 1u);
+                node = NODE_NONE;
                 break;
             }
         }
         last[i] = node;
-        len[i] = k + 1 + steps;
+        len[i] = node == NODE_NONE ? 0 : k + 1 + steps;
+        if (node == NODE_NONE) first[i] = NODE_NONE;
     }
 }
 
-// pass 2: write the nucleotides (ASCII) and mark every k-mer on the path (both strands share the rank) as visited
+// keep iff !(s < !s) (:305-306), decided before anything is written. RC(s) begins with the reverse complement of the last k-mer,
+// i.e. with the oriented k-mer of node last^1, and s begins with the start k-mer: unless those two k-mers are equal they decide.
+// If they are equal the path leads from the start node A to A^1 (a hairpin): RC(s) is then itself a path leaving A, and the two are
+// compared nucleotide by nucleotide with two forward walkers. flags: bit 0 keep, bit 1 s == RC(s) (self-conjugate edge).
+// kw[i] = 64-bit words of the packed sequence (0 if dropped), one[i] = keep.
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_walk_write(const unsigned long long *cand, uint64_t C, const void *kmers_, const uint8_t *mask,
-                                                    const uint32_t *succ, unsigned k, const uint32_t *first, const unsigned long long *soff,
-                                                    char *seq, uint8_t *visited) {
+__global__ void __launch_bounds__(BLK) k_keep(const unsigned long long *cand, uint64_t C, const void *kmers_, const uint8_t *mask,
+                                              const node_t *succ, unsigned k, const unsigned long long *len, const node_t *first,
+                                              const node_t *last, uint8_t *flags, unsigned long long *kw, unsigned long long *one) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
-        const unsigned long long cd = cand[i];
-        const uint32_t r = (uint32_t)(cd >> 3), side = (uint32_t)((cd >> 2) & 1), c = (uint32_t)(cd & 3);
-        uint32_t node = first[i];
-        if (node == NODE_NONE) continue;
-        Rec<NW> x = kmers[r];
-        if (side) x = rec_rc<NW>(x, k);
-        char *s = seq + soff[i];
-        const unsigned long long n = soff[i + 1] - soff[i];
-        for (unsigned j = 0; j < k; ++j) s[j] = "ACGT"[rec_nucl<NW>(x, j)];
-        s[k] = "ACGT"[c];
-        visited[r] = 1;
-        unsigned long long p = k + 1;
-        while (p < n) {
-            const unsigned m = mask[node >> 1];
-            const unsigned mo = (node & 1) ? brev8(m) : m;
-            visited[node >> 1] = 1;
-            s[p++] = "ACGT"[__ffs(mo & 15) - 1];
-            node = succ[node];
-        }
-        visited[node >> 1] = 1;
-    }
-}
-
-// keep iff !(s < !s) (:305-306); also self-conjugate flag (s == !s)
-__global__ void k_keep(const char *seq, const unsigned long long *soff, uint64_t C, unsigned long long *keeplen, uint8_t *flags) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (uint64_t)gridDim.x * blockDim.x) {
-        const char *s = seq + soff[i];
-        const unsigned long long n = soff[i + 1] - soff[i];
-        int cmp = 0;  // sign of s - rc(s)
-        for (unsigned long long j = 0; j < n; ++j) {
-            const char a = s[j], b = s[n - 1 - j];
-            const char cb = b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : 'A';
-            if (a != cb) {
-                cmp = a < cb ? -1 : 1;
-                break;
+        const unsigned long long n = len[i];
+        int cmp = -1;
+        if (n) {
+            const unsigned long long cd = cand[i];
+            const node_t A = cd >> 2, L = last[i];
+            const Rec<NW> x0 = node_kmer<NW>(kmers, A, k);
+            cmp = rec_lex_cmp<NW>(x0, node_kmer<NW>(kmers, L ^ 1, k));
+            if (cmp == 0) {
+                // nodes after A: n_1 = first .. n_m = L = A^1, m = n - k. RC(s) = A, n_{m-1}^1, .., n_1^1, A^1.
+                const unsigned long long m = n - k;
+                node_t a = first[i], prev = A;
+                for (unsigned long long t = 1; t < m; ++t) {
+                    prev = a;
+                    a = succ[a];
+                }
+                // prev = n_{m-1} (A itself when m == 1); RC(s)[k] = complement of the first nucleotide of its k-mer
+                const unsigned c2 = 3u - rec_nucl<NW>(node_kmer<NW>(kmers, prev, k), 0);
+                const unsigned c1 = (unsigned)(cd & 3);
+                cmp = c1 < c2 ? -1 : (c1 > c2 ? 1 : 0);
+                a = first[i];
+                node_t b = prev ^ 1;
+                for (unsigned long long t = 1; t < m && cmp == 0; ++t) {
+                    const unsigned ma = mask[a >> 1], mb = mask[b >> 1];
+                    const unsigned na = __ffs(((a & 1) ? brev8(ma) : ma) & 15) - 1, nb = __ffs(((b & 1) ? brev8(mb) : mb) & 15) - 1;
+                    cmp = na < nb ? -1 : (na > nb ? 1 : 0);
+                    a = succ[a];
+                    b = succ[b];
+                }
             }
         }
         const bool keep = n > 0 && cmp >= 0;
-        flags[i] = (uint8_t)((keep ? 1 : 0) | (cmp == 0 ? 2 : 0));
-        keeplen[i] = keep ? n : 0;
+        flags[i] = (uint8_t)((keep ? 1 : 0) | ((n > 0 && cmp == 0) ? 2 : 0));
+        kw[i] = keep ? (n + 31) / 32 : 0;
+        one[i] = keep ? 1 : 0;
     }
 }
-// kept candidates -> dense edge arrays
-__global__ void k_gather(const char *seq, const unsigned long long *soff, const unsigned long long *koff, const uint8_t *flags,
-                         const unsigned long long *eidx, const unsigned long long *cand, const uint32_t *last, uint64_t C,
-                         char *kseq, unsigned long long *eoff, uint32_t *estart, uint32_t *eend, uint8_t *eself) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (uint64_t)gridDim.x * blockDim.x) {
+
+// pass 2, kept paths only: the packed nucleotides (the start (k+1)-mer is the first NW words, then 2 bits per step) at their final
+// place, the dense edge arrays, and a visited mark on every k-mer of the path (both strands share the rank)
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_walk_write(const unsigned long long *cand, uint64_t C, const void *kmers_, const uint8_t *mask,
+                                                    const node_t *succ, unsigned k, const unsigned long long *len, const node_t *first,
+                                                    const node_t *last, const uint8_t *flags, const unsigned long long *woff,
+                                                    const unsigned long long *eidx, uint64_t *words, unsigned long long *eoffw,
+                                                    unsigned long long *elen, node_t *estart, node_t *eend, uint8_t *eself, uint8_t *visited) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         if (!(flags[i] & 1)) continue;
-        const unsigned long long e = eidx[i], n = soff[i + 1] - soff[i], o = koff[i];
-        const char *s = seq + soff[i];
-        for (unsigned long long j = 0; j < n; ++j) kseq[o + j] = s[j];
-        eoff[e] = o;
-        estart[e] = (uint32_t)(((cand[i] >> 3) << 1) | ((cand[i] >> 2) & 1));
+        const unsigned long long cd = cand[i], n = len[i], e = eidx[i], wo = woff[i];
+        const unsigned c = (unsigned)(cd & 3);
+        const Rec<NW> x = node_kmer<NW>(kmers, cd >> 2, k);
+        uint64_t *dst = words + wo;
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w) dst[w] = x.w[w];
+        uint64_t cur = x.w[NW - 1] | ((uint64_t)c << ((k & 31) << 1));
+        visited[cd >> 3] = 1;
+        node_t node = first[i];
+        for (unsigned long long p = k + 1; p < n; ++p) {
+            if ((p & 31) == 0) {
+                dst[(p >> 5) - 1] = cur;
+                cur = 0;
+            }
+            const unsigned m = mask[node >> 1];
+            const unsigned mo = (node & 1) ? brev8(m) : m;
+            visited[node >> 1] = 1;
+            cur |= (uint64_t)(__ffs(mo & 15) - 1) << ((p & 31) << 1);
+            node = succ[node];
+        }
+        dst[(n - 1) >> 5] = cur;
+        visited[node >> 1] = 1;
+        eoffw[e] = wo;
+        elen[e] = n;
+        estart[e] = cd >> 2;
         eend[e] = last[i];
         eself[e] = (flags[i] >> 1) & 1;
     }
 }
-__global__ void k_keep_flag(const uint8_t *flags, uint64_t C, unsigned long long *one) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < C; i += (uint64_t)gridDim.x * blockDim.x) one[i] = flags[i] & 1;
-}
+
 // k-mers left on perfect loops: non-junction and not on any extracted path (CollectLoops pass 1, :362-374)
-__global__ void k_loop_nodes(const uint8_t *mask, const uint8_t *visited, uint64_t D0, uint32_t *count, uint32_t *list, uint32_t cap) {
+__global__ void k_loop_count(const uint8_t *mask, const uint8_t *visited, uint64_t D0, unsigned long long *count) {
+    __shared__ unsigned long long scratch[BLK / 64 + 2];
+    unsigned long long c = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x)
+        if (!mask_junction(mask[r]) && !visited[r]) ++c;
+    unsigned long long tot;
+    block_excl_scan<unsigned long long>(c, scratch, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(count, tot);
+}
+__global__ void k_loop_list(const uint8_t *mask, const uint8_t *visited, uint64_t D0, unsigned long long *count, unsigned long long *list,
+                            unsigned long long cap) {
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x) {
         if (!mask_junction(mask[r]) && !visited[r]) {
-            uint32_t p = atomicAdd(count, 1u);
-            if (p < cap) list[p] = (uint32_t)r;
+            const unsigned long long p = atomicAdd(count, 1ull);
+            if (p < cap) list[p] = r;
         }
     }
 }
 template <int NW>
-__global__ void k_gather_kmers(const void *kmers_, const uint32_t *list, uint32_t n, void *out_) {
+__global__ void k_gather_kmers(const void *kmers_, const uint8_t *mask, const unsigned long long *list, uint64_t n, void *out_, uint8_t *omask) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     Rec<NW> *out = (Rec<NW> *)out_;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = kmers[list[i]];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        out[i] = kmers[list[i]];
+        omask[i] = mask[list[i]];
+    }
 }
 
 // ---- link records + vertices on the device (FastGraphFromSequencesConstructor::ConstructGraph, debruijn_graph_constructor.hpp:506-567) ----
-// Record key = rank << 33 | EdgeAndMask (edge id << 2 | rc << 1 | is_start), left-shifted by sh so that the MSD digits of the
-// sorting pipeline see a spread-out fraction. The end record of a self-conjugate edge does not exist (LinkRecord() is invalid): it is
-// emitted as a copy of the start record, which the sort + unique pipeline drops.
-__global__ void k_link_keys(const uint32_t *estart, const uint32_t *eend, const uint8_t *eself, uint64_t ne, unsigned sh,
-                            unsigned long long *keys) {
+// Record = two words: w0 = rank of the vertex k-mer (left-shifted by sh so that the MSD digits of the sorting pipeline see a
+// spread-out fraction), w1 = EdgeAndMask (edge id << 2 | rc << 1 | is_start); the pipeline orders by (w0, w1) = CompareByVertexKMer-
+// EdgeIdAndMask. The end record of a self-conjugate edge does not exist (LinkRecord() is invalid): it is emitted as a copy of the
+// start record, which the sort + unique pipeline drops.
+__global__ void k_link_keys(const node_t *estart, const node_t *eend, const uint8_t *eself, uint64_t ne, unsigned sh, Rec<2> *keys) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t edge = 3 + 2 * i;
-        const uint32_t s = estart[i], e = eend[i];
-        const unsigned long long ks = ((uint64_t)(s >> 1) << 33) | (edge << 2) | ((uint64_t)(s & 1) << 1) | 1ull;
-        const unsigned long long ke = ((uint64_t)(e >> 1) << 33) | (edge << 2) | ((uint64_t)(e & 1) << 1);
-        keys[2 * i] = ks << sh;
-        keys[2 * i + 1] = (eself[i] ? ks : ke) << sh;
+        const node_t s = estart[i], e = eend[i];
+        Rec<2> ks, ke;
+        ks.w[0] = (s >> 1) << sh;
+        ks.w[1] = (edge << 2) | ((s & 1) << 1) | 1ull;
+        ke.w[0] = (e >> 1) << sh;
+        ke.w[1] = (edge << 2) | ((e & 1) << 1);
+        keys[2 * i] = ks;
+        keys[2 * i + 1] = eself[i] ? ks : ke;
     }
 }
-// sorted keys (still shifted): un-shift in place; one[i] = 1 where a new rank (vertex) starts
-__global__ void k_vertex_flags(unsigned long long *keys, uint64_t n, unsigned sh, unsigned long long *one) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const unsigned long long k = keys[i] >> sh;
-        const unsigned long long p = i ? keys[i - 1] >> sh : ~0ull;
-        one[i] = (i == 0 || (k >> 33) != (p >> 33)) ? 1ull : 0ull;
-    }
+// sorted records: one[i] = 1 where a new rank (vertex) starts
+__global__ void k_vertex_flags(const Rec<2> *keys, uint64_t n, unsigned long long *one) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        one[i] = (i == 0 || keys[i].w[0] != keys[i - 1].w[0]) ? 1ull : 0ull;
 }
-__global__ void k_unshift(unsigned long long *keys, uint64_t n, unsigned sh) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) keys[i] >>= sh;
-}
-// vertex v = the run of records starting at position i: vpos[v] = i, vkey[v] = smallest EdgeAndMask of the vertex << 31 | v (shifted)
-__global__ void k_vertex_collect(const unsigned long long *keys, const unsigned long long *one, const unsigned long long *vidx, uint64_t n,
-                                 unsigned sh2, unsigned long long *vpos, unsigned long long *vkeys) {
+// vertex v = the run of records starting at position i: vpos[v] = i, vkey[v] = (smallest EdgeAndMask of the vertex (shifted), v)
+__global__ void k_vertex_collect(const Rec<2> *keys, const unsigned long long *one, const unsigned long long *vidx, uint64_t n,
+                                 unsigned sh2, unsigned long long *vpos, Rec<2> *vkeys) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         if (!one[i]) continue;
         const unsigned long long v = vidx[i];
         vpos[v] = i;
-        vkeys[v] = (((keys[i] & ((1ull << 33) - 1)) << 31) | v) << sh2;
+        Rec<2> r;
+        r.w[0] = keys[i].w[1] << sh2;
+        r.w[1] = v;
+        vkeys[v] = r;
     }
 }
-__global__ void k_vertex_permute(const unsigned long long *vkeys_sorted, const unsigned long long *vpos, uint64_t nv, unsigned sh2,
-                                 unsigned long long *vstart) {
+__global__ void k_vertex_permute(const Rec<2> *vkeys_sorted, const unsigned long long *vpos, uint64_t nv, unsigned long long *vstart) {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nv; j += (uint64_t)gridDim.x * blockDim.x)
-        vstart[j] = vpos[(vkeys_sorted[j] >> sh2) & ((1ull << 31) - 1)];
+        vstart[j] = vpos[vkeys_sorted[j].w[1]];
+}
+
+// ---- packed unitigs <-> other forms -----------------------------------------------------------------------------------------
+// (start, len) of every unitig as a read batch: the coverage pass marks its (k+1)-mer windows like those of reads
+__global__ void k_edge_as_reads(const unsigned long long *eoffw, const unsigned long long *elen, uint64_t ne, uint64_t *start, uint32_t *len) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += (uint64_t)gridDim.x * blockDim.x) {
+        start[i] = eoffw[i] * 32;
+        len[i] = (uint32_t)min(elen[i], 0xFFFFFFFFull);
+    }
 }
 
 // ---- coverage (-c) -----------------------------------------------------------------------------------------------
@@ -607,7 +805,7 @@ __global__ void k_vertex_permute(const unsigned long long *vkeys_sorted, const u
 // complement (both strand instances are minimal then).
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_kpo_coverage(const uint64_t *seq, const uint64_t *mask, uint64_t G, unsigned K1,
-                                                      const void *kpo_, RankIndex ix, uint32_t *cnt) {
+                                                      const void *kpo_, RankDir ix, uint32_t *cnt) {
     const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
     for (uint64_t g = (uint64_t)blockIdx.x * BLK + threadIdx.x; g < G; g += (uint64_t)gridDim.x * BLK) {
         if (!((mask[g >> 6] >> (g & 63)) & 1)) continue;
@@ -615,41 +813,37 @@ __global__ void __launch_bounds__(BLK) k_kpo_coverage(const uint64_t *seq, const
         Rec<NW> y = rec_rc<NW>(x, K1);
         const bool pal = rec_eq<NW>(x, y);
         const Rec<NW> c = rc_ge<NW>(y, x) ? x : y;
-        const uint32_t r = kmer_rank<NW>(kpo, ix, c);
+        const node_t r = kmer_rank<NW>(kpo, ix, c);
         if (r != NODE_NONE) atomicAdd(&cnt[r], pal ? 2u : 1u);
     }
 }
 
 // edge raw coverage = sum of the counters of the edge's (k+1)-mers (graph_support/coverage_filling.hpp:46-62), uint32; flanking raw
 // coverage = the same sum over the first `flank` (k+1)-mers (inc_coverage: offset < averaging_range, :40-44) of the edge (fl_s) and
-// of its conjugate, i.e. the last `flank` ones (fl_e)
+// of its conjugate, i.e. the last `flank` ones (fl_e). The unitigs are a packed stream with word-aligned starts; wmask marks the
+// positions where a (k+1)-mer of some unitig starts.
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_edge_coverage(const char *seq, const unsigned long long *eoff, uint64_t n_edges, uint64_t total,
-                                                       unsigned K1, const void *kpo_, RankIndex ix,
+__global__ void __launch_bounds__(BLK) k_edge_coverage(const uint64_t *words, const uint64_t *wmask, const unsigned long long *eoffw,
+                                                       const unsigned long long *elen, uint64_t n_edges, uint64_t G,
+                                                       unsigned K1, const void *kpo_, RankDir ix,
                                                        const uint32_t *cnt, uint32_t *ecov, uint32_t flank, uint32_t *fl_s, uint32_t *fl_e) {
     const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
-    for (uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x; p < total; p += (uint64_t)gridDim.x * BLK) {
-        uint64_t lo = 0, hi = n_edges;  // edge e with eoff[e] <= p < eoff[e+1]
+    for (uint64_t p = (uint64_t)blockIdx.x * BLK + threadIdx.x; p < G; p += (uint64_t)gridDim.x * BLK) {
+        if (!((wmask[p >> 6] >> (p & 63)) & 1)) continue;
+        const uint64_t pw = p >> 5;
+        uint64_t lo = 0, hi = n_edges;  // edge e with eoffw[e] <= pw < eoffw[e+1]
         while (hi - lo > 1) {
             uint64_t mid = (lo + hi) >> 1;
-            if (eoff[mid] <= p) lo = mid; else hi = mid;
+            if (eoffw[mid] <= pw) lo = mid; else hi = mid;
         }
-        if (p + K1 > eoff[lo + 1]) continue;
-        Rec<NW> x;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) x.w[w] = 0;
-        for (unsigned j = 0; j < K1; ++j) {
-            const char ch = seq[p + j];
-            const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
-            x.w[j >> 5] |= code << ((j & 31) << 1);
-        }
+        const Rec<NW> x = load_window<NW>(words, p, K1);
         unsigned f;
         const Rec<NW> c = rec_canon<NW>(x, K1, f);
-        const uint32_t r = kmer_rank<NW>(kpo, ix, c);
+        const node_t r = kmer_rank<NW>(kpo, ix, c);
         if (r != NODE_NONE) {
             const uint32_t v = cnt[r];
             atomicAdd(&ecov[lo], v);
-            const uint64_t j = p - eoff[lo], nk = eoff[lo + 1] - eoff[lo] - K1 + 1;
+            const uint64_t j = p - eoffw[lo] * 32, nk = elen[lo] - K1 + 1;
             if (j < flank) atomicAdd(&fl_s[lo], v);
             if (j + flank >= nk) atomicAdd(&fl_e[lo], v);
         }

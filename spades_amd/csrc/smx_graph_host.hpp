@@ -28,8 +28,8 @@ struct GraphHost {
     // edges in the reference's enumeration order (unbranching paths, then loops)
     std::vector<uint64_t> eoff;    // [n_edges+1] offsets into seq
     std::string seq;               // ACGT
-    std::vector<uint32_t> estart;  // node = 2*rank + rc of the first k-mer
-    std::vector<uint32_t> eend;    // node of the last k-mer
+    std::vector<uint64_t> estart;  // node = 2*rank + rc of the first k-mer (rank: size_t in the reference, 64 bits here)
+    std::vector<uint64_t> eend;    // node of the last k-mer
     std::vector<uint8_t> eself;    // s == RC(s)
     std::vector<uint32_t> ecov;    // raw coverage per edge (filled by smx_graph_fill_coverage; empty = no -c)
     std::vector<uint32_t> eflank_s, eflank_e;  // flanking raw coverage of the edge and of its conjugate (first / last 50 (k+1)-mers)
@@ -54,7 +54,7 @@ inline std::string revcomp(const std::string &s) {
 // nodes: canonical k-mers (as strings) that are non-junction and lie on no extracted path, in k-mer-file order,
 // with their masks. All k-mers of a perfect loop are in this set, so the walk never leaves it.
 struct LoopNode {
-    uint32_t rank;
+    uint64_t rank;
     std::string kmer;
     uint8_t mask;
 };
@@ -111,11 +111,11 @@ class LoopCollector {
     LoopCollector(std::vector<LoopNode> &nodes, unsigned k) : nodes_(nodes), k_(k) {
         for (size_t i = 0; i < nodes.size(); ++i) idx_[nodes[i].kmer] = i;
     }
-    uint32_t node_of(const std::string &x) const {  // 2*rank + rc
+    uint64_t node_of(const std::string &x) const {  // 2*rank + rc
         size_t i;
         bool mn;
-        if (!lookup(x, i, mn)) return 0xFFFFFFFFu;
-        return (nodes_[i].rank << 1) | (mn ? 0u : 1u);
+        if (!lookup(x, i, mn)) return ~0ull;
+        return (nodes_[i].rank << 1) | (mn ? 0ull : 1ull);
     }
     // appends loops (max(s, RC s) each) in the reference's order
     void collect(std::vector<std::string> &out) {
@@ -307,7 +307,9 @@ inline void build_links(GraphHost &g, const KeySorter &sorter = radix_sort_u64) 
     auto eam = [](const GraphHost::Rec &r) { return (r.edge << 2) | (r.hash_and_mask & 3); };
     // CompareByVertexKMerEdgeIdAndMask: (rank, EdgeAndMask). rank < 2^31 and edge id < 2^31, so the pair packs into one
     // 64-bit key (rank << 33 | EdgeAndMask); invalid records (self-conjugate ends) sort last as ~0.
-    const bool packable = ne < (1ull << 29);
+    uint64_t max_rank = 0;
+    for (size_t i = 0; i < ne; ++i) max_rank = std::max(max_rank, std::max(g.estart[i], g.eend[i]) >> 1);
+    const bool packable = ne < (1ull << 29) && max_rank < (1ull << 31);
     if (packable) {
         std::vector<uint64_t> keys(g.recs.size());
         for (size_t i = 0; i < g.recs.size(); ++i) {
@@ -332,7 +334,7 @@ inline void build_links(GraphHost &g, const KeySorter &sorter = radix_sort_u64) 
             }
         }
     } else {
-        std::sort(g.recs.begin(), g.recs.end(), [&](const GraphHost::Rec &a, const GraphHost::Rec &b) {
+        parallel_sort(g.recs, [&](const GraphHost::Rec &a, const GraphHost::Rec &b) {
             uint64_t ha = a.hash_and_mask >> 2, hb = b.hash_and_mask >> 2;
             if (ha != hb) return ha < hb;
             return eam(a) < eam(b);

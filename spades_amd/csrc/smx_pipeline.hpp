@@ -140,7 +140,6 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (ctx->opt_leaf_cap > 0) cap = (uint32_t)std::min<int64_t>(ctx->opt_leaf_cap, cap);
     const uint32_t cap1 = std::min<uint32_t>(Tune<NW>::CAP1, cap);
     const bool from_reads = d_recs == nullptr;
-    ctx->last_idx_bins = 0;
     clear_result(ctx);
     ctx->K = K;
     ctx->nw = NW;
@@ -470,15 +469,6 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
                        (const unsigned long long *)uoff, B, (uint32_t)(nb / B), bucket_off);
     HIPCHK(hipGetLastError());
     tend(ctx);
-    if (ctx->want_index) {
-        if (ctx->last_idx_off) arena_put(ctx, ctx->last_idx_off);
-        ctx->last_idx_off = nullptr;
-        if (int rc = dalloc(ctx, &ctx->last_idx_off, nb + 1, false)) return rc;
-        HIPCHK(hipMemcpyAsync(ctx->last_idx_off, uoff, (size_t)(nb + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        ctx->last_idx_bins = nb;
-        ctx->last_idx_S1 = S1;
-        ctx->last_idx_f = lv;
-    }
     std::vector<unsigned long long> h(B + 1);
     HIPCHK(hipMemcpyAsync(h.data(), bucket_off, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -493,8 +483,9 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
 
 // Super-k-mer pre-deduplication of the selected windows (smx_superkmer.hip). *out: canonical K-mers, every k-mer of the
 // selection at least once and most of them exactly once (temp buffer of nwin records), *n_out: how many.
+constexpr int SMX_RETRY_SMALLER = 1001;  // internal: the pre-dedupe output did not fit the capacity it was given
 template <int NW>
-int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, Rec<NW> **out, uint64_t *n_out) {
+int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, Rec<NW> **out, uint64_t *n_out, uint64_t out_cap = 0) {
     constexpr int SW = 2 * NW;
     const std::vector<uint64_t *> &masks = *sel.masks;
     unsigned long long *cnt, *soff, *ocount, *cursor;  // ocount[0] clean, ocount[1] dirty survivors
@@ -582,7 +573,12 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
                     hp[8 * ph + 3] ? (double)hp[8 * ph] / hp[8 * ph + 3] : 0.0, hp[8 * ph + 3] ? (double)hp[8 * ph + 1] / hp[8 * ph + 3] : 0.0,
                     hp[8 * ph + 3] ? (double)hp[8 * ph + 2] / hp[8 * ph + 3] : 0.0);
     }
-    if (int rc = dalloc(ctx, out, nwin + 1)) return rc;
+    // Output capacity: one record per window can never overflow; a smaller buffer (HBM-bounded) keeps a share for the survivors of
+    // cut keys at its far end and reports an overflow (the caller then takes smaller batches).
+    if (out_cap == 0 || out_cap > nwin) out_cap = nwin;
+    const uint64_t dirty_cap = out_cap == nwin ? out_cap : std::max<uint64_t>(out_cap / 8, 1);
+    const uint64_t clean_cap = out_cap == nwin ? out_cap : out_cap - dirty_cap;
+    if (int rc = dalloc(ctx, out, out_cap + 1)) return rc;
     // Chunk capacity of the LDS hash set: every copy of a k-mer sits in ONE partition, and a partition that does not fit a chunk is
     // cut (its survivors need a unique pass of their own). The partition a typical super-k-mer lives in holds sum(c^2)/sum(c) slots —
     // one genomic locus at coverage 30 is ~46 slots = ~860 instances; deeper coverage grows it linearly. 2048 instances is the fastest
@@ -617,7 +613,8 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     }
     tbegin(ctx, "skm_dedupe");
     hipLaunchKernelGGL((k_skm_dedupe<NW>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
-                       (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)nwin, ocount, ocount + 1, prof);
+                       (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)out_cap, (unsigned long long)clean_cap,
+                       (unsigned long long)dirty_cap, ocount, ocount + 1, prof);
     HIPCHK(hipGetLastError());
     tend(ctx);
     if (prof) {
@@ -631,9 +628,10 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     HIPCHK(hipMemcpyAsync(nn, ocount, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (nn[0] + nn[1] > nwin) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication produced %llu records from %llu windows", nn[0] + nn[1], (unsigned long long)nwin);
+    if (nn[0] > clean_cap || nn[1] > dirty_cap) return SMX_RETRY_SMALLER;
     unsigned long long n = nn[0];
     if (nn[1]) {  // survivors of cut keys: sort + unique them on their own, then the whole array is exactly distinct
-        if (int rc = run_count<NW>(ctx, K, SMX_MODE_ALL, 1, *out + (nwin - nn[1]), nn[1])) return rc;
+        if (int rc = run_count<NW>(ctx, K, SMX_MODE_ALL, 1, *out + (out_cap - nn[1]), nn[1])) return rc;
         HIPCHK(hipMemcpyAsync(*out + nn[0], ctx->d_result_buf, ctx->n_records * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         n += ctx->n_records;
@@ -649,26 +647,41 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
 
 // One pipeline run over a selection of the resident reads: straight from the windows, or through the pre-dedupe stage.
 template <int NW>
+bool prededupe_applies(const smx_ctx *ctx, unsigned K, uint64_t nwin) {
+    return K >= 21 && nwin > 0 && (ctx->opt_prededupe > 0 || (ctx->opt_prededupe < 0 && nwin >= (1u << 20)));
+}
+template <int NW>
 int count_selection(smx_ctx *ctx, unsigned K, int mode, unsigned B, const ReadSel &sel) {
     const uint64_t nwin = mode == SMX_MODE_ALL ? sel.nrec / 2 : sel.nrec;
-    const bool possible = K >= 21 && nwin > 0;
-    const bool use = possible && (ctx->opt_prededupe > 0 || (ctx->opt_prededupe < 0 && nwin >= (1u << 20)));
-    if (!use) return run_count<NW>(ctx, K, mode, B, nullptr, 0, &sel);
+    if (!prededupe_applies<NW>(ctx, K, nwin)) return run_count<NW>(ctx, K, mode, B, nullptr, 0, &sel);
+    // HBM plan: behind the pre-dedupe stage only the distinct canonical records exist. Its output buffer never needs more than one
+    // record per window, and not more than what leaves room for the pipeline's own buffers (mode B: the output buffer doubles as one
+    // of the two ping-pong buffers; mode A: two buffers of twice the records).
+    uint64_t out_cap = nwin;
+    {
+        const double W = NW * 8.0;
+        const double room = (double)arena_avail(ctx) - 5.0 * (double)nwin;  // super-k-mer slots + staging: < 5 B per window
+        const double per = mode == SMX_MODE_ALL ? 5.0 * W + 24 : 2.0 * W + 12;
+        const uint64_t fit = room > 0 ? (uint64_t)(room / per) : 0;
+        if (fit < nwin) out_cap = std::max<uint64_t>(fit, 1);
+    }
     Rec<NW> *recs = nullptr;
     uint64_t n = 0;
-    if (int rc = run_prededupe<NW>(ctx, K, sel, nwin, &recs, &n)) return rc;
+    if (int rc = run_prededupe<NW>(ctx, K, sel, nwin, &recs, &n, out_cap)) return rc;
     free_temps(ctx, recs);
     ctx->temps.push_back(recs);
-    if (int rc = run_count<NW>(ctx, K, mode, B, recs, n, nullptr, false, mode == SMX_MODE_ALL, /*distinct_hint=*/true)) return rc;
+    if (int rc = run_count<NW>(ctx, K, mode, B, recs, n, nullptr, /*recs_reusable=*/mode != SMX_MODE_ALL, mode == SMX_MODE_ALL, /*distinct_hint=*/true)) return rc;
     ctx->n_instances = sel.nrec;
     return 0;
 }
 
 // Counting from the resident reads with HBM-bounded batches (the reference's dump + merge, kmer_splitter.hpp:123-170 +
-// kmer_index_builder.hpp:346-430): when two record buffers of the whole batch do not fit the budget, the position
+// kmer_index_builder.hpp:346-430): when the buffers of the whole batch do not fit the budget, the position
 // space of every read chunk is cut into ranges; each range is counted on its own (sorted-unique run), and runs are
 // folded into the accumulated set by concatenation + one more pass of the same pipeline from records (= k-way
 // merge-unique; the pipeline is a sort, so equal keys of different runs meet in the same leaf).
+// Behind the pre-dedupe stage the footprint depends on the number of DISTINCT k-mers, which nobody knows in advance: the first
+// attempt takes everything in one batch and a buffer overflow (SMX_RETRY_SMALLER) doubles the number of batches.
 template <int NW>
 int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
     std::vector<uint64_t *> masks;
@@ -685,99 +698,121 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
     }
     const int rpp = mode == SMX_MODE_ALL ? 2 : 1;
     const uint64_t nrec = nwin * rpp;
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
-    size_t cached = 0;
-    for (auto &b : ctx->arena_free) cached += b.second;
-    const uint64_t budget = ctx->budget ? ctx->budget : (uint64_t)((free_b + cached) * 0.92);
-    // per record: two ping-pong copies + ~1/4 record of bin bookkeeping
-    uint64_t max_batch = budget / ((uint64_t)NW * 8 * 2 + 8);
-    if (ctx->opt_batch_records > 0) max_batch = (uint64_t)ctx->opt_batch_records;
-    uint64_t nbatch = nrec ? (nrec + max_batch - 1) / max_batch : 1;
-    if (nbatch > 1) nbatch = (2 * nrec + max_batch - 1) / max_batch;  // keep half of the budget for the accumulated set + merge
-    if (nbatch <= 1) {
-        ReadSel sel;
-        sel.masks = &masks;
-        sel.nrec = nrec;
-        rc = count_selection<NW>(ctx, K, mode, B, sel);
-        drop_masks();
-        return rc;
+    const uint64_t budget = arena_avail(ctx);
+    const bool dedupe = prededupe_applies<NW>(ctx, K, nwin);
+    uint64_t nbatch;
+    if (ctx->opt_batch_records > 0) {
+        nbatch = nrec ? (nrec + ctx->opt_batch_records - 1) / ctx->opt_batch_records : 1;
+        if (nbatch > 1) nbatch = (2 * nrec + ctx->opt_batch_records - 1) / ctx->opt_batch_records;
+    } else if (dedupe) {
+        nbatch = std::max<uint64_t>(1, (uint64_t)std::ceil(10.0 * (double)nwin / (double)std::max<uint64_t>(budget, 1)));  // slots + staging <= half of HBM
+    } else {
+        // direct pipeline, per record: two ping-pong copies + ~1/4 record of bin bookkeeping
+        const uint64_t max_batch = std::max<uint64_t>(budget / ((uint64_t)NW * 8 * 2 + 8), 1);
+        nbatch = nrec ? (nrec + max_batch - 1) / max_batch : 1;
+        if (nbatch > 1) nbatch = (2 * nrec + max_batch - 1) / max_batch;  // keep half of the budget for the accumulated set + merge
     }
     void *acc = nullptr;
-    uint64_t nacc = 0;
     unsigned long long *d_cnt = nullptr;
-    if ((rc = dalloc(ctx, &d_cnt, 1, false))) {
-        drop_masks();
-        return rc;
-    }
     auto cleanup = [&](int code) {
         drop_masks();
         arena_put(ctx, d_cnt);
         if (acc && acc != ctx->d_result_buf) arena_put(ctx, acc);
+        acc = nullptr;
         return code;
     };
-    uint64_t total_inst = 0;
-    for (uint64_t bi = 0; bi < nbatch; ++bi) {
-        std::vector<std::pair<uint64_t, uint64_t>> ranges(ctx->chunks.size());
-        HIPCHK(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
-        for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
-            const uint64_t G = ctx->chunks[ci].n_bases;
-            const uint64_t words = (G + 63) / 64;
-            const uint64_t w0 = words * bi / nbatch, w1 = words * (bi + 1) / nbatch;
-            ranges[ci] = {w0 * 64, std::min<uint64_t>(w1 * 64, G)};
-            if (masks[ci] && w1 > w0) {
-                hipLaunchKernelGGL(k_count_range, dim3((unsigned)std::min<uint64_t>((w1 - w0 + BLK - 1) / BLK, 4096)), dim3(BLK), 0, ctx->stream,
-                                   (const unsigned long long *)masks[ci], w0, w1, d_cnt);
-                if (hipGetLastError() != hipSuccess) return cleanup(fail(ctx, SMX_DEVICE_ERROR, "k_count_range launch failed"));
+    for (;; nbatch = std::max<uint64_t>(2, 2 * nbatch)) {  // one trip unless the pre-dedupe output overflowed
+        if (nbatch > (1u << 16)) return cleanup(fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the distinct k-mers do not fit the HBM budget"));
+        if (nbatch <= 1) {
+            ReadSel sel;
+            sel.masks = &masks;
+            sel.nrec = nrec;
+            rc = count_selection<NW>(ctx, K, mode, B, sel);
+            if (rc == SMX_RETRY_SMALLER) {
+                free_temps(ctx);
+                clear_result(ctx);
+                continue;
             }
-        }
-        unsigned long long nw_b = 0;
-        if (hipMemcpyAsync(&nw_b, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
-            return cleanup(fail(ctx, SMX_DEVICE_ERROR, "batch window count failed"));
-        ReadSel sel;
-        sel.masks = &masks;
-        sel.ranges = &ranges;
-        sel.nrec = nw_b * rpp;
-        total_inst += sel.nrec;
-        if ((rc = count_selection<NW>(ctx, K, mode, B, sel))) return cleanup(rc);
-        void *run = ctx->d_result_buf;
-        const uint64_t nrun = ctx->n_records;
-        ctx->d_result_buf = ctx->d_result = nullptr;
-        free_temps(ctx, run);
-        if (!acc) {
-            acc = run;
-            nacc = nrun;
-            continue;
-        }
-        // fold: acc U run -> acc
-        Rec<NW> *cat;
-        if ((rc = dalloc(ctx, &cat, nacc + nrun))) {
-            arena_put(ctx, run);
             return cleanup(rc);
         }
-        hipError_t e1 = hipMemcpyAsync(cat, acc, nacc * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream);
-        hipError_t e2 = hipMemcpyAsync(cat + nacc, run, nrun * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream);
-        hipError_t e3 = hipStreamSynchronize(ctx->stream);
-        arena_put(ctx, acc);
-        arena_put(ctx, run);
-        acc = nullptr;
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return cleanup(fail(ctx, SMX_DEVICE_ERROR, "run concatenation failed"));
-        tbegin(ctx, "merge_runs");
-        tend(ctx);
-        if ((rc = run_count<NW>(ctx, K, mode, B, cat, nacc + nrun, nullptr, /*recs_reusable=*/true))) return cleanup(rc);
-        acc = ctx->d_result_buf;
-        nacc = ctx->n_records;
-        if (bi + 1 < nbatch) {
+        uint64_t nacc = 0;
+        if (!d_cnt && (rc = dalloc(ctx, &d_cnt, 1, false))) return cleanup(rc);
+        uint64_t total_inst = 0;
+        bool retry = false;
+        for (uint64_t bi = 0; bi < nbatch && !retry; ++bi) {
+            std::vector<std::pair<uint64_t, uint64_t>> ranges(ctx->chunks.size());
+            if (hipMemsetAsync(d_cnt, 0, 8, ctx->stream) != hipSuccess) return cleanup(fail(ctx, SMX_DEVICE_ERROR, "batch counter reset failed"));
+            for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
+                const uint64_t G = ctx->chunks[ci].n_bases;
+                const uint64_t words = (G + 63) / 64;
+                const uint64_t w0 = words * bi / nbatch, w1 = words * (bi + 1) / nbatch;
+                ranges[ci] = {w0 * 64, std::min<uint64_t>(w1 * 64, G)};
+                if (masks[ci] && w1 > w0) {
+                    hipLaunchKernelGGL(k_count_range, dim3((unsigned)std::min<uint64_t>((w1 - w0 + BLK - 1) / BLK, 4096)), dim3(BLK), 0, ctx->stream,
+                                       (const unsigned long long *)masks[ci], w0, w1, d_cnt);
+                    if (hipGetLastError() != hipSuccess) return cleanup(fail(ctx, SMX_DEVICE_ERROR, "k_count_range launch failed"));
+                }
+            }
+            unsigned long long nw_b = 0;
+            if (hipMemcpyAsync(&nw_b, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+                return cleanup(fail(ctx, SMX_DEVICE_ERROR, "batch window count failed"));
+            ReadSel sel;
+            sel.masks = &masks;
+            sel.ranges = &ranges;
+            sel.nrec = nw_b * rpp;
+            total_inst += sel.nrec;
+            rc = count_selection<NW>(ctx, K, mode, B, sel);
+            if (rc == SMX_RETRY_SMALLER) {
+                retry = true;
+                break;
+            }
+            if (rc) return cleanup(rc);
+            void *run = ctx->d_result_buf;
+            const uint64_t nrun = ctx->n_records;
             ctx->d_result_buf = ctx->d_result = nullptr;
-            free_temps(ctx, acc);
+            free_temps(ctx, run);
+            if (!acc) {
+                acc = run;
+                nacc = nrun;
+                continue;
+            }
+            // fold: acc U run -> acc
+            Rec<NW> *cat;
+            if ((rc = dalloc(ctx, &cat, nacc + nrun))) {
+                arena_put(ctx, run);
+                return cleanup(rc);
+            }
+            hipError_t e1 = hipMemcpyAsync(cat, acc, nacc * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream);
+            hipError_t e2 = hipMemcpyAsync(cat + nacc, run, nrun * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream);
+            hipError_t e3 = hipStreamSynchronize(ctx->stream);
+            arena_put(ctx, acc);
+            arena_put(ctx, run);
+            acc = nullptr;
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return cleanup(fail(ctx, SMX_DEVICE_ERROR, "run concatenation failed"));
+            tbegin(ctx, "merge_runs");
+            tend(ctx);
+            if ((rc = run_count<NW>(ctx, K, mode, B, cat, nacc + nrun, nullptr, /*recs_reusable=*/true))) return cleanup(rc);
+            acc = ctx->d_result_buf;
+            nacc = ctx->n_records;
+            if (bi + 1 < nbatch) {
+                ctx->d_result_buf = ctx->d_result = nullptr;
+                free_temps(ctx, acc);
+            }
         }
+        if (retry) {
+            free_temps(ctx);
+            if (acc && acc != ctx->d_result_buf) arena_put(ctx, acc);
+            acc = nullptr;
+            clear_result(ctx);
+            continue;
+        }
+        if (ctx->d_result_buf != acc) {  // a single run that was never folded: install it
+            ctx->d_result_buf = ctx->d_result = acc;
+        }
+        ctx->n_instances = total_inst;
+        acc = nullptr;
+        return cleanup(0);
     }
-    if (ctx->d_result_buf != acc) {  // last batch was the first (cannot happen for nbatch > 1) or a fold result: install it
-        ctx->d_result_buf = ctx->d_result = acc;
-    }
-    ctx->n_instances = total_inst;
-    acc = nullptr;
-    return cleanup(0);
 }
 
 int dispatch_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in) {

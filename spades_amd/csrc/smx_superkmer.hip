@@ -371,7 +371,7 @@ __device__ __forceinline__ Rec<NW> skm_extract(const uint64_t *s, unsigned j, un
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__ slots, const unsigned long long *__restrict__ slot_off,
                                                     unsigned K, uint32_t nitems, uint32_t cap, uint32_t T, uint32_t scap, void *out_,
-                                                    unsigned long long out_cap, unsigned long long *out_count,
+                                                    unsigned long long out_cap, unsigned long long clean_cap, unsigned long long dirty_cap, unsigned long long *out_count,
                                                     unsigned long long *dirty_count, unsigned long long *prof) {
     constexpr int SW = 2 * NW;
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
@@ -385,6 +385,7 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
     __shared__ uint32_t scr[BLK / 64 + 2];
     __shared__ uint32_t s_take, s_nfit, s_ninst, s_wcount, s_endb;
     __shared__ unsigned long long s_gbase;
+    __shared__ uint32_t s_skip;  // the output buffer is full: the counters keep counting (the host sees the overflow), nothing is written
     Rec<NW> *out = (Rec<NW> *)out_;
     const unsigned lane = threadIdx.x & 63;
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;  // SMX_DEBUG: 100 MHz ticks per phase seen by thread 0
@@ -502,12 +503,19 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
             const bool dirty = !on_boundary || !s_endb;
             on_boundary = s_endb != 0;
             if (threadIdx.x == 0) {
+                s_skip = 0;
                 if (!wcount) s_gbase = 0;
-                else if (!dirty) s_gbase = atomicAdd(out_count, (unsigned long long)wcount);
-                else s_gbase = out_cap - atomicAdd(dirty_count, (unsigned long long)wcount) - wcount;
+                else if (!dirty) {
+                    s_gbase = atomicAdd(out_count, (unsigned long long)wcount);
+                    s_skip = s_gbase + wcount > clean_cap;
+                } else {
+                    const unsigned long long d = atomicAdd(dirty_count, (unsigned long long)wcount);
+                    s_skip = d + wcount > dirty_cap;
+                    s_gbase = s_skip ? 0 : out_cap - d - wcount;
+                }
             }
             __syncthreads();
-            {
+            if (!s_skip) {
                 Rec<NW> *dst = out + s_gbase;
                 for (uint32_t i = threadIdx.x; i < wcount; i += BLK) {
                     const uint32_t code = wl[i];

@@ -27,7 +27,7 @@ def _nodes(unitigs, k):
             c = min(km, _rc(km))
             r = ids.setdefault(c, len(ids))
             arr.append(2 * r + (0 if km == c else 1))
-    return np.array(st, dtype=np.uint32), np.array(en, dtype=np.uint32)
+    return np.array(st, dtype=np.uint64), np.array(en, dtype=np.uint64)
 
 
 def _write(unitigs, k, fmt, path, cov=None, sort_edges=0):
@@ -38,7 +38,7 @@ def _write(unitigs, k, fmt, path, cov=None, sort_edges=0):
     st, en = _nodes(unitigs, k)
     covp = cov.ctypes.data_as(C.POINTER(C.c_uint32)) if cov is not None else None
     rc = lib.smx_host_write_graph(k, len(unitigs), off.ctypes.data_as(C.POINTER(C.c_uint64)), "".join(unitigs).encode(),
-                                  st.ctypes.data_as(C.POINTER(C.c_uint32)), en.ctypes.data_as(C.POINTER(C.c_uint32)), covp,
+                                  st.ctypes.data_as(C.POINTER(C.c_uint64)), en.ctypes.data_as(C.POINTER(C.c_uint64)), covp,
                                   sort_edges, fmt, path.encode(), b"SPAdes-4.3.0-dev")
     assert rc == 0
 

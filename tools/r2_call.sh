@@ -1,0 +1,13 @@
+#!/bin/bash
+# generic round-2 GPU call: $1 = tag, rest = what to run (tests | probe args...)
+tag=$1; shift
+mkdir -p gpurun_out/$tag; exec > gpurun_out/$tag/log.txt 2>&1
+for step in "$@"; do
+  case $step in
+    tests) timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ;;
+    g10) SMX_DEBUG=1 timeout 600 python tools/scale_probe.py 10e6 50e6 graph 2>&1 | grep -v "big leaf\|^\[smx\] \(mark+alloc\|level1\|levels2+\|leaf sort\|compact\|leaves\|skm_scan\|dedupe\|prededupe\)" ;;
+    g100) SMX_DEBUG=1 timeout 900 python tools/scale_probe.py 100e6 500e6 graph 2>&1 | grep -v "big leaf\|^\[smx\] \(mark+alloc\|level1\|levels2+\|leaf sort\|compact\|leaves\|skm_scan\|dedupe\)" ;;
+    c100) SMX_DEBUG=1 timeout 900 python tools/scale_probe.py 100e6 500e6 count 2>&1 | grep -v "big leaf\|^\[smx\] \(mark+alloc\|level1\|levels2+\|leaf sort\|compact\|leaves\|skm_scan\|dedupe\)" ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
