@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: M reads/s k-mer-counted (k=55, PE150) on N x MI355X.
 
-One step = one pass of the whole hot path (mark -> extract+XXH3 bucket -> MSD partition ->
-leaf sort/unique -> compact) over one synthetic batch that is already resident in HBM.
-N=1 : smx_count on the batch.  N>1 : every rank counts its own read shard, records are
-redistributed by bucket owner with ONE RCCL all-to-all, owners sort/unique.
-Rank 0 prints ONE JSON line (contract in the task statement). cpu_baseline (rank 0, N=1 only)
-times the reference's own classes (oracle/_ref/ref_kmercount) on a bounded sample of the SAME reads.
+N = 1 (default): BASELINE.json config 3 — synthetic 100 M PE150 reads, k=55: ONE step = packed reads in page-locked host memory ->
+HBM (the upload is inside the timed region) -> canonical (k+1)-mers counted (160 buckets = -t 16) -> de Bruijn construction
+(k-mer file, extension masks, unitigs, link records + vertices; the graph is resident in HBM when the step ends).
+N > 1: BASELINE.json config 4 shape — every rank counts the canonical (k+1)-mers of its own 100 M reads, records are
+redistributed by bucket owner with ONE RCCL all-to-all, owners sort/unique. The construction of a graph whose
+k-mer file is spread over the ranks is not part of the N > 1 step. `python bench.py --gpus N` spawns the N ranks itself
+when it was not started by a launcher.
+Rank 0 prints ONE JSON line (contract in the task statement). cpu_baseline (rank 0, N=1 only) times the reference's own classes
+(oracle/_ref: KMerDiskCounter for the count, + extension index + UnbranchingPathExtractor for the construction) on all host cores on
+a bounded sample of the SAME reads and compares their output with the GPU's for that sample.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -19,15 +24,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402  (device memory, streams, torch.distributed: plumbing only)
+import torch  # noqa: E402  (device memory for the generator, pinned host buffers, torch.distributed: plumbing only)
 
 L = 150
 INSERT = 350
 
 
-def synth_reads_device(seed, genome_len, n_reads, dev, err=0.01, genome_seed=2):
-    """SURVEY.md §8d generator on the GPU: iid genome, PE150 pairs (read2 = RC of the far end), 1 % substitutions.
-    Returns (words int64[n_words+8], start int64[n], len int32[n], codes uint8[n, L])."""
+def synth_reads_device(seed, genome_len, n_reads, dev, err=0.01, genome_seed=2, n_rate=0.0):
+    """SURVEY.md §8d generator on the GPU: iid genome, PE150 pairs (read2 = RC of the far end), 1 % substitutions, n_rate N's
+    (each read is then cut to its longest ACGT run, first one on ties — io::LongestValid — by choosing (start, len)).
+    Returns (words int64[n_words+8], start int64[n], len int32[n], codes uint8[n, L] with 4 = N)."""
     assert n_reads % 32 == 0
     gg = torch.Generator(device=dev)
     gg.manual_seed(genome_seed)
@@ -43,92 +49,182 @@ def synth_reads_device(seed, genome_len, n_reads, dev, err=0.01, genome_seed=2):
         p = torch.randint(0, genome_len - INSERT + 1, (c1 - c0,), device=dev, generator=g)
         codes[2 * c0:2 * c1:2] = genome[p[:, None] + idx[None, :]]
         codes[2 * c0 + 1:2 * c1:2] = 3 - genome[(p + INSERT - 1)[:, None] - idx[None, :]]
+    del genome
+    start = torch.arange(n_reads, device=dev, dtype=torch.int64) * L
+    ln = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
     for c0 in range(0, n_reads, 1 << 20):
         blk = codes[c0:c0 + (1 << 20)]
-        e = torch.rand(blk.shape, device=dev, generator=g) < err
+        x = torch.rand(blk.shape, device=dev, generator=g)
         sub = torch.randint(1, 4, blk.shape, dtype=torch.uint8, device=dev, generator=g)
-        blk[:] = torch.where(e, (blk + sub) % 4, blk)
+        blk[:] = torch.where(x < err, (blk + sub) % 4, blk)
+        if n_rate > 0:
+            isn = (x >= err) & (x < err + n_rate)
+            blk[isn] = 4
+            pos = idx[None, :].expand(blk.shape)
+            last_bad = torch.cummax(torch.where(isn, pos, torch.full_like(pos, -1)), dim=1).values
+            run = pos - last_bad  # length of the ACGT run ending here (0 on an N)
+            best = run.max(dim=1)
+            end = torch.argmax(run, dim=1)  # first position where the maximum is reached = end of the first longest run
+            start[c0:c0 + blk.shape[0]] += (end - best.values + 1)
+            ln[c0:c0 + blk.shape[0]] = best.values.to(torch.int32)
     flat = codes.reshape(-1, 32)
     shifts = (2 * torch.arange(32, device=dev, dtype=torch.int64))[None, :]
     words = torch.zeros(flat.shape[0] + 8, dtype=torch.int64, device=dev)
     for c0 in range(0, flat.shape[0], 1 << 22):
-        part = (flat[c0:c0 + (1 << 22)].to(torch.int64) << shifts).sum(dim=1)
+        part = ((flat[c0:c0 + (1 << 22)] & 3).to(torch.int64) << shifts).sum(dim=1)
         words[c0:c0 + part.numel()] = part
-    start = torch.arange(n_reads, device=dev, dtype=torch.int64) * L
-    ln = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
     return words, start, ln, codes
 
 
-def cpu_baseline(codes_sample, K, mode, nb, gpu_result=None):
-    """Reference classes (kind 'reference') when oracle/_ref exists, else the C port (kind 'port').
-    gpu_result(n) -> (device int64 tensor [D, nw], bucket sizes) of the GPU count of the same first n reads: when given, the
+def _reads_file(codes_sample, path):
+    import numpy as np
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    arr = lut[codes_sample.cpu().numpy()]
+    with open(path, "wb") as f:
+        f.write(b"\n".join(r.tobytes() for r in arr) + b"\n")
+    return arr.shape[0]
+
+
+def _cpu_info():
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def cpu_baseline_count(codes_sample, K, mode, nb, gpu_result=None, runs=3):
+    """Reference classes (oracle/_ref/ref_kmercount = KMerDiskCounter & co. compiled from /root/reference) on ALL host cores, tmpfs
+    workdir, median of `runs`. gpu_result(n) -> device int64 tensor [D, nw] of the GPU count of the same first n reads: the
     reference's output file is compared with it byte for byte (the checker role of oracle/_ref)."""
     import numpy as np
-    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
-    arr = lut[codes_sample.cpu().numpy()]
-    n = arr.shape[0]
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_kmercount")
-    if os.path.exists(ref):
-        cores = max(1, min(os.cpu_count() or 1, 64))
-        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
-            rf = os.path.join(td, "reads.txt")
-            with open(rf, "wb") as f:
-                f.write(b"\n".join(r.tobytes() for r in arr) + b"\n")
+    model, cores = _cpu_info()
+    if not os.path.exists(ref):
+        from oracle import oracle
+        lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+        reads = [r.tobytes().decode() for r in lut[codes_sample[:50000].cpu().numpy()]]
+        t0 = time.time()
+        oracle.count(reads, K, mode, nb)
+        dt = time.time() - t0
+        return {"value": round(len(reads) / dt / 1e6, 4), "unit": "M reads/s", "cores": 1, "kind": "port", "cpu": model,
+                "sample": f"first {len(reads)} reads of the bench batch, oracle/smx_oracle.c, {dt:.1f} s"}
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        rf = os.path.join(td, "reads.txt")
+        n = _reads_file(codes_sample, rf)
+        times = []
+        for it in range(runs):
             t0 = time.time()
-            subprocess.check_call([ref, mode, str(K), str(nb), "0", rf, os.path.join(td, "wd"), os.path.join(td, "out"), str(cores)],
+            subprocess.check_call([ref, mode, str(K), str(nb), "0", rf, os.path.join(td, f"wd{it}"), os.path.join(td, "out"), str(cores)],
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            dt = time.time() - t0
-            parity = None
-            if gpu_result is not None:
-                import torch
-                rec = gpu_result(n).reshape(-1)  # int64 words on the device, the GPU's final_kmers of the same reads
-                out = os.path.join(td, "out")
-                same = os.path.getsize(out) == rec.numel() * 8
-                CH = 1 << 25  # words per compared chunk (256 MiB)
-                with open(out, "rb") as f:
-                    for c0 in range(0, rec.numel(), CH):
-                        if not same:
-                            break
-                        ref_chunk = torch.from_numpy(np.fromfile(f, dtype=np.int64, count=min(CH, rec.numel() - c0))).to(rec.device)
-                        same = bool(torch.equal(ref_chunk, rec[c0:c0 + ref_chunk.numel()]))
-                parity = {"bit_identical_to_reference_output": same, "compared_bytes": int(rec.numel() * 8)}
-        res = {"value": round(n / dt / 1e6, 4), "unit": "M reads/s", "cores": cores, "kind": "reference",
-               "sample": f"first {n} reads of the bench batch, oracle/_ref/ref_kmercount (reference KMerDiskCounter, tmpfs workdir), {dt:.1f} s"}
-        if parity:
-            res.update(parity)
-        return res
-    from oracle import oracle
-    reads = [r.tobytes().decode() for r in arr[:50000]]
-    t0 = time.time()
-    oracle.count(reads, K, mode, nb)
-    dt = time.time() - t0
-    return {"value": round(len(reads) / dt / 1e6, 4), "unit": "M reads/s", "cores": 1, "kind": "port",
-            "sample": f"first {len(reads)} reads of the bench batch, oracle/smx_oracle.c, {dt:.1f} s"}
+            times.append(time.time() - t0)
+            subprocess.call(["rm", "-rf", os.path.join(td, f"wd{it}")])
+        dt = sorted(times)[len(times) // 2]
+        parity = None
+        if gpu_result is not None:
+            rec = gpu_result(n).reshape(-1)  # int64 words on the device, the GPU's final_kmers of the same reads
+            out = os.path.join(td, "out")
+            same = os.path.getsize(out) == rec.numel() * 8
+            CH = 1 << 25  # words per compared chunk (256 MiB)
+            with open(out, "rb") as f:
+                for c0 in range(0, rec.numel(), CH):
+                    if not same:
+                        break
+                    ref_chunk = torch.from_numpy(np.fromfile(f, dtype=np.int64, count=min(CH, rec.numel() - c0))).to(rec.device)
+                    same = bool(torch.equal(ref_chunk, rec[c0:c0 + ref_chunk.numel()]))
+            parity = {"bit_identical_to_reference_output": same, "compared_bytes": int(rec.numel() * 8)}
+    res = {"value": round(n / dt / 1e6, 4), "unit": "M reads/s", "cores": cores, "cpu": model, "kind": "reference",
+           "sample": f"first {n} reads of the bench batch, oracle/_ref/ref_kmercount (reference KMerDiskCounter, mode {mode}, K={K}, {nb} buckets, "
+                     f"tmpfs workdir), median of {runs} runs = {dt:.1f} s"}
+    if parity:
+        res.update(parity)
+    return res
+
+
+def cpu_baseline_construct(codes_sample, k, gpu_unitigs=None):
+    """The reference's construction classes on ALL host cores (oracle/_ref/ref_earlytip: KMerDiskCounter -> DeBruijnExtensionIndexBuilder
+    -> UnbranchingPathExtractor::ExtractUnbranchingPathsAndLoops, 10 x cores buckets). gpu_unitigs(n, threads) -> list of the GPU's
+    unitigs for the same reads and bucket count: compared as multisets (the reference's edge order is thread-schedule dependent)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_earlytip")
+    if not os.path.exists(ref):
+        return None
+    model, cores = _cpu_info()
+    threads = min(cores, 400)  # 10 x threads buckets <= 4096 (level-1 fan-out limit of the GPU path that checks the result)
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        rf = os.path.join(td, "reads.txt")
+        n = _reads_file(codes_sample, rf)
+        t0 = time.time()
+        subprocess.check_call([ref, str(k), str(threads), "0", rf, os.path.join(td, "wd"), os.path.join(td, "out.txt")],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.time() - t0
+        res = {"value": round(n / dt / 1e6, 4), "unit": "M reads/s", "cores": cores, "cpu": model, "kind": "reference",
+               "sample": f"first {n} reads of the bench batch, oracle/_ref/ref_earlytip (reference KMerDiskCounter + extension index + "
+                         f"UnbranchingPathExtractor, {10 * threads} buckets, {threads} threads, tmpfs workdir), one run = {dt:.1f} s"}
+        if gpu_unitigs is not None:
+            with open(os.path.join(td, "out.txt"), "rb") as f:
+                ref_u = f.read().split(b"\n")
+            if ref_u and ref_u[-1] == b"":
+                ref_u.pop()
+            got = gpu_unitigs(n, threads)
+            ref_u.sort()
+            got.sort()
+            h1, h2 = hashlib.md5(), hashlib.md5()
+            for u in ref_u:
+                h1.update(u + b"\n")
+            for u in got:
+                h2.update(u + b"\n")
+            res.update({"unitig_multiset_identical_to_reference": h1.digest() == h2.digest(), "compared_unitigs": len(ref_u)})
+    return res
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) and relay rank 0's line."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but only {n_dev} GPU(s) are visible")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    raise SystemExit(rc)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=float, default=10e6, help="reads per GPU (weak scaling)")
+    ap.add_argument("--reads", type=float, default=100e6, help="reads per GPU (weak scaling)")
     ap.add_argument("--k", type=int, default=55)
-    ap.add_argument("--mode", default="A", choices=["A", "B"])
-    ap.add_argument("--buckets", type=int, default=16)
-    ap.add_argument("--genome", type=float, default=50e6)
-    ap.add_argument("--cpu-sample", type=float, default=4e6, help="reads timed on the host with the reference classes (~10-15 s)")
+    ap.add_argument("--threads", type=int, default=16, help="the reference's -t that the output order reproduces: 10 x threads buckets")
+    ap.add_argument("--genome", type=float, default=500e6)
+    ap.add_argument("--n-rate", type=float, default=0.001)
+    ap.add_argument("--count-only", action="store_true", help="N=1: time the (k+1)-mer count alone (no construction)")
+    ap.add_argument("--cpu-sample", type=float, default=2e6, help="reads timed on the host with the reference classes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--construct-reads", type=float, default=2e6,
-                    help="extra (untimed for the headline): de Bruijn construction (k=55, -t 16, -c) on this many reads; 0 disables")
-    ap.add_argument("--construct-sharded", action="store_true",
-                    help="with N>1 (or --force-sharded): also time spades_amd.dist.sharded_build_graph on --construct-reads reads per rank")
+    ap.add_argument("--extra-kmercount", type=float, default=10e6,
+                    help="extra (untimed for the headline): spades-kmercount mode (all k-mers of read + RC, 16 buckets) on this many reads; 0 disables")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (there is no CPU fallback)")
@@ -140,29 +236,50 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != world:
+            raise SystemExit(f"RCCL reports world size {dist.get_world_size()}, expected {world}")
 
     from spades_amd import KMerDiskCounter, ReadKMerSplitter
     from spades_amd.kmercount import Context
+    from spades_amd.gbuilder import GraphBuilder
     from spades_amd import dist as smx_dist
 
     n_reads = int(args.reads) // 32 * 32
-    K, nb = args.k, args.buckets
-    nw = (K + 31) // 32
-    words, start, ln, codes = synth_reads_device(1000 + rank, int(args.genome), n_reads, dev)
-    sample = codes[:int(min(args.cpu_sample, n_reads))].clone() if rank == 0 else None
+    k, T = args.k, args.threads
+    K1, nb = k + 1, 10 * T
+    nw = (K1 + 31) // 32
+    W = 8 * nw
+    words, start, ln, codes = synth_reads_device(1000 + rank, int(args.genome), n_reads, dev, n_rate=args.n_rate)
+    n_sample = int(min(args.cpu_sample, n_reads)) // 32 * 32
+    sample = codes[:n_sample].clone() if rank == 0 else None
     del codes
+    # the batch waits in page-locked host memory ("packed read batches resident in pinned host memory")
+    h_words, h_start, h_len = words.cpu().pin_memory(), start.cpu().pin_memory(), ln.cpu().pin_memory()
+    if not sharded:
+        del words, start, ln
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    hw, hs, hl = h_words.numpy().view("uint64"), h_start.numpy().view("uint64"), h_len.numpy().view("uint32")
 
     ctx = Context(device=local_rank)
-    sp = ReadKMerSplitter(K, args.mode, ctx)
-    sp.push_back_device(words.data_ptr(), words.numel() - 8, start.data_ptr(), ln.data_ptr(), n_reads)
-    counter = KMerDiskCounter(None, sp)
-    engine = smx_dist.GpuEngine(ctx, args.mode) if sharded else None
+    gb = GraphBuilder(k, T, ctx)
+    engine = None
+    if sharded:
+        gb.push_back_device(words.data_ptr(), words.numel() - 8, start.data_ptr(), ln.data_ptr(), n_reads)
+        engine = smx_dist.GpuEngine(ctx, "B")
+
+    last = {}
 
     def step():
-        if not sharded:
-            return counter.Count(nb)
-        return smx_dist.sharded_count(engine, K, nb, rank, world, dev)
+        if sharded:
+            last["st"] = smx_dist.sharded_count(engine, K1, nb, rank, world, dev)
+            return
+        gb.reads.clear()
+        gb.reads.push_back_packed(hw[:-8], hs, hl)  # H2D inside the step
+        if args.count_only:
+            last["st"] = KMerDiskCounter(None, gb.reads).Count(nb)
+        else:
+            last["info"] = gb.build()
 
     def sync():
         torch.cuda.synchronize()
@@ -170,16 +287,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # setup (not a step of the measurement): let the library's device arena and torch's caching allocator reach their steady-state
-    # footprint — the first passes hipMalloc tens of GB, which stalls for tens of ms each
-    for _ in range(2 if sharded else 1):
-        st = step()
+    # setup (not a step of the measurement): the library's device arena maps its physical memory the first time an address is used
+    # (~17 ms per GiB, once per context): one untimed pass brings it to its steady-state footprint
+    step()
     for _ in range(args.warmup):
-        st = step()
+        step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        st = step()
+        step()
     sync()
     dt = time.perf_counter() - t0
     if sharded:
@@ -190,104 +306,120 @@ def main():
     total_reads = n_reads * world
     value = total_reads / (dt / args.steps) / 1e6
 
-    # ---- roofline of the counting pipeline (this rank), SURVEY.md §8d: B_alg = N*L/4 + 2*I*W + D*W ----
-    tm = ctx.timings()
-    kernel_ms = sum(ms for _, ms in tm)
-    inst = st.kmer_instances() if not sharded else st["instances"]
-    distinct = st.total_kmers() if not sharded else st["distinct"]
-    W = 8 * nw
-    b_alg = n_reads * L / 4 + 2 * inst * W + distinct * W
-    achieved = b_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # ---- stage times of the last step (HIP events on the library's stream) and roofline figures ----
     stages = {}
-    for name, ms in tm:  # a stage name repeats when the pipeline runs more than once (batches, the cut-key pass)
+    for name, ms in ctx.timings():  # a stage name repeats when the pipeline runs more than once
         stages[name] = stages.get(name, 0.0) + ms
+    count_ms = sum(ms for n_, ms in stages.items() if ":" not in n_ and n_ not in
+                   ("rank_dir", "fill_masks", "candidates", "walk_len", "keep", "walk_write", "derive_hist", "derive_kmers", "succ", "early_at", "early_tips"))
+    construct_ms = sum(stages.values()) - count_ms
+    if sharded:
+        inst, D1 = last["st"]["instances"], last["st"]["distinct"]
+        info = None
+    elif args.count_only:
+        inst, D1 = last["st"].kmer_instances(), last["st"].total_kmers()
+        info = None
+    else:
+        info = last["info"]
+        D1 = info["n_kpomers"]
+        icnt = os.environ.get("SMX_BENCH_INST")
+        inst = int(icnt) if icnt else int((torch.from_numpy(h_len.numpy().astype("int64")) - K1 + 1).clamp(min=0).sum().item())
+    # B_alg(count) = N*L/4 + 2*I*W + D*W
+    b_count = n_reads * L / 4 + 2 * inst * W + D1 * W
+    roof_count = {"bound": "hbm", "achieved": round(b_count / max(count_ms, 1e-9) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                  "frac": round(b_count / max(count_ms, 1e-9) / 1e6 / 8000.0, 4), "traffic": None,
+                  "kernel": "counting pipeline of the canonical (k+1)-mers (sum of its stage kernels, HIP events on the library stream)",
+                  "algorithmic_bytes_per_step": int(b_count), "kernel_ms_per_step": round(count_ms, 3)}
     dom = max(stages.items(), key=lambda x: x[1]) if stages else ("", 0.0)
-    # HBM traffic per step from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, FETCH x2
-    # gfx950 correction: profiles/r01/bench_k55A_10M_pmc_hbm_traffic.csv). Only valid for the workload it was taken on.
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "bench_k55A_10M_pmc_hbm_traffic.csv")
-    if not sharded and K == 55 and args.mode == "A" and n_reads == 10_000_000 and nb == 16 and os.path.exists(pmc):
-        for line in open(pmc):
-            if line.startswith("TOTAL"):
-                f = line.strip().split(",")
-                traffic = round(float(f[3]) + float(f[5]), 1)
-    # per-stage view: algorithmic GB a stage has to move / its measured time. Behind the pre-dedupe stage the sort
-    # pipeline sees Dc = D/2 canonical records in and n2 = D (mode A) or D (mode B: Dc = D) records through its levels.
-    n2 = float(distinct)
-    dc = n2 / 2 if args.mode == "A" else n2
-    slots_b = inst / (2 if args.mode == "A" else 1) * 1.3  # ~1.3 B per canonical instance in super-k-mer slots (k=55)
-    alg = {"skm_count": n_reads * L / 4, "skm_scatter": n_reads * L / 4 + slots_b, "skm_dedupe": slots_b + dc * W,
-           "l1_hist": dc * W, "l1_scatter": dc * W + n2 * W, "l2_hist": n2 * W, "l2_scatter": 2 * n2 * W, "l3_hist": n2 * W,
-           "l3_scatter": 2 * n2 * W, "sort_unique": 2 * n2 * W}
-    stage_roofline = {}
-    if "skm_dedupe" in stages:
-        for name, b in alg.items():
-            if stages.get(name, 0) > 0.05:
-                stage_roofline[name] = {"alg_GB": round(b / 1e9, 2), "ms": round(stages[name], 3),
-                                        "TBps": round(b / (stages[name] * 1e-3) / 1e12, 2), "frac": round(b / (stages[name] * 1e-3) / 8e12, 3)}
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_unit": "GB per step (PMC, profiles/r01)",
-                "kernel": "smx_count pipeline (sum of stage kernels, HIP events on the library stream)",
-                "algorithmic_bytes_per_step": int(b_alg), "kernel_ms_per_step": round(kernel_ms, 3),
-                "dominant_stage": dom[0], "dominant_stage_ms": round(dom[1], 3),
-                "stages_ms": {n: round(ms, 3) for n, ms in stages.items()}, "stage_roofline": stage_roofline}
+    roof_count["dominant_stage"] = dom[0]
+    roof_count["dominant_stage_ms"] = round(dom[1], 3)
+    roof_count["stages_ms"] = {n_: round(ms, 3) for n_, ms in stages.items()}
 
     out = {
-        "metric": "M reads/sec k-mer-counted (k=55, PE150)" if K == 55 else f"M reads/sec k-mer-counted (k={K}, PE150)",
+        "metric": f"M reads/sec k-mer-counted (k={k}, PE150)",
         "value": round(value, 3), "unit": "M reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"synthetic {n_reads / 1e6:g} M PE150 reads per GPU (genome {args.genome / 1e6:g} Mbp iid, 1% subst.), "
-                               f"k={K}, mode {args.mode} ({'spades-kmercount: all k-mers of read+RC' if args.mode == 'A' else 'construction: canonical (k)-mers'}), "
-                               f"{nb} buckets, inputs resident in HBM",
-                   "reads_per_gpu": n_reads, "k": K, "mode": args.mode, "num_buckets": nb,
-                   "kmer_instances": int(inst), "distinct_kmers": int(distinct),
-                   "parallelism": "1 GPU" if not sharded else f"{world} GPU(s), bucket-range owners, one RCCL all-to-all"},
-        "roofline": roofline,
+        "config": {"workload": (f"BASELINE config 3: synthetic {n_reads / 1e6:g} M PE150 reads (genome {args.genome / 1e6:g} Mbp iid, 1% subst., "
+                                f"{args.n_rate * 100:g}% N), k={k}: upload from page-locked host memory + count of the canonical {K1}-mers "
+                                f"({nb} buckets = -t {T})" + ("" if args.count_only else " + de Bruijn construction (k-mer file, extension masks, "
+                                "unitigs, link records + vertices; graph resident in HBM)")) if not sharded else
+                               (f"BASELINE config 4 shape: {n_reads / 1e6:g} M PE150 reads per GPU, k={k}: sharded count of the canonical {K1}-mers "
+                                f"({nb} buckets, bucket-range owners, one RCCL all-to-all); inputs resident in HBM; no construction in the N>1 step"),
+                   "reads_per_gpu": n_reads, "k": k, "num_buckets": nb, "kmer_instances": int(inst), "distinct_kpomers": int(D1),
+                   "h2d_in_timed_region": not sharded, "construct_in_metric": (not sharded and not args.count_only),
+                   "parallelism": "1 GPU" if not sharded else f"{world} GPU(s), bucket-range owners, one RCCL all-to-all (RCCL world size {world})"},
+        "roofline": roof_count,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_sharded:
-        def gpu_result(n):  # GPU count of the first n reads of the batch (they are the first n*L bases of the stream)
-            class Wrap:
-                def __init__(self, ptr, shape):
-                    self.__cuda_array_interface__ = {"shape": shape, "typestr": "<i8", "data": (ptr, False), "version": 2}
-            sp.clear()
-            sp.push_back_device(words.data_ptr(), n * L // 32, start.data_ptr(), ln.data_ptr(), n)
-            stn = counter.Count(nb)
-            return torch.as_tensor(Wrap(stn.device_ptr(), (stn.total_kmers(), nw)), device=dev)
-        out["cpu_baseline"] = cpu_baseline(sample, K, args.mode, nb, gpu_result if sample.shape[0] % 32 == 0 else None)
-    if rank == 0 and world == 1 and args.construct_reads > 0 and not args.force_sharded:
-        # BASELINE.json config 3 in small: count + construct + coverage on the first reads of the same batch (reported, not the metric)
-        from spades_amd.gbuilder import GraphBuilder
-        nc = int(min(args.construct_reads, n_reads)) // 32 * 32
-        gb = GraphBuilder(55, 16, ctx)
-        sp.clear()
-        gb.push_back_device(words.data_ptr(), nc * L // 32, start.data_ptr(), ln.data_ptr(), nc)
-        gb.build()  # warm-up (arena growth)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        info = gb.build()
-        t1 = time.perf_counter()
-        gb.fill_coverage()
-        t2 = time.perf_counter()
-        out["construct"] = {"workload": f"first {nc} reads, k=55, 160 buckets (-t 16): canonical 56-mers -> 55-mers -> masks -> unitigs -> links",
-                            "reads": nc, "build_s": round(t1 - t0, 4), "coverage_s": round(t2 - t1, 4),
-                            "M_reads_per_s": round(nc / (t1 - t0) / 1e6, 3), "n_kpomers": int(info["n_kpomers"]),
-                            "n_kmers": int(info["n_kmers"]), "n_unitigs": int(info["n_unitigs"]), "n_vertices": int(info["n_vertices"])}
-    if sharded and args.construct_sharded and args.construct_reads > 0:
-        # multi-GPU construction (collective): sharded (k+1)-mer count -> gather -> replicated build -> all-reduced coverage
-        nc = int(min(args.construct_reads, n_reads)) // 32 * 32
-        sp.clear()
-        sp.push_back_device(words.data_ptr(), nc * L // 32, start.data_ptr(), ln.data_ptr(), nc)
-        geng = smx_dist.GpuEngine(ctx, "B")
-        smx_dist.sharded_build_graph(geng, 55, 16, rank, world, dev, coverage=True)  # warm-up
-        sync()
-        t0 = time.perf_counter()
-        info = smx_dist.sharded_build_graph(geng, 55, 16, rank, world, dev, coverage=True)
-        sync()
-        t1 = time.perf_counter()
-        out["construct_sharded"] = {"workload": f"{nc} reads per rank x {world} ranks, k=55, 160 buckets, -c; replicated graph on every rank",
-                                    "seconds": round(t1 - t0, 4), "M_reads_per_s": round(nc * world / (t1 - t0) / 1e6, 3),
-                                    "n_kpomers": int(info["n_kpomers"]), "n_unitigs": int(info["n_unitigs"])}
+    if info is not None:
+        D0, ne, nbases = info["n_kmers"], info["n_unitigs"], info["unitig_bases"]
+        # algorithmic bytes of the construction: k-mer file = read the (k+1)-mers, write + read the 2 derived k-mers each,
+        # write the file; masks + successors = read the (k+1)-mers, 2 k-mer records looked up, 2 mask bytes and 2 successor entries
+        # written; walks = successor + mask of every node read twice (length pass, write pass of the kept half: 1.5x), unitigs written
+        # 2 bits per base; links = 2 records of 16 B per edge written, sorted (read + write), read.
+        b_con = D1 * W + 2 * (2 * D1 * W) + D0 * W + D1 * W + 2 * D1 * W + 2 * D1 * (1 + 8) + 1.5 * 2 * D0 * 9 + nbases / 4 + 4 * 2 * ne * 16
+        out["construct"] = {"n_kpomers": int(D1), "n_kmers": int(D0), "n_unitigs": int(ne), "n_vertices": int(info["n_vertices"]),
+                            "unitig_bases": int(nbases),
+                            "roofline": {"bound": "hbm", "achieved": round(b_con / max(construct_ms, 1e-9) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                                         "frac": round(b_con / max(construct_ms, 1e-9) / 1e6 / 8000.0, 4), "traffic": None,
+                                         "kernel": "construction (k-mer file, rank directory, masks + successors, walks, link records): sum of its stage kernels",
+                                         "algorithmic_bytes_per_step": int(b_con), "kernel_ms_per_step": round(construct_ms, 3)}}
+        out["step_breakdown_ms"] = {"count_kernels": round(count_ms, 1), "construct_kernels": round(construct_ms, 1),
+                                    "host_and_upload": round(ms_per_step - count_ms - construct_ms, 1)}
+    if rank == 0 and world == 1 and not args.force_sharded:
+        class Wrap:
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": "<i8", "data": (ptr, False), "version": 2}
+        # full-size parity properties of the timed result (size-independent): see tools/verify_scale.py for the complete set
+        if info is not None:
+            out["construct"]["checks"] = {"unitigs_plus_loops": int(info["n_unitigs"]), "perfect_loops": int(info["n_loops"])}
+        if not args.no_cpu_baseline and n_sample:
+            hw_s = hw[:n_sample * L // 32 + 8]
+
+            def gpu_count(n):  # GPU count of the first n reads of the batch (they are the first n*L bases of the stream)
+                sp = ReadKMerSplitter(K1, "B", ctx)
+                sp.clear()
+                sp.push_back_packed(hw_s[:n * L // 32], hs[:n], hl[:n])
+                stn = KMerDiskCounter(None, sp).Count(nb)
+                return torch.as_tensor(Wrap(stn.device_ptr(), (stn.total_kmers(), nw)), device=dev)
+
+            def gpu_unitigs(n, threads):
+                g2 = GraphBuilder(k, threads, ctx)
+                g2.reads.clear()
+                g2.reads.push_back_packed(hw_s[:n * L // 32], hs[:n], hl[:n])
+                g2.build()
+                return [u.encode() for u in g2.unitigs()]
+
+            out["cpu_baseline"] = cpu_baseline_count(sample, K1, "B", nb, gpu_count)
+            if not args.count_only:
+                cb = cpu_baseline_construct(sample, k, gpu_unitigs)
+                if cb:
+                    out["cpu_baseline"]["construct"] = cb
+        if args.extra_kmercount > 0:
+            # BASELINE config 2 shape at k=55 (the round-1 headline, kept for continuity): spades-kmercount mode, inputs resident in HBM
+            ne_ = int(min(args.extra_kmercount, n_reads)) // 32 * 32
+            w2 = torch.from_numpy(hw[:ne_ * L // 32 + 8].view("int64")).to(dev)
+            s2 = torch.from_numpy(hs[:ne_].view("int64")).to(dev)
+            l2 = torch.from_numpy(hl[:ne_].view("int32")).to(dev)
+            spa = ReadKMerSplitter(k, "A", ctx)
+            spa.clear()
+            spa.push_back_device(w2.data_ptr(), w2.numel() - 8, s2.data_ptr(), l2.data_ptr(), ne_)
+            ca = KMerDiskCounter(None, spa)
+            ca.Count(16)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                sta = ca.Count(16)
+            torch.cuda.synchronize()
+            dta = (time.perf_counter() - t1) / 5
+            tma = sum(ms for _, ms in ctx.timings())
+            ia, da = sta.kmer_instances(), sta.total_kmers()
+            Wa = 8 * ((k + 31) // 32)
+            ba = ne_ * L / 4 + 2 * ia * Wa + da * Wa
+            out["kmercount_mode"] = {"workload": f"first {ne_} reads, k={k}, all k-mers of read + RC (spades-kmercount), 16 buckets, inputs resident in HBM",
+                                     "M_reads_per_s": round(ne_ / dta / 1e6, 2), "ms_per_step": round(dta * 1e3, 3), "kernel_ms": round(tma, 3),
+                                     "kmer_instances": int(ia), "distinct_kmers": int(da),
+                                     "roofline_frac": round(ba / max(tma, 1e-9) / 1e6 / 8000.0, 4)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <ctime>
 #include <cstdlib>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -116,25 +117,39 @@ int smx_submit_reads_packed(smx_ctx *ctx, const uint64_t *words, uint64_t n_word
     if (!ctx) return SMX_INVALID_PARAMETER;
     if (n_reads == 0) return SMX_OK;
     if (!words || !start || !len) return fail(ctx, SMX_INVALID_PARAMETER, "null read arrays");
-    uint64_t nb = 0;
-    for (uint64_t i = 0; i < n_reads; ++i) {
-        uint64_t e = start[i] + len[i];
-        if (e > n_words * 32) return fail(ctx, SMX_INVALID_INPUT_FORMAT, "read %llu exceeds the packed stream", (unsigned long long)i);
-        nb = std::max(nb, e);
-    }
     HIPCHK(hipSetDevice(ctx->device));
     ReadChunk c;
     c.n_words = n_words;
     c.n_reads = n_reads;
-    c.n_bases = nb;
+    unsigned long long *d_ext;
     if (int rc = dalloc(ctx, &c.d_words, n_words + 8, false)) return rc;
     if (int rc = dalloc(ctx, &c.d_start, n_reads, false)) return rc;
     if (int rc = dalloc(ctx, &c.d_len, n_reads, false)) return rc;
-    HIPCHK(hipMemsetAsync(c.d_words + n_words, 0, 64, ctx->stream));
-    HIPCHK(hipMemcpyAsync(c.d_words, words, n_words * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(c.d_start, start, n_reads * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(c.d_len, len, n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (int rc = dalloc(ctx, &d_ext, 2)) return rc;
+    auto bail = [&](int code) {
+        arena_put(ctx, c.d_words);
+        arena_put(ctx, c.d_start);
+        arena_put(ctx, c.d_len);
+        free_temps(ctx);
+        return code;
+    };
+    hipError_t e = hipMemsetAsync(c.d_words + n_words, 0, 64, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_ext, 0, 16, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c.d_words, words, n_words * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c.d_start, start, n_reads * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c.d_len, len, n_reads * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "read upload failed: %s", hipGetErrorString(e)));
+    // the reference's streams cannot hand over a read that is not there; here the (start, len) pairs are checked against the stream
+    hipLaunchKernelGGL(k_reads_extent, dim3((unsigned)std::min<uint64_t>((n_reads + BLK - 1) / BLK, 2048)), dim3(BLK), 0, ctx->stream,
+                       (const uint64_t *)c.d_start, (const uint32_t *)c.d_len, n_reads, (uint64_t)n_words * 32, d_ext);
+    unsigned long long ext[2] = {0, 0};
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(ext, d_ext, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "read upload failed: %s", hipGetErrorString(e)));
+    if (ext[1]) return bail(fail(ctx, SMX_INVALID_INPUT_FORMAT, "%llu reads exceed the packed stream", ext[1]));
+    c.n_bases = ext[0];
+    free_temps(ctx);
     c.contigs = ctx->opt_submit_contigs != 0;
     ctx->chunks.push_back(c);
     return SMX_OK;

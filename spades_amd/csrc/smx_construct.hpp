@@ -58,6 +58,25 @@ void clear_graph(smx_ctx *ctx) {
     ctx->gh = smxh::GraphHost();
 }
 
+// A pipeline result that becomes part of the graph state leaves the temporaries' end of the arena for the long-lived end (one
+// device copy at the r+w rate); the other temporaries are released first. Without the VMM arena the block just changes owner.
+int adopt_result(smx_ctx *ctx, void **p, size_t bytes) {
+    free_temps(ctx, *p);
+    detach_temp(ctx, *p);
+    if (!ctx->arena.vmm || bytes == 0) return 0;
+    void *q = arena_get(ctx, std::max<size_t>(bytes, 256), /*top=*/true);
+    if (!q) return 0;  // no room for a second copy: it stays where it is
+    hipError_t e = hipMemcpyAsync(q, *p, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        arena_put(ctx, q);
+        return fail(ctx, SMX_DEVICE_ERROR, "moving a result failed: %s", hipGetErrorString(e));
+    }
+    arena_put(ctx, *p);
+    *p = q;
+    return 0;
+}
+
 template <typename T>
 int d2h(smx_ctx *ctx, std::vector<T> &dst, const void *src, size_t n) {
     dst.resize(n);
@@ -227,12 +246,10 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B) {
         tend(ctx);
         if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, derived, 2 * nkpo, nullptr, /*recs_reusable=*/true)) return rc;
         ctx->g_kmers = ctx->d_result_buf;
-        detach_temp(ctx, ctx->g_kmers);
         ctx->g_nkmers = ctx->n_records;
         ctx->g_kboff = ctx->bucket_off;
         ctx->d_result_buf = nullptr;
-        free_temps(ctx);
-        return 0;
+        return adopt_result(ctx, &ctx->g_kmers, (size_t)ctx->g_nkmers * W);
     }
     if (B > 12 * 1024) return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets=%u too large for the bucket histogram", B);
     unsigned long long *d_hist, *d_count;
@@ -251,10 +268,11 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B) {
     Rec<NW> *file;
     if (int rc = dalloc(ctx, &file, cap, false)) return rc;
     ctx->g_kmers = file;
-    uint64_t max_batch = (uint64_t)((double)arena_avail(ctx) / (2.25 * (double)W));
+    uint64_t max_batch = (uint64_t)((double)arena_avail(ctx) / (2.6 * (double)W));  // two buffers + bin bookkeeping + slack for placement
     if (ctx->opt_derive_batches > 1) max_batch = (2 * nkpo + ctx->opt_derive_batches - 1) / ctx->opt_derive_batches;
     uint64_t used = 0, remaining = 2 * nkpo;
     ctx->g_kboff.assign(B + 1, 0);
+    WallTrace dwt;
     for (uint32_t b0 = 0; b0 < B;) {
         uint32_t b1 = b0;
         uint64_t sum = 0;
@@ -270,7 +288,9 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B) {
                                (void *)derived, d_count);
             HIPCHK(hipGetLastError());
             tend(ctx);
-            if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, derived, sum, nullptr, /*recs_reusable=*/true)) return rc;
+            dwt.mark(ctx, "d:derive");
+            if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, derived, sum, nullptr, /*recs_reusable=*/true, false, false, b1 - b0)) return rc;
+            dwt.mark(ctx, "d:sort");
             const uint64_t nres = ctx->n_records;
             remaining -= sum;
             if (used + nres > cap) {
@@ -295,6 +315,7 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B) {
                 else arena_put(ctx, p);
             }
             ctx->temps = rest;
+            dwt.mark(ctx, "d:append");
         } else {
             for (uint32_t b = b0; b < b1; ++b) ctx->g_kboff[b + 1] = used;
         }
@@ -422,9 +443,8 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         if (int rc = count_reads<NW>(ctx, k + 1, SMX_MODE_CANONICAL, B)) return rc;
     }
     ctx->g_kpo = ctx->d_result_buf;
-    detach_temp(ctx, ctx->g_kpo);
     ctx->d_result_buf = ctx->d_result = nullptr;
-    free_temps(ctx);
+    if (int rc = adopt_result(ctx, &ctx->g_kpo, (size_t)ctx->n_records * NW * 8)) return rc;
     ctx->g_nkpo = ctx->n_records;
     ctx->g_kpoboff = ctx->bucket_off;
     const uint64_t nkpo = ctx->g_nkpo;
@@ -439,7 +459,15 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         return 0;
     }
     // ---- 2. canonical k-mers in k-mer-file order ----------------------------------------------
-    if (int rc = derive_kmer_file<NW>(ctx, k, B)) return rc;
+    struct Prefix {  // stage names of the pipeline runs below tell which part of the construction they belong to
+        smx_ctx *c;
+        Prefix(smx_ctx *c_, const char *p) : c(c_) { c->tprefix = p; }
+        ~Prefix() { c->tprefix.clear(); }
+    };
+    {
+        Prefix pf(ctx, "kmers:");
+        if (int rc = derive_kmer_file<NW>(ctx, k, B)) return rc;
+    }
     ctx->d_result = ctx->g_kmers;  // smx_copy_final_kmers() now yields the k-mer file
     gwt.mark(ctx, "g:kmer file");
     const uint64_t D0 = ctx->g_nkmers;
@@ -800,6 +828,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         });
         if (sort_rc) return sort_rc;
     } else {
+        Prefix pf(ctx, "links:");
         if (int rc = device_build_links(ctx, D0)) return rc;
         free_temps(ctx);
     }
@@ -829,8 +858,8 @@ int run_coverage(smx_ctx *ctx) {
         if (ctx->n_records != D1) return fail(ctx, SMX_DEVICE_ERROR, "recount of the (k+1)-mers gave %llu records, the graph was built from %llu",
                                               (unsigned long long)ctx->n_records, (unsigned long long)D1);
         ctx->g_kpo = ctx->d_result_buf;
-        detach_temp(ctx, ctx->g_kpo);
         ctx->d_result_buf = nullptr;
+        if (int rc = adopt_result(ctx, &ctx->g_kpo, (size_t)D1 * NW * 8)) return rc;
         ctx->d_result = sv_res;
         ctx->n_records = sv_n;
         ctx->K = sv_K;

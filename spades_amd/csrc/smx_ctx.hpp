@@ -20,8 +20,24 @@ struct Timing {
 
 }  // namespace
 
+struct Arena {  // one virtual range, physically backed up to `mapped`
+    bool tried = false, vmm = false;
+    char *base = nullptr;
+    size_t reserved = 0, gran = 0;
+    size_t lo = 0, hi = 0;  // [0, lo) and [hi, reserved) are backed by physical memory
+    struct Chunk {
+        hipMemGenericAllocationHandle_t h{};
+        bool mapped = false;
+    };
+    std::vector<Chunk> chunk;  // one entry per A.gran of the reserved range
+    std::map<size_t, size_t> free_blocks;                                     // offset -> bytes, inside [0, mapped)
+    std::unordered_map<void *, size_t> live;                                  // block -> bytes
+    std::string last_err;                                                     // why the last growth failed
+};
+
 struct smx_ctx {
     int device = 0;
+    Arena arena;
     size_t budget = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -50,6 +66,7 @@ struct smx_ctx {
     int64_t opt_leaf_grid = 0, opt_leaf_tab = 0;  // tuning experiments (tools/sweep.py)  // spades-core construction variant (debruijn_graph_constructor.hpp:590-604)
     // timings
     std::vector<Timing> timings;
+    std::string tprefix;  // prepended to stage names (which part of a construction a pipeline run belongs to)
     std::vector<std::string> tnames, xnames;  // last count stages / last extract_partition stages
     std::vector<float> tms, xms;
     std::vector<void *> temps;  // allocations of the pipeline in flight
@@ -104,8 +121,255 @@ int fail(smx_ctx *c, int code, const char *fmt, ...) {
                         "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);           \
     } while (0)
 
-void *arena_get(smx_ctx *ctx, size_t bytes) {
-    // best fit among cached blocks that waste at most 2x
+// ---- device arena -----------------------------------------------------------------------------------------------------------
+// hipMalloc / hipFree of tens of GB stall for seconds, and a construction at BASELINE-config-3 scale asks for a few hundred blocks
+// of every size up to 80 GB. So the context owns ONE virtual address range of the size of the device memory (HIP virtual memory
+// management: hipMemAddressReserve / hipMemCreate / hipMemMap) and backs it with physical chunks the first time an address is
+// needed; blocks are carved out first-fit with coalescing of neighbours, which costs nothing on the device. Mapping is slow too
+// (measured ~17 ms per GiB), so nothing is ever unmapped before smx_destroy(): a second call with the same shape maps nothing.
+// Placement keeps the range unfragmented: pipeline temporaries (freed wholesale between phases) grow from the bottom, long-lived
+// blocks (reads, the k-mer files, the graph) from the top; a pipeline result that becomes long-lived is moved to the top
+// (adopt_result). SMX_ARENA=malloc (or a HIP runtime without the VMM calls) falls back to a cache of hipMalloc'ed blocks.
+constexpr size_t ARENA_ALIGN = 256;
+
+bool arena_vmm_init(smx_ctx *ctx) {
+    Arena &A = ctx->arena;
+    if (A.tried) return A.vmm;
+    A.tried = true;
+    const char *e = getenv("SMX_ARENA");
+    if (e && !strcmp(e, "malloc")) return false;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    // Every physical chunk has the same size: on this stack hipMemSetAccess rejects a mapping whose size differs from its
+    // neighbour's in many combinations (tools/vmm_probe.hip: 2 MiB, 6 MiB, 64 MiB or 1 GiB chunks back to back all work, mixed
+    // sizes fail with "invalid argument"), and the reported granularity (4 KiB) says nothing about it.
+    A.gran = (size_t)512 << 20;
+    A.reserved = (total_b + A.gran - 1) / A.gran * A.gran;
+    if (ctx->budget) A.reserved = std::min(A.reserved, (ctx->budget + A.gran - 1) / A.gran * A.gran + A.gran);
+    void *base = nullptr;
+    if (hipMemAddressReserve(&base, A.reserved, 0, nullptr, 0) != hipSuccess || !base) {
+        (void)hipGetLastError();
+        return false;
+    }
+    A.base = (char *)base;
+    A.chunk.assign(A.reserved / A.gran, Arena::Chunk{});
+    A.lo = 0;
+    A.hi = A.reserved;
+    A.vmm = true;
+    return true;
+}
+// back the chunks [c0, c1) with physical memory
+bool arena_map_chunks(smx_ctx *ctx, size_t c0, size_t c1) {
+    Arena &A = ctx->arena;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    size_t ci = c0;
+    for (; ci < c1; ++ci) {
+        char *at = A.base + ci * A.gran;
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = hipMemCreate(&h, A.gran, &prop, 0);
+        if (e != hipSuccess) {
+            A.last_err = std::string("hipMemCreate: ") + hipGetErrorString(e);
+            break;
+        }
+        if ((e = hipMemMap(at, A.gran, 0, h, 0)) != hipSuccess) {
+            A.last_err = std::string("hipMemMap: ") + hipGetErrorString(e);
+            (void)hipMemRelease(h);
+            break;
+        }
+        if ((e = hipMemSetAccess(at, A.gran, &acc, 1)) != hipSuccess) {
+            A.last_err = std::string("hipMemSetAccess: ") + hipGetErrorString(e);
+            (void)hipMemUnmap(at, A.gran);
+            (void)hipMemRelease(h);
+            break;
+        }
+        A.chunk[ci].h = h;
+        A.chunk[ci].mapped = true;
+    }
+    if (ci < c1) {  // out of device memory: undo
+        (void)hipGetLastError();
+        while (ci > c0) {
+            --ci;
+            (void)hipMemUnmap(A.base + ci * A.gran, A.gran);
+            (void)hipMemRelease(A.chunk[ci].h);
+            A.chunk[ci].mapped = false;
+        }
+        return false;
+    }
+    return true;
+}
+void arena_add_free(Arena &A, size_t off, size_t sz) {  // with coalescing
+    auto nx = A.free_blocks.lower_bound(off);
+    if (nx != A.free_blocks.end() && off + sz == nx->first) {
+        sz += nx->second;
+        nx = A.free_blocks.erase(nx);
+    }
+    if (nx != A.free_blocks.begin()) {
+        auto pv = std::prev(nx);
+        if (pv->first + pv->second == off) {
+            off = pv->first;
+            sz += pv->second;
+            A.free_blocks.erase(pv);
+        }
+    }
+    A.free_blocks[off] = sz;
+}
+// make `want` free bytes end at the bottom mark (grow it upwards) or start at the top mark (grow it downwards)
+bool arena_grow(smx_ctx *ctx, size_t want, bool top) {
+    Arena &A = ctx->arena;
+    A.last_err.clear();
+    size_t have = 0;  // free bytes already adjacent to the mark
+    if (!top) {
+        auto it = A.free_blocks.lower_bound(A.lo);
+        if (it != A.free_blocks.begin()) {
+            auto pv = std::prev(it);
+            if (pv->first + pv->second == A.lo) have = pv->second;
+        }
+    } else {
+        auto it = A.free_blocks.find(A.hi);
+        if (it != A.free_blocks.end()) have = it->second;
+    }
+    if (have >= want) return true;
+    const size_t bytes = (want - have + A.gran - 1) / A.gran * A.gran;
+    if (A.lo + bytes > A.hi) {
+        A.last_err = "the arena is full";
+        return false;
+    }
+    if (!top) {
+        if (!arena_map_chunks(ctx, A.lo / A.gran, (A.lo + bytes) / A.gran)) return false;
+        arena_add_free(A, A.lo, bytes);
+        A.lo += bytes;
+    } else {
+        if (!arena_map_chunks(ctx, (A.hi - bytes) / A.gran, A.hi / A.gran)) return false;
+        A.hi -= bytes;
+        arena_add_free(A, A.hi, bytes);
+    }
+    return true;
+}
+
+void *arena_get_malloc(smx_ctx *ctx, size_t bytes);
+void arena_put_malloc(smx_ctx *ctx, void *p);
+
+// first fit among the free blocks that start inside [r0, r1): ascending addresses, block taken from its low end — or descending,
+// taken from its high end
+void *arena_take(smx_ctx *ctx, size_t bytes, size_t r0, size_t r1, bool descending) {
+    Arena &A = ctx->arena;
+    size_t off = 0, sz = 0;
+    bool found = false;
+    if (!descending) {
+        for (auto it = A.free_blocks.lower_bound(r0); it != A.free_blocks.end() && it->first < r1; ++it)
+            if (it->second >= bytes) {
+                off = it->first;
+                sz = it->second;
+                found = true;
+                break;
+            }
+    } else {
+        auto it = A.free_blocks.lower_bound(r1);
+        while (it != A.free_blocks.begin()) {
+            --it;
+            if (it->first < r0) break;
+            if (it->second >= bytes) {
+                off = it->first;
+                sz = it->second;
+                found = true;
+                break;
+            }
+        }
+    }
+    if (!found) return nullptr;
+    A.free_blocks.erase(off);
+    size_t at = off;
+    if (!descending) {
+        if (sz > bytes) A.free_blocks[off + bytes] = sz - bytes;
+    } else {
+        at = off + (sz - bytes);
+        if (sz > bytes) A.free_blocks[off] = sz - bytes;
+    }
+    void *p = A.base + at;
+    A.live[p] = bytes;
+    ctx->arena_live += bytes;
+    return p;
+}
+// top = long-lived block (top region, highest address first); otherwise a temporary (bottom region, lowest address first).
+// Each kind spills into the other region's free blocks only when its own region cannot grow any more.
+void *arena_get(smx_ctx *ctx, size_t bytes, bool top = false) {
+    if (!arena_vmm_init(ctx)) return arena_get_malloc(ctx, bytes);
+    Arena &A = ctx->arena;
+    bytes = (bytes + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN;
+    void *p;
+    if (!top) {
+        if ((p = arena_take(ctx, bytes, 0, A.lo, false))) return p;
+        if (arena_grow(ctx, bytes, false) && (p = arena_take(ctx, bytes, 0, A.lo, false))) return p;
+        if ((p = arena_take(ctx, bytes, A.hi, A.reserved, false))) return p;
+        if (arena_grow(ctx, bytes, true) && (p = arena_take(ctx, bytes, A.hi, A.reserved, false))) return p;
+    } else {
+        if ((p = arena_take(ctx, bytes, A.hi, A.reserved, true))) return p;
+        if (arena_grow(ctx, bytes, true) && (p = arena_take(ctx, bytes, A.hi, A.reserved, true))) return p;
+        if ((p = arena_take(ctx, bytes, 0, A.lo, true))) return p;
+        if (arena_grow(ctx, bytes, false) && (p = arena_take(ctx, bytes, 0, A.lo, true))) return p;
+    }
+    return nullptr;
+}
+void arena_put(smx_ctx *ctx, void *p) {
+    if (!p) return;
+    Arena &A = ctx->arena;
+    if (!A.vmm) {
+        arena_put_malloc(ctx, p);
+        return;
+    }
+    auto it = A.live.find(p);
+    if (it == A.live.end()) return;  // not ours (borrowed pointer), or already returned: one owner only
+    const size_t off = (size_t)((char *)p - A.base), sz = it->second;
+    ctx->arena_live -= std::min(ctx->arena_live, sz);
+    A.live.erase(it);
+    arena_add_free(A, off, sz);
+}
+// give the memory back to the device (smx_destroy: every block has been returned by then)
+void arena_release(smx_ctx *ctx) {
+    Arena &A = ctx->arena;
+    if (A.vmm) {
+        if (!A.live.empty()) return;
+        (void)hipDeviceSynchronize();
+        for (size_t ci = 0; ci < A.chunk.size(); ++ci)
+            if (A.chunk[ci].mapped) {
+                (void)hipMemUnmap(A.base + ci * A.gran, A.gran);
+                (void)hipMemRelease(A.chunk[ci].h);
+            }
+        (void)hipMemAddressFree(A.base, A.reserved);
+        A = Arena();
+        return;
+    }
+    for (auto &b : ctx->arena_free) {
+        ctx->arena_size.erase(b.first);
+        (void)hipFree(b.first);
+    }
+    ctx->arena_free.clear();
+}
+// HBM still obtainable for new allocations (bytes): free blocks of the arena + what can still be mapped between its two marks, as
+// far as the device has it, or what is left of the caller's budget
+size_t arena_avail(smx_ctx *ctx) {
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    size_t cached = 0;
+    if (ctx->arena.vmm) {
+        for (auto &b : ctx->arena.free_blocks) cached += b.second;
+        free_b = std::min(free_b, ctx->arena.hi - ctx->arena.lo);
+    } else {
+        for (auto &b : ctx->arena_free) cached += b.second;
+    }
+    const size_t dev = (size_t)((double)(free_b + cached) * 0.94);
+    if (!ctx->budget) return dev;
+    return std::min(dev, ctx->budget > ctx->arena_live ? ctx->budget - ctx->arena_live : (size_t)0);
+}
+
+// fallback: a cache of hipMalloc'ed blocks, best fit with at most 2x waste
+void *arena_get_malloc(smx_ctx *ctx, size_t bytes) {
     size_t best = (size_t)-1, bi = 0;
     for (size_t i = 0; i < ctx->arena_free.size(); ++i) {
         size_t sz = ctx->arena_free[i].second;
@@ -139,41 +403,21 @@ void *arena_get(smx_ctx *ctx, size_t bytes) {
     ctx->arena_live += bytes;
     return q;
 }
-void arena_put(smx_ctx *ctx, void *p) {
-    if (!p) return;
+void arena_put_malloc(smx_ctx *ctx, void *p) {
     auto it = ctx->arena_size.find(p);
-    if (it == ctx->arena_size.end()) {
-        (void)hipFree(p);
-        return;
-    }
+    if (it == ctx->arena_size.end()) return;  // not ours
     for (auto &b : ctx->arena_free)
         if (b.first == p) return;  // already returned (an error path released it twice): one owner only
     ctx->arena_free.emplace_back(p, it->second);
     ctx->arena_live -= std::min(ctx->arena_live, it->second);
 }
-// HBM still obtainable for new allocations: what the device has free plus the cached blocks (or what is left of the caller's budget)
-size_t arena_avail(smx_ctx *ctx) {
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
-    size_t cached = 0;
-    for (auto &b : ctx->arena_free) cached += b.second;
-    const size_t dev = (size_t)((double)(free_b + cached) * 0.94);
-    if (!ctx->budget) return dev;
-    return std::min(dev, ctx->budget > ctx->arena_live ? ctx->budget - ctx->arena_live : (size_t)0);
-}
-void arena_release(smx_ctx *ctx) {
-    for (auto &b : ctx->arena_free) {
-        ctx->arena_size.erase(b.first);
-        (void)hipFree(b.first);
-    }
-    ctx->arena_free.clear();
-}
 
 template <typename T>
 int dalloc(smx_ctx *ctx, T **p, size_t count, bool temp = true) {
     size_t bytes = std::max<size_t>(count * sizeof(T), 256);
-    void *q = arena_get(ctx, bytes);
-    if (!q) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "device allocation of %zu bytes failed", bytes);
+    void *q = arena_get(ctx, bytes, /*top=*/!temp);
+    if (!q) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "device allocation of %zu bytes failed (%s; arena: %zu mapped, %zu in use)", bytes,
+                        ctx->arena.last_err.c_str(), ctx->arena.lo + (ctx->arena.reserved - ctx->arena.hi), ctx->arena_live);
     if (temp) ctx->temps.push_back(q);
     *p = (T *)q;
     return 0;
@@ -214,7 +458,7 @@ struct WallTrace {  // SMX_DEBUG=1: host wall-clock per pipeline section (includ
 
 void tbegin(smx_ctx *ctx, const char *name) {
     Timing t;
-    t.name = name;
+    t.name = ctx->tprefix + name;
     (void)hipEventCreate(&t.e0);
     (void)hipEventCreate(&t.e1);
     (void)hipEventRecord(t.e0, ctx->stream);

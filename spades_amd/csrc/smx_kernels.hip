@@ -109,6 +109,26 @@ __global__ void k_pack_ascii(const char *__restrict__ bases, uint64_t nbases, ui
     }
 }
 
+// submitted (start, len) pairs: furthest nucleotide any read reaches, and how many reads leave the stream (checked on the device:
+// a host loop over 10^8 reads would sit in the timed path of every submission)
+__global__ void k_reads_extent(const uint64_t *__restrict__ start, const uint32_t *__restrict__ len, uint64_t n, uint64_t limit,
+                               unsigned long long *out /* [2]: max end, reads beyond limit */) {
+    unsigned long long mx = 0, bad = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long e = start[r] + len[r];
+        if (e > limit || e < start[r]) ++bad;
+        else mx = max(mx, e);
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        mx = max(mx, (unsigned long long)__shfl_xor(mx, d, 64));
+        bad += __shfl_xor(bad, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mx) atomicMax(&out[0], mx);
+        if (bad) atomicAdd(&out[1], bad);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ mark
 __global__ void k_mark_windows(const uint64_t *__restrict__ start, const uint32_t *__restrict__ len, uint64_t n,
                                unsigned K, unsigned long long *mask, unsigned long long *total) {

@@ -135,7 +135,7 @@ struct ReadSel {  // which part of the resident reads one pipeline run covers
 
 template <int NW>
 int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in, const ReadSel *sel = nullptr,
-              bool recs_reusable = false, bool expand_rc = false, bool distinct_hint = false) {
+              bool recs_reusable = false, bool expand_rc = false, bool distinct_hint = false, uint32_t active_buckets = 0) {
     uint32_t cap = Tune<NW>::CAP;
     if (ctx->opt_leaf_cap > 0) cap = (uint32_t)std::min<int64_t>(ctx->opt_leaf_cap, cap);
     const uint32_t cap1 = std::min<uint32_t>(Tune<NW>::CAP1, cap);
@@ -174,7 +174,9 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     uint64_t leaf = std::max<uint32_t>(cap1 * 7 / 10, 1);
     if (ctx->opt_leaf_target > 0) leaf = (uint64_t)ctx->opt_leaf_target;
     // per-bucket key fan-out needed, realised as a mixed-radix product S1 * F2 * F3 ... (every factor <= FMAX)
-    uint64_t R = ((nrec + leaf - 1) / leaf + B - 1) / B;
+    // (active_buckets: the caller knows that only this many of the B buckets receive records — a bucket range of the k-mer file)
+    const uint64_t nact = active_buckets ? std::min<uint32_t>(active_buckets, B) : B;
+    uint64_t R = ((nrec + leaf - 1) / leaf + nact - 1) / nact;
     const uint64_t rmax = 1ull << std::min(avail, 40u);  // no more key bins than key values
     R = std::max<uint64_t>(1, std::min(R, rmax));
     const uint32_t fmax1 = from_reads ? Tune<NW>::FMAX1 : Tune<NW>::FMAX;
@@ -489,6 +491,9 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     constexpr int SW = 2 * NW;
     const std::vector<uint64_t *> &masks = *sel.masks;
     unsigned long long *cnt, *soff, *ocount, *cursor;  // ocount[0] clean, ocount[1] dirty survivors
+    // partitions: ~256 windows each on average (a genomic locus at 30x is ~600), at least 2^24
+    uint32_t SKM_NKEY = SKM_NKEY_MIN;
+    while (SKM_NKEY < SKM_NKEY_MAX && (uint64_t)SKM_NKEY * 256 < nwin) SKM_NKEY <<= 1;
     if (int rc = dalloc(ctx, &cnt, SKM_NKEY)) return rc;
     if (int rc = dalloc(ctx, &soff, SKM_NKEY + 1)) return rc;
     if (int rc = dalloc(ctx, &cursor, SKM_NKEY)) return rc;
@@ -499,6 +504,7 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     a.K = K;
     a.m = skm_m(K);
     a.w = K - a.m + 1;
+    a.pshift = 32 - ceil_log2(SKM_NKEY);
     a.cnt = cnt;
     if (getenv("SMX_DEBUG")) {
         if (int rc = dalloc(ctx, &a.prof, 16)) return rc;

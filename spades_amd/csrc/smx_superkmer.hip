@@ -19,7 +19,8 @@
 
 namespace smx {
 
-constexpr uint32_t SKM_NKEY = 1u << 24;               // partitions ("keys") the minimizers are hashed into
+constexpr uint32_t SKM_NKEY_MIN = 1u << 24;           // partitions ("keys") the minimizers are hashed into: 2^24 .. 2^28, so that a
+constexpr uint32_t SKM_NKEY_MAX = 1u << 28;           // partition holds ~one genomic locus whatever the input size (run_prededupe)
 constexpr int SKM_WMAX = 128 - 16 + 1;                // windows per super-k-mer <= K - m + 1
 // Minimizer length: long enough that an m-mer is (nearly) unique in a genome — with m = 12 every 12-mer recurs ~6 times
 // per strand of a 50 Mbp genome, the few 12-mers that win the minimizer order collect thousands of instances each and
@@ -36,6 +37,7 @@ struct SkmArgs {
     const uint64_t *mask;
     uint64_t g0, G;   // windows starting outside [g0, G) are not part of this run
     unsigned K, m, w;  // w = K - m + 1
+    unsigned pshift;   // partition = mixed key >> pshift (32 - log2 of the partition count)
     unsigned long long *cnt;             // [NKEY] super-k-mers per key (phase 0)
     unsigned long long *cursor;          // [NKEY] next free slot of every key, starts at its offset (phase 1)
     uint64_t *slots;
@@ -62,11 +64,11 @@ __device__ __forceinline__ uint32_t skm_key(uint32_t v, unsigned m) {
 }
 // order key -> partition: the order keys of the chosen minimizers crowd the low end of the key space by construction
 // (a minimizer IS the smallest key of its window), so the partition id is an independent mix of the same value.
-__device__ __forceinline__ uint32_t skm_part(uint32_t key) {
+__device__ __forceinline__ uint32_t skm_part(uint32_t key, unsigned pshift) {
     key *= 0x9E3779B1u;
     key ^= key >> 16;
     key *= 0x85EBCA6Bu;
-    return key >> 8;
+    return key >> pshift;
 }
 
 template <int PHASE, int NW>
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
                 c = (uint32_t)(acc + (x ? __ffsll((unsigned long long)x) - 1 : 64)) + 1;
             }
             if (c > w) c = w;
-            const uint32_t key = skm_part(keys[e & 0xFFFu]);
+            const uint32_t key = skm_part(keys[e & 0xFFFu], a.pshift);
             uint64_t *dst = nullptr;
             if constexpr (PHASE == 0) {
                 atomicAdd(&a.cnt[key], 1ull);

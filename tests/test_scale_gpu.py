@@ -1,0 +1,71 @@
+"""Parity at size: the product against md5s of what the REAL reference binaries (spades-kmercount, spades-gbuilder -t 16, built
+from /root/reference) wrote for a seeded 2 M-read set — tests/golden/scale_*.json, made by tests/golden/make_golden_scale.py in
+the build container. The GPU box regenerates the identical reads (tests/synth.py, numpy PCG64); only md5s travel.
+At this size the code paths of the big runs are active: pre-dedupe stage, three MSD levels, rank directory, device link records."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from spades_amd import KMerDiskCounter, ReadKMerSplitter
+from spades_amd.gbuilder import GraphBuilder
+from spades_amd.kmercount import Context
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = sorted(glob.glob(os.path.join(HERE, "golden", "scale_*.json")))
+
+
+def _md5_file(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+@pytest.fixture(scope="module", params=CASES, ids=lambda p: os.path.basename(p))
+def case(request):
+    g = json.load(open(request.param))
+    codes = synth.synth_codes(g["seed"], g["genome_len"], g["n_reads"], g["err"], g["n_rate"])
+    assert hashlib.md5(codes.tobytes()).hexdigest() == g["codes_md5"], "the generator does not reproduce the golden read set"
+    bases, off = synth.ascii_and_offsets(codes)
+    return g, bases.tobytes(), off
+
+
+def test_final_kmers_equal_spades_kmercount(case, tmp_path):
+    g, bases, off = case
+    ctx = Context()
+    sp = ReadKMerSplitter(g["k"], "A", ctx)
+    sp.push_back_ascii(bases, off)
+    st = KMerDiskCounter(str(tmp_path), sp).CountAll(16)
+    assert os.path.getsize(st.final_kmers()) == g["final_kmers_bytes"]
+    assert _md5_file(st.final_kmers()) == g["final_kmers_md5"]
+    ctx.close()
+
+
+@pytest.mark.parametrize("batches", [0, 3])
+def test_gfa_equals_spades_gbuilder(case, tmp_path, batches):
+    g, bases, off = case
+    ctx = Context()
+    if batches:
+        ctx.set_option("derive_batches", batches)  # the k-mer file in bucket ranges, as at BASELINE config 3
+        ctx.set_option("keep_kpo", 0)              # ... and the coverage pass recounts the (k+1)-mers
+    gb = GraphBuilder(g["k"], g["effective_threads"], ctx)
+    gb.reads.push_back_ascii(bases, off)
+    info = gb.build()
+    out = str(tmp_path / "g.gfa")
+    gb.write_gfa(out)
+    assert info["n_unitigs"] == g["gfa_S_lines"]
+    assert os.path.getsize(out) == g["gfa_bytes"]
+    assert _md5_file(out) == g["gfa_md5"]
+    assert gb.info()["n_links"] == g["gfa_L_lines"]
+    gb.fill_coverage()
+    gb.write_gfa(out)
+    assert os.path.getsize(out) == g["gfa_cov_bytes"]
+    assert _md5_file(out) == g["gfa_cov_md5"]
+    ctx.close()

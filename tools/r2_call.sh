@@ -6,8 +6,10 @@ for step in "$@"; do
   case $step in
     tests) timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ;;
     g10) SMX_DEBUG=1 timeout 600 python tools/scale_probe.py 10e6 50e6 graph 2>&1 | grep -v "big leaf\|^\[smx\] \(mark+alloc\|level1\|levels2+\|leaf sort\|compact\|leaves\|skm_scan\|dedupe\|prededupe\)" ;;
-    g100) SMX_DEBUG=1 timeout 900 python tools/scale_probe.py 100e6 500e6 graph 2>&1 | grep -v "big leaf\|^\[smx\] \(mark+alloc\|level1\|levels2+\|leaf sort\|compact\|leaves\|skm_scan\|dedupe\)" ;;
-    c100) SMX_DEBUG=1 timeout 900 python tools/scale_probe.py 100e6 500e6 count 2>&1 | grep -v "big leaf\|^\[smx\] \(mark+alloc\|level1\|levels2+\|leaf sort\|compact\|leaves\|skm_scan\|dedupe\)" ;;
+    g100) SMX_DEBUG=1 timeout 900 python tools/scale_probe.py 100e6 500e6 graph 2>&1 | grep -v "big leaf\|^\[smx\] \(skm_scan\|dedupe\)" ;;
+    c100) SMX_DEBUG=1 timeout 900 python tools/scale_probe.py 100e6 500e6 count 2>&1 | grep -v "big leaf\|^\[smx\] \(skm_scan\|dedupe\)" ;;
+    scale) timeout 900 python -m pytest tests/test_scale_gpu.py -m gpu -x -q 2>&1 | tail -15 ;;
+    bench) timeout 1500 python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err; tail -5 gpurun_out/$tag/bench.err; cat gpurun_out/$tag/bench.json ;;
     *) echo "unknown step $step" ;;
   esac
 done
