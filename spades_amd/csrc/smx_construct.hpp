@@ -253,11 +253,15 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B) {
     }
     if (B > 12 * 1024) return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets=%u too large for the bucket histogram", B);
     unsigned long long *d_hist, *d_count;
+    uint32_t *d_tags = nullptr;  // buckets of the two k-mers of every (k+1)-mer, found once by the histogram pass (4 B per (k+1)-mer)
     if (int rc = dalloc(ctx, &d_hist, B)) return rc;
     if (int rc = dalloc(ctx, &d_count, 1)) return rc;
+    if (B <= 0xFFFF)
+        if (int rc = dalloc(ctx, &d_tags, nkpo)) return rc;
     HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)B * 8, ctx->stream));
     tbegin(ctx, "derive_hist");
-    hipLaunchKernelGGL((k_derive_hist<NW>), dim3(grid_for(nkpo, 4096)), dim3(BLK), (size_t)B * 4, ctx->stream, (const void *)ctx->g_kpo, nkpo, k, B, d_hist);
+    hipLaunchKernelGGL((k_derive_hist<NW>), dim3(grid_for(nkpo, 4096)), dim3(BLK), (size_t)B * 4, ctx->stream, (const void *)ctx->g_kpo, nkpo, k, B, d_hist,
+                       d_tags);
     HIPCHK(hipGetLastError());
     tend(ctx);
     std::vector<unsigned long long> h(B);
@@ -285,7 +289,7 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B) {
             HIPCHK(hipMemsetAsync(d_count, 0, 8, ctx->stream));
             tbegin(ctx, "derive_kmers");
             hipLaunchKernelGGL((k_derive_range<NW>), dim3(grid_for(nkpo, 256 * 32)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kpo, nkpo, k, B, b0, b1,
-                               (void *)derived, d_count);
+                               (const uint32_t *)d_tags, (void *)derived, d_count);
             HIPCHK(hipGetLastError());
             tend(ctx);
             dwt.mark(ctx, "d:derive");
@@ -308,10 +312,10 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B) {
             used += nres;
             ctx->d_result_buf = ctx->d_result = nullptr;  // one of the temps
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            void *keep[2] = {d_hist, d_count};
+            void *keep[3] = {d_hist, d_count, d_tags};
             std::vector<void *> rest;
             for (void *p : ctx->temps) {
-                if (p == keep[0] || p == keep[1]) rest.push_back(p);
+                if (p == keep[0] || p == keep[1] || p == keep[2]) rest.push_back(p);
                 else arena_put(ctx, p);
             }
             ctx->temps = rest;
@@ -493,7 +497,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     tend(ctx);
     {
         // the (k+1)-mer file is only needed again by -c; when HBM is short it goes now and the coverage pass recounts it
-        const size_t later = (size_t)D0 * 40;  // visited + candidate and edge arrays of the walks, generously
+        const size_t later = (size_t)D0 * 40;  // candidate and edge arrays of the walks, generously
         const bool keep = ctx->opt_keep_kpo > 0 || (ctx->opt_keep_kpo < 0 && arena_avail(ctx) > later);
         if (!keep) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -601,26 +605,31 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     }
     // ---- 4. start de-edges -----------------------------------------------------------------------
     const uint64_t ntiles = (D0 + CAND_TILE - 1) / CAND_TILE;
-    unsigned long long *tcnt, *toff;
+    unsigned long long *tcnt, *toff, *counters;  // counters: [0] junction k-mers, [1] non-junction k-mers on kept paths, [2..3] loop k-mers
     if (int rc = dalloc(ctx, &tcnt, ntiles)) return rc;
     if (int rc = dalloc(ctx, &toff, ntiles + 1)) return rc;
+    if (int rc = dalloc(ctx, &counters, 4)) return rc;
+    HIPCHK(hipMemsetAsync(counters, 0, 32, ctx->stream));
     tbegin(ctx, "candidates");
-    hipLaunchKernelGGL(k_cand_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, tcnt);
+    hipLaunchKernelGGL(k_succ_junctions, dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, succ);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_cand_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, tcnt, counters);
     HIPCHK(hipGetLastError());
     if (int rc = scan_u64(ctx, tcnt, toff, ntiles)) return rc;
-    unsigned long long C = 0;
+    unsigned long long C = 0, n_junction = 0;
     HIPCHK(hipMemcpyAsync(&C, toff + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&n_junction, counters, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     tend(ctx);
     gwt.mark(ctx, "g:masks+succ");
-    uint8_t *visited;
-    if (int rc = dalloc(ctx, &visited, D0 + 8)) return rc;
-    HIPCHK(hipMemsetAsync(visited, 0, D0 + 8, ctx->stream));
     uint64_t nkept = 0, ktotalw = 0;
+    unsigned long long interior = 0;
+    unsigned long long *cand = nullptr, *len = nullptr;
+    node_t *first = nullptr;
+    uint8_t *flags = nullptr;
     if (C > 0) {
-        unsigned long long *cand, *len, *kw, *one;
-        node_t *first, *last;
-        uint8_t *flags;
+        unsigned long long *kw, *one;
+        node_t *last;
         if (int rc = dalloc(ctx, &cand, C)) return rc;
         if (int rc = dalloc(ctx, &len, C)) return rc;
         if (int rc = dalloc(ctx, &kw, C + 1)) return rc;
@@ -634,14 +643,13 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         HIPCHK(hipGetLastError());
         tbegin(ctx, "walk_len");
         hipLaunchKernelGGL((k_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const node_t *)succ, k, ixk,
-                           (uint64_t)(2 * D0), len, first, last, d_err);
+                           (const void *)ctx->g_kmers, (const node_t *)succ, k, ixk, (uint64_t)(2 * D0), len, first, last, d_err);
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "keep");
         hipLaunchKernelGGL((k_keep<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const node_t *)succ, k, (const unsigned long long *)len,
-                           (const node_t *)first, (const node_t *)last, flags, kw, one);
+                           (const void *)ctx->g_kmers, (const node_t *)succ, k, (const unsigned long long *)len,
+                           (const node_t *)first, (const node_t *)last, flags, kw, one, counters + 1);
         HIPCHK(hipGetLastError());
         // word offsets and edge indices of the kept paths (scans in place: kw -> woff, one -> eidx)
         if (int rc = scan_u64(ctx, kw, kw, C)) return rc;
@@ -649,6 +657,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         unsigned long long tw = 0, nk = 0;
         HIPCHK(hipMemcpyAsync(&tw, kw + C, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(&nk, one + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&interior, counters + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         tend(ctx);
         nkept = nk;
@@ -662,9 +671,9 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         HIPCHK(hipMemsetAsync(ctx->g_uwords + ktotalw, 0, 64, ctx->stream));
         tbegin(ctx, "walk_write");
         hipLaunchKernelGGL((k_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const node_t *)succ, k, (const unsigned long long *)len,
+                           (const void *)ctx->g_kmers, (const node_t *)succ, k, (const unsigned long long *)len,
                            (const node_t *)first, (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw,
-                           (const unsigned long long *)one, ctx->g_uwords, ctx->g_eoffw, ctx->g_elen, ctx->g_estart, ctx->g_eend, ctx->g_eself, visited);
+                           (const unsigned long long *)one, ctx->g_uwords, ctx->g_eoffw, ctx->g_elen, ctx->g_estart, ctx->g_eend, ctx->g_eself);
         HIPCHK(hipGetLastError());
         tend(ctx);
     } else {
@@ -679,17 +688,24 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     ctx->g_ne = ctx->g_npaths = nkept;
     ctx->g_nuwords = ktotalw;
     gwt.mark(ctx, "g:walks");
-    {
-        // ---- perfect loops: non-junction k-mers on no path (CollectLoops, :359-397; serial in the reference too) ----
-        unsigned long long *lcount;
-        if (int rc = dalloc(ctx, &lcount, 2)) return rc;
-        HIPCHK(hipMemsetAsync(lcount, 0, 16, ctx->stream));
+    // ---- perfect loops: non-junction k-mers on no path (CollectLoops, :359-397; serial in the reference too) ----
+    // Every non-junction k-mer lies on exactly one kept path or on a perfect loop: the count of k_keep tells whether there is any.
+    if (D0 - n_junction != interior && ctx->opt_keep_loops) {
+        uint8_t *visited;
+        unsigned long long *lcount = counters + 2;
+        if (int rc = dalloc(ctx, &visited, D0 + 8)) return rc;
+        HIPCHK(hipMemsetAsync(visited, 0, D0 + 8, ctx->stream));
+        if (C > 0) {
+            hipLaunchKernelGGL(k_walk_mark, dim3(grid_for(C)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C, (const node_t *)succ, k,
+                               (const unsigned long long *)len, (const node_t *)first, (const uint8_t *)flags, visited);
+            HIPCHK(hipGetLastError());
+        }
         hipLaunchKernelGGL(k_loop_count, dim3(grid_for(D0, 4096)), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const uint8_t *)visited, D0, lcount);
         HIPCHK(hipGetLastError());
         unsigned long long nloopk = 0;
         HIPCHK(hipMemcpyAsync(&nloopk, lcount, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (nloopk && ctx->opt_keep_loops) {
+        if (nloopk) {
             unsigned long long *llist;
             if (int rc = dalloc(ctx, &llist, nloopk)) return rc;
             hipLaunchKernelGGL(k_loop_list, dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const uint8_t *)visited, D0,
@@ -728,17 +744,17 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
                 std::vector<uint8_t> l_self(nl);
                 std::vector<uint64_t> lwords;
                 for (uint64_t i = 0; i < nl; ++i) {
-                    const std::string &s = loops[i];
+                    const std::string &sq = loops[i];
                     l_offw[i] = ktotalw + lwords.size();
-                    l_len[i] = s.size();
+                    l_len[i] = sq.size();
                     // node ids must be taken from the untouched masks' k-mers (collect() zeroed the masks, not the index)
-                    l_start[i] = lc.node_of(s.substr(0, k));
-                    l_end[i] = lc.node_of(s.substr(s.size() - k));
-                    l_self[i] = s == smxh::revcomp(s) ? 1 : 0;
+                    l_start[i] = lc.node_of(sq.substr(0, k));
+                    l_end[i] = lc.node_of(sq.substr(sq.size() - k));
+                    l_self[i] = sq == smxh::revcomp(sq) ? 1 : 0;
                     const size_t w0 = lwords.size();
-                    lwords.resize(w0 + (s.size() + 31) / 32, 0);
-                    for (size_t t = 0; t < s.size(); ++t) {
-                        const char ch = s[t];
+                    lwords.resize(w0 + (sq.size() + 31) / 32, 0);
+                    for (size_t t = 0; t < sq.size(); ++t) {
+                        const char ch = sq[t];
                         const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
                         lwords[w0 + (t >> 5)] |= code << ((t & 31) << 1);
                     }

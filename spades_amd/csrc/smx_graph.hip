@@ -22,6 +22,11 @@ namespace smx {
 
 typedef unsigned long long node_t;
 constexpr node_t NODE_NONE = ~0ull;
+// A successor-table entry: the successor node in the low 62 bits, the nucleotide that leads to it in the top 2; NODE_NONE in the
+// entries of junction nodes (written by k_succ_junctions once the masks are final), so that a walk needs ONE read per step.
+constexpr node_t NODE_MASK = (1ull << 62) - 1;
+__device__ __forceinline__ node_t succ_node(node_t e) { return e == NODE_NONE ? NODE_NONE : (e & NODE_MASK); }
+__device__ __forceinline__ unsigned succ_nucl(node_t e) { return (unsigned)(e >> 62); }
 
 template <int NW>
 __device__ __forceinline__ Rec<NW> rec_shl(const Rec<NW> &x, unsigned K, unsigned c) {  // operator<<, rtseq.hpp:437-457
@@ -174,7 +179,8 @@ __global__ void __launch_bounds__(BLK) k_derive_kmers(const void *kpo_, uint64_t
 // time. The buckets of the k-mer file are disjoint by construction, so each range is final on its own (no merge of runs).
 // k_derive_hist: how many derived k-mers land in every bucket (decides the ranges); k_derive_range: emit those of [b0, b1).
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_derive_hist(const void *kpo_, uint64_t n, unsigned k, uint32_t B, unsigned long long *hist) {
+__global__ void __launch_bounds__(BLK) k_derive_hist(const void *kpo_, uint64_t n, unsigned k, uint32_t B, unsigned long long *hist,
+                                                     uint32_t *tags /* nullable: bucket of the prefix | bucket of the suffix << 16 */) {
     extern __shared__ uint32_t lh[];
     const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
     for (uint32_t t = threadIdx.x; t < B; t += BLK) lh[t] = 0;
@@ -182,40 +188,79 @@ __global__ void __launch_bounds__(BLK) k_derive_hist(const void *kpo_, uint64_t 
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
         const Rec<NW> x = kpo[i];
         unsigned f;
-        atomicAdd(&lh[bucket_of(xxh3_rec<NW>(rec_canon<NW>(rec_prefix<NW>(x, k), k, f)), B)], 1u);
-        atomicAdd(&lh[bucket_of(xxh3_rec<NW>(rec_canon<NW>(rec_suffix<NW>(x), k, f)), B)], 1u);
+        const uint32_t bp = bucket_of(xxh3_rec<NW>(rec_canon<NW>(rec_prefix<NW>(x, k), k, f)), B);
+        const uint32_t bs = bucket_of(xxh3_rec<NW>(rec_canon<NW>(rec_suffix<NW>(x), k, f)), B);
+        atomicAdd(&lh[bp], 1u);
+        atomicAdd(&lh[bs], 1u);
+        if (tags) tags[i] = bp | (bs << 16);
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < B; t += BLK)
         if (lh[t]) atomicAdd(&hist[t], (unsigned long long)lh[t]);
 }
+// One reservation (a single-address atomic: ~88 per microsecond on this chip) per tile of DR_ITEMS x 256 (k+1)-mers.
+constexpr int DR_ITEMS = 16;
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_derive_range(const void *kpo_, uint64_t n, unsigned k, uint32_t B, uint32_t b0, uint32_t b1,
-                                                      void *out_, unsigned long long *count) {
+                                                      const uint32_t *tags, void *out_, unsigned long long *count) {
+    static_assert(DR_ITEMS * (BLK / 64) == 64, "one wave scans the run lengths");
     __shared__ uint32_t scratch[BLK / 64 + 2];
+    __shared__ uint32_t s_cnt[DR_ITEMS * (BLK / 64)];
     __shared__ unsigned long long s_base;
     const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
     Rec<NW> *out = (Rec<NW> *)out_;
-    for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n; base += (uint64_t)gridDim.x * BLK) {
-        const uint64_t i = base + threadIdx.x;
-        Rec<NW> p, s;
-        bool kp = false, ks = false;
-        if (i < n) {
-            const Rec<NW> x = kpo[i];
-            unsigned f;
-            p = rec_canon<NW>(rec_prefix<NW>(x, k), k, f);
-            s = rec_canon<NW>(rec_suffix<NW>(x), k, f);
-            const uint32_t bp = bucket_of(xxh3_rec<NW>(p), B), bs = bucket_of(xxh3_rec<NW>(s), B);
-            kp = bp >= b0 && bp < b1;
-            ks = bs >= b0 && bs < b1;
+    const uint64_t tile = (uint64_t)DR_ITEMS * BLK;
+    for (uint64_t base = (uint64_t)blockIdx.x * tile; base < n; base += (uint64_t)gridDim.x * tile) {
+        uint32_t fl = 0, cnt = 0;  // 2 flag bits per item: emit the prefix / the suffix k-mer
+#pragma unroll
+        for (int j = 0; j < DR_ITEMS; ++j) {
+            const uint64_t i = base + (uint64_t)j * BLK + threadIdx.x;
+            if (i >= n) continue;
+            uint32_t bp, bs;
+            if (tags) {  // the buckets were found by the histogram pass
+                const uint32_t t = tags[i];
+                bp = t & 0xFFFFu;
+                bs = t >> 16;
+            } else {
+                const Rec<NW> x = kpo[i];
+                unsigned f;
+                bp = bucket_of(xxh3_rec<NW>(rec_canon<NW>(rec_prefix<NW>(x, k), k, f)), B);
+                bs = bucket_of(xxh3_rec<NW>(rec_canon<NW>(rec_suffix<NW>(x), k, f)), B);
+            }
+            const uint32_t kp = (bp >= b0 && bp < b1) ? 1u : 0u, ks = (bs >= b0 && bs < b1) ? 1u : 0u;
+            fl |= (kp | (ks << 1)) << (2 * j);
+            cnt += kp + ks;
         }
-        uint32_t tot;
-        const uint32_t off = block_excl_scan<uint32_t>((kp ? 1u : 0u) + (ks ? 1u : 0u), scratch, &tot);
-        if (threadIdx.x == 0) s_base = tot ? atomicAdd(count, (unsigned long long)tot) : 0ull;
+        // offsets per (item, wave): the 64 lanes of a wave then write one contiguous run per item
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int j = 0; j < DR_ITEMS; ++j) {
+            const uint32_t f2 = (fl >> (2 * j)) & 3u;
+            const unsigned long long bp_ = __ballot(f2 & 1), bs_ = __ballot(f2 & 2);
+            if (lane == 0) s_cnt[j * (BLK / 64) + wave] = (uint32_t)(__popcll(bp_) + __popcll(bs_));
+        }
         __syncthreads();
-        unsigned long long o = s_base + off;
-        if (kp) out[o++] = p;
-        if (ks) out[o] = s;
+        if (threadIdx.x < 64) {  // exclusive scan of the DR_ITEMS * 4 = 64 run lengths by one wave
+            const uint32_t v = s_cnt[threadIdx.x];
+            const uint32_t inc = wave_incl_scan<uint32_t>(v);
+            s_cnt[threadIdx.x] = inc - v;
+            if (threadIdx.x == 63) s_base = inc ? atomicAdd(count, (unsigned long long)inc) : 0ull;
+        }
+        __syncthreads();
+        (void)cnt;
+        (void)scratch;
+#pragma unroll
+        for (int j = 0; j < DR_ITEMS; ++j) {
+            const uint32_t f2 = (fl >> (2 * j)) & 3u;
+            const unsigned long long bp_ = __ballot(f2 & 1), bs_ = __ballot(f2 & 2);
+            if (!f2) continue;
+            const unsigned long long lt = (1ull << lane) - 1;
+            const unsigned long long o = s_base + s_cnt[j * (BLK / 64) + wave];
+            const Rec<NW> x = kpo[base + (uint64_t)j * BLK + threadIdx.x];
+            unsigned f;
+            if (f2 & 1) out[o + __popcll(bp_ & lt)] = rec_canon<NW>(rec_prefix<NW>(x, k), k, f);
+            if (f2 & 2) out[o + __popcll(bp_) + __popcll(bs_ & lt)] = rec_canon<NW>(rec_suffix<NW>(x), k, f);
+        }
         __syncthreads();
     }
 }
@@ -223,7 +268,7 @@ __global__ void __launch_bounds__(BLK) k_derive_range(const void *kpo_, uint64_t
 // a15: out[prefix] |= bit(x_k), in[suffix] |= bit(x_0), positions mirrored (7-p) for non-minimal keys. The two rank lookups also
 // tell where the de Bruijn edge x leads: succ[P] = S and, on the other strand, succ[S^1] = P^1 (P, S = the oriented prefix / suffix
 // nodes). A node with a unique outgoing extension is written by exactly one (k+1)-mer, so its entry is exact; entries of nodes with
-// several outgoing extensions are written more than once and are never read (the walks stop at junctions).
+// several outgoing extensions are written more than once and are overwritten by k_succ_junctions before anything reads them.
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_fill_masks(const void *kpo_, uint64_t n, unsigned k, const void *kmers_,
                                                     RankDir ix, uint32_t *mask32, node_t *succ, uint32_t *err) {
@@ -244,10 +289,10 @@ __global__ void __launch_bounds__(BLK) k_fill_masks(const void *kpo_, uint64_t n
         const unsigned bs = src ? 3 - pn : pn + 4;
         atomicOr(&mask32[rp >> 2], (1u << bp) << ((rp & 3) * 8));
         atomicOr(&mask32[rs >> 2], (1u << bs) << ((rs & 3) * 8));
-        if (succ) {
+        if (succ) {  // the step P -> S appends nn; on the other strand S^1 -> P^1 appends the complement of x_0
             const node_t P = (rp << 1) | prc, S = (rs << 1) | src;
-            succ[P] = S;
-            succ[S ^ 1] = P ^ 1;
+            succ[P] = S | ((node_t)nn << 62);
+            succ[S ^ 1] = (P ^ 1) | ((node_t)(3 - pn) << 62);
         }
     }
 }
@@ -270,11 +315,20 @@ __global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t 
         Rec<NW> x = kmers[r];
         if (o) x = rec_rc<NW>(x, k);
         unsigned yo;
-        Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, __ffs(mo & 15) - 1), k, yo);
+        const unsigned c = __ffs(mo & 15) - 1;
+        Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
         const node_t ry = kmer_rank<NW>(kmers, ix, y);
         if (ry == NODE_NONE) atomicAdd(err, 1u);
-        succ[node] = ry == NODE_NONE ? NODE_NONE : (ry << 1) | yo;
+        succ[node] = ry == NODE_NONE ? NODE_NONE : ((ry << 1) | yo | ((node_t)c << 62));
     }
+}
+// junction nodes end every walk: their entries become NODE_NONE (both orientations of a rank are neighbours in the table)
+__global__ void k_succ_junctions(const uint8_t *mask, uint64_t D0, node_t *succ) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x)
+        if (mask_junction(mask[r])) {
+            succ[2 * r] = NODE_NONE;
+            succ[2 * r + 1] = NODE_NONE;
+        }
 }
 
 // ---- early tip clipper (spades-core Construction stage; EarlyTipClipperProcessor, construction/early_simplification.hpp:38-162) ----
@@ -318,7 +372,7 @@ __global__ void __launch_bounds__(BLK) k_tip_mark(const void *kmers_, const uint
             first[c] = nd;
             while (cnt < bound && !mask_junction(mask[nd >> 1])) {
                 ++cnt;
-                nd = succ[nd];
+                nd = succ_node(succ[nd]);
                 if (nd == NODE_NONE) break;  // inconsistent index (reported by k_succ): never walk off the array
             }
             if (nd == NODE_NONE) {
@@ -339,7 +393,7 @@ __global__ void __launch_bounds__(BLK) k_tip_mark(const void *kmers_, const uint
             node_t nd = first[c];
             for (uint32_t i = 0; i + 1 < len[c]; ++i) {
                 isolate[nd >> 1] = 1;
-                nd = succ[nd];
+                nd = succ_node(succ[nd]);
             }
             isolate[nd >> 1] = 1;
             any = true;
@@ -511,7 +565,7 @@ __global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const 
                 }
                 nd = (ry << 1) | yo;
             } else {
-                const node_t sp = succ[nd ^ 1];
+                const node_t sp = succ_node(succ[nd ^ 1]);
                 if (sp == NODE_NONE) {
                     bad = true;
                     break;
@@ -545,7 +599,7 @@ __global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const 
                     const Rec<NW> y = rec_canon<NW>(z, k, yo);
                     q = (kmer_rank<NW>(kmers, ix, y) << 1) | yo;
                 } else {
-                    q = succ[q ^ 1] ^ 1;
+                    q = succ_node(succ[q ^ 1]) ^ 1;
                 }
                 const unsigned mm = mask[q >> 1];
                 mq = (q & 1) ? brev8(mm) : mm;
@@ -562,15 +616,23 @@ __global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const 
 constexpr int CAND_PER = 8;
 constexpr int CAND_TILE = BLK * CAND_PER;
 __device__ __forceinline__ unsigned cand_of_mask(unsigned m) { return mask_junction(m) ? (unsigned)(__popc(m & 15) + __popc(m >> 4)) : 0u; }
-__global__ void __launch_bounds__(BLK) k_cand_tiles(const uint8_t *mask, uint64_t D0, unsigned long long *tcnt) {
+__global__ void __launch_bounds__(BLK) k_cand_tiles(const uint8_t *mask, uint64_t D0, unsigned long long *tcnt, unsigned long long *njunction) {
     __shared__ uint32_t scratch[BLK / 64 + 2];
     const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
-    uint32_t c = 0;
+    uint32_t c = 0, j_ = 0;
     for (int j = 0; j < CAND_PER; ++j)
-        if (r0 + j < D0) c += cand_of_mask(mask[r0 + j]);
-    uint32_t tot;
+        if (r0 + j < D0) {
+            const unsigned m = mask[r0 + j];
+            c += cand_of_mask(m);
+            j_ += mask_junction(m) ? 1u : 0u;
+        }
+    uint32_t tot, jt;
     block_excl_scan<uint32_t>(c, scratch, &tot);
-    if (threadIdx.x == 0) tcnt[blockIdx.x] = tot;
+    block_excl_scan<uint32_t>(j_, scratch, &jt);
+    if (threadIdx.x == 0) {
+        tcnt[blockIdx.x] = tot;
+        if (jt) atomicAdd(njunction, (unsigned long long)jt);
+    }
 }
 __global__ void __launch_bounds__(BLK) k_cand_expand(const uint8_t *mask, const unsigned long long *toff, uint64_t D0, unsigned long long *cand) {
     __shared__ uint32_t scratch[BLK / 64 + 2];
@@ -593,9 +655,10 @@ __global__ void __launch_bounds__(BLK) k_cand_expand(const uint8_t *mask, const 
     }
 }
 
-// ConstructSequenceWithEdge (:264-273), pass 1: length and end node of every start de-edge
+// ConstructSequenceWithEdge (:264-273), pass 1: length and end node of every start de-edge. One successor-table read per step:
+// the entry of a junction node is NODE_NONE.
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_walk_len(const unsigned long long *cand, uint64_t C, const void *kmers_, const uint8_t *mask,
+__global__ void __launch_bounds__(BLK) k_walk_len(const unsigned long long *cand, uint64_t C, const void *kmers_,
                                                   const node_t *succ, unsigned k, RankDir ix,
                                                   uint64_t n_nodes, unsigned long long *len, node_t *first, node_t *last,
                                                   uint32_t *err) {
@@ -616,8 +679,10 @@ __global__ void __launch_bounds__(BLK) k_walk_len(const unsigned long long *cand
         node_t node = (ry << 1) | yo;
         first[i] = node;
         uint64_t steps = 0;
-        while (!mask_junction(mask[node >> 1])) {
-            node = succ[node];
+        for (;;) {
+            const node_t e = succ[node];
+            if (e == NODE_NONE) break;  // a junction ends the path
+            node = e & NODE_MASK;
             if (++steps > n_nodes || node >= n_nodes) {  // cannot happen on a consistent index; never hang the GPU or leave the arrays
                 atomicAdd(err, 1u);
                 node = NODE_NONE;
@@ -634,12 +699,16 @@ __global__ void __launch_bounds__(BLK) k_walk_len(const unsigned long long *cand
 // i.e. with the oriented k-mer of node last^1, and s begins with the start k-mer: unless those two k-mers are equal they decide.
 // If they are equal the path leads from the start node A to A^1 (a hairpin): RC(s) is then itself a path leaving A, and the two are
 // compared nucleotide by nucleotide with two forward walkers. flags: bit 0 keep, bit 1 s == RC(s) (self-conjugate edge).
-// kw[i] = 64-bit words of the packed sequence (0 if dropped), one[i] = keep.
+// kw[i] = 64-bit words of the packed sequence (0 if dropped), one[i] = keep. *interior += the non-junction k-mers (ranks) the kept
+// paths run through: when that equals the number of non-junction k-mers there is no perfect loop left to look for.
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_keep(const unsigned long long *cand, uint64_t C, const void *kmers_, const uint8_t *mask,
+__global__ void __launch_bounds__(BLK) k_keep(const unsigned long long *cand, uint64_t C, const void *kmers_,
                                               const node_t *succ, unsigned k, const unsigned long long *len, const node_t *first,
-                                              const node_t *last, uint8_t *flags, unsigned long long *kw, unsigned long long *one) {
+                                              const node_t *last, uint8_t *flags, unsigned long long *kw, unsigned long long *one,
+                                              unsigned long long *interior) {
+    __shared__ unsigned long long scratch[BLK / 64 + 2];
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    unsigned long long inner = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         const unsigned long long n = len[i];
         int cmp = -1;
@@ -654,7 +723,7 @@ __global__ void __launch_bounds__(BLK) k_keep(const unsigned long long *cand, ui
                 node_t a = first[i], prev = A;
                 for (unsigned long long t = 1; t < m; ++t) {
                     prev = a;
-                    a = succ[a];
+                    a = succ[a] & NODE_MASK;
                 }
                 // prev = n_{m-1} (A itself when m == 1); RC(s)[k] = complement of the first nucleotide of its k-mer
                 const unsigned c2 = 3u - rec_nucl<NW>(node_kmer<NW>(kmers, prev, k), 0);
@@ -663,11 +732,11 @@ __global__ void __launch_bounds__(BLK) k_keep(const unsigned long long *cand, ui
                 a = first[i];
                 node_t b = prev ^ 1;
                 for (unsigned long long t = 1; t < m && cmp == 0; ++t) {
-                    const unsigned ma = mask[a >> 1], mb = mask[b >> 1];
-                    const unsigned na = __ffs(((a & 1) ? brev8(ma) : ma) & 15) - 1, nb = __ffs(((b & 1) ? brev8(mb) : mb) & 15) - 1;
+                    const node_t ea = succ[a], eb = succ[b];
+                    const unsigned na = succ_nucl(ea), nb = succ_nucl(eb);
                     cmp = na < nb ? -1 : (na > nb ? 1 : 0);
-                    a = succ[a];
-                    b = succ[b];
+                    a = ea & NODE_MASK;
+                    b = eb & NODE_MASK;
                 }
             }
         }
@@ -675,17 +744,21 @@ __global__ void __launch_bounds__(BLK) k_keep(const unsigned long long *cand, ui
         flags[i] = (uint8_t)((keep ? 1 : 0) | ((n > 0 && cmp == 0) ? 2 : 0));
         kw[i] = keep ? (n + 31) / 32 : 0;
         one[i] = keep ? 1 : 0;
+        if (keep) inner += cmp == 0 ? (n - k - 1) / 2 : (n - k - 1);  // a self-conjugate path meets every rank twice
     }
+    unsigned long long tot;
+    block_excl_scan<unsigned long long>(inner, scratch, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(interior, tot);
 }
 
-// pass 2, kept paths only: the packed nucleotides (the start (k+1)-mer is the first NW words, then 2 bits per step) at their final
-// place, the dense edge arrays, and a visited mark on every k-mer of the path (both strands share the rank)
+// pass 2, kept paths only: the packed nucleotides (the start (k+1)-mer is the first NW words, then 2 bits per step, taken from the
+// successor entries) at their final place, and the dense edge arrays
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_walk_write(const unsigned long long *cand, uint64_t C, const void *kmers_, const uint8_t *mask,
+__global__ void __launch_bounds__(BLK) k_walk_write(const unsigned long long *cand, uint64_t C, const void *kmers_,
                                                     const node_t *succ, unsigned k, const unsigned long long *len, const node_t *first,
                                                     const node_t *last, const uint8_t *flags, const unsigned long long *woff,
                                                     const unsigned long long *eidx, uint64_t *words, unsigned long long *eoffw,
-                                                    unsigned long long *elen, node_t *estart, node_t *eend, uint8_t *eself, uint8_t *visited) {
+                                                    unsigned long long *elen, node_t *estart, node_t *eend, uint8_t *eself) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         if (!(flags[i] & 1)) continue;
@@ -696,26 +769,35 @@ __global__ void __launch_bounds__(BLK) k_walk_write(const unsigned long long *ca
 #pragma unroll
         for (int w = 0; w < NW - 1; ++w) dst[w] = x.w[w];
         uint64_t cur = x.w[NW - 1] | ((uint64_t)c << ((k & 31) << 1));
-        visited[cd >> 3] = 1;
         node_t node = first[i];
         for (unsigned long long p = k + 1; p < n; ++p) {
             if ((p & 31) == 0) {
                 dst[(p >> 5) - 1] = cur;
                 cur = 0;
             }
-            const unsigned m = mask[node >> 1];
-            const unsigned mo = (node & 1) ? brev8(m) : m;
-            visited[node >> 1] = 1;
-            cur |= (uint64_t)(__ffs(mo & 15) - 1) << ((p & 31) << 1);
-            node = succ[node];
+            const node_t en = succ[node];
+            cur |= (uint64_t)succ_nucl(en) << ((p & 31) << 1);
+            node = en & NODE_MASK;
         }
         dst[(n - 1) >> 5] = cur;
-        visited[node >> 1] = 1;
         eoffw[e] = wo;
         elen[e] = n;
         estart[e] = cd >> 2;
         eend[e] = last[i];
         eself[e] = (flags[i] >> 1) & 1;
+    }
+}
+// only when the count of k_keep says that some non-junction k-mers are on no path: mark the ones that are
+__global__ void __launch_bounds__(BLK) k_walk_mark(const unsigned long long *cand, uint64_t C, const node_t *succ, unsigned k,
+                                                   const unsigned long long *len, const node_t *first, const uint8_t *flags, uint8_t *visited) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
+        if (!(flags[i] & 1)) continue;
+        const unsigned long long n = len[i];
+        node_t node = first[i];
+        for (unsigned long long p = k + 1; p < n; ++p) {
+            visited[node >> 1] = 1;
+            node = succ[node] & NODE_MASK;
+        }
     }
 }
 

@@ -10,6 +10,7 @@ for step in "$@"; do
     c100) SMX_DEBUG=1 timeout 900 python tools/scale_probe.py 100e6 500e6 count 2>&1 | grep -v "big leaf\|^\[smx\] \(skm_scan\|dedupe\)" ;;
     scale) timeout 900 python -m pytest tests/test_scale_gpu.py -m gpu -x -q 2>&1 | tail -15 ;;
     bench) timeout 1500 python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err; tail -5 gpurun_out/$tag/bench.err; cat gpurun_out/$tag/bench.json ;;
+    benchq) timeout 1500 python bench.py --no-cpu-baseline --extra-kmercount 0 > gpurun_out/$tag/benchq.json 2> gpurun_out/$tag/benchq.err; tail -5 gpurun_out/$tag/benchq.err; cat gpurun_out/$tag/benchq.json ;;
     *) echo "unknown step $step" ;;
   esac
 done
