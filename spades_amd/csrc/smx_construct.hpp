@@ -206,7 +206,7 @@ int build_rank_dir(smx_ctx *ctx, const void *recs, uint64_t n, const std::vector
     uint64_t mx = 0;
     for (uint32_t b = 0; b < B; ++b) mx = std::max(mx, boff[b + 1] - boff[b]);
     if (mx >= (1ull << 32)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "a bucket of %llu records exceeds the directory's 32-bit offsets (use more buckets)", (unsigned long long)mx);
-    const uint64_t sb = std::min<uint64_t>(std::max<uint64_t>(1, (n / B + 1) / 2), 1ull << 30);
+    const uint64_t sb = std::min<uint64_t>(std::max<uint64_t>(1, n / B), 1ull << 30);  // ~1 record per slot
     unsigned long long *d_boff;
     uint32_t *dir;
     if (int rc = dalloc(ctx, &d_boff, (size_t)B + 1, false)) return rc;
@@ -216,6 +216,7 @@ int build_rank_dir(smx_ctx *ctx, const void *recs, uint64_t n, const std::vector
     ix.B = B;
     ix.SB = (uint32_t)sb;
     ix.K = K;
+    ix.verify = ctx->opt_verify_lookups ? 1u : 0u;
     std::vector<unsigned long long> hb(boff.begin(), boff.begin() + B + 1);
     HIPCHK(hipMemcpyAsync(d_boff, hb.data(), ((size_t)B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(dir, 0, (size_t)B * (sb + 1) * 4, ctx->stream));
@@ -293,7 +294,7 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B) {
             HIPCHK(hipGetLastError());
             tend(ctx);
             dwt.mark(ctx, "d:derive");
-            if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, derived, sum, nullptr, /*recs_reusable=*/true, false, false, b1 - b0)) return rc;
+            if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, derived, sum, nullptr, /*recs_reusable=*/true, false, false, b0, b1 - b0)) return rc;
             dwt.mark(ctx, "d:sort");
             const uint64_t nres = ctx->n_records;
             remaining -= sum;
@@ -480,20 +481,23 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     tbegin(ctx, "rank_dir");
     if (int rc = build_rank_dir<NW>(ctx, ctx->g_kmers, D0, ctx->g_kboff, B, k, ctx->g_dir_kmers)) return rc;
     tend(ctx);
-    // ---- 3. extension masks + successors --------------------------------------------------------
+    // ---- 3. node table (extensions + successors) and the InOutMask bytes ------------------------
     uint32_t *d_err;
     if (int rc = dalloc(ctx, &d_err, 1)) return rc;
     HIPCHK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
     const smx::RankDir ixk = ctx->g_dir_kmers;
     const size_t mask_bytes = (size_t)((D0 + 7) / 8 * 8 + 8);
     if (int rc = dalloc(ctx, &ctx->g_mask, mask_bytes, false)) return rc;
-    HIPCHK(hipMemsetAsync(ctx->g_mask, 0, mask_bytes, ctx->stream));
-    node_t *succ;
-    if (int rc = dalloc(ctx, &succ, 2 * D0)) return rc;
+    node_t *tab;
+    if (int rc = dalloc(ctx, &tab, 2 * D0 + 2)) return rc;
+    HIPCHK(hipMemsetAsync(tab, 0, (size_t)(2 * D0 + 2) * 8, ctx->stream));
     tbegin(ctx, "fill_masks");
-    hipLaunchKernelGGL((k_fill_masks<NW>), dim3(grid_for(nkpo)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kpo, nkpo, k, (const void *)ctx->g_kmers,
-                       ixk, (uint32_t *)ctx->g_mask, succ, d_err);
+    hipLaunchKernelGGL((k_fill_tab<NW>), dim3(grid_for(nkpo)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kpo, nkpo, k, (const void *)ctx->g_kmers,
+                       ixk, tab, d_err);
     HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_tab_masks, dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, (const node_t *)tab, D0, ctx->g_mask);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(ctx->g_mask + D0, 0, mask_bytes - D0, ctx->stream));
     tend(ctx);
     {
         // the (k+1)-mer file is only needed again by -c; when HBM is short it goes now and the coverage pass recounts it
@@ -504,6 +508,9 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
             drop_kpo(ctx);
         }
     }
+    node_t *succ = nullptr;  // successor table of the early clippers (their own format, by lookup)
+    if (ctx->opt_early_at || ctx->opt_early_tip_bound > 0)
+        if (int rc = dalloc(ctx, &succ, 2 * D0)) return rc;
     bool clipped = false;
     // ---- 3a. early A/T remover (RNA pipelines: EarlyATClipper::run, stages/construction.cpp:317-326) --------------
     ctx->g_at_edges = ctx->g_at_tip_kmers = 0;
@@ -597,9 +604,10 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         ctx->g_tip_kmers = hs[0];
         ctx->g_tips = hs[1];
     }
-    if (clipped) {  // the successor table has to describe the clipped masks
+    if (clipped) {  // the node table has to describe the clipped masks
         tbegin(ctx, "succ");
-        hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, succ, d_err);
+        hipLaunchKernelGGL((k_tab_from_masks<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, tab,
+                           d_err);
         HIPCHK(hipGetLastError());
         tend(ctx);
     }
@@ -611,8 +619,6 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     if (int rc = dalloc(ctx, &counters, 4)) return rc;
     HIPCHK(hipMemsetAsync(counters, 0, 32, ctx->stream));
     tbegin(ctx, "candidates");
-    hipLaunchKernelGGL(k_succ_junctions, dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, succ);
-    HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_cand_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, tcnt, counters);
     HIPCHK(hipGetLastError());
     if (int rc = scan_u64(ctx, tcnt, toff, ntiles)) return rc;
@@ -643,12 +649,12 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         HIPCHK(hipGetLastError());
         tbegin(ctx, "walk_len");
         hipLaunchKernelGGL((k_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const node_t *)succ, k, ixk, (uint64_t)(2 * D0), len, first, last, d_err);
+                           (const void *)ctx->g_kmers, (const node_t *)tab, k, ixk, (uint64_t)(2 * D0), len, first, last, d_err);
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "keep");
         hipLaunchKernelGGL((k_keep<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const node_t *)succ, k, (const unsigned long long *)len,
+                           (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len,
                            (const node_t *)first, (const node_t *)last, flags, kw, one, counters + 1);
         HIPCHK(hipGetLastError());
         // word offsets and edge indices of the kept paths (scans in place: kw -> woff, one -> eidx)
@@ -671,7 +677,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         HIPCHK(hipMemsetAsync(ctx->g_uwords + ktotalw, 0, 64, ctx->stream));
         tbegin(ctx, "walk_write");
         hipLaunchKernelGGL((k_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const node_t *)succ, k, (const unsigned long long *)len,
+                           (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len,
                            (const node_t *)first, (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw,
                            (const unsigned long long *)one, ctx->g_uwords, ctx->g_eoffw, ctx->g_elen, ctx->g_estart, ctx->g_eend, ctx->g_eself);
         HIPCHK(hipGetLastError());
@@ -696,7 +702,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         if (int rc = dalloc(ctx, &visited, D0 + 8)) return rc;
         HIPCHK(hipMemsetAsync(visited, 0, D0 + 8, ctx->stream));
         if (C > 0) {
-            hipLaunchKernelGGL(k_walk_mark, dim3(grid_for(C)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C, (const node_t *)succ, k,
+            hipLaunchKernelGGL(k_walk_mark, dim3(grid_for(C)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C, (const node_t *)tab, k,
                                (const unsigned long long *)len, (const node_t *)first, (const uint8_t *)flags, visited);
             HIPCHK(hipGetLastError());
         }

@@ -27,6 +27,12 @@ constexpr node_t NODE_NONE = ~0ull;
 constexpr node_t NODE_MASK = (1ull << 62) - 1;
 __device__ __forceinline__ node_t succ_node(node_t e) { return e == NODE_NONE ? NODE_NONE : (e & NODE_MASK); }
 __device__ __forceinline__ unsigned succ_nucl(node_t e) { return (unsigned)(e >> 62); }
+// The node table of the default path: one 64-bit entry per oriented k-mer, bits 40..43 = its outgoing extensions (the incoming
+// ones of a node are the outgoing ones of its reverse complement, the neighbouring entry), bits 0..39 = the successor node,
+// meaningful when exactly one outgoing bit is set (several writers OR their successors together, and nobody reads the mix).
+constexpr unsigned TAB_OUT_SHIFT = 40;
+constexpr node_t TAB_NODE_MASK = (1ull << TAB_OUT_SHIFT) - 1;
+__device__ __forceinline__ unsigned tab_out4(node_t e) { return (unsigned)(e >> TAB_OUT_SHIFT) & 15u; }
 
 template <int NW>
 __device__ __forceinline__ Rec<NW> rec_shl(const Rec<NW> &x, unsigned K, unsigned c) {  // operator<<, rtseq.hpp:437-457
@@ -88,17 +94,22 @@ struct RankDir {
     const unsigned long long *boff;  // [B + 1] bucket offsets of the file
     uint32_t B, SB;
     unsigned K;
+    uint32_t verify;  // 1: every lookup compares the record it finds
 };
 template <int NW>
 __device__ __forceinline__ uint64_t dir_slot(const Rec<NW> &x, const RankDir &ix) {
     return __umul64hi(key_top64<NW>(x, ix.K), (uint64_t)ix.SB);
 }
-template <int NW>
+// PRESENT: the caller knows that the k-mer is in the file (it was derived from it): a slot that holds a single record then IS the
+// answer and the record is not read at all (~37 % of the lookups with one record per slot on average). RankDir::verify (option
+// "verify_lookups", the tests) turns the shortcut off.
+template <int NW, bool PRESENT = false>
 __device__ __forceinline__ node_t kmer_rank(const Rec<NW> *__restrict__ kmers, const RankDir &ix, const Rec<NW> &canon) {
     const uint32_t b = bucket_of(xxh3_rec<NW>(canon), ix.B);
     const uint32_t *d = ix.dir + (uint64_t)b * (ix.SB + 1) + dir_slot<NW>(canon, ix);
     const uint64_t base = ix.boff[b];
     uint64_t lo = base + d[0], hi = base + d[1];
+    if (PRESENT && hi - lo == 1 && !ix.verify) return lo;
     const uint64_t end = hi;
     while (hi - lo > 8) {  // crowded slot (skewed keys): halve first (lower bound: the answer stays in [lo, hi])
         const uint64_t mid = (lo + hi) >> 1;
@@ -157,6 +168,17 @@ __global__ void __launch_bounds__(BLK) k_dir_fill(const void *kmers_, uint64_t n
 __device__ __forceinline__ unsigned brev8(unsigned m) { return __brev(m) >> 24; }  // InOutMask::conjugate, inout_mask.hpp:18-39,112-115
 __device__ __forceinline__ bool uniq4(unsigned m) { return m && !(m & (m - 1)); }
 __device__ __forceinline__ bool mask_junction(unsigned m) { return !uniq4(m & 15) || !uniq4((m >> 4) & 15); }  // inout_mask.hpp:157-159
+// one step of a walk: false at a junction k-mer, else the successor and the nucleotide that leads to it — ONE 16-byte read (the
+// entries of both orientations of a k-mer are neighbours)
+__device__ __forceinline__ bool tab_step(const node_t *__restrict__ tab, node_t node, node_t &next, unsigned &nuc) {
+    const ulonglong2 pr = *reinterpret_cast<const ulonglong2 *>(tab + (node & ~1ull));
+    const node_t es = (node & 1) ? pr.y : pr.x, ec = (node & 1) ? pr.x : pr.y;
+    const unsigned o = tab_out4(es);
+    if (!uniq4(o) || !uniq4(tab_out4(ec))) return false;
+    next = es & TAB_NODE_MASK;
+    nuc = __ffs(o) - 1;
+    return true;
+}
 template <int NW>
 __device__ __forceinline__ Rec<NW> node_kmer(const Rec<NW> *__restrict__ kmers, node_t node, unsigned k) {  // oriented k-mer of a node
     const Rec<NW> x = kmers[node >> 1];
@@ -265,13 +287,13 @@ __global__ void __launch_bounds__(BLK) k_derive_range(const void *kpo_, uint64_t
     }
 }
 
-// a15: out[prefix] |= bit(x_k), in[suffix] |= bit(x_0), positions mirrored (7-p) for non-minimal keys. The two rank lookups also
-// tell where the de Bruijn edge x leads: succ[P] = S and, on the other strand, succ[S^1] = P^1 (P, S = the oriented prefix / suffix
-// nodes). A node with a unique outgoing extension is written by exactly one (k+1)-mer, so its entry is exact; entries of nodes with
-// several outgoing extensions are written more than once and are overwritten by k_succ_junctions before anything reads them.
+// a15: every canonical (k+1)-mer x is a de Bruijn edge P -> S between its oriented prefix and suffix nodes (and S^1 -> P^1 on the
+// other strand): out[P] |= bit(x_k), out[S^1] |= bit(complement of x_0) — the reference's out[prefix] / in[suffix] updates
+// (kmer_extension_index_builder.hpp:45-60; in-bits = the out-bits of the reverse complement, inout_mask.hpp:92-131) — and the same
+// two atomics carry the successor nodes, which the two rank lookups have just produced.
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_fill_masks(const void *kpo_, uint64_t n, unsigned k, const void *kmers_,
-                                                    RankDir ix, uint32_t *mask32, node_t *succ, uint32_t *err) {
+__global__ void __launch_bounds__(BLK) k_fill_tab(const void *kpo_, uint64_t n, unsigned k, const void *kmers_,
+                                                  RankDir ix, node_t *tab, uint32_t *err) {
     const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
@@ -280,20 +302,38 @@ __global__ void __launch_bounds__(BLK) k_fill_masks(const void *kpo_, uint64_t n
         unsigned prc, src;
         Rec<NW> p = rec_canon<NW>(rec_prefix<NW>(x, k), k, prc);
         Rec<NW> s = rec_canon<NW>(rec_suffix<NW>(x), k, src);
-        const node_t rp = kmer_rank<NW>(kmers, ix, p), rs = kmer_rank<NW>(kmers, ix, s);
+        const node_t rp = kmer_rank<NW, true>(kmers, ix, p), rs = kmer_rank<NW, true>(kmers, ix, s);
         if (rp == NODE_NONE || rs == NODE_NONE) {
             atomicAdd(err, 1u);
             continue;
         }
-        const unsigned bp = prc ? 7 - nn : nn;
-        const unsigned bs = src ? 3 - pn : pn + 4;
-        atomicOr(&mask32[rp >> 2], (1u << bp) << ((rp & 3) * 8));
-        atomicOr(&mask32[rs >> 2], (1u << bs) << ((rs & 3) * 8));
-        if (succ) {  // the step P -> S appends nn; on the other strand S^1 -> P^1 appends the complement of x_0
-            const node_t P = (rp << 1) | prc, S = (rs << 1) | src;
-            succ[P] = S | ((node_t)nn << 62);
-            succ[S ^ 1] = (P ^ 1) | ((node_t)(3 - pn) << 62);
+        const node_t P = (rp << 1) | prc, S = (rs << 1) | src;
+        atomicOr(&tab[P], S | (1ull << (TAB_OUT_SHIFT + nn)));
+        atomicOr(&tab[S ^ 1], (P ^ 1) | (1ull << (TAB_OUT_SHIFT + 3 - pn)));
+    }
+}
+// InOutMask bytes of the canonical k-mers from the node table: out bits 0-3, in bits 4-7 = the bit-reversed out bits of the RC node
+__global__ void k_tab_masks(const node_t *tab, uint64_t D0, uint8_t *mask) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x)
+        mask[r] = (uint8_t)(tab_out4(tab[2 * r]) | brev8(tab_out4(tab[2 * r + 1])));
+}
+// the node table of clipped masks (spades-core variants): extensions from the masks, successors by lookup
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_tab_from_masks(const void *kmers_, const uint8_t *mask, uint64_t D0, unsigned k, RankDir ix, node_t *tab,
+                                                        uint32_t *err) {
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
+        const unsigned m = mask[node >> 1];
+        const unsigned mo = ((node & 1) ? brev8(m) : m) & 15u;
+        node_t e = (node_t)mo << TAB_OUT_SHIFT;
+        if (uniq4(mo)) {
+            unsigned yo;
+            const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(node_kmer<NW>(kmers, node, k), k, __ffs(mo) - 1), k, yo);
+            const node_t ry = kmer_rank<NW>(kmers, ix, y);
+            if (ry == NODE_NONE) atomicAdd(err, 1u);
+            else e |= (ry << 1) | yo;
         }
+        tab[node] = e;
     }
 }
 
@@ -321,14 +361,6 @@ __global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t 
         if (ry == NODE_NONE) atomicAdd(err, 1u);
         succ[node] = ry == NODE_NONE ? NODE_NONE : ((ry << 1) | yo | ((node_t)c << 62));
     }
-}
-// junction nodes end every walk: their entries become NODE_NONE (both orientations of a rank are neighbours in the table)
-__global__ void k_succ_junctions(const uint8_t *mask, uint64_t D0, node_t *succ) {
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x)
-        if (mask_junction(mask[r])) {
-            succ[2 * r] = NODE_NONE;
-            succ[2 * r + 1] = NODE_NONE;
-        }
 }
 
 // ---- early tip clipper (spades-core Construction stage; EarlyTipClipperProcessor, construction/early_simplification.hpp:38-162) ----
@@ -655,8 +687,7 @@ __global__ void __launch_bounds__(BLK) k_cand_expand(const uint8_t *mask, const 
     }
 }
 
-// ConstructSequenceWithEdge (:264-273), pass 1: length and end node of every start de-edge. One successor-table read per step:
-// the entry of a junction node is NODE_NONE.
+// ConstructSequenceWithEdge (:264-273), pass 1: length and end node of every start de-edge. One node-table read per step.
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_walk_len(const unsigned long long *cand, uint64_t C, const void *kmers_,
                                                   const node_t *succ, unsigned k, RankDir ix,
@@ -679,10 +710,10 @@ __global__ void __launch_bounds__(BLK) k_walk_len(const unsigned long long *cand
         node_t node = (ry << 1) | yo;
         first[i] = node;
         uint64_t steps = 0;
-        for (;;) {
-            const node_t e = succ[node];
-            if (e == NODE_NONE) break;  // a junction ends the path
-            node = e & NODE_MASK;
+        node_t nx;
+        unsigned nuc;
+        while (tab_step(succ, node, nx, nuc)) {  // a junction ends the path
+            node = nx;
             if (++steps > n_nodes || node >= n_nodes) {  // cannot happen on a consistent index; never hang the GPU or leave the arrays
                 atomicAdd(err, 1u);
                 node = NODE_NONE;
@@ -723,7 +754,7 @@ __global__ void __launch_bounds__(BLK) k_keep(const unsigned long long *cand, ui
                 node_t a = first[i], prev = A;
                 for (unsigned long long t = 1; t < m; ++t) {
                     prev = a;
-                    a = succ[a] & NODE_MASK;
+                    a = succ[a] & TAB_NODE_MASK;
                 }
                 // prev = n_{m-1} (A itself when m == 1); RC(s)[k] = complement of the first nucleotide of its k-mer
                 const unsigned c2 = 3u - rec_nucl<NW>(node_kmer<NW>(kmers, prev, k), 0);
@@ -731,12 +762,12 @@ __global__ void __launch_bounds__(BLK) k_keep(const unsigned long long *cand, ui
                 cmp = c1 < c2 ? -1 : (c1 > c2 ? 1 : 0);
                 a = first[i];
                 node_t b = prev ^ 1;
-                for (unsigned long long t = 1; t < m && cmp == 0; ++t) {
+                for (unsigned long long t = 1; t < m && cmp == 0; ++t) {  // interior nodes: exactly one outgoing bit each
                     const node_t ea = succ[a], eb = succ[b];
-                    const unsigned na = succ_nucl(ea), nb = succ_nucl(eb);
+                    const unsigned na = __ffs(tab_out4(ea)) - 1, nb = __ffs(tab_out4(eb)) - 1;
                     cmp = na < nb ? -1 : (na > nb ? 1 : 0);
-                    a = ea & NODE_MASK;
-                    b = eb & NODE_MASK;
+                    a = ea & TAB_NODE_MASK;
+                    b = eb & TAB_NODE_MASK;
                 }
             }
         }
@@ -752,7 +783,7 @@ __global__ void __launch_bounds__(BLK) k_keep(const unsigned long long *cand, ui
 }
 
 // pass 2, kept paths only: the packed nucleotides (the start (k+1)-mer is the first NW words, then 2 bits per step, taken from the
-// successor entries) at their final place, and the dense edge arrays
+// node table) at their final place, and the dense edge arrays
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_walk_write(const unsigned long long *cand, uint64_t C, const void *kmers_,
                                                     const node_t *succ, unsigned k, const unsigned long long *len, const node_t *first,
@@ -776,8 +807,8 @@ __global__ void __launch_bounds__(BLK) k_walk_write(const unsigned long long *ca
                 cur = 0;
             }
             const node_t en = succ[node];
-            cur |= (uint64_t)succ_nucl(en) << ((p & 31) << 1);
-            node = en & NODE_MASK;
+            cur |= (uint64_t)(__ffs(tab_out4(en)) - 1) << ((p & 31) << 1);
+            node = en & TAB_NODE_MASK;
         }
         dst[(n - 1) >> 5] = cur;
         eoffw[e] = wo;
@@ -796,7 +827,7 @@ __global__ void __launch_bounds__(BLK) k_walk_mark(const unsigned long long *can
         node_t node = first[i];
         for (unsigned long long p = k + 1; p < n; ++p) {
             visited[node >> 1] = 1;
-            node = succ[node] & NODE_MASK;
+            node = succ[node] & TAB_NODE_MASK;
         }
     }
 }

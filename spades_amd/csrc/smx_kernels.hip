@@ -39,7 +39,8 @@ struct PassArgs {
     // binning
     unsigned K;
     uint32_t num_buckets;
-    uint32_t S1;        // BIN_L1: bin = bucket * S1 + floor(keyfrac * S1)
+    uint32_t bucket0;   // BIN_L1: first bucket that receives records (a bucket range of a file): level-1 bins start there
+    uint32_t S1;        // BIN_L1: bin = (bucket - bucket0) * S1 + floor(keyfrac * S1)
     uint32_t nprev;     // BIN_LK: key fan-outs already applied (S1, F2, ...), mixed radix on the key fraction
     uint32_t fprev[6];
     uint32_t world;
@@ -53,7 +54,7 @@ struct PassArgs {
 template <int NW, int BINF>
 __device__ __forceinline__ uint32_t bin_of(const Rec<NW> &x, const PassArgs &a) {
     if constexpr (BINF == BIN_L1) {
-        uint32_t b = bucket_of(xxh3_rec<NW>(x), a.num_buckets);
+        uint32_t b = bucket_of(xxh3_rec<NW>(x), a.num_buckets) - a.bucket0;
         return a.S1 > 1 ? b * a.S1 + (uint32_t)__umul64hi(key_top64<NW>(x, a.K), (uint64_t)a.S1) : b;
     } else if constexpr (BINF == BIN_LK) {
         uint64_t f = key_top64<NW>(x, a.K);  // key as a fraction in [0,1) scaled by 2^64

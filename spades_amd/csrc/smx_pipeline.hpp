@@ -135,7 +135,8 @@ struct ReadSel {  // which part of the resident reads one pipeline run covers
 
 template <int NW>
 int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in, const ReadSel *sel = nullptr,
-              bool recs_reusable = false, bool expand_rc = false, bool distinct_hint = false, uint32_t active_buckets = 0) {
+              bool recs_reusable = false, bool expand_rc = false, bool distinct_hint = false, uint32_t active_first = 0,
+              uint32_t active_buckets = 0) {
     uint32_t cap = Tune<NW>::CAP;
     if (ctx->opt_leaf_cap > 0) cap = (uint32_t)std::min<int64_t>(ctx->opt_leaf_cap, cap);
     const uint32_t cap1 = std::min<uint32_t>(Tune<NW>::CAP1, cap);
@@ -174,17 +175,19 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     uint64_t leaf = std::max<uint32_t>(cap1 * 7 / 10, 1);
     if (ctx->opt_leaf_target > 0) leaf = (uint64_t)ctx->opt_leaf_target;
     // per-bucket key fan-out needed, realised as a mixed-radix product S1 * F2 * F3 ... (every factor <= FMAX)
-    // (active_buckets: the caller knows that only this many of the B buckets receive records — a bucket range of the k-mer file)
-    const uint64_t nact = active_buckets ? std::min<uint32_t>(active_buckets, B) : B;
+    // (active_first / active_buckets: the caller knows that only the buckets [first, first + count) receive records — a bucket
+    // range of the k-mer file; the level-1 bins then cover just those, with the key fan-out the others leave free)
+    const uint32_t b_first = active_buckets ? std::min<uint32_t>(active_first, B - 1) : 0;
+    const uint32_t nact = active_buckets ? std::min<uint32_t>(active_buckets, B - b_first) : B;
     uint64_t R = ((nrec + leaf - 1) / leaf + nact - 1) / nact;
     const uint64_t rmax = 1ull << std::min(avail, 40u);  // no more key bins than key values
     R = std::max<uint64_t>(1, std::min(R, rmax));
     const uint32_t fmax1 = from_reads ? Tune<NW>::FMAX1 : Tune<NW>::FMAX;
-    uint32_t S1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(R, B <= fmax1 ? fmax1 / B : 1));
+    uint32_t S1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(R, nact <= fmax1 ? fmax1 / nact : 1));
     std::vector<uint32_t> lv;  // fan-outs of levels 2..
     if (ctx->opt_s1 >= 0 || ctx->opt_s2 >= 0) {  // test hook: explicit split (powers of two)
         unsigned s1 = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_s1, 0), std::min(avail, 12u));
-        while (s1 > 0 && ((uint64_t)B << s1) > 4096) --s1;
+        while (s1 > 0 && ((uint64_t)nact << s1) > 4096) --s1;
         S1 = 1u << s1;
         unsigned s2 = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_s2, 0), std::min(avail - std::min(avail, s1), 11u));
         if (s2) lv.push_back(1u << s2);
@@ -200,7 +203,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
             if (lv.size() >= 5) break;
         }
     }
-    const uint32_t F1 = B * S1;
+    const uint32_t F1 = nact * S1;
     uint64_t nb = F1;  // fine bins after all levels
     uint64_t nb_parent_max = F1;
     for (uint32_t t : lv) {
@@ -243,13 +246,14 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (int rc = dalloc(ctx, &smallcount, 1)) return rc;
     HIPCHK(hipMemsetAsync(smallcount, 0, 4, ctx->stream));
     if (int rc = dalloc(ctx, &runlen, nrec / cap + nb + 2)) return rc;
-    if (int rc = dalloc(ctx, &bucket_off, B + 1)) return rc;
+    if (int rc = dalloc(ctx, &bucket_off, nact + 1)) return rc;
     HIPCHK(hipMemsetAsync(bigcount, 0, 4, ctx->stream));
     wt.mark(ctx, "mark+alloc");
 
     PassArgs a{};
     a.K = K;
     a.num_buckets = B;
+    a.bucket0 = b_first;
     a.S1 = S1;
     a.world = 1;
 
@@ -467,15 +471,15 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
                            (uint32_t)nb, (void *)other);
     }
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_bucket_offsets, dim3((B + 1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream,
-                       (const unsigned long long *)uoff, B, (uint32_t)(nb / B), bucket_off);
+    hipLaunchKernelGGL(k_bucket_offsets, dim3((nact + 1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream,
+                       (const unsigned long long *)uoff, nact, (uint32_t)(nb / nact), bucket_off);
     HIPCHK(hipGetLastError());
     tend(ctx);
-    std::vector<unsigned long long> h(B + 1);
-    HIPCHK(hipMemcpyAsync(h.data(), bucket_off, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> h(nact + 1);
+    HIPCHK(hipMemcpyAsync(h.data(), bucket_off, (size_t)(nact + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (unsigned i = 0; i <= B; ++i) ctx->bucket_off[i] = h[i];
-    ctx->n_records = h[B];
+    for (unsigned i = 0; i <= B; ++i) ctx->bucket_off[i] = i < b_first ? 0 : h[std::min<unsigned>(i - b_first, nact)];
+    ctx->n_records = h[nact];
     ctx->d_result_buf = other;
     ctx->d_result = other;
     wt.mark(ctx, "compact");
