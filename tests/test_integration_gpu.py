@@ -1,0 +1,70 @@
+"""The reference-side binding in action (integration/): the reference's own classes, compiled from /root/reference, running on top
+of kmers::KMerGpuCounter (a KMerCounter<RtSeq> subclass that calls libspades_mi355x.so).
+  * kmercount_gpu            = spades-kmercount's main with the counter swapped -> final_kmers equal to the reference counter's
+  * construction_gpu_counter = KMerGpuCounter -> DeBruijnExtensionIndexBuilder::BuildExtensionIndexFromKPOMers (boomphf MPHF over the
+                               bucket files the GPU wrote) -> UnbranchingPathExtractor  -> unitigs equal to the all-reference run
+The binaries are built in the container by integration/Makefile (they travel with the snapshot, like oracle/_ref)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "integration", "_build")
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _need(path):
+    if not os.path.exists(path):
+        pytest.skip(f"{path} was not built (needs /root/reference at build time)")
+    return path
+
+
+def _reads(seed, n, genome_len=20000, L=100):
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, genome_len)
+    out = []
+    for _ in range(n):
+        p = int(rng.integers(0, genome_len - L))
+        r = g[p:p + L].copy()
+        e = rng.random(L) < 0.01
+        r[e] = (r[e] + rng.integers(1, 4, int(e.sum()))) % 4
+        s = "".join("ACGT"[c] for c in r)
+        if rng.random() < 0.3:
+            s = s[:40] + "N" + s[41:]
+        if rng.random() < 0.5:
+            s = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        out.append(s)
+    return out
+
+
+@pytest.mark.parametrize("K", [21, 55])
+def test_reference_kmercount_main_on_the_gpu_counter(tmp_path, K):
+    exe, ref = _need(os.path.join(BUILD, "kmercount_gpu")), _need(os.path.join(REF, "ref_kmercount"))
+    reads = _reads(5, 3000)
+    fq = tmp_path / "r.fq"
+    fq.write_text("".join(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n" for i, r in enumerate(reads)))
+    txt = tmp_path / "r.txt"
+    txt.write_text("\n".join(reads) + "\n")
+    subprocess.check_call([exe, "-k", str(K), "-t", "2", "-w", str(tmp_path / "gpu"), str(fq)], stdout=subprocess.DEVNULL)
+    subprocess.check_call([ref, "A", str(K), "16", "0", str(txt), str(tmp_path / "cpu"), str(tmp_path / "cpu_final"), "2"],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    a, b = (tmp_path / "gpu" / "final_kmers").read_bytes(), (tmp_path / "cpu_final").read_bytes()
+    assert len(a) > 0 and a == b
+
+
+@pytest.mark.parametrize("k,threads", [(21, 1), (55, 3)])
+def test_reference_construction_consumes_the_gpu_counter(tmp_path, k, threads):
+    exe, ref = _need(os.path.join(BUILD, "construction_gpu_counter")), _need(os.path.join(REF, "ref_earlytip"))
+    reads = _reads(6, 2500)
+    txt = tmp_path / "r.txt"
+    txt.write_text("\n".join(reads) + "\n")
+    subprocess.check_call([exe, str(k), str(threads), str(txt), str(tmp_path / "gpu"), str(tmp_path / "gpu.txt")],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([ref, str(k), str(threads), "0", str(txt), str(tmp_path / "cpu"), str(tmp_path / "cpu.txt")],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    a, b = (tmp_path / "gpu.txt").read_text().split(), (tmp_path / "cpu.txt").read_text().split()
+    assert len(a) > 0
+    assert (a == b) if threads == 1 else (sorted(a) == sorted(b))  # the reference's order depends on its thread schedule
