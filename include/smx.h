@@ -157,6 +157,28 @@ int smx_build_graph(smx_ctx *ctx, unsigned k, unsigned num_buckets);
  * smx_graph_fill_coverage counts; per-rank raw coverages add up (smx_graph_copy_coverage -> all-reduce SUM ->
  * smx_graph_set_coverage), because edge coverage is a sum of per-(k+1)-mer counts (coverage_filling.hpp:17-55). */
 int smx_build_graph_from_records(smx_ctx *ctx, unsigned k, unsigned num_buckets, const void *d_kpomers, uint64_t n_records);
+/* Sharded construction (owner-side mask fill; precedent: hpcSPAdes counts per node and OR-reduces the masks,
+ * hpcspades/mpi/stages/construction_mpi.cpp:343-354, mpi/pipeline/partask_mpi.hpp:293). No rank holds the whole (k+1)-mer file:
+ *   1. sharded count of the canonical (k+1)-mers (smx_extract_partition -> all-to-all -> smx_count_records): the rank's shard is the
+ *      context's count result;
+ *   2. smx_graph_shard_updates: the extension updates of the shard — one (canonical k-mer, InOutMask bit) record of words_per_kmer + 1
+ *      uint64 per k-mer of every (k+1)-mer (DeBruijnKMerKMerSplitter + FillExtensionsFromIndex in one stream,
+ *      kmer_mph/kmer_splitters.hpp:138-207, extension_index/kmer_extension_index_builder.hpp:45-60) — grouped by the rank that owns the
+ *      k-mer's bucket, into a caller-provided HBM buffer of >= 2 x shard records; the caller runs the all-to-all;
+ *   3. smx_graph_shard_build: the owner sorts/uniques the k-mers it received (its bucket range of the k-mer file) and ORs the bits
+ *      into their InOutMask bytes; smx_graph_shard_info / smx_graph_shard_copy hand the shard out for the gather;
+ *   4. smx_build_graph_from_kmers: every rank builds the graph from the gathered compact structure {k-mer file, mask bytes}
+ *      (17 B per k-mer at k = 55): unitigs, loops, link records as in smx_build_graph. n_kpomers only feeds smx_graph_info.
+ * smx_graph_set_kpomers installs a (k+1)-mer file (sorted, bucket-major) for smx_graph_fill_coverage on a graph built this way. */
+int smx_graph_shard_updates(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsigned world, void *d_updates, uint64_t capacity_records,
+                            uint64_t *counts /* [world] */);
+int smx_graph_shard_build(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsigned world, unsigned rank, const void *d_updates,
+                          uint64_t n_updates);
+int smx_graph_shard_info(const smx_ctx *ctx, uint64_t *n_kmers, uint64_t *bucket_sizes /* [num_buckets] or NULL */);
+int smx_graph_shard_copy(const smx_ctx *ctx, void *d_kmers, void *d_masks);
+int smx_build_graph_from_kmers(smx_ctx *ctx, unsigned k, unsigned num_buckets, const void *d_kmers, const void *d_masks, uint64_t n_kmers,
+                               const uint64_t *bucket_sizes /* [num_buckets] */, uint64_t n_kpomers);
+int smx_graph_set_kpomers(smx_ctx *ctx, const void *d_kpomers, uint64_t n_kpomers, const uint64_t *bucket_sizes /* [num_buckets] */);
 int smx_graph_set_coverage(smx_ctx *ctx, const uint32_t *raw_coverage, uint64_t n_unitigs);
 /* info[8] = { #canonical (k+1)-mers, #canonical k-mers, #unitigs (incl. loops), #perfect loops, #vertices, #links
  * (valid after a GFA was written), total unitig nucleotides, words per k-mer } */

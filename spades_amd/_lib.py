@@ -52,6 +52,12 @@ def load():
         "smx_graph_copy_flanking": (C.c_int, [vp, u32p, u32p]),
         "smx_build_graph_from_records": (C.c_int, [vp, C.c_uint, C.c_uint, vp, C.c_uint64]),
         "smx_graph_set_coverage": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_uint64]),
+        "smx_graph_shard_updates": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, vp, C.c_uint64, u64p]),
+        "smx_graph_shard_build": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, C.c_uint64]),
+        "smx_graph_shard_info": (C.c_int, [vp, u64p, u64p]),
+        "smx_graph_shard_copy": (C.c_int, [vp, vp, vp]),
+        "smx_build_graph_from_kmers": (C.c_int, [vp, C.c_uint, C.c_uint, vp, vp, C.c_uint64, u64p, C.c_uint64]),
+        "smx_graph_set_kpomers": (C.c_int, [vp, vp, C.c_uint64, u64p]),
         "smx_copy_kmers_device": (C.c_int, [vp, vp]),
         "smx_submit_fastq_text": (C.c_int, [vp, C.c_char_p, C.c_uint64, C.c_int, u64p, u64p]),
         "smx_pinned_alloc": (vp, [C.c_size_t]),

@@ -559,6 +559,118 @@ int smx_build_graph_from_records(smx_ctx *ctx, unsigned k, unsigned num_buckets,
     return build_graph_impl(ctx, k, num_buckets, n_records ? d_kpomers : (const void *)&dummy, n_records);
 }
 
+static int finish_call(smx_ctx *ctx, int rc, bool graph) {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (rc == 0) {
+        tcollect(ctx);
+    } else {
+        for (auto &t : ctx->timings) {
+            (void)hipEventDestroy(t.e0);
+            (void)hipEventDestroy(t.e1);
+        }
+        ctx->timings.clear();
+    }
+    free_temps(ctx);
+    if (rc && graph) clear_graph(ctx);
+    return rc;
+}
+
+int smx_graph_shard_updates(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsigned world, void *d_updates, uint64_t capacity_records,
+                            uint64_t *counts) {
+    if (!ctx || !counts) return SMX_INVALID_PARAMETER;
+    if (k < 1 || k >= 128 || k % 2 == 0) return fail(ctx, SMX_INVALID_PARAMETER, "k-mer size must be odd and below 128");
+    if (world < 1 || world > 1024 || num_buckets < 1) return fail(ctx, SMX_INVALID_PARAMETER, "bad world/num_buckets");
+    if (ctx->n_records && (ctx->K != k + 1 || ctx->num_buckets != num_buckets || !ctx->d_result))
+        return fail(ctx, SMX_INVALID_PARAMETER, "the context does not hold a count of canonical %u-mers in %u buckets", k + 1, num_buckets);
+    if (ctx->n_records && !d_updates) return fail(ctx, SMX_INVALID_PARAMETER, "null update buffer");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    switch ((k + 32) / 32) {
+        case 1: rc = shard_updates<1>(ctx, k, num_buckets, world, d_updates, capacity_records, counts); break;
+        case 2: rc = shard_updates<2>(ctx, k, num_buckets, world, d_updates, capacity_records, counts); break;
+        case 3: rc = shard_updates<3>(ctx, k, num_buckets, world, d_updates, capacity_records, counts); break;
+        default: rc = shard_updates<4>(ctx, k, num_buckets, world, d_updates, capacity_records, counts); break;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    free_temps(ctx);
+    return rc;
+}
+
+int smx_graph_shard_build(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsigned world, unsigned rank, const void *d_updates, uint64_t n_updates) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    if (k < 1 || k >= 128 || k % 2 == 0) return fail(ctx, SMX_INVALID_PARAMETER, "k-mer size must be odd and below 128");
+    if (world < 1 || rank >= world || num_buckets < 1) return fail(ctx, SMX_INVALID_PARAMETER, "bad world/rank/num_buckets");
+    if (n_updates && !d_updates) return fail(ctx, SMX_INVALID_PARAMETER, "null updates");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->xnames.clear();
+    ctx->xms.clear();
+    int rc;
+    switch ((k + 32) / 32) {
+        case 1: rc = shard_build<1>(ctx, k, num_buckets, world, rank, d_updates, n_updates); break;
+        case 2: rc = shard_build<2>(ctx, k, num_buckets, world, rank, d_updates, n_updates); break;
+        case 3: rc = shard_build<3>(ctx, k, num_buckets, world, rank, d_updates, n_updates); break;
+        default: rc = shard_build<4>(ctx, k, num_buckets, world, rank, d_updates, n_updates); break;
+    }
+    return finish_call(ctx, rc, true);
+}
+
+int smx_graph_shard_info(const smx_ctx *ctx, uint64_t *n_kmers, uint64_t *bucket_sizes) {
+    if (!ctx || !n_kmers) return SMX_INVALID_PARAMETER;
+    *n_kmers = ctx->g_nkmers;
+    if (bucket_sizes)
+        for (unsigned b = 0; b < ctx->g_B; ++b) bucket_sizes[b] = ctx->g_kboff.size() > b + 1 ? ctx->g_kboff[b + 1] - ctx->g_kboff[b] : 0;
+    return SMX_OK;
+}
+
+int smx_graph_shard_copy(const smx_ctx *cctx, void *d_kmers, void *d_masks) {
+    smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    if (ctx->g_nkmers == 0) return SMX_OK;
+    if (!d_kmers || !d_masks) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(d_kmers, ctx->g_kmers, ctx->g_nkmers * ctx->g_nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_masks, ctx->g_mask, ctx->g_nkmers, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SMX_OK;
+}
+
+int smx_build_graph_from_kmers(smx_ctx *ctx, unsigned k, unsigned num_buckets, const void *d_kmers, const void *d_masks, uint64_t n_kmers,
+                               const uint64_t *bucket_sizes, uint64_t n_kpomers) {
+    if (!ctx || !bucket_sizes) return SMX_INVALID_PARAMETER;
+    if (k < 1 || k >= 128 || k % 2 == 0) return fail(ctx, SMX_INVALID_PARAMETER, "k-mer size must be odd and below 128");
+    if (n_kmers && (!d_kmers || !d_masks)) return fail(ctx, SMX_INVALID_PARAMETER, "null k-mer file");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->xnames.clear();
+    ctx->xms.clear();
+    int rc;
+    switch ((k + 32) / 32) {
+        case 1: rc = run_graph_from_kmers<1>(ctx, k, num_buckets, d_kmers, d_masks, n_kmers, bucket_sizes); break;
+        case 2: rc = run_graph_from_kmers<2>(ctx, k, num_buckets, d_kmers, d_masks, n_kmers, bucket_sizes); break;
+        case 3: rc = run_graph_from_kmers<3>(ctx, k, num_buckets, d_kmers, d_masks, n_kmers, bucket_sizes); break;
+        default: rc = run_graph_from_kmers<4>(ctx, k, num_buckets, d_kmers, d_masks, n_kmers, bucket_sizes); break;
+    }
+    rc = finish_call(ctx, rc, true);
+    if (rc == 0) ctx->g_nkpo = n_kpomers;
+    return rc;
+}
+
+// (k+1)-mer file for the coverage pass of a graph that was built without one on this rank (sharded construction): sorted, bucket-major
+int smx_graph_set_kpomers(smx_ctx *ctx, const void *d_kpomers, uint64_t n, const uint64_t *bucket_sizes) {
+    if (!ctx || !ctx->g_ready || !bucket_sizes) return SMX_INVALID_PARAMETER;
+    if (n && !d_kpomers) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    drop_kpo(ctx);
+    ctx->g_kpoboff.assign(ctx->g_B + 1, 0);
+    for (unsigned b = 0; b < ctx->g_B; ++b) ctx->g_kpoboff[b + 1] = ctx->g_kpoboff[b] + bucket_sizes[b];
+    if (ctx->g_kpoboff[ctx->g_B] != n) return fail(ctx, SMX_INVALID_PARAMETER, "bucket sizes do not add up to the number of (k+1)-mers");
+    ctx->g_nkpo = n;
+    if (n == 0) return SMX_OK;
+    if (int rc = dalloc(ctx, (uint64_t **)&ctx->g_kpo, (size_t)n * ctx->g_nw, false)) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->g_kpo, d_kpomers, (size_t)n * ctx->g_nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SMX_OK;
+}
+
 int smx_graph_set_coverage(smx_ctx *ctx, const uint32_t *raw_coverage, uint64_t n_edges) {
     if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
     if (n_edges != ctx->g_ne) return fail(ctx, SMX_INVALID_PARAMETER, "coverage array has %llu entries, graph has %llu unitigs",

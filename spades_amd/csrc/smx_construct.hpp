@@ -432,86 +432,23 @@ int upload_graph(smx_ctx *ctx) {
     return 0;
 }
 
+// Everything after the extension masks: early clippers (options), node table of the final masks, start de-edges, walks, perfect
+// loops, link records + vertices. tab: 2 * D0 + 2 entries; tab_valid: k_fill_tab has already filled it for the current masks.
 template <int NW>
-int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullptr, uint64_t n_kpo_recs = 0) {
-    clear_graph(ctx);
-    WallTrace gwt;
-    ctx->g_k = k;
-    ctx->g_nw = NW;
-    ctx->g_B = B;
-    ctx->gh.k = k;
-    ctx->gh.eoff.assign(1, 0);
-    // ---- 1. canonical (k+1)-mers -------------------------------------------------------------
-    if (kpo_recs) {  // multi-GPU: the (k+1)-mer file gathered from its owner ranks (any order; re-sorted here)
-        if (int rc = run_count<NW>(ctx, k + 1, SMX_MODE_ALL, B, kpo_recs, n_kpo_recs)) return rc;
-    } else {
-        if (int rc = count_reads<NW>(ctx, k + 1, SMX_MODE_CANONICAL, B)) return rc;
-    }
-    ctx->g_kpo = ctx->d_result_buf;
-    ctx->d_result_buf = ctx->d_result = nullptr;
-    if (int rc = adopt_result(ctx, &ctx->g_kpo, (size_t)ctx->n_records * NW * 8)) return rc;
-    ctx->g_nkpo = ctx->n_records;
-    ctx->g_kpoboff = ctx->bucket_off;
-    const uint64_t nkpo = ctx->g_nkpo;
-    ctx->g_kboff.assign(B + 1, 0);
-    gwt.mark(ctx, "g:kpo count");
-    if (nkpo == 0) {
-        ctx->g_host_valid = true;  // the empty graph
-        ctx->g_ready = true;
-        ctx->n_records = 0;
-        ctx->K = k;
-        ctx->bucket_off.assign(B + 1, 0);
-        return 0;
-    }
-    // ---- 2. canonical k-mers in k-mer-file order ----------------------------------------------
-    struct Prefix {  // stage names of the pipeline runs below tell which part of the construction they belong to
+int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint32_t *d_err, WallTrace &gwt) {
+    const uint64_t D0 = ctx->g_nkmers;
+    const unsigned grid = grid_for(2 * D0);
+    const smx::RankDir ixk = ctx->g_dir_kmers;
+    struct Prefix {
         smx_ctx *c;
         Prefix(smx_ctx *c_, const char *p) : c(c_) { c->tprefix = p; }
         ~Prefix() { c->tprefix.clear(); }
     };
-    {
-        Prefix pf(ctx, "kmers:");
-        if (int rc = derive_kmer_file<NW>(ctx, k, B)) return rc;
-    }
-    ctx->d_result = ctx->g_kmers;  // smx_copy_final_kmers() now yields the k-mer file
-    gwt.mark(ctx, "g:kmer file");
-    const uint64_t D0 = ctx->g_nkmers;
-    if (D0 >= (1ull << 60)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%llu k-mers exceed the node-id range", (unsigned long long)D0);
-    const unsigned grid = grid_for(2 * D0);
-    tbegin(ctx, "rank_dir");
-    if (int rc = build_rank_dir<NW>(ctx, ctx->g_kmers, D0, ctx->g_kboff, B, k, ctx->g_dir_kmers)) return rc;
-    tend(ctx);
-    // ---- 3. node table (extensions + successors) and the InOutMask bytes ------------------------
-    uint32_t *d_err;
-    if (int rc = dalloc(ctx, &d_err, 1)) return rc;
-    HIPCHK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
-    const smx::RankDir ixk = ctx->g_dir_kmers;
-    const size_t mask_bytes = (size_t)((D0 + 7) / 8 * 8 + 8);
-    if (int rc = dalloc(ctx, &ctx->g_mask, mask_bytes, false)) return rc;
-    node_t *tab;
-    if (int rc = dalloc(ctx, &tab, 2 * D0 + 2)) return rc;
-    HIPCHK(hipMemsetAsync(tab, 0, (size_t)(2 * D0 + 2) * 8, ctx->stream));
-    tbegin(ctx, "fill_masks");
-    hipLaunchKernelGGL((k_fill_tab<NW>), dim3(grid_for(nkpo)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kpo, nkpo, k, (const void *)ctx->g_kmers,
-                       ixk, tab, d_err);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_tab_masks, dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, (const node_t *)tab, D0, ctx->g_mask);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(ctx->g_mask + D0, 0, mask_bytes - D0, ctx->stream));
-    tend(ctx);
-    {
-        // the (k+1)-mer file is only needed again by -c; when HBM is short it goes now and the coverage pass recounts it
-        const size_t later = (size_t)D0 * 40;  // candidate and edge arrays of the walks, generously
-        const bool keep = ctx->opt_keep_kpo > 0 || (ctx->opt_keep_kpo < 0 && arena_avail(ctx) > later);
-        if (!keep) {
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            drop_kpo(ctx);
-        }
-    }
     node_t *succ = nullptr;  // successor table of the early clippers (their own format, by lookup)
     if (ctx->opt_early_at || ctx->opt_early_tip_bound > 0)
         if (int rc = dalloc(ctx, &succ, 2 * D0)) return rc;
-    bool clipped = false;
+    bool clipped = !tab_valid;
+
     // ---- 3a. early A/T remover (RNA pipelines: EarlyATClipper::run, stages/construction.cpp:317-326) --------------
     ctx->g_at_edges = ctx->g_at_tip_kmers = 0;
     if (ctx->opt_early_at) {
@@ -613,19 +550,20 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     }
     // ---- 4. start de-edges -----------------------------------------------------------------------
     const uint64_t ntiles = (D0 + CAND_TILE - 1) / CAND_TILE;
-    unsigned long long *tcnt, *toff, *counters;  // counters: [0] junction k-mers, [1] non-junction k-mers on kept paths, [2..3] loop k-mers
+    unsigned long long *tcnt, *toff, *counters;  // counters: [0] spare, [1] non-junction k-mers on kept paths, [2..3] loop k-mers, [4..] junction k-mers
     if (int rc = dalloc(ctx, &tcnt, ntiles)) return rc;
     if (int rc = dalloc(ctx, &toff, ntiles + 1)) return rc;
-    if (int rc = dalloc(ctx, &counters, 4)) return rc;
-    HIPCHK(hipMemsetAsync(counters, 0, 32, ctx->stream));
+    if (int rc = dalloc(ctx, &counters, 4 + CAND_NJ)) return rc;
+    HIPCHK(hipMemsetAsync(counters, 0, (4 + CAND_NJ) * 8, ctx->stream));
     tbegin(ctx, "candidates");
-    hipLaunchKernelGGL(k_cand_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, tcnt, counters);
+    hipLaunchKernelGGL(k_cand_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, tcnt, counters + 4);
     HIPCHK(hipGetLastError());
     if (int rc = scan_u64(ctx, tcnt, toff, ntiles)) return rc;
-    unsigned long long C = 0, n_junction = 0;
+    unsigned long long C = 0, n_junction = 0, h_nj[CAND_NJ];
     HIPCHK(hipMemcpyAsync(&C, toff + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&n_junction, counters, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h_nj, counters + 4, CAND_NJ * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < CAND_NJ; ++i) n_junction += h_nj[i];
     tend(ctx);
     gwt.mark(ctx, "g:masks+succ");
     uint64_t nkept = 0, ktotalw = 0;
@@ -857,6 +795,192 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     gwt.mark(ctx, "g:links");
     ctx->g_ready = true;
     return 0;
+}
+
+template <int NW>
+int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullptr, uint64_t n_kpo_recs = 0) {
+    clear_graph(ctx);
+    WallTrace gwt;
+    ctx->g_k = k;
+    ctx->g_nw = NW;
+    ctx->g_B = B;
+    ctx->gh.k = k;
+    ctx->gh.eoff.assign(1, 0);
+    // ---- 1. canonical (k+1)-mers -------------------------------------------------------------
+    if (kpo_recs) {  // multi-GPU: the (k+1)-mer file gathered from its owner ranks (any order; re-sorted here)
+        if (int rc = run_count<NW>(ctx, k + 1, SMX_MODE_ALL, B, kpo_recs, n_kpo_recs)) return rc;
+    } else {
+        if (int rc = count_reads<NW>(ctx, k + 1, SMX_MODE_CANONICAL, B)) return rc;
+    }
+    ctx->g_kpo = ctx->d_result_buf;
+    ctx->d_result_buf = ctx->d_result = nullptr;
+    if (int rc = adopt_result(ctx, &ctx->g_kpo, (size_t)ctx->n_records * NW * 8)) return rc;
+    ctx->g_nkpo = ctx->n_records;
+    ctx->g_kpoboff = ctx->bucket_off;
+    const uint64_t nkpo = ctx->g_nkpo;
+    ctx->g_kboff.assign(B + 1, 0);
+    gwt.mark(ctx, "g:kpo count");
+    if (nkpo == 0) {
+        ctx->g_host_valid = true;  // the empty graph
+        ctx->g_ready = true;
+        ctx->n_records = 0;
+        ctx->K = k;
+        ctx->bucket_off.assign(B + 1, 0);
+        return 0;
+    }
+    // ---- 2. canonical k-mers in k-mer-file order ----------------------------------------------
+    struct Prefix {  // stage names of the pipeline runs below tell which part of the construction they belong to
+        smx_ctx *c;
+        Prefix(smx_ctx *c_, const char *p) : c(c_) { c->tprefix = p; }
+        ~Prefix() { c->tprefix.clear(); }
+    };
+    {
+        Prefix pf(ctx, "kmers:");
+        if (int rc = derive_kmer_file<NW>(ctx, k, B)) return rc;
+    }
+    ctx->d_result = ctx->g_kmers;  // smx_copy_final_kmers() now yields the k-mer file
+    gwt.mark(ctx, "g:kmer file");
+    const uint64_t D0 = ctx->g_nkmers;
+    if (D0 >= (1ull << 60)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%llu k-mers exceed the node-id range", (unsigned long long)D0);
+    const unsigned grid = grid_for(2 * D0);
+    tbegin(ctx, "rank_dir");
+    if (int rc = build_rank_dir<NW>(ctx, ctx->g_kmers, D0, ctx->g_kboff, B, k, ctx->g_dir_kmers)) return rc;
+    tend(ctx);
+    // ---- 3. node table (extensions + successors) and the InOutMask bytes ------------------------
+    uint32_t *d_err;
+    if (int rc = dalloc(ctx, &d_err, 1)) return rc;
+    HIPCHK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    const smx::RankDir ixk = ctx->g_dir_kmers;
+    const size_t mask_bytes = (size_t)((D0 + 7) / 8 * 8 + 8);
+    if (int rc = dalloc(ctx, &ctx->g_mask, mask_bytes, false)) return rc;
+    node_t *tab;
+    if (int rc = dalloc(ctx, &tab, 2 * D0 + 2)) return rc;
+    HIPCHK(hipMemsetAsync(tab, 0, (size_t)(2 * D0 + 2) * 8, ctx->stream));
+    tbegin(ctx, "fill_masks");
+    hipLaunchKernelGGL((k_fill_tab<NW>), dim3(grid_for(nkpo)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kpo, nkpo, k, (const void *)ctx->g_kmers,
+                       ixk, tab, d_err);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_tab_masks, dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, (const node_t *)tab, D0, ctx->g_mask);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(ctx->g_mask + D0, 0, mask_bytes - D0, ctx->stream));
+    tend(ctx);
+    {
+        // the (k+1)-mer file is only needed again by -c; when HBM is short it goes now and the coverage pass recounts it
+        const size_t later = (size_t)D0 * 40;  // candidate and edge arrays of the walks, generously
+        const bool keep = ctx->opt_keep_kpo > 0 || (ctx->opt_keep_kpo < 0 && arena_avail(ctx) > later);
+        if (!keep) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            drop_kpo(ctx);
+        }
+    }
+    return graph_from_masks<NW>(ctx, k, tab, /*tab_valid=*/true, d_err, gwt);
+}
+
+// ---- sharded construction: owner-side mask fill, replicated compact structure --------------------------------
+// 1. extension updates of this rank's (k+1)-mer shard (= the context's current count result), grouped by the owner rank of the k-mer
+template <int NW>
+int shard_updates(smx_ctx *ctx, unsigned k, unsigned B, unsigned world, void *d_out, uint64_t capacity, uint64_t *counts) {
+    const uint64_t n = ctx->n_records;
+    if (2 * n > capacity) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "update buffer too small: need %llu records", (unsigned long long)(2 * n));
+    unsigned long long *hist, *off, *cur;
+    if (int rc = dalloc(ctx, &hist, world)) return rc;
+    if (int rc = dalloc(ctx, &off, world + 1)) return rc;
+    if (int rc = dalloc(ctx, &cur, world)) return rc;
+    HIPCHK(hipMemsetAsync(hist, 0, (size_t)world * 8, ctx->stream));
+    const size_t lds = (size_t)world * 16;
+    if (n) {
+        hipLaunchKernelGGL((k_upd_partition<NW, 0>), dim3(grid_for(n, 4096)), dim3(BLK), lds, ctx->stream, (const void *)ctx->d_result, n, k, B, world, hist, (void *)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    if (int rc = scan_u64(ctx, hist, off, world)) return rc;
+    HIPCHK(hipMemcpyAsync(cur, off, (size_t)world * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (n) {
+        hipLaunchKernelGGL((k_upd_partition<NW, 1>), dim3(grid_for(n, 4096)), dim3(BLK), lds, ctx->stream, (const void *)ctx->d_result, n, k, B, world, cur, d_out);
+        HIPCHK(hipGetLastError());
+    }
+    std::vector<unsigned long long> h(world);
+    HIPCHK(hipMemcpyAsync(h.data(), hist, (size_t)world * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (unsigned i = 0; i < world; ++i) counts[i] = h[i];
+    return 0;
+}
+// 2. owner side: the k-mers this rank owns (sorted-unique, its bucket range of the k-mer file) and their InOutMask bytes
+template <int NW>
+int shard_build(smx_ctx *ctx, unsigned k, unsigned B, unsigned world, unsigned rank, const void *d_upd, uint64_t n) {
+    clear_graph(ctx);
+    ctx->g_k = k;
+    ctx->g_nw = NW;
+    ctx->g_B = B;
+    ctx->g_kboff.assign(B + 1, 0);
+    const unsigned b0 = (unsigned)(((uint64_t)rank * B + world - 1) / world), b1 = (unsigned)(((uint64_t)(rank + 1) * B + world - 1) / world);
+    if (n == 0) return 0;
+    Rec<NW> *recs;
+    if (int rc = dalloc(ctx, &recs, n)) return rc;
+    hipLaunchKernelGGL((k_upd_strip<NW>), dim3(grid_for(n)), dim3(BLK), 0, ctx->stream, d_upd, n, (void *)recs);
+    HIPCHK(hipGetLastError());
+    if (int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, recs, n, nullptr, /*recs_reusable=*/true, false, false, b0, std::max(1u, b1 - b0))) return rc;
+    ctx->g_kmers = ctx->d_result_buf;
+    ctx->g_nkmers = ctx->n_records;
+    ctx->g_kboff = ctx->bucket_off;
+    ctx->d_result_buf = ctx->d_result = nullptr;
+    if (int rc = adopt_result(ctx, &ctx->g_kmers, (size_t)ctx->g_nkmers * NW * 8)) return rc;
+    const uint64_t D = ctx->g_nkmers;
+    if (int rc = build_rank_dir<NW>(ctx, ctx->g_kmers, D, ctx->g_kboff, B, k, ctx->g_dir_kmers)) return rc;
+    const size_t mask_bytes = (size_t)((D + 7) / 8 * 8 + 8);
+    if (int rc = dalloc(ctx, &ctx->g_mask, mask_bytes, false)) return rc;
+    HIPCHK(hipMemsetAsync(ctx->g_mask, 0, mask_bytes, ctx->stream));
+    uint32_t *d_err;
+    if (int rc = dalloc(ctx, &d_err, 1)) return rc;
+    HIPCHK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    hipLaunchKernelGGL((k_upd_apply<NW>), dim3(grid_for(n)), dim3(BLK), 0, ctx->stream, d_upd, n, (const void *)ctx->g_kmers, ctx->g_dir_kmers,
+                       (uint32_t *)ctx->g_mask, d_err);
+    HIPCHK(hipGetLastError());
+    unsigned herr = 0;
+    HIPCHK(hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost));
+    if (herr) return fail(ctx, SMX_DEVICE_ERROR, "%u extension updates did not find their k-mer in this rank's shard", herr);
+    free_temps(ctx);
+    return 0;
+}
+// 3. the graph from the gathered compact structure {k-mer file, InOutMask bytes} (replicated on every rank)
+template <int NW>
+int run_graph_from_kmers(smx_ctx *ctx, unsigned k, unsigned B, const void *d_kmers, const void *d_masks, uint64_t n, const uint64_t *bucket_sizes) {
+    clear_graph(ctx);
+    WallTrace gwt;
+    ctx->g_k = k;
+    ctx->g_nw = NW;
+    ctx->g_B = B;
+    ctx->gh.k = k;
+    ctx->gh.eoff.assign(1, 0);
+    ctx->g_kboff.assign(B + 1, 0);
+    for (unsigned b = 0; b < B; ++b) ctx->g_kboff[b + 1] = ctx->g_kboff[b] + bucket_sizes[b];
+    if (ctx->g_kboff[B] != n) return fail(ctx, SMX_INVALID_PARAMETER, "bucket sizes add up to %llu, %llu k-mers given", (unsigned long long)ctx->g_kboff[B], (unsigned long long)n);
+    ctx->n_records = n;
+    ctx->K = k;
+    ctx->nw = NW;
+    ctx->num_buckets = B;
+    ctx->bucket_off = ctx->g_kboff;
+    if (n == 0) {
+        ctx->g_host_valid = true;
+        ctx->g_ready = true;
+        return 0;
+    }
+    Rec<NW> *file;
+    if (int rc = dalloc(ctx, &file, n, false)) return rc;
+    ctx->g_kmers = file;
+    ctx->g_nkmers = n;
+    ctx->d_result = file;
+    const size_t mask_bytes = (size_t)((n + 7) / 8 * 8 + 8);
+    if (int rc = dalloc(ctx, &ctx->g_mask, mask_bytes, false)) return rc;
+    HIPCHK(hipMemsetAsync(ctx->g_mask, 0, mask_bytes, ctx->stream));
+    HIPCHK(hipMemcpyAsync(file, d_kmers, (size_t)n * NW * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->g_mask, d_masks, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (int rc = build_rank_dir<NW>(ctx, ctx->g_kmers, n, ctx->g_kboff, B, k, ctx->g_dir_kmers)) return rc;
+    uint32_t *d_err;
+    if (int rc = dalloc(ctx, &d_err, 1)) return rc;
+    HIPCHK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    node_t *tab;
+    if (int rc = dalloc(ctx, &tab, 2 * n + 2)) return rc;
+    return graph_from_masks<NW>(ctx, k, tab, /*tab_valid=*/false, d_err, gwt);
 }
 
 // -c: per-(k+1)-mer multiplicities over the resident reads, summed per edge (and over the edge flanks)

@@ -645,6 +645,7 @@ __global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const 
 
 // start de-edges per junction k-mer: out bits of kh, then out bits of !kh (AddStartDeEdges, :203-226), in k-mer-file order.
 // Tiles of CAND_TILE ranks (8 consecutive ranks per thread): per-tile totals, a scan over the tiles, then every tile places its own.
+constexpr int CAND_NJ = 256;  // partial junction counters
 constexpr int CAND_PER = 8;
 constexpr int CAND_TILE = BLK * CAND_PER;
 __device__ __forceinline__ unsigned cand_of_mask(unsigned m) { return mask_junction(m) ? (unsigned)(__popc(m & 15) + __popc(m >> 4)) : 0u; }
@@ -663,7 +664,7 @@ __global__ void __launch_bounds__(BLK) k_cand_tiles(const uint8_t *mask, uint64_
     block_excl_scan<uint32_t>(j_, scratch, &jt);
     if (threadIdx.x == 0) {
         tcnt[blockIdx.x] = tot;
-        if (jt) atomicAdd(njunction, (unsigned long long)jt);
+        if (jt) atomicAdd(&njunction[blockIdx.x & (CAND_NJ - 1)], (unsigned long long)jt);  // spread: one address takes ~88 atomics/us
     }
 }
 __global__ void __launch_bounds__(BLK) k_cand_expand(const uint8_t *mask, const unsigned long long *toff, uint64_t D0, unsigned long long *cand) {
@@ -900,6 +901,96 @@ __global__ void k_vertex_collect(const Rec<2> *keys, const unsigned long long *o
 __global__ void k_vertex_permute(const Rec<2> *vkeys_sorted, const unsigned long long *vpos, uint64_t nv, unsigned long long *vstart) {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nv; j += (uint64_t)gridDim.x * blockDim.x)
         vstart[j] = vpos[vkeys_sorted[j].w[1]];
+}
+
+// ---- sharded construction: owner-side mask fill -----------------------------------------------------------------
+// Every rank holds a shard of the (k+1)-mer file. A (k+1)-mer sets one InOutMask bit in each of its two k-mers, and those live on
+// the ranks that own THEIR buckets: the updates travel there in one all-to-all (precedent: hpcSPAdes counts per node and OR-reduces
+// the masks, construction_mpi.cpp:343-354, partask_mpi.hpp:293). Update record = canonical k-mer (NW words) + one word = the bit.
+// Rank r owns buckets [ceil(r*B/world), ceil((r+1)*B/world)), i.e. owner(b) = floor(b*world/B).
+template <int NW>
+struct Upd {
+    uint64_t w[NW + 1];
+};
+template <int NW>
+__device__ __forceinline__ void upd_of_kpo(const Rec<NW> &x, unsigned k, Upd<NW> &up, Upd<NW> &us) {
+    const unsigned pn = rec_nucl<NW>(x, 0), nn = rec_nucl<NW>(x, k);
+    unsigned prc, src;
+    const Rec<NW> p = rec_canon<NW>(rec_prefix<NW>(x, k), k, prc), s = rec_canon<NW>(rec_suffix<NW>(x), k, src);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        up.w[i] = p.w[i];
+        us.w[i] = s.w[i];
+    }
+    up.w[NW] = prc ? 7 - nn : nn;       // out[prefix] |= bit(x_k), mirrored for a non-minimal key (inout_mask.hpp:92-94)
+    us.w[NW] = src ? 3 - pn : pn + 4;   // in[suffix] |= bit(x_0)
+}
+template <int NW>
+__device__ __forceinline__ uint32_t upd_owner(const Upd<NW> &u, uint32_t B, uint32_t world) {
+    Rec<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = u.w[i];
+    return (uint32_t)(((uint64_t)bucket_of(xxh3_rec<NW>(r), B) * world) / B);
+}
+// pass 0: updates per owner; pass 1: place them (LDS counters per owner and tile, one reservation per owner and tile)
+template <int NW, int PASS>
+__global__ void __launch_bounds__(BLK) k_upd_partition(const void *kpo_, uint64_t n, unsigned k, uint32_t B, uint32_t world,
+                                                       unsigned long long *hist_or_cursor, void *out_) {
+    extern __shared__ unsigned long long lds_u[];  // [world] counts, then [world] bases
+    unsigned long long *lcnt = lds_u, *lbase = lds_u + world;
+    const Rec<NW> *kpo = (const Rec<NW> *)kpo_;
+    Upd<NW> *out = (Upd<NW> *)out_;
+    for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n; base += (uint64_t)gridDim.x * BLK) {
+        for (uint32_t t = threadIdx.x; t < world; t += BLK) lcnt[t] = 0;
+        __syncthreads();
+        const uint64_t i = base + threadIdx.x;
+        Upd<NW> up, us;
+        uint32_t op = 0, os = 0;
+        unsigned long long ip = 0, is = 0;
+        if (i < n) {
+            upd_of_kpo<NW>(kpo[i], k, up, us);
+            op = upd_owner<NW>(up, B, world);
+            os = upd_owner<NW>(us, B, world);
+            ip = atomicAdd(&lcnt[op], 1ull);
+            is = atomicAdd(&lcnt[os], 1ull);
+        }
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < world; t += BLK)
+            if (lcnt[t]) lbase[t] = atomicAdd(&hist_or_cursor[t], lcnt[t]);
+        __syncthreads();
+        if (PASS == 1 && i < n) {
+            out[lbase[op] + ip] = up;
+            out[lbase[os] + is] = us;
+        }
+        __syncthreads();
+    }
+}
+template <int NW>
+__global__ void k_upd_strip(const void *upd_, uint64_t n, void *out_) {
+    const Upd<NW> *upd = (const Upd<NW> *)upd_;
+    Rec<NW> *out = (Rec<NW> *)out_;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        Rec<NW> r;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) r.w[w] = upd[i].w[w];
+        out[i] = r;
+    }
+}
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_upd_apply(const void *upd_, uint64_t n, const void *kmers_, RankDir ix, uint32_t *mask32, uint32_t *err) {
+    const Upd<NW> *upd = (const Upd<NW> *)upd_;
+    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        Rec<NW> r;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) r.w[w] = upd[i].w[w];
+        const node_t rk = kmer_rank<NW, true>(kmers, ix, r);
+        if (rk == NODE_NONE) {
+            atomicAdd(err, 1u);
+            continue;
+        }
+        atomicOr(&mask32[rk >> 2], (1u << (upd[i].w[NW] & 7)) << ((rk & 3) * 8));
+    }
 }
 
 // ---- packed unitigs <-> other forms -----------------------------------------------------------------------------------------

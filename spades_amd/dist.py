@@ -67,6 +67,40 @@ class GpuEngine:
         return dict(n_kpomers=info[0], n_kmers=info[1], n_unitigs=info[2], n_loops=info[3], n_vertices=info[4],
                     unitig_bases=info[6], words=info[7])
 
+    # -- sharded construction (owner-side mask fill) --
+    def shard_updates(self, k: int, nb: int, world: int, buf: torch.Tensor, capacity: int):
+        counts = (C.c_uint64 * world)()
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_shard_updates(self.ctx._h, k, nb, world, buf.data_ptr(), capacity, counts))
+        return [int(c) for c in counts]
+
+    def shard_build(self, k: int, nb: int, world: int, rank: int, buf: torch.Tensor, n: int):
+        h = self.ctx._h
+        _chk(h, self.ctx.lib.smx_graph_shard_build(h, k, nb, world, rank, buf.data_ptr(), n))
+        nk = C.c_uint64()
+        sizes = (C.c_uint64 * nb)()
+        _chk(h, self.ctx.lib.smx_graph_shard_info(h, C.byref(nk), sizes))
+        return nk.value, [int(x) for x in sizes]
+
+    def shard_copy(self, kmers: torch.Tensor, masks: torch.Tensor):
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_shard_copy(self.ctx._h, kmers.data_ptr(), masks.data_ptr()))
+
+    def alloc_bytes(self, n: int, dev):
+        return torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+
+    def build_graph_from_kmers(self, k: int, nb: int, kmers: torch.Tensor, masks: torch.Tensor, n: int, bucket_sizes, n_kpomers: int):
+        h = self.ctx._h
+        bs = (C.c_uint64 * nb)(*bucket_sizes)
+        _chk(h, self.ctx.lib.smx_build_graph_from_kmers(h, k, nb, kmers.data_ptr(), masks.data_ptr(), n, bs, n_kpomers))
+        info = (C.c_uint64 * 8)()
+        _chk(h, self.ctx.lib.smx_graph_info(h, info))
+        return dict(n_kpomers=info[0], n_kmers=info[1], n_unitigs=info[2], n_loops=info[3], n_vertices=info[4],
+                    unitig_bases=info[6], words=info[7])
+
+    def set_kpomers(self, buf: torch.Tensor, n: int, bucket_sizes):
+        nb = len(bucket_sizes)
+        bs = (C.c_uint64 * nb)(*bucket_sizes)
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_set_kpomers(self.ctx._h, buf.data_ptr(), n, bs))
+
     def local_raw_coverage(self, n_unitigs: int) -> torch.Tensor:
         h = self.ctx._h
         _chk(h, self.ctx.lib.smx_graph_fill_coverage(h))
@@ -79,35 +113,30 @@ class GpuEngine:
         _chk(self.ctx._h, self.ctx.lib.smx_graph_set_coverage(self.ctx._h, C.cast(cov.data_ptr(), C.POINTER(C.c_uint32)), cov.numel()))
 
 
-def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
-    """One step of the sharded path on this rank. Returns the owner-side result dict of the engine
-    (+ 'sent'/'received' record counts). Collective: every rank must call it."""
-    nw = (K + 31) // 32
-    n_local = engine.extract_count(K)
-    send = engine.alloc(n_local * nw, dev)
-    counts = engine.extract_partition(K, nb, world, send, n_local)
-    n_sent = sum(counts)  # < n_local when the engine pre-dedupes its shard before the exchange
+def _exchange(engine, send: torch.Tensor, counts, wpr: int, rank: int, world: int, dev):
+    """ONE all-to-all of records of `wpr` int64 words: counts[p] records go to rank p. Returns (recv tensor, records received).
+    Splits are capped at XCHG_LIMIT elements per (pair, round): one all_to_all_single of a 30 GB buffer (3.8 G int64 elements)
+    silently truncates on this stack (measured: tail left untouched), so large segments go in several rounds of views (no staging
+    copies); every pair still moves each record exactly once."""
+    n_sent = sum(counts)
     cnt_t = torch.tensor(counts, dtype=torch.int64, device=dev)
     rcv_t = torch.empty_like(cnt_t)
     dist.all_to_all_single(rcv_t, cnt_t)
     rcounts = [int(c) for c in rcv_t.tolist()]
     n_recv = sum(rcounts)
-    recv = engine.alloc(n_recv * nw, dev)
-    # The exchange proper. Splits are capped at XCHG_LIMIT elements per (pair, round): one all_to_all_single of a
-    # 30 GB buffer (3.8 G int64 elements) silently truncates on this stack (measured: tail left untouched), so large
-    # segments go in several rounds of views (no staging copies); every pair still moves each record exactly once.
+    recv = engine.alloc(n_recv * wpr, dev)
     soff = [0]
     for c in counts:
-        soff.append(soff[-1] + c * nw)
+        soff.append(soff[-1] + c * wpr)
     roff = [0]
     for c in rcounts:
-        roff.append(roff[-1] + c * nw)
-    mx = torch.tensor([max(counts) * nw if counts else 0], dtype=torch.int64, device=dev)
+        roff.append(roff[-1] + c * wpr)
+    mx = torch.tensor([max(counts) * wpr if counts else 0], dtype=torch.int64, device=dev)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     rounds = max(1, -(-int(mx.item()) // XCHG_LIMIT))
     if rounds == 1:
-        dist.all_to_all_single(recv[:n_recv * nw], send[:n_sent * nw],
-                               output_split_sizes=[c * nw for c in rcounts], input_split_sizes=[c * nw for c in counts])
+        dist.all_to_all_single(recv[:n_recv * wpr], send[:n_sent * wpr],
+                               output_split_sizes=[c * wpr for c in rcounts], input_split_sizes=[c * wpr for c in counts])
     else:
         # grouped point-to-point rounds on views (ncclSend/ncclRecv pairs under one group on RCCL): every pair has its own
         # xGMI link, there is no ring to serialise on, and no staging copy is needed
@@ -128,6 +157,20 @@ def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
+    if dev.type == "cuda":  # the library runs on its own stream: the received records must have landed before it reads them
+        torch.cuda.current_stream(dev).synchronize()
+    return recv, n_recv
+
+
+def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
+    """One step of the sharded path on this rank. Returns the owner-side result dict of the engine
+    (+ 'sent'/'received' record counts). Collective: every rank must call it."""
+    nw = (K + 31) // 32
+    n_local = engine.extract_count(K)
+    send = engine.alloc(n_local * nw, dev)
+    counts = engine.extract_partition(K, nb, world, send, n_local)
+    n_sent = sum(counts)  # < n_local when the engine pre-dedupes its shard before the exchange
+    recv, n_recv = _exchange(engine, send, counts, nw, rank, world, dev)
     res = engine.count_records(K, nb, recv, n_recv)
     res["sent"], res["received"] = n_sent, n_recv
     res["instances"] = n_local  # k-mer instances extracted from this rank's reads
@@ -142,36 +185,75 @@ def _bcast_chunks(t: torch.Tensor, a: int, b: int, src: int):
         a = e
 
 
+def _gather_shards(engine, mine: torch.Tensor, n_mine: int, per_rank, unit: int, rank: int, world: int, dev, alloc):
+    """all ranks end with the concatenation (rank order) of every rank's `n * unit` elements; mine = this rank's part"""
+    off = [0]
+    for c in per_rank:
+        off.append(off[-1] + c * unit)
+    full = alloc(off[-1], dev)
+    if n_mine:
+        full[off[rank]:off[rank + 1]].copy_(mine[:n_mine * unit])
+    for r in range(world):
+        _bcast_chunks(full, off[r], off[r + 1], r)
+    return full
+
+
 def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev, coverage: bool = False):
-    """Construction on `world` ranks (collective). Counting of the canonical (k+1)-mers is sharded exactly like
-    sharded_count; the owners' sorted-unique arrays are then all-gathered (bucket-major, so the concatenation in rank
-    order IS the (k+1)-mer file) and every rank derives the same k-mer file, masks, unitigs and links from it — the
-    replicated-lookup variant of SURVEY.md §8e (unitig walks cross owners at every step). Coverage (-c) stays sharded:
-    each rank counts its own reads against the replicated (k+1)-mer file, raw edge coverages are all-reduced (SUM mod 2^32).
-    Every rank ends with the same graph; rank 0 normally writes it. Returns the engine's graph info dict."""
+    """Construction on `world` ranks (collective), owner-side mask fill:
+      1. sharded count of the canonical (k+1)-mers (sharded_count): every rank owns a bucket range of that file;
+      2. every rank turns its shard into extension updates (canonical k-mer, InOutMask bit), grouped by the owner of the K-MER, and
+         a second all-to-all delivers them: the mask fill never sees more than the rank's own shard;
+      3. the owners sort/unique their k-mers and OR the bits into the mask bytes;
+      4. the compact structure {k-mer file, masks} (bucket-major, so rank order IS file order) is gathered and every rank derives the
+         same unitigs and link records from it (unitig walks cross owners at every step).
+    No rank holds the whole (k+1)-mer file — unless coverage (-c) is asked for: the counters of the coverage pass are keyed by
+    (k+1)-mer, so the file is gathered for that pass only; each rank counts its own reads and the raw edge coverages are
+    all-reduced (SUM mod 2^32). Every rank ends with the same graph; rank 0 normally writes it. Returns the engine's graph info."""
     K1, nb = k + 1, 10 * threads
     nw = (K1 + 31) // 32
     res = sharded_count(engine, K1, nb, rank, world, dev)
-    mine = torch.tensor([res["distinct"]], dtype=torch.int64, device=dev)
-    every = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(every, mine)
-    counts = [int(c.item()) for c in every]
-    off = [0]
-    for c in counts:
-        off.append(off[-1] + c * nw)
-    full = engine.alloc(off[-1], dev)
-    if counts[rank]:
-        full[off[rank]:off[rank + 1]].copy_(engine.result_tensor(counts[rank] * nw, dev)[:counts[rank] * nw])
-    for r in range(world):
-        _bcast_chunks(full, off[r], off[r + 1], r)
-    info = engine.build_graph_from_records(k, nb, full, sum(counts))
-    del full
+    n_kpo = res["distinct"]
+    kpo_sizes = res["bucket_sizes"]
+    kpo_mine = engine.result_tensor(n_kpo * nw, dev) if coverage else None  # the count result is consumed by the next steps
+    # 2. extension updates -> owners of the k-mers
+    upd = engine.alloc(2 * n_kpo * (nw + 1), dev)
+    ucounts = engine.shard_updates(k, nb, world, upd, 2 * n_kpo)
+    recv, n_recv = _exchange(engine, upd, ucounts, nw + 1, rank, world, dev)
+    del upd
+    # 3. owner side
+    n_kmers, ksizes = engine.shard_build(k, nb, world, rank, recv, n_recv)
+    del recv
+    # 4. gather {k-mers, masks}
+    me = torch.tensor([n_kmers, n_kpo] + ksizes + kpo_sizes, dtype=torch.int64, device=dev)
+    every = [torch.empty_like(me) for _ in range(world)]
+    dist.all_gather(every, me)
+    every = [e.tolist() for e in every]
+    kmers_per_rank = [int(e[0]) for e in every]
+    kpo_per_rank = [int(e[1]) for e in every]
+    g_ksizes = [sum(int(e[2 + b]) for e in every) for b in range(nb)]
+    g_psizes = [sum(int(e[2 + nb + b]) for e in every) for b in range(nb)]
+    my_k = engine.alloc(n_kmers * nw, dev)
+    my_m = engine.alloc_bytes(n_kmers, dev)
+    engine.shard_copy(my_k, my_m)
+    full_k = _gather_shards(engine, my_k, n_kmers, kmers_per_rank, nw, rank, world, dev, engine.alloc)
+    full_m = _gather_shards(engine, my_m, n_kmers, kmers_per_rank, 1, rank, world, dev, engine.alloc_bytes)
+    del my_k, my_m
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+    info = engine.build_graph_from_kmers(k, nb, full_k, full_m, sum(kmers_per_rank), g_ksizes, sum(kpo_per_rank))
+    del full_k, full_m
     if coverage:
+        full_p = _gather_shards(engine, kpo_mine, n_kpo, kpo_per_rank, nw, rank, world, dev, engine.alloc)
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        engine.set_kpomers(full_p, sum(kpo_per_rank), g_psizes)
+        del full_p
         cov = engine.local_raw_coverage(info["n_unitigs"]).to(torch.int64) & 0xFFFFFFFF
         cov = cov.to(dev)
         dist.all_reduce(cov, op=dist.ReduceOp.SUM)
         cov = (cov & 0xFFFFFFFF).to("cpu")
         cov = torch.where(cov >= 2 ** 31, cov - 2 ** 32, cov).to(torch.int32)  # uint32 bit pattern
         engine.set_raw_coverage(cov)
-    info["kpomers_per_rank"] = counts
+    info["kpomers_per_rank"] = kpo_per_rank
+    info["kmers_per_rank"] = kmers_per_rank
     return info

@@ -110,7 +110,7 @@ def test_sharded_count_gloo(K, mode, nb, limit, world):
 
 
 class OracleGraphEngine(OracleEngine):
-    """adds the construction half of the GpuEngine contract (replicated graph, sharded coverage)"""
+    """adds the construction half of the GpuEngine contract (owner-side mask fill, gathered compact structure, sharded coverage)"""
 
     def __init__(self, reads, all_reads):
         super().__init__(reads, "B")
@@ -119,14 +119,71 @@ class OracleGraphEngine(OracleEngine):
     def result_tensor(self, n_words, dev):
         return torch.from_numpy(self.result.reshape(-1).view(np.int64).copy())
 
-    def build_graph_from_records(self, k, nb, buf, n):
+    # -- sharded construction (owner-side mask fill): the same contract as GpuEngine, oracle arithmetic --
+    def alloc_bytes(self, n, dev):
+        return torch.empty(max(n, 1), dtype=torch.uint8)
+
+    def shard_updates(self, k, nb, world, buf, capacity):
+        """extension updates of this rank's (k+1)-mer shard (self.result), grouped by the owner of the k-mer"""
         from oracle import oracle
-        nw = (k + 1 + 31) // 32
-        self.gathered = buf[:n * nw].numpy().view(np.uint64).reshape(n, nw).copy()
+        tr = str.maketrans("ACGT", "TGCA")
+        nwk = (k + 31) // 32
+        upd = []
+        for rec in self.result:
+            x = oracle.kmer_to_string(rec, k + 1)
+            pn, nn = "ACGT".index(x[0]), "ACGT".index(x[k])
+            for km, fwd_bit, rc_bit in ((x[:k], nn, 7 - nn), (x[1:], pn + 4, 3 - pn)):
+                r = km[::-1].translate(tr)
+                canon, bit = (km, fwd_bit) if km <= r else (r, rc_bit)
+                w = oracle.kmer_from_string(canon)
+                owner = oracle.bucket(w, k, nb) * world // nb
+                upd.append((owner, tuple(int(v) for v in w) + (bit,)))
+        upd.sort(key=lambda u: u[0])
+        flat = np.array([u[1] for u in upd], dtype=np.uint64).reshape(-1)
+        assert len(upd) <= capacity
+        buf[:len(flat)] = torch.from_numpy(flat.view(np.int64).copy())
+        return [sum(1 for u in upd if u[0] == r) for r in range(world)]
+
+    def shard_build(self, k, nb, world, rank, buf, n):
+        from oracle import oracle
+        nwk = (k + 31) // 32
+        rec = buf[:n * (nwk + 1)].numpy().view(np.uint64).reshape(n, nwk + 1)
+        masks = {}
+        for r in rec:
+            key = (oracle.bucket(r[:nwk], k, nb),) + tuple(int(v) for v in r[:nwk])
+            masks[key] = masks.get(key, 0) | (1 << int(r[nwk]))
+        keys = sorted(masks)
+        lo, hi = (rank * nb + world - 1) // world, ((rank + 1) * nb + world - 1) // world
+        assert all(lo <= key[0] < hi for key in keys)  # only k-mers of the rank's own buckets arrive
+        self.shard_kmers = np.array([key[1:] for key in keys], dtype=np.uint64).reshape(-1, nwk)
+        self.shard_masks = np.array([masks[key] for key in keys], dtype=np.uint8)
+        self.shard_updates_seen = n
+        sizes = [0] * nb
+        for key in keys:
+            sizes[key[0]] += 1
+        return len(keys), sizes
+
+    def shard_copy(self, kmers, masks):
+        kmers[:self.shard_kmers.size] = torch.from_numpy(self.shard_kmers.reshape(-1).view(np.int64).copy())
+        masks[:self.shard_masks.size] = torch.from_numpy(self.shard_masks.copy())
+
+    def build_graph_from_kmers(self, k, nb, kmers, masks, n, bucket_sizes, n_kpomers):
+        from oracle import oracle
+        nw = (k + 31) // 32
         self.k = k
         self.g = oracle.build_graph(self.all_reads, k, nb, coverage=True)
+        # the gathered compact structure must be the reference's k-mer file and its InOutMask bytes
+        self.gathered_kmers = kmers[:n * nw].numpy().view(np.uint64).reshape(n, nw).copy()
+        self.gathered_masks = masks[:n].numpy().copy()
+        assert self.gathered_kmers.tobytes() == self.g["kmers"].tobytes()
+        assert (self.gathered_masks == self.g["masks"]).all()
+        assert sum(bucket_sizes) == n and n_kpomers == self.g["n_kpomers"]
         return dict(n_kpomers=self.g["n_kpomers"], n_kmers=len(self.g["kmers"]), n_unitigs=len(self.g["unitigs"]),
                     n_loops=self.g["n_loops"], n_vertices=self.g["n_vertices"], unitig_bases=0, words=nw)
+
+    def set_kpomers(self, buf, n, bucket_sizes):
+        nw = (self.k + 1 + 31) // 32
+        self.gathered = buf[:n * nw].numpy().view(np.uint64).reshape(n, nw).copy()
 
     def local_raw_coverage(self, n_unitigs):
         # (k+1)-mer instances of this rank's reads (+RC), per unitig; a (k+1)-mer and its RC are the same canonical key
@@ -161,7 +218,8 @@ def _graph_worker(rank, world, port, k, threads, q):
     reads = read_lines("reads_small.txt")[:120]
     eng = OracleGraphEngine(reads[rank::world], reads)
     info = smx_dist.sharded_build_graph(eng, k, threads, rank, world, torch.device("cpu"), coverage=True)
-    q.put((rank, eng.gathered.tobytes(), eng.cov.tobytes(), info["kpomers_per_rank"], eng.g["gfa"]))
+    q.put((rank, eng.gathered.tobytes(), eng.cov.tobytes(), info["kpomers_per_rank"], eng.g["gfa"], len(eng.result), eng.shard_updates_seen,
+           info["kmers_per_rank"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -182,7 +240,10 @@ def test_sharded_build_graph_world2_gloo():
     reads = read_lines("reads_small.txt")[:120]
     ref, _ = oracle.count(reads, k + 1, "B", 10 * threads)
     kc = np.array([int(l.split("KC:i:")[1]) for l in got[0][4].splitlines() if l.startswith("S\t")], dtype=np.uint32)
-    for rank, gathered, cov, per_rank, _ in got:
-        assert gathered == ref.tobytes()  # every rank holds the reference's (k+1)-mer file
+    for rank, gathered, cov, per_rank, _, n_shard, n_upd, kmers_per_rank in got:
+        assert gathered == ref.tobytes()  # (for -c only) every rank holds the reference's (k+1)-mer file
         assert sum(per_rank) == len(ref)
+        assert n_shard == per_rank[rank] < len(ref)  # the mask fill of a rank started from ITS shard of the (k+1)-mer file ...
         assert (np.frombuffer(cov, dtype=np.uint32) == kc).all()  # all-reduced sharded coverage == reference KC tags
+    assert sum(g[6] for g in got) == 2 * len(ref)  # ... and every (k+1)-mer sent exactly two extension updates
+    assert all(0 < c for c in got[0][7])  # both ranks own a part of the k-mer file (its assembly is asserted inside the engine)

@@ -129,3 +129,86 @@ def test_two_rank_construction_through_the_c_abi(k, t, tmp_path):
         gb.write_gfa(out)
         assert open(out).read() == want
         gb.ctx.close()
+
+
+@pytest.mark.parametrize("k,t", [(21, 1), (21, 3), (55, 3)])
+def test_two_rank_sharded_mask_fill_through_the_c_abi(k, t, tmp_path):
+    """The world-2 data flow of sharded_build_graph (owner-side mask fill) replayed in one process on one GPU: two contexts = two
+    ranks, the collectives replaced by tensor copies. (k+1)-mer shards -> extension updates grouped by k-mer owner -> owner-side
+    k-mer shard + masks -> gathered compact structure -> graph on BOTH ranks; coverage through the gathered (k+1)-mer file.
+    Both ranks must write the reference's `spades-gbuilder -c` bytes, and the gathered structure must be the single-GPU k-mer file."""
+    import torch
+    from spades_amd import dist as smx_dist
+    from spades_amd.gbuilder import GraphBuilder
+    dev = torch.device("cuda", 0)
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    world, K1, nb = 2, k + 1, 10 * t
+    nw = (K1 + 31) // 32
+    gbs = [GraphBuilder(k, t) for _ in range(world)]
+    engs = []
+    for r, gb in enumerate(gbs):
+        gb.push_back_reads(reads[r::world])
+        engs.append(smx_dist.GpuEngine(gb.ctx, "B"))
+
+    def all_to_all(sends, counts, wpr):
+        out = []
+        for r in range(world):
+            segs = []
+            for s_ in range(world):
+                a = sum(counts[s_][:r]) * wpr
+                segs.append(sends[s_][a:a + counts[s_][r] * wpr])
+            n = sum(counts[s_][r] for s_ in range(world))
+            out.append((torch.cat(segs) if n else engs[r].alloc(0, dev), n))
+        return out
+
+    sends, counts = [], []
+    for e in engs:
+        n = e.extract_count(K1)
+        buf = e.alloc(n * nw, dev)
+        counts.append(e.extract_partition(K1, nb, world, buf, n))
+        sends.append(buf)
+    kpo_shards, kpo_sizes, usends, ucounts = [], [], [], []
+    for r, (recv, n) in enumerate(all_to_all(sends, counts, nw)):
+        res = engs[r].count_records(K1, nb, recv, n)
+        kpo_shards.append(engs[r].result_tensor(res["distinct"] * nw, dev)[:res["distinct"] * nw].clone())
+        kpo_sizes.append(res["bucket_sizes"])
+        ub = engs[r].alloc(2 * res["distinct"] * (nw + 1), dev)
+        ucounts.append(engs[r].shard_updates(k, nb, world, ub, 2 * res["distinct"]))
+        assert sum(ucounts[-1]) == 2 * res["distinct"]
+        usends.append(ub)
+    shards, ksizes = [], []
+    for r, (recv, n) in enumerate(all_to_all(usends, ucounts, nw + 1)):
+        nk, sz = engs[r].shard_build(k, nb, world, r, recv, n)
+        km, mk = engs[r].alloc(nk * nw, dev), engs[r].alloc_bytes(nk, dev)
+        engs[r].shard_copy(km, mk)
+        shards.append((km[:nk * nw], mk[:nk], nk))
+        ksizes.append(sz)
+    full_k = torch.cat([s_[0] for s_ in shards])
+    full_m = torch.cat([s_[1] for s_ in shards])
+    n_k = sum(s_[2] for s_ in shards)
+    g_ks = [sum(z[b] for z in ksizes) for b in range(nb)]
+    g_ps = [sum(z[b] for z in kpo_sizes) for b in range(nb)]
+    full_p = torch.cat(kpo_shards)
+    # the gathered compact structure is the k-mer file + masks of a single-GPU build on all reads
+    ref = GraphBuilder(k, t)
+    ref.push_back_reads(reads)
+    ref.build()
+    rk, rm = ref.kmers()
+    assert n_k == len(rk) and (full_k.cpu().numpy().view(np.uint64).reshape(-1, nw) == rk).all() and (full_m.cpu().numpy() == rm).all()
+    ref.ctx.close()
+    covs, infos = [], []
+    for e in engs:
+        info = e.build_graph_from_kmers(k, nb, full_k, full_m, n_k, g_ks, full_p.numel() // nw)
+        e.set_kpomers(full_p, full_p.numel() // nw, g_ps)
+        covs.append(e.local_raw_coverage(info["n_unitigs"]).to(torch.int64) & 0xFFFFFFFF)
+        infos.append(info)
+    total = (sum(covs) & 0xFFFFFFFF)
+    total = torch.where(total >= 2 ** 31, total - 2 ** 32, total).to(torch.int32)
+    want = _golden(f"graphcov_small_k{k}_t{t}.gfa")
+    for r, (gb, e) in enumerate(zip(gbs, engs)):
+        e.set_raw_coverage(total)
+        gb.adopt(infos[r])
+        out = os.path.join(str(tmp_path), f"s{r}.gfa")
+        gb.write_gfa(out)
+        assert open(out).read() == want
+        gb.ctx.close()
