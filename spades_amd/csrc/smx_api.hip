@@ -96,6 +96,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "derive_batches")) ctx->opt_derive_batches = value;
     else if (!strcmp(key, "keep_kpo")) ctx->opt_keep_kpo = value;
     else if (!strcmp(key, "verify_lookups")) ctx->opt_verify_lookups = value;
+    else if (!strcmp(key, "spill")) ctx->opt_spill = value;
     else return fail(ctx, SMX_INVALID_PARAMETER, "unknown option %s", key);
     return SMX_OK;
 }
@@ -401,8 +402,19 @@ int smx_copy_bucket(const smx_ctx *cctx, unsigned bucket, void *host_dst) {
     if (bucket >= ctx->num_buckets) return fail(ctx, SMX_INVALID_PARAMETER, "bucket %u out of range", bucket);
     const uint64_t o = ctx->bucket_off[bucket], n = ctx->bucket_off[bucket + 1] - o;
     if (n == 0) return SMX_OK;
-    HIPCHK(hipSetDevice(ctx->device));
     const size_t w = (size_t)ctx->nw * 8;
+    if (ctx->result_on_host) {  // spilled result: chunks of whole buckets in file order
+        uint64_t base = 0;
+        for (auto &c : ctx->h_result) {
+            if (o >= base && o + n <= base + c.n) {
+                memcpy(host_dst, c.data + (o - base) * w, n * w);
+                return SMX_OK;
+            }
+            base += c.n;
+        }
+        return fail(ctx, SMX_DEVICE_ERROR, "bucket %u is not inside one chunk of the spilled result", bucket);
+    }
+    HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpy(host_dst, (const char *)ctx->d_result + o * w, n * w, hipMemcpyDeviceToHost));
     return SMX_OK;
 }
@@ -412,6 +424,14 @@ int smx_copy_final_kmers(const smx_ctx *cctx, void *host_dst) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     if (ctx->n_records == 0) return SMX_OK;
     if (!host_dst) return SMX_INVALID_PARAMETER;
+    if (ctx->result_on_host) {
+        char *dst = (char *)host_dst;
+        for (auto &c : ctx->h_result) {
+            memcpy(dst, c.data, c.n * ctx->nw * 8);
+            dst += c.n * ctx->nw * 8;
+        }
+        return SMX_OK;
+    }
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpy(host_dst, ctx->d_result, ctx->n_records * ctx->nw * 8, hipMemcpyDeviceToHost));
     return SMX_OK;
@@ -422,6 +442,15 @@ int smx_write_final_kmers(const smx_ctx *cctx, const char *path) {
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
+    if (ctx->result_on_host) {
+        int hrc = SMX_OK;
+        for (auto &c : ctx->h_result) {
+            const size_t nb_ = c.n * (size_t)ctx->nw * 8;
+            if (nb_ && fwrite(c.data, 1, nb_, f) != nb_) hrc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
+        }
+        if (fclose(f) != 0 && hrc == SMX_OK) hrc = fail(ctx, SMX_IO_ERROR, "I/O error closing %s", path);
+        return hrc;
+    }
     const size_t total = ctx->n_records * (size_t)ctx->nw * 8;
     const size_t chunk = (size_t)64 << 20;
     (void)hipSetDevice(ctx->device);
@@ -685,6 +714,7 @@ int smx_copy_kmers_device(const smx_ctx *cctx, void *d_dst) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     if (ctx->n_records == 0) return SMX_OK;
     if (!d_dst) return SMX_INVALID_PARAMETER;
+    if (ctx->result_on_host) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the result was spilled to host memory (it does not fit the HBM budget)");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(d_dst, ctx->d_result, ctx->n_records * ctx->nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

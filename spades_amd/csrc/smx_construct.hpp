@@ -812,6 +812,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     } else {
         if (int rc = count_reads<NW>(ctx, k + 1, SMX_MODE_CANONICAL, B)) return rc;
     }
+    if (ctx->result_on_host) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the (k+1)-mer file does not fit the HBM budget (it was spilled to the host): the construction needs it resident");
     ctx->g_kpo = ctx->d_result_buf;
     ctx->d_result_buf = ctx->d_result = nullptr;
     if (int rc = adopt_result(ctx, &ctx->g_kpo, (size_t)ctx->n_records * NW * 8)) return rc;

@@ -45,6 +45,13 @@ struct smx_ctx {
     // result of the last count
     void *d_result_buf = nullptr;  // allocation holding the result
     void *d_result = nullptr;
+    // ... or, when the sorted-unique set does not fit the HBM budget, in host memory: chunks of whole buckets in file order
+    struct HostChunk {
+        char *data = nullptr;
+        uint64_t n = 0;  // records
+    };
+    std::vector<HostChunk> h_result;
+    bool result_on_host = false;
     uint64_t n_records = 0, n_instances = 0;
     unsigned nw = 0, K = 0, num_buckets = 0;
     std::vector<uint64_t> bucket_off;
@@ -57,6 +64,7 @@ struct smx_ctx {
     int64_t opt_early_tip_bound = 0;  // > 0: spades-core's early tip clipper with this length bound (RL - K there) before condensation
     int64_t opt_skm_stage = 1;     // pass 0 of the super-k-mer scan stages its output so that placing it needs no second scan
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
+    int64_t opt_spill = -1;  // sorted runs to host memory + merge by bucket ranges: -1 when the accumulated set outgrows HBM, 1 always (tests)
     int64_t opt_verify_lookups = 0;  // 1: rank lookups of k-mers that are known to be present still compare the record
     int64_t opt_derive_batches = 0;  // > 1: derive the k-mer file in this many bucket ranges (tests; 0 = as HBM requires)
     int64_t opt_keep_kpo = -1;       // keep the (k+1)-mer file after the masks are filled: -1 = if HBM allows, 0 = drop (coverage recounts)

@@ -120,6 +120,9 @@ int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint6
 }
 
 void clear_result(smx_ctx *ctx) {
+    for (auto &c : ctx->h_result) free(c.data);
+    ctx->h_result.clear();
+    ctx->result_on_host = false;
     if (ctx->d_result_buf) arena_put(ctx, ctx->d_result_buf);
     ctx->d_result_buf = ctx->d_result = nullptr;
     ctx->n_records = 0;
@@ -749,6 +752,30 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
         if (!d_cnt && (rc = dalloc(ctx, &d_cnt, 1, false))) return cleanup(rc);
         uint64_t total_inst = 0;
         bool retry = false;
+        // Host spill (the reference's dump to kmers_raw files + merge, kmer_splitter.hpp:123-170, kmer_index_builder.hpp:346-430): when
+        // the accumulated set and a new run cannot be folded inside the HBM budget, the sorted-unique runs go to host memory and are
+        // merged at the end one bucket range at a time (a run is bucket-major, so a range is one slice of every run).
+        struct HostRun {
+            char *data;
+            uint64_t n;
+            std::vector<uint64_t> boff;
+        };
+        std::vector<HostRun> runs;
+        std::vector<uint64_t> acc_boff;
+        bool spilling = false;
+        const size_t W = sizeof(Rec<NW>);
+        auto drop_runs = [&]() {
+            for (auto &r : runs) free(r.data);
+            runs.clear();
+        };
+        auto spill = [&](void *d, uint64_t n, const std::vector<uint64_t> &boff) -> int {
+            HostRun r{(char *)malloc(std::max<size_t>(n * W, 1)), n, boff};
+            if (!r.data) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "host allocation of %zu bytes for a spilled run failed", (size_t)(n * W));
+            runs.push_back(r);
+            if (n && hipMemcpy(r.data, d, n * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "spilling a run to the host failed");
+            arena_put(ctx, d);
+            return 0;
+        };
         for (uint64_t bi = 0; bi < nbatch && !retry; ++bi) {
             std::vector<std::pair<uint64_t, uint64_t>> ranges(ctx->chunks.size());
             if (hipMemsetAsync(d_cnt, 0, 8, ctx->stream) != hipSuccess) return cleanup(fail(ctx, SMX_DEVICE_ERROR, "batch counter reset failed"));
@@ -779,11 +806,35 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
             if (rc) return cleanup(rc);
             void *run = ctx->d_result_buf;
             const uint64_t nrun = ctx->n_records;
+            const std::vector<uint64_t> run_boff = ctx->bucket_off;
             ctx->d_result_buf = ctx->d_result = nullptr;
             free_temps(ctx, run);
+            if (spilling) {
+                if ((rc = spill(run, nrun, run_boff))) {
+                    drop_runs();
+                    return cleanup(rc);
+                }
+                continue;
+            }
             if (!acc) {
                 acc = run;
                 nacc = nrun;
+                acc_boff = run_boff;
+                continue;
+            }
+            if (ctx->opt_spill > 0 || (double)(nacc + nrun) * (double)W * 1.3 > (double)arena_avail(ctx)) {  // the fold (two buffers of the union; acc and run are released on the way) would not fit
+                spilling = true;
+                if ((rc = spill(acc, nacc, acc_boff))) {
+                    acc = nullptr;
+                    arena_put(ctx, run);
+                    drop_runs();
+                    return cleanup(rc);
+                }
+                acc = nullptr;
+                if ((rc = spill(run, nrun, run_boff))) {
+                    drop_runs();
+                    return cleanup(rc);
+                }
                 continue;
             }
             // fold: acc U run -> acc
@@ -804,6 +855,7 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
             if ((rc = run_count<NW>(ctx, K, mode, B, cat, nacc + nrun, nullptr, /*recs_reusable=*/true))) return cleanup(rc);
             acc = ctx->d_result_buf;
             nacc = ctx->n_records;
+            acc_boff = ctx->bucket_off;
             if (bi + 1 < nbatch) {
                 ctx->d_result_buf = ctx->d_result = nullptr;
                 free_temps(ctx, acc);
@@ -813,8 +865,76 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
             free_temps(ctx);
             if (acc && acc != ctx->d_result_buf) arena_put(ctx, acc);
             acc = nullptr;
+            drop_runs();
             clear_result(ctx);
             continue;
+        }
+        if (spilling) {  // merge the host runs, one bucket range at a time; the result stays on the host
+            free_temps(ctx);
+            clear_result(ctx);
+            std::vector<uint64_t> tot(B, 0);
+            for (auto &r : runs)
+                for (unsigned b = 0; b < B; ++b) tot[b] += r.boff[b + 1] - r.boff[b];
+            const uint64_t max_merge = std::max<uint64_t>((uint64_t)((double)arena_avail(ctx) / (2.6 * (double)W)), 1);
+            std::vector<uint64_t> gboff(B + 1, 0);
+            std::vector<smx_ctx::HostChunk> chunks;  // installed at the end: every run_count below clears the context's result
+            uint64_t done = 0;
+            rc = 0;
+            for (unsigned b0 = 0; b0 < B && !rc;) {
+                unsigned b1 = b0;
+                uint64_t sum = 0;
+                while (b1 < B && (b1 == b0 || sum + tot[b1] <= max_merge)) sum += tot[b1++];
+                if (sum > max_merge) {
+                    rc = fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "bucket %u alone holds %llu records in the spilled runs: more than the HBM budget can merge (use more buckets)",
+                              b0, (unsigned long long)sum);
+                    break;
+                }
+                smx_ctx::HostChunk ch;
+                if (sum) {
+                    Rec<NW> *cat;
+                    if ((rc = dalloc(ctx, &cat, sum))) break;
+                    uint64_t at = 0;
+                    for (auto &r : runs) {
+                        const uint64_t o = r.boff[b0], n = r.boff[b1] - o;
+                        if (n && hipMemcpyAsync(cat + at, r.data + o * W, n * W, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "run upload failed");
+                        at += n;
+                    }
+                    if (!rc) rc = run_count<NW>(ctx, K, mode, B, cat, sum, nullptr, /*recs_reusable=*/true, false, false, b0, b1 - b0);
+                    if (!rc) {
+                        ch.n = ctx->n_records;
+                        ch.data = (char *)malloc(std::max<size_t>(ch.n * W, 1));
+                        if (!ch.data) rc = fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "host allocation for the merged result failed");
+                        else if (ch.n && hipMemcpy(ch.data, ctx->d_result_buf, ch.n * W, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "result read-back failed");
+                        for (unsigned b = b0; b < b1 && !rc; ++b) gboff[b + 1] = done + ctx->bucket_off[b + 1];
+                        done += ch.n;
+                    }
+                    ctx->d_result_buf = ctx->d_result = nullptr;
+                    free_temps(ctx);
+                    if (rc) {
+                        free(ch.data);
+                        break;
+                    }
+                } else {
+                    for (unsigned b = b0; b < b1; ++b) gboff[b + 1] = done;
+                }
+                chunks.push_back(ch);
+                b0 = b1;
+            }
+            drop_runs();
+            clear_result(ctx);
+            if (rc) {
+                for (auto &c : chunks) free(c.data);
+                return cleanup(rc);
+            }
+            ctx->h_result = chunks;
+            ctx->result_on_host = true;
+            ctx->K = K;
+            ctx->nw = NW;
+            ctx->num_buckets = B;
+            ctx->bucket_off = gboff;
+            ctx->n_records = done;
+            ctx->n_instances = total_inst;
+            return cleanup(0);
         }
         if (ctx->d_result_buf != acc) {  // a single run that was never folded: install it
             ctx->d_result_buf = ctx->d_result = acc;

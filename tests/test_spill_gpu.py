@@ -1,0 +1,57 @@
+"""Host spill (the reference's dump of sorted runs + merge, kmer_splitter.hpp:123-170, kmer_index_builder.hpp:346-430):
+when the sorted-unique set does not fit the HBM budget of the context, sorted runs go to host memory and are merged one bucket range
+at a time; the result is then served from the host. Bytes must equal the run that had all of HBM."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import read_lines
+from spades_amd import KMerDiskCounter, ReadKMerSplitter
+from spades_amd.kmercount import Context
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("K,mode,nb", [(21, "A", 16), (55, "A", 16), (56, "B", 30)])
+def test_forced_spill_small(K, mode, nb):
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    want = None
+    for spill in (0, 1):
+        ctx = Context()
+        if spill:
+            ctx.set_option("spill", 1)
+            ctx.set_option("batch_records", 3000)  # many position batches -> many host runs
+        sp = ReadKMerSplitter(K, mode, ctx)
+        sp.push_back_reads(reads)
+        st = KMerDiskCounter(None, sp).Count(nb)
+        got = (st.records().tobytes(), st.bucket_sizes().tolist(), [st.bucket(b).tobytes() for b in range(nb)])
+        assert (st.device_ptr() == 0) == bool(spill)
+        if want is None:
+            want = got
+        else:
+            assert got == want
+        ctx.close()
+
+
+def test_result_larger_than_the_hbm_budget(tmp_path):
+    """2 M PE150 reads, k=55, spades-kmercount mode: 2.7 GB of k-mers with a 2 GiB budget"""
+    codes = synth.synth_codes(77, 10_000_000, 2_000_000)
+    bases, off = synth.ascii_and_offsets(codes)
+    bases = bases.tobytes()
+    md5 = []
+    for budget in (0, 2 << 30):
+        ctx = Context(hbm_budget=budget)
+        sp = ReadKMerSplitter(55, "A", ctx)
+        sp.push_back_ascii(bases, off)
+        st = KMerDiskCounter(str(tmp_path), sp).CountAll(16)
+        assert st.total_kmers() * 16 > (2 << 30)
+        assert (st.device_ptr() == 0) == bool(budget)  # served from the host when it did not fit
+        h = hashlib.md5()
+        with open(st.final_kmers(), "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        md5.append((h.hexdigest(), st.bucket_sizes().tolist()))
+        ctx.close()
+    assert md5[0] == md5[1]
