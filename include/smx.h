@@ -61,8 +61,18 @@ const char *smx_version(void);
  * Engine knobs (no reference equivalent; closest is the -b buffer-size knob of kmercount.cpp:139); results never depend on them:
  *   "prededupe" (-1 auto, 0 direct pipeline, 1 force the super-k-mer stage), "skm_cap", "skm_scap", "skm_stage" (its chunk sizes / staging),
  *   "batch_records" (force HBM-bounded batches), "leaf_cap", "leaf_target", "leaf_grid", "leaf_tab", "s1", "s2" (leaf / MSD split geometry),
- *   "joint_hist" (level-2 histogram counted with level 1), "device_links" (0 host, 1 device from 65 536 edges, 2 always).
- * SMX_OPTS="key=value,..." in the environment applies options to every new context. */
+ *   "joint_hist" (level-2 histogram counted with level 1), "device_links" (0 host, 1 device from 65 536 edges, 2 always),
+ *   "derive_batches" (k-mer file of the construction in this many bucket ranges; 0 = as HBM requires), "keep_kpo" (-1 keep the
+ *   (k+1)-mer file after the masks if HBM allows, 0 drop it: the coverage pass recounts), "verify_lookups" (1: rank lookups of
+ *   k-mers that are present by construction still compare the record), "spill" (1: always keep sorted runs in host memory and
+ *   merge them by bucket ranges; -1 only when the set outgrows the HBM budget).
+ * SMX_OPTS="key=value,..." in the environment applies options to every new context.
+ *
+ * HBM budget (smx_create): the context never holds more device memory than hbm_budget_bytes (0 = what the device has). A count whose
+ * sorted-unique set does not fit is cut into batches whose runs are folded on the device or, when even that does not fit, kept in
+ * host memory and merged one bucket range at a time (the reference's dump + merge, kmer_splitter.hpp:123-170,
+ * kmer_index_builder.hpp:346-430); the result is then served from host memory: smx_copy_bucket / smx_copy_final_kmers /
+ * smx_write_final_kmers work as usual, smx_device_kmers returns NULL and smx_build_graph refuses (it needs the file resident). */
 int smx_set_option(smx_ctx *ctx, const char *key, int64_t value);
 
 /* ---- reads -> HBM -------------------------------------------------------------------------
@@ -77,7 +87,8 @@ int smx_reads_clear(smx_ctx *ctx);
 int smx_submit_reads_ascii(smx_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 /* Already-packed reads in host memory: one 2-bit stream (layout as a k-mer record, arbitrarily
  * long), read i occupies nucleotides [start[i], start[i]+len[i]). Mirrors Sequence::BinWrite's
- * payload (common/sequence/sequence.hpp BinWrite: size_t len + words). */
+ * payload (common/sequence/sequence.hpp BinWrite: size_t len + words). The (start, len) pairs are checked against the stream on
+ * the device; page-locked arrays (smx_pinned_alloc) upload at the PCIe rate. */
 int smx_submit_reads_packed(smx_ctx *ctx, const uint64_t *words, uint64_t n_words,
                             const uint64_t *start, const uint32_t *len, uint64_t n_reads);
 /* SPAdes' own binary read format: one <prefix>.seq file written by io::ReadConverter::ConvertToBinary
