@@ -232,9 +232,25 @@ int build_rank_dir(smx_ctx *ctx, const void *recs, uint64_t n, const std::vector
 // Whole: 2 derived records per (k+1)-mer through the pipeline at once. In bucket ranges when that does not fit HBM (or on request):
 // the buckets of the k-mer file are disjoint, so the sorted-unique output of a range is final and only has to be appended.
 template <int NW>
-int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B) {
+int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B, bool from_reads) {
     const uint64_t nkpo = ctx->g_nkpo;
     const size_t W = (size_t)NW * 8;
+    // From the reads when they are resident: the canonical k-mers of every valid run that holds a (k+1)-mer ARE the prefixes and
+    // suffixes of the (k+1)-mers, and behind the pre-dedupe stage counting them costs less than sorting 2 derived records per
+    // (k+1)-mer. (Not when the (k+1)-mer file came from other ranks: there are no reads for it here.)
+    if (from_reads && ctx->opt_kmers_from_reads != 0 && ctx->opt_derive_batches == 0) {
+        int rc = count_reads<NW>(ctx, k, SMX_MODE_CANONICAL, B, k + 1);
+        if (rc == 0 && !ctx->result_on_host) {
+            ctx->g_kmers = ctx->d_result_buf;
+            ctx->g_nkmers = ctx->n_records;
+            ctx->g_kboff = ctx->bucket_off;
+            ctx->d_result_buf = ctx->d_result = nullptr;
+            return adopt_result(ctx, &ctx->g_kmers, (size_t)ctx->g_nkmers * W);
+        }
+        if (rc && rc != SMX_MEMORY_LIMIT_EXCEEDED) return rc;
+        free_temps(ctx);  // no room for that route: derive from the (k+1)-mer file in bucket ranges
+        clear_result(ctx);
+    }
     const size_t avail = arena_avail(ctx);
     const size_t need_whole = (size_t)(4.25 * (double)nkpo * (double)W) + ((size_t)64 << 20);
     const bool whole = ctx->opt_derive_batches > 1 ? false : (ctx->opt_derive_batches == 1 || need_whole <= avail);
@@ -837,7 +853,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     };
     {
         Prefix pf(ctx, "kmers:");
-        if (int rc = derive_kmer_file<NW>(ctx, k, B)) return rc;
+        if (int rc = derive_kmer_file<NW>(ctx, k, B, /*from_reads=*/kpo_recs == nullptr)) return rc;
     }
     ctx->d_result = ctx->g_kmers;  // smx_copy_final_kmers() now yields the k-mer file
     gwt.mark(ctx, "g:kmer file");

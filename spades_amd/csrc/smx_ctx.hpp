@@ -66,6 +66,7 @@ struct smx_ctx {
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
     int64_t opt_spill = -1;  // sorted runs to host memory + merge by bucket ranges: -1 when the accumulated set outgrows HBM, 1 always (tests)
     int64_t opt_verify_lookups = 0;  // 1: rank lookups of k-mers that are known to be present still compare the record
+    int64_t opt_kmers_from_reads = 1;  // construction: k-mer file counted from the resident reads (0: derived from the (k+1)-mer file)
     int64_t opt_derive_batches = 0;  // > 1: derive the k-mer file in this many bucket ranges (tests; 0 = as HBM requires)
     int64_t opt_keep_kpo = -1;       // keep the (k+1)-mer file after the masks are filled: -1 = if HBM allows, 0 = drop (coverage recounts)
     int64_t opt_joint_hist = 1;  // fuse the level-2 histogram into the level-1 histogram pass (records source)

@@ -96,7 +96,7 @@ int pass_recs(smx_ctx *ctx, bool scatter, PassArgs a, uint64_t nrec, unsigned lo
 }
 
 // mark valid windows of every chunk; returns total windows
-int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint64_t *total, bool temp_masks = true) {
+int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint64_t *total, bool temp_masks = true, unsigned min_len = 0) {
     unsigned long long *d_total;
     if (int rc = dalloc(ctx, &d_total, 1)) return rc;
     HIPCHK(hipMemsetAsync(d_total, 0, 8, ctx->stream));
@@ -109,7 +109,7 @@ int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint6
         HIPCHK(hipMemsetAsync(masks[ci], 0, mw * 8, ctx->stream));
         unsigned grid = (unsigned)((ch.n_reads + BLK - 1) / BLK);
         hipLaunchKernelGGL(k_mark_windows, dim3(grid), dim3(BLK), 0, ctx->stream, ch.d_start, ch.d_len, ch.n_reads, K,
-                           (unsigned long long *)masks[ci], d_total);
+                           (unsigned long long *)masks[ci], d_total, min_len);
         HIPCHK(hipGetLastError());
     }
     unsigned long long t = 0;
@@ -696,11 +696,11 @@ int count_selection(smx_ctx *ctx, unsigned K, int mode, unsigned B, const ReadSe
 // Behind the pre-dedupe stage the footprint depends on the number of DISTINCT k-mers, which nobody knows in advance: the first
 // attempt takes everything in one batch and a buffer overflow (SMX_RETRY_SMALLER) doubles the number of batches.
 template <int NW>
-int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
+int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len = 0) {
     std::vector<uint64_t *> masks;
     uint64_t nwin = 0;
     tbegin(ctx, "mark_windows");
-    int rc = mark_windows(ctx, K, masks, &nwin, /*temp_masks=*/false);
+    int rc = mark_windows(ctx, K, masks, &nwin, /*temp_masks=*/false, min_len);
     tend(ctx);
     auto drop_masks = [&]() {
         for (auto *m : masks) arena_put(ctx, m);
@@ -741,7 +741,7 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
             sel.masks = &masks;
             sel.nrec = nrec;
             rc = count_selection<NW>(ctx, K, mode, B, sel);
-            if (rc == SMX_RETRY_SMALLER) {
+            if (rc == SMX_RETRY_SMALLER || rc == SMX_MEMORY_LIMIT_EXCEEDED) {  // (an allocation can also fail on a fragmented arena)
                 free_temps(ctx);
                 clear_result(ctx);
                 continue;
@@ -799,7 +799,7 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
             sel.nrec = nw_b * rpp;
             total_inst += sel.nrec;
             rc = count_selection<NW>(ctx, K, mode, B, sel);
-            if (rc == SMX_RETRY_SMALLER) {
+            if (rc == SMX_RETRY_SMALLER || rc == SMX_MEMORY_LIMIT_EXCEEDED) {
                 retry = true;
                 break;
             }
@@ -822,7 +822,22 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
                 acc_boff = run_boff;
                 continue;
             }
-            if (ctx->opt_spill > 0 || (double)(nacc + nrun) * (double)W * 1.3 > (double)arena_avail(ctx)) {  // the fold (two buffers of the union; acc and run are released on the way) would not fit
+            // the fold needs two buffers of the union (acc and run are released on the way): by the plan, and by what the arena can
+            // actually place (the accumulated set sits between the temporaries and fragments them)
+            bool fold_fits = ctx->opt_spill <= 0 && (double)(nacc + nrun) * (double)W * 1.3 <= (double)arena_avail(ctx);
+            Rec<NW> *cat = nullptr;
+            if (fold_fits) {
+                void *p1 = arena_get(ctx, (nacc + nrun) * W), *p2 = p1 ? arena_get(ctx, (nacc + nrun) * W) : nullptr;
+                fold_fits = p1 && p2;
+                arena_put(ctx, p2);
+                if (fold_fits) {
+                    cat = (Rec<NW> *)p1;
+                    ctx->temps.push_back(p1);
+                } else {
+                    arena_put(ctx, p1);
+                }
+            }
+            if (!fold_fits) {
                 spilling = true;
                 if ((rc = spill(acc, nacc, acc_boff))) {
                     acc = nullptr;
@@ -838,11 +853,6 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
                 continue;
             }
             // fold: acc U run -> acc
-            Rec<NW> *cat;
-            if ((rc = dalloc(ctx, &cat, nacc + nrun))) {
-                arena_put(ctx, run);
-                return cleanup(rc);
-            }
             hipError_t e1 = hipMemcpyAsync(cat, acc, nacc * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream);
             hipError_t e2 = hipMemcpyAsync(cat + nacc, run, nrun * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream);
             hipError_t e3 = hipStreamSynchronize(ctx->stream);
@@ -875,7 +885,7 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
             std::vector<uint64_t> tot(B, 0);
             for (auto &r : runs)
                 for (unsigned b = 0; b < B; ++b) tot[b] += r.boff[b + 1] - r.boff[b];
-            const uint64_t max_merge = std::max<uint64_t>((uint64_t)((double)arena_avail(ctx) / (2.6 * (double)W)), 1);
+            uint64_t max_merge = std::max<uint64_t>((uint64_t)((double)arena_avail(ctx) / (2.6 * (double)W)), 1);
             std::vector<uint64_t> gboff(B + 1, 0);
             std::vector<smx_ctx::HostChunk> chunks;  // installed at the end: every run_count below clears the context's result
             uint64_t done = 0;
@@ -884,15 +894,24 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B) {
                 unsigned b1 = b0;
                 uint64_t sum = 0;
                 while (b1 < B && (b1 == b0 || sum + tot[b1] <= max_merge)) sum += tot[b1++];
-                if (sum > max_merge) {
-                    rc = fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "bucket %u alone holds %llu records in the spilled runs: more than the HBM budget can merge (use more buckets)",
-                              b0, (unsigned long long)sum);
-                    break;
-                }
                 smx_ctx::HostChunk ch;
                 if (sum) {
                     Rec<NW> *cat;
-                    if ((rc = dalloc(ctx, &cat, sum))) break;
+                    // two buffers of the range have to be placed; a fragmented arena gets a smaller range, a single bucket that does not fit is final
+                    void *p1 = arena_get(ctx, sum * W), *p2 = p1 ? arena_get(ctx, sum * W) : nullptr;
+                    arena_put(ctx, p2);
+                    if (!p1 || !p2) {
+                        arena_put(ctx, p1);
+                        if (b1 - b0 > 1) {
+                            max_merge = std::max<uint64_t>(sum / 2, 1);
+                            continue;
+                        }
+                        rc = fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "bucket %u alone holds %llu records in the spilled runs: more than the HBM budget can merge (use more buckets)",
+                                  b0, (unsigned long long)sum);
+                        break;
+                    }
+                    cat = (Rec<NW> *)p1;
+                    ctx->temps.push_back(p1);
                     uint64_t at = 0;
                     for (auto &r : runs) {
                         const uint64_t o = r.boff[b0], n = r.boff[b1] - o;

@@ -3,7 +3,8 @@
 write for a seeded >= 2 M-read set, generated in the build container (binaries under $SMX_REF_BIN, built from /root/reference by
 the survey's cmake recipe). The read set comes from tests/synth.py, so the GPU box regenerates the identical reads and only the
 md5s travel (tests/golden/scale_*.json).
-usage: make_golden_scale.py [n_reads=2000000] [genome_len=10000000] [seed=77]"""
+usage: make_golden_scale.py [n_reads=2000000] [genome_len=10000000] [seed=77] [k=55] [what=all|kmercount]
+  BASELINE config 2 (10 M PE150 reads, k=21, spades-kmercount):  make_golden_scale.py 1e7 5e7 1 21 kmercount"""
 import hashlib
 import json
 import os
@@ -31,8 +32,10 @@ def main():
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2_000_000
     g = int(float(sys.argv[2])) if len(sys.argv) > 2 else 10_000_000
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 77
+    k = int(sys.argv[4]) if len(sys.argv) > 4 else 55
+    what = sys.argv[5] if len(sys.argv) > 5 else "all"
     threads = 16
-    out = {"n_reads": n, "genome_len": g, "seed": seed, "k": 55, "threads": threads, "err": 0.01, "n_rate": 0.001,
+    out = {"n_reads": n, "genome_len": g, "seed": seed, "k": k, "threads": threads, "err": 0.01, "n_rate": 0.001,
            # spades-gbuilder clamps -t to omp_get_max_threads() (gbuilder.cpp:154): the bucket count that fixes the unitig order is 10 x this
            "effective_threads": min(threads, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))}
     codes = synth.synth_codes(seed, g, n)
@@ -44,17 +47,17 @@ def main():
         synth.write_fastq(codes, fq)
         out["fastq_md5"] = md5_file(fq)
         t0 = time.time()
-        subprocess.check_call([os.path.join(REF_BIN, "spades-kmercount"), "-k", "55", "-t", str(threads), "-w", os.path.join(td, "kc"), fq],
+        subprocess.check_call([os.path.join(REF_BIN, "spades-kmercount"), "-k", str(k), "-t", str(threads), "-w", os.path.join(td, "kc"), fq],
                               stdout=subprocess.DEVNULL)
         out["kmercount_s"] = round(time.time() - t0, 1)
         fk = os.path.join(td, "kc", "final_kmers")
         out["final_kmers_md5"] = md5_file(fk)
         out["final_kmers_bytes"] = os.path.getsize(fk)
         os.remove(fk)
-        for cov in (False, True):
+        for cov in ((False, True) if what == "all" else ()):
             gfa = os.path.join(td, "g.gfa")
             t0 = time.time()
-            subprocess.check_call([os.path.join(REF_BIN, "spades-gbuilder"), fq, gfa, "-k", "55", "-t", str(threads), "--gfa"] + (["-c"] if cov else []) +
+            subprocess.check_call([os.path.join(REF_BIN, "spades-gbuilder"), fq, gfa, "-k", str(k), "-t", str(threads), "--gfa"] + (["-c"] if cov else []) +
                                   ["-tmp-dir", os.path.join(td, "tmp")], stdout=subprocess.DEVNULL)
             key = "gfa_cov" if cov else "gfa"
             out[key + "_s"] = round(time.time() - t0, 1)
@@ -68,7 +71,7 @@ def main():
                         nl += line[:1] == b"L"
                 out["gfa_S_lines"], out["gfa_L_lines"] = ns, nl
             os.remove(gfa)
-    name = os.path.join(HERE, f"scale_{n // 1000}k_g{g // 1000}k_s{seed}.json")
+    name = os.path.join(HERE, f"scale_{n // 1000}k_g{g // 1000}k_s{seed}" + ("" if k == 55 else f"_k{k}") + ".json")
     with open(name, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
