@@ -154,7 +154,10 @@ bool arena_vmm_init(smx_ctx *ctx) {
     // neighbour's in many combinations (tools/vmm_probe.hip: 2 MiB, 6 MiB, 64 MiB or 1 GiB chunks back to back all work, mixed
     // sizes fail with "invalid argument"), and the reported granularity (4 KiB) says nothing about it.
     A.gran = (size_t)512 << 20;
-    A.reserved = (total_b + A.gran - 1) / A.gran * A.gran;
+    // Never more than 94 % of what is free now: a box whose VRAM is mapped to the last chunk dies instead of returning an error
+    // (measured the hard way: the page tables of these very mappings need VRAM too).
+    A.reserved = (size_t)((double)free_b * 0.94) / A.gran * A.gran;
+    if (A.reserved < A.gran) return false;
     if (ctx->budget) A.reserved = std::min(A.reserved, (ctx->budget + A.gran - 1) / A.gran * A.gran + A.gran);
     void *base = nullptr;
     if (hipMemAddressReserve(&base, A.reserved, 0, nullptr, 0) != hipSuccess || !base) {

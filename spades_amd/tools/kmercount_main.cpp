@@ -1,6 +1,7 @@
 // spades_amd/tools/kmercount_main.cpp — drop-in CLI for `spades-kmercount`
 // (reference: projects/spades_tools/kmercount.cpp:134-229; docs/standalone.md:5-45) over libspades_mi355x.so.
-//   spades-kmercount-mi355x [-k 21] [-t N] [-w dir] [-b bytes] files...   ->  <dir>/final_kmers
+//   spades-kmercount-mi355x [-k 21] [-t N] [-w dir] [-b bytes] [--gpus N] files...   ->  <dir>/final_kmers
+// --gpus N: one process per GPU, k-mers redistributed by bucket owner with one RCCL exchange (kmercount_mgpu.hpp).
 // -t and -b are accepted for command-line compatibility; the result does not depend on them (SURVEY.md finding 3).
 // Exit codes follow common/utils/logger/error_codes.hpp (64-68).
 #include <cerrno>
@@ -12,6 +13,7 @@
 
 #include "../../include/smx.h"
 #include "read_input.hpp"
+#include "kmercount_mgpu.hpp"
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -32,6 +34,7 @@ static void usage(const char *a0) {
 
 int main(int argc, char **argv) {
     unsigned K = 21, nthreads = 1;
+    int gpus = 0;
     std::string workdir = ".";
     std::vector<std::string> input;
     std::string dataset;
@@ -49,6 +52,7 @@ int main(int argc, char **argv) {
         else if (a == "-w" || a == "--workdir") workdir = need("-w");
         else if (a == "-b" || a == "--bufsize") (void)need("-b");
         else if (a == "-d" || a == "--dataset") dataset = need("-d");
+        else if (a == "--gpus") gpus = atoi(need("--gpus"));
         else if (a == "-h" || a == "--help") {
             usage(argv[0]);
             return 0;
@@ -71,6 +75,10 @@ int main(int argc, char **argv) {
     if (input.empty()) {
         fprintf(stderr, "No input files were specified\n");
         return SMX_INVALID_PARAMETER;
+    }
+    if (gpus > 0) {  // the sharded path (also with one GPU: same code, self-exchange)
+        printf("K-mer length set to %u\n", K);
+        return smxtool::run_sharded(gpus, K, workdir, input);
     }
     smx_ctx *ctx = nullptr;
     double t_stage = now_s();

@@ -1,0 +1,225 @@
+// spades_amd/tools/kmercount_mgpu.hpp — spades-kmercount on N GPUs of one node, C++ host over librccl.
+// One process per GPU (forked by the tool itself before any HIP call), bucket-range owners, ONE exchange:
+//   own input files -> smx_extract_partition (local pre-dedupe, records grouped by owner) -> counts by ncclAllGather ->
+//   grouped ncclSend / ncclRecv between all pairs (every pair has its own xGMI link; no ring) -> smx_count_records on the owner ->
+//   every rank writes its bucket range into <workdir>/final_kmers at its byte offset (buckets are contiguous per rank, so the file
+//   is the concatenation of the rank outputs: KMerDiskStorage::merge, kmer_index_builder.hpp:190-203).
+// The ncclUniqueId travels through a file in the work directory. Input files are dealt out to the ranks round-robin.
+#pragma once
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include "../../include/smx.h"
+#include "read_input.hpp"
+
+namespace smxtool {
+
+#define MG_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            fprintf(stderr, "[rank %d] %s failed: %s\n", rank, #call, hipGetErrorString(e_));     \
+            return SMX_DEVICE_ERROR;                                                              \
+        }                                                                                         \
+    } while (0)
+#define MG_NCCL(call)                                                                             \
+    do {                                                                                          \
+        ncclResult_t r_ = (call);                                                                 \
+        if (r_ != ncclSuccess) {                                                                  \
+            fprintf(stderr, "[rank %d] %s failed: %s\n", rank, #call, ncclGetErrorString(r_));    \
+            return SMX_DEVICE_ERROR;                                                              \
+        }                                                                                         \
+    } while (0)
+
+inline int sharded_rank_main(int rank, int world, unsigned K, const std::string &workdir, const std::vector<std::string> &input) {
+    smx_ctx *ctx = nullptr;
+    if (int rc = smx_create(&ctx, rank, 0)) {
+        fprintf(stderr, "[rank %d] no usable MI355X device %d (smx_create -> %d)\n", rank, rank, rc);
+        return rc;
+    }
+    // communicator: rank 0 publishes the id through the work directory
+    const std::string idfile = workdir + "/.smx_nccl_id";
+    ncclUniqueId id;
+    if (rank == 0) {
+        MG_NCCL(ncclGetUniqueId(&id));
+        const std::string tmp = idfile + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&id, sizeof id, 1, f) != 1) return SMX_IO_ERROR;
+        fclose(f);
+        if (rename(tmp.c_str(), idfile.c_str()) != 0) return SMX_IO_ERROR;
+    } else {
+        bool got = false;
+        for (int t = 0; t < 12000 && !got; ++t) {  // up to 2 minutes
+            FILE *f = fopen(idfile.c_str(), "rb");
+            if (f) {
+                got = fread(&id, sizeof id, 1, f) == 1;
+                fclose(f);
+            }
+            if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+        if (!got) {
+            fprintf(stderr, "[rank %d] no communicator id from rank 0\n", rank);
+            return SMX_IO_ERROR;
+        }
+    }
+    MG_HIP(hipSetDevice(rank));
+    ncclComm_t comm;
+    MG_NCCL(ncclCommInitRank(&comm, world, id, rank));
+    hipStream_t stream;
+    MG_HIP(hipStreamCreate(&stream));
+    // this rank's share of the input
+    for (size_t i = 0; i < input.size(); ++i) {
+        if ((int)(i % (size_t)world) != rank) continue;
+        int rc;
+        try {
+            rc = submit_file(ctx, input[i]);
+        } catch (const std::string &e) {
+            fprintf(stderr, "%s\n", e.c_str());
+            return SMX_INVALID_INPUT_FORMAT;
+        }
+        if (rc == -1) {
+            fprintf(stderr, "File %s doesn't exist or can't be read!\n", input[i].c_str());
+            return SMX_INPUT_FILE_NOT_FOUND;
+        }
+        if (rc) {
+            fprintf(stderr, "%s\n", smx_last_error(ctx));
+            return rc;
+        }
+    }
+    const unsigned NB = 16, nw = (K + 31) / 32;  // 16 buckets: kmercount.cpp:220
+    uint64_t n_local = 0;
+    if (int rc = smx_extract_count(ctx, K, SMX_MODE_ALL, &n_local)) return rc;
+    uint64_t *d_send = nullptr, *d_recv = nullptr, *d_cnt = nullptr, *d_all = nullptr;
+    MG_HIP(hipMalloc((void **)&d_send, std::max<uint64_t>(n_local, 1) * nw * 8));
+    std::vector<uint64_t> counts(world, 0);
+    if (int rc = smx_extract_partition(ctx, K, SMX_MODE_ALL, NB, (unsigned)world, d_send, n_local, counts.data())) {
+        fprintf(stderr, "%s\n", smx_last_error(ctx));
+        return rc;
+    }
+    // counts of every pair
+    MG_HIP(hipMalloc((void **)&d_cnt, (size_t)world * 8));
+    MG_HIP(hipMalloc((void **)&d_all, (size_t)world * world * 8));
+    MG_HIP(hipMemcpy(d_cnt, counts.data(), (size_t)world * 8, hipMemcpyHostToDevice));
+    MG_NCCL(ncclAllGather(d_cnt, d_all, (size_t)world, ncclUint64, comm, stream));
+    MG_HIP(hipStreamSynchronize(stream));
+    std::vector<uint64_t> all((size_t)world * world);
+    MG_HIP(hipMemcpy(all.data(), d_all, all.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> soff(world + 1, 0), roff(world + 1, 0);
+    for (int p = 0; p < world; ++p) {
+        soff[p + 1] = soff[p] + counts[p];
+        roff[p + 1] = roff[p] + all[(size_t)p * world + rank];  // what rank p sends to me
+    }
+    const uint64_t n_recv = roff[world];
+    MG_HIP(hipMalloc((void **)&d_recv, std::max<uint64_t>(n_recv, 1) * nw * 8));
+    // the exchange: all pairs at once, every pair on its own xGMI link
+    MG_NCCL(ncclGroupStart());
+    for (int p = 0; p < world; ++p) {
+        if (counts[p]) MG_NCCL(ncclSend(d_send + soff[p] * nw, counts[p] * nw, ncclUint64, p, comm, stream));
+        const uint64_t rc_ = roff[p + 1] - roff[p];
+        if (rc_) MG_NCCL(ncclRecv(d_recv + roff[p] * nw, rc_ * nw, ncclUint64, p, comm, stream));
+    }
+    MG_NCCL(ncclGroupEnd());
+    MG_HIP(hipStreamSynchronize(stream));
+    MG_HIP(hipFree(d_send));
+    if (int rc = smx_count_records(ctx, K, NB, d_recv, n_recv)) {
+        fprintf(stderr, "%s\n", smx_last_error(ctx));
+        return rc;
+    }
+    MG_HIP(hipFree(d_recv));
+    // file offsets: records per rank
+    uint64_t n_mine = 0;
+    smx_count_info(ctx, &n_mine, nullptr, nullptr);
+    const std::string out = workdir + "/final_kmers";
+    if (rank == 0) {  // created before the collective below, which orders it before everybody's writes
+        FILE *f = fopen(out.c_str(), "wb");
+        if (!f) {
+            fprintf(stderr, "Cannot open %s for writing\n", out.c_str());
+            return SMX_IO_ERROR;
+        }
+        fclose(f);
+    }
+    MG_HIP(hipMemcpy(d_cnt, &n_mine, 8, hipMemcpyHostToDevice));
+    MG_NCCL(ncclAllGather(d_cnt, d_all, 1, ncclUint64, comm, stream));
+    MG_HIP(hipStreamSynchronize(stream));
+    std::vector<uint64_t> per(world);
+    MG_HIP(hipMemcpy(per.data(), d_all, (size_t)world * 8, hipMemcpyDeviceToHost));
+    uint64_t before = 0, total = 0;
+    for (int p = 0; p < world; ++p) {
+        if (p < rank) before += per[p];
+        total += per[p];
+    }
+    {
+        const int fd = open(out.c_str(), O_WRONLY);
+        if (fd < 0) return SMX_IO_ERROR;
+        std::vector<uint64_t> sizes(NB);
+        smx_bucket_sizes(ctx, sizes.data());
+        std::vector<char> buf;
+        uint64_t at = before * nw * 8;
+        for (unsigned b = 0; b < NB; ++b) {
+            if (!sizes[b]) continue;
+            buf.resize(sizes[b] * nw * 8);
+            if (int rc = smx_copy_bucket(ctx, b, buf.data())) return rc;
+            size_t done = 0;
+            while (done < buf.size()) {
+                const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(at + done));
+                if (w <= 0) {
+                    close(fd);
+                    return SMX_IO_ERROR;
+                }
+                done += (size_t)w;
+            }
+            at += buf.size();
+        }
+        close(fd);
+    }
+    // everybody has written before rank 0 reports
+    MG_NCCL(ncclAllGather(d_cnt, d_all, 1, ncclUint64, comm, stream));
+    MG_HIP(hipStreamSynchronize(stream));
+    if (rank == 0) {
+        printf("K-mer counting done. There are %llu kmers in total.\n", (unsigned long long)total);
+        printf("K-mer counting done, kmers saved to \"%s\"\n", out.c_str());
+        unlink(idfile.c_str());
+    }
+    (void)hipFree(d_cnt);
+    (void)hipFree(d_all);
+    ncclCommDestroy(comm);
+    (void)hipStreamDestroy(stream);
+    smx_destroy(ctx);
+    return 0;
+}
+
+// fork one process per GPU (nothing of HIP has been touched yet in this process) and wait for them
+inline int run_sharded(int world, unsigned K, const std::string &workdir, const std::vector<std::string> &input) {
+    mkdir(workdir.c_str(), 0777);
+    unlink((workdir + "/.smx_nccl_id").c_str());
+    std::vector<pid_t> kids;
+    for (int r = 0; r < world; ++r) {
+        const pid_t pid = fork();
+        if (pid < 0) return SMX_DEVICE_ERROR;
+        if (pid == 0) _exit(sharded_rank_main(r, world, K, workdir, input));
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t pid : kids) {
+        int st = 0;
+        waitpid(pid, &st, 0);
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : SMX_DEVICE_ERROR;
+        if (code && !rc) rc = code;
+    }
+    return rc;
+}
+
+}  // namespace smxtool
