@@ -34,6 +34,21 @@ def test_kmercount_cli_matches_reference_bytes(tmp_path):
         assert open(wd / "final_kmers", "rb").read() == open(os.path.join(GOLDEN, c["file"]), "rb").read()
 
 
+def test_kmercount_cli_rccl_host_one_rank(tmp_path):
+    """--gpus 1: the C++ multi-GPU host (forked rank, librccl communicator, grouped ncclSend/ncclRecv to itself, owner-side count,
+    pwrite of the bucket range) must write the reference bytes; N > 1 needs N GPUs (the driver's boxes)."""
+    cases = [c for c in load_manifest()["cases"] if c["kind"] == "count" and c.get("file") and c["mode"] == "A" and c["num_buckets"] == 16]
+    reads = read_lines("reads_tiny.txt")
+    f1, f2 = str(tmp_path / "a.fq"), str(tmp_path / "b.fq.gz")
+    _fastq(f1, reads[0::2])
+    _fastq(f2, reads[1::2], gz=True)
+    for c in cases[:4]:
+        wd = tmp_path / f"m{c['K']}"
+        wd.mkdir()
+        subprocess.check_call([KC, "-k", str(c["K"]), "-w", str(wd), "--gpus", "1", f1, f2], stdout=subprocess.DEVNULL, timeout=300)
+        assert open(wd / "final_kmers", "rb").read() == open(os.path.join(GOLDEN, c["file"]), "rb").read()
+
+
 def test_gbuilder_cli_matches_reference_gfa(tmp_path):
     for c in [c for c in load_manifest()["cases"] if c["kind"] == "graph" and c["file"] and c["reads"] in ("reads_small.txt", "reads_loop.txt")]:
         reads = [r for r in read_lines(c["reads"]) if r]
