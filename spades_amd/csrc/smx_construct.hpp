@@ -238,8 +238,16 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B, bool from_reads) {
     // From the reads when they are resident: the canonical k-mers of every valid run that holds a (k+1)-mer ARE the prefixes and
     // suffixes of the (k+1)-mers, and behind the pre-dedupe stage counting them costs less than sorting 2 derived records per
     // (k+1)-mer. (Not when the (k+1)-mer file came from other ranks: there are no reads for it here.)
-    if (from_reads && ctx->opt_kmers_from_reads != 0 && ctx->opt_derive_batches == 0) {
+    uint64_t n_bases = 0;
+    for (auto &c : ctx->chunks) n_bases += c.n_bases;
+    // (only when one batch is sure to fit next to the (k+1)-mer file: super-k-mer slots < 5 B per window, two buffers of about as many
+    // k-mers as there are (k+1)-mers; batches, folds or a host spill would cost more than the derivation)
+    const double need_reads_route = 1.15 * (5.0 * (double)n_bases + 2.2 * (double)nkpo * (double)W);
+    if (from_reads && ctx->opt_kmers_from_reads != 0 && ctx->opt_derive_batches == 0 &&
+        (ctx->opt_kmers_from_reads > 1 || need_reads_route <= (double)arena_avail(ctx))) {
+        ctx->single_batch_only = true;
         int rc = count_reads<NW>(ctx, k, SMX_MODE_CANONICAL, B, k + 1);
+        ctx->single_batch_only = false;
         if (rc == 0 && !ctx->result_on_host) {
             ctx->g_kmers = ctx->d_result_buf;
             ctx->g_nkmers = ctx->n_records;

@@ -52,6 +52,7 @@ struct smx_ctx {
     };
     std::vector<HostChunk> h_result;
     bool result_on_host = false;
+    bool single_batch_only = false;  // count_reads: fail (memory limit) rather than cut the input into batches
     uint64_t n_records = 0, n_instances = 0;
     unsigned nw = 0, K = 0, num_buckets = 0;
     std::vector<uint64_t> bucket_off;

@@ -736,6 +736,7 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
     };
     for (;; nbatch = std::max<uint64_t>(2, 2 * nbatch)) {  // one trip unless the pre-dedupe output overflowed
         if (nbatch > (1u << 16)) return cleanup(fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the distinct k-mers do not fit the HBM budget"));
+        if (nbatch > 1 && ctx->single_batch_only) return cleanup(fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "one batch does not fit the HBM budget"));
         if (nbatch <= 1) {
             ReadSel sel;
             sel.masks = &masks;
