@@ -334,6 +334,21 @@ def main():
     roof_count["dominant_stage"] = dom[0]
     roof_count["dominant_stage_ms"] = round(dom[1], 3)
     roof_count["stages_ms"] = {n_: round(ms, 3) for n_, ms in stages.items()}
+    # HBM traffic per step from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, FETCH x2 gfx950
+    # correction: profiles/r02/config3_pmc_hbm_traffic.csv, taken at the commit named in profiles/r02/README.md). Only valid for the
+    # workload it was taken on; a constant of that measurement, not of this run.
+    pmc = os.path.join(ROOT, "profiles", "r02", "config3_pmc_hbm_traffic.csv")
+    pmc_rows = {}
+    if not sharded and not args.count_only and n_reads == 100_000_000 and k == 55 and T == 16 and os.path.exists(pmc):
+        for line in open(pmc):
+            f = line.strip().split(",")
+            if len(f) >= 6 and f[0] not in ("kernel", "TOTAL"):
+                try:
+                    pmc_rows[f[0]] = float(f[3]) + float(f[5])
+                except ValueError:
+                    pass
+        roof_count["traffic"] = round(sum(pmc_rows.values()), 1) if pmc_rows else None
+        roof_count["traffic_unit"] = "GB per step over ALL kernels of the step (PMC, profiles/r02; see README there for the commit)"
 
     out = {
         "metric": f"M reads/sec k-mer-counted (k={k}, PE150)",
@@ -366,6 +381,13 @@ def main():
                                          "algorithmic_bytes_per_step": int(b_con), "kernel_ms_per_step": round(construct_ms, 3)}}
         out["step_breakdown_ms"] = {"count_kernels": round(count_ms, 1), "construct_kernels": round(construct_ms, 1),
                                     "host_and_upload": round(ms_per_step - count_ms - construct_ms, 1)}
+        # the dominant single kernel of the step: k_fill_tab (node table: two rank lookups + two 64-bit atomics per (k+1)-mer)
+        fm = stages.get("fill_masks", 0.0)
+        b_fill = D1 * W + 2 * D1 * W + 2 * D1 * 8
+        out["dominant_kernel"] = {"name": "smx::k_fill_tab (+ k_tab_masks)", "ms": round(fm, 3), "algorithmic_bytes": int(b_fill),
+                                  "achieved_GBps": round(b_fill / max(fm, 1e-9) / 1e6, 1), "frac": round(b_fill / max(fm, 1e-9) / 1e6 / 8000.0, 4),
+                                  "traffic_GB": round(pmc_rows.get("smx::k_fill_tab<2>", 0.0), 1) or None,
+                                  "bound": "random HBM transactions (~64 B fetched per 8/16-B access), not bytes"}
     if rank == 0 and world == 1 and not args.force_sharded:
         class Wrap:
             def __init__(self, ptr, shape):
@@ -421,6 +443,8 @@ def main():
                                      "kmer_instances": int(ia), "distinct_kmers": int(da),
                                      "roofline_frac": round(ba / max(tma, 1e-9) / 1e6 / 8000.0, 4)}
     if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: out before the result line, not after it
         print(json.dumps(out), flush=True)
     ctx.close()
     if sharded:
