@@ -110,6 +110,10 @@ void smx_pinned_free(void *p);
  * d_words must be readable for n_words + 8 words (tail pad). */
 int smx_submit_reads_device(smx_ctx *ctx, const void *d_words, uint64_t n_words,
                             const void *d_start, const void *d_len, uint64_t n_reads);
+/* Stream contract of every entry point that takes device pointers (smx_submit_reads_device, smx_count_records, smx_graph_shard_build,
+ * smx_build_graph_from_kmers, smx_graph_set_kpomers, ...): the library works on a stream of its own. Whatever filled those buffers
+ * (a kernel or a collective on another stream) must have completed before the call — synchronise that stream first, as
+ * spades_amd/dist.py does after its exchanges; results handed out through device pointers are complete when the call returns. */
 int smx_reads_info(const smx_ctx *ctx, uint64_t *n_reads, uint64_t *n_bases);
 
 /* ---- counting -----------------------------------------------------------------------------

@@ -155,6 +155,7 @@ bool arena_vmm_init(smx_ctx *ctx) {
     // neighbour's in many combinations (tools/vmm_probe.hip: 2 MiB, 6 MiB, 64 MiB or 1 GiB chunks back to back all work, mixed
     // sizes fail with "invalid argument"), and the reported granularity (4 KiB) says nothing about it.
     A.gran = (size_t)512 << 20;
+    if (const char *c = getenv("SMX_ARENA_CHUNK_MB")) A.gran = std::max<size_t>((size_t)atoll(c), 2) << 20;  // experiments
     // Never more than 94 % of what is free now: a box whose VRAM is mapped to the last chunk dies instead of returning an error
     // (measured the hard way: the page tables of these very mappings need VRAM too).
     A.reserved = (size_t)((double)free_b * 0.94) / A.gran * A.gran;

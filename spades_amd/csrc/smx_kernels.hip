@@ -1051,6 +1051,7 @@ __global__ void k_classify(const unsigned long long *off, uint32_t nbins, uint32
     if (b >= nbins) return;
     const uint64_t n = off[b + 1] - off[b];
     if (n == 0) ucount[b] = 0;
+    else if (n > 0xFFFFFFFEull) atomicOr(bigcount, 0x80000000u);  // the rank-merge path keeps 32-bit run lengths: the host reports it
     else if (n > cap2) biglist[atomicAdd(bigcount, 1u)] = b;
     else if (n > cap1) med2list[atomicAdd(med2count, 1u)] = b;  // second LDS class (4x larger leaves, 1 workgroup per CU)
     else if (n > 128) medlist[atomicAdd(medcount, 1u)] = b;     // R=4 register sorts cost more per record than the LDS kernel

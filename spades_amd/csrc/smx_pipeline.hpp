@@ -383,6 +383,13 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
                            smalllist, smallcount, medlist, medcount, med2list, med2count, biglist, bigcount);
         HIPCHK(hipGetLastError());
         tend(ctx);
+        if (nrec > 0xFFFFFFFEull) {  // only then can a fine bin be too long for the skew path (k_sort_big, 32-bit run lengths)
+            uint32_t hb = 0;
+            HIPCHK(hipMemcpyAsync(&hb, bigcount, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (hb & 0x80000000u)
+                return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "one sort bin holds 2^32 or more records with the same leading key bits; the skew path cannot take it");
+        }
         tbegin(ctx, "sort_wave");
         hipLaunchKernelGGL((k_sort_wave<NW>), dim3((unsigned)std::min<uint64_t>((nb + 3) / 4, 256 * 16)), dim3(BLK), 0, ctx->stream,
                            (void *)sortbuf, fine_off, ucount, (const uint32_t *)smalllist, (const uint32_t *)smallcount);

@@ -11,6 +11,8 @@ for step in "$@"; do
     scale) timeout 900 python -m pytest tests/test_scale_gpu.py -m gpu -x -q 2>&1 | tail -15 ;;
     bench) timeout 1500 python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err; tail -5 gpurun_out/$tag/bench.err; cat gpurun_out/$tag/bench.json ;;
     benchq) timeout 1500 python bench.py --no-cpu-baseline --extra-kmercount 0 > gpurun_out/$tag/benchq.json 2> gpurun_out/$tag/benchq.err; tail -5 gpurun_out/$tag/benchq.err; cat gpurun_out/$tag/benchq.json ;;
+    benchq2g) SMX_ARENA_CHUNK_MB=2048 timeout 1500 python bench.py --no-cpu-baseline --extra-kmercount 0 > gpurun_out/$tag/benchq2g.json 2> gpurun_out/$tag/benchq2g.err; tail -3 gpurun_out/$tag/benchq2g.err ;;
+    benchq64) SMX_ARENA_CHUNK_MB=64 timeout 1500 python bench.py --no-cpu-baseline --extra-kmercount 0 > gpurun_out/$tag/benchq64.json 2> gpurun_out/$tag/benchq64.err; tail -3 gpurun_out/$tag/benchq64.err ;;
     *) echo "unknown step $step" ;;
   esac
 done
