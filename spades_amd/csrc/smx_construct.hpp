@@ -1026,6 +1026,14 @@ int run_coverage(smx_ctx *ctx) {
         std::vector<uint64_t> sv_boff = ctx->bucket_off;
         ctx->d_result = nullptr;
         if (int rc = count_reads<NW>(ctx, K1, SMX_MODE_CANONICAL, B)) return rc;
+        if (ctx->result_on_host) {
+            clear_result(ctx);
+            ctx->d_result = sv_res;
+            ctx->n_records = sv_n;
+            ctx->K = sv_K;
+            ctx->bucket_off = sv_boff;
+            return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the coverage pass needs the (k+1)-mer file resident next to the graph: not enough HBM");
+        }
         if (ctx->n_records != D1) return fail(ctx, SMX_DEVICE_ERROR, "recount of the (k+1)-mers gave %llu records, the graph was built from %llu",
                                               (unsigned long long)ctx->n_records, (unsigned long long)D1);
         ctx->g_kpo = ctx->d_result_buf;
