@@ -218,6 +218,11 @@ int smx_graph_copy_unitigs(const smx_ctx *ctx, uint64_t *offsets, char *seq);
  * but are not counted here — "Has to be separate stream for not counting it in coverage" (stages/construction.cpp:108-117). */
 int smx_graph_fill_coverage(smx_ctx *ctx);
 int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage /* [n_unitigs] */);
+/* Multiplicity histogram of the canonical (k+1)-mers after smx_graph_fill_coverage: hist[c] = how many have been seen c times
+ * (hist[0] = those met only in contig streams). What PHMCoverageFiller gives to GenomicInfo::set_cov_histogram
+ * (stages/construction.cpp:414-431; there hist[c-1] += 2 per canonical record). *n_entries = largest multiplicity + 1. */
+int smx_graph_coverage_histogram(const smx_ctx *ctx, uint64_t *hist, uint64_t capacity, uint64_t *n_entries);
+
 /* Flanking raw coverage, filled by the same pass (FillCoverageAndFlankingFromPHM, graph_support/coverage_filling.hpp:40-44,89-96;
  * omnigraph::FlankingCoverage, detail_coverage.hpp:22-100): sum of the counters of the first `flank_range` (option, default 50 as in
  * spades-core) (k+1)-mers of every canonical edge, and of its conjugate (= the last ones). Values restated from the reference source,

@@ -83,6 +83,7 @@ def load():
         "smx_graph_write_gfa": (C.c_int, [vp, C.c_char_p, C.c_char_p]),
         "smx_graph_fill_coverage": (C.c_int, [vp]),
         "smx_graph_copy_coverage": (C.c_int, [vp, u32p]),
+        "smx_graph_coverage_histogram": (C.c_int, [vp, u64p, C.c_uint64, u64p]),
         "smx_graph_write_unitigs": (C.c_int, [vp, C.c_char_p]),
         "smx_graph_write_spades": (C.c_int, [vp, C.c_char_p]),
         "smx_graph_write_fastg": (C.c_int, [vp, C.c_char_p]),

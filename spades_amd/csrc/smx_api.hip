@@ -799,6 +799,14 @@ int smx_graph_copy_flanking(const smx_ctx *ctx, uint32_t *flank_edge, uint32_t *
     return SMX_OK;
 }
 
+int smx_graph_coverage_histogram(const smx_ctx *ctx, uint64_t *hist, uint64_t capacity, uint64_t *n_entries) {
+    if (!ctx || !ctx->g_ready || !n_entries) return SMX_INVALID_PARAMETER;
+    *n_entries = ctx->g_cov_hist.size();
+    if (hist)
+        for (uint64_t c = 0; c < std::min<uint64_t>(capacity, ctx->g_cov_hist.size()); ++c) hist[c] = ctx->g_cov_hist[c];
+    return SMX_OK;
+}
+
 int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage) {
     if (!ctx || !ctx->g_ready || !raw_coverage) return SMX_INVALID_PARAMETER;
     if (ctx->gh.ecov.size() != ctx->g_ne) return SMX_INVALID_PARAMETER;

@@ -55,6 +55,7 @@ void clear_graph(smx_ctx *ctx) {
     ctx->g_ne = ctx->g_nuwords = ctx->g_nbases = ctx->g_npaths = ctx->g_nloops = 0;
     ctx->g_ready = false;
     ctx->g_host_valid = false;
+    ctx->g_cov_hist.clear();
     ctx->gh = smxh::GraphHost();
 }
 
@@ -1070,6 +1071,33 @@ int run_coverage(smx_ctx *ctx) {
         HIPCHK(hipGetLastError());
     }
     tend(ctx);
+    {   // multiplicity histogram of the (k+1)-mers
+        unsigned long long *d_hist, *d_nbig;
+        uint32_t *d_big;
+        const uint32_t bigcap = 1u << 20;
+        if (int rc = dalloc(ctx, &d_hist, COVH_N)) return rc;
+        if (int rc = dalloc(ctx, &d_nbig, 1)) return rc;
+        if (int rc = dalloc(ctx, &d_big, bigcap)) return rc;
+        HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)COVH_N * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(d_nbig, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(k_cov_hist, dim3(grid_for(D1, 4096)), dim3(BLK), 0, ctx->stream, (const uint32_t *)cnt, D1, d_hist, d_nbig, d_big, bigcap);
+        HIPCHK(hipGetLastError());
+        std::vector<unsigned long long> hh(COVH_N);
+        unsigned long long nbig = 0;
+        HIPCHK(hipMemcpyAsync(hh.data(), d_hist, (size_t)COVH_N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&nbig, d_nbig, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (nbig > bigcap) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%llu (k+1)-mers occur 65536 times or more: beyond the histogram's overflow list", nbig);
+        std::vector<uint32_t> hb;
+        if (int rc = d2h(ctx, hb, d_big, (size_t)nbig)) return rc;
+        uint64_t mx = 0;
+        for (uint32_t c = 0; c < COVH_N; ++c)
+            if (hh[c]) mx = c;
+        for (uint32_t c : hb) mx = std::max<uint64_t>(mx, c);
+        ctx->g_cov_hist.assign(mx + 1, 0);
+        for (uint32_t c = 0; c <= std::min<uint64_t>(mx, COVH_N - 1); ++c) ctx->g_cov_hist[c] = hh[c];
+        for (uint32_t c : hb) ctx->g_cov_hist[c]++;
+    }
     // the unitigs as a read batch: (k+1)-mer windows marked the same way
     tbegin(ctx, "edge_coverage");
     const uint64_t G = ctx->g_nuwords * 32;

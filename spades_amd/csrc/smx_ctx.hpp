@@ -109,6 +109,7 @@ struct smx_ctx {
     void *g_kpo_block = nullptr;  // allocation behind g_kpo
     uint64_t g_tip_kmers = 0, g_tips = 0;  // early tip clipper: k-mers isolated, tips removed
     uint64_t g_at_edges = 0, g_at_tip_kmers = 0;  // early A/T remover: length-1 edges marked, tip k-mers isolated
+    std::vector<uint64_t> g_cov_hist;  // [c] = canonical (k+1)-mers with multiplicity c (after smx_graph_fill_coverage)
     smxh::GraphHost gh;
 };
 

@@ -1022,6 +1022,28 @@ __global__ void __launch_bounds__(BLK) k_kpo_coverage(const uint64_t *seq, const
     }
 }
 
+// multiplicity histogram of the canonical (k+1)-mers (PHMCoverageFiller hands it to GenomicInfo::set_cov_histogram,
+// stages/construction.cpp:414-431): hist[c] for c < COVH_N, larger multiplicities (repeats; rare) appended to a list
+constexpr uint32_t COVH_LDS = 1024, COVH_N = 1u << 16;
+__global__ void __launch_bounds__(BLK) k_cov_hist(const uint32_t *cnt, uint64_t n, unsigned long long *hist, unsigned long long *nbig, uint32_t *big,
+                                                  uint32_t bigcap) {
+    __shared__ uint32_t lh[COVH_LDS];
+    for (uint32_t t = threadIdx.x; t < COVH_LDS; t += BLK) lh[t] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        const uint32_t c = cnt[i];
+        if (c < COVH_LDS) atomicAdd(&lh[c], 1u);
+        else if (c < COVH_N) atomicAdd(&hist[c], 1ull);
+        else {
+            const unsigned long long p = atomicAdd(nbig, 1ull);
+            if (p < bigcap) big[p] = c;
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < COVH_LDS; t += BLK)
+        if (lh[t]) atomicAdd(&hist[t], (unsigned long long)lh[t]);
+}
+
 // edge raw coverage = sum of the counters of the edge's (k+1)-mers (graph_support/coverage_filling.hpp:46-62), uint32; flanking raw
 // coverage = the same sum over the first `flank` (k+1)-mers (inc_coverage: offset < averaging_range, :40-44) of the edge (fl_s) and
 // of its conjugate, i.e. the last `flank` ones (fl_e). The unitigs are a packed stream with word-aligned starts; wmask marks the

@@ -68,3 +68,36 @@ def test_reference_construction_consumes_the_gpu_counter(tmp_path, k, threads):
     a, b = (tmp_path / "gpu.txt").read_text().split(), (tmp_path / "cpu.txt").read_text().split()
     assert len(a) > 0
     assert (a == b) if threads == 1 else (sorted(a) == sorted(b))  # the reference's order depends on its thread schedule
+
+
+@pytest.mark.parametrize("name", ["ecoli_1K", "synth_60k"])
+def test_spades_core_with_the_gpu_construction_stage(name):
+    """BASELINE config 1 plumbing through the GPU: the reference's spades-core, linked with integration/construction_gpu.cpp in place
+    of its Construction stage (link-time substitution, integration/Makefile), run on the configs the reference's spades.py generated.
+    Everything after the stage — simplification, repeat resolution, contig output — is the reference's code working on the graph,
+    coverage, flanking coverage and multiplicity histogram the MI355X produced: contigs, scaffolds and graphs must equal the all-CPU
+    run's byte for byte (assets: integration/make_spades_case.py, ecoli_1K = the data of `spades.py --test`)."""
+    import shutil
+    exe = _need(os.path.join(BUILD, "spades-core-gpu"))
+    src = _need(os.path.join(BUILD, "spades_case", name))
+    meta = dict(l.split() for l in open(os.path.join(src, "case.txt")))
+    case = meta["case_dir"]
+    shutil.rmtree(case, ignore_errors=True)
+    os.makedirs(case)
+    for f in ("reads_1.fq.gz", "reads_2.fq.gz"):
+        shutil.copy(os.path.join(src, f), os.path.join(case, f))
+    shutil.copytree(os.path.join(src, "run"), os.path.join(case, "run"))
+    os.makedirs(meta["tmp_dir"], exist_ok=True)
+    log = os.path.join(case, "core.log")
+    with open(log, "w") as lf:
+        rc = subprocess.call([exe, os.path.join(case, "run", "K21", "configs", "config.info")], stdout=lf, stderr=subprocess.STDOUT, timeout=600)
+    assert rc == 0, open(log).read()[-3000:]
+    assert "Graph construction on the MI355X" in open(log).read()
+    exp = os.path.join(src, "expected")
+    n = 0
+    for root, _, files in os.walk(exp):
+        for f in files:
+            rel = os.path.relpath(os.path.join(root, f), exp)
+            assert open(os.path.join(case, "run", rel), "rb").read() == open(os.path.join(root, f), "rb").read(), rel
+            n += 1
+    assert n >= 5
