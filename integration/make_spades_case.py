@@ -56,31 +56,34 @@ def write_pairs(codes, p1, p2):
             f2.write(b"@p%d/2\n%s\n+\n%s\n" % (i // 2, b, b"I" * len(b)))
 
 
-def make(name, r1, r2):
+def make(name, r1, r2, ks=("21",)):
     case = os.path.join(CASES, name)
     shutil.rmtree(case, ignore_errors=True)
     os.makedirs(case)
     shutil.copy(r1, os.path.join(case, "reads_1.fq.gz"))
     shutil.copy(r2, os.path.join(case, "reads_2.fq.gz"))
     run = os.path.join(case, "run")
-    subprocess.check_call([sys.executable, os.path.join(SCRATCH, "src/projects/spades/pipeline/spades.py"), "--only-assembler", "-k", "21",
+    subprocess.check_call([sys.executable, os.path.join(SCRATCH, "src/projects/spades/pipeline/spades.py"), "--only-assembler", "-k", ",".join(ks),
                            "-1", os.path.join(case, "reads_1.fq.gz"), "-2", os.path.join(case, "reads_2.fq.gz"), "-o", run, "-t", "4"],
                           stdout=subprocess.DEVNULL)
     out = os.path.join(HERE, "_build", "spades_case", name)
     shutil.rmtree(out, ignore_errors=True)
-    os.makedirs(os.path.join(out, "expected/K21"))
-    os.makedirs(os.path.join(out, "run/K21"))
+    os.makedirs(os.path.join(out, "run"))
     for f in ("reads_1.fq.gz", "reads_2.fq.gz"):
         shutil.copy(os.path.join(case, f), os.path.join(out, f))
-    shutil.copytree(os.path.join(run, "K21/configs"), os.path.join(out, "run/K21/configs"))
     for f in ("dataset.info", "input_dataset.yaml"):
         shutil.copy(os.path.join(run, f), os.path.join(out, "run", f))
-    for f in KEEP:
-        if os.path.exists(os.path.join(run, f)):
-            shutil.copy(os.path.join(run, f), os.path.join(out, "expected", f))
+    for kk in ks:
+        os.makedirs(os.path.join(out, f"expected/K{kk}"))
+        os.makedirs(os.path.join(out, f"run/K{kk}"))
+        shutil.copytree(os.path.join(run, f"K{kk}/configs"), os.path.join(out, f"run/K{kk}/configs"))
+        for f in KEEP:
+            f = f.replace("K21", f"K{kk}")
+            if os.path.exists(os.path.join(run, f)):
+                shutil.copy(os.path.join(run, f), os.path.join(out, "expected", f))
     tmp_dir = [l.split()[1] for l in open(os.path.join(run, "K21/configs/config.info")) if l.startswith("tmp_dir")][0]
     with open(os.path.join(out, "case.txt"), "w") as f:
-        f.write(f"case_dir {case}\ntmp_dir {tmp_dir}\n")
+        f.write(f"case_dir {case}\ntmp_dir {tmp_dir}\nks {','.join(ks)}\n")
     print(name, "->", out, [os.path.getsize(os.path.join(out, "expected", k)) for k in KEEP if os.path.exists(os.path.join(out, "expected", k))])
 
 
@@ -93,3 +96,4 @@ if __name__ == "__main__":
     p1, p2 = os.path.join(CASES, "s1.fq.gz"), os.path.join(CASES, "s2.fq.gz")
     write_pairs(codes, p1, p2)
     make("synth_60k", p1, p2)
+    make("synth_60k_k21_33", p1, p2, ks=("21", "33"))  # the K33 iteration takes the K21 contigs as an extra stream (construction.cpp:108-117)

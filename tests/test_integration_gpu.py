@@ -70,7 +70,7 @@ def test_reference_construction_consumes_the_gpu_counter(tmp_path, k, threads):
     assert (a == b) if threads == 1 else (sorted(a) == sorted(b))  # the reference's order depends on its thread schedule
 
 
-@pytest.mark.parametrize("name", ["ecoli_1K", "synth_60k"])
+@pytest.mark.parametrize("name", ["ecoli_1K", "synth_60k", "synth_60k_k21_33"])
 def test_spades_core_with_the_gpu_construction_stage(name):
     """BASELINE config 1 plumbing through the GPU: the reference's spades-core, linked with integration/construction_gpu.cpp in place
     of its Construction stage (link-time substitution, integration/Makefile), run on the configs the reference's spades.py generated.
@@ -88,11 +88,15 @@ def test_spades_core_with_the_gpu_construction_stage(name):
         shutil.copy(os.path.join(src, f), os.path.join(case, f))
     shutil.copytree(os.path.join(src, "run"), os.path.join(case, "run"))
     os.makedirs(meta["tmp_dir"], exist_ok=True)
-    log = os.path.join(case, "core.log")
-    with open(log, "w") as lf:
-        rc = subprocess.call([exe, os.path.join(case, "run", "K21", "configs", "config.info")], stdout=lf, stderr=subprocess.STDOUT, timeout=600)
-    assert rc == 0, open(log).read()[-3000:]
-    assert "Graph construction on the MI355X" in open(log).read()
+    for kk in meta.get("ks", "21").split(","):  # the iterations of a multi-k run, in spades.py's order
+        for line in open(os.path.join(case, "run", f"K{kk}", "configs", "config.info")):
+            if line.startswith("tmp_dir"):
+                os.makedirs(line.split()[1], exist_ok=True)
+        log = os.path.join(case, f"core_K{kk}.log")
+        with open(log, "w") as lf:
+            rc = subprocess.call([exe, os.path.join(case, "run", f"K{kk}", "configs", "config.info")], stdout=lf, stderr=subprocess.STDOUT, timeout=600)
+        assert rc == 0, open(log).read()[-3000:]
+        assert "Graph construction on the MI355X" in open(log).read()
     exp = os.path.join(src, "expected")
     n = 0
     for root, _, files in os.walk(exp):
