@@ -150,6 +150,12 @@ int smx_copy_kmers_device(const smx_ctx *ctx, void *d_dst);
 int smx_extract_count(smx_ctx *ctx, unsigned K, int mode, uint64_t *n_records);
 int smx_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets, unsigned world,
                           void *d_records, uint64_t capacity_records, uint64_t *counts /* [world] */);
+/* Same, into a buffer the library allocates itself, sized to what the local pre-dedupe leaves (one record per window instance — all
+ * the caller could provide for without knowing the data — is 150 GB at 100 M PE150 reads): *d_records is valid until the next
+ * smx_extract_partition* / smx_extract_release / smx_destroy. Release it before smx_count_records when HBM is short. */
+int smx_extract_partition_owned(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets, unsigned world, const void **d_records,
+                                uint64_t *counts /* [world] */);
+int smx_extract_release(smx_ctx *ctx);
 int smx_count_records(smx_ctx *ctx, unsigned K, unsigned num_buckets, const void *d_records,
                       uint64_t n_records);
 /* first bucket owned by rank r of world (rank r owns [first(r), first(r+1))) */

@@ -62,6 +62,7 @@ void smx_destroy(smx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     smx_reads_clear(ctx);
+    (void)smx_extract_release(ctx);
     clear_graph(ctx);
     clear_result(ctx);
     free_temps(ctx);
@@ -517,18 +518,20 @@ int smx_extract_count(smx_ctx *ctx, unsigned K, int mode, uint64_t *n_records) {
 }
 
 
-int smx_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets, unsigned world, void *d_records,
-                          uint64_t capacity_records, uint64_t *counts) {
+static int extract_partition_impl(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets, unsigned world, void *d_records,
+                                  uint64_t capacity_records, uint64_t *counts, void **owned) {
     if (!ctx || !counts) return SMX_INVALID_PARAMETER;
     if (K < 1 || K > 128) return fail(ctx, SMX_INVALID_PARAMETER, "K=%u out of range [1,128]", K);
     if (world < 1 || world > 4096 || num_buckets < 1) return fail(ctx, SMX_INVALID_PARAMETER, "bad world/num_buckets");
     HIPCHK(hipSetDevice(ctx->device));
+    arena_put(ctx, ctx->x_owned);
+    ctx->x_owned = nullptr;
     int rc;
     switch ((K + 31) / 32) {
-        case 1: rc = run_extract_partition<1>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts); break;
-        case 2: rc = run_extract_partition<2>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts); break;
-        case 3: rc = run_extract_partition<3>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts); break;
-        default: rc = run_extract_partition<4>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts); break;
+        case 1: rc = run_extract_partition<1>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned); break;
+        case 2: rc = run_extract_partition<2>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned); break;
+        case 3: rc = run_extract_partition<3>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned); break;
+        default: rc = run_extract_partition<4>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned); break;
     }
     (void)hipStreamSynchronize(ctx->stream);
     if (rc == 0) {
@@ -537,15 +540,41 @@ int smx_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned num_bucke
         ctx->xms = ctx->tms;
         ctx->tnames.clear();
         ctx->tms.clear();
+        if (owned) ctx->x_owned = *owned;
     } else {
         for (auto &t : ctx->timings) {
             (void)hipEventDestroy(t.e0);
             (void)hipEventDestroy(t.e1);
         }
         ctx->timings.clear();
+        if (owned && *owned) {
+            arena_put(ctx, *owned);
+            *owned = nullptr;
+        }
     }
     free_temps(ctx);
     return rc;
+}
+
+int smx_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets, unsigned world, void *d_records,
+                          uint64_t capacity_records, uint64_t *counts) {
+    return extract_partition_impl(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, nullptr);
+}
+
+int smx_extract_partition_owned(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets, unsigned world, const void **d_records,
+                                uint64_t *counts) {
+    if (!d_records) return SMX_INVALID_PARAMETER;
+    void *p = nullptr;
+    const int rc = extract_partition_impl(ctx, K, mode, num_buckets, world, nullptr, 0, counts, &p);
+    *d_records = p;
+    return rc;
+}
+
+int smx_extract_release(smx_ctx *ctx) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    arena_put(ctx, ctx->x_owned);
+    ctx->x_owned = nullptr;
+    return SMX_OK;
 }
 
 static int build_graph_impl(smx_ctx *ctx, unsigned k, unsigned num_buckets, const void *recs, uint64_t nrecs) {

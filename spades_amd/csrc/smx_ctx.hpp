@@ -52,6 +52,7 @@ struct smx_ctx {
     };
     std::vector<HostChunk> h_result;
     bool result_on_host = false;
+    void *x_owned = nullptr;  // output of smx_extract_partition_owned (released by the next count / extract / smx_extract_release)
     bool single_batch_only = false;  // count_reads: fail (memory limit) rather than cut the input into batches
     uint64_t n_records = 0, n_instances = 0;
     unsigned nw = 0, K = 0, num_buckets = 0;
@@ -255,6 +256,14 @@ bool arena_grow(smx_ctx *ctx, size_t want, bool top) {
     if (A.lo + bytes > A.hi) {
         A.last_err = "the arena is full";
         return false;
+    }
+    {   // somebody else (torch in the same process, another context) may have taken VRAM since the range was sized: never map into the
+        // last 5 % of the device (a box whose VRAM is mapped to the last chunk dies instead of returning an error)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < bytes + total_b / 20) {
+            A.last_err = "the device has no free memory left for the arena";
+            return false;
+        }
     }
     if (!top) {
         if (!arena_map_chunks(ctx, A.lo / A.gran, (A.lo + bytes) / A.gran)) return false;

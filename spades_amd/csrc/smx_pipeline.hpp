@@ -1009,12 +1009,14 @@ int dispatch_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d
 namespace {
 template <int NW>
 int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned world, void *d_records, uint64_t capacity,
-                          uint64_t *counts) {
+                          uint64_t *counts, void **owned_out = nullptr) {
+    // owned_out: the library allocates the output itself, sized to what the local pre-dedupe leaves (the caller cannot know that
+    // number in advance; one record per window instance would be 150 GB at 100 M reads), and hands the block out (*owned_out)
     std::vector<uint64_t *> masks;
     uint64_t nwin = 0;
     if (int rc = mark_windows(ctx, K, masks, &nwin)) return rc;
     uint64_t nrec = mode == SMX_MODE_ALL ? 2 * nwin : nwin;
-    if (nrec > capacity) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "record buffer too small: need %llu", (unsigned long long)nrec);
+    if (!owned_out && nrec > capacity) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "record buffer too small: need %llu", (unsigned long long)nrec);
     // Local pre-dedupe first ("optional local sort-unique per destination to cut volume by ~coverage"): the
     // exchange then carries every distinct k-mer of this rank once instead of every instance.
     Rec<NW> *recs = nullptr;
@@ -1024,8 +1026,23 @@ int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsign
         ReadSel sel;
         sel.masks = &masks;
         sel.nrec = nrec;
-        if (int rc = run_prededupe<NW>(ctx, K, sel, nwin, &recs, &n_dedup)) return rc;
+        uint64_t out_cap = 0;  // 0 = one record per window
+        if (owned_out) {       // HBM plan: pre-dedupe output + the partitioned copy of it (x2 in mode A)
+            const double W = NW * 8.0;
+            const double room = (double)arena_avail(ctx) - 5.0 * (double)nwin;
+            const uint64_t fit = room > 0 ? (uint64_t)(room / ((mode == SMX_MODE_ALL ? 3.0 : 2.0) * W + 12)) : 0;
+            out_cap = std::max<uint64_t>(std::min<uint64_t>(fit, nwin), 1);
+        }
+        int rc = run_prededupe<NW>(ctx, K, sel, nwin, &recs, &n_dedup, out_cap);
+        if (rc == SMX_RETRY_SMALLER) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the distinct k-mers of this rank's reads do not fit the HBM budget for the exchange");
+        if (rc) return rc;
         nrec = mode == SMX_MODE_ALL ? 2 * n_dedup : n_dedup;
+    }
+    if (owned_out) {
+        Rec<NW> *o;
+        if (int rc = dalloc(ctx, &o, std::max<uint64_t>(nrec, 1), false)) return rc;
+        d_records = o;
+        *owned_out = o;
     }
     unsigned long long *hist, *off, *cur, *seg1 = nullptr, *tcnt = nullptr, *tstart = nullptr;
     if (int rc = dalloc(ctx, &hist, world)) return rc;

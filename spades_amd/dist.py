@@ -42,6 +42,24 @@ class GpuEngine:
         _chk(self.ctx._h, self.ctx.lib.smx_extract_partition(self.ctx._h, K, self.mode, nb, world, buf.data_ptr(), capacity, counts))
         return [int(c) for c in counts]
 
+    def extract_partition_owned(self, K: int, nb: int, world: int, dev):
+        """records of this rank grouped by owner, in a buffer the library sized after its local pre-dedupe; returned as a tensor view"""
+        counts = (C.c_uint64 * world)()
+        ptr = C.c_void_p()
+        _chk(self.ctx._h, self.ctx.lib.smx_extract_partition_owned(self.ctx._h, K, self.mode, nb, world, C.byref(ptr), counts))
+        counts = [int(c) for c in counts]
+        n_words = sum(counts) * ((K + 31) // 32)
+
+        class _View:
+            def __init__(self, p, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (p, False), "version": 2}
+        if n_words == 0:
+            return torch.empty(1, dtype=torch.int64, device=dev), counts
+        return torch.as_tensor(_View(ptr.value, n_words), device=dev), counts
+
+    def extract_release(self):
+        _chk(self.ctx._h, self.ctx.lib.smx_extract_release(self.ctx._h))
+
     def count_records(self, K: int, nb: int, buf: torch.Tensor, n: int):
         h = self.ctx._h
         _chk(h, self.ctx.lib.smx_count_records(h, K, nb, buf.data_ptr(), n))
@@ -167,10 +185,17 @@ def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
     (+ 'sent'/'received' record counts). Collective: every rank must call it."""
     nw = (K + 31) // 32
     n_local = engine.extract_count(K)
-    send = engine.alloc(n_local * nw, dev)
-    counts = engine.extract_partition(K, nb, world, send, n_local)
+    if hasattr(engine, "extract_partition_owned"):
+        # the library sizes the send buffer itself: what its local pre-dedupe leaves, not one record per window instance
+        send, counts = engine.extract_partition_owned(K, nb, world, dev)
+    else:
+        send = engine.alloc(n_local * nw, dev)
+        counts = engine.extract_partition(K, nb, world, send, n_local)
     n_sent = sum(counts)  # < n_local when the engine pre-dedupes its shard before the exchange
     recv, n_recv = _exchange(engine, send, counts, nw, rank, world, dev)
+    del send
+    if hasattr(engine, "extract_release"):
+        engine.extract_release()  # room for the owner-side count
     res = engine.count_records(K, nb, recv, n_recv)
     res["sent"], res["received"] = n_sent, n_recv
     res["instances"] = n_local  # k-mer instances extracted from this rank's reads
