@@ -156,6 +156,12 @@ int smx_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned num_bucke
 int smx_extract_partition_owned(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets, unsigned world, const void **d_records,
                                 uint64_t *counts /* [world] */);
 int smx_extract_release(smx_ctx *ctx);
+/* Receive side of the exchange in the library's HBM pool (what a framework allocator caches after the step is out of the pool's
+ * reach): n_words 64-bit words, valid until smx_count_records is given exactly this pointer — which consumes it: the records are
+ * sorted in place, one record buffer less than for caller memory — or smx_exchange_release / smx_destroy.
+ * smx_extract_partition_owned drops the context's previous count result and graph (the next step needs their room). */
+int smx_exchange_buffer(smx_ctx *ctx, uint64_t n_words, void **d_buf);
+int smx_exchange_release(smx_ctx *ctx);
 int smx_count_records(smx_ctx *ctx, unsigned K, unsigned num_buckets, const void *d_records,
                       uint64_t n_records);
 /* first bucket owned by rank r of world (rank r owns [first(r), first(r+1))) */

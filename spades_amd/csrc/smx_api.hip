@@ -63,6 +63,7 @@ void smx_destroy(smx_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     smx_reads_clear(ctx);
     (void)smx_extract_release(ctx);
+    (void)smx_exchange_release(ctx);
     clear_graph(ctx);
     clear_result(ctx);
     free_temps(ctx);
@@ -381,7 +382,26 @@ int smx_count_records(smx_ctx *ctx, unsigned K, unsigned num_buckets, const void
     if (!ctx) return SMX_INVALID_PARAMETER;
     if (n_records && !d_records) return fail(ctx, SMX_INVALID_PARAMETER, "null records");
     static const uint64_t dummy = 0;
-    return dispatch_count(ctx, K, SMX_MODE_ALL, num_buckets, n_records ? d_records : (const void *)&dummy, n_records);
+    // records in the library's own exchange buffer are consumed: the buffer serves as one of the sort's ping-pong buffers
+    const bool own = ctx->x_recv && d_records == ctx->x_recv;
+    const int rc = dispatch_count(ctx, K, SMX_MODE_ALL, num_buckets, n_records ? d_records : (const void *)&dummy, n_records, own);
+    if (own) {
+        if (ctx->d_result_buf != ctx->x_recv) arena_put(ctx, ctx->x_recv);
+        ctx->x_recv = nullptr;
+    }
+    return rc;
+}
+
+int smx_exchange_buffer(smx_ctx *ctx, uint64_t n_words, void **d_buf) {
+    if (!ctx || !d_buf) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    arena_put(ctx, ctx->x_recv);
+    ctx->x_recv = nullptr;
+    *d_buf = nullptr;
+    void *p = arena_get(ctx, std::max<uint64_t>(n_words, 1) * 8, false);
+    if (!p) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "no room for an exchange buffer of %llu words", (unsigned long long)n_words);
+    *d_buf = ctx->x_recv = p;
+    return SMX_OK;
 }
 
 int smx_count_info(const smx_ctx *ctx, uint64_t *n_records, unsigned *words_per_record, uint64_t *n_kmer_instances) {
@@ -526,6 +546,10 @@ static int extract_partition_impl(smx_ctx *ctx, unsigned K, int mode, unsigned n
     HIPCHK(hipSetDevice(ctx->device));
     arena_put(ctx, ctx->x_owned);
     ctx->x_owned = nullptr;
+    if (owned) {  // the library plans the HBM of this step itself: the previous step's result and graph make room
+        clear_graph(ctx);
+        clear_result(ctx);
+    }
     int rc;
     switch ((K + 31) / 32) {
         case 1: rc = run_extract_partition<1>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned); break;
@@ -574,6 +598,13 @@ int smx_extract_release(smx_ctx *ctx) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     arena_put(ctx, ctx->x_owned);
     ctx->x_owned = nullptr;
+    return SMX_OK;
+}
+
+int smx_exchange_release(smx_ctx *ctx) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    arena_put(ctx, ctx->x_recv);
+    ctx->x_recv = nullptr;
     return SMX_OK;
 }
 

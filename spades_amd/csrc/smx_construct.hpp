@@ -241,9 +241,10 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B, bool from_reads) {
     // (k+1)-mer. (Not when the (k+1)-mer file came from other ranks: there are no reads for it here.)
     uint64_t n_bases = 0;
     for (auto &c : ctx->chunks) n_bases += c.n_bases;
-    // (only when one batch is sure to fit next to the (k+1)-mer file: super-k-mer slots < 5 B per window, two buffers of about as many
-    // k-mers as there are (k+1)-mers; batches, folds or a host spill would cost more than the derivation)
-    const double need_reads_route = 1.15 * (5.0 * (double)n_bases + 2.2 * (double)nkpo * (double)W);
+    // (only when one batch should fit next to the (k+1)-mer file — first the super-k-mer slots, < 5 B per window, next to one buffer of
+    // about as many k-mers as there are (k+1)-mers, then two such buffers; batches, folds or a host spill would cost more than the
+    // derivation, and count_reads gives up instead of taking them: single_batch_only)
+    const double need_reads_route = 1.08 * std::max(5.0 * (double)n_bases + 1.1 * (double)nkpo * (double)W, 2.25 * (double)nkpo * (double)W);
     if (from_reads && ctx->opt_kmers_from_reads != 0 && ctx->opt_derive_batches == 0 &&
         (ctx->opt_kmers_from_reads > 1 || need_reads_route <= (double)arena_avail(ctx))) {
         ctx->single_batch_only = true;

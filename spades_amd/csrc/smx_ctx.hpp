@@ -52,7 +52,8 @@ struct smx_ctx {
     };
     std::vector<HostChunk> h_result;
     bool result_on_host = false;
-    void *x_owned = nullptr;  // output of smx_extract_partition_owned (released by the next count / extract / smx_extract_release)
+    void *x_owned = nullptr;  // output of smx_extract_partition_owned (released by the next extract / smx_extract_release)
+    void *x_recv = nullptr;   // smx_exchange_buffer: receive side of the exchange, consumed by smx_count_records
     bool single_batch_only = false;  // count_reads: fail (memory limit) rather than cut the input into batches
     uint64_t n_records = 0, n_instances = 0;
     unsigned nw = 0, K = 0, num_buckets = 0;

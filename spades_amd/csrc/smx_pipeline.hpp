@@ -596,7 +596,7 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     // Output capacity: one record per window can never overflow; a smaller buffer (HBM-bounded) keeps a share for the survivors of
     // cut keys at its far end and reports an overflow (the caller then takes smaller batches).
     if (out_cap == 0 || out_cap > nwin) out_cap = nwin;
-    const uint64_t dirty_cap = out_cap == nwin ? out_cap : std::max<uint64_t>(out_cap / 8, 1);
+    const uint64_t dirty_cap = out_cap == nwin ? out_cap : std::max<uint64_t>(out_cap / 16, 1);
     const uint64_t clean_cap = out_cap == nwin ? out_cap : out_cap - dirty_cap;
     if (int rc = dalloc(ctx, out, out_cap + 1)) return rc;
     // Chunk capacity of the LDS hash set: every copy of a k-mer sits in ONE partition, and a partition that does not fit a chunk is
@@ -677,13 +677,15 @@ int count_selection(smx_ctx *ctx, unsigned K, int mode, unsigned B, const ReadSe
     // HBM plan: behind the pre-dedupe stage only the distinct canonical records exist. Its output buffer never needs more than one
     // record per window, and not more than what leaves room for the pipeline's own buffers (mode B: the output buffer doubles as one
     // of the two ping-pong buffers; mode A: two buffers of twice the records).
+    // Two phases share the budget: the stage itself (super-k-mer slots + staging, < 5 B per window, next to its output buffer) and
+    // the sort (the output buffer + the ping-pong buffers of the distinct records; the stage's temporaries are gone by then).
     uint64_t out_cap = nwin;
     {
-        const double W = NW * 8.0;
-        const double room = (double)arena_avail(ctx) - 5.0 * (double)nwin;  // super-k-mer slots + staging: < 5 B per window
-        const double per = mode == SMX_MODE_ALL ? 5.0 * W + 24 : 2.0 * W + 12;
-        const uint64_t fit = room > 0 ? (uint64_t)(room / per) : 0;
-        if (fit < nwin) out_cap = std::max<uint64_t>(fit, 1);
+        const double W = NW * 8.0, avail = (double)arena_avail(ctx);
+        const double fit1 = (avail - 5.0 * (double)nwin) / W;
+        const double fit2 = avail / (mode == SMX_MODE_ALL ? 5.0 * W + 24 : 2.0 * W + 12);
+        const double fit = std::max(std::min(fit1, fit2), 1.0);
+        if (fit < (double)nwin) out_cap = (uint64_t)fit;
     }
     Rec<NW> *recs = nullptr;
     uint64_t n = 0;
@@ -972,7 +974,7 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
     }
 }
 
-int dispatch_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in) {
+int dispatch_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs, uint64_t n_in, bool recs_reusable = false) {
     if (K < 1 || K > 128) return fail(ctx, SMX_INVALID_PARAMETER, "K=%u out of range [1,128]", K);
     if (B < 1) return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets must be >= 1");
     if (mode != SMX_MODE_ALL && mode != SMX_MODE_CANONICAL) return fail(ctx, SMX_INVALID_PARAMETER, "bad mode %d", mode);
@@ -980,10 +982,10 @@ int dispatch_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d
     int rc;
     const bool reads = d_recs == nullptr;
     switch ((K + 31) / 32) {
-        case 1: rc = reads ? count_reads<1>(ctx, K, mode, B) : run_count<1>(ctx, K, mode, B, d_recs, n_in); break;
-        case 2: rc = reads ? count_reads<2>(ctx, K, mode, B) : run_count<2>(ctx, K, mode, B, d_recs, n_in); break;
-        case 3: rc = reads ? count_reads<3>(ctx, K, mode, B) : run_count<3>(ctx, K, mode, B, d_recs, n_in); break;
-        default: rc = reads ? count_reads<4>(ctx, K, mode, B) : run_count<4>(ctx, K, mode, B, d_recs, n_in); break;
+        case 1: rc = reads ? count_reads<1>(ctx, K, mode, B) : run_count<1>(ctx, K, mode, B, d_recs, n_in, nullptr, recs_reusable); break;
+        case 2: rc = reads ? count_reads<2>(ctx, K, mode, B) : run_count<2>(ctx, K, mode, B, d_recs, n_in, nullptr, recs_reusable); break;
+        case 3: rc = reads ? count_reads<3>(ctx, K, mode, B) : run_count<3>(ctx, K, mode, B, d_recs, n_in, nullptr, recs_reusable); break;
+        default: rc = reads ? count_reads<4>(ctx, K, mode, B) : run_count<4>(ctx, K, mode, B, d_recs, n_in, nullptr, recs_reusable); break;
     }
     if (rc == 0) {
         WallTrace wt;
@@ -1027,16 +1029,19 @@ int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsign
         sel.masks = &masks;
         sel.nrec = nrec;
         uint64_t out_cap = 0;  // 0 = one record per window
-        if (owned_out) {       // HBM plan: pre-dedupe output + the partitioned copy of it (x2 in mode A)
-            const double W = NW * 8.0;
-            const double room = (double)arena_avail(ctx) - 5.0 * (double)nwin;
-            const uint64_t fit = room > 0 ? (uint64_t)(room / ((mode == SMX_MODE_ALL ? 3.0 : 2.0) * W + 12)) : 0;
-            out_cap = std::max<uint64_t>(std::min<uint64_t>(fit, nwin), 1);
+        if (owned_out) {       // HBM plan: the stage's temporaries next to its output, then the output next to its partitioned copy (x2 in mode A)
+            const double W = NW * 8.0, avail = (double)arena_avail(ctx);
+            const double fit = std::max(std::min((avail - 5.0 * (double)nwin) / W, avail / ((mode == SMX_MODE_ALL ? 3.0 : 2.0) * W + 12)), 1.0);
+            out_cap = (uint64_t)std::min(fit, (double)nwin);
         }
         int rc = run_prededupe<NW>(ctx, K, sel, nwin, &recs, &n_dedup, out_cap);
         if (rc == SMX_RETRY_SMALLER) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the distinct k-mers of this rank's reads do not fit the HBM budget for the exchange");
         if (rc) return rc;
         nrec = mode == SMX_MODE_ALL ? 2 * n_dedup : n_dedup;
+        if (owned_out) {  // the stage's slots and staging area are no longer needed
+            free_temps(ctx, recs);
+            ctx->temps.push_back(recs);
+        }
     }
     if (owned_out) {
         Rec<NW> *o;

@@ -24,6 +24,13 @@ def rank_first_bucket(num_buckets: int, world: int, rank: int) -> int:
     return (rank * num_buckets + world - 1) // world
 
 
+class _DevView:
+    """int64 view of library-owned HBM for torch.as_tensor (no copy, no ownership)"""
+
+    def __init__(self, p: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (p, False), "version": 2}
+
+
 class GpuEngine:
     def __init__(self, ctx: Context, mode: str):
         self.ctx = ctx
@@ -49,13 +56,17 @@ class GpuEngine:
         _chk(self.ctx._h, self.ctx.lib.smx_extract_partition_owned(self.ctx._h, K, self.mode, nb, world, C.byref(ptr), counts))
         counts = [int(c) for c in counts]
         n_words = sum(counts) * ((K + 31) // 32)
-
-        class _View:
-            def __init__(self, p, n):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (p, False), "version": 2}
         if n_words == 0:
             return torch.empty(1, dtype=torch.int64, device=dev), counts
-        return torch.as_tensor(_View(ptr.value, n_words), device=dev), counts
+        return torch.as_tensor(_DevView(ptr.value, n_words), device=dev), counts
+
+    def alloc_recv(self, n_words: int, dev):
+        """receive side of the exchange in the library's own HBM pool (consumed by count_records), as a tensor view"""
+        if n_words == 0:
+            return torch.empty(1, dtype=torch.int64, device=dev)
+        ptr = C.c_void_p()
+        _chk(self.ctx._h, self.ctx.lib.smx_exchange_buffer(self.ctx._h, n_words, C.byref(ptr)))
+        return torch.as_tensor(_DevView(ptr.value, n_words), device=dev)
 
     def extract_release(self):
         _chk(self.ctx._h, self.ctx.lib.smx_extract_release(self.ctx._h))
@@ -131,7 +142,7 @@ class GpuEngine:
         _chk(self.ctx._h, self.ctx.lib.smx_graph_set_coverage(self.ctx._h, C.cast(cov.data_ptr(), C.POINTER(C.c_uint32)), cov.numel()))
 
 
-def _exchange(engine, send: torch.Tensor, counts, wpr: int, rank: int, world: int, dev):
+def _exchange(engine, send: torch.Tensor, counts, wpr: int, rank: int, world: int, dev, pool: bool = False):
     """ONE all-to-all of records of `wpr` int64 words: counts[p] records go to rank p. Returns (recv tensor, records received).
     Splits are capped at XCHG_LIMIT elements per (pair, round): one all_to_all_single of a 30 GB buffer (3.8 G int64 elements)
     silently truncates on this stack (measured: tail left untouched), so large segments go in several rounds of views (no staging
@@ -142,7 +153,8 @@ def _exchange(engine, send: torch.Tensor, counts, wpr: int, rank: int, world: in
     dist.all_to_all_single(rcv_t, cnt_t)
     rcounts = [int(c) for c in rcv_t.tolist()]
     n_recv = sum(rcounts)
-    recv = engine.alloc(n_recv * wpr, dev)
+    # pool: the receive buffer comes from the engine's own HBM pool and is consumed by the count that follows
+    recv = (engine.alloc_recv if pool and hasattr(engine, "alloc_recv") else engine.alloc)(n_recv * wpr, dev)
     soff = [0]
     for c in counts:
         soff.append(soff[-1] + c * wpr)
@@ -192,7 +204,7 @@ def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
         send = engine.alloc(n_local * nw, dev)
         counts = engine.extract_partition(K, nb, world, send, n_local)
     n_sent = sum(counts)  # < n_local when the engine pre-dedupes its shard before the exchange
-    recv, n_recv = _exchange(engine, send, counts, nw, rank, world, dev)
+    recv, n_recv = _exchange(engine, send, counts, nw, rank, world, dev, pool=True)
     del send
     if hasattr(engine, "extract_release"):
         engine.extract_release()  # room for the owner-side count

@@ -1,6 +1,6 @@
 // spades_amd/tools/kmercount_mgpu.hpp — spades-kmercount on N GPUs of one node, C++ host over librccl.
 // One process per GPU (forked by the tool itself before any HIP call), bucket-range owners, ONE exchange:
-//   own input files -> smx_extract_partition (local pre-dedupe, records grouped by owner) -> counts by ncclAllGather ->
+//   own input files -> smx_extract_partition_owned (local pre-dedupe, records grouped by owner) -> counts by ncclAllGather ->
 //   grouped ncclSend / ncclRecv between all pairs (every pair has its own xGMI link; no ring) -> smx_count_records on the owner ->
 //   every rank writes its bucket range into <workdir>/final_kmers at its byte offset (buckets are contiguous per rank, so the file
 //   is the concatenation of the rank outputs: KMerDiskStorage::merge, kmer_index_builder.hpp:190-203).
@@ -100,14 +100,16 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
         }
     }
     const unsigned NB = 16, nw = (K + 31) / 32;  // 16 buckets: kmercount.cpp:220
-    uint64_t n_local = 0;
-    if (int rc = smx_extract_count(ctx, K, SMX_MODE_ALL, &n_local)) return rc;
+    // records grouped by owner in a buffer of the library's pool, sized after the local pre-dedupe (not one record per k-mer instance)
     uint64_t *d_send = nullptr, *d_recv = nullptr, *d_cnt = nullptr, *d_all = nullptr;
-    MG_HIP(hipMalloc((void **)&d_send, std::max<uint64_t>(n_local, 1) * nw * 8));
     std::vector<uint64_t> counts(world, 0);
-    if (int rc = smx_extract_partition(ctx, K, SMX_MODE_ALL, NB, (unsigned)world, d_send, n_local, counts.data())) {
-        fprintf(stderr, "%s\n", smx_last_error(ctx));
-        return rc;
+    {
+        const void *p = nullptr;
+        if (int rc = smx_extract_partition_owned(ctx, K, SMX_MODE_ALL, NB, (unsigned)world, &p, counts.data())) {
+            fprintf(stderr, "%s\n", smx_last_error(ctx));
+            return rc;
+        }
+        d_send = (uint64_t *)const_cast<void *>(p);
     }
     // counts of every pair
     MG_HIP(hipMalloc((void **)&d_cnt, (size_t)world * 8));
@@ -123,7 +125,14 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
         roff[p + 1] = roff[p] + all[(size_t)p * world + rank];  // what rank p sends to me
     }
     const uint64_t n_recv = roff[world];
-    MG_HIP(hipMalloc((void **)&d_recv, std::max<uint64_t>(n_recv, 1) * nw * 8));
+    {  // receive side in the pool as well: smx_count_records sorts it in place
+        void *p = nullptr;
+        if (int rc = smx_exchange_buffer(ctx, n_recv * nw, &p)) {
+            fprintf(stderr, "%s\n", smx_last_error(ctx));
+            return rc;
+        }
+        d_recv = (uint64_t *)p;
+    }
     // the exchange: all pairs at once, every pair on its own xGMI link
     MG_NCCL(ncclGroupStart());
     for (int p = 0; p < world; ++p) {
@@ -133,12 +142,11 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
     }
     MG_NCCL(ncclGroupEnd());
     MG_HIP(hipStreamSynchronize(stream));
-    MG_HIP(hipFree(d_send));
+    smx_extract_release(ctx);
     if (int rc = smx_count_records(ctx, K, NB, d_recv, n_recv)) {
         fprintf(stderr, "%s\n", smx_last_error(ctx));
         return rc;
     }
-    MG_HIP(hipFree(d_recv));
     // file offsets: records per rank
     uint64_t n_mine = 0;
     smx_count_info(ctx, &n_mine, nullptr, nullptr);
