@@ -341,7 +341,7 @@ def main():
     pmc_rows = {}
     if not sharded and not args.count_only and n_reads == 100_000_000 and k == 55 and T == 16 and os.path.exists(pmc):
         for line in open(pmc):
-            f = line.strip().split(",")
+            f = line.strip().rsplit(",", 5)  # kernel names hold commas (template arguments)
             if len(f) >= 6 and f[0] not in ("kernel", "TOTAL"):
                 try:
                     pmc_rows[f[0]] = float(f[3]) + float(f[5])

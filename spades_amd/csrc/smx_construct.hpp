@@ -363,6 +363,94 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B, bool from_reads) {
     return 0;
 }
 
+// The k-mer file AND the InOutMask bytes from one count of the resident reads (no (k+1)-mer file, no mask fill): the pre-dedupe
+// stage knows the bases next to every k-mer instance — the (k+1)-mers around it — and hands the OR of their extension bits on inside
+// the records (EXT layout, smx_device.hpp); after the sort one streaming pass splits records into k-mers and bytes.
+// Equivalent to the reference's route (count the (k+1)-mers, out[prefix] / in[suffix] per (k+1)-mer,
+// kmer_extension_index_builder.hpp:45-60): a (k+1)-mer is in that file iff it is a valid window of some read, and then it is the
+// window behind its prefix instance and before its suffix instance. Needs >= 8 spare bits in the last record word, two words
+// or more, the pre-dedupe stage (k >= 21, enough windows) and one batch; SMX_ROUTE_NA otherwise (nothing changed).
+template <int NW>
+int kmer_file_with_masks(smx_ctx *ctx, unsigned k, unsigned B) {
+    if (ctx->opt_ext_route == 0 || !ext_layout_fits(k, NW) || ctx->chunks.empty() || ctx->opt_derive_batches != 0) return SMX_ROUTE_NA;
+    const size_t W = (size_t)NW * 8;
+    ctx->ext_mode = true;
+    ctx->single_batch_only = true;
+    int rc = count_reads<NW>(ctx, k, SMX_MODE_CANONICAL, B, k + 1);
+    ctx->ext_mode = false;
+    ctx->single_batch_only = false;
+    if (rc == SMX_ROUTE_NA) return rc;
+    if (rc == SMX_MEMORY_LIMIT_EXCEEDED || (rc == 0 && ctx->result_on_host)) {
+        free_temps(ctx);
+        clear_result(ctx);
+        return SMX_ROUTE_NA;
+    }
+    if (rc) return rc;
+    void *raw = ctx->d_result_buf;
+    const uint64_t n = ctx->n_records;
+    const std::vector<uint64_t> raw_off = ctx->bucket_off;
+    ctx->d_result_buf = ctx->d_result = nullptr;
+    free_temps(ctx, raw);
+    ctx->temps.push_back(raw);
+    ctx->g_kboff.assign(B + 1, 0);
+    if (n == 0) {
+        free_temps(ctx);
+        ctx->g_nkmers = ctx->g_nkpo = 0;
+        return 0;
+    }
+    const uint64_t ntiles = (n + XM_TILE - 1) / XM_TILE;
+    unsigned long long *tcnt, *toff, *stats, *d_old, *d_new;
+    if (int rc2 = dalloc(ctx, &tcnt, ntiles)) return rc2;
+    if (int rc2 = dalloc(ctx, &toff, ntiles + 1)) return rc2;
+    if (int rc2 = dalloc(ctx, &stats, 2)) return rc2;
+    if (int rc2 = dalloc(ctx, &d_old, B + 1)) return rc2;
+    if (int rc2 = dalloc(ctx, &d_new, B + 1)) return rc2;
+    HIPCHK(hipMemsetAsync(stats, 0, 16, ctx->stream));
+    {
+        std::vector<unsigned long long> h(raw_off.begin(), raw_off.end());
+        HIPCHK(hipMemcpyAsync(d_old, h.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    tbegin(ctx, "ext_merge");
+    const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 16);
+    hipLaunchKernelGGL((k_ext_heads<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)raw, n, tcnt);
+    HIPCHK(hipGetLastError());
+    if (int rc2 = scan_u64(ctx, tcnt, toff, ntiles)) return rc2;
+    unsigned long long nk = 0;
+    HIPCHK(hipMemcpyAsync(&nk, toff + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    Rec<NW> *file;
+    if (int rc2 = dalloc(ctx, &file, nk, false)) return rc2;
+    ctx->g_kmers = file;
+    ctx->g_nkmers = nk;
+    const size_t mask_bytes = (size_t)((nk + 7) / 8 * 8 + 8);
+    if (int rc2 = dalloc(ctx, &ctx->g_mask, mask_bytes, false)) return rc2;
+    HIPCHK(hipMemsetAsync(ctx->g_mask + nk, 0, mask_bytes - nk, ctx->stream));
+    hipLaunchKernelGGL((k_ext_merge<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)raw, n, (const unsigned long long *)toff, k, (void *)file,
+                       ctx->g_mask, stats);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL((k_ext_boff<NW>), dim3((B + 1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, (const void *)raw, n, (const unsigned long long *)toff,
+                       (const unsigned long long *)d_old, B + 1, d_new);
+    HIPCHK(hipGetLastError());
+    tend(ctx);
+    std::vector<unsigned long long> hn(B + 1);
+    unsigned long long hs[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(hn.data(), d_new, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hs, stats, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (unsigned b = 0; b <= B; ++b) ctx->g_kboff[b] = hn[b];
+    if (ctx->g_kboff[B] != nk) return fail(ctx, SMX_DEVICE_ERROR, "inconsistent bucket offsets after the extension merge (%llu vs %llu)", hn[B], nk);
+    if ((hs[0] + hs[1]) & 1) return fail(ctx, SMX_DEVICE_ERROR, "odd number of extension bits (%llu + %llu palindromes)", hs[0], hs[1]);
+    ctx->g_nkpo = (hs[0] + hs[1]) / 2;
+    free_temps(ctx);
+    ctx->n_records = nk;
+    ctx->bucket_off = ctx->g_kboff;
+    ctx->K = k;
+    ctx->nw = NW;
+    ctx->num_buckets = B;
+    return 0;
+}
+
 // ---- host mirror of the device graph -----------------------------------------------------------------------------------------
 // 2-bit words -> ACGT, several threads
 inline void unpack_unitigs(const uint64_t *words, const unsigned long long *eoffw, const uint64_t *eoff, size_t ne, char *seq) {
@@ -461,7 +549,7 @@ int upload_graph(smx_ctx *ctx) {
 // Everything after the extension masks: early clippers (options), node table of the final masks, start de-edges, walks, perfect
 // loops, link records + vertices. tab: 2 * D0 + 2 entries; tab_valid: k_fill_tab has already filled it for the current masks.
 template <int NW>
-int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint32_t *d_err, WallTrace &gwt) {
+int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint32_t *d_err, WallTrace &gwt, bool present = false) {
     const uint64_t D0 = ctx->g_nkmers;
     const unsigned grid = grid_for(2 * D0);
     const smx::RankDir ixk = ctx->g_dir_kmers;
@@ -569,8 +657,13 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
     }
     if (clipped) {  // the node table has to describe the clipped masks
         tbegin(ctx, "succ");
-        hipLaunchKernelGGL((k_tab_from_masks<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, tab,
-                           d_err);
+        // (present: masks that came from the reads and were not clipped — every extension leads to a k-mer of the file)
+        if (present && !ctx->opt_early_at && ctx->opt_early_tip_bound <= 0)
+            hipLaunchKernelGGL((k_tab_from_masks<NW, true>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k,
+                               ixk, tab, d_err);
+        else
+            hipLaunchKernelGGL((k_tab_from_masks<NW, false>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k,
+                               ixk, tab, d_err);
         HIPCHK(hipGetLastError());
         tend(ctx);
     }
@@ -832,6 +925,43 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     ctx->g_B = B;
     ctx->gh.k = k;
     ctx->gh.eoff.assign(1, 0);
+    struct Prefix {  // stage names of the pipeline runs below tell which part of the construction they belong to
+        smx_ctx *c;
+        Prefix(smx_ctx *c_, const char *p) : c(c_) { c->tprefix = p; }
+        ~Prefix() { c->tprefix.clear(); }
+    };
+    // ---- 0. k-mers and masks from one count of the reads, when that applies ---------------------
+    if (!kpo_recs) {
+        int rc;
+        {
+            Prefix pf(ctx, "kmers:");
+            rc = kmer_file_with_masks<NW>(ctx, k, B);
+        }
+        if (rc == 0) {
+            gwt.mark(ctx, "g:kmers+masks");
+            const uint64_t D0 = ctx->g_nkmers;
+            if (D0 == 0) {
+                ctx->g_host_valid = true;  // the empty graph
+                ctx->g_ready = true;
+                ctx->n_records = 0;
+                ctx->K = k;
+                ctx->bucket_off.assign(B + 1, 0);
+                return 0;
+            }
+            ctx->d_result = ctx->g_kmers;
+            if (D0 >= (1ull << 60)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "%llu k-mers exceed the node-id range", (unsigned long long)D0);
+            tbegin(ctx, "rank_dir");
+            if (int rc2 = build_rank_dir<NW>(ctx, ctx->g_kmers, D0, ctx->g_kboff, B, k, ctx->g_dir_kmers)) return rc2;
+            tend(ctx);
+            uint32_t *d_err;
+            if (int rc2 = dalloc(ctx, &d_err, 1)) return rc2;
+            HIPCHK(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+            node_t *tab;
+            if (int rc2 = dalloc(ctx, &tab, 2 * D0 + 2)) return rc2;
+            return graph_from_masks<NW>(ctx, k, tab, /*tab_valid=*/false, d_err, gwt, /*present=*/true);
+        }
+        if (rc != SMX_ROUTE_NA) return rc;
+    }
     // ---- 1. canonical (k+1)-mers -------------------------------------------------------------
     if (kpo_recs) {  // multi-GPU: the (k+1)-mer file gathered from its owner ranks (any order; re-sorted here)
         if (int rc = run_count<NW>(ctx, k + 1, SMX_MODE_ALL, B, kpo_recs, n_kpo_recs)) return rc;
@@ -856,11 +986,6 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         return 0;
     }
     // ---- 2. canonical k-mers in k-mer-file order ----------------------------------------------
-    struct Prefix {  // stage names of the pipeline runs below tell which part of the construction they belong to
-        smx_ctx *c;
-        Prefix(smx_ctx *c_, const char *p) : c(c_) { c->tprefix = p; }
-        ~Prefix() { c->tprefix.clear(); }
-    };
     {
         Prefix pf(ctx, "kmers:");
         if (int rc = derive_kmer_file<NW>(ctx, k, B, /*from_reads=*/kpo_recs == nullptr)) return rc;
@@ -1039,6 +1164,7 @@ int run_coverage(smx_ctx *ctx) {
         if (ctx->n_records != D1) return fail(ctx, SMX_DEVICE_ERROR, "recount of the (k+1)-mers gave %llu records, the graph was built from %llu",
                                               (unsigned long long)ctx->n_records, (unsigned long long)D1);
         ctx->g_kpo = ctx->d_result_buf;
+        ctx->g_kpoboff = ctx->bucket_off;
         ctx->d_result_buf = nullptr;
         if (int rc = adopt_result(ctx, &ctx->g_kpo, (size_t)D1 * NW * 8)) return rc;
         ctx->d_result = sv_res;

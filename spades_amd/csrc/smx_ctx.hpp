@@ -52,6 +52,7 @@ struct smx_ctx {
     };
     std::vector<HostChunk> h_result;
     bool result_on_host = false;
+    bool ext_mode = false;    // the count in flight carries extension bytes in its records (EXT layout, smx_device.hpp): set by the construction
     void *x_owned = nullptr;  // output of smx_extract_partition_owned (released by the next extract / smx_extract_release)
     void *x_recv = nullptr;   // smx_exchange_buffer: receive side of the exchange, consumed by smx_count_records
     bool single_batch_only = false;  // count_reads: fail (memory limit) rather than cut the input into batches
@@ -69,6 +70,7 @@ struct smx_ctx {
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
     int64_t opt_spill = -1;  // sorted runs to host memory + merge by bucket ranges: -1 when the accumulated set outgrows HBM, 1 always (tests)
     int64_t opt_verify_lookups = 0;  // 1: rank lookups of k-mers that are known to be present still compare the record
+    int64_t opt_ext_route = -1;        // construction: k-mers AND their extension masks from one count of the reads (-1 when it applies, 0 never, 1 = -1)
     int64_t opt_kmers_from_reads = 1;  // construction: k-mer file counted from the resident reads (0: derived from the (k+1)-mer file)
     int64_t opt_derive_batches = 0;  // > 1: derive the k-mer file in this many bucket ranges (tests; 0 = as HBM requires)
     int64_t opt_keep_kpo = -1;       // keep the (k+1)-mer file after the masks are filled: -1 = if HBM allows, 0 = drop (coverage recounts)

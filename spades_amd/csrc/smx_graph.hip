@@ -317,8 +317,132 @@ __global__ void k_tab_masks(const node_t *tab, uint64_t D0, uint8_t *mask) {
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x)
         mask[r] = (uint8_t)(tab_out4(tab[2 * r]) | brev8(tab_out4(tab[2 * r + 1])));
 }
-// the node table of clipped masks (spades-core variants): extensions from the masks, successors by lookup
+// ---- k-mer file + InOutMask bytes straight from a count in the EXT layout (smx_device.hpp) -------------------------------------------
+// The sorted records hold (k-mer << 8 | byte) in their last word; copies of a k-mer whose bytes differ (survivors of cut minimizer
+// partitions) sit next to each other. A head is the first record of a k-mer; its byte is the OR over its copies.
+constexpr int XM_ITEMS = 4;
+constexpr int XM_TILE = BLK * XM_ITEMS;
 template <int NW>
+__device__ __forceinline__ bool range_is_rc_palindrome(const Rec<NW> &x, unsigned a, unsigned len) {  // bases a .. a+len-1, len even
+    for (unsigned i = 0; i < len / 2; ++i)
+        if (rec_nucl<NW>(x, a + i) + rec_nucl<NW>(x, a + len - 1 - i) != 3) return false;
+    return true;
+}
+template <int NW>
+__device__ __forceinline__ bool ext_head(const Rec<NW> *__restrict__ in, uint64_t i) {
+    return i == 0 || !rec_eq<NW>(rec_pure<NW>(in[i]), rec_pure<NW>(in[i - 1]));
+}
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_ext_heads(const void *in_, uint64_t n, unsigned long long *tcnt) {
+    const Rec<NW> *in = (const Rec<NW> *)in_;
+    __shared__ uint32_t s_cnt;
+    const uint64_t ntiles = (n + XM_TILE - 1) / XM_TILE;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < XM_ITEMS; ++j) {
+            const uint64_t i = tile * XM_TILE + (uint64_t)j * BLK + threadIdx.x;
+            if (i < n && ext_head<NW>(in, i)) ++c;
+        }
+        const uint32_t inc = wave_incl_scan<uint32_t>(c);
+        if ((threadIdx.x & 63) == 63 && inc) atomicAdd(&s_cnt, inc);
+        __syncthreads();
+        if (threadIdx.x == 0) tcnt[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+// stats: [0] extension bits set, [1] palindromic (k+1)-mers among them (k+1 is even): with both, the number of canonical (k+1)-mers
+// the reads hold = (bits + palindromes) / 2 — every other (k+1)-mer sets one bit at its prefix node and one at the reverse
+// complement of its suffix node (k_fill_tab), a palindrome sets the same bit twice.
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_ext_merge(const void *in_, uint64_t n, const unsigned long long *toff, unsigned k, void *kmers_, uint8_t *mask,
+                                                   unsigned long long *stats) {
+    const Rec<NW> *in = (const Rec<NW> *)in_;
+    Rec<NW> *kmers = (Rec<NW> *)kmers_;
+    __shared__ uint32_t s_w[XM_ITEMS * (BLK / 64)];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t ntiles = (n + XM_TILE - 1) / XM_TILE;
+    unsigned long long bits = 0, pals = 0;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t fl = 0;
+        unsigned long long bal[XM_ITEMS];
+#pragma unroll
+        for (int j = 0; j < XM_ITEMS; ++j) {
+            const uint64_t i = tile * XM_TILE + (uint64_t)j * BLK + threadIdx.x;
+            const bool h = i < n && ext_head<NW>(in, i);
+            fl |= (h ? 1u : 0u) << j;
+            bal[j] = __ballot(h);
+            if (lane == 0) s_w[j * (BLK / 64) + wave] = (uint32_t)__popcll(bal[j]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {  // exclusive scan of the XM_ITEMS * 4 wave counts (tile order: item-major, then wave)
+            uint32_t run = 0;
+            for (int t = 0; t < XM_ITEMS * (BLK / 64); ++t) {
+                const uint32_t v = s_w[t];
+                s_w[t] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+        const uint64_t obase = toff[tile];
+#pragma unroll
+        for (int j = 0; j < XM_ITEMS; ++j) {
+            if (!((fl >> j) & 1)) continue;
+            uint64_t i = tile * XM_TILE + (uint64_t)j * BLK + threadIdx.x;
+            const Rec<NW> raw = in[i];
+            const Rec<NW> x = rec_pure<NW>(raw);
+            unsigned m = (unsigned)(raw.w[NW - 1] & 0xFFu);
+            for (++i; i < n; ++i) {  // the copies of this k-mer (possibly into the next tile)
+                const Rec<NW> y = in[i];
+                if (!rec_eq<NW>(rec_pure<NW>(y), x)) break;
+                m |= (unsigned)(y.w[NW - 1] & 0xFFu);
+            }
+            const uint64_t o = obase + s_w[j * (BLK / 64) + wave] + __popcll(bal[j] & ((1ull << lane) - 1));
+            kmers[o] = x;
+            mask[o] = (uint8_t)m;
+            bits += __popc(m);
+            {  // x + c is its own reverse complement iff c = complement of base 0 and bases 1..k-1 are; likewise for rc(x) + c'
+                const unsigned x0 = rec_nucl<NW>(x, 0), xl = rec_nucl<NW>(x, k - 1);
+                if (((m >> (3 - x0)) & 1) && range_is_rc_palindrome<NW>(x, 1, k - 1)) ++pals;
+                if (((m >> (7 - xl)) & 1) && range_is_rc_palindrome<NW>(x, 0, k - 1)) ++pals;
+            }
+        }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        bits += __shfl_down(bits, o, 64);
+        pals += __shfl_down(pals, o, 64);
+    }
+    if (lane == 0) {
+        if (bits) atomicAdd(&stats[0], bits);
+        if (pals) atomicAdd(&stats[1], pals);
+    }
+}
+// bucket offsets of the merged file: heads before the old offset
+template <int NW>
+__global__ void k_ext_boff(const void *in_, uint64_t n, const unsigned long long *toff, const unsigned long long *old_off, uint32_t nb1,
+                           unsigned long long *new_off) {
+    const Rec<NW> *in = (const Rec<NW> *)in_;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb1) return;
+    const uint64_t pos = old_off[b];
+    const uint64_t tile = pos / XM_TILE;
+    unsigned long long c = pos < n ? toff[tile] : 0;
+    if (pos >= n) {
+        const uint64_t ntiles = (n + XM_TILE - 1) / XM_TILE;
+        new_off[b] = toff[ntiles];  // total
+        return;
+    }
+    // tile order is item-major: position p of the tile sits at index (p % BLK) of item (p / BLK) — the same order as the file
+    for (uint64_t i = tile * XM_TILE; i < pos; ++i) c += ext_head<NW>(in, i) ? 1u : 0u;
+    new_off[b] = c;
+}
+
+// the node table of clipped masks (spades-core variants): extensions from the masks, successors by lookup
+// (PRESENT: the masks come from the reads themselves, every extension leads to a k-mer of the file)
+template <int NW, bool PRESENT = false>
 __global__ void __launch_bounds__(BLK) k_tab_from_masks(const void *kmers_, const uint8_t *mask, uint64_t D0, unsigned k, RankDir ix, node_t *tab,
                                                         uint32_t *err) {
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
@@ -329,7 +453,7 @@ __global__ void __launch_bounds__(BLK) k_tab_from_masks(const void *kmers_, cons
         if (uniq4(mo)) {
             unsigned yo;
             const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(node_kmer<NW>(kmers, node, k), k, __ffs(mo) - 1), k, yo);
-            const node_t ry = kmer_rank<NW>(kmers, ix, y);
+            const node_t ry = kmer_rank<NW, PRESENT>(kmers, ix, y);
             if (ry == NODE_NONE) atomicAdd(err, 1u);
             else e |= (ry << 1) | yo;
         }

@@ -45,6 +45,7 @@ struct PassArgs {
     uint32_t fprev[6];
     uint32_t world;
     uint32_t expand;  // records source, level 1 only: instance i = record i/2, odd i = its reverse complement
+    uint32_t ext;     // records carry an extension byte below the k-mer bits of their last word (smx_device.hpp, EXT layout)
     uint32_t F;  // bins per segment
     unsigned long long *hist;    // [nseg*F]
     unsigned long long *cursor;  // [nseg*F]
@@ -54,14 +55,14 @@ struct PassArgs {
 template <int NW, int BINF>
 __device__ __forceinline__ uint32_t bin_of(const Rec<NW> &x, const PassArgs &a) {
     if constexpr (BINF == BIN_L1) {
-        uint32_t b = bucket_of(xxh3_rec<NW>(x), a.num_buckets) - a.bucket0;
+        uint32_t b = bucket_of(xxh3_rec<NW>(a.ext ? rec_pure<NW>(x) : x), a.num_buckets) - a.bucket0;
         return a.S1 > 1 ? b * a.S1 + (uint32_t)__umul64hi(key_top64<NW>(x, a.K), (uint64_t)a.S1) : b;
     } else if constexpr (BINF == BIN_LK) {
         uint64_t f = key_top64<NW>(x, a.K);  // key as a fraction in [0,1) scaled by 2^64
         for (uint32_t i = 0; i < a.nprev; ++i) f *= a.fprev[i];  // fractional part after each earlier digit
         return (uint32_t)__umul64hi(f, (uint64_t)a.F);
     } else {
-        uint32_t b = bucket_of(xxh3_rec<NW>(x), a.num_buckets);
+        uint32_t b = bucket_of(xxh3_rec<NW>(a.ext ? rec_pure<NW>(x) : x), a.num_buckets);
         return (uint32_t)(((uint64_t)b * a.world) / a.num_buckets);
     }
 }

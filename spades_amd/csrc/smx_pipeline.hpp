@@ -255,6 +255,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
 
     PassArgs a{};
     a.K = K;
+    a.ext = (!from_reads && ctx->ext_mode) ? 1u : 0u;
     a.num_buckets = B;
     a.bucket0 = b_first;
     a.S1 = S1;
@@ -500,6 +501,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
 // Super-k-mer pre-deduplication of the selected windows (smx_superkmer.hip). *out: canonical K-mers, every k-mer of the
 // selection at least once and most of them exactly once (temp buffer of nwin records), *n_out: how many.
 constexpr int SMX_RETRY_SMALLER = 1001;  // internal: the pre-dedupe output did not fit the capacity it was given
+constexpr int SMX_ROUTE_NA = 1002;       // internal: the extension-carrying count does not apply to this input (the caller takes the other route)
 template <int NW>
 int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, Rec<NW> **out, uint64_t *n_out, uint64_t out_cap = 0) {
     constexpr int SW = 2 * NW;
@@ -623,8 +625,10 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     }
     const uint32_t T = 2 * cap;
     const uint32_t scap = std::min<uint32_t>(SKM_SCAP, ctx->opt_skm_scap > 0 ? (uint32_t)ctx->opt_skm_scap : cap / 8);  // ~12+ windows per slot on average
-    const size_t lds = (size_t)scap * SW * 8 + (size_t)T * 4 + 514 * 4 + (size_t)cap * 4 + 512 + 16;
-    if (int rc = set_lds(ctx, k_skm_dedupe<NW>, lds)) return rc;
+    const size_t lds = (size_t)scap * SW * 8 + (size_t)T * 4 + 514 * 4 + (size_t)cap * 4 + 512 + 512 + 16;
+    const bool ext = ctx->ext_mode;  // the survivors carry their extension byte (EXT layout)
+    if (ext && !ext_layout_fits(K, NW)) return fail(ctx, SMX_INVALID_PARAMETER, "K=%u leaves no room for the extension byte", K);
+    if (int rc = ext ? set_lds(ctx, k_skm_dedupe<NW, true>, lds) : set_lds(ctx, k_skm_dedupe<NW, false>, lds)) return rc;
     const uint32_t nitems = SKM_NKEY / SKM_KEYS_PER_ITEM;
     unsigned long long *prof = nullptr;
     if (getenv("SMX_DEBUG")) {
@@ -632,9 +636,14 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         HIPCHK(hipMemsetAsync(prof, 0, 64, ctx->stream));
     }
     tbegin(ctx, "skm_dedupe");
-    hipLaunchKernelGGL((k_skm_dedupe<NW>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
-                       (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)out_cap, (unsigned long long)clean_cap,
-                       (unsigned long long)dirty_cap, ocount, ocount + 1, prof);
+    if (ext)
+        hipLaunchKernelGGL((k_skm_dedupe<NW, true>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
+                           (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)out_cap,
+                           (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof);
+    else
+        hipLaunchKernelGGL((k_skm_dedupe<NW, false>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
+                           (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)out_cap,
+                           (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof);
     HIPCHK(hipGetLastError());
     tend(ctx);
     if (prof) {
@@ -722,6 +731,10 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
     const uint64_t nrec = nwin * rpp;
     const uint64_t budget = arena_avail(ctx);
     const bool dedupe = prededupe_applies<NW>(ctx, K, nwin);
+    if (ctx->ext_mode && !dedupe) {  // the extension bytes are gathered by the pre-dedupe stage
+        drop_masks();
+        return SMX_ROUTE_NA;
+    }
     uint64_t nbatch;
     if (ctx->opt_batch_records > 0) {
         nbatch = nrec ? (nrec + ctx->opt_batch_records - 1) / ctx->opt_batch_records : 1;

@@ -229,8 +229,8 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
             if (starts) {
                 uint32_t at = atomicAdd(&s_nstart, (uint32_t)__popc(starts));
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (starts & (1u << j)) slist[at++] = ((uint32_t)(b8 + j) << 12) | m9[j + 1];
+                for (int j = 0; j < 8; ++j)  // bit 31: the window before the start is valid (same read, no N): its first base precedes the run
+                    if (starts & (1u << j)) slist[at++] = (((vb >> j) & 1u) << 31) | ((uint32_t)(b8 + j) << 12) | m9[j + 1];
             }
         }
         __syncthreads();
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
         }
         for (uint32_t si = threadIdx.x; si < nstart; si += BLK) {
             const uint32_t e = slist[si];
-            const int pr = (int)(e >> 12);  // window position relative to p0
+            const int pr = (int)((e >> 12) & 0x7FFFFu);  // window position relative to p0
             uint32_t c;                     // windows until the next break (within w: the minimizer leaves the window)
             {
                 const int nb1 = pr + 1;
@@ -294,13 +294,25 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
                 const int wi = (int)((p >> 5) - wq0);
                 const unsigned sh = (unsigned)(p & 31) << 1;
                 const unsigned nbits = 2 * (c + K - 1);
+                // the bases next to the run, where the neighbouring window is valid — i.e. where the (K+1)-mer across the end of the run
+                // exists: bit 0 left valid, bits 1-2 left base, bit 3 right valid, bits 4-5 right base (slot bits 48..53 of the last word)
+                uint32_t nb = 0;
+                auto base_at = [&](int64_t q) -> uint32_t {
+                    const int bw = (int)((q >> 5) - wq0);
+                    return (uint32_t)(sw[bw] >> ((unsigned)(q & 31) << 1)) & 3u;
+                };
+                if (e >> 31) nb |= 1u | (base_at(p - 1) << 1);
+                {
+                    const int64_t q = p + (int64_t)c;  // the window behind the run
+                    if ((mw[(q >> 6) - mq0] >> (q & 63)) & 1) nb |= 8u | (base_at(q + (int64_t)K - 1) << 4);
+                }
 #pragma unroll
                 for (int i = 0; i < SW; ++i) {
                     uint64_t v = sw[wi + i] >> sh;
                     if (sh) v |= sw[wi + i + 1] << (64 - sh);
                     if (nbits <= 64u * i) v = 0;
                     else if (nbits < 64u * (i + 1)) v &= (1ull << (nbits - 64u * i)) - 1;
-                    if (i == SW - 1) v |= (uint64_t)c << 56;
+                    if (i == SW - 1) v |= ((uint64_t)c << 56) | ((uint64_t)nb << 48);
                     dst[i] = v;
                 }
             }
@@ -369,8 +381,12 @@ __device__ __forceinline__ Rec<NW> skm_extract(const uint64_t *s, unsigned j, un
 // whole keys holding <= cap instances (a key larger than that is cut). Per chunk: stage the slots in LDS, expand the
 // instance list (slot, offset), insert every instance into an exact hash set whose entries are 16-bit fingerprint |
 // 16-bit (slot, offset) reference (the k-mers themselves stay in the staged slots), append the winners to HBM.
-// LDS (dynamic): sl[scap*SW] u64 | tab[T] u32 | cpre[514] u32 | imap[cap] u16 | wl[cap] u16 | cl[512] u8
-template <int NW>
+// LDS (dynamic): sl[scap*SW] u64 | tab[T] u32 | cpre[514] u32 | imap[cap] u16 | wl[cap] u16 | cl[512] u8 | nbv[512] u8
+// EXT: every instance also knows the bases next to it inside its read (the slot, or the slot's neighbour bases at its two ends) —
+// the extensions the (K+1)-mers around it give its k-mer (InOutMask bits in the k-mer's canonical frame: out bits 0-3 by next
+// base, in bits 4-7 by previous base; kmer_extension_index_builder.hpp:45-60, inout_mask.hpp:92-131). The table entries then are
+// 8-bit fingerprint | 8 extension bits (OR of all copies) | reference, and the survivors leave in the EXT layout (smx_device.hpp).
+template <int NW, bool EXT>
 __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__ slots, const unsigned long long *__restrict__ slot_off,
                                                     unsigned K, uint32_t nitems, uint32_t cap, uint32_t T, uint32_t scap, void *out_,
                                                     unsigned long long out_cap, unsigned long long clean_cap, unsigned long long dirty_cap, unsigned long long *out_count,
@@ -383,6 +399,7 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
     uint16_t *imap = (uint16_t *)(cpre + 514);
     uint16_t *wl = imap + cap;
     uint8_t *cl = (uint8_t *)(wl + cap);
+    uint8_t *nbv = cl + 512;
     __shared__ unsigned long long koff[SKM_KEYS_PER_ITEM + 1];
     __shared__ uint32_t scr[BLK / 64 + 2];
     __shared__ uint32_t s_take, s_nfit, s_ninst, s_wcount, s_endb;
@@ -411,7 +428,8 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                 uint64_t v = slots[s_cur * SW + i];
                 if (i % SW == SW - 1) {
                     cl[i / SW] = (uint8_t)(v >> 56);
-                    v &= ~(0xFFull << 56);
+                    nbv[i / SW] = (uint8_t)((v >> 48) & 0x3Fu);
+                    v &= ~(0xFFFFull << 48);
                 }
                 sl[i] = v;
             }
@@ -472,19 +490,32 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                     for (int t = 0; t < NW; ++t) cx.w[t] = fwd ? x.w[t] : y.w[t];
                     const uint32_t hh = rec_hash32<NW>(cx);
                     uint32_t h = hh & (T - 1);
-                    const uint32_t fp = hh >> 16;
-                    const uint32_t entry = (fp << 16) | code;
+                    // (EXT: fingerprint 0xFF is not used, so that no live entry can ever read as the empty marker)
+                    const uint32_t fp = EXT ? (((hh >> 24) == 0xFFu) ? 0xFEu : (hh >> 24)) : (hh >> 16);
+                    const uint32_t entry = EXT ? ((fp << 24) | code) : ((fp << 16) | code);
                     for (;;) {
                         const uint32_t old = atomicCAS(&tab[h], 0xFFFFFFFFu, entry);
                         if (old == 0xFFFFFFFFu) {
                             won = true;
                             break;
                         }
-                        if ((old >> 16) == fp) {
+                        if ((EXT ? (old >> 24) : (old >> 16)) == fp) {
                             const Rec<NW> xo = skm_extract<NW>(sl + (size_t)((old & 0xFFFFu) >> 7) * SW, old & 127u, K);
                             if (rec_eq<NW>(xo, x) || rec_eq<NW>(xo, y)) break;  // same canonical k-mer already present
                         }
                         h = (h + 1) & (T - 1);
+                    }
+                    if constexpr (EXT) {
+                        const uint32_t s = code >> 7, j = code & 127u, c = cl[s], nb = nbv[s];
+                        const uint64_t *ss = sl + (size_t)s * SW;
+                        auto base = [&](uint32_t t) -> uint32_t { return (uint32_t)(ss[t >> 5] >> ((t & 31u) << 1)) & 3u; };
+                        const bool hasl = j > 0 || (nb & 1u), hasr = j + 1 < c || (nb & 8u);
+                        const uint32_t L = j > 0 ? base(j - 1) : ((nb >> 1) & 3u), R = j + 1 < c ? base(j + K) : ((nb >> 4) & 3u);
+                        uint32_t eb;
+                        if (fwd) eb = (hasr ? (1u << R) : 0u) | (hasl ? (16u << L) : 0u);
+                        else eb = (hasl ? (1u << (3u - L)) : 0u) | (hasr ? (16u << (3u - R)) : 0u);
+                        if (eb) atomicOr(&tab[h], eb << 16);
+                        code = h;  // the winners are listed by their table entry
                     }
                 }
                 const unsigned long long m = __ballot(won);
@@ -520,13 +551,19 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
             if (!s_skip) {
                 Rec<NW> *dst = out + s_gbase;
                 for (uint32_t i = threadIdx.x; i < wcount; i += BLK) {
-                    const uint32_t code = wl[i];
+                    uint32_t code = wl[i], eb = 0;
+                    if constexpr (EXT) {
+                        const uint32_t ent = tab[code];
+                        code = ent & 0xFFFFu;
+                        eb = (ent >> 16) & 0xFFu;
+                    }
                     const Rec<NW> x = skm_extract<NW>(sl + (size_t)(code >> 7) * SW, code & 127u, K);
                     const Rec<NW> y = rec_rc<NW>(x, K);
                     const bool fwd = rc_ge<NW>(y, x);
                     Rec<NW> cx;
 #pragma unroll
                     for (int t = 0; t < NW; ++t) cx.w[t] = fwd ? x.w[t] : y.w[t];
+                    if constexpr (EXT) cx.w[NW - 1] = (cx.w[NW - 1] << EXT_BITS) | eb;
                     dst[i] = cx;
                 }
             }

@@ -15,6 +15,8 @@ for step in "$@"; do
     benchq64) SMX_ARENA_CHUNK_MB=64 timeout 1500 python bench.py --no-cpu-baseline --extra-kmercount 0 > gpurun_out/$tag/benchq64.json 2> gpurun_out/$tag/benchq64.err; tail -3 gpurun_out/$tag/benchq64.err ;;
     shard100) SMX_DEBUG=1 timeout 900 python bench.py --gpus 1 --force-sharded --steps 2 --warmup 1 2>&1 | grep -v "big leaf\|^\[smx\] \(skm_scan\|dedupe\)" | tail -40 ;;
     tdist) timeout 900 python -m pytest tests/test_dist_gpu.py tests/test_cli_gpu.py -m gpu -x -q 2>&1 | tail -8 ;;
+    text) timeout 900 python -m pytest tests/test_ext_route_gpu.py -m gpu -x -q 2>&1 | tail -40 ;;
+    tgraph) timeout 900 python -m pytest tests/test_graph_gpu.py tests/test_prededupe_gpu.py tests/test_count_gpu.py -m gpu -x -q 2>&1 | tail -15 ;;
     *) echo "unknown step $step" ;;
   esac
 done
