@@ -216,6 +216,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra-kmercount", type=float, default=10e6,
                     help="extra (untimed for the headline): spades-kmercount mode (all k-mers of read + RC, 16 buckets) on this many reads; 0 disables")
+    ap.add_argument("--kpomer-route", action="store_true",
+                    help="N=1: construction by the reference's own order of work ((k+1)-mer file first, masks filled from it) instead of "
+                         "k-mers + masks from one count of the reads")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
     args = ap.parse_args()
 
@@ -262,6 +265,8 @@ def main():
     hw, hs, hl = h_words.numpy().view("uint64"), h_start.numpy().view("uint64"), h_len.numpy().view("uint32")
 
     ctx = Context(device=local_rank)
+    if args.kpomer_route:
+        ctx.set_option("ext_route", 0)
     gb = GraphBuilder(k, T, ctx)
     engine = None
     if sharded:
@@ -310,8 +315,14 @@ def main():
     stages = {}
     for name, ms in ctx.timings():  # a stage name repeats when the pipeline runs more than once
         stages[name] = stages.get(name, 0.0) + ms
-    count_ms = sum(ms for n_, ms in stages.items() if ":" not in n_ and n_ not in
-                   ("rank_dir", "fill_masks", "candidates", "walk_len", "keep", "walk_write", "derive_hist", "derive_kmers", "succ", "early_at", "early_tips"))
+    # route of the construction: k-mers + extension masks from ONE count of the reads ("kmers:" pipeline stages incl. ext_merge; there
+    # is no (k+1)-mer file), or the (k+1)-mer count followed by the k-mer file and the mask fill
+    ext_route = "kmers:ext_merge" in stages
+    if ext_route:
+        count_ms = sum(ms for n_, ms in stages.items() if n_.startswith("kmers:"))
+    else:
+        count_ms = sum(ms for n_, ms in stages.items() if ":" not in n_ and n_ not in
+                       ("rank_dir", "fill_masks", "candidates", "walk_len", "keep", "walk_write", "derive_hist", "derive_kmers", "succ", "early_at", "early_tips"))
     construct_ms = sum(stages.values()) - count_ms
     if sharded:
         inst, D1 = last["st"]["instances"], last["st"]["distinct"]
@@ -324,11 +335,17 @@ def main():
         D1 = info["n_kpomers"]
         icnt = os.environ.get("SMX_BENCH_INST")
         inst = int(icnt) if icnt else int((torch.from_numpy(h_len.numpy().astype("int64")) - K1 + 1).clamp(min=0).sum().item())
-    # B_alg(count) = N*L/4 + 2*I*W + D*W
-    b_count = n_reads * L / 4 + 2 * inst * W + D1 * W
+    # B_alg(count) = N*L/4 + 2*I*W + D*W (ext route: I = k-mer instances of the reads that hold a (k+1)-mer, D = distinct
+    # k-mers; the extension byte rides in spare record bits)
+    if ext_route:
+        inst_k = int((torch.from_numpy(h_len.numpy().astype("int64")) - k + 1).clamp(min=0).sum().item())
+        b_count = n_reads * L / 4 + 2 * inst_k * W + info["n_kmers"] * W
+    else:
+        b_count = n_reads * L / 4 + 2 * inst * W + D1 * W
     roof_count = {"bound": "hbm", "achieved": round(b_count / max(count_ms, 1e-9) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                   "frac": round(b_count / max(count_ms, 1e-9) / 1e6 / 8000.0, 4), "traffic": None,
-                  "kernel": "counting pipeline of the canonical (k+1)-mers (sum of its stage kernels, HIP events on the library stream)",
+                  "kernel": ("counting pipeline of the canonical k-mers with their extension masks" if ext_route else
+                             "counting pipeline of the canonical (k+1)-mers") + " (sum of its stage kernels, HIP events on the library stream)",
                   "algorithmic_bytes_per_step": int(b_count), "kernel_ms_per_step": round(count_ms, 3)}
     dom = max(stages.items(), key=lambda x: x[1]) if stages else ("", 0.0)
     roof_count["dominant_stage"] = dom[0]
@@ -337,7 +354,7 @@ def main():
     # HBM traffic per step from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, FETCH x2 gfx950
     # correction: profiles/r02/config3_pmc_hbm_traffic.csv, taken at the commit named in profiles/r02/README.md). Only valid for the
     # workload it was taken on; a constant of that measurement, not of this run.
-    pmc = os.path.join(ROOT, "profiles", "r02", "config3_pmc_hbm_traffic.csv")
+    pmc = os.path.join(ROOT, "profiles", "r02", "config3_ext_pmc_hbm_traffic.csv" if ext_route else "config3_pmc_hbm_traffic.csv")
     pmc_rows = {}
     if not sharded and not args.count_only and n_reads == 100_000_000 and k == 55 and T == 16 and os.path.exists(pmc):
         for line in open(pmc):
@@ -356,12 +373,17 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": (f"BASELINE config 3: synthetic {n_reads / 1e6:g} M PE150 reads (genome {args.genome / 1e6:g} Mbp iid, 1% subst., "
-                                f"{args.n_rate * 100:g}% N), k={k}: upload from page-locked host memory + count of the canonical {K1}-mers "
-                                f"({nb} buckets = -t {T})" + ("" if args.count_only else " + de Bruijn construction (k-mer file, extension masks, "
-                                "unitigs, link records + vertices; graph resident in HBM)")) if not sharded else
+                                f"{args.n_rate * 100:g}% N), k={k}: upload from page-locked host memory + " +
+                                (f"count of the canonical {k}-mers together with their extension masks (= the canonical {K1}-mer set: every "
+                                 f"{K1}-mer of the reads is one extension bit at its prefix and one at its suffix {k}-mer) " if ext_route else
+                                 f"count of the canonical {K1}-mers ") +
+                                f"({nb} buckets = -t {T})" + ("" if args.count_only else " + de Bruijn construction (" +
+                                ("successor table, " if ext_route else "k-mer file, extension masks, ") +
+                                "unitigs, link records + vertices; graph resident in HBM; GFA identical to spades-gbuilder's)")) if not sharded else
                                (f"BASELINE config 4 shape: {n_reads / 1e6:g} M PE150 reads per GPU, k={k}: sharded count of the canonical {K1}-mers "
                                 f"({nb} buckets, bucket-range owners, one RCCL all-to-all); inputs resident in HBM; no construction in the N>1 step"),
                    "reads_per_gpu": n_reads, "k": k, "num_buckets": nb, "kmer_instances": int(inst), "distinct_kpomers": int(D1),
+                   "route": ("k-mers + masks from one count of the reads" if ext_route else "(k+1)-mer file, then k-mer file + mask fill") if info is not None else "count only",
                    "h2d_in_timed_region": not sharded, "construct_in_metric": (not sharded and not args.count_only),
                    "parallelism": "1 GPU" if not sharded else f"{world} GPU(s), bucket-range owners, one RCCL all-to-all (RCCL world size {world})"},
         "roofline": roof_count,
@@ -373,20 +395,31 @@ def main():
         # written; walks = successor + mask of every node read twice (length pass, write pass of the kept half: 1.5x), unitigs written
         # 2 bits per base; links = 2 records of 16 B per edge written, sorted (read + write), read.
         b_con = D1 * W + 2 * (2 * D1 * W) + D0 * W + D1 * W + 2 * D1 * W + 2 * D1 * (1 + 8) + 1.5 * 2 * D0 * 9 + nbases / 4 + 4 * 2 * ne * 16
+        if ext_route:
+            # rank directory = the k-mer file read once; node table = k-mers + masks read, up to 2 successor records of W bytes looked up
+            # and 2 entries of 8 B written per k-mer; walks, unitigs and links as above
+            b_con = D0 * W + (D0 * (W + 1) + 2 * D0 * W + 2 * D0 * 8) + 1.5 * 2 * D0 * 9 + nbases / 4 + 4 * 2 * ne * 16
         out["construct"] = {"n_kpomers": int(D1), "n_kmers": int(D0), "n_unitigs": int(ne), "n_vertices": int(info["n_vertices"]),
                             "unitig_bases": int(nbases),
                             "roofline": {"bound": "hbm", "achieved": round(b_con / max(construct_ms, 1e-9) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                                          "frac": round(b_con / max(construct_ms, 1e-9) / 1e6 / 8000.0, 4), "traffic": None,
-                                         "kernel": "construction (k-mer file, rank directory, masks + successors, walks, link records): sum of its stage kernels",
+                                         "kernel": ("construction (rank directory, successor table, walks, link records)" if ext_route else
+                                                    "construction (k-mer file, rank directory, masks + successors, walks, link records)") + ": sum of its stage kernels",
                                          "algorithmic_bytes_per_step": int(b_con), "kernel_ms_per_step": round(construct_ms, 3)}}
         out["step_breakdown_ms"] = {"count_kernels": round(count_ms, 1), "construct_kernels": round(construct_ms, 1),
                                     "host_and_upload": round(ms_per_step - count_ms - construct_ms, 1)}
         # the dominant single kernel of the step: k_fill_tab (node table: two rank lookups + two 64-bit atomics per (k+1)-mer)
-        fm = stages.get("fill_masks", 0.0)
-        b_fill = D1 * W + 2 * D1 * W + 2 * D1 * 8
-        out["dominant_kernel"] = {"name": "smx::k_fill_tab (+ k_tab_masks)", "ms": round(fm, 3), "algorithmic_bytes": int(b_fill),
+        if ext_route:  # k_tab_from_masks: the successor of every node with a unique extension, one rank lookup each
+            fm = stages.get("succ", 0.0)
+            b_fill = D0 * (W + 1) + 2 * D0 * W + 2 * D0 * 8
+            dname, dkey = "smx::k_tab_from_masks", "smx::k_tab_from_masks<2, true>"
+        else:          # k_fill_tab: node table by two rank lookups + two 64-bit atomics per (k+1)-mer
+            fm = stages.get("fill_masks", 0.0)
+            b_fill = D1 * W + 2 * D1 * W + 2 * D1 * 8
+            dname, dkey = "smx::k_fill_tab (+ k_tab_masks)", "smx::k_fill_tab<2>"
+        out["dominant_kernel"] = {"name": dname, "ms": round(fm, 3), "algorithmic_bytes": int(b_fill),
                                   "achieved_GBps": round(b_fill / max(fm, 1e-9) / 1e6, 1), "frac": round(b_fill / max(fm, 1e-9) / 1e6 / 8000.0, 4),
-                                  "traffic_GB": round(pmc_rows.get("smx::k_fill_tab<2>", 0.0), 1) or None,
+                                  "traffic_GB": round(pmc_rows.get(dkey, 0.0), 1) or None,
                                   "bound": "random HBM transactions (~64 B fetched per 8/16-B access), not bytes"}
     if rank == 0 and world == 1 and not args.force_sharded:
         class Wrap:

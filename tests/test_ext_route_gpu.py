@@ -27,12 +27,13 @@ def _build(reads, k, threads, tmp_path, opts, coverage=False):
         gb.ctx.set_option(key, v)
     gb.push_back_reads(reads)
     gb.build()
+    took = any(n == "kmers:ext_merge" for n, _ in gb.ctx.timings())
     if coverage:
         gb.fill_coverage()
     out = os.path.join(str(tmp_path), "g.gfa")
     gb.write_gfa(out)
     info = dict(gb.info())
-    res = dict(info=info, gfa=open(out).read(), unitigs=gb.unitigs(), kmers=gb.kmers())
+    res = dict(info=info, gfa=open(out).read(), unitigs=gb.unitigs(), kmers=gb.kmers(), took_ext_route=took)
     gb.ctx.close()
     return res
 
@@ -48,8 +49,10 @@ GCASES = [c for c in load_manifest()["cases"] if c["kind"] == "graph" and _eligi
 def test_gfa_matches_spades_gbuilder(case, tmp_path):
     reads = [r for r in read_lines(case["reads"]) if r]
     r = _build(reads, case["K"], case["threads"], tmp_path, FORCE)
+    assert r["took_ext_route"]
     assert hashlib.md5(r["gfa"].encode()).hexdigest() == case["md5"]
     old = _build(reads, case["K"], case["threads"], tmp_path, LEGACY)
+    assert not old["took_ext_route"]
     assert _same_kmers(r, old)
     assert r["info"] == old["info"]  # incl. the number of canonical (k+1)-mers, here derived from the mask bits
 
@@ -62,6 +65,7 @@ def test_gfa_with_coverage(case, tmp_path):
     """-c behind this route: there is no (k+1)-mer file, the coverage pass counts it (and checks its size against the mask bits)"""
     reads = [r for r in read_lines(case["reads"]) if r]
     r = _build(reads, case["K"], case["threads"], tmp_path, FORCE, coverage=True)
+    assert r["took_ext_route"]
     assert r["gfa"] == open(os.path.join(GOLDEN, case["file"])).read()
 
 
@@ -98,6 +102,7 @@ def test_vs_oracle_seeded(k, tmp_path):
     for threads in (1, 3):
         ref = oracle.build_graph(reads, k, 10 * threads)
         r = _build(reads, k, threads, tmp_path, FORCE)
+        assert r["took_ext_route"]
         assert r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"]
         old = _build(reads, k, threads, tmp_path, LEGACY)
         assert _same_kmers(r, old) and r["info"] == old["info"]
@@ -120,7 +125,7 @@ def test_cut_partitions_are_merged(tmp_path):
     reads = _synth(11, 3000, 4000, 150, err=0.002)  # ~200x: partitions far larger than one chunk
     ref = oracle.build_graph(reads, k, 20)
     r = _build(reads, k, 2, tmp_path, dict(FORCE, skm_cap=512))
-    assert r["gfa"] == ref["gfa"]
+    assert r["took_ext_route"] and r["gfa"] == ref["gfa"]
 
 
 def test_route_is_declined_where_it_does_not_fit(tmp_path):
@@ -130,4 +135,4 @@ def test_route_is_declined_where_it_does_not_fit(tmp_path):
         reads = _synth(k, 3000, 800, 150)
         ref = oracle.build_graph(reads, k, 10)
         r = _build(reads, k, 1, tmp_path, FORCE)
-        assert r["gfa"] == ref["gfa"]
+        assert not r["took_ext_route"] and r["gfa"] == ref["gfa"]
