@@ -137,16 +137,17 @@ __device__ __forceinline__ uint64_t xxh3_rec(const Rec<NW> &x) {
 }
 
 // EXT layout (construction route that takes the extensions straight from the reads): the last word of a record holds
-// (k-mer bits << 8) | InOutMask byte. Word 0 is untouched (NW >= 2), so the MSD key digits are those of the k-mer, and the raw
-// word order of two records is the order of their k-mers, then of their bytes: copies of a k-mer with different bytes sort next
-// to each other and are merged (OR) after the sort. Only the bucket hash has to see the k-mer alone.
+// (k-mer bits << 8) | InOutMask byte. Word 0 is untouched when NW >= 2, so the MSD key digits are those of the k-mer (with one word
+// the sort simply treats the record as a (K+4)-mer), and the raw word order of two records is the order of their k-mers, then of
+// their bytes: copies of a k-mer with different bytes sort next to each other and are merged (OR) after the sort. Only the bucket
+// hash has to see the k-mer alone.
 constexpr unsigned EXT_BITS = 8;
 template <int NW>
 __host__ __device__ __forceinline__ Rec<NW> rec_pure(Rec<NW> x) {
     x.w[NW - 1] >>= EXT_BITS;
     return x;
 }
-__host__ __device__ inline bool ext_layout_fits(unsigned K, int nw) { return nw >= 2 && 2 * K + EXT_BITS <= 64u * (unsigned)nw; }
+__host__ __device__ inline bool ext_layout_fits(unsigned K, int nw) { return 2 * K + EXT_BITS <= 64u * (unsigned)nw; }
 
 __device__ __forceinline__ uint32_t bucket_of(uint64_t hash, uint32_t num_buckets) {
     return num_buckets == 1 ? 0u : (uint32_t)__umul64hi(hash, (uint64_t)num_buckets);

@@ -171,7 +171,9 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     if (B > 4096) return fail(ctx, SMX_INVALID_PARAMETER, "num_buckets=%u too large (level-1 fan-out limit 4096)", B);
 
     // ---- choose the MSD split: level 1 = bucket + s1 key bits, then levels of <= log2(FMAX) bits ----
-    const unsigned avail = std::min(64u, 2 * K);  // key bits visible in key_top64
+    // EXT layout with one word per record: the byte sits below the k-mer bits of word 0, the key is (k-mer, byte) — 4 more "bases"
+    const unsigned Kk = (ctx->ext_mode && !from_reads && NW == 1) ? K + EXT_BITS / 2 : K;
+    const unsigned avail = std::min(64u, 2 * Kk);  // key bits visible in key_top64
     // average leaf = 0.7 * cap1, hit exactly thanks to the mixed-radix fan-outs. Leaf sizes are compound-Poisson (every genomic
     // k-mer arrives ~coverage times), sigma ~ sqrt(coverage * mean) ~ 110 at mean 716: ~3 sigma below cap1, the tail goes to the
     // 4x class. (At mean 915 one leaf in five overflowed: sort_unique2 9.6 ms.)
@@ -254,7 +256,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     wt.mark(ctx, "mark+alloc");
 
     PassArgs a{};
-    a.K = K;
+    a.K = Kk;
     a.ext = (!from_reads && ctx->ext_mode) ? 1u : 0u;
     a.num_buckets = B;
     a.bucket0 = b_first;
@@ -406,14 +408,14 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         if (sb1 > 0) {
             const dim3 grid1(ctx->opt_leaf_grid > 0 ? (unsigned)ctx->opt_leaf_grid : 256 * 16);
             if (distinct_hint)
-                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1, true>), grid1, dim3(BLK), lds1n, ctx->stream, (void *)sortbuf, fine_off, cap1, K, fa,
+                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1, true>), grid1, dim3(BLK), lds1n, ctx->stream, (void *)sortbuf, fine_off, cap1, Kk, fa,
                                    sb1, T1n, ucount, (const uint32_t *)medlist, (const uint32_t *)medcount, fblist, fbcount);
             else
-                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1, false>), grid1, dim3(BLK), lds1, ctx->stream, (void *)sortbuf, fine_off, cap1, K, fa,
+                hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT1, false>), grid1, dim3(BLK), lds1, ctx->stream, (void *)sortbuf, fine_off, cap1, Kk, fa,
                                    sb1, T1, ucount, (const uint32_t *)medlist, (const uint32_t *)medcount, fblist, fbcount);
         } else {  // leaves too small for the digit table (test-sized caps): the general kernel takes the list directly
             hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT1>), dim3(256 * 8), dim3(BLK), lds1, ctx->stream, (void *)sortbuf,
-                               fine_off, (uint32_t)nb, cap1, K, fa, sb1, T1, ucount, biglist, bigcount,
+                               fine_off, (uint32_t)nb, cap1, Kk, fa, sb1, T1, ucount, biglist, bigcount,
                                (const uint32_t *)medlist, (const uint32_t *)medcount);
         }
         HIPCHK(hipGetLastError());
@@ -422,19 +424,19 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
         if (sb2 > 0) {
             if (distinct_hint)
                 hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT, true>), dim3(256 * 2), dim3(BLK), lds2n, ctx->stream, (void *)sortbuf, fine_off, cap,
-                                   K, fa, sb2, T2n, ucount, (const uint32_t *)med2list, (const uint32_t *)med2count, fblist, fbcount);
+                                   Kk, fa, sb2, T2n, ucount, (const uint32_t *)med2list, (const uint32_t *)med2count, fblist, fbcount);
             else
                 hipLaunchKernelGGL((k_sort_hash<NW, Tune<NW>::LPT, false>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf, fine_off, cap,
-                                   K, fa, sb2, T2, ucount, (const uint32_t *)med2list, (const uint32_t *)med2count, fblist, fbcount);
+                                   Kk, fa, sb2, T2, ucount, (const uint32_t *)med2list, (const uint32_t *)med2count, fblist, fbcount);
         } else {
             hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf,
-                               fine_off, (uint32_t)nb, cap, K, fa, sb2, T2, ucount, biglist, bigcount,
+                               fine_off, (uint32_t)nb, cap, Kk, fa, sb2, T2, ucount, biglist, bigcount,
                                (const uint32_t *)med2list, (const uint32_t *)med2count);
         }
         HIPCHK(hipGetLastError());
         // skewed leaves left over by the fast kernel (any size <= cap): general kernel with the bitonic fallback
         hipLaunchKernelGGL((k_sort_small<NW, Tune<NW>::LPT>), dim3(256 * 2), dim3(BLK), lds2, ctx->stream, (void *)sortbuf,
-                           fine_off, (uint32_t)nb, cap, K, fa, sb2, T2, ucount, biglist, bigcount,
+                           fine_off, (uint32_t)nb, cap, Kk, fa, sb2, T2, ucount, biglist, bigcount,
                            (const uint32_t *)fblist, (const uint32_t *)fbcount);
         HIPCHK(hipGetLastError());
         tend(ctx);

@@ -15,9 +15,9 @@ FORCE = {"prededupe": 1, "ext_route": 1}   # small inputs: the pre-dedupe stage 
 LEGACY = {"prededupe": 1, "ext_route": 0}
 
 
-def _eligible(k):
+def _eligible(k):  # 8 spare bits in the last record word, and the pre-dedupe stage (where the bytes are gathered) applies
     nw = (k + 31) // 32
-    return nw >= 2 and 2 * k + 8 <= 64 * nw
+    return k >= 21 and 2 * k + 8 <= 64 * nw
 
 
 def _build(reads, k, threads, tmp_path, opts, coverage=False):
@@ -87,7 +87,7 @@ def _synth(seed, glen, n, L, err=0.01, nrate=0.002):
     return reads
 
 
-@pytest.mark.parametrize("k", [33, 41, 55, 59, 77, 91, 123])
+@pytest.mark.parametrize("k", [21, 25, 27, 33, 41, 55, 59, 77, 91, 123])
 def test_vs_oracle_seeded(k, tmp_path):
     """ragged reads (1 .. 150 bases, some exactly k and k+1 long), both strands, N, rc-palindromic (k+1)-mers (ACGT / AT repeats),
     homopolymers; several bucket counts"""
@@ -110,7 +110,7 @@ def test_vs_oracle_seeded(k, tmp_path):
 
 def test_coverage_vs_oracle_seeded(tmp_path):
     from oracle import oracle
-    for k, threads in ((55, 1), (77, 2)):
+    for k, threads in ((21, 2), (55, 1), (77, 2)):
         reads = _synth(5 + k, 6000, 1500, 150) + ["ACGT" * 40] * 3 + ["A" * 100] * 5
         ref = oracle.build_graph(reads, k, 10 * threads, coverage=True)
         r = _build(reads, k, threads, tmp_path, FORCE, coverage=True)
@@ -129,9 +129,10 @@ def test_cut_partitions_are_merged(tmp_path):
 
 
 def test_route_is_declined_where_it_does_not_fit(tmp_path):
-    """k = 31 / 63 / 127 leave fewer than 8 spare bits in the last record word, k <= 31 has one word: same results by the other route"""
+    """k = 29, 31 / 61, 63 / 127 leave fewer than 8 spare bits in the last record word, k < 21 has no pre-dedupe stage: same results by
+    the other route"""
     from oracle import oracle
-    for k in (21, 31, 63):
+    for k in (15, 29, 31, 63):
         reads = _synth(k, 3000, 800, 150)
         ref = oracle.build_graph(reads, k, 10)
         r = _build(reads, k, 1, tmp_path, FORCE)
