@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--kpomer-route", action="store_true",
                     help="N=1: construction by the reference's own order of work ((k+1)-mer file first, masks filled from it) instead of "
                          "k-mers + masks from one count of the reads")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option for this run (smx_set_option), e.g. dir_slots=2")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
     args = ap.parse_args()
 
@@ -267,6 +268,9 @@ def main():
     ctx = Context(device=local_rank)
     if args.kpomer_route:
         ctx.set_option("ext_route", 0)
+    for kv in args.opt:
+        key, _, val = kv.partition("=")
+        ctx.set_option(key, int(val))
     gb = GraphBuilder(k, T, ctx)
     engine = None
     if sharded:

@@ -101,6 +101,8 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "spill")) ctx->opt_spill = value;
     else if (!strcmp(key, "kmers_from_reads")) ctx->opt_kmers_from_reads = value;
     else if (!strcmp(key, "ext_route")) ctx->opt_ext_route = value;
+    else if (!strcmp(key, "dir_slots")) ctx->opt_dir_slots = value;
+    else if (!strcmp(key, "ext_presort")) ctx->opt_ext_presort = value;
     else return fail(ctx, SMX_INVALID_PARAMETER, "unknown option %s", key);
     return SMX_OK;
 }

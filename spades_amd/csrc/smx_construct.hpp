@@ -207,7 +207,11 @@ int build_rank_dir(smx_ctx *ctx, const void *recs, uint64_t n, const std::vector
     uint64_t mx = 0;
     for (uint32_t b = 0; b < B; ++b) mx = std::max(mx, boff[b + 1] - boff[b]);
     if (mx >= (1ull << 32)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "a bucket of %llu records exceeds the directory's 32-bit offsets (use more buckets)", (unsigned long long)mx);
-    const uint64_t sb = std::min<uint64_t>(std::max<uint64_t>(1, n / B), 1ull << 30);  // ~1 record per slot
+    // slots per bucket (option "dir_slots": slots per record — more slots, more present k-mers alone in theirs, 4 B each)
+    // (measured at 4.3 G k-mers: 1 -> 2 slots per record takes the successor lookups from 340 to 284 ms and costs 9 ms more here,
+    // 4 slots cost more than they save; with the (k+1)-mer file resident next to the graph the HBM goes to that instead)
+    const uint64_t per = ctx->opt_dir_slots > 0 ? (uint64_t)std::min<int64_t>(ctx->opt_dir_slots, 8) : (ctx->g_kpo ? 1 : 2);
+    const uint64_t sb = std::min<uint64_t>(std::max<uint64_t>(1, n / B * per), 1ull << 30);
     unsigned long long *d_boff;
     uint32_t *dir;
     if (int rc = dalloc(ctx, &d_boff, (size_t)B + 1, false)) return rc;
@@ -398,48 +402,73 @@ int kmer_file_with_masks(smx_ctx *ctx, unsigned k, unsigned B) {
         ctx->g_nkmers = ctx->g_nkpo = 0;
         return 0;
     }
-    const uint64_t ntiles = (n + XM_TILE - 1) / XM_TILE;
-    unsigned long long *tcnt, *toff, *stats, *d_old, *d_new;
-    if (int rc2 = dalloc(ctx, &tcnt, ntiles)) return rc2;
-    if (int rc2 = dalloc(ctx, &toff, ntiles + 1)) return rc2;
-    if (int rc2 = dalloc(ctx, &stats, 2)) return rc2;
-    if (int rc2 = dalloc(ctx, &d_old, B + 1)) return rc2;
-    if (int rc2 = dalloc(ctx, &d_new, B + 1)) return rc2;
-    HIPCHK(hipMemsetAsync(stats, 0, 16, ctx->stream));
-    {
-        std::vector<unsigned long long> h(raw_off.begin(), raw_off.end());
-        HIPCHK(hipMemcpyAsync(d_old, h.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    tbegin(ctx, "ext_merge");
-    const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 16);
-    hipLaunchKernelGGL((k_ext_heads<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)raw, n, tcnt);
-    HIPCHK(hipGetLastError());
-    if (int rc2 = scan_u64(ctx, tcnt, toff, ntiles)) return rc2;
-    unsigned long long nk = 0;
-    HIPCHK(hipMemcpyAsync(&nk, toff + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // the usual case first: every k-mer occurs once (run_prededupe merged the survivors of cut partitions) — one streaming pass
+    unsigned long long *stats;
+    if (int rc2 = dalloc(ctx, &stats, 3)) return rc2;
+    HIPCHK(hipMemsetAsync(stats, 0, 24, ctx->stream));
     Rec<NW> *file;
-    if (int rc2 = dalloc(ctx, &file, nk, false)) return rc2;
+    if (int rc2 = dalloc(ctx, &file, n, false)) return rc2;
     ctx->g_kmers = file;
-    ctx->g_nkmers = nk;
-    const size_t mask_bytes = (size_t)((nk + 7) / 8 * 8 + 8);
+    size_t mask_bytes = (size_t)((n + 7) / 8 * 8 + 8);
     if (int rc2 = dalloc(ctx, &ctx->g_mask, mask_bytes, false)) return rc2;
-    HIPCHK(hipMemsetAsync(ctx->g_mask + nk, 0, mask_bytes - nk, ctx->stream));
-    hipLaunchKernelGGL((k_ext_merge<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)raw, n, (const unsigned long long *)toff, k, (void *)file,
-                       ctx->g_mask, stats);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL((k_ext_boff<NW>), dim3((B + 1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, (const void *)raw, n, (const unsigned long long *)toff,
-                       (const unsigned long long *)d_old, B + 1, d_new);
+    tbegin(ctx, "ext_merge");
+    hipLaunchKernelGGL((k_ext_split<NW>), dim3(grid_for(n)), dim3(BLK), 0, ctx->stream, (const void *)raw, n, k, (void *)file, ctx->g_mask, stats);
     HIPCHK(hipGetLastError());
     tend(ctx);
-    std::vector<unsigned long long> hn(B + 1);
-    unsigned long long hs[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(hn.data(), d_new, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(hs, stats, 16, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long hs[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(hs, stats, 24, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (unsigned b = 0; b <= B; ++b) ctx->g_kboff[b] = hn[b];
-    if (ctx->g_kboff[B] != nk) return fail(ctx, SMX_DEVICE_ERROR, "inconsistent bucket offsets after the extension merge (%llu vs %llu)", hn[B], nk);
+    uint64_t nk = n;
+    if (hs[2] == 0) {
+        HIPCHK(hipMemsetAsync(ctx->g_mask + nk, 0, mask_bytes - nk, ctx->stream));
+        for (unsigned b = 0; b <= B; ++b) ctx->g_kboff[b] = raw_off[b];
+    } else {  // copies of a k-mer with different bytes are still there: heads, scan, merge
+        arena_put(ctx, file);
+        arena_put(ctx, ctx->g_mask);
+        ctx->g_kmers = nullptr;
+        ctx->g_mask = nullptr;
+        const uint64_t ntiles = (n + XM_TILE - 1) / XM_TILE;
+        unsigned long long *tcnt, *toff, *d_old, *d_new;
+        if (int rc2 = dalloc(ctx, &tcnt, ntiles)) return rc2;
+        if (int rc2 = dalloc(ctx, &toff, ntiles + 1)) return rc2;
+        if (int rc2 = dalloc(ctx, &d_old, B + 1)) return rc2;
+        if (int rc2 = dalloc(ctx, &d_new, B + 1)) return rc2;
+        HIPCHK(hipMemsetAsync(stats, 0, 24, ctx->stream));
+        {
+            std::vector<unsigned long long> h(raw_off.begin(), raw_off.end());
+            HIPCHK(hipMemcpyAsync(d_old, h.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+        tbegin(ctx, "ext_merge");
+        const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 16);
+        hipLaunchKernelGGL((k_ext_heads<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)raw, n, tcnt);
+        HIPCHK(hipGetLastError());
+        if (int rc2 = scan_u64(ctx, tcnt, toff, ntiles)) return rc2;
+        unsigned long long nkd = 0;
+        HIPCHK(hipMemcpyAsync(&nkd, toff + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        nk = nkd;
+        if (int rc2 = dalloc(ctx, &file, nk, false)) return rc2;
+        ctx->g_kmers = file;
+        mask_bytes = (size_t)((nk + 7) / 8 * 8 + 8);
+        if (int rc2 = dalloc(ctx, &ctx->g_mask, mask_bytes, false)) return rc2;
+        HIPCHK(hipMemsetAsync(ctx->g_mask + nk, 0, mask_bytes - nk, ctx->stream));
+        hipLaunchKernelGGL((k_ext_merge<NW, true>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)raw, n, (const unsigned long long *)toff, k, (void *)file,
+                           ctx->g_mask, stats);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL((k_ext_boff<NW>), dim3((B + 1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, (const void *)raw, n, (const unsigned long long *)toff,
+                           (const unsigned long long *)d_old, B + 1, d_new);
+        HIPCHK(hipGetLastError());
+        tend(ctx);
+        std::vector<unsigned long long> hn(B + 1);
+        HIPCHK(hipMemcpyAsync(hn.data(), d_new, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(hs, stats, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (unsigned b = 0; b <= B; ++b) ctx->g_kboff[b] = hn[b];
+    }
+    ctx->g_nkmers = nk;
+    if (ctx->g_kboff[B] != nk) return fail(ctx, SMX_DEVICE_ERROR, "inconsistent bucket offsets after the extension merge (%llu vs %llu)",
+                                           (unsigned long long)ctx->g_kboff[B], (unsigned long long)nk);
     if ((hs[0] + hs[1]) & 1) return fail(ctx, SMX_DEVICE_ERROR, "odd number of extension bits (%llu + %llu palindromes)", hs[0], hs[1]);
     ctx->g_nkpo = (hs[0] + hs[1]) / 2;
     free_temps(ctx);

@@ -356,7 +356,8 @@ __global__ void __launch_bounds__(BLK) k_ext_heads(const void *in_, uint64_t n, 
 // stats: [0] extension bits set, [1] palindromic (k+1)-mers among them (k+1 is even): with both, the number of canonical (k+1)-mers
 // the reads hold = (bits + palindromes) / 2 — every other (k+1)-mer sets one bit at its prefix node and one at the reverse
 // complement of its suffix node (k_fill_tab), a palindrome sets the same bit twice.
-template <int NW>
+// SPLIT: k-mer file + bytes + stats; else the merged records stay in the EXT layout (the survivors of cut partitions, before the sort)
+template <int NW, bool SPLIT>
 __global__ void __launch_bounds__(BLK) k_ext_merge(const void *in_, uint64_t n, const unsigned long long *toff, unsigned k, void *kmers_, uint8_t *mask,
                                                    unsigned long long *stats) {
     const Rec<NW> *in = (const Rec<NW> *)in_;
@@ -400,6 +401,12 @@ __global__ void __launch_bounds__(BLK) k_ext_merge(const void *in_, uint64_t n, 
                 m |= (unsigned)(y.w[NW - 1] & 0xFFu);
             }
             const uint64_t o = obase + s_w[j * (BLK / 64) + wave] + __popcll(bal[j] & ((1ull << lane) - 1));
+            if constexpr (!SPLIT) {
+                Rec<NW> y = raw;
+                y.w[NW - 1] = (raw.w[NW - 1] & ~0xFFull) | m;
+                kmers[o] = y;
+                continue;
+            }
             kmers[o] = x;
             mask[o] = (uint8_t)m;
             bits += __popc(m);
@@ -411,13 +418,46 @@ __global__ void __launch_bounds__(BLK) k_ext_merge(const void *in_, uint64_t n, 
         }
         __syncthreads();
     }
+    if constexpr (SPLIT) {
+        for (int o = 32; o > 0; o >>= 1) {
+            bits += __shfl_down(bits, o, 64);
+            pals += __shfl_down(pals, o, 64);
+        }
+        if (lane == 0) {
+            if (bits) atomicAdd(&stats[0], bits);
+            if (pals) atomicAdd(&stats[1], pals);
+        }
+    }
+}
+// The usual case: every k-mer occurs once (cut partitions were merged before the sort) — one streaming pass splits the records;
+// stats[2] counts records that repeat the k-mer before them (then the general merge above runs instead).
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_ext_split(const void *in_, uint64_t n, unsigned k, void *kmers_, uint8_t *mask, unsigned long long *stats) {
+    const Rec<NW> *in = (const Rec<NW> *)in_;
+    Rec<NW> *kmers = (Rec<NW> *)kmers_;
+    const unsigned lane = threadIdx.x & 63;
+    unsigned long long bits = 0, pals = 0, rep = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        const Rec<NW> raw = in[i];
+        const Rec<NW> x = rec_pure<NW>(raw);
+        const unsigned m = (unsigned)(raw.w[NW - 1] & 0xFFu);
+        if (i && rec_eq<NW>(rec_pure<NW>(in[i - 1]), x)) ++rep;
+        kmers[i] = x;
+        mask[i] = (uint8_t)m;
+        bits += __popc(m);
+        const unsigned x0 = rec_nucl<NW>(x, 0), xl = rec_nucl<NW>(x, k - 1);
+        if (((m >> (3 - x0)) & 1) && range_is_rc_palindrome<NW>(x, 1, k - 1)) ++pals;
+        if (((m >> (7 - xl)) & 1) && range_is_rc_palindrome<NW>(x, 0, k - 1)) ++pals;
+    }
     for (int o = 32; o > 0; o >>= 1) {
         bits += __shfl_down(bits, o, 64);
         pals += __shfl_down(pals, o, 64);
+        rep += __shfl_down(rep, o, 64);
     }
     if (lane == 0) {
         if (bits) atomicAdd(&stats[0], bits);
         if (pals) atomicAdd(&stats[1], pals);
+        if (rep) atomicAdd(&stats[2], rep);
     }
 }
 // bucket offsets of the merged file: heads before the old offset

@@ -663,6 +663,27 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     unsigned long long n = nn[0];
     if (nn[1]) {  // survivors of cut keys: sort + unique them on their own, then the whole array is exactly distinct
         if (int rc = run_count<NW>(ctx, K, SMX_MODE_ALL, 1, *out + (out_cap - nn[1]), nn[1])) return rc;
+        if (ext && ctx->n_records && ctx->opt_ext_presort != 0) {
+            // copies of a k-mer that left different chunks with different extension bytes are neighbours now: one record, bytes ORed
+            const uint64_t nd = ctx->n_records, ntiles = (nd + XM_TILE - 1) / XM_TILE;
+            unsigned long long *tcnt, *toff;
+            Rec<NW> *merged;
+            if (int rc = dalloc(ctx, &tcnt, ntiles)) return rc;
+            if (int rc = dalloc(ctx, &toff, ntiles + 1)) return rc;
+            if (int rc = dalloc(ctx, &merged, nd)) return rc;
+            const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 16);
+            hipLaunchKernelGGL((k_ext_heads<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->d_result_buf, nd, tcnt);
+            HIPCHK(hipGetLastError());
+            if (int rc = scan_u64(ctx, tcnt, toff, ntiles)) return rc;
+            hipLaunchKernelGGL((k_ext_merge<NW, false>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->d_result_buf, nd,
+                               (const unsigned long long *)toff, K, (void *)merged, (uint8_t *)nullptr, (unsigned long long *)nullptr);
+            HIPCHK(hipGetLastError());
+            unsigned long long nm = 0;
+            HIPCHK(hipMemcpyAsync(&nm, toff + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            ctx->d_result_buf = ctx->d_result = merged;  // (both buffers stay in the temp list)
+            ctx->n_records = nm;
+        }
         HIPCHK(hipMemcpyAsync(*out + nn[0], ctx->d_result_buf, ctx->n_records * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         n += ctx->n_records;

@@ -126,6 +126,9 @@ def test_cut_partitions_are_merged(tmp_path):
     ref = oracle.build_graph(reads, k, 20)
     r = _build(reads, k, 2, tmp_path, dict(FORCE, skm_cap=512))
     assert r["took_ext_route"] and r["gfa"] == ref["gfa"]
+    # ... or, when they were not merged before it (the general merge: heads, scan, OR)
+    r2 = _build(reads, k, 2, tmp_path, dict(FORCE, skm_cap=512, ext_presort=0))
+    assert r2["took_ext_route"] and r2["gfa"] == ref["gfa"] and _same_kmers(r, r2) and r["info"] == r2["info"]
 
 
 def test_route_is_declined_where_it_does_not_fit(tmp_path):

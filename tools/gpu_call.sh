@@ -17,6 +17,7 @@ for step in "$@"; do
     tdist) timeout 900 python -m pytest tests/test_dist_gpu.py tests/test_cli_gpu.py -m gpu -x -q 2>&1 | tail -8 ;;
     text) timeout 900 python -m pytest tests/test_ext_route_gpu.py -m gpu -x -q > gpurun_out/$tag/text.txt 2>&1; grep -v "^  File" gpurun_out/$tag/text.txt | tail -40 ;;
     tgraph) timeout 900 python -m pytest tests/test_graph_gpu.py tests/test_prededupe_gpu.py tests/test_count_gpu.py -m gpu -x -q 2>&1 | tail -15 ;;
+    benchopt=*) o=${step#benchopt=}; timeout 1500 python bench.py --no-cpu-baseline --extra-kmercount 0 --steps 2 --opt $o > gpurun_out/$tag/bench_$o.json 2> gpurun_out/$tag/bench_$o.err; tail -2 gpurun_out/$tag/bench_$o.err; python tools/bench_summary.py gpurun_out/$tag/bench_$o.json ;;
     *) echo "unknown step $step" ;;
   esac
 done
