@@ -65,7 +65,12 @@ const char *smx_version(void);
  *   "derive_batches" (k-mer file of the construction in this many bucket ranges; 0 = as HBM requires), "keep_kpo" (-1 keep the
  *   (k+1)-mer file after the masks if HBM allows, 0 drop it: the coverage pass recounts), "verify_lookups" (1: rank lookups of
  *   k-mers that are present by construction still compare the record), "spill" (1: always keep sorted runs in host memory and
- *   merge them by bucket ranges; -1 only when the set outgrows the HBM budget).
+ *   merge them by bucket ranges; -1 only when the set outgrows the HBM budget), "ext_route" (-1 / 1: the construction takes k-mers and
+ *   InOutMask bytes from ONE count of the reads where the record has 8 spare bits, the pre-dedupe stage applies and one batch fits;
+ *   0: always the (k+1)-mer file first, as the reference does), "ext_presort" (0: copies of a k-mer from cut partitions are merged
+ *   after the sort instead of before it), "kmers_from_reads" (0: the k-mer file of the second route is derived from the (k+1)-mer
+ *   file, not counted from the reads), "dir_slots" (rank directory: slots per record, 1..8; -1 = 2, or 1 next to a resident
+ *   (k+1)-mer file).
  * SMX_OPTS="key=value,..." in the environment applies options to every new context.
  *
  * HBM budget (smx_create): the context never holds more device memory than hbm_budget_bytes (0 = what the device has). A count whose
