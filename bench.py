@@ -479,6 +479,17 @@ def main():
                                      "M_reads_per_s": round(ne_ / dta / 1e6, 2), "ms_per_step": round(dta * 1e3, 3), "kernel_ms": round(tma, 3),
                                      "kmer_instances": int(ia), "distinct_kmers": int(da),
                                      "roofline_frac": round(ba / max(tma, 1e-9) / 1e6 / 8000.0, 4)}
+    if sharded and rank == 0:
+        # the N = 1 default line is another workload (config 3: upload + count + construction); the figure to divide an N-rank value by
+        # is this same sharded step on ONE rank, measured with --gpus 1 --force-sharded and committed under profiles/
+        ref = os.path.join(ROOT, "profiles", "r02", "bench_sharded_1rank_100M.json")
+        try:
+            r1 = json.load(open(ref))
+            if r1["config"]["reads_per_gpu"] == n_reads and r1["config"]["k"] == k and r1["config"]["num_buckets"] == nb:
+                out["same_step_on_one_rank"] = {"value": r1["value"], "unit": r1["unit"], "ms_per_step": r1["ms_per_step"],
+                                                "source": "profiles/r02/bench_sharded_1rank_100M.json (bench.py --gpus 1 --force-sharded)"}
+        except (OSError, ValueError, KeyError):
+            pass
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: out before the result line, not after it

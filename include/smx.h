@@ -206,6 +206,20 @@ int smx_graph_shard_updates(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsi
                             uint64_t *counts /* [world] */);
 int smx_graph_shard_build(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsigned world, unsigned rank, const void *d_updates,
                           uint64_t n_updates);
+/* The same owner-side shard by ONE exchange, for k whose record has 8 spare bits (smx_kmers_with_masks_supported; the single-GPU
+ * construction takes this route by itself): smx_extract_kmers_ext_owned hands out the canonical k-mers of this rank's reads (those
+ * with a (k+1)-mer), each with the InOutMask byte ITS reads give it, as records of ceil(k/32) words whose last word is
+ * (k-mer bits << 8 | byte), grouped by owner rank like smx_extract_partition_owned; after the all-to-all smx_graph_shard_from_ext
+ * sorts what arrived, ORs the bytes of the copies of a k-mer and leaves the shard where smx_graph_shard_info / _copy find it
+ * (records in the smx_exchange_buffer are consumed). smx_graph_shard_ext_stats: [0] extension bits set in the shard, [1] those
+ * whose (k+1)-mer is its own reverse complement — the graph has (sum over ranks of [0] + [1]) / 2 canonical (k+1)-mers, the
+ * n_kpomers of smx_build_graph_from_kmers. (kmer_extension_index_builder.hpp:45-60: a (k+1)-mer of the reads is the window behind
+ * its prefix instance and before its suffix instance.) */
+int smx_kmers_with_masks_supported(unsigned k);
+int smx_extract_kmers_ext_owned(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsigned world, const void **d_records, uint64_t *counts /* [world] */);
+int smx_graph_shard_from_ext(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsigned world, unsigned rank, const void *d_records,
+                             uint64_t n_records);
+int smx_graph_shard_ext_stats(const smx_ctx *ctx, uint64_t *stats /* [2] */);
 int smx_graph_shard_info(const smx_ctx *ctx, uint64_t *n_kmers, uint64_t *bucket_sizes /* [num_buckets] or NULL */);
 int smx_graph_shard_copy(const smx_ctx *ctx, void *d_kmers, void *d_masks);
 int smx_build_graph_from_kmers(smx_ctx *ctx, unsigned k, unsigned num_buckets, const void *d_kmers, const void *d_masks, uint64_t n_kmers,

@@ -542,7 +542,7 @@ int smx_extract_count(smx_ctx *ctx, unsigned K, int mode, uint64_t *n_records) {
 
 
 static int extract_partition_impl(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets, unsigned world, void *d_records,
-                                  uint64_t capacity_records, uint64_t *counts, void **owned) {
+                                  uint64_t capacity_records, uint64_t *counts, void **owned, unsigned min_len = 0) {
     if (!ctx || !counts) return SMX_INVALID_PARAMETER;
     if (K < 1 || K > 128) return fail(ctx, SMX_INVALID_PARAMETER, "K=%u out of range [1,128]", K);
     if (world < 1 || world > 4096 || num_buckets < 1) return fail(ctx, SMX_INVALID_PARAMETER, "bad world/num_buckets");
@@ -555,10 +555,10 @@ static int extract_partition_impl(smx_ctx *ctx, unsigned K, int mode, unsigned n
     }
     int rc;
     switch ((K + 31) / 32) {
-        case 1: rc = run_extract_partition<1>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned); break;
-        case 2: rc = run_extract_partition<2>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned); break;
-        case 3: rc = run_extract_partition<3>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned); break;
-        default: rc = run_extract_partition<4>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned); break;
+        case 1: rc = run_extract_partition<1>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned, min_len); break;
+        case 2: rc = run_extract_partition<2>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned, min_len); break;
+        case 3: rc = run_extract_partition<3>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned, min_len); break;
+        default: rc = run_extract_partition<4>(ctx, K, mode, num_buckets, world, d_records, capacity_records, counts, owned, min_len); break;
     }
     (void)hipStreamSynchronize(ctx->stream);
     if (rc == 0) {
@@ -593,6 +593,19 @@ int smx_extract_partition_owned(smx_ctx *ctx, unsigned K, int mode, unsigned num
     if (!d_records) return SMX_INVALID_PARAMETER;
     void *p = nullptr;
     const int rc = extract_partition_impl(ctx, K, mode, num_buckets, world, nullptr, 0, counts, &p);
+    *d_records = p;
+    return rc;
+}
+
+int smx_kmers_with_masks_supported(unsigned k) { return (k >= 21 && k < 128 && (k & 1) && ext_layout_fits(k, (int)((k + 31) / 32))) ? 1 : 0; }
+
+int smx_extract_kmers_ext_owned(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsigned world, const void **d_records, uint64_t *counts) {
+    if (!ctx || !d_records) return SMX_INVALID_PARAMETER;
+    if (!smx_kmers_with_masks_supported(k)) return fail(ctx, SMX_INVALID_PARAMETER, "k=%u: no room for an extension byte in the k-mer record (or k < 21)", k);
+    void *p = nullptr;
+    ctx->ext_mode = true;
+    const int rc = extract_partition_impl(ctx, k, SMX_MODE_CANONICAL, num_buckets, world, nullptr, 0, counts, &p, k + 1);
+    ctx->ext_mode = false;
     *d_records = p;
     return rc;
 }
@@ -705,6 +718,37 @@ int smx_graph_shard_build(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsign
         default: rc = shard_build<4>(ctx, k, num_buckets, world, rank, d_updates, n_updates); break;
     }
     return finish_call(ctx, rc, true);
+}
+
+int smx_graph_shard_from_ext(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsigned world, unsigned rank, const void *d_records, uint64_t n_records) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    if (k < 1 || k >= 128 || k % 2 == 0) return fail(ctx, SMX_INVALID_PARAMETER, "k-mer size must be odd and below 128");
+    if (world < 1 || rank >= world || num_buckets < 1) return fail(ctx, SMX_INVALID_PARAMETER, "bad world/rank/num_buckets");
+    if (n_records && !d_records) return fail(ctx, SMX_INVALID_PARAMETER, "null records");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->xnames.clear();
+    ctx->xms.clear();
+    // records in the library's own exchange buffer are consumed: the buffer becomes one of the sort's temporaries
+    const bool own = ctx->x_recv && d_records == ctx->x_recv;
+    if (own) {
+        ctx->temps.push_back(ctx->x_recv);
+        ctx->x_recv = nullptr;
+    }
+    int rc;
+    switch ((k + 31) / 32) {
+        case 1: rc = shard_from_ext<1>(ctx, k, num_buckets, world, rank, d_records, n_records, own); break;
+        case 2: rc = shard_from_ext<2>(ctx, k, num_buckets, world, rank, d_records, n_records, own); break;
+        case 3: rc = shard_from_ext<3>(ctx, k, num_buckets, world, rank, d_records, n_records, own); break;
+        default: rc = shard_from_ext<4>(ctx, k, num_buckets, world, rank, d_records, n_records, own); break;
+    }
+    return finish_call(ctx, rc, true);
+}
+
+int smx_graph_shard_ext_stats(const smx_ctx *ctx, uint64_t *stats) {
+    if (!ctx || !stats) return SMX_INVALID_PARAMETER;
+    stats[0] = ctx->g_ext_bits;
+    stats[1] = ctx->g_ext_pals;
+    return SMX_OK;
 }
 
 int smx_graph_shard_info(const smx_ctx *ctx, uint64_t *n_kmers, uint64_t *bucket_sizes) {

@@ -375,9 +375,10 @@ int derive_kmer_file(smx_ctx *ctx, unsigned k, unsigned B, bool from_reads) {
 // window behind its prefix instance and before its suffix instance. Needs >= 8 spare bits in the last record word, two words
 // or more, the pre-dedupe stage (k >= 21, enough windows) and one batch; SMX_ROUTE_NA otherwise (nothing changed).
 template <int NW>
+int ext_result_to_file(smx_ctx *ctx, unsigned k, unsigned B, bool whole);
+template <int NW>
 int kmer_file_with_masks(smx_ctx *ctx, unsigned k, unsigned B) {
     if (ctx->opt_ext_route == 0 || !ext_layout_fits(k, NW) || ctx->chunks.empty() || ctx->opt_derive_batches != 0) return SMX_ROUTE_NA;
-    const size_t W = (size_t)NW * 8;
     ctx->ext_mode = true;
     ctx->single_batch_only = true;
     int rc = count_reads<NW>(ctx, k, SMX_MODE_CANONICAL, B, k + 1);
@@ -390,6 +391,15 @@ int kmer_file_with_masks(smx_ctx *ctx, unsigned k, unsigned B) {
         return SMX_ROUTE_NA;
     }
     if (rc) return rc;
+    if (int rc2 = ext_result_to_file<NW>(ctx, k, B, /*whole=*/true)) return rc2;
+    return 0;
+}
+
+// The context's count result in the EXT layout (sorted, bucket-major) -> k-mer file, InOutMask bytes, bucket offsets; the raw
+// records are released. whole: the result covers all reads of the graph (one GPU) — an odd number of extension bits is then an
+// error and g_nkpo is set; a shard only reports its bits and palindromes (g_ext_bits / g_ext_pals), the caller adds the ranks up.
+template <int NW>
+int ext_result_to_file(smx_ctx *ctx, unsigned k, unsigned B, bool whole) {
     void *raw = ctx->d_result_buf;
     const uint64_t n = ctx->n_records;
     const std::vector<uint64_t> raw_off = ctx->bucket_off;
@@ -397,6 +407,7 @@ int kmer_file_with_masks(smx_ctx *ctx, unsigned k, unsigned B) {
     free_temps(ctx, raw);
     ctx->temps.push_back(raw);
     ctx->g_kboff.assign(B + 1, 0);
+    ctx->g_ext_bits = ctx->g_ext_pals = 0;
     if (n == 0) {
         free_temps(ctx);
         ctx->g_nkmers = ctx->g_nkpo = 0;
@@ -469,8 +480,12 @@ int kmer_file_with_masks(smx_ctx *ctx, unsigned k, unsigned B) {
     ctx->g_nkmers = nk;
     if (ctx->g_kboff[B] != nk) return fail(ctx, SMX_DEVICE_ERROR, "inconsistent bucket offsets after the extension merge (%llu vs %llu)",
                                            (unsigned long long)ctx->g_kboff[B], (unsigned long long)nk);
-    if ((hs[0] + hs[1]) & 1) return fail(ctx, SMX_DEVICE_ERROR, "odd number of extension bits (%llu + %llu palindromes)", hs[0], hs[1]);
-    ctx->g_nkpo = (hs[0] + hs[1]) / 2;
+    ctx->g_ext_bits = hs[0];
+    ctx->g_ext_pals = hs[1];
+    if (whole) {
+        if ((hs[0] + hs[1]) & 1) return fail(ctx, SMX_DEVICE_ERROR, "odd number of extension bits (%llu + %llu palindromes)", hs[0], hs[1]);
+        ctx->g_nkpo = (hs[0] + hs[1]) / 2;
+    }
     free_temps(ctx);
     ctx->n_records = nk;
     ctx->bucket_off = ctx->g_kboff;
@@ -1123,6 +1138,26 @@ int shard_build(smx_ctx *ctx, unsigned k, unsigned B, unsigned world, unsigned r
     return 0;
 }
 // 3. the graph from the gathered compact structure {k-mer file, InOutMask bytes} (replicated on every rank)
+// 2'. owner side of the one-exchange route: the records received are canonical k-mers in the EXT layout, every rank's copy with the
+// extension byte ITS reads gave the k-mer; sort (exact copies drop out), OR the bytes of the copies, split into file + bytes
+template <int NW>
+int shard_from_ext(smx_ctx *ctx, unsigned k, unsigned B, unsigned world, unsigned rank, const void *d_recs, uint64_t n, bool recs_reusable) {
+    clear_graph(ctx);
+    ctx->g_k = k;
+    ctx->g_nw = NW;
+    ctx->g_B = B;
+    ctx->g_kboff.assign(B + 1, 0);
+    ctx->g_ext_bits = ctx->g_ext_pals = 0;
+    if (!ext_layout_fits(k, NW)) return fail(ctx, SMX_INVALID_PARAMETER, "k=%u leaves no room for the extension byte", k);
+    const unsigned b0 = (unsigned)(((uint64_t)rank * B + world - 1) / world), b1 = (unsigned)(((uint64_t)(rank + 1) * B + world - 1) / world);
+    if (n == 0) return 0;
+    ctx->ext_mode = true;
+    int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, d_recs, n, nullptr, recs_reusable, false, false, b0, std::max(1u, b1 - b0));
+    ctx->ext_mode = false;
+    if (rc) return rc;
+    return ext_result_to_file<NW>(ctx, k, B, /*whole=*/false);
+}
+
 template <int NW>
 int run_graph_from_kmers(smx_ctx *ctx, unsigned k, unsigned B, const void *d_kmers, const void *d_masks, uint64_t n, const uint64_t *bucket_sizes) {
     clear_graph(ctx);

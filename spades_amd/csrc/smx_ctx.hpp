@@ -52,6 +52,7 @@ struct smx_ctx {
     };
     std::vector<HostChunk> h_result;
     bool result_on_host = false;
+    uint64_t g_ext_bits = 0, g_ext_pals = 0;  // extension bits / palindromic (k+1)-mers among them in the k-mer file or shard built from EXT records
     bool ext_mode = false;    // the count in flight carries extension bytes in its records (EXT layout, smx_device.hpp): set by the construction
     void *x_owned = nullptr;  // output of smx_extract_partition_owned (released by the next extract / smx_extract_release)
     void *x_recv = nullptr;   // smx_exchange_buffer: receive side of the exchange, consumed by smx_count_records

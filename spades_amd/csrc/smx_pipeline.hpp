@@ -1047,19 +1047,22 @@ int dispatch_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d
 namespace {
 template <int NW>
 int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned world, void *d_records, uint64_t capacity,
-                          uint64_t *counts, void **owned_out = nullptr) {
+                          uint64_t *counts, void **owned_out = nullptr, unsigned min_len = 0) {
+    // ctx->ext_mode (set by the caller): canonical K-mers of the reads that hold a (K+1)-mer (min_len = K + 1), each with the extension
+    // byte its instances on THIS rank give it, in the EXT layout; the pre-dedupe stage gathers the bytes, so it always runs
     // owned_out: the library allocates the output itself, sized to what the local pre-dedupe leaves (the caller cannot know that
     // number in advance; one record per window instance would be 150 GB at 100 M reads), and hands the block out (*owned_out)
     std::vector<uint64_t *> masks;
     uint64_t nwin = 0;
-    if (int rc = mark_windows(ctx, K, masks, &nwin)) return rc;
+    if (int rc = mark_windows(ctx, K, masks, &nwin, /*temp_masks=*/true, min_len)) return rc;
     uint64_t nrec = mode == SMX_MODE_ALL ? 2 * nwin : nwin;
     if (!owned_out && nrec > capacity) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "record buffer too small: need %llu", (unsigned long long)nrec);
     // Local pre-dedupe first ("optional local sort-unique per destination to cut volume by ~coverage"): the
     // exchange then carries every distinct k-mer of this rank once instead of every instance.
     Rec<NW> *recs = nullptr;
     uint64_t n_dedup = 0;
-    const bool dedupe = K >= 21 && nwin > 0 && (ctx->opt_prededupe > 0 || (ctx->opt_prededupe < 0 && nwin >= (1u << 20)));
+    const bool dedupe = K >= 21 && nwin > 0 && (ctx->ext_mode || ctx->opt_prededupe > 0 || (ctx->opt_prededupe < 0 && nwin >= (1u << 20)));
+    if (ctx->ext_mode && nwin > 0 && !dedupe) return fail(ctx, SMX_INVALID_PARAMETER, "K=%u has no pre-dedupe stage to gather extension bytes in", K);
     if (dedupe) {
         ReadSel sel;
         sel.masks = &masks;
@@ -1092,6 +1095,7 @@ int run_extract_partition(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsign
     HIPCHK(hipMemsetAsync(hist, 0, (size_t)world * 8, ctx->stream));
     PassArgs a{};
     a.K = K;
+    a.ext = (dedupe && ctx->ext_mode) ? 1u : 0u;
     a.num_buckets = B;
     a.world = world;
     a.F = world;

@@ -110,6 +110,31 @@ class GpuEngine:
         _chk(h, self.ctx.lib.smx_graph_shard_info(h, C.byref(nk), sizes))
         return nk.value, [int(x) for x in sizes]
 
+    # -- the same shard by ONE exchange: k-mers travel with the InOutMask byte the sender's reads give them --
+    def ext_supported(self, k: int) -> bool:
+        return bool(self.ctx.lib.smx_kmers_with_masks_supported(k))
+
+    def extract_kmers_ext_owned(self, k: int, nb: int, world: int, dev):
+        counts = (C.c_uint64 * world)()
+        ptr = C.c_void_p()
+        _chk(self.ctx._h, self.ctx.lib.smx_extract_kmers_ext_owned(self.ctx._h, k, nb, world, C.byref(ptr), counts))
+        counts = [int(c) for c in counts]
+        n_words = sum(counts) * ((k + 31) // 32)
+        if n_words == 0:
+            return torch.empty(1, dtype=torch.int64, device=dev), counts
+        return torch.as_tensor(_DevView(ptr.value, n_words), device=dev), counts
+
+    def shard_from_ext(self, k: int, nb: int, world: int, rank: int, buf: torch.Tensor, n: int):
+        """-> (k-mers of the shard, their bucket sizes, extension bits set, palindromic (k+1)-mers among them)"""
+        h = self.ctx._h
+        _chk(h, self.ctx.lib.smx_graph_shard_from_ext(h, k, nb, world, rank, buf.data_ptr(), n))
+        nk = C.c_uint64()
+        sizes = (C.c_uint64 * nb)()
+        st = (C.c_uint64 * 2)()
+        _chk(h, self.ctx.lib.smx_graph_shard_info(h, C.byref(nk), sizes))
+        _chk(h, self.ctx.lib.smx_graph_shard_ext_stats(h, st))
+        return nk.value, [int(x) for x in sizes], int(st[0]), int(st[1])
+
     def shard_copy(self, kmers: torch.Tensor, masks: torch.Tensor):
         _chk(self.ctx._h, self.ctx.lib.smx_graph_shard_copy(self.ctx._h, kmers.data_ptr(), masks.data_ptr()))
 
@@ -235,40 +260,68 @@ def _gather_shards(engine, mine: torch.Tensor, n_mine: int, per_rank, unit: int,
     return full
 
 
-def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev, coverage: bool = False):
-    """Construction on `world` ranks (collective), owner-side mask fill:
+def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev, coverage: bool = False, route: str = "auto"):
+    """Construction on `world` ranks (collective), owner-side masks. Two routes to the owner's shard of
+    {k-mer file, InOutMask bytes}:
+      route "ext" (taken by "auto" where the k-mer record has 8 spare bits): every rank extracts the canonical k-mers of ITS reads, each
+         with the InOutMask byte those reads give it (the (k+1)-mers around every instance), and ONE all-to-all delivers them to the
+         owners of the k-mers, which sort them and OR the bytes of the copies (smx_extract_kmers_ext_owned / smx_graph_shard_from_ext);
+      route "kpomers" (the reference's order of work):
       1. sharded count of the canonical (k+1)-mers (sharded_count): every rank owns a bucket range of that file;
       2. every rank turns its shard into extension updates (canonical k-mer, InOutMask bit), grouped by the owner of the K-MER, and
          a second all-to-all delivers them: the mask fill never sees more than the rank's own shard;
-      3. the owners sort/unique their k-mers and OR the bits into the mask bytes;
+      3. the owners sort/unique their k-mers and OR the bits into the mask bytes.
+    Then, either way:
       4. the compact structure {k-mer file, masks} (bucket-major, so rank order IS file order) is gathered and every rank derives the
          same unitigs and link records from it (unitig walks cross owners at every step).
     No rank holds the whole (k+1)-mer file — unless coverage (-c) is asked for: the counters of the coverage pass are keyed by
-    (k+1)-mer, so the file is gathered for that pass only; each rank counts its own reads and the raw edge coverages are
-    all-reduced (SUM mod 2^32). Every rank ends with the same graph; rank 0 normally writes it. Returns the engine's graph info."""
+    (k+1)-mer, so the file is counted (sharded) and gathered for that pass only; each rank counts its own reads and the raw edge
+    coverages are all-reduced (SUM mod 2^32). Every rank ends with the same graph; rank 0 normally writes it. Returns the engine's
+    graph info."""
     K1, nb = k + 1, 10 * threads
     nw = (K1 + 31) // 32
-    res = sharded_count(engine, K1, nb, rank, world, dev)
-    n_kpo = res["distinct"]
-    kpo_sizes = res["bucket_sizes"]
-    kpo_mine = engine.result_tensor(n_kpo * nw, dev) if coverage else None  # the count result is consumed by the next steps
-    # 2. extension updates -> owners of the k-mers
-    upd = engine.alloc(2 * n_kpo * (nw + 1), dev)
-    ucounts = engine.shard_updates(k, nb, world, upd, 2 * n_kpo)
-    recv, n_recv = _exchange(engine, upd, ucounts, nw + 1, rank, world, dev)
-    del upd
-    # 3. owner side
-    n_kmers, ksizes = engine.shard_build(k, nb, world, rank, recv, n_recv)
-    del recv
+    ext = route != "kpomers" and hasattr(engine, "shard_from_ext") and engine.ext_supported(k)
+    if route == "ext" and not ext:
+        raise ValueError(f"k={k}: the one-exchange route needs 8 spare bits in the k-mer record")
+    n_kpo, kpo_sizes, kpo_mine, bits, pals = 0, [0] * nb, None, 0, 0
+    if coverage or not ext:
+        res = sharded_count(engine, K1, nb, rank, world, dev)
+        n_kpo = res["distinct"]
+        kpo_sizes = res["bucket_sizes"]
+        kpo_mine = engine.result_tensor(n_kpo * nw, dev) if coverage else None  # the count result is consumed by the next steps
+    if ext:
+        send, counts = engine.extract_kmers_ext_owned(k, nb, world, dev)
+        recv, n_recv = _exchange(engine, send, counts, nw, rank, world, dev, pool=True)
+        del send
+        if hasattr(engine, "extract_release"):
+            engine.extract_release()
+        n_kmers, ksizes, bits, pals = engine.shard_from_ext(k, nb, world, rank, recv, n_recv)
+        del recv
+    else:
+        # 2. extension updates -> owners of the k-mers
+        upd = engine.alloc(2 * n_kpo * (nw + 1), dev)
+        ucounts = engine.shard_updates(k, nb, world, upd, 2 * n_kpo)
+        recv, n_recv = _exchange(engine, upd, ucounts, nw + 1, rank, world, dev)
+        del upd
+        # 3. owner side
+        n_kmers, ksizes = engine.shard_build(k, nb, world, rank, recv, n_recv)
+        del recv
     # 4. gather {k-mers, masks}
-    me = torch.tensor([n_kmers, n_kpo] + ksizes + kpo_sizes, dtype=torch.int64, device=dev)
+    me = torch.tensor([n_kmers, n_kpo, bits, pals] + ksizes + kpo_sizes, dtype=torch.int64, device=dev)
     every = [torch.empty_like(me) for _ in range(world)]
     dist.all_gather(every, me)
     every = [e.tolist() for e in every]
     kmers_per_rank = [int(e[0]) for e in every]
     kpo_per_rank = [int(e[1]) for e in every]
-    g_ksizes = [sum(int(e[2 + b]) for e in every) for b in range(nb)]
-    g_psizes = [sum(int(e[2 + nb + b]) for e in every) for b in range(nb)]
+    g_ksizes = [sum(int(e[4 + b]) for e in every) for b in range(nb)]
+    g_psizes = [sum(int(e[4 + nb + b]) for e in every) for b in range(nb)]
+    if ext:  # every non-palindromic (k+1)-mer set two extension bits somewhere in the graph, a palindromic one a single bit
+        tot = sum(int(e[2]) + int(e[3]) for e in every)
+        assert tot % 2 == 0, "odd number of extension bits over all shards"
+        n_kpo_all = tot // 2
+        assert not coverage or n_kpo_all == sum(kpo_per_rank), "the masks and the (k+1)-mer count disagree"
+    else:
+        n_kpo_all = sum(kpo_per_rank)
     my_k = engine.alloc(n_kmers * nw, dev)
     my_m = engine.alloc_bytes(n_kmers, dev)
     engine.shard_copy(my_k, my_m)
@@ -277,7 +330,7 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
     del my_k, my_m
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()
-    info = engine.build_graph_from_kmers(k, nb, full_k, full_m, sum(kmers_per_rank), g_ksizes, sum(kpo_per_rank))
+    info = engine.build_graph_from_kmers(k, nb, full_k, full_m, sum(kmers_per_rank), g_ksizes, n_kpo_all)
     del full_k, full_m
     if coverage:
         full_p = _gather_shards(engine, kpo_mine, n_kpo, kpo_per_rank, nw, rank, world, dev, engine.alloc)
@@ -291,6 +344,7 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
         cov = (cov & 0xFFFFFFFF).to("cpu")
         cov = torch.where(cov >= 2 ** 31, cov - 2 ** 32, cov).to(torch.int32)  # uint32 bit pattern
         engine.set_raw_coverage(cov)
+    info["route"] = "ext" if ext else "kpomers"
     info["kpomers_per_rank"] = kpo_per_rank
     info["kmers_per_rank"] = kmers_per_rank
     return info

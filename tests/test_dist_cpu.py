@@ -163,6 +163,54 @@ class OracleGraphEngine(OracleEngine):
             sizes[key[0]] += 1
         return len(keys), sizes
 
+    # -- the one-exchange route: k-mers travel with the InOutMask byte the sender's reads give them (EXT layout: last word =
+    #    k-mer bits << 8 | byte) --
+    def ext_supported(self, k):
+        nw = (k + 31) // 32
+        return k >= 21 and 2 * k + 8 <= 64 * nw
+
+    def extract_kmers_ext_owned(self, k, nb, world, dev):
+        from oracle import oracle
+        g = oracle.build_graph(self.reads, k, nb)  # k-mers and masks of THIS rank's reads
+        nwk = (k + 31) // 32
+        rec = np.array(g["kmers"], dtype=np.uint64).reshape(-1, nwk).copy()
+        owner = np.array([oracle.bucket(r, k, nb) * world // nb for r in rec], dtype=np.int64)
+        rec[:, nwk - 1] = (rec[:, nwk - 1] << np.uint64(8)) | np.asarray(g["masks"], dtype=np.uint64)
+        order = np.argsort(owner, kind="stable")
+        self.ext_sent = len(rec)
+        flat = rec[order].reshape(-1).view(np.int64)
+        return torch.from_numpy(flat.copy()) if len(flat) else torch.empty(1, dtype=torch.int64), [int((owner == r).sum()) for r in range(world)]
+
+    def shard_from_ext(self, k, nb, world, rank, buf, n):
+        from oracle import oracle
+        tr = str.maketrans("ACGT", "TGCA")
+        nwk = (k + 31) // 32
+        rec = buf[:n * nwk].numpy().view(np.uint64).reshape(n, nwk).copy()
+        byte = (rec[:, nwk - 1] & np.uint64(0xFF)).astype(np.uint8)
+        rec[:, nwk - 1] >>= np.uint64(8)
+        masks = {}
+        for r, m in zip(rec, byte):
+            key = (oracle.bucket(r, k, nb),) + tuple(int(v) for v in r)
+            masks[key] = masks.get(key, 0) | int(m)
+        keys = sorted(masks)
+        lo, hi = (rank * nb + world - 1) // world, ((rank + 1) * nb + world - 1) // world
+        assert all(lo <= key[0] < hi for key in keys)  # only k-mers of the rank's own buckets arrive
+        self.shard_kmers = np.array([key[1:] for key in keys], dtype=np.uint64).reshape(-1, nwk)
+        self.shard_masks = np.array([masks[key] for key in keys], dtype=np.uint8)
+        self.shard_updates_seen = n
+        sizes = [0] * nb
+        bits = pals = 0
+        for key in keys:
+            sizes[key[0]] += 1
+            m = masks[key]
+            x = oracle.kmer_to_string(np.array(key[1:], dtype=np.uint64), k)
+            for c in range(4):
+                for e, on in ((x + "ACGT"[c], m >> c & 1), ("ACGT"[c] + x, m >> (4 + c) & 1)):
+                    if on:
+                        bits += 1
+                        pals += e == e[::-1].translate(tr)
+        return len(keys), sizes, bits, pals
+
     def shard_copy(self, kmers, masks):
         kmers[:self.shard_kmers.size] = torch.from_numpy(self.shard_kmers.reshape(-1).view(np.int64).copy())
         masks[:self.shard_masks.size] = torch.from_numpy(self.shard_masks.copy())
@@ -208,7 +256,7 @@ class OracleGraphEngine(OracleEngine):
         self.cov = cov.numpy().astype(np.uint32)
 
 
-def _graph_worker(rank, world, port, k, threads, q):
+def _graph_worker(rank, world, port, k, threads, q, route="kpomers", coverage=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -217,9 +265,10 @@ def _graph_worker(rank, world, port, k, threads, q):
     smx_dist.XCHG_LIMIT = 700  # several broadcast rounds per owner
     reads = read_lines("reads_small.txt")[:120]
     eng = OracleGraphEngine(reads[rank::world], reads)
-    info = smx_dist.sharded_build_graph(eng, k, threads, rank, world, torch.device("cpu"), coverage=True)
-    q.put((rank, eng.gathered.tobytes(), eng.cov.tobytes(), info["kpomers_per_rank"], eng.g["gfa"], len(eng.result), eng.shard_updates_seen,
-           info["kmers_per_rank"]))
+    info = smx_dist.sharded_build_graph(eng, k, threads, rank, world, torch.device("cpu"), coverage=coverage, route=route)
+    assert info["route"] == route
+    q.put((rank, eng.gathered.tobytes() if coverage else b"", eng.cov.tobytes() if coverage else b"", info["kpomers_per_rank"], eng.g["gfa"],
+           len(eng.result) if hasattr(eng, "result") else 0, eng.shard_updates_seen, info["kmers_per_rank"], getattr(eng, "ext_sent", 0)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -240,10 +289,40 @@ def test_sharded_build_graph_world2_gloo():
     reads = read_lines("reads_small.txt")[:120]
     ref, _ = oracle.count(reads, k + 1, "B", 10 * threads)
     kc = np.array([int(l.split("KC:i:")[1]) for l in got[0][4].splitlines() if l.startswith("S\t")], dtype=np.uint32)
-    for rank, gathered, cov, per_rank, _, n_shard, n_upd, kmers_per_rank in got:
+    for rank, gathered, cov, per_rank, _, n_shard, n_upd, kmers_per_rank, _ in got:
         assert gathered == ref.tobytes()  # (for -c only) every rank holds the reference's (k+1)-mer file
         assert sum(per_rank) == len(ref)
         assert n_shard == per_rank[rank] < len(ref)  # the mask fill of a rank started from ITS shard of the (k+1)-mer file ...
         assert (np.frombuffer(cov, dtype=np.uint32) == kc).all()  # all-reduced sharded coverage == reference KC tags
     assert sum(g[6] for g in got) == 2 * len(ref)  # ... and every (k+1)-mer sent exactly two extension updates
     assert all(0 < c for c in got[0][7])  # both ranks own a part of the k-mer file (its assembly is asserted inside the engine)
+
+
+@pytest.mark.parametrize("k,coverage,world", [(21, False, 2), (21, True, 2), (33, False, 3)])
+def test_sharded_build_graph_one_exchange_gloo(k, coverage, world):
+    """route "ext": every rank sends the canonical k-mers of ITS reads with the InOutMask byte those reads give them; the owners OR
+    the bytes. The engine asserts (build_graph_from_kmers) that the gathered structure is the reference's k-mer file and masks and
+    that the (k+1)-mer count derived from the mask bits is the reference's; -c adds the sharded (k+1)-mer count for the coverage pass."""
+    from oracle import oracle
+    threads = 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, k, threads, q, "ext", coverage)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    reads = read_lines("reads_small.txt")[:120]
+    g = oracle.build_graph(reads, k, 10 * threads, coverage=True)
+    assert all(x[4] == g["gfa"] for x in got)
+    assert sum(got[0][7]) == len(g["kmers"]) and all(0 < c for c in got[0][7])  # the owners' shards add up to the k-mer file
+    assert sum(x[6] for x in got) == sum(x[8] for x in got)                      # every record sent arrived at exactly one owner
+    assert sum(x[8] for x in got) > len(g["kmers"])                              # (k-mers shared by the ranks' reads travel once per rank)
+    if coverage:
+        ref, _ = oracle.count(reads, k + 1, "B", 10 * threads)
+        kc = np.array([int(l.split("KC:i:")[1]) for l in got[0][4].splitlines() if l.startswith("S\t")], dtype=np.uint32)
+        for x in got:
+            assert x[1] == ref.tobytes() and (np.frombuffer(x[2], dtype=np.uint32) == kc).all()

@@ -67,10 +67,11 @@ def test_sharded_build_graph_single_rank_nccl(tmp_path):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         reads = [r for r in read_lines("reads_small.txt") if r]
-        for k, t in ((21, 3), (55, 1)):
+        for k, t, route in ((21, 3, "kpomers"), (55, 1, "kpomers"), (21, 3, "ext"), (55, 1, "ext")):
             gb = GraphBuilder(k, t)
             gb.push_back_reads(reads)
-            info = smx_dist.sharded_build_graph(smx_dist.GpuEngine(gb.ctx, "B"), k, t, 0, 1, dev, coverage=True)
+            info = smx_dist.sharded_build_graph(smx_dist.GpuEngine(gb.ctx, "B"), k, t, 0, 1, dev, coverage=True, route=route)
+            assert info["route"] == route
             gb.adopt(info)
             out = os.path.join(str(tmp_path), f"g{k}.gfa")
             gb.write_gfa(out)
@@ -211,4 +212,67 @@ def test_two_rank_sharded_mask_fill_through_the_c_abi(k, t, tmp_path):
         out = os.path.join(str(tmp_path), f"s{r}.gfa")
         gb.write_gfa(out)
         assert open(out).read() == want
+        gb.ctx.close()
+
+
+@pytest.mark.parametrize("k,t", [(21, 1), (21, 3), (33, 1), (55, 3)])
+def test_two_rank_one_exchange_through_the_c_abi(k, t, tmp_path):
+    """Route "ext" of sharded_build_graph replayed in one process on one GPU (two contexts = two ranks, the all-to-all replaced by
+    tensor copies): k-mers of each rank's reads with the InOutMask byte those reads give them -> owners -> bytes ORed -> gathered
+    compact structure -> graph on BOTH ranks. The gathered structure must be the single-GPU k-mer file and masks, the (k+1)-mer
+    count derived from the mask bits the single-GPU one, the GFA the single-GPU GFA."""
+    import torch
+    from spades_amd import dist as smx_dist
+    from spades_amd.gbuilder import GraphBuilder
+    dev = torch.device("cuda", 0)
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    world, nb = 2, 10 * t
+    nw = (k + 31) // 32
+    gbs = [GraphBuilder(k, t) for _ in range(world)]
+    engs = []
+    for r, gb in enumerate(gbs):
+        gb.push_back_reads(reads[r::world])
+        engs.append(smx_dist.GpuEngine(gb.ctx, "B"))
+        assert engs[-1].ext_supported(k)
+    sends, counts = [], []
+    for e in engs:
+        view, c = e.extract_kmers_ext_owned(k, nb, world, dev)
+        sends.append(view.clone())  # (the view is the library's buffer)
+        counts.append(c)
+        e.extract_release()
+    shards, ksizes, bits, pals = [], [], 0, 0
+    for r, e in enumerate(engs):  # "all-to-all": rank r receives segment r of every sender
+        segs = []
+        for s_ in range(world):
+            a = sum(counts[s_][:r]) * nw
+            segs.append(sends[s_][a:a + counts[s_][r] * nw])
+        n = sum(counts[s_][r] for s_ in range(world))
+        recv = e.alloc_recv(n * nw, dev)  # the library's exchange buffer: consumed by shard_from_ext
+        recv[:n * nw].copy_(torch.cat(segs))
+        nk, sz, b_, p_ = e.shard_from_ext(k, nb, world, r, recv, n)
+        km, mk = e.alloc(nk * nw, dev), e.alloc_bytes(nk, dev)
+        e.shard_copy(km, mk)
+        shards.append((km[:nk * nw], mk[:nk], nk))
+        ksizes.append(sz)
+        bits += b_
+        pals += p_
+    full_k = torch.cat([s_[0] for s_ in shards])
+    full_m = torch.cat([s_[1] for s_ in shards])
+    n_k = sum(s_[2] for s_ in shards)
+    g_ks = [sum(z[b] for z in ksizes) for b in range(nb)]
+    ref = GraphBuilder(k, t)
+    ref.push_back_reads(reads)
+    ref.build()
+    rk, rm = ref.kmers()
+    assert n_k == len(rk) and (full_k.cpu().numpy().view(np.uint64).reshape(-1, nw) == rk).all() and (full_m.cpu().numpy() == rm).all()
+    assert (bits + pals) % 2 == 0 and (bits + pals) // 2 == ref.info()["n_kpomers"]
+    want = os.path.join(str(tmp_path), "ref.gfa")
+    ref.write_gfa(want)
+    ref.ctx.close()
+    for r, (gb, e) in enumerate(zip(gbs, engs)):
+        info = e.build_graph_from_kmers(k, nb, full_k, full_m, n_k, g_ks, (bits + pals) // 2)
+        gb.adopt(info)
+        out = os.path.join(str(tmp_path), f"g{r}.gfa")
+        gb.write_gfa(out)
+        assert open(out).read() == open(want).read()
         gb.ctx.close()

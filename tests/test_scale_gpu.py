@@ -60,6 +60,11 @@ def test_gfa_equals_spades_gbuilder(case, tmp_path, batches):
     gb = GraphBuilder(g["k"], g["effective_threads"], ctx)
     gb.reads.push_back_ascii(bases, off)
     info = gb.build()
+    # which of the two construction routes ran: k-mers + masks from one count of the reads where the k-mer record has
+    # 8 spare bits (k = 21, 33, 55 here), the (k+1)-mer file first when the k-mer file is asked for in bucket ranges
+    took_ext = any(n == "kmers:ext_merge" for n, _ in ctx.timings())
+    nw = (g["k"] + 31) // 32
+    assert took_ext == (batches == 0 and g["k"] >= 21 and 2 * g["k"] + 8 <= 64 * nw)
     out = str(tmp_path / "g.gfa")
     gb.write_gfa(out)
     assert info["n_unitigs"] == g["gfa_S_lines"]

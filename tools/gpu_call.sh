@@ -14,7 +14,7 @@ for step in "$@"; do
     benchq2g) SMX_ARENA_CHUNK_MB=2048 timeout 1500 python bench.py --no-cpu-baseline --extra-kmercount 0 > gpurun_out/$tag/benchq2g.json 2> gpurun_out/$tag/benchq2g.err; tail -3 gpurun_out/$tag/benchq2g.err ;;
     benchq64) SMX_ARENA_CHUNK_MB=64 timeout 1500 python bench.py --no-cpu-baseline --extra-kmercount 0 > gpurun_out/$tag/benchq64.json 2> gpurun_out/$tag/benchq64.err; tail -3 gpurun_out/$tag/benchq64.err ;;
     shard100) SMX_DEBUG=1 timeout 900 python bench.py --gpus 1 --force-sharded --steps 2 --warmup 1 2>&1 | grep -v "big leaf\|^\[smx\] \(skm_scan\|dedupe\)" | tail -40 ;;
-    tdist) timeout 900 python -m pytest tests/test_dist_gpu.py tests/test_cli_gpu.py -m gpu -x -q 2>&1 | tail -8 ;;
+    tdist) timeout 900 python -m pytest tests/test_dist_gpu.py tests/test_cli_gpu.py -m gpu -x -q > gpurun_out/$tag/tdist.txt 2>&1; grep -v "^  File" gpurun_out/$tag/tdist.txt | tail -40 ;;
     text) timeout 900 python -m pytest tests/test_ext_route_gpu.py -m gpu -x -q > gpurun_out/$tag/text.txt 2>&1; grep -v "^  File" gpurun_out/$tag/text.txt | tail -40 ;;
     tgraph) timeout 900 python -m pytest tests/test_graph_gpu.py tests/test_prededupe_gpu.py tests/test_count_gpu.py -m gpu -x -q 2>&1 | tail -15 ;;
     benchopt=*) o=${step#benchopt=}; timeout 1500 python bench.py --no-cpu-baseline --extra-kmercount 0 --steps 2 --opt $o > gpurun_out/$tag/bench_$o.json 2> gpurun_out/$tag/bench_$o.err; tail -2 gpurun_out/$tag/bench_$o.err; python tools/bench_summary.py gpurun_out/$tag/bench_$o.json ;;
