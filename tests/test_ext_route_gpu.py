@@ -140,3 +140,23 @@ def test_route_is_declined_where_it_does_not_fit(tmp_path):
         ref = oracle.build_graph(reads, k, 10)
         r = _build(reads, k, 1, tmp_path, FORCE)
         assert not r["took_ext_route"] and r["gfa"] == ref["gfa"]
+
+
+def test_several_read_chunks(tmp_path):
+    """reads submitted in several calls are separate device chunks: the neighbour bases of a k-mer never come from another chunk"""
+    from oracle import oracle
+    from spades_amd.gbuilder import GraphBuilder
+    k = 33
+    reads = _synth(5, 3000, 1200, 150)
+    ref = oracle.build_graph(reads, k, 20)
+    gb = GraphBuilder(k, 2)
+    for key, v in FORCE.items():
+        gb.ctx.set_option(key, v)
+    for a in range(0, len(reads), 250):
+        gb.push_back_reads(reads[a:a + 250])
+    gb.build()
+    assert any(n == "kmers:ext_merge" for n, _ in gb.ctx.timings())
+    out = os.path.join(str(tmp_path), "g.gfa")
+    gb.write_gfa(out)
+    assert gb.unitigs() == ref["unitigs"] and open(out).read() == ref["gfa"]
+    gb.ctx.close()

@@ -1,5 +1,3 @@
-mkdir -p gpurun_out/c52
-bash tools/profile_bench.sh r02ext > gpurun_out/c52/prof.log 2>&1
-timeout 900 python bench.py --kpomer-route --no-cpu-baseline --extra-kmercount 0 > gpurun_out/c52/bench_kpomer_route.json 2> gpurun_out/c52/kpo.err
-timeout 900 python bench.py --gpus 1 --force-sharded --steps 3 --warmup 1 > gpurun_out/c52/bench_sharded_1rank_100M.json 2> gpurun_out/c52/sh.err
-tail -3 gpurun_out/c52/prof.log gpurun_out/c52/kpo.err gpurun_out/c52/sh.err
+mkdir -p gpurun_out/c55
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/c55/tests.txt 2>&1; echo "tests rc=$?"; grep -v "^  File" gpurun_out/c55/tests.txt | tail -6
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/c55/smoke.txt 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/c55/smoke.txt
