@@ -432,6 +432,12 @@ def main():
         # full-size parity properties of the timed result (size-independent): see tools/verify_scale.py for the complete set
         if info is not None:
             out["construct"]["checks"] = {"unitigs_plus_loops": int(info["n_unitigs"]), "perfect_loops": int(info["n_loops"])}
+            try:  # order-sensitive checksums of the device-resident graph (k-mer file, masks, packed unitigs, lengths, end nodes, link
+                # records, vertices): equal between the two construction routes on the same input (profiles/r02)
+                out["construct"]["checks"]["graph_fingerprint"] = "%032x" % (int.from_bytes(__import__("hashlib").md5(
+                    b"".join(int(v).to_bytes(8, "little") for v in gb.fingerprint())).digest(), "big"))
+            except Exception as e:  # noqa: BLE001 — a check, never the measurement
+                out["construct"]["checks"]["graph_fingerprint"] = f"unavailable: {e}"
         if not args.no_cpu_baseline and n_sample:
             hw_s = hw[:n_sample * L // 32 + 8]
 

@@ -220,6 +220,10 @@ int smx_extract_kmers_ext_owned(smx_ctx *ctx, unsigned k, unsigned num_buckets, 
 int smx_graph_shard_from_ext(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsigned world, unsigned rank, const void *d_records,
                              uint64_t n_records);
 int smx_graph_shard_ext_stats(const smx_ctx *ctx, uint64_t *stats /* [2] */);
+/* Fingerprint of the device-resident graph, for comparing two builds that are too big to leave the device: for each of the arrays
+ * k-mer file, InOutMask bytes, packed unitig words, unitig lengths, start nodes, end nodes, sorted link records, vertex starts —
+ * out[2i] = sum of the elements, out[2i+1] = sum of element * (2 * index + 1), both mod 2^64 (order-sensitive). */
+int smx_graph_fingerprint(const smx_ctx *ctx, uint64_t *out /* [16] */);
 int smx_graph_shard_info(const smx_ctx *ctx, uint64_t *n_kmers, uint64_t *bucket_sizes /* [num_buckets] or NULL */);
 int smx_graph_shard_copy(const smx_ctx *ctx, void *d_kmers, void *d_masks);
 int smx_build_graph_from_kmers(smx_ctx *ctx, unsigned k, unsigned num_buckets, const void *d_kmers, const void *d_masks, uint64_t n_kmers,

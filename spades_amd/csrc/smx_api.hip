@@ -744,6 +744,39 @@ int smx_graph_shard_from_ext(smx_ctx *ctx, unsigned k, unsigned num_buckets, uns
     return finish_call(ctx, rc, true);
 }
 
+int smx_graph_fingerprint(const smx_ctx *cctx, uint64_t *out) {
+    smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
+    if (!ctx || !out) return SMX_INVALID_PARAMETER;
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph");
+    if (ctx->g_nkmers == 0) return SMX_OK;
+    if (!ctx->g_dev_valid) return fail(ctx, SMX_INVALID_PARAMETER, "the graph is not resident on the device");
+    HIPCHK(hipSetDevice(ctx->device));
+    unsigned long long *d;
+    if (int rc = dalloc(ctx, &d, 16)) return rc;
+    HIPCHK(hipMemsetAsync(d, 0, 128, ctx->stream));
+    auto run64 = [&](const void *p, uint64_t n, int slot) {
+        if (p && n) hipLaunchKernelGGL((k_fingerprint<unsigned long long>), dim3(grid_for(n)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)p, n, d + 2 * slot);
+    };
+    run64(ctx->g_kmers, ctx->g_nkmers * ctx->g_nw, 0);
+    hipLaunchKernelGGL((k_fingerprint<uint8_t>), dim3(grid_for(ctx->g_nkmers)), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, ctx->g_nkmers, d + 2);
+    run64(ctx->g_uwords, ctx->g_nuwords, 2);
+    run64(ctx->g_elen, ctx->g_ne, 3);
+    run64(ctx->g_estart, ctx->g_ne, 4);
+    run64(ctx->g_eend, ctx->g_ne, 5);
+    if (ctx->g_links_dev) {
+        run64(ctx->g_lrecs, ctx->g_nlrec * 2, 6);
+        run64(ctx->g_vstart, ctx->g_nv, 7);
+    }
+    HIPCHK(hipGetLastError());
+    unsigned long long h[16];
+    HIPCHK(hipMemcpyAsync(h, d, 128, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_temps(ctx);
+    for (int i = 0; i < 16; ++i) out[i] = h[i];
+    return SMX_OK;
+}
+
 int smx_graph_shard_ext_stats(const smx_ctx *ctx, uint64_t *stats) {
     if (!ctx || !stats) return SMX_INVALID_PARAMETER;
     stats[0] = ctx->g_ext_bits;

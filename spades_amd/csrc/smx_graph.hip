@@ -317,6 +317,26 @@ __global__ void k_tab_masks(const node_t *tab, uint64_t D0, uint8_t *mask) {
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x)
         mask[r] = (uint8_t)(tab_out4(tab[2 * r]) | brev8(tab_out4(tab[2 * r + 1])));
 }
+// position-weighted checksum of an array of 64-bit words (or bytes): sum of value * (2 * index + 1) mod 2^64 and the plain sum — a
+// fingerprint of the device graph for comparing two builds that are too big to leave the device (smx_graph_fingerprint)
+template <typename T>
+__global__ void __launch_bounds__(BLK) k_fingerprint(const T *a, uint64_t n, unsigned long long *out) {
+    unsigned long long s0 = 0, s1 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        const unsigned long long v = (unsigned long long)a[i];
+        s0 += v;
+        s1 += v * (2ull * i + 1ull);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_down(s0, o, 64);
+        s1 += __shfl_down(s1, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], s0);
+        atomicAdd(&out[1], s1);
+    }
+}
+
 // ---- k-mer file + InOutMask bytes straight from a count in the EXT layout (smx_device.hpp) -------------------------------------------
 // The sorted records hold (k-mer << 8 | byte) in their last word; copies of a k-mer whose bytes differ (survivors of cut minimizer
 // partitions) sit next to each other. A head is the first record of a k-mer; its byte is the OR over its copies.

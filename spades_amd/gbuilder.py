@@ -51,6 +51,13 @@ class GraphBuilder:
         self._info.update(n_links=info[5])
         return self._info
 
+    def fingerprint(self):
+        """order-sensitive checksums of the device-resident graph arrays (smx_graph_fingerprint): k-mer file, masks, packed unitigs,
+        unitig lengths, start / end nodes, link records, vertex starts — (sum, position-weighted sum) each"""
+        out = (C.c_uint64 * 16)()
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_fingerprint(self.ctx._h, out))
+        return [int(v) for v in out]
+
     def tip_stats(self):
         """(k-mers isolated, tips removed) by the early tip clipper and (A/T edges, A/T tip k-mers) by the early A/T remover of the
         last build (options early_tip_bound, early_at_remover)."""

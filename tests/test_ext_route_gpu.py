@@ -28,12 +28,13 @@ def _build(reads, k, threads, tmp_path, opts, coverage=False):
     gb.push_back_reads(reads)
     gb.build()
     took = any(n == "kmers:ext_merge" for n, _ in gb.ctx.timings())
+    fp = gb.fingerprint()  # checksums of the device-resident graph arrays (what bench.py compares between the routes at full size)
     if coverage:
         gb.fill_coverage()
     out = os.path.join(str(tmp_path), "g.gfa")
     gb.write_gfa(out)
     info = dict(gb.info())
-    res = dict(info=info, gfa=open(out).read(), unitigs=gb.unitigs(), kmers=gb.kmers(), took_ext_route=took)
+    res = dict(info=info, gfa=open(out).read(), unitigs=gb.unitigs(), kmers=gb.kmers(), took_ext_route=took, fp=fp)
     gb.ctx.close()
     return res
 
@@ -54,6 +55,7 @@ def test_gfa_matches_spades_gbuilder(case, tmp_path):
     old = _build(reads, case["K"], case["threads"], tmp_path, LEGACY)
     assert not old["took_ext_route"]
     assert _same_kmers(r, old)
+    assert r["fp"] == old["fp"] and any(r["fp"])
     assert r["info"] == old["info"]  # incl. the number of canonical (k+1)-mers, here derived from the mask bits
 
 
@@ -105,7 +107,7 @@ def test_vs_oracle_seeded(k, tmp_path):
         assert r["took_ext_route"]
         assert r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"]
         old = _build(reads, k, threads, tmp_path, LEGACY)
-        assert _same_kmers(r, old) and r["info"] == old["info"]
+        assert _same_kmers(r, old) and r["info"] == old["info"] and r["fp"] == old["fp"]
 
 
 def test_coverage_vs_oracle_seeded(tmp_path):

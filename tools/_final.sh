@@ -1,3 +1,5 @@
-mkdir -p gpurun_out/c55
-timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/c55/tests.txt 2>&1; echo "tests rc=$?"; grep -v "^  File" gpurun_out/c55/tests.txt | tail -6
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/c55/smoke.txt 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/c55/smoke.txt
+mkdir -p gpurun_out/c56
+timeout 900 python -m pytest tests/test_ext_route_gpu.py -m gpu -x -q > gpurun_out/c56/text.txt 2>&1; grep -v "^  File" gpurun_out/c56/text.txt | tail -4
+timeout 900 python bench.py --no-cpu-baseline --extra-kmercount 0 > gpurun_out/c56/bench_ext.json 2> gpurun_out/c56/e1.err
+timeout 900 python bench.py --kpomer-route --no-cpu-baseline --extra-kmercount 0 > gpurun_out/c56/bench_kpo.json 2> gpurun_out/c56/e2.err
+tail -2 gpurun_out/c56/e1.err; tail -2 gpurun_out/c56/e2.err
