@@ -207,13 +207,13 @@ int build_rank_dir(smx_ctx *ctx, const void *recs, uint64_t n, const std::vector
     uint64_t mx = 0;
     for (uint32_t b = 0; b < B; ++b) mx = std::max(mx, boff[b + 1] - boff[b]);
     if (mx >= (1ull << 32)) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "a bucket of %llu records exceeds the directory's 32-bit offsets (use more buckets)", (unsigned long long)mx);
-    // slots per bucket (option "dir_slots": slots per record — more slots, more present k-mers alone in theirs, 4 B each)
-    // (measured at 4.3 G k-mers: 1 -> 2 slots per record takes the successor lookups from 340 to 284 ms and costs 9 ms more here,
-    // 4 slots cost more than they save; with the (k+1)-mer file resident next to the graph the HBM goes to that instead)
-    const uint64_t per = ctx->opt_dir_slots > 0 ? (uint64_t)std::min<int64_t>(ctx->opt_dir_slots, 8) : (ctx->g_kpo ? 1 : 2);
+    // slots per bucket: one per record on average, 8 B each (option "dir_slots": slots per record). Measured at 4.3 G k-mers with
+    // 4-byte entries without fingerprints: 1 -> 2 slots per record took the successor lookups from 340 to 284 ms for 9 ms more
+    // here, 4 slots cost more than they saved; the fingerprints settle more lookups in the same 8 B per record (smx_graph.hip).
+    const uint64_t per = ctx->opt_dir_slots > 0 ? (uint64_t)std::min<int64_t>(ctx->opt_dir_slots, 8) : 1;
     const uint64_t sb = std::min<uint64_t>(std::max<uint64_t>(1, n / B * per), 1ull << 30);
     unsigned long long *d_boff;
-    uint32_t *dir;
+    uint64_t *dir;
     if (int rc = dalloc(ctx, &d_boff, (size_t)B + 1, false)) return rc;
     ix.boff = d_boff;
     if (int rc = dalloc(ctx, &dir, (size_t)B * (sb + 1), false)) return rc;
@@ -224,7 +224,9 @@ int build_rank_dir(smx_ctx *ctx, const void *recs, uint64_t n, const std::vector
     ix.verify = ctx->opt_verify_lookups ? 1u : 0u;
     std::vector<unsigned long long> hb(boff.begin(), boff.begin() + B + 1);
     HIPCHK(hipMemcpyAsync(d_boff, hb.data(), ((size_t)B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(dir, 0, (size_t)B * (sb + 1) * 4, ctx->stream));
+    // (k_dir_fill writes every entry of a bucket that has records; only the entries of empty buckets have to be cleared)
+    for (uint32_t b = 0; b < B; ++b)
+        if (boff[b + 1] == boff[b]) HIPCHK(hipMemsetAsync(dir + (size_t)b * (sb + 1), 0, (size_t)(sb + 1) * 8, ctx->stream));
     if (n) {
         hipLaunchKernelGGL((k_dir_fill<NW>), dim3(grid_for(n)), dim3(BLK), 0, ctx->stream, recs, n, ix, dir);
         HIPCHK(hipGetLastError());

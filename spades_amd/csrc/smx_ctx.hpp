@@ -71,7 +71,7 @@ struct smx_ctx {
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
     int64_t opt_spill = -1;  // sorted runs to host memory + merge by bucket ranges: -1 when the accumulated set outgrows HBM, 1 always (tests)
     int64_t opt_verify_lookups = 0;  // 1: rank lookups of k-mers that are known to be present still compare the record
-    int64_t opt_dir_slots = -1;        // rank directory: slots per record (-1: 2, or 1 while the (k+1)-mer file is resident)
+    int64_t opt_dir_slots = -1;        // rank directory: slots per record (-1: 1)
     int64_t opt_ext_presort = 1;       // ext route: merge the survivors of cut partitions before the sort (0: after it — the general merge; tests)
     int64_t opt_ext_route = -1;        // construction: k-mers AND their extension masks from one count of the reads (-1 when it applies, 0 never, 1 = -1)
     int64_t opt_kmers_from_reads = 1;  // construction: k-mer file counted from the resident reads (0: derived from the (k+1)-mer file)
