@@ -8,6 +8,9 @@
 #include "smx_graph_host.hpp"
 
 #include <algorithm>
+#include <execinfo.h>
+#include <csignal>
+#include <unistd.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -30,7 +33,39 @@ extern "C" {
 
 const char *smx_version(void) { return "spades-mi355x 0.1 (gfx950)"; }
 
+// SMX_SEGV_TRACE=1: a native backtrace on SIGSEGV / SIGABRT (module + offset per frame; addr2line -e <module> <offset>), then the
+// default action. Diagnostics only.
+static void segv_trace(int sig) {
+    const char msg[] = "[smx] fatal signal, native frames:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int smx_create(smx_ctx **out, int device, size_t hbm_budget_bytes) {
+    static bool traced = false;
+    if (!traced && getenv("SMX_SEGV_TRACE")) {
+        traced = true;
+        {
+            void *warm[4];
+            (void)backtrace(warm, 4);  // loads the unwinder now: no allocation inside the handler
+        }
+        static char altstack[1 << 16];
+        stack_t ss{};
+        ss.ss_sp = altstack;
+        ss.ss_size = sizeof(altstack);
+        (void)sigaltstack(&ss, nullptr);
+        struct sigaction sa{};
+        sa.sa_handler = segv_trace;
+        sa.sa_flags = SA_ONSTACK | SA_NODEFER;
+        sigemptyset(&sa.sa_mask);
+        (void)sigaction(SIGSEGV, &sa, nullptr);
+        (void)sigaction(SIGABRT, &sa, nullptr);
+        (void)sigaction(SIGBUS, &sa, nullptr);
+    }
     if (!out) return SMX_INVALID_PARAMETER;
     *out = nullptr;
     int ndev = 0;

@@ -210,8 +210,9 @@ int build_rank_dir(smx_ctx *ctx, const void *recs, uint64_t n, const std::vector
     // slots per bucket: one per record on average, 8 B each (option "dir_slots": slots per record). Measured at 4.3 G k-mers with
     // 4-byte entries without fingerprints: 1 -> 2 slots per record took the successor lookups from 340 to 284 ms for 9 ms more
     // here, 4 slots cost more than they saved; the fingerprints settle more lookups in the same 8 B per record (smx_graph.hip).
-    const uint64_t per = ctx->opt_dir_slots > 0 ? (uint64_t)std::min<int64_t>(ctx->opt_dir_slots, 8) : 1;
-    const uint64_t sb = std::min<uint64_t>(std::max<uint64_t>(1, n / B * per), 1ull << 30);
+    // (next to a resident (k+1)-mer file — the second construction route at config 3 — HBM is short: one slot per two records there)
+    const uint64_t per2 = ctx->opt_dir_slots > 0 ? 2 * (uint64_t)std::min<int64_t>(ctx->opt_dir_slots, 8) : (ctx->g_kpo ? 1 : 2);  // half slots per record
+    const uint64_t sb = std::min<uint64_t>(std::max<uint64_t>(1, n / B * per2 / 2), 1ull << 30);
     unsigned long long *d_boff;
     uint64_t *dir;
     if (int rc = dalloc(ctx, &d_boff, (size_t)B + 1, false)) return rc;

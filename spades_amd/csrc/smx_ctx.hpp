@@ -1,6 +1,7 @@
 // spades_amd/csrc/smx_ctx.hpp — the context behind the C ABI: resident read chunks, result view, options, grow-only device
 // arena, temp bookkeeping, stage timers (included by smx_api.hip; one translation unit).
 #pragma once
+#include <mutex>
 
 namespace {
 
@@ -151,6 +152,30 @@ int fail(smx_ctx *c, int code, const char *fmt, ...) {
 // (adopt_result). SMX_ARENA=malloc (or a HIP runtime without the VMM calls) falls back to a cache of hipMalloc'ed blocks.
 constexpr size_t ARENA_ALIGN = 256;
 
+// Arenas of destroyed contexts wait here for the next context on the same device instead of being unmapped: tearing a range down
+// (hipMemUnmap / hipMemAddressFree) crashed inside the HIP runtime once in a few hundred context lifetimes on this stack (native
+// backtraces from smx_destroy, immediately with MALLOC_PERTURB_: the runtime touches freed host memory), and a process that makes
+// context after context — a multi-k pipeline, the tests — also saves the mapping time (~17 ms per GiB). A pooled arena keeps its
+// physical memory; it is handed to the next context whose budget class matches (no budget: any unbudgeted arena of the device).
+// SMX_ARENA_POOL=0 restores the teardown.
+struct PooledArena {
+    int device;
+    size_t budget_reserved;  // 0 = made by a context without a budget, else its reserved size
+    Arena a;
+};
+inline std::vector<PooledArena> &arena_pool() {
+    static std::vector<PooledArena> pool;
+    return pool;
+}
+inline std::mutex &arena_pool_mutex() {
+    static std::mutex m;
+    return m;
+}
+inline bool arena_pool_enabled() {
+    const char *e = getenv("SMX_ARENA_POOL");
+    return !(e && !strcmp(e, "0"));
+}
+
 bool arena_vmm_init(smx_ctx *ctx) {
     Arena &A = ctx->arena;
     if (A.tried) return A.vmm;
@@ -159,6 +184,20 @@ bool arena_vmm_init(smx_ctx *ctx) {
     if (e && !strcmp(e, "malloc")) return false;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    if (arena_pool_enabled()) {
+        const size_t g = getenv("SMX_ARENA_CHUNK_MB") ? std::max<size_t>((size_t)atoll(getenv("SMX_ARENA_CHUNK_MB")), 2) << 20 : (size_t)512 << 20;
+        const size_t want = ctx->budget ? (ctx->budget + g - 1) / g * g + g : 0;
+        std::lock_guard<std::mutex> lk(arena_pool_mutex());
+        auto &pool = arena_pool();
+        for (size_t i = 0; i < pool.size(); ++i)
+            if (pool[i].device == ctx->device && pool[i].a.gran == g && pool[i].budget_reserved == want) {
+                A = std::move(pool[i].a);
+                pool.erase(pool.begin() + i);
+                A.tried = A.vmm = true;
+                A.last_err.clear();
+                return true;
+            }
+    }
     // Every physical chunk has the same size: on this stack hipMemSetAccess rejects a mapping whose size differs from its
     // neighbour's in many combinations (tools/vmm_probe.hip: 2 MiB, 6 MiB, 64 MiB or 1 GiB chunks back to back all work, mixed
     // sizes fail with "invalid argument"), and the reported granularity (4 KiB) says nothing about it.
@@ -367,6 +406,16 @@ void arena_release(smx_ctx *ctx) {
     if (A.vmm) {
         if (!A.live.empty()) return;
         (void)hipDeviceSynchronize();
+        if (arena_pool_enabled()) {
+            // (a budgeted context whose reserved size was cut by the free memory of its day does not match its class: torn down below)
+            const size_t cls = ctx->budget ? (ctx->budget + A.gran - 1) / A.gran * A.gran + A.gran : 0;
+            if (cls == 0 || cls == A.reserved) {
+                std::lock_guard<std::mutex> lk(arena_pool_mutex());
+                arena_pool().push_back(PooledArena{ctx->device, cls, std::move(A)});
+                A = Arena();
+                return;
+            }
+        }
         for (size_t ci = 0; ci < A.chunk.size(); ++ci)
             if (A.chunk[ci].mapped) {
                 (void)hipMemUnmap(A.base + ci * A.gran, A.gran);
