@@ -275,7 +275,7 @@ int run_count(smx_ctx *ctx, unsigned K, int mode, unsigned B, const void *d_recs
     a.hist = histA;
     HIPCHK(hipMemsetAsync(histA, 0, (size_t)F1 * 8, ctx->stream));
     // records source: level-1 histogram fused with the level-2 one (LDS table of F1*F2 counters)
-    const bool joint = !from_reads && !lv.empty() && (uint64_t)F1 * lv[0] <= 24 * 1024 && F1 <= 256 && ctx->opt_joint_hist != 0;
+    const bool joint = !from_reads && !lv.empty() && (uint64_t)F1 * lv[0] <= 36 * 1024 && F1 <= 256 && ctx->opt_joint_hist != 0;
     unsigned long long *histJ = nullptr;
     tbegin(ctx, "l1_hist");
     if (from_reads) {
