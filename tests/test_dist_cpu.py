@@ -326,3 +326,13 @@ def test_sharded_build_graph_one_exchange_gloo(k, coverage, world):
         kc = np.array([int(l.split("KC:i:")[1]) for l in got[0][4].splitlines() if l.startswith("S\t")], dtype=np.uint32)
         for x in got:
             assert x[1] == ref.tobytes() and (np.frombuffer(x[2], dtype=np.uint32) == kc).all()
+
+
+def test_one_exchange_route_is_refused_where_the_record_has_no_room():
+    """route "ext" asked for a k whose k-mer record has no 8 spare bits: an error before anything is exchanged ("auto" takes the
+    (k+1)-mer route there)"""
+    from spades_amd import dist as smx_dist
+    eng = OracleGraphEngine(["ACGT" * 40], ["ACGT" * 40])
+    assert not eng.ext_supported(31) and not eng.ext_supported(63) and eng.ext_supported(21) and eng.ext_supported(55)
+    with pytest.raises(ValueError):
+        smx_dist.sharded_build_graph(eng, 31, 1, 0, 1, torch.device("cpu"), route="ext")
