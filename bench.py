@@ -359,17 +359,26 @@ def main():
     # correction: profiles/r02/config3_pmc_hbm_traffic.csv, taken at the commit named in profiles/r02/README.md). Only valid for the
     # workload it was taken on; a constant of that measurement, not of this run.
     pmc = os.path.join(ROOT, "profiles", "r02", "config3_ext_pmc_hbm_traffic.csv" if ext_route else "config3_pmc_hbm_traffic.csv")
-    pmc_rows = {}
+    pmc_rows, pmc_split = {}, None
     if not sharded and not args.count_only and n_reads == 100_000_000 and k == 55 and T == 16 and os.path.exists(pmc):
         for line in open(pmc):
             f = line.strip().rsplit(",", 5)  # kernel names hold commas (template arguments)
             if len(f) >= 6 and f[0] not in ("kernel", "TOTAL"):
+                if "k_fingerprint" in f[0]:  # the check of the result, not the step
+                    continue
                 try:
                     pmc_rows[f[0]] = float(f[3]) + float(f[5])
                 except ValueError:
                     pass
-        roof_count["traffic"] = round(sum(pmc_rows.values()), 1) if pmc_rows else None
-        roof_count["traffic_unit"] = "GB per step over ALL kernels of the step (PMC, profiles/r02; see README there for the commit)"
+        # the kernels of the construction proper; everything else in the table belongs to the counting pipeline (the link-record sort of
+        # the construction runs on the pipeline's kernels too: ~5 % of their records, counted with the count here)
+        con_kernels = ("k_dir_fill", "k_tab_from_masks", "k_fill_tab", "k_tab_masks", "k_cand_", "k_walk_", "k_keep", "k_link_keys", "k_vertex_",
+                       "k_loop_", "k_derive_", "k_succ", "k_tip_", "k_at_", "k_gather_kmers")
+        con_traffic = sum(v for n_, v in pmc_rows.items() if any(c in n_ for c in con_kernels))
+        pmc_split = {"count": round(sum(pmc_rows.values()) - con_traffic, 1), "construct": round(con_traffic, 1)} if pmc_rows else None
+        roof_count["traffic"] = pmc_split["count"] if pmc_split else None
+        roof_count["traffic_unit"] = ("GB per step, HBM fetch (x2 gfx950 correction) + write of the counting pipeline's kernels (PMC passes of "
+                                      "profiles/r02, see README there for the commit); whole step: %.1f GB" % sum(pmc_rows.values()))
 
     out = {
         "metric": f"M reads/sec k-mer-counted (k={k}, PE150)",
@@ -406,7 +415,8 @@ def main():
         out["construct"] = {"n_kpomers": int(D1), "n_kmers": int(D0), "n_unitigs": int(ne), "n_vertices": int(info["n_vertices"]),
                             "unitig_bases": int(nbases),
                             "roofline": {"bound": "hbm", "achieved": round(b_con / max(construct_ms, 1e-9) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
-                                         "frac": round(b_con / max(construct_ms, 1e-9) / 1e6 / 8000.0, 4), "traffic": None,
+                                         "frac": round(b_con / max(construct_ms, 1e-9) / 1e6 / 8000.0, 4),
+                                         "traffic": pmc_split["construct"] if pmc_rows else None,
                                          "kernel": ("construction (rank directory, successor table, walks, link records)" if ext_route else
                                                     "construction (k-mer file, rank directory, masks + successors, walks, link records)") + ": sum of its stage kernels",
                                          "algorithmic_bytes_per_step": int(b_con), "kernel_ms_per_step": round(construct_ms, 3)}}
