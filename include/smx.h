@@ -70,7 +70,10 @@ const char *smx_version(void);
  *   0: always the (k+1)-mer file first, as the reference does), "ext_presort" (0: copies of a k-mer from cut partitions are merged
  *   after the sort instead of before it), "kmers_from_reads" (0: the k-mer file of the second route is derived from the (k+1)-mer
  *   file, not counted from the reads), "dir_slots" (rank directory: slots per record, 1..8; -1 = 2, or 1 next to a resident
- *   (k+1)-mer file).
+ *   (k+1)-mer file), "pm_route" (-1 / 1: where "ext_route" applies and no early clipper is asked for, the construction does not sort
+ *   the k-mers at all — nodes are numbered by minimizer partition, only the junction k-mers are put into k-mer-file order to number
+ *   the unitigs, and the sorted k-mer file is made the first time smx_copy_final_kmers / smx_bucket_sizes / smx_graph_copy_kmers ask
+ *   for it; 0: the k-mers are sorted first, as in the reference).
  * SMX_OPTS="key=value,..." in the environment applies options to every new context.
  *
  * HBM budget (smx_create): the context never holds more device memory than hbm_budget_bytes (0 = what the device has). A count whose
@@ -181,7 +184,8 @@ unsigned smx_rank_first_bucket(unsigned num_buckets, unsigned world, unsigned ra
  *   FastGraphFromSequencesConstructor::ConstructGraph (same file :506-567).
  * num_buckets = 10 * nthreads of the reference run being reproduced (kmer_extension_index_builder.hpp:75): the GFA
  * of spades-gbuilder depends on it (SURVEY.md finding 3). k odd, 1 <= k < 128 (projects/spades_tools/gbuilder.cpp:130-135).
- * After the call smx_copy_final_kmers()/smx_bucket_sizes() describe the canonical k-mer file. */
+ * After the call smx_copy_final_kmers()/smx_bucket_sizes() describe the canonical k-mer file (made at that moment when the
+ * construction did not need it: option "pm_route"). Node ids (smx_host_write_graph's start_node / end_node) are opaque. */
 int smx_build_graph(smx_ctx *ctx, unsigned k, unsigned num_buckets);
 /* Multi-GPU construction ("replicated lookup"; precedent: hpcspades/mpi/stages/construction_mpi.cpp:343-354,
  * count per node + merge): the same steps on a canonical (k+1)-mer file that the caller gathered from its owner ranks
@@ -224,6 +228,12 @@ int smx_graph_shard_ext_stats(const smx_ctx *ctx, uint64_t *stats /* [2] */);
  * k-mer file, InOutMask bytes, packed unitig words, unitig lengths, start nodes, end nodes, sorted link records, vertex starts —
  * out[2i] = sum of the elements, out[2i+1] = sum of element * (2 * index + 1), both mod 2^64 (order-sensitive). */
 int smx_graph_fingerprint(const smx_ctx *ctx, uint64_t *out /* [16] */);
+/* The part of it that does not depend on how the k-mers are numbered (k-mer indices never reach the output,
+ * debruijn_graph_constructor.hpp:540-547; the construction route "pm_route" numbers them by minimizer partition): packed unitig words,
+ * unitig lengths, self-conjugate flags (same sums as above), and the link structure as the writers see it — out[6] = sum of the
+ * EdgeAndMask words of all link records, out[7] = sum of word * (2 * (64 * vertex + place) + 1), vertices in id order, records of a
+ * vertex in their sorted order. Equal between the construction routes on the same input (needs the link records on the device). */
+int smx_graph_fingerprint_portable(const smx_ctx *ctx, uint64_t *out /* [8] */);
 int smx_graph_shard_info(const smx_ctx *ctx, uint64_t *n_kmers, uint64_t *bucket_sizes /* [num_buckets] or NULL */);
 int smx_graph_shard_copy(const smx_ctx *ctx, void *d_kmers, void *d_masks);
 int smx_build_graph_from_kmers(smx_ctx *ctx, unsigned k, unsigned num_buckets, const void *d_kmers, const void *d_masks, uint64_t n_kmers,

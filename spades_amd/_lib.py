@@ -82,6 +82,7 @@ def load():
         "smx_graph_shard_from_ext": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, C.c_uint64]),
         "smx_graph_shard_ext_stats": (C.c_int, [vp, u64p]),
         "smx_graph_fingerprint": (C.c_int, [vp, u64p]),
+        "smx_graph_fingerprint_portable": (C.c_int, [vp, u64p]),
         "smx_count_records": (C.c_int, [vp, C.c_uint, C.c_uint, vp, C.c_uint64]),
         "smx_rank_first_bucket": (C.c_uint, [C.c_uint, C.c_uint, C.c_uint]),
         "smx_last_timings": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),

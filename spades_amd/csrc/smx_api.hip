@@ -5,6 +5,7 @@
 #include "smx_superkmer.hip"
 #include "smx_ingest.hip"
 #include "smx_graph.hip"
+#include "smx_pm.hip"
 #include "smx_graph_host.hpp"
 
 #include <algorithm>
@@ -27,6 +28,7 @@ using namespace smx;
 #include "smx_ctx.hpp"
 #include "smx_pipeline.hpp"
 #include "smx_construct.hpp"
+#include "smx_pm.hpp"
 
 // ============================================================================ C ABI
 extern "C" {
@@ -136,6 +138,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "spill")) ctx->opt_spill = value;
     else if (!strcmp(key, "kmers_from_reads")) ctx->opt_kmers_from_reads = value;
     else if (!strcmp(key, "ext_route")) ctx->opt_ext_route = value;
+    else if (!strcmp(key, "pm_route")) ctx->opt_pm_route = value;
     else if (!strcmp(key, "dir_slots")) ctx->opt_dir_slots = value;
     else if (!strcmp(key, "ext_presort")) ctx->opt_ext_presort = value;
     else return fail(ctx, SMX_INVALID_PARAMETER, "unknown option %s", key);
@@ -452,6 +455,7 @@ int smx_count_info(const smx_ctx *ctx, uint64_t *n_records, unsigned *words_per_
 
 int smx_bucket_sizes(const smx_ctx *ctx, uint64_t *sizes) {
     if (!ctx || !sizes) return SMX_INVALID_PARAMETER;
+    if (int rc = ensure_kmer_file(const_cast<smx_ctx *>(ctx))) return rc;  // (a graph built without a sorted k-mer file: made now)
     for (unsigned b = 0; b < ctx->num_buckets; ++b) sizes[b] = ctx->bucket_off[b + 1] - ctx->bucket_off[b];
     return SMX_OK;
 }
@@ -459,6 +463,7 @@ int smx_bucket_sizes(const smx_ctx *ctx, uint64_t *sizes) {
 int smx_copy_bucket(const smx_ctx *cctx, unsigned bucket, void *host_dst) {
     smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
     if (!ctx || !host_dst) return SMX_INVALID_PARAMETER;
+    if (int rc = ensure_kmer_file(ctx)) return rc;
     if (bucket >= ctx->num_buckets) return fail(ctx, SMX_INVALID_PARAMETER, "bucket %u out of range", bucket);
     const uint64_t o = ctx->bucket_off[bucket], n = ctx->bucket_off[bucket + 1] - o;
     if (n == 0) return SMX_OK;
@@ -484,6 +489,7 @@ int smx_copy_final_kmers(const smx_ctx *cctx, void *host_dst) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     if (ctx->n_records == 0) return SMX_OK;
     if (!host_dst) return SMX_INVALID_PARAMETER;
+    if (int rc = ensure_kmer_file(ctx)) return rc;
     if (ctx->result_on_host) {
         char *dst = (char *)host_dst;
         for (auto &c : ctx->h_result) {
@@ -500,6 +506,7 @@ int smx_copy_final_kmers(const smx_ctx *cctx, void *host_dst) {
 int smx_write_final_kmers(const smx_ctx *cctx, const char *path) {
     smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
+    if (int rc = ensure_kmer_file(ctx)) return rc;
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
     if (ctx->result_on_host) {
@@ -556,7 +563,10 @@ int smx_write_final_kmers(const smx_ctx *cctx, const char *path) {
     return rc;
 }
 
-const void *smx_device_kmers(const smx_ctx *ctx) { return ctx ? ctx->d_result : nullptr; }
+const void *smx_device_kmers(const smx_ctx *ctx) {
+    if (!ctx || ensure_kmer_file(const_cast<smx_ctx *>(ctx))) return nullptr;
+    return ctx->d_result;
+}
 
 unsigned smx_rank_first_bucket(unsigned num_buckets, unsigned world, unsigned rank) {
     return (unsigned)(((uint64_t)rank * num_buckets + world - 1) / world);
@@ -786,6 +796,8 @@ int smx_graph_fingerprint(const smx_ctx *cctx, uint64_t *out) {
     if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph");
     if (ctx->g_nkmers == 0) return SMX_OK;
     if (!ctx->g_dev_valid) return fail(ctx, SMX_INVALID_PARAMETER, "the graph is not resident on the device");
+    if (ctx->g_pm) return fail(ctx, SMX_INVALID_PARAMETER, "this graph was built without a sorted k-mer file (partition-major route): its k-mer and node arrays "
+                                                           "are numbered differently; compare builds with smx_graph_fingerprint_portable");
     HIPCHK(hipSetDevice(ctx->device));
     unsigned long long *d;
     if (int rc = dalloc(ctx, &d, 16)) return rc;
@@ -812,6 +824,34 @@ int smx_graph_fingerprint(const smx_ctx *cctx, uint64_t *out) {
     return SMX_OK;
 }
 
+int smx_graph_fingerprint_portable(const smx_ctx *cctx, uint64_t *out) {
+    smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
+    if (!ctx || !out) return SMX_INVALID_PARAMETER;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph");
+    if (ctx->g_nkmers == 0) return SMX_OK;
+    if (!ctx->g_dev_valid || !ctx->g_links_dev) return fail(ctx, SMX_INVALID_PARAMETER, "the graph (with its link records) is not resident on the device");
+    HIPCHK(hipSetDevice(ctx->device));
+    unsigned long long *d;
+    if (int rc = dalloc(ctx, &d, 8)) return rc;
+    HIPCHK(hipMemsetAsync(d, 0, 64, ctx->stream));
+    if (ctx->g_nuwords) hipLaunchKernelGGL((k_fingerprint<unsigned long long>), dim3(grid_for(ctx->g_nuwords)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)ctx->g_uwords, ctx->g_nuwords, d);
+    if (ctx->g_ne) {
+        hipLaunchKernelGGL((k_fingerprint<unsigned long long>), dim3(grid_for(ctx->g_ne)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)ctx->g_elen, ctx->g_ne, d + 2);
+        hipLaunchKernelGGL((k_fingerprint<uint8_t>), dim3(grid_for(ctx->g_ne)), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_eself, ctx->g_ne, d + 4);
+    }
+    if (ctx->g_nv)
+        hipLaunchKernelGGL(k_pm_link_fingerprint, dim3(grid_for(ctx->g_nv)), dim3(BLK), 0, ctx->stream, (const Rec<2> *)ctx->g_lrecs, ctx->g_nlrec,
+                           (const unsigned long long *)ctx->g_vstart, ctx->g_nv, d + 6);
+    HIPCHK(hipGetLastError());
+    unsigned long long h[8];
+    HIPCHK(hipMemcpyAsync(h, d, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_temps(ctx);
+    for (int i = 0; i < 8; ++i) out[i] = h[i];
+    return SMX_OK;
+}
+
 int smx_graph_shard_ext_stats(const smx_ctx *ctx, uint64_t *stats) {
     if (!ctx || !stats) return SMX_INVALID_PARAMETER;
     stats[0] = ctx->g_ext_bits;
@@ -832,6 +872,7 @@ int smx_graph_shard_copy(const smx_ctx *cctx, void *d_kmers, void *d_masks) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     if (ctx->g_nkmers == 0) return SMX_OK;
     if (!d_kmers || !d_masks) return SMX_INVALID_PARAMETER;
+    if (int rc = ensure_kmer_file(ctx)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(d_kmers, ctx->g_kmers, ctx->g_nkmers * ctx->g_nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_masks, ctx->g_mask, ctx->g_nkmers, hipMemcpyDeviceToDevice, ctx->stream));
@@ -890,6 +931,7 @@ int smx_copy_kmers_device(const smx_ctx *cctx, void *d_dst) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     if (ctx->n_records == 0) return SMX_OK;
     if (!d_dst) return SMX_INVALID_PARAMETER;
+    if (int rc = ensure_kmer_file(ctx)) return rc;
     if (ctx->result_on_host) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the result was spilled to host memory (it does not fit the HBM budget)");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(d_dst, ctx->d_result, ctx->n_records * ctx->nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -925,6 +967,7 @@ int smx_graph_copy_kmers(const smx_ctx *cctx, void *kmers_host, uint8_t *masks_h
     if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->g_nkmers == 0) return SMX_OK;
+    if (int rc = ensure_kmer_file(ctx)) return rc;
     if (kmers_host) HIPCHK(hipMemcpy(kmers_host, ctx->g_kmers, ctx->g_nkmers * ctx->g_nw * 8, hipMemcpyDeviceToHost));
     if (masks_host) HIPCHK(hipMemcpy(masks_host, ctx->g_mask, ctx->g_nkmers, hipMemcpyDeviceToHost));
     return SMX_OK;

@@ -8,6 +8,11 @@
 // debruijn_graph_constructor.hpp:399-406,506-567).
 #pragma once
 
+void pm_release(smx_ctx *ctx);  // smx_pm.hpp
+template <int NW>
+int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt);
+inline uint32_t pm_host_bucket(const uint64_t *w, int nw, uint32_t B);
+
 void drop_device_graph(smx_ctx *ctx) {
     arena_put(ctx, ctx->g_uwords);
     arena_put(ctx, ctx->g_eoffw);
@@ -49,6 +54,8 @@ void clear_graph(smx_ctx *ctx) {
     arena_put(ctx, ctx->g_mask);
     drop_rank_dir(ctx, ctx->g_dir_kmers);
     drop_device_graph(ctx);
+    pm_release(ctx);
+    ctx->g_pm = false;
     ctx->g_kmers = nullptr;
     ctx->g_mask = nullptr;
     ctx->g_nkpo = ctx->g_nkmers = 0;
@@ -595,8 +602,10 @@ int upload_graph(smx_ctx *ctx) {
 
 // Everything after the extension masks: early clippers (options), node table of the final masks, start de-edges, walks, perfect
 // loops, link records + vertices. tab: 2 * D0 + 2 entries; tab_valid: k_fill_tab has already filled it for the current masks.
+// pm: the partition-major route (smx_pm.hpp) — g_kmers holds EXT records in the dedupe stage's order, tab is filled, walks cross chunks by
+// jump words, and the start de-edges are numbered through the sorted junction k-mers.
 template <int NW>
-int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint32_t *d_err, WallTrace &gwt, bool present = false) {
+int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint32_t *d_err, WallTrace &gwt, bool present = false, const PmWalk *pm = nullptr) {
     const uint64_t D0 = ctx->g_nkmers;
     const unsigned grid = grid_for(2 * D0);
     const smx::RankDir ixk = ctx->g_dir_kmers;
@@ -717,13 +726,20 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
     // ---- 4. start de-edges -----------------------------------------------------------------------
     const uint64_t ntiles = (D0 + CAND_TILE - 1) / CAND_TILE;
     unsigned long long *tcnt, *toff, *counters;  // counters: [0] spare, [1] non-junction k-mers on kept paths, [2..3] loop k-mers, [4..] junction k-mers
+    unsigned long long *tjcnt = nullptr, *tjoff = nullptr;  // pm: junction k-mers per tile
     if (int rc = dalloc(ctx, &tcnt, ntiles)) return rc;
     if (int rc = dalloc(ctx, &toff, ntiles + 1)) return rc;
     if (int rc = dalloc(ctx, &counters, 4 + CAND_NJ)) return rc;
+    if (pm) {
+        if (int rc = dalloc(ctx, &tjcnt, ntiles)) return rc;
+        if (int rc = dalloc(ctx, &tjoff, ntiles + 1)) return rc;
+    }
     HIPCHK(hipMemsetAsync(counters, 0, (4 + CAND_NJ) * 8, ctx->stream));
     tbegin(ctx, "candidates");
-    hipLaunchKernelGGL(k_cand_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, tcnt, counters + 4);
+    hipLaunchKernelGGL(k_cand_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, tcnt, counters + 4, tjcnt);
     HIPCHK(hipGetLastError());
+    if (pm)
+        if (int rc = scan_u64(ctx, tjcnt, tjoff, ntiles)) return rc;
     if (int rc = scan_u64(ctx, tcnt, toff, ntiles)) return rc;
     unsigned long long C = 0, n_junction = 0, h_nj[CAND_NJ];
     HIPCHK(hipMemcpyAsync(&C, toff + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -748,18 +764,88 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         if (int rc = dalloc(ctx, &last, C)) return rc;
         if (int rc = dalloc(ctx, &flags, C)) return rc;
         const unsigned cgrid = grid_for(C);
-        hipLaunchKernelGGL(k_cand_expand, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask,
-                           (const unsigned long long *)toff, D0, cand);
-        HIPCHK(hipGetLastError());
+        unsigned long long *qidx = nullptr, *vq = nullptr;  // pm: number of every start de-edge in the reference's order; words << 1 | keep there
+        if (!pm) {
+            hipLaunchKernelGGL(k_cand_expand, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask,
+                               (const unsigned long long *)toff, D0, cand);
+            HIPCHK(hipGetLastError());
+        } else {
+            // The reference visits the junction k-mers in k-mer-file order (AddStartDeEdges, debruijn_graph_constructor.hpp:203-226): they
+            // alone — n_junction of D0 k-mers — go through the sort pipeline (EXT records: the byte gives every k-mer its number of start
+            // de-edges), and the de-edges of a k-mer are numbered from the prefix sum at its place in that file.
+            const uint64_t nj = n_junction;
+            if (int rc = dalloc(ctx, &qidx, C)) return rc;
+            if (int rc = dalloc(ctx, &vq, C)) return rc;
+            Rec<NW> *jrecs, *jk;
+            uint8_t *jm;
+            unsigned long long *jstats, *jcnt, *candoff;
+            if (int rc = dalloc(ctx, &jrecs, nj + 1)) return rc;
+            tbegin(ctx, "junctions");
+            hipLaunchKernelGGL((k_pm_junc_write<NW>), dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const void *)ctx->g_kmers,
+                               (const unsigned long long *)tjoff, D0, (void *)jrecs);
+            HIPCHK(hipGetLastError());
+            tend(ctx);
+            {
+                Prefix pf(ctx, "jsort:");
+                ctx->ext_mode = true;
+                const int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, ctx->g_B, jrecs, nj, nullptr, /*recs_reusable=*/true, false, /*distinct_hint=*/true);
+                ctx->ext_mode = false;
+                if (rc) return rc;
+            }
+            const Rec<NW> *jsorted = (const Rec<NW> *)ctx->d_result_buf;
+            const std::vector<uint64_t> jboff = ctx->bucket_off;
+            const uint64_t nj2 = ctx->n_records;
+            ctx->d_result_buf = ctx->d_result = nullptr;  // stays in the temp list
+            ctx->n_records = 0;
+            if (nj2 != nj) return fail(ctx, SMX_DEVICE_ERROR, "junction k-mers: %llu after the sort, %llu before", (unsigned long long)nj2, (unsigned long long)nj);
+            if (int rc = dalloc(ctx, &jk, nj + 1)) return rc;
+            if (int rc = dalloc(ctx, &jm, nj + 16)) return rc;
+            if (int rc = dalloc(ctx, &jstats, 3)) return rc;
+            if (int rc = dalloc(ctx, &jcnt, nj + 1)) return rc;
+            if (int rc = dalloc(ctx, &candoff, nj + 2)) return rc;
+            HIPCHK(hipMemsetAsync(jstats, 0, 24, ctx->stream));
+            tbegin(ctx, "junction_order");
+            hipLaunchKernelGGL((k_ext_split<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jsorted, nj, k, (void *)jk, jm, jstats);
+            HIPCHK(hipGetLastError());
+            smx::RankDir jix{};
+            if (int rc = build_rank_dir<NW>(ctx, jk, nj, jboff, ctx->g_B, k, jix)) return rc;
+            hipLaunchKernelGGL(k_pm_cand_counts, dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const uint8_t *)jm, nj, jcnt);
+            if (int rc = scan_u64(ctx, jcnt, candoff, nj)) {
+                drop_rank_dir(ctx, jix);
+                return rc;
+            }
+            hipLaunchKernelGGL((k_pm_cand_expand<NW>), dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const void *)ctx->g_kmers,
+                               (const unsigned long long *)toff, D0, (const void *)jk, jix, (const unsigned long long *)candoff, cand, qidx, d_err);
+            unsigned long long ctot = 0;
+            hipError_t e1 = hipGetLastError();
+            if (e1 == hipSuccess) e1 = hipMemcpyAsync(&ctot, candoff + nj, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+            tend(ctx);
+            drop_rank_dir(ctx, jix);
+            if (e1 != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "numbering the start de-edges failed: %s", hipGetErrorString(e1));
+            if (ctot != C) return fail(ctx, SMX_DEVICE_ERROR, "start de-edges: %llu by the sorted junction k-mers, %llu by the masks", ctot, C);
+        }
         tbegin(ctx, "walk_len");
-        hipLaunchKernelGGL((k_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const node_t *)tab, k, ixk, (uint64_t)(2 * D0), len, first, last, d_err);
+        if (pm)
+            hipLaunchKernelGGL((k_pm_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C, pm->ix, (const node_t *)tab,
+                               pm->jmp, k, (uint64_t)(2 * D0), len, first, last, d_err);
+        else
+            hipLaunchKernelGGL((k_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
+                               (const void *)ctx->g_kmers, (const node_t *)tab, k, ixk, (uint64_t)(2 * D0), len, first, last, d_err);
         HIPCHK(hipGetLastError());
         tend(ctx);
         tbegin(ctx, "keep");
-        hipLaunchKernelGGL((k_keep<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len,
-                           (const node_t *)first, (const node_t *)last, flags, kw, one, counters + 1);
+        if (pm) {
+            hipLaunchKernelGGL((k_pm_keep<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (const unsigned long long *)qidx, (uint64_t)C,
+                               (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len, (const node_t *)first, (const node_t *)last,
+                               flags, vq, counters + 1);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_pm_unpack, dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)vq, (uint64_t)C, kw, one);  // kw / one: indexed by q
+        } else {
+            hipLaunchKernelGGL((k_keep<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
+                               (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len,
+                               (const node_t *)first, (const node_t *)last, flags, kw, one, counters + 1);
+        }
         HIPCHK(hipGetLastError());
         // word offsets and edge indices of the kept paths (scans in place: kw -> woff, one -> eidx)
         if (int rc = scan_u64(ctx, kw, kw, C)) return rc;
@@ -780,10 +866,16 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         if (int rc = dalloc(ctx, &ctx->g_eself, nkept + 1, false)) return rc;
         HIPCHK(hipMemsetAsync(ctx->g_uwords + ktotalw, 0, 64, ctx->stream));
         tbegin(ctx, "walk_write");
-        hipLaunchKernelGGL((k_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
-                           (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len,
-                           (const node_t *)first, (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw,
-                           (const unsigned long long *)one, ctx->g_uwords, ctx->g_eoffw, ctx->g_elen, ctx->g_estart, ctx->g_eend, ctx->g_eself);
+        if (pm)
+            hipLaunchKernelGGL((k_pm_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (const unsigned long long *)qidx,
+                               (uint64_t)C, (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len, (const node_t *)first,
+                               (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw, (const unsigned long long *)one, ctx->g_uwords,
+                               ctx->g_eoffw, ctx->g_elen, ctx->g_estart, ctx->g_eend, ctx->g_eself);
+        else
+            hipLaunchKernelGGL((k_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
+                               (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len,
+                               (const node_t *)first, (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw,
+                               (const unsigned long long *)one, ctx->g_uwords, ctx->g_eoffw, ctx->g_elen, ctx->g_estart, ctx->g_eend, ctx->g_eself);
         HIPCHK(hipGetLastError());
         tend(ctx);
     } else {
@@ -837,12 +929,26 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             if (int rc = d2h(ctx, hk, lk, (size_t)nloopk * NW)) return rc;
             std::vector<uint8_t> hmask;
             if (int rc = d2h(ctx, hmask, lm, (size_t)nloopk)) return rc;
+            std::vector<uint64_t> order(nloopk);
+            for (uint64_t i = 0; i < nloopk; ++i) order[i] = i;
+            if (pm) {  // EXT records in partition-major order: drop the byte, then k-mer-file order = (bucket, words) on the host
+                for (uint64_t i = 0; i < nloopk; ++i) hk[(size_t)i * NW + NW - 1] >>= smx::EXT_BITS;
+                std::vector<uint32_t> bk(nloopk);
+                for (uint64_t i = 0; i < nloopk; ++i) bk[i] = pm_host_bucket(&hk[(size_t)i * NW], NW, ctx->g_B);
+                std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+                    if (bk[a] != bk[b]) return bk[a] < bk[b];
+                    for (int w = 0; w < NW; ++w)
+                        if (hk[(size_t)a * NW + w] != hk[(size_t)b * NW + w]) return hk[(size_t)a * NW + w] < hk[(size_t)b * NW + w];
+                    return false;
+                });
+            }
             std::vector<smxh::LoopNode> nodes(nloopk);
-            for (uint64_t i = 0; i < nloopk; ++i) {
-                nodes[i].rank = ranks[i];
-                nodes[i].kmer.resize(k);
-                for (unsigned j = 0; j < k; ++j) nodes[i].kmer[j] = "ACGT"[(hk[(size_t)i * NW + (j >> 5)] >> ((j & 31) << 1)) & 3];
-                nodes[i].mask = hmask[i];
+            for (uint64_t t = 0; t < nloopk; ++t) {
+                const uint64_t i = order[t];
+                nodes[t].rank = ranks[i];
+                nodes[t].kmer.resize(k);
+                for (unsigned j = 0; j < k; ++j) nodes[t].kmer[j] = "ACGT"[(hk[(size_t)i * NW + (j >> 5)] >> ((j & 31) << 1)) & 3];
+                nodes[t].mask = hmask[i];
             }
             smxh::LoopCollector lc(nodes, k);
             std::vector<std::string> loops;
@@ -979,7 +1085,13 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
     };
     // ---- 0. k-mers and masks from one count of the reads, when that applies ---------------------
     if (!kpo_recs) {
-        int rc;
+        int rc = pm_route<NW>(ctx, k, B, gwt);  // no sorted k-mer file at all where that applies (smx_pm.hpp)
+        if (rc != SMX_ROUTE_NA) return rc;
+        ctx->g_k = k;  // (a route that gave up cleared the graph state)
+        ctx->g_nw = NW;
+        ctx->g_B = B;
+        ctx->gh.k = k;
+        ctx->gh.eoff.assign(1, 0);
         {
             Prefix pf(ctx, "kmers:");
             rc = kmer_file_with_masks<NW>(ctx, k, B);

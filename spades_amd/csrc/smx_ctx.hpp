@@ -36,6 +36,20 @@ struct Arena {  // one virtual range, physically backed up to `mapped`
     std::string last_err;                                                     // why the last growth failed
 };
 
+// Partition-major construction route (smx_pm.hip / smx_pm.hpp): side arrays the dedupe stage leaves next to its records, and the
+// sorted tail of the k-mers of cut partitions.
+struct PmState {
+    bool active = false;  // the dedupe stage in flight writes partition-major output (set by the route, like smx_ctx::ext_mode)
+    unsigned long long *pinfo = nullptr, *cinfo = nullptr;
+    uint32_t *meta = nullptr, *overflow = nullptr;
+    uint8_t *mask = nullptr;
+    uint32_t max_chunks = 0, nchunks = 0, T = 0, nkey = 0;
+    unsigned m = 0, w = 0, pshift = 0;
+    uint64_t nclean = 0, ndirty = 0;
+    void *dk = nullptr;  // the k-mers of the dirty region without their bytes (sorted: what its rank directory indexes)
+    smx::RankDir ddir{};
+};
+
 struct smx_ctx {
     int device = 0;
     Arena arena;
@@ -54,6 +68,9 @@ struct smx_ctx {
     std::vector<HostChunk> h_result;
     bool result_on_host = false;
     uint64_t g_ext_bits = 0, g_ext_pals = 0;  // extension bits / palindromic (k+1)-mers among them in the k-mer file or shard built from EXT records
+    PmState pm;               // partition-major construction route
+    bool g_pm = false;        // g_kmers holds EXT records in partition-major order (no sorted k-mer file yet: made on demand)
+    int64_t opt_pm_route = -1;  // construction without the sort of the k-mers: -1 where it applies, 0 never, 1 = -1
     bool ext_mode = false;    // the count in flight carries extension bytes in its records (EXT layout, smx_device.hpp): set by the construction
     void *x_owned = nullptr;  // output of smx_extract_partition_owned (released by the next extract / smx_extract_release)
     void *x_recv = nullptr;   // smx_exchange_buffer: receive side of the exchange, consumed by smx_count_records
@@ -399,6 +416,19 @@ void arena_put(smx_ctx *ctx, void *p) {
     ctx->arena_live -= std::min(ctx->arena_live, sz);
     A.live.erase(it);
     arena_add_free(A, off, sz);
+}
+// a live block gives its tail back (a result buffer sized for the worst case)
+void arena_shrink(smx_ctx *ctx, void *p, size_t bytes) {
+    Arena &A = ctx->arena;
+    if (!p || !A.vmm) return;
+    auto it = A.live.find(p);
+    if (it == A.live.end()) return;
+    bytes = std::max<size_t>((bytes + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN, ARENA_ALIGN);
+    if (bytes >= it->second) return;
+    const size_t off = (size_t)((char *)p - A.base), old = it->second;
+    it->second = bytes;
+    ctx->arena_live -= std::min(ctx->arena_live, old - bytes);
+    arena_add_free(A, off + bytes, old - bytes);
 }
 // give the memory back to the device (smx_destroy: every block has been returned by then)
 void arena_release(smx_ctx *ctx) {

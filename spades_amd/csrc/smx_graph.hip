@@ -864,7 +864,8 @@ constexpr int CAND_NJ = 256;  // partial junction counters
 constexpr int CAND_PER = 8;
 constexpr int CAND_TILE = BLK * CAND_PER;
 __device__ __forceinline__ unsigned cand_of_mask(unsigned m) { return mask_junction(m) ? (unsigned)(__popc(m & 15) + __popc(m >> 4)) : 0u; }
-__global__ void __launch_bounds__(BLK) k_cand_tiles(const uint8_t *mask, uint64_t D0, unsigned long long *tcnt, unsigned long long *njunction) {
+__global__ void __launch_bounds__(BLK) k_cand_tiles(const uint8_t *mask, uint64_t D0, unsigned long long *tcnt, unsigned long long *njunction,
+                                                    unsigned long long *tjcnt /* nullable: junction k-mers of every tile */) {
     __shared__ uint32_t scratch[BLK / 64 + 2];
     const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
     uint32_t c = 0, j_ = 0;
@@ -879,6 +880,7 @@ __global__ void __launch_bounds__(BLK) k_cand_tiles(const uint8_t *mask, uint64_
     block_excl_scan<uint32_t>(j_, scratch, &jt);
     if (threadIdx.x == 0) {
         tcnt[blockIdx.x] = tot;
+        if (tjcnt) tjcnt[blockIdx.x] = jt;
         if (jt) atomicAdd(&njunction[blockIdx.x & (CAND_NJ - 1)], (unsigned long long)jt);  // spread: one address takes ~88 atomics/us
     }
 }

@@ -629,23 +629,54 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     const uint32_t scap = std::min<uint32_t>(SKM_SCAP, ctx->opt_skm_scap > 0 ? (uint32_t)ctx->opt_skm_scap : cap / 8);  // ~12+ windows per slot on average
     const size_t lds = (size_t)scap * SW * 8 + (size_t)T * 4 + 514 * 4 + (size_t)cap * 4 + 512 + 512 + 16;
     const bool ext = ctx->ext_mode;  // the survivors carry their extension byte (EXT layout)
+    const bool pmode = ext && ctx->pm.active;  // ... and leave in partition-major order with their side arrays (smx_pm.hpp)
     if (ext && !ext_layout_fits(K, NW)) return fail(ctx, SMX_INVALID_PARAMETER, "K=%u leaves no room for the extension byte", K);
-    if (int rc = ext ? set_lds(ctx, k_skm_dedupe<NW, true>, lds) : set_lds(ctx, k_skm_dedupe<NW, false>, lds)) return rc;
+    if (int rc = pmode ? set_lds(ctx, k_skm_dedupe<NW, 2>, lds) : ext ? set_lds(ctx, k_skm_dedupe<NW, 1>, lds) : set_lds(ctx, k_skm_dedupe<NW, 0>, lds)) return rc;
     const uint32_t nitems = SKM_NKEY / SKM_KEYS_PER_ITEM;
+    PmOut pmo{};
+    if (pmode) {
+        PmState &P = ctx->pm;
+        // chunks: a chunk that is not the last of its item holds more than half the capacity unless a key boundary cut it short
+        const uint64_t mc = 3 * nwin / cap + 2 * (uint64_t)nitems + 1024;
+        if (mc >= (1ull << 24) || out_cap >= PM_BASE_MASK) return SMX_ROUTE_NA;  // beyond the packed (base, chunk) words
+        P.max_chunks = (uint32_t)mc;
+        P.T = T;
+        P.nkey = SKM_NKEY;
+        P.m = a.m;
+        P.w = a.w;
+        P.pshift = a.pshift;
+        if (int rc = dalloc(ctx, &P.pinfo, SKM_NKEY, false)) return rc;
+        if (int rc = dalloc(ctx, &P.meta, (size_t)P.max_chunks * (T >> 4), false)) return rc;
+        if (int rc = dalloc(ctx, &P.cinfo, P.max_chunks, false)) return rc;
+        if (int rc = dalloc(ctx, &P.mask, out_cap + 16, false)) return rc;
+        if (int rc = dalloc(ctx, &P.overflow, 1, false)) return rc;
+        HIPCHK(hipMemsetAsync(P.pinfo, 0xFF, (size_t)SKM_NKEY * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(P.overflow, 0, 4, ctx->stream));
+        pmo.pinfo = P.pinfo;
+        pmo.meta = P.meta;
+        pmo.cinfo = P.cinfo;
+        pmo.mask = P.mask;
+        pmo.max_chunks = P.max_chunks;
+        pmo.overflow = P.overflow;
+    }
     unsigned long long *prof = nullptr;
     if (getenv("SMX_DEBUG")) {
         if (int rc = dalloc(ctx, &prof, 8)) return rc;
         HIPCHK(hipMemsetAsync(prof, 0, 64, ctx->stream));
     }
     tbegin(ctx, "skm_dedupe");
-    if (ext)
-        hipLaunchKernelGGL((k_skm_dedupe<NW, true>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
+    if (pmode)
+        hipLaunchKernelGGL((k_skm_dedupe<NW, 2>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
                            (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)out_cap,
-                           (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof);
+                           (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo);
+    else if (ext)
+        hipLaunchKernelGGL((k_skm_dedupe<NW, 1>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
+                           (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)out_cap,
+                           (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo);
     else
-        hipLaunchKernelGGL((k_skm_dedupe<NW, false>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
+        hipLaunchKernelGGL((k_skm_dedupe<NW, 0>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
                            (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)out_cap,
-                           (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof);
+                           (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo);
     HIPCHK(hipGetLastError());
     tend(ctx);
     if (prof) {
@@ -657,7 +688,14 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     }
     unsigned long long nn[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(nn, ocount, 16, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t pm_over = 0;
+    if (pmode) HIPCHK(hipMemcpyAsync(&pm_over, ctx->pm.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (pmode) {  // the clean counter carries the number of chunks in its upper bits
+        ctx->pm.nchunks = (uint32_t)(nn[0] >> PM_BASE_BITS);
+        nn[0] &= PM_BASE_MASK;
+        if (pm_over) return SMX_ROUTE_NA;  // more chunks than planned for (pathological partition sizes): the caller takes the sorted route
+    }
     if (nn[0] + nn[1] > nwin) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication produced %llu records from %llu windows", nn[0] + nn[1], (unsigned long long)nwin);
     if (nn[0] > clean_cap || nn[1] > dirty_cap) return SMX_RETRY_SMALLER;
     unsigned long long n = nn[0];
@@ -689,6 +727,10 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         n += ctx->n_records;
         ctx->d_result_buf = ctx->d_result = nullptr;  // stays in the temp list
         ctx->n_records = 0;
+    }
+    if (pmode) {
+        ctx->pm.nclean = nn[0];
+        ctx->pm.ndirty = n - nn[0];
     }
     *n_out = n;
     if (getenv("SMX_DEBUG"))

@@ -1,0 +1,264 @@
+// spades_amd/csrc/smx_pm.hpp — host side of the partition-major construction route (kernels: smx_pm.hip; included by smx_api.hip
+// after smx_construct.hpp).
+//
+// Route: mark the k-mer windows of the reads that hold a (k+1)-mer -> super-k-mer pre-dedupe with extension bytes, winners in
+// partition-major order with their side arrays (run_prededupe, MODE 2) -> node table + jump words per chunk (k_pm_tab) ->
+// graph_from_masks on that numbering (smx_construct.hpp; the junction k-mers alone are sorted into the reference's k-mer-file order to
+// number the start de-edges). The sorted k-mer file itself (smx_copy_final_kmers & co. after smx_build_graph) is made on demand.
+#pragma once
+
+void pm_release(smx_ctx *ctx) {
+    PmState &P = ctx->pm;
+    arena_put(ctx, P.pinfo);
+    arena_put(ctx, P.cinfo);
+    arena_put(ctx, P.meta);
+    arena_put(ctx, P.overflow);
+    arena_put(ctx, P.mask);
+    arena_put(ctx, P.dk);
+    arena_put(ctx, (void *)P.ddir.dir);
+    arena_put(ctx, (void *)P.ddir.boff);
+    P = PmState();
+}
+
+// XXH3-64 of a k-mer record on the host (xxh3_rec of smx_device.hpp, for the handful of k-mers the host has to put into k-mer-file order)
+inline uint64_t pm_host_xxh3(const uint64_t *w, int nw) {
+    auto fold = [](uint64_t a, uint64_t b) {
+        const unsigned __int128 p = (unsigned __int128)a * b;
+        return (uint64_t)p ^ (uint64_t)(p >> 64);
+    };
+    auto rotl = [](uint64_t v, int r) { return (v << r) | (v >> (64 - r)); };
+    auto aval = [](uint64_t h) {
+        h ^= h >> 37;
+        h *= SMX_XXH_MX1;
+        h ^= h >> 32;
+        return h;
+    };
+    if (nw == 1) {
+        uint64_t h = rotl(w[0], 32) ^ SMX_XXH_BITFLIP8;
+        h ^= rotl(h, 49) ^ rotl(h, 24);
+        h *= SMX_XXH_MX2;
+        h ^= (h >> 35) + 8;
+        h *= SMX_XXH_MX2;
+        return h ^ (h >> 28);
+    }
+    if (nw == 2) {
+        const uint64_t lo = w[0] ^ SMX_XXH_BITFLIP16A, hi = w[1] ^ SMX_XXH_BITFLIP16B;
+        return aval(16 + __builtin_bswap64(lo) + hi + fold(lo, hi));
+    }
+    uint64_t acc = (uint64_t)(8 * nw) * SMX_XXH_P64_1;
+    acc += fold(w[0] ^ SMX_XXH_SEC0, w[1] ^ SMX_XXH_SEC8);
+    acc += fold(w[nw - 2] ^ SMX_XXH_SEC16, w[nw - 1] ^ SMX_XXH_SEC24);
+    return aval(acc);
+}
+inline uint32_t pm_host_bucket(const uint64_t *w, int nw, uint32_t B) {
+    return B == 1 ? 0u : (uint32_t)(((unsigned __int128)pm_host_xxh3(w, nw) * B) >> 64);
+}
+
+// 0: the graph is built; SMX_ROUTE_NA: the route does not apply to this input or did not fit (nothing left behind, the caller takes
+// another route); anything else: an error.
+template <int NW>
+int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
+    if (ctx->opt_pm_route == 0 || ctx->opt_ext_route == 0 || !ext_layout_fits(k, NW) || ctx->chunks.empty() || ctx->opt_derive_batches != 0 ||
+        ctx->opt_ext_presort == 0 || ctx->opt_early_at || ctx->opt_early_tip_bound > 0 || ctx->opt_batch_records > 0)
+        return SMX_ROUTE_NA;
+    const size_t W = sizeof(Rec<NW>);
+    auto bail = [&](int rc) {  // leave nothing behind
+        ctx->ext_mode = false;
+        ctx->pm.active = false;
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto &t : ctx->timings) {
+            (void)hipEventDestroy(t.e0);
+            (void)hipEventDestroy(t.e1);
+        }
+        ctx->timings.clear();
+        ctx->tprefix.clear();
+        free_temps(ctx);
+        clear_graph(ctx);
+        clear_result(ctx);
+        return (rc == SMX_MEMORY_LIMIT_EXCEEDED || rc == SMX_RETRY_SMALLER) ? SMX_ROUTE_NA : rc;
+    };
+    ctx->tprefix = "kmers:";
+    std::vector<uint64_t *> masks;
+    uint64_t nwin = 0;
+    tbegin(ctx, "mark_windows");
+    int rc = mark_windows(ctx, k, masks, &nwin, /*temp_masks=*/true, /*min_len=*/k + 1);
+    tend(ctx);
+    if (rc) return bail(rc);
+    if (!prededupe_applies<NW>(ctx, k, nwin)) return bail(SMX_ROUTE_NA);
+    // HBM plan. The stage: super-k-mer slots + staging (< 5 B per window, run_prededupe) next to the output buffer and its side arrays;
+    // then per distinct k-mer: record + byte + 2 node-table entries + 2 jump words + ~8 B of walk arrays and group words.
+    uint64_t out_cap = nwin;
+    {
+        const double avail = (double)arena_avail(ctx);
+        if (10.0 * (double)nwin > avail) return bail(SMX_ROUTE_NA);  // the stage alone would need batches
+        const double fit1 = (avail - 5.0 * (double)nwin) / ((double)W + 3.0);
+        const double fit2 = avail / ((double)W + 1.0 + 16.0 + 8.0 + 8.0);
+        const double fit = std::max(std::min(fit1, fit2), 1.0);
+        if (fit < (double)nwin) out_cap = (uint64_t)fit;
+    }
+    Rec<NW> *recs = nullptr;
+    uint64_t n = 0;
+    {
+        ReadSel sel;
+        sel.masks = &masks;
+        sel.nrec = nwin;
+        ctx->ext_mode = true;
+        ctx->pm.active = true;
+        rc = run_prededupe<NW>(ctx, k, sel, nwin, &recs, &n, out_cap);
+        ctx->ext_mode = false;
+        ctx->pm.active = false;
+    }
+    if (rc) return bail(rc);
+    ctx->tprefix.clear();
+    PmState &P = ctx->pm;
+    if (P.nclean + P.ndirty != n || n >= (1ull << 39)) return bail(fail(ctx, SMX_DEVICE_ERROR, "partition-major dedupe: %llu clean + %llu dirty k-mers, %llu in all",
+                                                                      (unsigned long long)P.nclean, (unsigned long long)P.ndirty, (unsigned long long)n));
+    // the stage's temporaries go; its output becomes the k-mer array of the graph (EXT records, partition-major)
+    free_temps(ctx, recs);
+    ctx->g_kmers = recs;
+    ctx->g_pm = true;
+    ctx->g_nkmers = n;
+    ctx->n_instances = nwin;
+    arena_shrink(ctx, recs, (size_t)std::max<uint64_t>(n, 1) * W);
+    arena_shrink(ctx, P.meta, (size_t)std::max<uint32_t>(P.nchunks, 1) * (P.T >> 4) * 4);
+    arena_shrink(ctx, P.cinfo, (size_t)std::max<uint32_t>(P.nchunks, 1) * 8);
+    arena_shrink(ctx, P.mask, (size_t)n + 16);
+    ctx->g_mask = P.mask;
+    P.mask = nullptr;
+    gwt.mark(ctx, "g:kmers+masks");
+    const uint64_t D0 = n;
+    if (D0 == 0) {
+        ctx->g_nkpo = 0;
+        ctx->g_host_valid = true;  // the empty graph
+        ctx->g_ready = true;
+        ctx->n_records = 0;
+        ctx->K = k;
+        ctx->nw = NW;
+        ctx->num_buckets = B;
+        ctx->bucket_off.assign(B + 1, 0);
+        return 0;
+    }
+    if (hipMemsetAsync(ctx->g_mask + D0, 0, 16, ctx->stream) != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "mask tail reset failed"));
+    // dirty region: k-mers without their bytes + rank directory (one bucket), bytes into the mask array
+    if (P.ndirty) {
+        Rec<NW> *dk;
+        if ((rc = dalloc(ctx, &dk, P.ndirty, false))) return bail(rc);
+        P.dk = dk;
+        hipLaunchKernelGGL((k_pm_dirty_split<NW>), dim3(grid_for(P.ndirty)), dim3(BLK), 0, ctx->stream, (const void *)recs, (uint64_t)P.nclean, (uint64_t)P.ndirty,
+                           (void *)dk, ctx->g_mask);
+        if (hipGetLastError() != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "k_pm_dirty_split launch failed"));
+        std::vector<uint64_t> dboff{0, P.ndirty};
+        tbegin(ctx, "rank_dir");
+        rc = build_rank_dir<NW>(ctx, dk, P.ndirty, dboff, 1, k, P.ddir);
+        tend(ctx);
+        if (rc) return bail(rc);
+    }
+    PmWalk pw{};
+    pw.ix.recs = recs;
+    pw.ix.pinfo = P.pinfo;
+    pw.ix.meta = P.meta;
+    pw.ix.T = P.T;
+    pw.ix.ngroups = P.T >> 4;
+    pw.ix.K = k;
+    pw.ix.m = P.m;
+    pw.ix.w = P.w;
+    pw.ix.pshift = P.pshift;
+    pw.ix.nclean = P.nclean;
+    pw.ix.dk = P.dk;
+    pw.ix.ddir = P.ddir;
+    uint32_t *d_err, *jmp;
+    node_t *tab;
+    unsigned long long *stats;
+    if ((rc = dalloc(ctx, &d_err, 1))) return bail(rc);
+    if ((rc = dalloc(ctx, &stats, 2))) return bail(rc);
+    if ((rc = dalloc(ctx, &tab, 2 * D0 + 2))) return bail(rc);
+    if ((rc = dalloc(ctx, &jmp, 2 * D0 + 2))) return bail(rc);
+    pw.jmp = jmp;
+    if (hipMemsetAsync(d_err, 0, 4, ctx->stream) != hipSuccess || hipMemsetAsync(stats, 0, 16, ctx->stream) != hipSuccess)
+        return bail(fail(ctx, SMX_DEVICE_ERROR, "counter reset failed"));
+    const uint32_t maxn = P.T / 2;  // winners of a chunk <= its instance capacity
+    const size_t lds = (size_t)(P.T >> 4) * 4 + (size_t)maxn * 4;
+    if ((rc = set_lds(ctx, k_pm_tab<NW>, lds))) return bail(rc);
+    tbegin(ctx, "pm_tab");
+    if (P.nchunks)
+        hipLaunchKernelGGL((k_pm_tab<NW>), dim3(std::min<uint32_t>(P.nchunks, 256 * 16)), dim3(BLK), lds, ctx->stream, pw.ix, (const unsigned long long *)P.cinfo,
+                           P.nchunks, maxn, k, tab, jmp, stats, d_err);
+    if (P.ndirty)
+        hipLaunchKernelGGL((k_pm_tab_dirty<NW>), dim3(grid_for(P.ndirty)), dim3(BLK), 0, ctx->stream, pw.ix, (uint64_t)P.ndirty, k, tab, jmp, stats, d_err);
+    tend(ctx);
+    if (hipGetLastError() != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "k_pm_tab launch failed"));
+    unsigned long long hs[2] = {0, 0};
+    if (hipMemcpyAsync(hs, stats, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return bail(fail(ctx, SMX_DEVICE_ERROR, "node table pass failed: %s", hipGetErrorString(hipGetLastError())));
+    if ((hs[0] + hs[1]) & 1) return bail(fail(ctx, SMX_DEVICE_ERROR, "odd number of extension bits (%llu + %llu palindromes)", hs[0], hs[1]));
+    ctx->g_ext_bits = hs[0];
+    ctx->g_ext_pals = hs[1];
+    ctx->g_nkpo = (hs[0] + hs[1]) / 2;
+    rc = graph_from_masks<NW>(ctx, k, tab, /*tab_valid=*/true, d_err, gwt, /*present=*/true, &pw);
+    if (rc) return bail(rc);
+    // the count-result view: the k-mer file is made when somebody asks for it (pm_materialize_file)
+    ctx->d_result = ctx->d_result_buf = nullptr;
+    ctx->n_records = D0;
+    ctx->K = k;
+    ctx->nw = NW;
+    ctx->num_buckets = B;
+    ctx->bucket_off.clear();
+    return 0;
+}
+
+// The sorted k-mer file + InOutMask bytes of a graph built by pm_route, on demand (smx_copy_final_kmers, smx_bucket_sizes,
+// smx_graph_copy_kmers, ... after smx_build_graph): the partition-major records go through the sort pipeline (they are consumed) and
+// the split pass of the sorted route. Node ids of the graph keep referring to the partition-major numbering (they are opaque).
+template <int NW>
+int pm_materialize_file(smx_ctx *ctx) {
+    if (!ctx->g_pm) return 0;
+    const unsigned k = ctx->g_k, B = ctx->g_B;
+    const uint64_t D0 = ctx->g_nkmers;
+    void *src = ctx->g_kmers;
+    uint8_t *old_mask = ctx->g_mask;
+    const uint64_t nkpo = ctx->g_nkpo;
+    ctx->g_kmers = nullptr;
+    ctx->g_mask = nullptr;
+    ctx->g_pm = false;
+    pm_release(ctx);  // no lookups on the old numbering from here on
+    arena_put(ctx, old_mask);
+    ctx->d_result = ctx->d_result_buf = nullptr;
+    ctx->ext_mode = true;
+    int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, src, D0, nullptr, /*recs_reusable=*/true, false, /*distinct_hint=*/true);
+    ctx->ext_mode = false;
+    if (rc == 0) {
+        if (ctx->d_result_buf != src) arena_put(ctx, src);
+        src = nullptr;
+        rc = ext_result_to_file<NW>(ctx, k, B, /*whole=*/true);
+    }
+    if (src) arena_put(ctx, src);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->timings) {
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    ctx->timings.clear();
+    free_temps(ctx);
+    if (rc) {
+        if (ctx->g_kmers) arena_put(ctx, ctx->g_kmers);
+        if (ctx->g_mask) arena_put(ctx, ctx->g_mask);
+        ctx->g_kmers = nullptr;
+        ctx->g_mask = nullptr;
+        ctx->d_result = ctx->d_result_buf = nullptr;
+        return rc;
+    }
+    ctx->g_nkpo = nkpo;
+    ctx->d_result = ctx->g_kmers;
+    ctx->d_result_buf = nullptr;
+    return 0;
+}
+int ensure_kmer_file(smx_ctx *ctx) {
+    if (!ctx || !ctx->g_pm) return 0;
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "hipSetDevice failed");
+    switch (ctx->g_nw) {
+        case 1: return pm_materialize_file<1>(ctx);
+        case 2: return pm_materialize_file<2>(ctx);
+        case 3: return pm_materialize_file<3>(ctx);
+        default: return pm_materialize_file<4>(ctx);
+    }
+}

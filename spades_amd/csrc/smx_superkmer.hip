@@ -377,6 +377,23 @@ __device__ __forceinline__ Rec<NW> skm_extract(const uint64_t *s, unsigned j, un
     return x;
 }
 
+// Partition-major output of the dedupe stage (MODE 2; construction route "pm", smx_pm.hip): the winners of a clean chunk leave in the
+// order of their LDS hash-table slots, and the occupancy of the table travels with them — 16 slots per group word (low half: winners
+// before the group, high half: occupancy bits) — so that the table can be probed again in HBM: slot h of chunk c holds record
+// base(c) + pre(h >> 4) + popc(occ & below(h & 15)). pinfo[partition] = base | chunk << 40 tells where the k-mers of a minimizer
+// partition went (PM_DIRTY: the partition was cut, its k-mers are in the sorted tail of the array; PM_EMPTY: it has none).
+struct PmOut {
+    unsigned long long *pinfo;  // [partitions], preset to PM_EMPTY
+    uint32_t *meta;             // [max_chunks * (T / 16)] group words
+    unsigned long long *cinfo;  // [max_chunks] base | winners << 40
+    uint8_t *mask;              // [out_cap] InOutMask byte of every clean winner, at its record's index
+    uint32_t max_chunks;
+    uint32_t *overflow;         // set when a chunk got no room in meta / cinfo
+};
+constexpr unsigned PM_BASE_BITS = 40;
+constexpr unsigned long long PM_BASE_MASK = (1ull << PM_BASE_BITS) - 1;
+constexpr unsigned long long PM_EMPTY = ~0ull, PM_DIRTY = ~0ull - 1;
+
 // One workgroup per item of SKM_KEYS_PER_ITEM consecutive minimizer keys; the item's slots are consumed in chunks of
 // whole keys holding <= cap instances (a key larger than that is cut). Per chunk: stage the slots in LDS, expand the
 // instance list (slot, offset), insert every instance into an exact hash set whose entries are 16-bit fingerprint |
@@ -386,12 +403,14 @@ __device__ __forceinline__ Rec<NW> skm_extract(const uint64_t *s, unsigned j, un
 // the extensions the (K+1)-mers around it give its k-mer (InOutMask bits in the k-mer's canonical frame: out bits 0-3 by next
 // base, in bits 4-7 by previous base; kmer_extension_index_builder.hpp:45-60, inout_mask.hpp:92-131). The table entries then are
 // 8-bit fingerprint | 8 extension bits (OR of all copies) | reference, and the survivors leave in the EXT layout (smx_device.hpp).
-template <int NW, bool EXT>
+// MODE: 0 plain, 1 EXT, 2 EXT + partition-major output (out_count then packs chunks << 40 | clean records)
+template <int NW, int MODE>
 __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__ slots, const unsigned long long *__restrict__ slot_off,
                                                     unsigned K, uint32_t nitems, uint32_t cap, uint32_t T, uint32_t scap, void *out_,
                                                     unsigned long long out_cap, unsigned long long clean_cap, unsigned long long dirty_cap, unsigned long long *out_count,
-                                                    unsigned long long *dirty_count, unsigned long long *prof) {
+                                                    unsigned long long *dirty_count, unsigned long long *prof, PmOut pm) {
     constexpr int SW = 2 * NW;
+    constexpr bool EXT = MODE >= 1, PM = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
     uint64_t *sl = lds64;
     uint32_t *tab = (uint32_t *)(sl + (size_t)scap * SW);
@@ -402,8 +421,8 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
     uint8_t *nbv = cl + 512;
     __shared__ unsigned long long koff[SKM_KEYS_PER_ITEM + 1];
     __shared__ uint32_t scr[BLK / 64 + 2];
-    __shared__ uint32_t s_take, s_nfit, s_ninst, s_wcount, s_endb;
-    __shared__ unsigned long long s_gbase;
+    __shared__ uint32_t s_take, s_nfit, s_ninst, s_wcount, s_endb, s_cid;
+    __shared__ unsigned long long s_gbase, s_kend;
     __shared__ uint32_t s_skip;  // the output buffer is full: the counters keep counting (the host sees the overflow), nothing is written
     Rec<NW> *out = (Rec<NW> *)out_;
     const unsigned lane = threadIdx.x & 63;
@@ -458,13 +477,26 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                     if (cpre[n] <= cap && (n == nst || cpre[n + 1] > cap)) s_nfit = n;
                 __syncthreads();
                 const unsigned long long x = s_cur + s_nfit;
-                if (x < s_end)
-                    for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)  // koff[t] <= x < koff[t+1], koff[t] > s_cur
-                        if (koff[t] <= x && koff[t + 1] > x && koff[t] > s_cur) s_take = (uint32_t)(koff[t] - s_cur);
+                if (on_boundary) {
+                    if (x < s_end)
+                        for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)  // koff[t] <= x < koff[t+1], koff[t] > s_cur
+                            if (koff[t] <= x && koff[t + 1] > x && koff[t] > s_cur) s_take = (uint32_t)(koff[t] - s_cur);
+                } else {  // the chunk continues a cut key: it takes the rest of THAT key only (whole keys behind it get clean chunks of their own)
+                    for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)
+                        if (koff[t] <= s_cur && koff[t + 1] > s_cur) s_kend = koff[t + 1];
+                }
                 __syncthreads();
                 if (threadIdx.x == 0) {
-                    s_endb = (x >= s_end || s_take != 0) ? 1u : 0u;  // the chunk ends with the last slot of a key
-                    if (s_take == 0) s_take = s_nfit;
+                    if (on_boundary) {
+                        s_endb = (x >= s_end || s_take != 0) ? 1u : 0u;  // the chunk ends with the last slot of a key
+                        if (s_take == 0) s_take = s_nfit;
+                    } else if (x >= s_kend) {
+                        s_take = (uint32_t)(s_kend - s_cur);
+                        s_endb = 1;
+                    } else {
+                        s_take = s_nfit;
+                        s_endb = 0;
+                    }
                     s_ninst = cpre[s_take];
                 }
             }
@@ -518,16 +550,41 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                         code = h;  // the winners are listed by their table entry
                     }
                 }
-                const unsigned long long m = __ballot(won);
-                if (m) {
-                    const int leader = __ffsll((unsigned long long)m) - 1;
-                    uint32_t base = 0;
-                    if ((int)lane == leader) base = atomicAdd(&s_wcount, (uint32_t)__popcll(m));
-                    base = __shfl(base, leader, 64);
-                    if (won) wl[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)code;
+                if constexpr (!PM) {
+                    const unsigned long long m = __ballot(won);
+                    if (m) {
+                        const int leader = __ffsll((unsigned long long)m) - 1;
+                        uint32_t base = 0;
+                        if ((int)lane == leader) base = atomicAdd(&s_wcount, (uint32_t)__popcll(m));
+                        base = __shfl(base, leader, 64);
+                        if (won) wl[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)code;
+                    }
                 }
             }
             __syncthreads();
+            // PM: the winners are listed in table-slot order; every thread owns gpt consecutive groups of 16 slots
+            const uint32_t ngroups = T >> 4, gpt = ngroups >= (uint32_t)BLK ? ngroups / BLK : 1u, g0 = threadIdx.x * gpt;
+            uint32_t occ[4] = {0, 0, 0, 0}, pre = 0;
+            if constexpr (PM) {
+                uint32_t cnt = 0;
+                if (g0 < ngroups)
+                    for (uint32_t g = 0; g < gpt; ++g) {
+                        uint32_t o = 0;
+                        for (uint32_t j = 0; j < 16; ++j)
+                            if (tab[(g0 + g) * 16 + j] != 0xFFFFFFFFu) o |= 1u << j;
+                        occ[g] = o;
+                        cnt += __popc(o);
+                    }
+                uint32_t tot;
+                pre = block_excl_scan<uint32_t>(cnt, scr, &tot);
+                if (g0 < ngroups) {
+                    uint32_t p = pre;
+                    for (uint32_t g = 0; g < gpt; ++g)
+                        for (uint32_t o = occ[g]; o; o &= o - 1) wl[p++] = (uint16_t)((g0 + g) * 16 + __ffs(o) - 1);
+                }
+                if (threadIdx.x == 0) s_wcount = tot;
+                __syncthreads();
+            }
             SKM_T(2)
             const uint32_t wcount = s_wcount;
             // A chunk of whole keys holds every copy of its k-mers: its winners are exactly distinct ("clean", front of out).
@@ -539,8 +596,19 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                 s_skip = 0;
                 if (!wcount) s_gbase = 0;
                 else if (!dirty) {
-                    s_gbase = atomicAdd(out_count, (unsigned long long)wcount);
-                    s_skip = s_gbase + wcount > clean_cap;
+                    if constexpr (PM) {
+                        const unsigned long long v = atomicAdd(out_count, (unsigned long long)wcount | (1ull << PM_BASE_BITS));
+                        s_gbase = v & PM_BASE_MASK;
+                        s_cid = (uint32_t)(v >> PM_BASE_BITS);
+                        s_skip = s_gbase + wcount > clean_cap;
+                        if (s_cid >= pm.max_chunks) {
+                            s_skip = 1;
+                            *pm.overflow = 1;
+                        }
+                    } else {
+                        s_gbase = atomicAdd(out_count, (unsigned long long)wcount);
+                        s_skip = s_gbase + wcount > clean_cap;
+                    }
                 } else {
                     const unsigned long long d = atomicAdd(dirty_count, (unsigned long long)wcount);
                     s_skip = d + wcount > dirty_cap;
@@ -548,6 +616,26 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                 }
             }
             __syncthreads();
+            if constexpr (PM) {
+                if (dirty) {  // the cut partition: its k-mers go to the sorted tail
+                    for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)
+                        if (koff[t] <= s_cur && koff[t + 1] > s_cur) pm.pinfo[(uint64_t)item * SKM_KEYS_PER_ITEM + t] = PM_DIRTY;
+                } else if (!s_skip && wcount) {
+                    const unsigned long long gb = s_gbase;
+                    const uint32_t cid = s_cid;
+                    if (g0 < ngroups) {
+                        uint32_t p = pre;
+                        for (uint32_t g = 0; g < gpt; ++g) {
+                            pm.meta[(size_t)cid * ngroups + g0 + g] = p | (occ[g] << 16);
+                            p += __popc(occ[g]);
+                        }
+                    }
+                    if (threadIdx.x == 0) pm.cinfo[cid] = gb | ((unsigned long long)wcount << PM_BASE_BITS);
+                    for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)  // the partitions that lie in this chunk
+                        if (koff[t + 1] > koff[t] && koff[t] >= s_cur && koff[t + 1] <= s_cur + ntake)
+                            pm.pinfo[(uint64_t)item * SKM_KEYS_PER_ITEM + t] = gb | ((unsigned long long)cid << PM_BASE_BITS);
+                }
+            }
             if (!s_skip) {
                 Rec<NW> *dst = out + s_gbase;
                 for (uint32_t i = threadIdx.x; i < wcount; i += BLK) {
@@ -565,6 +653,8 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                     for (int t = 0; t < NW; ++t) cx.w[t] = fwd ? x.w[t] : y.w[t];
                     if constexpr (EXT) cx.w[NW - 1] = (cx.w[NW - 1] << EXT_BITS) | eb;
                     dst[i] = cx;
+                    if constexpr (PM)
+                        if (!dirty) pm.mask[s_gbase + i] = (uint8_t)eb;
                 }
             }
             s_cur += ntake;

@@ -58,6 +58,13 @@ class GraphBuilder:
         _chk(self.ctx._h, self.ctx.lib.smx_graph_fingerprint(self.ctx._h, out))
         return [int(v) for v in out]
 
+    def fingerprint_portable(self):
+        """the part of fingerprint() that does not depend on how the k-mers are numbered (smx_graph_fingerprint_portable): packed
+        unitigs, lengths, self-conjugate flags, link structure by vertex order — equal between the construction routes"""
+        out = (C.c_uint64 * 8)()
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_fingerprint_portable(self.ctx._h, out))
+        return [int(v) for v in out]
+
     def tip_stats(self):
         """(k-mers isolated, tips removed) by the early tip clipper and (A/T edges, A/T tip k-mers) by the early A/T remover of the
         last build (options early_tip_bound, early_at_remover)."""

@@ -11,7 +11,9 @@ from conftest import GOLDEN, load_manifest, read_lines
 
 pytestmark = pytest.mark.gpu
 
-FORCE = {"prededupe": 1, "ext_route": 1}   # small inputs: the pre-dedupe stage (where the bytes are gathered) forced on
+# small inputs: the pre-dedupe stage (where the bytes are gathered) forced on; pm_route = 0: the k-mers ARE sorted into the file here
+# (tests/test_pm_route_gpu.py covers the route that does not)
+FORCE = {"prededupe": 1, "ext_route": 1, "pm_route": 0}
 LEGACY = {"prededupe": 1, "ext_route": 0}
 
 

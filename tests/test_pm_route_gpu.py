@@ -1,0 +1,177 @@
+"""GPU parity of the construction route that never sorts the k-mers (option "pm_route": nodes numbered by minimizer partition, only the
+junction k-mers are put into k-mer-file order to number the unitigs): the real spades-gbuilder goldens, the oracle and the sorted
+routes of the same library must agree — graph text, unitig order, coverage, the k-mer file made on demand, and the part of the device
+fingerprint that does not depend on the numbering."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_manifest, read_lines
+from test_ext_route_gpu import _eligible, _same_kmers, _synth
+
+pytestmark = pytest.mark.gpu
+
+PM = {"prededupe": 1, "ext_route": 1, "pm_route": 1}
+SORTED = {"prededupe": 1, "ext_route": 1, "pm_route": 0}
+
+
+def _build(reads, k, threads, tmp_path, opts, coverage=False, want_kmers=True):
+    from spades_amd.gbuilder import GraphBuilder
+    gb = GraphBuilder(k, threads)
+    for key, v in opts.items():
+        gb.ctx.set_option(key, v)
+    if isinstance(reads, list) and reads and isinstance(reads[0], list):
+        for part in reads:
+            gb.push_back_reads(part)
+    else:
+        gb.push_back_reads(reads)
+    gb.build()
+    names = [n for n, _ in gb.ctx.timings()]
+    took = "pm_tab" in names
+    gb.ctx.set_option("device_links", 2)
+    fp = None
+    try:
+        fp = gb.fingerprint_portable()
+    except Exception:  # noqa: BLE001 — tiny graphs keep their link records on the host
+        pass
+    if coverage:
+        gb.fill_coverage()
+    out = os.path.join(str(tmp_path), "g.gfa")
+    gb.write_gfa(out)
+    info = dict(gb.info())
+    res = dict(info=info, gfa=open(out).read(), unitigs=gb.unitigs(), took_pm_route=took, fp=fp, names=names)
+    if want_kmers:
+        res["kmers"] = gb.kmers()  # the sorted k-mer file + masks, made on demand behind this route
+    gb.ctx.close()
+    return res
+
+
+GCASES = [c for c in load_manifest()["cases"] if c["kind"] == "graph" and _eligible(c["K"])]
+
+
+@pytest.mark.parametrize("case", GCASES, ids=lambda c: f"{c['reads'][6:-4]}-k{c['K']}-t{c['threads']}")
+def test_gfa_matches_spades_gbuilder(case, tmp_path):
+    reads = [r for r in read_lines(case["reads"]) if r]
+    r = _build(reads, case["K"], case["threads"], tmp_path, dict(PM, device_links=2))
+    assert r["took_pm_route"]
+    assert hashlib.md5(r["gfa"].encode()).hexdigest() == case["md5"]
+    old = _build(reads, case["K"], case["threads"], tmp_path, dict(SORTED, device_links=2))
+    assert not old["took_pm_route"]
+    assert _same_kmers(r, old)
+    assert r["fp"] is not None and r["fp"] == old["fp"] and any(r["fp"])
+    assert r["info"] == old["info"]
+
+
+CCASES = [c for c in load_manifest()["cases"] if c["kind"] == "graph_cov" and _eligible(c["K"])]
+
+
+@pytest.mark.parametrize("case", CCASES, ids=lambda c: f"{c['reads'][6:-4]}-k{c['K']}-t{c['threads']}")
+def test_gfa_with_coverage(case, tmp_path):
+    reads = [r for r in read_lines(case["reads"]) if r]
+    r = _build(reads, case["K"], case["threads"], tmp_path, PM, coverage=True, want_kmers=False)
+    assert r["took_pm_route"]
+    assert r["gfa"] == open(os.path.join(GOLDEN, case["file"])).read()
+
+
+@pytest.mark.parametrize("k", [21, 25, 27, 33, 41, 55, 59, 77, 91, 123])
+def test_vs_oracle_seeded(k, tmp_path):
+    """ragged reads, both strands, N, rc-palindromic (k+1)-mers, homopolymers, hairpins; several bucket counts"""
+    from oracle import oracle
+    rng = np.random.default_rng(k)
+    pal = "".join("ACGT"[i] for i in rng.integers(0, 4, (k + 1) // 2))
+    pal = pal + "".join("TGCA"["ACGT".index(c)] for c in reversed(pal))
+    reads = (_synth(3 * k, 4000, 1500, 150) + ["ACGT" * 40] * 3 + ["AT" * 70] * 2 + ["A" * 140] * 4 + [pal, "G" + pal + "T", pal[:k], pal[1:]]
+             + ["C" * k, "C" * (k + 1), "N" * 150, ""])
+    for threads in (1, 3):
+        ref = oracle.build_graph(reads, k, 10 * threads)
+        r = _build(reads, k, threads, tmp_path, PM)
+        assert r["took_pm_route"]
+        assert r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"]
+        old = _build(reads, k, threads, tmp_path, SORTED)
+        assert _same_kmers(r, old) and r["info"] == old["info"]
+
+
+def test_coverage_vs_oracle_seeded(tmp_path):
+    from oracle import oracle
+    for k, threads in ((21, 2), (55, 1), (77, 2)):
+        reads = _synth(5 + k, 6000, 1500, 150) + ["ACGT" * 40] * 3 + ["A" * 100] * 5
+        ref = oracle.build_graph(reads, k, 10 * threads, coverage=True)
+        r = _build(reads, k, threads, tmp_path, PM, coverage=True, want_kmers=False)
+        assert r["took_pm_route"] and r["gfa"] == ref["gfa"]
+
+
+@pytest.mark.parametrize("k,cap", [(55, 512), (33, 512), (21, 1024), (77, 512)])
+def test_cut_partitions_go_to_the_sorted_tail(k, cap, tmp_path):
+    """a tiny chunk capacity cuts most minimizer partitions: their k-mers leave the chunks for the sorted tail ("dirty region"), and
+    lookups and walks cross between the two kinds of place all the time"""
+    from oracle import oracle
+    reads = _synth(11 + k, 3000, 4000, 150, err=0.002)  # ~200x: partitions far larger than one chunk
+    ref = oracle.build_graph(reads, k, 20)
+    r = _build(reads, k, 2, tmp_path, dict(PM, skm_cap=cap))
+    assert r["took_pm_route"] and r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"]
+    old = _build(reads, k, 2, tmp_path, dict(SORTED, skm_cap=cap))
+    assert _same_kmers(r, old) and r["info"] == old["info"]
+
+
+def test_perfect_loops_and_their_order(tmp_path):
+    """circular genomes without junctions: perfect loops, collected on the host in k-mer-file order of their k-mers"""
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    k = 33
+    reads = _synth(9, 3000, 600, 150)
+    for _ in range(6):
+        n = int(rng.integers(200, 500))
+        circle = "".join(rng.choice(list("ACGT"), n))
+        reads += [(circle + circle)[p:p + 120] for p in range(0, n, 7)]
+    ref = oracle.build_graph(reads, k, 30)
+    r = _build(reads, k, 3, tmp_path, PM)
+    assert r["took_pm_route"] and r["info"]["n_loops"] >= 6
+    assert r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"]
+
+
+def test_route_is_declined_where_it_does_not_fit(tmp_path):
+    from oracle import oracle
+    for k, opts in ((15, PM), (29, PM), (63, PM), (33, dict(PM, early_tip_bound=60))):
+        reads = _synth(k, 3000, 800, 150)
+        r = _build(reads, k, 1, tmp_path, opts)
+        assert not r["took_pm_route"]
+        if "early_tip_bound" not in opts:
+            assert r["gfa"] == oracle.build_graph(reads, k, 10)["gfa"]
+
+
+def test_several_read_chunks_and_formats(tmp_path):
+    from oracle import oracle
+    k = 33
+    reads = _synth(5, 3000, 1200, 150)
+    ref = oracle.build_graph(reads, k, 20)
+    r = _build([reads[a:a + 250] for a in range(0, len(reads), 250)], k, 2, tmp_path, PM)
+    assert r["took_pm_route"] and r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"]
+
+
+def test_count_view_after_the_graph(tmp_path):
+    """smx_build_graph promises that smx_copy_final_kmers / smx_bucket_sizes describe the canonical k-mer file afterwards: made on demand"""
+    from oracle import oracle
+    from spades_amd.gbuilder import GraphBuilder
+    from spades_amd.kmercount import KMerDiskStorage
+    k = 55
+    reads = _synth(3, 5000, 1500, 150)
+    gb = GraphBuilder(k, 2)
+    for key, v in PM.items():
+        gb.ctx.set_option(key, v)
+    gb.push_back_reads(reads)
+    gb.build()
+    assert "pm_tab" in [n for n, _ in gb.ctx.timings()]
+    st = KMerDiskStorage(gb.ctx, k, 20, None)
+    rec, sizes = st.records(), st.bucket_sizes()
+    krec, _ = gb.kmers()
+    assert rec.shape == krec.shape and (rec == krec).all() and int(sizes.sum()) == rec.shape[0]
+    ref = oracle.build_graph(reads, k, 20)
+    if "kmers" in ref:
+        assert (rec == np.asarray(ref["kmers"]).reshape(rec.shape)).all()
+    # the graph is still there and writes the same text
+    out = os.path.join(str(tmp_path), "g.gfa")
+    gb.write_gfa(out)
+    assert open(out).read() == oracle.build_graph(reads, k, 20)["gfa"]
+    gb.ctx.close()
