@@ -219,6 +219,9 @@ def main():
     ap.add_argument("--kpomer-route", action="store_true",
                     help="N=1: construction by the reference's own order of work ((k+1)-mer file first, masks filled from it) instead of "
                          "k-mers + masks from one count of the reads")
+    ap.add_argument("--sorted-route", action="store_true",
+                    help="N=1: k-mers + masks from one count of the reads, SORTED into the k-mer file before the construction (the round-2 default); "
+                         "without it the construction never sorts the k-mers (nodes numbered by minimizer partition)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option for this run (smx_set_option), e.g. dir_slots=2")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
     args = ap.parse_args()
@@ -268,6 +271,8 @@ def main():
     ctx = Context(device=local_rank)
     if args.kpomer_route:
         ctx.set_option("ext_route", 0)
+    if args.sorted_route:
+        ctx.set_option("pm_route", 0)
     for kv in args.opt:
         key, _, val = kv.partition("=")
         ctx.set_option(key, int(val))
@@ -321,7 +326,8 @@ def main():
         stages[name] = stages.get(name, 0.0) + ms
     # route of the construction: k-mers + extension masks from ONE count of the reads ("kmers:" pipeline stages incl. ext_merge; there
     # is no (k+1)-mer file), or the (k+1)-mer count followed by the k-mer file and the mask fill
-    ext_route = "kmers:ext_merge" in stages
+    pm_route = "pm_tab" in stages  # ... and without any sort of the k-mers (nodes numbered by minimizer partition)
+    ext_route = "kmers:ext_merge" in stages or pm_route
     if ext_route:
         count_ms = sum(ms for n_, ms in stages.items() if n_.startswith("kmers:"))
     else:
@@ -392,11 +398,13 @@ def main():
                                  f"count of the canonical {K1}-mers ") +
                                 f"({nb} buckets = -t {T})" + ("" if args.count_only else " + de Bruijn construction (" +
                                 ("successor table, " if ext_route else "k-mer file, extension masks, ") +
-                                "unitigs, link records + vertices; graph resident in HBM; GFA identical to spades-gbuilder's)")) if not sharded else
+                                "unitigs in the reference's order, link records + vertices; graph resident in HBM; GFA identical to spades-gbuilder's)")) if not sharded else
                                (f"BASELINE config 4 shape: {n_reads / 1e6:g} M PE150 reads per GPU, k={k}: sharded count of the canonical {K1}-mers "
                                 f"({nb} buckets, bucket-range owners, one RCCL all-to-all); inputs resident in HBM; no construction in the N>1 step"),
                    "reads_per_gpu": n_reads, "k": k, "num_buckets": nb, "kmer_instances": int(inst), "distinct_kpomers": int(D1),
-                   "route": ("k-mers + masks from one count of the reads" if ext_route else "(k+1)-mer file, then k-mer file + mask fill") if info is not None else "count only",
+                   "route": (("k-mers + masks from one count of the reads, never sorted: nodes numbered by minimizer partition" if pm_route else
+                              "k-mers + masks from one count of the reads, sorted into the k-mer file") if ext_route else
+                             "(k+1)-mer file, then k-mer file + mask fill") if info is not None else "count only",
                    "h2d_in_timed_region": not sharded, "construct_in_metric": (not sharded and not args.count_only),
                    "parallelism": "1 GPU" if not sharded else f"{world} GPU(s), bucket-range owners, one RCCL all-to-all (RCCL world size {world})"},
         "roofline": roof_count,
@@ -423,7 +431,11 @@ def main():
         out["step_breakdown_ms"] = {"count_kernels": round(count_ms, 1), "construct_kernels": round(construct_ms, 1),
                                     "host_and_upload": round(ms_per_step - count_ms - construct_ms, 1)}
         # the dominant single kernel of the step: k_fill_tab (node table: two rank lookups + two 64-bit atomics per (k+1)-mer)
-        if ext_route:  # k_tab_from_masks: the successor of every node with a unique extension, one rank lookup each
+        if pm_route:   # k_pm_tab: the successor of every node with a unique extension, looked up inside its own chunk first; + jump words
+            fm = stages.get("pm_tab", 0.0)
+            b_fill = D0 * (W + 1) + 2 * D0 * W + 2 * D0 * 8 + 2 * D0 * 4
+            dname, dkey = "smx::k_pm_tab", "smx::k_pm_tab<2>"
+        elif ext_route:  # k_tab_from_masks: the successor of every node with a unique extension, one rank lookup each
             fm = stages.get("succ", 0.0)
             b_fill = D0 * (W + 1) + 2 * D0 * W + 2 * D0 * 8
             dname, dkey = "smx::k_tab_from_masks", "smx::k_tab_from_masks<2, true>"
@@ -445,7 +457,9 @@ def main():
             try:  # order-sensitive checksums of the device-resident graph (k-mer file, masks, packed unitigs, lengths, end nodes, link
                 # records, vertices): equal between the two construction routes on the same input (profiles/r02)
                 out["construct"]["checks"]["graph_fingerprint"] = "%032x" % (int.from_bytes(__import__("hashlib").md5(
-                    b"".join(int(v).to_bytes(8, "little") for v in gb.fingerprint())).digest(), "big"))
+                    b"".join(int(v).to_bytes(8, "little") for v in gb.fingerprint_portable())).digest(), "big"))
+                out["construct"]["checks"]["graph_fingerprint_of"] = ("packed unitigs, lengths, self-conjugate flags, link records by vertex order "
+                                                                      "(smx_graph_fingerprint_portable: independent of the k-mer numbering, equal between routes)")
             except Exception as e:  # noqa: BLE001 — a check, never the measurement
                 out["construct"]["checks"]["graph_fingerprint"] = f"unavailable: {e}"
         if not args.no_cpu_baseline and n_sample:

@@ -48,23 +48,27 @@ def test_final_kmers_equal_spades_kmercount(case, tmp_path):
     ctx.close()
 
 
-@pytest.mark.parametrize("batches", [0, 3])
-def test_gfa_equals_spades_gbuilder(case, tmp_path, batches):
+@pytest.mark.parametrize("route", ["pm", "ext", "kpo"])
+def test_gfa_equals_spades_gbuilder(case, tmp_path, route):
     g, bases, off = case
     if "gfa_md5" not in g:
         pytest.skip("k-mer counting golden only")
     ctx = Context()
-    if batches:
-        ctx.set_option("derive_batches", batches)  # the k-mer file in bucket ranges, as at BASELINE config 3
+    if route == "ext":
+        ctx.set_option("pm_route", 0)              # the k-mers (with their extension bytes) ARE sorted into the k-mer file
+    if route == "kpo":
+        ctx.set_option("derive_batches", 3)        # the (k+1)-mer file first, the k-mer file in bucket ranges (round-2 config-3 path)
         ctx.set_option("keep_kpo", 0)              # ... and the coverage pass recounts the (k+1)-mers
     gb = GraphBuilder(g["k"], g["effective_threads"], ctx)
     gb.reads.push_back_ascii(bases, off)
     info = gb.build()
-    # which of the two construction routes ran: k-mers + masks from one count of the reads where the k-mer record has
-    # 8 spare bits (k = 21, 33, 55 here), the (k+1)-mer file first when the k-mer file is asked for in bucket ranges
-    took_ext = any(n == "kmers:ext_merge" for n, _ in ctx.timings())
+    # which construction route ran: where the k-mer record has 8 spare bits (k = 21, 33, 55, 77 here) the k-mers and
+    # their masks come from one count of the reads — without any sort of the k-mers by default (pm), sorted into the file on request
+    names = [n for n, _ in ctx.timings()]
+    took = "pm" if "pm_tab" in names else ("ext" if "kmers:ext_merge" in names else "kpo")
     nw = (g["k"] + 31) // 32
-    assert took_ext == (batches == 0 and g["k"] >= 21 and 2 * g["k"] + 8 <= 64 * nw)
+    fits = g["k"] >= 21 and 2 * g["k"] + 8 <= 64 * nw
+    assert took == (route if fits else "kpo")
     out = str(tmp_path / "g.gfa")
     gb.write_gfa(out)
     assert info["n_unitigs"] == g["gfa_S_lines"]
