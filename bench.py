@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--sorted-route", action="store_true",
                     help="N=1: k-mers + masks from one count of the reads, SORTED into the k-mer file before the construction (the round-2 default); "
                          "without it the construction never sorts the k-mers (nodes numbered by minimizer partition)")
+    ap.add_argument("--sync-upload", action="store_true", help="N=1: the H2D copy of the step finishes before any kernel starts (round-2 behaviour)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option for this run (smx_set_option), e.g. dir_slots=2")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
     args = ap.parse_args()
@@ -273,6 +274,9 @@ def main():
         ctx.set_option("ext_route", 0)
     if args.sorted_route:
         ctx.set_option("pm_route", 0)
+    # the upload inside the step is asynchronous: (start, len) first, then the 2-bit stream in pieces that the first scan of the reads
+    # follows as they land (the page-locked host arrays stay where they are for the whole run)
+    ctx.set_option("async_upload", 0 if args.sync_upload else 1)
     for kv in args.opt:
         key, _, val = kv.partition("=")
         ctx.set_option(key, int(val))

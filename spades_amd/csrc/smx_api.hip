@@ -106,6 +106,7 @@ void smx_destroy(smx_ctx *ctx) {
     free_temps(ctx);
     arena_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;
 }
 
@@ -139,6 +140,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "kmers_from_reads")) ctx->opt_kmers_from_reads = value;
     else if (!strcmp(key, "ext_route")) ctx->opt_ext_route = value;
     else if (!strcmp(key, "pm_route")) ctx->opt_pm_route = value;
+    else if (!strcmp(key, "async_upload")) ctx->opt_async_upload = value;
     else if (!strcmp(key, "dir_slots")) ctx->opt_dir_slots = value;
     else if (!strcmp(key, "ext_presort")) ctx->opt_ext_presort = value;
     else return fail(ctx, SMX_INVALID_PARAMETER, "unknown option %s", key);
@@ -148,13 +150,82 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
 int smx_reads_clear(smx_ctx *ctx) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     (void)hipSetDevice(ctx->device);
-    for (auto &c : ctx->chunks)
+    for (auto &c : ctx->chunks) {
+        if (c.ev_meta) {  // an asynchronous submission: its copies must be over before the buffers go
+            (void)hipEventSynchronize(c.piece_ev.empty() ? c.ev_meta : c.piece_ev.back());
+            (void)hipEventDestroy(c.ev_meta);
+            for (auto e : c.piece_ev) (void)hipEventDestroy(e);
+            if (c.h_ext) (void)hipHostFree(c.h_ext);
+        }
         if (c.owned) {
             arena_put(ctx, c.d_words);
             arena_put(ctx, c.d_start);
             arena_put(ctx, c.d_len);
         }
+    }
     ctx->chunks.clear();
+    return SMX_OK;
+}
+
+// smx_submit_reads_packed with option "async_upload": nothing is waited for. (start, len) go first (the window marks need only them),
+// then the stream in pieces; every piece has an event, so that the first scan of the reads can follow the upload piece by piece
+// (run_prededupe) instead of waiting for the last byte. The caller's arrays must stay valid until the reads have been used.
+static int submit_packed_async(smx_ctx *ctx, const uint64_t *words, uint64_t n_words, const uint64_t *start, const uint32_t *len, uint64_t n_reads) {
+    if (!ctx->copy_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    ReadChunk c;
+    c.n_words = n_words;
+    c.n_reads = n_reads;
+    c.n_bases = n_words * 32;  // until the check says how far the reads really go
+    unsigned long long *d_ext = nullptr;
+    if (int rc = dalloc(ctx, &c.d_words, n_words + 8, false)) return rc;
+    if (int rc = dalloc(ctx, &c.d_start, n_reads, false)) return rc;
+    if (int rc = dalloc(ctx, &c.d_len, n_reads, false)) return rc;
+    auto bail = [&](int code) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        if (c.ev_meta) (void)hipEventDestroy(c.ev_meta);
+        for (auto e : c.piece_ev) (void)hipEventDestroy(e);
+        if (c.h_ext) (void)hipHostFree(c.h_ext);
+        arena_put(ctx, c.d_words);
+        arena_put(ctx, c.d_start);
+        arena_put(ctx, c.d_len);
+        arena_put(ctx, d_ext);
+        return code;
+    };
+    if (int rc = dalloc(ctx, &d_ext, 2, false)) return bail(rc);
+    hipStream_t cs = ctx->copy_stream;
+    hipError_t e = hipHostMalloc((void **)&c.h_ext, 16, hipHostMallocDefault);
+    if (e == hipSuccess) {
+        c.h_ext[0] = 0;
+        c.h_ext[1] = 0;
+        e = hipMemsetAsync(d_ext, 0, 16, cs);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(c.d_start, start, n_reads * 8, hipMemcpyHostToDevice, cs);
+    if (e == hipSuccess) e = hipMemcpyAsync(c.d_len, len, n_reads * 4, hipMemcpyHostToDevice, cs);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_reads_extent, dim3((unsigned)std::min<uint64_t>((n_reads + BLK - 1) / BLK, 2048)), dim3(BLK), 0, cs, (const uint64_t *)c.d_start,
+                           (const uint32_t *)c.d_len, n_reads, (uint64_t)n_words * 32, d_ext);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(c.h_ext, d_ext, 16, hipMemcpyDeviceToHost, cs);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ev_meta, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(c.ev_meta, cs);
+    if (e == hipSuccess) e = hipMemsetAsync(c.d_words + n_words, 0, 64, cs);
+    const uint64_t npieces = std::min<uint64_t>(16, std::max<uint64_t>(2, n_words / ((uint64_t)32 << 20)));  // pieces of >= 256 MB
+    for (uint64_t p = 0; p < npieces && e == hipSuccess; ++p) {
+        const uint64_t w0 = n_words * p / npieces / 2 * 2, w1 = p + 1 == npieces ? n_words : n_words * (p + 1) / npieces / 2 * 2;  // multiples of 64 positions
+        if (w1 > w0) e = hipMemcpyAsync(c.d_words + w0, words + w0, (w1 - w0) * 8, hipMemcpyHostToDevice, cs);
+        hipEvent_t ev = nullptr;
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) {
+            c.piece_ev.push_back(ev);
+            c.piece_end.push_back(w1);
+            e = hipEventRecord(ev, cs);
+        }
+    }
+    if (e != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "read upload failed: %s", hipGetErrorString(e)));
+    ctx->temps.push_back(d_ext);  // released with the temporaries of the call that uses the reads (the copy stream is done with it by then)
+    c.contigs = ctx->opt_submit_contigs != 0;
+    ctx->chunks.push_back(c);
     return SMX_OK;
 }
 
@@ -164,6 +235,7 @@ int smx_submit_reads_packed(smx_ctx *ctx, const uint64_t *words, uint64_t n_word
     if (n_reads == 0) return SMX_OK;
     if (!words || !start || !len) return fail(ctx, SMX_INVALID_PARAMETER, "null read arrays");
     HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->opt_async_upload > 0 && n_words >= ((uint64_t)1 << 24)) return submit_packed_async(ctx, words, n_words, start, len, n_reads);
     ReadChunk c;
     c.n_words = n_words;
     c.n_reads = n_reads;

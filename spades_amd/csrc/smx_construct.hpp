@@ -778,8 +778,9 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             if (int rc = dalloc(ctx, &vq, C)) return rc;
             Rec<NW> *jrecs, *jk;
             uint8_t *jm;
-            unsigned long long *jstats, *jcnt, *candoff;
+            unsigned long long *jstats, *jcnt, *candoff, *qbase;
             if (int rc = dalloc(ctx, &jrecs, nj + 1)) return rc;
+            if (int rc = dalloc(ctx, &qbase, nj + 1)) return rc;
             tbegin(ctx, "junctions");
             hipLaunchKernelGGL((k_pm_junc_write<NW>), dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const void *)ctx->g_kmers,
                                (const unsigned long long *)tjoff, D0, (void *)jrecs);
@@ -788,7 +789,7 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             {
                 Prefix pf(ctx, "jsort:");
                 ctx->ext_mode = true;
-                const int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, ctx->g_B, jrecs, nj, nullptr, /*recs_reusable=*/true, false, /*distinct_hint=*/true);
+                const int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, ctx->g_B, jrecs, nj, nullptr, /*recs_reusable=*/false, false, /*distinct_hint=*/true);
                 ctx->ext_mode = false;
                 if (rc) return rc;
             }
@@ -814,8 +815,10 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
                 drop_rank_dir(ctx, jix);
                 return rc;
             }
-            hipLaunchKernelGGL((k_pm_cand_expand<NW>), dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const void *)ctx->g_kmers,
-                               (const unsigned long long *)toff, D0, (const void *)jk, jix, (const unsigned long long *)candoff, cand, qidx, d_err);
+            hipLaunchKernelGGL((k_pm_jrank<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, nj, (const void *)jk, jix,
+                               (const unsigned long long *)candoff, qbase, d_err);
+            hipLaunchKernelGGL(k_pm_cand_expand, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const unsigned long long *)toff,
+                               (const unsigned long long *)tjoff, D0, (const unsigned long long *)qbase, cand, qidx);
             unsigned long long ctot = 0;
             hipError_t e1 = hipGetLastError();
             if (e1 == hipSuccess) e1 = hipMemcpyAsync(&ctot, candoff + nj, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -868,7 +871,7 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         tbegin(ctx, "walk_write");
         if (pm)
             hipLaunchKernelGGL((k_pm_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (const unsigned long long *)qidx,
-                               (uint64_t)C, (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len, (const node_t *)first,
+                               (uint64_t)C, (const void *)ctx->g_kmers, (const node_t *)tab, pm->jmp, k, (const unsigned long long *)len, (const node_t *)first,
                                (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw, (const unsigned long long *)one, ctx->g_uwords,
                                ctx->g_eoffw, ctx->g_elen, ctx->g_estart, ctx->g_eend, ctx->g_eself);
         else

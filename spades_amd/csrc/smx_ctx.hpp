@@ -12,6 +12,13 @@ struct ReadChunk {
     uint64_t n_words = 0, n_reads = 0, n_bases = 0;
     bool owned = true;
     bool contigs = false;  // takes part in the construction, not in the coverage (trusted / previous-k contigs)
+    // asynchronous submission (option "async_upload"): (start, len) first, then the 2-bit stream in pieces on the context's copy stream.
+    // ev_meta: start / len are there and checked (h_ext: pinned, [0] furthest nucleotide, [1] reads beyond the stream);
+    // piece_ev[p]: words [0, piece_end[p]) are there. Consumers make their stream wait (mark_windows; run_prededupe range by range).
+    hipEvent_t ev_meta = nullptr;
+    unsigned long long *h_ext = nullptr;
+    std::vector<uint64_t> piece_end;
+    std::vector<hipEvent_t> piece_ev;
 };
 
 struct Timing {
@@ -55,6 +62,8 @@ struct smx_ctx {
     Arena arena;
     size_t budget = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // uploads of asynchronous submissions
+    int64_t opt_async_upload = 0;       // smx_submit_reads_packed returns before the copy is done (the host arrays stay valid until the reads are used)
     std::string err;
     std::vector<ReadChunk> chunks;
     // result of the last count

@@ -134,14 +134,16 @@ __global__ void k_reads_extent(const uint64_t *__restrict__ start, const uint32_
 // ------------------------------------------------------------------------------------------ mark
 // min_len: only reads (valid runs) of at least this many nucleotides contribute windows (K-mers of the runs that hold a (K+1)-mer:
 // the k-mer file of the construction, kmer_splitters.hpp:138-207, taken from the reads instead of from the (k+1)-mer file)
+// limit: positions the mask covers — a read that leaves them is skipped (an asynchronous submission is checked by k_reads_extent on
+// the copy stream; its verdict reaches the host only after this kernel was launched)
 __global__ void k_mark_windows(const uint64_t *__restrict__ start, const uint32_t *__restrict__ len, uint64_t n,
-                               unsigned K, unsigned long long *mask, unsigned long long *total, unsigned min_len = 0) {
+                               unsigned K, unsigned long long *mask, unsigned long long *total, unsigned min_len = 0, uint64_t limit = ~0ull) {
     __shared__ unsigned long long scratch[BLK / 64 + 2];
     uint64_t r = (uint64_t)blockIdx.x * BLK + threadIdx.x;
     unsigned long long nwin = 0;
     if (r < n) {
         uint32_t l = len[r];
-        if (l >= K && l >= min_len) {
+        if (l >= K && l >= min_len && start[r] <= limit && (uint64_t)l <= limit - start[r]) {
             nwin = l - K + 1;
             uint64_t s = start[r], e = s + nwin - 1;
             uint64_t fw = s >> 6, lw = e >> 6;

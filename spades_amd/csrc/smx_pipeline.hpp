@@ -96,11 +96,19 @@ int pass_recs(smx_ctx *ctx, bool scatter, PassArgs a, uint64_t nrec, unsigned lo
 }
 
 // mark valid windows of every chunk; returns total windows
-int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint64_t *total, bool temp_masks = true, unsigned min_len = 0) {
+// Asynchronous submissions: the library's stream waits for (start, len) of every chunk, and — unless the caller follows the upload
+// piece by piece itself (wait_words = false: run_prededupe's first scan) — for the whole 2-bit stream. Every path that reads the
+// resident reads starts here.
+int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint64_t *total, bool temp_masks = true, unsigned min_len = 0, bool wait_words = true) {
     unsigned long long *d_total;
     if (int rc = dalloc(ctx, &d_total, 1)) return rc;
     HIPCHK(hipMemsetAsync(d_total, 0, 8, ctx->stream));
     masks.assign(ctx->chunks.size(), nullptr);
+    for (auto &ch : ctx->chunks)
+        if (ch.ev_meta) {
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ch.ev_meta, 0));
+            if (wait_words && !ch.piece_ev.empty()) HIPCHK(hipStreamWaitEvent(ctx->stream, ch.piece_ev.back(), 0));
+        }
     for (size_t ci = 0; ci < ctx->chunks.size(); ++ci) {
         const ReadChunk &ch = ctx->chunks[ci];
         if (ch.n_reads == 0) continue;
@@ -109,12 +117,14 @@ int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint6
         HIPCHK(hipMemsetAsync(masks[ci], 0, mw * 8, ctx->stream));
         unsigned grid = (unsigned)((ch.n_reads + BLK - 1) / BLK);
         hipLaunchKernelGGL(k_mark_windows, dim3(grid), dim3(BLK), 0, ctx->stream, ch.d_start, ch.d_len, ch.n_reads, K,
-                           (unsigned long long *)masks[ci], d_total, min_len);
+                           (unsigned long long *)masks[ci], d_total, min_len, (uint64_t)ch.n_bases);
         HIPCHK(hipGetLastError());
     }
     unsigned long long t = 0;
     HIPCHK(hipMemcpyAsync(&t, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (auto &ch : ctx->chunks)
+        if (ch.h_ext && ch.h_ext[1]) return fail(ctx, SMX_INVALID_INPUT_FORMAT, "%llu reads exceed the packed stream", ch.h_ext[1]);
     *total = t;
     return 0;
 }
@@ -538,11 +548,25 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
             a.g0 = sel.ranges ? (*sel.ranges)[ci].first : 0;
             a.G = sel.ranges ? (*sel.ranges)[ci].second : ch.n_bases;
             if (a.G <= a.g0) continue;
-            const uint64_t ntiles = (a.G - a.g0 + SKM_TP - 1) / SKM_TP;
-            const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 16);
-            if (phase == 0) hipLaunchKernelGGL((k_skm_scan<0, NW>), dim3(grid), dim3(BLK), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((k_skm_scan<1, NW>), dim3(grid), dim3(BLK), 0, ctx->stream, a);
-            HIPCHK(hipGetLastError());
+            // an asynchronous submission is scanned piece by piece as it lands: positions of piece p once piece p + 1 is there (a tile
+            // reads up to ~100 words past its last position), the last piece after the end of the upload
+            const uint64_t r0 = a.g0, r1 = a.G;
+            const size_t np = std::max<size_t>(ch.piece_ev.size(), 1);
+            for (size_t p = 0; p < np; ++p) {
+                a.vG = 0;
+                if (!ch.piece_ev.empty()) {
+                    HIPCHK(hipStreamWaitEvent(ctx->stream, ch.piece_ev[std::min(p + 1, np - 1)], 0));
+                    a.g0 = std::max<uint64_t>(r0, p ? ch.piece_end[p - 1] * 32 : 0);
+                    a.G = std::min<uint64_t>(r1, p + 1 == np ? r1 : ch.piece_end[p] * 32);
+                    if (a.G <= a.g0) continue;
+                    if (!sel.ranges) a.vG = ch.n_bases;  // pieces of ONE batch: runs and neighbour bases cross the piece boundaries
+                }
+                const uint64_t ntiles = (a.G - a.g0 + SKM_TP - 1) / SKM_TP;
+                const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 256 * 16);
+                if (phase == 0) hipLaunchKernelGGL((k_skm_scan<0, NW>), dim3(grid), dim3(BLK), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((k_skm_scan<1, NW>), dim3(grid), dim3(BLK), 0, ctx->stream, a);
+                HIPCHK(hipGetLastError());
+            }
         }
         return 0;
     };
@@ -551,7 +575,9 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     unsigned long long *st_alloc = nullptr;
     // (short runs — K < 35, w < 16 windows — make placing atomics-bound either way and the staging round trip a loss: K=21 17.9 vs 14.4 ms)
     if (ctx->opt_skm_stage >= 2 || (ctx->opt_skm_stage == 1 && a.w >= 16)) {
-        const uint64_t blocks = 256 * 16;
+        uint64_t launches = 0;  // every workgroup of every launch may leave most of a 4096-entry block unused
+        for (auto &ch : ctx->chunks) launches += std::max<size_t>(ch.piece_ev.size(), 1);
+        const uint64_t blocks = 256 * 16 * std::max<uint64_t>(launches, 1);
         a.stage_cap = (uint64_t)((double)nwin * 3.0 / (double)(a.w + 1)) + blocks * 4096 + 4096;
         if (ctx->opt_skm_stage == 2) a.stage_cap = 4096;  // tests: force the overflow fallback
         if (int rc = dalloc(ctx, &a.stage_slots, (size_t)a.stage_cap * SW)) return rc;

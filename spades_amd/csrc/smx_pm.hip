@@ -91,70 +91,149 @@ __device__ __forceinline__ Rec<NW> pm_node_kmer(const Rec<NW> *__restrict__ recs
 constexpr uint16_t PM_ADV_NONE = 0xFFFFu;
 
 // Node table of the clean chunks: one workgroup per chunk. Per node: outgoing extensions from the mask byte; where there is exactly
-// one, the successor k-mer is looked up — first in the chunk itself (its group words are staged in LDS; consecutive k-mers of a path
-// share their minimizer, ~9 in 10 are found here), else through the partition table. Then the chains inside the chunk are followed
-// in LDS to write the jump words. stats: [0] extension bits, [1] palindromic (k+1)-mers among them (k_ext_split's figures).
-// LDS (dynamic): gm[ngroups] u32 | adv[2 * maxn] u16
+// one, the successor k-mer is looked up in the chunk itself (its group words are staged in LDS; consecutive k-mers of a path share
+// their minimizer, 19 in 20 are found here); a miss leaves TAB_NODE_MASK in the entry for k_pm_remote. Then the chains inside the
+// chunk are followed in LDS, once each, from their heads (the nodes no local link leads to — the only places where a walk can enter
+// a chain) by a dense loop over a list; only heads get a jump word, the others 0 (= step by the node table).
+// stats: [0] extension bits, [1] palindromic (k+1)-mers among them (k_ext_split's figures).
+// LDS (dynamic): gm[ngroups] u32 | jw[2 * maxn] u32 | list[2 * maxn] u16 (chain heads) | hp[maxn / 16] u32
+// Canonical successor k-mers of both orientations of x from ONE reverse complement: with y = RC(x), the successor of orientation 0
+// by nucleotide c is z = x[1..] + c and RC(z) = (3 - c) + y[..k-2]; of orientation 1, z = y[1..] + c and RC(z) = (3 - c) + x[..k-2] —
+// shifts of x and y. yo = 1 where the successor is the non-minimal strand.
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_pm_tab(PmIndex ix, const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t maxn, unsigned k, node_t *tab,
-                                                uint32_t *jmp, unsigned long long *stats, uint32_t *err) {
+__device__ __forceinline__ Rec<NW> pm_succ_from(const Rec<NW> &fw, const Rec<NW> &bw, unsigned k, unsigned mo, unsigned &yo) {
+    const unsigned c = __ffs(mo) - 1;
+    const Rec<NW> z = rec_shl<NW>(fw, k, c), zr = rec_shr<NW>(bw, k, 3u - c);
+    const bool minimal = rc_ge<NW>(zr, z);
+    yo = minimal ? 0u : 1u;
+    return minimal ? z : zr;
+}
+template <int NW>
+__device__ __forceinline__ Rec<NW> pm_succ_kmer(const Rec<NW> &x, unsigned k, unsigned o, unsigned mo, unsigned &yo) {  // canonical successor of orientation o
+    const Rec<NW> y = rec_rc<NW>(x, k);
+    return o ? pm_succ_from<NW>(y, x, k, mo, yo) : pm_succ_from<NW>(x, y, k, mo, yo);
+}
+// palindromic (k+1)-mers among the extensions of x (k_ext_split's second figure), registers only. x + c is its own reverse complement
+// iff c = complement of x[0] and x[1..k-1] equals its reverse complement, which is y[0..k-2] (y = RC(x)); likewise b + x on the other
+// side with x[0..k-2] against y[1..k-1].
+template <int NW>
+__device__ __forceinline__ unsigned pm_palindromes(const Rec<NW> &x, unsigned m, unsigned k) {
+    const unsigned x0 = rec_nucl<NW>(x, 0), xl = (unsigned)(x.w[NW - 1] >> (((k - 1) & 31u) << 1)) & 3u;
+    const Rec<NW> y = rec_rc<NW>(x, k);
+    unsigned n = 0;
+    if ((m >> (3 - x0)) & 1) n += rec_eq<NW>(rec_suffix<NW>(x), rec_prefix<NW>(y, k - 1)) ? 1u : 0u;
+    if ((m >> (7 - xl)) & 1) n += rec_eq<NW>(rec_prefix<NW>(x, k - 1), rec_suffix<NW>(y)) ? 1u : 0u;
+    return n;
+}
+template <int NW>
+__global__ void __launch_bounds__(BLK, 6) k_pm_tab(PmIndex ix, const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t maxn, unsigned k, node_t *tab,
+                                                uint32_t *jmp, unsigned long long *stats, uint32_t *err, unsigned long long *prof) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pm_lds[];
     uint32_t *gm = pm_lds;
-    uint16_t *adv = (uint16_t *)(gm + ix.ngroups);
+    uint32_t *jw = gm + ix.ngroups;
+    uint16_t *list = (uint16_t *)(jw + 2 * maxn);
+    uint32_t *hp = (uint32_t *)(list + 2 * maxn);  // bit nd: some local link leads to node nd
+    __shared__ uint32_t s_nhead;
     const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
     unsigned long long bits = 0, pals = 0;
+    // SMX_DEBUG: prof[0..3] = 100 MHz ticks of thread 0 (stage, node table, chain heads, jumps), [4] chunks, [5] successors outside their chunk, [6] chain heads
+    unsigned long long pt[4] = {0, 0, 0, 0}, t0 = 0, pc[3] = {0, 0, 0};
+#define PM_T(i)                                  \
+    if (prof && threadIdx.x == 0) {              \
+        unsigned long long t1 = wall_clock64();  \
+        pt[i] += t1 - t0;                        \
+        t0 = t1;                                 \
+    }
+    if (prof && threadIdx.x == 0) t0 = wall_clock64();
+    unsigned long long ci = blockIdx.x < nchunks ? cinfo[blockIdx.x] : 0ull;
     for (uint32_t cid = blockIdx.x; cid < nchunks; cid += gridDim.x) {
-        const unsigned long long ci = cinfo[cid];
         const uint64_t base = ci & PM_BASE_MASK;
-        const uint32_t n = (uint32_t)(ci >> PM_BASE_BITS);
+        const uint32_t n = (uint32_t)(ci >> PM_BASE_BITS), nn = 2 * n;
         __syncthreads();
         for (uint32_t t = threadIdx.x; t < ix.ngroups; t += BLK) gm[t] = ix.meta[(size_t)cid * ix.ngroups + t];
+        for (uint32_t t = threadIdx.x; t < (maxn >> 4); t += BLK) hp[t] = 0;
+        if (threadIdx.x == 0) s_nhead = 0;
+        Rec<NW> nxt{};
+        if (threadIdx.x < n && n <= maxn) nxt = recs[base + threadIdx.x];
+        if (cid + gridDim.x < nchunks) ci = cinfo[cid + gridDim.x];  // the next chunk's descriptor flies while this one is worked on
         __syncthreads();
+        PM_T(0)
         if (n > maxn) {  // cannot happen (a chunk never has more winners than its capacity): never leave the LDS arrays
             if (threadIdx.x == 0) atomicAdd(err, 1u);
             continue;
         }
         for (uint32_t r = threadIdx.x; r < n; r += BLK) {
-            const Rec<NW> raw = recs[base + r];
+            const Rec<NW> raw = nxt;
+            if (r + BLK < n) nxt = recs[base + r + BLK];  // prefetch: the record of the next round
             const Rec<NW> x = rec_pure<NW>(raw);
             const unsigned m = (unsigned)(raw.w[NW - 1] & 0xFFu);
             bits += __popc(m);
-            {
-                const unsigned x0 = rec_nucl<NW>(x, 0), xl = rec_nucl<NW>(x, k - 1);
-                if (((m >> (3 - x0)) & 1) && range_is_rc_palindrome<NW>(x, 1, k - 1)) ++pals;
-                if (((m >> (7 - xl)) & 1) && range_is_rc_palindrome<NW>(x, 0, k - 1)) ++pals;
+            {   // a palindromic (k+1)-mer needs the matching extension bit AND complementary outermost bases of the inner (k-1)-mer
+                const uint64_t wsel = ((k - 2) >> 5) == (unsigned)(NW - 1) ? x.w[NW - 1] : x.w[NW > 1 ? NW - 2 : 0];  // the word of base k-2
+                const unsigned x0 = rec_nucl<NW>(x, 0), x1 = rec_nucl<NW>(x, 1), xl = (unsigned)(x.w[NW - 1] >> (((k - 1) & 31u) << 1)) & 3u,
+                               xm = (unsigned)(wsel >> (((k - 2) & 31u) << 1)) & 3u;
+                if ((((m >> (3 - x0)) & 1) && x1 + xl == 3) || (((m >> (7 - xl)) & 1) && x0 + xm == 3)) pals += pm_palindromes<NW>(x, m, k);
             }
             const bool junction = mask_junction(m);
+            const Rec<NW> y = rec_rc<NW>(x, k);
 #pragma unroll
             for (unsigned o = 0; o < 2; ++o) {
                 const unsigned mo = (o ? brev8(m) : m) & 15u;
-                node_t e = (node_t)mo << TAB_OUT_SHIFT;
-                uint16_t a = PM_ADV_NONE;
+                const uint32_t me = 2 * r + o;
+                uint32_t w = 0xFFFFu;  // no local successor
                 if (uniq4(mo)) {
                     unsigned yo;
-                    const Rec<NW> xo = o ? rec_rc<NW>(x, k) : x;
-                    const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(xo, k, __ffs(mo) - 1), k, yo);
-                    node_t ry = pm_probe<NW>(recs, gm, ix.T, base, y, rec_hash32<NW>(y));
+                    const Rec<NW> sk = o ? pm_succ_from<NW>(y, x, k, mo, yo) : pm_succ_from<NW>(x, y, k, mo, yo);
+                    const node_t ry = pm_probe<NW>(recs, gm, ix.T, base, sk, rec_hash32<NW>(sk));
                     if (ry != NODE_NONE) {
-                        if (!junction) a = (uint16_t)(((uint32_t)(ry - base) << 1) | yo);
-                    } else {
-                        ry = pm_find<NW>(ix, y);
+                        tab[2 * (base + r) + o] = ((node_t)mo << TAB_OUT_SHIFT) | (ry << 1) | yo;
+                        if (!junction) {
+                            w = ((uint32_t)(ry - base) << 1) | yo;
+                            atomicOr(&hp[w >> 5], 1u << (w & 31u));
+                        }
+                    } else {  // not in this chunk: k_pm_remote looks it up through the partition table
+                        tab[2 * (base + r) + o] = ((node_t)mo << TAB_OUT_SHIFT) | TAB_NODE_MASK;
+                        if (prof) ++pc[0];
                     }
-                    if (ry == NODE_NONE) atomicAdd(err, 1u);
-                    else e |= (ry << 1) | yo;
+                } else {
+                    tab[2 * (base + r) + o] = (node_t)mo << TAB_OUT_SHIFT;
                 }
-                tab[2 * (base + r) + o] = e;
-                adv[2 * r + o] = a;
+                jw[me] = w;
             }
         }
         __syncthreads();
-        const uint32_t nn = 2 * n;
-        for (uint32_t nd = threadIdx.x; nd < nn; nd += BLK) {
-            uint32_t cur = nd, s = 0;
-            for (uint32_t a; (a = adv[cur]) != PM_ADV_NONE && s < nn; ++s) cur = a;
-            jmp[2 * base + nd] = ((uint32_t)(cur - nd) & 0xFFFFu) | (s << 16);
+        PM_T(1)
+        for (uint32_t nd = threadIdx.x; nd < nn; nd += BLK)  // chain heads: a local successor, no local predecessor
+            if (jw[nd] != 0xFFFFu && !((hp[nd >> 5] >> (nd & 31u)) & 1u)) list[atomicAdd(&s_nhead, 1u)] = (uint16_t)nd;
+        __syncthreads();
+        PM_T(2)
+        const uint32_t nhead = s_nhead;
+        for (uint32_t i = threadIdx.x; i < nhead; i += BLK) {  // every chain once, from its head
+            const uint32_t h = list[i];
+            uint32_t cur = h, st = 0;
+            for (uint32_t a; (a = jw[cur] & 0xFFFFu) != 0xFFFFu && st < nn; ++st) cur = a;
+            jw[h] = (((cur - h) & 0xFFFFu) | (st << 16)) | 0x80000000u;  // (bit 31 marks the word as a result; st <= nn < 2^15)
         }
+        __syncthreads();
+        for (uint32_t nd = threadIdx.x; nd < nn; nd += BLK) {
+            const uint32_t v = jw[nd];
+            jmp[2 * base + nd] = (v & 0x80000000u) ? (v & 0x7FFFFFFFu) : 0u;
+        }
+        if (prof && threadIdx.x == 0) {
+            pc[1] += nhead;
+            pc[2] += 1;
+        }
+        PM_T(3)
     }
+    if (prof) {
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < 4; ++i) atomicAdd(&prof[i], pt[i]);
+            atomicAdd(&prof[4], pc[2]);
+            atomicAdd(&prof[6], pc[1]);
+        }
+        if (pc[0]) atomicAdd(&prof[5], pc[0]);
+    }
+#undef PM_T
     for (int o = 32; o > 0; o >>= 1) {
         bits += __shfl_down(bits, o, 64);
         pals += __shfl_down(pals, o, 64);
@@ -162,6 +241,44 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(PmIndex ix, const unsigned long 
     if ((threadIdx.x & 63) == 0) {
         if (bits) atomicAdd(&stats[0], bits);
         if (pals) atomicAdd(&stats[1], pals);
+    }
+}
+// The successors k_pm_tab did not find in the node's own chunk (~5 % of the nodes; their entries carry TAB_NODE_MASK in the node field):
+// tiles of PMR_TILE table entries, the marked ones compacted into an LDS list, then a dense loop in which every lane has a lookup —
+// minimizer scan of the successor k-mer, partition table, the other chunk's group word, the record. (Left inside k_pm_tab's per-node
+// loop, nearly every wave paid that path for its few misses: 62 of 80 us per chunk.)
+constexpr int PMR_TILE = BLK * 16;
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_pm_remote(PmIndex ix, uint64_t n_nodes, unsigned k, node_t *tab, uint32_t *err) {
+    __shared__ uint16_t lst[PMR_TILE];
+    __shared__ uint32_t s_n;
+    const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
+    const uint64_t ntiles = (n_nodes + PMR_TILE - 1) / PMR_TILE;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * PMR_TILE;
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < PMR_TILE / BLK; ++j) {
+            const uint32_t li = (uint32_t)j * BLK + threadIdx.x;
+            if (t0 + li < n_nodes && (tab[t0 + li] & TAB_NODE_MASK) == TAB_NODE_MASK && uniq4(tab_out4(tab[t0 + li]))) lst[atomicAdd(&s_n, 1u)] = (uint16_t)li;
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        for (uint32_t i = threadIdx.x; i < n; i += BLK) {
+            const node_t node = t0 + lst[i];
+            const Rec<NW> raw = recs[node >> 1];
+            const unsigned m = (unsigned)(raw.w[NW - 1] & 0xFFu), o = (unsigned)(node & 1);
+            const unsigned mo = (o ? brev8(m) : m) & 15u;
+            unsigned yo;
+            const Rec<NW> y = pm_succ_kmer<NW>(rec_pure<NW>(raw), k, o, mo, yo);
+            const node_t ry = pm_find<NW>(ix, y);
+            node_t e = (node_t)mo << TAB_OUT_SHIFT;
+            if (ry == NODE_NONE) atomicAdd(err, 1u);
+            else e |= (ry << 1) | yo;
+            tab[node] = e;
+        }
+        __syncthreads();
     }
 }
 // ... and of the dirty region: every successor through the partition table; no jumps (delta 0, 0 steps)
@@ -238,30 +355,41 @@ __global__ void __launch_bounds__(BLK) k_pm_junc_write(const uint8_t *mask, cons
 __global__ void k_pm_cand_counts(const uint8_t *jm, uint64_t nj, unsigned long long *cnt) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += (uint64_t)gridDim.x * blockDim.x) cnt[i] = cand_of_mask(jm[i]);
 }
-// k_cand_expand in node order + q[o] = number of the de-edge in the reference's order: first de-edge of the junction k-mer in the
-// sorted junction file (rank lookup, candoff) + its place among the k-mer's de-edges
+// first start de-edge of every junction k-mer in the reference's order: its place in the sorted junction file (rank lookup) -> candoff.
+// Dense over the junction k-mers in node order (jn: what k_pm_junc_write left), every lane does a lookup.
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_pm_cand_expand(const uint8_t *mask, const void *recs_, const unsigned long long *toff, uint64_t D0, const void *jk_,
-                                                        RankDir jix, const unsigned long long *candoff, unsigned long long *cand, unsigned long long *q,
-                                                        uint32_t *err) {
-    __shared__ uint32_t scratch[BLK / 64 + 2];
-    const Rec<NW> *recs = (const Rec<NW> *)recs_;
+__global__ void __launch_bounds__(BLK) k_pm_jrank(const void *jn_, uint64_t nj, const void *jk_, RankDir jix, const unsigned long long *candoff, unsigned long long *qbase,
+                                                  uint32_t *err) {
+    const Rec<NW> *jn = (const Rec<NW> *)jn_;
     const Rec<NW> *jk = (const Rec<NW> *)jk_;
+    for (uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x; j < nj; j += (uint64_t)gridDim.x * BLK) {
+        const node_t jr = kmer_rank<NW, false>(jk, jix, rec_pure<NW>(jn[j]));
+        if (jr == NODE_NONE) atomicAdd(err, 1u);
+        qbase[j] = jr == NODE_NONE ? 0ull : candoff[jr];
+    }
+}
+// k_cand_expand in node order + q[o] = number of the de-edge in the reference's order: qbase of its junction k-mer (the tile's
+// junction k-mers are numbered like k_pm_junc_write numbered them) + its place among the k-mer's de-edges
+__global__ void __launch_bounds__(BLK) k_pm_cand_expand(const uint8_t *mask, const unsigned long long *toff, const unsigned long long *tjoff, uint64_t D0,
+                                                        const unsigned long long *qbase, unsigned long long *cand, unsigned long long *q) {
+    __shared__ uint32_t scratch[BLK / 64 + 2];
     const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
-    uint32_t c = 0;
+    uint32_t c = 0, nj = 0;
     for (int j = 0; j < CAND_PER; ++j)
-        if (r0 + j < D0) c += cand_of_mask(mask[r0 + j]);
+        if (r0 + j < D0) {
+            const unsigned m = mask[r0 + j];
+            c += cand_of_mask(m);
+            nj += mask_junction(m) ? 1u : 0u;
+        }
     uint32_t tot;
     unsigned long long o = toff[blockIdx.x] + block_excl_scan<uint32_t>(c, scratch, &tot);
+    unsigned long long ji = tjoff[blockIdx.x] + block_excl_scan<uint32_t>(nj, scratch, &tot);
     for (int j = 0; j < CAND_PER; ++j) {
         const uint64_t r = r0 + j;
         if (r >= D0) break;
         const unsigned m = mask[r];
         if (!mask_junction(m)) continue;
-        const node_t jr = kmer_rank<NW, false>(jk, jix, rec_pure<NW>(recs[r]));
-        unsigned long long qq = 0;
-        if (jr == NODE_NONE) atomicAdd(err, 1u);
-        else qq = candoff[jr];
+        unsigned long long qq = qbase[ji++];
         for (unsigned cc = 0; cc < 4; ++cc)
             if (m & (1u << cc)) {
                 cand[o] = (r << 3) | cc;
@@ -372,11 +500,45 @@ __global__ void k_pm_unpack(const unsigned long long *vq, uint64_t C, unsigned l
         one[i] = v & 1ull;
     }
 }
-// k_walk_write: the kept paths, walked in node order, written at their place in the reference's order (woffq / eidxq are indexed by q)
+// 2-bit stream written word by word
+struct PmBitOut {
+    uint64_t *dst;
+    uint64_t cur, pos;  // bits of word (pos >> 6) so far; position in bits
+};
+__device__ __forceinline__ void pm_put(PmBitOut &b, uint64_t v, unsigned nbits) {  // append the low nbits (1..64) of v
+    if (nbits < 64) v &= (1ull << nbits) - 1;
+    const unsigned off = (unsigned)(b.pos & 63);
+    b.cur |= v << off;
+    if (off + nbits >= 64) {
+        b.dst[b.pos >> 6] = b.cur;
+        b.cur = off ? (v >> (64 - off)) : 0ull;
+    }
+    b.pos += nbits;
+}
+template <int NW>
+__device__ __forceinline__ Rec<NW> rec_shr_bits(const Rec<NW> &x, unsigned b) {  // x >> b over all words, b < 64 * NW
+    const unsigned sw = b >> 6, sb = b & 63u;
+    Rec<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int t = 0; t < NW; ++t) {
+            if ((unsigned)t == i + sw) lo = x.w[t];
+            if ((unsigned)t == i + sw + 1) hi = x.w[t];
+        }
+        r.w[i] = sb ? ((lo >> sb) | (hi << (64 - sb))) : lo;
+    }
+    return r;
+}
+// k_walk_write: the kept paths, walked in node order, written at their place in the reference's order (woffq / eidxq are indexed by
+// q). The path is followed like k_pm_walk_len followed it — one jump word per chunk — and the nucleotides of the s <= k steps of a
+// jump are the last s bases of the k-mer at its far end (every step appends one base): one record read per chunk instead of one
+// node-table read per k-mer.
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long *cand, const unsigned long long *q, uint64_t C, const void *recs_, const node_t *succ,
-                                                       unsigned k, const unsigned long long *len, const node_t *first, const node_t *last, const uint8_t *flags,
-                                                       const unsigned long long *woffq, const unsigned long long *eidxq, uint64_t *words,
+                                                       const uint32_t *jmp, unsigned k, const unsigned long long *len, const node_t *first, const node_t *last,
+                                                       const uint8_t *flags, const unsigned long long *woffq, const unsigned long long *eidxq, uint64_t *words,
                                                        unsigned long long *eoffw, unsigned long long *elen, node_t *estart, node_t *eend, uint8_t *eself) {
     const Rec<NW> *recs = (const Rec<NW> *)recs_;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
@@ -385,21 +547,50 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long 
         const unsigned long long cd = cand[i], n = len[i], e = eidxq[qi], wo = woffq[qi];
         const unsigned c = (unsigned)(cd & 3);
         const Rec<NW> x = pm_node_kmer<NW>(recs, cd >> 2, k);
-        uint64_t *dst = words + wo;
+        PmBitOut bo;
+        bo.dst = words + wo;
 #pragma unroll
-        for (int w = 0; w < NW - 1; ++w) dst[w] = x.w[w];
-        uint64_t cur = x.w[NW - 1] | ((uint64_t)c << ((k & 31) << 1));
-        node_t node = first[i];
-        for (unsigned long long p = k + 1; p < n; ++p) {
-            if ((p & 31) == 0) {
-                dst[(p >> 5) - 1] = cur;
-                cur = 0;
-            }
-            const node_t en = succ[node];
-            cur |= (uint64_t)(__ffs(tab_out4(en)) - 1) << ((p & 31) << 1);
-            node = en & TAB_NODE_MASK;
+        for (int w = 0; w < NW - 1; ++w) bo.dst[w] = x.w[w];
+        bo.cur = x.w[NW - 1] | ((uint64_t)c << ((k & 31) << 1));
+        bo.pos = 2ull * (k + 1);
+        if (((k + 1) & 31u) == 0) {  // the start (k+1)-mer fills its last word
+            bo.dst[NW - 1] = bo.cur;
+            bo.cur = 0;
         }
-        dst[(n - 1) >> 5] = cur;
+        node_t node = first[i];
+        unsigned long long p = k + 1;
+        while (p < n) {
+            const uint32_t j = jmp[node];
+            const uint32_t s = j >> 16;
+            const node_t far = (node_t)((long long)node + (long long)(int16_t)(j & 0xFFFFu));
+            if (s) {
+                if (s <= k && p + s <= n) {
+                    const Rec<NW> t = rec_shr_bits<NW>(pm_node_kmer<NW>(recs, far, k), 2 * (k - s));
+                    unsigned rem = 2 * s;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w)
+                        if (rem) {
+                            const unsigned nb = rem < 64 ? rem : 64;
+                            pm_put(bo, t.w[w], nb);
+                            rem -= nb;
+                        }
+                    p += s;
+                    node = far;
+                } else {  // a chain longer than a k-mer (or an inconsistent length): step by step
+                    for (uint32_t t = 0; t < s && p < n; ++t, ++p) {
+                        const node_t en = succ[node];
+                        pm_put(bo, (uint64_t)(__ffs(tab_out4(en)) - 1), 2);
+                        node = en & TAB_NODE_MASK;
+                    }
+                }
+            }
+            if (p >= n) break;
+            const node_t en = succ[node];  // the step into the next chunk
+            pm_put(bo, (uint64_t)(__ffs(tab_out4(en)) - 1), 2);
+            node = en & TAB_NODE_MASK;
+            ++p;
+        }
+        if (bo.pos & 63) bo.dst[bo.pos >> 6] = bo.cur;
         eoffw[e] = wo;
         elen[e] = n;
         estart[e] = cd >> 2;

@@ -81,7 +81,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     std::vector<uint64_t *> masks;
     uint64_t nwin = 0;
     tbegin(ctx, "mark_windows");
-    int rc = mark_windows(ctx, k, masks, &nwin, /*temp_masks=*/true, /*min_len=*/k + 1);
+    int rc = mark_windows(ctx, k, masks, &nwin, /*temp_masks=*/true, /*min_len=*/k + 1, /*wait_words=*/false);  // (the first scan follows the upload piece by piece)
     tend(ctx);
     if (rc) return bail(rc);
     if (!prededupe_applies<NW>(ctx, k, nwin)) return bail(SMX_ROUTE_NA);
@@ -177,19 +177,37 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     if (hipMemsetAsync(d_err, 0, 4, ctx->stream) != hipSuccess || hipMemsetAsync(stats, 0, 16, ctx->stream) != hipSuccess)
         return bail(fail(ctx, SMX_DEVICE_ERROR, "counter reset failed"));
     const uint32_t maxn = P.T / 2;  // winners of a chunk <= its instance capacity
-    const size_t lds = (size_t)(P.T >> 4) * 4 + (size_t)maxn * 4;
+    const size_t lds = (size_t)(P.T >> 4) * 4 + (size_t)maxn * 8 + (size_t)maxn * 4 + (size_t)(maxn >> 4) * 4 + 16;
     if ((rc = set_lds(ctx, k_pm_tab<NW>, lds))) return bail(rc);
+    unsigned long long *prof = nullptr;
+    if (getenv("SMX_DEBUG")) {
+        if ((rc = dalloc(ctx, &prof, 8))) return bail(rc);
+        if (hipMemsetAsync(prof, 0, 64, ctx->stream) != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "counter reset failed"));
+    }
     tbegin(ctx, "pm_tab");
     if (P.nchunks)
         hipLaunchKernelGGL((k_pm_tab<NW>), dim3(std::min<uint32_t>(P.nchunks, 256 * 16)), dim3(BLK), lds, ctx->stream, pw.ix, (const unsigned long long *)P.cinfo,
-                           P.nchunks, maxn, k, tab, jmp, stats, d_err);
+                           P.nchunks, maxn, k, tab, jmp, stats, d_err, prof);
     if (P.ndirty)
         hipLaunchKernelGGL((k_pm_tab_dirty<NW>), dim3(grid_for(P.ndirty)), dim3(BLK), 0, ctx->stream, pw.ix, (uint64_t)P.ndirty, k, tab, jmp, stats, d_err);
+    tend(ctx);
+    tbegin(ctx, "pm_remote");
+    if (P.nclean)
+        hipLaunchKernelGGL((k_pm_remote<NW>), dim3((unsigned)std::min<uint64_t>((2 * P.nclean + PMR_TILE - 1) / PMR_TILE, 256 * 32)), dim3(BLK), 0, ctx->stream, pw.ix,
+                           (uint64_t)(2 * P.nclean), k, tab, d_err);
     tend(ctx);
     if (hipGetLastError() != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "k_pm_tab launch failed"));
     unsigned long long hs[2] = {0, 0};
     if (hipMemcpyAsync(hs, stats, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
         return bail(fail(ctx, SMX_DEVICE_ERROR, "node table pass failed: %s", hipGetErrorString(hipGetLastError())));
+    if (prof) {
+        unsigned long long hp[8];
+        if (hipMemcpy(hp, prof, 64, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[smx] pm_tab: %u chunks (%llu k-mers clean, %llu dirty); 100MHz ticks per chunk: stage %.1f, node table %.1f, chain heads %.1f, jumps %.1f; "
+                            "successors outside their chunk %llu, chain heads per chunk %.1f\n", P.nchunks, (unsigned long long)P.nclean, (unsigned long long)P.ndirty,
+                    hp[4] ? (double)hp[0] / hp[4] : 0.0, hp[4] ? (double)hp[1] / hp[4] : 0.0, hp[4] ? (double)hp[2] / hp[4] : 0.0, hp[4] ? (double)hp[3] / hp[4] : 0.0,
+                    hp[5], hp[4] ? (double)hp[6] / hp[4] : 0.0);
+    }
     if ((hs[0] + hs[1]) & 1) return bail(fail(ctx, SMX_DEVICE_ERROR, "odd number of extension bits (%llu + %llu palindromes)", hs[0], hs[1]));
     ctx->g_ext_bits = hs[0];
     ctx->g_ext_pals = hs[1];

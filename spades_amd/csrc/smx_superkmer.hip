@@ -36,6 +36,9 @@ struct SkmArgs {
     uint64_t nwords;  // words of seq that may be read
     const uint64_t *mask;
     uint64_t g0, G;   // windows starting outside [g0, G) are not part of this run
+    uint64_t vG;      // 0: windows outside [g0, G) count as invalid (a run ends at the range). Else the range is "open": validity is the
+                      // chunk's own ([0, vG)), a run may reach past G and only its START must lie in [g0, G) — the ranges of one batch
+                      // that is scanned piece by piece (no (K+1)-mer across a boundary loses its extension bits)
     unsigned K, m, w;  // w = K - m + 1
     unsigned pshift;   // partition = mixed key >> pshift (32 - log2 of the partition count)
     unsigned long long *cnt;             // [NKEY] super-k-mers per key (phase 0)
@@ -104,18 +107,19 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
     if (a.prof && threadIdx.x == 0) t0 = wall_clock64();
     // stream / mask words of a tile, one per thread, fetched one tile ahead (the loads fly while the previous tile is scanned)
     static_assert(NSW <= BLK && NFW <= BLK, "one staged word per thread");
-    const int64_t mwords = (int64_t)((a.G + 63) >> 6);
+    const int64_t mwords = (int64_t)(((a.vG ? a.vG : a.G) + 63) >> 6);
     auto fetch = [&](uint64_t tile, uint64_t &rs, uint64_t &rm) {
         const int64_t o = (int64_t)(a.g0 + tile * SKM_TP) - 1;
         const int64_t wq0 = o < 0 ? 0 : (o >> 5), mq0 = o < 0 ? 0 : (o >> 6);
         const int i = threadIdx.x;
         rs = (i < NSW && (uint64_t)(wq0 + i) < a.nwords) ? a.seq[wq0 + i] : 0ull;
         uint64_t v = 0;
-        if (i < NFW) {  // valid = mask bit, restricted to [g0, G) (g0 is a multiple of 64; G is cut inside its word)
+        if (i < NFW) {  // valid = mask bit, restricted to [g0, G) (g0 is a multiple of 64; G is cut inside its word) or, open range, to [0, vG)
             v = (mq0 + i < mwords) ? a.mask[mq0 + i] : 0ull;
             const int64_t first = (mq0 + i) << 6;
-            if (first < (int64_t)a.g0) v = 0;
-            if (first + 64 > (int64_t)a.G) v = first >= (int64_t)a.G ? 0ull : (v & ((1ull << (a.G - first)) - 1));
+            const int64_t lo = a.vG ? 0 : (int64_t)a.g0, hi = a.vG ? (int64_t)a.vG : (int64_t)a.G;
+            if (first < lo) v = 0;
+            if (first + 64 > hi) v = first >= hi ? 0ull : (v & ((1ull << (hi - first)) - 1));
         }
         rm = v;
     };
@@ -226,6 +230,8 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
         // The starts are first gathered into a dense list so that every lane of the emitting loop has one.
         {
             uint32_t starts = b8 < SKM_TP ? ((vb >> 1) & brk & 0xFFu) : 0u;
+            if (a.vG && p0 + b8 + 8 > (int64_t)a.G)  // open range: starts at positions >= G belong to the next range
+                starts &= p0 + b8 >= (int64_t)a.G ? 0u : ((1u << (unsigned)((int64_t)a.G - p0 - b8)) - 1u);
             if (starts) {
                 uint32_t at = atomicAdd(&s_nstart, (uint32_t)__popc(starts));
 #pragma unroll

@@ -106,6 +106,8 @@ class ReadKMerSplitter:
         words = np.ascontiguousarray(words, dtype=np.uint64)
         start = np.ascontiguousarray(start, dtype=np.uint64)
         length = np.ascontiguousarray(length, dtype=np.uint32)
+        # (option "async_upload": the call returns before the copy is done — the arrays stay referenced until the reads are cleared)
+        self._keep = getattr(self, "_keep", []) + [(words, start, length)]
         _chk(self.ctx._h, self.ctx.lib.smx_submit_reads_packed(
             self.ctx._h, words.ctypes.data_as(C.POINTER(C.c_uint64)), len(words),
             start.ctypes.data_as(C.POINTER(C.c_uint64)), length.ctypes.data_as(C.POINTER(C.c_uint32)), len(start)))
@@ -126,6 +128,7 @@ class ReadKMerSplitter:
 
     def clear(self):
         _chk(self.ctx._h, self.ctx.lib.smx_reads_clear(self.ctx._h))
+        self._keep = []
 
 
 class KMerDiskStorage:

@@ -175,3 +175,37 @@ def test_count_view_after_the_graph(tmp_path):
     gb.write_gfa(out)
     assert open(out).read() == oracle.build_graph(reads, k, 20)["gfa"]
     gb.ctx.close()
+
+
+def test_async_upload_in_pieces(tmp_path):
+    """option "async_upload": smx_submit_reads_packed returns at once, (start, len) first, the 2-bit stream in pieces; the first scan of
+    the reads follows the pieces, every other path waits for the whole stream — same graph, same count"""
+    import torch
+    from spades_amd import KMerDiskCounter, ReadKMerSplitter
+    from spades_amd.gbuilder import GraphBuilder
+    from spades_amd.kmercount import Context
+    rng = np.random.default_rng(3)
+    n, L, G = 4 << 20, 150, 3_000_000   # 629 M bases = 19.7 M words: the piece path starts at 2^24 words
+    genome = rng.integers(0, 4, G, dtype=np.uint8)
+    pos = rng.integers(0, G - L, n)
+    codes = genome[pos[:, None] + np.arange(L)[None, :]]
+    flat = codes.reshape(-1, 32).astype(np.uint64)
+    words = np.zeros(flat.shape[0] + 8, dtype=np.uint64)
+    words[:-8] = (flat << (2 * np.arange(32, dtype=np.uint64))[None, :]).sum(axis=1, dtype=np.uint64)
+    start = (np.arange(n, dtype=np.uint64) * L)
+    ln = np.full(n, L, dtype=np.uint32)
+    res = {}
+    for mode in (0, 1):
+        ctx = Context()
+        ctx.set_option("async_upload", mode)
+        ctx.set_option("device_links", 2)
+        gb = GraphBuilder(55, 2, ctx)
+        hw = torch.from_numpy(words.view(np.int64)).pin_memory().numpy().view(np.uint64) if mode else words
+        gb.reads.push_back_packed(hw[:-8], start, ln)
+        info = gb.build()
+        assert "pm_tab" in [nm for nm, _ in ctx.timings()]
+        fp = gb.fingerprint_portable()
+        st = KMerDiskCounter(None, gb.reads).Count(20)   # a path that waits for the whole stream
+        res[mode] = (dict(info), fp, st.total_kmers(), hash(st.records().tobytes()))
+        ctx.close()
+    assert res[0] == res[1]
