@@ -778,13 +778,18 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             if (int rc = dalloc(ctx, &vq, C)) return rc;
             Rec<NW> *jrecs, *jk;
             uint8_t *jm;
-            unsigned long long *jstats, *jcnt, *candoff, *qbase;
+            unsigned long long *jstats, *jcnt, *candoff, *qbase, *jrank_of, *coff;
             if (int rc = dalloc(ctx, &jrecs, nj + 1)) return rc;
             if (int rc = dalloc(ctx, &qbase, nj + 1)) return rc;
+            if (int rc = dalloc(ctx, &jrank_of, nj + 1)) return rc;
+            if (int rc = dalloc(ctx, &coff, nj + 2)) return rc;
             tbegin(ctx, "junctions");
             hipLaunchKernelGGL((k_pm_junc_write<NW>), dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const void *)ctx->g_kmers,
-                               (const unsigned long long *)tjoff, D0, (void *)jrecs);
+                               (const unsigned long long *)tjoff, D0, (void *)jrecs, jrank_of);
             HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL((k_pm_cand_counts_node<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, nj, coff);
+            HIPCHK(hipGetLastError());
+            if (int rc = scan_u64(ctx, coff, coff, nj)) return rc;
             tend(ctx);
             {
                 Prefix pf(ctx, "jsort:");
@@ -817,8 +822,8 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             }
             hipLaunchKernelGGL((k_pm_jrank<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, nj, (const void *)jk, jix,
                                (const unsigned long long *)candoff, qbase, d_err);
-            hipLaunchKernelGGL(k_pm_cand_expand, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const unsigned long long *)toff,
-                               (const unsigned long long *)tjoff, D0, (const unsigned long long *)qbase, cand, qidx);
+            hipLaunchKernelGGL((k_pm_cand_expand<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, (const unsigned long long *)jrank_of, nj,
+                               (const unsigned long long *)coff, (const unsigned long long *)qbase, cand, qidx);
             unsigned long long ctot = 0;
             hipError_t e1 = hipGetLastError();
             if (e1 == hipSuccess) e1 = hipMemcpyAsync(&ctot, candoff + nj, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -830,8 +835,8 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         }
         tbegin(ctx, "walk_len");
         if (pm)
-            hipLaunchKernelGGL((k_pm_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C, pm->ix, (const node_t *)tab,
-                               pm->jmp, k, (uint64_t)(2 * D0), len, first, last, d_err);
+            hipLaunchKernelGGL((k_pm_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C, pm->ix, pm->cinfo, pm->cob,
+                               pm->nchunks, (const node_t *)tab, pm->jmp, k, (uint64_t)(2 * D0), len, first, last, flags, d_err);
         else
             hipLaunchKernelGGL((k_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
                                (const void *)ctx->g_kmers, (const node_t *)tab, k, ixk, (uint64_t)(2 * D0), len, first, last, d_err);
@@ -840,8 +845,7 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         tbegin(ctx, "keep");
         if (pm) {
             hipLaunchKernelGGL((k_pm_keep<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (const unsigned long long *)qidx, (uint64_t)C,
-                               (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len, (const node_t *)first, (const node_t *)last,
-                               flags, vq, counters + 1);
+                               (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len, (const node_t *)first, flags, vq, counters + 1);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_pm_unpack, dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)vq, (uint64_t)C, kw, one);  // kw / one: indexed by q
         } else {
@@ -869,12 +873,16 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         if (int rc = dalloc(ctx, &ctx->g_eself, nkept + 1, false)) return rc;
         HIPCHK(hipMemsetAsync(ctx->g_uwords + ktotalw, 0, 64, ctx->stream));
         tbegin(ctx, "walk_write");
-        if (pm)
+        if (pm) {
+            ulonglong4 *erec;
+            if (int rc = dalloc(ctx, &erec, nkept + 1)) return rc;
             hipLaunchKernelGGL((k_pm_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (const unsigned long long *)qidx,
                                (uint64_t)C, (const void *)ctx->g_kmers, (const node_t *)tab, pm->jmp, k, (const unsigned long long *)len, (const node_t *)first,
-                               (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw, (const unsigned long long *)one, ctx->g_uwords,
-                               ctx->g_eoffw, ctx->g_elen, ctx->g_estart, ctx->g_eend, ctx->g_eself);
-        else
+                               (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw, (const unsigned long long *)one, ctx->g_uwords, erec);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_pm_edges, dim3(grid_for(nkept)), dim3(BLK), 0, ctx->stream, (const ulonglong4 *)erec, (uint64_t)nkept, ctx->g_eoffw, ctx->g_elen,
+                               ctx->g_estart, ctx->g_eend, ctx->g_eself);
+        } else
             hipLaunchKernelGGL((k_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
                                (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len,
                                (const node_t *)first, (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw,

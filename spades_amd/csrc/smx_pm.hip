@@ -32,6 +32,9 @@ struct PmIndex {
 struct PmWalk {  // what graph_from_masks (smx_construct.hpp) needs beyond the node table on this route
     PmIndex ix;
     const uint32_t *jmp;
+    const unsigned long long *cinfo;  // [nchunks] base | winners << 40
+    const uint32_t *cob;              // chunk of every 256th record (k_pm_cob)
+    uint32_t nchunks;
 };
 
 // minimizer partition of a k-mer (either orientation: the m-mer keys are those of the canonical m-mers) — the same function the
@@ -335,7 +338,8 @@ __global__ void k_pm_dirty_split(const void *recs_, uint64_t nclean, uint64_t nd
 // ---- the reference's order of the start de-edges ------------------------------------------------------------------------------
 // Junction k-mers (EXT records, byte included) compacted in node order; tiles as k_cand_tiles (which also counts them per tile).
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_pm_junc_write(const uint8_t *mask, const void *recs_, const unsigned long long *tjoff, uint64_t D0, void *out_) {
+__global__ void __launch_bounds__(BLK) k_pm_junc_write(const uint8_t *mask, const void *recs_, const unsigned long long *tjoff, uint64_t D0, void *out_,
+                                                       unsigned long long *jrank_of /* [junctions] node-order rank of every junction k-mer */) {
     __shared__ uint32_t scratch[BLK / 64 + 2];
     const Rec<NW> *recs = (const Rec<NW> *)recs_;
     Rec<NW> *out = (Rec<NW> *)out_;
@@ -349,7 +353,17 @@ __global__ void __launch_bounds__(BLK) k_pm_junc_write(const uint8_t *mask, cons
     uint32_t tot;
     unsigned long long o = tjoff[blockIdx.x] + block_excl_scan<uint32_t>(c, scratch, &tot);
     for (int j = 0; j < CAND_PER; ++j)
-        if (fl & (1u << j)) out[o++] = recs[r0 + j];
+        if (fl & (1u << j)) {
+            jrank_of[o] = r0 + j;
+            out[o++] = recs[r0 + j];
+        }
+}
+// start de-edges of the junction k-mers in node order (the byte of the EXT record is the mask)
+template <int NW>
+__global__ void k_pm_cand_counts_node(const void *jn_, uint64_t nj, unsigned long long *cnt) {
+    const Rec<NW> *jn = (const Rec<NW> *)jn_;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += (uint64_t)gridDim.x * blockDim.x)
+        cnt[i] = cand_of_mask((unsigned)(jn[i].w[NW - 1] & 0xFFu));
 }
 // start de-edges of every sorted junction k-mer (the reference's enumeration: its position in the file, then the de-edge)
 __global__ void k_pm_cand_counts(const uint8_t *jm, uint64_t nj, unsigned long long *cnt) {
@@ -368,28 +382,17 @@ __global__ void __launch_bounds__(BLK) k_pm_jrank(const void *jn_, uint64_t nj, 
         qbase[j] = jr == NODE_NONE ? 0ull : candoff[jr];
     }
 }
-// k_cand_expand in node order + q[o] = number of the de-edge in the reference's order: qbase of its junction k-mer (the tile's
-// junction k-mers are numbered like k_pm_junc_write numbered them) + its place among the k-mer's de-edges
-__global__ void __launch_bounds__(BLK) k_pm_cand_expand(const uint8_t *mask, const unsigned long long *toff, const unsigned long long *tjoff, uint64_t D0,
+// The start de-edges in node order (what k_cand_expand lists from the masks) with q[o] = their number in the reference's order: dense
+// over the junction k-mers — coff: first de-edge of the junction in node order, qbase: in the reference's order; then out bits of the
+// k-mer, out bits of its reverse complement (AddStartDeEdges, debruijn_graph_constructor.hpp:203-226).
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_pm_cand_expand(const void *jn_, const unsigned long long *jrank_of, uint64_t nj, const unsigned long long *coff,
                                                         const unsigned long long *qbase, unsigned long long *cand, unsigned long long *q) {
-    __shared__ uint32_t scratch[BLK / 64 + 2];
-    const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
-    uint32_t c = 0, nj = 0;
-    for (int j = 0; j < CAND_PER; ++j)
-        if (r0 + j < D0) {
-            const unsigned m = mask[r0 + j];
-            c += cand_of_mask(m);
-            nj += mask_junction(m) ? 1u : 0u;
-        }
-    uint32_t tot;
-    unsigned long long o = toff[blockIdx.x] + block_excl_scan<uint32_t>(c, scratch, &tot);
-    unsigned long long ji = tjoff[blockIdx.x] + block_excl_scan<uint32_t>(nj, scratch, &tot);
-    for (int j = 0; j < CAND_PER; ++j) {
-        const uint64_t r = r0 + j;
-        if (r >= D0) break;
-        const unsigned m = mask[r];
-        if (!mask_junction(m)) continue;
-        unsigned long long qq = qbase[ji++];
+    const Rec<NW> *jn = (const Rec<NW> *)jn_;
+    for (uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x; j < nj; j += (uint64_t)gridDim.x * BLK) {
+        const unsigned m = (unsigned)(jn[j].w[NW - 1] & 0xFFu);
+        const unsigned long long r = jrank_of[j];
+        unsigned long long o = coff[j], qq = qbase[j];
         for (unsigned cc = 0; cc < 4; ++cc)
             if (m & (1u << cc)) {
                 cand[o] = (r << 3) | cc;
@@ -404,22 +407,56 @@ __global__ void __launch_bounds__(BLK) k_pm_cand_expand(const uint8_t *mask, con
     }
 }
 
+// cob[b] = chunk that holds record 256 * b (one entry per 256 records): from a record index to its chunk without a search
+__global__ void k_pm_cob(const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t *cob) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += gridDim.x * blockDim.x) {
+        const unsigned long long ci = cinfo[c];
+        const uint64_t base = ci & PM_BASE_MASK, n = ci >> PM_BASE_BITS;
+        for (uint64_t b = (base + 255) >> 8; (b << 8) < base + n; ++b) cob[b] = c;
+    }
+}
+// chunk (id, base) of clean record r
+__device__ __forceinline__ uint32_t pm_chunk_of(const unsigned long long *__restrict__ cinfo, const uint32_t *__restrict__ cob, uint32_t nchunks, uint64_t r,
+                                                uint64_t &base) {
+    uint32_t c = cob[r >> 8];  // the chunk of record 256 * (r >> 8); r lies in it or in one of the next few
+    unsigned long long ci = cinfo[c];
+    while (c + 1 < nchunks) {
+        const unsigned long long nx = cinfo[c + 1];
+        if ((nx & PM_BASE_MASK) > r) break;
+        ci = nx;
+        ++c;
+    }
+    base = ci & PM_BASE_MASK;
+    return c;
+}
+
 // ---- walks ----------------------------------------------------------------------------------------------------------------------
 // k_walk_len on the partition-major numbering: the first node by pm_find, chunks crossed by their jump words
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *cand, uint64_t C, PmIndex ix, const node_t *tab, const uint32_t *jmp, unsigned k,
-                                                     uint64_t n_nodes, unsigned long long *len, node_t *first, node_t *last, uint32_t *err) {
+__global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *cand, uint64_t C, PmIndex ix, const unsigned long long *cinfo, const uint32_t *cob,
+                                                     uint32_t nchunks, const node_t *tab, const uint32_t *jmp, unsigned k, uint64_t n_nodes, unsigned long long *len,
+                                                     node_t *first, node_t *last, uint8_t *flags, uint32_t *err) {
     const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         const unsigned long long cd = cand[i];
         const Rec<NW> x = pm_node_kmer<NW>(recs, cd >> 2, k);
         unsigned yo;
         const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, (unsigned)(cd & 3)), k, yo);
-        const node_t ry = pm_find<NW>(ix, y);
+        // the first k-mer of the path: in the junction's own chunk 19 times in 20 (no minimizer scan, group word and record next to
+        // what the neighbouring lanes read), else through the partition table
+        node_t ry = NODE_NONE;
+        const uint64_t rj = cd >> 3;
+        if (rj < ix.nclean) {
+            uint64_t cbase;
+            const uint32_t cid = pm_chunk_of(cinfo, cob, nchunks, rj, cbase);
+            ry = pm_probe<NW>(recs, ix.meta + (size_t)cid * ix.ngroups, ix.T, cbase, y, rec_hash32<NW>(y));
+        }
+        if (ry == NODE_NONE) ry = pm_find<NW>(ix, y);
         if (ry == NODE_NONE) {
             atomicAdd(err, 1u);
             len[i] = 0;
             first[i] = last[i] = NODE_NONE;
+            flags[i] = 0;
             continue;
         }
         node_t node = (ry << 1) | yo;
@@ -445,49 +482,55 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
         last[i] = node;
         len[i] = node == NODE_NONE ? 0 : k + 1 + steps;
         if (node == NODE_NONE) first[i] = NODE_NONE;
+        // keep iff !(s < RC(s)): the start k-mer (in registers) against the reverse complement of the last one decides unless they are
+        // equal (a hairpin: k_pm_keep walks it); flags: bit 0 keep, bit 2 undecided
+        uint8_t fl = 0;
+        if (node != NODE_NONE) {
+            const int cmp = rec_lex_cmp<NW>(x, pm_node_kmer<NW>(recs, node ^ 1, k));
+            fl = cmp > 0 ? 1 : (cmp == 0 ? 4 : 0);
+        }
+        flags[i] = fl;
     }
 }
-// k_keep with EXT records; the flags / word counts leave in node order, vq[q[i]] = words << 1 | keep in the reference's order
+// The rest of k_keep: the hairpins k_pm_walk_len left undecided (flag bit 2) are compared nucleotide by nucleotide; then, for every
+// de-edge, vq[q[i]] = words << 1 | keep in the reference's order and the count of non-junction k-mers on kept paths.
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_pm_keep(const unsigned long long *cand, const unsigned long long *q, uint64_t C, const void *recs_, const node_t *succ,
-                                                 unsigned k, const unsigned long long *len, const node_t *first, const node_t *last, uint8_t *flags,
-                                                 unsigned long long *vq, unsigned long long *interior) {
+                                                 unsigned k, const unsigned long long *len, const node_t *first, uint8_t *flags, unsigned long long *vq,
+                                                 unsigned long long *interior) {
     __shared__ unsigned long long scratch[BLK / 64 + 2];
     const Rec<NW> *recs = (const Rec<NW> *)recs_;
     unsigned long long inner = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         const unsigned long long n = len[i];
-        int cmp = -1;
-        if (n) {
+        uint8_t fl = flags[i];
+        if (fl & 4) {  // the path leads from the start node A to A^1: RC(s) is itself a path leaving A (see k_keep)
             const unsigned long long cd = cand[i];
-            const node_t A = cd >> 2, L = last[i];
-            const Rec<NW> x0 = pm_node_kmer<NW>(recs, A, k);
-            cmp = rec_lex_cmp<NW>(x0, pm_node_kmer<NW>(recs, L ^ 1, k));
-            if (cmp == 0) {  // hairpin: see k_keep
-                const unsigned long long m = n - k;
-                node_t a = first[i], prev = A;
-                for (unsigned long long t = 1; t < m; ++t) {
-                    prev = a;
-                    a = succ[a] & TAB_NODE_MASK;
-                }
-                const unsigned c2 = 3u - rec_nucl<NW>(pm_node_kmer<NW>(recs, prev, k), 0);
-                const unsigned c1 = (unsigned)(cd & 3);
-                cmp = c1 < c2 ? -1 : (c1 > c2 ? 1 : 0);
-                a = first[i];
-                node_t b = prev ^ 1;
-                for (unsigned long long t = 1; t < m && cmp == 0; ++t) {
-                    const node_t ea = succ[a], eb = succ[b];
-                    const unsigned na = __ffs(tab_out4(ea)) - 1, nb = __ffs(tab_out4(eb)) - 1;
-                    cmp = na < nb ? -1 : (na > nb ? 1 : 0);
-                    a = ea & TAB_NODE_MASK;
-                    b = eb & TAB_NODE_MASK;
-                }
+            const node_t A = cd >> 2;
+            const unsigned long long m = n - k;
+            node_t a = first[i], prev = A;
+            for (unsigned long long t = 1; t < m; ++t) {
+                prev = a;
+                a = succ[a] & TAB_NODE_MASK;
             }
+            const unsigned c2 = 3u - rec_nucl<NW>(pm_node_kmer<NW>(recs, prev, k), 0);
+            const unsigned c1 = (unsigned)(cd & 3);
+            int cmp = c1 < c2 ? -1 : (c1 > c2 ? 1 : 0);
+            a = first[i];
+            node_t b = prev ^ 1;
+            for (unsigned long long t = 1; t < m && cmp == 0; ++t) {
+                const node_t ea = succ[a], eb = succ[b];
+                const unsigned na = __ffs(tab_out4(ea)) - 1, nb = __ffs(tab_out4(eb)) - 1;
+                cmp = na < nb ? -1 : (na > nb ? 1 : 0);
+                a = ea & TAB_NODE_MASK;
+                b = eb & TAB_NODE_MASK;
+            }
+            fl = (uint8_t)((cmp >= 0 ? 1 : 0) | (cmp == 0 ? 2 : 0));
+            flags[i] = fl;
         }
-        const bool keep = n > 0 && cmp >= 0;
-        flags[i] = (uint8_t)((keep ? 1 : 0) | ((n > 0 && cmp == 0) ? 2 : 0));
+        const bool keep = fl & 1;
         vq[q[i]] = keep ? ((((n + 31) / 32) << 1) | 1ull) : 0ull;
-        if (keep) inner += cmp == 0 ? (n - k - 1) / 2 : (n - k - 1);
+        if (keep) inner += (fl & 2) ? (n - k - 1) / 2 : (n - k - 1);  // a self-conjugate path meets every rank twice
     }
     unsigned long long tot;
     block_excl_scan<unsigned long long>(inner, scratch, &tot);
@@ -539,7 +582,7 @@ template <int NW>
 __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long *cand, const unsigned long long *q, uint64_t C, const void *recs_, const node_t *succ,
                                                        const uint32_t *jmp, unsigned k, const unsigned long long *len, const node_t *first, const node_t *last,
                                                        const uint8_t *flags, const unsigned long long *woffq, const unsigned long long *eidxq, uint64_t *words,
-                                                       unsigned long long *eoffw, unsigned long long *elen, node_t *estart, node_t *eend, uint8_t *eself) {
+                                                       ulonglong4 *erec /* [edges]: word offset, length, start node, end node | self << 63 */) {
     const Rec<NW> *recs = (const Rec<NW> *)recs_;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         if (!(flags[i] & 1)) continue;
@@ -591,11 +634,17 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long 
             ++p;
         }
         if (bo.pos & 63) bo.dst[bo.pos >> 6] = bo.cur;
-        eoffw[e] = wo;
-        elen[e] = n;
-        estart[e] = cd >> 2;
-        eend[e] = last[i];
-        eself[e] = (flags[i] >> 1) & 1;
+        erec[e] = make_ulonglong4(wo, n, cd >> 2, last[i] | ((unsigned long long)((flags[i] >> 1) & 1) << 63));  // one 32-byte store; k_pm_edges spreads it
+    }
+}
+__global__ void k_pm_edges(const ulonglong4 *erec, uint64_t ne, unsigned long long *eoffw, unsigned long long *elen, node_t *estart, node_t *eend, uint8_t *eself) {
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (uint64_t)gridDim.x * blockDim.x) {
+        const ulonglong4 r = erec[e];
+        eoffw[e] = r.x;
+        elen[e] = r.y;
+        estart[e] = r.z;
+        eend[e] = r.w & ~(1ull << 63);
+        eself[e] = (uint8_t)(r.w >> 63);
     }
 }
 

@@ -174,6 +174,13 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     if ((rc = dalloc(ctx, &tab, 2 * D0 + 2))) return bail(rc);
     if ((rc = dalloc(ctx, &jmp, 2 * D0 + 2))) return bail(rc);
     pw.jmp = jmp;
+    uint32_t *cob;
+    if ((rc = dalloc(ctx, &cob, (size_t)(D0 >> 8) + 2))) return bail(rc);
+    if (hipMemsetAsync(cob, 0, ((size_t)(D0 >> 8) + 2) * 4, ctx->stream) != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "chunk map reset failed"));
+    if (P.nchunks) hipLaunchKernelGGL(k_pm_cob, dim3(std::min<uint32_t>((P.nchunks + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)P.cinfo, P.nchunks, cob);
+    pw.cinfo = P.cinfo;
+    pw.cob = cob;
+    pw.nchunks = P.nchunks;
     if (hipMemsetAsync(d_err, 0, 4, ctx->stream) != hipSuccess || hipMemsetAsync(stats, 0, 16, ctx->stream) != hipSuccess)
         return bail(fail(ctx, SMX_DEVICE_ERROR, "counter reset failed"));
     const uint32_t maxn = P.T / 2;  // winners of a chunk <= its instance capacity
