@@ -46,7 +46,15 @@ enum { /* which k-mers a read contributes */
  * Replaces the pair (workdir, KMerDiskCounter object): kmer_index_builder.hpp:284-304.
  * device = HIP device ordinal; hbm_budget_bytes = 0 -> use what the device has free. */
 int smx_create(smx_ctx **out, int device, size_t hbm_budget_bytes);
+/* Device memory after smx_destroy: the context's arena (one virtual range, physically backed as far as it was ever used) is NOT
+ * unmapped — it is parked for the next context of this process on the same device with the same budget class (mapping costs
+ * ~17 ms per GiB; tearing a range down has crashed inside the HIP runtime). At most one arena per device is parked: a context with
+ * another budget class, or the next destroy, tears the parked one down. SMX_ARENA_POOL=0 in the environment unmaps at every destroy. */
 void smx_destroy(smx_ctx *ctx);
+/* Gives the free physical memory at the two ends of the context's arena back to the device now (whole 512 MiB chunks), e.g. before
+ * another allocator of the same process (a framework's caching allocator) needs the room; *bytes_returned may be NULL. The context
+ * stays usable; what it needs again is mapped again. */
+int smx_trim(smx_ctx *ctx, size_t *bytes_returned);
 const char *smx_last_error(const smx_ctx *ctx);
 const char *smx_version(void);
 /* Options. Behaviour switches of the reference's spades-core Construction stage (defaults reproduce spades-gbuilder):

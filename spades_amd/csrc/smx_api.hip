@@ -110,6 +110,14 @@ void smx_destroy(smx_ctx *ctx) {
     delete ctx;
 }
 
+int smx_trim(smx_ctx *ctx, size_t *bytes_returned) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = arena_trim(ctx);
+    if (bytes_returned) *bytes_returned = n;
+    return SMX_OK;
+}
+
 const char *smx_last_error(const smx_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
@@ -177,9 +185,6 @@ static int submit_packed_async(smx_ctx *ctx, const uint64_t *words, uint64_t n_w
     c.n_reads = n_reads;
     c.n_bases = n_words * 32;  // until the check says how far the reads really go
     unsigned long long *d_ext = nullptr;
-    if (int rc = dalloc(ctx, &c.d_words, n_words + 8, false)) return rc;
-    if (int rc = dalloc(ctx, &c.d_start, n_reads, false)) return rc;
-    if (int rc = dalloc(ctx, &c.d_len, n_reads, false)) return rc;
     auto bail = [&](int code) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         if (c.ev_meta) (void)hipEventDestroy(c.ev_meta);
@@ -191,6 +196,9 @@ static int submit_packed_async(smx_ctx *ctx, const uint64_t *words, uint64_t n_w
         arena_put(ctx, d_ext);
         return code;
     };
+    if (int rc = dalloc(ctx, &c.d_words, n_words + 8, false)) return bail(rc);
+    if (int rc = dalloc(ctx, &c.d_start, n_reads, false)) return bail(rc);
+    if (int rc = dalloc(ctx, &c.d_len, n_reads, false)) return bail(rc);
     if (int rc = dalloc(ctx, &d_ext, 2, false)) return bail(rc);
     hipStream_t cs = ctx->copy_stream;
     hipError_t e = hipHostMalloc((void **)&c.h_ext, 16, hipHostMallocDefault);
@@ -240,17 +248,17 @@ int smx_submit_reads_packed(smx_ctx *ctx, const uint64_t *words, uint64_t n_word
     c.n_words = n_words;
     c.n_reads = n_reads;
     unsigned long long *d_ext;
-    if (int rc = dalloc(ctx, &c.d_words, n_words + 8, false)) return rc;
-    if (int rc = dalloc(ctx, &c.d_start, n_reads, false)) return rc;
-    if (int rc = dalloc(ctx, &c.d_len, n_reads, false)) return rc;
-    if (int rc = dalloc(ctx, &d_ext, 2)) return rc;
-    auto bail = [&](int code) {
+    auto bail = [&](int code) {  // (every early return: the long-lived blocks taken so far go back)
         arena_put(ctx, c.d_words);
         arena_put(ctx, c.d_start);
         arena_put(ctx, c.d_len);
         free_temps(ctx);
         return code;
     };
+    if (int rc = dalloc(ctx, &c.d_words, n_words + 8, false)) return bail(rc);
+    if (int rc = dalloc(ctx, &c.d_start, n_reads, false)) return bail(rc);
+    if (int rc = dalloc(ctx, &c.d_len, n_reads, false)) return bail(rc);
+    if (int rc = dalloc(ctx, &d_ext, 2)) return bail(rc);
     hipError_t e = hipMemsetAsync(c.d_words + n_words, 0, 64, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_ext, 0, 16, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c.d_words, words, n_words * 8, hipMemcpyHostToDevice, ctx->stream);
@@ -292,11 +300,18 @@ int smx_submit_reads_ascii(smx_ctx *ctx, const char *bases, const uint64_t *offs
     c.n_words = (nbases + 31) / 32 + 1;
     char *d_bases;
     unsigned long long *d_off;
-    if (int rc = dalloc(ctx, &d_bases, nbases + 1)) return rc;
-    if (int rc = dalloc(ctx, &d_off, n_reads + 1)) return rc;
-    if (int rc = dalloc(ctx, &c.d_words, c.n_words + 8, false)) return rc;
-    if (int rc = dalloc(ctx, &c.d_start, n_reads, false)) return rc;
-    if (int rc = dalloc(ctx, &c.d_len, n_reads, false)) return rc;
+    auto bail = [&](int code) {
+        arena_put(ctx, c.d_words);
+        arena_put(ctx, c.d_start);
+        arena_put(ctx, c.d_len);
+        free_temps(ctx);
+        return code;
+    };
+    if (int rc = dalloc(ctx, &d_bases, nbases + 1)) return bail(rc);
+    if (int rc = dalloc(ctx, &d_off, n_reads + 1)) return bail(rc);
+    if (int rc = dalloc(ctx, &c.d_words, c.n_words + 8, false)) return bail(rc);
+    if (int rc = dalloc(ctx, &c.d_start, n_reads, false)) return bail(rc);
+    if (int rc = dalloc(ctx, &c.d_len, n_reads, false)) return bail(rc);
     std::vector<unsigned long long> rel(n_reads + 1);
     for (uint64_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - base0;
     if (nbases) HIPCHK(hipMemcpyAsync(d_bases, bases + base0, nbases, hipMemcpyHostToDevice, ctx->stream));

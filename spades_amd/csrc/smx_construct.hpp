@@ -1342,25 +1342,38 @@ int run_coverage(smx_ctx *ctx) {
         const unsigned sv_K = ctx->K;
         std::vector<uint64_t> sv_boff = ctx->bucket_off;
         ctx->d_result = nullptr;
-        if (int rc = count_reads<NW>(ctx, K1, SMX_MODE_CANONICAL, B)) return rc;
-        if (ctx->result_on_host) {
-            clear_result(ctx);
+        auto restore = [&]() {  // the count-result view of the context describes the graph's k-mer file again (every way out of here)
             ctx->d_result = sv_res;
             ctx->n_records = sv_n;
             ctx->K = sv_K;
             ctx->bucket_off = sv_boff;
+        };
+        if (int rc = count_reads<NW>(ctx, K1, SMX_MODE_CANONICAL, B)) {
+            free_temps(ctx);
+            clear_result(ctx);
+            restore();
+            return rc;
+        }
+        if (ctx->result_on_host) {
+            clear_result(ctx);
+            restore();
             return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the coverage pass needs the (k+1)-mer file resident next to the graph: not enough HBM");
         }
-        if (ctx->n_records != D1) return fail(ctx, SMX_DEVICE_ERROR, "recount of the (k+1)-mers gave %llu records, the graph was built from %llu",
-                                              (unsigned long long)ctx->n_records, (unsigned long long)D1);
+        if (ctx->n_records != D1) {
+            const unsigned long long got = ctx->n_records;
+            free_temps(ctx);
+            clear_result(ctx);
+            restore();
+            return fail(ctx, SMX_DEVICE_ERROR, "recount of the (k+1)-mers gave %llu records, the graph was built from %llu", got, (unsigned long long)D1);
+        }
         ctx->g_kpo = ctx->d_result_buf;
         ctx->g_kpoboff = ctx->bucket_off;
         ctx->d_result_buf = nullptr;
-        if (int rc = adopt_result(ctx, &ctx->g_kpo, (size_t)D1 * NW * 8)) return rc;
-        ctx->d_result = sv_res;
-        ctx->n_records = sv_n;
-        ctx->K = sv_K;
-        ctx->bucket_off = sv_boff;
+        if (int rc = adopt_result(ctx, &ctx->g_kpo, (size_t)D1 * NW * 8)) {
+            restore();
+            return rc;
+        }
+        restore();
         ctx->n_instances = 0;
         free_temps(ctx);
     }

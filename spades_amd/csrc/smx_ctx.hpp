@@ -98,7 +98,7 @@ struct smx_ctx {
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
     int64_t opt_spill = -1;  // sorted runs to host memory + merge by bucket ranges: -1 when the accumulated set outgrows HBM, 1 always (tests)
     int64_t opt_verify_lookups = 0;  // 1: rank lookups of k-mers that are known to be present still compare the record
-    int64_t opt_dir_slots = -1;        // rank directory: slots per record (-1: 1)
+    int64_t opt_dir_slots = -1;        // rank directory: slots per record (-1: 2, or 1 next to a resident (k+1)-mer file)
     int64_t opt_ext_presort = 1;       // ext route: merge the survivors of cut partitions before the sort (0: after it — the general merge; tests)
     int64_t opt_ext_route = -1;        // construction: k-mers AND their extension masks from one count of the reads (-1 when it applies, 0 never, 1 = -1)
     int64_t opt_kmers_from_reads = 1;  // construction: k-mer file counted from the resident reads (0: derived from the (k+1)-mer file)
@@ -140,7 +140,6 @@ struct smx_ctx {
     bool g_links_dev = false;   // link records / vertices live in g_lrecs / g_vstart (else gh holds them)
     bool g_host_valid = false;  // gh mirrors the device graph
     bool g_dev_valid = false;   // the device arrays above describe the graph (false after a host-side edge sort until re-uploaded)
-    void *g_kpo_block = nullptr;  // allocation behind g_kpo
     uint64_t g_tip_kmers = 0, g_tips = 0;  // early tip clipper: k-mers isolated, tips removed
     uint64_t g_at_edges = 0, g_at_tip_kmers = 0;  // early A/T remover: length-1 edges marked, tip k-mers isolated
     std::vector<uint64_t> g_cov_hist;  // [c] = canonical (k+1)-mers with multiplicity c (after smx_graph_fill_coverage)
@@ -202,6 +201,19 @@ inline bool arena_pool_enabled() {
     return !(e && !strcmp(e, "0"));
 }
 
+// unmap and release every chunk, free the address range
+inline void arena_teardown(Arena &A) {
+    if (!A.vmm) return;
+    (void)hipDeviceSynchronize();
+    for (size_t ci = 0; ci < A.chunk.size(); ++ci)
+        if (A.chunk[ci].mapped) {
+            (void)hipMemUnmap(A.base + ci * A.gran, A.gran);
+            (void)hipMemRelease(A.chunk[ci].h);
+        }
+    (void)hipMemAddressFree(A.base, A.reserved);
+    A = Arena();
+}
+
 bool arena_vmm_init(smx_ctx *ctx) {
     Arena &A = ctx->arena;
     if (A.tried) return A.vmm;
@@ -223,6 +235,16 @@ bool arena_vmm_init(smx_ctx *ctx) {
                 A.last_err.clear();
                 return true;
             }
+        // a parked arena of this device that does not fit this context would keep its physical memory for nothing: it is torn down
+        // before a new one is made (the pool never holds more than one arena per device)
+        for (size_t i = 0; i < pool.size();)
+            if (pool[i].device == ctx->device) {
+                arena_teardown(pool[i].a);
+                pool.erase(pool.begin() + i);
+            } else {
+                ++i;
+            }
+        (void)hipMemGetInfo(&free_b, &total_b);
     }
     // Every physical chunk has the same size: on this stack hipMemSetAccess rejects a mapping whose size differs from its
     // neighbour's in many combinations (tools/vmm_probe.hip: 2 MiB, 6 MiB, 64 MiB or 1 GiB chunks back to back all work, mixed
@@ -443,25 +465,32 @@ void arena_shrink(smx_ctx *ctx, void *p, size_t bytes) {
 void arena_release(smx_ctx *ctx) {
     Arena &A = ctx->arena;
     if (A.vmm) {
-        if (!A.live.empty()) return;
+        if (!A.live.empty()) {  // somebody still holds a block (a bug of the caller's bookkeeping): the range cannot go, say so
+            size_t bytes = 0;
+            for (auto &b : A.live) bytes += b.second;
+            fprintf(stderr, "[smx] smx_destroy: %zu device blocks (%zu bytes) are still handed out; the context's device arena is left mapped\n", A.live.size(), bytes);
+            return;
+        }
         (void)hipDeviceSynchronize();
         if (arena_pool_enabled()) {
             // (a budgeted context whose reserved size was cut by the free memory of its day does not match its class: torn down below)
             const size_t cls = ctx->budget ? (ctx->budget + A.gran - 1) / A.gran * A.gran + A.gran : 0;
             if (cls == 0 || cls == A.reserved) {
                 std::lock_guard<std::mutex> lk(arena_pool_mutex());
-                arena_pool().push_back(PooledArena{ctx->device, cls, std::move(A)});
+                auto &pool = arena_pool();
+                for (size_t i = 0; i < pool.size();)  // one parked arena per device: an older one of another class gives its memory back now
+                    if (pool[i].device == ctx->device) {
+                        arena_teardown(pool[i].a);
+                        pool.erase(pool.begin() + i);
+                    } else {
+                        ++i;
+                    }
+                pool.push_back(PooledArena{ctx->device, cls, std::move(A)});
                 A = Arena();
                 return;
             }
         }
-        for (size_t ci = 0; ci < A.chunk.size(); ++ci)
-            if (A.chunk[ci].mapped) {
-                (void)hipMemUnmap(A.base + ci * A.gran, A.gran);
-                (void)hipMemRelease(A.chunk[ci].h);
-            }
-        (void)hipMemAddressFree(A.base, A.reserved);
-        A = Arena();
+        arena_teardown(A);
         return;
     }
     for (auto &b : ctx->arena_free) {
@@ -469,6 +498,62 @@ void arena_release(smx_ctx *ctx) {
         (void)hipFree(b.first);
     }
     ctx->arena_free.clear();
+}
+// Give whole free chunks at the two marks back to the device (smx_trim): the temporaries' end shrinks down to its highest live
+// block, the long-lived end up to its lowest one. Returns the bytes unmapped.
+size_t arena_trim(smx_ctx *ctx) {
+    Arena &A = ctx->arena;
+    if (!A.vmm) {
+        size_t freed = 0;
+        for (auto &b : ctx->arena_free) {
+            freed += b.second;
+            ctx->arena_size.erase(b.first);
+            (void)hipFree(b.first);
+        }
+        ctx->arena_free.clear();
+        return freed;
+    }
+    (void)hipDeviceSynchronize();
+    size_t freed = 0;
+    for (;;) {  // bottom region: the free block that ends at the mark
+        auto it = A.free_blocks.lower_bound(A.lo);
+        if (it == A.free_blocks.begin()) break;
+        auto pv = std::prev(it);
+        if (pv->first + pv->second != A.lo) break;
+        const size_t keep_to = (pv->first + A.gran - 1) / A.gran * A.gran;  // first chunk boundary inside the free block
+        if (keep_to >= A.lo) break;
+        const size_t off = pv->first, sz = pv->second;
+        A.free_blocks.erase(pv);
+        if (keep_to > off) A.free_blocks[off] = keep_to - off;
+        (void)sz;
+        for (size_t ci = keep_to / A.gran; ci < A.lo / A.gran; ++ci)
+            if (A.chunk[ci].mapped) {
+                (void)hipMemUnmap(A.base + ci * A.gran, A.gran);
+                (void)hipMemRelease(A.chunk[ci].h);
+                A.chunk[ci].mapped = false;
+                freed += A.gran;
+            }
+        A.lo = keep_to;
+        break;
+    }
+    for (;;) {  // top region: the free block that starts at the mark
+        auto it = A.free_blocks.find(A.hi);
+        if (it == A.free_blocks.end()) break;
+        const size_t end = it->first + it->second, keep_from = end / A.gran * A.gran;  // last chunk boundary inside the free block
+        if (keep_from <= A.hi) break;
+        A.free_blocks.erase(it);
+        if (end > keep_from) A.free_blocks[keep_from] = end - keep_from;
+        for (size_t ci = A.hi / A.gran; ci < keep_from / A.gran; ++ci)
+            if (A.chunk[ci].mapped) {
+                (void)hipMemUnmap(A.base + ci * A.gran, A.gran);
+                (void)hipMemRelease(A.chunk[ci].h);
+                A.chunk[ci].mapped = false;
+                freed += A.gran;
+            }
+        A.hi = keep_from;
+        break;
+    }
+    return freed;
 }
 // HBM still obtainable for new allocations (bytes): free blocks of the arena + what can still be mapped between its two marks, as
 // far as the device has it, or what is left of the caller's budget

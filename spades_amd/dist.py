@@ -20,6 +20,31 @@ from .kmercount import Context, _chk
 XCHG_LIMIT = 1 << 27  # int64 elements (1 GiB) per pair and round
 
 
+class CollectiveFailure(RuntimeError):
+    """A local step failed on SOME rank: raised on EVERY rank (code = the worst code any rank saw), so that nobody is left waiting
+    in the next collective. .code carries the reference's exit code (68 = memory limit exceeded, ...)."""
+
+    def __init__(self, code: int, what: str, cause: Exception = None):
+        super().__init__(f"{what}: " + (str(cause) if cause is not None else f"another rank failed with code {code}"))
+        self.code = code
+
+
+def _guarded(dev, what: str, fn, *args):
+    """run a rank-local step between two collectives; every rank then learns (one tiny all-reduce) whether all of them got through"""
+    err, res = None, None
+    try:
+        res = fn(*args)
+    except Exception as e:  # noqa: BLE001 — whatever it is, the other ranks must hear of it
+        err = e
+    code = 0 if err is None else int(getattr(err, "code", 1) or 1)
+    t = torch.tensor([code], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    worst = int(t.item())
+    if worst:
+        raise CollectiveFailure(worst, what, err)
+    return res
+
+
 def rank_first_bucket(num_buckets: int, world: int, rank: int) -> int:
     return (rank * num_buckets + world - 1) // world
 
@@ -38,6 +63,9 @@ class GpuEngine:
 
     def alloc(self, n_words: int, dev):
         return torch.empty(max(n_words, 1), dtype=torch.int64, device=dev)
+
+    def trim(self) -> int:
+        return self.ctx.trim()
 
     def extract_count(self, K: int) -> int:
         n = C.c_uint64()
@@ -179,7 +207,7 @@ def _exchange(engine, send: torch.Tensor, counts, wpr: int, rank: int, world: in
     rcounts = [int(c) for c in rcv_t.tolist()]
     n_recv = sum(rcounts)
     # pool: the receive buffer comes from the engine's own HBM pool and is consumed by the count that follows
-    recv = (engine.alloc_recv if pool and hasattr(engine, "alloc_recv") else engine.alloc)(n_recv * wpr, dev)
+    recv = _guarded(dev, "receive buffer", engine.alloc_recv if pool and hasattr(engine, "alloc_recv") else engine.alloc, n_recv * wpr, dev)
     soff = [0]
     for c in counts:
         soff.append(soff[-1] + c * wpr)
@@ -221,19 +249,24 @@ def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
     """One step of the sharded path on this rank. Returns the owner-side result dict of the engine
     (+ 'sent'/'received' record counts). Collective: every rank must call it."""
     nw = (K + 31) // 32
-    n_local = engine.extract_count(K)
-    if hasattr(engine, "extract_partition_owned"):
-        # the library sizes the send buffer itself: what its local pre-dedupe leaves, not one record per window instance
-        send, counts = engine.extract_partition_owned(K, nb, world, dev)
-    else:
-        send = engine.alloc(n_local * nw, dev)
-        counts = engine.extract_partition(K, nb, world, send, n_local)
+
+    def local_extract():
+        n_local = engine.extract_count(K)
+        if hasattr(engine, "extract_partition_owned"):
+            # the library sizes the send buffer itself: what its local pre-dedupe leaves, not one record per window instance
+            send, counts = engine.extract_partition_owned(K, nb, world, dev)
+        else:
+            send = engine.alloc(n_local * nw, dev)
+            counts = engine.extract_partition(K, nb, world, send, n_local)
+        return n_local, send, counts
+
+    n_local, send, counts = _guarded(dev, "extract + partition by owner", local_extract)
     n_sent = sum(counts)  # < n_local when the engine pre-dedupes its shard before the exchange
     recv, n_recv = _exchange(engine, send, counts, nw, rank, world, dev, pool=True)
     del send
     if hasattr(engine, "extract_release"):
         engine.extract_release()  # room for the owner-side count
-    res = engine.count_records(K, nb, recv, n_recv)
+    res = _guarded(dev, "owner-side count", engine.count_records, K, nb, recv, n_recv)
     res["sent"], res["received"] = n_sent, n_recv
     res["instances"] = n_local  # k-mer instances extracted from this rank's reads
     return res
@@ -284,27 +317,41 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
     if route == "ext" and not ext:
         raise ValueError(f"k={k}: the one-exchange route needs 8 spare bits in the k-mer record")
     n_kpo, kpo_sizes, kpo_mine, bits, pals = 0, [0] * nb, None, 0, 0
-    if coverage or not ext:
+
+    def count_kpomers():
         res = sharded_count(engine, K1, nb, rank, world, dev)
-        n_kpo = res["distinct"]
-        kpo_sizes = res["bucket_sizes"]
-        kpo_mine = engine.result_tensor(n_kpo * nw, dev) if coverage else None  # the count result is consumed by the next steps
+        return res["distinct"], res["bucket_sizes"], (engine.result_tensor(res["distinct"] * nw, dev) if coverage else None)
+
+    if coverage or not ext:
+        n_kpo, kpo_sizes, kpo_mine = count_kpomers()  # (the count result is consumed by the next steps)
     if ext:
-        send, counts = engine.extract_kmers_ext_owned(k, nb, world, dev)
-        recv, n_recv = _exchange(engine, send, counts, nw, rank, world, dev, pool=True)
-        del send
-        if hasattr(engine, "extract_release"):
-            engine.extract_release()
-        n_kmers, ksizes, bits, pals = engine.shard_from_ext(k, nb, world, rank, recv, n_recv)
-        del recv
-    else:
+        try:
+            send, counts = _guarded(dev, "k-mers with extension bytes, grouped by owner", engine.extract_kmers_ext_owned, k, nb, world, dev)
+            recv, n_recv = _exchange(engine, send, counts, nw, rank, world, dev, pool=True)
+            del send
+            if hasattr(engine, "extract_release"):
+                engine.extract_release()
+            n_kmers, ksizes, bits, pals = _guarded(dev, "owner-side shard from the extension records", engine.shard_from_ext, k, nb, world, rank, recv, n_recv)
+            del recv
+        except CollectiveFailure as e:
+            # one rank's distinct k-mers did not fit where the one-exchange route needs them: EVERY rank heard of it (same exception
+            # everywhere) and all take the other route together — the single-GPU library falls back the same way (SMX_ROUTE_NA)
+            if e.code != _lib.MEMORY_LIMIT_EXCEEDED or route == "ext":
+                raise
+            ext = False
+            send = recv = None
+            if hasattr(engine, "extract_release"):
+                engine.extract_release()
+            if not coverage:
+                n_kpo, kpo_sizes, kpo_mine = count_kpomers()
+    if not ext:
         # 2. extension updates -> owners of the k-mers
-        upd = engine.alloc(2 * n_kpo * (nw + 1), dev)
-        ucounts = engine.shard_updates(k, nb, world, upd, 2 * n_kpo)
+        upd = _guarded(dev, "update buffer", engine.alloc, 2 * n_kpo * (nw + 1), dev)
+        ucounts = _guarded(dev, "extension updates grouped by owner", engine.shard_updates, k, nb, world, upd, 2 * n_kpo)
         recv, n_recv = _exchange(engine, upd, ucounts, nw + 1, rank, world, dev)
         del upd
         # 3. owner side
-        n_kmers, ksizes = engine.shard_build(k, nb, world, rank, recv, n_recv)
+        n_kmers, ksizes = _guarded(dev, "owner-side k-mer shard + masks", engine.shard_build, k, nb, world, rank, recv, n_recv)
         del recv
     # 4. gather {k-mers, masks}
     me = torch.tensor([n_kmers, n_kpo, bits, pals] + ksizes + kpo_sizes, dtype=torch.int64, device=dev)
@@ -317,20 +364,27 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
     g_psizes = [sum(int(e[4 + nb + b]) for e in every) for b in range(nb)]
     if ext:  # every non-palindromic (k+1)-mer set two extension bits somewhere in the graph, a palindromic one a single bit
         tot = sum(int(e[2]) + int(e[3]) for e in every)
-        assert tot % 2 == 0, "odd number of extension bits over all shards"
+        if tot % 2:
+            raise RuntimeError("odd number of extension bits over all shards")
         n_kpo_all = tot // 2
-        assert not coverage or n_kpo_all == sum(kpo_per_rank), "the masks and the (k+1)-mer count disagree"
+        if coverage and n_kpo_all != sum(kpo_per_rank):
+            raise RuntimeError(f"the masks ({n_kpo_all} (k+1)-mers) and the (k+1)-mer count ({sum(kpo_per_rank)}) disagree")
     else:
         n_kpo_all = sum(kpo_per_rank)
-    my_k = engine.alloc(n_kmers * nw, dev)
-    my_m = engine.alloc_bytes(n_kmers, dev)
-    engine.shard_copy(my_k, my_m)
+    def my_shard():
+        if hasattr(engine, "trim"):
+            engine.trim()  # the library's arena gives its free physical memory back before torch allocates the gathered structure
+        a, b = engine.alloc(n_kmers * nw, dev), engine.alloc_bytes(n_kmers, dev)
+        engine.shard_copy(a, b)
+        return a, b
+
+    my_k, my_m = _guarded(dev, "copy of the owner-side shard", my_shard)
     full_k = _gather_shards(engine, my_k, n_kmers, kmers_per_rank, nw, rank, world, dev, engine.alloc)
     full_m = _gather_shards(engine, my_m, n_kmers, kmers_per_rank, 1, rank, world, dev, engine.alloc_bytes)
     del my_k, my_m
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()
-    info = engine.build_graph_from_kmers(k, nb, full_k, full_m, sum(kmers_per_rank), g_ksizes, n_kpo_all)
+    info = _guarded(dev, "graph from the gathered k-mers + masks", engine.build_graph_from_kmers, k, nb, full_k, full_m, sum(kmers_per_rank), g_ksizes, n_kpo_all)
     del full_k, full_m
     if coverage:
         full_p = _gather_shards(engine, kpo_mine, n_kpo, kpo_per_rank, nw, rank, world, dev, engine.alloc)

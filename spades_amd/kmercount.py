@@ -51,6 +51,12 @@ class Context:
     def set_option(self, key: str, value: int):
         _chk(self._h, self.lib.smx_set_option(self._h, key.encode(), int(value)))
 
+    def trim(self) -> int:
+        """smx_trim: free physical memory at the ends of the context's device arena goes back to the device; returns the bytes"""
+        n = C.c_size_t()
+        _chk(self._h, self.lib.smx_trim(self._h, C.byref(n)))
+        return int(n.value)
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.smx_destroy(self._h)

@@ -6,6 +6,7 @@
 //   is the concatenation of the rank outputs: KMerDiskStorage::merge, kmer_index_builder.hpp:190-203).
 // The ncclUniqueId travels through a file in the work directory. Input files are dealt out to the ranks round-robin.
 #pragma once
+#include <signal.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -211,21 +212,50 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
 
 // fork one process per GPU (nothing of HIP has been touched yet in this process) and wait for them
 inline int run_sharded(int world, unsigned K, const std::string &workdir, const std::vector<std::string> &input) {
+    // a rank that leaves between two collectives (unreadable input, a failed count, a write error) would leave the others waiting in
+    // the next one for ever: what can be checked before the fork is checked here, and the first rank that fails takes the others down
+    for (const std::string &f : input) {
+        FILE *t = fopen(f.c_str(), "rb");
+        if (!t) {
+            fprintf(stderr, "File %s doesn't exist or can't be read!\n", f.c_str());
+            return SMX_INPUT_FILE_NOT_FOUND;
+        }
+        fclose(t);
+    }
     mkdir(workdir.c_str(), 0777);
     unlink((workdir + "/.smx_nccl_id").c_str());
     std::vector<pid_t> kids;
     for (int r = 0; r < world; ++r) {
         const pid_t pid = fork();
-        if (pid < 0) return SMX_DEVICE_ERROR;
+        if (pid < 0) {
+            for (pid_t k : kids) kill(k, SIGKILL);
+            for (pid_t k : kids) waitpid(k, nullptr, 0);
+            return SMX_DEVICE_ERROR;
+        }
         if (pid == 0) _exit(sharded_rank_main(r, world, K, workdir, input));
         kids.push_back(pid);
     }
     int rc = 0;
-    for (pid_t pid : kids) {
+    size_t left = kids.size();
+    while (left) {
         int st = 0;
-        waitpid(pid, &st, 0);
+        const pid_t pid = waitpid(-1, &st, 0);
+        if (pid < 0) break;
+        bool ours = false;
+        for (pid_t &k : kids)
+            if (k == pid) {
+                k = -1;
+                ours = true;
+            }
+        if (!ours) continue;
+        --left;
         const int code = WIFEXITED(st) ? WEXITSTATUS(st) : SMX_DEVICE_ERROR;
-        if (code && !rc) rc = code;
+        if (code && !rc) {
+            rc = code;
+            fprintf(stderr, "a rank failed with code %d: stopping the other ranks\n", code);
+            for (pid_t k : kids)
+                if (k > 0) kill(k, SIGKILL);
+        }
     }
     return rc;
 }

@@ -149,3 +149,33 @@ def test_spades_binary_reads_input():
     with pytest.raises(SmxError) as e:
         sp.push_back_binary("/nonexistent.seq")
     assert e.value.code == 65
+
+
+def test_trim_and_one_parked_arena_per_device():
+    """smx_trim gives the free physical memory of the context's arena back to the device and the context keeps working; destroyed
+    contexts park at most ONE arena per device (a context of another budget class tears the parked one down)"""
+    import torch
+    from spades_amd import KMerDiskCounter, ReadKMerSplitter
+    from spades_amd.kmercount import Context
+    rng = np.random.default_rng(2)
+    reads = ["".join(rng.choice(list("ACGT"), 150)) for _ in range(3000)]
+
+    def count(ctx):
+        sp = ReadKMerSplitter(33, "A", ctx)
+        sp.push_back_reads(reads)
+        st = KMerDiskCounter(None, sp).Count(16)
+        return st.records().tobytes()
+
+    free0 = torch.cuda.mem_get_info()[0]
+    ctx = Context()
+    a = count(ctx)
+    got = ctx.trim()
+    assert got >= 0
+    assert count(ctx) == a          # what was unmapped is mapped again on demand
+    ctx.close()
+    for budget in (2 << 30, 0, 3 << 30, 0):  # alternating budget classes: never more than one parked arena
+        c = Context(hbm_budget=budget) if budget else Context()
+        assert count(c) == a
+        c.close()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 30), "parked arenas pile up"

@@ -336,3 +336,66 @@ def test_one_exchange_route_is_refused_where_the_record_has_no_room():
     assert not eng.ext_supported(31) and not eng.ext_supported(63) and eng.ext_supported(21) and eng.ext_supported(55)
     with pytest.raises(ValueError):
         smx_dist.sharded_build_graph(eng, 31, 1, 0, 1, torch.device("cpu"), route="ext")
+
+
+class _FailingEngine(OracleGraphEngine):
+    """a rank whose local step fails between two collectives (what a GPU rank does when ITS distinct k-mers overflow its HBM plan)"""
+
+    def __init__(self, reads, all_reads, fail_in, code):
+        super().__init__(reads, all_reads)
+        self.fail_in, self.code = fail_in, code
+
+    def _maybe(self, what):
+        if what == self.fail_in:
+            from spades_amd.kmercount import SmxError
+            raise SmxError(self.code, f"injected failure in {what}")
+
+    def shard_from_ext(self, *a):
+        self._maybe("shard_from_ext")
+        return super().shard_from_ext(*a)
+
+    def count_records(self, *a):
+        self._maybe("count_records")
+        return super().count_records(*a)
+
+
+def _failing_worker(rank, world, port, k, fail_rank, fail_in, code, route, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spades_amd import dist as smx_dist
+    reads = read_lines("reads_small.txt")[:120]
+    eng = _FailingEngine(reads[rank::world], reads, fail_in if rank == fail_rank else None, code)
+    try:
+        info = smx_dist.sharded_build_graph(eng, k, 1, rank, world, torch.device("cpu"), coverage=False, route=route)
+        q.put((rank, "ok", info["route"], eng.g["gfa"]))
+    except smx_dist.CollectiveFailure as e:
+        q.put((rank, "failed", e.code, ""))
+    dist.barrier()  # nobody is stuck in a collective the failing rank never entered
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_in,code,route,expect", [
+    ("shard_from_ext", 68, "auto", "fallback"),   # memory limit on ONE rank: all ranks take the (k+1)-mer route together
+    ("shard_from_ext", 70, "auto", "all_fail"),   # any other error: every rank raises
+    ("count_records", 68, "kpomers", "all_fail"),  # no further route to fall back to
+])
+def test_a_failing_rank_does_not_leave_the_others_waiting(fail_in, code, route, expect):
+    from oracle import oracle
+    world, k = 2, 21
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000) + code
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, k, 1, fail_in, code, route, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if expect == "fallback":
+        g = oracle.build_graph(read_lines("reads_small.txt")[:120], k, 10, coverage=True)  # (the test engine always asks for the tags)
+        assert all(x[1] == "ok" and x[2] == "kpomers" and x[3] == g["gfa"] for x in got)
+    else:
+        assert all(x[1] == "failed" and x[2] == code for x in got)
