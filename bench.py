@@ -77,12 +77,28 @@ def synth_reads_device(seed, genome_len, n_reads, dev, err=0.01, genome_seed=2, 
 
 
 def _reads_file(codes_sample, path):
+    """one read per line (what oracle/_ref's front-end reads), written in blocks: the full 100 M-read batch is 15 GB of text"""
     import numpy as np
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
-    arr = lut[codes_sample.cpu().numpy()]
+    n = codes_sample.shape[0]
     with open(path, "wb") as f:
-        f.write(b"\n".join(r.tobytes() for r in arr) + b"\n")
-    return arr.shape[0]
+        for c0 in range(0, n, 1 << 22):
+            blk = lut[codes_sample[c0:c0 + (1 << 22)].cpu().numpy()]
+            out = np.empty((blk.shape[0], blk.shape[1] + 1), dtype=np.uint8)
+            out[:, :-1] = blk
+            out[:, -1] = 10
+            out.tofile(f)
+    return n
+
+
+def _src_hash():
+    """sha256 over the library sources (the same function as tools/pmc_summary.py): a PMC table is quoted only for the kernels it was taken on"""
+    import glob
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "spades_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "spades_amd", "csrc", "*.hpp")) +
+                    [os.path.join(ROOT, "include", "smx.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _cpu_info():
@@ -113,6 +129,16 @@ def cpu_baseline_count(codes_sample, K, mode, nb, gpu_result=None, runs=3):
         dt = time.time() - t0
         return {"value": round(len(reads) / dt / 1e6, 4), "unit": "M reads/s", "cores": 1, "kind": "port", "cpu": model,
                 "sample": f"first {len(reads)} reads of the bench batch, oracle/smx_oracle.c, {dt:.1f} s"}
+    # tmpfs holds the reads (151 B each), the reference's raw k-mer dumps (every instance once: ~1.6 KB per read at k = 55) and its
+    # output: never start a sample the host cannot hold (a box that runs out of memory is lost)
+    need = codes_sample.shape[0] * 2600 + (8 << 30)
+    try:
+        avail = next(int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable"))
+    except (OSError, StopIteration, ValueError):
+        avail = None
+    if avail is not None and avail < need:
+        return {"value": None, "unit": "M reads/s", "cores": cores, "cpu": model, "kind": "reference",
+                "sample": f"skipped: {codes_sample.shape[0]} reads need ~{need >> 30} GiB of host memory (tmpfs), {avail >> 30} GiB are available"}
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         rf = os.path.join(td, "reads.txt")
         n = _reads_file(codes_sample, rf)
@@ -212,7 +238,13 @@ def main():
     ap.add_argument("--genome", type=float, default=500e6)
     ap.add_argument("--n-rate", type=float, default=0.001)
     ap.add_argument("--count-only", action="store_true", help="N=1: time the (k+1)-mer count alone (no construction)")
-    ap.add_argument("--cpu-sample", type=float, default=2e6, help="reads timed on the host with the reference classes")
+    ap.add_argument("--cpu-sample", type=float, default=20e6,
+                    help="reads of the bench batch counted on the host by the reference classes (same coverage regime as the step from ~20 M reads on: "
+                         "at 2 M reads over a 500 Mbp genome almost every k-mer is distinct and the fixed costs of a 256-thread launch dominate)")
+    ap.add_argument("--cpu-sample-construct", type=float, default=2e6,
+                    help="reads for the reference CONSTRUCTION classes on the host (0.04 M reads/s: 20 M reads would take 8 minutes; the sample bias is stated in the line)")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the reference count on the host (median reported)")
+    ap.add_argument("--cpu-count-only", action="store_true", help="host baseline: the count only (with --cpu-sample = --reads this is the full-size parity check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra-kmercount", type=float, default=10e6,
                     help="extra (untimed for the headline): spades-kmercount mode (all k-mers of read + RC, 16 buckets) on this many reads; 0 disables")
@@ -224,6 +256,8 @@ def main():
                          "without it the construction never sorts the k-mers (nodes numbered by minimizer partition)")
     ap.add_argument("--sync-upload", action="store_true", help="N=1: the H2D copy of the step finishes before any kernel starts (round-2 behaviour)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option for this run (smx_set_option), e.g. dir_slots=2")
+    ap.add_argument("--sharded-construct", type=float, default=10e6,
+                    help="N>1 (or --force-sharded): after the timed steps, ONE construction over the ranks on this many reads per GPU (extra key; 0 disables)")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
     args = ap.parse_args()
 
@@ -259,7 +293,9 @@ def main():
     W = 8 * nw
     words, start, ln, codes = synth_reads_device(1000 + rank, int(args.genome), n_reads, dev, n_rate=args.n_rate)
     n_sample = int(min(args.cpu_sample, n_reads)) // 32 * 32
-    sample = codes[:n_sample].clone() if rank == 0 else None
+    if args.no_cpu_baseline:
+        n_sample = 0
+    sample = (codes[:n_sample].cpu() if n_sample else None) if rank == 0 else None  # host memory: 150 B per read
     del codes
     # the batch waits in page-locked host memory ("packed read batches resident in pinned host memory")
     h_words, h_start, h_len = words.cpu().pin_memory(), start.cpu().pin_memory(), ln.cpu().pin_memory()
@@ -324,7 +360,15 @@ def main():
     total_reads = n_reads * world
     value = total_reads / (dt / args.steps) / 1e6
 
-    # ---- stage times of the last step (HIP events on the library's stream) and roofline figures ----
+    # ---- stage times (HIP events on the library's stream) and roofline figures ----
+    # The timed steps upload asynchronously: their first stages (window marks, first scan of the reads) wait for PCIe pieces, so their
+    # event intervals hold transfer time. The kernel durations the rooflines are computed from come from ONE more step, untimed, with
+    # the upload finished before the first kernel.
+    if not sharded and not args.sync_upload:
+        ctx.set_option("async_upload", 0)
+        step()
+        sync()
+        ctx.set_option("async_upload", 1)
     stages = {}
     for name, ms in ctx.timings():  # a stage name repeats when the pipeline runs more than once
         stages[name] = stages.get(name, 0.0) + ms
@@ -365,30 +409,38 @@ def main():
     roof_count["dominant_stage"] = dom[0]
     roof_count["dominant_stage_ms"] = round(dom[1], 3)
     roof_count["stages_ms"] = {n_: round(ms, 3) for n_, ms in stages.items()}
-    # HBM traffic per step from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, FETCH x2 gfx950
-    # correction: profiles/r02/config3_pmc_hbm_traffic.csv, taken at the commit named in profiles/r02/README.md). Only valid for the
-    # workload it was taken on; a constant of that measurement, not of this run.
-    pmc = os.path.join(ROOT, "profiles", "r02", "config3_ext_pmc_hbm_traffic.csv" if ext_route else "config3_pmc_hbm_traffic.csv")
-    pmc_rows, pmc_split = {}, None
+    # HBM traffic per step from the committed PMC passes (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+    # FETCH x2 gfx950 correction). A table is a constant of ITS measurement: it is quoted only for the workload it was taken on and only
+    # while the library sources are the ones it was taken on (first line of the CSV: their sha256) — otherwise traffic stays null.
+    pmc = os.path.join(ROOT, "profiles", "r03", "config3_pm_pmc_hbm_traffic.csv" if pm_route else
+                       ("config3_sorted_pmc_hbm_traffic.csv" if ext_route else "config3_kpomer_pmc_hbm_traffic.csv"))
+    pmc_rows, pmc_split, pmc_note = {}, None, None
     if not sharded and not args.count_only and n_reads == 100_000_000 and k == 55 and T == 16 and os.path.exists(pmc):
-        for line in open(pmc):
+        lines = open(pmc).read().splitlines()
+        sha = lines[0].split("src_sha256=")[1].split()[0] if lines and "src_sha256=" in lines[0] else None
+        if sha != _src_hash():
+            pmc_note = f"profiles/r03 PMC table was taken on other library sources ({sha}): not quoted"
+            lines = []
+        for line in lines:
             f = line.strip().rsplit(",", 5)  # kernel names hold commas (template arguments)
-            if len(f) >= 6 and f[0] not in ("kernel", "TOTAL"):
+            if len(f) >= 6 and f[0] not in ("kernel", "TOTAL") and not f[0].startswith("#"):
                 if "k_fingerprint" in f[0]:  # the check of the result, not the step
                     continue
                 try:
                     pmc_rows[f[0]] = float(f[3]) + float(f[5])
                 except ValueError:
                     pass
-        # the kernels of the construction proper; everything else in the table belongs to the counting pipeline (the link-record sort of
-        # the construction runs on the pipeline's kernels too: ~5 % of their records, counted with the count here)
+        # the kernels of the construction proper; everything else in the table belongs to the counting pipeline (the sorts of the
+        # junction k-mers and of the link records run on the pipeline's kernels too: a few % of its records, counted with the count here)
         con_kernels = ("k_dir_fill", "k_tab_from_masks", "k_fill_tab", "k_tab_masks", "k_cand_", "k_walk_", "k_keep", "k_link_keys", "k_vertex_",
-                       "k_loop_", "k_derive_", "k_succ", "k_tip_", "k_at_", "k_gather_kmers")
+                       "k_loop_", "k_derive_", "k_succ", "k_tip_", "k_at_", "k_gather_kmers", "k_pm_")
         con_traffic = sum(v for n_, v in pmc_rows.items() if any(c in n_ for c in con_kernels))
         pmc_split = {"count": round(sum(pmc_rows.values()) - con_traffic, 1), "construct": round(con_traffic, 1)} if pmc_rows else None
         roof_count["traffic"] = pmc_split["count"] if pmc_split else None
         roof_count["traffic_unit"] = ("GB per step, HBM fetch (x2 gfx950 correction) + write of the counting pipeline's kernels (PMC passes of "
-                                      "profiles/r02, see README there for the commit); whole step: %.1f GB" % sum(pmc_rows.values()))
+                                      "profiles/r03 on these very sources); whole step: %.1f GB" % sum(pmc_rows.values())) if pmc_rows else pmc_note
+    elif not sharded and not args.count_only:
+        roof_count["traffic_unit"] = "no PMC table for this workload / route under profiles/r03"
 
     out = {
         "metric": f"M reads/sec k-mer-counted (k={k}, PE150)",
@@ -468,8 +520,10 @@ def main():
                 out["construct"]["checks"]["graph_fingerprint"] = f"unavailable: {e}"
         if not args.no_cpu_baseline and n_sample:
             hw_s = hw[:n_sample * L // 32 + 8]
+            ctx.set_option("async_upload", 0)  # (the checks below submit temporary slices)
 
             def gpu_count(n):  # GPU count of the first n reads of the batch (they are the first n*L bases of the stream)
+                ctx.graph_clear()  # (the timed graph is no longer needed: its HBM goes to the count)
                 sp = ReadKMerSplitter(K1, "B", ctx)
                 sp.clear()
                 sp.push_back_packed(hw_s[:n * L // 32], hs[:n], hl[:n])
@@ -483,10 +537,15 @@ def main():
                 g2.build()
                 return [u.encode() for u in g2.unitigs()]
 
-            out["cpu_baseline"] = cpu_baseline_count(sample, K1, "B", nb, gpu_count)
-            if not args.count_only:
-                cb = cpu_baseline_construct(sample, k, gpu_unitigs)
+            out["cpu_baseline"] = cpu_baseline_count(sample, K1, "B", nb, gpu_count, runs=max(1, args.cpu_runs))
+            out["cpu_baseline"]["sample_regime"] = (f"{n_sample / 1e6:g} M of the {n_reads / 1e6:g} M bench reads = coverage {n_sample * L / args.genome:.1f}x of the "
+                                                    f"{args.genome / 1e6:g} Mbp genome (the step itself runs at {n_reads * L / args.genome:.0f}x: more duplicates per distinct "
+                                                    "k-mer, which favours the CPU's per-bucket sort less than the GPU's on-chip dedupe)")
+            n_con = int(min(args.cpu_sample_construct, n_sample)) // 32 * 32
+            if not args.count_only and not args.cpu_count_only and n_con:
+                cb = cpu_baseline_construct(sample[:n_con], k, gpu_unitigs)
                 if cb:
+                    cb["sample_regime"] = f"first {n_con / 1e6:g} M reads only (coverage {n_con * L / args.genome:.1f}x): one run of the reference classes takes {n_con / 1e6 / max(cb['value'], 1e-9):.0f} s"
                     out["cpu_baseline"]["construct"] = cb
         if args.extra_kmercount > 0:
             # BASELINE config 2 shape at k=55 (the round-1 headline, kept for continuity): spades-kmercount mode, inputs resident in HBM
@@ -513,15 +572,68 @@ def main():
                                      "M_reads_per_s": round(ne_ / dta / 1e6, 2), "ms_per_step": round(dta * 1e3, 3), "kernel_ms": round(tma, 3),
                                      "kmer_instances": int(ia), "distinct_kmers": int(da),
                                      "roofline_frac": round(ba / max(tma, 1e-9) / 1e6 / 8000.0, 4)}
+    if sharded:
+        # per-rank figures of the last step, gathered on rank 0: records sent / received, distinct records owned, phase times
+        st = last["st"]
+        mine = torch.tensor([st["sent"], st["received"], st["distinct"], int(st["phase_ms"]["extract"] * 1e3), int(st["phase_ms"]["exchange"] * 1e3),
+                             int(st["phase_ms"]["owner_count"] * 1e3)], dtype=torch.int64, device=dev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        if rank == 0:
+            rows = [e.tolist() for e in every]
+            out["per_rank"] = [{"rank": r, "sent": v[0], "received": v[1], "owned_distinct": v[2], "extract_ms": v[3] / 1e3, "exchange_ms": v[4] / 1e3,
+                                "owner_count_ms": v[5] / 1e3} for r, v in enumerate(rows)]
+            out["rccl_world_size"] = dist.get_world_size()
+            out["exchange_ms_max"] = max(v[4] for v in rows) / 1e3
+            out["owner_count_ms_max"] = max(v[5] for v in rows) / 1e3
+            out["records_exchanged"] = sum(v[0] for v in rows)
+        # the construction over the ranks (owner-side masks, gathered compact structure: spades_amd.dist.sharded_build_graph) on a reduced
+        # input — every rank holds the whole k-mer file + masks in this design, so 100 M reads per GPU do not fit from 2 ranks on
+        # (DESIGN.md §5). Never part of the headline; an error here is reported, not raised.
+        if args.sharded_construct > 0:
+            import threading
+
+            def watchdog():  # a rank stuck in a collective must not cost the headline: the line goes out without this extra and every rank leaves
+                if rank == 0:
+                    out["construct_sharded"] = {"error": "timed out after 240 s (watchdog)"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+            wd = threading.Timer(240.0, watchdog)
+            wd.daemon = True
+            wd.start()
+            try:
+                n_c = int(min(args.sharded_construct, n_reads)) // 32 * 32
+                ctx.graph_clear()
+                gb.reads.clear()
+                gb.push_back_device(words.data_ptr(), n_c * L // 32, start.data_ptr(), ln.data_ptr(), n_c)
+                eng2 = smx_dist.GpuEngine(ctx, "B")
+                torch.cuda.synchronize()
+                dist.barrier()
+                tc = time.perf_counter()
+                ginfo = smx_dist.sharded_build_graph(eng2, k, T, rank, world, dev)
+                torch.cuda.synchronize()
+                dist.barrier()
+                dtc = time.perf_counter() - tc
+                if rank == 0:
+                    out["construct_sharded"] = {"reads_per_gpu": n_c, "seconds": round(dtc, 3), "M_reads_per_s": round(n_c * world / dtc / 1e6, 2),
+                                                "route": ginfo["route"], "n_kmers": int(ginfo["n_kmers"]), "n_unitigs": int(ginfo["n_unitigs"]),
+                                                "kmers_per_rank": [int(v) for v in ginfo["kmers_per_rank"]]}
+            except Exception as e:  # noqa: BLE001
+                if rank == 0:
+                    out["construct_sharded"] = {"error": str(e)[:300]}
+            wd.cancel()
     if sharded and rank == 0:
         # the N = 1 default line is another workload (config 3: upload + count + construction); the figure to divide an N-rank value by
         # is this same sharded step on ONE rank, measured with --gpus 1 --force-sharded and committed under profiles/
-        ref = os.path.join(ROOT, "profiles", "r02", "bench_sharded_1rank_100M.json")
+        ref = os.path.join(ROOT, "profiles", "r03", "bench_sharded_1rank_100M.json")
+        if not os.path.exists(ref):
+            ref = os.path.join(ROOT, "profiles", "r02", "bench_sharded_1rank_100M.json")
         try:
             r1 = json.load(open(ref))
             if r1["config"]["reads_per_gpu"] == n_reads and r1["config"]["k"] == k and r1["config"]["num_buckets"] == nb:
                 out["same_step_on_one_rank"] = {"value": r1["value"], "unit": r1["unit"], "ms_per_step": r1["ms_per_step"],
-                                                "source": "profiles/r02/bench_sharded_1rank_100M.json (bench.py --gpus 1 --force-sharded)"}
+                                                "source": os.path.relpath(ref, ROOT) + " (bench.py --gpus 1 --force-sharded)"}
         except (OSError, ValueError, KeyError):
             pass
     if rank == 0:

@@ -195,6 +195,9 @@ unsigned smx_rank_first_bucket(unsigned num_buckets, unsigned world, unsigned ra
  * After the call smx_copy_final_kmers()/smx_bucket_sizes() describe the canonical k-mer file (made at that moment when the
  * construction did not need it: option "pm_route"). Node ids (smx_host_write_graph's start_node / end_node) are opaque. */
 int smx_build_graph(smx_ctx *ctx, unsigned k, unsigned num_buckets);
+/* Drops the graph (and the HBM it holds: k-mers, masks, unitigs, link records) without destroying the context; the resident reads
+ * stay. The reference frees its extension index and graph when their owners go out of scope (projects/spades_tools/gbuilder.cpp:232). */
+int smx_graph_clear(smx_ctx *ctx);
 /* Multi-GPU construction ("replicated lookup"; precedent: hpcspades/mpi/stages/construction_mpi.cpp:343-354,
  * count per node + merge): the same steps on a canonical (k+1)-mer file that the caller gathered from its owner ranks
  * (HBM pointer, any order, duplicates allowed) instead of on the resident reads. The resident reads are still what

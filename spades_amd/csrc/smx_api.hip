@@ -788,6 +788,19 @@ static int build_graph_impl(smx_ctx *ctx, unsigned k, unsigned num_buckets, cons
     return rc;
 }
 
+int smx_graph_clear(smx_ctx *ctx) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->pm_view_pending || (ctx->d_result && ctx->d_result == ctx->g_kmers)) {  // the count-result view showed (or stood for) the graph's k-mer file
+        ctx->pm_view_pending = false;
+        ctx->d_result = nullptr;
+        ctx->n_records = 0;
+        ctx->bucket_off.assign(ctx->num_buckets + 1, 0);
+    }
+    clear_graph(ctx);
+    return SMX_OK;
+}
+
 int smx_build_graph(smx_ctx *ctx, unsigned k, unsigned num_buckets) { return build_graph_impl(ctx, k, num_buckets, nullptr, 0); }
 
 int smx_build_graph_from_records(smx_ctx *ctx, unsigned k, unsigned num_buckets, const void *d_kpomers, uint64_t n_records) {
@@ -959,7 +972,7 @@ int smx_graph_shard_copy(const smx_ctx *cctx, void *d_kmers, void *d_masks) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     if (ctx->g_nkmers == 0) return SMX_OK;
     if (!d_kmers || !d_masks) return SMX_INVALID_PARAMETER;
-    if (int rc = ensure_kmer_file(ctx)) return rc;
+    if (int rc = ensure_kmer_file(ctx, /*view=*/false)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(d_kmers, ctx->g_kmers, ctx->g_nkmers * ctx->g_nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_masks, ctx->g_mask, ctx->g_nkmers, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1054,7 +1067,7 @@ int smx_graph_copy_kmers(const smx_ctx *cctx, void *kmers_host, uint8_t *masks_h
     if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->g_nkmers == 0) return SMX_OK;
-    if (int rc = ensure_kmer_file(ctx)) return rc;
+    if (int rc = ensure_kmer_file(ctx, /*view=*/false)) return rc;
     if (kmers_host) HIPCHK(hipMemcpy(kmers_host, ctx->g_kmers, ctx->g_nkmers * ctx->g_nw * 8, hipMemcpyDeviceToHost));
     if (masks_host) HIPCHK(hipMemcpy(masks_host, ctx->g_mask, ctx->g_nkmers, hipMemcpyDeviceToHost));
     return SMX_OK;

@@ -56,6 +56,7 @@ void clear_graph(smx_ctx *ctx) {
     drop_device_graph(ctx);
     pm_release(ctx);
     ctx->g_pm = false;
+    ctx->pm_view_pending = false;
     ctx->g_kmers = nullptr;
     ctx->g_mask = nullptr;
     ctx->g_nkpo = ctx->g_nkmers = 0;

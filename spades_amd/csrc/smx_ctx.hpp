@@ -79,6 +79,8 @@ struct smx_ctx {
     uint64_t g_ext_bits = 0, g_ext_pals = 0;  // extension bits / palindromic (k+1)-mers among them in the k-mer file or shard built from EXT records
     PmState pm;               // partition-major construction route
     bool g_pm = false;        // g_kmers holds EXT records in partition-major order (no sorted k-mer file yet: made on demand)
+    bool pm_view_pending = false;  // the count-result view (smx_copy_final_kmers, smx_bucket_sizes, ...) stands for the k-mer file of that
+                                   // graph, not made yet; any later count owns the view again (clear_result)
     int64_t opt_pm_route = -1;  // construction without the sort of the k-mers: -1 where it applies, 0 never, 1 = -1
     bool ext_mode = false;    // the count in flight carries extension bytes in its records (EXT layout, smx_device.hpp): set by the construction
     void *x_owned = nullptr;  // output of smx_extract_partition_owned (released by the next extract / smx_extract_release)
@@ -410,6 +412,14 @@ void *arena_take(smx_ctx *ctx, size_t bytes, size_t r0, size_t r1, bool descendi
         if (sz > bytes) A.free_blocks[off] = sz - bytes;
     }
     void *p = A.base + at;
+    if (getenv("SMX_ARENA_CHECK")) {  // diagnostics: a block handed out must lie inside mapped chunks
+        for (size_t ci = at / A.gran; ci <= (at + bytes - 1) / A.gran; ++ci)
+            if (ci >= A.chunk.size() || !A.chunk[ci].mapped) {
+                fprintf(stderr, "[smx] ARENA: block [%zu, %zu) handed out over unmapped chunk %zu (lo %zu hi %zu reserved %zu, free block was [%zu, %zu), %s)\n", at,
+                        at + bytes, ci, A.lo, A.hi, A.reserved, off, off + sz, descending ? "descending" : "ascending");
+                break;
+            }
+    }
     A.live[p] = bytes;
     ctx->arena_live += bytes;
     return p;

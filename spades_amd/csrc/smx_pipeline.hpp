@@ -130,6 +130,7 @@ int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint6
 }
 
 void clear_result(smx_ctx *ctx) {
+    ctx->pm_view_pending = false;  // whatever fills the view next is not the pending k-mer file of a graph
     for (auto &c : ctx->h_result) free(c.data);
     ctx->h_result.clear();
     ctx->result_on_host = false;

@@ -228,6 +228,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     ctx->nw = NW;
     ctx->num_buckets = B;
     ctx->bucket_off.clear();
+    ctx->pm_view_pending = true;
     return 0;
 }
 
@@ -235,8 +236,30 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
 // smx_graph_copy_kmers, ... after smx_build_graph): the partition-major records go through the sort pipeline (they are consumed) and
 // the split pass of the sorted route. Node ids of the graph keep referring to the partition-major numbering (they are opaque).
 template <int NW>
-int pm_materialize_file(smx_ctx *ctx) {
+int pm_materialize_file(smx_ctx *ctx, bool for_view) {
     if (!ctx->g_pm) return 0;
+    // for_view: the count-result view is waiting for this file (nothing was counted since the graph was built). Otherwise the file is
+    // asked for through the graph (smx_graph_copy_kmers) while the view shows a later count: that count's result is kept.
+    void *sv_buf = ctx->d_result_buf, *sv_res = ctx->d_result;
+    const uint64_t sv_n = ctx->n_records, sv_inst = ctx->n_instances;
+    const unsigned sv_nw = ctx->nw, sv_K = ctx->K, sv_B = ctx->num_buckets;
+    const std::vector<uint64_t> sv_boff = ctx->bucket_off;
+    const bool sv_host = ctx->result_on_host;
+    std::vector<smx_ctx::HostChunk> sv_h;
+    sv_h.swap(ctx->h_result);
+    ctx->result_on_host = false;
+    auto restore_view = [&]() {
+        ctx->d_result_buf = sv_buf;
+        ctx->d_result = sv_res;
+        ctx->n_records = sv_n;
+        ctx->n_instances = sv_inst;
+        ctx->nw = sv_nw;
+        ctx->K = sv_K;
+        ctx->num_buckets = sv_B;
+        ctx->bucket_off = sv_boff;
+        ctx->result_on_host = sv_host;
+        ctx->h_result.swap(sv_h);
+    };
     const unsigned k = ctx->g_k, B = ctx->g_B;
     const uint64_t D0 = ctx->g_nkmers;
     void *src = ctx->g_kmers;
@@ -264,26 +287,36 @@ int pm_materialize_file(smx_ctx *ctx) {
     }
     ctx->timings.clear();
     free_temps(ctx);
+    ctx->pm_view_pending = false;
     if (rc) {
         if (ctx->g_kmers) arena_put(ctx, ctx->g_kmers);
         if (ctx->g_mask) arena_put(ctx, ctx->g_mask);
         ctx->g_kmers = nullptr;
         ctx->g_mask = nullptr;
         ctx->d_result = ctx->d_result_buf = nullptr;
+        if (!for_view) restore_view();
         return rc;
     }
     ctx->g_nkpo = nkpo;
-    ctx->d_result = ctx->g_kmers;
-    ctx->d_result_buf = nullptr;
+    if (for_view) {
+        ctx->d_result = ctx->g_kmers;
+        ctx->d_result_buf = nullptr;
+    } else {
+        restore_view();
+    }
     return 0;
 }
-int ensure_kmer_file(smx_ctx *ctx) {
+// view: the caller reads the count-result view (smx_copy_final_kmers, smx_bucket_sizes, ...): only a view that still stands for the
+// graph's file needs it made; else (smx_graph_copy_kmers & co.) whenever the graph has none yet
+int ensure_kmer_file(smx_ctx *ctx, bool view = true) {
     if (!ctx || !ctx->g_pm) return 0;
+    if (view && !ctx->pm_view_pending) return 0;
+    const bool for_view = ctx->pm_view_pending;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "hipSetDevice failed");
     switch (ctx->g_nw) {
-        case 1: return pm_materialize_file<1>(ctx);
-        case 2: return pm_materialize_file<2>(ctx);
-        case 3: return pm_materialize_file<3>(ctx);
-        default: return pm_materialize_file<4>(ctx);
+        case 1: return pm_materialize_file<1>(ctx, for_view);
+        case 2: return pm_materialize_file<2>(ctx, for_view);
+        case 3: return pm_materialize_file<3>(ctx, for_view);
+        default: return pm_materialize_file<4>(ctx, for_view);
     }
 }

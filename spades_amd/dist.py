@@ -247,8 +247,11 @@ def _exchange(engine, send: torch.Tensor, counts, wpr: int, rank: int, world: in
 
 def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
     """One step of the sharded path on this rank. Returns the owner-side result dict of the engine
-    (+ 'sent'/'received' record counts). Collective: every rank must call it."""
+    (+ 'sent'/'received' record counts, + 'phase_ms': wall time of extract / exchange / owner count on this rank — every phase
+    already ends in a synchronisation, nothing is added for the timing). Collective: every rank must call it."""
+    import time
     nw = (K + 31) // 32
+    t0 = time.perf_counter()
 
     def local_extract():
         n_local = engine.extract_count(K)
@@ -262,11 +265,14 @@ def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
 
     n_local, send, counts = _guarded(dev, "extract + partition by owner", local_extract)
     n_sent = sum(counts)  # < n_local when the engine pre-dedupes its shard before the exchange
+    t1 = time.perf_counter()
     recv, n_recv = _exchange(engine, send, counts, nw, rank, world, dev, pool=True)
+    t2 = time.perf_counter()
     del send
     if hasattr(engine, "extract_release"):
         engine.extract_release()  # room for the owner-side count
     res = _guarded(dev, "owner-side count", engine.count_records, K, nb, recv, n_recv)
+    res["phase_ms"] = {"extract": (t1 - t0) * 1e3, "exchange": (t2 - t1) * 1e3, "owner_count": (time.perf_counter() - t2) * 1e3}
     res["sent"], res["received"] = n_sent, n_recv
     res["instances"] = n_local  # k-mer instances extracted from this rank's reads
     return res

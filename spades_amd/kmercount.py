@@ -51,6 +51,10 @@ class Context:
     def set_option(self, key: str, value: int):
         _chk(self._h, self.lib.smx_set_option(self._h, key.encode(), int(value)))
 
+    def graph_clear(self):
+        """smx_graph_clear: the graph of the last smx_build_graph gives its HBM back; reads stay resident"""
+        _chk(self._h, self.lib.smx_graph_clear(self._h))
+
     def trim(self) -> int:
         """smx_trim: free physical memory at the ends of the context's device arena goes back to the device; returns the bytes"""
         n = C.c_size_t()

@@ -209,3 +209,33 @@ def test_async_upload_in_pieces(tmp_path):
         res[mode] = (dict(info), fp, st.total_kmers(), hash(st.records().tobytes()))
         ctx.close()
     assert res[0] == res[1]
+
+
+def test_a_later_count_owns_the_result_view(tmp_path):
+    """after a graph built without a k-mer file, a count on the same context must see ITS result through smx_bucket_sizes & co. (the
+    pending k-mer file of the graph is only made for a view that still stands for it), and the graph's file stays available"""
+    from oracle import oracle
+    from spades_amd import KMerDiskCounter, ReadKMerSplitter
+    from spades_amd.gbuilder import GraphBuilder
+    k = 55
+    reads = _synth(21, 5000, 1500, 150)
+    gb = GraphBuilder(k, 2)
+    for key, v in PM.items():
+        gb.ctx.set_option(key, v)
+    gb.push_back_reads(reads)
+    gb.build()
+    assert "pm_tab" in [n for n, _ in gb.ctx.timings()]
+    sp = ReadKMerSplitter(33, "A", gb.ctx)     # another K, another bucket count, same context
+    sp.clear()
+    sp.push_back_reads(reads)
+    st = KMerDiskCounter(None, sp).Count(16)
+    ref, sizes = oracle.count(reads, 33, "A", 16)
+    assert (st.records() == ref).all() and (st.bucket_sizes() == sizes).all()
+    g = oracle.build_graph(reads, k, 20)
+    rec, masks = gb.kmers()                   # the graph's k-mer file, made now; the count's result survives it
+    assert (rec == np.asarray(g["kmers"]).reshape(rec.shape)).all() and (masks == g["masks"]).all()
+    assert (st.records() == ref).all()
+    out = os.path.join(str(tmp_path), "g.gfa")
+    gb.write_gfa(out)
+    assert open(out).read() == g["gfa"]
+    gb.ctx.close()

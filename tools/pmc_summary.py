@@ -4,10 +4,20 @@
   <dir>/pmc_hbm_traffic.csv   HBM GB per kernel for ONE step: FETCH_SIZE (KB) x2 (gfx950 correction, MI355X_MICROARCH.md HBM
                                section; calibrated on a 4 GiB copy with tools/ubench) and WRITE_SIZE (KB)
 The PMC runs execute setup + 1 step = S passes of the pipeline; per-step = total / S (S = dispatches of k_mark_windows)."""
-import csv, glob, os, shutil, sys
+import csv, glob, hashlib, os, shutil, sys
 from collections import defaultdict
 
 d = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def src_hash():
+    """sha256 over the library sources: bench.py quotes a PMC table only while the kernels it was taken on are the ones that run"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "spades_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "spades_amd", "csrc", "*.hpp")) +
+                    [os.path.join(ROOT, "include", "smx.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def find(sub, suffix):
@@ -33,6 +43,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 names = sorted(set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"]), key=lambda n: -(tot["FETCH_SIZE"][n][1] * 2 + tot["WRITE_SIZE"][n][1]))
 passes = max(1, (tot["FETCH_SIZE"].get("smx::k_fill_tab<2>") or tot["FETCH_SIZE"].get("smx::k_mark_windows", [1]))[0])  # passes of the hot path in the PMC run
 with open(os.path.join(d, "pmc_hbm_traffic.csv"), "w") as o:
+    o.write(f"# src_sha256={src_hash()} (library sources the counters were taken on; bench.py refuses the table when they changed)\n")
     o.write("kernel,launches_per_step,FETCH_SIZE_KB(raw),fetch_GB(x2 gfx950 correction),WRITE_SIZE_KB,write_GB\n")
     tf = tw = 0.0
     for n in names:
