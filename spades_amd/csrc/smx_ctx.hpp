@@ -48,7 +48,8 @@ struct Arena {  // one virtual range, physically backed up to `mapped`
 struct PmState {
     bool active = false;  // the dedupe stage in flight writes partition-major output (set by the route, like smx_ctx::ext_mode)
     unsigned long long *pinfo = nullptr, *cinfo = nullptr;
-    uint32_t *meta = nullptr, *overflow = nullptr;
+    uint32_t *meta = nullptr, *overflow = nullptr, *llink = nullptr;
+    unsigned long long *pals = nullptr;
     uint8_t *mask = nullptr;
     uint32_t max_chunks = 0, nchunks = 0, T = 0, nkey = 0;
     unsigned m = 0, w = 0, pshift = 0;

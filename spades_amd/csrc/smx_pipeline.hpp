@@ -677,12 +677,18 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         if (int rc = dalloc(ctx, &P.cinfo, P.max_chunks, false)) return rc;
         if (int rc = dalloc(ctx, &P.mask, out_cap + 16, false)) return rc;
         if (int rc = dalloc(ctx, &P.overflow, 1, false)) return rc;
+        if (int rc = dalloc(ctx, &P.llink, out_cap + 16, false)) return rc;
+        if (int rc = dalloc(ctx, &P.pals, 1, false)) return rc;
         HIPCHK(hipMemsetAsync(P.pinfo, 0xFF, (size_t)SKM_NKEY * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(P.llink, 0xFF, (size_t)(out_cap + 16) * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(P.pals, 0, 8, ctx->stream));
         HIPCHK(hipMemsetAsync(P.overflow, 0, 4, ctx->stream));
         pmo.pinfo = P.pinfo;
         pmo.meta = P.meta;
         pmo.cinfo = P.cinfo;
         pmo.mask = P.mask;
+        pmo.llink = P.llink;
+        pmo.pals = P.pals;
         pmo.max_chunks = P.max_chunks;
         pmo.overflow = P.overflow;
     }

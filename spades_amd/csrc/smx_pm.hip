@@ -93,13 +93,17 @@ __device__ __forceinline__ Rec<NW> pm_node_kmer(const Rec<NW> *__restrict__ recs
 // A walk that enters a chunk reads ONE word to cross it (smx_pm_walk_len) instead of one node-table entry per k-mer.
 constexpr uint16_t PM_ADV_NONE = 0xFFFFu;
 
-// Node table of the clean chunks: one workgroup per chunk. Per node: outgoing extensions from the mask byte; where there is exactly
-// one, the successor k-mer is looked up in the chunk itself (its group words are staged in LDS; consecutive k-mers of a path share
-// their minimizer, 19 in 20 are found here); a miss leaves TAB_NODE_MASK in the entry for k_pm_remote. Then the chains inside the
-// chunk are followed in LDS, once each, from their heads (the nodes no local link leads to — the only places where a walk can enter
-// a chain) by a dense loop over a list; only heads get a jump word, the others 0 (= step by the node table).
-// stats: [0] extension bits, [1] palindromic (k+1)-mers among them (k_ext_split's figures).
-// LDS (dynamic): gm[ngroups] u32 | jw[2 * maxn] u32 | list[2 * maxn] u16 (chain heads) | hp[maxn / 16] u32
+// Node table of the clean chunks: one workgroup per chunk. The dedupe stage already knows which k-mers of a chunk follow each other:
+// two k-mers side by side in one super-k-mer of some read are a de Bruijn edge between two entries of its LDS hash table, and it
+// hands those local links out with the records (PmOut::llink, 16 bits per node; ~95 % of the successors — consecutive k-mers of a
+// path share their minimizer for ~17 steps). So this kernel computes nothing about k-mers: per node, outgoing extensions from the
+// mask byte; where there is exactly one, the successor is the local link, or, without one, TAB_NODE_MASK for k_pm_remote (the
+// successor lies across a super-k-mer boundary: another partition, looked up there). Then the chains inside the chunk are followed
+// in LDS, once each, from their heads (the nodes no local link leads to — the only places where a walk can enter a chain) by a
+// dense loop over a list; only heads get a jump word, the others 0 (= step by the node table).
+// (Round-3 history: with the successor k-mer hashed and probed here — canonical form, hash, group word, record compare, ~900
+// instructions per k-mer — this kernel took 124 ms at config 3, ALU-bound.)
+// stats[0] += extension bits. LDS (dynamic): jw[2 * maxn] u32 | list[2 * maxn] u16 (chain heads) | hp[maxn / 16] u32
 // Canonical successor k-mers of both orientations of x from ONE reverse complement: with y = RC(x), the successor of orientation 0
 // by nucleotide c is z = x[1..] + c and RC(z) = (3 - c) + y[..k-2]; of orientation 1, z = y[1..] + c and RC(z) = (3 - c) + x[..k-2] —
 // shifts of x and y. yo = 1 where the successor is the non-minimal strand.
@@ -128,17 +132,15 @@ __device__ __forceinline__ unsigned pm_palindromes(const Rec<NW> &x, unsigned m,
     if ((m >> (7 - xl)) & 1) n += rec_eq<NW>(rec_prefix<NW>(x, k - 1), rec_suffix<NW>(y)) ? 1u : 0u;
     return n;
 }
-template <int NW>
-__global__ void __launch_bounds__(BLK, 6) k_pm_tab(PmIndex ix, const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t maxn, unsigned k, node_t *tab,
-                                                uint32_t *jmp, unsigned long long *stats, uint32_t *err, unsigned long long *prof) {
+__global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t maxn, const uint8_t *__restrict__ mask,
+                                                const uint32_t *__restrict__ llink, node_t *tab, uint32_t *jmp, unsigned long long *stats, uint32_t *err,
+                                                unsigned long long *prof) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pm_lds[];
-    uint32_t *gm = pm_lds;
-    uint32_t *jw = gm + ix.ngroups;
+    uint32_t *jw = pm_lds;
     uint16_t *list = (uint16_t *)(jw + 2 * maxn);
     uint32_t *hp = (uint32_t *)(list + 2 * maxn);  // bit nd: some local link leads to node nd
     __shared__ uint32_t s_nhead;
-    const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
-    unsigned long long bits = 0, pals = 0;
+    unsigned long long bits = 0;
     // SMX_DEBUG: prof[0..3] = 100 MHz ticks of thread 0 (stage, node table, chain heads, jumps), [4] chunks, [5] successors outside their chunk, [6] chain heads
     unsigned long long pt[4] = {0, 0, 0, 0}, t0 = 0, pc[3] = {0, 0, 0};
 #define PM_T(i)                                  \
@@ -153,11 +155,8 @@ __global__ void __launch_bounds__(BLK, 6) k_pm_tab(PmIndex ix, const unsigned lo
         const uint64_t base = ci & PM_BASE_MASK;
         const uint32_t n = (uint32_t)(ci >> PM_BASE_BITS), nn = 2 * n;
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < ix.ngroups; t += BLK) gm[t] = ix.meta[(size_t)cid * ix.ngroups + t];
         for (uint32_t t = threadIdx.x; t < (maxn >> 4); t += BLK) hp[t] = 0;
         if (threadIdx.x == 0) s_nhead = 0;
-        Rec<NW> nxt{};
-        if (threadIdx.x < n && n <= maxn) nxt = recs[base + threadIdx.x];
         if (cid + gridDim.x < nchunks) ci = cinfo[cid + gridDim.x];  // the next chunk's descriptor flies while this one is worked on
         __syncthreads();
         PM_T(0)
@@ -166,43 +165,32 @@ __global__ void __launch_bounds__(BLK, 6) k_pm_tab(PmIndex ix, const unsigned lo
             continue;
         }
         for (uint32_t r = threadIdx.x; r < n; r += BLK) {
-            const Rec<NW> raw = nxt;
-            if (r + BLK < n) nxt = recs[base + r + BLK];  // prefetch: the record of the next round
-            const Rec<NW> x = rec_pure<NW>(raw);
-            const unsigned m = (unsigned)(raw.w[NW - 1] & 0xFFu);
+            const unsigned m = mask[base + r];
+            const uint32_t ll = llink[base + r];
             bits += __popc(m);
-            {   // a palindromic (k+1)-mer needs the matching extension bit AND complementary outermost bases of the inner (k-1)-mer
-                const uint64_t wsel = ((k - 2) >> 5) == (unsigned)(NW - 1) ? x.w[NW - 1] : x.w[NW > 1 ? NW - 2 : 0];  // the word of base k-2
-                const unsigned x0 = rec_nucl<NW>(x, 0), x1 = rec_nucl<NW>(x, 1), xl = (unsigned)(x.w[NW - 1] >> (((k - 1) & 31u) << 1)) & 3u,
-                               xm = (unsigned)(wsel >> (((k - 2) & 31u) << 1)) & 3u;
-                if ((((m >> (3 - x0)) & 1) && x1 + xl == 3) || (((m >> (7 - xl)) & 1) && x0 + xm == 3)) pals += pm_palindromes<NW>(x, m, k);
-            }
             const bool junction = mask_junction(m);
-            const Rec<NW> y = rec_rc<NW>(x, k);
+            node_t e[2];
 #pragma unroll
             for (unsigned o = 0; o < 2; ++o) {
                 const unsigned mo = (o ? brev8(m) : m) & 15u;
-                const uint32_t me = 2 * r + o;
+                const uint32_t l = o ? (ll >> 16) : (ll & 0xFFFFu);
                 uint32_t w = 0xFFFFu;  // no local successor
+                e[o] = (node_t)mo << TAB_OUT_SHIFT;
                 if (uniq4(mo)) {
-                    unsigned yo;
-                    const Rec<NW> sk = o ? pm_succ_from<NW>(y, x, k, mo, yo) : pm_succ_from<NW>(x, y, k, mo, yo);
-                    const node_t ry = pm_probe<NW>(recs, gm, ix.T, base, sk, rec_hash32<NW>(sk));
-                    if (ry != NODE_NONE) {
-                        tab[2 * (base + r) + o] = ((node_t)mo << TAB_OUT_SHIFT) | (ry << 1) | yo;
+                    if (l != 0xFFFFu && l < nn) {
+                        e[o] |= 2 * base + l;
                         if (!junction) {
-                            w = ((uint32_t)(ry - base) << 1) | yo;
+                            w = l;
                             atomicOr(&hp[w >> 5], 1u << (w & 31u));
                         }
-                    } else {  // not in this chunk: k_pm_remote looks it up through the partition table
-                        tab[2 * (base + r) + o] = ((node_t)mo << TAB_OUT_SHIFT) | TAB_NODE_MASK;
+                    } else {  // not next to it in any super-k-mer: k_pm_remote looks it up through the partition table
+                        e[o] |= TAB_NODE_MASK;
                         if (prof) ++pc[0];
                     }
-                } else {
-                    tab[2 * (base + r) + o] = (node_t)mo << TAB_OUT_SHIFT;
                 }
-                jw[me] = w;
+                jw[2 * r + o] = w;
             }
+            *reinterpret_cast<ulonglong2 *>(tab + 2 * (base + r)) = make_ulonglong2(e[0], e[1]);  // both orientations: one 16-byte store
         }
         __syncthreads();
         PM_T(1)
@@ -237,14 +225,8 @@ __global__ void __launch_bounds__(BLK, 6) k_pm_tab(PmIndex ix, const unsigned lo
         if (pc[0]) atomicAdd(&prof[5], pc[0]);
     }
 #undef PM_T
-    for (int o = 32; o > 0; o >>= 1) {
-        bits += __shfl_down(bits, o, 64);
-        pals += __shfl_down(pals, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (bits) atomicAdd(&stats[0], bits);
-        if (pals) atomicAdd(&stats[1], pals);
-    }
+    for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o, 64);
+    if ((threadIdx.x & 63) == 0 && bits) atomicAdd(&stats[0], bits);
 }
 // The successors k_pm_tab did not find in the node's own chunk (~5 % of the nodes; their entries carry TAB_NODE_MASK in the node field):
 // tiles of PMR_TILE table entries, the marked ones compacted into an LDS list, then a dense loop in which every lane has a lookup —

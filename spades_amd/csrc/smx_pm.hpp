@@ -14,6 +14,8 @@ void pm_release(smx_ctx *ctx) {
     arena_put(ctx, P.meta);
     arena_put(ctx, P.overflow);
     arena_put(ctx, P.mask);
+    arena_put(ctx, P.llink);
+    arena_put(ctx, P.pals);
     arena_put(ctx, P.dk);
     arena_put(ctx, (void *)P.ddir.dir);
     arena_put(ctx, (void *)P.ddir.boff);
@@ -91,7 +93,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     {
         const double avail = (double)arena_avail(ctx);
         if (10.0 * (double)nwin > avail) return bail(SMX_ROUTE_NA);  // the stage alone would need batches
-        const double fit1 = (avail - 5.0 * (double)nwin) / ((double)W + 3.0);
+        const double fit1 = (avail - 5.0 * (double)nwin) / ((double)W + 7.0);  // record + mask byte + local links + share of the group words
         const double fit2 = avail / ((double)W + 1.0 + 16.0 + 8.0 + 8.0);
         const double fit = std::max(std::min(fit1, fit2), 1.0);
         if (fit < (double)nwin) out_cap = (uint64_t)fit;
@@ -123,6 +125,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     arena_shrink(ctx, P.meta, (size_t)std::max<uint32_t>(P.nchunks, 1) * (P.T >> 4) * 4);
     arena_shrink(ctx, P.cinfo, (size_t)std::max<uint32_t>(P.nchunks, 1) * 8);
     arena_shrink(ctx, P.mask, (size_t)n + 16);
+    arena_shrink(ctx, P.llink, ((size_t)n + 16) * 4);
     ctx->g_mask = P.mask;
     P.mask = nullptr;
     gwt.mark(ctx, "g:kmers+masks");
@@ -184,8 +187,8 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     if (hipMemsetAsync(d_err, 0, 4, ctx->stream) != hipSuccess || hipMemsetAsync(stats, 0, 16, ctx->stream) != hipSuccess)
         return bail(fail(ctx, SMX_DEVICE_ERROR, "counter reset failed"));
     const uint32_t maxn = P.T / 2;  // winners of a chunk <= its instance capacity
-    const size_t lds = (size_t)(P.T >> 4) * 4 + (size_t)maxn * 8 + (size_t)maxn * 4 + (size_t)(maxn >> 4) * 4 + 16;
-    if ((rc = set_lds(ctx, k_pm_tab<NW>, lds))) return bail(rc);
+    const size_t lds = (size_t)maxn * 8 + (size_t)maxn * 4 + (size_t)(maxn >> 4) * 4 + 16;
+    if ((rc = set_lds(ctx, k_pm_tab, lds))) return bail(rc);
     unsigned long long *prof = nullptr;
     if (getenv("SMX_DEBUG")) {
         if ((rc = dalloc(ctx, &prof, 8))) return bail(rc);
@@ -193,8 +196,8 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     }
     tbegin(ctx, "pm_tab");
     if (P.nchunks)
-        hipLaunchKernelGGL((k_pm_tab<NW>), dim3(std::min<uint32_t>(P.nchunks, 256 * 16)), dim3(BLK), lds, ctx->stream, pw.ix, (const unsigned long long *)P.cinfo,
-                           P.nchunks, maxn, k, tab, jmp, stats, d_err, prof);
+        hipLaunchKernelGGL(k_pm_tab, dim3(std::min<uint32_t>(P.nchunks, 256 * 16)), dim3(BLK), lds, ctx->stream, (const unsigned long long *)P.cinfo, P.nchunks,
+                           maxn, (const uint8_t *)ctx->g_mask, (const uint32_t *)P.llink, tab, jmp, stats, d_err, prof);
     if (P.ndirty)
         hipLaunchKernelGGL((k_pm_tab_dirty<NW>), dim3(grid_for(P.ndirty)), dim3(BLK), 0, ctx->stream, pw.ix, (uint64_t)P.ndirty, k, tab, jmp, stats, d_err);
     tend(ctx);
@@ -204,9 +207,13 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
                            (uint64_t)(2 * P.nclean), k, tab, d_err);
     tend(ctx);
     if (hipGetLastError() != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "k_pm_tab launch failed"));
-    unsigned long long hs[2] = {0, 0};
-    if (hipMemcpyAsync(hs, stats, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+    unsigned long long hs[2] = {0, 0}, hpal = 0;
+    if (hipMemcpyAsync(hs, stats, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(&hpal, P.pals, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
         return bail(fail(ctx, SMX_DEVICE_ERROR, "node table pass failed: %s", hipGetErrorString(hipGetLastError())));
+    hs[1] += hpal;  // palindromic (k+1)-mers: the clean winners' by the dedupe stage, the dirty region's by k_pm_tab_dirty
+    arena_put(ctx, P.llink);  // (only k_pm_tab reads the local links)
+    P.llink = nullptr;
     if (prof) {
         unsigned long long hp[8];
         if (hipMemcpy(hp, prof, 64, hipMemcpyDeviceToHost) == hipSuccess)

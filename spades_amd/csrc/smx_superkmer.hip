@@ -393,6 +393,10 @@ struct PmOut {
     uint32_t *meta;             // [max_chunks * (T / 16)] group words
     unsigned long long *cinfo;  // [max_chunks] base | winners << 40
     uint8_t *mask;              // [out_cap] InOutMask byte of every clean winner, at its record's index
+    uint32_t *llink;            // [out_cap] preset to ~0: per winner two 16-bit local links (low half: successor of the k-mer as stored,
+                                // high half: of its reverse complement) = 2 * (index in the chunk) + orientation of the successor node where
+                                // some read holds the two k-mers side by side inside one super-k-mer; 0xFFFF: none seen (k_pm_remote asks)
+    unsigned long long *pals;   // palindromic (k+1)-mers among the extensions of the clean winners (k_ext_split's second figure)
     uint32_t max_chunks;
     uint32_t *overflow;         // set when a chunk got no room in meta / cinfo
 };
@@ -433,6 +437,7 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
     Rec<NW> *out = (Rec<NW> *)out_;
     const unsigned lane = threadIdx.x & 63;
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;  // SMX_DEBUG: 100 MHz ticks per phase seen by thread 0
+    unsigned npal = 0;
 #define SKM_T(i)                                 \
     if (prof && threadIdx.x == 0) {              \
         unsigned long long t1 = wall_clock64();  \
@@ -554,6 +559,7 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                         else eb = (hasl ? (1u << (3u - L)) : 0u) | (hasr ? (16u << (3u - R)) : 0u);
                         if (eb) atomicOr(&tab[h], eb << 16);
                         code = h;  // the winners are listed by their table entry
+                        if constexpr (PM) imap[i] = (uint16_t)((h << 2) | (fwd ? 2u : 0u) | (j + 1 == c ? 1u : 0u));  // for the link pass below
                     }
                 }
                 if constexpr (!PM) {
@@ -589,6 +595,13 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                         for (uint32_t o = occ[g]; o; o &= o - 1) wl[p++] = (uint16_t)((g0 + g) * 16 + __ffs(o) - 1);
                 }
                 if (threadIdx.x == 0) s_wcount = tot;
+                if (ngroups * 4u <= 2056u && g0 < ngroups) {  // the group words in LDS too (over cpre, dead by now): rank of any table slot
+                    uint32_t p = pre;
+                    for (uint32_t g = 0; g < gpt; ++g) {
+                        cpre[g0 + g] = p | (occ[g] << 16);
+                        p += __popc(occ[g]);
+                    }
+                }
                 __syncthreads();
             }
             SKM_T(2)
@@ -657,10 +670,59 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                     Rec<NW> cx;
 #pragma unroll
                     for (int t = 0; t < NW; ++t) cx.w[t] = fwd ? x.w[t] : y.w[t];
+                    if constexpr (PM) {
+                        if (!dirty) {
+                            pm.mask[s_gbase + i] = (uint8_t)eb;
+                            // palindromic (k+1)-mers among the extensions (registers only): cx + c is its own reverse complement iff c is the
+                            // complement of cx[0] and cx[1..K-1] equals RC(cx)[0..K-2]; likewise b + cx with cx[0..K-2] against RC(cx)[1..K-1]
+                            const Rec<NW> &rx = fwd ? y : x;  // reverse complement of the canonical k-mer
+                            const unsigned c0 = (unsigned)cx.w[0] & 3u, cl_ = (unsigned)(cx.w[NW - 1] >> (((K - 1) & 31u) << 1)) & 3u;
+                            if (((eb >> (3 - c0)) & 1) || ((eb >> (7 - cl_)) & 1)) {
+                                Rec<NW> xs, rs, xp = cx, rp = rx;  // suffixes (drop base 0) and prefixes (drop base K-1)
+#pragma unroll
+                                for (int t = 0; t < NW; ++t) {
+                                    xs.w[t] = (cx.w[t] >> 2) | (t + 1 < NW ? cx.w[t + 1] << 62 : 0ull);
+                                    rs.w[t] = (rx.w[t] >> 2) | (t + 1 < NW ? rx.w[t + 1] << 62 : 0ull);
+                                }
+                                const uint64_t topm = ~(3ull << (((K - 1) & 31u) << 1));
+                                xp.w[NW - 1] &= topm;
+                                rp.w[NW - 1] &= topm;
+                                if (((eb >> (3 - c0)) & 1) && rec_eq<NW>(xs, rp)) ++npal;
+                                if (((eb >> (7 - cl_)) & 1) && rec_eq<NW>(xp, rs)) ++npal;
+                            }
+                        }
+                    }
                     if constexpr (EXT) cx.w[NW - 1] = (cx.w[NW - 1] << EXT_BITS) | eb;
                     dst[i] = cx;
-                    if constexpr (PM)
-                        if (!dirty) pm.mask[s_gbase + i] = (uint8_t)eb;
+                }
+            }
+            if constexpr (PM) {
+                // Local links. imap[i] = (table slot, strand, last of its slot) of instance i: instances i, i+1 of one super-k-mer are k-mers
+                // X_i -> X_{i+1} side by side in a read, i.e. a de Bruijn edge between the nodes of their table entries (and the reverse
+                // one between the other strands). A node with ONE outgoing extension has one successor, whichever read shows it; where
+                // several reads disagree the node has several extensions and nobody reads the link. The link table (16 bits per node,
+                // indexed by winner rank) lies over the slot staging area, dead after the output above.
+                __syncthreads();
+                uint16_t *lnk = (uint16_t *)sl;
+                const bool fits = !dirty && !s_skip && wcount && (size_t)wcount * 4 <= (size_t)scap * SW * 8 && ngroups * 4u <= 2056u;
+                if (fits) {
+                    for (uint32_t t = threadIdx.x; t < 2 * wcount; t += BLK) lnk[t] = 0xFFFFu;
+                    __syncthreads();
+                    auto rank_of = [&](uint32_t h) -> uint32_t {
+                        const uint32_t g = cpre[h >> 4];
+                        return (g & 0xFFFFu) + __popc((g >> 16) & ((1u << (h & 15u)) - 1u));
+                    };
+                    for (uint32_t i = threadIdx.x; i + 1 < ninst; i += BLK) {
+                        const uint32_t v = imap[i];
+                        if (v & 1u) continue;  // the last window of its super-k-mer: its neighbour lives in another slot
+                        const uint32_t w2 = imap[i + 1];
+                        const uint32_t na = 2 * rank_of(v >> 2) + ((v & 2u) ? 0u : 1u), nb = 2 * rank_of(w2 >> 2) + ((w2 & 2u) ? 0u : 1u);
+                        lnk[na] = (uint16_t)nb;
+                        lnk[nb ^ 1u] = (uint16_t)(na ^ 1u);
+                    }
+                    __syncthreads();
+                    uint16_t *gl = (uint16_t *)(pm.llink + s_gbase);
+                    for (uint32_t t = threadIdx.x; t < 2 * wcount; t += BLK) gl[t] = lnk[t];
                 }
             }
             s_cur += ntake;
@@ -674,6 +736,8 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
     }
     if (prof && threadIdx.x == 0)
         for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], pt[i]);
+    if constexpr (PM)
+        if (npal) atomicAdd(pm.pals, (unsigned long long)npal);
 #undef SKM_T
 }
 
