@@ -584,7 +584,7 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         if (int rc = dalloc(ctx, &a.stage_slots, (size_t)a.stage_cap * SW)) return rc;
         if (int rc = dalloc(ctx, &a.stage_part, (size_t)a.stage_cap)) return rc;
         if (int rc = dalloc(ctx, &st_alloc, 2)) return rc;
-        HIPCHK(hipMemsetAsync(a.stage_part, 0xFF, (size_t)a.stage_cap * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(a.stage_part, 0xFF, (size_t)a.stage_cap * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(st_alloc, 0, 16, ctx->stream));
         a.stage_alloc = st_alloc;
     }
@@ -608,7 +608,7 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         const uint64_t n_stage = std::min<uint64_t>(st[0], a.stage_cap);
         if (n_stage) {
             hipLaunchKernelGGL((k_skm_permute<NW>), dim3((unsigned)std::min<uint64_t>((n_stage + BLK - 1) / BLK, 1u << 16)), dim3(BLK), 0, ctx->stream,
-                               (const uint64_t *)a.stage_slots, (const uint32_t *)a.stage_part, n_stage, cursor, slots);
+                               (const uint64_t *)a.stage_slots, (const unsigned long long *)a.stage_part, n_stage, (const unsigned long long *)soff, slots);
             HIPCHK(hipGetLastError());
         }
     } else {

@@ -48,7 +48,8 @@ struct SkmArgs {
     // phase 0 with staging: the super-k-mers are also written out in scan order (dense, coalesced) together with their partition,
     // so that placing them (k_skm_permute) does not have to scan the reads a second time
     uint64_t *stage_slots;               // [stage_cap * SW] or nullptr
-    uint32_t *stage_part;                // [stage_cap], preset to 0xFFFFFFFF (= unused entry)
+    unsigned long long *stage_part;      // [stage_cap], preset to all ones (= unused entry): partition | rank inside the partition << 32 (what the
+                                         // counting atomic returned: placing the entry needs no second atomic, only the partition's offset)
     unsigned long long stage_cap;
     unsigned long long *stage_alloc;     // [2]: next free staging entry (handed out in blocks), overflow flag
 };
@@ -287,10 +288,10 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
             const uint32_t key = skm_part(keys[e & 0xFFFu], a.pshift);
             uint64_t *dst = nullptr;
             if constexpr (PHASE == 0) {
-                atomicAdd(&a.cnt[key], 1ull);
+                const unsigned long long rank = atomicAdd(&a.cnt[key], 1ull);
                 if (stage0 != ~0ull) {
                     dst = a.stage_slots + (stage0 + si) * SW;
-                    a.stage_part[stage0 + si] = key;
+                    a.stage_part[stage0 + si] = (unsigned long long)key | (rank << 32);
                 }
             } else {
                 dst = a.slots + atomicAdd(&a.cursor[key], 1ull) * SW;
@@ -334,16 +335,16 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
 
 // staged super-k-mers (scan order) -> their place in the partition-sorted slot array
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_skm_permute(const uint64_t *__restrict__ stage_slots, const uint32_t *__restrict__ stage_part,
-                                                     uint64_t n_stage, unsigned long long *cursor, uint64_t *slots) {
+__global__ void __launch_bounds__(BLK) k_skm_permute(const uint64_t *__restrict__ stage_slots, const unsigned long long *__restrict__ stage_part,
+                                                     uint64_t n_stage, const unsigned long long *__restrict__ soff, uint64_t *slots) {
     constexpr int SW = 2 * NW;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n_stage; i += (uint64_t)gridDim.x * BLK) {
-        const uint32_t part = stage_part[i];
-        if (part == 0xFFFFFFFFu) continue;
+        const unsigned long long pr = stage_part[i];
+        if (pr == ~0ull) continue;
         uint64_t v[SW];
 #pragma unroll
         for (int t = 0; t < SW; ++t) v[t] = stage_slots[i * SW + t];
-        uint64_t *dst = slots + atomicAdd(&cursor[part], 1ull) * SW;
+        uint64_t *dst = slots + (soff[(uint32_t)pr] + (pr >> 32)) * SW;  // the place the counting pass reserved
 #pragma unroll
         for (int t = 0; t < SW; ++t) dst[t] = v[t];
     }
@@ -677,7 +678,10 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
                             // complement of cx[0] and cx[1..K-1] equals RC(cx)[0..K-2]; likewise b + cx with cx[0..K-2] against RC(cx)[1..K-1]
                             const Rec<NW> &rx = fwd ? y : x;  // reverse complement of the canonical k-mer
                             const unsigned c0 = (unsigned)cx.w[0] & 3u, cl_ = (unsigned)(cx.w[NW - 1] >> (((K - 1) & 31u) << 1)) & 3u;
-                            if (((eb >> (3 - c0)) & 1) || ((eb >> (7 - cl_)) & 1)) {
+                            // (first the matching extension bit AND complementary outermost bases of the inner (K-1)-mer: 1 winner in 16)
+                            const uint64_t wsel = ((K - 2) >> 5) == (unsigned)(NW - 1) ? cx.w[NW - 1] : cx.w[NW > 1 ? NW - 2 : 0];
+                            const unsigned c1 = (unsigned)(cx.w[0] >> 2) & 3u, cm = (unsigned)(wsel >> (((K - 2) & 31u) << 1)) & 3u;
+                            if ((((eb >> (3 - c0)) & 1) && c1 + cl_ == 3) || (((eb >> (7 - cl_)) & 1) && c0 + cm == 3)) {
                                 Rec<NW> xs, rs, xp = cx, rp = rx;  // suffixes (drop base 0) and prefixes (drop base K-1)
 #pragma unroll
                                 for (int t = 0; t < NW; ++t) {
