@@ -30,7 +30,39 @@ L = 150
 INSERT = 350
 
 
-def synth_reads_device(seed, genome_len, n_reads, dev, err=0.01, genome_seed=2, n_rate=0.0):
+def skew_genome_device(genome, gg, n_genomes=1000, repeat_frac=0.3, lowc_frac=0.01):
+    """SURVEY.md §8d config-4 shape, in place on the device: the sequence is cut into `n_genomes` genomes (a read never spans two), 30 % of
+    it is overwritten by copies (half of them inverted) of random 500..5000-bp segments of the same genome, 1 % by low-complexity runs
+    (homopolymers, di- and trinucleotide repeats of 50..300 bp). Returns the genome starts (int64[n_genomes + 1], host)."""
+    import numpy as np
+    G = genome.numel()
+    rng = np.random.default_rng(12345)
+    cuts = np.sort(rng.choice(np.arange(10000, G - 10000), n_genomes - 1, replace=False))
+    starts = np.concatenate([[0], cuts, [G]]).astype(np.int64)
+    done = 0
+    while done < repeat_frac * G:
+        gi = int(rng.integers(0, n_genomes))
+        a, b = int(starts[gi]), int(starts[gi + 1])
+        ln = int(rng.integers(500, 5001))
+        if b - a < 2 * ln + 10:
+            continue
+        src, dst = int(rng.integers(a, b - ln)), int(rng.integers(a, b - ln))
+        seg = genome[src:src + ln].clone()
+        if rng.random() < 0.5:
+            seg = (3 - seg).flip(0)
+        genome[dst:dst + ln] = seg
+        done += ln
+    done = 0
+    while done < lowc_frac * G:
+        ln = int(rng.integers(50, 301))
+        dst = int(rng.integers(0, G - ln))
+        unit = torch.from_numpy(rng.integers(0, 4, int(rng.integers(1, 4)), dtype=np.uint8)).to(genome.device)
+        genome[dst:dst + ln] = unit.repeat(ln // unit.numel() + 1)[:ln]
+        done += ln
+    return starts
+
+
+def synth_reads_device(seed, genome_len, n_reads, dev, err=0.01, genome_seed=2, n_rate=0.0, skew=False):
     """SURVEY.md §8d generator on the GPU: iid genome, PE150 pairs (read2 = RC of the far end), 1 % substitutions, n_rate N's
     (each read is then cut to its longest ACGT run, first one on ties — io::LongestValid — by choosing (start, len)).
     Returns (words int64[n_words+8], start int64[n], len int32[n], codes uint8[n, L] with 4 = N)."""
@@ -44,9 +76,22 @@ def synth_reads_device(seed, genome_len, n_reads, dev, err=0.01, genome_seed=2, 
     codes = torch.empty((n_reads, L), dtype=torch.uint8, device=dev)
     idx = torch.arange(L, device=dev)
     chunk = 1 << 19
+    if skew:  # log-normal abundances (sigma 1.5) over 1000 genomes with repeats and low-complexity runs
+        import numpy as np
+        starts_h = skew_genome_device(genome, gg)
+        rs = np.random.default_rng(777)
+        size = np.diff(starts_h).astype(np.float64)
+        ab = rs.lognormal(0.0, 1.5, len(size)) * size
+        ab_t = torch.from_numpy(ab / ab.sum()).to(dev)
+        st_t, sz_t = torch.from_numpy(starts_h[:-1]).to(dev), torch.from_numpy(size).to(dev)
     for c0 in range(0, n_pairs, chunk):
         c1 = min(n_pairs, c0 + chunk)
-        p = torch.randint(0, genome_len - INSERT + 1, (c1 - c0,), device=dev, generator=g)
+        if skew:
+            gi = torch.multinomial(ab_t, c1 - c0, replacement=True, generator=g)
+            p = st_t[gi] + (torch.rand(c1 - c0, device=dev, generator=g, dtype=torch.float64) * (sz_t[gi] - INSERT).clamp(min=1)).to(torch.int64)
+            p = torch.minimum(p, st_t[gi] + sz_t[gi].to(torch.int64) - INSERT)
+        else:
+            p = torch.randint(0, genome_len - INSERT + 1, (c1 - c0,), device=dev, generator=g)
         codes[2 * c0:2 * c1:2] = genome[p[:, None] + idx[None, :]]
         codes[2 * c0 + 1:2 * c1:2] = 3 - genome[(p + INSERT - 1)[:, None] - idx[None, :]]
     del genome
@@ -254,6 +299,9 @@ def main():
     ap.add_argument("--sorted-route", action="store_true",
                     help="N=1: k-mers + masks from one count of the reads, SORTED into the k-mer file before the construction (the round-2 default); "
                          "without it the construction never sorts the k-mers (nodes numbered by minimizer partition)")
+    ap.add_argument("--skew", action="store_true",
+                    help="SURVEY.md §8d config-4 shape of data: 1000 genomes with log-normal abundances, 30 %% repeats (500..5000-bp copies, half inverted), "
+                         "1 %% low-complexity runs — same size and read model (the default genome is iid uniform)")
     ap.add_argument("--sync-upload", action="store_true", help="N=1: the H2D copy of the step finishes before any kernel starts (round-2 behaviour)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option for this run (smx_set_option), e.g. dir_slots=2")
     ap.add_argument("--sharded-construct", type=float, default=10e6,
@@ -291,7 +339,7 @@ def main():
     K1, nb = k + 1, 10 * T
     nw = (K1 + 31) // 32
     W = 8 * nw
-    words, start, ln, codes = synth_reads_device(1000 + rank, int(args.genome), n_reads, dev, n_rate=args.n_rate)
+    words, start, ln, codes = synth_reads_device(1000 + rank, int(args.genome), n_reads, dev, n_rate=args.n_rate, skew=args.skew)
     n_sample = int(min(args.cpu_sample, n_reads)) // 32 * 32
     if args.no_cpu_baseline:
         n_sample = 0
@@ -447,7 +495,8 @@ def main():
         "value": round(value, 3), "unit": "M reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": (f"BASELINE config 3: synthetic {n_reads / 1e6:g} M PE150 reads (genome {args.genome / 1e6:g} Mbp iid, 1% subst., "
+        "config": {"workload": (f"BASELINE config 3: synthetic {n_reads / 1e6:g} M PE150 reads (genome {args.genome / 1e6:g} Mbp " +
+                                ("in 1000 genomes with log-normal abundances, 30% repeats, 1% low complexity" if args.skew else "iid") + ", 1% subst., "
                                 f"{args.n_rate * 100:g}% N), k={k}: upload from page-locked host memory + " +
                                 (f"count of the canonical {k}-mers together with their extension masks (= the canonical {K1}-mer set: every "
                                  f"{K1}-mer of the reads is one extension bit at its prefix and one at its suffix {k}-mer) " if ext_route else
@@ -484,6 +533,10 @@ def main():
                                          "kernel": ("construction (rank directory, successor table, walks, link records)" if ext_route else
                                                     "construction (k-mer file, rank directory, masks + successors, walks, link records)") + ": sum of its stage kernels",
                                          "algorithmic_bytes_per_step": int(b_con), "kernel_ms_per_step": round(construct_ms, 3)}}
+        try:
+            out["construct"]["route_stats"] = gb.route_stats()
+        except Exception as e:  # noqa: BLE001
+            out["construct"]["route_stats"] = str(e)
         out["step_breakdown_ms"] = {"count_kernels": round(count_ms, 1), "construct_kernels": round(construct_ms, 1),
                                     "host_and_upload": round(ms_per_step - count_ms - construct_ms, 1)}
         # the dominant single kernel of the step: k_fill_tab (node table: two rank lookups + two 64-bit atomics per (k+1)-mer)

@@ -51,6 +51,7 @@ def load():
         "smx_submit_reads_packed": (C.c_int, [vp, u64p, C.c_uint64, u64p, u32p, C.c_uint64]),
         "smx_submit_reads_device": (C.c_int, [vp, vp, C.c_uint64, vp, vp, C.c_uint64]),
         "smx_graph_tip_stats": (C.c_int, [vp, u64p]),
+        "smx_graph_route_stats": (C.c_int, [vp, u64p]),
         "smx_graph_copy_flanking": (C.c_int, [vp, u32p, u32p]),
         "smx_build_graph_from_records": (C.c_int, [vp, C.c_uint, C.c_uint, vp, C.c_uint64]),
         "smx_graph_set_coverage": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_uint64]),

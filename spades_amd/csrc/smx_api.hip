@@ -1053,6 +1053,12 @@ int smx_graph_info(const smx_ctx *ctx, uint64_t *info /* [8] */) {
     return SMX_OK;
 }
 
+int smx_graph_route_stats(const smx_ctx *ctx, uint64_t *stats /* [8] */) {
+    if (!ctx || !stats || !ctx->g_ready) return SMX_INVALID_PARAMETER;
+    for (int i = 0; i < 8; ++i) stats[i] = ctx->g_route_stats[i];
+    return SMX_OK;
+}
+
 int smx_graph_tip_stats(const smx_ctx *ctx, uint64_t *stats /* [4] */) {
     if (!ctx || !stats || !ctx->g_ready) return SMX_INVALID_PARAMETER;
     stats[0] = ctx->g_tip_kmers;

@@ -748,6 +748,8 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < CAND_NJ; ++i) n_junction += h_nj[i];
     tend(ctx);
+    ctx->g_route_stats[4] = n_junction;
+    ctx->g_route_stats[5] = C;
     gwt.mark(ctx, "g:masks+succ");
     uint64_t nkept = 0, ktotalw = 0;
     unsigned long long interior = 0;
@@ -1096,9 +1098,11 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         ~Prefix() { c->tprefix.clear(); }
     };
     // ---- 0. k-mers and masks from one count of the reads, when that applies ---------------------
+    for (auto &v : ctx->g_route_stats) v = 0;
     if (!kpo_recs) {
         int rc = pm_route<NW>(ctx, k, B, gwt);  // no sorted k-mer file at all where that applies (smx_pm.hpp)
         if (rc != SMX_ROUTE_NA) return rc;
+        for (auto &v : ctx->g_route_stats) v = 0;
         ctx->g_k = k;  // (a route that gave up cleared the graph state)
         ctx->g_nw = NW;
         ctx->g_B = B;
@@ -1110,6 +1114,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         }
         if (rc == 0) {
             gwt.mark(ctx, "g:kmers+masks");
+            ctx->g_route_stats[0] = 1;
             const uint64_t D0 = ctx->g_nkmers;
             if (D0 == 0) {
                 ctx->g_host_valid = true;  // the empty graph
@@ -1134,6 +1139,7 @@ int run_graph(smx_ctx *ctx, unsigned k, unsigned B, const void *kpo_recs = nullp
         if (rc != SMX_ROUTE_NA) return rc;
     }
     // ---- 1. canonical (k+1)-mers -------------------------------------------------------------
+    ctx->g_route_stats[0] = 2;
     if (kpo_recs) {  // multi-GPU: the (k+1)-mer file gathered from its owner ranks (any order; re-sorted here)
         if (int rc = run_count<NW>(ctx, k + 1, SMX_MODE_ALL, B, kpo_recs, n_kpo_recs)) return rc;
     } else {

@@ -54,6 +54,8 @@ struct PmState {
     uint32_t max_chunks = 0, nchunks = 0, T = 0, nkey = 0;
     unsigned m = 0, w = 0, pshift = 0;
     uint64_t nclean = 0, ndirty = 0;
+    unsigned dirty_B = 1;               // the dirty region is sorted bucket-major in this many hash buckets
+    std::vector<uint64_t> dirty_boff;   // their offsets
     void *dk = nullptr;  // the k-mers of the dirty region without their bytes (sorted: what its rank directory indexes)
     smx::RankDir ddir{};
 };
@@ -79,6 +81,7 @@ struct smx_ctx {
     bool result_on_host = false;
     uint64_t g_ext_bits = 0, g_ext_pals = 0;  // extension bits / palindromic (k+1)-mers among them in the k-mer file or shard built from EXT records
     PmState pm;               // partition-major construction route
+    uint64_t g_route_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // smx_graph_route_stats of the last build
     bool g_pm = false;        // g_kmers holds EXT records in partition-major order (no sorted k-mer file yet: made on demand)
     bool pm_view_pending = false;  // the count-result view (smx_copy_final_kmers, smx_bucket_sizes, ...) stands for the k-mer file of that
                                    // graph, not made yet; any later count owns the view again (clear_result)

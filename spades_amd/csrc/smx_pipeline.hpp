@@ -627,8 +627,11 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     // Output capacity: one record per window can never overflow; a smaller buffer (HBM-bounded) keeps a share for the survivors of
     // cut keys at its far end and reports an overflow (the caller then takes smaller batches).
     if (out_cap == 0 || out_cap > nwin) out_cap = nwin;
-    const uint64_t dirty_cap = out_cap == nwin ? out_cap : std::max<uint64_t>(out_cap / 16, 1);
-    const uint64_t clean_cap = out_cap == nwin ? out_cap : out_cap - dirty_cap;
+    // The clean winners grow from the front of the buffer, the survivors of cut keys from its back: each side only has to stay inside the
+    // buffer (no write can leave it); whether the two met is seen from the two counts afterwards (then the caller takes smaller
+    // batches / another route). A fixed share for the survivors made skewed abundances (a fifth of the k-mers in cut partitions) fail
+    // for no reason.
+    const uint64_t dirty_cap = out_cap, clean_cap = out_cap;
     if (int rc = dalloc(ctx, out, out_cap + 1)) return rc;
     // Chunk capacity of the LDS hash set: every copy of a k-mer sits in ONE partition, and a partition that does not fit a chunk is
     // cut (its survivors need a unique pass of their own). The partition a typical super-k-mer lives in holds sum(c^2)/sum(c) slots —
@@ -640,17 +643,31 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         while (cap < (uint32_t)std::min<int64_t>(ctx->opt_skm_cap, 8192)) cap <<= 1;
     } else if (nslots) {
         unsigned long long *sums;
-        if (int rc = dalloc(ctx, &sums, 2)) return rc;
-        HIPCHK(hipMemsetAsync(sums, 0, 16, ctx->stream));
-        hipLaunchKernelGGL(k_skm_moments, dim3(1024), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cnt, SKM_NKEY, sums);
+        if (int rc = dalloc(ctx, &sums, 5)) return rc;
+        HIPCHK(hipMemsetAsync(sums, 0, 40, ctx->stream));
+        const double ips0 = (double)nwin / (double)std::max<unsigned long long>(nslots, 1);
+        hipLaunchKernelGGL(k_skm_moments, dim3(1024), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cnt, SKM_NKEY, sums,
+                           (unsigned long long)(2048.0 / ips0), (unsigned long long)(4096.0 / ips0), (unsigned long long)(8192.0 / ips0));
         HIPCHK(hipGetLastError());
-        unsigned long long hs[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(hs, sums, 16, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long hs[5] = {0, 0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(hs, sums, 40, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         const double typical_slots = hs[0] ? (double)hs[1] / (double)hs[0] : 0.0;
         const double typical_inst = typical_slots * (double)nwin / (double)nslots;
-        while (cap < 8192 && typical_inst * 1.6 > cap) cap <<= 1;
-        if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] prededupe: typical partition %.0f slots = %.0f instances -> chunk capacity %u\n", typical_slots, typical_inst, cap);
+        // A bigger chunk costs occupancy for EVERY partition (8192 instances: one workgroup per CU, measured 5x slower), a cut partition
+        // only costs its own k-mers a trip through the sort (measured on log-normal abundances + low complexity: 39 % of the slots in
+        // cut partitions at 2048 cost less than the halved occupancy of 4096). So the capacity follows the bulk of the partitions, not
+        // the heavy tail: the smallest one that leaves at most 60 % of the slots in partitions that will be cut (uniformly deep
+        // coverage moves to 4096 / 8192) — and 2048 where even 8192 does not.
+        const double ips = (double)nwin / (double)nslots;  // instances per slot on average
+        uint32_t pick = 0;
+        for (uint32_t c = 2048, t = 0; c <= 8192 && !pick; c <<= 1, ++t)
+            if ((double)hs[2 + t] <= 0.6 * (double)hs[0]) pick = c;
+        cap = pick ? pick : 2048;
+        if (getenv("SMX_DEBUG"))
+            fprintf(stderr, "[smx] prededupe: typical partition %.0f slots = %.0f instances; slots in partitions beyond 2048/4096/8192 instances: %.1f%% %.1f%% %.1f%% -> chunk capacity %u\n",
+                    typical_slots, typical_inst, hs[0] ? 100.0 * hs[2] / hs[0] : 0.0, hs[0] ? 100.0 * hs[3] / hs[0] : 0.0, hs[0] ? 100.0 * hs[4] / hs[0] : 0.0, cap);
+        (void)ips;
     }
     const uint32_t T = 2 * cap;
     const uint32_t scap = std::min<uint32_t>(SKM_SCAP, ctx->opt_skm_scap > 0 ? (uint32_t)ctx->opt_skm_scap : cap / 8);  // ~12+ windows per slot on average
@@ -730,10 +747,14 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         if (pm_over) return SMX_ROUTE_NA;  // more chunks than planned for (pathological partition sizes): the caller takes the sorted route
     }
     if (nn[0] + nn[1] > nwin) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication produced %llu records from %llu windows", nn[0] + nn[1], (unsigned long long)nwin);
-    if (nn[0] > clean_cap || nn[1] > dirty_cap) return SMX_RETRY_SMALLER;
+    if (nn[0] + nn[1] > out_cap) return SMX_RETRY_SMALLER;
     unsigned long long n = nn[0];
     if (nn[1]) {  // survivors of cut keys: sort + unique them on their own, then the whole array is exactly distinct
-        if (int rc = run_count<NW>(ctx, K, SMX_MODE_ALL, 1, *out + (out_cap - nn[1]), nn[1])) return rc;
+        // (hash buckets first, like every other count: the cut partitions are the low-complexity and the heavy ones, and by raw key alone
+        // 10^5 near-copies of a homopolymer k-mer fall into ONE sort bin — measured 1.5 s in the single-workgroup path of oversized bins)
+        const unsigned DB = SKM_DIRTY_BUCKETS;
+        if (int rc = run_count<NW>(ctx, K, SMX_MODE_ALL, DB, *out + (out_cap - nn[1]), nn[1])) return rc;
+        std::vector<uint64_t> dboff = ctx->bucket_off;
         if (ext && ctx->n_records && ctx->opt_ext_presort != 0) {
             // copies of a k-mer that left different chunks with different extension bytes are neighbours now: one record, bytes ORed
             const uint64_t nd = ctx->n_records, ntiles = (nd + XM_TILE - 1) / XM_TILE;
@@ -751,9 +772,26 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
             HIPCHK(hipGetLastError());
             unsigned long long nm = 0;
             HIPCHK(hipMemcpyAsync(&nm, toff + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (pmode) {  // the bucket offsets of the merged array (its rank directory needs them)
+                unsigned long long *d_old, *d_new;
+                if (int rc = dalloc(ctx, &d_old, DB + 1)) return rc;
+                if (int rc = dalloc(ctx, &d_new, DB + 1)) return rc;
+                std::vector<unsigned long long> h(dboff.begin(), dboff.end());
+                HIPCHK(hipMemcpyAsync(d_old, h.data(), (size_t)(DB + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL((k_ext_boff<NW>), dim3((DB + 1 + BLK - 1) / BLK), dim3(BLK), 0, ctx->stream, (const void *)ctx->d_result_buf, nd,
+                                   (const unsigned long long *)toff, (const unsigned long long *)d_old, DB + 1, d_new);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(h.data(), d_new, (size_t)(DB + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                for (unsigned b = 0; b <= DB; ++b) dboff[b] = h[b];
+            }
             HIPCHK(hipStreamSynchronize(ctx->stream));
             ctx->d_result_buf = ctx->d_result = merged;  // (both buffers stay in the temp list)
             ctx->n_records = nm;
+        }
+        if (pmode) {
+            ctx->pm.dirty_B = DB;
+            ctx->pm.dirty_boff = dboff;
         }
         HIPCHK(hipMemcpyAsync(*out + nn[0], ctx->d_result_buf, ctx->n_records * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -150,9 +150,11 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         hipLaunchKernelGGL((k_pm_dirty_split<NW>), dim3(grid_for(P.ndirty)), dim3(BLK), 0, ctx->stream, (const void *)recs, (uint64_t)P.nclean, (uint64_t)P.ndirty,
                            (void *)dk, ctx->g_mask);
         if (hipGetLastError() != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "k_pm_dirty_split launch failed"));
-        std::vector<uint64_t> dboff{0, P.ndirty};
+        if (P.dirty_boff.size() != (size_t)P.dirty_B + 1 || P.dirty_boff.back() != P.ndirty)
+            return bail(fail(ctx, SMX_DEVICE_ERROR, "bucket offsets of the sorted tail do not add up (%llu of %llu)",
+                             (unsigned long long)(P.dirty_boff.empty() ? 0 : P.dirty_boff.back()), (unsigned long long)P.ndirty));
         tbegin(ctx, "rank_dir");
-        rc = build_rank_dir<NW>(ctx, dk, P.ndirty, dboff, 1, k, P.ddir);
+        rc = build_rank_dir<NW>(ctx, dk, P.ndirty, P.dirty_boff, P.dirty_B, k, P.ddir);
         tend(ctx);
         if (rc) return bail(rc);
     }
@@ -226,6 +228,10 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     ctx->g_ext_bits = hs[0];
     ctx->g_ext_pals = hs[1];
     ctx->g_nkpo = (hs[0] + hs[1]) / 2;
+    ctx->g_route_stats[0] = 0;
+    ctx->g_route_stats[1] = P.nclean;
+    ctx->g_route_stats[2] = P.ndirty;
+    ctx->g_route_stats[3] = P.nchunks;
     rc = graph_from_masks<NW>(ctx, k, tab, /*tab_valid=*/true, d_err, gwt, /*present=*/true, &pw);
     if (rc) return bail(rc);
     // the count-result view: the k-mer file is made when somebody asks for it (pm_materialize_file)

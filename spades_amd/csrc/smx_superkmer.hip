@@ -30,6 +30,7 @@ constexpr int SKM_TC = BLK * 8;                       // windows examined per ti
 constexpr int SKM_TP = SKM_TC - 128;                  // windows a tile emits starts for; the rest is look-ahead (>= WMAX)
 constexpr uint32_t SKM_SCAP = 512;                    // most slots staged per dedupe chunk (two per thread in the prefix scan)
 constexpr uint32_t SKM_KEYS_PER_ITEM = 256;
+constexpr unsigned SKM_DIRTY_BUCKETS = 1024;          // hash buckets of the sort of the survivors of cut partitions
 
 struct SkmArgs {
     const uint64_t *seq;
@@ -351,20 +352,31 @@ __global__ void __launch_bounds__(BLK) k_skm_permute(const uint64_t *__restrict_
 }
 
 // sum and sum of squares of the per-partition slot counts: sum2 / sum = the partition size a random super-k-mer lives in
-__global__ void __launch_bounds__(BLK) k_skm_moments(const unsigned long long *__restrict__ cnt, uint32_t n, unsigned long long *sums) {
+// ... and sums[2..4] = slots in partitions of more than thr0 / thr1 / thr2 slots (the partitions a chunk capacity would cut)
+__global__ void __launch_bounds__(BLK) k_skm_moments(const unsigned long long *__restrict__ cnt, uint32_t n, unsigned long long *sums, unsigned long long thr0,
+                                                     unsigned long long thr1, unsigned long long thr2) {
     __shared__ unsigned long long scratch[BLK / 64 + 2];
-    unsigned long long s1 = 0, s2 = 0;
+    unsigned long long s1 = 0, s2 = 0, b0 = 0, b1 = 0, b2 = 0;
     for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
         const unsigned long long c = cnt[i];
         s1 += c;
         s2 += c * c;
+        if (c > thr0) b0 += c;
+        if (c > thr1) b1 += c;
+        if (c > thr2) b2 += c;
     }
-    unsigned long long t1, t2;
+    unsigned long long t1, t2, u0, u1, u2;
     block_excl_scan<unsigned long long>(s1, scratch, &t1);
     block_excl_scan<unsigned long long>(s2, scratch, &t2);
+    block_excl_scan<unsigned long long>(b0, scratch, &u0);
+    block_excl_scan<unsigned long long>(b1, scratch, &u1);
+    block_excl_scan<unsigned long long>(b2, scratch, &u2);
     if (threadIdx.x == 0) {
         atomicAdd(&sums[0], t1);
         atomicAdd(&sums[1], t2);
+        if (u0) atomicAdd(&sums[2], u0);
+        if (u1) atomicAdd(&sums[3], u1);
+        if (u2) atomicAdd(&sums[4], u2);
     }
 }
 

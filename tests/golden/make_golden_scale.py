@@ -3,7 +3,7 @@
 write for a seeded >= 2 M-read set, generated in the build container (binaries under $SMX_REF_BIN, built from /root/reference by
 the survey's cmake recipe). The read set comes from tests/synth.py, so the GPU box regenerates the identical reads and only the
 md5s travel (tests/golden/scale_*.json).
-usage: make_golden_scale.py [n_reads=2000000] [genome_len=10000000] [seed=77] [k=55] [what=all|kmercount]
+usage: make_golden_scale.py [n_reads=2000000] [genome_len=10000000] [seed=77] [k=55] [what=all|kmercount|allskew]
   BASELINE config 2 (10 M PE150 reads, k=21, spades-kmercount):  make_golden_scale.py 1e7 5e7 1 21 kmercount"""
 import hashlib
 import json
@@ -38,7 +38,11 @@ def main():
     out = {"n_reads": n, "genome_len": g, "seed": seed, "k": k, "threads": threads, "err": 0.01, "n_rate": 0.001,
            # spades-gbuilder clamps -t to omp_get_max_threads() (gbuilder.cpp:154): the bucket count that fixes the unitig order is 10 x this
            "effective_threads": min(threads, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))}
-    codes = synth.synth_codes(seed, g, n)
+    skew = what.endswith("skew")  # repeats, low complexity, log-normal abundances over 64 genomes (tests/synth.py: synth_codes_skewed)
+    if skew:
+        what = what[:-4] or "all"
+        out["skew"] = True
+    codes = synth.synth_codes_skewed(seed, g, n) if skew else synth.synth_codes(seed, g, n)
     out["codes_md5"] = hashlib.md5(codes.tobytes()).hexdigest()
     with tempfile.TemporaryDirectory(dir=os.environ.get("SMX_GOLDEN_TMP", "/tmp")) as td:
         os.makedirs(os.path.join(td, "kc"))
@@ -71,7 +75,7 @@ def main():
                         nl += line[:1] == b"L"
                 out["gfa_S_lines"], out["gfa_L_lines"] = ns, nl
             os.remove(gfa)
-    name = os.path.join(HERE, f"scale_{n // 1000}k_g{g // 1000}k_s{seed}" + ("" if k == 55 else f"_k{k}") + ".json")
+    name = os.path.join(HERE, f"scale_{n // 1000}k_g{g // 1000}k_s{seed}" + ("" if k == 55 else f"_k{k}") + ("_skew" if out.get("skew") else "") + ".json")
     with open(name, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))

@@ -31,6 +31,66 @@ def synth_codes(seed, genome_len, n_reads, err=0.01, n_rate=0.001):
     return codes
 
 
+def skewed_genome(rng, total_len, n_genomes=64, repeat_frac=0.3, lowc_frac=0.01):
+    """SURVEY.md §8d config-4 shape: `n_genomes` iid genomes (concatenated; a read never spans two), 30 % of the sequence overwritten by
+    copies of random 500..5000-bp segments of the same genome (repeats), 1 % by low-complexity runs (homopolymers, di- and
+    trinucleotide repeats of 50..300 bp). Returns (genome uint8[total_len], genome starts int64[n_genomes + 1])."""
+    g = rng.integers(0, 4, total_len, dtype=np.uint8)
+    cuts = np.sort(rng.choice(np.arange(2000, total_len - 2000), n_genomes - 1, replace=False)) if n_genomes > 1 else np.zeros(0, dtype=np.int64)
+    starts = np.concatenate([[0], cuts, [total_len]]).astype(np.int64)
+    done = 0
+    while done < repeat_frac * total_len:
+        gi = int(rng.integers(0, n_genomes))
+        a, b = int(starts[gi]), int(starts[gi + 1])
+        ln = int(rng.integers(500, 5001))
+        if b - a < 2 * ln + 10:
+            continue
+        src = int(rng.integers(a, b - ln))
+        dst = int(rng.integers(a, b - ln))
+        seg = g[src:src + ln].copy()
+        if rng.random() < 0.5:
+            seg = (3 - seg)[::-1]  # inverted repeat
+        g[dst:dst + ln] = seg
+        done += ln
+    done = 0
+    while done < lowc_frac * total_len:
+        ln = int(rng.integers(50, 301))
+        dst = int(rng.integers(0, total_len - ln))
+        unit = rng.integers(0, 4, int(rng.integers(1, 4)), dtype=np.uint8)
+        g[dst:dst + ln] = np.resize(unit, ln)
+        done += ln
+    return g, starts
+
+
+def synth_codes_skewed(seed, total_len, n_reads, err=0.01, n_rate=0.001, n_genomes=64, sigma=1.5):
+    """reads from skewed_genome with log-normal abundances over the genomes (sigma of the underlying normal); same read model as synth_codes"""
+    assert n_reads % 2 == 0
+    rng = np.random.default_rng(seed)
+    genome, starts = skewed_genome(rng, total_len, n_genomes)
+    size = np.diff(starts).astype(np.float64)
+    ab = rng.lognormal(0.0, sigma, n_genomes) * size  # reads per genome ~ abundance x length
+    ab /= ab.sum()
+    n_pairs = n_reads // 2
+    gi = rng.choice(n_genomes, n_pairs, p=ab)
+    p = (starts[gi] + (rng.random(n_pairs) * np.maximum(size[gi] - INSERT, 1)).astype(np.int64)).astype(np.int64)
+    p = np.minimum(p, starts[gi + 1] - INSERT)
+    idx = np.arange(L)
+    codes = np.empty((n_reads, L), dtype=np.uint8)
+    CH = 1 << 18
+    for c0 in range(0, n_pairs, CH):
+        c1 = min(n_pairs, c0 + CH)
+        q = p[c0:c1]
+        codes[2 * c0:2 * c1:2] = genome[q[:, None] + idx[None, :]]
+        codes[2 * c0 + 1:2 * c1:2] = 3 - genome[(q + INSERT - 1)[:, None] - idx[None, :]]
+    for c0 in range(0, n_reads, CH):
+        blk = codes[c0:c0 + CH]
+        x = rng.random(blk.shape, dtype=np.float32)
+        sub = rng.integers(1, 4, blk.shape, dtype=np.uint8)
+        blk[:] = np.where(x < err, (blk + sub) % 4, blk)
+        blk[(x >= err) & (x < err + n_rate)] = 4
+    return codes
+
+
 def write_fastq(codes, path):
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
     n = codes.shape[0]

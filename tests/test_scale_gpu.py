@@ -31,7 +31,8 @@ def _md5_file(path):
 @pytest.fixture(scope="module", params=CASES, ids=lambda p: os.path.basename(p))
 def case(request):
     g = json.load(open(request.param))
-    codes = synth.synth_codes(g["seed"], g["genome_len"], g["n_reads"], g["err"], g["n_rate"])
+    gen = synth.synth_codes_skewed if g.get("skew") else synth.synth_codes
+    codes = gen(g["seed"], g["genome_len"], g["n_reads"], g["err"], g["n_rate"])
     assert hashlib.md5(codes.tobytes()).hexdigest() == g["codes_md5"], "the generator does not reproduce the golden read set"
     bases, off = synth.ascii_and_offsets(codes)
     return g, bases.tobytes(), off
