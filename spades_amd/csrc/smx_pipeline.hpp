@@ -714,20 +714,66 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         if (int rc = dalloc(ctx, &prof, 8)) return rc;
         HIPCHK(hipMemsetAsync(prof, 0, 64, ctx->stream));
     }
-    tbegin(ctx, "skm_dedupe");
-    if (pmode)
-        hipLaunchKernelGGL((k_skm_dedupe<NW, 2>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
-                           (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)out_cap,
-                           (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo);
-    else if (ext)
-        hipLaunchKernelGGL((k_skm_dedupe<NW, 1>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
-                           (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)out_cap,
-                           (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo);
-    else
-        hipLaunchKernelGGL((k_skm_dedupe<NW, 0>), dim3(std::min<uint32_t>(nitems, 256 * 8)), dim3(BLK), lds, ctx->stream, (const uint64_t *)slots,
-                           (const unsigned long long *)soff, K, nitems, cap, T, scap, (void *)*out, (unsigned long long)out_cap,
-                           (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo);
+    // Oversized partitions (homopolymer / short-period runs: every window of such a run is a super-k-mer of its own and all share one
+    // minimizer) are taken out of the items and cut into pieces of BIG_PIECE slots, each an item of a second launch.
+    const unsigned long long BIG_THR = 1u << 15, BIG_PIECE = 1u << 13;  // slots (~17 instances each)
+    const uint32_t BIG_CAP = 1u << 16;
+    unsigned long long *biglist;
+    if (int rc = dalloc(ctx, &biglist, 1 + 3 * (size_t)BIG_CAP)) return rc;
+    HIPCHK(hipMemsetAsync(biglist, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_skm_bigkeys, dim3(1024), dim3(BLK), 0, ctx->stream, (const unsigned long long *)soff, SKM_NKEY, BIG_THR, biglist, BIG_CAP);
     HIPCHK(hipGetLastError());
+    unsigned long long nbig = 0;
+    HIPCHK(hipMemcpyAsync(&nbig, biglist, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    unsigned long long skip_slots = ~0ull;
+    unsigned long long *voff = nullptr;
+    uint32_t nvirt = 0;
+    if (nbig > 0 && nbig <= BIG_CAP) {
+        std::vector<unsigned long long> hl(3 * (size_t)nbig);
+        HIPCHK(hipMemcpy(hl.data(), biglist + 1, hl.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> hv;
+        for (unsigned long long b = 0; b < nbig; ++b) {
+            const unsigned long long a = hl[3 * b + 1], c = hl[3 * b + 2];
+            for (unsigned long long o = 0; o < c; o += BIG_PIECE) {  // one pseudo-item: the piece is its key 0, its other 255 keys are empty
+                hv.push_back(a + o);
+                const unsigned long long e = a + std::min(c, o + BIG_PIECE);
+                for (uint32_t t = 1; t < SKM_KEYS_PER_ITEM; ++t) hv.push_back(e);
+            }
+        }
+        if (!hv.empty() && hv.size() / SKM_KEYS_PER_ITEM < (1u << 22)) {
+            // every pseudo-item gets a row of 257 offsets of its own (the items of the first launch share their boundary entries; these
+            // pieces must not: entry 256 of a row is the piece's end, not the next piece's start)
+            const size_t ni = hv.size() / SKM_KEYS_PER_ITEM;
+            nvirt = (uint32_t)ni;
+            if (int rc = dalloc(ctx, &voff, (size_t)nvirt * (SKM_KEYS_PER_ITEM + 1))) return rc;
+            std::vector<unsigned long long> rows((size_t)nvirt * (SKM_KEYS_PER_ITEM + 1));
+            for (size_t i = 0; i < ni; ++i) {
+                for (uint32_t t = 0; t < SKM_KEYS_PER_ITEM; ++t) rows[i * (SKM_KEYS_PER_ITEM + 1) + t] = hv[i * SKM_KEYS_PER_ITEM + t];
+                rows[i * (SKM_KEYS_PER_ITEM + 1) + SKM_KEYS_PER_ITEM] = hv[i * SKM_KEYS_PER_ITEM + SKM_KEYS_PER_ITEM - 1];
+            }
+            HIPCHK(hipMemcpy(voff, rows.data(), rows.size() * 8, hipMemcpyHostToDevice));
+            skip_slots = BIG_THR;
+        }
+    }
+    if (getenv("SMX_DEBUG") && nbig) fprintf(stderr, "[smx] prededupe: %llu partitions of more than %llu slots -> %u pieces in a launch of their own\n", nbig, BIG_THR, nvirt);
+    tbegin(ctx, "skm_dedupe");
+    for (int pass = 0; pass < (nvirt ? 2 : 1); ++pass) {
+        const unsigned long long *offs = pass ? (const unsigned long long *)voff : (const unsigned long long *)soff;
+        const uint32_t ni = pass ? nvirt : nitems, stride = pass ? SKM_KEYS_PER_ITEM + 1 : SKM_KEYS_PER_ITEM, force = pass ? 1u : 0u;
+        const unsigned long long skip = pass ? ~0ull : skip_slots;
+        const dim3 grid(std::min<uint32_t>(ni, 256 * 8));
+        if (pmode)
+            hipLaunchKernelGGL((k_skm_dedupe<NW, 2>), grid, dim3(BLK), lds, ctx->stream, (const uint64_t *)slots, offs, K, ni, cap, T, scap, (void *)*out,
+                               (unsigned long long)out_cap, (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo, skip, force, stride);
+        else if (ext)
+            hipLaunchKernelGGL((k_skm_dedupe<NW, 1>), grid, dim3(BLK), lds, ctx->stream, (const uint64_t *)slots, offs, K, ni, cap, T, scap, (void *)*out,
+                               (unsigned long long)out_cap, (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo, skip, force, stride);
+        else
+            hipLaunchKernelGGL((k_skm_dedupe<NW, 0>), grid, dim3(BLK), lds, ctx->stream, (const uint64_t *)slots, offs, K, ni, cap, T, scap, (void *)*out,
+                               (unsigned long long)out_cap, (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo, skip, force, stride);
+        HIPCHK(hipGetLastError());
+    }
     tend(ctx);
     if (prof) {
         unsigned long long hp[6];

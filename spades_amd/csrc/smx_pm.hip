@@ -83,6 +83,13 @@ __device__ __forceinline__ node_t pm_find(const PmIndex &ix, const Rec<NW> &y) {
     }
     return pm_probe<NW>((const Rec<NW> *)ix.recs, ix.meta + (size_t)(pi >> PM_BASE_BITS) * ix.ngroups, ix.T, pi & PM_BASE_MASK, y, rec_hash32<NW>(y));
 }
+// the same for a successor of a k-mer of the sorted tail: its partition was cut, and a path seldom leaves a cut partition at once — the
+// tail's own directory first (hash + directory word + record, no minimizer scan), the partition table only when it is not there
+template <int NW>
+__device__ __forceinline__ node_t pm_find_from_tail(const PmIndex &ix, const Rec<NW> &y) {
+    const node_t r = kmer_rank<NW, false>((const Rec<NW> *)ix.dk, ix.ddir, y);
+    return r != NODE_NONE ? ix.nclean + r : pm_find<NW>(ix, y);
+}
 template <int NW>
 __device__ __forceinline__ Rec<NW> pm_node_kmer(const Rec<NW> *__restrict__ recs, node_t node, unsigned k) {  // oriented k-mer of a node
     const Rec<NW> x = rec_pure<NW>(recs[node >> 1]);
@@ -288,7 +295,7 @@ __global__ void __launch_bounds__(BLK) k_pm_tab_dirty(PmIndex ix, uint64_t nd, u
                 unsigned yo;
                 const Rec<NW> xo = o ? rec_rc<NW>(x, k) : x;
                 const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(xo, k, __ffs(mo) - 1), k, yo);
-                const node_t ry = pm_find<NW>(ix, y);
+                const node_t ry = pm_find_from_tail<NW>(ix, y);
                 if (ry == NODE_NONE) atomicAdd(err, 1u);
                 else e |= (ry << 1) | yo;
             }
@@ -433,7 +440,7 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
             const uint32_t cid = pm_chunk_of(cinfo, cob, nchunks, rj, cbase);
             ry = pm_probe<NW>(recs, ix.meta + (size_t)cid * ix.ngroups, ix.T, cbase, y, rec_hash32<NW>(y));
         }
-        if (ry == NODE_NONE) ry = pm_find<NW>(ix, y);
+        if (ry == NODE_NONE) ry = rj < ix.nclean ? pm_find<NW>(ix, y) : pm_find_from_tail<NW>(ix, y);
         if (ry == NODE_NONE) {
             atomicAdd(err, 1u);
             len[i] = 0;

@@ -289,7 +289,32 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
             const uint32_t key = skm_part(keys[e & 0xFFFu], a.pshift);
             uint64_t *dst = nullptr;
             if constexpr (PHASE == 0) {
-                const unsigned long long rank = atomicAdd(&a.cnt[key], 1ull);
+                // One atomic per super-k-mer — unless the neighbouring lanes hold the same partition: every window of a homopolymer or
+                // short-period run is a super-k-mer of its own, millions of them share a handful of minimizers, and ONE address takes
+                // ~88 atomics per microsecond (measured: +150 ms at 1 % low-complexity sequence). Up to three peels: the lanes that hold
+                // the key of the first remaining lane add up in one atomic and number themselves.
+                unsigned long long rank = 0;
+                {
+                    unsigned long long todo = __ballot(1);
+                    bool mine = true;
+                    // (only where the wave shows repeats at all: neighbouring lanes with one key — ordinary sequence never does)
+                    const bool rep = __popcll(__ballot(key == (uint32_t)__shfl_down((int)key, 1, 64))) >= 8;
+                    for (int peel = 0; rep && peel < 3 && todo; ++peel) {
+                        const int lead = __ffsll(todo) - 1;
+                        const uint32_t k0 = (uint32_t)__shfl((int)key, lead, 64);
+                        const bool hit = mine && key == k0;
+                        const unsigned long long same = __ballot(hit) & todo;
+                        unsigned long long base = 0;
+                        if ((int)(threadIdx.x & 63) == lead) base = atomicAdd(&a.cnt[k0], (unsigned long long)__popcll(same));
+                        base = __shfl(base, lead, 64);  // (every active lane takes part: no shuffle inside a divergent branch)
+                        if (hit) {
+                            rank = base + __popcll(same & ((1ull << (threadIdx.x & 63)) - 1));
+                            mine = false;
+                        }
+                        todo &= ~same;
+                    }
+                    if (mine) rank = atomicAdd(&a.cnt[key], 1ull);
+                }
                 if (stage0 != ~0ull) {
                     dst = a.stage_slots + (stage0 + si) * SW;
                     a.stage_part[stage0 + si] = (unsigned long long)key | (rank << 32);
@@ -380,6 +405,22 @@ __global__ void __launch_bounds__(BLK) k_skm_moments(const unsigned long long *_
     }
 }
 
+// keys (partitions) of more than thr slots: (key, first slot, slots) triples appended to list (count in list[0]; capacity cap triples)
+__global__ void __launch_bounds__(BLK) k_skm_bigkeys(const unsigned long long *__restrict__ soff, uint32_t n, unsigned long long thr, unsigned long long *list,
+                                                     uint32_t cap) {
+    for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+        const unsigned long long a = soff[i], c = soff[i + 1] - a;
+        if (c > thr) {
+            const unsigned long long p = atomicAdd(&list[0], 1ull);
+            if (p < cap) {
+                list[1 + 3 * p] = i;
+                list[2 + 3 * p] = a;
+                list[3 + 3 * p] = c;
+            }
+        }
+    }
+}
+
 // k-mer number j of a staged slot
 template <int NW>
 __device__ __forceinline__ Rec<NW> skm_extract(const uint64_t *s, unsigned j, unsigned K) {
@@ -431,7 +472,13 @@ template <int NW, int MODE>
 __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__ slots, const unsigned long long *__restrict__ slot_off,
                                                     unsigned K, uint32_t nitems, uint32_t cap, uint32_t T, uint32_t scap, void *out_,
                                                     unsigned long long out_cap, unsigned long long clean_cap, unsigned long long dirty_cap, unsigned long long *out_count,
-                                                    unsigned long long *dirty_count, unsigned long long *prof, PmOut pm) {
+                                                    unsigned long long *dirty_count, unsigned long long *prof, PmOut pm, unsigned long long skip_slots,
+                                                    uint32_t force_dirty, uint32_t item_stride /* entries of slot_off per item: 256 (items share their
+                                                    boundary entries) or 257 (rows of their own) */) {
+    // skip_slots: a key (partition) of more slots than this is left out here — one workgroup would chew on a homopolymer partition of
+    // 10^7 instances for 100 ms while the others idle; its slot range is cut into pieces that a second launch deals out as items of their
+    // own (slot_off = one pseudo-key per piece, force_dirty = 1: every chunk of such a piece is a dirty one, its partition is cut by
+    // construction, and the partition table is not touched).
     constexpr int SW = 2 * NW;
     constexpr bool EXT = MODE >= 1, PM = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
@@ -460,12 +507,28 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
     if (prof && threadIdx.x == 0) t0 = wall_clock64();
     for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t <= SKM_KEYS_PER_ITEM; t += BLK) koff[t] = slot_off[(uint64_t)item * SKM_KEYS_PER_ITEM + t];
+        for (uint32_t t = threadIdx.x; t <= SKM_KEYS_PER_ITEM; t += BLK) koff[t] = slot_off[(uint64_t)item * item_stride + t];
         __syncthreads();
         uint64_t s_cur = koff[0];
         const uint64_t s_end = koff[SKM_KEYS_PER_ITEM];
         bool on_boundary = true;  // the chunk starts with the first slot of a key
         while (s_cur < s_end) {
+            if (skip_slots != ~0ull && on_boundary) {  // an oversized key starts here: its pieces are items of the second launch
+                if (threadIdx.x == 0) s_kend = 0;
+                __syncthreads();
+                for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)
+                    if (koff[t] == s_cur && koff[t + 1] > koff[t] && koff[t + 1] - koff[t] > skip_slots) {
+                        s_kend = koff[t + 1];
+                        if constexpr (PM) pm.pinfo[(uint64_t)item * SKM_KEYS_PER_ITEM + t] = PM_DIRTY;
+                    }
+                __syncthreads();
+                const unsigned long long ke = s_kend;
+                __syncthreads();
+                if (ke) {
+                    s_cur = ke;
+                    continue;
+                }
+            }
             const uint32_t nst = (uint32_t)((s_end - s_cur < scap) ? s_end - s_cur : scap);
             for (uint32_t i = threadIdx.x; i < nst * SW; i += BLK) {
                 uint64_t v = slots[s_cur * SW + i];
@@ -622,7 +685,7 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
             // A chunk of whole keys holds every copy of its k-mers: its winners are exactly distinct ("clean", front of out).
             // Winners of a key that had to be cut may recur in its other chunks ("dirty", stacked from the back of out; the
             // host uniques that part on its own before the two are joined).
-            const bool dirty = !on_boundary || !s_endb;
+            const bool dirty = !on_boundary || !s_endb || force_dirty;
             on_boundary = s_endb != 0;
             if (threadIdx.x == 0) {
                 s_skip = 0;
@@ -650,8 +713,9 @@ __global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__
             __syncthreads();
             if constexpr (PM) {
                 if (dirty) {  // the cut partition: its k-mers go to the sorted tail
-                    for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)
-                        if (koff[t] <= s_cur && koff[t + 1] > s_cur) pm.pinfo[(uint64_t)item * SKM_KEYS_PER_ITEM + t] = PM_DIRTY;
+                    if (!force_dirty)
+                        for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)
+                            if (koff[t] <= s_cur && koff[t + 1] > s_cur) pm.pinfo[(uint64_t)item * SKM_KEYS_PER_ITEM + t] = PM_DIRTY;
                 } else if (!s_skip && wcount) {
                     const unsigned long long gb = s_gbase;
                     const uint32_t cid = s_cid;
