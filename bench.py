@@ -252,6 +252,50 @@ def cpu_baseline_construct(codes_sample, k, gpu_unitigs=None):
     return res
 
 
+def end_to_end(codes_sample, k, T):
+    """SURVEY.md §8d, 'additionally to files written': uncompressed FASTQ on tmpfs -> the CLI clones (spades_amd/tools) -> GFA / final_kmers
+    on tmpfs, wall clock of the whole process (device init, FASTQ cut on the device, count / construction, writers) with the tools'
+    own stage split. The reference's single-threaded GFA writer was 13 % of its wall (io/graph/gfa_writer.cpp:19-47)."""
+    import numpy as np
+    n = codes_sample.shape[0]
+    tools = os.path.join(ROOT, "spades_amd", "tools")
+    res = {"reads": int(n)}
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        fq = os.path.join(td, "r.fq")
+        lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+        with open(fq, "wb") as f:
+            for c0 in range(0, n, 1 << 21):
+                blk = lut[codes_sample[c0:c0 + (1 << 21)].numpy()]
+                m = blk.shape[0]
+                rec = np.empty((m, 12 + L + 3 + L + 1), dtype=np.uint8)  # "@r%09d\n" + bases + "\n+\n" + qualities + "\n"
+                rec[:, 0], rec[:, 1] = ord("@"), ord("r")
+                rec[:, 2:11] = np.frombuffer("".join(np.char.zfill(np.arange(c0, c0 + m).astype(str), 9)).encode(), dtype=np.uint8).reshape(m, 9)
+                rec[:, 11] = 10
+                rec[:, 12:12 + L] = blk
+                rec[:, 12 + L], rec[:, 13 + L], rec[:, 14 + L] = 10, ord("+"), 10
+                rec[:, 15 + L:15 + 2 * L] = ord("I")
+                rec[:, 15 + 2 * L] = 10
+                rec.tofile(f)
+        res["fastq_bytes"] = os.path.getsize(fq)
+        for name, exe, argv, outf in (("gbuilder_gfa", "spades-gbuilder-mi355x", [fq, os.path.join(td, "o.gfa"), "-k", str(k), "-t", str(T), "--gfa"], "o.gfa"),
+                                     ("kmercount", "spades-kmercount-mi355x", ["-k", str(k), "-w", td, fq], "final_kmers")):
+            try:
+                best, split = None, None
+                for _ in range(2):  # second run: the page cache and the GPU's clocks are warm
+                    t0 = time.time()
+                    r = subprocess.run([os.path.join(tools, exe)] + argv, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, SMX_DEBUG="1"),
+                                       check=True, timeout=600)
+                    dt = time.time() - t0
+                    if best is None or dt < best:
+                        best = dt
+                        split = {l[7:19].strip(): float(l[19:].split()[0]) for l in r.stderr.decode().splitlines() if l.startswith("[tool]")}
+                res[name] = {"seconds": round(best, 2), "M_reads_per_s": round(n / best / 1e6, 2), "stages_s": split,
+                             "output_bytes": os.path.getsize(os.path.join(td, outf))}
+            except Exception as e:  # noqa: BLE001 — an extra, never the measurement
+                res[name] = {"error": str(e)[:200]}
+    return res
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) and relay rank 0's line."""
     n_dev = torch.cuda.device_count()
@@ -288,6 +332,9 @@ def main():
                          "at 2 M reads over a 500 Mbp genome almost every k-mer is distinct and the fixed costs of a 256-thread launch dominate)")
     ap.add_argument("--cpu-sample-construct", type=float, default=2e6,
                     help="reads for the reference CONSTRUCTION classes on the host (0.04 M reads/s: 20 M reads would take 8 minutes; the sample bias is stated in the line)")
+    ap.add_argument("--end-to-end", type=float, default=20e6,
+                    help="extra (untimed for the headline): uncompressed FASTQ of this many bench reads on tmpfs -> spades-gbuilder-mi355x --gfa and "
+                         "spades-kmercount-mi355x -> files on tmpfs, wall clock with the tools' stage split; 0 disables")
     ap.add_argument("--cpu-runs", type=int, default=3, help="runs of the reference count on the host (median reported)")
     ap.add_argument("--cpu-count-only", action="store_true", help="host baseline: the count only (with --cpu-sample = --reads this is the full-size parity check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -343,7 +390,8 @@ def main():
     n_sample = int(min(args.cpu_sample, n_reads)) // 32 * 32
     if args.no_cpu_baseline:
         n_sample = 0
-    sample = (codes[:n_sample].cpu() if n_sample else None) if rank == 0 else None  # host memory: 150 B per read
+    n_e2e = int(min(args.end_to_end, n_reads)) // 32 * 32 if (rank == 0 and world == 1 and not args.force_sharded) else 0
+    sample = (codes[:max(n_sample, n_e2e)].cpu() if max(n_sample, n_e2e) else None) if rank == 0 else None  # host memory: 150 B per read
     del codes
     # the batch waits in page-locked host memory ("packed read batches resident in pinned host memory")
     h_words, h_start, h_len = words.cpu().pin_memory(), start.cpu().pin_memory(), ln.cpu().pin_memory()
@@ -352,6 +400,8 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     hw, hs, hl = h_words.numpy().view("uint64"), h_start.numpy().view("uint64"), h_len.numpy().view("uint32")
+    # the end-to-end extra runs the CLI tools as processes of their own: before this process takes its device arena
+    e2e_res = end_to_end(sample[:n_e2e], k, T) if n_e2e else None
 
     ctx = Context(device=local_rank)
     if args.kpomer_route:
@@ -571,7 +621,10 @@ def main():
                                                                       "(smx_graph_fingerprint_portable: independent of the k-mer numbering, equal between routes)")
             except Exception as e:  # noqa: BLE001 — a check, never the measurement
                 out["construct"]["checks"]["graph_fingerprint"] = f"unavailable: {e}"
+        if e2e_res is not None:
+            out["end_to_end"] = e2e_res
         if not args.no_cpu_baseline and n_sample:
+            sample = sample[:n_sample]
             hw_s = hw[:n_sample * L // 32 + 8]
             ctx.set_option("async_upload", 0)  # (the checks below submit temporary slices)
 

@@ -1142,11 +1142,14 @@ int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_vers
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
     if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
     (void)hipSetDevice(ctx->device);
+    const double t0 = wall_now();
     if (int rc = materialize_host(ctx)) return rc;
+    const double t1 = wall_now();
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
     bool ok = smxh::write_gfa(ctx->gh, f, flavour_version ? flavour_version : "SPAdes-4.3.0-dev");
     if (fclose(f) != 0) ok = false;
+    if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] write_gfa: graph to the host %.3f s, text %.3f s\n", t1 - t0, wall_now() - t1);
     return ok ? SMX_OK : fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path);
 }
 
