@@ -41,7 +41,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             acc[name][1] += float(row["Counter_Value"])
     tot[c] = acc
 names = sorted(set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"]), key=lambda n: -(tot["FETCH_SIZE"][n][1] * 2 + tot["WRITE_SIZE"][n][1]))
-passes = max(1, (tot["FETCH_SIZE"].get("smx::k_fill_tab<2>") or tot["FETCH_SIZE"].get("smx::k_mark_windows", [1]))[0])  # passes of the hot path in the PMC run
+# passes of the hot path in the PMC run (setup pass + timed steps + the synchronous-upload step the stage times come from): one
+# k_cand_tiles launch per construction
+passes = max(1, (tot["FETCH_SIZE"].get("smx::k_cand_tiles") or tot["FETCH_SIZE"].get("smx::k_mark_windows", [1]))[0])
 with open(os.path.join(d, "pmc_hbm_traffic.csv"), "w") as o:
     o.write(f"# src_sha256={src_hash()} (library sources the counters were taken on; bench.py refuses the table when they changed)\n")
     o.write("kernel,launches_per_step,FETCH_SIZE_KB(raw),fetch_GB(x2 gfx950 correction),WRITE_SIZE_KB,write_GB\n")
