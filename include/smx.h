@@ -104,7 +104,11 @@ int smx_submit_reads_ascii(smx_ctx *ctx, const char *bases, const uint64_t *offs
 /* Already-packed reads in host memory: one 2-bit stream (layout as a k-mer record, arbitrarily
  * long), read i occupies nucleotides [start[i], start[i]+len[i]). Mirrors Sequence::BinWrite's
  * payload (common/sequence/sequence.hpp BinWrite: size_t len + words). The (start, len) pairs are checked against the stream on
- * the device; page-locked arrays (smx_pinned_alloc) upload at the PCIe rate. */
+ * the device; page-locked arrays (smx_pinned_alloc) upload at the PCIe rate. With option "async_upload" = 1 and a stream of
+ * >= 2^24 words the call returns before the copies are over: (start, len) go first, the stream follows in pieces on a copy stream and
+ * the first scan of the next smx_count / smx_build_graph follows the upload piece by piece; the three arrays must then stay valid
+ * (and page-locked, to overlap at all) until that call returns, and a (start, len) pair that leaves the stream is reported by that
+ * call (SMX_INVALID_PARAMETER) instead of this one. */
 int smx_submit_reads_packed(smx_ctx *ctx, const uint64_t *words, uint64_t n_words,
                             const uint64_t *start, const uint32_t *len, uint64_t n_reads);
 /* SPAdes' own binary read format: one <prefix>.seq file written by io::ReadConverter::ConvertToBinary
