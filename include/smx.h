@@ -239,6 +239,38 @@ int smx_extract_kmers_ext_owned(smx_ctx *ctx, unsigned k, unsigned num_buckets, 
 int smx_graph_shard_from_ext(smx_ctx *ctx, unsigned k, unsigned num_buckets, unsigned world, unsigned rank, const void *d_records,
                              uint64_t n_records);
 int smx_graph_shard_ext_stats(const smx_ctx *ctx, uint64_t *stats /* [2] */);
+/* Distributed walks: unitigs of a graph whose k-mer file stays sharded over the ranks, for graphs that do not
+ * fit one GPU as a gathered {k-mer file, masks} structure. The shard is what smx_graph_shard_from_ext / smx_graph_shard_build left in
+ * the context. A walk of the reference (UnbranchingPathExtractor::ConstructSequenceWithEdge,
+ * assembly_graph/construction/debruijn_graph_constructor.hpp:264-273) would leave its rank at every step, so no rank walks:
+ *   1. smx_shard_walk_counts / smx_shard_walk_requests(starts = 0): every oriented non-junction k-mer of the shard (a node: 2 * local
+ *      rank + orientation) asks for its unique successor: canonical k-mer records of ceil(k/32) words grouped by the rank that owns
+ *      the successor's bucket, counts[world]; d_tags (same order, stays here) = node << 4 | rc << 2 | nucleotide, rc = the successor
+ *      node is the reverse complement of the stored k-mer. With starts = 1 the same for the start de-edges of the junction k-mers
+ *      (AddStartDeEdges, :203-226) in k-mer-file order: tag = index << 4 | 8 | rc << 2 | nucleotide; smx_shard_walk_starts copies
+ *      them out as (local rank << 3 | orientation << 2 | nucleotide).
+ *   2. all-to-all; smx_shard_lookup on the owner: reply = local rank << 1 | (junction k-mer), all ones if the k-mer is not in the shard;
+ *      replies go back in request order.
+ *   3. the caller ranks the chains of non-junction k-mers by pointer doubling over the exchange (integers only, spades_amd/dist.py) and
+ *      delivers, per start de-edge, the number of chain k-mers behind it, the node the walk ends at and the chain's nucleotides;
+ *   4. smx_shard_unitigs assembles start (k+1)-mer + chain nucleotides, keeps a unitig iff !(s < !s) (:305-306) and leaves the kept
+ *      ones — this rank's part of the edge list, in the reference's order — for smx_shard_unitigs_copy (2-bit packed, every unitig on
+ *      a word boundary; start / end = global nodes, first_rank = global rank of the shard's first k-mer);
+ *   5. smx_build_graph_from_unitigs on every rank that wants the graph: the ranks' unitigs concatenated in rank order, plus the k-mers
+ *      that no chain reached (perfect loops, CollectLoops :359-397; smx_shard_gather_kmers fetches them by local rank; host arrays
+ *      in k-mer-file order with GLOBAL ranks) -> link records, vertices, every writer and smx_graph_fill_coverage as after
+ *      smx_build_graph. That graph has no k-mer file: smx_graph_copy_kmers / smx_graph_fingerprint refuse. */
+int smx_shard_walk_counts(smx_ctx *ctx, uint64_t *n_chain_requests, uint64_t *n_start_requests);
+int smx_shard_walk_requests(smx_ctx *ctx, int starts, unsigned world, void *d_records, uint64_t *d_tags, uint64_t *counts /* [world] */);
+int smx_shard_walk_starts(const smx_ctx *ctx, uint64_t *d_starts);
+int smx_shard_lookup(smx_ctx *ctx, const void *d_records, uint64_t n, uint64_t *d_reply);
+int smx_shard_gather_kmers(smx_ctx *ctx, const uint64_t *d_local_ranks, uint64_t n, void *d_kmers, uint8_t *d_masks);
+int smx_shard_unitigs(smx_ctx *ctx, uint64_t first_rank, const uint64_t *d_steps, const uint64_t *d_last, const uint64_t *d_base_off /* [n + 1] */,
+                      const uint8_t *d_bases, uint64_t *n_kept, uint64_t *n_words);
+int smx_shard_unitigs_copy(const smx_ctx *ctx, uint64_t *d_words, uint64_t *d_len, uint64_t *d_start, uint64_t *d_end, uint8_t *d_self);
+int smx_build_graph_from_unitigs(smx_ctx *ctx, unsigned k, unsigned num_buckets, uint64_t n_kmers, uint64_t n_kpomers, const uint64_t *d_words, uint64_t n_words,
+                                 const uint64_t *d_len, const uint64_t *d_start, const uint64_t *d_end, const uint8_t *d_self, uint64_t n_unitigs,
+                                 const uint64_t *loop_ranks, const uint64_t *loop_kmers, const uint8_t *loop_masks, uint64_t n_loop_kmers);
 /* Fingerprint of the device-resident graph, for comparing two builds that are too big to leave the device: for each of the arrays
  * k-mer file, InOutMask bytes, packed unitig words, unitig lengths, start nodes, end nodes, sorted link records, vertex starts —
  * out[2i] = sum of the elements, out[2i+1] = sum of element * (2 * index + 1), both mod 2^64 (order-sensitive). */

@@ -84,6 +84,15 @@ def load():
         "smx_extract_kmers_ext_owned": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(vp), u64p]),
         "smx_graph_shard_from_ext": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, C.c_uint64]),
         "smx_graph_shard_ext_stats": (C.c_int, [vp, u64p]),
+        "smx_shard_walk_counts": (C.c_int, [vp, u64p, u64p]),
+        "smx_shard_walk_requests": (C.c_int, [vp, C.c_int, C.c_uint, vp, u64p, u64p]),
+        "smx_shard_walk_starts": (C.c_int, [vp, u64p]),
+        "smx_shard_lookup": (C.c_int, [vp, vp, C.c_uint64, u64p]),
+        "smx_shard_gather_kmers": (C.c_int, [vp, u64p, C.c_uint64, vp, C.POINTER(C.c_uint8)]),
+        "smx_shard_unitigs": (C.c_int, [vp, C.c_uint64, u64p, u64p, u64p, C.POINTER(C.c_uint8), u64p, u64p]),
+        "smx_shard_unitigs_copy": (C.c_int, [vp, u64p, u64p, u64p, u64p, C.POINTER(C.c_uint8)]),
+        "smx_build_graph_from_unitigs": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64, u64p, C.c_uint64, u64p, u64p, u64p, C.POINTER(C.c_uint8),
+                                                  C.c_uint64, u64p, u64p, C.POINTER(C.c_uint8), C.c_uint64]),
         "smx_graph_fingerprint": (C.c_int, [vp, u64p]),
         "smx_graph_fingerprint_portable": (C.c_int, [vp, u64p]),
         "smx_count_records": (C.c_int, [vp, C.c_uint, C.c_uint, vp, C.c_uint64]),

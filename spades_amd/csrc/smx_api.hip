@@ -6,6 +6,7 @@
 #include "smx_ingest.hip"
 #include "smx_graph.hip"
 #include "smx_pm.hip"
+#include "smx_dwalk.hip"
 #include "smx_graph_host.hpp"
 
 #include <algorithm>
@@ -29,6 +30,7 @@ using namespace smx;
 #include "smx_pipeline.hpp"
 #include "smx_construct.hpp"
 #include "smx_pm.hpp"
+#include "smx_dwalk.hpp"
 
 // ============================================================================ C ABI
 extern "C" {
@@ -896,6 +898,7 @@ int smx_graph_fingerprint(const smx_ctx *cctx, uint64_t *out) {
     if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph");
     if (ctx->g_nkmers == 0) return SMX_OK;
     if (!ctx->g_dev_valid) return fail(ctx, SMX_INVALID_PARAMETER, "the graph is not resident on the device");
+    if (ctx->g_sharded_file) return fail(ctx, SMX_INVALID_PARAMETER, "this graph was built from gathered unitigs: the k-mer file is sharded over the ranks; compare builds with smx_graph_fingerprint_portable");
     if (ctx->g_pm) return fail(ctx, SMX_INVALID_PARAMETER, "this graph was built without a sorted k-mer file (partition-major route): its k-mer and node arrays "
                                                            "are numbered differently; compare builds with smx_graph_fingerprint_portable");
     HIPCHK(hipSetDevice(ctx->device));
@@ -972,6 +975,7 @@ int smx_graph_shard_copy(const smx_ctx *cctx, void *d_kmers, void *d_masks) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     if (ctx->g_nkmers == 0) return SMX_OK;
     if (!d_kmers || !d_masks) return SMX_INVALID_PARAMETER;
+    if (ctx->g_sharded_file) return fail(ctx, SMX_INVALID_PARAMETER, "this graph was built from gathered unitigs: the k-mer file is sharded over the ranks");
     if (int rc = ensure_kmer_file(ctx, /*view=*/false)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(d_kmers, ctx->g_kmers, ctx->g_nkmers * ctx->g_nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -998,6 +1002,138 @@ int smx_build_graph_from_kmers(smx_ctx *ctx, unsigned k, unsigned num_buckets, c
     rc = finish_call(ctx, rc, true);
     if (rc == 0) ctx->g_nkpo = n_kpomers;
     return rc;
+}
+
+// ---- distributed walks (smx_dwalk.hpp) -----------------------------------------------------------------------
+static int dw_check_shard(smx_ctx *ctx) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    if (ctx->g_nw < 1 || ctx->g_nw > 4 || ctx->g_k == 0)
+        return fail(ctx, SMX_INVALID_PARAMETER, "no shard of the k-mer file in this context (smx_graph_shard_from_ext / smx_graph_shard_build first)");
+    return SMX_OK;
+}
+
+int smx_shard_walk_counts(smx_ctx *ctx, uint64_t *n_chain_requests, uint64_t *n_start_requests) {
+    if (int rc = dw_check_shard(ctx)) return rc;
+    if (!n_chain_requests || !n_start_requests) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    switch (ctx->g_nw) {
+        case 1: rc = dw_prepare<1>(ctx); break;
+        case 2: rc = dw_prepare<2>(ctx); break;
+        case 3: rc = dw_prepare<3>(ctx); break;
+        default: rc = dw_prepare<4>(ctx); break;
+    }
+    rc = finish_call(ctx, rc, false);
+    *n_chain_requests = ctx->dw_nchain;
+    *n_start_requests = ctx->dw_ncand;
+    return rc;
+}
+
+int smx_shard_walk_requests(smx_ctx *ctx, int starts, unsigned world, void *d_records, uint64_t *d_tags, uint64_t *counts) {
+    if (int rc = dw_check_shard(ctx)) return rc;
+    if (!counts || world < 1 || world > 1024) return fail(ctx, SMX_INVALID_PARAMETER, "bad world / null counts");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    switch (ctx->g_nw) {
+        case 1: rc = dw_requests<1>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts); break;
+        case 2: rc = dw_requests<2>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts); break;
+        case 3: rc = dw_requests<3>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts); break;
+        default: rc = dw_requests<4>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts); break;
+    }
+    return finish_call(ctx, rc, false);
+}
+
+int smx_shard_walk_starts(const smx_ctx *cctx, uint64_t *d_starts) {
+    smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
+    if (!ctx || !ctx->dw_ready) return SMX_INVALID_PARAMETER;
+    if (ctx->dw_ncand == 0) return SMX_OK;
+    if (!d_starts) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(d_starts, ctx->dw_cand, ctx->dw_ncand * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SMX_OK;
+}
+
+int smx_shard_lookup(smx_ctx *ctx, const void *d_records, uint64_t n, uint64_t *d_reply) {
+    if (int rc = dw_check_shard(ctx)) return rc;
+    if (n && (!d_records || !d_reply)) return fail(ctx, SMX_INVALID_PARAMETER, "null lookup buffers");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    switch (ctx->g_nw) {
+        case 1: rc = dw_lookup<1>(ctx, d_records, n, (unsigned long long *)d_reply); break;
+        case 2: rc = dw_lookup<2>(ctx, d_records, n, (unsigned long long *)d_reply); break;
+        case 3: rc = dw_lookup<3>(ctx, d_records, n, (unsigned long long *)d_reply); break;
+        default: rc = dw_lookup<4>(ctx, d_records, n, (unsigned long long *)d_reply); break;
+    }
+    return finish_call(ctx, rc, false);
+}
+
+int smx_shard_gather_kmers(smx_ctx *ctx, const uint64_t *d_local_ranks, uint64_t n, void *d_kmers, uint8_t *d_masks) {
+    if (int rc = dw_check_shard(ctx)) return rc;
+    if (n == 0) return SMX_OK;
+    if (!d_local_ranks || !d_kmers || !d_masks || !ctx->g_kmers || !ctx->g_mask) return fail(ctx, SMX_INVALID_PARAMETER, "null buffers / no shard");
+    HIPCHK(hipSetDevice(ctx->device));
+    switch (ctx->g_nw) {
+        case 1: hipLaunchKernelGGL((k_gather_kmers<1>), dim3(grid_for(n)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const unsigned long long *)d_local_ranks, n, d_kmers, d_masks); break;
+        case 2: hipLaunchKernelGGL((k_gather_kmers<2>), dim3(grid_for(n)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const unsigned long long *)d_local_ranks, n, d_kmers, d_masks); break;
+        case 3: hipLaunchKernelGGL((k_gather_kmers<3>), dim3(grid_for(n)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const unsigned long long *)d_local_ranks, n, d_kmers, d_masks); break;
+        default: hipLaunchKernelGGL((k_gather_kmers<4>), dim3(grid_for(n)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, (const unsigned long long *)d_local_ranks, n, d_kmers, d_masks); break;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SMX_OK;
+}
+
+int smx_shard_unitigs(smx_ctx *ctx, uint64_t first_rank, const uint64_t *d_steps, const uint64_t *d_last, const uint64_t *d_base_off, const uint8_t *d_bases,
+                      uint64_t *n_kept, uint64_t *n_words) {
+    if (int rc = dw_check_shard(ctx)) return rc;
+    if (!n_kept || !n_words) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    switch (ctx->g_nw) {
+        case 1: rc = dw_unitigs<1>(ctx, first_rank, (const unsigned long long *)d_steps, (const unsigned long long *)d_last, (const unsigned long long *)d_base_off, d_bases, n_kept, n_words); break;
+        case 2: rc = dw_unitigs<2>(ctx, first_rank, (const unsigned long long *)d_steps, (const unsigned long long *)d_last, (const unsigned long long *)d_base_off, d_bases, n_kept, n_words); break;
+        case 3: rc = dw_unitigs<3>(ctx, first_rank, (const unsigned long long *)d_steps, (const unsigned long long *)d_last, (const unsigned long long *)d_base_off, d_bases, n_kept, n_words); break;
+        default: rc = dw_unitigs<4>(ctx, first_rank, (const unsigned long long *)d_steps, (const unsigned long long *)d_last, (const unsigned long long *)d_base_off, d_bases, n_kept, n_words); break;
+    }
+    return finish_call(ctx, rc, false);
+}
+
+int smx_shard_unitigs_copy(const smx_ctx *cctx, uint64_t *d_words, uint64_t *d_len, uint64_t *d_start, uint64_t *d_end, uint8_t *d_self) {
+    smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
+    if (!ctx || !ctx->dw_ready) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t ne = ctx->g_ne;
+    if (ctx->g_nuwords && d_words) HIPCHK(hipMemcpyAsync(d_words, ctx->g_uwords, ctx->g_nuwords * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (ne && d_len) HIPCHK(hipMemcpyAsync(d_len, ctx->g_elen, ne * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (ne && d_start) HIPCHK(hipMemcpyAsync(d_start, ctx->g_estart, ne * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (ne && d_end) HIPCHK(hipMemcpyAsync(d_end, ctx->g_eend, ne * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (ne && d_self) HIPCHK(hipMemcpyAsync(d_self, ctx->g_eself, ne, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SMX_OK;
+}
+
+int smx_build_graph_from_unitigs(smx_ctx *ctx, unsigned k, unsigned num_buckets, uint64_t n_kmers, uint64_t n_kpomers, const uint64_t *d_words, uint64_t n_words,
+                                 const uint64_t *d_len, const uint64_t *d_start, const uint64_t *d_end, const uint8_t *d_self, uint64_t n_unitigs,
+                                 const uint64_t *loop_ranks, const uint64_t *loop_kmers, const uint8_t *loop_masks, uint64_t n_loop_kmers) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    if (k < 1 || k >= 128 || k % 2 == 0) return fail(ctx, SMX_INVALID_PARAMETER, "k-mer size must be odd and below 128");
+    if (n_unitigs && (!d_words || !d_len || !d_start || !d_end || !d_self)) return fail(ctx, SMX_INVALID_PARAMETER, "null unitig arrays");
+    if (n_loop_kmers && (!loop_ranks || !loop_kmers || !loop_masks)) return fail(ctx, SMX_INVALID_PARAMETER, "null loop k-mer arrays");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->xnames.clear();
+    ctx->xms.clear();
+    int rc;
+#define SMX_GFU(N) graph_from_unitigs<N>(ctx, k, num_buckets, n_kmers, n_kpomers, d_words, n_words, (const unsigned long long *)d_len, (const unsigned long long *)d_start, \
+                                         (const unsigned long long *)d_end, d_self, n_unitigs, loop_ranks, loop_kmers, loop_masks, n_loop_kmers)
+    switch ((k + 32) / 32) {
+        case 1: rc = SMX_GFU(1); break;
+        case 2: rc = SMX_GFU(2); break;
+        case 3: rc = SMX_GFU(3); break;
+        default: rc = SMX_GFU(4); break;
+    }
+#undef SMX_GFU
+    return finish_call(ctx, rc, true);
 }
 
 // (k+1)-mer file for the coverage pass of a graph that was built without one on this rank (sharded construction): sorted, bucket-major
@@ -1073,6 +1209,7 @@ int smx_graph_copy_kmers(const smx_ctx *cctx, void *kmers_host, uint8_t *masks_h
     if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->g_nkmers == 0) return SMX_OK;
+    if (ctx->g_sharded_file) return fail(ctx, SMX_INVALID_PARAMETER, "this graph was built from gathered unitigs: the k-mer file is sharded over the ranks");
     if (int rc = ensure_kmer_file(ctx, /*view=*/false)) return rc;
     if (kmers_host) HIPCHK(hipMemcpy(kmers_host, ctx->g_kmers, ctx->g_nkmers * ctx->g_nw * 8, hipMemcpyDeviceToHost));
     if (masks_host) HIPCHK(hipMemcpy(masks_host, ctx->g_mask, ctx->g_nkmers, hipMemcpyDeviceToHost));

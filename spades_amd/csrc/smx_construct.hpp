@@ -55,6 +55,11 @@ void clear_graph(smx_ctx *ctx) {
     drop_rank_dir(ctx, ctx->g_dir_kmers);
     drop_device_graph(ctx);
     pm_release(ctx);
+    arena_put(ctx, ctx->dw_cand);
+    ctx->dw_cand = nullptr;
+    ctx->dw_ncand = ctx->dw_nchain = 0;
+    ctx->dw_ready = false;
+    ctx->g_sharded_file = false;
     ctx->g_pm = false;
     ctx->pm_view_pending = false;
     ctx->g_kmers = nullptr;
@@ -601,6 +606,82 @@ int upload_graph(smx_ctx *ctx) {
     return 0;
 }
 
+// Perfect loops (CollectLoops, debruijn_graph_constructor.hpp:359-397; serial in the reference too) from their k-mers in k-mer-file order,
+// appended to the device graph: bigger arrays, old content copied, loop edges uploaded.
+inline int append_loops(smx_ctx *ctx, unsigned k, std::vector<smxh::LoopNode> &nodes, uint64_t nkept, uint64_t ktotalw) {
+    smxh::LoopCollector lc(nodes, k);
+    std::vector<std::string> loops;
+    lc.collect(loops);
+    // the loops are appended to the device graph: bigger arrays, old content copied, loop edges uploaded
+    const uint64_t nl = loops.size();
+    if (nl) {
+        std::vector<unsigned long long> l_offw(nl), l_len(nl), l_start(nl), l_end(nl);
+        std::vector<uint8_t> l_self(nl);
+        std::vector<uint64_t> lwords;
+        for (uint64_t i = 0; i < nl; ++i) {
+            const std::string &sq = loops[i];
+            l_offw[i] = ktotalw + lwords.size();
+            l_len[i] = sq.size();
+            // node ids must be taken from the untouched masks' k-mers (collect() zeroed the masks, not the index)
+            l_start[i] = lc.node_of(sq.substr(0, k));
+            l_end[i] = lc.node_of(sq.substr(sq.size() - k));
+            l_self[i] = sq == smxh::revcomp(sq) ? 1 : 0;
+            const size_t w0 = lwords.size();
+            lwords.resize(w0 + (sq.size() + 31) / 32, 0);
+            for (size_t t = 0; t < sq.size(); ++t) {
+                const char ch = sq[t];
+                const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+                lwords[w0 + (t >> 5)] |= code << ((t & 31) << 1);
+            }
+        }
+        const uint64_t ne2 = nkept + nl, tw2 = ktotalw + lwords.size();
+        uint64_t *uw2;
+        unsigned long long *eo2, *el2;
+        node_t *es2, *ee2;
+        uint8_t *sf2;
+        if (int rc = dalloc(ctx, &uw2, tw2 + 8, false)) return rc;
+        if (int rc = dalloc(ctx, &eo2, ne2 + 1, false)) return rc;
+        if (int rc = dalloc(ctx, &el2, ne2 + 1, false)) return rc;
+        if (int rc = dalloc(ctx, &es2, ne2 + 1, false)) return rc;
+        if (int rc = dalloc(ctx, &ee2, ne2 + 1, false)) return rc;
+        if (int rc = dalloc(ctx, &sf2, ne2 + 1, false)) return rc;
+        hipError_t e = hipSuccess;
+        auto cp = [&](void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+            if (bytes && e == hipSuccess) e = hipMemcpy(dst, src, bytes, kind);
+        };
+        cp(uw2, ctx->g_uwords, ktotalw * 8, hipMemcpyDeviceToDevice);
+        cp(uw2 + ktotalw, lwords.data(), lwords.size() * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(uw2 + tw2, 0, 64);
+        cp(eo2, ctx->g_eoffw, nkept * 8, hipMemcpyDeviceToDevice);
+        cp(eo2 + nkept, l_offw.data(), nl * 8, hipMemcpyHostToDevice);
+        cp(el2, ctx->g_elen, nkept * 8, hipMemcpyDeviceToDevice);
+        cp(el2 + nkept, l_len.data(), nl * 8, hipMemcpyHostToDevice);
+        cp(es2, ctx->g_estart, nkept * 8, hipMemcpyDeviceToDevice);
+        cp(es2 + nkept, l_start.data(), nl * 8, hipMemcpyHostToDevice);
+        cp(ee2, ctx->g_eend, nkept * 8, hipMemcpyDeviceToDevice);
+        cp(ee2 + nkept, l_end.data(), nl * 8, hipMemcpyHostToDevice);
+        cp(sf2, ctx->g_eself, nkept, hipMemcpyDeviceToDevice);
+        cp(sf2 + nkept, l_self.data(), nl, hipMemcpyHostToDevice);
+        arena_put(ctx, ctx->g_uwords);
+        arena_put(ctx, ctx->g_eoffw);
+        arena_put(ctx, ctx->g_elen);
+        arena_put(ctx, ctx->g_estart);
+        arena_put(ctx, ctx->g_eend);
+        arena_put(ctx, ctx->g_eself);
+        ctx->g_uwords = uw2;
+        ctx->g_eoffw = eo2;
+        ctx->g_elen = el2;
+        ctx->g_estart = es2;
+        ctx->g_eend = ee2;
+        ctx->g_eself = sf2;
+        if (e != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "appending the perfect loops failed: %s", hipGetErrorString(e));
+        ctx->g_ne = ne2;
+        ctx->g_nuwords = tw2;
+        ctx->g_nloops = nl;
+    }
+    return 0;
+}
+
 // Everything after the extension masks: early clippers (options), node table of the final masks, start de-edges, walks, perfect
 // loops, link records + vertices. tab: 2 * D0 + 2 entries; tab_valid: k_fill_tab has already filled it for the current masks.
 // pm: the partition-major route (smx_pm.hpp) — g_kmers holds EXT records in the dedupe stage's order, tab is filled, walks cross chunks by
@@ -964,76 +1045,7 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
                 for (unsigned j = 0; j < k; ++j) nodes[t].kmer[j] = "ACGT"[(hk[(size_t)i * NW + (j >> 5)] >> ((j & 31) << 1)) & 3];
                 nodes[t].mask = hmask[i];
             }
-            smxh::LoopCollector lc(nodes, k);
-            std::vector<std::string> loops;
-            lc.collect(loops);
-            // the loops are appended to the device graph: bigger arrays, old content copied, loop edges uploaded
-            const uint64_t nl = loops.size();
-            if (nl) {
-                std::vector<unsigned long long> l_offw(nl), l_len(nl), l_start(nl), l_end(nl);
-                std::vector<uint8_t> l_self(nl);
-                std::vector<uint64_t> lwords;
-                for (uint64_t i = 0; i < nl; ++i) {
-                    const std::string &sq = loops[i];
-                    l_offw[i] = ktotalw + lwords.size();
-                    l_len[i] = sq.size();
-                    // node ids must be taken from the untouched masks' k-mers (collect() zeroed the masks, not the index)
-                    l_start[i] = lc.node_of(sq.substr(0, k));
-                    l_end[i] = lc.node_of(sq.substr(sq.size() - k));
-                    l_self[i] = sq == smxh::revcomp(sq) ? 1 : 0;
-                    const size_t w0 = lwords.size();
-                    lwords.resize(w0 + (sq.size() + 31) / 32, 0);
-                    for (size_t t = 0; t < sq.size(); ++t) {
-                        const char ch = sq[t];
-                        const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
-                        lwords[w0 + (t >> 5)] |= code << ((t & 31) << 1);
-                    }
-                }
-                const uint64_t ne2 = nkept + nl, tw2 = ktotalw + lwords.size();
-                uint64_t *uw2;
-                unsigned long long *eo2, *el2;
-                node_t *es2, *ee2;
-                uint8_t *sf2;
-                if (int rc = dalloc(ctx, &uw2, tw2 + 8, false)) return rc;
-                if (int rc = dalloc(ctx, &eo2, ne2 + 1, false)) return rc;
-                if (int rc = dalloc(ctx, &el2, ne2 + 1, false)) return rc;
-                if (int rc = dalloc(ctx, &es2, ne2 + 1, false)) return rc;
-                if (int rc = dalloc(ctx, &ee2, ne2 + 1, false)) return rc;
-                if (int rc = dalloc(ctx, &sf2, ne2 + 1, false)) return rc;
-                hipError_t e = hipSuccess;
-                auto cp = [&](void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
-                    if (bytes && e == hipSuccess) e = hipMemcpy(dst, src, bytes, kind);
-                };
-                cp(uw2, ctx->g_uwords, ktotalw * 8, hipMemcpyDeviceToDevice);
-                cp(uw2 + ktotalw, lwords.data(), lwords.size() * 8, hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemset(uw2 + tw2, 0, 64);
-                cp(eo2, ctx->g_eoffw, nkept * 8, hipMemcpyDeviceToDevice);
-                cp(eo2 + nkept, l_offw.data(), nl * 8, hipMemcpyHostToDevice);
-                cp(el2, ctx->g_elen, nkept * 8, hipMemcpyDeviceToDevice);
-                cp(el2 + nkept, l_len.data(), nl * 8, hipMemcpyHostToDevice);
-                cp(es2, ctx->g_estart, nkept * 8, hipMemcpyDeviceToDevice);
-                cp(es2 + nkept, l_start.data(), nl * 8, hipMemcpyHostToDevice);
-                cp(ee2, ctx->g_eend, nkept * 8, hipMemcpyDeviceToDevice);
-                cp(ee2 + nkept, l_end.data(), nl * 8, hipMemcpyHostToDevice);
-                cp(sf2, ctx->g_eself, nkept, hipMemcpyDeviceToDevice);
-                cp(sf2 + nkept, l_self.data(), nl, hipMemcpyHostToDevice);
-                arena_put(ctx, ctx->g_uwords);
-                arena_put(ctx, ctx->g_eoffw);
-                arena_put(ctx, ctx->g_elen);
-                arena_put(ctx, ctx->g_estart);
-                arena_put(ctx, ctx->g_eend);
-                arena_put(ctx, ctx->g_eself);
-                ctx->g_uwords = uw2;
-                ctx->g_eoffw = eo2;
-                ctx->g_elen = el2;
-                ctx->g_estart = es2;
-                ctx->g_eend = ee2;
-                ctx->g_eself = sf2;
-                if (e != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "appending the perfect loops failed: %s", hipGetErrorString(e));
-                ctx->g_ne = ne2;
-                ctx->g_nuwords = tw2;
-                ctx->g_nloops = nl;
-            }
+            if (int rc = append_loops(ctx, k, nodes, nkept, ktotalw)) return rc;
         }
     }
     unsigned herr = 0;

@@ -133,6 +133,11 @@ struct smx_ctx {
     std::vector<uint64_t> g_kboff, g_kpoboff;
     smx::RankDir g_dir_kmers{}, g_dir_kpo{};  // .dir / .boff owned by the graph state
     bool g_ready = false;
+    // distributed walks (smx_dwalk.hpp): the start de-edges of this rank's shard in k-mer-file order, the requests its chain k-mers have
+    unsigned long long *dw_cand = nullptr;
+    uint64_t dw_ncand = 0, dw_nchain = 0;
+    bool dw_ready = false;
+    bool g_sharded_file = false;  // the graph was built from gathered unitigs: no k-mer file, no masks on this rank (smx_build_graph_from_unitigs)
     // the graph itself, resident in HBM (unitigs 2-bit packed, word-aligned starts; edges in the reference's enumeration order)
     uint64_t *g_uwords = nullptr;                          // [g_nuwords + 8]
     unsigned long long *g_eoffw = nullptr, *g_elen = nullptr;  // [g_ne] word offset / nucleotides of every unitig

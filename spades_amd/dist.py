@@ -29,6 +29,31 @@ class CollectiveFailure(RuntimeError):
         self.code = code
 
 
+def _staged(t: torch.Tensor) -> bool:
+    """ranks that share a GPU, or a box without RCCL between them, run on gloo: it moves HBM tensors only for broadcast / all-reduce, so
+    the all-to-all and the all-gather go through host memory there (tests/test_dist_gpu.py: two processes on one MI355X)"""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_to_all_single(out: torch.Tensor, inp: torch.Tensor, output_split_sizes=None, input_split_sizes=None):
+    if _staged(inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes)
+
+
+def _all_gather(outs, t: torch.Tensor):
+    if _staged(t):
+        o = [torch.empty(x.shape, dtype=x.dtype) for x in outs]
+        dist.all_gather(o, t.cpu())
+        for x, y in zip(outs, o):
+            x.copy_(y)
+    else:
+        dist.all_gather(outs, t)
+
+
 def _guarded(dev, what: str, fn, *args):
     """run a rank-local step between two collectives; every rank then learns (one tiny all-reduce) whether all of them got through"""
     err, res = None, None
@@ -178,6 +203,71 @@ class GpuEngine:
         return dict(n_kpomers=info[0], n_kmers=info[1], n_unitigs=info[2], n_loops=info[3], n_vertices=info[4],
                     unitig_bases=info[6], words=info[7])
 
+    # -- distributed walks: the k-mer-specific steps, on this rank's shard --
+    def walk_counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _chk(self.ctx._h, self.ctx.lib.smx_shard_walk_counts(self.ctx._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def walk_requests(self, starts: bool, k: int, world: int, dev):
+        """-> (canonical successor k-mers grouped by owner, their tags in the same order, records per owner)"""
+        n_chain, n_start = self.walk_counts()
+        n = n_start if starts else n_chain
+        recs = torch.empty(max(n * ((k + 31) // 32), 1), dtype=torch.int64, device=dev)
+        tags = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        counts = (C.c_uint64 * world)()
+        _chk(self.ctx._h, self.ctx.lib.smx_shard_walk_requests(self.ctx._h, 1 if starts else 0, world, recs.data_ptr(),
+                                                              C.cast(tags.data_ptr(), C.POINTER(C.c_uint64)), counts))
+        return recs, tags[:n], [int(c) for c in counts]
+
+    def walk_starts(self, dev):
+        _, n = self.walk_counts()
+        t = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        _chk(self.ctx._h, self.ctx.lib.smx_shard_walk_starts(self.ctx._h, C.cast(t.data_ptr(), C.POINTER(C.c_uint64))))
+        return t[:n]
+
+    def shard_lookup(self, recs: torch.Tensor, n: int, dev):
+        out = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        _chk(self.ctx._h, self.ctx.lib.smx_shard_lookup(self.ctx._h, recs.data_ptr(), n, C.cast(out.data_ptr(), C.POINTER(C.c_uint64))))
+        return out[:n]
+
+    def shard_gather_kmers(self, local_ranks: torch.Tensor, k: int, dev):
+        n = local_ranks.numel()
+        km = torch.empty(max(n * ((k + 31) // 32), 1), dtype=torch.int64, device=dev)
+        mk = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        _chk(self.ctx._h, self.ctx.lib.smx_shard_gather_kmers(self.ctx._h, C.cast(local_ranks.data_ptr(), C.POINTER(C.c_uint64)), n, km.data_ptr(),
+                                                             C.cast(mk.data_ptr(), C.POINTER(C.c_uint8))))
+        return km, mk
+
+    def shard_unitigs(self, first_rank: int, steps: torch.Tensor, last: torch.Tensor, boff: torch.Tensor, bases: torch.Tensor, dev):
+        """-> this rank's kept unitigs: (packed words, lengths, start nodes, end nodes, self-conjugate flags)"""
+        u64 = C.POINTER(C.c_uint64)
+        nk, nwd = C.c_uint64(), C.c_uint64()
+        _chk(self.ctx._h, self.ctx.lib.smx_shard_unitigs(self.ctx._h, first_rank, C.cast(steps.data_ptr(), u64), C.cast(last.data_ptr(), u64),
+                                                        C.cast(boff.data_ptr(), u64), C.cast(bases.data_ptr(), C.POINTER(C.c_uint8)), C.byref(nk), C.byref(nwd)))
+        ne, nwords = nk.value, nwd.value
+        words = torch.empty(max(nwords, 1), dtype=torch.int64, device=dev)
+        ln, st, en = (torch.empty(max(ne, 1), dtype=torch.int64, device=dev) for _ in range(3))
+        sf = torch.empty(max(ne, 1), dtype=torch.uint8, device=dev)
+        _chk(self.ctx._h, self.ctx.lib.smx_shard_unitigs_copy(self.ctx._h, C.cast(words.data_ptr(), u64), C.cast(ln.data_ptr(), u64), C.cast(st.data_ptr(), u64),
+                                                             C.cast(en.data_ptr(), u64), C.cast(sf.data_ptr(), C.POINTER(C.c_uint8))))
+        return words[:nwords], ln[:ne], st[:ne], en[:ne], sf[:ne]
+
+    def build_graph_from_unitigs(self, k: int, nb: int, n_kmers: int, n_kpomers: int, words, n_words: int, ln, st, en, sf, ne: int, loop_ranks, loop_kmers, loop_masks):
+        """loop_*: host numpy arrays (uint64 global ranks in file order, uint64 k-mer words, uint8 masks)"""
+        h = self.ctx._h
+        u64 = C.POINTER(C.c_uint64)
+        nl = int(len(loop_ranks))
+        _chk(h, self.ctx.lib.smx_build_graph_from_unitigs(
+            h, k, nb, n_kmers, n_kpomers, C.cast(words.data_ptr(), u64), n_words, C.cast(ln.data_ptr(), u64), C.cast(st.data_ptr(), u64),
+            C.cast(en.data_ptr(), u64), C.cast(sf.data_ptr(), C.POINTER(C.c_uint8)), ne,
+            loop_ranks.ctypes.data_as(u64) if nl else None, loop_kmers.ctypes.data_as(u64) if nl else None,
+            loop_masks.ctypes.data_as(C.POINTER(C.c_uint8)) if nl else None, nl))
+        info = (C.c_uint64 * 8)()
+        _chk(h, self.ctx.lib.smx_graph_info(h, info))
+        return dict(n_kpomers=info[0], n_kmers=info[1], n_unitigs=info[2], n_loops=info[3], n_vertices=info[4],
+                    unitig_bases=info[6], words=info[7])
+
     def set_kpomers(self, buf: torch.Tensor, n: int, bucket_sizes):
         nb = len(bucket_sizes)
         bs = (C.c_uint64 * nb)(*bucket_sizes)
@@ -195,31 +285,29 @@ class GpuEngine:
         _chk(self.ctx._h, self.ctx.lib.smx_graph_set_coverage(self.ctx._h, C.cast(cov.data_ptr(), C.POINTER(C.c_uint32)), cov.numel()))
 
 
-def _exchange(engine, send: torch.Tensor, counts, wpr: int, rank: int, world: int, dev, pool: bool = False):
-    """ONE all-to-all of records of `wpr` int64 words: counts[p] records go to rank p. Returns (recv tensor, records received).
+def _a2a(send: torch.Tensor, counts, rank: int, world: int, dev, alloc=None):
+    """ONE all-to-all of a 1-D tensor: counts[p] ELEMENTS go to rank p. Returns (recv, elements received from every rank).
     Splits are capped at XCHG_LIMIT elements per (pair, round): one all_to_all_single of a 30 GB buffer (3.8 G int64 elements)
     silently truncates on this stack (measured: tail left untouched), so large segments go in several rounds of views (no staging
-    copies); every pair still moves each record exactly once."""
+    copies); every pair still moves each element exactly once."""
     n_sent = sum(counts)
     cnt_t = torch.tensor(counts, dtype=torch.int64, device=dev)
     rcv_t = torch.empty_like(cnt_t)
-    dist.all_to_all_single(rcv_t, cnt_t)
+    _all_to_all_single(rcv_t, cnt_t)
     rcounts = [int(c) for c in rcv_t.tolist()]
     n_recv = sum(rcounts)
-    # pool: the receive buffer comes from the engine's own HBM pool and is consumed by the count that follows
-    recv = _guarded(dev, "receive buffer", engine.alloc_recv if pool and hasattr(engine, "alloc_recv") else engine.alloc, n_recv * wpr, dev)
+    recv = alloc(n_recv) if alloc is not None else torch.empty(max(n_recv, 1), dtype=send.dtype, device=dev)
     soff = [0]
     for c in counts:
-        soff.append(soff[-1] + c * wpr)
+        soff.append(soff[-1] + c)
     roff = [0]
     for c in rcounts:
-        roff.append(roff[-1] + c * wpr)
-    mx = torch.tensor([max(counts) * wpr if counts else 0], dtype=torch.int64, device=dev)
+        roff.append(roff[-1] + c)
+    mx = torch.tensor([max(counts) if counts else 0], dtype=torch.int64, device=dev)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     rounds = max(1, -(-int(mx.item()) // XCHG_LIMIT))
     if rounds == 1:
-        dist.all_to_all_single(recv[:n_recv * wpr], send[:n_sent * wpr],
-                               output_split_sizes=[c * wpr for c in rcounts], input_split_sizes=[c * wpr for c in counts])
+        _all_to_all_single(recv[:n_recv], send[:n_sent], output_split_sizes=rcounts, input_split_sizes=list(counts))
     else:
         # grouped point-to-point rounds on views (ncclSend/ncclRecv pairs under one group on RCCL): every pair has its own
         # xGMI link, there is no ring to serialise on, and no staging copy is needed
@@ -240,9 +328,17 @@ def _exchange(engine, send: torch.Tensor, counts, wpr: int, rank: int, world: in
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
-    if dev.type == "cuda":  # the library runs on its own stream: the received records must have landed before it reads them
+    if dev.type == "cuda":  # the library runs on its own stream: what was received must have landed before it reads it
         torch.cuda.current_stream(dev).synchronize()
-    return recv, n_recv
+    return recv, rcounts
+
+
+def _exchange(engine, send: torch.Tensor, counts, wpr: int, rank: int, world: int, dev, pool: bool = False):
+    """ONE all-to-all of records of `wpr` int64 words: counts[p] records go to rank p. Returns (recv tensor, records received)."""
+    # pool: the receive buffer comes from the engine's own HBM pool and is consumed by the count that follows
+    alloc = engine.alloc_recv if pool and hasattr(engine, "alloc_recv") else engine.alloc
+    recv, rcounts = _a2a(send, [c * wpr for c in counts], rank, world, dev, alloc=lambda n: _guarded(dev, "receive buffer", alloc, n, dev))
+    return recv, sum(rcounts) // wpr
 
 
 def sharded_count(engine, K: int, nb: int, rank: int, world: int, dev):
@@ -299,7 +395,188 @@ def _gather_shards(engine, mine: torch.Tensor, n_mine: int, per_rank, unit: int,
     return full
 
 
-def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev, coverage: bool = False, route: str = "auto"):
+def _sync(dev):
+    if dev.type == "cuda":  # the library runs on its own stream: torch's work on its inputs must be over
+        torch.cuda.current_stream(dev).synchronize()
+
+
+def _by_owner(owner: torch.Tensor, world: int):
+    """-> (stable order that groups by owner, elements per owner)"""
+    order = torch.argsort(owner, stable=True)
+    return order, [int(c) for c in torch.bincount(owner, minlength=world).tolist()]
+
+
+def _remote_rows(targets: torch.Tensor, owner: torch.Tensor, table: torch.Tensor, my_base: int, rank: int, world: int, dev):
+    """table[targets - base of the owner] from the ranks that own them: one all-to-all of the indices, one of the rows (both in the order
+    of the requests, so nothing but the indices and the rows travels). The rows are read before anything comes back: a round of pointer
+    doubling sees the state of the round before on every rank."""
+    w = table.shape[1]
+    order, counts = _by_owner(owner, world)
+    q, rcounts = _a2a(targets[order].contiguous(), counts, rank, world, dev)
+    nq = sum(rcounts)
+    rows = table[q[:nq] - my_base].reshape(-1).contiguous()
+    back, _ = _a2a(rows, [c * w for c in rcounts], rank, world, dev)
+    out = torch.empty((targets.numel(), w), dtype=table.dtype, device=dev)
+    out[order] = back[:targets.numel() * w].reshape(-1, w)
+    return out
+
+
+def _ragged(off: torch.Tensor, ln: torch.Tensor, dev):
+    """indices off[i] .. off[i] + ln[i] of every i, concatenated"""
+    tot = int(ln.sum().item()) if ln.numel() else 0
+    if tot == 0:
+        return torch.empty(0, dtype=torch.int64, device=dev)
+    seg = torch.repeat_interleave(torch.arange(ln.numel(), device=dev), ln)
+    start = torch.cumsum(ln, 0) - ln
+    return off[seg] + (torch.arange(tot, device=dev) - start[seg])
+
+
+def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank):
+    """Unitigs of a graph whose k-mer file stays sharded (collective). Every rank holds its bucket range of
+    {k-mer file, InOutMask bytes}; a walk of the reference (debruijn_graph_constructor.hpp:264-273) would change rank at every step, so
+    nothing is walked:
+      1. every oriented non-junction k-mer learns its successor node and whether that is a junction k-mer (ONE lookup exchange: the
+         canonical successor k-mer travels to its owner, a node id comes back), every start de-edge its first node (a second one);
+      2. the chains of non-junction k-mers are ranked by pointer doubling — per round one exchange of node ids and one of (pointer,
+         distance, last chain k-mer, end node) rows, ceil(log2(longest chain)) rounds; what never finishes lies on perfect loops;
+      3. a chain k-mer x is d(x^1) steps behind the head tail(x^1)^1 of its chain (the reverse strand ran through the same doubling):
+         it sends its outgoing nucleotide there, and the owner of the head lays the chain's nucleotides out in order;
+      4. the owner of a start de-edge fetches length, end node and nucleotides of the chain behind it and assembles, keeps or drops the
+         unitig exactly as the single-GPU route does (engine.shard_unitigs).
+    Returns this rank's kept unitigs (k-mer-file order of their start k-mers: concatenated in rank order they are the reference's edge
+    list) and the local ranks of its k-mers on perfect loops."""
+    nw = (k + 31) // 32
+    first = [0]
+    for c in kmers_per_rank:
+        first.append(first[-1] + int(c))
+    n_mine = int(kmers_per_rank[rank])
+    base = 2 * first[rank]
+    first_t = torch.tensor(first[:world], dtype=torch.int64, device=dev)
+    bounds = torch.tensor([2 * f for f in first[1:]], dtype=torch.int64, device=dev)
+
+    def owner_of(nodes):
+        return torch.bucketize(nodes, bounds, right=True)
+
+    def lookup(starts: bool):
+        recs, tags, counts = _guarded(dev, "successor requests of the shard", engine.walk_requests, starts, k, world, dev)
+        recv, rcounts = _a2a(recs, [c * nw for c in counts], rank, world, dev)
+        n_recv = sum(rcounts) // nw
+        reply = _guarded(dev, "lookup in the shard", engine.shard_lookup, recv, n_recv, dev)
+        back, _ = _a2a(reply.contiguous(), [c // nw for c in rcounts], rank, world, dev)
+        n = sum(counts)
+        back = back[:n]
+        asked = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(counts, dtype=torch.int64, device=dev))
+
+        def check():
+            if n and bool((back < 0).any().item()):
+                raise RuntimeError(f"{int((back < 0).sum().item())} successor k-mers are in no shard: the k-mer file and the masks disagree")
+        _guarded(dev, "successor lookups", check)
+        node = (((back >> 1) + first_t[asked]) << 1) | ((tags >> 2) & 1)
+        return tags, node, (back & 1).to(torch.bool)
+
+    # 1. successors of the chain k-mers, first nodes of the start de-edges
+    n2 = 2 * n_mine
+    tags, node, junc = lookup(False)
+    xl = tags >> 4
+    succ = torch.full((n2,), -1, dtype=torch.int64, device=dev)
+    nonj = torch.zeros(n2, dtype=torch.bool, device=dev)
+    sj = torch.zeros(n2, dtype=torch.bool, device=dev)
+    code = torch.zeros(n2, dtype=torch.uint8, device=dev)
+    succ[xl] = node
+    nonj[xl] = True
+    sj[xl] = junc
+    code[xl] = (tags & 3).to(torch.uint8)
+    ctags, cfirst, cjunc = lookup(True)
+    n_cand = ctags.numel()
+    ci = ctags >> 4
+    c_first = torch.empty(n_cand, dtype=torch.int64, device=dev)
+    c_fj = torch.empty(n_cand, dtype=torch.bool, device=dev)
+    c_first[ci] = cfirst
+    c_fj[ci] = cjunc
+    del tags, node, junc, xl, ctags, cfirst, cjunc, ci
+
+    # 2. pointer doubling over the chains. Row of a node: pointer (-1 once the chain end is known), hops to it, last chain k-mer, end node
+    gl = base + torch.arange(n2, dtype=torch.int64, device=dev)
+    ends_here = nonj & sj
+    table = torch.stack([torch.where(nonj & ~sj, succ, torch.full_like(succ, -1)), (nonj & ~sj).to(torch.int64),
+                         torch.where(ends_here, gl, torch.full_like(gl, -1)), torch.where(ends_here, succ, torch.full_like(succ, -1))], 1).contiguous()
+    del gl, ends_here
+    prev, rounds = -1, 0
+    while True:
+        act = (table[:, 0] >= 0).nonzero().squeeze(1)
+        tot = torch.tensor([act.numel()], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        tot = int(tot.item())
+        if tot == 0 or tot == prev:  # every round ends at least one k-mer of every open chain: what is left runs in circles
+            break
+        prev = tot
+        rounds += 1
+        tg = table[act, 0]
+        rows = _remote_rows(tg, owner_of(tg), table, base, rank, world, dev)
+        fin = rows[:, 0] < 0
+        neg = torch.full_like(rows[:, 0], -1)
+        table[act] = torch.stack([rows[:, 0], table[act, 1] + rows[:, 1], torch.where(fin, rows[:, 2], neg), torch.where(fin, rows[:, 3], neg)], 1)
+    loop_local = torch.unique(act >> 1) if act.numel() else torch.empty(0, dtype=torch.int64, device=dev)
+    done = nonj & (table[:, 0] < 0)
+
+    # 3. every chain k-mer to the head of its chain
+    xs = done.nonzero().squeeze(1)
+    head = table[xs ^ 1, 2] ^ 1
+    payload = (table[xs ^ 1, 1] << 2) | code[xs].to(torch.int64)
+    is_head = done & sj[torch.arange(n2, device=dev) ^ 1] if n2 else done
+    clen = torch.where(is_head, table[:, 1] + 1, torch.zeros_like(table[:, 1]))
+    coff = torch.cumsum(clen, 0) - clen
+    total = int(clen.sum().item()) if n2 else 0
+    order, counts = _by_owner(owner_of(head), world)
+    msg = torch.stack([head[order], payload[order]], 1).reshape(-1).contiguous()
+    got, rcounts = _a2a(msg, [2 * c for c in counts], rank, world, dev)
+    n_got = sum(rcounts) // 2
+    got = got[:2 * n_got].reshape(-1, 2)
+    bases = torch.zeros(max(total, 1), dtype=torch.uint8, device=dev)
+
+    def place():
+        if n_got != total:
+            raise RuntimeError(f"{n_got} chain nucleotides arrived for chains of {total} k-mers")
+        if n_got:
+            hl = got[:, 0] - base
+            if not bool(is_head[hl].all().item()):
+                raise RuntimeError("a chain nucleotide arrived at a k-mer that heads no chain")
+            bases[coff[hl] + (got[:, 1] >> 2)] = (got[:, 1] & 3).to(torch.uint8)
+    _guarded(dev, "chain nucleotides at the heads", place)
+    del xs, head, payload, msg, got
+
+    # 4. the chains behind this rank's start de-edges
+    q = (~c_fj).nonzero().squeeze(1)
+    tq = c_first[q]
+    order, counts = _by_owner(owner_of(tq), world)
+    asks, rcounts = _a2a(tq[order].contiguous(), counts, rank, world, dev)
+    n_asks = sum(rcounts)
+    al = asks[:n_asks] - base
+    a_len, a_end, a_off = clen[al], table[al, 3], coff[al]
+    rows, _ = _a2a(torch.stack([a_len, a_end], 1).reshape(-1).contiguous(), [2 * c for c in rcounts], rank, world, dev)
+    seg_of = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(rcounts, dtype=torch.int64, device=dev))
+    per_rank = torch.zeros(world, dtype=torch.int64, device=dev).index_add_(0, seg_of, a_len) if n_asks else torch.zeros(world, dtype=torch.int64, device=dev)
+    flat = bases[_ragged(a_off, a_len, dev)] if n_asks else torch.empty(0, dtype=torch.uint8, device=dev)
+    my_bases, _ = _a2a(flat.contiguous(), [int(c) for c in per_rank.tolist()], rank, world, dev)
+    rows = rows[:2 * q.numel()].reshape(-1, 2)
+    steps = torch.zeros(n_cand, dtype=torch.int64, device=dev)
+    last = c_first.clone()
+    boff = torch.zeros(n_cand + 1, dtype=torch.int64, device=dev)
+    qo = q[order]
+    steps[qo] = rows[:, 0]
+    last[qo] = rows[:, 1]
+    boff[qo] = torch.cumsum(rows[:, 0], 0) - rows[:, 0]
+
+    def check_chains():
+        if q.numel() and bool((rows[:, 0] <= 0).any().item()):
+            raise RuntimeError("a start de-edge leads to a k-mer that heads no chain")
+    _guarded(dev, "chains behind the start de-edges", check_chains)
+    _sync(dev)
+    unitigs = _guarded(dev, "unitigs of the shard", engine.shard_unitigs, first[rank], steps, last, boff, my_bases, dev)
+    return unitigs, loop_local, rounds
+
+
+def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev, coverage: bool = False, route: str = "auto", walks: str = "gathered"):
     """Construction on `world` ranks (collective), owner-side masks. Two routes to the owner's shard of
     {k-mer file, InOutMask bytes}:
       route "ext" (taken by "auto" where the k-mer record has 8 spare bits): every rank extracts the canonical k-mers of ITS reads, each
@@ -313,6 +590,10 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
     Then, either way:
       4. the compact structure {k-mer file, masks} (bucket-major, so rank order IS file order) is gathered and every rank derives the
          same unitigs and link records from it (unitig walks cross owners at every step).
+    walks = "distributed" replaces step 4 for graphs whose gathered structure does not fit one GPU: the k-mer file stays sharded, the
+    unitigs come out of distributed_walks() (lookup exchanges + pointer doubling), and only the UNITIGS (2 bits per nucleotide + 25 B per
+    unitig, a few % of the k-mer file) and the k-mers of perfect loops are gathered; every rank then derives link records and vertices
+    from them (engine.build_graph_from_unitigs). The graph is the same, bit for bit; it has no k-mer file on any rank.
     No rank holds the whole (k+1)-mer file — unless coverage (-c) is asked for: the counters of the coverage pass are keyed by
     (k+1)-mer, so the file is counted (sharded) and gathered for that pass only; each rank counts its own reads and the raw edge
     coverages are all-reduced (SUM mod 2^32). Every rank ends with the same graph; rank 0 normally writes it. Returns the engine's
@@ -362,7 +643,7 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
     # 4. gather {k-mers, masks}
     me = torch.tensor([n_kmers, n_kpo, bits, pals] + ksizes + kpo_sizes, dtype=torch.int64, device=dev)
     every = [torch.empty_like(me) for _ in range(world)]
-    dist.all_gather(every, me)
+    _all_gather(every, me)
     every = [e.tolist() for e in every]
     kmers_per_rank = [int(e[0]) for e in every]
     kpo_per_rank = [int(e[1]) for e in every]
@@ -377,6 +658,45 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
             raise RuntimeError(f"the masks ({n_kpo_all} (k+1)-mers) and the (k+1)-mer count ({sum(kpo_per_rank)}) disagree")
     else:
         n_kpo_all = sum(kpo_per_rank)
+    if walks == "distributed":
+        nwk = (k + 31) // 32
+        (u_words, u_len, u_st, u_en, u_sf), loop_local, rounds = distributed_walks(engine, k, rank, world, dev, kmers_per_rank)
+        first_mine = sum(kmers_per_rank[:rank])
+        loop_local = loop_local.contiguous()
+        _sync(dev)
+        l_k, l_m = _guarded(dev, "k-mers on perfect loops", engine.shard_gather_kmers, loop_local, k, dev)
+        me2 = torch.tensor([u_len.numel(), u_words.numel(), loop_local.numel()], dtype=torch.int64, device=dev)
+        every2 = [torch.empty_like(me2) for _ in range(world)]
+        _all_gather(every2, me2)
+        every2 = [e.tolist() for e in every2]
+        ne_r, nwd_r, nl_r = ([int(e[i]) for e in every2] for i in range(3))
+        if hasattr(engine, "trim"):
+            engine.trim()
+        g_words = _gather_shards(engine, u_words, u_words.numel(), nwd_r, 1, rank, world, dev, engine.alloc)
+        g_len = _gather_shards(engine, u_len, u_len.numel(), ne_r, 1, rank, world, dev, engine.alloc)
+        g_st = _gather_shards(engine, u_st, u_st.numel(), ne_r, 1, rank, world, dev, engine.alloc)
+        g_en = _gather_shards(engine, u_en, u_en.numel(), ne_r, 1, rank, world, dev, engine.alloc)
+        g_sf = _gather_shards(engine, u_sf, u_sf.numel(), ne_r, 1, rank, world, dev, engine.alloc_bytes)
+        g_lr = _gather_shards(engine, (loop_local + first_mine).contiguous(), loop_local.numel(), nl_r, 1, rank, world, dev, engine.alloc)
+        g_lk = _gather_shards(engine, l_k, loop_local.numel(), nl_r, nwk, rank, world, dev, engine.alloc)
+        g_lm = _gather_shards(engine, l_m, loop_local.numel(), nl_r, 1, rank, world, dev, engine.alloc_bytes)
+        del u_words, u_len, u_st, u_en, u_sf, l_k, l_m
+        _sync(dev)
+        import numpy as np
+        nl = sum(nl_r)
+        h_lr = g_lr[:nl].cpu().numpy().view(np.uint64).copy()
+        h_lk = g_lk[:nl * nwk].cpu().numpy().view(np.uint64).copy()
+        h_lm = g_lm[:nl].cpu().numpy().copy()
+        info = _guarded(dev, "graph from the gathered unitigs", engine.build_graph_from_unitigs, k, nb, sum(kmers_per_rank), n_kpo_all, g_words, sum(nwd_r),
+                        g_len, g_st, g_en, g_sf, sum(ne_r), h_lr, h_lk, h_lm)
+        info["walk_rounds"] = rounds
+        info["unitigs_per_rank"] = ne_r
+        del g_words, g_len, g_st, g_en, g_sf
+    elif walks != "gathered":
+        raise ValueError(f"walks = {walks!r}: 'gathered' or 'distributed'")
+    else:
+        info = None
+
     def my_shard():
         if hasattr(engine, "trim"):
             engine.trim()  # the library's arena gives its free physical memory back before torch allocates the gathered structure
@@ -384,14 +704,15 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
         engine.shard_copy(a, b)
         return a, b
 
-    my_k, my_m = _guarded(dev, "copy of the owner-side shard", my_shard)
-    full_k = _gather_shards(engine, my_k, n_kmers, kmers_per_rank, nw, rank, world, dev, engine.alloc)
-    full_m = _gather_shards(engine, my_m, n_kmers, kmers_per_rank, 1, rank, world, dev, engine.alloc_bytes)
-    del my_k, my_m
-    if dev.type == "cuda":
-        torch.cuda.current_stream(dev).synchronize()
-    info = _guarded(dev, "graph from the gathered k-mers + masks", engine.build_graph_from_kmers, k, nb, full_k, full_m, sum(kmers_per_rank), g_ksizes, n_kpo_all)
-    del full_k, full_m
+    if info is None:
+        my_k, my_m = _guarded(dev, "copy of the owner-side shard", my_shard)
+        full_k = _gather_shards(engine, my_k, n_kmers, kmers_per_rank, nw, rank, world, dev, engine.alloc)
+        full_m = _gather_shards(engine, my_m, n_kmers, kmers_per_rank, 1, rank, world, dev, engine.alloc_bytes)
+        del my_k, my_m
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        info = _guarded(dev, "graph from the gathered k-mers + masks", engine.build_graph_from_kmers, k, nb, full_k, full_m, sum(kmers_per_rank), g_ksizes, n_kpo_all)
+        del full_k, full_m
     if coverage:
         full_p = _gather_shards(engine, kpo_mine, n_kpo, kpo_per_rank, nw, rank, world, dev, engine.alloc)
         if dev.type == "cuda":
@@ -407,4 +728,5 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
     info["route"] = "ext" if ext else "kpomers"
     info["kpomers_per_rank"] = kpo_per_rank
     info["kmers_per_rank"] = kmers_per_rank
+    info["walks"] = walks
     return info

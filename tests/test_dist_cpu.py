@@ -399,3 +399,198 @@ def test_a_failing_rank_does_not_leave_the_others_waiting(fail_in, code, route, 
         assert all(x[1] == "ok" and x[2] == "kpomers" and x[3] == g["gfa"] for x in got)
     else:
         assert all(x[1] == "failed" and x[2] == code for x in got)
+
+
+# ---- distributed walks: spades_amd.dist.distributed_walks on a CPU double of the shard primitives ----------------
+_TR = str.maketrans("ACGT", "TGCA")
+
+
+def _rcs(s):
+    return s[::-1].translate(_TR)
+
+
+class OracleWalkEngine(OracleGraphEngine):
+    """the k-mer-specific steps of the distributed walks (GpuEngine: smx_shard_walk_requests, smx_shard_lookup, smx_shard_unitigs,
+    smx_build_graph_from_unitigs) restated on strings; everything between them is spades_amd.dist's own code, the code under test"""
+
+    @staticmethod
+    def _brev8(m):
+        return int(f"{m:08b}"[::-1], 2)
+
+    @staticmethod
+    def _junction(m):
+        o, i = m & 15, m >> 4
+        return not (o in (1, 2, 4, 8) and i in (1, 2, 4, 8))
+
+    def _prepare(self, k):
+        from oracle import oracle
+        if getattr(self, "_wk", None) == k:
+            return
+        self._wk = k
+        self.strs = [oracle.kmer_to_string(r, k) for r in self.shard_kmers]
+        self.index = {s: i for i, s in enumerate(self.strs)}
+        self.cands = []
+        for r, m in enumerate(self.shard_masks):
+            m = int(m)
+            if not self._junction(m):
+                continue
+            for c in range(4):
+                if m >> c & 1:
+                    self.cands.append((r, 0, c))
+            mi = self._brev8(m)
+            for c in range(4):
+                if mi >> c & 1:
+                    self.cands.append((r, 1, c))
+
+    def _node_str(self, node):
+        s = self.strs[node >> 1]
+        return _rcs(s) if node & 1 else s
+
+    def walk_requests(self, starts, k, world, dev):
+        from oracle import oracle
+        self._prepare(k)
+        nb = self.nb
+        items = []
+        if starts:
+            for i, (r, side, c) in enumerate(self.cands):
+                items.append((i, 2 * r + side, c))
+        else:
+            for r, m in enumerate(self.shard_masks):
+                m = int(m)
+                if self._junction(m):
+                    continue
+                items.append((2 * r, 2 * r, (m & 15).bit_length() - 1))
+                items.append((2 * r + 1, 2 * r + 1, (self._brev8(m) & 15).bit_length() - 1))
+        req = []
+        for item, node, c in items:
+            y = self._node_str(node)[1:] + "ACGT"[c]
+            ry = _rcs(y)
+            yo = 0 if y <= ry else 1
+            w = oracle.kmer_from_string(y if yo == 0 else ry)
+            owner = oracle.bucket(w, k, nb) * world // nb
+            req.append((owner, tuple(int(v) for v in w), (item << 4) | (8 if starts else 0) | (yo << 2) | c))
+        req.sort(key=lambda t: t[0])
+        nw = (k + 31) // 32
+        recs = np.array([t[1] for t in req], dtype=np.uint64).reshape(-1, nw)
+        tags = np.array([t[2] for t in req], dtype=np.int64)
+        counts = [sum(1 for t in req if t[0] == p) for p in range(world)]
+        rt = torch.from_numpy(recs.reshape(-1).view(np.int64).copy()) if len(req) else torch.empty(1, dtype=torch.int64)
+        return rt, torch.from_numpy(tags), counts
+
+    def shard_lookup(self, recs, n, dev):
+        from oracle import oracle
+        k = self._wk
+        nw = (k + 31) // 32
+        rec = recs[:n * nw].numpy().view(np.uint64).reshape(n, nw)
+        out = []
+        for r in rec:
+            i = self.index.get(oracle.kmer_to_string(r, k))
+            out.append(-1 if i is None else (i << 1) | (1 if self._junction(int(self.shard_masks[i])) else 0))
+        return torch.tensor(out, dtype=torch.int64)
+
+    def shard_gather_kmers(self, local_ranks, k, dev):
+        idx = local_ranks.numpy()
+        km = self.shard_kmers[idx].reshape(-1).view(np.int64).copy() if len(idx) else np.zeros(1, dtype=np.int64)
+        mk = self.shard_masks[idx].copy() if len(idx) else np.zeros(1, dtype=np.uint8)
+        return torch.from_numpy(km), torch.from_numpy(mk)
+
+    def shard_unitigs(self, first_rank, steps, last, boff, bases, dev):
+        k = self._wk
+        words, ln, st, en, sf = [], [], [], [], []
+        for i, (r, side, c) in enumerate(self.cands):
+            n = int(steps[i])
+            b = bases[int(boff[i]):int(boff[i]) + n].numpy()
+            s = self._node_str(2 * r + side) + "ACGT"[c] + "".join("ACGT"[int(x)] for x in b)
+            rs = _rcs(s)
+            if s < rs:
+                continue
+            w = [0] * ((len(s) + 31) // 32)
+            for t, ch in enumerate(s):
+                w[t >> 5] |= "ACGT".index(ch) << ((t & 31) << 1)
+            words += w
+            ln.append(len(s))
+            st.append(2 * (first_rank + r) + side)
+            en.append(int(last[i]))
+            sf.append(1 if s == rs else 0)
+        self.my_unitigs = len(ln)
+        t64 = lambda a: torch.from_numpy(np.array(a, dtype=np.uint64).view(np.int64).copy()) if a else torch.empty(0, dtype=torch.int64)
+        return t64(words), t64(ln), t64(st), t64(en), torch.tensor(sf, dtype=torch.uint8)
+
+    def build_graph_from_unitigs(self, k, nb, n_kmers, n_kpomers, words, n_words, ln, st, en, sf, ne, loop_ranks, loop_kmers, loop_masks):
+        from oracle import oracle
+        self.k = k
+        g = self.g = oracle.build_graph(self.all_reads, k, nb, coverage=True)
+        w = words[:n_words].numpy().view(np.uint64)
+        seqs, o = [], 0
+        for i in range(ne):
+            n = int(ln[i])
+            seqs.append("".join("ACGT"[(int(w[o + (t >> 5)]) >> ((t & 31) << 1)) & 3] for t in range(n)))
+            o += (n + 31) // 32
+        assert o == n_words
+        npaths = len(g["unitigs"]) - g["n_loops"]
+        # the ranks' kept unitigs, concatenated in rank order, are the reference's edge list (before the perfect loops)
+        assert seqs == g["unitigs"][:npaths]
+        rank_of = {oracle.kmer_to_string(r, k): i for i, r in enumerate(g["kmers"])}
+
+        def node(x):
+            rx = _rcs(x)
+            return 2 * rank_of[min(x, rx)] + (0 if x <= rx else 1)
+        assert [int(v) for v in st[:ne]] == [node(s[:k]) for s in seqs]
+        assert [int(v) for v in en[:ne]] == [node(s[-k:]) for s in seqs]
+        assert [int(v) for v in sf[:ne]] == [1 if s == _rcs(s) else 0 for s in seqs]
+        # k-mers no chain reached == the k-mers of the reference's perfect loops, in file order with their global ranks and masks
+        want = sorted({rank_of[min(u[j:j + k], _rcs(u[j:j + k]))] for u in g["unitigs"][npaths:] for j in range(len(u) - k + 1)})
+        assert [int(v) for v in loop_ranks] == want
+        nw = (k + 31) // 32
+        assert loop_kmers.reshape(-1, nw).tobytes() == g["kmers"][want].tobytes() if want else len(loop_kmers) == 0
+        assert (np.asarray(loop_masks) == g["masks"][want]).all()
+        assert n_kmers == len(g["kmers"]) and n_kpomers == g["n_kpomers"]
+        self.n_loop_kmers = len(want)
+        return dict(n_kpomers=g["n_kpomers"], n_kmers=len(g["kmers"]), n_unitigs=len(g["unitigs"]), n_loops=g["n_loops"], n_vertices=g["n_vertices"],
+                    unitig_bases=0, words=nw)
+
+
+def _walk_worker(rank, world, port, k, threads, q, reads_file, nreads, coverage, limit):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spades_amd import dist as smx_dist
+    smx_dist.XCHG_LIMIT = limit
+    reads = read_lines(reads_file)[:nreads]
+    eng = OracleWalkEngine(reads[rank::world], reads)
+    eng.nb = 10 * threads
+    info = smx_dist.sharded_build_graph(eng, k, threads, rank, world, torch.device("cpu"), coverage=coverage, route="ext", walks="distributed")
+    q.put((rank, info["walk_rounds"], info["unitigs_per_rank"], eng.my_unitigs, eng.n_loop_kmers, info["n_unitigs"], info["n_loops"],
+           eng.cov.tobytes() if coverage else b"", eng.g["gfa"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,world,reads_file,nreads,coverage,limit", [(21, 2, "reads_small.txt", 120, False, 1 << 27), (21, 3, "reads_small.txt", 120, True, 500),
+                                                                      (33, 2, "reads_small.txt", 80, False, 1 << 27), (21, 2, "reads_loop.txt", 10 ** 6, False, 1 << 27),
+                                                                      (21, 4, "reads_mixed.txt", 10 ** 6, False, 300)])
+def test_distributed_walks_gloo(k, world, reads_file, nreads, coverage, limit):
+    """the k-mer file stays sharded; lookups, pointer doubling, chain nucleotides and the gather of the unitigs go over gloo. The engine
+    asserts that the concatenated unitigs, their end nodes and the loop k-mers are the reference's (build_graph_from_unitigs above)."""
+    threads = 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000) + 11 * world + k
+    procs = [ctx.Process(target=_walk_worker, args=(r, world, port, k, threads, q, reads_file, nreads, coverage, limit)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rounds, per_rank, mine, nloopk, nu, nl, cov, gfa in got:
+        assert per_rank[rank] == mine and sum(per_rank) == nu - nl
+        assert rounds >= 1
+    assert len({g[1] for g in got}) == 1  # every rank ran the same number of doubling rounds
+    if reads_file == "reads_loop.txt":
+        assert got[0][6] > 0 and got[0][4] > 0  # perfect loops: found as the k-mers the doubling never finishes
+    if coverage:
+        kc = np.array([int(l.split("KC:i:")[1]) for l in got[0][8].splitlines() if l.startswith("S\t")], dtype=np.uint32)
+        for g in got:
+            assert (np.frombuffer(g[7], dtype=np.uint32) == kc).all()

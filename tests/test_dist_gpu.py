@@ -276,3 +276,101 @@ def test_two_rank_one_exchange_through_the_c_abi(k, t, tmp_path):
         gb.write_gfa(out)
         assert open(out).read() == open(want).read()
         gb.ctx.close()
+
+
+def test_distributed_walks_single_rank_nccl(tmp_path):
+    """walks = "distributed"  on the real engine, world 1 over RCCL: successor requests -> lookups -> pointer doubling
+    -> chain nucleotides -> smx_shard_unitigs -> smx_build_graph_from_unitigs, against the real tool's `-c` GFA (goldens), perfect loops
+    included; the graph has no k-mer file afterwards and says so."""
+    import torch
+    import torch.distributed as dist
+    from spades_amd import dist as smx_dist
+    from spades_amd.gbuilder import GraphBuilder
+    from spades_amd.kmercount import SmxError
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        for name, k, t, route in (("small", 21, 3, "ext"), ("small", 55, 1, "ext"), ("loop", 21, 1, "ext"), ("small", 21, 1, "kpomers"), ("polyA", 21, 1, "ext")):
+            reads = [r for r in read_lines(f"reads_{name}.txt") if r]
+            gb = GraphBuilder(k, t)
+            gb.push_back_reads(reads)
+            info = smx_dist.sharded_build_graph(smx_dist.GpuEngine(gb.ctx, "B"), k, t, 0, 1, dev, coverage=True, route=route, walks="distributed")
+            assert info["route"] == route and info["walks"] == "distributed" and info["walk_rounds"] >= 1
+            gb.adopt(info)
+            out = os.path.join(str(tmp_path), f"g_{name}_{k}.gfa")
+            gb.write_gfa(out)
+            assert open(out).read() == _golden(f"graphcov_{name}_k{k}_t{t}.gfa"), (name, k, t, route)
+            if name == "loop":
+                assert info["n_loops"] > 0
+            with pytest.raises(SmxError):
+                gb.kmers()  # the k-mer file stayed sharded
+            gb.ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _dwalk_rank(rank, world, port, k, t, seed, n_reads, genome, coverage, outdir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from spades_amd import dist as smx_dist
+    from spades_amd.gbuilder import GraphBuilder
+    import synth
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # ranks that share a GPU cannot use RCCL: host-staged exchanges (dist._staged)
+    try:
+        codes = synth.synth_codes(seed, genome, n_reads)
+        lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+        reads = [lut[c].tobytes().decode() for c in codes[rank::world]]
+        gb = GraphBuilder(k, t)
+        gb.push_back_reads(reads)
+        info = smx_dist.sharded_build_graph(smx_dist.GpuEngine(gb.ctx, "B"), k, t, rank, world, dev, coverage=coverage, walks="distributed")
+        gb.adopt(info)
+        gb.write_gfa(os.path.join(outdir, f"rank{rank}.gfa"))
+        with open(os.path.join(outdir, f"rank{rank}.info"), "w") as f:
+            f.write(repr({kk: v for kk, v in info.items() if isinstance(v, (int, str, list))}))
+        gb.ctx.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,t,n_reads,genome,coverage,world", [(55, 2, 20000, 100000, False, 2), (21, 1, 6000, 30000, True, 2), (77, 1, 10000, 60000, False, 3)])
+def test_distributed_walks_ranks_sharing_one_gpu(k, t, n_reads, genome, coverage, world, tmp_path):
+    """`world` processes, one context each on the same MI355X, every exchange of the distributed walks for real (gloo, staged through host
+    memory): no rank ever holds more than its bucket range of the k-mer file, and every rank writes the single-GPU graph, byte for byte."""
+    import torch.multiprocessing as mp
+    import synth
+    from spades_amd.gbuilder import GraphBuilder
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_dwalk_rank, args=(r, world, port, k, t, 4242 + k, n_reads, genome, coverage, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    codes = synth.synth_codes(4242 + k, genome, n_reads)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    ref = GraphBuilder(k, t)
+    ref.push_back_reads([lut[c].tobytes().decode() for c in codes])
+    ref.build()
+    if coverage:
+        ref.fill_coverage()
+    want = os.path.join(str(tmp_path), "ref.gfa")
+    ref.write_gfa(want)
+    n_kmers = ref.info()["n_kmers"]
+    ref.ctx.close()
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), f"rank{r}.gfa")).read() == open(want).read()
+        info = eval(open(os.path.join(str(tmp_path), f"rank{r}.info")).read())
+        assert sum(info["kmers_per_rank"]) == n_kmers and max(info["kmers_per_rank"]) < n_kmers  # the file was sharded
+        assert all(u > 0 for u in info["unitigs_per_rank"])
