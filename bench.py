@@ -353,6 +353,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option for this run (smx_set_option), e.g. dir_slots=2")
     ap.add_argument("--sharded-construct", type=float, default=10e6,
                     help="N>1 (or --force-sharded): after the timed steps, ONE construction over the ranks on this many reads per GPU (extra key; 0 disables)")
+    ap.add_argument("--distributed-walks", type=float, default=2e6,
+                    help="... and ONE more with the k-mer file left sharded (spades_amd.dist.distributed_walks) on this many reads per GPU (0 disables)")
     ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
     args = ap.parse_args()
 
@@ -699,17 +701,27 @@ def main():
         if args.sharded_construct > 0:
             import threading
 
-            def watchdog():  # a rank stuck in a collective must not cost the headline: the line goes out without this extra and every rank leaves
-                if rank == 0:
-                    out["construct_sharded"] = {"error": "timed out after 240 s (watchdog)"}
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
+            def guarded_leg(key, seconds, fn):
+                """a rank stuck in a collective must not cost the headline: after `seconds` the line goes out with what is there and every rank leaves"""
+                def watchdog():
+                    if rank == 0:
+                        out.setdefault("construct_sharded", {})[key] = f"timed out after {seconds} s (watchdog)"
+                        print(json.dumps(out), flush=True)
+                    os._exit(0)
+                wd = threading.Timer(float(seconds), watchdog)
+                wd.daemon = True
+                wd.start()
+                try:
+                    fn()
+                except Exception as e:  # noqa: BLE001
+                    if rank == 0:
+                        out.setdefault("construct_sharded", {})[key] = str(e)[:300]
+                wd.cancel()
 
-            wd = threading.Timer(240.0, watchdog)
-            wd.daemon = True
-            wd.start()
-            try:
-                n_c = int(min(args.sharded_construct, n_reads)) // 32 * 32
+            n_c = int(min(args.sharded_construct, n_reads)) // 32 * 32
+            fps = {}
+
+            def one_build(walks, n_c):
                 ctx.graph_clear()
                 gb.reads.clear()
                 gb.push_back_device(words.data_ptr(), n_c * L // 32, start.data_ptr(), ln.data_ptr(), n_c)
@@ -717,18 +729,42 @@ def main():
                 torch.cuda.synchronize()
                 dist.barrier()
                 tc = time.perf_counter()
-                ginfo = smx_dist.sharded_build_graph(eng2, k, T, rank, world, dev)
+                ginfo = smx_dist.sharded_build_graph(eng2, k, T, rank, world, dev, walks=walks)
                 torch.cuda.synchronize()
                 dist.barrier()
                 dtc = time.perf_counter() - tc
+                gb.adopt(ginfo)
+                try:
+                    fps[walks] = gb.fingerprint_portable()
+                except Exception:  # noqa: BLE001 — small graphs keep their link records on the host
+                    fps[walks] = None
+                return ginfo, dtc
+
+            def gathered():
+                ginfo, dtc = one_build("gathered", n_c)
                 if rank == 0:
                     out["construct_sharded"] = {"reads_per_gpu": n_c, "seconds": round(dtc, 3), "M_reads_per_s": round(n_c * world / dtc / 1e6, 2),
                                                 "route": ginfo["route"], "n_kmers": int(ginfo["n_kmers"]), "n_unitigs": int(ginfo["n_unitigs"]),
                                                 "kmers_per_rank": [int(v) for v in ginfo["kmers_per_rank"]]}
-            except Exception as e:  # noqa: BLE001
+
+            def distributed():
+                # the same graph with the k-mer file left sharded (spades_amd.dist.distributed_walks): lookups by
+                # exchange, chains ranked by pointer doubling, only the unitigs gathered
+                # (its node arrays are torch tensors next to an arena that keeps the high-water mark of the 100 M-read steps: a smaller input)
+                n_d = int(min(args.distributed_walks, n_c)) // 32 * 32
+                if n_d != n_c:
+                    one_build("gathered", n_d)  # the graph to compare with
+                ginfo, dtc = one_build("distributed", n_d)
                 if rank == 0:
-                    out["construct_sharded"] = {"error": str(e)[:300]}
-            wd.cancel()
+                    same = fps.get("gathered") is not None and fps.get("gathered") == fps.get("distributed")
+                    out.setdefault("construct_sharded", {})["distributed_walks"] = {
+                        "reads_per_gpu": n_d, "seconds": round(dtc, 3), "M_reads_per_s": round(n_d * world / dtc / 1e6, 2), "doubling_rounds": int(ginfo["walk_rounds"]),
+                        "n_unitigs": int(ginfo["n_unitigs"]), "unitigs_per_rank": [int(v) for v in ginfo["unitigs_per_rank"]],
+                        "graph_identical_to_gathered_build": bool(same) if fps.get("gathered") is not None else None}
+
+            guarded_leg("error", 240, gathered)
+            if args.distributed_walks > 0:
+                guarded_leg("distributed_walks_error", 240, distributed)
     if sharded and rank == 0:
         # the N = 1 default line is another workload (config 3: upload + count + construction); the figure to divide an N-rank value by
         # is this same sharded step on ONE rank, measured with --gpus 1 --force-sharded and committed under profiles/

@@ -51,9 +51,11 @@ int smx_create(smx_ctx **out, int device, size_t hbm_budget_bytes);
  * ~17 ms per GiB; tearing a range down has crashed inside the HIP runtime). At most one arena per device is parked: a context with
  * another budget class, or the next destroy, tears the parked one down. SMX_ARENA_POOL=0 in the environment unmaps at every destroy. */
 void smx_destroy(smx_ctx *ctx);
-/* Gives the free physical memory at the two ends of the context's arena back to the device now (whole 512 MiB chunks), e.g. before
- * another allocator of the same process (a framework's caching allocator) needs the room; *bytes_returned may be NULL. The context
- * stays usable; what it needs again is mapped again. */
+/* Asks the context to give unused device memory back now, e.g. before another allocator of the same process (a framework's caching
+ * allocator) needs the room; *bytes_returned (may be NULL) says how much went. With the default arena (one virtual range, mapped in
+ * 512 MiB chunks) that is currently always 0: releasing chunks and mapping memory again shortly afterwards lost writes on this stack
+ * (arena_trim in smx_ctx.hpp has the measurements), so the arena only grows while its context lives and goes back at smx_destroy; the
+ * hipMalloc fallback (SMX_ARENA=malloc) frees its cached blocks. The context stays usable either way. */
 int smx_trim(smx_ctx *ctx, size_t *bytes_returned);
 const char *smx_last_error(const smx_ctx *ctx);
 const char *smx_version(void);

@@ -421,7 +421,14 @@ void *arena_take(smx_ctx *ctx, size_t bytes, size_t r0, size_t r1, bool descendi
         if (sz > bytes) A.free_blocks[off] = sz - bytes;
     }
     void *p = A.base + at;
-    if (getenv("SMX_ARENA_CHECK")) {  // diagnostics: a block handed out must lie inside mapped chunks
+    if (getenv("SMX_ARENA_CHECK")) {  // diagnostics: a block handed out must not overlap a live one ...
+        for (auto &lb : A.live) {
+            const size_t lo_ = (size_t)((char *)lb.first - A.base), hi_ = lo_ + lb.second;
+            if (lo_ < at + bytes && at < hi_)
+                fprintf(stderr, "[smx] ARENA: block [%zu, %zu) handed out over the live block [%zu, %zu) (lo %zu hi %zu)\n", at, at + bytes, lo_, hi_, A.lo, A.hi);
+        }
+    }
+    if (getenv("SMX_ARENA_CHECK")) {  // ... and must lie inside mapped chunks
         for (size_t ci = at / A.gran; ci <= (at + bytes - 1) / A.gran; ++ci)
             if (ci >= A.chunk.size() || !A.chunk[ci].mapped) {
                 fprintf(stderr, "[smx] ARENA: block [%zu, %zu) handed out over unmapped chunk %zu (lo %zu hi %zu reserved %zu, free block was [%zu, %zu), %s)\n", at,
@@ -431,6 +438,11 @@ void *arena_take(smx_ctx *ctx, size_t bytes, size_t r0, size_t r1, bool descendi
     }
     A.live[p] = bytes;
     ctx->arena_live += bytes;
+    if (const char *pz = getenv("SMX_ARENA_POISON")) {  // diagnostics: no block may be read before it is written — fill it with a byte that breaks what does
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(p, atoi(pz) & 0xFF, bytes);
+        (void)hipDeviceSynchronize();
+    }
     return p;
 }
 // top = long-lived block (top region, highest address first); otherwise a temporary (bottom region, lowest address first).
@@ -518,60 +530,23 @@ void arena_release(smx_ctx *ctx) {
     }
     ctx->arena_free.clear();
 }
-// Give whole free chunks at the two marks back to the device (smx_trim): the temporaries' end shrinks down to its highest live
-// block, the long-lived end up to its lowest one. Returns the bytes unmapped.
+// smx_trim. The VMM arena does NOT give physical memory back while its context lives: unmapping chunks (hipMemUnmap + hipMemRelease)
+// and mapping memory again shortly afterwards — the very next count — lost writes on this stack: kernels ran, their atomics and stores
+// never arrived ("0 super-k-mers", garbage masks; tools/trim_probe.py at 2 M reads, every time; gone under SMX_DEBUG's extra
+// synchronisation; the same with a whole new address range, so it is the physical pages, not the addresses: most likely the
+// driver's deferred clear of released VRAM racing with the next owner). tools/vmm_remap_probe.hip, which lets hipMalloc take the
+// released pages first, sees nothing wrong. Until that window is understood the arena only grows; memory goes back at smx_destroy
+// (parked arenas: at most one per device). The hipMalloc fallback (SMX_ARENA=malloc) frees its cache. Returns the bytes released.
 size_t arena_trim(smx_ctx *ctx) {
     Arena &A = ctx->arena;
-    if (!A.vmm) {
-        size_t freed = 0;
-        for (auto &b : ctx->arena_free) {
-            freed += b.second;
-            ctx->arena_size.erase(b.first);
-            (void)hipFree(b.first);
-        }
-        ctx->arena_free.clear();
-        return freed;
-    }
-    (void)hipDeviceSynchronize();
+    if (A.vmm) return 0;
     size_t freed = 0;
-    for (;;) {  // bottom region: the free block that ends at the mark
-        auto it = A.free_blocks.lower_bound(A.lo);
-        if (it == A.free_blocks.begin()) break;
-        auto pv = std::prev(it);
-        if (pv->first + pv->second != A.lo) break;
-        const size_t keep_to = (pv->first + A.gran - 1) / A.gran * A.gran;  // first chunk boundary inside the free block
-        if (keep_to >= A.lo) break;
-        const size_t off = pv->first, sz = pv->second;
-        A.free_blocks.erase(pv);
-        if (keep_to > off) A.free_blocks[off] = keep_to - off;
-        (void)sz;
-        for (size_t ci = keep_to / A.gran; ci < A.lo / A.gran; ++ci)
-            if (A.chunk[ci].mapped) {
-                (void)hipMemUnmap(A.base + ci * A.gran, A.gran);
-                (void)hipMemRelease(A.chunk[ci].h);
-                A.chunk[ci].mapped = false;
-                freed += A.gran;
-            }
-        A.lo = keep_to;
-        break;
+    for (auto &b : ctx->arena_free) {
+        freed += b.second;
+        ctx->arena_size.erase(b.first);
+        (void)hipFree(b.first);
     }
-    for (;;) {  // top region: the free block that starts at the mark
-        auto it = A.free_blocks.find(A.hi);
-        if (it == A.free_blocks.end()) break;
-        const size_t end = it->first + it->second, keep_from = end / A.gran * A.gran;  // last chunk boundary inside the free block
-        if (keep_from <= A.hi) break;
-        A.free_blocks.erase(it);
-        if (end > keep_from) A.free_blocks[keep_from] = end - keep_from;
-        for (size_t ci = A.hi / A.gran; ci < keep_from / A.gran; ++ci)
-            if (A.chunk[ci].mapped) {
-                (void)hipMemUnmap(A.base + ci * A.gran, A.gran);
-                (void)hipMemRelease(A.chunk[ci].h);
-                A.chunk[ci].mapped = false;
-                freed += A.gran;
-            }
-        A.hi = keep_from;
-        break;
-    }
+    ctx->arena_free.clear();
     return freed;
 }
 // HBM still obtainable for new allocations (bytes): free blocks of the arena + what can still be mapped between its two marks, as

@@ -216,6 +216,7 @@ class GpuEngine:
         recs = torch.empty(max(n * ((k + 31) // 32), 1), dtype=torch.int64, device=dev)
         tags = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
         counts = (C.c_uint64 * world)()
+        _sync(dev)  # the caching allocator may hand out a block that queued torch kernels still read: the library writes from its own stream
         _chk(self.ctx._h, self.ctx.lib.smx_shard_walk_requests(self.ctx._h, 1 if starts else 0, world, recs.data_ptr(),
                                                               C.cast(tags.data_ptr(), C.POINTER(C.c_uint64)), counts))
         return recs, tags[:n], [int(c) for c in counts]
@@ -228,6 +229,7 @@ class GpuEngine:
 
     def shard_lookup(self, recs: torch.Tensor, n: int, dev):
         out = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        _sync(dev)
         _chk(self.ctx._h, self.ctx.lib.smx_shard_lookup(self.ctx._h, recs.data_ptr(), n, C.cast(out.data_ptr(), C.POINTER(C.c_uint64))))
         return out[:n]
 
@@ -235,6 +237,7 @@ class GpuEngine:
         n = local_ranks.numel()
         km = torch.empty(max(n * ((k + 31) // 32), 1), dtype=torch.int64, device=dev)
         mk = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        _sync(dev)
         _chk(self.ctx._h, self.ctx.lib.smx_shard_gather_kmers(self.ctx._h, C.cast(local_ranks.data_ptr(), C.POINTER(C.c_uint64)), n, km.data_ptr(),
                                                              C.cast(mk.data_ptr(), C.POINTER(C.c_uint8))))
         return km, mk
@@ -243,12 +246,14 @@ class GpuEngine:
         """-> this rank's kept unitigs: (packed words, lengths, start nodes, end nodes, self-conjugate flags)"""
         u64 = C.POINTER(C.c_uint64)
         nk, nwd = C.c_uint64(), C.c_uint64()
+        _sync(dev)
         _chk(self.ctx._h, self.ctx.lib.smx_shard_unitigs(self.ctx._h, first_rank, C.cast(steps.data_ptr(), u64), C.cast(last.data_ptr(), u64),
                                                         C.cast(boff.data_ptr(), u64), C.cast(bases.data_ptr(), C.POINTER(C.c_uint8)), C.byref(nk), C.byref(nwd)))
         ne, nwords = nk.value, nwd.value
         words = torch.empty(max(nwords, 1), dtype=torch.int64, device=dev)
         ln, st, en = (torch.empty(max(ne, 1), dtype=torch.int64, device=dev) for _ in range(3))
         sf = torch.empty(max(ne, 1), dtype=torch.uint8, device=dev)
+        _sync(dev)
         _chk(self.ctx._h, self.ctx.lib.smx_shard_unitigs_copy(self.ctx._h, C.cast(words.data_ptr(), u64), C.cast(ln.data_ptr(), u64), C.cast(st.data_ptr(), u64),
                                                              C.cast(en.data_ptr(), u64), C.cast(sf.data_ptr(), C.POINTER(C.c_uint8))))
         return words[:nwords], ln[:ne], st[:ne], en[:ne], sf[:ne]
@@ -407,14 +412,14 @@ def _by_owner(owner: torch.Tensor, world: int):
 
 
 def _remote_rows(targets: torch.Tensor, owner: torch.Tensor, table: torch.Tensor, my_base: int, rank: int, world: int, dev):
-    """table[targets - base of the owner] from the ranks that own them: one all-to-all of the indices, one of the rows (both in the order
-    of the requests, so nothing but the indices and the rows travels). The rows are read before anything comes back: a round of pointer
-    doubling sees the state of the round before on every rank."""
-    w = table.shape[1]
+    """table[:, targets - base of the owner] from the ranks that own them (table: one row per field, one column per local node): one
+    all-to-all of the indices, one of the fields (both in the order of the requests, so nothing but indices and fields travels).
+    -> (len(targets), fields)"""
+    w = table.shape[0]
     order, counts = _by_owner(owner, world)
     q, rcounts = _a2a(targets[order].contiguous(), counts, rank, world, dev)
     nq = sum(rcounts)
-    rows = table[q[:nq] - my_base].reshape(-1).contiguous()
+    rows = table[:, q[:nq] - my_base].t().reshape(-1).contiguous()
     back, _ = _a2a(rows, [c * w for c in rcounts], rank, world, dev)
     out = torch.empty((targets.numel(), w), dtype=table.dtype, device=dev)
     out[order] = back[:targets.numel() * w].reshape(-1, w)
@@ -431,6 +436,17 @@ def _ragged(off: torch.Tensor, ln: torch.Tensor, dev):
     return off[seg] + (torch.arange(tot, device=dev) - start[seg])
 
 
+WALK_CHUNK = 1 << 26       # local nodes per exchange of the doubling / of the chain nucleotides (bounds the temporaries: ~40 B per node)
+WALK_START_CHUNK = 1 << 22  # start de-edges per fetch of their chains
+
+
+def _rounds_of(n_local: int, chunk: int, dev) -> int:
+    """chunks the rank with the most elements needs: every rank runs that many (collective) rounds"""
+    t = torch.tensor([-(-n_local // chunk)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
 def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank):
     """Unitigs of a graph whose k-mer file stays sharded (collective). Every rank holds its bucket range of
     {k-mer file, InOutMask bytes}; a walk of the reference (debruijn_graph_constructor.hpp:264-273) would change rank at every step, so
@@ -438,54 +454,80 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
       1. every oriented non-junction k-mer learns its successor node and whether that is a junction k-mer (ONE lookup exchange: the
          canonical successor k-mer travels to its owner, a node id comes back), every start de-edge its first node (a second one);
       2. the chains of non-junction k-mers are ranked by pointer doubling — per round one exchange of node ids and one of (pointer,
-         distance, last chain k-mer, end node) rows, ceil(log2(longest chain)) rounds; what never finishes lies on perfect loops;
-      3. a chain k-mer x is d(x^1) steps behind the head tail(x^1)^1 of its chain (the reverse strand ran through the same doubling):
-         it sends its outgoing nucleotide there, and the owner of the head lays the chain's nucleotides out in order;
+         hops, last chain k-mer, end node), ceil(log2(longest chain)) rounds at most; what never finishes lies on perfect loops.
+         (Rows may be read in the state of this round or of the one before — a pointer only ever moves ahead along its chain, the
+         hops with it — so the rounds run in chunks of WALK_CHUNK nodes and the temporaries stay bounded.)
+      3. a chain k-mer x is hops(x^1) steps behind the head tail(x^1)^1 of its chain (the reverse strand went through the same
+         doubling): it sends its outgoing nucleotide there, and the owner of the head lays the chain's nucleotides out in order;
       4. the owner of a start de-edge fetches length, end node and nucleotides of the chain behind it and assembles, keeps or drops the
          unitig exactly as the single-GPU route does (engine.shard_unitigs).
     Returns this rank's kept unitigs (k-mer-file order of their start k-mers: concatenated in rank order they are the reference's edge
-    list) and the local ranks of its k-mers on perfect loops."""
+    list), the local ranks of its k-mers on perfect loops, and the number of doubling rounds."""
+    import os
+    import time
     nw = (k + 31) // 32
     first = [0]
     for c in kmers_per_rank:
         first.append(first[-1] + int(c))
     n_mine = int(kmers_per_rank[rank])
     base = 2 * first[rank]
-    first_t = torch.tensor(first[:world], dtype=torch.int64, device=dev)
     bounds = torch.tensor([2 * f for f in first[1:]], dtype=torch.int64, device=dev)
+    t_last = [time.perf_counter()]
+
+    def mark(what):  # SMX_DEBUG: wall time of every phase on rank 0
+        if os.environ.get("SMX_DEBUG") and rank == 0:
+            _sync(dev)
+            now = time.perf_counter()
+            print(f"[dist] walks: {what} {1e3 * (now - t_last[0]):.0f} ms", flush=True)
+            t_last[0] = now
 
     def owner_of(nodes):
         return torch.bucketize(nodes, bounds, right=True)
 
     def lookup(starts: bool):
+        """-> (tags of this rank's requests, node each one leads to, is that a junction k-mer) in the order the library grouped them"""
         recs, tags, counts = _guarded(dev, "successor requests of the shard", engine.walk_requests, starts, k, world, dev)
         recv, rcounts = _a2a(recs, [c * nw for c in counts], rank, world, dev)
+        del recs
         n_recv = sum(rcounts) // nw
         reply = _guarded(dev, "lookup in the shard", engine.shard_lookup, recv, n_recv, dev)
+        del recv
         back, _ = _a2a(reply.contiguous(), [c // nw for c in rcounts], rank, world, dev)
+        del reply
         n = sum(counts)
         back = back[:n]
-        asked = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(counts, dtype=torch.int64, device=dev))
 
         def check():
             if n and bool((back < 0).any().item()):
                 raise RuntimeError(f"{int((back < 0).sum().item())} successor k-mers are in no shard: the k-mer file and the masks disagree")
         _guarded(dev, "successor lookups", check)
-        node = (((back >> 1) + first_t[asked]) << 1) | ((tags >> 2) & 1)
-        return tags, node, (back & 1).to(torch.bool)
+        junc = (back & 1).to(torch.bool)
+        back >>= 1
+        o = 0
+        for p_, c in enumerate(counts):  # local rank at the owner -> global rank
+            back[o:o + c] += first[p_]
+            o += c
+        back <<= 1
+        back |= (tags >> 2) & 1
+        return tags, back, junc
 
-    # 1. successors of the chain k-mers, first nodes of the start de-edges
+    # 1. successors of the chain k-mers, first nodes of the start de-edges. tab: pointer (-1 once the chain end is known), hops to it,
+    #    last chain k-mer, end node — one row each, one column per local oriented node
     n2 = 2 * n_mine
     tags, node, junc = lookup(False)
     xl = tags >> 4
-    succ = torch.full((n2,), -1, dtype=torch.int64, device=dev)
+    tab = torch.empty((4, n2), dtype=torch.int64, device=dev)
     nonj = torch.zeros(n2, dtype=torch.bool, device=dev)
     sj = torch.zeros(n2, dtype=torch.bool, device=dev)
     code = torch.zeros(n2, dtype=torch.uint8, device=dev)
-    succ[xl] = node
+    tab[0].fill_(-1)
+    tab[0][xl] = node
+    del node
     nonj[xl] = True
     sj[xl] = junc
+    del junc
     code[xl] = (tags & 3).to(torch.uint8)
+    del tags, xl
     ctags, cfirst, cjunc = lookup(True)
     n_cand = ctags.numel()
     ci = ctags >> 4
@@ -493,86 +535,138 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     c_fj = torch.empty(n_cand, dtype=torch.bool, device=dev)
     c_first[ci] = cfirst
     c_fj[ci] = cjunc
-    del tags, node, junc, xl, ctags, cfirst, cjunc, ci
-
-    # 2. pointer doubling over the chains. Row of a node: pointer (-1 once the chain end is known), hops to it, last chain k-mer, end node
-    gl = base + torch.arange(n2, dtype=torch.int64, device=dev)
+    del ctags, cfirst, cjunc, ci
     ends_here = nonj & sj
-    table = torch.stack([torch.where(nonj & ~sj, succ, torch.full_like(succ, -1)), (nonj & ~sj).to(torch.int64),
-                         torch.where(ends_here, gl, torch.full_like(gl, -1)), torch.where(ends_here, succ, torch.full_like(succ, -1))], 1).contiguous()
-    del gl, ends_here
+    tab[3].copy_(tab[0])
+    tab[3].masked_fill_(~ends_here, -1)
+    if n2:
+        torch.arange(base, base + n2, dtype=torch.int64, device=dev, out=tab[2])
+    tab[2].masked_fill_(~ends_here, -1)
+    del ends_here
+    open_ = nonj & ~sj
+    tab[0].masked_fill_(~open_, -1)
+    tab[1].copy_(open_)
+    del open_
+
+    mark("successor lookups")
+    # 2. pointer doubling over the chains
+    node_rounds = _rounds_of(n2, WALK_CHUNK, dev)
     prev, rounds = -1, 0
     while True:
-        act = (table[:, 0] >= 0).nonzero().squeeze(1)
-        tot = torch.tensor([act.numel()], dtype=torch.int64, device=dev)
+        tot = (tab[0] >= 0).sum().reshape(1)
         dist.all_reduce(tot)
         tot = int(tot.item())
         if tot == 0 or tot == prev:  # every round ends at least one k-mer of every open chain: what is left runs in circles
             break
         prev = tot
         rounds += 1
-        tg = table[act, 0]
-        rows = _remote_rows(tg, owner_of(tg), table, base, rank, world, dev)
-        fin = rows[:, 0] < 0
-        neg = torch.full_like(rows[:, 0], -1)
-        table[act] = torch.stack([rows[:, 0], table[act, 1] + rows[:, 1], torch.where(fin, rows[:, 2], neg), torch.where(fin, rows[:, 3], neg)], 1)
-    loop_local = torch.unique(act >> 1) if act.numel() else torch.empty(0, dtype=torch.int64, device=dev)
-    done = nonj & (table[:, 0] < 0)
+        mark(f"round {rounds}: {tot} open")
+        for c in range(node_rounds):
+            a, b = min(c * WALK_CHUNK, n2), min((c + 1) * WALK_CHUNK, n2)
+            act = (tab[0, a:b] >= 0).nonzero().squeeze(1) + a
+            tg = tab[0, act]
+            rows = _remote_rows(tg, owner_of(tg), tab, base, rank, world, dev)
+            fin = rows[:, 0] < 0
+            tab[1, act] += rows[:, 1]
+            tab[0, act] = rows[:, 0]
+            tab[2, act] = torch.where(fin, rows[:, 2], -1)
+            tab[3, act] = torch.where(fin, rows[:, 3], -1)
+            del act, tg, rows, fin
+    left = (tab[0] >= 0).nonzero().squeeze(1)
+    loop_local = torch.unique(left >> 1) if left.numel() else torch.empty(0, dtype=torch.int64, device=dev)
+    del left
+    done = nonj & (tab[0] < 0)
+    del nonj
 
+    mark("doubling")
     # 3. every chain k-mer to the head of its chain
-    xs = done.nonzero().squeeze(1)
-    head = table[xs ^ 1, 2] ^ 1
-    payload = (table[xs ^ 1, 1] << 2) | code[xs].to(torch.int64)
-    is_head = done & sj[torch.arange(n2, device=dev) ^ 1] if n2 else done
-    clen = torch.where(is_head, table[:, 1] + 1, torch.zeros_like(table[:, 1]))
+    is_head = done & sj.view(-1, 2).flip(1).reshape(-1)  # the predecessor (the successor of the reverse complement) is a junction k-mer
+    del sj
+    clen = (tab[1] + 1) * is_head
     coff = torch.cumsum(clen, 0) - clen
     total = int(clen.sum().item()) if n2 else 0
-    order, counts = _by_owner(owner_of(head), world)
-    msg = torch.stack([head[order], payload[order]], 1).reshape(-1).contiguous()
-    got, rcounts = _a2a(msg, [2 * c for c in counts], rank, world, dev)
-    n_got = sum(rcounts) // 2
-    got = got[:2 * n_got].reshape(-1, 2)
     bases = torch.zeros(max(total, 1), dtype=torch.uint8, device=dev)
-
-    def place():
-        if n_got != total:
-            raise RuntimeError(f"{n_got} chain nucleotides arrived for chains of {total} k-mers")
+    n_got_all, bad_head = 0, False
+    for c in range(node_rounds):
+        a, b = min(c * WALK_CHUNK, n2), min((c + 1) * WALK_CHUNK, n2)
+        xs = done[a:b].nonzero().squeeze(1) + a
+        xr = xs ^ 1
+        head = tab[2, xr] ^ 1
+        payload = (tab[1, xr] << 2) | code[xs].to(torch.int64)
+        order, counts = _by_owner(owner_of(head), world)
+        msg = torch.stack([head[order], payload[order]], 1).reshape(-1).contiguous()
+        del xs, xr, head, payload, order
+        got, rcounts = _a2a(msg, [2 * c_ for c_ in counts], rank, world, dev)
+        del msg
+        n_got = sum(rcounts) // 2
+        got = got[:2 * n_got].reshape(-1, 2)
         if n_got:
             hl = got[:, 0] - base
-            if not bool(is_head[hl].all().item()):
-                raise RuntimeError("a chain nucleotide arrived at a k-mer that heads no chain")
-            bases[coff[hl] + (got[:, 1] >> 2)] = (got[:, 1] & 3).to(torch.uint8)
-    _guarded(dev, "chain nucleotides at the heads", place)
-    del xs, head, payload, msg, got
+            bad_head = bad_head or not bool(is_head[hl].all().item())
+            pos = coff[hl] + (got[:, 1] >> 2)
+            pos.clamp_(0, max(total, 1) - 1)
+            bases[pos] = (got[:, 1] & 3).to(torch.uint8)
+            del hl, pos
+        n_got_all += n_got
+        del got
 
+    def placed():
+        if bad_head:
+            raise RuntimeError("a chain nucleotide arrived at a k-mer that heads no chain")
+        if n_got_all != total:
+            raise RuntimeError(f"{n_got_all} chain nucleotides arrived for chains of {total} k-mers")
+    _guarded(dev, "chain nucleotides at the heads", placed)
+    del done, code
+
+    mark("chain nucleotides to the heads")
     # 4. the chains behind this rank's start de-edges
     q = (~c_fj).nonzero().squeeze(1)
-    tq = c_first[q]
-    order, counts = _by_owner(owner_of(tq), world)
-    asks, rcounts = _a2a(tq[order].contiguous(), counts, rank, world, dev)
-    n_asks = sum(rcounts)
-    al = asks[:n_asks] - base
-    a_len, a_end, a_off = clen[al], table[al, 3], coff[al]
-    rows, _ = _a2a(torch.stack([a_len, a_end], 1).reshape(-1).contiguous(), [2 * c for c in rcounts], rank, world, dev)
-    seg_of = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(rcounts, dtype=torch.int64, device=dev))
-    per_rank = torch.zeros(world, dtype=torch.int64, device=dev).index_add_(0, seg_of, a_len) if n_asks else torch.zeros(world, dtype=torch.int64, device=dev)
-    flat = bases[_ragged(a_off, a_len, dev)] if n_asks else torch.empty(0, dtype=torch.uint8, device=dev)
-    my_bases, _ = _a2a(flat.contiguous(), [int(c) for c in per_rank.tolist()], rank, world, dev)
-    rows = rows[:2 * q.numel()].reshape(-1, 2)
     steps = torch.zeros(n_cand, dtype=torch.int64, device=dev)
     last = c_first.clone()
     boff = torch.zeros(n_cand + 1, dtype=torch.int64, device=dev)
-    qo = q[order]
-    steps[qo] = rows[:, 0]
-    last[qo] = rows[:, 1]
-    boff[qo] = torch.cumsum(rows[:, 0], 0) - rows[:, 0]
+    pieces, have, headless = [], 0, False
+    for c in range(_rounds_of(q.numel(), WALK_START_CHUNK, dev)):
+        qc = q[c * WALK_START_CHUNK:(c + 1) * WALK_START_CHUNK]
+        tq = c_first[qc]
+        order, counts = _by_owner(owner_of(tq), world)
+        asks, rcounts = _a2a(tq[order].contiguous(), counts, rank, world, dev)
+        n_asks = sum(rcounts)
+        al = asks[:n_asks] - base
+        a_len, a_end, a_off = clen[al], tab[3, al], coff[al]
+        rows, _ = _a2a(torch.stack([a_len, a_end], 1).reshape(-1).contiguous(), [2 * c_ for c_ in rcounts], rank, world, dev)
+        seg_of = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(rcounts, dtype=torch.int64, device=dev))
+        per_rank = torch.zeros(world, dtype=torch.int64, device=dev)
+        if n_asks:
+            per_rank.index_add_(0, seg_of, a_len)
+        flat = bases[_ragged(a_off, a_len, dev)] if n_asks else torch.empty(0, dtype=torch.uint8, device=dev)
+        mine, rc2 = _a2a(flat.contiguous(), [int(v) for v in per_rank.tolist()], rank, world, dev)
+        rows = rows[:2 * qc.numel()].reshape(-1, 2)
+        qo = qc[order]
+        steps[qo] = rows[:, 0]
+        last[qo] = rows[:, 1]
+        boff[qo] = have + torch.cumsum(rows[:, 0], 0) - rows[:, 0]
+        headless = headless or (qc.numel() > 0 and bool((rows[:, 0] <= 0).any().item()))
+        pieces.append(mine[:sum(rc2)])
+        have += sum(rc2)
+        del asks, al, a_len, a_end, a_off, rows, flat, mine
 
     def check_chains():
-        if q.numel() and bool((rows[:, 0] <= 0).any().item()):
+        if headless:
             raise RuntimeError("a start de-edge leads to a k-mer that heads no chain")
     _guarded(dev, "chains behind the start de-edges", check_chains)
+    my_bases = torch.cat(pieces) if len(pieces) > 1 else (pieces[0] if pieces else torch.zeros(1, dtype=torch.uint8, device=dev))
+    if my_bases.numel() == 0:
+        my_bases = torch.zeros(1, dtype=torch.uint8, device=dev)
+    del tab, clen, coff, bases, pieces
+    # (no torch.cuda.empty_cache() here: VRAM that one allocator has just released is not safe for the next one to take at once on this
+    # stack — arena_trim in csrc/smx_ctx.hpp has the measurements)
     _sync(dev)
+    mark("chains of the start de-edges")
+    if os.environ.get("SMX_DEBUG") and n_cand:
+        print(f"[dist] walks: rank {rank}: {n_cand} start de-edges, steps max {int(steps.max().item())} sum {int(steps.sum().item())}, "
+              f"{my_bases.numel()} nucleotides fetched", flush=True)
     unitigs = _guarded(dev, "unitigs of the shard", engine.shard_unitigs, first[rank], steps, last, boff, my_bases, dev)
+    mark("unitigs")
     return unitigs, loop_local, rounds
 
 
@@ -670,8 +764,6 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
         _all_gather(every2, me2)
         every2 = [e.tolist() for e in every2]
         ne_r, nwd_r, nl_r = ([int(e[i]) for e in every2] for i in range(3))
-        if hasattr(engine, "trim"):
-            engine.trim()
         g_words = _gather_shards(engine, u_words, u_words.numel(), nwd_r, 1, rank, world, dev, engine.alloc)
         g_len = _gather_shards(engine, u_len, u_len.numel(), ne_r, 1, rank, world, dev, engine.alloc)
         g_st = _gather_shards(engine, u_st, u_st.numel(), ne_r, 1, rank, world, dev, engine.alloc)
@@ -699,7 +791,7 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
 
     def my_shard():
         if hasattr(engine, "trim"):
-            engine.trim()  # the library's arena gives its free physical memory back before torch allocates the gathered structure
+            engine.trim()  # (a no-op with the default arena: smx_trim in include/smx.h)
         a, b = engine.alloc(n_kmers * nw, dev), engine.alloc_bytes(n_kmers, dev)
         engine.shard_copy(a, b)
         return a, b

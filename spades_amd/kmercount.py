@@ -56,7 +56,7 @@ class Context:
         _chk(self._h, self.lib.smx_graph_clear(self._h))
 
     def trim(self) -> int:
-        """smx_trim: free physical memory at the ends of the context's device arena goes back to the device; returns the bytes"""
+        """smx_trim: unused device memory back to the device; returns the bytes (0 with the default arena: it only grows, include/smx.h)"""
         n = C.c_size_t()
         _chk(self._h, self.lib.smx_trim(self._h, C.byref(n)))
         return int(n.value)

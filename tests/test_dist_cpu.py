@@ -557,6 +557,8 @@ def _walk_worker(rank, world, port, k, threads, q, reads_file, nreads, coverage,
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from spades_amd import dist as smx_dist
     smx_dist.XCHG_LIMIT = limit
+    if limit < 1000:  # several chunks per doubling round / per fetch of the chains, uneven over the ranks
+        smx_dist.WALK_CHUNK, smx_dist.WALK_START_CHUNK = 97, 13
     reads = read_lines(reads_file)[:nreads]
     eng = OracleWalkEngine(reads[rank::world], reads)
     eng.nb = 10 * threads

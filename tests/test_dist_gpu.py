@@ -332,6 +332,8 @@ def _dwalk_rank(rank, world, port, k, t, seed, n_reads, genome, coverage, outdir
         reads = [lut[c].tobytes().decode() for c in codes[rank::world]]
         gb = GraphBuilder(k, t)
         gb.push_back_reads(reads)
+        if k == 21:  # several chunks per doubling round and per fetch of the chains
+            smx_dist.WALK_CHUNK, smx_dist.WALK_START_CHUNK = 1 << 14, 1 << 10
         info = smx_dist.sharded_build_graph(smx_dist.GpuEngine(gb.ctx, "B"), k, t, rank, world, dev, coverage=coverage, walks="distributed")
         gb.adopt(info)
         gb.write_gfa(os.path.join(outdir, f"rank{rank}.gfa"))
