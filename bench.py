@@ -595,7 +595,7 @@ def main():
         if pm_route:   # k_pm_tab: the successor of every node with a unique extension, looked up inside its own chunk first; + jump words
             fm = stages.get("pm_tab", 0.0)
             b_fill = D0 * (W + 1) + 2 * D0 * W + 2 * D0 * 8 + 2 * D0 * 4
-            dname, dkey = "smx::k_pm_tab", "smx::k_pm_tab<2>"
+            dname, dkey = "smx::k_pm_tab", "smx::k_pm_tab"  # (not a template any more)
         elif ext_route:  # k_tab_from_masks: the successor of every node with a unique extension, one rank lookup each
             fm = stages.get("succ", 0.0)
             b_fill = D0 * (W + 1) + 2 * D0 * W + 2 * D0 * 8
