@@ -684,7 +684,8 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
     Then, either way:
       4. the compact structure {k-mer file, masks} (bucket-major, so rank order IS file order) is gathered and every rank derives the
          same unitigs and link records from it (unitig walks cross owners at every step).
-    walks = "distributed" replaces step 4 for graphs whose gathered structure does not fit one GPU: the k-mer file stays sharded, the
+    walks = "distributed" ("auto": when the gathered structure would take more than two thirds of some rank's free HBM) replaces step 4 for
+    graphs whose gathered structure does not fit one GPU: the k-mer file stays sharded, the
     unitigs come out of distributed_walks() (lookup exchanges + pointer doubling), and only the UNITIGS (2 bits per nucleotide + 25 B per
     unitig, a few % of the k-mer file) and the k-mers of perfect loops are gathered; every rank then derives link records and vertices
     from them (engine.build_graph_from_unitigs). The graph is the same, bit for bit; it has no k-mer file on any rank.
@@ -752,6 +753,16 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
             raise RuntimeError(f"the masks ({n_kpo_all} (k+1)-mers) and the (k+1)-mer count ({sum(kpo_per_rank)}) disagree")
     else:
         n_kpo_all = sum(kpo_per_rank)
+    if walks == "auto":
+        # the gathered structure costs every rank 8 * words + 1 B per k-mer of the WHOLE graph twice over (torch's gathered copy + the
+        # library's), its successor table 16 B more: distributed walks as soon as that leaves some rank less than a third of its free HBM
+        need = sum(kmers_per_rank) * (2 * (8 * nw + 1) + 16)
+        short = 0
+        if dev.type == "cuda":
+            short = 1 if need > (2 * torch.cuda.mem_get_info(dev)[0]) // 3 else 0
+        t_short = torch.tensor([short], dtype=torch.int64, device=dev)
+        dist.all_reduce(t_short, op=dist.ReduceOp.MAX)
+        walks = "distributed" if int(t_short.item()) else "gathered"
     if walks == "distributed":
         nwk = (k + 31) // 32
         (u_words, u_len, u_st, u_en, u_sf), loop_local, rounds = distributed_walks(engine, k, rank, world, dev, kmers_per_rank)
@@ -785,7 +796,7 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
         info["unitigs_per_rank"] = ne_r
         del g_words, g_len, g_st, g_en, g_sf
     elif walks != "gathered":
-        raise ValueError(f"walks = {walks!r}: 'gathered' or 'distributed'")
+        raise ValueError(f"walks = {walks!r}: 'gathered', 'distributed' or 'auto'")
     else:
         info = None
 

@@ -265,8 +265,8 @@ def _graph_worker(rank, world, port, k, threads, q, route="kpomers", coverage=Tr
     smx_dist.XCHG_LIMIT = 700  # several broadcast rounds per owner
     reads = read_lines("reads_small.txt")[:120]
     eng = OracleGraphEngine(reads[rank::world], reads)
-    info = smx_dist.sharded_build_graph(eng, k, threads, rank, world, torch.device("cpu"), coverage=coverage, route=route)
-    assert info["route"] == route
+    info = smx_dist.sharded_build_graph(eng, k, threads, rank, world, torch.device("cpu"), coverage=coverage, route=route, walks="auto" if route == "ext" else "gathered")
+    assert info["route"] == route and info["walks"] == "gathered"  # ("auto" has room for the gathered structure here)
     q.put((rank, eng.gathered.tobytes() if coverage else b"", eng.cov.tobytes() if coverage else b"", info["kpomers_per_rank"], eng.g["gfa"],
            len(eng.result) if hasattr(eng, "result") else 0, eng.shard_updates_seen, info["kmers_per_rank"], getattr(eng, "ext_sent", 0)))
     dist.barrier()
