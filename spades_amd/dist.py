@@ -406,9 +406,11 @@ def _sync(dev):
 
 
 def _by_owner(owner: torch.Tensor, world: int):
-    """-> (stable order that groups by owner, elements per owner)"""
-    order = torch.argsort(owner, stable=True)
-    return order, [int(c) for c in torch.bincount(owner, minlength=world).tolist()]
+    """-> (stable order that groups by owner, elements per owner). The keys are ranks: sorted as 16-bit integers (two radix passes
+    instead of the eight of an int64 sort), counted from the sorted keys."""
+    skey, order = torch.sort(owner.to(torch.int16), stable=True)
+    edges = torch.searchsorted(skey, torch.arange(world + 1, dtype=torch.int16, device=owner.device))
+    return order, [int(c) for c in (edges[1:] - edges[:-1]).tolist()]
 
 
 def _remote_rows(targets: torch.Tensor, owner: torch.Tensor, table: torch.Tensor, my_base: int, rank: int, world: int, dev):
