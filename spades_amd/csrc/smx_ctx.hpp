@@ -114,6 +114,7 @@ struct smx_ctx {
     int64_t opt_prededupe = -1;  // super-k-mer pre-deduplication: -1 auto, 0 off, 1 on whenever K allows it
     int64_t opt_skm_cap = 0;     // instances per LDS dedupe chunk (0 = default)
     int64_t opt_skm_scap = 0;    // slots staged per chunk (0 = default)
+    int64_t opt_skm_fold = 1;    // identical super-k-mers are folded by the chunk plan before they are expanded (0: tests)
     int64_t opt_leaf_grid = 0, opt_leaf_tab = 0;  // tuning experiments (tools/sweep.py)  // spades-core construction variant (debruijn_graph_constructor.hpp:590-604)
     // timings
     std::vector<Timing> timings;

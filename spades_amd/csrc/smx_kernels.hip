@@ -666,13 +666,24 @@ __device__ __forceinline__ uint32_t frac_digit(const Rec<NW> &x, unsigned K, con
     return (uint32_t)__umul64hi(f, (uint64_t)S);
 }
 
+// 32-bit hash of a record for the on-chip hash tables (LDS dedupe sets, and the chunk tables of the "pm" route that are probed again
+// in HBM: every user must see the same function). The 32-bit halves are folded by XOR under odd rotations, then murmur3's fmix32: two
+// v_mul_lo_u32 per record — the round-3 form (three 64-bit multiplies = nine quarter-rate multiplies) was a quarter of the dedupe
+// kernel's VALU time. A colliding pair only costs a probe: every table compares the records themselves.
 template <int NW>
 __device__ __forceinline__ uint32_t rec_hash32(const Rec<NW> &x) {
-    uint64_t h = x.w[0] * 0x9E3779B97F4A7C15ull;
+    uint32_t h = 0;
 #pragma unroll
-    for (int w = 1; w < NW; ++w) h = (h ^ (h >> 29)) * 0xBF58476D1CE4E5B9ull + x.w[w] * 0x94D049BB133111EBull;
-    h ^= h >> 32;
-    return (uint32_t)h;
+    for (int w = 0; w < NW; ++w) {
+        const uint32_t lo = (uint32_t)x.w[w], hi = (uint32_t)(x.w[w] >> 32);
+        h ^= __builtin_rotateleft32(lo, (7 * w) & 31) ^ __builtin_rotateleft32(hi, (7 * w + 13) & 31);
+    }
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
 }
 
 template <int NW, int LPT>

@@ -526,9 +526,9 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     if (int rc = dalloc(ctx, &cnt, SKM_NKEY)) return rc;
     if (int rc = dalloc(ctx, &soff, SKM_NKEY + 1)) return rc;
     if (int rc = dalloc(ctx, &cursor, SKM_NKEY)) return rc;
-    if (int rc = dalloc(ctx, &ocount, 2)) return rc;
+    if (int rc = dalloc(ctx, &ocount, 4)) return rc;
     HIPCHK(hipMemsetAsync(cnt, 0, (size_t)SKM_NKEY * 8, ctx->stream));
-    HIPCHK(hipMemsetAsync(ocount, 0, 16, ctx->stream));
+    HIPCHK(hipMemsetAsync(ocount, 0, 32, ctx->stream));
     SkmArgs a{};
     a.K = K;
     a.m = skm_m(K);
@@ -592,6 +592,10 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     if (int rc = pass(0)) return rc;
     tend(ctx);
     tbegin(ctx, "skm_scan");
+    uint32_t *kseg;  // segments per partition (counted with the slots: upper bits of the counters)
+    if (int rc = dalloc(ctx, &kseg, SKM_NKEY)) return rc;
+    hipLaunchKernelGGL(k_skm_split, dim3(2048), dim3(BLK), 0, ctx->stream, cnt, kseg, SKM_NKEY);
+    HIPCHK(hipGetLastError());
     if (int rc = scan_u64(ctx, cnt, soff, SKM_NKEY)) return rc;
     unsigned long long nslots = 0, st[2] = {0, 1};
     HIPCHK(hipMemcpyAsync(&nslots, soff + SKM_NKEY, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -669,46 +673,19 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
                     typical_slots, typical_inst, hs[0] ? 100.0 * hs[2] / hs[0] : 0.0, hs[0] ? 100.0 * hs[3] / hs[0] : 0.0, hs[0] ? 100.0 * hs[4] / hs[0] : 0.0, cap);
         (void)ips;
     }
-    const uint32_t T = 2 * cap;
-    const uint32_t scap = std::min<uint32_t>(SKM_SCAP, ctx->opt_skm_scap > 0 ? (uint32_t)ctx->opt_skm_scap : cap / 8);  // ~12+ windows per slot on average
-    const size_t lds = (size_t)scap * SW * 8 + (size_t)T * 4 + 514 * 4 + (size_t)cap * 4 + 512 + 512 + 16;
+    // Geometry of the dedupe kernel (smx_skm_dedupe.hip): a workgroup of NT threads = NT segments of <= SEG instances per chunk, hash
+    // table of 16 * NT slots, at most scap super-k-mer slots staged.
+    constexpr uint32_t SEG = (uint32_t)SkmSeg<NW>::value;
+    const uint32_t want = cap / SEG;  // segments per chunk
+    const uint32_t NT = want <= 64 ? 64 : want <= 256 ? 256 : want <= 512 ? 512 : 1024;
+    const uint32_t maxseg = std::min<uint32_t>(std::max<uint32_t>(want, 32), NT);
+    const uint32_t T = 16 * NT;
+    const uint32_t scap = std::min<uint32_t>(std::min<uint32_t>(SKM_SCAP, NT), ctx->opt_skm_scap > 0 ? (uint32_t)ctx->opt_skm_scap : SKM_SCAP);
+    const size_t lds = (size_t)scap * SW * 8 + (size_t)T * 4 + (size_t)NT * 4 + (size_t)NT * 4 + 2 * (size_t)scap + 48;
     const bool ext = ctx->ext_mode;  // the survivors carry their extension byte (EXT layout)
     const bool pmode = ext && ctx->pm.active;  // ... and leave in partition-major order with their side arrays (smx_pm.hpp)
     if (ext && !ext_layout_fits(K, NW)) return fail(ctx, SMX_INVALID_PARAMETER, "K=%u leaves no room for the extension byte", K);
-    if (int rc = pmode ? set_lds(ctx, k_skm_dedupe<NW, 2>, lds) : ext ? set_lds(ctx, k_skm_dedupe<NW, 1>, lds) : set_lds(ctx, k_skm_dedupe<NW, 0>, lds)) return rc;
     const uint32_t nitems = SKM_NKEY / SKM_KEYS_PER_ITEM;
-    PmOut pmo{};
-    if (pmode) {
-        PmState &P = ctx->pm;
-        // chunks: a chunk that is not the last of its item holds more than half the capacity unless a key boundary cut it short
-        const uint64_t mc = 3 * nwin / cap + 2 * (uint64_t)nitems + 1024;
-        if (mc >= (1ull << 24) || out_cap >= PM_BASE_MASK) return SMX_ROUTE_NA;  // beyond the packed (base, chunk) words
-        P.max_chunks = (uint32_t)mc;
-        P.T = T;
-        P.nkey = SKM_NKEY;
-        P.m = a.m;
-        P.w = a.w;
-        P.pshift = a.pshift;
-        if (int rc = dalloc(ctx, &P.pinfo, SKM_NKEY, false)) return rc;
-        if (int rc = dalloc(ctx, &P.meta, (size_t)P.max_chunks * (T >> 4), false)) return rc;
-        if (int rc = dalloc(ctx, &P.cinfo, P.max_chunks, false)) return rc;
-        if (int rc = dalloc(ctx, &P.mask, out_cap + 16, false)) return rc;
-        if (int rc = dalloc(ctx, &P.overflow, 1, false)) return rc;
-        if (int rc = dalloc(ctx, &P.llink, out_cap + 16, false)) return rc;
-        if (int rc = dalloc(ctx, &P.pals, 1, false)) return rc;
-        HIPCHK(hipMemsetAsync(P.pinfo, 0xFF, (size_t)SKM_NKEY * 8, ctx->stream));
-        HIPCHK(hipMemsetAsync(P.llink, 0xFF, (size_t)(out_cap + 16) * 4, ctx->stream));
-        HIPCHK(hipMemsetAsync(P.pals, 0, 8, ctx->stream));
-        HIPCHK(hipMemsetAsync(P.overflow, 0, 4, ctx->stream));
-        pmo.pinfo = P.pinfo;
-        pmo.meta = P.meta;
-        pmo.cinfo = P.cinfo;
-        pmo.mask = P.mask;
-        pmo.llink = P.llink;
-        pmo.pals = P.pals;
-        pmo.max_chunks = P.max_chunks;
-        pmo.overflow = P.overflow;
-    }
     unsigned long long *prof = nullptr;
     if (getenv("SMX_DEBUG")) {
         if (int rc = dalloc(ctx, &prof, 8)) return rc;
@@ -757,36 +734,112 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         }
     }
     if (getenv("SMX_DEBUG") && nbig) fprintf(stderr, "[smx] prededupe: %llu partitions of more than %llu slots -> %u pieces in a launch of their own\n", nbig, BIG_THR, nvirt);
+    // the chunk plan (k_skm_plan): identical super-k-mers folded, one list for the items and the pieces of oversized partitions
+    SkmChunk *clist = nullptr;
+    uint32_t nlist = 0;
+    unsigned long long nclean_chunks = 0;
+    PmOut pmo{};
+    if (pmode) {  // the partition table first: the plan marks the partitions it cuts
+        if (int rc = dalloc(ctx, &ctx->pm.pinfo, SKM_NKEY, false)) return rc;
+        HIPCHK(hipMemsetAsync(ctx->pm.pinfo, 0xFF, (size_t)SKM_NKEY * 8, ctx->stream));
+    }
+    {
+        tbegin(ctx, "skm_plan");
+        const uint64_t segs = nwin / SEG + nslots;  // upper bound of the segments
+        const uint64_t plan_grid = std::min<uint64_t>(nitems, 256 * 8);
+        const uint64_t list_cap = 3 * (segs / std::max<uint32_t>(maxseg - std::min<uint32_t>(maxseg - 1, 32), 1)) + 3 * (nslots / scap) + 2 * (uint64_t)nitems + 2 * (uint64_t)nvirt +
+                                  (plan_grid + nvirt + 2) * SKM_PLAN_BLOCK + 1024;
+        if (list_cap >= (1ull << 32)) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication: %llu chunks planned for", (unsigned long long)list_cap);
+        unsigned long long *lalloc;
+        if (int rc = dalloc(ctx, &clist, list_cap)) return rc;
+        if (int rc = dalloc(ctx, &lalloc, 4)) return rc;
+        HIPCHK(hipMemsetAsync(clist, 0, (size_t)list_cap * sizeof(SkmChunk), ctx->stream));
+        HIPCHK(hipMemsetAsync(lalloc, 0, 32, ctx->stream));
+        for (int pass = 0; pass < (nvirt ? 2 : 1); ++pass) {
+            const unsigned long long *offs = pass ? (const unsigned long long *)voff : (const unsigned long long *)soff;
+            const uint32_t ni = pass ? nvirt : nitems, stride = pass ? SKM_KEYS_PER_ITEM + 1 : SKM_KEYS_PER_ITEM;
+            hipLaunchKernelGGL((k_skm_plan<NW>), dim3(std::min<uint32_t>(ni, 256 * 8)), dim3(BLK), 0, ctx->stream, slots, offs,
+                               pass ? (const uint32_t *)nullptr : (const uint32_t *)kseg, ctx->opt_skm_fold ? 1u : 0u, ni, stride,
+                               pass ? 1u : 0u, pass ? ~0ull : skip_slots, maxseg, scap, clist, lalloc, (unsigned long long)list_cap,
+                               pmode && !pass ? ctx->pm.pinfo : (unsigned long long *)nullptr);
+            HIPCHK(hipGetLastError());
+        }
+        unsigned long long la[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(la, lalloc, 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        tend(ctx);
+        if (la[2] || la[0] > list_cap) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication: the chunk plan outgrew its list (%llu entries)", (unsigned long long)list_cap);
+        nlist = (uint32_t)la[0];
+        nclean_chunks = la[1];
+        if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] prededupe: %llu instances in folded (identical) super-k-mers, %u list entries, %llu clean chunks\n", la[3], nlist, nclean_chunks);
+    }
+    if (pmode) {
+        PmState &P = ctx->pm;
+        // chunks: a chunk that is not the last of its item holds more than half the capacity unless a key boundary cut it short
+        const uint64_t mc = nclean_chunks + 1;  // (the plan counted the clean chunks)
+        if (mc >= (1ull << 24) || out_cap >= PM_BASE_MASK) return SMX_ROUTE_NA;  // beyond the packed (base, chunk) words
+        P.max_chunks = (uint32_t)mc;
+        P.T = T;
+        P.nkey = SKM_NKEY;
+        P.m = a.m;
+        P.w = a.w;
+        P.pshift = a.pshift;
+        if (int rc = dalloc(ctx, &P.meta, (size_t)P.max_chunks * (T >> 4), false)) return rc;
+        if (int rc = dalloc(ctx, &P.cinfo, P.max_chunks, false)) return rc;
+        if (int rc = dalloc(ctx, &P.mask, out_cap + 16, false)) return rc;
+        if (int rc = dalloc(ctx, &P.overflow, 1, false)) return rc;
+        if (int rc = dalloc(ctx, &P.llink, out_cap + 16, false)) return rc;
+        if (int rc = dalloc(ctx, &P.pals, 1, false)) return rc;
+        HIPCHK(hipMemsetAsync(P.llink, 0xFF, (size_t)(out_cap + 16) * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(P.pals, 0, 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(P.overflow, 0, 4, ctx->stream));
+        pmo.pinfo = P.pinfo;
+        pmo.meta = P.meta;
+        pmo.cinfo = P.cinfo;
+        pmo.mask = P.mask;
+        pmo.llink = P.llink;
+        pmo.pals = P.pals;
+        pmo.max_chunks = P.max_chunks;
+        pmo.overflow = P.overflow;
+    }
     tbegin(ctx, "skm_dedupe");
-    for (int pass = 0; pass < (nvirt ? 2 : 1); ++pass) {
-        const unsigned long long *offs = pass ? (const unsigned long long *)voff : (const unsigned long long *)soff;
-        const uint32_t ni = pass ? nvirt : nitems, stride = pass ? SKM_KEYS_PER_ITEM + 1 : SKM_KEYS_PER_ITEM, force = pass ? 1u : 0u;
-        const unsigned long long skip = pass ? ~0ull : skip_slots;
-        const dim3 grid(std::min<uint32_t>(ni, 256 * 8));
-        if (pmode)
-            hipLaunchKernelGGL((k_skm_dedupe<NW, 2>), grid, dim3(BLK), lds, ctx->stream, (const uint64_t *)slots, offs, K, ni, cap, T, scap, (void *)*out,
-                               (unsigned long long)out_cap, (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo, skip, force, stride);
-        else if (ext)
-            hipLaunchKernelGGL((k_skm_dedupe<NW, 1>), grid, dim3(BLK), lds, ctx->stream, (const uint64_t *)slots, offs, K, ni, cap, T, scap, (void *)*out,
-                               (unsigned long long)out_cap, (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo, skip, force, stride);
-        else
-            hipLaunchKernelGGL((k_skm_dedupe<NW, 0>), grid, dim3(BLK), lds, ctx->stream, (const uint64_t *)slots, offs, K, ni, cap, T, scap, (void *)*out,
-                               (unsigned long long)out_cap, (unsigned long long)clean_cap, (unsigned long long)dirty_cap, ocount, ocount + 1, prof, pmo, skip, force, stride);
+    if (nlist) {
+        const dim3 grid(std::min<uint32_t>(nlist, 256 * 16));
+        int rc2 = 0;
+        auto go = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            auto launch = [&](auto nt_tag) {
+                constexpr int NTC = decltype(nt_tag)::value;
+                if ((rc2 = set_lds(ctx, k_skm_dedupe2<NW, MODE, NTC>, lds))) return;
+                hipLaunchKernelGGL((k_skm_dedupe2<NW, MODE, NTC>), grid, dim3(NTC), lds, ctx->stream, (const uint64_t *)slots, (const unsigned long long *)soff, K,
+                                   (const SkmChunk *)clist, nlist, scap, (void *)*out, (unsigned long long)out_cap, (unsigned long long)clean_cap,
+                                   (unsigned long long)dirty_cap, ocount, ocount + 1, ocount + 2, prof, pmo);
+            };
+            if (NT == 64) launch(std::integral_constant<int, 64>{});
+            else if (NT == 256) launch(std::integral_constant<int, 256>{});
+            else if (NT == 512) launch(std::integral_constant<int, 512>{});
+            else launch(std::integral_constant<int, 1024>{});
+        };
+        if (pmode) go(std::integral_constant<int, 2>{});
+        else if (ext) go(std::integral_constant<int, 1>{});
+        else go(std::integral_constant<int, 0>{});
+        if (rc2) return rc2;
         HIPCHK(hipGetLastError());
     }
     tend(ctx);
     if (prof) {
-        unsigned long long hp[6];
-        HIPCHK(hipMemcpy(hp, prof, 48, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[smx] dedupe chunks=%llu slots/chunk=%.1f; 100MHz ticks per chunk: stage+clear %.1f, scan+plan %.1f, insert %.1f, output %.1f\n",
+        unsigned long long hp[7];
+        HIPCHK(hipMemcpy(hp, prof, 56, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[smx] dedupe chunks=%llu slots/chunk=%.1f; 100MHz ticks per chunk: stage + segment list %.1f, insert %.1f, occupancy + allocation %.1f, output + links %.1f\n",
                 hp[4], hp[4] ? (double)hp[5] / hp[4] : 0.0, hp[4] ? (double)hp[0] / hp[4] : 0.0, hp[4] ? (double)hp[1] / hp[4] : 0.0,
                 hp[4] ? (double)hp[2] / hp[4] : 0.0, hp[4] ? (double)hp[3] / hp[4] : 0.0);
     }
-    unsigned long long nn[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(nn, ocount, 16, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long nn[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(nn, ocount, 24, hipMemcpyDeviceToHost, ctx->stream));
     uint32_t pm_over = 0;
     if (pmode) HIPCHK(hipMemcpyAsync(&pm_over, ctx->pm.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (nn[2]) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication: the chunk plan disagrees with the super-k-mer slots");
     if (pmode) {  // the clean counter carries the number of chunks in its upper bits
         ctx->pm.nchunks = (uint32_t)(nn[0] >> PM_BASE_BITS);
         nn[0] &= PM_BASE_MASK;

@@ -4,11 +4,11 @@
 // kmer_index/kmer_mph/kmer_splitter.hpp:55-179): I records of W bytes. On the GPU that stream is the HBM traffic of
 // every MSD level. This stage removes most duplicates BEFORE anything of size I*W exists:
 //   1. k_skm_scan   cut the valid windows of the 2-bit read stream into super-k-mers (maximal runs of consecutive
-//                   windows sharing their canonical minimizer, m = 11) and counting-sort them by minimizer key into
+//                   windows sharing their canonical minimizer, m = 16) and counting-sort them by minimizer key into
 //                   fixed slots of 2*NW words (<= 2K-m nucleotides + a count byte): ~1.3 bytes per instance;
-//   2. k_skm_dedupe a workgroup expands a few thousand instances of consecutive minimizer keys inside LDS, keeps one
-//                   canonical copy of each k-mer (exact hash set keyed by (slot, offset) references) and appends the
-//                   survivors to a record array in HBM.
+//   2. k_skm_plan / k_skm_dedupe2 (smx_skm_dedupe.hip)  identical slots are folded, the slots of consecutive minimizer keys are cut
+//                   into chunks, and a workgroup expands a chunk of a few thousand instances inside LDS, keeps one canonical copy
+//                   of each k-mer (exact hash set keyed by (slot, offset) references) and appends the survivors to a record array.
 // All copies of a k-mer (either strand) share their canonical minimizer, hence their key, hence — unless the key is
 // cut by the LDS capacity — their workgroup. The stage is only a FILTER: the sort/unique pipeline that follows is
 // exact on any multiset, so duplicates that survive a cut cost time, never correctness, and the survivors' order
@@ -31,6 +31,18 @@ constexpr int SKM_TP = SKM_TC - 128;                  // windows a tile emits st
 constexpr uint32_t SKM_SCAP = 512;                    // most slots staged per dedupe chunk (two per thread in the prefix scan)
 constexpr uint32_t SKM_KEYS_PER_ITEM = 256;
 constexpr unsigned SKM_DIRTY_BUCKETS = 1024;          // hash buckets of the sort of the survivors of cut partitions
+// Round-4 dedupe kernel (smx_skm_dedupe.hip): a thread works through a SEGMENT of up to SEG consecutive instances of one super-k-mer.
+// The counting pass of the scan also counts the segments of every partition (upper 24 bits of its 64-bit counter: the chunk plan
+// needs them and would otherwise read every slot once more).
+#ifndef SMX_SEG_OVERRIDE
+#define SMX_SEG_OVERRIDE 0
+#endif
+template <int NW>
+struct SkmSeg {
+    static constexpr int value = SMX_SEG_OVERRIDE ? SMX_SEG_OVERRIDE : (NW <= 2 ? 8 : 4);  // (registers: SEG k-mers of NW words in flight per thread)
+};
+constexpr unsigned SKM_CNT_BITS = 40;  // cnt[key]: slots in the low 40 bits, segments above
+constexpr unsigned long long SKM_CNT_MASK = (1ull << SKM_CNT_BITS) - 1;
 
 struct SkmArgs {
     const uint64_t *seq;
@@ -294,6 +306,7 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
                 // ~88 atomics per microsecond (measured: +150 ms at 1 % low-complexity sequence). Up to three peels: the lanes that hold
                 // the key of the first remaining lane add up in one atomic and number themselves.
                 unsigned long long rank = 0;
+                const uint32_t nsg = (c + SkmSeg<NW>::value - 1) / SkmSeg<NW>::value;  // segments of this super-k-mer (<= 29: 5 bits)
                 {
                     unsigned long long todo = __ballot(1);
                     bool mine = true;
@@ -304,16 +317,19 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
                         const uint32_t k0 = (uint32_t)__shfl((int)key, lead, 64);
                         const bool hit = mine && key == k0;
                         const unsigned long long same = __ballot(hit) & todo;
+                        unsigned long long segs = 0;  // segments of the lanes in `same` (ballots: only the active lanes count)
+#pragma unroll
+                        for (int b = 0; b < 5; ++b) segs += (unsigned long long)__popcll(__ballot(hit && ((nsg >> b) & 1u)) & same) << b;
                         unsigned long long base = 0;
-                        if ((int)(threadIdx.x & 63) == lead) base = atomicAdd(&a.cnt[k0], (unsigned long long)__popcll(same));
+                        if ((int)(threadIdx.x & 63) == lead) base = atomicAdd(&a.cnt[k0], (unsigned long long)__popcll(same) | (segs << SKM_CNT_BITS));
                         base = __shfl(base, lead, 64);  // (every active lane takes part: no shuffle inside a divergent branch)
                         if (hit) {
-                            rank = base + __popcll(same & ((1ull << (threadIdx.x & 63)) - 1));
+                            rank = (base & SKM_CNT_MASK) + __popcll(same & ((1ull << (threadIdx.x & 63)) - 1));
                             mine = false;
                         }
                         todo &= ~same;
                     }
-                    if (mine) rank = atomicAdd(&a.cnt[key], 1ull);
+                    if (mine) rank = atomicAdd(&a.cnt[key], 1ull | ((unsigned long long)nsg << SKM_CNT_BITS)) & SKM_CNT_MASK;
                 }
                 if (stage0 != ~0ull) {
                     dst = a.stage_slots + (stage0 + si) * SW;
@@ -328,25 +344,60 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
                 const unsigned sh = (unsigned)(p & 31) << 1;
                 const unsigned nbits = 2 * (c + K - 1);
                 // the bases next to the run, where the neighbouring window is valid — i.e. where the (K+1)-mer across the end of the run
-                // exists: bit 0 left valid, bits 1-2 left base, bit 3 right valid, bits 4-5 right base (slot bits 48..53 of the last word)
+                // exists — as two sets of one bit per base: bits 0-3 the base before the run, bits 4-7 the base behind it (slot bits 48..55
+                // of the last word; sets, because the dedupe stage folds identical slots and ORs their neighbours together)
                 uint32_t nb = 0;
                 auto base_at = [&](int64_t q) -> uint32_t {
                     const int bw = (int)((q >> 5) - wq0);
                     return (uint32_t)(sw[bw] >> ((unsigned)(q & 31) << 1)) & 3u;
                 };
-                if (e >> 31) nb |= 1u | (base_at(p - 1) << 1);
+                if (e >> 31) nb |= 1u << base_at(p - 1);
                 {
                     const int64_t q = p + (int64_t)c;  // the window behind the run
-                    if ((mw[(q >> 6) - mq0] >> (q & 63)) & 1) nb |= 8u | (base_at(q + (int64_t)K - 1) << 4);
+                    if ((mw[(q >> 6) - mq0] >> (q & 63)) & 1) nb |= 16u << base_at(q + (int64_t)K - 1);
                 }
+                // Orientation: the slot is stored on the strand on which its minimizer reads as the canonical m-mer, so that copies of one
+                // stretch of the genome from reads of either strand are the SAME slot, bit for bit, and the dedupe stage can fold them before
+                // it expands them (smx_skm_dedupe.hip). A slot is only a bag of k-mer instances with their neighbour bases: either strand
+                // yields the same canonical k-mers and extension bits. (A minimizer that is its own reverse complement stays as read.)
+                bool flip;
+                {
+                    const int64_t q = o + (int64_t)(e & 0xFFFu);
+                    const int mi = (int)((q >> 5) - wq0);
+                    const unsigned msh = (unsigned)(q & 31) << 1;
+                    const uint32_t mv = (uint32_t)((sw[mi] >> msh) | ((sw[mi + 1] << (63 - msh)) << 1)) & mmask;
+                    const uint32_t mr = (uint32_t)(rev2_64((uint64_t)mv) >> (64 - 2 * m)) ^ mmask;
+                    flip = mr < mv;
+                }
+                if (!flip) {
 #pragma unroll
-                for (int i = 0; i < SW; ++i) {
-                    uint64_t v = sw[wi + i] >> sh;
-                    if (sh) v |= sw[wi + i + 1] << (64 - sh);
-                    if (nbits <= 64u * i) v = 0;
-                    else if (nbits < 64u * (i + 1)) v &= (1ull << (nbits - 64u * i)) - 1;
-                    if (i == SW - 1) v |= ((uint64_t)c << 56) | ((uint64_t)nb << 48);
-                    dst[i] = v;
+                    for (int i = 0; i < SW; ++i) {
+                        uint64_t v = sw[wi + i] >> sh;
+                        if (sh) v |= sw[wi + i + 1] << (64 - sh);
+                        if (nbits <= 64u * i) v = 0;
+                        else if (nbits < 64u * (i + 1)) v &= (1ull << (nbits - 64u * i)) - 1;
+                        if (i == SW - 1) v |= ((uint64_t)c << 56) | ((uint64_t)nb << 48);
+                        dst[i] = v;
+                    }
+                } else {
+                    // reverse complement of the run: word i holds the complements of the bases pl + len - 32 i - 1 down to pl + len - 32 i - 32
+                    // (pl = the run's first base, local to the staged words); what lies before the run is masked out with the tail
+                    const int pl = (int)(p - (wq0 << 5)), len = (int)(c + K - 1);
+                    nb = (__brev(nb & 15u) >> 24) | (__brev(nb >> 4) >> 28);  // the sets change sides, every base to its complement (bit b -> 3 - b)
+#pragma unroll
+                    for (int i = 0; i < SW; ++i) {
+                        const int s0 = pl + len - 32 * (i + 1);
+                        const int wj = s0 >> 5;  // (arithmetic shift: may be negative)
+                        const unsigned sj = (unsigned)(s0 & 31) << 1;
+                        const uint64_t lo = wj >= 0 ? sw[wj] : 0ull, hi = wj + 1 >= 0 ? sw[wj + 1] : 0ull;
+                        uint64_t v = lo >> sj;
+                        if (sj) v |= hi << (64 - sj);
+                        v = rev2_64(~v);
+                        if (nbits <= 64u * i) v = 0;
+                        else if (nbits < 64u * (i + 1)) v &= (1ull << (nbits - 64u * i)) - 1;
+                        if (i == SW - 1) v |= ((uint64_t)c << 56) | ((uint64_t)nb << 48);
+                        dst[i] = v;
+                    }
                 }
             }
         }
@@ -373,6 +424,15 @@ __global__ void __launch_bounds__(BLK) k_skm_permute(const uint64_t *__restrict_
         uint64_t *dst = slots + (soff[(uint32_t)pr] + (pr >> 32)) * SW;  // the place the counting pass reserved
 #pragma unroll
         for (int t = 0; t < SW; ++t) dst[t] = v[t];
+    }
+}
+
+// counters of the counting pass -> slots per partition (in place) and segments per partition
+__global__ void __launch_bounds__(BLK) k_skm_split(unsigned long long *cnt, uint32_t *kseg, uint32_t n) {
+    for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+        const unsigned long long v = cnt[i];
+        kseg[i] = (uint32_t)(v >> SKM_CNT_BITS);
+        cnt[i] = v & SKM_CNT_MASK;
     }
 }
 
@@ -458,367 +518,6 @@ constexpr unsigned PM_BASE_BITS = 40;
 constexpr unsigned long long PM_BASE_MASK = (1ull << PM_BASE_BITS) - 1;
 constexpr unsigned long long PM_EMPTY = ~0ull, PM_DIRTY = ~0ull - 1;
 
-// One workgroup per item of SKM_KEYS_PER_ITEM consecutive minimizer keys; the item's slots are consumed in chunks of
-// whole keys holding <= cap instances (a key larger than that is cut). Per chunk: stage the slots in LDS, expand the
-// instance list (slot, offset), insert every instance into an exact hash set whose entries are 16-bit fingerprint |
-// 16-bit (slot, offset) reference (the k-mers themselves stay in the staged slots), append the winners to HBM.
-// LDS (dynamic): sl[scap*SW] u64 | tab[T] u32 | cpre[514] u32 | imap[cap] u16 | wl[cap] u16 | cl[512] u8 | nbv[512] u8
-// EXT: every instance also knows the bases next to it inside its read (the slot, or the slot's neighbour bases at its two ends) —
-// the extensions the (K+1)-mers around it give its k-mer (InOutMask bits in the k-mer's canonical frame: out bits 0-3 by next
-// base, in bits 4-7 by previous base; kmer_extension_index_builder.hpp:45-60, inout_mask.hpp:92-131). The table entries then are
-// 8-bit fingerprint | 8 extension bits (OR of all copies) | reference, and the survivors leave in the EXT layout (smx_device.hpp).
-// MODE: 0 plain, 1 EXT, 2 EXT + partition-major output (out_count then packs chunks << 40 | clean records)
-template <int NW, int MODE>
-__global__ void __launch_bounds__(BLK) k_skm_dedupe(const uint64_t *__restrict__ slots, const unsigned long long *__restrict__ slot_off,
-                                                    unsigned K, uint32_t nitems, uint32_t cap, uint32_t T, uint32_t scap, void *out_,
-                                                    unsigned long long out_cap, unsigned long long clean_cap, unsigned long long dirty_cap, unsigned long long *out_count,
-                                                    unsigned long long *dirty_count, unsigned long long *prof, PmOut pm, unsigned long long skip_slots,
-                                                    uint32_t force_dirty, uint32_t item_stride /* entries of slot_off per item: 256 (items share their
-                                                    boundary entries) or 257 (rows of their own) */) {
-    // skip_slots: a key (partition) of more slots than this is left out here — one workgroup would chew on a homopolymer partition of
-    // 10^7 instances for 100 ms while the others idle; its slot range is cut into pieces that a second launch deals out as items of their
-    // own (slot_off = one pseudo-key per piece, force_dirty = 1: every chunk of such a piece is a dirty one, its partition is cut by
-    // construction, and the partition table is not touched).
-    constexpr int SW = 2 * NW;
-    constexpr bool EXT = MODE >= 1, PM = MODE == 2;
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
-    uint64_t *sl = lds64;
-    uint32_t *tab = (uint32_t *)(sl + (size_t)scap * SW);
-    uint32_t *cpre = tab + T;
-    uint16_t *imap = (uint16_t *)(cpre + 514);
-    uint16_t *wl = imap + cap;
-    uint8_t *cl = (uint8_t *)(wl + cap);
-    uint8_t *nbv = cl + 512;
-    __shared__ unsigned long long koff[SKM_KEYS_PER_ITEM + 1];
-    __shared__ uint32_t scr[BLK / 64 + 2];
-    __shared__ uint32_t s_take, s_nfit, s_ninst, s_wcount, s_endb, s_cid;
-    __shared__ unsigned long long s_gbase, s_kend;
-    __shared__ uint32_t s_skip;  // the output buffer is full: the counters keep counting (the host sees the overflow), nothing is written
-    Rec<NW> *out = (Rec<NW> *)out_;
-    const unsigned lane = threadIdx.x & 63;
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;  // SMX_DEBUG: 100 MHz ticks per phase seen by thread 0
-    unsigned npal = 0;
-#define SKM_T(i)                                 \
-    if (prof && threadIdx.x == 0) {              \
-        unsigned long long t1 = wall_clock64();  \
-        pt[i] += t1 - t0;                        \
-        t0 = t1;                                 \
-    }
-    if (prof && threadIdx.x == 0) t0 = wall_clock64();
-    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t <= SKM_KEYS_PER_ITEM; t += BLK) koff[t] = slot_off[(uint64_t)item * item_stride + t];
-        __syncthreads();
-        uint64_t s_cur = koff[0];
-        const uint64_t s_end = koff[SKM_KEYS_PER_ITEM];
-        bool on_boundary = true;  // the chunk starts with the first slot of a key
-        while (s_cur < s_end) {
-            if (skip_slots != ~0ull && on_boundary) {  // an oversized key starts here: its pieces are items of the second launch
-                if (threadIdx.x == 0) s_kend = 0;
-                __syncthreads();
-                for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)
-                    if (koff[t] == s_cur && koff[t + 1] > koff[t] && koff[t + 1] - koff[t] > skip_slots) {
-                        s_kend = koff[t + 1];
-                        if constexpr (PM) pm.pinfo[(uint64_t)item * SKM_KEYS_PER_ITEM + t] = PM_DIRTY;
-                    }
-                __syncthreads();
-                const unsigned long long ke = s_kend;
-                __syncthreads();
-                if (ke) {
-                    s_cur = ke;
-                    continue;
-                }
-            }
-            const uint32_t nst = (uint32_t)((s_end - s_cur < scap) ? s_end - s_cur : scap);
-            for (uint32_t i = threadIdx.x; i < nst * SW; i += BLK) {
-                uint64_t v = slots[s_cur * SW + i];
-                if (i % SW == SW - 1) {
-                    cl[i / SW] = (uint8_t)(v >> 56);
-                    nbv[i / SW] = (uint8_t)((v >> 48) & 0x3Fu);
-                    v &= ~(0xFFFFull << 48);
-                }
-                sl[i] = v;
-            }
-            for (uint32_t i = threadIdx.x; i < T; i += BLK) tab[i] = 0xFFFFFFFFu;
-            if (threadIdx.x == 0) s_wcount = 0;
-            __syncthreads();
-            SKM_T(0)
-            {  // exclusive prefix of the window counts, two consecutive slots per thread
-                const uint32_t i0 = 2 * threadIdx.x, i1 = i0 + 1;
-                const uint32_t c0 = i0 < nst ? cl[i0] : 0, c1 = i1 < nst ? cl[i1] : 0;
-                uint32_t tot;
-                uint32_t ex = block_excl_scan<uint32_t>(c0 + c1, scr, &tot);
-                cpre[i0] = ex;
-                cpre[i1] = ex + c0;
-                if (threadIdx.x == BLK - 1) cpre[2 * BLK] = tot;
-            }
-            __syncthreads();
-            {  // chunk = the staged slots whose instances fit the table, cut back to the last key boundary inside if there
-               // is one (every thread tests its own candidates; exactly one matches each condition)
-                if (threadIdx.x == 0) {
-                    s_take = 0;
-                    s_endb = 0;
-                }
-                __syncthreads();
-                for (uint32_t n = threadIdx.x + 1; n <= nst; n += BLK)  // largest n in [1, nst] with cpre[n] <= cap
-                    if (cpre[n] <= cap && (n == nst || cpre[n + 1] > cap)) s_nfit = n;
-                __syncthreads();
-                const unsigned long long x = s_cur + s_nfit;
-                if (on_boundary) {
-                    if (x < s_end)
-                        for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)  // koff[t] <= x < koff[t+1], koff[t] > s_cur
-                            if (koff[t] <= x && koff[t + 1] > x && koff[t] > s_cur) s_take = (uint32_t)(koff[t] - s_cur);
-                } else {  // the chunk continues a cut key: it takes the rest of THAT key only (whole keys behind it get clean chunks of their own)
-                    for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)
-                        if (koff[t] <= s_cur && koff[t + 1] > s_cur) s_kend = koff[t + 1];
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    if (on_boundary) {
-                        s_endb = (x >= s_end || s_take != 0) ? 1u : 0u;  // the chunk ends with the last slot of a key
-                        if (s_take == 0) s_take = s_nfit;
-                    } else if (x >= s_kend) {
-                        s_take = (uint32_t)(s_kend - s_cur);
-                        s_endb = 1;
-                    } else {
-                        s_take = s_nfit;
-                        s_endb = 0;
-                    }
-                    s_ninst = cpre[s_take];
-                }
-            }
-            __syncthreads();
-            const uint32_t ntake = s_take, ninst = s_ninst;
-            for (uint32_t s = threadIdx.x; s < ntake; s += BLK) {
-                const uint32_t base = cpre[s], c = cl[s];
-                for (uint32_t j = 0; j < c; ++j) imap[base + j] = (uint16_t)((s << 7) | j);
-            }
-            __syncthreads();
-            SKM_T(1)
-            for (uint32_t i0 = 0; i0 < ninst; i0 += BLK) {
-                const uint32_t i = i0 + threadIdx.x;
-                bool won = false;
-                uint32_t code = 0;
-                if (i < ninst) {
-                    code = imap[i];
-                    const Rec<NW> x = skm_extract<NW>(sl + (size_t)(code >> 7) * SW, code & 127u, K);
-                    const Rec<NW> y = rec_rc<NW>(x, K);
-                    const bool fwd = rc_ge<NW>(y, x);
-                    Rec<NW> cx;
-#pragma unroll
-                    for (int t = 0; t < NW; ++t) cx.w[t] = fwd ? x.w[t] : y.w[t];
-                    const uint32_t hh = rec_hash32<NW>(cx);
-                    uint32_t h = hh & (T - 1);
-                    // (EXT: fingerprint 0xFF is not used, so that no live entry can ever read as the empty marker)
-                    const uint32_t fp = EXT ? (((hh >> 24) == 0xFFu) ? 0xFEu : (hh >> 24)) : (hh >> 16);
-                    const uint32_t entry = EXT ? ((fp << 24) | code) : ((fp << 16) | code);
-                    for (;;) {
-                        const uint32_t old = atomicCAS(&tab[h], 0xFFFFFFFFu, entry);
-                        if (old == 0xFFFFFFFFu) {
-                            won = true;
-                            break;
-                        }
-                        if ((EXT ? (old >> 24) : (old >> 16)) == fp) {
-                            const Rec<NW> xo = skm_extract<NW>(sl + (size_t)((old & 0xFFFFu) >> 7) * SW, old & 127u, K);
-                            if (rec_eq<NW>(xo, x) || rec_eq<NW>(xo, y)) break;  // same canonical k-mer already present
-                        }
-                        h = (h + 1) & (T - 1);
-                    }
-                    if constexpr (EXT) {
-                        const uint32_t s = code >> 7, j = code & 127u, c = cl[s], nb = nbv[s];
-                        const uint64_t *ss = sl + (size_t)s * SW;
-                        auto base = [&](uint32_t t) -> uint32_t { return (uint32_t)(ss[t >> 5] >> ((t & 31u) << 1)) & 3u; };
-                        const bool hasl = j > 0 || (nb & 1u), hasr = j + 1 < c || (nb & 8u);
-                        const uint32_t L = j > 0 ? base(j - 1) : ((nb >> 1) & 3u), R = j + 1 < c ? base(j + K) : ((nb >> 4) & 3u);
-                        uint32_t eb;
-                        if (fwd) eb = (hasr ? (1u << R) : 0u) | (hasl ? (16u << L) : 0u);
-                        else eb = (hasl ? (1u << (3u - L)) : 0u) | (hasr ? (16u << (3u - R)) : 0u);
-                        if (eb) atomicOr(&tab[h], eb << 16);
-                        code = h;  // the winners are listed by their table entry
-                        if constexpr (PM) imap[i] = (uint16_t)((h << 2) | (fwd ? 2u : 0u) | (j + 1 == c ? 1u : 0u));  // for the link pass below
-                    }
-                }
-                if constexpr (!PM) {
-                    const unsigned long long m = __ballot(won);
-                    if (m) {
-                        const int leader = __ffsll((unsigned long long)m) - 1;
-                        uint32_t base = 0;
-                        if ((int)lane == leader) base = atomicAdd(&s_wcount, (uint32_t)__popcll(m));
-                        base = __shfl(base, leader, 64);
-                        if (won) wl[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)code;
-                    }
-                }
-            }
-            __syncthreads();
-            // PM: the winners are listed in table-slot order; every thread owns gpt consecutive groups of 16 slots
-            const uint32_t ngroups = T >> 4, gpt = ngroups >= (uint32_t)BLK ? ngroups / BLK : 1u, g0 = threadIdx.x * gpt;
-            uint32_t occ[4] = {0, 0, 0, 0}, pre = 0;
-            if constexpr (PM) {
-                uint32_t cnt = 0;
-                if (g0 < ngroups)
-                    for (uint32_t g = 0; g < gpt; ++g) {
-                        uint32_t o = 0;
-                        for (uint32_t j = 0; j < 16; ++j)
-                            if (tab[(g0 + g) * 16 + j] != 0xFFFFFFFFu) o |= 1u << j;
-                        occ[g] = o;
-                        cnt += __popc(o);
-                    }
-                uint32_t tot;
-                pre = block_excl_scan<uint32_t>(cnt, scr, &tot);
-                if (g0 < ngroups) {
-                    uint32_t p = pre;
-                    for (uint32_t g = 0; g < gpt; ++g)
-                        for (uint32_t o = occ[g]; o; o &= o - 1) wl[p++] = (uint16_t)((g0 + g) * 16 + __ffs(o) - 1);
-                }
-                if (threadIdx.x == 0) s_wcount = tot;
-                if (ngroups * 4u <= 2056u && g0 < ngroups) {  // the group words in LDS too (over cpre, dead by now): rank of any table slot
-                    uint32_t p = pre;
-                    for (uint32_t g = 0; g < gpt; ++g) {
-                        cpre[g0 + g] = p | (occ[g] << 16);
-                        p += __popc(occ[g]);
-                    }
-                }
-                __syncthreads();
-            }
-            SKM_T(2)
-            const uint32_t wcount = s_wcount;
-            // A chunk of whole keys holds every copy of its k-mers: its winners are exactly distinct ("clean", front of out).
-            // Winners of a key that had to be cut may recur in its other chunks ("dirty", stacked from the back of out; the
-            // host uniques that part on its own before the two are joined).
-            const bool dirty = !on_boundary || !s_endb || force_dirty;
-            on_boundary = s_endb != 0;
-            if (threadIdx.x == 0) {
-                s_skip = 0;
-                if (!wcount) s_gbase = 0;
-                else if (!dirty) {
-                    if constexpr (PM) {
-                        const unsigned long long v = atomicAdd(out_count, (unsigned long long)wcount | (1ull << PM_BASE_BITS));
-                        s_gbase = v & PM_BASE_MASK;
-                        s_cid = (uint32_t)(v >> PM_BASE_BITS);
-                        s_skip = s_gbase + wcount > clean_cap;
-                        if (s_cid >= pm.max_chunks) {
-                            s_skip = 1;
-                            *pm.overflow = 1;
-                        }
-                    } else {
-                        s_gbase = atomicAdd(out_count, (unsigned long long)wcount);
-                        s_skip = s_gbase + wcount > clean_cap;
-                    }
-                } else {
-                    const unsigned long long d = atomicAdd(dirty_count, (unsigned long long)wcount);
-                    s_skip = d + wcount > dirty_cap;
-                    s_gbase = s_skip ? 0 : out_cap - d - wcount;
-                }
-            }
-            __syncthreads();
-            if constexpr (PM) {
-                if (dirty) {  // the cut partition: its k-mers go to the sorted tail
-                    if (!force_dirty)
-                        for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)
-                            if (koff[t] <= s_cur && koff[t + 1] > s_cur) pm.pinfo[(uint64_t)item * SKM_KEYS_PER_ITEM + t] = PM_DIRTY;
-                } else if (!s_skip && wcount) {
-                    const unsigned long long gb = s_gbase;
-                    const uint32_t cid = s_cid;
-                    if (g0 < ngroups) {
-                        uint32_t p = pre;
-                        for (uint32_t g = 0; g < gpt; ++g) {
-                            pm.meta[(size_t)cid * ngroups + g0 + g] = p | (occ[g] << 16);
-                            p += __popc(occ[g]);
-                        }
-                    }
-                    if (threadIdx.x == 0) pm.cinfo[cid] = gb | ((unsigned long long)wcount << PM_BASE_BITS);
-                    for (uint32_t t = threadIdx.x; t < SKM_KEYS_PER_ITEM; t += BLK)  // the partitions that lie in this chunk
-                        if (koff[t + 1] > koff[t] && koff[t] >= s_cur && koff[t + 1] <= s_cur + ntake)
-                            pm.pinfo[(uint64_t)item * SKM_KEYS_PER_ITEM + t] = gb | ((unsigned long long)cid << PM_BASE_BITS);
-                }
-            }
-            if (!s_skip) {
-                Rec<NW> *dst = out + s_gbase;
-                for (uint32_t i = threadIdx.x; i < wcount; i += BLK) {
-                    uint32_t code = wl[i], eb = 0;
-                    if constexpr (EXT) {
-                        const uint32_t ent = tab[code];
-                        code = ent & 0xFFFFu;
-                        eb = (ent >> 16) & 0xFFu;
-                    }
-                    const Rec<NW> x = skm_extract<NW>(sl + (size_t)(code >> 7) * SW, code & 127u, K);
-                    const Rec<NW> y = rec_rc<NW>(x, K);
-                    const bool fwd = rc_ge<NW>(y, x);
-                    Rec<NW> cx;
-#pragma unroll
-                    for (int t = 0; t < NW; ++t) cx.w[t] = fwd ? x.w[t] : y.w[t];
-                    if constexpr (PM) {
-                        if (!dirty) {
-                            pm.mask[s_gbase + i] = (uint8_t)eb;
-                            // palindromic (k+1)-mers among the extensions (registers only): cx + c is its own reverse complement iff c is the
-                            // complement of cx[0] and cx[1..K-1] equals RC(cx)[0..K-2]; likewise b + cx with cx[0..K-2] against RC(cx)[1..K-1]
-                            const Rec<NW> &rx = fwd ? y : x;  // reverse complement of the canonical k-mer
-                            const unsigned c0 = (unsigned)cx.w[0] & 3u, cl_ = (unsigned)(cx.w[NW - 1] >> (((K - 1) & 31u) << 1)) & 3u;
-                            // (first the matching extension bit AND complementary outermost bases of the inner (K-1)-mer: 1 winner in 16)
-                            const uint64_t wsel = ((K - 2) >> 5) == (unsigned)(NW - 1) ? cx.w[NW - 1] : cx.w[NW > 1 ? NW - 2 : 0];
-                            const unsigned c1 = (unsigned)(cx.w[0] >> 2) & 3u, cm = (unsigned)(wsel >> (((K - 2) & 31u) << 1)) & 3u;
-                            if ((((eb >> (3 - c0)) & 1) && c1 + cl_ == 3) || (((eb >> (7 - cl_)) & 1) && c0 + cm == 3)) {
-                                Rec<NW> xs, rs, xp = cx, rp = rx;  // suffixes (drop base 0) and prefixes (drop base K-1)
-#pragma unroll
-                                for (int t = 0; t < NW; ++t) {
-                                    xs.w[t] = (cx.w[t] >> 2) | (t + 1 < NW ? cx.w[t + 1] << 62 : 0ull);
-                                    rs.w[t] = (rx.w[t] >> 2) | (t + 1 < NW ? rx.w[t + 1] << 62 : 0ull);
-                                }
-                                const uint64_t topm = ~(3ull << (((K - 1) & 31u) << 1));
-                                xp.w[NW - 1] &= topm;
-                                rp.w[NW - 1] &= topm;
-                                if (((eb >> (3 - c0)) & 1) && rec_eq<NW>(xs, rp)) ++npal;
-                                if (((eb >> (7 - cl_)) & 1) && rec_eq<NW>(xp, rs)) ++npal;
-                            }
-                        }
-                    }
-                    if constexpr (EXT) cx.w[NW - 1] = (cx.w[NW - 1] << EXT_BITS) | eb;
-                    dst[i] = cx;
-                }
-            }
-            if constexpr (PM) {
-                // Local links. imap[i] = (table slot, strand, last of its slot) of instance i: instances i, i+1 of one super-k-mer are k-mers
-                // X_i -> X_{i+1} side by side in a read, i.e. a de Bruijn edge between the nodes of their table entries (and the reverse
-                // one between the other strands). A node with ONE outgoing extension has one successor, whichever read shows it; where
-                // several reads disagree the node has several extensions and nobody reads the link. The link table (16 bits per node,
-                // indexed by winner rank) lies over the slot staging area, dead after the output above.
-                __syncthreads();
-                uint16_t *lnk = (uint16_t *)sl;
-                const bool fits = !dirty && !s_skip && wcount && (size_t)wcount * 4 <= (size_t)scap * SW * 8 && ngroups * 4u <= 2056u;
-                if (fits) {
-                    for (uint32_t t = threadIdx.x; t < 2 * wcount; t += BLK) lnk[t] = 0xFFFFu;
-                    __syncthreads();
-                    auto rank_of = [&](uint32_t h) -> uint32_t {
-                        const uint32_t g = cpre[h >> 4];
-                        return (g & 0xFFFFu) + __popc((g >> 16) & ((1u << (h & 15u)) - 1u));
-                    };
-                    for (uint32_t i = threadIdx.x; i + 1 < ninst; i += BLK) {
-                        const uint32_t v = imap[i];
-                        if (v & 1u) continue;  // the last window of its super-k-mer: its neighbour lives in another slot
-                        const uint32_t w2 = imap[i + 1];
-                        const uint32_t na = 2 * rank_of(v >> 2) + ((v & 2u) ? 0u : 1u), nb = 2 * rank_of(w2 >> 2) + ((w2 & 2u) ? 0u : 1u);
-                        lnk[na] = (uint16_t)nb;
-                        lnk[nb ^ 1u] = (uint16_t)(na ^ 1u);
-                    }
-                    __syncthreads();
-                    uint16_t *gl = (uint16_t *)(pm.llink + s_gbase);
-                    for (uint32_t t = threadIdx.x; t < 2 * wcount; t += BLK) gl[t] = lnk[t];
-                }
-            }
-            s_cur += ntake;
-            __syncthreads();
-            SKM_T(3)
-            if (prof && threadIdx.x == 0) {
-                pt[4] += 1;
-                pt[5] += ntake;
-            }
-        }
-    }
-    if (prof && threadIdx.x == 0)
-        for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], pt[i]);
-    if constexpr (PM)
-        if (npal) atomicAdd(pm.pals, (unsigned long long)npal);
-#undef SKM_T
-}
-
 }  // namespace smx
+
+#include "smx_skm_dedupe.hip"

@@ -3,7 +3,7 @@
 write for a seeded >= 2 M-read set, generated in the build container (binaries under $SMX_REF_BIN, built from /root/reference by
 the survey's cmake recipe). The read set comes from tests/synth.py, so the GPU box regenerates the identical reads and only the
 md5s travel (tests/golden/scale_*.json).
-usage: make_golden_scale.py [n_reads=2000000] [genome_len=10000000] [seed=77] [k=55] [what=all|kmercount|allskew]
+usage: make_golden_scale.py [n_reads=2000000] [genome_len=10000000] [seed=77] [k=55] [what=all|kmercount|gfa|allskew]
   BASELINE config 2 (10 M PE150 reads, k=21, spades-kmercount):  make_golden_scale.py 1e7 5e7 1 21 kmercount"""
 import hashlib
 import json
@@ -50,15 +50,16 @@ def main():
         fq = os.path.join(td, "reads.fq")
         synth.write_fastq(codes, fq)
         out["fastq_md5"] = md5_file(fq)
-        t0 = time.time()
-        subprocess.check_call([os.path.join(REF_BIN, "spades-kmercount"), "-k", str(k), "-t", str(threads), "-w", os.path.join(td, "kc"), fq],
-                              stdout=subprocess.DEVNULL)
-        out["kmercount_s"] = round(time.time() - t0, 1)
-        fk = os.path.join(td, "kc", "final_kmers")
-        out["final_kmers_md5"] = md5_file(fk)
-        out["final_kmers_bytes"] = os.path.getsize(fk)
-        os.remove(fk)
-        for cov in ((False, True) if what == "all" else ()):
+        if what != "gfa":  # "gfa": spades-gbuilder only (at 20 M reads the k-mer file of spades-kmercount alone is 50 GB)
+            t0 = time.time()
+            subprocess.check_call([os.path.join(REF_BIN, "spades-kmercount"), "-k", str(k), "-t", str(threads), "-w", os.path.join(td, "kc"), fq],
+                                  stdout=subprocess.DEVNULL)
+            out["kmercount_s"] = round(time.time() - t0, 1)
+            fk = os.path.join(td, "kc", "final_kmers")
+            out["final_kmers_md5"] = md5_file(fk)
+            out["final_kmers_bytes"] = os.path.getsize(fk)
+            os.remove(fk)
+        for cov in ((False, True) if what in ("all", "gfa") else ()):
             gfa = os.path.join(td, "g.gfa")
             t0 = time.time()
             subprocess.check_call([os.path.join(REF_BIN, "spades-gbuilder"), fq, gfa, "-k", str(k), "-t", str(threads), "--gfa"] + (["-c"] if cov else []) +
