@@ -18,6 +18,10 @@ from spades_amd.kmercount import Context
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = sorted(glob.glob(os.path.join(HERE, "golden", "scale_*.json")))
+# The 20 M-read golden (30x over 100 Mbp: 37.5 M unitigs, 5 GB of GFA per route) takes minutes: it runs when SMX_SCALE_BIG=1
+# (tools/r4_scale20m.sh; log under profiles/r04/), the default suite stays at the 2 M / 10 M cases.
+if not os.environ.get("SMX_SCALE_BIG"):
+    CASES = [c for c in CASES if json.load(open(c))["n_reads"] <= 10_000_000]
 
 
 def _md5_file(path):
@@ -40,6 +44,8 @@ def case(request):
 
 def test_final_kmers_equal_spades_kmercount(case, tmp_path):
     g, bases, off = case
+    if "final_kmers_md5" not in g:
+        pytest.skip("spades-gbuilder golden only")
     ctx = Context()
     sp = ReadKMerSplitter(g["k"], "A", ctx)
     sp.push_back_ascii(bases, off)
