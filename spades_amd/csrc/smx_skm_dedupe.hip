@@ -51,8 +51,8 @@ constexpr uint32_t SKM_PLAN_BUF = 256;
 // partition of 10^7 instances for 100 ms while the others idle; its slot range is cut into pieces that a second launch deals out as items
 // of their own (slot_off = one pseudo-key per piece with rows of item_stride = 257 offsets, kseg == nullptr, force_dirty = 1: every
 // chunk of such a piece is a dirty one and the partition table is not touched).
-constexpr uint32_t SKM_FOLD_TAB = 8192;        // slot set of the fold (entries of 4 B), per planning workgroup
-constexpr uint32_t SKM_FOLD_ITEM_MAX = 5120;   // most slots of an item that are folded (beyond: the item is planned unfolded)
+constexpr uint32_t SKM_FOLD_TAB = 4096;        // slot set of the fold (entries of 4 B), per planning workgroup
+constexpr uint32_t SKM_FOLD_ITEM_MAX = 3328;   // most slots of an item that are folded (beyond: the item is planned unfolded)
 constexpr uint32_t SKM_FOLD_KEY_MAX = 1024;    // a partition of more slots is left alone (low complexity: every window a slot of its own)
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_skm_plan(uint64_t *__restrict__ slots, const unsigned long long *__restrict__ slot_off,

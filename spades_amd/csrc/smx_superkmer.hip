@@ -79,6 +79,15 @@ __device__ __forceinline__ uint32_t skm_key(uint32_t v, unsigned m) {
     c ^= c >> 13;
     return c;
 }
+// the same from the m-mer and its reverse complement (both masked to 2m bits) — the scan rolls the two along the stream
+__device__ __forceinline__ uint32_t skm_key_vr(uint32_t v, uint32_t r) {
+    uint32_t c = v < r ? v : r;
+    c *= 0x2C9277B5u;
+    c ^= c >> 15;
+    c *= 0x1B873593u;
+    c ^= c >> 13;
+    return c;
+}
 // order key -> partition: the order keys of the chosen minimizers crowd the low end of the key space by construction
 // (a minimizer IS the smallest key of its window), so the partition id is an independent mix of the same value.
 __device__ __forceinline__ uint32_t skm_part(uint32_t key, unsigned pshift) {
@@ -88,14 +97,18 @@ __device__ __forceinline__ uint32_t skm_part(uint32_t key, unsigned pshift) {
     return key >> pshift;
 }
 
+#ifndef SMX_SCAN_WPE
+#define SMX_SCAN_WPE 6  // waves per SIMD the scan is compiled for: it waits on the counting atomics (measured 65.9 / 60.5 / 56.4 / 55.4 ms at 4 / 5 / 6 / 8)
+#endif
 template <int PHASE, int NW>
-__global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
+__global__ void __launch_bounds__(BLK, SMX_SCAN_WPE) k_skm_scan(SkmArgs a) {
     constexpr int SW = 2 * NW;
     constexpr int NSW = (SKM_TC + SKM_WMAX + 64) / 32 + 2 * 4 + 4;  // staged stream words
     constexpr int NKQ = SKM_TC + SKM_WMAX + 16;
     constexpr int NFW = SKM_TC / 64 + 3;
     __shared__ uint64_t sw[NSW];
     __shared__ __attribute__((aligned(16))) uint32_t keys[NKQ];
+    __shared__ uint64_t bmin[NKQ / 8 + 2];  // leftmost minimum of every aligned block of 8 keys: key << 32 | position
     __shared__ uint64_t fw[NFW];  // break flags, bit i <-> window position p0 + i
     __shared__ uint64_t mw[NFW];  // window-valid bits, bit i <-> position 64*mq0 + i
     __shared__ uint32_t slist[SKM_TP];  // starts of the tile: (window position << 12) | minimizer position
@@ -152,54 +165,96 @@ __global__ void __launch_bounds__(BLK) k_skm_scan(SkmArgs a) {
         if (threadIdx.x == 0) s_nstart = 0;
         __syncthreads();
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, pf_s, pf_m);
+        // Keys of the m-mers at the local positions 0 .. nq-1, a block of 8 consecutive positions per thread: the m-mer and its reverse
+        // complement are taken from the stream once and ROLLED over the block (two shifts per position instead of an extraction and a
+        // 64-bit bit reversal). The block's leftmost minimum goes to bmin; the thread keeps the suffix minima of ITS block (8t..8t+7).
         const int nq = SKM_TC + (int)w + 8;
-        for (int qi = threadIdx.x; qi < nq; qi += BLK) {
-            const int64_t q = o + qi;
-            uint32_t key = 0xFFFFFFFFu;
-            if (q >= 0 && q + (int64_t)m <= nbases) {
-                const int wi = (int)((q >> 5) - wq0);
-                const unsigned sh = (unsigned)(q & 31) << 1;
-                const uint64_t v = (sw[wi] >> sh) | ((sw[wi + 1] << (63 - sh)) << 1);
-                key = skm_key((uint32_t)v & mmask, m);
+        const int b8 = threadIdx.x * 8;
+        uint32_t sk[8], sp[8];  // suffix minima of the keys b8 .. b8+7 (leftmost wins ties)
+        for (int blk = threadIdx.x; blk * 8 < nq; blk += BLK) {
+            const int q0i = blk * 8;
+            const int64_t q0 = o + q0i;
+            uint32_t kk[8];
+            if (q0 >= 0 && q0 + 8 + (int64_t)m <= nbases) {
+                const int wi = (int)((q0 >> 5) - wq0);
+                const unsigned sh = (unsigned)(q0 & 31) << 1;
+                uint32_t v = (uint32_t)((sw[wi] >> sh) | ((sw[wi + 1] << (63 - sh)) << 1)) & mmask;
+                uint32_t r = __brev(v);
+                r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+                r = (r >> (32 - 2 * m)) ^ mmask;
+                const int64_t qn = q0 + (int64_t)m;  // the 8 bases behind the first m-mer
+                const int wn = (int)((qn >> 5) - wq0);
+                const unsigned shn = (unsigned)(qn & 31) << 1;
+                uint32_t nxt = (uint32_t)((sw[wn] >> shn) | ((sw[wn + 1] << (63 - shn)) << 1)) & 0xFFFFu;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    kk[j] = skm_key_vr(v, r);
+                    const uint32_t b = nxt & 3u;
+                    nxt >>= 2;
+                    v = (v >> 2) | (b << (2 * m - 2));
+                    r = ((r << 2) | (3u - b)) & mmask;
+                }
+            } else {  // at either end of the stream: position by position
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t q = q0 + j;
+                    uint32_t key = 0xFFFFFFFFu;
+                    if (q >= 0 && q + (int64_t)m <= nbases) {
+                        const int wi = (int)((q >> 5) - wq0);
+                        const unsigned sh = (unsigned)(q & 31) << 1;
+                        const uint64_t v = (sw[wi] >> sh) | ((sw[wi + 1] << (63 - sh)) << 1);
+                        key = skm_key((uint32_t)v & mmask, m);
+                    }
+                    kk[j] = key;
+                }
             }
-            keys[qi] = key;
+            *(uint4 *)&keys[q0i] = make_uint4(kk[0], kk[1], kk[2], kk[3]);
+            *(uint4 *)&keys[q0i + 4] = make_uint4(kk[4], kk[5], kk[6], kk[7]);
+            uint32_t tk[8], tp[8];
+            tk[7] = kk[7];
+            tp[7] = (uint32_t)(q0i + 7);
+#pragma unroll
+            for (int j = 6; j >= 0; --j) {
+                const bool le = kk[j] <= tk[j + 1];
+                tk[j] = le ? kk[j] : tk[j + 1];
+                tp[j] = le ? (uint32_t)(q0i + j) : tp[j + 1];
+            }
+            bmin[blk] = ((uint64_t)tk[0] << 32) | tp[0];
+            if (blk == (int)threadIdx.x) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sk[j] = tk[j];
+                    sp[j] = tp[j];
+                }
+            }
         }
         __syncthreads();
         SKM_T(0)
         // Minimizer position (qi) of the windows pi = b8 .. b8+8: pi = b8 is the predecessor of the thread's 8 windows
-        // p0 + b8 .. p0 + b8 + 7. Window pi spans qi in [pi, pi+w-1] = L (b8+j..b8+7) + C (b8+8..b8+w-1, shared by all nine)
-        // + R (b8+w..b8+w+j-1); leftmost position wins ties.
-        const int b8 = threadIdx.x * 8;
+        // p0 + b8 .. p0 + b8 + 7. Window pi spans qi in [pi, pi+w-1] = L (b8+j..b8+7) + C (b8+8..b8+w-1, shared by all nine: whole
+        // blocks of 8 from bmin, the rest key by key) + R (b8+w..b8+w+j-1); leftmost position wins ties.
         uint32_t m9[9];
         {
             const int cend = b8 + (int)w - 1;
-            uint32_t ck = keys[b8 + 8], cp = (uint32_t)(b8 + 8);
-            for (int q4 = b8 + 8; q4 <= cend; q4 += 4) {
-                const uint4 k4 = *(const uint4 *)&keys[q4];
-                const uint32_t e0 = k4.x, e1 = q4 + 1 <= cend ? k4.y : 0xFFFFFFFFu, e2 = q4 + 2 <= cend ? k4.z : 0xFFFFFFFFu,
-                               e3 = q4 + 3 <= cend ? k4.w : 0xFFFFFFFFu;
-                if (e0 < ck) { ck = e0; cp = (uint32_t)q4; }
-                if (e1 < ck) { ck = e1; cp = (uint32_t)q4 + 1; }
-                if (e2 < ck) { ck = e2; cp = (uint32_t)q4 + 2; }
-                if (e3 < ck) { ck = e3; cp = (uint32_t)q4 + 3; }
+            uint32_t ck = 0xFFFFFFFFu, cp = (uint32_t)(b8 + 8);
+            int q4 = b8 + 8;
+            for (; q4 + 7 <= cend; q4 += 8) {
+                const uint64_t e = bmin[q4 >> 3];
+                if ((uint32_t)(e >> 32) < ck) {
+                    ck = (uint32_t)(e >> 32);
+                    cp = (uint32_t)e;
+                }
             }
-            uint32_t lk[8], rk[8];
-            {
-                const uint4 l0 = *(const uint4 *)&keys[b8], l1 = *(const uint4 *)&keys[b8 + 4];
-                lk[0] = l0.x; lk[1] = l0.y; lk[2] = l0.z; lk[3] = l0.w;
-                lk[4] = l1.x; lk[5] = l1.y; lk[6] = l1.z; lk[7] = l1.w;
+            for (; q4 <= cend; ++q4) {
+                const uint32_t e = keys[q4];
+                if (e < ck) {
+                    ck = e;
+                    cp = (uint32_t)q4;
+                }
             }
+            uint32_t rk[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) rk[j] = keys[b8 + (int)w + j];
-            uint32_t sk[8], sp[8];  // suffix minima of L
-            sk[7] = lk[7];
-            sp[7] = (uint32_t)(b8 + 7);
-#pragma unroll
-            for (int j = 6; j >= 0; --j) {
-                const bool t = lk[j] <= sk[j + 1];
-                sk[j] = t ? lk[j] : sk[j + 1];
-                sp[j] = t ? (uint32_t)(b8 + j) : sp[j + 1];
-            }
             uint32_t pk = 0xFFFFFFFFu, pp = 0;  // prefix minimum of R (nothing yet: never smaller)
             bool phave = false;
 #pragma unroll

@@ -6,7 +6,7 @@ timeout 900 python -m pytest tests/test_prededupe_gpu.py tests/test_pm_route_gpu
 SMX_DEBUG=1 timeout 600 $B --steps 1 --warmup 0 > $O/dbg.json 2> $O/dbg.err
 timeout 600 $B > $O/b_fold.json 2> $O/b_fold.err
 timeout 600 $B --opt skm_fold=0 > $O/b_nofold.json 2> $O/b_nofold.err
-timeout 600 $B --opt skm_cap=4096 > $O/b_cap4096.json 2> $O/b_cap4096.err
+
 for f in $O/b_*.json; do echo $f; python - $f <<'PY'
 import json,sys
 try:
