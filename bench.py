@@ -216,10 +216,14 @@ def cpu_baseline_count(codes_sample, K, mode, nb, gpu_result=None, runs=3):
     return res
 
 
-def cpu_baseline_construct(codes_sample, k, gpu_unitigs=None):
+def cpu_baseline_construct(codes_sample, k, gpu_graph=None, runs=3, unitigs=True):
     """The reference's construction classes on ALL host cores (oracle/_ref/ref_earlytip: KMerDiskCounter -> DeBruijnExtensionIndexBuilder
-    -> UnbranchingPathExtractor::ExtractUnbranchingPathsAndLoops, 10 x cores buckets). gpu_unitigs(n, threads) -> list of the GPU's
-    unitigs for the same reads and bucket count: compared as multisets (the reference's edge order is thread-schedule dependent)."""
+    -> UnbranchingPathExtractor::ExtractUnbranchingPathsAndLoops, 10 x cores buckets), median of `runs`. gpu_graph(n, threads) ->
+    (unitigs, k-mer file words, mask bytes) of the GPU's DEFAULT route for the same reads and bucket count: the unitigs are compared as
+    multisets (the reference's edge order is thread-schedule dependent), the k-mer file and the InOutMask bytes byte for byte with what
+    the reference's extension index holds (kmer_extension_index_builder.hpp:45-107; the default route never makes that file for the
+    graph — it is materialised from the partition-major records for this check). unitigs=False: extension index only (at-size check)."""
+    import numpy as np
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_earlytip")
     if not os.path.exists(ref):
         return None
@@ -228,27 +232,37 @@ def cpu_baseline_construct(codes_sample, k, gpu_unitigs=None):
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         rf = os.path.join(td, "reads.txt")
         n = _reads_file(codes_sample, rf)
-        t0 = time.time()
-        subprocess.check_call([ref, str(k), str(threads), "0", rf, os.path.join(td, "wd"), os.path.join(td, "out.txt")],
-                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        dt = time.time() - t0
+        times = []
+        for it in range(max(1, runs)):
+            subprocess.call(["rm", "-rf", os.path.join(td, "wd")])
+            t0 = time.time()
+            subprocess.check_call([ref, str(k), str(threads), "0", rf, os.path.join(td, "wd"), os.path.join(td, "out.txt"), "kmers=" + os.path.join(td, "km")] +
+                                  ([] if unitigs else ["nounitigs"]), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            times.append(time.time() - t0)
+        subprocess.call(["rm", "-rf", os.path.join(td, "wd")])
+        dt = sorted(times)[len(times) // 2]
         res = {"value": round(n / dt / 1e6, 4), "unit": "M reads/s", "cores": cores, "cpu": model, "kind": "reference",
-               "sample": f"first {n} reads of the bench batch, oracle/_ref/ref_earlytip (reference KMerDiskCounter + extension index + "
-                         f"UnbranchingPathExtractor, {10 * threads} buckets, {threads} threads, tmpfs workdir), one run = {dt:.1f} s"}
-        if gpu_unitigs is not None:
-            with open(os.path.join(td, "out.txt"), "rb") as f:
-                ref_u = f.read().split(b"\n")
-            if ref_u and ref_u[-1] == b"":
-                ref_u.pop()
-            got = gpu_unitigs(n, threads)
-            ref_u.sort()
-            got.sort()
-            h1, h2 = hashlib.md5(), hashlib.md5()
-            for u in ref_u:
-                h1.update(u + b"\n")
-            for u in got:
-                h2.update(u + b"\n")
-            res.update({"unitig_multiset_identical_to_reference": h1.digest() == h2.digest(), "compared_unitigs": len(ref_u)})
+               "sample": f"{n} reads, oracle/_ref/ref_earlytip (reference KMerDiskCounter + extension index" + (" + UnbranchingPathExtractor" if unitigs else "") +
+                         f", {10 * threads} buckets, {threads} threads, tmpfs workdir), median of {len(times)} runs = {dt:.1f} s ({', '.join('%.1f' % t for t in times)})"}
+        if gpu_graph is not None:
+            got, gk, gm = gpu_graph(n, threads)
+            rk = np.fromfile(os.path.join(td, "km"), dtype=np.uint64)
+            rm = np.fromfile(os.path.join(td, "km.masks"), dtype=np.uint8)
+            res.update({"kmer_file_identical_to_reference": bool(rk.size == gk.size and np.array_equal(rk, gk.reshape(-1))),
+                        "inout_masks_identical_to_reference": bool(rm.size == gm.size and np.array_equal(rm, gm)), "compared_kmers": int(rm.size)})
+            if unitigs:
+                with open(os.path.join(td, "out.txt"), "rb") as f:
+                    ref_u = f.read().split(b"\n")
+                if ref_u and ref_u[-1] == b"":
+                    ref_u.pop()
+                ref_u.sort()
+                got.sort()
+                h1, h2 = hashlib.md5(), hashlib.md5()
+                for u in ref_u:
+                    h1.update(u + b"\n")
+                for u in got:
+                    h2.update(u + b"\n")
+                res.update({"unitig_multiset_identical_to_reference": h1.digest() == h2.digest(), "compared_unitigs": len(ref_u)})
     return res
 
 
@@ -331,7 +345,9 @@ def main():
                     help="reads of the bench batch counted on the host by the reference classes (same coverage regime as the step from ~20 M reads on: "
                          "at 2 M reads over a 500 Mbp genome almost every k-mer is distinct and the fixed costs of a 256-thread launch dominate)")
     ap.add_argument("--cpu-sample-construct", type=float, default=2e6,
-                    help="reads for the reference CONSTRUCTION classes on the host (0.04 M reads/s: 20 M reads would take 8 minutes; the sample bias is stated in the line)")
+                    help="reads of a separately generated 30x batch for the reference CONSTRUCTION classes on the host (median of --cpu-runs; unitigs, k-mer file and masks compared)")
+    ap.add_argument("--cpu-masks-sample", type=float, default=0,
+                    help="extra: the reference's extension index (k-mer file + InOutMask bytes) on this many of the bench reads against the timed route's (minutes at 20e6)")
     ap.add_argument("--end-to-end", type=float, default=20e6,
                     help="extra (untimed for the headline): uncompressed FASTQ of this many bench reads on tmpfs -> spades-gbuilder-mi355x --gfa and "
                          "spades-kmercount-mi355x -> files on tmpfs, wall clock with the tools' stage split; 0 disables")
@@ -512,14 +528,14 @@ def main():
     # HBM traffic per step from the committed PMC passes (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
     # FETCH x2 gfx950 correction). A table is a constant of ITS measurement: it is quoted only for the workload it was taken on and only
     # while the library sources are the ones it was taken on (first line of the CSV: their sha256) — otherwise traffic stays null.
-    pmc = os.path.join(ROOT, "profiles", "r03", "config3_pm_pmc_hbm_traffic.csv" if pm_route else
-                       ("config3_sorted_pmc_hbm_traffic.csv" if ext_route else "config3_kpomer_pmc_hbm_traffic.csv"))
+    pmc_name = "config3_pm_pmc_hbm_traffic.csv" if pm_route else ("config3_sorted_pmc_hbm_traffic.csv" if ext_route else "config3_kpomer_pmc_hbm_traffic.csv")
+    pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, pmc_name) for r_ in ("r04", "r03")) if os.path.exists(p_)), os.path.join(ROOT, "profiles", "r04", pmc_name))
     pmc_rows, pmc_split, pmc_note = {}, None, None
     if not sharded and not args.count_only and n_reads == 100_000_000 and k == 55 and T == 16 and os.path.exists(pmc):
         lines = open(pmc).read().splitlines()
         sha = lines[0].split("src_sha256=")[1].split()[0] if lines and "src_sha256=" in lines[0] else None
         if sha != _src_hash():
-            pmc_note = f"profiles/r03 PMC table was taken on other library sources ({sha}): not quoted"
+            pmc_note = f"{os.path.relpath(pmc, ROOT)} was taken on other library sources ({sha}): not quoted"
             lines = []
         for line in lines:
             f = line.strip().rsplit(",", 5)  # kernel names hold commas (template arguments)
@@ -537,10 +553,10 @@ def main():
         con_traffic = sum(v for n_, v in pmc_rows.items() if any(c in n_ for c in con_kernels))
         pmc_split = {"count": round(sum(pmc_rows.values()) - con_traffic, 1), "construct": round(con_traffic, 1)} if pmc_rows else None
         roof_count["traffic"] = pmc_split["count"] if pmc_split else None
-        roof_count["traffic_unit"] = ("GB per step, HBM fetch (x2 gfx950 correction) + write of the counting pipeline's kernels (PMC passes of "
-                                      "profiles/r03 on these very sources); whole step: %.1f GB" % sum(pmc_rows.values())) if pmc_rows else pmc_note
+        roof_count["traffic_unit"] = ("GB per step, RECORDED: HBM fetch (x2 gfx950 correction) + write of the counting pipeline's kernels from the PMC passes of "
+                                      + os.path.relpath(pmc, ROOT) + " (taken on these very sources: sha256 checked); whole step: %.1f GB" % sum(pmc_rows.values())) if pmc_rows else pmc_note
     elif not sharded and not args.count_only:
-        roof_count["traffic_unit"] = "no PMC table for this workload / route under profiles/r03"
+        roof_count["traffic_unit"] = "no PMC table for this workload / route under profiles/"
 
     out = {
         "metric": f"M reads/sec k-mer-counted (k={k}, PE150)",
@@ -591,23 +607,35 @@ def main():
             out["construct"]["route_stats"] = str(e)
         out["step_breakdown_ms"] = {"count_kernels": round(count_ms, 1), "construct_kernels": round(construct_ms, 1),
                                     "host_and_upload": round(ms_per_step - count_ms - construct_ms, 1)}
-        # the dominant single kernel of the step: k_fill_tab (node table: two rank lookups + two 64-bit atomics per (k+1)-mer)
-        if pm_route:   # k_pm_tab: the successor of every node with a unique extension, looked up inside its own chunk first; + jump words
-            fm = stages.get("pm_tab", 0.0)
-            b_fill = D0 * (W + 1) + 2 * D0 * W + 2 * D0 * 8 + 2 * D0 * 4
-            dname, dkey = "smx::k_pm_tab", "smx::k_pm_tab"  # (not a template any more)
-        elif ext_route:  # k_tab_from_masks: the successor of every node with a unique extension, one rank lookup each
-            fm = stages.get("succ", 0.0)
-            b_fill = D0 * (W + 1) + 2 * D0 * W + 2 * D0 * 8
-            dname, dkey = "smx::k_tab_from_masks", "smx::k_tab_from_masks<2, true>"
-        else:          # k_fill_tab: node table by two rank lookups + two 64-bit atomics per (k+1)-mer
-            fm = stages.get("fill_masks", 0.0)
-            b_fill = D1 * W + 2 * D1 * W + 2 * D1 * 8
-            dname, dkey = "smx::k_fill_tab (+ k_tab_masks)", "smx::k_fill_tab<2>"
-        out["dominant_kernel"] = {"name": dname, "ms": round(fm, 3), "algorithmic_bytes": int(b_fill),
-                                  "achieved_GBps": round(b_fill / max(fm, 1e-9) / 1e6, 1), "frac": round(b_fill / max(fm, 1e-9) / 1e6 / 8000.0, 4),
-                                  "traffic_GB": round(pmc_rows.get(dkey, 0.0), 1) or None,
-                                  "bound": "random HBM transactions (~64 B fetched per 8/16-B access), not bytes"}
+        # The dominant single kernel of the step = the longest stage that is ONE kernel (HIP events on the library stream), priced on the
+        # bytes that kernel must move (stated per kernel below); its measured HBM traffic is quoted from the recorded PMC table when
+        # that table belongs to these sources.
+        rs = out["construct"]["route_stats"] if isinstance(out["construct"]["route_stats"], dict) else {}
+        nslots, nchunks = rs.get("superkmer_slots", 0), rs.get("chunks", 0)
+        n_cand = rs.get("start_de_edges", 0)
+        single = {  # stage -> (kernel, substring of its name in the PMC table, algorithmic bytes, what they are)
+            "kmers:skm_dedupe": ("smx::k_skm_dedupe2", "k_skm_dedupe2", nslots * 8 * 2 * nw + D0 * (W + 1 + 4) + nchunks * 4 * 256,
+                                 "super-k-mer slots read once; per distinct k-mer its record, mask byte and link word written; 1 KB of group words per chunk"),
+            "kmers:skm_count": ("smx::k_skm_scan<0>", "k_skm_scan", n_reads * L / 4 + n_reads * 12 + nslots * (8 * 2 * nw + 8) + nslots * 16,
+                                "2-bit stream + window marks read; per super-k-mer a staged slot and its (partition, rank) word written, one 8-byte counter updated"),
+            "kmers:skm_scatter": ("smx::k_skm_permute", "k_skm_permute", nslots * (2 * 8 * 2 * nw + 8 + 8), "staged slots read and written at their place"),
+            "pm_tab": ("smx::k_pm_tab", "k_pm_tab", D0 * (1 + 4) + 2 * D0 * 8 + 2 * D0 * 4, "mask byte + link word read, two node-table entries and two jump words written per k-mer"),
+            "pm_remote": ("smx::k_pm_remote", "k_pm_remote", 2 * D0 * 8 + 0.1 * 2 * D0 * (W + 8 + 4 + W + 8),
+                          "node table scanned; per successor outside its chunk (~5 % of the nodes) the record, the partition word, a group word and the found record read, the entry written"),
+            "walk_len": ("smx::k_pm_walk_len", "k_pm_walk_len", n_cand * (8 + 2 * W + 4 + 3 * (4 + 16) + W + 8 * 3 + 1),
+                         "per start de-edge: its junction record, the first k-mer's group word and record, ~3 chunks crossed (jump word + node-table entry), the last record; length, first, last, flag written"),
+            "walk_write": ("smx::k_pm_walk_write", "k_pm_walk_write", ne * (8 * 6 + W + 3 * (4 + W + 16) + 32) + nbases / 4,
+                           "per kept path: its bookkeeping words, the start record, ~3 chunks crossed (jump word, far record, node-table entry), 2 bits per base and a 32-byte edge record written"),
+        }
+        cand_st = [(st_, ms_) for st_, ms_ in stages.items() if st_ in single]
+        if cand_st:
+            dst, fm = max(cand_st, key=lambda x: x[1])
+            dname, dkey, b_dom, what = single[dst]
+            tr = sum(v for n_, v in pmc_rows.items() if dkey in n_)
+            out["dominant_kernel"] = {"name": dname, "stage": dst, "ms": round(fm, 3), "algorithmic_bytes": int(b_dom), "algorithmic_bytes_are": what,
+                                      "achieved_GBps": round(b_dom / max(fm, 1e-9) / 1e6, 1), "frac": round(b_dom / max(fm, 1e-9) / 1e6 / 8000.0, 4),
+                                      "traffic_GB_recorded": round(tr, 1) if tr else None,
+                                      "traffic_source": (os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes on these very sources)") if tr else pmc_note}
     if rank == 0 and world == 1 and not args.force_sharded:
         class Wrap:
             def __init__(self, ptr, shape):
@@ -638,23 +666,45 @@ def main():
                 stn = KMerDiskCounter(None, sp).Count(nb)
                 return torch.as_tensor(Wrap(stn.device_ptr(), (stn.total_kmers(), nw)), device=dev)
 
-            def gpu_unitigs(n, threads):
-                g2 = GraphBuilder(k, threads, ctx)
-                g2.reads.clear()
-                g2.reads.push_back_packed(hw_s[:n * L // 32], hs[:n], hl[:n])
-                g2.build()
-                return [u.encode() for u in g2.unitigs()]
+            def gpu_graph_of(wn, sn, ln_, want_unitigs=True):
+                def f(n, threads):  # the GPU's default route on the same reads: unitigs + the k-mer file and masks materialised from its records
+                    ctx.graph_clear()
+                    g2 = GraphBuilder(k, threads, ctx)
+                    g2.reads.clear()
+                    g2.reads.push_back_packed(wn[:n * L // 32], sn[:n], ln_[:n])
+                    g2.build()
+                    took = g2.route_stats()["route"]
+                    us = [u.encode() for u in g2.unitigs()] if want_unitigs else []
+                    gk, gm = g2.kmers()
+                    checked_routes.append(took)
+                    return us, gk, gm
+                return f
 
+            checked_routes = []
             out["cpu_baseline"] = cpu_baseline_count(sample, K1, "B", nb, gpu_count, runs=max(1, args.cpu_runs))
             out["cpu_baseline"]["sample_regime"] = (f"{n_sample / 1e6:g} M of the {n_reads / 1e6:g} M bench reads = coverage {n_sample * L / args.genome:.1f}x of the "
                                                     f"{args.genome / 1e6:g} Mbp genome (the step itself runs at {n_reads * L / args.genome:.0f}x: more duplicates per distinct "
                                                     "k-mer, which favours the CPU's per-bucket sort less than the GPU's on-chip dedupe)")
-            n_con = int(min(args.cpu_sample_construct, n_sample)) // 32 * 32
+            n_con = int(args.cpu_sample_construct) // 32 * 32
             if not args.count_only and not args.cpu_count_only and n_con:
-                cb = cpu_baseline_construct(sample[:n_con], k, gpu_unitigs)
+                # a batch of its own in the step's regime (30x coverage: real junction density), not a thin slice of the bench genome
+                g_con = int(n_con * L / 30)
+                cw, cs, cl, ccodes = synth_reads_device(4242, g_con, n_con, dev, n_rate=args.n_rate)
+                cb = cpu_baseline_construct(ccodes.cpu(), k, gpu_graph_of(cw.cpu().numpy().view("uint64"), cs.cpu().numpy().view("uint64"), cl.cpu().numpy().view("uint32")),
+                                            runs=max(1, args.cpu_runs))
+                del cw, cs, cl, ccodes
                 if cb:
-                    cb["sample_regime"] = f"first {n_con / 1e6:g} M reads only (coverage {n_con * L / args.genome:.1f}x): one run of the reference classes takes {n_con / 1e6 / max(cb['value'], 1e-9):.0f} s"
+                    cb["sample_regime"] = (f"{n_con / 1e6:g} M reads of their own over a {g_con / 1e6:g} Mbp genome (coverage 30x like the step, same read model); "
+                                           f"GPU side of the check: construction route {checked_routes[-1] if checked_routes else '?'}")
                     out["cpu_baseline"]["construct"] = cb
+            n_msk = int(min(args.cpu_masks_sample, n_sample)) // 32 * 32
+            if not args.count_only and not args.cpu_count_only and n_msk:
+                # at size: the reference's extension index (k-mer file + InOutMask bytes) of the first n_msk bench reads against what the
+                # timed route leaves (the count the step is compared on must be the path it times)
+                cm = cpu_baseline_construct(sample[:n_msk], k, gpu_graph_of(hw_s, hs, hl, want_unitigs=False), runs=1, unitigs=False)
+                if cm:
+                    cm["gpu_route"] = checked_routes[-1] if checked_routes else None
+                    out["cpu_baseline"]["extension_index_at_size"] = cm
         if args.extra_kmercount > 0:
             # BASELINE config 2 shape at k=55 (the round-1 headline, kept for continuity): spades-kmercount mode, inputs resident in HBM
             ne_ = int(min(args.extra_kmercount, n_reads)) // 32 * 32

@@ -302,7 +302,8 @@ int smx_graph_info(const smx_ctx *ctx, uint64_t *info);
 int smx_graph_tip_stats(const smx_ctx *ctx, uint64_t *stats);
 /* How the last smx_build_graph went (engine diagnostics, no reference equivalent): stats[8] = { route: 0 no sort of the k-mers
  * ("pm_route"), 1 k-mers + masks from one count, sorted ("ext_route"), 2 (k+1)-mer file first; route 0: k-mers in chunks of whole
- * minimizer partitions, k-mers of cut partitions (sorted tail), chunks; junction k-mers; start de-edges; 0; 0 }. */
+ * minimizer partitions, k-mers of cut partitions (sorted tail), chunks; junction k-mers; start de-edges; route 0: super-k-mer slots of
+ * the count behind the graph; k-mer instances in super-k-mers that were folded away as identical copies }. */
 int smx_graph_route_stats(const smx_ctx *ctx, uint64_t *stats /* [8] */);
 /* k-mer file order: records [n_kmers * words] and InOutMask bytes (extension_index/inout_mask.hpp:55-221) */
 int smx_graph_copy_kmers(const smx_ctx *ctx, void *kmers_host, uint8_t *masks_host);

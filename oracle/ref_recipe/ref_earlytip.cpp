@@ -14,7 +14,9 @@
 //                                                                                                  early_simplification.hpp:164-347, construction.cpp:317-326
 //   spades-core edge order ("sorted" among the trailing arguments): the unitigs sorted by Sequence::RawCompare, as
 //                                     DeBruijnGraphExtentionConstructor::ConstructGraph does before ids are assigned   :590-604
-//   ref_earlytip <k> <nthreads> <tip_length_bound|0> <reads.txt> <workdir> <out.txt> [at] [sorted] [noloops]
+//   k-mer file + InOutMask bytes ("kmers=<path>"): the index's k-mers in file order (kmer_begin .. kmer_end, the order the MPHF indexes)
+//                                     as RtSeq words -> <path>, their masks (out bits 0-3, in bits 4-7) -> <path>.masks; "nounitigs" stops there
+//   ref_earlytip <k> <nthreads> <tip_length_bound|0> <reads.txt> <workdir> <out.txt> [at] [sorted] [noloops] [kmers=<path>] [nounitigs]
 //   out.txt: one edge sequence per line in the extractor's order (nthreads = 1 makes the order and the clipping deterministic)
 #include "line_splitter.hpp"
 #include "kmer_index/extension_index/kmer_extension_index_builder.hpp"
@@ -44,13 +46,34 @@ int main(int argc, char **argv) {
         auto kpomers = counter.Count(10 * nthreads, nthreads);
         kmers::DeBruijnExtensionIndexBuilder().BuildExtensionIndexFromKPOMers(tmp, index, kpomers, nthreads, 0);
     }
-    bool at = false, sorted = false, keep_loops = true;
+    bool at = false, sorted = false, keep_loops = true, unitigs = true;
+    std::string dump;
     for (int i = 7; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "at") at = true;
         if (a == "sorted") sorted = true;
         if (a == "noloops") keep_loops = false;
+        if (a == "nounitigs") unitigs = false;
+        if (a.rfind("kmers=", 0) == 0) dump = a.substr(6);
     }
+    if (!dump.empty()) {  // before any clipper touches the masks: the extension index as BuildExtensionIndexFromKPOMers left it
+        std::ofstream ok(dump, std::ios::binary), om(dump + ".masks", std::ios::binary);
+        const size_t nw = RtSeq::GetDataSize(k);
+        auto its = index.kmer_begin(1);  // (one part: the whole file, in order — as CollectLoops / ExtractUnbranchingPaths iterate it, :353-370)
+        for (auto &it = its.front(); it.good(); ++it) {
+            RtSeq kmer(k, *it);
+            auto kwh = index.ConstructKWH(kmer);
+            const auto mask = index.get_value(kwh);
+            unsigned char b = 0;
+            for (char c = 0; c < 4; ++c) {
+                if (mask.CheckOutgoing(c)) b |= (unsigned char) (1u << c);
+                if (mask.CheckIncoming(c)) b |= (unsigned char) (16u << c);
+            }
+            ok.write((const char *) kmer.data(), (std::streamsize) (nw * sizeof(RtSeq::DataType)));
+            om.put((char) b);
+        }
+    }
+    if (!unitigs) return 0;
     if (at) {
         debruijn_graph::EarlyLowComplexityClipperProcessor at_processor(index, 0.8, 10, 200);
         at_processor.RemoveATEdges();

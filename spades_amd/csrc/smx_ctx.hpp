@@ -54,6 +54,7 @@ struct PmState {
     uint32_t max_chunks = 0, nchunks = 0, T = 0, nkey = 0;
     unsigned m = 0, w = 0, pshift = 0;
     uint64_t nclean = 0, ndirty = 0;
+    uint64_t nslots = 0, nfolded = 0;   // super-k-mer slots of the count behind this graph; k-mer instances in slots that were folded away
     unsigned dirty_B = 1;               // the dirty region is sorted bucket-major in this many hash buckets
     std::vector<uint64_t> dirty_boff;   // their offsets
     void *dk = nullptr;  // the k-mers of the dirty region without their bytes (sorted: what its rank directory indexes)

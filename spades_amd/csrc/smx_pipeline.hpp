@@ -771,6 +771,10 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         if (la[2] || la[0] > list_cap) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication: the chunk plan outgrew its list (%llu entries)", (unsigned long long)list_cap);
         nlist = (uint32_t)la[0];
         nclean_chunks = la[1];
+        if (pmode) {
+            ctx->pm.nslots = nslots;
+            ctx->pm.nfolded = la[3];
+        }
         if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] prededupe: %llu instances in folded (identical) super-k-mers, %u list entries, %llu clean chunks\n", la[3], nlist, nclean_chunks);
     }
     if (pmode) {

@@ -232,6 +232,8 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     ctx->g_route_stats[1] = P.nclean;
     ctx->g_route_stats[2] = P.ndirty;
     ctx->g_route_stats[3] = P.nchunks;
+    ctx->g_route_stats[6] = P.nslots;
+    ctx->g_route_stats[7] = P.nfolded;
     rc = graph_from_masks<NW>(ctx, k, tab, /*tab_valid=*/true, d_err, gwt, /*present=*/true, &pw);
     if (rc) return bail(rc);
     // the count-result view: the k-mer file is made when somebody asks for it (pm_materialize_file)

@@ -70,7 +70,7 @@ class GraphBuilder:
         st = (C.c_uint64 * 8)()
         _chk(self.ctx._h, self.ctx.lib.smx_graph_route_stats(self.ctx._h, st))
         return dict(route=("pm", "ext", "kpo")[min(int(st[0]), 2)], kmers_in_chunks=int(st[1]), kmers_of_cut_partitions=int(st[2]), chunks=int(st[3]),
-                    junction_kmers=int(st[4]), start_de_edges=int(st[5]))
+                    junction_kmers=int(st[4]), start_de_edges=int(st[5]), superkmer_slots=int(st[6]), folded_instances=int(st[7]))
 
     def tip_stats(self):
         """(k-mers isolated, tips removed) by the early tip clipper and (A/T edges, A/T tip k-mers) by the early A/T remover of the
