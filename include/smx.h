@@ -57,6 +57,10 @@ void smx_destroy(smx_ctx *ctx);
  * (arena_trim in smx_ctx.hpp has the measurements), so the arena only grows while its context lives and goes back at smx_destroy; the
  * hipMalloc fallback (SMX_ARENA=malloc) frees its cached blocks. The context stays usable either way. */
 int smx_trim(smx_ctx *ctx, size_t *bytes_returned);
+/* Device memory the context holds but does not use right now (free blocks inside its arena, bytes): a neighbour that sizes its own
+ * work from the device's free memory (hipMemGetInfo) must add this — the arena only grows, so what the library released after a big
+ * step is invisible to the device-level figure. No reference equivalent (the reference has no device). */
+int smx_arena_free_bytes(smx_ctx *ctx, size_t *bytes);
 const char *smx_last_error(const smx_ctx *ctx);
 const char *smx_version(void);
 /* Options. Behaviour switches of the reference's spades-core Construction stage (defaults reproduce spades-gbuilder):

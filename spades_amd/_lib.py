@@ -42,6 +42,7 @@ def load():
         "smx_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_size_t]),
         "smx_destroy": (None, [vp]),
         "smx_trim": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+        "smx_arena_free_bytes": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
         "smx_graph_clear": (C.c_int, [vp]),
         "smx_last_error": (C.c_char_p, [vp]),
         "smx_version": (C.c_char_p, []),

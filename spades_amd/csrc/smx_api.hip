@@ -167,6 +167,7 @@ int smx_reads_clear(smx_ctx *ctx) {
             (void)hipEventDestroy(c.ev_meta);
             for (auto e : c.piece_ev) (void)hipEventDestroy(e);
             if (c.h_ext) (void)hipHostFree(c.h_ext);
+            arena_put(ctx, c.d_ext);
         }
         if (c.owned) {
             arena_put(ctx, c.d_words);
@@ -234,7 +235,7 @@ static int submit_packed_async(smx_ctx *ctx, const uint64_t *words, uint64_t n_w
         }
     }
     if (e != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "read upload failed: %s", hipGetErrorString(e)));
-    ctx->temps.push_back(d_ext);  // released with the temporaries of the call that uses the reads (the copy stream is done with it by then)
+    c.d_ext = d_ext;  // released with the chunk (smx_reads_clear, after its events): a free_temps() of some other call must not hand it out
     c.contigs = ctx->opt_submit_contigs != 0;
     ctx->chunks.push_back(c);
     return SMX_OK;
@@ -789,6 +790,18 @@ static int build_graph_impl(smx_ctx *ctx, unsigned k, unsigned num_buckets, cons
     free_temps(ctx);
     if (rc) clear_graph(ctx);
     return rc;
+}
+
+int smx_arena_free_bytes(smx_ctx *ctx, size_t *bytes) {
+    if (!ctx || !bytes) return SMX_INVALID_PARAMETER;
+    size_t cached = 0;
+    if (ctx->arena.vmm) {
+        for (auto &b : ctx->arena.free_blocks) cached += b.second;
+    } else {
+        for (auto &b : ctx->arena_free) cached += b.second;
+    }
+    *bytes = cached;
+    return SMX_OK;
 }
 
 int smx_graph_clear(smx_ctx *ctx) {

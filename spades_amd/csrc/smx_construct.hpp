@@ -47,6 +47,14 @@ void drop_kpo(smx_ctx *ctx) {
 
 void clear_graph(smx_ctx *ctx) {
     drop_kpo(ctx);
+    // the count-result view may BE this graph's k-mer file — pending (pm route: to be materialised on request) or shared (d_result ==
+    // g_kmers): with the graph gone there is nothing behind it any more, so it becomes an empty result (smx_bucket_sizes and
+    // smx_copy_final_kmers then report 0 records instead of indexing an empty offset table / copying from a freed block)
+    if (ctx->pm_view_pending || (ctx->g_kmers && ctx->d_result == ctx->g_kmers)) {
+        ctx->n_records = 0;
+        ctx->bucket_off.assign((size_t)ctx->num_buckets + 1, 0);
+        ctx->d_result = nullptr;
+    }
     if (ctx->g_kmers) {
         if (ctx->d_result == ctx->g_kmers) ctx->d_result = nullptr;
         arena_put(ctx, ctx->g_kmers);

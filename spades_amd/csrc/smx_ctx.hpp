@@ -17,6 +17,7 @@ struct ReadChunk {
     // piece_ev[p]: words [0, piece_end[p]) are there. Consumers make their stream wait (mark_windows; run_prededupe range by range).
     hipEvent_t ev_meta = nullptr;
     unsigned long long *h_ext = nullptr;
+    unsigned long long *d_ext = nullptr;  // device side of h_ext: lives as long as the chunk (the copy stream writes it long after the submit returned)
     std::vector<uint64_t> piece_end;
     std::vector<hipEvent_t> piece_ev;
 };

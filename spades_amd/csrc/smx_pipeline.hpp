@@ -124,7 +124,10 @@ int mark_windows(smx_ctx *ctx, unsigned K, std::vector<uint64_t *> &masks, uint6
     HIPCHK(hipMemcpyAsync(&t, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (auto &ch : ctx->chunks)
-        if (ch.h_ext && ch.h_ext[1]) return fail(ctx, SMX_INVALID_INPUT_FORMAT, "%llu reads exceed the packed stream", ch.h_ext[1]);
+        if (ch.h_ext) {  // (ev_meta has been waited for on this stream, and the stream is idle: the extent is there)
+            if (ch.h_ext[1]) return fail(ctx, SMX_INVALID_INPUT_FORMAT, "%llu reads exceed the packed stream", ch.h_ext[1]);
+            ch.n_bases = std::min<uint64_t>(ch.n_bases, ch.h_ext[0]);  // as the synchronous submission reports it
+        }
     *total = t;
     return 0;
 }

@@ -310,6 +310,13 @@ int pm_materialize_file(smx_ctx *ctx, bool for_view) {
         ctx->g_mask = nullptr;
         ctx->d_result = ctx->d_result_buf = nullptr;
         if (!for_view) restore_view();
+        else {
+            ctx->n_records = 0;
+            ctx->bucket_off.assign((size_t)ctx->num_buckets + 1, 0);
+        }
+        // the partition-major records were consumed and no file took their place: the graph has no k-mers to look up or copy any
+        // more — it is not a graph any longer (callers see "no graph" instead of a copy from a null block)
+        clear_graph(ctx);
         return rc;
     }
     ctx->g_nkpo = nkpo;

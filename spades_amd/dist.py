@@ -27,6 +27,7 @@ class CollectiveFailure(RuntimeError):
     def __init__(self, code: int, what: str, cause: Exception = None):
         super().__init__(f"{what}: " + (str(cause) if cause is not None else f"another rank failed with code {code}"))
         self.code = code
+        self.memory_only = code == _lib.MEMORY_LIMIT_EXCEEDED  # (_guarded sets it from what ALL ranks reported)
 
 
 def _staged(t: torch.Tensor) -> bool:
@@ -54,19 +55,36 @@ def _all_gather(outs, t: torch.Tensor):
         dist.all_gather(outs, t)
 
 
+def _error_code(err: Exception) -> int:
+    """the reference's exit code of a local failure: the library's own (.code), 68 for an allocator that ran out of HBM on the torch side
+    (torch.cuda.OutOfMemoryError carries no .code), 1 for anything else"""
+    code = getattr(err, "code", None)
+    if isinstance(code, int) and code:
+        return code
+    oom = getattr(getattr(torch, "cuda", None), "OutOfMemoryError", None)
+    if (oom is not None and isinstance(err, oom)) or isinstance(err, MemoryError):
+        return _lib.MEMORY_LIMIT_EXCEEDED
+    return 1
+
+
 def _guarded(dev, what: str, fn, *args):
-    """run a rank-local step between two collectives; every rank then learns (one tiny all-reduce) whether all of them got through"""
+    """run a rank-local step between two collectives; every rank then learns (one tiny all-reduce) whether all of them got through.
+    Two figures travel: the worst code any rank saw, and whether EVERY failure was a memory limit — only then may a caller fall back
+    to a leaner route; a genuine error on some other rank (invalid parameter, an exception) must not be swallowed by a rank's 68."""
     err, res = None, None
     try:
         res = fn(*args)
     except Exception as e:  # noqa: BLE001 — whatever it is, the other ranks must hear of it
         err = e
-    code = 0 if err is None else int(getattr(err, "code", 1) or 1)
-    t = torch.tensor([code], dtype=torch.int64, device=dev)
+    code = 0 if err is None else _error_code(err)
+    other = 1 if (code and code != _lib.MEMORY_LIMIT_EXCEEDED) else 0
+    t = torch.tensor([code, other], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    worst = int(t.item())
+    worst, any_other = int(t[0].item()), int(t[1].item())
     if worst:
-        raise CollectiveFailure(worst, what, err)
+        f = CollectiveFailure(worst, what, err)
+        f.memory_only = not any_other  # every rank that failed ran out of memory: the one condition a fallback may handle
+        raise f
     return res
 
 
@@ -123,6 +141,17 @@ class GpuEngine:
 
     def extract_release(self):
         _chk(self.ctx._h, self.ctx.lib.smx_extract_release(self.ctx._h))
+
+    def arena_free_bytes(self) -> int:
+        return self.ctx.arena_free_bytes()
+
+    def exchange_release(self):
+        """give back a receive buffer of the library's pool that no count consumed (a route abandoned between two collectives)"""
+        _chk(self.ctx._h, self.ctx.lib.smx_exchange_release(self.ctx._h))
+
+    def graph_clear(self):
+        """drop whatever shard / graph state the context holds (smx_graph_clear)"""
+        _chk(self.ctx._h, self.ctx.lib.smx_graph_clear(self.ctx._h))
 
     def count_records(self, K: int, nb: int, buf: torch.Tensor, n: int):
         h = self.ctx._h
@@ -720,12 +749,15 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
         except CollectiveFailure as e:
             # one rank's distinct k-mers did not fit where the one-exchange route needs them: EVERY rank heard of it (same exception
             # everywhere) and all take the other route together — the single-GPU library falls back the same way (SMX_ROUTE_NA)
-            if e.code != _lib.MEMORY_LIMIT_EXCEEDED or route == "ext":
+            if not getattr(e, "memory_only", False) or route == "ext":
                 raise
             ext = False
             send = recv = None
-            if hasattr(engine, "extract_release"):
-                engine.extract_release()
+            # a rank has just run out of HBM: everything the abandoned route left behind goes before the retry — the ranks whose
+            # shard_from_ext succeeded hold a shard (k-mers, masks, rank directory), and an unconsumed receive buffer may be resident
+            for rel in ("extract_release", "exchange_release", "graph_clear"):
+                if hasattr(engine, rel):
+                    getattr(engine, rel)()
             if not coverage:
                 n_kpo, kpo_sizes, kpo_mine = count_kpomers()
     if not ext:
@@ -761,7 +793,10 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
         need = sum(kmers_per_rank) * (2 * (8 * nw + 1) + 16)
         short = 0
         if dev.type == "cuda":
-            short = 1 if need > (2 * torch.cuda.mem_get_info(dev)[0]) // 3 else 0
+            # free HBM as this rank's library sees it: the device's figure + what the library's own arena holds unused (it only grows:
+            # the room a finished step left inside it is invisible to the device-level number)
+            free_b = torch.cuda.mem_get_info(dev)[0] + (engine.arena_free_bytes() if hasattr(engine, "arena_free_bytes") else 0)
+            short = 1 if need > (2 * free_b) // 3 else 0
         t_short = torch.tensor([short], dtype=torch.int64, device=dev)
         dist.all_reduce(t_short, op=dist.ReduceOp.MAX)
         walks = "distributed" if int(t_short.item()) else "gathered"

@@ -50,10 +50,18 @@ class Context:
 
     def set_option(self, key: str, value: int):
         _chk(self._h, self.lib.smx_set_option(self._h, key.encode(), int(value)))
+        if key == "async_upload":
+            self.async_upload = int(value) > 0  # (push_back_packed keeps its host arrays alive only then)
 
     def graph_clear(self):
         """smx_graph_clear: the graph of the last smx_build_graph gives its HBM back; reads stay resident"""
         _chk(self._h, self.lib.smx_graph_clear(self._h))
+
+    def arena_free_bytes(self) -> int:
+        """smx_arena_free_bytes: HBM the context holds but does not use right now (invisible to hipMemGetInfo: the arena only grows)"""
+        n = C.c_size_t()
+        _chk(self._h, self.lib.smx_arena_free_bytes(self._h, C.byref(n)))
+        return int(n.value)
 
     def trim(self) -> int:
         """smx_trim: unused device memory back to the device; returns the bytes (0 with the default arena: it only grows, include/smx.h)"""
@@ -116,8 +124,10 @@ class ReadKMerSplitter:
         words = np.ascontiguousarray(words, dtype=np.uint64)
         start = np.ascontiguousarray(start, dtype=np.uint64)
         length = np.ascontiguousarray(length, dtype=np.uint32)
-        # (option "async_upload": the call returns before the copy is done — the arrays stay referenced until the reads are cleared)
-        self._keep = getattr(self, "_keep", []) + [(words, start, length)]
+        # option "async_upload": the call returns before the copy is done — the arrays stay referenced until the reads are cleared
+        # (a synchronous submission has copied them when it returns: nothing is kept, however often the caller submits)
+        if getattr(self.ctx, "async_upload", False):
+            self._keep = getattr(self, "_keep", []) + [(words, start, length)]
         _chk(self.ctx._h, self.ctx.lib.smx_submit_reads_packed(
             self.ctx._h, words.ctypes.data_as(C.POINTER(C.c_uint64)), len(words),
             start.ctypes.data_as(C.POINTER(C.c_uint64)), length.ctypes.data_as(C.POINTER(C.c_uint32)), len(start)))

@@ -359,14 +359,14 @@ class _FailingEngine(OracleGraphEngine):
         return super().count_records(*a)
 
 
-def _failing_worker(rank, world, port, k, fail_rank, fail_in, code, route, q):
+def _failing_worker(rank, world, port, k, fail_rank, fail_in, code, route, q, other_code=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from spades_amd import dist as smx_dist
     reads = read_lines("reads_small.txt")[:120]
-    eng = _FailingEngine(reads[rank::world], reads, fail_in if rank == fail_rank else None, code)
+    eng = _FailingEngine(reads[rank::world], reads, fail_in if (rank == fail_rank or other_code) else None, code if rank == fail_rank else other_code)
     try:
         info = smx_dist.sharded_build_graph(eng, k, 1, rank, world, torch.device("cpu"), coverage=False, route=route)
         q.put((rank, "ok", info["route"], eng.g["gfa"]))
@@ -380,6 +380,7 @@ def _failing_worker(rank, world, port, k, fail_rank, fail_in, code, route, q):
     ("shard_from_ext", 68, "auto", "fallback"),   # memory limit on ONE rank: all ranks take the (k+1)-mer route together
     ("shard_from_ext", 70, "auto", "all_fail"),   # any other error: every rank raises
     ("count_records", 68, "kpomers", "all_fail"),  # no further route to fall back to
+    ("shard_from_ext", 68, "auto", "mixed"),      # a memory limit on one rank AND a genuine error (67) on the other: no fallback may swallow the 67
 ])
 def test_a_failing_rank_does_not_leave_the_others_waiting(fail_in, code, route, expect):
     from oracle import oracle
@@ -387,7 +388,8 @@ def test_a_failing_rank_does_not_leave_the_others_waiting(fail_in, code, route, 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 35500 + (os.getpid() % 2000) + code
-    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, k, 1, fail_in, code, route, q)) for r in range(world)]
+    port += 7 if expect == "mixed" else 0
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, k, 1, fail_in, code, route, q, 67 if expect == "mixed" else 0)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=180) for _ in range(world))

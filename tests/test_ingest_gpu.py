@@ -66,3 +66,29 @@ def test_other_formats_are_refused_untouched(text):
     assert e.value.code == 64  # SMX_INVALID_INPUT_FORMAT
     assert sp.ctx.reads_info()[0] == 0
     sp.ctx.close()
+
+
+def test_async_and_sync_submissions_can_be_mixed():
+    """An asynchronous packed submission (its extent check runs on the copy stream long after the call returned) followed by a
+    synchronous one (which releases the call's temporaries): the device block the asynchronous check writes to belongs to its read
+    chunk, not to the temporaries — the count equals that of two synchronous submissions (smx_api.hip submit_packed_async)."""
+    from spades_amd import KMerDiskCounter, ReadKMerSplitter
+    from spades_amd.kmercount import Context
+    rng = np.random.default_rng(11)
+    L, K, nb = 150, 25, 16
+    n_big = ((1 << 24) * 32) // L + 1000  # >= 2^24 words: the asynchronous path
+    res = []
+    for use_async in (True, False):
+        ctx = Context()
+        sp = ReadKMerSplitter(K, "B", ctx)
+        for n, asyn in ((n_big, use_async), (5000, False), (n_big // 4, use_async)):
+            words = rng.integers(0, 1 << 63, (n * L + 31) // 32 + 8, dtype=np.int64).view(np.uint64)
+            start = (np.arange(n, dtype=np.uint64) * L)
+            ln = np.full(n, L, dtype=np.uint32)
+            ctx.set_option("async_upload", 1 if asyn else 0)
+            sp.push_back_packed(words[:-8], start, ln)
+        st = KMerDiskCounter(None, sp).Count(nb)
+        res.append((st.total_kmers(), st.kmer_instances(), tuple(int(x) for x in st.bucket_sizes())))
+        ctx.close()
+        rng = np.random.default_rng(11)
+    assert res[0] == res[1]
