@@ -143,11 +143,13 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "skm_cap")) ctx->opt_skm_cap = value;
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;
     else if (!strcmp(key, "skm_fold")) ctx->opt_skm_fold = value;
+    else if (!strcmp(key, "two_strand")) ctx->opt_two_strand = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
     else if (!strcmp(key, "derive_batches")) ctx->opt_derive_batches = value;
     else if (!strcmp(key, "keep_kpo")) ctx->opt_keep_kpo = value;
     else if (!strcmp(key, "verify_lookups")) ctx->opt_verify_lookups = value;
     else if (!strcmp(key, "spill")) ctx->opt_spill = value;
+    else if (!strcmp(key, "single_batch")) ctx->opt_single_batch = value;
     else if (!strcmp(key, "kmers_from_reads")) ctx->opt_kmers_from_reads = value;
     else if (!strcmp(key, "ext_route")) ctx->opt_ext_route = value;
     else if (!strcmp(key, "pm_route")) ctx->opt_pm_route = value;
@@ -507,6 +509,7 @@ int smx_count(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     ctx->xnames.clear();
     ctx->xms.clear();
+    clear_result(ctx);  // the previous count's result goes first: the HBM plan of this one is made from what is free
     return dispatch_count(ctx, K, mode, num_buckets, nullptr, 0);
 }
 
@@ -544,6 +547,21 @@ int smx_count_info(const smx_ctx *ctx, uint64_t *n_records, unsigned *words_per_
     return SMX_OK;
 }
 
+// Two-strand result (smx_ctx::TwoStrand): bucket b merged into a device block of its own (caller releases it with arena_put)
+static int ts_bucket_block(smx_ctx *ctx, unsigned b, void **blk) {
+    const uint64_t n = ctx->bucket_off[b + 1] - ctx->bucket_off[b];
+    uint64_t *p = nullptr;
+    if (int rc = dalloc(ctx, &p, std::max<uint64_t>(n * ctx->nw, 1), false)) return rc;
+    int rc = ts_merge_bucket_any(ctx, b, p);
+    if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "two-strand merge failed");
+    if (rc) {
+        arena_put(ctx, p);
+        return rc;
+    }
+    *blk = p;
+    return SMX_OK;
+}
+
 int smx_bucket_sizes(const smx_ctx *ctx, uint64_t *sizes) {
     if (!ctx || !sizes) return SMX_INVALID_PARAMETER;
     if (int rc = ensure_kmer_file(const_cast<smx_ctx *>(ctx))) return rc;  // (a graph built without a sorted k-mer file: made now)
@@ -571,6 +589,14 @@ int smx_copy_bucket(const smx_ctx *cctx, unsigned bucket, void *host_dst) {
         return fail(ctx, SMX_DEVICE_ERROR, "bucket %u is not inside one chunk of the spilled result", bucket);
     }
     HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->ts.active) {  // the bucket is the merge of its two strands
+        void *blk = nullptr;
+        if (int rc = ts_bucket_block(ctx, bucket, &blk)) return rc;
+        const hipError_t e = hipMemcpy(host_dst, blk, n * w, hipMemcpyDeviceToHost);
+        arena_put(ctx, blk);
+        if (e != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "device read-back failed: %s", hipGetErrorString(e));
+        return SMX_OK;
+    }
     HIPCHK(hipMemcpy(host_dst, (const char *)ctx->d_result + o * w, n * w, hipMemcpyDeviceToHost));
     return SMX_OK;
 }
@@ -590,6 +616,18 @@ int smx_copy_final_kmers(const smx_ctx *cctx, void *host_dst) {
         return SMX_OK;
     }
     HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->ts.active) {
+        for (unsigned b = 0; b < ctx->num_buckets; ++b) {
+            const uint64_t o = ctx->bucket_off[b], n = ctx->bucket_off[b + 1] - o;
+            if (!n) continue;
+            void *blk = nullptr;
+            if (int rc = ts_bucket_block(ctx, b, &blk)) return rc;
+            const hipError_t e = hipMemcpy((char *)host_dst + o * ctx->nw * 8, blk, n * ctx->nw * 8, hipMemcpyDeviceToHost);
+            arena_put(ctx, blk);
+            if (e != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "device read-back failed: %s", hipGetErrorString(e));
+        }
+        return SMX_OK;
+    }
     HIPCHK(hipMemcpy(host_dst, ctx->d_result, ctx->n_records * ctx->nw * 8, hipMemcpyDeviceToHost));
     return SMX_OK;
 }
@@ -614,49 +652,67 @@ int smx_write_final_kmers(const smx_ctx *cctx, const char *path) {
     (void)hipSetDevice(ctx->device);
     // two page-locked buffers: the read-back of chunk i+1 runs while chunk i is written
     char *buf[2] = {nullptr, nullptr};
-    hipEvent_t ev[2];
+    hipEvent_t ev[2] = {nullptr, nullptr};
     bool pinned = total > 0;
     for (int i = 0; i < 2 && pinned; ++i)
         if (hipHostMalloc((void **)&buf[i], std::min(chunk, total), hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             pinned = false;
         }
-    int rc = SMX_OK;
-    if (pinned) {
+    if (pinned)
         for (int i = 0; i < 2; ++i) (void)hipEventCreate(&ev[i]);
-        auto issue = [&](size_t idx) {
-            const size_t o = idx * chunk, n = std::min(chunk, total - o);
-            if (hipMemcpyAsync(buf[idx & 1], (const char *)ctx->d_result + o, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
-            return hipEventRecord(ev[idx & 1], ctx->stream) == hipSuccess;
-        };
-        const size_t nchunks = (total + chunk - 1) / chunk;
-        bool ok = nchunks == 0 || issue(0);
-        for (size_t i = 0; i < nchunks && ok && rc == SMX_OK; ++i) {
-            if (i + 1 < nchunks) ok = issue(i + 1);
-            if (hipEventSynchronize(ev[i & 1]) != hipSuccess) ok = false;
-            const size_t n = std::min(chunk, total - i * chunk);
-            if (ok && fwrite(buf[i & 1], 1, n, f) != n) rc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
+    std::vector<char> hb(pinned ? 0 : std::min<size_t>(chunk, std::max<size_t>(total, 1)));
+    int rc = SMX_OK;
+    auto stream_out = [&](const char *src, size_t bytes) {  // one device block to the file
+        if (pinned) {
+            auto issue = [&](size_t idx) {
+                const size_t o = idx * chunk, n = std::min(chunk, bytes - o);
+                if (hipMemcpyAsync(buf[idx & 1], src + o, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+                return hipEventRecord(ev[idx & 1], ctx->stream) == hipSuccess;
+            };
+            const size_t nchunks = (bytes + chunk - 1) / chunk;
+            bool ok = nchunks == 0 || issue(0);
+            for (size_t i = 0; i < nchunks && ok && rc == SMX_OK; ++i) {
+                if (i + 1 < nchunks) ok = issue(i + 1);
+                if (hipEventSynchronize(ev[i & 1]) != hipSuccess) ok = false;
+                const size_t n = std::min(chunk, bytes - i * chunk);
+                if (ok && fwrite(buf[i & 1], 1, n, f) != n) rc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
+            }
+            (void)hipStreamSynchronize(ctx->stream);
+            if (!ok) rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
+        } else {
+            for (size_t o = 0; o < bytes && rc == SMX_OK; o += chunk) {
+                const size_t n = std::min(chunk, bytes - o);
+                if (hipMemcpy(hb.data(), src + o, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
+                else if (fwrite(hb.data(), 1, n, f) != n) rc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
+            }
         }
-        (void)hipStreamSynchronize(ctx->stream);
-        if (!ok) rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
-        for (int i = 0; i < 2; ++i) (void)hipEventDestroy(ev[i]);
+    };
+    if (ctx->ts.active) {  // two strands: bucket after bucket, each merged on the device first (kmer_index_builder.hpp:190-203 concatenates buckets too)
+        for (unsigned b = 0; b < ctx->num_buckets && rc == SMX_OK; ++b) {
+            const uint64_t n = ctx->bucket_off[b + 1] - ctx->bucket_off[b];
+            if (!n) continue;
+            void *blk = nullptr;
+            rc = ts_bucket_block(ctx, b, &blk);
+            if (rc == SMX_OK) {
+                stream_out((const char *)blk, n * (size_t)ctx->nw * 8);
+                arena_put(ctx, blk);
+            }
+        }
     } else {
-        std::vector<char> hb(std::min<size_t>(chunk, std::max<size_t>(total, 1)));
-        for (size_t o = 0; o < total && rc == SMX_OK; o += chunk) {
-            const size_t n = std::min(chunk, total - o);
-            if (hipMemcpy(hb.data(), (const char *)ctx->d_result + o, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
-            else if (fwrite(hb.data(), 1, n, f) != n) rc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
-        }
+        stream_out((const char *)ctx->d_result, total);
     }
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
         if (buf[i]) (void)hipHostFree(buf[i]);
+    }
     if (fclose(f) != 0 && rc == SMX_OK) rc = fail(ctx, SMX_IO_ERROR, "I/O error closing %s", path);
     return rc;
 }
 
 const void *smx_device_kmers(const smx_ctx *ctx) {
     if (!ctx || ensure_kmer_file(const_cast<smx_ctx *>(ctx))) return nullptr;
-    return ctx->d_result;
+    return ctx->d_result;  // (NULL for a result that is not one resident array: spilled to the host, or held as two strands)
 }
 
 unsigned smx_rank_first_bucket(unsigned num_buckets, unsigned world, unsigned rank) {
@@ -1184,6 +1240,12 @@ int smx_copy_kmers_device(const smx_ctx *cctx, void *d_dst) {
     if (int rc = ensure_kmer_file(ctx)) return rc;
     if (ctx->result_on_host) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the result was spilled to host memory (it does not fit the HBM budget)");
     HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->ts.active) {  // merged straight into the caller's block
+        for (unsigned b = 0; b < ctx->num_buckets; ++b)
+            if (int rc = ts_merge_bucket_any(ctx, b, (char *)d_dst + ctx->bucket_off[b] * ctx->nw * 8)) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return SMX_OK;
+    }
     HIPCHK(hipMemcpyAsync(d_dst, ctx->d_result, ctx->n_records * ctx->nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SMX_OK;

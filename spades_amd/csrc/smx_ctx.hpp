@@ -81,6 +81,14 @@ struct smx_ctx {
     };
     std::vector<HostChunk> h_result;
     bool result_on_host = false;
+    // ... or as the two strands of a both-strands count that is too large to hold merged (smx_pipeline.hpp: two_strand_finish): the
+    // sorted canonical set and the sorted set of its reverse complements, both bucket-major; the accessors merge bucket by bucket
+    struct TwoStrand {
+        bool active = false;
+        void *c = nullptr, *r = nullptr;
+        uint64_t nc = 0, nr = 0;
+        std::vector<uint64_t> boff_c, boff_r;
+    } ts;
     uint64_t g_ext_bits = 0, g_ext_pals = 0;  // extension bits / palindromic (k+1)-mers among them in the k-mer file or shard built from EXT records
     PmState pm;               // partition-major construction route
     uint64_t g_route_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // smx_graph_route_stats of the last build
@@ -104,6 +112,9 @@ struct smx_ctx {
     int64_t opt_early_tip_bound = 0;  // > 0: spades-core's early tip clipper with this length bound (RL - K there) before condensation
     int64_t opt_skm_stage = 1;     // pass 0 of the super-k-mer scan stages its output so that placing it needs no second scan
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
+    int64_t opt_two_strand = -1;  // both-strands count as canonical set + its reverse complements: -1 when the direct expansion does not fit HBM, 0 never,
+                                  // 1 always (merged into one array when that fits), 2 always and left unmerged (tests of the bucket-wise accessors)
+    int64_t opt_single_batch = 0;  // 1: a count that does not fit one batch fails with the memory limit instead of taking batches / spilling (probes at size)
     int64_t opt_spill = -1;  // sorted runs to host memory + merge by bucket ranges: -1 when the accumulated set outgrows HBM, 1 always (tests)
     int64_t opt_verify_lookups = 0;  // 1: rank lookups of k-mers that are known to be present still compare the record
     int64_t opt_dir_slots = -1;        // rank directory: slots per record (-1: 2, or 1 next to a resident (k+1)-mer file)

@@ -1223,4 +1223,95 @@ __global__ void k_bucket_offsets(const unsigned long long *uoff, uint32_t num_bu
     if (b <= num_buckets) bucket_off[b] = uoff[(uint64_t)b * bins_per_bucket];
 }
 
+
+// ---- two-strand result of a both-strands count (spades-kmercount: every k-mer of read and reverse complement, kmercount.cpp:48-122) --
+// The set is closed under reverse complement: it is the sorted canonical set C and the sorted set R = RC(C) (minus the k-mers that are
+// their own reverse complement, which C holds), bucket by bucket merged. k_ts_rc makes R's records; k_ts_merge merges one bucket.
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_ts_rc(const void *c_, uint64_t n, unsigned K, void *r_, unsigned long long *count /* K even: records written */) {
+    const Rec<NW> *c = (const Rec<NW> *)c_;
+    Rec<NW> *r = (Rec<NW> *)r_;
+    __shared__ uint32_t scratch[BLK / 64 + 2];
+    __shared__ unsigned long long s_base;
+    const bool odd = K & 1u;  // no k-mer of odd length is its own reverse complement: R[i] = RC(C[i]), nothing to leave out
+    constexpr int PER = 16;
+    for (uint64_t t0 = (uint64_t)blockIdx.x * BLK * PER; t0 < n; t0 += (uint64_t)gridDim.x * BLK * PER) {
+        if (odd) {
+#pragma unroll 4
+            for (int j = 0; j < PER; ++j) {
+                const uint64_t i = t0 + (uint64_t)j * BLK + threadIdx.x;
+                if (i < n) r[i] = rec_rc<NW>(c[i], K);
+            }
+            continue;
+        }
+        Rec<NW> y[PER];
+        uint32_t keep = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint64_t i = t0 + (uint64_t)j * BLK + threadIdx.x;
+            if (i < n) {
+                const Rec<NW> x = c[i];
+                y[j] = rec_rc<NW>(x, K);
+                if (!rec_eq<NW>(x, y[j])) keep |= 1u << j;
+            }
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<uint32_t>(__popc(keep), scratch, &tot);
+        if (threadIdx.x == 0) s_base = tot ? atomicAdd(count, (unsigned long long)tot) : 0ull;
+        __syncthreads();
+        uint64_t o = s_base + ex;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (keep & (1u << j)) r[o++] = y[j];
+        __syncthreads();
+    }
+}
+
+// merge of two sorted, disjoint record arrays (merge path): tiles of TS_TILE outputs; the two splits of a tile by binary search in
+// HBM, its inputs staged in LDS, every thread merges TS_TILE / BLK consecutive outputs from its own split
+constexpr int TS_TILE = BLK * 8;
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_ts_merge(const void *a_, uint64_t na, const void *b_, uint64_t nb, void *out_) {
+    const Rec<NW> *A = (const Rec<NW> *)a_, *Bv = (const Rec<NW> *)b_;
+    Rec<NW> *out = (Rec<NW> *)out_;
+    extern __shared__ __attribute__((aligned(16))) uint64_t ts_lds[];
+    Rec<NW> *st = (Rec<NW> *)ts_lds;  // [TS_TILE]: the tile's part of A, then its part of B
+    __shared__ uint64_t s_split[2];
+    const uint64_t total = na + nb, ntiles = (total + TS_TILE - 1) / TS_TILE;
+    auto split = [&](uint64_t d) -> uint64_t {  // elements of A among the first d outputs (A before B on ties: there are none)
+        uint64_t lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (rec_less<NW>(A[mid], Bv[d - 1 - mid])) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    };
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t d0 = tile * TS_TILE, d1 = d0 + TS_TILE < total ? d0 + TS_TILE : total;
+        __syncthreads();
+        if (threadIdx.x < 2) s_split[threadIdx.x] = split(threadIdx.x ? d1 : d0);
+        __syncthreads();
+        const uint64_t a0 = s_split[0], a1 = s_split[1], b0 = d0 - a0, b1 = d1 - a1;
+        const uint32_t ca = (uint32_t)(a1 - a0), cb = (uint32_t)(b1 - b0);
+        for (uint32_t i = threadIdx.x; i < ca; i += BLK) st[i] = A[a0 + i];
+        for (uint32_t i = threadIdx.x; i < cb; i += BLK) st[ca + i] = Bv[b0 + i];
+        __syncthreads();
+        const uint32_t n = ca + cb, dd = min(threadIdx.x * 8u, n), de = min(dd + 8u, n);
+        uint32_t lo = dd > cb ? dd - cb : 0, hi = dd < ca ? dd : ca;  // local merge path
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rec_less<NW>(st[mid], st[ca + dd - 1 - mid])) lo = mid + 1;
+            else hi = mid;
+        }
+        uint32_t ia = lo, ib = dd - lo;
+        for (uint32_t o = dd; o < de; ++o) {
+            const bool ta = ib >= cb || (ia < ca && rec_less<NW>(st[ia], st[ca + ib]));
+            out[d0 + o] = ta ? st[ia] : st[ca + ib];
+            ia += ta ? 1u : 0u;
+            ib += ta ? 0u : 1u;
+        }
+    }
+}
+
 }  // namespace smx

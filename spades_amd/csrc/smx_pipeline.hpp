@@ -139,6 +139,11 @@ void clear_result(smx_ctx *ctx) {
     ctx->result_on_host = false;
     if (ctx->d_result_buf) arena_put(ctx, ctx->d_result_buf);
     ctx->d_result_buf = ctx->d_result = nullptr;
+    if (ctx->ts.active) {
+        arena_put(ctx, ctx->ts.c);
+        arena_put(ctx, ctx->ts.r);
+        ctx->ts = smx_ctx::TwoStrand();
+    }
     ctx->n_records = 0;
     ctx->bucket_off.clear();
 }
@@ -916,6 +921,111 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     return 0;
 }
 
+// ---- both-strands count as two strands (spades-kmercount at sizes where 2 x the records do not fit twice) ------------------------
+// The reference counts every k-mer of read and reverse complement (kmercount.cpp:48-122): the result is closed under reverse
+// complement, i.e. it is C u RC(C) for the canonical set C. Direct expansion sorts 2|C| records and needs two buffers of them next to
+// C (5 W |C| bytes: 343 GB at BASELINE config 3). Here C is sorted (one bucket-major array), R = RC(C) is sorted (a second one), and a
+// bucket of the result is the merge of the two buckets — made at once into one array when that fits, else left to the accessors
+// (smx_copy_bucket, smx_write_final_kmers, ...: one bucket at a time). Peak 3 W |C|, resident 2 W |C|.
+template <int NW>
+int ts_merge_bucket(smx_ctx *ctx, unsigned b, void *d_dst) {
+    const smx_ctx::TwoStrand &t = ctx->ts;
+    const uint64_t ca = t.boff_c[b], na = t.boff_c[b + 1] - ca, cb = t.boff_r[b], nb = t.boff_r[b + 1] - cb;
+    if (na + nb == 0) return 0;
+    const size_t lds = (size_t)TS_TILE * sizeof(Rec<NW>);
+    if (int rc = set_lds(ctx, k_ts_merge<NW>, lds)) return rc;
+    const uint64_t ntiles = (na + nb + TS_TILE - 1) / TS_TILE;
+    hipLaunchKernelGGL((k_ts_merge<NW>), dim3((unsigned)std::min<uint64_t>(ntiles, 256 * 8)), dim3(BLK), lds, ctx->stream,
+                       (const void *)((const Rec<NW> *)t.c + ca), na, (const void *)((const Rec<NW> *)t.r + cb), nb, d_dst);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int ts_merge_bucket_any(smx_ctx *ctx, unsigned b, void *d_dst) {
+    switch (ctx->nw) {
+        case 1: return ts_merge_bucket<1>(ctx, b, d_dst);
+        case 2: return ts_merge_bucket<2>(ctx, b, d_dst);
+        case 3: return ts_merge_bucket<3>(ctx, b, d_dst);
+        default: return ts_merge_bucket<4>(ctx, b, d_dst);
+    }
+}
+
+// after a canonical count of the reads (result in ctx): the reverse complements, sorted, and the two-strand view (or its merge)
+template <int NW>
+int two_strand_finish(smx_ctx *ctx, unsigned K, unsigned B) {
+    smx_ctx::TwoStrand t;
+    t.c = ctx->d_result_buf;
+    t.nc = ctx->n_records;
+    t.boff_c = ctx->bucket_off;
+    detach_temp(ctx, t.c);
+    ctx->d_result_buf = ctx->d_result = nullptr;
+    free_temps(ctx);
+    auto bail = [&](int code) {
+        arena_put(ctx, t.c);
+        arena_put(ctx, t.r);
+        return code;
+    };
+    Rec<NW> *raw;
+    unsigned long long *d_cnt;
+    if (int rc = dalloc(ctx, &raw, t.nc + 1)) return bail(rc);
+    if (int rc = dalloc(ctx, &d_cnt, 1)) return bail(rc);
+    HIPCHK(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+    tbegin(ctx, "ts_rc");
+    if (t.nc) {
+        hipLaunchKernelGGL((k_ts_rc<NW>), dim3((unsigned)std::min<uint64_t>((t.nc + BLK * 16 - 1) / (BLK * 16), 256 * 16)), dim3(BLK), 0, ctx->stream, (const void *)t.c,
+                           t.nc, K, (void *)raw, d_cnt);
+        HIPCHK(hipGetLastError());
+    }
+    tend(ctx);
+    unsigned long long nr = t.nc;
+    if (!(K & 1u)) {
+        HIPCHK(hipMemcpyAsync(&nr, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    // (run_count starts with clear_result: the context holds nothing of this count at the moment; C is in `t`)
+    if (int rc = run_count<NW>(ctx, K, SMX_MODE_CANONICAL, B, raw, nr, nullptr, /*recs_reusable=*/true, /*expand_rc=*/false, /*distinct_hint=*/true)) return bail(rc);
+    if (ctx->n_records != nr) return bail(fail(ctx, SMX_DEVICE_ERROR, "two-strand count: %llu reverse complements, %llu after their sort", nr, (unsigned long long)ctx->n_records));
+    t.r = ctx->d_result_buf;
+    t.nr = ctx->n_records;
+    t.boff_r = ctx->bucket_off;
+    detach_temp(ctx, t.r);
+    ctx->d_result_buf = ctx->d_result = nullptr;
+    free_temps(ctx);
+    ctx->bucket_off.assign((size_t)B + 1, 0);
+    for (unsigned b = 0; b <= B; ++b) ctx->bucket_off[b] = t.boff_c[b] + t.boff_r[b];
+    ctx->n_records = t.nc + t.nr;
+    ctx->K = K;
+    ctx->nw = NW;
+    ctx->num_buckets = B;
+    ctx->ts = t;
+    ctx->ts.active = true;
+    // one array when there is room for it next to the two strands
+    const size_t bytes = (size_t)ctx->n_records * sizeof(Rec<NW>);
+    if (ctx->opt_two_strand != 2 && bytes && arena_avail(ctx) > bytes + ((size_t)1 << 28)) {
+        Rec<NW> *m = nullptr;
+        if (dalloc(ctx, &m, ctx->n_records + 1, false) == 0) {
+            tbegin(ctx, "ts_merge");
+            int rc = 0;
+            for (unsigned b = 0; b < B && rc == 0; ++b) rc = ts_merge_bucket<NW>(ctx, b, (void *)(m + ctx->bucket_off[b]));
+            tend(ctx);
+            if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "two-strand merge failed");
+            if (rc) {
+                arena_put(ctx, m);
+                const uint64_t n = ctx->n_records;
+                clear_result(ctx);
+                (void)n;
+                return rc;
+            }
+            arena_put(ctx, ctx->ts.c);
+            arena_put(ctx, ctx->ts.r);
+            ctx->ts = smx_ctx::TwoStrand();
+            ctx->d_result_buf = ctx->d_result = m;
+        } else {
+            ctx->err.clear();  // (no room after all: the view stays in two strands)
+        }
+    }
+    return 0;
+}
+
 // One pipeline run over a selection of the resident reads: straight from the windows, or through the pre-dedupe stage.
 template <int NW>
 bool prededupe_applies(const smx_ctx *ctx, unsigned K, uint64_t nwin) {
@@ -934,7 +1044,8 @@ int count_selection(smx_ctx *ctx, unsigned K, int mode, unsigned B, const ReadSe
     {
         const double W = NW * 8.0, avail = (double)arena_avail(ctx);
         const double fit1 = (avail - 5.0 * (double)nwin) / W;
-        const double fit2 = avail / (mode == SMX_MODE_ALL ? 5.0 * W + 24 : 2.0 * W + 12);
+        // (both strands: the canonical set, its reverse complements and one ping-pong buffer — two_strand_finish — unless that route is off)
+        const double fit2 = avail / (mode == SMX_MODE_ALL ? (ctx->opt_two_strand != 0 ? 3.0 * W + 2 : 5.0 * W + 24) : 2.0 * W + 12);
         const double fit = std::max(std::min(fit1, fit2), 1.0);
         if (fit < (double)nwin) out_cap = (uint64_t)fit;
     }
@@ -943,6 +1054,16 @@ int count_selection(smx_ctx *ctx, unsigned K, int mode, unsigned B, const ReadSe
     if (int rc = run_prededupe<NW>(ctx, K, sel, nwin, &recs, &n, out_cap)) return rc;
     free_temps(ctx, recs);
     ctx->temps.push_back(recs);
+    if (mode == SMX_MODE_ALL && ctx->opt_two_strand != 0) {
+        // direct expansion needs two buffers of 2 n records next to the n records that are there; else (or on request) two strands
+        const double need = 4.0 * (double)n * NW * 8 + 24.0 * (double)n;
+        if (ctx->opt_two_strand > 0 || need > (double)arena_avail(ctx)) {
+            if (int rc = run_count<NW>(ctx, K, SMX_MODE_CANONICAL, B, recs, n, nullptr, /*recs_reusable=*/true, /*expand_rc=*/false, /*distinct_hint=*/true)) return rc;
+            if (int rc = two_strand_finish<NW>(ctx, K, B)) return rc;
+            ctx->n_instances = sel.nrec;
+            return 0;
+        }
+    }
     if (int rc = run_count<NW>(ctx, K, mode, B, recs, n, nullptr, /*recs_reusable=*/mode != SMX_MODE_ALL, mode == SMX_MODE_ALL, /*distinct_hint=*/true)) return rc;
     ctx->n_instances = sel.nrec;
     return 0;
@@ -1000,13 +1121,16 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
     };
     for (;; nbatch = std::max<uint64_t>(2, 2 * nbatch)) {  // one trip unless the pre-dedupe output overflowed
         if (nbatch > (1u << 16)) return cleanup(fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the distinct k-mers do not fit the HBM budget"));
-        if (nbatch > 1 && ctx->single_batch_only) return cleanup(fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "one batch does not fit the HBM budget"));
+        if (nbatch > 1 && (ctx->single_batch_only || ctx->opt_single_batch)) return cleanup(fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "one batch does not fit the HBM budget"));
         if (nbatch <= 1) {
             ReadSel sel;
             sel.masks = &masks;
             sel.nrec = nrec;
             rc = count_selection<NW>(ctx, K, mode, B, sel);
             if (rc == SMX_RETRY_SMALLER || rc == SMX_MEMORY_LIMIT_EXCEEDED) {  // (an allocation can also fail on a fragmented arena)
+                if (getenv("SMX_DEBUG"))
+                    fprintf(stderr, "[smx] count_reads: one batch did not work (%s%s): %llu windows, %.1f GB obtainable\n", rc == SMX_RETRY_SMALLER ? "pre-dedupe output overflowed" : "allocation failed: ",
+                            rc == SMX_RETRY_SMALLER ? "" : ctx->err.c_str(), (unsigned long long)nwin, (double)arena_avail(ctx) / 1e9);
                 free_temps(ctx);
                 clear_result(ctx);
                 continue;
