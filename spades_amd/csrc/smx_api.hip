@@ -7,12 +7,16 @@
 #include "smx_graph.hip"
 #include "smx_pm.hip"
 #include "smx_dwalk.hip"
+#include "smx_gfa.hip"
 #include "smx_graph_host.hpp"
 
 #include <algorithm>
 #include <execinfo.h>
 #include <csignal>
 #include <unistd.h>
+#include <fcntl.h>
+#include <atomic>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -144,6 +148,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;
     else if (!strcmp(key, "skm_fold")) ctx->opt_skm_fold = value;
     else if (!strcmp(key, "two_strand")) ctx->opt_two_strand = value;
+    else if (!strcmp(key, "device_gfa")) ctx->opt_device_gfa = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
     else if (!strcmp(key, "derive_batches")) ctx->opt_derive_batches = value;
     else if (!strcmp(key, "keep_kpo")) ctx->opt_keep_kpo = value;
@@ -547,6 +552,65 @@ int smx_count_info(const smx_ctx *ctx, uint64_t *n_records, unsigned *words_per_
     return SMX_OK;
 }
 
+// Device memory -> file: a ring of page-locked buffers; while the calling thread writes one chunk, the copies of the next ones run.
+// (One writer: on tmpfs — where the tools' outputs are measured — 8 pwrite threads on one file reached 3.4 GB/s, a single thread 6.4:
+// page allocation serialises on the inode.) Used by the k-mer file and the GFA text writers.
+struct DevToFile {
+    static constexpr int NBUF = 4;
+    size_t chunk = (size_t)64 << 20;
+    char *buf[NBUF] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[NBUF] = {nullptr, nullptr, nullptr, nullptr};
+    bool wok = true;
+    int nbuf = 0;
+    size_t seq = 0;  // chunks issued so far (a buffer per chunk, round robin)
+    bool init(size_t total) {
+        chunk = std::min(chunk, std::max<size_t>(total, 1));
+        for (; nbuf < NBUF && (size_t)nbuf * chunk < total + chunk; ++nbuf)
+            if (hipHostMalloc((void **)&buf[nbuf], chunk, hipHostMallocDefault) != hipSuccess || hipEventCreate(&ev[nbuf]) != hipSuccess) {
+                (void)hipGetLastError();
+                if (buf[nbuf]) (void)hipHostFree(buf[nbuf]);
+                buf[nbuf] = nullptr;
+                break;
+            }
+        return nbuf > 0;
+    }
+    // bytes [0, n) of device block src -> file offset off; returns false on a device error (I/O errors: wok)
+    bool send(hipStream_t st, int fd, off_t off, const char *src, size_t n) {
+        const size_t nchunks = (n + chunk - 1) / chunk;
+        size_t issued = 0;
+        std::vector<int> bof(nchunks);
+        auto issue = [&](size_t c) {  // (its buffer was written out by this thread before: free)
+            const int b = (int)(seq++ % (size_t)nbuf);
+            bof[c] = b;
+            const size_t o = c * chunk, m = std::min(chunk, n - o);
+            return hipMemcpyAsync(buf[b], src + o, m, hipMemcpyDeviceToHost, st) == hipSuccess && hipEventRecord(ev[b], st) == hipSuccess;
+        };
+        for (size_t c = 0; c < nchunks; ++c) {
+            while (issued < nchunks && issued < c + (size_t)nbuf)
+                if (!issue(issued++)) return false;
+            const int b = bof[c];
+            if (hipEventSynchronize(ev[b]) != hipSuccess) return false;
+            const size_t o = c * chunk, m = std::min(chunk, n - o);
+            size_t w = 0;
+            while (w < m && wok) {
+                const ssize_t r = pwrite(fd, buf[b] + w, m - w, off + (off_t)(o + w));
+                if (r <= 0) wok = false;
+                else w += (size_t)r;
+            }
+        }
+        return true;
+    }
+    bool finish() {
+        for (int i = 0; i < NBUF; ++i) {
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (buf[i]) (void)hipHostFree(buf[i]);
+            ev[i] = nullptr;
+            buf[i] = nullptr;
+        }
+        return wok;
+    }
+};
+
 // Two-strand result (smx_ctx::TwoStrand): bucket b merged into a device block of its own (caller releases it with arena_put)
 static int ts_bucket_block(smx_ctx *ctx, unsigned b, void **blk) {
     const uint64_t n = ctx->bucket_off[b + 1] - ctx->bucket_off[b];
@@ -648,64 +712,35 @@ int smx_write_final_kmers(const smx_ctx *cctx, const char *path) {
         return hrc;
     }
     const size_t total = ctx->n_records * (size_t)ctx->nw * 8;
-    const size_t chunk = (size_t)64 << 20;
     (void)hipSetDevice(ctx->device);
-    // two page-locked buffers: the read-back of chunk i+1 runs while chunk i is written
-    char *buf[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    bool pinned = total > 0;
-    for (int i = 0; i < 2 && pinned; ++i)
-        if (hipHostMalloc((void **)&buf[i], std::min(chunk, total), hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            pinned = false;
-        }
-    if (pinned)
-        for (int i = 0; i < 2; ++i) (void)hipEventCreate(&ev[i]);
-    std::vector<char> hb(pinned ? 0 : std::min<size_t>(chunk, std::max<size_t>(total, 1)));
+    if (fflush(f) != 0) {
+        fclose(f);
+        return fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path);
+    }
+    const int fd = fileno(f);
     int rc = SMX_OK;
-    auto stream_out = [&](const char *src, size_t bytes) {  // one device block to the file
-        if (pinned) {
-            auto issue = [&](size_t idx) {
-                const size_t o = idx * chunk, n = std::min(chunk, bytes - o);
-                if (hipMemcpyAsync(buf[idx & 1], src + o, n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
-                return hipEventRecord(ev[idx & 1], ctx->stream) == hipSuccess;
-            };
-            const size_t nchunks = (bytes + chunk - 1) / chunk;
-            bool ok = nchunks == 0 || issue(0);
-            for (size_t i = 0; i < nchunks && ok && rc == SMX_OK; ++i) {
-                if (i + 1 < nchunks) ok = issue(i + 1);
-                if (hipEventSynchronize(ev[i & 1]) != hipSuccess) ok = false;
-                const size_t n = std::min(chunk, bytes - i * chunk);
-                if (ok && fwrite(buf[i & 1], 1, n, f) != n) rc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
+    DevToFile d2f;
+    if (total && !d2f.init(total)) rc = fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "no page-locked memory for the read-back");
+    if (rc == SMX_OK && total) {
+        if (ctx->ts.active) {  // two strands: bucket after bucket, each merged on the device first (kmer_index_builder.hpp:190-203 concatenates buckets too)
+            for (unsigned b = 0; b < ctx->num_buckets && rc == SMX_OK; ++b) {
+                const uint64_t n = ctx->bucket_off[b + 1] - ctx->bucket_off[b];
+                if (!n) continue;
+                void *blk = nullptr;
+                rc = ts_bucket_block(ctx, b, &blk);
+                if (rc == SMX_OK) {
+                    if (!d2f.send(ctx->stream, fd, (off_t)(ctx->bucket_off[b] * (size_t)ctx->nw * 8), (const char *)blk, n * (size_t)ctx->nw * 8))
+                        rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
+                    (void)hipStreamSynchronize(ctx->stream);  // (the block goes back to the arena: its copies must be over)
+                    arena_put(ctx, blk);
+                }
             }
-            (void)hipStreamSynchronize(ctx->stream);
-            if (!ok) rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
-        } else {
-            for (size_t o = 0; o < bytes && rc == SMX_OK; o += chunk) {
-                const size_t n = std::min(chunk, bytes - o);
-                if (hipMemcpy(hb.data(), src + o, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
-                else if (fwrite(hb.data(), 1, n, f) != n) rc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
-            }
+        } else if (!d2f.send(ctx->stream, fd, 0, (const char *)ctx->d_result, total)) {
+            rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
         }
-    };
-    if (ctx->ts.active) {  // two strands: bucket after bucket, each merged on the device first (kmer_index_builder.hpp:190-203 concatenates buckets too)
-        for (unsigned b = 0; b < ctx->num_buckets && rc == SMX_OK; ++b) {
-            const uint64_t n = ctx->bucket_off[b + 1] - ctx->bucket_off[b];
-            if (!n) continue;
-            void *blk = nullptr;
-            rc = ts_bucket_block(ctx, b, &blk);
-            if (rc == SMX_OK) {
-                stream_out((const char *)blk, n * (size_t)ctx->nw * 8);
-                arena_put(ctx, blk);
-            }
-        }
-    } else {
-        stream_out((const char *)ctx->d_result, total);
     }
-    for (int i = 0; i < 2; ++i) {
-        if (ev[i]) (void)hipEventDestroy(ev[i]);
-        if (buf[i]) (void)hipHostFree(buf[i]);
-    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (!d2f.finish() && rc == SMX_OK) rc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
     if (fclose(f) != 0 && rc == SMX_OK) rc = fail(ctx, SMX_IO_ERROR, "I/O error closing %s", path);
     return rc;
 }
@@ -1351,16 +1386,133 @@ int smx_graph_copy_coverage(const smx_ctx *ctx, uint32_t *raw_coverage) {
     return SMX_OK;
 }
 
+// Device-formatted GFA (smx_gfa.hip). Returns 1 when this writer does not apply (link records on the host, no room for the text):
+// the caller then takes the host writer.
+static int write_gfa_device(smx_ctx *ctx, const char *path, const char *flavour) {
+    const uint64_t ne = ctx->g_ne, nv = ctx->g_nv;
+    if (!ctx->g_links_dev || ne == 0 || ctx->opt_device_gfa == 0) return 1;
+    const bool cov = ctx->gh.ecov.size() == ne;
+    std::vector<void *> mine;  // device blocks of this call
+    auto done = [&](int code) {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void *p : mine) arena_put(ctx, p);
+        return code;
+    };
+    auto take = [&](auto **p, size_t n) {
+        const int rc = dalloc(ctx, p, std::max<size_t>(n, 1), false);
+        if (rc == 0) mine.push_back((void *)*p);
+        return rc;
+    };
+    unsigned long long *soff, *loff, *d_nl;
+    uint32_t *d_taglen = nullptr;
+    unsigned long long *d_tagoff = nullptr;
+    char *d_pool = nullptr;
+    if (take(&soff, ne + 1) || take(&loff, nv + 1) || take(&d_nl, 1)) {
+        ctx->err.clear();
+        return done(1);
+    }
+    // coverage tags: "\tDP:f:%g\tKC:i:%u\n" per edge, formatted by the host threads ("DP:f:" << float(cov): ostream default = %g)
+    if (cov) {
+        std::vector<unsigned long long> elen;
+        if (int rc = d2h(ctx, elen, ctx->g_elen, ne)) return done(rc);
+        std::vector<uint32_t> tl(ne);
+        std::vector<unsigned long long> to(ne + 1, 0);
+        const unsigned k = ctx->g_k;
+        const uint32_t *ec = ctx->gh.ecov.data();
+        auto fmt = [&](size_t i, char *t) {
+            const double c = (double)ec[i] / (double)(elen[i] - k);
+            return snprintf(t, 64, "\tDP:f:%g\tKC:i:%u\n", (double)(float)c, ec[i]);
+        };
+        smxh::parallel_blocks(ne, (size_t)1 << 16, [&](size_t b, size_t e) {
+            char t[64];
+            for (size_t i = b; i < e; ++i) tl[i] = (uint32_t)fmt(i, t);
+        });
+        for (size_t i = 0; i < ne; ++i) to[i + 1] = to[i] + tl[i];
+        std::vector<char> pool(to[ne] + 64);
+        smxh::parallel_blocks(ne, (size_t)1 << 16, [&](size_t b, size_t e) {
+            char t[64];
+            for (size_t i = b; i < e; ++i) {
+                fmt(i, t);
+                memcpy(pool.data() + to[i], t, tl[i]);
+            }
+        });
+        if (take(&d_taglen, ne) || take(&d_tagoff, ne + 1) || take(&d_pool, pool.size())) {
+            ctx->err.clear();
+            return done(1);
+        }
+        HIPCHK(hipMemcpyAsync(d_taglen, tl.data(), ne * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_tagoff, to.data(), (ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_pool, pool.data(), pool.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    const unsigned g1 = (unsigned)std::min<uint64_t>((ne + BLK - 1) / BLK, 256 * 16), g2 = (unsigned)std::min<uint64_t>((nv + BLK - 1) / BLK, 256 * 16);
+    hipLaunchKernelGGL(k_gfa_s_len, dim3(g1), dim3(BLK), 0, ctx->stream, (const unsigned long long *)ctx->g_elen, ne, (const uint32_t *)d_taglen, soff);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(d_nl, 0, 8, ctx->stream));
+    if (nv) {
+        hipLaunchKernelGGL((k_gfa_l<false>), dim3(std::max(g2, 1u)), dim3(BLK), 0, ctx->stream, (const Rec<2> *)ctx->g_lrecs, ctx->g_nlrec, ctx->g_lsh,
+                           (const unsigned long long *)ctx->g_vstart, nv, (const uint8_t *)ctx->g_eself, ctx->g_k, loff, d_nl, (const unsigned long long *)nullptr, (char *)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    if (int rc = scan_u64(ctx, soff, soff, ne)) return done(rc);
+    if (nv)
+        if (int rc = scan_u64(ctx, loff, loff, nv)) return done(rc);
+    unsigned long long ts = 0, tl_ = 0, nlinks = 0;
+    HIPCHK(hipMemcpyAsync(&ts, soff + ne, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (nv) HIPCHK(hipMemcpyAsync(&tl_, loff + nv, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&nlinks, d_nl, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_temps(ctx);  // (the scans' scratch)
+    const size_t total = (size_t)ts + (size_t)tl_;
+    char *text;
+    if (take(&text, total + 64)) {  // no room for the text next to the graph: the host writer streams it block by block
+        ctx->err.clear();
+        return done(1);
+    }
+    hipLaunchKernelGGL(k_gfa_s_write, dim3(std::max(g1, 1u)), dim3(BLK), 0, ctx->stream, (const uint64_t *)ctx->g_uwords, (const unsigned long long *)ctx->g_eoffw,
+                       (const unsigned long long *)ctx->g_elen, ne, (const unsigned long long *)soff, (const char *)d_pool, (const unsigned long long *)d_tagoff, text);
+    HIPCHK(hipGetLastError());
+    if (nv) {
+        hipLaunchKernelGGL((k_gfa_l<true>), dim3(std::max(g2, 1u)), dim3(BLK), 0, ctx->stream, (const Rec<2> *)ctx->g_lrecs, ctx->g_nlrec, ctx->g_lsh,
+                           (const unsigned long long *)ctx->g_vstart, nv, (const uint8_t *)ctx->g_eself, ctx->g_k, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                           (const unsigned long long *)loff, text + ts);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // to the file: the header, then the text through a ring of page-locked buffers; every buffer is written by several pwrite threads
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return done(fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path));
+    const std::string head = std::string("H\tsp:Z:") + flavour + "\n";
+    bool ok = write(fd, head.data(), head.size()) == (ssize_t)head.size();
+    DevToFile d2f;
+    if (!d2f.init(total)) ok = false;
+    if (ok && !d2f.send(ctx->stream, fd, (off_t)head.size(), text, total)) ok = false;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (!d2f.finish()) ok = false;
+    if (close(fd) != 0) ok = false;
+    ctx->gh.n_links = nlinks;
+    if (!ok) return done(fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path));
+    return done(SMX_OK);
+}
+
 int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_version) {
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
     if (!ctx->g_ready) return fail(ctx, SMX_INVALID_PARAMETER, "no graph built");
     (void)hipSetDevice(ctx->device);
+    const char *fv = flavour_version ? flavour_version : "SPAdes-4.3.0-dev";
     const double t0 = wall_now();
+    {
+        const int rc = write_gfa_device(ctx, path, fv);  // the text formatted on the device; 1: this graph takes the host writer
+        if (rc != 1) {
+            if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] write_gfa: formatted on the device, %.3f s\n", wall_now() - t0);
+            return rc;
+        }
+    }
     if (int rc = materialize_host(ctx)) return rc;
     const double t1 = wall_now();
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
-    bool ok = smxh::write_gfa(ctx->gh, f, flavour_version ? flavour_version : "SPAdes-4.3.0-dev");
+    bool ok = smxh::write_gfa(ctx->gh, f, fv);
     if (fclose(f) != 0) ok = false;
     if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] write_gfa: graph to the host %.3f s, text %.3f s\n", t1 - t0, wall_now() - t1);
     return ok ? SMX_OK : fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path);

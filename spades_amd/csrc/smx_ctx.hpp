@@ -111,6 +111,7 @@ struct smx_ctx {
     int64_t opt_early_at = 0;         // 1: the early A/T remover of the RNA pipelines before the tip clipper
     int64_t opt_early_tip_bound = 0;  // > 0: spades-core's early tip clipper with this length bound (RL - K there) before condensation
     int64_t opt_skm_stage = 1;     // pass 0 of the super-k-mer scan stages its output so that placing it needs no second scan
+    int64_t opt_device_gfa = 1;    // GFA text formatted on the device when the link records live there (0: always the host writer)
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
     int64_t opt_two_strand = -1;  // both-strands count as canonical set + its reverse complements: -1 when the direct expansion does not fit HBM, 0 never,
                                   // 1 always (merged into one array when that fits), 2 always and left unmerged (tests of the bucket-wise accessors)
