@@ -31,7 +31,7 @@
 namespace smx {
 
 #ifndef SMX_WPE
-#define SMX_WPE 4
+#define SMX_WPE 5  // waves per SIMD the dedupe kernel is compiled for (96 VGPRs, a few spilled: 119.0 -> 115.8 ms against 4 at config 3)
 #endif
 #ifndef SMX_SB
 #define SMX_SB 2
@@ -132,50 +132,65 @@ __global__ void __launch_bounds__(BLK) k_skm_plan(uint64_t *__restrict__ slots, 
             ksg[t] = n > SKM_FOLD_KEY_MAX ? sg : 0u;
             __syncthreads();
             unsigned nfold = 0;
-            for (uint32_t i = t; i < (uint32_t)SN; i += BLK) {
-                uint32_t lo = 0, hi = SKM_KEYS_PER_ITEM;  // key of slot S0 + i: koff[lo] <= S0 + i < koff[lo + 1]
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (koff[mid] <= S0 + i) lo = mid;
-                    else hi = mid;
-                }
-                if (koff[lo + 1] - koff[lo] > SKM_FOLD_KEY_MAX) continue;
-                uint64_t w[SW];
-                const uint64_t *ps = slots + (S0 + i) * SW;
+            constexpr int FB = 4;  // slots per thread in flight: their words are loaded together (the loop is bound by the latency of those loads)
+            for (uint32_t i0 = t; i0 < (uint32_t)SN; i0 += FB * BLK) {
+                uint64_t wq[FB][SW];
 #pragma unroll
-                for (int q = 0; q < SW; ++q) w[q] = ps[q];
-                const uint32_t c = (uint32_t)(w[SW - 1] >> 56), sets = (uint32_t)(w[SW - 1] >> 48) & 0xFFu;
-                w[SW - 1] &= ~(0xFFull << 48);  // what must be equal: the bases and the window count
-                uint32_t h = 0x9E3779B1u;
+                for (int f = 0; f < FB; ++f) {
+                    const uint32_t i = i0 + (uint32_t)f * BLK;
+                    if (i < (uint32_t)SN) {
+                        const uint64_t *ps = slots + (S0 + i) * SW;
 #pragma unroll
-                for (int q = 0; q < SW; ++q) h = (h ^ (uint32_t)w[q] ^ __builtin_rotateleft32((uint32_t)(w[q] >> 32), 13)) * 0x85EBCA6Bu;
-                h ^= h >> 15;
-                h *= 0xC2B2AE35u;
-                h ^= h >> 16;
-                const uint32_t ent = (h & 0xFFFF0000u) | i;
-                h &= SKM_FOLD_TAB - 1;
-                bool dup = false;
-                for (;;) {
-                    const uint32_t o = atomicCAS(&ftab[h], 0xFFFFFFFFu, ent);
-                    if (o == 0xFFFFFFFFu) break;
-                    if ((o ^ ent) >> 16 == 0) {  // same tag: compare with the slot that sits there (L2 has it)
-                        const uint64_t *po = slots + (S0 + (o & 0xFFFFu)) * SW;
-                        bool eq = true;
-#pragma unroll
-                        for (int q = 0; q < SW; ++q) eq &= (q == SW - 1 ? (po[q] & ~(0xFFull << 48)) : po[q]) == w[q];
-                        if (eq) {
-                            if (sets) atomicOr((unsigned long long *)(po + SW - 1), (unsigned long long)sets << 48);
-                            dup = true;
-                            break;
-                        }
+                        for (int q = 0; q < SW; ++q) wq[f][q] = ps[q];
                     }
-                    h = (h + 1) & (SKM_FOLD_TAB - 1);
                 }
-                if (dup) {
-                    slots[(S0 + i) * SW + SW - 1] = w[SW - 1] & ~(0xFFull << 56);  // no window of its own any more
-                    nfold += c;
-                } else {
-                    atomicAdd(&ksg[lo], (c + SEG - 1) / SEG);
+#pragma unroll
+                for (int f = 0; f < FB; ++f) {
+                    const uint32_t i = i0 + (uint32_t)f * BLK;
+                    if (i >= (uint32_t)SN) break;
+                    uint32_t lo = 0, hi = SKM_KEYS_PER_ITEM;  // key of slot S0 + i: koff[lo] <= S0 + i < koff[lo + 1]
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (koff[mid] <= S0 + i) lo = mid;
+                        else hi = mid;
+                    }
+                    if (koff[lo + 1] - koff[lo] > SKM_FOLD_KEY_MAX) continue;
+                    uint64_t w[SW];
+#pragma unroll
+                    for (int q = 0; q < SW; ++q) w[q] = wq[f][q];
+                    const uint32_t c = (uint32_t)(w[SW - 1] >> 56), sets = (uint32_t)(w[SW - 1] >> 48) & 0xFFu;
+                    w[SW - 1] &= ~(0xFFull << 48);  // what must be equal: the bases and the window count
+                    uint32_t h = 0x9E3779B1u;
+#pragma unroll
+                    for (int q = 0; q < SW; ++q) h = (h ^ (uint32_t)w[q] ^ __builtin_rotateleft32((uint32_t)(w[q] >> 32), 13)) * 0x85EBCA6Bu;
+                    h ^= h >> 15;
+                    h *= 0xC2B2AE35u;
+                    h ^= h >> 16;
+                    const uint32_t ent = (h & 0xFFFF0000u) | i;
+                    h &= SKM_FOLD_TAB - 1;
+                    bool dup = false;
+                    for (;;) {
+                        const uint32_t o = atomicCAS(&ftab[h], 0xFFFFFFFFu, ent);
+                        if (o == 0xFFFFFFFFu) break;
+                        if ((o ^ ent) >> 16 == 0) {  // same tag: compare with the slot that sits there (L2 has it)
+                            const uint64_t *po = slots + (S0 + (o & 0xFFFFu)) * SW;
+                            bool eq = true;
+#pragma unroll
+                            for (int q = 0; q < SW; ++q) eq &= (q == SW - 1 ? (po[q] & ~(0xFFull << 48)) : po[q]) == w[q];
+                            if (eq) {
+                                if (sets) atomicOr((unsigned long long *)(po + SW - 1), (unsigned long long)sets << 48);
+                                dup = true;
+                                break;
+                            }
+                        }
+                        h = (h + 1) & (SKM_FOLD_TAB - 1);
+                    }
+                    if (dup) {
+                        slots[(S0 + i) * SW + SW - 1] = w[SW - 1] & ~(0xFFull << 56);  // no window of its own any more
+                        nfold += c;
+                    } else {
+                        atomicAdd(&ksg[lo], (c + SEG - 1) / SEG);
+                    }
                 }
             }
             if (nfold) atomicAdd(&s_folded, (unsigned long long)nfold);
