@@ -666,16 +666,17 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         HIPCHK(hipStreamSynchronize(ctx->stream));
         const double typical_slots = hs[0] ? (double)hs[1] / (double)hs[0] : 0.0;
         const double typical_inst = typical_slots * (double)nwin / (double)nslots;
-        // A bigger chunk costs occupancy for EVERY partition (8192 instances: one workgroup per CU, measured 5x slower), a cut partition
-        // only costs its own k-mers a trip through the sort (measured on log-normal abundances + low complexity: 39 % of the slots in
-        // cut partitions at 2048 cost less than the halved occupancy of 4096). So the capacity follows the bulk of the partitions, not
-        // the heavy tail: the smallest one that leaves at most 60 % of the slots in partitions that will be cut (uniformly deep
-        // coverage moves to 4096 / 8192) — and 2048 where even 8192 does not.
+        // A cut partition sends its k-mers through the sort and, on the route that never sorts the k-mers, into the sorted tail whose
+        // lookups are the slow ones; a bigger chunk costs the dedupe kernel occupancy (its workgroup grows with the chunk: 4096 instances
+        // = 512 threads and 55 KB of LDS, 8192 = 1024 threads and 100 KB). Measured on log-normal abundances + repeats + low complexity
+        // (38.8 / 20.0 / 10.4 % of the slots in partitions beyond 2048 / 4096 / 8192 instances), whole config-3 step: 808 ms at 2048,
+        // 705 at 4096, 701 at 8192 (dedupe alone 89 / 103 / 126 ms; round 3's kernel was 5x slower at 8192). So: the smallest capacity
+        // that leaves at most a quarter of the slots in partitions that will be cut, 4096 where even 8192 does not.
         const double ips = (double)nwin / (double)nslots;  // instances per slot on average
         uint32_t pick = 0;
         for (uint32_t c = 2048, t = 0; c <= 8192 && !pick; c <<= 1, ++t)
-            if ((double)hs[2 + t] <= 0.6 * (double)hs[0]) pick = c;
-        cap = pick ? pick : 2048;
+            if ((double)hs[2 + t] <= 0.25 * (double)hs[0]) pick = c;
+        cap = pick ? pick : 4096;
         if (getenv("SMX_DEBUG"))
             fprintf(stderr, "[smx] prededupe: typical partition %.0f slots = %.0f instances; slots in partitions beyond 2048/4096/8192 instances: %.1f%% %.1f%% %.1f%% -> chunk capacity %u\n",
                     typical_slots, typical_inst, hs[0] ? 100.0 * hs[2] / hs[0] : 0.0, hs[0] ? 100.0 * hs[3] / hs[0] : 0.0, hs[0] ? 100.0 * hs[4] / hs[0] : 0.0, cap);

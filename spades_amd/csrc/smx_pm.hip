@@ -141,11 +141,12 @@ __device__ __forceinline__ unsigned pm_palindromes(const Rec<NW> &x, unsigned m,
 }
 __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t maxn, const uint8_t *__restrict__ mask,
                                                 const uint32_t *__restrict__ llink, node_t *tab, uint32_t *jmp, unsigned long long *stats, uint32_t *err,
-                                                unsigned long long *prof) {
+                                                unsigned long long *prof, uint32_t *rbits /* [nchunks * (maxn >> 4)]: bit nd of a chunk's words = node nd asks k_pm_remote */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pm_lds[];
     uint32_t *jw = pm_lds;
     uint16_t *list = (uint16_t *)(jw + 2 * maxn);
     uint32_t *hp = (uint32_t *)(list + 2 * maxn);  // bit nd: some local link leads to node nd
+    uint32_t *rm = hp + (maxn >> 4);               // bit nd: the successor of node nd is not in this chunk (for k_pm_remote)
     __shared__ uint32_t s_nhead;
     unsigned long long bits = 0;
     // SMX_DEBUG: prof[0..3] = 100 MHz ticks of thread 0 (stage, node table, chain heads, jumps), [4] chunks, [5] successors outside their chunk, [6] chain heads
@@ -162,7 +163,10 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
         const uint64_t base = ci & PM_BASE_MASK;
         const uint32_t n = (uint32_t)(ci >> PM_BASE_BITS), nn = 2 * n;
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < (maxn >> 4); t += BLK) hp[t] = 0;
+        for (uint32_t t = threadIdx.x; t < (maxn >> 4); t += BLK) {
+            hp[t] = 0;
+            rm[t] = 0;
+        }
         if (threadIdx.x == 0) s_nhead = 0;
         if (cid + gridDim.x < nchunks) ci = cinfo[cid + gridDim.x];  // the next chunk's descriptor flies while this one is worked on
         __syncthreads();
@@ -192,6 +196,7 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
                         }
                     } else {  // not next to it in any super-k-mer: k_pm_remote looks it up through the partition table
                         e[o] |= TAB_NODE_MASK;
+                        atomicOr(&rm[(2 * r + o) >> 5], 1u << ((2 * r + o) & 31u));
                         if (prof) ++pc[0];
                     }
                 }
@@ -201,6 +206,7 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
         }
         __syncthreads();
         PM_T(1)
+        for (uint32_t t = threadIdx.x; t < (maxn >> 4); t += BLK) rbits[(size_t)cid * (maxn >> 4) + t] = rm[t];
         for (uint32_t nd = threadIdx.x; nd < nn; nd += BLK)  // chain heads: a local successor, no local predecessor
             if (jw[nd] != 0xFFFFu && !((hp[nd >> 5] >> (nd & 31u)) & 1u)) list[atomicAdd(&s_nhead, 1u)] = (uint16_t)nd;
         __syncthreads();
@@ -235,42 +241,52 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
     for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o, 64);
     if ((threadIdx.x & 63) == 0 && bits) atomicAdd(&stats[0], bits);
 }
-// The successors k_pm_tab did not find in the node's own chunk (~5 % of the nodes; their entries carry TAB_NODE_MASK in the node field):
-// tiles of PMR_TILE table entries, the marked ones compacted into an LDS list, then a dense loop in which every lane has a lookup —
-// minimizer scan of the successor k-mer, partition table, the other chunk's group word, the record. (Left inside k_pm_tab's per-node
-// loop, nearly every wave paid that path for its few misses: 62 of 80 us per chunk.)
-constexpr int PMR_TILE = BLK * 16;
+// The successors k_pm_tab did not find in the node's own chunk (~5 % of the nodes; their entries carry TAB_NODE_MASK in the node field and
+// their bit in the chunk's words of rbits): a wave takes a chunk, expands its bits (64 words at a time) into an LDS list of its own, then
+// a dense loop in which every lane has a lookup — minimizer scan of the successor k-mer, partition table, the other
+// chunk's group word, the record. (Left inside k_pm_tab's per-node loop, nearly every wave paid that path for its few misses: 62 of 80 us
+// per chunk. Round 3 found the marked nodes by scanning the whole node table: 69 GB read for 3 GB of answers.)
+constexpr int PMR_CH = BLK / 64;
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_pm_remote(PmIndex ix, uint64_t n_nodes, unsigned k, node_t *tab, uint32_t *err) {
-    __shared__ uint16_t lst[PMR_TILE];
-    __shared__ uint32_t s_n;
+__global__ void __launch_bounds__(BLK) k_pm_remote(PmIndex ix, const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t wpc /* words of rbits per chunk */,
+                                                   const uint32_t *__restrict__ rbits, unsigned k, node_t *tab, uint32_t *err) {
+    __shared__ uint16_t lst[PMR_CH][64 * 32];  // per wave: the marked local nodes of 64 words of its chunk
     const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
-    const uint64_t ntiles = (n_nodes + PMR_TILE - 1) / PMR_TILE;
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t t0 = tile * PMR_TILE;
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
-#pragma unroll 4
-        for (int j = 0; j < PMR_TILE / BLK; ++j) {
-            const uint32_t li = (uint32_t)j * BLK + threadIdx.x;
-            if (t0 + li < n_nodes && (tab[t0 + li] & TAB_NODE_MASK) == TAB_NODE_MASK && uniq4(tab_out4(tab[t0 + li]))) lst[atomicAdd(&s_n, 1u)] = (uint16_t)li;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint16_t *my = lst[wave];
+    for (uint32_t cid = blockIdx.x * PMR_CH + wave; cid < nchunks; cid += gridDim.x * PMR_CH) {  // (a wave per chunk: no workgroup barrier in here)
+        const uint64_t base = cinfo[cid] & PM_BASE_MASK;
+        for (uint32_t w0 = 0; w0 < wpc; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            const uint32_t bits = w < wpc ? rbits[(size_t)cid * wpc + w] : 0u;
+            const uint32_t cnt = __popc(bits);
+            uint32_t inc = cnt;  // inclusive scan over the wave
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d, 64);
+                if ((int)lane >= d) inc += o;
+            }
+            const uint32_t n = __shfl(inc, 63, 64);
+            uint32_t at = inc - cnt;
+            for (uint32_t b = bits; b; b &= b - 1) my[at++] = (uint16_t)(w * 32u + (uint32_t)__ffs(b) - 1u);
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (uint32_t i = lane; i < n; i += 64) {
+                const node_t node = 2 * base + my[i];
+                const Rec<NW> raw = recs[node >> 1];
+                const unsigned m = (unsigned)(raw.w[NW - 1] & 0xFFu), o = (unsigned)(node & 1);
+                const unsigned mo = (o ? brev8(m) : m) & 15u;
+                unsigned yo;
+                const Rec<NW> y = pm_succ_kmer<NW>(rec_pure<NW>(raw), k, o, mo, yo);
+                const node_t ry = pm_find<NW>(ix, y);
+                node_t e = (node_t)mo << TAB_OUT_SHIFT;
+                if (ry == NODE_NONE) atomicAdd(err, 1u);
+                else e |= (ry << 1) | yo;
+                tab[node] = e;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
-        const uint32_t n = s_n;
-        for (uint32_t i = threadIdx.x; i < n; i += BLK) {
-            const node_t node = t0 + lst[i];
-            const Rec<NW> raw = recs[node >> 1];
-            const unsigned m = (unsigned)(raw.w[NW - 1] & 0xFFu), o = (unsigned)(node & 1);
-            const unsigned mo = (o ? brev8(m) : m) & 15u;
-            unsigned yo;
-            const Rec<NW> y = pm_succ_kmer<NW>(rec_pure<NW>(raw), k, o, mo, yo);
-            const node_t ry = pm_find<NW>(ix, y);
-            node_t e = (node_t)mo << TAB_OUT_SHIFT;
-            if (ry == NODE_NONE) atomicAdd(err, 1u);
-            else e |= (ry << 1) | yo;
-            tab[node] = e;
-        }
-        __syncthreads();
     }
 }
 // ... and of the dirty region: every successor through the partition table; no jumps (delta 0, 0 steps)

@@ -189,8 +189,13 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     if (hipMemsetAsync(d_err, 0, 4, ctx->stream) != hipSuccess || hipMemsetAsync(stats, 0, 16, ctx->stream) != hipSuccess)
         return bail(fail(ctx, SMX_DEVICE_ERROR, "counter reset failed"));
     const uint32_t maxn = P.T / 2;  // winners of a chunk <= its instance capacity
-    const size_t lds = (size_t)maxn * 8 + (size_t)maxn * 4 + (size_t)(maxn >> 4) * 4 + 16;
+    const size_t lds = (size_t)maxn * 8 + (size_t)maxn * 4 + 2 * (size_t)(maxn >> 4) * 4 + 16;
     if ((rc = set_lds(ctx, k_pm_tab, lds))) return bail(rc);
+    // per chunk maxn / 16 words: the nodes whose successor lies in another chunk (k_pm_tab marks, k_pm_remote looks up)
+    const uint32_t wpc = maxn >> 4;
+    uint32_t *rbits = nullptr;
+    if ((rc = dalloc(ctx, &rbits, (size_t)std::max<uint32_t>(P.nchunks, 1) * wpc))) return bail(rc);
+    if (hipMemsetAsync(rbits, 0, (size_t)std::max<uint32_t>(P.nchunks, 1) * wpc * 4, ctx->stream) != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "counter reset failed"));
     unsigned long long *prof = nullptr;
     if (getenv("SMX_DEBUG")) {
         if ((rc = dalloc(ctx, &prof, 8))) return bail(rc);
@@ -199,14 +204,14 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     tbegin(ctx, "pm_tab");
     if (P.nchunks)
         hipLaunchKernelGGL(k_pm_tab, dim3(std::min<uint32_t>(P.nchunks, 256 * 16)), dim3(BLK), lds, ctx->stream, (const unsigned long long *)P.cinfo, P.nchunks,
-                           maxn, (const uint8_t *)ctx->g_mask, (const uint32_t *)P.llink, tab, jmp, stats, d_err, prof);
+                           maxn, (const uint8_t *)ctx->g_mask, (const uint32_t *)P.llink, tab, jmp, stats, d_err, prof, rbits);
     if (P.ndirty)
         hipLaunchKernelGGL((k_pm_tab_dirty<NW>), dim3(grid_for(P.ndirty)), dim3(BLK), 0, ctx->stream, pw.ix, (uint64_t)P.ndirty, k, tab, jmp, stats, d_err);
     tend(ctx);
     tbegin(ctx, "pm_remote");
-    if (P.nclean)
-        hipLaunchKernelGGL((k_pm_remote<NW>), dim3((unsigned)std::min<uint64_t>((2 * P.nclean + PMR_TILE - 1) / PMR_TILE, 256 * 32)), dim3(BLK), 0, ctx->stream, pw.ix,
-                           (uint64_t)(2 * P.nclean), k, tab, d_err);
+    if (P.nchunks)
+        hipLaunchKernelGGL((k_pm_remote<NW>), dim3((unsigned)std::min<uint64_t>((P.nchunks + PMR_CH - 1) / PMR_CH, 256 * 32)), dim3(BLK), 0, ctx->stream, pw.ix,
+                           (const unsigned long long *)P.cinfo, P.nchunks, wpc, (const uint32_t *)rbits, k, tab, d_err);
     tend(ctx);
     if (hipGetLastError() != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "k_pm_tab launch failed"));
     unsigned long long hs[2] = {0, 0}, hpal = 0;
