@@ -542,23 +542,24 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         back |= (tags >> 2) & 1
         return tags, back, junc
 
-    # 1. successors of the chain k-mers, first nodes of the start de-edges. tab: pointer (-1 once the chain end is known), hops to it,
-    #    last chain k-mer, end node — one row each, one column per local oriented node
+    # 1. successors of the chain k-mers, first nodes of the start de-edges. State of a local oriented node: ONE packed word + one byte
+    #    (round 3 kept four int64 rows + two more int64 arrays per node: 110 B per owned k-mer; this is 18 B):
+    #      word  F << 63 | T << 62 | id << 24 | hops      F: the end of the chain is known; T: this node IS the end (its successor is a
+    #            open:      id = pointer, hops = steps to it    junction k-mer); id: 38 bits (2.7e11 nodes), hops: 24 bits (a chain of
+    #            tail (T):  id = the junction node behind it    more than 16.7 M k-mers is refused)
+    #            finished:  id = the tail of its chain, hops = steps to the tail
+    #      byte  bit 0 chain k-mer (non-junction), bit 1 its successor is a junction k-mer, bits 2-3 its outgoing nucleotide
     n2 = 2 * n_mine
+    FBIT, TBIT, IDM, HM = -(1 << 63), 1 << 62, (1 << 38) - 1, (1 << 24) - 1
+    if 2 * first[-1] > IDM:
+        raise ValueError(f"{first[-1]} k-mers: node ids beyond 38 bits")
     tags, node, junc = lookup(False)
     xl = tags >> 4
-    tab = torch.empty((4, n2), dtype=torch.int64, device=dev)
-    nonj = torch.zeros(n2, dtype=torch.bool, device=dev)
-    sj = torch.zeros(n2, dtype=torch.bool, device=dev)
-    code = torch.zeros(n2, dtype=torch.uint8, device=dev)
-    tab[0].fill_(-1)
-    tab[0][xl] = node
-    del node
-    nonj[xl] = True
-    sj[xl] = junc
-    del junc
-    code[xl] = (tags & 3).to(torch.uint8)
-    del tags, xl
+    word = torch.zeros(n2, dtype=torch.int64, device=dev)
+    flag = torch.zeros(n2, dtype=torch.uint8, device=dev)
+    word[xl] = torch.where(junc, node << 24 | (FBIT | TBIT), node << 24 | 1)  # tails know their end node; the others: pointer, one step
+    flag[xl] = (1 | (junc.to(torch.int64) << 1) | ((tags & 3) << 2)).to(torch.uint8)
+    del node, junc, tags, xl
     ctags, cfirst, cjunc = lookup(True)
     n_cand = ctags.numel()
     ci = ctags >> 4
@@ -567,24 +568,17 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     c_first[ci] = cfirst
     c_fj[ci] = cjunc
     del ctags, cfirst, cjunc, ci
-    ends_here = nonj & sj
-    tab[3].copy_(tab[0])
-    tab[3].masked_fill_(~ends_here, -1)
-    if n2:
-        torch.arange(base, base + n2, dtype=torch.int64, device=dev, out=tab[2])
-    tab[2].masked_fill_(~ends_here, -1)
-    del ends_here
-    open_ = nonj & ~sj
-    tab[0].masked_fill_(~open_, -1)
-    tab[1].copy_(open_)
-    del open_
+
+    def is_open(w, f):
+        return ((f & 1) != 0) & (w >= 0)
 
     mark("successor lookups")
     # 2. pointer doubling over the chains
     node_rounds = _rounds_of(n2, WALK_CHUNK, dev)
     prev, rounds = -1, 0
+    too_long = False
     while True:
-        tot = (tab[0] >= 0).sum().reshape(1)
+        tot = is_open(word, flag).sum().reshape(1)
         dist.all_reduce(tot)
         tot = int(tot.item())
         if tot == 0 or tot == prev:  # every round ends at least one k-mer of every open chain: what is left runs in circles
@@ -594,36 +588,67 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         mark(f"round {rounds}: {tot} open")
         for c in range(node_rounds):
             a, b = min(c * WALK_CHUNK, n2), min((c + 1) * WALK_CHUNK, n2)
-            act = (tab[0, a:b] >= 0).nonzero().squeeze(1) + a
-            tg = tab[0, act]
-            rows = _remote_rows(tg, owner_of(tg), tab, base, rank, world, dev)
-            fin = rows[:, 0] < 0
-            tab[1, act] += rows[:, 1]
-            tab[0, act] = rows[:, 0]
-            tab[2, act] = torch.where(fin, rows[:, 2], -1)
-            tab[3, act] = torch.where(fin, rows[:, 3], -1)
-            del act, tg, rows, fin
-    left = (tab[0] >= 0).nonzero().squeeze(1)
+            act = is_open(word[a:b], flag[a:b]).nonzero().squeeze(1) + a
+            mine_w = word[act]
+            tg = (mine_w >> 24) & IDM
+            wp = _remote_rows(tg, owner_of(tg), word.unsqueeze(0), base, rank, world, dev)[:, 0]
+            p_tail = (wp & TBIT) != 0                 # the target ends its chain: it is the tail, no step is added
+            p_fin = wp < 0
+            hops = (mine_w & HM) + torch.where(p_tail, torch.zeros_like(wp), wp & HM)
+            too_long = too_long or (act.numel() > 0 and bool((hops > HM).any().item()))
+            nid = torch.where(p_tail, tg, (wp >> 24) & IDM)
+            word[act] = torch.where(p_fin, torch.full_like(wp, FBIT), torch.zeros_like(wp)) | (nid << 24) | (hops & HM)
+            del act, mine_w, tg, wp, p_tail, p_fin, hops, nid
+
+    def check_hops():
+        if too_long:
+            raise RuntimeError("a chain of more than 2^24 k-mers: beyond the packed hop count of the distributed walks")
+    _guarded(dev, "chain lengths", check_hops)
+    left = is_open(word, flag).nonzero().squeeze(1)
     loop_local = torch.unique(left >> 1) if left.numel() else torch.empty(0, dtype=torch.int64, device=dev)
     del left
-    done = nonj & (tab[0] < 0)
-    del nonj
+    done = ((flag & 1) != 0) & (word < 0)
 
     mark("doubling")
-    # 3. every chain k-mer to the head of its chain
-    is_head = done & sj.view(-1, 2).flip(1).reshape(-1)  # the predecessor (the successor of the reverse complement) is a junction k-mer
-    del sj
-    clen = (tab[1] + 1) * is_head
-    coff = torch.cumsum(clen, 0) - clen
-    total = int(clen.sum().item()) if n2 else 0
+    # 3. every chain k-mer to the head of its chain. A node is a head when the reverse strand's node of its k-mer is a tail; the heads'
+    #    bookkeeping (chain length, offset of its nucleotides, end node) is kept per HEAD (hidx: their local nodes, ascending), not per node
+    rev_tail = ((word & TBIT) != 0).view(-1, 2).flip(1).reshape(-1) if n2 else torch.zeros(0, dtype=torch.bool, device=dev)
+    hidx = (done & rev_tail).nonzero().squeeze(1)
+    del rev_tail
+    hw = word[hidx]
+    hlen = torch.where((hw & TBIT) != 0, torch.zeros_like(hw), hw & HM) + 1  # k-mers of the chain (a head that is its own tail: 1)
+    del hw
+    hoff = torch.cumsum(hlen, 0) - hlen
+    hend = torch.full_like(hlen, -1)
+    total = int(hlen.sum().item()) if hidx.numel() else 0
     bases = torch.zeros(max(total, 1), dtype=torch.uint8, device=dev)
+    n_heads = hidx.numel()
+
+    def head_slot(local_nodes):
+        """ordinal among this rank's heads of local nodes that must be heads (-> slots, all found)"""
+        if n_heads == 0:
+            return torch.zeros_like(local_nodes), local_nodes.numel() == 0
+        slot = torch.searchsorted(hidx, local_nodes).clamp_(max=n_heads - 1)
+        return slot, bool((hidx[slot] == local_nodes).all().item())
+
+    def tail_of(nodes, w):  # the tail of the chain of finished nodes (w = their words)
+        return torch.where((w & TBIT) != 0, nodes, (w >> 24) & IDM)
+
     n_got_all, bad_head = 0, False
     for c in range(node_rounds):
         a, b = min(c * WALK_CHUNK, n2), min((c + 1) * WALK_CHUNK, n2)
         xs = done[a:b].nonzero().squeeze(1) + a
         xr = xs ^ 1
-        head = tab[2, xr] ^ 1
-        payload = (tab[1, xr] << 2) | code[xs].to(torch.int64)
+        wr = word[xr]
+        head = tail_of(xr + base, wr) ^ 1
+        steps_back = torch.where((wr & TBIT) != 0, torch.zeros_like(wr), wr & HM)  # x is that many k-mers behind the head of its chain
+        payload = (steps_back << 2) | ((flag[xs].to(torch.int64) >> 2) & 3)
+        # the tails also tell the head which junction node ends the chain (payload: end node << 2 | 3 marks it: no nucleotide code 3 + huge)
+        ws = word[xs]
+        tl = ((ws & TBIT) != 0).nonzero().squeeze(1)
+        head = torch.cat([head, head[tl]])
+        payload = torch.cat([payload, -(((ws[tl] >> 24) & IDM) + 1)])  # negative: "the end node of your chain is -(payload) - 1"
+        del wr, steps_back, ws, tl
         order, counts = _by_owner(owner_of(head), world)
         msg = torch.stack([head[order], payload[order]], 1).reshape(-1).contiguous()
         del xs, xr, head, payload, order
@@ -632,13 +657,17 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         n_got = sum(rcounts) // 2
         got = got[:2 * n_got].reshape(-1, 2)
         if n_got:
-            hl = got[:, 0] - base
-            bad_head = bad_head or not bool(is_head[hl].all().item())
-            pos = coff[hl] + (got[:, 1] >> 2)
+            slot, ok_ = head_slot(got[:, 0] - base)
+            bad_head = bad_head or not ok_
+            is_end = got[:, 1] < 0
+            e_sl = slot[is_end]
+            hend[e_sl] = -got[:, 1][is_end] - 1
+            n_sl, n_pl = slot[~is_end], got[:, 1][~is_end]
+            pos = hoff[n_sl] + (n_pl >> 2)
             pos.clamp_(0, max(total, 1) - 1)
-            bases[pos] = (got[:, 1] & 3).to(torch.uint8)
-            del hl, pos
-        n_got_all += n_got
+            bases[pos] = (n_pl & 3).to(torch.uint8)
+            n_got_all += int(n_pl.numel())
+            del slot, is_end, e_sl, n_sl, n_pl, pos
         del got
 
     def placed():
@@ -646,8 +675,10 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
             raise RuntimeError("a chain nucleotide arrived at a k-mer that heads no chain")
         if n_got_all != total:
             raise RuntimeError(f"{n_got_all} chain nucleotides arrived for chains of {total} k-mers")
+        if n_heads and bool((hend < 0).any().item()):
+            raise RuntimeError("a chain whose end node never reached its head")
     _guarded(dev, "chain nucleotides at the heads", placed)
-    del done, code
+    del done, flag, word
 
     mark("chain nucleotides to the heads")
     # 4. the chains behind this rank's start de-edges
@@ -662,8 +693,11 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         order, counts = _by_owner(owner_of(tq), world)
         asks, rcounts = _a2a(tq[order].contiguous(), counts, rank, world, dev)
         n_asks = sum(rcounts)
-        al = asks[:n_asks] - base
-        a_len, a_end, a_off = clen[al], tab[3, al], coff[al]
+        slot, ok_ = head_slot(asks[:n_asks] - base)
+        headless = headless or not ok_
+        a_len, a_end, a_off = hlen[slot], hend[slot], hoff[slot]
+        if not ok_:  # (reported below, on every rank; nothing may be indexed with a wrong slot's length meanwhile)
+            a_len = torch.zeros_like(a_len)
         rows, _ = _a2a(torch.stack([a_len, a_end], 1).reshape(-1).contiguous(), [2 * c_ for c_ in rcounts], rank, world, dev)
         seg_of = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(rcounts, dtype=torch.int64, device=dev))
         per_rank = torch.zeros(world, dtype=torch.int64, device=dev)
@@ -679,7 +713,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         headless = headless or (qc.numel() > 0 and bool((rows[:, 0] <= 0).any().item()))
         pieces.append(mine[:sum(rc2)])
         have += sum(rc2)
-        del asks, al, a_len, a_end, a_off, rows, flat, mine
+        del asks, slot, a_len, a_end, a_off, rows, flat, mine
 
     def check_chains():
         if headless:
@@ -688,7 +722,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     my_bases = torch.cat(pieces) if len(pieces) > 1 else (pieces[0] if pieces else torch.zeros(1, dtype=torch.uint8, device=dev))
     if my_bases.numel() == 0:
         my_bases = torch.zeros(1, dtype=torch.uint8, device=dev)
-    del tab, clen, coff, bases, pieces
+    del hidx, hlen, hoff, hend, bases, pieces
     # (no torch.cuda.empty_cache() here: VRAM that one allocator has just released is not safe for the next one to take at once on this
     # stack — arena_trim in csrc/smx_ctx.hpp has the measurements)
     _sync(dev)

@@ -37,6 +37,19 @@ def test_seeded_vs_oracle_with_prededupe(K, mode, nb, cap):
     assert rec.shape == ref.shape and (rec == ref).all()
 
 
+@pytest.mark.parametrize("K,mode,nb", [(21, "A", 16), (55, "B", 160), (77, "A", 16), (127, "B", 20)])
+@pytest.mark.parametrize("opts", [dict(skm_fold=0), dict(skm_cap=4096), dict(skm_cap=8192), dict(skm_scap=8)])
+def test_fold_and_geometry_variants(K, mode, nb, opts):
+    """30x reads of a small genome (every error-free stretch is there many times, on both strands: the fold of identical super-k-mers has
+    work to do) with the fold off, with the workgroup geometries of larger chunks (512 / 1024 threads), and with a tiny slot budget that
+    cuts every partition: the same bytes as the oracle"""
+    from oracle import oracle
+    reads = _synth(7 + K, 3000, 600, 150) + ["ACGT" * 40] * 30 + ["A" * 150] * 10
+    ref, rs = oracle.count(reads, K, mode, nb)
+    rec, sizes = _count(reads, K, mode, nb, dict(ON, **opts))
+    assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
+
+
 @pytest.mark.parametrize("K,mode,nb,batch", [(21, "A", 16, 100_000), (55, "A", 16, 40_000), (56, "B", 80, 30_000), (77, "B", 30, 200_000)])
 def test_multi_batch_with_prededupe(K, mode, nb, batch):
     """position-range batches: super-k-mers are cut at the range borders"""
