@@ -268,6 +268,11 @@ int smx_graph_shard_ext_stats(const smx_ctx *ctx, uint64_t *stats /* [2] */);
  *      smx_build_graph. That graph has no k-mer file: smx_graph_copy_kmers / smx_graph_fingerprint refuse. */
 int smx_shard_walk_counts(smx_ctx *ctx, uint64_t *n_chain_requests, uint64_t *n_start_requests);
 int smx_shard_walk_requests(smx_ctx *ctx, int starts, unsigned world, void *d_records, uint64_t *d_tags, uint64_t *counts /* [world] */);
+/* ... the same for the items [first_item, first_item + n_items) only (oriented nodes 2 * local rank + orientation, or start de-edges in
+ * k-mer-file order): at most one request per item, so buffers of n_items records / tags suffice — a caller that walks a shard of
+ * billions of k-mers asks range by range and never holds more than one range's requests (16 + 8 B per oriented node otherwise). */
+int smx_shard_walk_requests_range(smx_ctx *ctx, int starts, unsigned world, uint64_t first_item, uint64_t n_items, void *d_records, uint64_t *d_tags,
+                                  uint64_t *counts /* [world] */);
 int smx_shard_walk_starts(const smx_ctx *ctx, uint64_t *d_starts);
 int smx_shard_lookup(smx_ctx *ctx, const void *d_records, uint64_t n, uint64_t *d_reply);
 int smx_shard_gather_kmers(smx_ctx *ctx, const uint64_t *d_local_ranks, uint64_t n, void *d_kmers, uint8_t *d_masks);

@@ -1134,18 +1134,23 @@ int smx_shard_walk_counts(smx_ctx *ctx, uint64_t *n_chain_requests, uint64_t *n_
     return rc;
 }
 
-int smx_shard_walk_requests(smx_ctx *ctx, int starts, unsigned world, void *d_records, uint64_t *d_tags, uint64_t *counts) {
+int smx_shard_walk_requests_range(smx_ctx *ctx, int starts, unsigned world, uint64_t first_item, uint64_t n_items, void *d_records, uint64_t *d_tags,
+                                  uint64_t *counts) {
     if (int rc = dw_check_shard(ctx)) return rc;
     if (!counts || world < 1 || world > 1024) return fail(ctx, SMX_INVALID_PARAMETER, "bad world / null counts");
     HIPCHK(hipSetDevice(ctx->device));
     int rc;
     switch (ctx->g_nw) {
-        case 1: rc = dw_requests<1>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts); break;
-        case 2: rc = dw_requests<2>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts); break;
-        case 3: rc = dw_requests<3>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts); break;
-        default: rc = dw_requests<4>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts); break;
+        case 1: rc = dw_requests<1>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts, first_item, n_items); break;
+        case 2: rc = dw_requests<2>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts, first_item, n_items); break;
+        case 3: rc = dw_requests<3>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts, first_item, n_items); break;
+        default: rc = dw_requests<4>(ctx, starts != 0, world, d_records, (unsigned long long *)d_tags, counts, first_item, n_items); break;
     }
     return finish_call(ctx, rc, false);
+}
+
+int smx_shard_walk_requests(smx_ctx *ctx, int starts, unsigned world, void *d_records, uint64_t *d_tags, uint64_t *counts) {
+    return smx_shard_walk_requests_range(ctx, starts, world, 0, ~0ull, d_records, d_tags, counts);
 }
 
 int smx_shard_walk_starts(const smx_ctx *cctx, uint64_t *d_starts) {

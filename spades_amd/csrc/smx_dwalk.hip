@@ -28,8 +28,8 @@ __device__ __forceinline__ uint32_t dw_owner(const Rec<NW> &canon, uint32_t B, u
 // CAND = true: items are the start de-edges (k_cand_expand). PASS 0 counts per owner, PASS 1 places record + tag.
 template <int NW, bool CAND, int PASS>
 __global__ void __launch_bounds__(BLK) k_dw_requests(const void *kmers_, const uint8_t *__restrict__ mask, const unsigned long long *__restrict__ cand,
-                                                     uint64_t n_items, unsigned k, uint32_t B, uint32_t world, unsigned long long *hist_or_cursor,
-                                                     void *out_, unsigned long long *tags) {
+                                                     uint64_t item0, uint64_t n_items, unsigned k, uint32_t B, uint32_t world,
+                                                     unsigned long long *hist_or_cursor, void *out_, unsigned long long *tags) {
     extern __shared__ unsigned long long lds_dw[];  // [world] counts, then [world] bases
     unsigned long long *lcnt = lds_dw, *lbase = lds_dw + world;
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
@@ -37,12 +37,12 @@ __global__ void __launch_bounds__(BLK) k_dw_requests(const void *kmers_, const u
     for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n_items; base += (uint64_t)gridDim.x * BLK) {
         for (uint32_t t = threadIdx.x; t < world; t += BLK) lcnt[t] = 0;
         __syncthreads();
-        const uint64_t i = base + threadIdx.x;
+        const uint64_t i = item0 + base + threadIdx.x;  // (the items [item0, item0 + n_items): a caller may ask range by range)
         bool asks = false;
         Rec<NW> y;
         uint32_t ow = 0;
         unsigned long long at = 0, tag = 0;
-        if (i < n_items) {
+        if (base + threadIdx.x < n_items) {
             node_t node;
             unsigned c = 0;
             if (CAND) {

@@ -48,12 +48,16 @@ int dw_prepare(smx_ctx *ctx) {
 
 // requests of the chain k-mers (cand = false) or of the start de-edges (cand = true), grouped by owner rank
 template <int NW>
-int dw_requests(smx_ctx *ctx, bool cand, unsigned world, void *d_recs, unsigned long long *d_tags, uint64_t *counts) {
+int dw_requests(smx_ctx *ctx, bool cand, unsigned world, void *d_recs, unsigned long long *d_tags, uint64_t *counts, uint64_t item0 = 0,
+                uint64_t item_n = ~0ull) {
     if (int rc = dw_prepare<NW>(ctx)) return rc;
     for (unsigned i = 0; i < world; ++i) counts[i] = 0;
-    const uint64_t n_items = cand ? ctx->dw_ncand : 2 * ctx->g_nkmers;
+    const uint64_t all_items = cand ? ctx->dw_ncand : 2 * ctx->g_nkmers;
+    const bool whole = item0 == 0 && item_n >= all_items;  // (a range: the caller sized its buffers for one request per item)
+    item0 = std::min(item0, all_items);
+    const uint64_t n_items = std::min(item_n, all_items - item0);
     const uint64_t expect = cand ? ctx->dw_ncand : ctx->dw_nchain;
-    if (expect == 0) return 0;
+    if (expect == 0 || n_items == 0) return 0;
     if (!d_recs || !d_tags) return fail(ctx, SMX_INVALID_PARAMETER, "null request buffers");
     unsigned long long *hist, *off, *cur;
     if (int rc = dalloc(ctx, &hist, world)) return rc;
@@ -65,26 +69,26 @@ int dw_requests(smx_ctx *ctx, bool cand, unsigned world, void *d_recs, unsigned 
     const unsigned k = ctx->g_k, B = ctx->g_B;
     if (cand)
         hipLaunchKernelGGL((k_dw_requests<NW, true, 0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const unsigned long long *)ctx->dw_cand, n_items, k, B, world, hist, (void *)nullptr, (unsigned long long *)nullptr);
+                           (const unsigned long long *)ctx->dw_cand, item0, n_items, k, B, world, hist, (void *)nullptr, (unsigned long long *)nullptr);
     else
         hipLaunchKernelGGL((k_dw_requests<NW, false, 0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const unsigned long long *)nullptr, n_items, k, B, world, hist, (void *)nullptr, (unsigned long long *)nullptr);
+                           (const unsigned long long *)nullptr, item0, n_items, k, B, world, hist, (void *)nullptr, (unsigned long long *)nullptr);
     HIPCHK(hipGetLastError());
     if (int rc = scan_u64(ctx, hist, off, world)) return rc;
     HIPCHK(hipMemcpyAsync(cur, off, (size_t)world * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (cand)
         hipLaunchKernelGGL((k_dw_requests<NW, true, 1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const unsigned long long *)ctx->dw_cand, n_items, k, B, world, cur, d_recs, d_tags);
+                           (const unsigned long long *)ctx->dw_cand, item0, n_items, k, B, world, cur, d_recs, d_tags);
     else
         hipLaunchKernelGGL((k_dw_requests<NW, false, 1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const unsigned long long *)nullptr, n_items, k, B, world, cur, d_recs, d_tags);
+                           (const unsigned long long *)nullptr, item0, n_items, k, B, world, cur, d_recs, d_tags);
     HIPCHK(hipGetLastError());
     std::vector<unsigned long long> h(world);
     HIPCHK(hipMemcpyAsync(h.data(), hist, (size_t)world * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     uint64_t tot = 0;
     for (unsigned i = 0; i < world; ++i) tot += (counts[i] = h[i]);
-    if (tot != expect) return fail(ctx, SMX_DEVICE_ERROR, "%llu requests placed, %llu expected", (unsigned long long)tot, (unsigned long long)expect);
+    if (whole && tot != expect) return fail(ctx, SMX_DEVICE_ERROR, "%llu requests placed, %llu expected", (unsigned long long)tot, (unsigned long long)expect);
     return 0;
 }
 

@@ -238,17 +238,26 @@ class GpuEngine:
         _chk(self.ctx._h, self.ctx.lib.smx_shard_walk_counts(self.ctx._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def walk_requests(self, starts: bool, k: int, world: int, dev):
-        """-> (canonical successor k-mers grouped by owner, their tags in the same order, records per owner)"""
+    def walk_requests(self, starts: bool, k: int, world: int, dev, first: int = 0, n_items: int = -1):
+        """-> (canonical successor k-mers grouped by owner, their tags in the same order, records per owner); first / n_items: only the
+        oriented nodes (or start de-edges) [first, first + n_items) ask — the caller walks a large shard range by range"""
         n_chain, n_start = self.walk_counts()
-        n = n_start if starts else n_chain
+        if n_items < 0:
+            n = n_start if starts else n_chain
+        else:
+            n = n_items  # (at most one request per item)
         recs = torch.empty(max(n * ((k + 31) // 32), 1), dtype=torch.int64, device=dev)
         tags = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
         counts = (C.c_uint64 * world)()
         _sync(dev)  # the caching allocator may hand out a block that queued torch kernels still read: the library writes from its own stream
-        _chk(self.ctx._h, self.ctx.lib.smx_shard_walk_requests(self.ctx._h, 1 if starts else 0, world, recs.data_ptr(),
-                                                              C.cast(tags.data_ptr(), C.POINTER(C.c_uint64)), counts))
-        return recs, tags[:n], [int(c) for c in counts]
+        if n_items < 0:
+            _chk(self.ctx._h, self.ctx.lib.smx_shard_walk_requests(self.ctx._h, 1 if starts else 0, world, recs.data_ptr(),
+                                                                  C.cast(tags.data_ptr(), C.POINTER(C.c_uint64)), counts))
+        else:
+            _chk(self.ctx._h, self.ctx.lib.smx_shard_walk_requests_range(self.ctx._h, 1 if starts else 0, world, int(first), int(n_items), recs.data_ptr(),
+                                                                        C.cast(tags.data_ptr(), C.POINTER(C.c_uint64)), counts))
+        counts = [int(c) for c in counts]
+        return recs, tags[:sum(counts)], counts
 
     def walk_starts(self, dev):
         _, n = self.walk_counts()
@@ -515,9 +524,13 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     def owner_of(nodes):
         return torch.bucketize(nodes, bounds, right=True)
 
-    def lookup(starts: bool):
-        """-> (tags of this rank's requests, node each one leads to, is that a junction k-mer) in the order the library grouped them"""
-        recs, tags, counts = _guarded(dev, "successor requests of the shard", engine.walk_requests, starts, k, world, dev)
+    def lookup(starts: bool, first_item: int = 0, n_items: int = -1):
+        """-> (tags of this rank's requests, node each one leads to, is that a junction k-mer) in the order the library grouped them;
+        first_item / n_items: the requests of that range of oriented nodes (start de-edges) only (collective: every rank its own range)"""
+        if n_items < 0:
+            recs, tags, counts = _guarded(dev, "successor requests of the shard", engine.walk_requests, starts, k, world, dev)
+        else:
+            recs, tags, counts = _guarded(dev, "successor requests of the shard", engine.walk_requests, starts, k, world, dev, first_item, n_items)
         recv, rcounts = _a2a(recs, [c * nw for c in counts], rank, world, dev)
         del recs
         n_recv = sum(rcounts) // nw
@@ -553,21 +566,27 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     FBIT, TBIT, IDM, HM = -(1 << 63), 1 << 62, (1 << 38) - 1, (1 << 24) - 1
     if 2 * first[-1] > IDM:
         raise ValueError(f"{first[-1]} k-mers: node ids beyond 38 bits")
-    tags, node, junc = lookup(False)
-    xl = tags >> 4
     word = torch.zeros(n2, dtype=torch.int64, device=dev)
     flag = torch.zeros(n2, dtype=torch.uint8, device=dev)
-    word[xl] = torch.where(junc, node << 24 | (FBIT | TBIT), node << 24 | 1)  # tails know their end node; the others: pointer, one step
-    flag[xl] = (1 | (junc.to(torch.int64) << 1) | ((tags & 3) << 2)).to(torch.uint8)
-    del node, junc, tags, xl
-    ctags, cfirst, cjunc = lookup(True)
-    n_cand = ctags.numel()
-    ci = ctags >> 4
+    # (range by range: the requests of WALK_CHUNK oriented nodes at a time — a k-mer record out and a node id back per request; all at once
+    # the exchange buffers of a shard were 48 B per oriented node, the peak of the whole construction)
+    for c in range(_rounds_of(n2, WALK_CHUNK, dev)):
+        a = min(c * WALK_CHUNK, n2)
+        tags, node, junc = lookup(False, a, min(WALK_CHUNK, n2 - a))
+        xl = tags >> 4
+        word[xl] = torch.where(junc, node << 24 | (FBIT | TBIT), node << 24 | 1)  # tails know their end node; the others: pointer, one step
+        flag[xl] = (1 | (junc.to(torch.int64) << 1) | ((tags & 3) << 2)).to(torch.uint8)
+        del node, junc, tags, xl
+    n_cand = int(engine.walk_counts()[1])
     c_first = torch.empty(n_cand, dtype=torch.int64, device=dev)
     c_fj = torch.empty(n_cand, dtype=torch.bool, device=dev)
-    c_first[ci] = cfirst
-    c_fj[ci] = cjunc
-    del ctags, cfirst, cjunc, ci
+    for c in range(_rounds_of(n_cand, WALK_CHUNK, dev)):
+        a = min(c * WALK_CHUNK, n_cand)
+        ctags, cfirst, cjunc = lookup(True, a, min(WALK_CHUNK, n_cand - a))
+        ci = ctags >> 4
+        c_first[ci] = cfirst
+        c_fj[ci] = cjunc
+        del ctags, cfirst, cjunc, ci
 
     def is_open(w, f):
         return ((f & 1) != 0) & (w >= 0)

@@ -448,7 +448,11 @@ class OracleWalkEngine(OracleGraphEngine):
         s = self.strs[node >> 1]
         return _rcs(s) if node & 1 else s
 
-    def walk_requests(self, starts, k, world, dev):
+    def walk_counts(self):
+        """(requests of the chain k-mers, start de-edges) of this shard: smx_shard_walk_counts"""
+        return 2 * sum(1 for m in self.shard_masks if not self._junction(int(m))), len(self.cands)
+
+    def walk_requests(self, starts, k, world, dev, first=0, n_items=-1):
         from oracle import oracle
         self._prepare(k)
         nb = self.nb
@@ -463,6 +467,8 @@ class OracleWalkEngine(OracleGraphEngine):
                     continue
                 items.append((2 * r, 2 * r, (m & 15).bit_length() - 1))
                 items.append((2 * r + 1, 2 * r + 1, (self._brev8(m) & 15).bit_length() - 1))
+        if n_items >= 0:  # (smx_shard_walk_requests_range: the items of that range only)
+            items = [t for t in items if first <= t[0] < first + n_items]
         req = []
         for item, node, c in items:
             y = self._node_str(node)[1:] + "ACGT"[c]
