@@ -148,6 +148,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "skm_scap")) ctx->opt_skm_scap = value;
     else if (!strcmp(key, "skm_fold")) ctx->opt_skm_fold = value;
     else if (!strcmp(key, "two_strand")) ctx->opt_two_strand = value;
+    else if (!strcmp(key, "two_strand_parts")) ctx->opt_two_strand_parts = value;
     else if (!strcmp(key, "device_gfa")) ctx->opt_device_gfa = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
     else if (!strcmp(key, "derive_batches")) ctx->opt_derive_batches = value;

@@ -85,9 +85,12 @@ struct smx_ctx {
     // sorted canonical set and the sorted set of its reverse complements, both bucket-major; the accessors merge bucket by bucket
     struct TwoStrand {
         bool active = false;
-        void *c = nullptr, *r = nullptr;
+        void *c = nullptr;                 // the canonical set, bucket-major
         uint64_t nc = 0, nr = 0;
-        std::vector<uint64_t> boff_c, boff_r;
+        std::vector<uint64_t> boff_c;      // its bucket offsets
+        std::vector<void *> rseg;          // the reverse complements, sorted in a few bucket ranges of their own (one block each)
+        std::vector<const void *> rb_ptr;  // per bucket: where its reverse-complement records start ...
+        std::vector<uint64_t> rb_n;        // ... and how many there are
     } ts;
     uint64_t g_ext_bits = 0, g_ext_pals = 0;  // extension bits / palindromic (k+1)-mers among them in the k-mer file or shard built from EXT records
     PmState pm;               // partition-major construction route
@@ -115,6 +118,7 @@ struct smx_ctx {
     int64_t opt_device_links = 1;  // link records + vertices of the graph on the device (0: host, 2: also for tiny graphs)
     int64_t opt_two_strand = -1;  // both-strands count as canonical set + its reverse complements: -1 when the direct expansion does not fit HBM, 0 never,
                                   // 1 always (merged into one array when that fits), 2 always and left unmerged (tests of the bucket-wise accessors)
+    int64_t opt_two_strand_parts = 0;  // > 0: the reverse complements of a two-strand count are sorted in this many bucket ranges (tests; 0 = as HBM requires)
     int64_t opt_single_batch = 0;  // 1: a count that does not fit one batch fails with the memory limit instead of taking batches / spilling (probes at size)
     int64_t opt_spill = -1;  // sorted runs to host memory + merge by bucket ranges: -1 when the accumulated set outgrows HBM, 1 always (tests)
     int64_t opt_verify_lookups = 0;  // 1: rank lookups of k-mers that are known to be present still compare the record

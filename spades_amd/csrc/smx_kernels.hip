@@ -1228,15 +1228,18 @@ __global__ void k_bucket_offsets(const unsigned long long *uoff, uint32_t num_bu
 // The set is closed under reverse complement: it is the sorted canonical set C and the sorted set R = RC(C) (minus the k-mers that are
 // their own reverse complement, which C holds), bucket by bucket merged. k_ts_rc makes R's records; k_ts_merge merges one bucket.
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_ts_rc(const void *c_, uint64_t n, unsigned K, void *r_, unsigned long long *count /* K even: records written */) {
+__global__ void __launch_bounds__(BLK) k_ts_rc(const void *c_, uint64_t n, unsigned K, void *r_, unsigned long long *count /* records written (when compacting) */,
+                                               uint32_t B, uint32_t b0, uint32_t b1 /* only the reverse complements that file under the buckets [b0, b1) */,
+                                               uint64_t cap /* records r has room for: nothing is written beyond (the count still counts) */) {
     const Rec<NW> *c = (const Rec<NW> *)c_;
     Rec<NW> *r = (Rec<NW> *)r_;
     __shared__ uint32_t scratch[BLK / 64 + 2];
     __shared__ unsigned long long s_base;
-    const bool odd = K & 1u;  // no k-mer of odd length is its own reverse complement: R[i] = RC(C[i]), nothing to leave out
+    // no k-mer of odd length is its own reverse complement: with all buckets wanted R[i] = RC(C[i]), nothing to leave out
+    const bool direct = (K & 1u) && b0 == 0 && b1 >= B;
     constexpr int PER = 16;
     for (uint64_t t0 = (uint64_t)blockIdx.x * BLK * PER; t0 < n; t0 += (uint64_t)gridDim.x * BLK * PER) {
-        if (odd) {
+        if (direct) {
 #pragma unroll 4
             for (int j = 0; j < PER; ++j) {
                 const uint64_t i = t0 + (uint64_t)j * BLK + threadIdx.x;
@@ -1244,15 +1247,14 @@ __global__ void __launch_bounds__(BLK) k_ts_rc(const void *c_, uint64_t n, unsig
             }
             continue;
         }
-        Rec<NW> y[PER];
         uint32_t keep = 0;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const uint64_t i = t0 + (uint64_t)j * BLK + threadIdx.x;
             if (i < n) {
-                const Rec<NW> x = c[i];
-                y[j] = rec_rc<NW>(x, K);
-                if (!rec_eq<NW>(x, y[j])) keep |= 1u << j;
+                const Rec<NW> x = c[i], y = rec_rc<NW>(x, K);
+                const uint32_t b = bucket_of(xxh3_rec<NW>(y), B);
+                if (!rec_eq<NW>(x, y) && b >= b0 && b < b1) keep |= 1u << j;
             }
         }
         uint32_t tot;
@@ -1262,7 +1264,10 @@ __global__ void __launch_bounds__(BLK) k_ts_rc(const void *c_, uint64_t n, unsig
         uint64_t o = s_base + ex;
 #pragma unroll
         for (int j = 0; j < PER; ++j)
-            if (keep & (1u << j)) r[o++] = y[j];
+            if (keep & (1u << j)) {
+                if (o < cap) r[o] = rec_rc<NW>(c[t0 + (uint64_t)j * BLK + threadIdx.x], K);  // (again: 16 records of NW words are not kept in registers)
+                ++o;
+            }
         __syncthreads();
     }
 }

@@ -141,7 +141,7 @@ void clear_result(smx_ctx *ctx) {
     ctx->d_result_buf = ctx->d_result = nullptr;
     if (ctx->ts.active) {
         arena_put(ctx, ctx->ts.c);
-        arena_put(ctx, ctx->ts.r);
+        for (void *p : ctx->ts.rseg) arena_put(ctx, p);
         ctx->ts = smx_ctx::TwoStrand();
     }
     ctx->n_records = 0;
@@ -931,13 +931,13 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
 template <int NW>
 int ts_merge_bucket(smx_ctx *ctx, unsigned b, void *d_dst) {
     const smx_ctx::TwoStrand &t = ctx->ts;
-    const uint64_t ca = t.boff_c[b], na = t.boff_c[b + 1] - ca, cb = t.boff_r[b], nb = t.boff_r[b + 1] - cb;
+    const uint64_t ca = t.boff_c[b], na = t.boff_c[b + 1] - ca, nb = t.rb_n[b];
     if (na + nb == 0) return 0;
     const size_t lds = (size_t)TS_TILE * sizeof(Rec<NW>);
     if (int rc = set_lds(ctx, k_ts_merge<NW>, lds)) return rc;
     const uint64_t ntiles = (na + nb + TS_TILE - 1) / TS_TILE;
     hipLaunchKernelGGL((k_ts_merge<NW>), dim3((unsigned)std::min<uint64_t>(ntiles, 256 * 8)), dim3(BLK), lds, ctx->stream,
-                       (const void *)((const Rec<NW> *)t.c + ca), na, (const void *)((const Rec<NW> *)t.r + cb), nb, d_dst);
+                       (const void *)((const Rec<NW> *)t.c + ca), na, t.rb_ptr[b], nb, d_dst);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -950,7 +950,9 @@ int ts_merge_bucket_any(smx_ctx *ctx, unsigned b, void *d_dst) {
     }
 }
 
-// after a canonical count of the reads (result in ctx): the reverse complements, sorted, and the two-strand view (or its merge)
+// after a canonical count of the reads (result in ctx): the reverse complements, sorted, and the two-strand view (or its merge).
+// The reverse complements are sorted in H bucket ranges (k_ts_rc filters by the bucket of the reverse complement), each range from a raw
+// array + one ping-pong buffer of ITS size: the peak is W |C| (2 + 1/H) instead of 3 W |C| — H follows what the arena can give.
 template <int NW>
 int two_strand_finish(smx_ctx *ctx, unsigned K, unsigned B) {
     smx_ctx::TwoStrand t;
@@ -960,39 +962,70 @@ int two_strand_finish(smx_ctx *ctx, unsigned K, unsigned B) {
     detach_temp(ctx, t.c);
     ctx->d_result_buf = ctx->d_result = nullptr;
     free_temps(ctx);
+    t.rb_ptr.assign(B, nullptr);
+    t.rb_n.assign(B, 0);
     auto bail = [&](int code) {
         arena_put(ctx, t.c);
-        arena_put(ctx, t.r);
+        for (void *p : t.rseg) arena_put(ctx, p);
         return code;
     };
-    Rec<NW> *raw;
+    const double wc = (double)t.nc * sizeof(Rec<NW>);
+    unsigned H = 1;
+    if (ctx->opt_two_strand_parts > 0) H = (unsigned)std::min<int64_t>(ctx->opt_two_strand_parts, B);
+    else
+        while (H < 8 && H < B && wc * (1.0 + 2.2 / H) + (double)((size_t)1 << 30) > (double)arena_avail(ctx)) H *= 2;  // (C is resident already)
     unsigned long long *d_cnt;
-    if (int rc = dalloc(ctx, &raw, t.nc + 1)) return bail(rc);
-    if (int rc = dalloc(ctx, &d_cnt, 1)) return bail(rc);
-    HIPCHK(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
-    tbegin(ctx, "ts_rc");
-    if (t.nc) {
-        hipLaunchKernelGGL((k_ts_rc<NW>), dim3((unsigned)std::min<uint64_t>((t.nc + BLK * 16 - 1) / (BLK * 16), 256 * 16)), dim3(BLK), 0, ctx->stream, (const void *)t.c,
-                           t.nc, K, (void *)raw, d_cnt);
-        HIPCHK(hipGetLastError());
+    if (int rc = dalloc(ctx, &d_cnt, 1, false)) return bail(rc);
+    uint64_t nr_total = 0;
+    int rc = 0;
+    for (unsigned h = 0; h < H && rc == 0; ++h) {
+        const unsigned b0 = (unsigned)((uint64_t)B * h / H), b1 = (unsigned)((uint64_t)B * (h + 1) / H);
+        if (b1 <= b0) continue;
+        // records of this range: the canonical records whose reverse complement files under [b0, b1) — by symmetry about |C| (b1 - b0) / B
+        const uint64_t cap = H == 1 ? t.nc : std::min<uint64_t>(t.nc, (uint64_t)((double)t.nc * (double)(b1 - b0) / (double)B * 1.02) + (1u << 20));
+        Rec<NW> *raw;
+        if ((rc = dalloc(ctx, &raw, cap + 1))) break;
+        HIPCHK(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+        tbegin(ctx, "ts_rc");
+        if (t.nc) {
+            // (a range's count is not known before the pass: a first pass with a null destination is not needed — the bound above holds
+            // unless the hash is badly skewed, which the count below catches)
+            hipLaunchKernelGGL((k_ts_rc<NW>), dim3((unsigned)std::min<uint64_t>((t.nc + BLK * 16 - 1) / (BLK * 16), 256 * 16)), dim3(BLK), 0, ctx->stream, (const void *)t.c,
+                               t.nc, K, (void *)raw, d_cnt, B, b0, b1, (uint64_t)cap);
+            HIPCHK(hipGetLastError());
+        }
+        tend(ctx);
+        unsigned long long nr = t.nc;
+        if (!((K & 1u) && H == 1)) {
+            HIPCHK(hipMemcpyAsync(&nr, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+        if (nr > cap) {  // (the kernel wrote past its block: never expected — the result cannot be trusted)
+            rc = fail(ctx, SMX_DEVICE_ERROR, "two-strand count: %llu reverse complements in a bucket range planned for %llu", nr, (unsigned long long)cap);
+            break;
+        }
+        // (run_count starts with clear_result: the context holds nothing of this count at the moment; C and the finished ranges are in `t`)
+        if ((rc = run_count<NW>(ctx, K, SMX_MODE_CANONICAL, B, raw, nr, nullptr, /*recs_reusable=*/true, /*expand_rc=*/false, /*distinct_hint=*/true, b0, b1 - b0))) break;
+        if (ctx->n_records != nr) {
+            rc = fail(ctx, SMX_DEVICE_ERROR, "two-strand count: %llu reverse complements, %llu after their sort", nr, (unsigned long long)ctx->n_records);
+            break;
+        }
+        void *seg = ctx->d_result_buf;
+        detach_temp(ctx, seg);
+        ctx->d_result_buf = ctx->d_result = nullptr;
+        free_temps(ctx);
+        t.rseg.push_back(seg);
+        for (unsigned b = b0; b < b1; ++b) {
+            t.rb_ptr[b] = (const void *)((const Rec<NW> *)seg + ctx->bucket_off[b]);
+            t.rb_n[b] = ctx->bucket_off[b + 1] - ctx->bucket_off[b];
+        }
+        nr_total += nr;
     }
-    tend(ctx);
-    unsigned long long nr = t.nc;
-    if (!(K & 1u)) {
-        HIPCHK(hipMemcpyAsync(&nr, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    // (run_count starts with clear_result: the context holds nothing of this count at the moment; C is in `t`)
-    if (int rc = run_count<NW>(ctx, K, SMX_MODE_CANONICAL, B, raw, nr, nullptr, /*recs_reusable=*/true, /*expand_rc=*/false, /*distinct_hint=*/true)) return bail(rc);
-    if (ctx->n_records != nr) return bail(fail(ctx, SMX_DEVICE_ERROR, "two-strand count: %llu reverse complements, %llu after their sort", nr, (unsigned long long)ctx->n_records));
-    t.r = ctx->d_result_buf;
-    t.nr = ctx->n_records;
-    t.boff_r = ctx->bucket_off;
-    detach_temp(ctx, t.r);
-    ctx->d_result_buf = ctx->d_result = nullptr;
-    free_temps(ctx);
+    arena_put(ctx, d_cnt);
+    if (rc) return bail(rc);
+    t.nr = nr_total;
     ctx->bucket_off.assign((size_t)B + 1, 0);
-    for (unsigned b = 0; b <= B; ++b) ctx->bucket_off[b] = t.boff_c[b] + t.boff_r[b];
+    for (unsigned b = 0; b < B; ++b) ctx->bucket_off[b + 1] = ctx->bucket_off[b] + (t.boff_c[b + 1] - t.boff_c[b]) + t.rb_n[b];
     ctx->n_records = t.nc + t.nr;
     ctx->K = K;
     ctx->nw = NW;
@@ -1005,19 +1038,17 @@ int two_strand_finish(smx_ctx *ctx, unsigned K, unsigned B) {
         Rec<NW> *m = nullptr;
         if (dalloc(ctx, &m, ctx->n_records + 1, false) == 0) {
             tbegin(ctx, "ts_merge");
-            int rc = 0;
-            for (unsigned b = 0; b < B && rc == 0; ++b) rc = ts_merge_bucket<NW>(ctx, b, (void *)(m + ctx->bucket_off[b]));
+            int mrc = 0;
+            for (unsigned b = 0; b < B && mrc == 0; ++b) mrc = ts_merge_bucket<NW>(ctx, b, (void *)(m + ctx->bucket_off[b]));
             tend(ctx);
-            if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "two-strand merge failed");
-            if (rc) {
+            if (mrc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) mrc = fail(ctx, SMX_DEVICE_ERROR, "two-strand merge failed");
+            if (mrc) {
                 arena_put(ctx, m);
-                const uint64_t n = ctx->n_records;
                 clear_result(ctx);
-                (void)n;
-                return rc;
+                return mrc;
             }
             arena_put(ctx, ctx->ts.c);
-            arena_put(ctx, ctx->ts.r);
+            for (void *p : ctx->ts.rseg) arena_put(ctx, p);
             ctx->ts = smx_ctx::TwoStrand();
             ctx->d_result_buf = ctx->d_result = m;
         } else {

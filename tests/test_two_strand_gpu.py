@@ -12,12 +12,14 @@ from test_count_gpu import _synth
 pytestmark = pytest.mark.gpu
 
 
-def _count_ts(reads, K, nb, ts, tmp_path=None):
+def _count_ts(reads, K, nb, ts, tmp_path=None, parts=0):
     from spades_amd import KMerDiskCounter, ReadKMerSplitter
     from spades_amd.kmercount import Context
     ctx = Context()
     ctx.set_option("prededupe", 1)
     ctx.set_option("two_strand", ts)
+    if parts:
+        ctx.set_option("two_strand_parts", parts)
     sp = ReadKMerSplitter(K, "A", ctx)
     sp.push_back_reads(reads)
     st = KMerDiskCounter(str(tmp_path) if tmp_path else None, sp).Count(nb)
@@ -47,6 +49,18 @@ def test_two_strand_count_equals_oracle(K, nb, ts, tmp_path):
         assert (per_bucket[b] == ref[off[b]:off[b + 1]]).all()
     assert md5 == hashlib.md5(ref.tobytes()).hexdigest()
     assert (dptr != 0) == (ts == 1 or len(ref) == 0)  # two strands: no single resident array to point to
+
+
+@pytest.mark.parametrize("K,nb,parts", [(21, 16, 2), (32, 16, 4), (55, 16, 3), (77, 5, 8), (128, 7, 2)])
+def test_reverse_complements_sorted_in_bucket_ranges(K, nb, parts):
+    """two_strand_parts: the reverse complements are sorted range by range of their buckets (what a count does whose three buffers of
+    |C| records do not fit next to each other)"""
+    from oracle import oracle
+    reads = _synth(500 + K, 20000, 2500, 150) + ["ACGT" * 40] * 20 + ["AT" * 75] * 10
+    ref, rs = oracle.count(reads, K, "A", nb)
+    for ts in (1, 2):
+        rec, sizes, per_bucket, _, _ = _count_ts(reads, K, nb, ts, parts=parts)
+        assert (sizes == rs).all() and rec.shape == ref.shape and (rec == ref).all()
 
 
 CASES = [c for c in load_manifest()["cases"] if c["kind"] == "count" and c["K"] >= 21 and c["mode"] == "A"]
