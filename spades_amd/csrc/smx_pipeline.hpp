@@ -973,7 +973,7 @@ int two_strand_finish(smx_ctx *ctx, unsigned K, unsigned B) {
     unsigned H = 1;
     if (ctx->opt_two_strand_parts > 0) H = (unsigned)std::min<int64_t>(ctx->opt_two_strand_parts, B);
     else
-        while (H < 8 && H < B && wc * (1.0 + 2.2 / H) + (double)((size_t)1 << 30) > (double)arena_avail(ctx)) H *= 2;  // (C is resident already)
+        while (H < 8 && H < B && wc * (2.2 / H) + (double)((size_t)1 << 30) > (double)arena_avail(ctx)) H *= 2;  // (C is resident already: what is obtainable is beyond it)
     unsigned long long *d_cnt;
     if (int rc = dalloc(ctx, &d_cnt, 1, false)) return bail(rc);
     uint64_t nr_total = 0;
