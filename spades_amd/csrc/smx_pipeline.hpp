@@ -978,6 +978,7 @@ int two_strand_finish(smx_ctx *ctx, unsigned K, unsigned B) {
     if (int rc = dalloc(ctx, &d_cnt, 1, false)) return bail(rc);
     uint64_t nr_total = 0;
     int rc = 0;
+retry_with_more_ranges:
     for (unsigned h = 0; h < H && rc == 0; ++h) {
         const unsigned b0 = (unsigned)((uint64_t)B * h / H), b1 = (unsigned)((uint64_t)B * (h + 1) / H);
         if (b1 <= b0) continue;
@@ -1020,6 +1021,21 @@ int two_strand_finish(smx_ctx *ctx, unsigned K, unsigned B) {
             t.rb_n[b] = ctx->bucket_off[b + 1] - ctx->bucket_off[b];
         }
         nr_total += nr;
+    }
+    if (rc == SMX_MEMORY_LIMIT_EXCEEDED && ctx->opt_two_strand_parts <= 0 && 2 * H <= 8 && 2 * H <= B) {
+        // what is obtainable was there, but not in one piece (a fragmented arena): smaller ranges need smaller blocks
+        free_temps(ctx);
+        if (ctx->d_result_buf) arena_put(ctx, ctx->d_result_buf);
+        ctx->d_result_buf = ctx->d_result = nullptr;
+        for (void *p : t.rseg) arena_put(ctx, p);
+        t.rseg.clear();
+        t.rb_ptr.assign(B, nullptr);
+        t.rb_n.assign(B, 0);
+        nr_total = 0;
+        ctx->err.clear();
+        rc = 0;
+        H *= 2;
+        goto retry_with_more_ranges;
     }
     arena_put(ctx, d_cnt);
     if (rc) return bail(rc);
