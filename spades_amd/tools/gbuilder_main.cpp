@@ -1,6 +1,8 @@
 // spades_amd/tools/gbuilder_main.cpp — drop-in CLI for `spades-gbuilder`
 // (reference: projects/spades_tools/gbuilder.cpp:66-245; docs/standalone.md) over libspades_mi355x.so.
-//   spades-gbuilder-mi355x <fasta/fastq[.gz]> <out> [-k 21] [-c] [-t N] [-tmp-dir d] [-b n] [--unitigs|--fastg|--gfa|--spades]
+//   spades-gbuilder-mi355x <fasta/fastq[.gz]> <out> [-k 21] [-c] [-t N] [-tmp-dir d] [-b n] [--unitigs|--fastg|--gfa|--spades] [--gpus N]
+// --gpus N: one process per GPU, every rank reads its share of the input, k-mers and masks meet at their bucket owners by one RCCL
+// exchange, the compact structure is gathered where the graph is built (gbuilder_mgpu.hpp). Same bytes as the single-GPU run.
 // -t selects the bucket count 10*t and therefore the unitig/segment numbering of the reference run being
 // reproduced (SURVEY.md finding 3); default = the reference's default (cores/2+1 is host dependent, so 1 here).
 // Not in this build: YAML datasets.
@@ -12,6 +14,7 @@
 
 #include "../../include/smx.h"
 #include "read_input.hpp"
+#include "gbuilder_mgpu.hpp"
 #include <chrono>
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define STAGE(what)                                                                 \
@@ -23,6 +26,7 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 
 int main(int argc, char **argv) {
     unsigned k = 21, nthreads = 1;
+    int gpus = 0;
     std::string file, outfile;
     enum { UNITIGS, GFA, SPADES, FASTG } mode = UNITIGS;
     bool coverage = false;
@@ -39,6 +43,7 @@ int main(int argc, char **argv) {
         if (a == "-k") k = (unsigned)atoi(need());
         else if (a == "-t") nthreads = (unsigned)atoi(need());
         else if (a == "-tmp-dir" || a == "-b") (void)need();
+        else if (a == "--gpus") gpus = atoi(need());
         else if (a == "--unitigs" || a == "-unitigs") mode = UNITIGS;
         else if (a == "--gfa" || a == "-gfa") mode = GFA;
         else if (a == "-c") coverage = true;
@@ -59,6 +64,27 @@ int main(int argc, char **argv) {
     if (k < 1) { fprintf(stderr, "k-mer size %u is too low\n", k); return SMX_INVALID_PARAMETER; }
     if (k >= 128) { fprintf(stderr, "k-mer size %u is too high\n", k); return SMX_INVALID_PARAMETER; }
     if (k % 2 == 0) { fprintf(stderr, "k-mer size must be odd\n"); return SMX_INVALID_PARAMETER; }
+    if (gpus < 0 || gpus > 64) { fprintf(stderr, "Invalid command line arguments\n"); return SMX_INVALID_PARAMETER; }
+    if (gpus > 0) {  // one process per GPU; nothing of HIP may be touched in this process before the fork
+        smxtool::GbOptions o;
+        o.k = k, o.nthreads = nthreads, o.coverage = coverage, o.mode = mode == GFA ? 1 : mode == SPADES ? 2 : mode == FASTG ? 3 : 0, o.outfile = outfile;
+        if (file.size() > 5 && file.compare(file.size() - 5, 5, ".yaml") == 0) {
+            std::vector<smxtool::DatasetLibrary> libs;
+            if (!smxtool::load_dataset_yaml(file, libs)) {
+                fprintf(stderr, "Dataset description file: %s does not exist or is not a valid YAML file\n", file.c_str());
+                return SMX_INPUT_FILE_NOT_FOUND;
+            }
+            for (const auto &lib : libs)
+                if (lib.graph_constructable()) o.files.insert(o.files.end(), lib.files.begin(), lib.files.end());
+        } else {
+            o.files.push_back(file);
+        }
+        printf("K-mer length set to %u\n", k);
+        fflush(stdout);
+        const int rc = smxtool::gb_run_sharded(gpus, o);
+        if (!rc) printf("SPAdes standalone graph builder finished\n");
+        return rc;
+    }
     smx_ctx *ctx = nullptr;
     double t_stage = now_s();
     if (int rc = smx_create(&ctx, 0, 0)) {

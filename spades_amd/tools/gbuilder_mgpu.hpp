@@ -1,0 +1,476 @@
+// spades_amd/tools/gbuilder_mgpu.hpp — spades-gbuilder on N GPUs of one node, C++ host over librccl (precedent for a
+// construction spread over processes: hpcspades/mpi/stages/construction_mpi.cpp:303-412). One process per GPU, forked by the tool
+// before any HIP call; the same steps, on the same C entry points, as spades_amd/dist.py: sharded_build_graph(walks = "gathered"):
+//   every rank reads ITS share of the input (a byte range of an uncompressed 4-line FASTQ file, cut at records; every n-th read of
+//   anything else) ->
+//   route "ext" (k whose record has 8 spare bits): smx_extract_kmers_ext_owned -> ONE exchange -> smx_graph_shard_from_ext;
+//   route "kpomers" (any k): sharded count of the canonical (k+1)-mers (smx_extract_partition_owned -> exchange -> smx_count_records),
+//     smx_graph_shard_updates -> second exchange -> smx_graph_shard_build;
+//   -> the owners' shards of {k-mer file, InOutMask bytes} (bucket ranges: rank order is file order) are gathered on the ranks that
+//   build the graph — rank 0, or every rank with -c, whose coverage pass counts each rank's own reads against the gathered (k+1)-mer
+//   file and sums the raw edge coverages (ncclAllReduce) — smx_build_graph_from_kmers; rank 0 writes the output.
+// Exchanges are grouped ncclSend / ncclRecv between all pairs (xGMI is point to point: every pair has its own link, no ring).
+// A graph whose gathered structure exceeds one GPU's HBM needs the distributed walks, which only dist.py drives today.
+#pragma once
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <signal.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include "../../include/smx.h"
+#include "fastq_split.hpp"
+#include "read_input.hpp"
+
+namespace smxtool {
+
+#define GM_HIP(call)                                                                                \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            fprintf(stderr, "[rank %d] %s failed: %s\n", c.rank, #call, hipGetErrorString(e_));     \
+            return SMX_DEVICE_ERROR;                                                                \
+        }                                                                                           \
+    } while (0)
+#define GM_NCCL(call)                                                                               \
+    do {                                                                                            \
+        ncclResult_t r_ = (call);                                                                   \
+        if (r_ != ncclSuccess) {                                                                    \
+            fprintf(stderr, "[rank %d] %s failed: %s\n", c.rank, #call, ncclGetErrorString(r_));    \
+            return SMX_DEVICE_ERROR;                                                                \
+        }                                                                                           \
+    } while (0)
+#define GM_SMX(call)                                                                                \
+    do {                                                                                            \
+        const int rc_ = (call);                                                                     \
+        if (rc_) {                                                                                  \
+            fprintf(stderr, "[rank %d] %s\n", c.rank, smx_last_error(ctx));                         \
+            return rc_;                                                                             \
+        }                                                                                           \
+    } while (0)
+
+struct GbOptions {
+    unsigned k = 21, nthreads = 1;
+    bool coverage = false;
+    int mode = 0;  // 0 unitigs, 1 GFA, 2 .grseq/.cvr, 3 FASTG
+    std::string outfile;
+    std::vector<std::string> files;
+};
+
+struct RankComm {
+    int rank = 0, world = 1;
+    ncclComm_t comm{};
+    hipStream_t stream{};
+};
+
+// ---- this rank's share of one input file ------------------------------------------------------------------------------------------
+// part / parts: the share (rank * sub + i of world * sub; SMX_MGPU_PARTS = sub > 1 makes every rank read its share in `sub` pieces — a
+// test hook that runs the range reader with one rank).
+inline int submit_fastq_range(smx_ctx *ctx, const std::string &path, long long begin, long long end) {
+    if (begin >= end) return 0;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return -1;
+    if (fseeko(f, (off_t)begin, SEEK_SET) != 0) {
+        fclose(f);
+        return -1;
+    }
+    size_t chunk_bytes = (size_t)std::min<long long>((long long)256 << 20, std::max<long long>(end - begin + 4096, (long long)1 << 20));
+    if (const char *e = getenv("SMX_MGPU_CHUNK")) chunk_bytes = (size_t)std::max(1024, atoi(e));  // test hook: the carry-over between chunks on small files
+    char *buf = (char *)smx_pinned_alloc(chunk_bytes);
+    const bool pinned = buf != nullptr;
+    if (!buf) buf = (char *)malloc(chunk_bytes);
+    long long pos = begin;
+    size_t have = 0;
+    int rc = 0;
+    for (;;) {
+        while (pos < end && have < chunk_bytes) {
+            const size_t got = fread(buf + have, 1, (size_t)std::min<long long>((long long)(chunk_bytes - have), end - pos), f);
+            if (got == 0) {
+                rc = SMX_IO_ERROR;
+                break;
+            }
+            have += got;
+            pos += (long long)got;
+        }
+        if (rc || have == 0) break;
+        const bool last = pos >= end;
+        uint64_t n = 0, used = 0;
+        rc = smx_submit_fastq_text(ctx, buf, have, last ? 1 : 0, &n, &used);
+        if (rc) break;
+        if (used == 0 && !last && have == chunk_bytes) {  // a single record larger than the chunk
+            rc = SMX_INVALID_INPUT_FORMAT;
+            break;
+        }
+        memmove(buf, buf + used, have - used);
+        have -= used;
+        if (last) break;
+    }
+    if (pinned) smx_pinned_free(buf); else free(buf);
+    fclose(f);
+    return rc;
+}
+
+// 0, an smx error code, or -1 when the file cannot be read; throws std::string on malformed input (host parser)
+inline int submit_share(smx_ctx *ctx, const std::string &path, unsigned part, unsigned parts) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return -1;
+    unsigned char head[2] = {0, 0};
+    const size_t nh = fread(head, 1, 2, f);
+    fclose(f);
+    const bool gz = nh == 2 && head[0] == 0x1f && head[1] == 0x8b;
+    if (!gz && nh == 2 && head[0] == '@' && !getenv("SMX_HOST_PARSE") && fastq_head_is_four_line(path)) {
+        long long b = 0, e = 0;
+        if (!fastq_part_range(path, part, parts, &b, &e)) return -1;
+        return submit_fastq_range(ctx, path, b, e);
+    }
+    // gzip, FASTA, multi-line FASTQ: every rank parses the file and keeps every parts-th sequence
+    ReadBatch batch;
+    int rc = 0;
+    uint64_t idx = 0;
+    const bool ok = for_each_sequence(path, [&](const std::string &s) {
+        if (idx++ % parts != part) return;
+        batch.add(s);
+        if (batch.bases.size() > ((size_t)1 << 30) && !rc) {
+            rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
+            batch.clear();
+        }
+    });
+    if (!ok) return -1;
+    if (!rc) rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
+    return rc;
+}
+
+// ---- communicator ----------------------------------------------------------------------------------------------------------------
+inline int comm_init(RankComm &c, const std::string &idfile) {
+    ncclUniqueId id;
+    if (c.rank == 0) {
+        GM_NCCL(ncclGetUniqueId(&id));
+        const std::string tmp = idfile + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&id, sizeof id, 1, f) != 1) return SMX_IO_ERROR;
+        fclose(f);
+        if (rename(tmp.c_str(), idfile.c_str()) != 0) return SMX_IO_ERROR;
+    } else {
+        bool got = false;
+        for (int t = 0; t < 12000 && !got; ++t) {  // up to 2 minutes
+            FILE *f = fopen(idfile.c_str(), "rb");
+            if (f) {
+                got = fread(&id, sizeof id, 1, f) == 1;
+                fclose(f);
+            }
+            if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+        if (!got) {
+            fprintf(stderr, "[rank %d] no communicator id from rank 0\n", c.rank);
+            return SMX_IO_ERROR;
+        }
+    }
+    GM_HIP(hipSetDevice(c.rank));
+    GM_NCCL(ncclCommInitRank(&c.comm, c.world, id, c.rank));
+    GM_HIP(hipStreamCreate(&c.stream));
+    return 0;
+}
+
+// every rank's `n` words -> all[world * n] on every rank
+inline int all_gather_words(RankComm &c, const uint64_t *mine, size_t n, std::vector<uint64_t> &all) {
+    uint64_t *d_in = nullptr;
+    GM_HIP(hipMalloc((void **)&d_in, n * (size_t)(c.world + 1) * 8));
+    uint64_t *d_out = d_in + n;
+    GM_HIP(hipMemcpy(d_in, mine, n * 8, hipMemcpyHostToDevice));
+    GM_NCCL(ncclAllGather(d_in, d_out, n, ncclUint64, c.comm, c.stream));
+    GM_HIP(hipStreamSynchronize(c.stream));
+    all.resize(n * (size_t)c.world);
+    GM_HIP(hipMemcpy(all.data(), d_out, all.size() * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in);
+    return 0;
+}
+
+// ONE all-to-all of records of `wpr` words: counts[p] records of d_send (grouped by destination) go to rank p. The receive side
+// comes from the library's pool (consumed by the call that follows) or from hipMalloc (*d_recv then belongs to the caller).
+inline int exchange(RankComm &c, smx_ctx *ctx, const uint64_t *d_send, const std::vector<uint64_t> &counts, unsigned wpr, bool pool,
+                    uint64_t **d_recv, uint64_t *n_recv) {
+    std::vector<uint64_t> all;
+    if (int rc = all_gather_words(c, counts.data(), (size_t)c.world, all)) return rc;
+    std::vector<uint64_t> soff(c.world + 1, 0), roff(c.world + 1, 0);
+    for (int p = 0; p < c.world; ++p) {
+        soff[p + 1] = soff[p] + counts[p];
+        roff[p + 1] = roff[p] + all[(size_t)p * c.world + c.rank];  // what rank p sends to me
+    }
+    *n_recv = roff[c.world];
+    *d_recv = nullptr;
+    if (pool) {
+        void *p = nullptr;
+        GM_SMX(smx_exchange_buffer(ctx, std::max<uint64_t>(*n_recv * wpr, 1), &p));
+        *d_recv = (uint64_t *)p;
+    } else {
+        GM_HIP(hipMalloc((void **)d_recv, std::max<size_t>((size_t)*n_recv * wpr * 8, 8)));
+    }
+    GM_NCCL(ncclGroupStart());
+    for (int p = 0; p < c.world; ++p) {
+        if (counts[p]) GM_NCCL(ncclSend(d_send + soff[p] * wpr, counts[p] * wpr, ncclUint64, p, c.comm, c.stream));
+        const uint64_t r = roff[p + 1] - roff[p];
+        if (r) GM_NCCL(ncclRecv(*d_recv + roff[p] * wpr, r * wpr, ncclUint64, p, c.comm, c.stream));
+    }
+    GM_NCCL(ncclGroupEnd());
+    GM_HIP(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+// The shards (per[p] units of `unit` bytes on rank p, this rank's at d_mine) side by side in rank order on rank 0, or on every rank
+// (to_all). *d_full (hipMalloc, the caller's) stays NULL on the ranks that receive nothing.
+inline int gather_shards(RankComm &c, const void *d_mine, const std::vector<uint64_t> &per, size_t unit, bool to_all, void **d_full) {
+    *d_full = nullptr;
+    std::vector<uint64_t> off(c.world + 1, 0);
+    for (int p = 0; p < c.world; ++p) off[p + 1] = off[p] + per[p];
+    const bool dest = to_all || c.rank == 0;
+    if (dest) {
+        GM_HIP(hipMalloc(d_full, std::max<size_t>((size_t)off[c.world] * unit, 8)));
+        if (per[c.rank]) GM_HIP(hipMemcpy((char *)*d_full + off[c.rank] * unit, d_mine, (size_t)per[c.rank] * unit, hipMemcpyDeviceToDevice));
+        GM_HIP(hipDeviceSynchronize());  // (the library reads the buffer on a stream of its own)
+    }
+    if (c.world == 1) return 0;
+    GM_NCCL(ncclGroupStart());
+    for (int p = 0; p < c.world; ++p) {
+        if (p == c.rank) continue;
+        if (per[c.rank] && (to_all || p == 0)) GM_NCCL(ncclSend(d_mine, (size_t)per[c.rank] * unit, ncclUint8, p, c.comm, c.stream));
+        if (dest && per[p]) GM_NCCL(ncclRecv((char *)*d_full + off[p] * unit, (size_t)per[p] * unit, ncclUint8, p, c.comm, c.stream));
+    }
+    GM_NCCL(ncclGroupEnd());
+    GM_HIP(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+// sharded count of the canonical K-mers: afterwards the context's count result is this rank's bucket range of the file
+inline int sharded_count_canonical(RankComm &c, smx_ctx *ctx, unsigned K, unsigned nb, uint64_t *n_mine, std::vector<uint64_t> &sizes) {
+    const unsigned nw = (K + 31) / 32;
+    std::vector<uint64_t> counts(c.world, 0);
+    const void *p = nullptr;
+    GM_SMX(smx_extract_partition_owned(ctx, K, SMX_MODE_CANONICAL, nb, (unsigned)c.world, &p, counts.data()));
+    uint64_t *d_recv = nullptr, n_recv = 0;
+    if (int rc = exchange(c, ctx, (const uint64_t *)p, counts, nw, true, &d_recv, &n_recv)) return rc;
+    GM_SMX(smx_extract_release(ctx));
+    GM_SMX(smx_count_records(ctx, K, nb, d_recv, n_recv));
+    GM_SMX(smx_count_info(ctx, n_mine, nullptr, nullptr));
+    sizes.assign(nb, 0);
+    GM_SMX(smx_bucket_sizes(ctx, sizes.data()));
+    return 0;
+}
+
+inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::string &idfile) {
+    RankComm c;
+    c.rank = rank;
+    c.world = world;
+    smx_ctx *ctx = nullptr;
+    if (int rc = smx_create(&ctx, rank, 0)) {
+        fprintf(stderr, "[rank %d] no usable MI355X device %d (smx_create -> %d)\n", rank, rank, rc);
+        return rc;
+    }
+    if (int rc = comm_init(c, idfile)) return rc;
+    // input
+    unsigned sub = 1;
+    if (const char *e = getenv("SMX_MGPU_PARTS")) sub = (unsigned)std::max(1, atoi(e));
+    for (const std::string &fn : o.files)
+        for (unsigned i = 0; i < sub; ++i) {
+            int rc;
+            try {
+                rc = submit_share(ctx, fn, (unsigned)rank * sub + i, (unsigned)world * sub);
+            } catch (const std::string &s) {
+                fprintf(stderr, "%s\n", s.c_str());
+                return SMX_INVALID_INPUT_FORMAT;
+            }
+            if (rc == -1) {
+                fprintf(stderr, "File %s doesn't exist or can't be read!\n", fn.c_str());
+                return SMX_INPUT_FILE_NOT_FOUND;
+            }
+            if (rc) {
+                fprintf(stderr, "[rank %d] %s\n", rank, smx_last_error(ctx));
+                return rc;
+            }
+        }
+    const unsigned k = o.k, K1 = k + 1, nb = 10 * o.nthreads, nw = (K1 + 31) / 32;  // (an odd k and k + 1 take the same number of words)
+    const bool ext = smx_kmers_with_masks_supported(k) != 0 && !getenv("SMX_MGPU_KPOMERS");
+    const bool cov = o.coverage && o.mode != 0;  // (-c does nothing for --unitigs: gbuilder.cpp:191-199)
+    uint64_t n_kpo = 0, n_kmers = 0, stats[2] = {0, 0};
+    std::vector<uint64_t> kpo_sizes(nb, 0), ksizes(nb, 0);
+    uint64_t *d_kpo_mine = nullptr;  // this rank's bucket range of the (k+1)-mer file, kept for -c
+    if (cov || !ext) {
+        if (int rc = sharded_count_canonical(c, ctx, K1, nb, &n_kpo, kpo_sizes)) return rc;
+        if (cov) {
+            GM_HIP(hipMalloc((void **)&d_kpo_mine, std::max<size_t>((size_t)n_kpo * nw * 8, 8)));
+            if (n_kpo) GM_SMX(smx_copy_kmers_device(ctx, d_kpo_mine));
+        }
+    }
+    if (ext) {
+        std::vector<uint64_t> counts(world, 0);
+        const void *p = nullptr;
+        GM_SMX(smx_extract_kmers_ext_owned(ctx, k, nb, (unsigned)world, &p, counts.data()));
+        uint64_t *d_recv = nullptr, n_recv = 0;
+        if (int rc = exchange(c, ctx, (const uint64_t *)p, counts, nw, true, &d_recv, &n_recv)) return rc;
+        GM_SMX(smx_extract_release(ctx));
+        GM_SMX(smx_graph_shard_from_ext(ctx, k, nb, (unsigned)world, (unsigned)rank, d_recv, n_recv));
+        GM_SMX(smx_graph_shard_ext_stats(ctx, stats));
+    } else {
+        uint64_t *d_upd = nullptr;
+        GM_HIP(hipMalloc((void **)&d_upd, std::max<size_t>((size_t)2 * n_kpo * (nw + 1) * 8, 8)));
+        std::vector<uint64_t> ucounts(world, 0);
+        GM_SMX(smx_graph_shard_updates(ctx, k, nb, (unsigned)world, d_upd, 2 * n_kpo, ucounts.data()));
+        uint64_t *d_recv = nullptr, n_recv = 0;
+        if (int rc = exchange(c, ctx, d_upd, ucounts, nw + 1, false, &d_recv, &n_recv)) return rc;
+        (void)hipFree(d_upd);
+        GM_SMX(smx_graph_shard_build(ctx, k, nb, (unsigned)world, (unsigned)rank, d_recv, n_recv));
+        (void)hipFree(d_recv);
+    }
+    GM_SMX(smx_graph_shard_info(ctx, &n_kmers, ksizes.data()));
+    // what every rank has: [k-mers, (k+1)-mers, extension bits, palindromic (k+1)-mers, k-mer bucket sizes, (k+1)-mer bucket sizes]
+    std::vector<uint64_t> me(4 + 2 * (size_t)nb), every;
+    me[0] = n_kmers, me[1] = n_kpo, me[2] = stats[0], me[3] = stats[1];
+    for (unsigned b = 0; b < nb; ++b) me[4 + b] = ksizes[b], me[4 + nb + b] = kpo_sizes[b];
+    if (int rc = all_gather_words(c, me.data(), me.size(), every)) return rc;
+    std::vector<uint64_t> kmers_per(world), kpo_per(world), g_ksizes(nb, 0), g_psizes(nb, 0);
+    uint64_t total_kmers = 0, total_kpo = 0, bits = 0;
+    for (int p = 0; p < world; ++p) {
+        const uint64_t *e = every.data() + (size_t)p * me.size();
+        kmers_per[p] = e[0], kpo_per[p] = e[1];
+        total_kmers += e[0], total_kpo += e[1], bits += e[2] + e[3];
+        for (unsigned b = 0; b < nb; ++b) g_ksizes[b] += e[4 + b], g_psizes[b] += e[4 + nb + b];
+    }
+    uint64_t n_kpo_all = total_kpo;
+    if (ext) {  // every non-palindromic (k+1)-mer set two extension bits somewhere, a palindromic one a single bit
+        if (bits % 2) {
+            fprintf(stderr, "[rank %d] odd number of extension bits over all shards\n", rank);
+            return SMX_DEVICE_ERROR;
+        }
+        n_kpo_all = bits / 2;
+        if (cov && n_kpo_all != total_kpo) {
+            fprintf(stderr, "[rank %d] the masks (%llu (k+1)-mers) and the (k+1)-mer count (%llu) disagree\n", rank, (unsigned long long)n_kpo_all,
+                    (unsigned long long)total_kpo);
+            return SMX_DEVICE_ERROR;
+        }
+    }
+    // gather {k-mers, masks} where a graph is built: everywhere with -c (every rank counts its own reads on it), else on rank 0
+    const bool builds = cov || rank == 0;
+    {
+        uint64_t *d_my_k = nullptr;
+        uint8_t *d_my_m = nullptr;
+        GM_HIP(hipMalloc((void **)&d_my_k, std::max<size_t>((size_t)n_kmers * nw * 8, 8)));
+        GM_HIP(hipMalloc((void **)&d_my_m, std::max<size_t>((size_t)n_kmers, 8)));
+        if (n_kmers) GM_SMX(smx_graph_shard_copy(ctx, d_my_k, d_my_m));
+        void *d_full_k = nullptr, *d_full_m = nullptr;
+        if (int rc = gather_shards(c, d_my_k, kmers_per, (size_t)nw * 8, cov, &d_full_k)) return rc;
+        if (int rc = gather_shards(c, d_my_m, kmers_per, 1, cov, &d_full_m)) return rc;
+        (void)hipFree(d_my_k);
+        (void)hipFree(d_my_m);
+        if (builds) GM_SMX(smx_build_graph_from_kmers(ctx, k, nb, d_full_k, d_full_m, total_kmers, g_ksizes.data(), n_kpo_all));
+        if (d_full_k) (void)hipFree(d_full_k);
+        if (d_full_m) (void)hipFree(d_full_m);
+    }
+    uint64_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (builds) GM_SMX(smx_graph_info(ctx, info));
+    if (cov) {
+        void *d_full_p = nullptr;
+        if (int rc = gather_shards(c, d_kpo_mine, kpo_per, (size_t)nw * 8, true, &d_full_p)) return rc;
+        (void)hipFree(d_kpo_mine);
+        GM_SMX(smx_graph_set_kpomers(ctx, d_full_p, total_kpo, g_psizes.data()));
+        (void)hipFree(d_full_p);
+        if (rank == 0) printf("Filling coverage index\n");
+        GM_SMX(smx_graph_fill_coverage(ctx));  // this rank's reads against the whole (k+1)-mer file
+        const uint64_t ne = info[2];
+        std::vector<uint32_t> raw(std::max<uint64_t>(ne, 1), 0);
+        GM_SMX(smx_graph_copy_coverage(ctx, raw.data()));
+        uint32_t *d_cov = nullptr;
+        GM_HIP(hipMalloc((void **)&d_cov, raw.size() * 4));
+        GM_HIP(hipMemcpy(d_cov, raw.data(), raw.size() * 4, hipMemcpyHostToDevice));
+        GM_NCCL(ncclAllReduce(d_cov, d_cov, raw.size(), ncclUint32, ncclSum, c.comm, c.stream));  // (wraps like the reference's uint32 counters)
+        GM_HIP(hipStreamSynchronize(c.stream));
+        GM_HIP(hipMemcpy(raw.data(), d_cov, raw.size() * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(d_cov);
+        GM_SMX(smx_graph_set_coverage(ctx, raw.data(), ne));
+    }
+    if (rank == 0) {
+        printf("Extracting unbranching paths finished. %llu sequences extracted\n", (unsigned long long)(info[2] - info[3]));
+        printf("Collecting perfect loops finished. %llu loops collected\n", (unsigned long long)info[3]);
+        printf("Saving %s to %s\n", o.mode == 1 ? "graph" : "unitigs", o.outfile.c_str());
+        GM_SMX(o.mode == 1   ? smx_graph_write_gfa(ctx, o.outfile.c_str(), "SPAdes-4.3.0-dev")
+               : o.mode == 2 ? smx_graph_write_spades(ctx, o.outfile.c_str())
+               : o.mode == 3 ? smx_graph_write_fastg(ctx, o.outfile.c_str())
+                             : smx_graph_write_unitigs(ctx, o.outfile.c_str()));
+        unlink(idfile.c_str());
+    }
+    ncclCommDestroy(c.comm);
+    (void)hipStreamDestroy(c.stream);
+    smx_destroy(ctx);
+    return 0;
+}
+
+// fork one process per GPU (nothing of HIP has been touched yet in this process) and wait for them; the first rank that fails takes
+// the others down (a rank that leaves between two collectives would leave them waiting in the next one for ever)
+inline int gb_run_sharded(int world, const GbOptions &o) {
+    for (const std::string &f : o.files) {
+        FILE *t = fopen(f.c_str(), "rb");
+        if (!t) {
+            fprintf(stderr, "File %s doesn't exist or can't be read!\n", f.c_str());
+            return SMX_INPUT_FILE_NOT_FOUND;
+        }
+        fclose(t);
+    }
+    const std::string idfile = o.outfile + ".smx_nccl_id";
+    unlink(idfile.c_str());
+    std::vector<pid_t> kids;
+    for (int r = 0; r < world; ++r) {
+        const pid_t pid = fork();
+        if (pid < 0) {
+            for (pid_t kk : kids) kill(kk, SIGKILL);
+            for (pid_t kk : kids) waitpid(kk, nullptr, 0);
+            return SMX_DEVICE_ERROR;
+        }
+        if (pid == 0) {
+            int rc;
+            try {
+                rc = gb_rank_main(r, world, o, idfile);
+            } catch (const std::string &s) {
+                fprintf(stderr, "%s\n", s.c_str());
+                rc = SMX_INVALID_INPUT_FORMAT;
+            }
+            fflush(stdout);
+            fflush(stderr);
+            _exit(rc);
+        }
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    size_t left = kids.size();
+    while (left) {
+        int st = 0;
+        const pid_t pid = waitpid(-1, &st, 0);
+        if (pid < 0) break;
+        bool ours = false;
+        for (pid_t &kk : kids)
+            if (kk == pid) {
+                kk = -1;
+                ours = true;
+            }
+        if (!ours) continue;
+        --left;
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : SMX_DEVICE_ERROR;
+        if (code && !rc) {
+            rc = code;
+            fprintf(stderr, "a rank failed with code %d: stopping the other ranks\n", code);
+            for (pid_t kk : kids)
+                if (kk > 0) kill(kk, SIGKILL);
+        }
+    }
+    unlink(idfile.c_str());
+    return rc;
+}
+
+}  // namespace smxtool

@@ -61,6 +61,46 @@ def test_gbuilder_cli_matches_reference_gfa(tmp_path):
         assert open(out).read() == open(os.path.join(GOLDEN, c["file"])).read()
 
 
+def test_gbuilder_cli_rccl_host_one_rank(tmp_path):
+    """--gpus 1: the C++ multi-GPU host of the construction (forked rank, librccl communicator, k-mers with their mask bytes exchanged
+    with itself, owner-side shard, gathered structure, graph, writer) writes the reference's GFA on both routes to the shard, with and
+    without -c; N > 1 needs N GPUs (the driver's boxes)."""
+    man = load_manifest()["cases"]
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    fa, fq = str(tmp_path / "r.fa"), str(tmp_path / "r.fq")
+    with open(fa, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(f">r{i}\n{r}\n")
+    _fastq(fq, reads)
+    out = str(tmp_path / "g.gfa")
+    runs = 0
+    for kind, cov in (("graph", []), ("graph_cov", ["-c"])):
+        for c in [c for c in man if c["kind"] == kind and c["file"] and c["reads"] == "reads_small.txt" and c["K"] in (21, 33, 55) and c["threads"] == 3]:
+            want = open(os.path.join(GOLDEN, c["file"])).read()
+            # FASTA: every rank parses the file and keeps its reads; FASTQ: its byte range, here in three pieces with a small chunk
+            # (carry-over of the cut record between chunks); SMX_MGPU_KPOMERS: the route by the sharded (k+1)-mer count
+            for inp, env in ((fa, {}), (fq, {"SMX_MGPU_PARTS": "3", "SMX_MGPU_CHUNK": "2048"}), (fq, {"SMX_MGPU_KPOMERS": "1", "SMX_MGPU_PARTS": "2"})):
+                if os.path.exists(out):
+                    os.remove(out)
+                subprocess.check_call([GB, inp, out, "-k", str(c["K"]), "-t", "3", "--gfa", "--gpus", "1"] + cov, stdout=subprocess.DEVNULL,
+                                      env=dict(os.environ, **env), timeout=300)
+                assert open(out).read() == want, (c["K"], cov, env)
+                runs += 1
+    assert runs >= 9
+
+
+def test_gbuilder_cli_rccl_host_other_outputs(tmp_path):
+    """--gpus 1 with --spades (-c) and a missing input: same files, same exit code"""
+    c = [c for c in load_manifest()["cases"] if c["kind"] == "graph_spades" and c["base"] == "spades_small_k21_t3_c"][0]
+    fq = str(tmp_path / "r.fq")
+    _fastq(fq, [r for r in read_lines(c["reads"]) if r])
+    out = str(tmp_path / "sp")
+    subprocess.check_call([GB, fq, out, "-k", "21", "-t", "3", "-c", "--spades", "--gpus", "1"], stdout=subprocess.DEVNULL, timeout=300)
+    for ext in (".grseq", ".cvr"):
+        assert open(out + ext, "rb").read() == open(os.path.join(GOLDEN, c["base"] + ext), "rb").read()
+    assert subprocess.call([GB, "/nonexistent.fq", str(tmp_path / "o"), "-k", "21", "--gpus", "1"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 65
+
+
 def test_gbuilder_cli_coverage_flag(tmp_path):
     c = [c for c in load_manifest()["cases"] if c["kind"] == "graph_cov" and c["reads"] == "reads_small.txt" and c["K"] == 21 and c["threads"] == 3][0]
     fq = str(tmp_path / "r.fq")
