@@ -291,20 +291,38 @@ def end_to_end(codes_sample, k, T):
                 rec[:, 15 + 2 * L] = 10
                 rec.tofile(f)
         res["fastq_bytes"] = os.path.getsize(fq)
-        for name, exe, argv, outf in (("gbuilder_gfa", "spades-gbuilder-mi355x", [fq, os.path.join(td, "o.gfa"), "-k", str(k), "-t", str(T), "--gfa"], "o.gfa"),
-                                     ("kmercount", "spades-kmercount-mi355x", ["-k", str(k), "-w", td, fq], "final_kmers")):
+        # third leg: the C++ multi-GPU host of the construction with ONE rank (forked rank, librccl, the exchange with itself, the input read
+        # as four byte ranges of the file): the wall clock of that code path at size, and its GFA must be the single-process GFA byte for byte
+        for name, exe, argv, outf, extra_env in (
+                ("gbuilder_gfa", "spades-gbuilder-mi355x", [fq, os.path.join(td, "o.gfa"), "-k", str(k), "-t", str(T), "--gfa"], "o.gfa", {}),
+                ("gbuilder_gfa_rccl_host_1rank", "spades-gbuilder-mi355x", [fq, os.path.join(td, "o2.gfa"), "-k", str(k), "-t", str(T), "--gfa", "--gpus", "1"], "o2.gfa",
+                 {"SMX_MGPU_PARTS": "4"}),
+                ("kmercount", "spades-kmercount-mi355x", ["-k", str(k), "-w", td, fq], "final_kmers", {})):
             try:
                 best, split = None, None
                 for _ in range(2):  # second run: the page cache and the GPU's clocks are warm
                     t0 = time.time()
-                    r = subprocess.run([os.path.join(tools, exe)] + argv, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, SMX_DEBUG="1"),
-                                       check=True, timeout=600)
+                    r = subprocess.run([os.path.join(tools, exe)] + argv, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                       env=dict(os.environ, SMX_DEBUG="1", **extra_env), check=True, timeout=600)
                     dt = time.time() - t0
                     if best is None or dt < best:
                         best = dt
                         split = {l[7:19].strip(): float(l[19:].split()[0]) for l in r.stderr.decode().splitlines() if l.startswith("[tool]")}
                 res[name] = {"seconds": round(best, 2), "M_reads_per_s": round(n / best / 1e6, 2), "stages_s": split,
                              "output_bytes": os.path.getsize(os.path.join(td, outf))}
+                if name == "gbuilder_gfa_rccl_host_1rank":
+                    def same(a, b):
+                        if os.path.getsize(a) != os.path.getsize(b):
+                            return False
+                        with open(a, "rb") as fa, open(b, "rb") as fb:
+                            while True:
+                                x, y = fa.read(1 << 26), fb.read(1 << 26)
+                                if x != y:
+                                    return False
+                                if not x:
+                                    return True
+                    res[name]["identical_to_single_process_gfa"] = same(os.path.join(td, "o.gfa"), os.path.join(td, "o2.gfa"))
+                    os.remove(os.path.join(td, "o2.gfa"))
             except Exception as e:  # noqa: BLE001 — an extra, never the measurement
                 res[name] = {"error": str(e)[:200]}
     return res
