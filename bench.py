@@ -324,7 +324,8 @@ def end_to_end(codes_sample, k, T):
                     res[name]["identical_to_single_process_gfa"] = same(os.path.join(td, "o.gfa"), os.path.join(td, "o2.gfa"))
                     os.remove(os.path.join(td, "o2.gfa"))
             except Exception as e:  # noqa: BLE001 — an extra, never the measurement
-                res[name] = {"error": str(e)[:200]}
+                err = getattr(e, "stderr", None)
+                res[name] = {"error": str(e)[-120:] + (" | stderr: " + err.decode(errors="replace")[-600:] if err else "")}
     return res
 
 

@@ -215,13 +215,27 @@ inline int exchange(RankComm &c, smx_ctx *ctx, const uint64_t *d_send, const std
     } else {
         GM_HIP(hipMalloc((void **)d_recv, std::max<size_t>((size_t)*n_recv * wpr * 8, 8)));
     }
-    GM_NCCL(ncclGroupStart());
-    for (int p = 0; p < c.world; ++p) {
-        if (counts[p]) GM_NCCL(ncclSend(d_send + soff[p] * wpr, counts[p] * wpr, ncclUint64, p, c.comm, c.stream));
-        const uint64_t r = roff[p + 1] - roff[p];
-        if (r) GM_NCCL(ncclRecv(*d_recv + roff[p] * wpr, r * wpr, ncclUint64, p, c.comm, c.stream));
+    // Rounds of <= 1 GiB per pair (one transfer of tens of GB was seen to stop short on this stack: dist.py, _a2a); every pair moves
+    // each word once, on views of the two buffers. The segment that stays on this rank is a device copy (SMX_MGPU_SELF_RCCL=1 sends it
+    // through ncclSend / ncclRecv as well: the one-rank tests exercise the RCCL calls that way).
+    const bool self_rccl = getenv("SMX_MGPU_SELF_RCCL") != nullptr;
+    const uint64_t LIM = (uint64_t)1 << 27;  // words
+    uint64_t mx = 0;
+    for (size_t i = 0; i < all.size(); ++i) mx = std::max<uint64_t>(mx, all[i] * wpr);
+    const uint64_t rounds = std::max<uint64_t>(1, (mx + LIM - 1) / LIM);
+    for (uint64_t r = 0; r < rounds && (c.world > 1 || self_rccl); ++r) {
+        GM_NCCL(ncclGroupStart());
+        for (int p = 0; p < c.world; ++p) {
+            if (p == c.rank && !self_rccl) continue;
+            const uint64_t s1 = soff[p + 1] * wpr, a = std::min(soff[p] * wpr + r * LIM, s1), b = std::min(a + LIM, s1);
+            const uint64_t r1 = roff[p + 1] * wpr, e = std::min(roff[p] * wpr + r * LIM, r1), f = std::min(e + LIM, r1);
+            if (b > a) GM_NCCL(ncclSend(d_send + a, b - a, ncclUint64, p, c.comm, c.stream));
+            if (f > e) GM_NCCL(ncclRecv(*d_recv + e, f - e, ncclUint64, p, c.comm, c.stream));
+        }
+        GM_NCCL(ncclGroupEnd());
     }
-    GM_NCCL(ncclGroupEnd());
+    if (!self_rccl && counts[c.rank])
+        GM_HIP(hipMemcpyAsync(*d_recv + roff[c.rank] * wpr, d_send + soff[c.rank] * wpr, (size_t)counts[c.rank] * wpr * 8, hipMemcpyDeviceToDevice, c.stream));
     GM_HIP(hipStreamSynchronize(c.stream));
     return 0;
 }
@@ -239,13 +253,21 @@ inline int gather_shards(RankComm &c, const void *d_mine, const std::vector<uint
         GM_HIP(hipDeviceSynchronize());  // (the library reads the buffer on a stream of its own)
     }
     if (c.world == 1) return 0;
-    GM_NCCL(ncclGroupStart());
-    for (int p = 0; p < c.world; ++p) {
-        if (p == c.rank) continue;
-        if (per[c.rank] && (to_all || p == 0)) GM_NCCL(ncclSend(d_mine, (size_t)per[c.rank] * unit, ncclUint8, p, c.comm, c.stream));
-        if (dest && per[p]) GM_NCCL(ncclRecv((char *)*d_full + off[p] * unit, (size_t)per[p] * unit, ncclUint8, p, c.comm, c.stream));
+    const uint64_t LIM = (uint64_t)1 << 30;  // bytes per pair and round, as in exchange()
+    uint64_t mx = 0;
+    for (int p = 0; p < c.world; ++p) mx = std::max<uint64_t>(mx, per[p] * unit);
+    const uint64_t rounds = std::max<uint64_t>(1, (mx + LIM - 1) / LIM);
+    for (uint64_t r = 0; r < rounds; ++r) {
+        GM_NCCL(ncclGroupStart());
+        for (int p = 0; p < c.world; ++p) {
+            if (p == c.rank) continue;
+            const uint64_t mine_b = per[c.rank] * unit, a = std::min(r * LIM, mine_b), b = std::min(a + LIM, mine_b);
+            if (b > a && (to_all || p == 0)) GM_NCCL(ncclSend((const char *)d_mine + a, b - a, ncclUint8, p, c.comm, c.stream));
+            const uint64_t theirs = per[p] * unit, e = std::min(r * LIM, theirs), f = std::min(e + LIM, theirs);
+            if (dest && f > e) GM_NCCL(ncclRecv((char *)*d_full + off[p] * unit + e, f - e, ncclUint8, p, c.comm, c.stream));
+        }
+        GM_NCCL(ncclGroupEnd());
     }
-    GM_NCCL(ncclGroupEnd());
     GM_HIP(hipStreamSynchronize(c.stream));
     return 0;
 }

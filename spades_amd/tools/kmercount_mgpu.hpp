@@ -12,6 +12,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -134,14 +135,29 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
         }
         d_recv = (uint64_t *)p;
     }
-    // the exchange: all pairs at once, every pair on its own xGMI link
-    MG_NCCL(ncclGroupStart());
-    for (int p = 0; p < world; ++p) {
-        if (counts[p]) MG_NCCL(ncclSend(d_send + soff[p] * nw, counts[p] * nw, ncclUint64, p, comm, stream));
-        const uint64_t rc_ = roff[p + 1] - roff[p];
-        if (rc_) MG_NCCL(ncclRecv(d_recv + roff[p] * nw, rc_ * nw, ncclUint64, p, comm, stream));
+    // the exchange: all pairs at once, every pair on its own xGMI link, in rounds of <= 1 GiB per pair (one transfer of tens of GB was
+    // seen to stop short on this stack: dist.py, _a2a); the segment that stays here is a device copy (SMX_MGPU_SELF_RCCL=1 sends it
+    // through ncclSend / ncclRecv as well: the one-rank tests exercise the RCCL calls that way)
+    {
+        const bool self_rccl = getenv("SMX_MGPU_SELF_RCCL") != nullptr;
+        const uint64_t LIM = (uint64_t)1 << 27;  // words
+        uint64_t mx = 0;
+        for (size_t i = 0; i < all.size(); ++i) mx = std::max<uint64_t>(mx, all[i] * nw);
+        const uint64_t rounds = std::max<uint64_t>(1, (mx + LIM - 1) / LIM);
+        for (uint64_t r = 0; r < rounds && (world > 1 || self_rccl); ++r) {
+            MG_NCCL(ncclGroupStart());
+            for (int p = 0; p < world; ++p) {
+                if (p == rank && !self_rccl) continue;
+                const uint64_t s1 = soff[p + 1] * nw, a = std::min(soff[p] * nw + r * LIM, s1), b = std::min(a + LIM, s1);
+                const uint64_t r1 = roff[p + 1] * nw, e = std::min(roff[p] * nw + r * LIM, r1), f = std::min(e + LIM, r1);
+                if (b > a) MG_NCCL(ncclSend(d_send + a, b - a, ncclUint64, p, comm, stream));
+                if (f > e) MG_NCCL(ncclRecv(d_recv + e, f - e, ncclUint64, p, comm, stream));
+            }
+            MG_NCCL(ncclGroupEnd());
+        }
+        if (!self_rccl && counts[rank])
+            MG_HIP(hipMemcpyAsync(d_recv + roff[rank] * nw, d_send + soff[rank] * nw, (size_t)counts[rank] * nw * 8, hipMemcpyDeviceToDevice, stream));
     }
-    MG_NCCL(ncclGroupEnd());
     MG_HIP(hipStreamSynchronize(stream));
     smx_extract_release(ctx);
     if (int rc = smx_count_records(ctx, K, NB, d_recv, n_recv)) {

@@ -42,10 +42,12 @@ def test_kmercount_cli_rccl_host_one_rank(tmp_path):
     f1, f2 = str(tmp_path / "a.fq"), str(tmp_path / "b.fq.gz")
     _fastq(f1, reads[0::2])
     _fastq(f2, reads[1::2], gz=True)
-    for c in cases[:4]:
+    for i, c in enumerate(cases[:4]):
         wd = tmp_path / f"m{c['K']}"
         wd.mkdir()
-        subprocess.check_call([KC, "-k", str(c["K"]), "-w", str(wd), "--gpus", "1", f1, f2], stdout=subprocess.DEVNULL, timeout=300)
+        # (alternately: the segment that stays on the rank as a device copy / through ncclSend + ncclRecv to itself)
+        subprocess.check_call([KC, "-k", str(c["K"]), "-w", str(wd), "--gpus", "1", f1, f2], stdout=subprocess.DEVNULL, timeout=300,
+                              env=dict(os.environ, **({"SMX_MGPU_SELF_RCCL": "1"} if i % 2 else {})))
         assert open(wd / "final_kmers", "rb").read() == open(os.path.join(GOLDEN, c["file"]), "rb").read()
 
 
@@ -79,7 +81,9 @@ def test_gbuilder_cli_rccl_host_one_rank(tmp_path):
             want = open(os.path.join(GOLDEN, c["file"])).read()
             # FASTA: every rank parses the file and keeps its reads; FASTQ: its byte range, here in three pieces with a small chunk
             # (carry-over of the cut record between chunks); SMX_MGPU_KPOMERS: the route by the sharded (k+1)-mer count
-            for inp, env in ((fa, {}), (fq, {"SMX_MGPU_PARTS": "3", "SMX_MGPU_CHUNK": "2048"}), (fq, {"SMX_MGPU_KPOMERS": "1", "SMX_MGPU_PARTS": "2"})):
+            # SMX_MGPU_SELF_RCCL: the segment that stays on the rank goes through ncclSend + ncclRecv instead of a device copy
+            for inp, env in ((fa, {"SMX_MGPU_SELF_RCCL": "1"}), (fq, {"SMX_MGPU_PARTS": "3", "SMX_MGPU_CHUNK": "2048"}),
+                             (fq, {"SMX_MGPU_KPOMERS": "1", "SMX_MGPU_PARTS": "2", "SMX_MGPU_SELF_RCCL": "1"})):
                 if os.path.exists(out):
                     os.remove(out)
                 subprocess.check_call([GB, inp, out, "-k", str(c["K"]), "-t", "3", "--gfa", "--gpus", "1"] + cov, stdout=subprocess.DEVNULL,
