@@ -296,7 +296,7 @@ def end_to_end(codes_sample, k, T):
         for name, exe, argv, outf, extra_env in (
                 ("gbuilder_gfa", "spades-gbuilder-mi355x", [fq, os.path.join(td, "o.gfa"), "-k", str(k), "-t", str(T), "--gfa"], "o.gfa", {}),
                 ("gbuilder_gfa_rccl_host_1rank", "spades-gbuilder-mi355x", [fq, os.path.join(td, "o2.gfa"), "-k", str(k), "-t", str(T), "--gfa", "--gpus", "1"], "o2.gfa",
-                 {"SMX_MGPU_PARTS": "4"}),
+                 {"SMX_MGPU_PARTS": "4", "SMX_MGPU_SELF_RCCL": "1"}),  # (the rank's own segment through ncclSend / ncclRecv, as between ranks)
                 ("kmercount", "spades-kmercount-mi355x", ["-k", str(k), "-w", td, fq], "final_kmers", {})):
             try:
                 best, split = None, None
