@@ -12,6 +12,7 @@
 // Exchanges are grouped ncclSend / ncclRecv between all pairs (xGMI is point to point: every pair has its own link, no ring).
 // A graph whose gathered structure exceeds one GPU's HBM needs the distributed walks, which only dist.py drives today.
 #pragma once
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <signal.h>
@@ -66,6 +67,12 @@ struct GbOptions {
     std::string outfile;
     std::vector<std::string> files;
 };
+
+#define GM_MARK(what)                                                                              \
+    if (getenv("SMX_DEBUG")) {                                                                    \
+        fprintf(stderr, "[rank %d] %s\n", c.rank, what);                                          \
+        fflush(stderr);                                                                            \
+    }
 
 struct RankComm {
     int rank = 0, world = 1;
@@ -223,6 +230,7 @@ inline int exchange(RankComm &c, smx_ctx *ctx, const uint64_t *d_send, const std
     uint64_t mx = 0;
     for (size_t i = 0; i < all.size(); ++i) mx = std::max<uint64_t>(mx, all[i] * wpr);
     const uint64_t rounds = std::max<uint64_t>(1, (mx + LIM - 1) / LIM);
+    GM_MARK(self_rccl ? "exchange: own segment through RCCL" : "exchange: own segment as a device copy")
     for (uint64_t r = 0; r < rounds && (c.world > 1 || self_rccl); ++r) {
         GM_NCCL(ncclGroupStart());
         for (int p = 0; p < c.world; ++p) {
@@ -298,6 +306,7 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
         return rc;
     }
     if (int rc = comm_init(c, idfile)) return rc;
+    GM_MARK("communicator up")
     // input
     unsigned sub = 1;
     if (const char *e = getenv("SMX_MGPU_PARTS")) sub = (unsigned)std::max(1, atoi(e));
@@ -319,6 +328,7 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
                 return rc;
             }
         }
+    GM_MARK("input submitted")
     const unsigned k = o.k, K1 = k + 1, nb = 10 * o.nthreads, nw = (K1 + 31) / 32;  // (an odd k and k + 1 take the same number of words)
     const bool ext = smx_kmers_with_masks_supported(k) != 0 && !getenv("SMX_MGPU_KPOMERS");
     const bool cov = o.coverage && o.mode != 0;  // (-c does nothing for --unitigs: gbuilder.cpp:191-199)
@@ -353,6 +363,7 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
         (void)hipFree(d_recv);
     }
     GM_SMX(smx_graph_shard_info(ctx, &n_kmers, ksizes.data()));
+    GM_MARK("owner-side shard built")
     // what every rank has: [k-mers, (k+1)-mers, extension bits, palindromic (k+1)-mers, k-mer bucket sizes, (k+1)-mer bucket sizes]
     std::vector<uint64_t> me(4 + 2 * (size_t)nb), every;
     me[0] = n_kmers, me[1] = n_kpo, me[2] = stats[0], me[3] = stats[1];
@@ -398,6 +409,7 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
     }
     uint64_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (builds) GM_SMX(smx_graph_info(ctx, info));
+    GM_MARK("graph built from the gathered shards")
     if (cov) {
         void *d_full_p = nullptr;
         if (int rc = gather_shards(c, d_kpo_mine, kpo_per, (size_t)nw * 8, true, &d_full_p)) return rc;
@@ -428,9 +440,11 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
                              : smx_graph_write_unitigs(ctx, o.outfile.c_str()));
         unlink(idfile.c_str());
     }
+    GM_MARK("output written")
     ncclCommDestroy(c.comm);
     (void)hipStreamDestroy(c.stream);
     smx_destroy(ctx);
+    GM_MARK("rank done")
     return 0;
 }
 
@@ -456,6 +470,7 @@ inline int gb_run_sharded(int world, const GbOptions &o) {
             return SMX_DEVICE_ERROR;
         }
         if (pid == 0) {
+            prctl(PR_SET_PDEATHSIG, SIGKILL);  // a rank never outlives the tool (a killed tool would leave its ranks on the GPUs)
             int rc;
             try {
                 rc = gb_rank_main(r, world, o, idfile);

@@ -8,6 +8,7 @@
 #pragma once
 #include <signal.h>
 #include <fcntl.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -248,7 +249,10 @@ inline int run_sharded(int world, unsigned K, const std::string &workdir, const 
             for (pid_t k : kids) waitpid(k, nullptr, 0);
             return SMX_DEVICE_ERROR;
         }
-        if (pid == 0) _exit(sharded_rank_main(r, world, K, workdir, input));
+        if (pid == 0) {
+            prctl(PR_SET_PDEATHSIG, SIGKILL);  // a rank never outlives the tool
+            _exit(sharded_rank_main(r, world, K, workdir, input));
+        }
         kids.push_back(pid);
     }
     int rc = 0;
