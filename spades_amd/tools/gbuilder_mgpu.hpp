@@ -157,6 +157,12 @@ inline int submit_share(smx_ctx *ctx, const std::string &path, unsigned part, un
     return rc;
 }
 
+// words per pair and round of an exchange (1 GiB; SMX_MGPU_ROUND_WORDS: a test hook that makes small inputs take several rounds)
+inline uint64_t round_limit_words() {
+    if (const char *e = getenv("SMX_MGPU_ROUND_WORDS")) return (uint64_t)std::max(1LL, atoll(e));
+    return (uint64_t)1 << 27;
+}
+
 // ---- communicator ----------------------------------------------------------------------------------------------------------------
 inline int comm_init(RankComm &c, const std::string &idfile) {
     ncclUniqueId id;
@@ -226,7 +232,7 @@ inline int exchange(RankComm &c, smx_ctx *ctx, const uint64_t *d_send, const std
     // each word once, on views of the two buffers. The segment that stays on this rank is a device copy (SMX_MGPU_SELF_RCCL=1 sends it
     // through ncclSend / ncclRecv as well: the one-rank tests exercise the RCCL calls that way).
     const bool self_rccl = getenv("SMX_MGPU_SELF_RCCL") != nullptr;
-    const uint64_t LIM = (uint64_t)1 << 27;  // words
+    const uint64_t LIM = round_limit_words();
     uint64_t mx = 0;
     for (size_t i = 0; i < all.size(); ++i) mx = std::max<uint64_t>(mx, all[i] * wpr);
     const uint64_t rounds = std::max<uint64_t>(1, (mx + LIM - 1) / LIM);
@@ -261,7 +267,7 @@ inline int gather_shards(RankComm &c, const void *d_mine, const std::vector<uint
         GM_HIP(hipDeviceSynchronize());  // (the library reads the buffer on a stream of its own)
     }
     if (c.world == 1) return 0;
-    const uint64_t LIM = (uint64_t)1 << 30;  // bytes per pair and round, as in exchange()
+    const uint64_t LIM = round_limit_words() * 8;  // bytes per pair and round, as in exchange()
     uint64_t mx = 0;
     for (int p = 0; p < c.world; ++p) mx = std::max<uint64_t>(mx, per[p] * unit);
     const uint64_t rounds = std::max<uint64_t>(1, (mx + LIM - 1) / LIM);
@@ -449,6 +455,7 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
     ncclCommDestroy(c.comm);
     (void)hipStreamDestroy(c.stream);
     smx_destroy(ctx);
+    alarm(0);
     GM_MARK("rank done")
     return 0;
 }

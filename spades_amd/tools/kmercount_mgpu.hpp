@@ -141,7 +141,7 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
     // through ncclSend / ncclRecv as well: the one-rank tests exercise the RCCL calls that way)
     {
         const bool self_rccl = getenv("SMX_MGPU_SELF_RCCL") != nullptr;
-        const uint64_t LIM = (uint64_t)1 << 27;  // words
+        const uint64_t LIM = getenv("SMX_MGPU_ROUND_WORDS") ? (uint64_t)std::max(1LL, atoll(getenv("SMX_MGPU_ROUND_WORDS"))) : (uint64_t)1 << 27;  // words (env: test hook)
         uint64_t mx = 0;
         for (size_t i = 0; i < all.size(); ++i) mx = std::max<uint64_t>(mx, all[i] * nw);
         const uint64_t rounds = std::max<uint64_t>(1, (mx + LIM - 1) / LIM);
@@ -227,6 +227,7 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
     ncclCommDestroy(comm);
     (void)hipStreamDestroy(stream);
     smx_destroy(ctx);
+    alarm(0);
     return 0;
 }
 
