@@ -303,7 +303,8 @@ def end_to_end(codes_sample, k, T):
                 for _ in range(2):  # second run: the page cache and the GPU's clocks are warm
                     t0 = time.time()
                     r = subprocess.run([os.path.join(tools, exe)] + argv, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                                       env=dict(os.environ, SMX_DEBUG="1", **extra_env), check=True, timeout=600)
+                                       env=dict(os.environ, SMX_DEBUG="1", **extra_env), check=True,
+                                       timeout=90 if "rccl_host" in name else 600)  # (an extra must not hold the line up: DESIGN.md §5, the launch that did not come back)
                     dt = time.time() - t0
                     if best is None or dt < best:
                         best = dt
