@@ -472,6 +472,8 @@ inline int gb_run_sharded(int world, const GbOptions &o) {
         fclose(t);
     }
     const std::string idfile = o.outfile + ".smx_nccl_id";
+    // RCCL between processes of one node shares device memory through dmabuf handles: the host driver of these boxes supports nothing else
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     unlink(idfile.c_str());
     std::vector<pid_t> kids;
     for (int r = 0; r < world; ++r) {

@@ -244,6 +244,8 @@ inline int run_sharded(int world, unsigned K, const std::string &workdir, const 
         fclose(t);
     }
     mkdir(workdir.c_str(), 0777);
+    // RCCL between processes of one node shares device memory through dmabuf handles: the host driver of these boxes supports nothing else
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     unlink((workdir + "/.smx_nccl_id").c_str());
     std::vector<pid_t> kids;
     for (int r = 0; r < world; ++r) {
