@@ -398,6 +398,26 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
     }
     // gather {k-mers, masks} where a graph is built: everywhere with -c (every rank counts its own reads on it), else on rank 0
     const bool builds = cov || rank == 0;
+    {   // Does the gathered structure fit where it is built? The gathered copy and the library's own cost (8 * words + 1) B per k-mer of
+        // the WHOLE graph each, the successor table 16 B more (dist.py decides by the same figure). Every rank hears the answer, so
+        // all leave together with the reference's "memory limit" code instead of one rank failing inside an allocation.
+        size_t dev_free = 0, dev_total = 0, arena_free = 0;
+        GM_HIP(hipMemGetInfo(&dev_free, &dev_total));
+        (void)smx_arena_free_bytes(ctx, &arena_free);
+        const double need = (double)total_kmers * (2.0 * (8.0 * nw + 1.0) + 16.0), have = (double)dev_free + (double)arena_free;
+        uint64_t fits = (!builds || need <= have) ? 1 : 0;
+        if (getenv("SMX_MGPU_ASSUME_FREE_BYTES")) fits = (!builds || need <= atof(getenv("SMX_MGPU_ASSUME_FREE_BYTES"))) ? 1 : 0;  // (test hook)
+        std::vector<uint64_t> all_fit;
+        if (int rc = all_gather_words(c, &fits, 1, all_fit)) return rc;
+        for (int p = 0; p < world; ++p)
+            if (!all_fit[p]) {
+                if (rank == p || (rank == 0 && all_fit[0]))
+                    fprintf(stderr, "[rank %d] the graph's k-mers and masks (%llu k-mers, %.1f GB to build from) do not fit rank %d's free device memory%s: "
+                                    "this graph needs the distributed walks (python: spades_amd.dist.sharded_build_graph(walks=\"distributed\"))\n",
+                            rank, (unsigned long long)total_kmers, need / 1e9, p, rank == p ? "" : " (reported by that rank)");
+                return SMX_MEMORY_LIMIT_EXCEEDED;
+            }
+    }
     {
         uint64_t *d_my_k = nullptr;
         uint8_t *d_my_m = nullptr;

@@ -93,6 +93,10 @@ hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipSt
     memmove(d, s, n);
     return hipSuccess;
 }
+hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
+    *free_b = (size_t)200 << 30, *total_b = (size_t)288 << 30;
+    return hipSuccess;
+}
 const char *hipGetErrorString(hipError_t) { return "hip (shim)"; }
 
 // ---- RCCL: forwarded ----------------------------------------------------------------------------------------------------------------
@@ -136,6 +140,10 @@ int smx_create(smx_ctx **out, int device, size_t) {
     return (int)fwd("smx_create", 1, LL(device));
 }
 void smx_destroy(smx_ctx *) {}
+int smx_arena_free_bytes(smx_ctx *, size_t *bytes) {
+    *bytes = (size_t)10 << 30;
+    return SMX_OK;
+}
 const char *smx_last_error(const smx_ctx *) { return g_err.c_str(); }
 void *smx_pinned_alloc(size_t n) { return malloc(n ? n : 1); }
 void smx_pinned_free(void *p) { free(p); }

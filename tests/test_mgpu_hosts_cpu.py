@@ -365,3 +365,15 @@ def test_kmercount_host_world_n(tmp_path, world, K, env):
     ref, _ = oracle.count(reads, K, "A", 16)
     assert open(tmp_path / "final_kmers", "rb").read() == ref.tobytes()  # the ranks' bucket ranges, each written at its offset
     assert sum(g["owned"] for g in got) == len(ref) and all(g["owned"] > 0 for g in got)
+
+
+def test_gbuilder_host_refuses_a_graph_that_does_not_fit(tmp_path):
+    """the gathered structure would not fit where the graph is built: EVERY rank leaves with the reference's memory-limit code (68), none
+    waits in a collective, nothing is written"""
+    reads = [r for r in read_lines("reads_small.txt")[:120] if r]
+    inp = str(tmp_path / "r.fq")
+    _write_fastq(inp, reads)
+    out = str(tmp_path / "g.gfa")
+    got = _run(2, "gbuilder", (21, 1, False, [inp], out), {"SMX_MGPU_ASSUME_FREE_BYTES": "1000"}, reads, 40500)
+    assert [g["rc"] for g in got] == [68, 68] and not os.path.exists(out)
+    assert all("smx_build_graph_from_kmers" not in g["calls"] for g in got)
