@@ -811,8 +811,9 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
             for rel in ("extract_release", "exchange_release", "graph_clear"):
                 if hasattr(engine, rel):
                     getattr(engine, rel)()
-            if not coverage:
-                n_kpo, kpo_sizes, kpo_mine = count_kpomers()
+            # the (k+1)-mer route starts from the count result IN THE CONTEXT: also when -c had counted before, that result went when the
+            # abandoned route extracted its k-mers (smx_extract_kmers_ext_owned drops it for room), so it is counted again
+            n_kpo, kpo_sizes, kpo_mine = count_kpomers()
     if not ext:
         # 2. extension updates -> owners of the k-mers
         upd = _guarded(dev, "update buffer", engine.alloc, 2 * n_kpo * (nw + 1), dev)

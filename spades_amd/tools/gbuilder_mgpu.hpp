@@ -208,6 +208,23 @@ inline int all_gather_words(RankComm &c, const uint64_t *mine, size_t n, std::ve
     return 0;
 }
 
+// What a rank-local step returned, heard by every rank (as dist.py: _guarded): 0 when it went well everywhere; otherwise the largest
+// code that is not the memory limit if there is one, and *memory_only says whether every failure was the memory limit (then all
+// ranks may take another route together).
+inline int agree(RankComm &c, int rc_local, bool *memory_only) {
+    const uint64_t mine = (uint64_t)rc_local;
+    std::vector<uint64_t> all;
+    if (int rc = all_gather_words(c, &mine, 1, all)) return rc;
+    int worst = 0, genuine = 0;
+    for (uint64_t v : all)
+        if (v) {
+            worst = std::max(worst, (int)v);
+            if ((int)v != SMX_MEMORY_LIMIT_EXCEEDED) genuine = std::max(genuine, (int)v);
+        }
+    *memory_only = worst != 0 && genuine == 0;
+    return genuine ? genuine : worst;  // (a memory limit next to another error is not what the user has to hear about)
+}
+
 // ONE all-to-all of records of `wpr` words: counts[p] records of d_send (grouped by destination) go to rank p. The receive side
 // comes from the library's pool (consumed by the call that follows) or from hipMalloc (*d_recv then belongs to the caller).
 inline int exchange(RankComm &c, smx_ctx *ctx, const uint64_t *d_send, const std::vector<uint64_t> &counts, unsigned wpr, bool pool,
@@ -348,16 +365,39 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
             if (n_kpo) GM_SMX(smx_copy_kmers_device(ctx, d_kpo_mine));
         }
     }
+    bool ext_now = ext;
     if (ext) {
+        // The one-exchange route keeps every distinct k-mer of the rank's reads and then of its bucket range in HBM at once; where that
+        // does not fit on SOME rank, ALL ranks hear of it and take the (k+1)-mer route together (the single-GPU library falls back the
+        // same way). Any other failure ends the run on every rank.
         std::vector<uint64_t> counts(world, 0);
         const void *p = nullptr;
-        GM_SMX(smx_extract_kmers_ext_owned(ctx, k, nb, (unsigned)world, &p, counts.data()));
-        uint64_t *d_recv = nullptr, n_recv = 0;
-        if (int rc = exchange(c, ctx, (const uint64_t *)p, counts, nw, true, &d_recv, &n_recv)) return rc;
-        GM_SMX(smx_extract_release(ctx));
-        GM_SMX(smx_graph_shard_from_ext(ctx, k, nb, (unsigned)world, (unsigned)rank, d_recv, n_recv));
-        GM_SMX(smx_graph_shard_ext_stats(ctx, stats));
-    } else {
+        bool memory_only = false;
+        int rc_local = smx_extract_kmers_ext_owned(ctx, k, nb, (unsigned)world, &p, counts.data());
+        if (rc_local) fprintf(stderr, "[rank %d] %s\n", rank, smx_last_error(ctx));
+        int worst = agree(c, rc_local, &memory_only);
+        if (!worst) {
+            uint64_t *d_recv = nullptr, n_recv = 0;
+            if (int rc = exchange(c, ctx, (const uint64_t *)p, counts, nw, true, &d_recv, &n_recv)) return rc;
+            GM_SMX(smx_extract_release(ctx));
+            rc_local = smx_graph_shard_from_ext(ctx, k, nb, (unsigned)world, (unsigned)rank, d_recv, n_recv);
+            if (rc_local) fprintf(stderr, "[rank %d] %s\n", rank, smx_last_error(ctx));
+            worst = agree(c, rc_local, &memory_only);
+        }
+        if (worst) {
+            if (!memory_only) return worst;
+            if (rank == 0) fprintf(stderr, "the one-exchange route does not fit on some rank: all ranks take the route by the (k+1)-mer count\n");
+            (void)smx_extract_release(ctx);   // whatever the abandoned route left behind goes before the retry: the send buffer,
+            (void)smx_exchange_release(ctx);  // an unconsumed receive buffer,
+            (void)smx_graph_clear(ctx);       // the shard of a rank whose own step had gone well
+            ext_now = false;
+            // (also when -c had counted the (k+1)-mers before: that result went when the abandoned route extracted its k-mers)
+            if (int rc = sharded_count_canonical(c, ctx, K1, nb, &n_kpo, kpo_sizes)) return rc;
+        } else {
+            GM_SMX(smx_graph_shard_ext_stats(ctx, stats));
+        }
+    }
+    if (!ext_now) {
         uint64_t *d_upd = nullptr;
         GM_HIP(hipMalloc((void **)&d_upd, std::max<size_t>((size_t)2 * n_kpo * (nw + 1) * 8, 8)));
         std::vector<uint64_t> ucounts(world, 0);
@@ -384,7 +424,7 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
         for (unsigned b = 0; b < nb; ++b) g_ksizes[b] += e[4 + b], g_psizes[b] += e[4 + nb + b];
     }
     uint64_t n_kpo_all = total_kpo;
-    if (ext) {  // every non-palindromic (k+1)-mer set two extension bits somewhere, a palindromic one a single bit
+    if (ext_now) {  // every non-palindromic (k+1)-mer set two extension bits somewhere, a palindromic one a single bit
         if (bits % 2) {
             fprintf(stderr, "[rank %d] odd number of extension bits over all shards\n", rank);
             return SMX_DEVICE_ERROR;

@@ -158,6 +158,8 @@ int smx_extract_partition_owned(smx_ctx *, unsigned K, int mode, unsigned nb, un
     return (int)fwd("smx_extract_partition_owned", 6, LL(K), LL(mode), LL(nb), LL(world), LL(d), LL(counts));
 }
 int smx_extract_release(smx_ctx *) { return (int)fwd("smx_extract_release", 0); }
+int smx_exchange_release(smx_ctx *) { return (int)fwd("smx_exchange_release", 0); }
+int smx_graph_clear(smx_ctx *) { return (int)fwd("smx_graph_clear", 0); }
 int smx_exchange_buffer(smx_ctx *, uint64_t n_words, void **d) { return (int)fwd("smx_exchange_buffer", 2, LL(n_words), LL(d)); }
 int smx_count_records(smx_ctx *, unsigned K, unsigned nb, const void *d, uint64_t n) { return (int)fwd("smx_count_records", 4, LL(K), LL(nb), LL(d), LL(n)); }
 int smx_count_info(const smx_ctx *, uint64_t *n, unsigned *wpr, uint64_t *inst) { return (int)fwd("smx_count_info", 3, LL(n), LL(wpr), LL(inst)); }

@@ -172,6 +172,7 @@ class OracleGraphEngine(OracleEngine):
     def extract_kmers_ext_owned(self, k, nb, world, dev):
         from oracle import oracle
         g = oracle.build_graph(self.reads, k, nb)  # k-mers and masks of THIS rank's reads
+        self.__dict__.pop("result", None)  # (as the library: the extraction drops the context's previous count result for room)
         nwk = (k + 31) // 32
         rec = np.array(g["kmers"], dtype=np.uint64).reshape(-1, nwk).copy()
         owner = np.array([oracle.bucket(r, k, nb) * world // nb for r in rec], dtype=np.int64)
@@ -359,7 +360,7 @@ class _FailingEngine(OracleGraphEngine):
         return super().count_records(*a)
 
 
-def _failing_worker(rank, world, port, k, fail_rank, fail_in, code, route, q, other_code=0):
+def _failing_worker(rank, world, port, k, fail_rank, fail_in, code, route, q, other_code=0, coverage=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -368,7 +369,7 @@ def _failing_worker(rank, world, port, k, fail_rank, fail_in, code, route, q, ot
     reads = read_lines("reads_small.txt")[:120]
     eng = _FailingEngine(reads[rank::world], reads, fail_in if (rank == fail_rank or other_code) else None, code if rank == fail_rank else other_code)
     try:
-        info = smx_dist.sharded_build_graph(eng, k, 1, rank, world, torch.device("cpu"), coverage=False, route=route)
+        info = smx_dist.sharded_build_graph(eng, k, 1, rank, world, torch.device("cpu"), coverage=coverage, route=route)
         q.put((rank, "ok", info["route"], eng.g["gfa"]))
     except smx_dist.CollectiveFailure as e:
         q.put((rank, "failed", e.code, ""))
@@ -381,6 +382,7 @@ def _failing_worker(rank, world, port, k, fail_rank, fail_in, code, route, q, ot
     ("shard_from_ext", 70, "auto", "all_fail"),   # any other error: every rank raises
     ("count_records", 68, "kpomers", "all_fail"),  # no further route to fall back to
     ("shard_from_ext", 68, "auto", "mixed"),      # a memory limit on one rank AND a genuine error (67) on the other: no fallback may swallow the 67
+    ("shard_from_ext", 68, "auto", "fallback_cov"),  # the fallback with -c: the (k+1)-mer count made for -c went with the abandoned route and is made again
 ])
 def test_a_failing_rank_does_not_leave_the_others_waiting(fail_in, code, route, expect):
     from oracle import oracle
@@ -388,15 +390,16 @@ def test_a_failing_rank_does_not_leave_the_others_waiting(fail_in, code, route, 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 35500 + (os.getpid() % 2000) + code
-    port += 7 if expect == "mixed" else 0
-    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, k, 1, fail_in, code, route, q, 67 if expect == "mixed" else 0)) for r in range(world)]
+    port += 7 if expect == "mixed" else 13 if expect == "fallback_cov" else 0
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, k, 1, fail_in, code, route, q, 67 if expect == "mixed" else 0, expect == "fallback_cov"))
+             for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    if expect == "fallback":
+    if expect in ("fallback", "fallback_cov"):
         g = oracle.build_graph(read_lines("reads_small.txt")[:120], k, 10, coverage=True)  # (the test engine always asks for the tags)
         assert all(x[1] == "ok" and x[2] == "kpomers" and x[3] == g["gfa"] for x in got)
     else:

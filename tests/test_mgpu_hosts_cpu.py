@@ -69,6 +69,12 @@ class ShimRank:
     def __call__(self, name, a):
         name = name.decode()
         self.calls.append(name)
+        inj = os.environ.get("SHIM_FAIL", "")  # "rank:function:code[,...]": that call fails once on that rank, as the library would
+        for item in [x for x in inj.split(",") if x]:
+            r, fn, code = item.split(":")
+            if int(r) == self.rank and fn == name and (fn, "done") not in self.keep:
+                self.keep.append((fn, "done"))
+                return int(code)
         try:
             return int(getattr(self, "f_" + name)(*[int(a[i]) for i in range(10)]) or 0)
         except Exception:  # noqa: BLE001 — report through the C ABI's error code, as the library would
@@ -154,6 +160,12 @@ class ShimRank:
 
     def f_smx_extract_release(self, *_):
         pass
+
+    def f_smx_exchange_release(self, *_):
+        pass
+
+    def f_smx_graph_clear(self, *_):
+        self.shard = None
 
     def f_smx_exchange_buffer(self, n_words, p_ptr, *_):
         buf = torch.full((max(n_words, 1),), -1, dtype=torch.int64)  # (words the exchange does not fill would show up as k-mers)
@@ -377,3 +389,23 @@ def test_gbuilder_host_refuses_a_graph_that_does_not_fit(tmp_path):
     got = _run(2, "gbuilder", (21, 1, False, [inp], out), {"SMX_MGPU_ASSUME_FREE_BYTES": "1000"}, reads, 40500)
     assert [g["rc"] for g in got] == [68, 68] and not os.path.exists(out)
     assert all("smx_build_graph_from_kmers" not in g["calls"] for g in got)
+
+
+@pytest.mark.parametrize("coverage,inject,expect", [
+    (False, "1:smx_graph_shard_from_ext:68", "fallback"),   # the memory limit on ONE rank: all ranks take the (k+1)-mer route together
+    (True, "0:smx_extract_kmers_ext_owned:68", "fallback"),  # ... also before the exchange, and with the (k+1)-mers already counted for -c
+    (False, "1:smx_graph_shard_from_ext:68,0:smx_graph_shard_from_ext:67", "fail67"),  # a genuine error next to it is not swallowed
+])
+def test_gbuilder_host_falls_back_on_all_ranks_together(tmp_path, coverage, inject, expect):
+    from oracle import oracle
+    reads = [r for r in read_lines("reads_small.txt")[:120] if r]
+    inp = str(tmp_path / "r.fq")
+    _write_fastq(inp, reads)
+    out = str(tmp_path / "g.gfa")
+    got = _run(2, "gbuilder", (21, 1, coverage, [inp], out), {"SHIM_FAIL": inject}, reads, 41500 + len(inject))
+    if expect == "fallback":
+        assert all(g["rc"] == 0 for g in got), [g["error"] for g in got]
+        assert all("smx_graph_shard_updates" in g["calls"] and "smx_graph_clear" in g["calls"] for g in got)
+        assert open(out).read() == oracle.build_graph(reads, 21, 10, coverage=True)["gfa"]
+    else:
+        assert [g["rc"] for g in got] == [67, 67] and not os.path.exists(out)
