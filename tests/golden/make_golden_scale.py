@@ -3,7 +3,9 @@
 write for a seeded >= 2 M-read set, generated in the build container (binaries under $SMX_REF_BIN, built from /root/reference by
 the survey's cmake recipe). The read set comes from tests/synth.py, so the GPU box regenerates the identical reads and only the
 md5s travel (tests/golden/scale_*.json).
-usage: make_golden_scale.py [n_reads=2000000] [genome_len=10000000] [seed=77] [k=55] [what=all|kmercount|gfa|allskew]
+usage: make_golden_scale.py [n_reads=2000000] [genome_len=10000000] [seed=77] [k=55] [what=all|kmercount|gfa|allskew|gfaplasmids]
+  gfaplasmids: error-free reads from genome_len / 5000 circular genomes of 5 kb (tests/synth.py: synth_codes_plasmids) — one perfect
+  loop per plasmid; written as next_scale_*.json, which tests/test_scale_gpu.py only takes with SMX_SCALE_NEXT=1
   BASELINE config 2 (10 M PE150 reads, k=21, spades-kmercount):  make_golden_scale.py 1e7 5e7 1 21 kmercount"""
 import hashlib
 import json
@@ -38,11 +40,15 @@ def main():
     out = {"n_reads": n, "genome_len": g, "seed": seed, "k": k, "threads": threads, "err": 0.01, "n_rate": 0.001,
            # spades-gbuilder clamps -t to omp_get_max_threads() (gbuilder.cpp:154): the bucket count that fixes the unitig order is 10 x this
            "effective_threads": min(threads, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))}
+    plasmids = what.endswith("plasmids")
+    if plasmids:
+        what = what[:-8] or "all"
+        out.update(plasmids=True, plasmid_len=5000, err=0.0, n_rate=0.0)
     skew = what.endswith("skew")  # repeats, low complexity, log-normal abundances over 64 genomes (tests/synth.py: synth_codes_skewed)
     if skew:
         what = what[:-4] or "all"
         out["skew"] = True
-    codes = synth.synth_codes_skewed(seed, g, n) if skew else synth.synth_codes(seed, g, n)
+    codes = synth.synth_codes_plasmids(seed, g, n) if plasmids else synth.synth_codes_skewed(seed, g, n) if skew else synth.synth_codes(seed, g, n)
     out["codes_md5"] = hashlib.md5(codes.tobytes()).hexdigest()
     with tempfile.TemporaryDirectory(dir=os.environ.get("SMX_GOLDEN_TMP", "/tmp")) as td:
         os.makedirs(os.path.join(td, "kc"))
@@ -62,8 +68,11 @@ def main():
         for cov in ((False, True) if what in ("all", "gfa") else ()):
             gfa = os.path.join(td, "g.gfa")
             t0 = time.time()
-            subprocess.check_call([os.path.join(REF_BIN, "spades-gbuilder"), fq, gfa, "-k", str(k), "-t", str(threads), "--gfa"] + (["-c"] if cov else []) +
-                                  ["-tmp-dir", os.path.join(td, "tmp")], stdout=subprocess.DEVNULL)
+            log = subprocess.check_output([os.path.join(REF_BIN, "spades-gbuilder"), fq, gfa, "-k", str(k), "-t", str(threads), "--gfa"] + (["-c"] if cov else []) +
+                                          ["-tmp-dir", os.path.join(td, "tmp")]).decode(errors="replace")
+            for line in log.splitlines():
+                if "loops collected" in line:
+                    out["perfect_loops"] = int(line.split("finished.")[1].split()[0])
             key = "gfa_cov" if cov else "gfa"
             out[key + "_s"] = round(time.time() - t0, 1)
             out[key + "_md5"] = md5_file(gfa)
@@ -76,7 +85,7 @@ def main():
                         nl += line[:1] == b"L"
                 out["gfa_S_lines"], out["gfa_L_lines"] = ns, nl
             os.remove(gfa)
-    name = os.path.join(HERE, f"scale_{n // 1000}k_g{g // 1000}k_s{seed}" + ("" if k == 55 else f"_k{k}") + ("_skew" if out.get("skew") else "") + ".json")
+    name = os.path.join(HERE, ("next_" if plasmids else "") + f"scale_{n // 1000}k_g{g // 1000}k_s{seed}" + ("" if k == 55 else f"_k{k}") + ("_skew" if out.get("skew") else "") + ("_plasmids" if plasmids else "") + ".json")
     with open(name, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))

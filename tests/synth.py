@@ -91,6 +91,34 @@ def synth_codes_skewed(seed, total_len, n_reads, err=0.01, n_rate=0.001, n_genom
     return codes
 
 
+def synth_codes_plasmids(seed, total_len, n_reads, err=0.0, n_rate=0.0, plasmid_len=5000):
+    """reads from total_len // plasmid_len CIRCULAR genomes (a read may run across the origin), error-free by default: every plasmid
+    that the reads cover completely is a perfect loop of the de Bruijn graph (debruijn_graph_constructor.hpp:252-293) — with errors the
+    tips and bubbles of the error k-mers would put junctions on every cycle. Same pair model as synth_codes."""
+    assert n_reads % 2 == 0
+    rng = np.random.default_rng(seed)
+    n_pl = total_len // plasmid_len
+    genome = rng.integers(0, 4, n_pl * plasmid_len, dtype=np.uint8).reshape(n_pl, plasmid_len)
+    n_pairs = n_reads // 2
+    codes = np.empty((n_reads, L), dtype=np.uint8)
+    idx = np.arange(L)
+    CH = 1 << 18
+    for c0 in range(0, n_pairs, CH):
+        c1 = min(n_pairs, c0 + CH)
+        g = rng.integers(0, n_pl, c1 - c0)
+        p = rng.integers(0, plasmid_len, c1 - c0)
+        codes[2 * c0:2 * c1:2] = genome[g[:, None], (p[:, None] + idx[None, :]) % plasmid_len]
+        codes[2 * c0 + 1:2 * c1:2] = 3 - genome[g[:, None], ((p + INSERT - 1)[:, None] - idx[None, :]) % plasmid_len]
+    if err > 0 or n_rate > 0:
+        for c0 in range(0, n_reads, CH):
+            blk = codes[c0:c0 + CH]
+            x = rng.random(blk.shape, dtype=np.float32)
+            sub = rng.integers(1, 4, blk.shape, dtype=np.uint8)
+            blk[:] = np.where(x < err, (blk + sub) % 4, blk)
+            blk[(x >= err) & (x < err + n_rate)] = 4
+    return codes
+
+
 def write_fastq(codes, path):
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
     n = codes.shape[0]

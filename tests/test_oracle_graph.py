@@ -108,3 +108,21 @@ def test_oracle_spades_core_edge_order_matches_reference(case):
     g = oracle.build_graph(reads, case["K"], case["num_buckets"], sort_edges=True, keep_loops=bool(case["keep_loops"]),
                            early_tip_bound=case["bound"], early_at=bool(case["at"]))
     assert g["unitigs"] == open(os.path.join(GOLDEN, case["file"])).read().split("\n")[:-1]
+
+
+def test_oracle_perfect_loops_match_spades_gbuilder_on_plasmids():
+    """200 circular 5 kb genomes, error-free reads (tests/synth.py: synth_codes_plasmids): the real spades-gbuilder collects 200 perfect
+    loops (debruijn_graph_constructor.hpp:252-293, 359-397: cycle minimum, self-conjugate split) and the C restatement writes the
+    same GFA, ± -c. Golden: tests/golden/next_scale_200k_g1000k_s83_plasmids.json (make_golden_scale.py ... gfaplasmids)."""
+    import hashlib
+    import json
+    import numpy as np
+    import synth
+    g = json.load(open(os.path.join(GOLDEN, "next_scale_200k_g1000k_s83_plasmids.json")))
+    codes = synth.synth_codes_plasmids(g["seed"], g["genome_len"], g["n_reads"], g["err"], g["n_rate"])
+    assert hashlib.md5(codes.tobytes()).hexdigest() == g["codes_md5"]
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    reads = [lut[c].tobytes().decode() for c in codes]
+    r = oracle.build_graph(reads, g["k"], 10 * g["effective_threads"], coverage=True)
+    assert r["n_loops"] == g["perfect_loops"] == 200 and len(r["unitigs"]) == g["gfa_S_lines"]
+    assert hashlib.md5(r["gfa"].encode()).hexdigest() == g["gfa_cov_md5"]
