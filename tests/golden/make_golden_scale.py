@@ -85,7 +85,8 @@ def main():
                         nl += line[:1] == b"L"
                 out["gfa_S_lines"], out["gfa_L_lines"] = ns, nl
             os.remove(gfa)
-    name = os.path.join(HERE, ("next_" if plasmids else "") + f"scale_{n // 1000}k_g{g // 1000}k_s{seed}" + ("" if k == 55 else f"_k{k}") + ("_skew" if out.get("skew") else "") + ("_plasmids" if plasmids else "") + ".json")
+    # (SMX_GOLDEN_NEXT=1: a golden made without a GPU run to compare with — tests/test_scale_gpu.py takes next_* only with SMX_SCALE_NEXT=1)
+    name = os.path.join(HERE, ("next_" if plasmids or os.environ.get("SMX_GOLDEN_NEXT") else "") + f"scale_{n // 1000}k_g{g // 1000}k_s{seed}" + ("" if k == 55 else f"_k{k}") + ("_skew" if out.get("skew") else "") + ("_plasmids" if plasmids else "") + ".json")
     with open(name, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))

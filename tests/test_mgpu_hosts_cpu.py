@@ -2,7 +2,7 @@
 they are into tests/mgpu_shim (hip* = host memory; nccl* and the product's C ABI forwarded to this file, which answers with gloo
 collectives and with the oracle-backed engine doubles of test_dist_cpu.py). Under test: the hosts' own logic at world size > 1 — who
 reads which part of the input, offsets / counts / rounds of the exchanges, the order of the gathered shards, bucket-size and (k+1)-mer
-bookkeeping, the coverage sum, who writes. (On the GPU box the same hosts run with one rank against the real library: test_cli_gpu.py.)"""
+bookkeeping, the coverage sum, who writes. (On the GPU box the same hosts run with one rank against the real library: test_zz_cli_rccl_gpu.py.)"""
 import ctypes
 import os
 import subprocess
