@@ -30,8 +30,7 @@
 #include <rccl/rccl.h>
 
 #include "../../include/smx.h"
-#include "fastq_split.hpp"
-#include "read_input.hpp"
+#include "read_share.hpp"
 
 namespace smxtool {
 
@@ -79,83 +78,6 @@ struct RankComm {
     ncclComm_t comm{};
     hipStream_t stream{};
 };
-
-// ---- this rank's share of one input file ------------------------------------------------------------------------------------------
-// part / parts: the share (rank * sub + i of world * sub; SMX_MGPU_PARTS = sub > 1 makes every rank read its share in `sub` pieces — a
-// test hook that runs the range reader with one rank).
-inline int submit_fastq_range(smx_ctx *ctx, const std::string &path, long long begin, long long end) {
-    if (begin >= end) return 0;
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return -1;
-    if (fseeko(f, (off_t)begin, SEEK_SET) != 0) {
-        fclose(f);
-        return -1;
-    }
-    size_t chunk_bytes = (size_t)std::min<long long>((long long)256 << 20, std::max<long long>(end - begin + 4096, (long long)1 << 20));
-    if (const char *e = getenv("SMX_MGPU_CHUNK")) chunk_bytes = (size_t)std::max(1024, atoi(e));  // test hook: the carry-over between chunks on small files
-    char *buf = (char *)smx_pinned_alloc(chunk_bytes);
-    const bool pinned = buf != nullptr;
-    if (!buf) buf = (char *)malloc(chunk_bytes);
-    long long pos = begin;
-    size_t have = 0;
-    int rc = 0;
-    for (;;) {
-        while (pos < end && have < chunk_bytes) {
-            const size_t got = fread(buf + have, 1, (size_t)std::min<long long>((long long)(chunk_bytes - have), end - pos), f);
-            if (got == 0) {
-                rc = SMX_IO_ERROR;
-                break;
-            }
-            have += got;
-            pos += (long long)got;
-        }
-        if (rc || have == 0) break;
-        const bool last = pos >= end;
-        uint64_t n = 0, used = 0;
-        rc = smx_submit_fastq_text(ctx, buf, have, last ? 1 : 0, &n, &used);
-        if (rc) break;
-        if (used == 0 && !last && have == chunk_bytes) {  // a single record larger than the chunk
-            rc = SMX_INVALID_INPUT_FORMAT;
-            break;
-        }
-        memmove(buf, buf + used, have - used);
-        have -= used;
-        if (last) break;
-    }
-    if (pinned) smx_pinned_free(buf); else free(buf);
-    fclose(f);
-    return rc;
-}
-
-// 0, an smx error code, or -1 when the file cannot be read; throws std::string on malformed input (host parser)
-inline int submit_share(smx_ctx *ctx, const std::string &path, unsigned part, unsigned parts) {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return -1;
-    unsigned char head[2] = {0, 0};
-    const size_t nh = fread(head, 1, 2, f);
-    fclose(f);
-    const bool gz = nh == 2 && head[0] == 0x1f && head[1] == 0x8b;
-    if (!gz && nh == 2 && head[0] == '@' && !getenv("SMX_HOST_PARSE") && fastq_head_is_four_line(path)) {
-        long long b = 0, e = 0;
-        if (!fastq_part_range(path, part, parts, &b, &e)) return -1;
-        return submit_fastq_range(ctx, path, b, e);
-    }
-    // gzip, FASTA, multi-line FASTQ: every rank parses the file and keeps every parts-th sequence
-    ReadBatch batch;
-    int rc = 0;
-    uint64_t idx = 0;
-    const bool ok = for_each_sequence(path, [&](const std::string &s) {
-        if (idx++ % parts != part) return;
-        batch.add(s);
-        if (batch.bases.size() > ((size_t)1 << 30) && !rc) {
-            rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
-            batch.clear();
-        }
-    });
-    if (!ok) return -1;
-    if (!rc) rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
-    return rc;
-}
 
 // words per pair and round of an exchange (1 GiB; SMX_MGPU_ROUND_WORDS: a test hook that makes small inputs take several rounds)
 inline uint64_t round_limit_words() {

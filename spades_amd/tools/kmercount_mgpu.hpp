@@ -4,7 +4,8 @@
 //   grouped ncclSend / ncclRecv between all pairs (every pair has its own xGMI link; no ring) -> smx_count_records on the owner ->
 //   every rank writes its bucket range into <workdir>/final_kmers at its byte offset (buckets are contiguous per rank, so the file
 //   is the concatenation of the rank outputs: KMerDiskStorage::merge, kmer_index_builder.hpp:190-203).
-// The ncclUniqueId travels through a file in the work directory. Input files are dealt out to the ranks round-robin.
+// The ncclUniqueId travels through a file in the work directory. Input: whole files round-robin when there is one per rank, else every
+// file cut among the ranks.
 #pragma once
 #include <signal.h>
 #include <fcntl.h>
@@ -26,7 +27,7 @@
 #include <rccl/rccl.h>
 
 #include "../../include/smx.h"
-#include "read_input.hpp"
+#include "read_share.hpp"
 
 namespace smxtool {
 
@@ -83,12 +84,15 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
     MG_NCCL(ncclCommInitRank(&comm, world, id, rank));
     hipStream_t stream;
     MG_HIP(hipStreamCreate(&stream));
-    // this rank's share of the input
+    // this rank's share of the input: whole files dealt out round-robin when there is at least one per rank (nothing is parsed twice);
+    // otherwise (R1 / R2 on eight GPUs) every file is cut among all ranks (read_share.hpp: byte ranges of plain FASTQ, every world-th
+    // read of anything else)
+    const bool whole_files = input.size() >= (size_t)world;
     for (size_t i = 0; i < input.size(); ++i) {
-        if ((int)(i % (size_t)world) != rank) continue;
+        if (whole_files && (int)(i % (size_t)world) != rank) continue;
         int rc;
         try {
-            rc = submit_file(ctx, input[i]);
+            rc = whole_files ? submit_file(ctx, input[i]) : submit_share(ctx, input[i], (unsigned)rank, (unsigned)world);
         } catch (const std::string &e) {
             fprintf(stderr, "%s\n", e.c_str());
             return SMX_INVALID_INPUT_FORMAT;

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.skipif(not HAVE_HEADERS, reason="the hosts include the 
 
 def _build_shim():
     srcs = [os.path.join(SHIM_DIR, "shim.cpp")] + [os.path.join(ROOT, "spades_amd", "tools", f) for f in
-                                                   ("gbuilder_mgpu.hpp", "kmercount_mgpu.hpp", "read_input.hpp", "fastq_split.hpp")]
+                                                   ("gbuilder_mgpu.hpp", "kmercount_mgpu.hpp", "read_input.hpp", "read_share.hpp", "fastq_split.hpp")]
     if os.path.exists(SHIM) and all(os.path.getmtime(SHIM) >= os.path.getmtime(s) for s in srcs):
         return
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", SHIM + ".tmp", srcs[0],
@@ -362,18 +362,24 @@ def test_gbuilder_host_world_n(tmp_path, world, k, coverage, fmt, env):
         assert all(g["p2p_ops"] > 2 * (world - 1) for g in got)  # the exchanges really went in several rounds
 
 
-@pytest.mark.parametrize("world,K,env", [(2, 21, {"SMX_MGPU_ROUND_WORDS": "64"}), (3, 33, {})])
-def test_kmercount_host_world_n(tmp_path, world, K, env):
+@pytest.mark.parametrize("world,K,nfiles,env", [(2, 21, 3, {"SMX_MGPU_ROUND_WORDS": "64"}), (3, 33, 4, {}), (3, 21, 2, {"SMX_MGPU_ROUND_WORDS": "512"}), (2, 33, 1, {})])
+def test_kmercount_host_world_n(tmp_path, world, K, nfiles, env):
+    """at least one file per rank: whole files round-robin; fewer (R1 / R2 on more GPUs): every file is cut among all ranks"""
     from oracle import oracle
     reads = [r for r in read_lines("reads_tiny.txt") if r]
     files = []
-    for i in range(world + 1):  # more files than ranks: dealt out round-robin
-        p = str(tmp_path / f"f{i}.fq")
-        _write_fastq(p, reads[i::world + 1])
+    for i in range(nfiles):
+        p = str(tmp_path / (f"f{i}.fq" if i != 1 else "f1.fa"))
+        if i == 1:
+            with open(p, "w") as f:
+                for j, r in enumerate(reads[i::nfiles]):
+                    f.write(f">s{j}\n{r}\n")
+        else:
+            _write_fastq(p, reads[i::nfiles])
         files.append(p)
     got = _run(world, "kmercount", (K, str(tmp_path), files), env, reads, 38500 + 11 * world + K)
     assert all(g["rc"] == 0 for g in got), [g["error"] for g in got]
-    assert sorted(r for g in got for r in g["reads"]) == sorted(reads)
+    assert sorted(r for g in got for r in g["reads"]) == sorted(reads) and all(g["reads"] for g in got)
     ref, _ = oracle.count(reads, K, "A", 16)
     assert open(tmp_path / "final_kmers", "rb").read() == ref.tobytes()  # the ranks' bucket ranges, each written at its offset
     assert sum(g["owned"] for g in got) == len(ref) and all(g["owned"] > 0 for g in got)
