@@ -1,0 +1,36 @@
+"""CPU: the bench line this round recorded on the GPU box (profiles/r04/bench_config3.json, printed by `python bench.py`) carries every
+field of the driver's contract and its numbers agree with each other."""
+import glob
+import json
+import os
+
+from conftest import ROOT
+
+
+def _latest():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_config3.json")))
+    assert files
+    return json.load(open(files[-1]))
+
+
+def test_recorded_bench_line_has_the_contract_fields():
+    d = _latest()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "M reads/s" and d["higher_is_better"] is True and d["n_gpus"] == 1 and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_step"] / (r["kernel_ms_per_step"] * 1e-3) / 1e9) < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["bit_identical_to_reference_output"] is True
+    # value = whole-job reads per second of the timed steps
+    assert abs(d["value"] - d["config"]["reads_per_gpu"] / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
+    # the dominant kernel is the longest single-kernel stage of the line and is priced on bytes of its own
+    dk = d["dominant_kernel"]
+    assert dk["ms"] == max(v for k, v in r["stages_ms"].items()) and 0 < dk["frac"] < 1
