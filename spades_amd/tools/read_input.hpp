@@ -3,6 +3,7 @@
 // Reads are handed to the library in ASCII; smx_submit_reads_ascii applies the longest-ACGT-run rule.
 #pragma once
 #include "../../include/smx.h"
+#include "bgzf_reader.hpp"
 #include <zlib.h>
 
 #include <cstdint>
@@ -245,10 +246,21 @@ inline int submit_file(smx_ctx *ctx, const std::string &path, std::mutex *mu = n
         size_t have = 0;
         bool fallback = false, any = false, eof = false;
         int rc = 0;
+        // BGZF (blocked gzip: what BCL Convert / DRAGEN and bgzip write): the blocks are inflated in parallel (bgzf_reader.hpp); an ordinary
+        // gzip stream has one thread's worth of work by construction
+        BgzfReader bz;
+        const bool bgzf = gz && !getenv("SMX_NO_BGZF") && BgzfReader::is_bgzf(path) && bz.open(path, io_threads());
         for (;;) {
             while (!eof && have < chunk_bytes) {  // fill the chunk
                 size_t got;
-                if (gz) {
+                if (bgzf) {  // whole blocks, inflated by several threads straight into the chunk
+                    if (chunk_bytes - have < 65536) break;
+                    got = bz.read(buf + have, chunk_bytes - have);
+                    if (got == BgzfReader::kError) {
+                        rc = SMX_INVALID_INPUT_FORMAT;
+                        break;
+                    }
+                } else if (gz) {
                     const int g = gzread(gzf, buf + have, (unsigned)std::min<size_t>(chunk_bytes - have, (size_t)1 << 30));
                     if (g < 0) {
                         rc = SMX_INVALID_INPUT_FORMAT;
@@ -275,7 +287,7 @@ inline int submit_file(smx_ctx *ctx, const std::string &path, std::mutex *mu = n
             }
             if (rc) break;
             any = any || n > 0;
-            if (used == 0 && !eof && have == chunk_bytes) {  // a single record larger than the chunk
+            if (used == 0 && !eof && (have == chunk_bytes || (bgzf && chunk_bytes - have < 65536))) {  // a single record larger than the chunk
                 fallback = !any;
                 if (!fallback) rc = SMX_INVALID_INPUT_FORMAT;
                 break;

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.skipif(not HAVE_HEADERS, reason="the hosts include the 
 
 def _build_shim():
     srcs = [os.path.join(SHIM_DIR, "shim.cpp")] + [os.path.join(ROOT, "spades_amd", "tools", f) for f in
-                                                   ("gbuilder_mgpu.hpp", "kmercount_mgpu.hpp", "read_input.hpp", "read_share.hpp", "fastq_split.hpp")]
+                                                   ("gbuilder_mgpu.hpp", "kmercount_mgpu.hpp", "read_input.hpp", "read_share.hpp", "fastq_split.hpp", "bgzf_reader.hpp")]
     if os.path.exists(SHIM) and all(os.path.getmtime(SHIM) >= os.path.getmtime(s) for s in srcs):
         return
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", SHIM + ".tmp", srcs[0],
@@ -374,6 +374,13 @@ def test_kmercount_host_world_n(tmp_path, world, K, nfiles, env):
             with open(p, "w") as f:
                 for j, r in enumerate(reads[i::nfiles]):
                     f.write(f">s{j}\n{r}\n")
+        elif i == 2:  # a BGZF-compressed FASTQ (what BCL Convert writes): inflated block-parallel by the tools' reader
+            from test_bgzf_cpu import bgzf_bytes
+            _write_fastq(p, reads[i::nfiles])
+            with open(p + ".gz", "wb") as f:
+                f.write(bgzf_bytes(open(p, "rb").read(), block=300))
+            os.remove(p)
+            p += ".gz"
         else:
             _write_fastq(p, reads[i::nfiles])
         files.append(p)
