@@ -48,6 +48,7 @@ class BgzfReader {
     }
 
   public:
+    static size_t header(const unsigned char *p, size_t n, size_t *hdr_len) { return parse_header(p, n, hdr_len); }
     ~BgzfReader() {
         if (fd_ >= 0) close(fd_);
     }
@@ -150,6 +151,114 @@ class BgzfReader {
         pos_ += p;
         if (out == 0 && !eof()) return read(dst, cap);  // (only empty blocks so far: 0 means the end of the file to the caller)
         return out;
+    }
+};
+
+// Random access to the TEXT of a BGZF file: the block index (where every block starts, how much text lies in front of it) comes from
+// one walk over the headers and trailers; read() inflates only the blocks that cover the range asked for. This is how several readers
+// (the ranks of the multi-GPU hosts) take disjoint parts of one *.fastq.gz.
+class BgzfText {
+    int fd_ = -1;
+    std::vector<uint64_t> coff_, toff_;  // compressed offset of block b; text in front of block b (toff_[n] = all of it)
+    std::vector<uint32_t> clen_, hlen_;
+
+  public:
+    ~BgzfText() {
+        if (fd_ >= 0) close(fd_);
+    }
+    uint64_t size() const { return toff_.empty() ? 0 : toff_.back(); }
+    size_t blocks() const { return clen_.size(); }
+    bool open(const std::string &path) {
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) return false;
+        struct stat st;
+        if (fstat(fd_, &st) != 0) return false;
+        const uint64_t fsize = (uint64_t)st.st_size;
+        std::vector<unsigned char> slab((size_t)16 << 20);
+        uint64_t pos = 0, text = 0;
+        toff_.assign(1, 0);
+        while (pos < fsize) {
+            const size_t want = (size_t)std::min<uint64_t>(fsize - pos, slab.size());
+            size_t got = 0;
+            while (got < want) {
+                const ssize_t r = pread(fd_, slab.data() + got, want - got, (off_t)(pos + got));
+                if (r <= 0) return false;
+                got += (size_t)r;
+            }
+            size_t p = 0;
+            while (p < got) {
+                size_t hl = 0;
+                const size_t bl = BgzfReader::header(slab.data() + p, got - p, &hl);
+                if (bl == 0 || p + bl > got) break;  // cut by the end of the slab (or not a block: decided below)
+                const unsigned char *t = slab.data() + p + bl - 4;
+                const uint32_t isize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                if (isize > 65536) return false;
+                coff_.push_back(pos + p);
+                clen_.push_back((uint32_t)bl);
+                hlen_.push_back((uint32_t)hl);
+                text += isize;
+                toff_.push_back(text);
+                p += bl;
+            }
+            if (p == 0) return false;  // not a block header, or a block that ends behind the file
+            pos += p;
+        }
+        return true;
+    }
+    // text bytes [off, off + n) -> dst; false on a damaged file or a range outside the text
+    bool read(uint64_t off, size_t n, char *dst, unsigned nthreads = 1) const {
+        if (off + n > size()) return false;
+        if (n == 0) return true;
+        const size_t b0 = (size_t)(std::upper_bound(toff_.begin(), toff_.end(), off) - toff_.begin()) - 1;
+        size_t b1 = b0;
+        while (toff_[b1 + 1] < off + n) ++b1;
+        std::atomic<size_t> next{b0};
+        std::atomic<bool> bad{false};
+        auto work = [&]() {
+            z_stream z;
+            memset(&z, 0, sizeof z);
+            if (inflateInit2(&z, -15) != Z_OK) {
+                bad = true;
+                return;
+            }
+            std::vector<unsigned char> in(65536 + 64), text(65536);
+            for (;;) {
+                const size_t b = next.fetch_add(1);
+                if (b > b1 || bad) break;
+                const uint32_t isize = (uint32_t)(toff_[b + 1] - toff_[b]);
+                if (isize == 0) continue;
+                size_t got = 0;
+                while (got < clen_[b]) {
+                    const ssize_t r = pread(fd_, in.data() + got, clen_[b] - got, (off_t)(coff_[b] + got));
+                    if (r <= 0) break;
+                    got += (size_t)r;
+                }
+                const unsigned char *t = in.data() + clen_[b] - 8;
+                const uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                // a block that lies inside the range goes straight to its place, the two at the ends through a buffer
+                const uint64_t lo = std::max<uint64_t>(toff_[b], off), hi = std::min<uint64_t>(toff_[b + 1], off + n);
+                const bool inside = lo == toff_[b] && hi == toff_[b + 1];
+                unsigned char *out = inside ? (unsigned char *)dst + (toff_[b] - off) : text.data();
+                inflateReset(&z);
+                z.next_in = in.data() + hlen_[b];
+                z.avail_in = (uInt)(clen_[b] - hlen_[b] - 8);
+                z.next_out = out;
+                z.avail_out = isize;
+                if (got != clen_[b] || inflate(&z, Z_FINISH) != Z_STREAM_END || z.avail_out != 0 ||
+                    (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, isize) != crc) {
+                    bad = true;
+                    break;
+                }
+                if (!inside) memcpy(dst + (lo - off), text.data() + (lo - toff_[b]), (size_t)(hi - lo));
+            }
+            inflateEnd(&z);
+        };
+        const unsigned nt = (unsigned)std::min<size_t>(nthreads ? nthreads : 1, (b1 - b0) / 8 + 1);
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < nt; ++i) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        return !bad;
     }
 };
 

@@ -34,6 +34,25 @@ int main(int argc, char **argv) {
 }
 """
 
+DRIVER_TEXT = r"""
+#include "%s/spades_amd/tools/bgzf_reader.hpp"
+#include <cstdio>
+// argv: file, then (offset, length, threads) triples: prints the size of the text, then the bytes of every range to stdout
+int main(int argc, char **argv) {
+    smxtool::BgzfText t;
+    if (!t.open(argv[1])) { printf("error\n"); return 0; }
+    printf("%%llu\n", (unsigned long long)t.size());
+    for (int i = 2; i + 2 < argc; i += 3) {
+        const unsigned long long off = strtoull(argv[i], nullptr, 10);
+        const size_t n = (size_t)strtoull(argv[i + 1], nullptr, 10);
+        std::vector<char> buf(n + 1);
+        if (!t.read(off, n, buf.data(), (unsigned)atoi(argv[i + 2]))) { printf("bad\n"); return 0; }
+        fwrite(buf.data(), 1, n, stdout);
+    }
+    return 0;
+}
+"""
+
 
 def bgzf_bytes(data, block=60000, level=6, empty_block_inside=False):
     """`data` as a BGZF file (SAM/BAM specification 4.1): gzip members of <= 64 KiB with the 'BC' extra subfield, an empty one at the end"""
@@ -77,3 +96,29 @@ def test_bgzf_reader(tmp_path):
     assert run(1 << 20, 4) == "error"      # the file ends inside a block
     open(gz, "wb").write(gzip.compress(_fastq(rng, 100)))
     assert run(1 << 20, 4) == "notbgzf"    # ordinary gzip
+
+
+def test_bgzf_random_access_text(tmp_path):
+    """BgzfText: the block index and ranges of the text (what the ranks of the multi-GPU hosts read of one *.fastq.gz)"""
+    src, exe = tmp_path / "drv.cpp", str(tmp_path / "drv")
+    src.write_text(DRIVER_TEXT % ROOT)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, str(src), "-lz", "-pthread"])
+    rng = random.Random(4)
+    gz = str(tmp_path / "t.gz")
+    for n, block, empty in ((2000, 777, True), (2000, 65280, False), (3, 60000, False)):
+        data = _fastq(rng, n)
+        with open(gz, "wb") as f:
+            f.write(bgzf_bytes(data, block, empty_block_inside=empty))
+        ranges = [(0, len(data), 4), (0, 0, 1), (len(data) - 1, 1, 1), (5, 1, 1)]
+        for _ in range(30):
+            a = rng.randrange(len(data))
+            ranges.append((a, rng.randrange(min(len(data) - a, 200000) + 1), rng.choice((1, 3, 8))))
+        out = subprocess.check_output([exe, gz] + [str(x) for r in ranges for x in r])
+        head, _, body = out.partition(b"\n")
+        assert int(head) == len(data)
+        assert body == b"".join(data[a:a + ln] for a, ln, _ in ranges)
+    out = subprocess.check_output([exe, gz, str(len(data)), "1", "1"])  # a range behind the text
+    assert out.endswith(b"bad\n")
+    whole = bytearray(open(gz, "rb").read())
+    open(gz, "wb").write(bytes(whole[:len(whole) - 40]))  # the last blocks cut
+    assert subprocess.check_output([exe, gz]).startswith(b"error")

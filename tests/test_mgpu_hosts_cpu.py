@@ -327,6 +327,8 @@ def _write_fastq(path, reads, final_newline=True):
     (3, 33, True, "fa", {"SMX_MGPU_ROUND_WORDS": "200"}),
     (3, 21, False, "fq", {"SMX_MGPU_KPOMERS": "1", "SMX_MGPU_ROUND_WORDS": "128", "SMX_MGPU_PARTS": "2"}),
     (2, 31, True, "fa", {}),  # (a k without room for the extension byte: the route by the sharded (k+1)-mer count)
+    (3, 21, False, "fq.gz", {"SMX_MGPU_CHUNK": "4096", "SMX_IO_THREADS": "3"}),
+    (2, 33, True, "fq.gz", {"TEST_BGZF_BLOCK": "65280", "SMX_MGPU_PARTS": "2"}),
 ])
 def test_gbuilder_host_world_n(tmp_path, world, k, coverage, fmt, env):
     from oracle import oracle
@@ -334,6 +336,12 @@ def test_gbuilder_host_world_n(tmp_path, world, k, coverage, fmt, env):
     inp = str(tmp_path / ("r." + fmt))
     if fmt == "fq":
         _write_fastq(inp, reads, final_newline=(k != 21 or coverage))
+    elif fmt == "fq.gz":  # BGZF: every rank inflates only the blocks under its range of the text
+        from test_bgzf_cpu import bgzf_bytes
+        _write_fastq(inp[:-3], reads)
+        with open(inp, "wb") as f:
+            f.write(bgzf_bytes(open(inp[:-3], "rb").read(), block=int(env.get("TEST_BGZF_BLOCK", "700"))))
+        os.remove(inp[:-3])
     else:
         with open(inp, "w") as f:
             for i, r in enumerate(reads):
@@ -343,6 +351,10 @@ def test_gbuilder_host_world_n(tmp_path, world, k, coverage, fmt, env):
     assert all(g["rc"] == 0 for g in got), [g["error"] for g in got]
     # the input: every read on exactly one rank, every rank has some
     assert sorted(r for g in got for r in g["reads"]) == sorted(reads) and all(g["reads"] for g in got)
+    if fmt in ("fq", "fq.gz"):  # byte ranges of the text (for BGZF: only the blocks under the range are inflated), never the read-dealing host parser
+        assert all("smx_submit_fastq_text" in g["calls"] and "smx_submit_reads_ascii" not in g["calls"] for g in got)
+    else:
+        assert all("smx_submit_reads_ascii" in g["calls"] for g in got)
     # who builds and who writes: rank 0, and with -c every rank (its coverage pass needs the graph); the engine double asserted inside
     # build_graph_from_kmers that the gathered structure IS the reference's k-mer file and mask bytes and that the (k+1)-mer count fits
     assert [g["built"] for g in got] == [True] + [coverage] * (world - 1)
@@ -362,7 +374,7 @@ def test_gbuilder_host_world_n(tmp_path, world, k, coverage, fmt, env):
         assert all(g["p2p_ops"] > 2 * (world - 1) for g in got)  # the exchanges really went in several rounds
 
 
-@pytest.mark.parametrize("world,K,nfiles,env", [(2, 21, 3, {"SMX_MGPU_ROUND_WORDS": "64"}), (3, 33, 4, {}), (3, 21, 2, {"SMX_MGPU_ROUND_WORDS": "512"}), (2, 33, 1, {})])
+@pytest.mark.parametrize("world,K,nfiles,env", [(2, 21, 3, {"SMX_MGPU_ROUND_WORDS": "64"}), (3, 33, 4, {}), (3, 21, 2, {"SMX_MGPU_ROUND_WORDS": "512"}), (2, 33, 1, {}), (3, 21, 1, {"TEST_FIRST_BGZF": "1"})])
 def test_kmercount_host_world_n(tmp_path, world, K, nfiles, env):
     """at least one file per rank: whole files round-robin; fewer (R1 / R2 on more GPUs): every file is cut among all ranks"""
     from oracle import oracle
@@ -383,6 +395,12 @@ def test_kmercount_host_world_n(tmp_path, world, K, nfiles, env):
             p += ".gz"
         else:
             _write_fastq(p, reads[i::nfiles])
+            if i == 0 and env.get("TEST_FIRST_BGZF"):
+                from test_bgzf_cpu import bgzf_bytes
+                with open(p + ".gz", "wb") as f:
+                    f.write(bgzf_bytes(open(p, "rb").read(), block=500))
+                os.remove(p)
+                p += ".gz"
         files.append(p)
     got = _run(world, "kmercount", (K, str(tmp_path), files), env, reads, 38500 + 11 * world + K)
     assert all(g["rc"] == 0 for g in got), [g["error"] for g in got]
