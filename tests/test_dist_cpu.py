@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import read_lines
+from conftest import free_port, read_lines
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -89,7 +89,7 @@ def test_sharded_count_gloo(K, mode, nb, limit, world):
     from spades_amd.dist import rank_first_bucket
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + 7 * world
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, K, mode, nb, q, limit)) for r in range(world)]
     for p in procs:
         p.start()
@@ -279,7 +279,7 @@ def test_sharded_build_graph_world2_gloo():
     world, k, threads = 2, 21, 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
+    port = free_port()
     procs = [ctx.Process(target=_graph_worker, args=(r, world, port, k, threads, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -308,7 +308,7 @@ def test_sharded_build_graph_one_exchange_gloo(k, coverage, world):
     threads = 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + world
+    port = free_port()
     procs = [ctx.Process(target=_graph_worker, args=(r, world, port, k, threads, q, "ext", coverage)) for r in range(world)]
     for p in procs:
         p.start()
@@ -389,8 +389,7 @@ def test_a_failing_rank_does_not_leave_the_others_waiting(fail_in, code, route, 
     world, k = 2, 21
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 35500 + (os.getpid() % 2000) + code
-    port += 7 if expect == "mixed" else 13 if expect == "fallback_cov" else 0
+    port = free_port()
     procs = [ctx.Process(target=_failing_worker, args=(r, world, port, k, 1, fail_in, code, route, q, 67 if expect == "mixed" else 0, expect == "fallback_cov"))
              for r in range(world)]
     for p in procs:
@@ -589,7 +588,7 @@ def test_distributed_walks_gloo(k, world, reads_file, nreads, coverage, limit):
     threads = 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 35500 + (os.getpid() % 2000) + 11 * world + k
+    port = free_port()
     procs = [ctx.Process(target=_walk_worker, args=(r, world, port, k, threads, q, reads_file, nreads, coverage, limit)) for r in range(world)]
     for p in procs:
         p.start()

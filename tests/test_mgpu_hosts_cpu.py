@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT, read_lines
+from conftest import ROOT, free_port, read_lines
 
 SHIM_DIR = os.path.join(ROOT, "tests", "mgpu_shim")
 SHIM = os.path.join(SHIM_DIR, "libmgpu_shim.so")
@@ -290,7 +290,7 @@ def _run(world, tool, args, env, all_reads, port_base):
     _build_shim()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = port_base + (os.getpid() % 2000)
+    port = free_port()  # (port_base: kept in the signature for the callers)
     procs = [ctx.Process(target=_worker, args=(r, world, port, tool, args, env, all_reads, q)) for r in range(world)]
     for p in procs:
         p.start()
