@@ -79,7 +79,8 @@ const char *smx_version(void);
  *   "derive_batches" (k-mer file of the construction in this many bucket ranges; 0 = as HBM requires), "keep_kpo" (-1 keep the
  *   (k+1)-mer file after the masks if HBM allows, 0 drop it: the coverage pass recounts), "verify_lookups" (1: rank lookups of
  *   k-mers that are present by construction still compare the record), "spill" (1: always keep sorted runs in host memory and
- *   merge them by bucket ranges; -1 only when the set outgrows the HBM budget), "ext_route" (-1 / 1: the construction takes k-mers and
+ *   merge them by bucket ranges; -1 only when the set outgrows the HBM budget), "spill_merge_max" (> 0: that merge takes at most
+ *   this many records at once, so a small input goes through the key-range split of a bucket), "ext_route" (-1 / 1: the construction takes k-mers and
  *   InOutMask bytes from ONE count of the reads where the record has 8 spare bits, the pre-dedupe stage applies and one batch fits;
  *   0: always the (k+1)-mer file first, as the reference does), "ext_presort" (0: copies of a k-mer from cut partitions are merged
  *   after the sort instead of before it), "kmers_from_reads" (0: the k-mer file of the second route is derived from the (k+1)-mer
@@ -93,7 +94,8 @@ const char *smx_version(void);
  * HBM budget (smx_create): the context never holds more device memory than hbm_budget_bytes (0 = what the device has). A count whose
  * sorted-unique set does not fit is cut into batches whose runs are folded on the device or, when even that does not fit, kept in
  * host memory and merged one bucket range at a time (the reference's dump + merge, kmer_splitter.hpp:123-170,
- * kmer_index_builder.hpp:346-430); the result is then served from host memory: smx_copy_bucket / smx_copy_final_kmers /
+ * kmer_index_builder.hpp:346-430) — a single bucket that is larger than what can be merged at once is cut by key range (every run's
+ * slice of it is sorted: splitter keys cut them all, the parts are merged one after the other); the result is then served from host memory: smx_copy_bucket / smx_copy_final_kmers /
  * smx_write_final_kmers work as usual, smx_device_kmers returns NULL and smx_build_graph refuses (it needs the file resident). */
 int smx_set_option(smx_ctx *ctx, const char *key, int64_t value);
 

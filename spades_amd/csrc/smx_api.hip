@@ -31,6 +31,7 @@
 using namespace smx;
 
 #include "smx_ctx.hpp"
+#include "smx_spill_split.hpp"
 #include "smx_pipeline.hpp"
 #include "smx_construct.hpp"
 #include "smx_pm.hpp"
@@ -155,6 +156,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "keep_kpo")) ctx->opt_keep_kpo = value;
     else if (!strcmp(key, "verify_lookups")) ctx->opt_verify_lookups = value;
     else if (!strcmp(key, "spill")) ctx->opt_spill = value;
+    else if (!strcmp(key, "spill_merge_max")) ctx->opt_spill_merge_max = value;
     else if (!strcmp(key, "single_batch")) ctx->opt_single_batch = value;
     else if (!strcmp(key, "kmers_from_reads")) ctx->opt_kmers_from_reads = value;
     else if (!strcmp(key, "ext_route")) ctx->opt_ext_route = value;

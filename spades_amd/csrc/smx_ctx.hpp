@@ -120,6 +120,7 @@ struct smx_ctx {
                                   // 1 always (merged into one array when that fits), 2 always and left unmerged (tests of the bucket-wise accessors)
     int64_t opt_two_strand_parts = 0;  // > 0: the reverse complements of a two-strand count are sorted in this many bucket ranges (tests; 0 = as HBM requires)
     int64_t opt_single_batch = 0;  // 1: a count that does not fit one batch fails with the memory limit instead of taking batches / spilling (probes at size)
+    int64_t opt_spill_merge_max = 0;  // > 0: the merge of the spilled runs takes at most this many records at once (tests: drives small inputs through the key-range split of a bucket)
     int64_t opt_spill = -1;  // sorted runs to host memory + merge by bucket ranges: -1 when the accumulated set outgrows HBM, 1 always (tests)
     int64_t opt_verify_lookups = 0;  // 1: rank lookups of k-mers that are known to be present still compare the record
     int64_t opt_dir_slots = -1;        // rank directory: slots per record (-1: 2, or 1 next to a resident (k+1)-mer file)

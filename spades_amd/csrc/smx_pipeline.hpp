@@ -1323,6 +1323,74 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
             for (auto &r : runs)
                 for (unsigned b = 0; b < B; ++b) tot[b] += r.boff[b + 1] - r.boff[b];
             uint64_t max_merge = std::max<uint64_t>((uint64_t)((double)arena_avail(ctx) / (2.6 * (double)W)), 1);
+            if (ctx->opt_spill_merge_max > 0) max_merge = std::min<uint64_t>(max_merge, (uint64_t)ctx->opt_spill_merge_max);  // (tests: small merges on small inputs)
+            // ONE bucket whose slices of the runs exceed what can be merged at once (spades-kmercount: B = 16 whatever the input,
+            // kmercount.cpp:220): cut by KEY RANGE — every slice is sorted-unique, splitter keys cut all of them by binary search, the
+            // parts are merged one after the other into ONE host chunk of the bucket (smx_spill_split.hpp; the reference streams the
+            // bucket through its loser tree, kmer_index_builder.hpp:346-430). A part that cannot be placed halves the part size and
+            // the REST of the bucket is planned again (what is merged stays).
+            auto merge_split_bucket = [&](unsigned b, uint64_t sum, smx_ctx::HostChunk &ch) -> int {
+                std::vector<smx_split::Slice> rest;
+                for (auto &r : runs) rest.push_back({r.data + r.boff[b] * W, r.boff[b + 1] - r.boff[b]});
+                ch.data = (char *)malloc(std::max<size_t>(sum * W, 1));  // (upper bound: the union cannot hold more; shrunk at the end)
+                ch.n = 0;
+                if (!ch.data) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "host allocation for the merged result failed");
+                uint64_t part_max = std::max<uint64_t>(std::min<uint64_t>(max_merge, sum / 2 + 1), 1);
+                const uint64_t floor_part = std::max<uint64_t>(runs.size(), ctx->opt_spill_merge_max > 0 ? 1 : (1u << 16));
+                for (;;) {
+                    const auto cuts = smx_split::plan(rest, NW, part_max);
+                    size_t p = 0;
+                    bool smaller = false;
+                    for (; p + 1 < cuts.size(); ++p) {
+                        uint64_t n = 0;
+                        for (size_t r = 0; r < rest.size(); ++r) n += cuts[p + 1][r] - cuts[p][r];
+                        if (!n) continue;
+                        void *p1 = arena_get(ctx, n * W), *p2 = p1 ? arena_get(ctx, n * W) : nullptr;
+                        arena_put(ctx, p2);
+                        if (!p1 || !p2) {
+                            arena_put(ctx, p1);
+                            smaller = true;
+                            break;
+                        }
+                        Rec<NW> *cat = (Rec<NW> *)p1;
+                        ctx->temps.push_back(p1);
+                        int prc = 0;
+                        uint64_t at = 0;
+                        for (size_t r = 0; r < rest.size(); ++r) {
+                            const uint64_t o = cuts[p][r], m = cuts[p + 1][r] - o;
+                            if (m && hipMemcpyAsync(cat + at, rest[r].p + o * W, m * W, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) prc = fail(ctx, SMX_DEVICE_ERROR, "run upload failed");
+                            at += m;
+                        }
+                        if (!prc) prc = run_count<NW>(ctx, K, mode, B, cat, n, nullptr, /*recs_reusable=*/true, false, false, b, 1);
+                        if (!prc) {
+                            const uint64_t nu = ctx->n_records;
+                            if (ch.n + nu > sum) prc = fail(ctx, SMX_DEVICE_ERROR, "a merged part holds more records than went in");
+                            else if (nu && hipMemcpy(ch.data + ch.n * W, ctx->d_result_buf, nu * W, hipMemcpyDeviceToHost) != hipSuccess) prc = fail(ctx, SMX_DEVICE_ERROR, "result read-back failed");
+                            else ch.n += nu;
+                        }
+                        ctx->d_result_buf = ctx->d_result = nullptr;
+                        free_temps(ctx);
+                        if (prc == SMX_RETRY_SMALLER || prc == SMX_MEMORY_LIMIT_EXCEEDED) {  // the pipeline's own temporaries did not fit next to the part
+                            smaller = true;
+                            break;
+                        }
+                        if (prc) return prc;
+                    }
+                    if (!smaller) break;
+                    if (part_max <= floor_part)
+                        return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "bucket %u: a part of %llu records of its spilled runs cannot be merged inside the HBM budget", b, (unsigned long long)part_max);
+                    part_max = std::max<uint64_t>(part_max / 2, floor_part);
+                    for (size_t r = 0; r < rest.size(); ++r) {  // what lies behind the parts that are done
+                        rest[r].p += cuts[p][r] * W;
+                        rest[r].n -= cuts[p][r];
+                    }
+                }
+                if (ch.n < sum) {
+                    char *sh = (char *)realloc(ch.data, std::max<size_t>(ch.n * W, 1));
+                    if (sh) ch.data = sh;
+                }
+                return 0;
+            };
             std::vector<uint64_t> gboff(B + 1, 0);
             std::vector<smx_ctx::HostChunk> chunks;  // installed at the end: every run_count below clears the context's result
             uint64_t done = 0;
@@ -1332,20 +1400,27 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
                 uint64_t sum = 0;
                 while (b1 < B && (b1 == b0 || sum + tot[b1] <= max_merge)) sum += tot[b1++];
                 smx_ctx::HostChunk ch;
-                if (sum) {
+                if (sum > max_merge && b1 - b0 == 1) {  // (b1 - b0 == 1: the loop above always takes one bucket, however large)
+                    rc = merge_split_bucket(b0, sum, ch);
+                    if (rc) {
+                        free(ch.data);
+                        break;
+                    }
+                    gboff[b0 + 1] = done + ch.n;
+                    done += ch.n;
+                } else if (sum) {
                     Rec<NW> *cat;
                     // two buffers of the range have to be placed; a fragmented arena gets a smaller range, a single bucket that does not fit is final
                     void *p1 = arena_get(ctx, sum * W), *p2 = p1 ? arena_get(ctx, sum * W) : nullptr;
                     arena_put(ctx, p2);
                     if (!p1 || !p2) {
                         arena_put(ctx, p1);
-                        if (b1 - b0 > 1) {
-                            max_merge = std::max<uint64_t>(sum / 2, 1);
-                            continue;
+                        if (sum < 2) {
+                            rc = fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "no room in the HBM budget to merge the spilled runs");
+                            break;
                         }
-                        rc = fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "bucket %u alone holds %llu records in the spilled runs: more than the HBM budget can merge (use more buckets)",
-                                  b0, (unsigned long long)sum);
-                        break;
+                        max_merge = std::max<uint64_t>(sum / 2, 1);  // a smaller range; a single bucket comes back here as a split one
+                        continue;
                     }
                     cat = (Rec<NW> *)p1;
                     ctx->temps.push_back(p1);

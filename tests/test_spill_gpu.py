@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import synth
-from conftest import read_lines
+from conftest import needs_next, read_lines
 from spades_amd import KMerDiskCounter, ReadKMerSplitter
 from spades_amd.kmercount import Context
 
@@ -55,3 +55,29 @@ def test_result_larger_than_the_hbm_budget(tmp_path):
         md5.append((h.hexdigest(), st.bucket_sizes().tolist()))
         ctx.close()
     assert md5[0] == md5[1]
+
+
+@needs_next
+@pytest.mark.parametrize("K,mode,nb,merge_max", [(21, "A", 16, 200), (55, "A", 16, 1000), (56, "B", 3, 500), (99, "B", 1, 300)])
+def test_a_bucket_larger_than_one_merge_is_cut_by_key_range(K, mode, nb, merge_max):
+    """spades-kmercount has 16 buckets whatever the input (kmercount.cpp:220): a bucket whose spilled runs exceed what the budget can
+    merge at once is cut into key ranges (smx_spill_split.hpp; planner tested on the CPU in test_spill_split_cpu.py). "spill_merge_max"
+    makes every bucket of a small input such a bucket; the result must be the unbounded one, bucket by bucket."""
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    want = None
+    for spill in (0, 1):
+        ctx = Context()
+        if spill:
+            ctx.set_option("spill", 1)
+            ctx.set_option("batch_records", 3000)
+            ctx.set_option("spill_merge_max", merge_max)
+        sp = ReadKMerSplitter(K, mode, ctx)
+        sp.push_back_reads(reads)
+        st = KMerDiskCounter(None, sp).Count(nb)
+        got = (st.records().tobytes(), st.bucket_sizes().tolist(), [st.bucket(b).tobytes() for b in range(nb)])
+        assert (st.device_ptr() == 0) == bool(spill)
+        if want is None:
+            want = got
+        else:
+            assert got == want
+        ctx.close()
