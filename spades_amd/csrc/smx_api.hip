@@ -9,6 +9,7 @@
 #include "smx_dwalk.hip"
 #include "smx_gfa.hip"
 #include "smx_graph_host.hpp"
+#include "smx_loops_host.hpp"
 
 #include <algorithm>
 #include <execinfo.h>

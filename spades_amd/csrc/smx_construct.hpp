@@ -614,33 +614,27 @@ int upload_graph(smx_ctx *ctx) {
     return 0;
 }
 
-// Perfect loops (CollectLoops, debruijn_graph_constructor.hpp:359-397; serial in the reference too) from their k-mers in k-mer-file order,
+// Perfect loops (CollectLoops, debruijn_graph_constructor.hpp:359-397; serial in the reference) from their k-mers in k-mer-file order
+// (packed, nw words each; ranks ascending; InOutMask bytes) — collected on the host by all cores (smx_loops_host.hpp) — and
 // appended to the device graph: bigger arrays, old content copied, loop edges uploaded.
-inline int append_loops(smx_ctx *ctx, unsigned k, std::vector<smxh::LoopNode> &nodes, uint64_t nkept, uint64_t ktotalw) {
-    smxh::LoopCollector lc(nodes, k);
-    std::vector<std::string> loops;
-    lc.collect(loops);
-    // the loops are appended to the device graph: bigger arrays, old content copied, loop edges uploaded
+inline int append_loops(smx_ctx *ctx, unsigned k, const uint64_t *lkmers, const uint64_t *lranks, const uint8_t *lmasks, uint64_t nloopk, uint64_t nkept,
+                        uint64_t ktotalw) {
+    std::vector<smxl::PackedLoop> loops;
+    if (const int lrc = smxl::collect_loops(lkmers, lranks, lmasks, nloopk, k, loops))
+        return fail(ctx, SMX_DEVICE_ERROR, "inconsistent k-mer index: the k-mers left over by the unbranching paths do not form perfect loops (%d)", lrc);
     const uint64_t nl = loops.size();
     if (nl) {
         std::vector<unsigned long long> l_offw(nl), l_len(nl), l_start(nl), l_end(nl);
         std::vector<uint8_t> l_self(nl);
         std::vector<uint64_t> lwords;
         for (uint64_t i = 0; i < nl; ++i) {
-            const std::string &sq = loops[i];
+            const smxl::PackedLoop &lp = loops[i];
             l_offw[i] = ktotalw + lwords.size();
-            l_len[i] = sq.size();
-            // node ids must be taken from the untouched masks' k-mers (collect() zeroed the masks, not the index)
-            l_start[i] = lc.node_of(sq.substr(0, k));
-            l_end[i] = lc.node_of(sq.substr(sq.size() - k));
-            l_self[i] = sq == smxh::revcomp(sq) ? 1 : 0;
-            const size_t w0 = lwords.size();
-            lwords.resize(w0 + (sq.size() + 31) / 32, 0);
-            for (size_t t = 0; t < sq.size(); ++t) {
-                const char ch = sq[t];
-                const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
-                lwords[w0 + (t >> 5)] |= code << ((t & 31) << 1);
-            }
+            l_len[i] = lp.len;
+            l_start[i] = lp.start_node;
+            l_end[i] = lp.end_node;
+            l_self[i] = lp.self_rc;
+            lwords.insert(lwords.end(), lp.words.begin(), lp.words.end());
         }
         const uint64_t ne2 = nkept + nl, tw2 = ktotalw + lwords.size();
         uint64_t *uw2;
@@ -1045,15 +1039,15 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
                     return false;
                 });
             }
-            std::vector<smxh::LoopNode> nodes(nloopk);
+            std::vector<uint64_t> fk((size_t)nloopk * NW), fr(nloopk);  // in k-mer-file order
+            std::vector<uint8_t> fm(nloopk);
             for (uint64_t t = 0; t < nloopk; ++t) {
                 const uint64_t i = order[t];
-                nodes[t].rank = ranks[i];
-                nodes[t].kmer.resize(k);
-                for (unsigned j = 0; j < k; ++j) nodes[t].kmer[j] = "ACGT"[(hk[(size_t)i * NW + (j >> 5)] >> ((j & 31) << 1)) & 3];
-                nodes[t].mask = hmask[i];
+                fr[t] = ranks[i];
+                for (int w = 0; w < NW; ++w) fk[(size_t)t * NW + w] = hk[(size_t)i * NW + w];
+                fm[t] = hmask[i];
             }
-            if (int rc = append_loops(ctx, k, nodes, nkept, ktotalw)) return rc;
+            if (int rc = append_loops(ctx, k, fk.data(), fr.data(), fm.data(), nloopk, nkept, ktotalw)) return rc;
         }
     }
     unsigned herr = 0;

@@ -203,15 +203,9 @@ int graph_from_unitigs(smx_ctx *ctx, unsigned k, unsigned B, uint64_t n_kmers_to
     ctx->g_nkmers = n_kmers_total;
     ctx->g_nkpo = n_kpomers;
     if (n_loop_kmers && ctx->opt_keep_loops) {
-        std::vector<smxh::LoopNode> nodes(n_loop_kmers);
-        for (uint64_t t = 0; t < n_loop_kmers; ++t) {
-            if (t && loop_ranks[t] <= loop_ranks[t - 1]) return fail(ctx, SMX_INVALID_PARAMETER, "loop k-mers must come in k-mer-file order");
-            nodes[t].rank = loop_ranks[t];
-            nodes[t].kmer.resize(k);
-            for (unsigned j = 0; j < k; ++j) nodes[t].kmer[j] = "ACGT"[(loop_kmers[(size_t)t * NW + (j >> 5)] >> ((j & 31) << 1)) & 3];
-            nodes[t].mask = loop_masks[t];
-        }
-        if (int rc = append_loops(ctx, k, nodes, ne, n_words)) return rc;
+        for (uint64_t t = 1; t < n_loop_kmers; ++t)
+            if (loop_ranks[t] <= loop_ranks[t - 1]) return fail(ctx, SMX_INVALID_PARAMETER, "loop k-mers must come in k-mer-file order");
+        if (int rc = append_loops(ctx, k, loop_kmers, loop_ranks, loop_masks, n_loop_kmers, ne, n_words)) return rc;
     }
     free_temps(ctx);
     ctx->g_dev_valid = true;

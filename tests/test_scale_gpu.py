@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import synth
+from conftest import NEXT
 from spades_amd import KMerDiskCounter, ReadKMerSplitter
 from spades_amd.gbuilder import GraphBuilder
 from spades_amd.kmercount import Context
@@ -23,8 +24,8 @@ CASES = sorted(glob.glob(os.path.join(HERE, "golden", "scale_*.json")))
 if os.environ.get("SMX_SCALE_SMALL"):
     CASES = [c for c in CASES if json.load(open(c))["n_reads"] <= 10_000_000]
 # Goldens of the real tools that no GPU run has been compared with yet (made when no GPU time was left: next_scale_*.json, e.g. 10 000
-# circular plasmids = 10 000 perfect loops) join with SMX_SCALE_NEXT=1; rename them to scale_* once they are green.
-if os.environ.get("SMX_SCALE_NEXT"):
+# circular plasmids = 10 000 perfect loops) join with SMX_NEXT=1 (conftest.NEXT; SMX_SCALE_NEXT=1 is the older name); rename them to scale_* once they are green.
+if NEXT:
     CASES += sorted(glob.glob(os.path.join(HERE, "golden", "next_scale_*.json")))
 
 
