@@ -10,6 +10,7 @@
 #include "smx_gfa.hip"
 #include "smx_graph_host.hpp"
 #include "smx_loops_host.hpp"
+#include "smx_file_sink.hpp"
 
 #include <algorithm>
 #include <execinfo.h>
@@ -556,9 +557,10 @@ int smx_count_info(const smx_ctx *ctx, uint64_t *n_records, unsigned *words_per_
     return SMX_OK;
 }
 
-// Device memory -> file: a ring of page-locked buffers; while the calling thread writes one chunk, the copies of the next ones run.
-// (One writer: on tmpfs — where the tools' outputs are measured — 8 pwrite threads on one file reached 3.4 GB/s, a single thread 6.4:
-// page allocation serialises on the inode.) Used by the k-mer file and the GFA text writers.
+// Device memory -> file: a ring of page-locked buffers; while the calling thread hands one chunk to the file, the copies of the next
+// ones run. (On tmpfs — where the tools' outputs are measured — 8 pwrite threads on one file reached 3.4 GB/s, a single thread 6.4:
+// pwrite allocates pages under the inode lock. smx_file_sink.hpp therefore maps a tmpfs output and fills it with several threads;
+// everything else stays on one pwrite thread.) Used by the k-mer file and the GFA text writers.
 struct DevToFile {
     static constexpr int NBUF = 4;
     size_t chunk = (size_t)64 << 20;
@@ -579,7 +581,7 @@ struct DevToFile {
         return nbuf > 0;
     }
     // bytes [0, n) of device block src -> file offset off; returns false on a device error (I/O errors: wok)
-    bool send(hipStream_t st, int fd, off_t off, const char *src, size_t n) {
+    bool send(hipStream_t st, smxio::FileSink &sink, off_t off, const char *src, size_t n) {
         const size_t nchunks = (n + chunk - 1) / chunk;
         size_t issued = 0;
         std::vector<int> bof(nchunks);
@@ -595,12 +597,7 @@ struct DevToFile {
             const int b = bof[c];
             if (hipEventSynchronize(ev[b]) != hipSuccess) return false;
             const size_t o = c * chunk, m = std::min(chunk, n - o);
-            size_t w = 0;
-            while (w < m && wok) {
-                const ssize_t r = pwrite(fd, buf[b] + w, m - w, off + (off_t)(o + w));
-                if (r <= 0) wok = false;
-                else w += (size_t)r;
-            }
+            if (wok && !sink.put(buf[b], m, off + (off_t)o)) wok = false;
         }
         return true;
     }
@@ -704,7 +701,7 @@ int smx_write_final_kmers(const smx_ctx *cctx, const char *path) {
     smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
     if (int rc = ensure_kmer_file(ctx)) return rc;
-    FILE *f = fopen(path, "wb");
+    FILE *f = fopen(path, "w+b");  // (read access too: a tmpfs output is filled through a shared mapping, smx_file_sink.hpp)
     if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
     if (ctx->result_on_host) {
         int hrc = SMX_OK;
@@ -724,7 +721,9 @@ int smx_write_final_kmers(const smx_ctx *cctx, const char *path) {
     const int fd = fileno(f);
     int rc = SMX_OK;
     DevToFile d2f;
+    smxio::FileSink sink;
     if (total && !d2f.init(total)) rc = fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "no page-locked memory for the read-back");
+    if (rc == SMX_OK && total) sink.begin(fd, total);
     if (rc == SMX_OK && total) {
         if (ctx->ts.active) {  // two strands: bucket after bucket, each merged on the device first (kmer_index_builder.hpp:190-203 concatenates buckets too)
             for (unsigned b = 0; b < ctx->num_buckets && rc == SMX_OK; ++b) {
@@ -733,18 +732,19 @@ int smx_write_final_kmers(const smx_ctx *cctx, const char *path) {
                 void *blk = nullptr;
                 rc = ts_bucket_block(ctx, b, &blk);
                 if (rc == SMX_OK) {
-                    if (!d2f.send(ctx->stream, fd, (off_t)(ctx->bucket_off[b] * (size_t)ctx->nw * 8), (const char *)blk, n * (size_t)ctx->nw * 8))
+                    if (!d2f.send(ctx->stream, sink, (off_t)(ctx->bucket_off[b] * (size_t)ctx->nw * 8), (const char *)blk, n * (size_t)ctx->nw * 8))
                         rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
                     (void)hipStreamSynchronize(ctx->stream);  // (the block goes back to the arena: its copies must be over)
                     arena_put(ctx, blk);
                 }
             }
-        } else if (!d2f.send(ctx->stream, fd, 0, (const char *)ctx->d_result, total)) {
+        } else if (!d2f.send(ctx->stream, sink, 0, (const char *)ctx->d_result, total)) {
             rc = fail(ctx, SMX_DEVICE_ERROR, "device read-back failed");
         }
     }
     (void)hipStreamSynchronize(ctx->stream);
-    if (!d2f.finish() && rc == SMX_OK) rc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
+    const bool sunk = sink.end();
+    if ((!d2f.finish() || !sunk) && rc == SMX_OK) rc = fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", path);
     if (fclose(f) != 0 && rc == SMX_OK) rc = fail(ctx, SMX_IO_ERROR, "I/O error closing %s", path);
     return rc;
 }
@@ -1489,15 +1489,18 @@ static int write_gfa_device(smx_ctx *ctx, const char *path, const char *flavour)
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     // to the file: the header, then the text through a ring of page-locked buffers; every buffer is written by several pwrite threads
-    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);  // (read access too: a tmpfs output is filled through a shared mapping)
     if (fd < 0) return done(fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path));
     const std::string head = std::string("H\tsp:Z:") + flavour + "\n";
-    bool ok = write(fd, head.data(), head.size()) == (ssize_t)head.size();
+    smxio::FileSink sink;
+    sink.begin(fd, head.size() + total);
+    bool ok = sink.put(head.data(), head.size(), 0);
     DevToFile d2f;
     if (!d2f.init(total)) ok = false;
-    if (ok && !d2f.send(ctx->stream, fd, (off_t)head.size(), text, total)) ok = false;
+    if (ok && !d2f.send(ctx->stream, sink, (off_t)head.size(), text, total)) ok = false;
     (void)hipStreamSynchronize(ctx->stream);
     if (!d2f.finish()) ok = false;
+    if (!sink.end()) ok = false;
     if (close(fd) != 0) ok = false;
     ctx->gh.n_links = nlinks;
     if (!ok) return done(fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path));
