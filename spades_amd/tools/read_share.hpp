@@ -34,7 +34,7 @@ inline int submit_fastq_range(smx_ctx *ctx, const std::string &path, long long b
     int rc = 0;
     for (;;) {
         while (pos < end && have < chunk_bytes) {
-            const size_t got = fread(buf + have, 1, (size_t)std::min<long long>((long long)(chunk_bytes - have), end - pos), f);
+            const size_t got = read_plain(f, buf + have, (size_t)std::min<long long>((long long)(chunk_bytes - have), end - pos));
             if (got == 0) {
                 rc = SMX_IO_ERROR;
                 break;
