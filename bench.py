@@ -552,12 +552,22 @@ def main():
     pmc_name = "config3_pm_pmc_hbm_traffic.csv" if pm_route else ("config3_sorted_pmc_hbm_traffic.csv" if ext_route else "config3_kpomer_pmc_hbm_traffic.csv")
     pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, pmc_name) for r_ in ("r04", "r03")) if os.path.exists(p_)), os.path.join(ROOT, "profiles", "r04", pmc_name))
     pmc_rows, pmc_split, pmc_note = {}, None, None
+    pmc_same = "these very sources: sha256 checked"
     if not sharded and not args.count_only and n_reads == 100_000_000 and k == 55 and T == 16 and os.path.exists(pmc):
         lines = open(pmc).read().splitlines()
         sha = lines[0].split("src_sha256=")[1].split()[0] if lines and "src_sha256=" in lines[0] else None
+        dev_sha = lines[0].split("dev_sha256=")[1].split()[0] if lines and "dev_sha256=" in lines[0] else None
         if sha != _src_hash():
-            pmc_note = f"{os.path.relpath(pmc, ROOT)} was taken on other library sources ({sha}): not quoted"
-            lines = []
+            # host-side edits change the sources, not the kernels: the table also stands while the MACHINE CODE of the kernels (.text and
+            # kernel descriptors of the gfx950 code object in the library that is loaded) is what it was taken on (tools/devcode_hash.py)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from devcode_hash import device_code_hash
+            now = device_code_hash()
+            if dev_sha and now == dev_sha:
+                pmc_same = f"these very kernels: the gfx950 machine code of the library, sha256 {dev_sha}, is unchanged; only host code has been edited since"
+            else:
+                pmc_note = f"{os.path.relpath(pmc, ROOT)} was taken on other library sources ({sha}; kernels {dev_sha}, now {now}): not quoted"
+                lines = []
         for line in lines:
             f = line.strip().rsplit(",", 5)  # kernel names hold commas (template arguments)
             if len(f) >= 6 and f[0] not in ("kernel", "TOTAL") and not f[0].startswith("#"):
@@ -575,7 +585,7 @@ def main():
         pmc_split = {"count": round(sum(pmc_rows.values()) - con_traffic, 1), "construct": round(con_traffic, 1)} if pmc_rows else None
         roof_count["traffic"] = pmc_split["count"] if pmc_split else None
         roof_count["traffic_unit"] = ("GB per step, RECORDED: HBM fetch (x2 gfx950 correction) + write of the counting pipeline's kernels from the PMC passes of "
-                                      + os.path.relpath(pmc, ROOT) + " (taken on these very sources: sha256 checked); whole step: %.1f GB" % sum(pmc_rows.values())) if pmc_rows else pmc_note
+                                      + os.path.relpath(pmc, ROOT) + " (taken on " + pmc_same + "); whole step: %.1f GB" % sum(pmc_rows.values())) if pmc_rows else pmc_note
     elif not sharded and not args.count_only:
         roof_count["traffic_unit"] = "no PMC table for this workload / route under profiles/"
 
@@ -656,7 +666,7 @@ def main():
             out["dominant_kernel"] = {"name": dname, "stage": dst, "ms": round(fm, 3), "algorithmic_bytes": int(b_dom), "algorithmic_bytes_are": what,
                                       "achieved_GBps": round(b_dom / max(fm, 1e-9) / 1e6, 1), "frac": round(b_dom / max(fm, 1e-9) / 1e6 / 8000.0, 4),
                                       "traffic_GB_recorded": round(tr, 1) if tr else None,
-                                      "traffic_source": (os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes on these very sources)") if tr else pmc_note}
+                                      "traffic_source": (os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc passes on " + pmc_same.split(":")[0] + ")") if tr else pmc_note}
     if rank == 0 and world == 1 and not args.force_sharded:
         class Wrap:
             def __init__(self, ptr, shape):

@@ -34,3 +34,28 @@ def test_recorded_bench_line_has_the_contract_fields():
     # the dominant kernel is the longest single-kernel stage of the line and is priced on bytes of its own
     dk = d["dominant_kernel"]
     assert dk["ms"] == max(v for k, v in r["stages_ms"].items()) and 0 < dk["frac"] < 1
+
+
+def test_the_pmc_table_bench_quotes_belongs_to_the_kernels_that_are_built():
+    """roofline.traffic is read from the PMC passes recorded under profiles/ and quoted only while they describe the kernels that run: the
+    library sources are the ones the table was taken on, or — after host-side edits — the machine code of the kernels is (tools/devcode_hash.py:
+    .text + kernel descriptors of the gfx950 code object). A kernel edit makes bench.py print traffic null until tools/profile_bench.sh has
+    been rerun; this test says which of the two holds."""
+    import sys
+    import pytest
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from devcode_hash import device_code_hash
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "config3_pm_pmc_hbm_traffic.csv")))
+    assert files
+    head = open(files[-1]).readline()
+    assert "src_sha256=" in head and "dev_sha256=" in head
+    dev = head.split("dev_sha256=")[1].split()[0]
+    lib = os.path.join(ROOT, "spades_amd", "csrc", "libspades_mi355x.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    now = device_code_hash(lib)
+    if now is None:
+        pytest.skip("no llvm-objcopy / clang-offload-bundler here")
+    if now != dev:
+        pytest.skip(f"the kernels changed since the PMC table was taken ({dev} -> {now}): bench.py prints traffic null until the PMC passes are rerun")
+    assert now == dev

@@ -45,7 +45,10 @@ names = sorted(set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"]), key=lambda n: -(
 # k_cand_tiles launch per construction
 passes = max(1, (tot["FETCH_SIZE"].get("smx::k_cand_tiles") or tot["FETCH_SIZE"].get("smx::k_mark_windows", [1]))[0])
 with open(os.path.join(d, "pmc_hbm_traffic.csv"), "w") as o:
-    o.write(f"# src_sha256={src_hash()} (library sources the counters were taken on; bench.py refuses the table when they changed)\n")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from devcode_hash import device_code_hash
+    o.write(f"# src_sha256={src_hash()} dev_sha256={device_code_hash()} (library sources the counters were taken on, and the sha256 over .text + .rodata of the "
+            "gfx950 code object they compile to — tools/devcode_hash.py; bench.py quotes the table while either is unchanged)\n")
     o.write("kernel,launches_per_step,FETCH_SIZE_KB(raw),fetch_GB(x2 gfx950 correction),WRITE_SIZE_KB,write_GB\n")
     tf = tw = 0.0
     for n in names:
