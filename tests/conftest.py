@@ -20,6 +20,18 @@ NEXT = bool(os.environ.get("SMX_NEXT") or os.environ.get("SMX_SCALE_NEXT"))
 needs_next = pytest.mark.skipif(not NEXT, reason="no GPU run behind this code yet: SMX_NEXT=1 takes it in")
 
 
+# SMX_EMU=1: the tests drive tests/simt_emu/_build/libspades_emu.so instead of the HIP library — the library's own sources (host code and
+# gfx950 kernels as written) compiled by g++ against a fiber-based SIMT stand-in for the HIP runtime (tests/simt_emu/). A way to run kernel
+# LOGIC where there is no GPU (slow: small cases only); it proves nothing about the hardware and the product never sees it — only this
+# test-side switch points the ctypes loader somewhere else.
+EMU = bool(os.environ.get("SMX_EMU"))
+if EMU:
+    sys.path.insert(0, os.path.join(ROOT, "tests", "simt_emu"))
+    import build_emu  # noqa: E402
+    import spades_amd._lib as _smx_lib  # noqa: E402
+    _smx_lib.LIB_PATH = build_emu.build()
+
+
 def free_port():
     """a port the kernel hands out (a rendezvous port derived from the pid can collide with a parallel test run or a socket in TIME_WAIT)"""
     import socket

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: builds tests/simt_emu/_build/libspades_emu.so — the library's single translation unit (spades_amd/csrc/smx_api.hip
+with everything it includes: C ABI, host pipeline, every gfx950 kernel as written) compiled by g++ against tests/simt_emu/hip/hip_runtime.h,
+the fiber-based SIMT stand-in. The sources are used as they are except for what only an AMDGPU assembler understands:
+  * inline `asm volatile("s_waitcnt ...")` (waits that order nothing in a sequential emulation) and the library's LDS barrier (s_barrier),
+  * `extern __shared__ T name[];` (dynamic LDS: a pointer to the emulator's one LDS buffer),
+  * two clang builtins g++ lacks.
+The transformed copies live under _build/src; nothing of this is ever loaded by spades_amd (the product has no CPU path)."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "spades_amd", "csrc")
+BUILD = os.path.join(HERE, "_build")
+LIB = os.path.join(BUILD, "libspades_emu.so")
+
+
+def transform(text):
+    text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)\\n\\ts_barrier" ::: "memory"\);', "EMU_LDS_BARRIER();", text)
+    text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', "/* s_waitcnt: nothing to wait for here */;", text)
+    text = text.replace("__builtin_amdgcn_wave_barrier();", "EMU_WAVE_BARRIER();")
+    text = re.sub(r"extern __shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_0-9 ]+?)\s+(\w+)\[\];", r"\1 *\2 = (\1 *)emu::g_ctx->lds;", text)
+    text = text.replace("__builtin_rotateleft32", "emu_rotl32")
+    assert "asm volatile" not in text and "extern __shared__" not in text, "an AMDGPU-only construct the transform does not know"
+    return text
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))] + [os.path.join(ROOT, "include", "smx.h"),
+                                                                                                os.path.join(HERE, "hip", "hip_runtime.h"), __file__]
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build(force=False):
+    if not force and not stale():
+        return LIB
+    src = os.path.join(BUILD, "src", "spades_amd", "csrc")
+    shutil.rmtree(os.path.join(BUILD, "src"), ignore_errors=True)
+    os.makedirs(src)
+    os.makedirs(os.path.join(BUILD, "src", "include"))
+    shutil.copy(os.path.join(ROOT, "include", "smx.h"), os.path.join(BUILD, "src", "include", "smx.h"))
+    for f in os.listdir(CSRC):
+        if f.endswith((".hip", ".hpp")):
+            open(os.path.join(src, f), "w").write(transform(open(os.path.join(CSRC, f)).read()))
+    cmd = ["g++", "-std=c++17", "-O1", "-g0", "-fPIC", "-shared", "-pthread", "-x", "c++", "-DEMU_DEFINE_SWITCH", "-Wno-unknown-pragmas", "-Wno-attributes",
+           "-fno-omit-frame-pointer", "-I", HERE, "-include", os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(src, "smx_api.hip"), "-o", LIB]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -52,3 +52,17 @@ def test_product_never_imports_oracle():
         for f in fs:
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 assert not pat.search(open(os.path.join(dp, f)).read()), (dp, f)
+
+
+def test_product_never_touches_the_simt_emulator():
+    """tests/simt_emu/ (the library's sources compiled by g++ against a fiber-based stand-in for the HIP runtime) is test infrastructure
+    like the oracle: nothing under spades_amd/, no tool, bench.py and __graft_entry__.py never name it — the product has no CPU path."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"simt_emu|libspades_emu|SMX_EMU|hip_emu|EMU_[A-Z_]+\(", re.M)
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    for top in ("spades_amd", "integration", "include"):
+        for dp, _, fs in os.walk(os.path.join(root, top)):
+            files += [os.path.join(dp, f) for f in fs if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h"))]
+    for f in files:
+        assert not pat.search(open(f).read()), f

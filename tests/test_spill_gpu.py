@@ -58,7 +58,7 @@ def test_result_larger_than_the_hbm_budget(tmp_path):
 
 
 @needs_next
-@pytest.mark.parametrize("K,mode,nb,merge_max", [(21, "A", 16, 200), (55, "A", 16, 1000), (56, "B", 3, 500), (99, "B", 1, 300)])
+@pytest.mark.parametrize("K,mode,nb,merge_max", [(21, "A", 16, 200), (55, "A", 16, 1000), (56, "B", 3, 500), (77, "B", 1, 300)])
 def test_a_bucket_larger_than_one_merge_is_cut_by_key_range(K, mode, nb, merge_max):
     """spades-kmercount has 16 buckets whatever the input (kmercount.cpp:220): a bucket whose spilled runs exceed what the budget can
     merge at once is cut into key ranges (smx_spill_split.hpp; planner tested on the CPU in test_spill_split_cpu.py). "spill_merge_max"
