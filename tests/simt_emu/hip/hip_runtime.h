@@ -107,15 +107,27 @@ emu_ctx_switch:
 
 inline void set_tid(unsigned t) {
     Ctx &c = ctx();
+    if (c.bdim.y == 1 && c.bdim.z == 1) {
+        c.tid.x = t;
+        return;
+    }
     c.tid.x = t % c.bdim.x;
     c.tid.y = (t / c.bdim.x) % c.bdim.y;
     c.tid.z = t / (c.bdim.x * c.bdim.y);
 }
+// The running fiber has just blocked (or finished): on to the next thread that can run, directly — the scheduler is entered only when
+// nobody can (one context switch per thread and synchronisation point instead of two).
 inline void yield_to_scheduler() {
     Ctx &c = ctx();
     const unsigned me = c.cur;
+    for (unsigned t = me + 1; t < c.nthreads; ++t)
+        if (c.lanes[t].state == RUN) {
+            c.cur = t;
+            set_tid(t);
+            emu_ctx_switch(&c.lanes[me].sp, c.lanes[t].sp);
+            return;  // resumed: whoever switched here has set cur and the thread index again
+        }
     emu_ctx_switch(&c.lanes[me].sp, c.sched_sp);
-    // resumed: the scheduler has set cur and the thread index again
 }
 inline void fiber_main() {
     Ctx &c = ctx();
