@@ -561,10 +561,14 @@ def main():
             # host-side edits change the sources, not the kernels: the table also stands while the MACHINE CODE of the kernels (.text and
             # kernel descriptors of the gfx950 code object in the library that is loaded) is what it was taken on (tools/devcode_hash.py)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
-            from devcode_hash import device_code_hash
+            from devcode_hash import device_code_hash, kernel_code_hash, pmc_table_kernels
             now = device_code_hash()
+            kern_sha = lines[0].split("kern_sha256=")[1].split()[0] if "kern_sha256=" in lines[0] else None
             if dev_sha and now == dev_sha:
                 pmc_same = f"these very kernels: the gfx950 machine code of the library, sha256 {dev_sha}, is unchanged; only host code has been edited since"
+            elif kern_sha and kernel_code_hash(pmc_table_kernels(pmc)) == kern_sha:
+                pmc_same = (f"these very kernels: the machine code and descriptors of every kernel in the table, sha256 {kern_sha}, are unchanged "
+                            "(kernels the step does not launch were added to the library since)")
             else:
                 pmc_note = f"{os.path.relpath(pmc, ROOT)} was taken on other library sources ({sha}; kernels {dev_sha}, now {now}): not quoted"
                 lines = []

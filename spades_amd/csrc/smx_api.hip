@@ -6,6 +6,7 @@
 #include "smx_ingest.hip"
 #include "smx_graph.hip"
 #include "smx_pm.hip"
+#include "smx_loops.hip"
 #include "smx_dwalk.hip"
 #include "smx_gfa.hip"
 #include "smx_graph_host.hpp"
@@ -154,6 +155,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "two_strand_parts")) ctx->opt_two_strand_parts = value;
     else if (!strcmp(key, "device_gfa")) ctx->opt_device_gfa = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
+    else if (!strcmp(key, "device_loops")) ctx->opt_device_loops = value;
     else if (!strcmp(key, "derive_batches")) ctx->opt_derive_batches = value;
     else if (!strcmp(key, "keep_kpo")) ctx->opt_keep_kpo = value;
     else if (!strcmp(key, "verify_lookups")) ctx->opt_verify_lookups = value;

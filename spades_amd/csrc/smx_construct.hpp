@@ -684,6 +684,158 @@ inline int append_loops(smx_ctx *ctx, unsigned k, const uint64_t *lkmers, const 
     return 0;
 }
 
+// Perfect loops on the device (smx_loops.hip; option "device_loops"): llist = the left-over k-mers (node ranks, any order), tab = the
+// successor table of the walks. O(loop k-mers) work — cycle leaders, rotation, palindrome search, orientation, the 2-bit sequences — runs
+// in kernels; the host only orders the leaders (one per loop) and lays out the edges. Same result as append_loops (tests run both).
+template <int NW>
+int device_loops(smx_ctx *ctx, unsigned k, bool pm, const unsigned long long *llist, uint64_t L, const node_t *tab, uint64_t D0, uint64_t nkept, uint64_t ktotalw) {
+    unsigned long long *lead, *llen, *cnt;
+    if (int rc = dalloc(ctx, &lead, L)) return rc;
+    if (int rc = dalloc(ctx, &llen, L)) return rc;
+    if (int rc = dalloc(ctx, &cnt, 2)) return rc;
+    HIPCHK(hipMemsetAsync(cnt, 0, 16, ctx->stream));
+    if (pm)
+        hipLaunchKernelGGL((k_lp_leaders<NW, true, true>), dim3(grid_for(L)), dim3(BLK), 0, ctx->stream, llist, L, tab, (const void *)ctx->g_kmers, (uint32_t)ctx->g_B,
+                           (unsigned long long)(2 * D0 + 2), lead, llen, cnt);
+    else
+        hipLaunchKernelGGL((k_lp_leaders<NW, false, false>), dim3(grid_for(L)), dim3(BLK), 0, ctx->stream, llist, L, tab, (const void *)ctx->g_kmers, (uint32_t)ctx->g_B,
+                           (unsigned long long)(2 * D0 + 2), lead, llen, cnt);
+    HIPCHK(hipGetLastError());
+    unsigned long long hc[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(hc, cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (hc[1]) return fail(ctx, SMX_DEVICE_ERROR, "inconsistent k-mer index: %llu left-over k-mers lie on no cycle", hc[1]);
+    const uint64_t nl = hc[0];
+    if (!nl) return 0;
+    std::vector<unsigned long long> hlead, hlen;
+    if (int rc = d2h(ctx, hlead, lead, nl)) return rc;
+    if (int rc = d2h(ctx, hlen, llen, nl)) return rc;
+    std::vector<uint64_t> order(nl);
+    for (uint64_t i = 0; i < nl; ++i) order[i] = i;
+    if (pm) {  // the reference meets the loops in k-mer-file order of their first k-mers: (bucket, record) of the leaders
+        Rec<NW> *lk;
+        uint8_t *lm;
+        if (int rc = dalloc(ctx, &lk, nl)) return rc;
+        if (int rc = dalloc(ctx, &lm, nl)) return rc;
+        hipLaunchKernelGGL((k_gather_kmers<NW>), dim3(grid_for(nl)), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
+                           (const unsigned long long *)lead, (uint64_t)nl, (void *)lk, lm);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::vector<uint64_t> hk;
+        if (int rc = d2h(ctx, hk, lk, (size_t)nl * NW)) return rc;
+        for (uint64_t i = 0; i < nl; ++i) hk[(size_t)i * NW + NW - 1] >>= smx::EXT_BITS;
+        std::vector<uint32_t> bk(nl);
+        for (uint64_t i = 0; i < nl; ++i) bk[i] = pm_host_bucket(&hk[(size_t)i * NW], NW, ctx->g_B);
+        std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+            if (bk[a] != bk[b]) return bk[a] < bk[b];
+            for (int w = 0; w < NW; ++w)
+                if (hk[(size_t)a * NW + w] != hk[(size_t)b * NW + w]) return hk[(size_t)a * NW + w] < hk[(size_t)b * NW + w];
+            return false;
+        });
+    } else {
+        std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return hlead[a] < hlead[b]; });
+    }
+    {
+        std::vector<unsigned long long> sl(nl), sn(nl);
+        for (uint64_t i = 0; i < nl; ++i) {
+            sl[i] = hlead[order[i]];
+            sn[i] = hlen[order[i]];
+        }
+        hlead.swap(sl);
+        hlen.swap(sn);
+    }
+    HIPCHK(hipMemcpy(lead, hlead.data(), nl * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(llen, hlen.data(), nl * 8, hipMemcpyHostToDevice));
+    unsigned long long *meas;
+    if (int rc = dalloc(ctx, &meas, 4 * nl)) return rc;
+    if (pm)
+        hipLaunchKernelGGL((k_lp_measure<NW, true>), dim3(grid_for(nl)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)lead, (const unsigned long long *)llen, nl, tab,
+                           (const void *)ctx->g_kmers, meas);
+    else
+        hipLaunchKernelGGL((k_lp_measure<NW, false>), dim3(grid_for(nl)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)lead, (const unsigned long long *)llen, nl, tab,
+                           (const void *)ctx->g_kmers, meas);
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned long long> hm;
+    if (int rc = d2h(ctx, hm, meas, 4 * nl)) return rc;
+    // edges: the loop from its smallest k-mer once around, or — split at its first palindromic (k+1)-mer — that (k+1)-mer and the rest
+    std::vector<unsigned long long> ea, eb, nnt, offw, elen;
+    uint64_t words = 0;
+    auto add = [&](unsigned long long a, unsigned long long b, unsigned long long n) {
+        ea.push_back(a);
+        eb.push_back(b);
+        nnt.push_back(n);
+        offw.push_back(ktotalw + words);
+        elen.push_back(k + n);
+        words += (k + n + 31) / 32;
+    };
+    for (uint64_t i = 0; i < nl; ++i) {
+        if (hm[4 * i + 1] == ~0ull) add(hm[4 * i], hm[4 * i], hlen[i]);
+        else {
+            add(hm[4 * i + 2], hm[4 * i + 3], 1);
+            add(hm[4 * i + 3], hm[4 * i + 2], hlen[i] - 1);
+        }
+    }
+    const uint64_t nle = ea.size(), ne2 = nkept + nle, tw2 = ktotalw + words;
+    uint64_t *uw2;
+    unsigned long long *eo2, *el2, *dea, *deb, *dnn, *dof;
+    node_t *es2, *ee2;
+    uint8_t *sf2;
+    if (int rc = dalloc(ctx, &uw2, tw2 + 8, false)) return rc;
+    if (int rc = dalloc(ctx, &eo2, ne2 + 1, false)) return rc;
+    if (int rc = dalloc(ctx, &el2, ne2 + 1, false)) return rc;
+    if (int rc = dalloc(ctx, &es2, ne2 + 1, false)) return rc;
+    if (int rc = dalloc(ctx, &ee2, ne2 + 1, false)) return rc;
+    if (int rc = dalloc(ctx, &sf2, ne2 + 1, false)) return rc;
+    if (int rc = dalloc(ctx, &dea, nle)) return rc;
+    if (int rc = dalloc(ctx, &deb, nle)) return rc;
+    if (int rc = dalloc(ctx, &dnn, nle)) return rc;
+    if (int rc = dalloc(ctx, &dof, nle)) return rc;
+    hipError_t e = hipSuccess;
+    auto cp = [&](void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+        if (bytes && e == hipSuccess) e = hipMemcpy(dst, src, bytes, kind);
+    };
+    cp(uw2, ctx->g_uwords, ktotalw * 8, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemset(uw2 + ktotalw, 0, (words + 8) * 8);
+    cp(eo2, ctx->g_eoffw, nkept * 8, hipMemcpyDeviceToDevice);
+    cp(eo2 + nkept, offw.data(), nle * 8, hipMemcpyHostToDevice);
+    cp(el2, ctx->g_elen, nkept * 8, hipMemcpyDeviceToDevice);
+    cp(el2 + nkept, elen.data(), nle * 8, hipMemcpyHostToDevice);
+    cp(es2, ctx->g_estart, nkept * 8, hipMemcpyDeviceToDevice);
+    cp(ee2, ctx->g_eend, nkept * 8, hipMemcpyDeviceToDevice);
+    cp(sf2, ctx->g_eself, nkept, hipMemcpyDeviceToDevice);
+    cp(dea, ea.data(), nle * 8, hipMemcpyHostToDevice);
+    cp(deb, eb.data(), nle * 8, hipMemcpyHostToDevice);
+    cp(dnn, nnt.data(), nle * 8, hipMemcpyHostToDevice);
+    cp(dof, offw.data(), nle * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (pm)
+            hipLaunchKernelGGL((k_lp_write<NW, true>), dim3(grid_for(nle)), dim3(BLK), 0, ctx->stream, (const node_t *)dea, (const node_t *)deb, (const unsigned long long *)dnn,
+                               (const unsigned long long *)dof, nle, tab, (const void *)ctx->g_kmers, k, uw2, es2 + nkept, ee2 + nkept, sf2 + nkept);
+        else
+            hipLaunchKernelGGL((k_lp_write<NW, false>), dim3(grid_for(nle)), dim3(BLK), 0, ctx->stream, (const node_t *)dea, (const node_t *)deb, (const unsigned long long *)dnn,
+                               (const unsigned long long *)dof, nle, tab, (const void *)ctx->g_kmers, k, uw2, es2 + nkept, ee2 + nkept, sf2 + nkept);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    arena_put(ctx, ctx->g_uwords);
+    arena_put(ctx, ctx->g_eoffw);
+    arena_put(ctx, ctx->g_elen);
+    arena_put(ctx, ctx->g_estart);
+    arena_put(ctx, ctx->g_eend);
+    arena_put(ctx, ctx->g_eself);
+    ctx->g_uwords = uw2;
+    ctx->g_eoffw = eo2;
+    ctx->g_elen = el2;
+    ctx->g_estart = es2;
+    ctx->g_eend = ee2;
+    ctx->g_eself = sf2;
+    if (e != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "the perfect loops on the device failed: %s", hipGetErrorString(e));
+    ctx->g_ne = ne2;
+    ctx->g_nuwords = tw2;
+    ctx->g_nloops = nle;
+    return 0;
+}
+
 // Everything after the extension masks: early clippers (options), node table of the final masks, start de-edges, walks, perfect
 // loops, link records + vertices. tab: 2 * D0 + 2 entries; tab_valid: k_fill_tab has already filled it for the current masks.
 // pm: the partition-major route (smx_pm.hpp) — g_kmers holds EXT records in the dedupe stage's order, tab is filled, walks cross chunks by
@@ -1010,6 +1162,9 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             hipLaunchKernelGGL(k_loop_list, dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const uint8_t *)visited, D0,
                                lcount + 1, llist, nloopk);
             HIPCHK(hipGetLastError());
+            if (ctx->opt_device_loops > 0 && (k & 1)) {  // (an even k has k-mers that are their own reverse complement: one node for two strands — host)
+                if (int rc = device_loops<NW>(ctx, k, pm, llist, nloopk, (const node_t *)tab, D0, nkept, ktotalw)) return rc;
+            } else {
             std::vector<unsigned long long> ranks;
             if (int rc = d2h(ctx, ranks, llist, nloopk)) return rc;
             std::sort(ranks.begin(), ranks.end());  // k-mer-file order
@@ -1048,6 +1203,7 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
                 fm[t] = hmask[i];
             }
             if (int rc = append_loops(ctx, k, fk.data(), fr.data(), fm.data(), nloopk, nkept, ktotalw)) return rc;
+            }
         }
     }
     unsigned herr = 0;

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_manifest, read_lines
+from conftest import GOLDEN, load_manifest, needs_next, read_lines
 
 pytestmark = pytest.mark.gpu
 
@@ -347,3 +347,36 @@ def test_flanking_coverage_is_the_coverage_of_the_edge_ends(tmp_path):
             cnt = [c[min(u[j:j + K1], u[j:j + K1][::-1].translate(tr))] for j in range(len(u) - K1 + 1)]
             assert raw[i] == sum(cnt) and fs[i] == sum(cnt[:R]) and fe[i] == sum(cnt[-R:])
         gb.ctx.close()
+
+
+def _circ_reads(seqs, L, step):
+    """error-free reads around circular sequences (every (k+1)-mer of the circle for k < L - step)"""
+    reads = []
+    for s in seqs:
+        ext = s * (L // len(s) + 2)
+        reads += [ext[p:p + L] for p in range(0, len(s), step)]
+    return reads
+
+
+@needs_next
+@pytest.mark.parametrize("k,route", [(21, {}), (33, {}), (55, {}), (77, {}), (21, {"prededupe": 1, "ext_route": 1, "pm_route": 0}),
+                                     (21, {"prededupe": 1, "pm_route": 1}), (55, {"prededupe": 1, "pm_route": 1})])
+def test_perfect_loops_on_the_device_equal_the_reference(k, route, tmp_path):
+    """option device_loops (smx_loops.hip: cycle leaders, rotation to the minimal k-mer, palindrome split and orientation in kernels, on the
+    walks' successor table) against the oracle: several loops at once next to an ordinary genome, a loop shorter than k, a hairpin (a loop
+    that is its own reverse complement: split at its first palindromic (k+1)-mer), on every construction route."""
+    from oracle import oracle
+    rng = np.random.default_rng(100 + k)
+    rnd = lambda n: "".join(rng.choice(list("ACGT"), n))
+    comp = str.maketrans("ACGT", "TGCA")
+    hp = rnd(2 * k + 30)
+    circles = [rnd(300), rnd(4 * k + 7), rnd(k - 3), rnd(150), hp + hp.translate(comp)[::-1]]
+    reads = _synth(60 + k, 5000, 900, 150) + _circ_reads(circles, 2 * k + 20, 3)
+    ref = oracle.build_graph(reads, k, 20)
+    assert ref["n_loops"] >= 5
+    got = {}
+    for dev in (0, 1):
+        r = _build(reads, k, 2, tmp_path, dict(route, device_loops=dev))
+        assert r["info"]["n_loops"] == ref["n_loops"] and r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"], dev
+        got[dev] = r["gfa"]
+    assert got[0] == got[1]

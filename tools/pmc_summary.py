@@ -47,8 +47,9 @@ passes = max(1, (tot["FETCH_SIZE"].get("smx::k_cand_tiles") or tot["FETCH_SIZE"]
 with open(os.path.join(d, "pmc_hbm_traffic.csv"), "w") as o:
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from devcode_hash import device_code_hash
-    o.write(f"# src_sha256={src_hash()} dev_sha256={device_code_hash()} (library sources the counters were taken on, and the sha256 over .text + .rodata of the "
-            "gfx950 code object they compile to — tools/devcode_hash.py; bench.py quotes the table while either is unchanged)\n")
+    o.write(f"# src_sha256={src_hash()} dev_sha256={device_code_hash()} kern_sha256=@KERN@ (library sources the counters were taken on; sha256 over .text + .rodata "
+            "of the gfx950 code object they compile to; sha256 over the machine code + descriptors of the kernels of this table alone — "
+            "tools/devcode_hash.py; bench.py quotes the table while any of the three is unchanged)\n")
     o.write("kernel,launches_per_step,FETCH_SIZE_KB(raw),fetch_GB(x2 gfx950 correction),WRITE_SIZE_KB,write_GB\n")
     tf = tw = 0.0
     for n in names:
@@ -62,4 +63,9 @@ with open(os.path.join(d, "pmc_hbm_traffic.csv"), "w") as o:
         tw += wg
         o.write(f"{n},{nl / passes:g},{f:.0f},{fg:.2f},{w:.0f},{wg:.2f}\n")
     o.write(f"TOTAL,,,{tf:.1f},,{tw:.1f}\n")
+# the hash over the kernels the table names (they are known only now)
+from devcode_hash import kernel_code_hash, pmc_table_kernels  # noqa: E402
+_p = os.path.join(d, "pmc_hbm_traffic.csv")
+_t = open(_p).read().replace("@KERN@", str(kernel_code_hash(pmc_table_kernels(_p))), 1)
+open(_p, "w").write(_t)
 print(f"passes={passes} fetch {tf:.1f} GB + write {tw:.1f} GB = {tf + tw:.1f} GB per step")
