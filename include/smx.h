@@ -79,7 +79,9 @@ const char *smx_version(void);
  *   "derive_batches" (k-mer file of the construction in this many bucket ranges; 0 = as HBM requires), "keep_kpo" (-1 keep the
  *   (k+1)-mer file after the masks if HBM allows, 0 drop it: the coverage pass recounts), "verify_lookups" (1: rank lookups of
  *   k-mers that are present by construction still compare the record), "spill" (1: always keep sorted runs in host memory and
- *   merge them by bucket ranges; -1 only when the set outgrows the HBM budget), "spill_merge_max" (> 0: that merge takes at most
+ *   merge them by bucket ranges; -1 only when the set outgrows the HBM budget), "device_loops" (1: the perfect loops — CollectLoops,
+ *   debruijn_graph_constructor.hpp:359-397 — are made by kernels on the walks' successor table, smx_loops.hip, odd k; 0: by all host
+ *   cores on the gathered left-over k-mers, smx_loops_host.hpp; same result), "spill_merge_max" (> 0: that merge takes at most
  *   this many records at once, so a small input goes through the key-range split of a bucket), "ext_route" (-1 / 1: the construction takes k-mers and
  *   InOutMask bytes from ONE count of the reads where the record has 8 spare bits, the pre-dedupe stage applies and one batch fits;
  *   0: always the (k+1)-mer file first, as the reference does), "ext_presort" (0: copies of a k-mer from cut partitions are merged
