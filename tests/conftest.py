@@ -31,6 +31,16 @@ if EMU:
     import spades_amd._lib as _smx_lib  # noqa: E402
     _smx_lib.LIB_PATH = build_emu.build()
 
+    def _host_view(p, n):
+        """dist.py hands library-owned "device" memory to torch through __cuda_array_interface__; under the stand-in that memory is host
+        memory: a numpy view of it (torch.as_tensor takes it without a copy)"""
+        import ctypes
+        import numpy as np
+        return np.ctypeslib.as_array((ctypes.c_int64 * n).from_address(p))
+
+    import spades_amd.dist as _smx_dist  # noqa: E402
+    _smx_dist._DevView = _host_view
+
 
 def free_port():
     """a port the kernel hands out (a rendezvous port derived from the pid can collide with a parallel test run or a socket in TIME_WAIT)"""

@@ -320,11 +320,15 @@ def _dwalk_rank(rank, world, port, k, t, seed, n_reads, genome, coverage, outdir
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import conftest  # (SMX_EMU=1: the spawned rank, too, drives the SIMT stand-in of the library — "device" memory is host memory then)
     from spades_amd import dist as smx_dist
     from spades_amd.gbuilder import GraphBuilder
     import synth
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    if conftest.EMU:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", rank=rank, world_size=world)  # ranks that share a GPU cannot use RCCL: host-staged exchanges (dist._staged)
     try:
         codes = synth.synth_codes(seed, genome, n_reads)
