@@ -55,5 +55,22 @@ def build(force=False):
     return LIB
 
 
+def build_tools():
+    """the two CLI clones (spades_amd/tools/*_main.cpp as they are) linked against the emulated library: tests/simt_emu/_build/spades-*-mi355x.
+    (Their --gpus N hosts call hip / RCCL directly: those paths stay for the GPU box; libamdhip64 / librccl are only link-time names here.)"""
+    lib = build()
+    tools = os.path.join(ROOT, "spades_amd", "tools")
+    out = []
+    for t in ("kmercount", "gbuilder"):
+        exe = os.path.join(BUILD, f"spades-{t}-mi355x")
+        srcs = [os.path.join(tools, f) for f in os.listdir(tools) if f.endswith((".cpp", ".hpp"))]
+        if not os.path.exists(exe) or any(os.path.getmtime(x) > os.path.getmtime(exe) for x in srcs + [lib]):
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(tools, f"{t}_main.cpp"), "-L" + BUILD, "-lspades_emu", "-lz", "-pthread",
+                                   "-Wl,-rpath," + BUILD, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64",
+                                   "-Wl,-rpath,/opt/rocm/lib"])
+        out.append(exe)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

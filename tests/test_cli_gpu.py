@@ -6,12 +6,15 @@ import subprocess
 
 import pytest
 
-from conftest import GOLDEN, ROOT, load_manifest, read_lines
+from conftest import EMU, GOLDEN, ROOT, load_manifest, read_lines
 
 pytestmark = pytest.mark.gpu
 TOOLS = os.path.join(ROOT, "spades_amd", "tools")
 KC = os.path.join(TOOLS, "spades-kmercount-mi355x")
 GB = os.path.join(TOOLS, "spades-gbuilder-mi355x")
+if EMU:  # SMX_EMU=1: the same main()s linked against the SIMT stand-in of the library (tests/simt_emu/build_emu.py)
+    import build_emu
+    KC, GB = build_emu.build_tools()
 
 
 def _fastq(path, reads, gz=False):
