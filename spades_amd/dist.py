@@ -773,10 +773,10 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
     unitigs come out of distributed_walks() (lookup exchanges + pointer doubling), and only the UNITIGS (2 bits per nucleotide + 25 B per
     unitig, a few % of the k-mer file) and the k-mers of perfect loops are gathered; every rank then derives link records and vertices
     from them (engine.build_graph_from_unitigs). The graph is the same, bit for bit; it has no k-mer file on any rank.
-    No rank holds the whole (k+1)-mer file — unless coverage (-c) is asked for: the counters of the coverage pass are keyed by
-    (k+1)-mer, so the file is counted (sharded) and gathered for that pass only; each rank counts its own reads and the raw edge
-    coverages are all-reduced (SUM mod 2^32). Every rank ends with the same graph; rank 0 normally writes it. Returns the engine's
-    graph info."""
+    No rank ever holds the whole (k+1)-mer file, coverage (-c) included: its counters are keyed by (k+1)-mer, so the pass runs shard
+    by shard — the owner broadcasts its bucket range, every rank counts its own reads against that shard alone and sums what the
+    unitigs' (k+1)-mers of the shard collected; the partial raw edge coverages are all-reduced (SUM mod 2^32). Every rank ends with
+    the same graph; rank 0 normally writes it. Returns the engine's graph info."""
     K1, nb = k + 1, 10 * threads
     nw = (K1 + 31) // 32
     ext = route != "kpomers" and hasattr(engine, "shard_from_ext") and engine.ext_supported(k)
@@ -908,14 +908,34 @@ def sharded_build_graph(engine, k: int, threads: int, rank: int, world: int, dev
         info = _guarded(dev, "graph from the gathered k-mers + masks", engine.build_graph_from_kmers, k, nb, full_k, full_m, sum(kmers_per_rank), g_ksizes, n_kpo_all)
         del full_k, full_m
     if coverage:
-        full_p = _gather_shards(engine, kpo_mine, n_kpo, kpo_per_rank, nw, rank, world, dev, engine.alloc)
-        if dev.type == "cuda":
-            torch.cuda.current_stream(dev).synchronize()
-        engine.set_kpomers(full_p, sum(kpo_per_rank), g_psizes)
-        del full_p
-        cov = engine.local_raw_coverage(info["n_unitigs"]).to(torch.int64) & 0xFFFFFFFF
-        cov = cov.to(dev)
+        # The counters of the coverage pass are keyed by (k+1)-mer, and no rank may hold that whole file (16 B per (k+1)-mer of the WHOLE
+        # graph: 8 x what a rank owns at world 8). So the pass runs shard by shard: the owner of a bucket range broadcasts its shard, every
+        # rank installs it as a (k+1)-mer file that holds those buckets only (the lookups of the coverage kernels miss everything else and
+        # skip it), counts ITS OWN reads against it and sums what the unitigs' (k+1)-mers of that shard collected. An edge's coverage is a
+        # sum over its (k+1)-mers and over the ranks' reads: the partial sums add up (mod 2^32, as the counters do). Never more than one
+        # shard of the file next to the graph — at the price of one pass over the reads and the unitigs per shard.
+        n_e = info["n_unitigs"]
+        cov = torch.zeros(max(n_e, 1), dtype=torch.int64, device=dev)
+        for s_ in range(world):
+            n_s = kpo_per_rank[s_]
+            if n_s == 0:
+                continue
+            b0, b1 = rank_first_bucket(nb, world, s_), rank_first_bucket(nb, world, s_ + 1)
+            sizes_s = [g_psizes[b] if b0 <= b < b1 else 0 for b in range(nb)]
+            if sum(sizes_s) != n_s:
+                raise RuntimeError(f"rank {s_} owns {n_s} (k+1)-mers, its buckets hold {sum(sizes_s)}")
+            shard = kpo_mine if s_ == rank else engine.alloc(n_s * nw, dev)
+            _bcast_chunks(shard, 0, n_s * nw, s_)
+            if dev.type == "cuda":
+                torch.cuda.current_stream(dev).synchronize()
+            engine.set_kpomers(shard, n_s, sizes_s)
+            if s_ != rank:
+                del shard
+            part = engine.local_raw_coverage(n_e).to(torch.int64) & 0xFFFFFFFF
+            cov[:n_e] += part.to(dev)
+        cov &= 0xFFFFFFFF
         dist.all_reduce(cov, op=dist.ReduceOp.SUM)
+        cov = cov[:n_e]
         cov = (cov & 0xFFFFFFFF).to("cpu")
         cov = torch.where(cov >= 2 ** 31, cov - 2 ** 32, cov).to(torch.int32)  # uint32 bit pattern
         engine.set_raw_coverage(cov)

@@ -7,8 +7,9 @@
 //   route "kpomers" (any k): sharded count of the canonical (k+1)-mers (smx_extract_partition_owned -> exchange -> smx_count_records),
 //     smx_graph_shard_updates -> second exchange -> smx_graph_shard_build;
 //   -> the owners' shards of {k-mer file, InOutMask bytes} (bucket ranges: rank order is file order) are gathered on the ranks that
-//   build the graph — rank 0, or every rank with -c, whose coverage pass counts each rank's own reads against the gathered (k+1)-mer
-//   file and sums the raw edge coverages (ncclAllReduce) — smx_build_graph_from_kmers; rank 0 writes the output.
+//   build the graph — rank 0, or every rank with -c, whose coverage pass counts each rank's own reads against ONE OWNER'S SHARD of the
+//   (k+1)-mer file at a time (never the whole file on a rank) and sums the raw edge coverages (ncclAllReduce) —
+//   smx_build_graph_from_kmers; rank 0 writes the output.
 // Exchanges are grouped ncclSend / ncclRecv between all pairs (xGMI is point to point: every pair has its own link, no ring).
 // A graph whose gathered structure exceeds one GPU's HBM needs the distributed walks, which only dist.py drives today.
 #pragma once
@@ -225,6 +226,25 @@ inline int gather_shards(RankComm &c, const void *d_mine, const std::vector<uint
     return 0;
 }
 
+// `bytes` bytes at d_buf of rank `root` to d_buf of every other rank: grouped ncclSend / ncclRecv in rounds, like the gathers
+inline int bcast_from(RankComm &c, int root, void *d_buf, uint64_t bytes) {
+    if (c.world == 1 || bytes == 0) return 0;
+    const uint64_t LIM = round_limit_words() * 8;
+    for (uint64_t a = 0; a < bytes; a += LIM) {
+        const uint64_t n = std::min(LIM, bytes - a);
+        GM_NCCL(ncclGroupStart());
+        if (c.rank == root) {
+            for (int p = 0; p < c.world; ++p)
+                if (p != root) GM_NCCL(ncclSend((const char *)d_buf + a, n, ncclUint8, p, c.comm, c.stream));
+        } else {
+            GM_NCCL(ncclRecv((char *)d_buf + a, n, ncclUint8, root, c.comm, c.stream));
+        }
+        GM_NCCL(ncclGroupEnd());
+    }
+    GM_HIP(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
 // sharded count of the canonical K-mers: afterwards the context's count result is this rank's bucket range of the file
 inline int sharded_count_canonical(RankComm &c, smx_ctx *ctx, unsigned K, unsigned nb, uint64_t *n_mine, std::vector<uint64_t> &sizes) {
     const unsigned nw = (K + 31) / 32;
@@ -399,16 +419,34 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
     if (builds) GM_SMX(smx_graph_info(ctx, info));
     GM_MARK("graph built from the gathered shards")
     if (cov) {
-        void *d_full_p = nullptr;
-        if (int rc = gather_shards(c, d_kpo_mine, kpo_per, (size_t)nw * 8, true, &d_full_p)) return rc;
-        (void)hipFree(d_kpo_mine);
-        GM_SMX(smx_graph_set_kpomers(ctx, d_full_p, total_kpo, g_psizes.data()));
-        (void)hipFree(d_full_p);
+        // The counters of the coverage pass are keyed by (k+1)-mer, and no rank may hold that whole file: shard by shard (dist.py does the
+        // same) — the owner of a bucket range sends its shard to everybody, every rank installs it as a (k+1)-mer file of those buckets
+        // alone (the lookups of the coverage kernels miss everything else), counts ITS reads against it and sums what the unitigs'
+        // (k+1)-mers of the shard collected. Partial sums add up (mod 2^32, like the reference's counters).
         if (rank == 0) printf("Filling coverage index\n");
-        GM_SMX(smx_graph_fill_coverage(ctx));  // this rank's reads against the whole (k+1)-mer file
         const uint64_t ne = info[2];
-        std::vector<uint32_t> raw(std::max<uint64_t>(ne, 1), 0);
-        GM_SMX(smx_graph_copy_coverage(ctx, raw.data()));
+        std::vector<uint32_t> raw(std::max<uint64_t>(ne, 1), 0), part(std::max<uint64_t>(ne, 1), 0);
+        for (int s_ = 0; s_ < world; ++s_) {
+            const uint64_t n_s = kpo_per[s_];
+            if (!n_s) continue;
+            const unsigned b0 = smx_rank_first_bucket(nb, (unsigned)world, (unsigned)s_), b1 = smx_rank_first_bucket(nb, (unsigned)world, (unsigned)s_ + 1);
+            std::vector<uint64_t> sizes_s(nb, 0);
+            uint64_t sum_s = 0;
+            for (unsigned b = b0; b < b1; ++b) sum_s += (sizes_s[b] = g_psizes[b]);
+            if (sum_s != n_s) {
+                fprintf(stderr, "[rank %d] rank %d owns %llu (k+1)-mers, its buckets hold %llu\n", rank, s_, (unsigned long long)n_s, (unsigned long long)sum_s);
+                return SMX_DEVICE_ERROR;
+            }
+            void *d_shard = d_kpo_mine;
+            if (s_ != rank) GM_HIP(hipMalloc(&d_shard, (size_t)n_s * nw * 8));
+            if (int rc = bcast_from(c, s_, d_shard, n_s * (uint64_t)nw * 8)) return rc;
+            GM_SMX(smx_graph_set_kpomers(ctx, d_shard, n_s, sizes_s.data()));
+            if (s_ != rank) (void)hipFree(d_shard);
+            GM_SMX(smx_graph_fill_coverage(ctx));  // this rank's reads against that shard
+            GM_SMX(smx_graph_copy_coverage(ctx, part.data()));
+            for (uint64_t e = 0; e < ne; ++e) raw[e] += part[e];
+        }
+        (void)hipFree(d_kpo_mine);
         uint32_t *d_cov = nullptr;
         GM_HIP(hipMalloc((void **)&d_cov, raw.size() * 4));
         GM_HIP(hipMemcpy(d_cov, raw.data(), raw.size() * 4, hipMemcpyHostToDevice));

@@ -154,6 +154,8 @@ int smx_submit_reads_ascii(smx_ctx *, const char *bases, const uint64_t *off, ui
     return (int)fwd("smx_submit_reads_ascii", 3, LL(bases), LL(off), LL(n));
 }
 int smx_kmers_with_masks_supported(unsigned k) { return (int)fwd("smx_kmers_with_masks_supported", 1, LL(k)); }
+// (pure arithmetic in the library, include/smx.h: the owner of a bucket range)
+unsigned smx_rank_first_bucket(unsigned num_buckets, unsigned world, unsigned rank) { return (unsigned)(((uint64_t)rank * num_buckets + world - 1) / world); }
 int smx_extract_partition_owned(smx_ctx *, unsigned K, int mode, unsigned nb, unsigned world, const void **d, uint64_t *counts) {
     return (int)fwd("smx_extract_partition_owned", 6, LL(K), LL(mode), LL(nb), LL(world), LL(d), LL(counts));
 }

@@ -231,8 +231,16 @@ class OracleGraphEngine(OracleEngine):
                     n_loops=self.g["n_loops"], n_vertices=self.g["n_vertices"], unitig_bases=0, words=nw)
 
     def set_kpomers(self, buf, n, bucket_sizes):
+        """a (k+1)-mer file that may hold some buckets only (dist.py installs one owner's shard at a time for -c; the C++ host the whole
+        file): the lookups of the coverage pass miss what is not in it, like the library's"""
         nw = (self.k + 1 + 31) // 32
-        self.gathered = buf[:n * nw].numpy().view(np.uint64).reshape(n, nw).copy()
+        assert bucket_sizes is None or sum(int(x) for x in bucket_sizes) == n  # (the C++ hosts' shim forwards no sizes)
+        part = buf[:n * nw].numpy().view(np.uint64).reshape(n, nw).copy()
+        self.kpo_parts = getattr(self, "kpo_parts", []) + [part]
+        self.gathered = np.concatenate(self.kpo_parts)  # (in rank order the shards ARE the file: the tests compare it with the reference's)
+        self.kpo_max_resident = max(getattr(self, "kpo_max_resident", 0), n)
+        K1 = self.k + 1
+        self.kpo_now = {"".join("ACGT"[(int(rec[j >> 5]) >> ((j & 31) << 1)) & 3] for j in range(K1)) for rec in part}
 
     def local_raw_coverage(self, n_unitigs):
         # (k+1)-mer instances of this rank's reads (+RC), per unitig; a (k+1)-mer and its RC are the same canonical key
@@ -247,6 +255,8 @@ class OracleGraphEngine(OracleEngine):
             for j in range(len(s) - K1 + 1):  # read + RC stream, minimal orientation counted: once per occurrence, palindromes twice
                 x = s[j:j + K1]
                 y = x[::-1].translate(tr)
+                if min(x, y) not in self.kpo_now:  # (not in the installed file: the rank lookup misses, nothing is counted)
+                    continue
                 c[min(x, y)] += 2 if x == y else 1
         out = []
         for u in self.g["unitigs"]:
@@ -268,6 +278,8 @@ def _graph_worker(rank, world, port, k, threads, q, route="kpomers", coverage=Tr
     eng = OracleGraphEngine(reads[rank::world], reads)
     info = smx_dist.sharded_build_graph(eng, k, threads, rank, world, torch.device("cpu"), coverage=coverage, route=route, walks="auto" if route == "ext" else "gathered")
     assert info["route"] == route and info["walks"] == "gathered"  # ("auto" has room for the gathered structure here)
+    if coverage and world > 1:  # -c: one owner's shard of the (k+1)-mer file at a time, never the whole file on a rank
+        assert 0 < eng.kpo_max_resident < sum(info["kpomers_per_rank"]) and len(eng.kpo_parts) == sum(1 for c in info["kpomers_per_rank"] if c)
     q.put((rank, eng.gathered.tobytes() if coverage else b"", eng.cov.tobytes() if coverage else b"", info["kpomers_per_rank"], eng.g["gfa"],
            len(eng.result) if hasattr(eng, "result") else 0, eng.shard_updates_seen, info["kmers_per_rank"], getattr(eng, "ext_sent", 0)))
     dist.barrier()
