@@ -70,6 +70,9 @@ struct Lane {
 
 struct Ctx {
     std::vector<Lane> lanes;
+    std::vector<unsigned> order;  // the order in which the runnable threads of a workgroup take their turns (identity, or shuffled: below)
+    unsigned pos = 0;             // position of the running thread in `order`
+    uint64_t rng = 0;             // SMX_EMU_SHUFFLE=seed: xorshift state, 0 = off
     unsigned cur = 0, nthreads = 0;
     void *sched_sp = nullptr;
     const std::function<void()> *body = nullptr;
@@ -120,13 +123,16 @@ inline void set_tid(unsigned t) {
 inline void yield_to_scheduler() {
     Ctx &c = ctx();
     const unsigned me = c.cur;
-    for (unsigned t = me + 1; t < c.nthreads; ++t)
+    for (unsigned p = c.pos + 1; p < c.nthreads; ++p) {
+        const unsigned t = c.order[p];
         if (c.lanes[t].state == RUN) {
+            c.pos = p;
             c.cur = t;
             set_tid(t);
             emu_ctx_switch(&c.lanes[me].sp, c.lanes[t].sp);
             return;  // resumed: whoever switched here has set cur and the thread index again
         }
+    }
     emu_ctx_switch(&c.lanes[me].sp, c.sched_sp);
 }
 inline void fiber_main() {
@@ -194,11 +200,28 @@ inline void run_block(const std::function<void()> &body) {
     const unsigned n = c.nthreads;
     if (c.lanes.size() < n) c.lanes.resize(n);
     for (unsigned t = 0; t < n; ++t) prepare(c.lanes[t]);
+    if (c.order.size() != n) {
+        c.order.resize(n);
+        for (unsigned t = 0; t < n; ++t) c.order[t] = t;
+    }
     for (;;) {
+        // SMX_EMU_SHUFFLE=seed: between two synchronisation points the threads take their turns in a fresh random order each time — the
+        // hardware promises no order either, so whatever a kernel's RESULT owes to the order in which its lanes reach an atomic shows up as
+        // a difference between runs (the library claims there is none: the order of the survivors never reaches the output)
+        if (c.rng) {
+            for (unsigned i = n - 1; i > 0; --i) {
+                c.rng ^= c.rng << 13;
+                c.rng ^= c.rng >> 7;
+                c.rng ^= c.rng << 17;
+                std::swap(c.order[i], c.order[c.rng % (i + 1)]);
+            }
+        }
         bool ran = false;
-        for (unsigned t = 0; t < n; ++t) {
+        for (unsigned p = 0; p < n; ++p) {
+            const unsigned t = c.order[p];
             if (c.lanes[t].state != RUN) continue;
             ran = true;
+            c.pos = p;
             c.cur = t;
             set_tid(t);
             emu_ctx_switch(&c.sched_sp, c.lanes[t].sp);
@@ -277,6 +300,8 @@ inline void launch(dim3 grid, dim3 block, const F &f, const char *name = "") {
         }
     } done{name, grid, t0};
     Ctx &c = ctx();
+    static const uint64_t seed = getenv("SMX_EMU_SHUFFLE") ? (uint64_t)atoll(getenv("SMX_EMU_SHUFFLE")) * 0x9E3779B97F4A7C15ull + 1 : 0;
+    if (seed && !c.rng) c.rng = seed;
     c.gdim = grid;
     c.bdim = block;
     c.nthreads = block.x * block.y * block.z;
