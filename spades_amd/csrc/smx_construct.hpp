@@ -710,6 +710,10 @@ int device_loops(smx_ctx *ctx, unsigned k, bool pm, const unsigned long long *ll
     std::vector<unsigned long long> hlead, hlen;
     if (int rc = d2h(ctx, hlead, lead, nl)) return rc;
     if (int rc = d2h(ctx, hlen, llen, nl)) return rc;
+    // One thread walks one loop (rotation, palindrome search, orientation, sequence): fine for plasmids by the thousand, not for ONE loop of
+    // millions of k-mers (a dependent load per step: seconds). Such an input goes to the host collector, which cuts a cycle among all cores.
+    for (uint64_t i = 0; i < nl; ++i)
+        if (hlen[i] > (1ull << 18)) return SMX_ROUTE_NA;
     std::vector<uint64_t> order(nl);
     for (uint64_t i = 0; i < nl; ++i) order[i] = i;
     if (pm) {  // the reference meets the loops in k-mer-file order of their first k-mers: (bucket, record) of the leaders
@@ -1162,9 +1166,10 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             hipLaunchKernelGGL(k_loop_list, dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const uint8_t *)visited, D0,
                                lcount + 1, llist, nloopk);
             HIPCHK(hipGetLastError());
-            if (ctx->opt_device_loops > 0 && (k & 1)) {  // (an even k has k-mers that are their own reverse complement: one node for two strands — host)
-                if (int rc = device_loops<NW>(ctx, k, pm, llist, nloopk, (const node_t *)tab, D0, nkept, ktotalw)) return rc;
-            } else {
+            int lrc = SMX_ROUTE_NA;  // (an even k has k-mers that are their own reverse complement: one node for two strands — host)
+            if (ctx->opt_device_loops > 0 && (k & 1)) lrc = device_loops<NW>(ctx, k, pm, llist, nloopk, (const node_t *)tab, D0, nkept, ktotalw);
+            if (lrc != 0 && lrc != SMX_ROUTE_NA) return lrc;
+            if (lrc == SMX_ROUTE_NA) {
             std::vector<unsigned long long> ranks;
             if (int rc = d2h(ctx, ranks, llist, nloopk)) return rc;
             std::sort(ranks.begin(), ranks.end());  // k-mer-file order
