@@ -35,8 +35,8 @@ def emu_lib():
     return build_emu.build()
 
 
-def _run(args, timeout=900):
-    env = dict(os.environ, SMX_EMU="1", SMX_NEXT="1")
+def _run(args, timeout=900, **extra):
+    env = dict(os.environ, SMX_EMU="1", SMX_NEXT="1", **extra)
     env.pop("PYTEST_XDIST_WORKER", None)
     return subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-p", "no:xdist"] + args, cwd=ROOT, env=env,
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, text=True)
@@ -47,6 +47,14 @@ def test_gpu_tests_pass_on_the_emulated_library(emu_lib, path, expr):
     r = _run([path, "-k", expr])
     tail = "\n".join(r.stdout.splitlines()[-15:])
     assert r.returncode == 0 and " passed" in r.stdout, tail
+
+
+def test_results_do_not_depend_on_the_order_in_which_lanes_reach_an_atomic(emu_lib):
+    """SMX_EMU_SHUFFLE: between two synchronisation points the threads of a workgroup take their turns in a fresh random order — the hardware
+    promises none. The sort leaves, the LDS hash sets and the multi-batch folds hand out places by atomics; the outputs must not notice."""
+    for seed in ("11", "12"):
+        r = _run(["tests/test_count_gpu.py", "-k", "test_multi_batch_runs_are_merged or (test_multilevel_and_oversized_bins and 55-B-30-opts1)"], SMX_EMU_SHUFFLE=seed)
+        assert r.returncode == 0 and " passed" in r.stdout, "\n".join(r.stdout.splitlines()[-15:])
 
 
 def test_smoke_graph_with_a_perfect_loop_on_the_emulated_library(emu_lib):
