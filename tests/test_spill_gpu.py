@@ -81,3 +81,28 @@ def test_a_bucket_larger_than_one_merge_is_cut_by_key_range(K, mode, nb, merge_m
         else:
             assert got == want
         ctx.close()
+
+
+@needs_next
+def test_a_budget_ten_times_smaller_than_the_result(monkeypatch):
+    """31 MB of k-mers (20 000 reads, k = 55, both strands, 16 buckets: 1.9 MB per bucket) under HBM budgets of 8 and 3 MiB (arena in 2 MiB
+    chunks): position batches, sorted runs on the host, and — at 3 MiB, where one bucket's runs exceed what can be merged at once — the
+    key-range split of every bucket, all chosen by the library itself. Round 3 refused such an input ("use more buckets")."""
+    monkeypatch.setenv("SMX_ARENA_CHUNK_MB", "2")
+    codes = synth.synth_codes(5, 200_000, 20000)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    reads = [lut[c].tobytes().decode() for c in codes]
+    want = None
+    for budget in (0, 8 << 20, 3 << 20):
+        ctx = Context(hbm_budget=budget)
+        ctx.set_option("prededupe", 0)
+        sp = ReadKMerSplitter(55, "A", ctx)
+        sp.push_back_reads(reads)
+        st = KMerDiskCounter(None, sp).Count(16)
+        got = (hashlib.md5(st.records().tobytes()).hexdigest(), st.bucket_sizes().tolist(), hashlib.md5(st.bucket(7).tobytes()).hexdigest())
+        assert (st.device_ptr() == 0) == bool(budget)
+        if want is None:
+            want = got
+        else:
+            assert got == want, budget
+        ctx.close()
