@@ -74,6 +74,7 @@ const char *smx_version(void);
  *   "flank_range" = 50        FlankingCoverage averaging range (graph_support/detail_coverage.hpp:69-76)
  * Engine knobs (no reference equivalent; closest is the -b buffer-size knob of kmercount.cpp:139); results never depend on them:
  *   "prededupe" (-1 auto, 0 direct pipeline, 1 force the super-k-mer stage), "skm_cap", "skm_scap", "skm_stage" (its chunk sizes / staging),
+ *   "skm_nkey_log2" (the stage starts from 2^this minimizer partitions instead of 2^24; 12..28, tests),
  *   "batch_records" (force HBM-bounded batches), "leaf_cap", "leaf_target", "leaf_grid", "leaf_tab", "s1", "s2" (leaf / MSD split geometry),
  *   "joint_hist" (level-2 histogram counted with level 1), "device_links" (0 host, 1 device from 65 536 edges, 2 always),
  *   "derive_batches" (k-mer file of the construction in this many bucket ranges; 0 = as HBM requires), "keep_kpo" (-1 keep the

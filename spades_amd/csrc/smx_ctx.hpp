@@ -109,6 +109,7 @@ struct smx_ctx {
     // tuning / test hooks
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;
+    int64_t opt_skm_nkey_log2 = 0;  // > 0: the super-k-mer stage starts from 2^this minimizer partitions instead of 2^24 (12..28; it still doubles with the input)
     int64_t opt_device_loops = 0;  // 1: perfect loops by the kernels of smx_loops.hip (odd k); 0: on the host (smx_loops_host.hpp) — the default until a GPU run has compared them
     int64_t opt_flank_range = 50;     // FlankingCoverage averaging range ((k+1)-mers at either end of an edge)
     int64_t opt_submit_contigs = 0;   // reads submitted while this is 1 are contigs: construction yes, coverage no

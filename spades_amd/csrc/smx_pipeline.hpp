@@ -530,6 +530,8 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     unsigned long long *cnt, *soff, *ocount, *cursor;  // ocount[0] clean, ocount[1] dirty survivors
     // partitions: ~256 windows each on average (a genomic locus at 30x is ~600), at least 2^24
     uint32_t SKM_NKEY = SKM_NKEY_MIN;
+    if (ctx->opt_skm_nkey_log2 > 0)  // engine knob (tests): fewer partitions to begin with — the SIMT stand-in pays for every one of the 2^24
+        SKM_NKEY = 1u << (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_skm_nkey_log2, 12), 28);
     while (SKM_NKEY < SKM_NKEY_MAX && (uint64_t)SKM_NKEY * 256 < nwin) SKM_NKEY <<= 1;
     if (int rc = dalloc(ctx, &cnt, SKM_NKEY)) return rc;
     if (int rc = dalloc(ctx, &soff, SKM_NKEY + 1)) return rc;
