@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_manifest, read_lines
+from conftest import GOLDEN, load_manifest, needs_next, read_lines
 from test_ext_route_gpu import _eligible, _same_kmers, _synth
 
 pytestmark = pytest.mark.gpu
@@ -91,6 +91,21 @@ def test_vs_oracle_seeded(k, tmp_path):
         assert r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"]
         old = _build(reads, k, threads, tmp_path, SORTED)
         assert _same_kmers(r, old) and r["info"] == old["info"]
+
+
+@needs_next
+@pytest.mark.parametrize("log2", [12, 13, 16])
+def test_partition_count_does_not_matter(log2, tmp_path):
+    """option skm_nkey_log2: the super-k-mer stage starts from 2^12 … 2^16 minimizer partitions instead of 2^24 — on these 1 500 reads that is
+    the ≈50–800 windows per partition of a production run (2^24 leaves a partition a window or none): full chunks, folded slots, cut
+    partitions and the sorted tail of the partition-major route all see work. Same graph as the oracle's, on both super-k-mer routes."""
+    from oracle import oracle
+    for k, threads in ((21, 1), (55, 2)):
+        reads = _synth(7 * k, 4000, 1500, 150) + ["ACGT" * 40] * 3 + ["AT" * 70] * 2 + ["A" * 140] * 4
+        ref = oracle.build_graph(reads, k, 10 * threads)
+        for route in (PM, SORTED):
+            r = _build(reads, k, threads, tmp_path, dict(route, skm_nkey_log2=log2))
+            assert r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"], (k, log2, route)
 
 
 def test_coverage_vs_oracle_seeded(tmp_path):

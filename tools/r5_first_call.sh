@@ -8,7 +8,7 @@ set -x
 #    default tier: smoke + graph tests), then the opt-in goldens (10 000 plasmids = 9 937 loops; k = 77 at 20 M reads)
 SMX_NEXT=1 timeout 600 python -m pytest tests/test_spill_gpu.py -m gpu -x -q > $out/t_spill_next.txt 2>&1; tail -5 $out/t_spill_next.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; tail -2 $out/smoke.txt
-SMX_NEXT=1 timeout 600 python -m pytest tests/test_graph_gpu.py tests/test_pm_route_gpu.py -m gpu -x -q > $out/t_graph.txt 2>&1; tail -3 $out/t_graph.txt   # (with NEXT: the device loops, option device_loops, against the oracle on every route)
+SMX_NEXT=1 timeout 600 python -m pytest tests/test_graph_gpu.py tests/test_pm_route_gpu.py -m gpu -x -q > $out/t_graph.txt 2>&1; tail -3 $out/t_graph.txt   # (with NEXT: the device loops, option device_loops, against the oracle on every route; production-like partition density on small inputs, option skm_nkey_log2)
 SMX_OPTS=device_loops=1 SMX_NEXT=1 SMX_DEBUG=1 timeout 900 python -m pytest tests/test_scale_gpu.py -m gpu -x -q -k "plasmids" > $out/t_scale_device_loops.txt 2>&1; grep -E "g:loops|passed|failed" $out/t_scale_device_loops.txt | tail -12   # 9 937 loops by the kernels; g:loops = their wall time (compare with the run below)
 SMX_NEXT=1 SMX_DEBUG=1 timeout 900 python -m pytest tests/test_scale_gpu.py -m gpu -x -q -k "next_scale" > $out/t_scale_next.txt 2>&1; grep -v "^\[smx\] \(skm\|dedupe\|level\|leaf\)" $out/t_scale_next.txt | tail -30
 # 2. the whole tier on these sources
