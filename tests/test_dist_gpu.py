@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import read_lines
+from conftest import needs_next, read_lines
 
 pytestmark = pytest.mark.gpu
 
@@ -312,7 +312,7 @@ def test_distributed_walks_single_rank_nccl(tmp_path):
         dist.destroy_process_group()
 
 
-def _dwalk_rank(rank, world, port, k, t, seed, n_reads, genome, coverage, outdir):
+def _dwalk_rank(rank, world, port, k, t, seed, n_reads, genome, coverage, outdir, walks="distributed"):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.dirname(here))
@@ -338,7 +338,7 @@ def _dwalk_rank(rank, world, port, k, t, seed, n_reads, genome, coverage, outdir
         gb.push_back_reads(reads)
         if k == 21:  # several chunks per doubling round and per fetch of the chains
             smx_dist.WALK_CHUNK, smx_dist.WALK_START_CHUNK = 1 << 14, 1 << 10
-        info = smx_dist.sharded_build_graph(smx_dist.GpuEngine(gb.ctx, "B"), k, t, rank, world, dev, coverage=coverage, walks="distributed")
+        info = smx_dist.sharded_build_graph(smx_dist.GpuEngine(gb.ctx, "B"), k, t, rank, world, dev, coverage=coverage, walks=walks)
         gb.adopt(info)
         gb.write_gfa(os.path.join(outdir, f"rank{rank}.gfa"))
         with open(os.path.join(outdir, f"rank{rank}.info"), "w") as f:
@@ -380,3 +380,34 @@ def test_distributed_walks_ranks_sharing_one_gpu(k, t, n_reads, genome, coverage
         info = eval(open(os.path.join(str(tmp_path), f"rank{r}.info")).read())
         assert sum(info["kmers_per_rank"]) == n_kmers and max(info["kmers_per_rank"]) < n_kmers  # the file was sharded
         assert all(u > 0 for u in info["unitigs_per_rank"])
+
+
+@needs_next
+@pytest.mark.parametrize("k,t,n_reads,genome,world", [(21, 1, 6000, 30000, 2), (55, 2, 8000, 40000, 3)])
+def test_gathered_construction_with_coverage_ranks_sharing_one_gpu(k, t, n_reads, genome, world, tmp_path):
+    """the gathered route at world 2-3 with -c: the coverage pass runs shard by shard over the (k+1)-mer file (no rank installs more than one
+    owner's bucket range at a time) and every rank ends with the single-process GFA, KC / DP tags included"""
+    import torch.multiprocessing as mp
+    import synth
+    from spades_amd.gbuilder import GraphBuilder
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_dwalk_rank, args=(r, world, port, k, t, 777 + k, n_reads, genome, True, str(tmp_path), "gathered")) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    codes = synth.synth_codes(777 + k, genome, n_reads)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    ref = GraphBuilder(k, t)
+    ref.push_back_reads([lut[c].tobytes().decode() for c in codes])
+    ref.build()
+    ref.fill_coverage()
+    want = os.path.join(str(tmp_path), "ref.gfa")
+    ref.write_gfa(want)
+    ref.ctx.close()
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), f"rank{r}.gfa")).read() == open(want).read()
+        info = eval(open(os.path.join(str(tmp_path), f"rank{r}.info")).read())
+        assert info["walks"] == "gathered" and max(info["kpomers_per_rank"]) < sum(info["kpomers_per_rank"])
