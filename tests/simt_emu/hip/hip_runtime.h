@@ -77,6 +77,7 @@ struct Ctx {
     void *sched_sp = nullptr;
     const std::function<void()> *body = nullptr;
     dim3 tid, bid, bdim, gdim;
+    size_t lds_used = 0;  // dynamic LDS the launch asked for (what SMX_EMU_POISON fills)
     alignas(64) unsigned char lds[LDS_BYTES];
 };
 inline Ctx *g_ctx = new Ctx;  // (one host thread drives the library in the tests)
@@ -200,6 +201,10 @@ inline void run_block(const std::function<void()> &body) {
     const unsigned n = c.nthreads;
     if (c.lanes.size() < n) c.lanes.resize(n);
     for (unsigned t = 0; t < n; ++t) prepare(c.lanes[t]);
+    // SMX_EMU_POISON=1: a workgroup finds garbage in its dynamic LDS, as on the hardware (here the previous group's bytes would still be
+    // there, and a kernel that counts on them — or on zeros — would pass by accident)
+    static const bool poison = getenv("SMX_EMU_POISON") != nullptr;
+    if (poison) memset(c.lds, 0xCD, c.lds_used ? c.lds_used : LDS_BYTES);
     if (c.order.size() != n) {
         c.order.resize(n);
         for (unsigned t = 0; t < n; ++t) c.order[t] = t;
@@ -460,6 +465,7 @@ static inline hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                   \
     do {                                                                                              \
         if ((size_t)(shmem) > emu::LDS_BYTES) emu::die("dynamic LDS request beyond 160 KB");          \
+        emu::g_ctx->lds_used = (size_t)(shmem);                                                       \
         auto emu_args_ = std::make_tuple(__VA_ARGS__);                                                \
         emu::launch(dim3(grid), dim3(block), [&]() { std::apply([&](auto &...a_) { kernel(a_...); }, emu_args_); }, #kernel); \
     } while (0)
