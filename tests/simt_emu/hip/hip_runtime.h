@@ -78,7 +78,20 @@ struct Ctx {
     const std::function<void()> *body = nullptr;
     dim3 tid, bid, bdim, gdim;
     size_t lds_used = 0;  // dynamic LDS the launch asked for (what SMX_EMU_POISON fills)
-    alignas(64) unsigned char lds[LDS_BYTES];
+    // dynamic LDS: the bytes a launch asked for END at a no-access page, so a kernel that uses more than it requested faults here instead of
+    // trampling its neighbours' LDS on the hardware (base is 16-byte aligned: an overrun of less than that goes unseen)
+    unsigned char *lds_area = nullptr, *lds = nullptr;
+    void place_lds(size_t bytes) {
+        if (!lds_area) {
+            lds_area = (unsigned char *)mmap(nullptr, LDS_BYTES + 2 * 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (lds_area == (unsigned char *)MAP_FAILED || mprotect(lds_area + LDS_BYTES + 4096, 4096, PROT_NONE) != 0) {
+                perror("emu: LDS area");
+                abort();
+            }
+        }
+        lds_used = bytes;
+        lds = lds_area + LDS_BYTES + 4096 - ((bytes + 15) & ~(size_t)15);
+    }
 };
 inline Ctx *g_ctx = new Ctx;  // (one host thread drives the library in the tests)
 inline Ctx &ctx() { return *g_ctx; }
@@ -204,7 +217,7 @@ inline void run_block(const std::function<void()> &body) {
     // SMX_EMU_POISON=1: a workgroup finds garbage in its dynamic LDS, as on the hardware (here the previous group's bytes would still be
     // there, and a kernel that counts on them — or on zeros — would pass by accident)
     static const bool poison = getenv("SMX_EMU_POISON") != nullptr;
-    if (poison) memset(c.lds, 0xCD, c.lds_used ? c.lds_used : LDS_BYTES);
+    if (poison && c.lds_used) memset(c.lds, 0xCD, c.lds_used);
     if (c.order.size() != n) {
         c.order.resize(n);
         for (unsigned t = 0; t < n; ++t) c.order[t] = t;
@@ -465,7 +478,7 @@ static inline hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                   \
     do {                                                                                              \
         if ((size_t)(shmem) > emu::LDS_BYTES) emu::die("dynamic LDS request beyond 160 KB");          \
-        emu::g_ctx->lds_used = (size_t)(shmem);                                                       \
+        emu::g_ctx->place_lds((size_t)(shmem));                                                       \
         auto emu_args_ = std::make_tuple(__VA_ARGS__);                                                \
         emu::launch(dim3(grid), dim3(block), [&]() { std::apply([&](auto &...a_) { kernel(a_...); }, emu_args_); }, #kernel); \
     } while (0)
