@@ -439,6 +439,7 @@ template <class T> static inline hipError_t hipMalloc(T **p, size_t n) {
     if (emu::in_use() + n > emu::device_bytes()) { *p = nullptr; return hipErrorOutOfMemory; }
     void *q = nullptr;
     if (posix_memalign(&q, 256, std::max<size_t>(n, 1)) != 0) { *p = nullptr; return hipErrorOutOfMemory; }
+    if (getenv("SMX_EMU_POISON")) memset(q, 0xCD, std::max<size_t>(n, 1));
     *p = (T *)q;
     return hipSuccess;
 }
@@ -467,7 +468,12 @@ static inline hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *h, size_t
 static inline hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) { emu::in_use() -= h->size; delete h; return hipSuccess; }
 static inline hipError_t hipMemMap(void *p, size_t n, size_t, hipMemGenericAllocationHandle_t, unsigned long long) {
     void *q = mmap(p, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_FIXED | MAP_NORESERVE, -1, 0);
-    return q == MAP_FAILED ? hipErrorOutOfMemory : hipSuccess;
+    if (q == MAP_FAILED) return hipErrorOutOfMemory;
+    // SMX_EMU_POISON=1: freshly mapped device memory holds garbage, as VRAM does (anonymous pages would be zeros: a kernel that reads what
+    // nobody wrote would get away with it here). Use small arena chunks (SMX_ARENA_CHUNK_MB=2) with it: every mapped byte is touched.
+    static const bool poison = getenv("SMX_EMU_POISON") != nullptr;
+    if (poison) memset(q, 0xCD, n);
+    return hipSuccess;
 }
 static inline hipError_t hipMemUnmap(void *p, size_t n) {
     void *q = mmap(p, n, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_FIXED | MAP_NORESERVE, -1, 0);
