@@ -325,12 +325,27 @@ inline void launch(dim3 grid, dim3 block, const F &f, const char *name = "") {
     c.nthreads = block.x * block.y * block.z;
     if (c.nthreads == 0 || c.nthreads > 1024) die("bad block size");
     const std::function<void()> body = f;
-    for (unsigned z = 0; z < grid.z; ++z)
-        for (unsigned y = 0; y < grid.y; ++y)
-            for (unsigned x = 0; x < grid.x; ++x) {
-                c.bid = dim3(x, y, z);
-                run_block(body);
-            }
+    // SMX_EMU_SHUFFLE_GROUPS=1 (with SMX_EMU_SHUFFLE): the workgroups of a launch run in a random order as well — the hardware dispatches them
+    // in no promised order, and everything the library numbers by atomics (chunk ids, places in the output, node ids of route 0) comes out
+    // differently; the RESULTS must not. (No kernel of the library waits for another workgroup, so any order completes.)
+    static const bool shuffle_groups = getenv("SMX_EMU_SHUFFLE_GROUPS") != nullptr;
+    const uint64_t ngroups = (uint64_t)grid.x * grid.y * grid.z;
+    std::vector<uint32_t> perm;
+    if (shuffle_groups && c.rng && ngroups > 1 && ngroups < (1ull << 31)) {
+        perm.resize(ngroups);
+        for (uint64_t i = 0; i < ngroups; ++i) perm[i] = (uint32_t)i;
+        for (uint64_t i = ngroups - 1; i > 0; --i) {
+            c.rng ^= c.rng << 13;
+            c.rng ^= c.rng >> 7;
+            c.rng ^= c.rng << 17;
+            std::swap(perm[i], perm[c.rng % (i + 1)]);
+        }
+    }
+    for (uint64_t g = 0; g < ngroups; ++g) {
+        const uint64_t id = perm.empty() ? g : perm[g];
+        c.bid = dim3((unsigned)(id % grid.x), (unsigned)((id / grid.x) % grid.y), (unsigned)(id / ((uint64_t)grid.x * grid.y)));
+        run_block(body);
+    }
 }
 
 template <class T>
