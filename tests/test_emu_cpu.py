@@ -67,9 +67,10 @@ def test_gpu_tests_pass_on_the_emulated_library(emu_lib, path, expr):
 
 def test_results_do_not_depend_on_the_order_in_which_lanes_reach_an_atomic(emu_lib):
     """SMX_EMU_SHUFFLE: between two synchronisation points the threads of a workgroup take their turns in a fresh random order — the hardware
-    promises none. The sort leaves, the LDS hash sets and the multi-batch folds hand out places by atomics; the outputs must not notice."""
+    promises none — and so do the workgroups of a launch (SMX_EMU_SHUFFLE_GROUPS); fresh device memory and dynamic LDS hold garbage
+    (SMX_EMU_POISON). The sort leaves, the LDS hash sets and the multi-batch folds hand out places by atomics; the outputs must not notice."""
     for seed in ("11",):
-        r = _run(["tests/test_count_gpu.py", "-k", "test_multi_batch_runs_are_merged or (test_multilevel_and_oversized_bins and 55-B-30-opts1)"], SMX_EMU_SHUFFLE=seed)
+        r = _run(["tests/test_count_gpu.py", "-k", "test_multi_batch_runs_are_merged or (test_multilevel_and_oversized_bins and 55-B-30-opts1)"], SMX_EMU_SHUFFLE=seed, SMX_EMU_SHUFFLE_GROUPS="1", SMX_EMU_POISON="1")
         assert r.returncode == 0 and " passed" in r.stdout, "\n".join(r.stdout.splitlines()[-15:])
 
 
