@@ -1259,6 +1259,7 @@ int smx_graph_set_kpomers(smx_ctx *ctx, const void *d_kpomers, uint64_t n, const
     if (n && !d_kpomers) return SMX_INVALID_PARAMETER;
     HIPCHK(hipSetDevice(ctx->device));
     drop_kpo(ctx);
+    if (!ctx->g_nkpo_total) ctx->g_nkpo_total = ctx->g_nkpo;  // (a shard of the file is about to stand for it: smx_graph_info keeps reporting the whole count — smx_graph_set_coverage puts it back)
     ctx->g_kpoboff.assign(ctx->g_B + 1, 0);
     for (unsigned b = 0; b < ctx->g_B; ++b) ctx->g_kpoboff[b + 1] = ctx->g_kpoboff[b] + bucket_sizes[b];
     if (ctx->g_kpoboff[ctx->g_B] != n) return fail(ctx, SMX_INVALID_PARAMETER, "bucket sizes do not add up to the number of (k+1)-mers");
@@ -1276,6 +1277,17 @@ int smx_graph_set_coverage(smx_ctx *ctx, const uint32_t *raw_coverage, uint64_t 
                                           (unsigned long long)n_edges, (unsigned long long)ctx->g_ne);
     if (n_edges && !raw_coverage) return SMX_INVALID_PARAMETER;
     ctx->gh.ecov.assign(raw_coverage, raw_coverage + n_edges);
+    // The caller summed the edge coverages itself (over ranks, or over shards of the (k+1)-mer file installed one after the other): what the
+    // last smx_graph_fill_coverage left next to them — flanking coverage and the multiplicity histogram — saw one rank's reads against one
+    // shard only. They are dropped rather than served (smx_graph_copy_flanking / smx_graph_coverage_histogram then say so), and the
+    // (k+1)-mer count of the whole file comes back after a shard stood in for it.
+    ctx->gh.eflank_s.clear();
+    ctx->gh.eflank_e.clear();
+    ctx->g_cov_hist.clear();
+    if (ctx->g_nkpo_total) {
+        ctx->g_nkpo = ctx->g_nkpo_total;
+        ctx->g_nkpo_total = 0;
+    }
     return SMX_OK;
 }
 
@@ -1377,7 +1389,8 @@ int smx_graph_fill_coverage(smx_ctx *ctx) {
 int smx_graph_copy_flanking(const smx_ctx *ctx, uint32_t *flank_edge, uint32_t *flank_conjugate) {
     if (!ctx || !ctx->g_ready) return SMX_INVALID_PARAMETER;
     const size_t ne = ctx->g_ne;
-    if (ctx->gh.eflank_s.size() != ne || ctx->gh.eflank_e.size() != ne) return SMX_INVALID_PARAMETER;
+    if (ctx->gh.eflank_s.size() != ne || ctx->gh.eflank_e.size() != ne)
+        return fail(const_cast<smx_ctx *>(ctx), SMX_INVALID_PARAMETER, "no flanking coverage: smx_graph_fill_coverage has not run on this graph, or its coverage was set from outside (smx_graph_set_coverage)");
     if (ne && flank_edge) memcpy(flank_edge, ctx->gh.eflank_s.data(), ne * 4);
     if (ne && flank_conjugate) memcpy(flank_conjugate, ctx->gh.eflank_e.data(), ne * 4);
     return SMX_OK;

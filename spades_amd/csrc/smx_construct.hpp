@@ -73,6 +73,7 @@ void clear_graph(smx_ctx *ctx) {
     ctx->g_kmers = nullptr;
     ctx->g_mask = nullptr;
     ctx->g_nkpo = ctx->g_nkmers = 0;
+    ctx->g_nkpo_total = 0;
     ctx->g_ne = ctx->g_nuwords = ctx->g_nbases = ctx->g_npaths = ctx->g_nloops = 0;
     ctx->g_ready = false;
     ctx->g_host_valid = false;

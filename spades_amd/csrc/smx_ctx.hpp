@@ -89,6 +89,7 @@ struct smx_ctx {
         uint64_t nc = 0, nr = 0;
         std::vector<uint64_t> boff_c;      // its bucket offsets
         std::vector<void *> rseg;          // the reverse complements, sorted in a few bucket ranges of their own (one block each)
+        std::vector<std::pair<unsigned, unsigned>> rseg_range;  // ... the buckets [first, last) each of them holds
         std::vector<const void *> rb_ptr;  // per bucket: where its reverse-complement records start ...
         std::vector<uint64_t> rb_n;        // ... and how many there are
     } ts;
@@ -175,6 +176,7 @@ struct smx_ctx {
     bool g_dev_valid = false;   // the device arrays above describe the graph (false after a host-side edge sort until re-uploaded)
     uint64_t g_tip_kmers = 0, g_tips = 0;  // early tip clipper: k-mers isolated, tips removed
     uint64_t g_at_edges = 0, g_at_tip_kmers = 0;  // early A/T remover: length-1 edges marked, tip k-mers isolated
+    uint64_t g_nkpo_total = 0;  // g_nkpo of the whole (k+1)-mer file while a shard installed by smx_graph_set_kpomers stands in for it
     std::vector<uint64_t> g_cov_hist;  // [c] = canonical (k+1)-mers with multiplicity c (after smx_graph_fill_coverage)
     smxh::GraphHost gh;
 };

@@ -7,8 +7,8 @@
 // allocate under the page's own lock, so several threads can fill DIFFERENT pages of one file at once. FileSink therefore maps a tmpfs
 // output of known final size (ftruncate + mmap MAP_SHARED) and copies every block with a few threads; any other file system, a small
 // file, a descriptor without read access, or a tmpfs without the room (a store into a mapped page that cannot be allocated is a
-// SIGBUS, not an error code — so the room is checked first) keeps the pwrite path. SMX_WRITE_MMAP=0 / =1 forces the choice,
-// SMX_WRITE_THREADS sets the copy threads (default 8).
+// SIGBUS, not an error code — so the room is checked first) keeps the pwrite path. SMX_WRITE_MMAP=0 / =1 forces the choice, -1 decides by
+// the file system; SMX_WRITE_THREADS sets the copy threads (default 8). DEFAULT since round 5: pwrite (see begin()).
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -87,8 +87,11 @@ class FileSink {
     void begin(int fd, size_t file_size) {
         fd_ = fd;
         ok_ = true;
-        int want = -1;  // -1: decide by the file system
-        if (const char *e = getenv("SMX_WRITE_MMAP")) want = atoi(e) ? 1 : 0;
+        // Round 5: the mapping is opt-in. On the GPU box (2 x EPYC 9575F, 256 threads) the driver measured 11.2 s for 38.5 GB through the
+        // mapping with 8 threads against 6.3 s through one pwrite thread (BENCH_r04 vs the builder's run before the change): the 4.1–4.5 GB/s
+        // of the mapping had been measured in an 8-core sandbox. SMX_WRITE_MMAP=-1 restores "decide by the file system".
+        int want = 0;
+        if (const char *e = getenv("SMX_WRITE_MMAP")) want = atoi(e) < 0 ? -1 : atoi(e) ? 1 : 0;
         if (want == 0 || file_size == 0) return;
         struct statfs sf;
         if (fstatfs(fd, &sf) != 0) return;

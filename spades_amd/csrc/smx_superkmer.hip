@@ -19,8 +19,9 @@
 
 namespace smx {
 
-constexpr uint32_t SKM_NKEY_MIN = 1u << 24;           // partitions ("keys") the minimizers are hashed into: 2^24 .. 2^28, so that a
-constexpr uint32_t SKM_NKEY_MAX = 1u << 28;           // partition holds ~one genomic locus whatever the input size (run_prededupe)
+constexpr uint32_t SKM_NKEY_MIN = 1u << 16;           // partitions ("keys") the minimizers are hashed into: 2^16 .. 2^28 by the number of windows, so
+constexpr uint32_t SKM_NKEY_MAX = 1u << 28;           // that a partition holds ~one genomic locus whatever the input size (run_prededupe; the floor
+                                                      // was 2^24 until round 5: 0.5 GB of tables and 65 536 planning workgroups for any input)
 constexpr int SKM_WMAX = 128 - 16 + 1;                // windows per super-k-mer <= K - m + 1
 // Minimizer length: long enough that an m-mer is (nearly) unique in a genome — with m = 12 every 12-mer recurs ~6 times
 // per strand of a 50 Mbp genome, the few 12-mers that win the minimizer order collect thousands of instances each and

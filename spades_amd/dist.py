@@ -476,6 +476,7 @@ def _ragged(off: torch.Tensor, ln: torch.Tensor, dev):
     return off[seg] + (torch.arange(tot, device=dev) - start[seg])
 
 
+WALK_HOP_BITS = 24         # bits of a node's packed word that count the steps to its pointer (a chain of 2^24 k-mers or more is refused)
 WALK_CHUNK = 1 << 26       # local nodes per exchange of the doubling / of the chain nucleotides (bounds the temporaries: ~40 B per node)
 WALK_START_CHUNK = 1 << 22  # start de-edges per fetch of their chains
 
@@ -559,13 +560,14 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     #    (round 3 kept four int64 rows + two more int64 arrays per node: 110 B per owned k-mer; this is 18 B):
     #      word  F << 63 | T << 62 | id << 24 | hops      F: the end of the chain is known; T: this node IS the end (its successor is a
     #            open:      id = pointer, hops = steps to it    junction k-mer); id: 38 bits (2.7e11 nodes), hops: 24 bits (a chain of
-    #            tail (T):  id = the junction node behind it    more than 16.7 M k-mers is refused)
+    #            tail (T):  id = the junction node behind it    16.7 M k-mers or more is refused)
     #            finished:  id = the tail of its chain, hops = steps to the tail
     #      byte  bit 0 chain k-mer (non-junction), bit 1 its successor is a junction k-mer, bits 2-3 its outgoing nucleotide
     n2 = 2 * n_mine
-    FBIT, TBIT, IDM, HM = -(1 << 63), 1 << 62, (1 << 38) - 1, (1 << 24) - 1
+    HB = WALK_HOP_BITS  # (24; tests make it small: chains at the limit and loops whose hop counts saturate, on inputs of a few thousand reads)
+    FBIT, TBIT, IDM, HM = -(1 << 63), 1 << 62, (1 << (62 - HB)) - 1, (1 << HB) - 1
     if 2 * first[-1] > IDM:
-        raise ValueError(f"{first[-1]} k-mers: node ids beyond 38 bits")
+        raise ValueError(f"{first[-1]} k-mers: node ids beyond {62 - HB} bits")
     word = torch.zeros(n2, dtype=torch.int64, device=dev)
     flag = torch.zeros(n2, dtype=torch.uint8, device=dev)
     # (range by range: the requests of WALK_CHUNK oriented nodes at a time — a k-mer record out and a node id back per request; all at once
@@ -574,7 +576,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         a = min(c * WALK_CHUNK, n2)
         tags, node, junc = lookup(False, a, min(WALK_CHUNK, n2 - a))
         xl = tags >> 4
-        word[xl] = torch.where(junc, node << 24 | (FBIT | TBIT), node << 24 | 1)  # tails know their end node; the others: pointer, one step
+        word[xl] = torch.where(junc, node << HB | (FBIT | TBIT), node << HB | 1)  # tails know their end node; the others: pointer, one step
         flag[xl] = (1 | (junc.to(torch.int64) << 1) | ((tags & 3) << 2)).to(torch.uint8)
         del node, junc, tags, xl
     n_cand = int(engine.walk_counts()[1])
@@ -609,19 +611,24 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
             a, b = min(c * WALK_CHUNK, n2), min((c + 1) * WALK_CHUNK, n2)
             act = is_open(word[a:b], flag[a:b]).nonzero().squeeze(1) + a
             mine_w = word[act]
-            tg = (mine_w >> 24) & IDM
+            tg = (mine_w >> HB) & IDM
             wp = _remote_rows(tg, owner_of(tg), word.unsqueeze(0), base, rank, world, dev)[:, 0]
             p_tail = (wp & TBIT) != 0                 # the target ends its chain: it is the tail, no step is added
             p_fin = wp < 0
             hops = (mine_w & HM) + torch.where(p_tail, torch.zeros_like(wp), wp & HM)
-            too_long = too_long or (act.numel() > 0 and bool((hops > HM).any().item()))
-            nid = torch.where(p_tail, tg, (wp >> 24) & IDM)
-            word[act] = torch.where(p_fin, torch.full_like(wp, FBIT), torch.zeros_like(wp)) | (nid << 24) | (hops & HM)
+            # Only a node that FINISHES this round has a chain length to overflow. A node on a perfect loop never finishes and its hop count
+            # doubles every round (2^r after r rounds): once an ordinary chain needs ~24 rounds, every plasmid in the input tripped the
+            # check although no real chain was that long. Open nodes saturate at HM instead — sticky: a node that finishes with
+            # HM or more hops is refused, so a saturated count can never pass for a real one.
+            too_long = too_long or (act.numel() > 0 and bool((p_fin & (hops >= HM)).any().item()))
+            hops = hops.clamp_(max=HM)
+            nid = torch.where(p_tail, tg, (wp >> HB) & IDM)
+            word[act] = torch.where(p_fin, torch.full_like(wp, FBIT), torch.zeros_like(wp)) | (nid << HB) | (hops & HM)
             del act, mine_w, tg, wp, p_tail, p_fin, hops, nid
 
     def check_hops():
         if too_long:
-            raise RuntimeError("a chain of more than 2^24 k-mers: beyond the packed hop count of the distributed walks")
+            raise RuntimeError(f"a chain of 2^{HB} k-mers or more: beyond the packed hop count of the distributed walks")
     _guarded(dev, "chain lengths", check_hops)
     left = is_open(word, flag).nonzero().squeeze(1)
     loop_local = torch.unique(left >> 1) if left.numel() else torch.empty(0, dtype=torch.int64, device=dev)
@@ -651,7 +658,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         return slot, bool((hidx[slot] == local_nodes).all().item())
 
     def tail_of(nodes, w):  # the tail of the chain of finished nodes (w = their words)
-        return torch.where((w & TBIT) != 0, nodes, (w >> 24) & IDM)
+        return torch.where((w & TBIT) != 0, nodes, (w >> HB) & IDM)
 
     n_got_all, bad_head = 0, False
     for c in range(node_rounds):
@@ -666,7 +673,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         ws = word[xs]
         tl = ((ws & TBIT) != 0).nonzero().squeeze(1)
         head = torch.cat([head, head[tl]])
-        payload = torch.cat([payload, -(((ws[tl] >> 24) & IDM) + 1)])  # negative: "the end node of your chain is -(payload) - 1"
+        payload = torch.cat([payload, -(((ws[tl] >> HB) & IDM) + 1)])  # negative: "the end node of your chain is -(payload) - 1"
         del wr, steps_back, ws, tl
         order, counts = _by_owner(owner_of(head), world)
         msg = torch.stack([head[order], payload[order]], 1).reshape(-1).contiguous()

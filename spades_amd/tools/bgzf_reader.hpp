@@ -72,6 +72,7 @@ class BgzfReader {
         return true;
     }
     bool eof() const { return pos_ >= fsize_; }
+    uint64_t pos() const { return pos_; }  // file offset of the next block (a failed read() leaves it where it was)
     static constexpr size_t kError = ~(size_t)0;
 
     // Text of the next whole blocks, as many as fit into cap bytes (cap >= 64 KiB): returns the number of bytes, 0 at the end of the

@@ -470,6 +470,8 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
     // The work is done and every collective has completed; what follows only gives resources back. Should that not finish (a
     // communicator teardown that waits for ever has been seen on other stacks), the rank leaves with success after a grace period
     // that lets the other ranks finish theirs.
+    fflush(stdout);  // (_exit does not flush: the report lines must not be lost with a teardown that hangs when stdout is a pipe)
+    fflush(stderr);
     signal(SIGALRM, [](int) { _exit(0); });
     alarm(30);
     ncclCommDestroy(c.comm);

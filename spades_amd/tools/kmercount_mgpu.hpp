@@ -224,6 +224,8 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
         unlink(idfile.c_str());
     }
     // (the work is done: should giving the resources back not finish, the rank leaves with success after a grace period)
+    fflush(stdout);  // (_exit does not flush: the report lines must not be lost with a teardown that hangs when stdout is a pipe)
+    fflush(stderr);
     signal(SIGALRM, [](int) { _exit(0); });
     alarm(30);
     (void)hipFree(d_cnt);

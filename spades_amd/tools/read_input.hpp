@@ -286,7 +286,7 @@ inline int submit_file(smx_ctx *ctx, const std::string &path, std::mutex *mu = n
         // BGZF (blocked gzip: what BCL Convert / DRAGEN and bgzip write): the blocks are inflated in parallel (bgzf_reader.hpp); an ordinary
         // gzip stream has one thread's worth of work by construction
         BgzfReader bz;
-        const bool bgzf = gz && !getenv("SMX_NO_BGZF") && BgzfReader::is_bgzf(path) && bz.open(path, io_threads());
+        bool bgzf = gz && !getenv("SMX_NO_BGZF") && BgzfReader::is_bgzf(path) && bz.open(path, io_threads());
         for (;;) {
             while (!eof && have < chunk_bytes) {  // fill the chunk
                 size_t got;
@@ -294,8 +294,21 @@ inline int submit_file(smx_ctx *ctx, const std::string &path, std::mutex *mu = n
                     if (chunk_bytes - have < 65536) break;
                     got = bz.read(buf + have, chunk_bytes - have);
                     if (got == BgzfReader::kError) {
-                        rc = SMX_INVALID_INPUT_FORMAT;
-                        break;
+                        // Not BGZF from here on — an ordinary gzip member behind BGZF blocks (`cat a.bgzf.gz b.gz`), a header flag the block
+                        // parser does not take: zlib reads on from the boundary of the last good block (a failed call consumes nothing), one
+                        // stream like any other .gz; a damaged file fails there with the format error as before.
+                        gzclose(gzf);
+                        gzf = nullptr;
+                        const int fd2 = ::open(path.c_str(), O_RDONLY);
+                        if (fd2 >= 0 && lseek(fd2, (off_t)bz.pos(), SEEK_SET) == (off_t)bz.pos()) gzf = gzdopen(fd2, "rb");
+                        if (!gzf) {
+                            if (fd2 >= 0) ::close(fd2);
+                            rc = SMX_INVALID_INPUT_FORMAT;
+                            break;
+                        }
+                        gzbuffer(gzf, 1 << 20);
+                        bgzf = false;
+                        continue;
                     }
                 } else if (gz) {
                     const int g = gzread(gzf, buf + have, (unsigned)std::min<size_t>(chunk_bytes - have, (size_t)1 << 30));

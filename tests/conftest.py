@@ -14,6 +14,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The GPU tier runs with -x: one failure hides everything collected after it (round 4: a red 2 M-read test kept 84 cheap tests from running on the
+    driver's box). So the order is by cost — the files of small cases first, the tests at size (2 M – 20 M reads) after them, the process-spawning
+    RCCL hosts last — and stable otherwise."""
+    def weight(it):
+        f = os.path.basename(str(it.fspath))
+        if f == "test_zz_cli_rccl_gpu.py":
+            return 3
+        if f == "test_scale_gpu.py" or "larger_than_the_hbm_budget" in it.name:
+            return 2
+        if f == "test_integration_gpu.py" and "spades_core" in it.name:
+            return 1
+        return 0
+    items.sort(key=weight)  # (list.sort is stable)
+
+
 # Tests of code that was written after a round's GPU time was spent: no GPU run stands behind them yet, and the tier runs with -x.
 # SMX_NEXT=1 (or SMX_SCALE_NEXT=1, the older name) takes them in — the first thing to run in the next round; drop the mark once green.
 NEXT = bool(os.environ.get("SMX_NEXT") or os.environ.get("SMX_SCALE_NEXT"))

@@ -572,13 +572,15 @@ class OracleWalkEngine(OracleGraphEngine):
                     unitig_bases=0, words=nw)
 
 
-def _walk_worker(rank, world, port, k, threads, q, reads_file, nreads, coverage, limit):
+def _walk_worker(rank, world, port, k, threads, q, reads_file, nreads, coverage, limit, hop_bits=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from spades_amd import dist as smx_dist
     smx_dist.XCHG_LIMIT = limit
+    if hop_bits:
+        smx_dist.WALK_HOP_BITS = hop_bits
     if limit < 1000:  # several chunks per doubling round / per fetch of the chains, uneven over the ranks
         smx_dist.WALK_CHUNK, smx_dist.WALK_START_CHUNK = 97, 13
     reads = read_lines(reads_file)[:nreads]
@@ -618,3 +620,31 @@ def test_distributed_walks_gloo(k, world, reads_file, nreads, coverage, limit):
         kc = np.array([int(l.split("KC:i:")[1]) for l in got[0][8].splitlines() if l.startswith("S\t")], dtype=np.uint32)
         for g in got:
             assert (np.frombuffer(g[7], dtype=np.uint32) == kc).all()
+
+
+@pytest.mark.parametrize("reads_file", ["reads_mixed.txt"])
+def test_loop_nodes_do_not_overflow_the_hop_count(reads_file):
+    """a node on a perfect loop never finishes and its hop count doubles every round; with the hops packed into 24 bits every
+    rank raised 'a chain of more than 2^24 k-mers' as soon as an ordinary chain needed ~24 rounds next to any plasmid. Here the hop field is
+    made just wide enough for the longest real chain (WALK_HOP_BITS), so the loops' counts pass it in the last rounds: open nodes saturate, only a
+    node that FINISHES with a saturated count is refused, and the graph is the reference's."""
+    from oracle import oracle
+    k, world = 21, 2
+    reads = read_lines(reads_file)
+    g = oracle.build_graph(reads, k, 10, coverage=False)
+    assert g["n_loops"] > 0
+    npaths = len(g["unitigs"]) - g["n_loops"]
+    longest = max([len(u) - k + 1 for u in g["unitigs"][:npaths]] + [1])
+    hop_bits = max(2, int(np.ceil(np.log2(longest + 2))))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_walk_worker, args=(r, world, port, k, 1, q, reads_file, 10 ** 6, False, 1 << 27, hop_bits)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][6] == g["n_loops"] and got[0][5] == len(g["unitigs"])
+    assert (1 << got[0][1]) > (1 << hop_bits) - 1  # the loops' hop counts (2^rounds) did pass the field

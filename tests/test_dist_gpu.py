@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import needs_next, read_lines
+from conftest import read_lines
 
 pytestmark = pytest.mark.gpu
 
@@ -382,7 +382,6 @@ def test_distributed_walks_ranks_sharing_one_gpu(k, t, n_reads, genome, coverage
         assert all(u > 0 for u in info["unitigs_per_rank"])
 
 
-@needs_next
 @pytest.mark.parametrize("k,t,n_reads,genome,world", [(21, 1, 6000, 30000, 2), (55, 2, 8000, 40000, 3)])
 def test_gathered_construction_with_coverage_ranks_sharing_one_gpu(k, t, n_reads, genome, world, tmp_path):
     """the gathered route at world 2-3 with -c: the coverage pass runs shard by shard over the (k+1)-mer file (no rank installs more than one

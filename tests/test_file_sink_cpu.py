@@ -59,7 +59,7 @@ def test_the_file_holds_the_bytes_in_every_mode(lib, tmp_path, monkeypatch, wher
             data = rng.integers(0, 256, size=n, dtype=np.uint8)
             mode = _write(lib, path, head, data, block, rng)
             assert mode >= 0
-            if force == "0" or (force is None and n < (64 << 20)):
+            if force == "0" or force is None:  # (round 5: pwrite unless asked)
                 assert mode == 0
             if force == "1" and n + len(head) > 0:
                 assert mode == 1
@@ -74,7 +74,7 @@ def test_the_file_holds_the_bytes_in_every_mode(lib, tmp_path, monkeypatch, wher
 def test_a_large_tmpfs_output_is_mapped_by_itself_and_a_write_only_descriptor_falls_back(lib, monkeypatch):
     if not (_is_tmpfs(SHM) and os.access(SHM, os.W_OK)):
         pytest.skip("/dev/shm is not a tmpfs here")
-    monkeypatch.delenv("SMX_WRITE_MMAP", raising=False)
+    monkeypatch.setenv("SMX_WRITE_MMAP", "-1")  # "decide by the file system" (round 5: opt-in; with nothing set every output goes through pwrite)
     rng = np.random.default_rng(4)
     n = (64 << 20) + 12345
     data = rng.integers(0, 256, size=n, dtype=np.uint8)

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_manifest, needs_next, read_lines
+from conftest import GOLDEN, load_manifest, read_lines
 
 pytestmark = pytest.mark.gpu
 
@@ -358,7 +358,6 @@ def _circ_reads(seqs, L, step):
     return reads
 
 
-@needs_next
 @pytest.mark.parametrize("k,route", [(21, {}), (33, {}), (55, {}), (77, {}), (21, {"prededupe": 1, "ext_route": 1, "pm_route": 0}),
                                      (21, {"prededupe": 1, "pm_route": 1}), (55, {"prededupe": 1, "pm_route": 1})])
 def test_perfect_loops_on_the_device_equal_the_reference(k, route, tmp_path):
@@ -380,3 +379,35 @@ def test_perfect_loops_on_the_device_equal_the_reference(k, route, tmp_path):
         assert r["info"]["n_loops"] == ref["n_loops"] and r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"], dev
         got[dev] = r["gfa"]
     assert got[0] == got[1]
+
+
+def test_coverage_set_from_outside_drops_the_rank_local_flanking_and_histogram():
+    """a sharded coverage pass (dist.py, tools/gbuilder_mgpu.hpp) fills coverage shard by shard and installs the SUM with
+    smx_graph_set_coverage; the flanking arrays and the multiplicity histogram of the last smx_graph_fill_coverage then describe one rank's
+    reads against one shard. They must not be served as if they were the graph's: the accessors refuse / come back empty, the raw coverage is
+    the installed one, and the (k+1)-mer count is the whole file's again after a shard stood in for it."""
+    import ctypes as C
+    from spades_amd.gbuilder import GraphBuilder
+    reads = _synth(11, 3000, 600, 120)
+    gb = GraphBuilder(21, 1)
+    gb.push_back_reads(reads)
+    gb.build()
+    gb.fill_coverage()
+    cov = gb.raw_coverage()
+    fl = gb.flanking_coverage()
+    assert len(fl[0]) == len(cov) and cov.sum() > 0
+    n_kpo = gb.info()["n_kpomers"]
+    lib, h = gb.ctx.lib, gb.ctx._h
+    # an empty shard of the (k+1)-mer file stands in for the file (what a rank sees between two owners' shards)
+    zeros = (C.c_uint64 * (10 * 1))()
+    assert lib.smx_graph_set_kpomers(h, None, 0, zeros) == 0
+    twice = (cov.astype(np.uint64) * 2).astype(np.uint32)
+    assert lib.smx_graph_set_coverage(h, twice.ctypes.data_as(C.POINTER(C.c_uint32)), len(twice)) == 0
+    assert (gb.raw_coverage() == twice).all()
+    with pytest.raises(Exception):
+        gb.flanking_coverage()
+    n = C.c_uint64(99)
+    assert lib.smx_graph_coverage_histogram(h, None, 0, C.byref(n)) == 0 and n.value == 0
+    info = (C.c_uint64 * 8)()
+    assert lib.smx_graph_info(h, info) == 0 and int(info[0]) == n_kpo
+    gb.ctx.close()

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_manifest, needs_next, read_lines
+from conftest import GOLDEN, load_manifest, read_lines
 from test_ext_route_gpu import _eligible, _same_kmers, _synth
 
 pytestmark = pytest.mark.gpu
@@ -93,11 +93,10 @@ def test_vs_oracle_seeded(k, tmp_path):
         assert _same_kmers(r, old) and r["info"] == old["info"]
 
 
-@needs_next
 @pytest.mark.parametrize("log2", [12, 13, 16])
 def test_partition_count_does_not_matter(log2, tmp_path):
-    """option skm_nkey_log2: the super-k-mer stage starts from 2^12 … 2^16 minimizer partitions instead of 2^24 — on these 1 500 reads that is
-    the ≈50–800 windows per partition of a production run (2^24 leaves a partition a window or none): full chunks, folded slots, cut
+    """option skm_nkey_log2: the super-k-mer stage starts from 2^12 … 2^16 minimizer partitions (2^16 is the default floor since round 5; 2^24 until then) — on
+    these 1 500 reads 2^12 is the ≈50–800 windows per partition of a production run (2^16 leaves a partition a few windows): full chunks, folded slots, cut
     partitions and the sorted tail of the partition-major route all see work. Same graph as the oracle's, on both super-k-mer routes."""
     from oracle import oracle
     for k, threads in ((21, 1), (55, 2)):

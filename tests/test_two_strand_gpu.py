@@ -71,3 +71,35 @@ def test_goldens_in_two_strands(case):
     rec, sizes, _, _, _ = _count_ts(read_lines(case["reads"]), case["K"], case["num_buckets"], 2)
     assert list(map(int, sizes)) == case["bucket_sizes"]
     assert hashlib.md5(rec.tobytes()).hexdigest() == case["md5"]
+
+
+@pytest.mark.parametrize("K,nb", [(55, 16), (33, 5), (96, 16)])
+@pytest.mark.parametrize("ts", [-1, 0, 1, 2])
+@pytest.mark.parametrize("spill", [-1, 1])
+@pytest.mark.parametrize("batch", [40000, 7000])
+def test_two_strand_inside_position_batches(K, nb, ts, spill, batch):
+    """a both-strands batch that comes back as a two-strand view (no room for the merged array, or two_strand = 2) has no single array
+    for the batch loop of count_reads to fold or spill — round 4 took the null pointer for a run (error 70 on the MI355X under a budget, on the
+    stand-in every batch but the last dropped with rc = 0). Its strands are runs of their own now. Every way into and out of the loop: the view left
+    unmerged (2), merged when there is room (1, -1), never made (0) × folded on the device or spilled × few and many batches."""
+    from oracle import oracle
+    from spades_amd import KMerDiskCounter, ReadKMerSplitter
+    from spades_amd.kmercount import Context
+    reads = _synth(900 + K, 8000, 1200, 150) + ["ACGT" * 40] * 5 + ["AT" * 75] * 5
+    ref, rs = oracle.count(reads, K, "A", nb)
+    ctx = Context()
+    ctx.set_option("prededupe", 1)
+    ctx.set_option("skm_nkey_log2", 12)
+    ctx.set_option("two_strand", ts)
+    ctx.set_option("spill", spill)
+    ctx.set_option("batch_records", batch)
+    sp = ReadKMerSplitter(K, "A", ctx)
+    sp.push_back_reads(reads)
+    st = KMerDiskCounter(None, sp).Count(nb)
+    rec, sizes = st.records(), st.bucket_sizes()
+    assert (sizes == rs).all(), (int(sizes.sum()), int(rs.sum()))
+    assert rec.shape == ref.shape and (rec == ref).all()
+    off = np.concatenate([[0], np.cumsum(rs.astype(np.int64))])
+    for b in (0, nb // 2, nb - 1):
+        assert (st.bucket(b) == ref[off[b]:off[b + 1]]).all()
+    ctx.close()
