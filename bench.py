@@ -460,12 +460,13 @@ def main():
 
     last = {}
 
-    def step():
+    def step(upload=False):
         if sharded:
             last["st"] = smx_dist.sharded_count(engine, K1, nb, rank, world, dev)
             return
-        gb.reads.clear()
-        gb.reads.push_back_packed(hw[:-8], hs, hl)  # H2D inside the step
+        if upload:
+            gb.reads.clear()
+            gb.reads.push_back_packed(hw[:-8], hs, hl)  # H2D inside the step
         if args.count_only:
             last["st"] = KMerDiskCounter(None, gb.reads).Count(nb)
         else:
@@ -477,35 +478,51 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # setup (not a step of the measurement): the library's device arena maps its physical memory the first time an address is used
-    # (~17 ms per GiB, once per context): one untimed pass brings it to its steady-state footprint
-    step()
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
+    def timed(upload):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(upload)
+        sync()
+        return time.perf_counter() - t0
+
+    # Two timed regions at N = 1 (task statement, measurement rules: `value` is the whole-job rate with the inputs ALREADY RESIDENT IN HBM
+    # when the timed region starts; the PCIe-inclusive rate is reported beside it and is never `value`). Rounds 1-4 had the H2D copy
+    # inside the one timed region: that figure is still measured, first, as `pcie_inclusive` — same steps, same warm-up.
+    #  (a) PCIe-inclusive: every step uploads the batch from page-locked host memory (asynchronously, in pieces that the first scan
+    #      follows) and builds;
+    #  (b) resident: the batch is uploaded once, outside the timed region; every step counts + constructs from the resident reads.
+    # Setup (not a step of either measurement): the library's device arena maps its physical memory the first time an address is used
+    # (~17 ms per GiB, once per context): one untimed pass brings it to its steady-state footprint.
+    pcie = None
     if sharded:
+        step()
+        for _ in range(args.warmup):
+            step()
+        dt = timed(False)
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    else:
+        ctx.set_option("async_upload", 0 if args.sync_upload else 1)
+        step(True)
+        for _ in range(args.warmup):
+            step(True)
+        dt_up = timed(True)
+        pcie = {"value": round(n_reads / (dt_up / args.steps) / 1e6, 3), "unit": "M reads/s", "ms_per_step": round(dt_up / args.steps * 1e3, 3),
+                "what": "the same step with the H2D copy of the batch inside it (37.5 B/read of 2-bit stream + 12 B of (start, len) from page-locked host "
+                        "memory, asynchronous, the first scan follows the pieces): the figure rounds 1-4 reported as `value`"}
+        ctx.set_option("async_upload", 0)
+        step(True)  # the batch becomes resident (synchronous upload: done when the call returns)
+        for _ in range(max(args.warmup, 1)):  # (the first step without an upload places its buffers differently: where the arena maps new memory, a stage's interval holds it)
+            step(False)
+        dt = timed(False)
     ms_per_step = dt / args.steps * 1e3
     total_reads = n_reads * world
     value = total_reads / (dt / args.steps) / 1e6
 
-    # ---- stage times (HIP events on the library's stream) and roofline figures ----
-    # The timed steps upload asynchronously: their first stages (window marks, first scan of the reads) wait for PCIe pieces, so their
-    # event intervals hold transfer time. The kernel durations the rooflines are computed from come from ONE more step, untimed, with
-    # the upload finished before the first kernel.
-    if not sharded and not args.sync_upload:
-        ctx.set_option("async_upload", 0)
-        for _ in range(2):  # (the first synchronous step places its buffers differently: where the arena maps new memory, a stage's interval holds it)
-            step()
-            sync()
-        ctx.set_option("async_upload", 1)
+    # ---- stage times (HIP events on the library's stream) and roofline figures: those of the LAST timed step (inputs
+    # resident: no stage waits for a PCIe piece) ----
     stages = {}
     for name, ms in ctx.timings():  # a stage name repeats when the pipeline runs more than once
         stages[name] = stages.get(name, 0.0) + ms
@@ -600,7 +617,7 @@ def main():
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": (f"BASELINE config 3: synthetic {n_reads / 1e6:g} M PE150 reads (genome {args.genome / 1e6:g} Mbp " +
                                 ("in 1000 genomes with log-normal abundances, 30% repeats, 1% low complexity" if args.skew else "iid") + ", 1% subst., "
-                                f"{args.n_rate * 100:g}% N), k={k}: upload from page-locked host memory + " +
+                                f"{args.n_rate * 100:g}% N), k={k}, packed reads resident in HBM: " +
                                 (f"count of the canonical {k}-mers together with their extension masks (= the canonical {K1}-mer set: every "
                                  f"{K1}-mer of the reads is one extension bit at its prefix and one at its suffix {k}-mer) " if ext_route else
                                  f"count of the canonical {K1}-mers ") +
@@ -613,10 +630,13 @@ def main():
                    "route": (("k-mers + masks from one count of the reads, never sorted: nodes numbered by minimizer partition" if pm_route else
                               "k-mers + masks from one count of the reads, sorted into the k-mer file") if ext_route else
                              "(k+1)-mer file, then k-mer file + mask fill") if info is not None else "count only",
-                   "h2d_in_timed_region": not sharded, "construct_in_metric": (not sharded and not args.count_only),
+                   "inputs": "resident in HBM when the timed region starts (uploaded once before it); the PCIe-inclusive rate of the same step is `pcie_inclusive`",
+                   "h2d_in_timed_region": False, "construct_in_metric": (not sharded and not args.count_only),
                    "parallelism": "1 GPU" if not sharded else f"{world} GPU(s), bucket-range owners, one RCCL all-to-all (RCCL world size {world})"},
         "roofline": roof_count,
     }
+    if pcie is not None:
+        out["pcie_inclusive"] = pcie
     if info is not None:
         D0, ne, nbases = info["n_kmers"], info["n_unitigs"], info["unitig_bases"]
         # algorithmic bytes of the construction: k-mer file = read the (k+1)-mers, write + read the 2 derived k-mers each,
@@ -641,7 +661,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["construct"]["route_stats"] = str(e)
         out["step_breakdown_ms"] = {"count_kernels": round(count_ms, 1), "construct_kernels": round(construct_ms, 1),
-                                    "host_and_upload": round(ms_per_step - count_ms - construct_ms, 1)}
+                                    "host": round(ms_per_step - count_ms - construct_ms, 1)}
         # The dominant single kernel of the step = the longest stage that is ONE kernel (HIP events on the library stream), priced on the
         # bytes that kernel must move (stated per kernel below); its measured HBM traffic is quoted from the recorded PMC table when
         # that table belongs to these sources.

@@ -2,7 +2,7 @@
 """one-screen summary of a bench.py JSON line"""
 import json, sys
 d = json.load(open(sys.argv[1]))
-print("value", d["value"], "ms/step", d["ms_per_step"], d.get("step_breakdown_ms"))
+print("value", d["value"], "ms/step", d["ms_per_step"], d.get("step_breakdown_ms"), "pcie_inclusive", (d.get("pcie_inclusive") or {}).get("value"), (d.get("pcie_inclusive") or {}).get("ms_per_step"))
 st = d["roofline"]["stages_ms"]
 con = ("rank_dir", "fill_masks", "candidates", "walk_len", "keep", "walk_write", "succ")
 agg = {}
