@@ -111,7 +111,9 @@ struct smx_ctx {
     int64_t opt_leaf_cap = 0, opt_leaf_target = 0, opt_s1 = -1, opt_s2 = -1, opt_batch_records = 0;
     int64_t opt_sort_edges = 0, opt_keep_loops = 1;
     int64_t opt_skm_nkey_log2 = 0;  // > 0: the super-k-mer stage starts from 2^this minimizer partitions instead of 2^24 (12..28; it still doubles with the input)
-    int64_t opt_device_loops = 0;  // 1: perfect loops by the kernels of smx_loops.hip (odd k); 0: on the host (smx_loops_host.hpp) — the default until a GPU run has compared them
+    int64_t opt_device_loops = 1;  // 1: perfect loops by the kernels of smx_loops.hip (odd k; even k always on the host); 0: on the host (smx_loops_host.hpp).
+                                   // Default 1 since round 5: on the MI355X the 9 937-loop golden of the real spades-gbuilder (6 M reads from 10 000 plasmids)
+                                   // is written byte for byte on all three routes, the six plasmid tests take 10 s against 63 s through the host collector
     int64_t opt_flank_range = 50;     // FlankingCoverage averaging range ((k+1)-mers at either end of an edge)
     int64_t opt_submit_contigs = 0;   // reads submitted while this is 1 are contigs: construction yes, coverage no
     int64_t opt_early_at = 0;         // 1: the early A/T remover of the RNA pipelines before the tip clipper

@@ -70,12 +70,20 @@ __device__ __forceinline__ Rec<NW> rec_rc(const Rec<NW> &x, unsigned K) {
 // x[i] != 3-x[K-1-i]; the reference returns x[i] < 3-x[K-1-i]. The highest nucleotide index where
 // RC(x) and x differ is j=K-1-i, where RC(x)[j]=3-x[i] and x[j]=x[K-1-i]; so INT(RC(x)) > INT(x)
 // (word NW-1 most significant) <=> 3-x[i] > x[K-1-i] <=> x[i] < 3-x[K-1-i]. Palindromes: equal -> true.
+// (As code: rc >= x as NW-word integers <=> rc - x leaves no borrow — ONE subtract-with-borrow chain, 2 NW full-rate VALU instructions
+// and no branch. The word-by-word form "first difference decides" compiled to exec-mask juggling: 14 instructions per call at NW = 2 in
+// the dedupe kernel's insert loop, which is VALU-issue bound, profiles/r04/dedupe2_sq_counters_20M.txt.)
 template <int NW>
 __device__ __forceinline__ bool rc_ge(const Rec<NW> &rc, const Rec<NW> &x) {
+    bool borrow = false;
 #pragma unroll
-    for (int i = NW - 1; i >= 0; --i)
-        if (rc.w[i] != x.w[i]) return rc.w[i] > x.w[i];
-    return true;
+    for (int i = 0; i < NW; ++i) {
+        uint64_t d;
+        const bool b1 = __builtin_sub_overflow(rc.w[i], x.w[i], &d);
+        const bool b2 = __builtin_sub_overflow(d, (uint64_t)borrow, &d);
+        borrow = b1 | b2;
+    }
+    return !borrow;
 }
 
 template <int NW>

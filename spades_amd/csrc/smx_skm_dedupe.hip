@@ -461,7 +461,9 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
                             // InOutMask bits in the canonical frame: out bits 0-3 by next base, in bits 4-7 by previous base; on the other
                             // strand the roles swap and the bases are complemented (bit b -> bit 3 - b: a 4-bit reversal)
                             const uint32_t Rset = j0 + j + 1 < c ? 1u << b : (nb >> 4);
-                            ebs[u] = fwd ? (Rset | (Lset << 4)) : ((__brev(Lset) >> 28) | ((__brev(Rset) >> 28) << 4));
+                            // (the other strand's byte is the 8-bit reversal of this strand's: one v_bfrev + shift + select, no branch)
+                            const uint32_t e8 = Rset | (Lset << 4);
+                            ebs[u] = fwd ? e8 : (__brev(e8) >> 24);
                             Lset = 1u << ((uint32_t)x.w[0] & 3u);
                         }
                         x = rec_roll_fw<NW>(x, K, (uint64_t)b);

@@ -356,12 +356,12 @@ __global__ void __launch_bounds__(BLK, SMX_SCAN_WPE) k_skm_scan(SkmArgs a) {
             if (c > w) c = w;
             const uint32_t key = skm_part(keys[e & 0xFFFu], a.pshift);
             uint64_t *dst = nullptr;
+            unsigned long long rank = 0;  // PHASE 0: what the counting atomic returned (raw: masked where it is used, after the slot words)
             if constexpr (PHASE == 0) {
                 // One atomic per super-k-mer — unless the neighbouring lanes hold the same partition: every window of a homopolymer or
                 // short-period run is a super-k-mer of its own, millions of them share a handful of minimizers, and ONE address takes
                 // ~88 atomics per microsecond (measured: +150 ms at 1 % low-complexity sequence). Up to three peels: the lanes that hold
                 // the key of the first remaining lane add up in one atomic and number themselves.
-                unsigned long long rank = 0;
                 const uint32_t nsg = (c + SkmSeg<NW>::value - 1) / SkmSeg<NW>::value;  // segments of this super-k-mer (<= 29: 5 bits)
                 {
                     unsigned long long todo = __ballot(1);
@@ -385,12 +385,12 @@ __global__ void __launch_bounds__(BLK, SMX_SCAN_WPE) k_skm_scan(SkmArgs a) {
                         }
                         todo &= ~same;
                     }
-                    if (mine) rank = atomicAdd(&a.cnt[key], 1ull | ((unsigned long long)nsg << SKM_CNT_BITS)) & SKM_CNT_MASK;
+                    // (the plain case: what this atomic returns is needed for ONE thing, the (partition, rank) word of the staged entry — that
+                    // store comes AFTER the slot words have been put together below, so the ~150 instructions of that work run while the
+                    // atomic is on its way; SQ counters of round 4: the waves of this kernel wait 65 % of their cycles)
+                    if (mine) rank = atomicAdd(&a.cnt[key], 1ull | ((unsigned long long)nsg << SKM_CNT_BITS));
                 }
-                if (stage0 != ~0ull) {
-                    dst = a.stage_slots + (stage0 + si) * SW;
-                    a.stage_part[stage0 + si] = (unsigned long long)key | (rank << 32);
-                }
+                if (stage0 != ~0ull) dst = a.stage_slots + (stage0 + si) * SW;
             } else {
                 dst = a.slots + atomicAdd(&a.cursor[key], 1ull) * SW;
             }
@@ -425,6 +425,7 @@ __global__ void __launch_bounds__(BLK, SMX_SCAN_WPE) k_skm_scan(SkmArgs a) {
                     const uint32_t mr = (uint32_t)(rev2_64((uint64_t)mv) >> (64 - 2 * m)) ^ mmask;
                     flip = mr < mv;
                 }
+                uint64_t vals[SW];
                 if (!flip) {
 #pragma unroll
                     for (int i = 0; i < SW; ++i) {
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(BLK, SMX_SCAN_WPE) k_skm_scan(SkmArgs a) {
                         if (nbits <= 64u * i) v = 0;
                         else if (nbits < 64u * (i + 1)) v &= (1ull << (nbits - 64u * i)) - 1;
                         if (i == SW - 1) v |= ((uint64_t)c << 56) | ((uint64_t)nb << 48);
-                        dst[i] = v;
+                        vals[i] = v;
                     }
                 } else {
                     // reverse complement of the run: word i holds the complements of the bases pl + len - 32 i - 1 down to pl + len - 32 i - 32
@@ -452,9 +453,12 @@ __global__ void __launch_bounds__(BLK, SMX_SCAN_WPE) k_skm_scan(SkmArgs a) {
                         if (nbits <= 64u * i) v = 0;
                         else if (nbits < 64u * (i + 1)) v &= (1ull << (nbits - 64u * i)) - 1;
                         if (i == SW - 1) v |= ((uint64_t)c << 56) | ((uint64_t)nb << 48);
-                        dst[i] = v;
+                        vals[i] = v;
                     }
                 }
+                if constexpr (PHASE == 0) a.stage_part[stage0 + si] = (unsigned long long)key | ((rank & SKM_CNT_MASK) << 32);  // (dst != nullptr in phase 0 <=> the tile has staging entries)
+#pragma unroll
+                for (int i = 0; i < SW; ++i) dst[i] = vals[i];
             }
         }
         __syncthreads();

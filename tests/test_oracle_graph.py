@@ -113,12 +113,12 @@ def test_oracle_spades_core_edge_order_matches_reference(case):
 def test_oracle_perfect_loops_match_spades_gbuilder_on_plasmids():
     """200 circular 5 kb genomes, error-free reads (tests/synth.py: synth_codes_plasmids): the real spades-gbuilder collects 200 perfect
     loops (debruijn_graph_constructor.hpp:252-293, 359-397: cycle minimum, self-conjugate split) and the C restatement writes the
-    same GFA, ± -c. Golden: tests/golden/next_scale_200k_g1000k_s83_plasmids.json (make_golden_scale.py ... gfaplasmids)."""
+    same GFA, ± -c. Golden: tests/golden/scale_200k_g1000k_s83_plasmids.json (make_golden_scale.py ... gfaplasmids)."""
     import hashlib
     import json
     import numpy as np
     import synth
-    g = json.load(open(os.path.join(GOLDEN, "next_scale_200k_g1000k_s83_plasmids.json")))
+    g = json.load(open(os.path.join(GOLDEN, "scale_200k_g1000k_s83_plasmids.json")))
     codes = synth.synth_codes_plasmids(g["seed"], g["genome_len"], g["n_reads"], g["err"], g["n_rate"])
     assert hashlib.md5(codes.tobytes()).hexdigest() == g["codes_md5"]
     lut = np.frombuffer(b"ACGTN", dtype=np.uint8)

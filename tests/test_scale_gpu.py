@@ -23,8 +23,9 @@ CASES = sorted(glob.glob(os.path.join(HERE, "golden", "scale_*.json")))
 # with the rest; SMX_SCALE_SMALL=1 leaves it out.)
 if os.environ.get("SMX_SCALE_SMALL"):
     CASES = [c for c in CASES if json.load(open(c))["n_reads"] <= 10_000_000]
-# Goldens of the real tools that no GPU run has been compared with yet (made when no GPU time was left: next_scale_*.json, e.g. 10 000
-# circular plasmids = 10 000 perfect loops) join with SMX_NEXT=1 (conftest.NEXT; SMX_SCALE_NEXT=1 is the older name); rename them to scale_* once they are green.
+# Goldens of the real tools that no GPU run has been compared with yet (next_scale_*.json, none at the moment) join with SMX_NEXT=1
+# (conftest.NEXT); they are renamed to scale_* once green — round 5 did that for k = 77 at 20 M reads and the two plasmid sets (200 and
+# 9 937 perfect loops), green on the MI355X on all three routes (profiles/r05/gpu_tests_first_call.log).
 if NEXT:
     CASES += sorted(glob.glob(os.path.join(HERE, "golden", "next_scale_*.json")))
 
@@ -75,6 +76,7 @@ def test_gfa_equals_spades_gbuilder(case, tmp_path, route):
     if route == "kpo":
         ctx.set_option("derive_batches", 3)        # the (k+1)-mer file first, the k-mer file in bucket ranges (round-2 config-3 path)
         ctx.set_option("keep_kpo", 0)              # ... and the coverage pass recounts the (k+1)-mers
+        ctx.set_option("device_loops", 0)          # ... and the perfect loops (plasmid goldens) are collected on the host: the default is the device (round 5)
     gb = GraphBuilder(g["k"], g["effective_threads"], ctx)
     gb.reads.push_back_ascii(bases, off)
     info = gb.build()
