@@ -414,6 +414,9 @@ def main():
         if dist.get_world_size() != world:
             raise SystemExit(f"RCCL reports world size {dist.get_world_size()}, expected {world}")
 
+    if os.environ.get("SMX_BENCH_LIB"):  # A/B runs of kernel variants on one box: another build of the library (tools/ab/*.so), same host code
+        from spades_amd import _lib as _smx_lib
+        _smx_lib.LIB_PATH = os.path.abspath(os.environ["SMX_BENCH_LIB"])
     from spades_amd import KMerDiskCounter, ReadKMerSplitter
     from spades_amd.kmercount import Context
     from spades_amd.gbuilder import GraphBuilder

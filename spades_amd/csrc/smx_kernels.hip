@@ -678,6 +678,8 @@ __device__ __forceinline__ uint32_t rec_hash32(const Rec<NW> &x) {
         const uint32_t lo = (uint32_t)x.w[w], hi = (uint32_t)(x.w[w] >> 32);
         h ^= __builtin_rotateleft32(lo, (7 * w) & 31) ^ __builtin_rotateleft32(hi, (7 * w + 13) & 31);
     }
+    // (round 5: ONE multiply instead of fmix32's two — h *= 0x9E3779B1; h ^= h >> 15 — made the dedupe kernel slower, 85.0 -> 88.4 ms at
+    // config 3: longer probe sequences cost more than the multiply saves; profiles/r05/kernel_variants_ab_and_phase_ticks.log)
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
     h ^= h >> 13;

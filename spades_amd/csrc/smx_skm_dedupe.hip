@@ -515,29 +515,44 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
         uint32_t wcount;
         const uint32_t pre = block_excl_scan_lds<uint32_t>(__popc(occ), scr, &wcount);
         grp[t] = pre | (occ << 16);
-        if (t == 0) {
+        // The chunk's place in the output: ONE counter serves every chunk of the launch (~88 atomics per microsecond on one address: at 4.6 M
+        // chunks the answer takes ~3 us to come back; round-5 phase ticks: "occupancy + allocation" 17 % of a chunk's time, every wave of the
+        // workgroup waiting for thread 0 at the next barrier). Nothing before the copy-out needs the answer — the winners are staged in LDS
+        // by rank first — so thread 0 ISSUES the atomic at the top of the first staging round (issue_place) and publishes what it returned
+        // (publish_place) behind that round's loop, just before the barrier in front of the copy-out: the staging runs while the atomic is
+        // on its way. (Between the two there is no other vector-memory instruction — not even a register reload from scratch: any of those
+        // would make the wave wait for the atomic first, vmcnt counts in order.)
+        unsigned long long place_raw = 0;
+        auto issue_place = [&]() {  // thread 0, once per chunk with winners
+            // (The counter's address goes through an empty asm statement: a pointer the compiler knows to be the same in every lane makes its
+            // atomic optimizer wrap the atomic in a wave reduction + v_readfirstlane of the result, i.e. an s_waitcnt right behind it — the
+            // very wait this is about. A "divergent" pointer is left alone, and the wait lands at the first use, in publish_place.)
+            unsigned long long *ctr = dirty ? dirty_count : out_count;
+            asm volatile("" : "+v"(ctr));
+            place_raw = atomicAdd(ctr, PM && !dirty ? ((unsigned long long)wcount | (1ull << PM_BASE_BITS)) : (unsigned long long)wcount);
+        };
+        auto publish_place = [&]() {  // thread 0, once per chunk
+            asm volatile("" : "+v"(place_raw));  // (the value is READ here and not before: none of what follows may be hoisted in front of the staging loop)
             s_skip = 0;
             if (!wcount) s_gbase = 0;
             else if (!dirty) {
                 if constexpr (PM) {
-                    const unsigned long long v = atomicAdd(out_count, (unsigned long long)wcount | (1ull << PM_BASE_BITS));
-                    s_gbase = v & PM_BASE_MASK;
-                    s_cid = (uint32_t)(v >> PM_BASE_BITS);
+                    s_gbase = place_raw & PM_BASE_MASK;
+                    s_cid = (uint32_t)(place_raw >> PM_BASE_BITS);
                     s_skip = s_gbase + wcount > clean_cap;
                     if (s_cid >= pm.max_chunks) {
                         s_skip = 1;
                         *pm.overflow = 1;
                     }
                 } else {
-                    s_gbase = atomicAdd(out_count, (unsigned long long)wcount);
+                    s_gbase = place_raw;
                     s_skip = s_gbase + wcount > clean_cap;
                 }
             } else {
-                const unsigned long long d = atomicAdd(dirty_count, (unsigned long long)wcount);
-                s_skip = d + wcount > dirty_cap;
-                s_gbase = s_skip ? 0 : out_cap - d - wcount;
+                s_skip = place_raw + wcount > dirty_cap;
+                s_gbase = s_skip ? 0 : out_cap - place_raw - wcount;
             }
-        }
+        };
         // The winners' bytes leave the table, and the first k-mer of the segment is taken from the slot once more, before the staging area
         // overwrites both: the winners are rolled out of it again below (holding the segment's canonical k-mers in registers across the
         // barriers instead cost 60 VGPRs, i.e. half the waves).
@@ -566,10 +581,8 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
                 }
             }
         }
-        lds_barrier();  // (thread 0 has its atomic's result in s_gbase by now)
+        lds_barrier();  // (grp[] is complete: rank_of below)
         SKM_T(2)
-        const unsigned long long gb = s_gbase;
-        const bool skip = s_skip != 0;
         auto rank_of = [&](uint32_t h) -> uint32_t {
             const uint32_t g = grp[h >> 4];
             return (g & 0xFFFFu) + __popc((g >> 16) & ((1u << (h & 15u)) - 1u));
@@ -582,7 +595,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
         bool links = false;
         uint32_t lnk_bytes = 0;
         if constexpr (PM) {
-            links = !dirty && !skip && wcount && (size_t)wcount * 8 <= (size_t)stage_bytes;
+            links = !dirty && wcount && (size_t)wcount * 8 <= (size_t)stage_bytes;  // (a chunk that does not fit the output any more — skip, known at the copy-out — stages its links for nothing)
             lnk_bytes = links ? ((wcount * 4 + 15u) & ~15u) : 0u;
         }
         uint16_t *lnk = (uint16_t *)lds64;
@@ -590,14 +603,6 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
         const uint32_t R = ((stage_bytes - lnk_bytes) / (uint32_t)(sizeof(Rec<NW>) + 1)) & ~15u;  // records per output round
         uint8_t *stm = (uint8_t *)(stg + R);
         if constexpr (PM) {
-            if (!dirty && !skip && wcount) {
-                const uint32_t cid = s_cid;
-                pm.meta[(size_t)cid * NT + t] = pre | (occ << 16);
-                if (t == 0) pm.cinfo[cid] = gb | ((unsigned long long)wcount << PM_BASE_BITS);
-                const uint32_t nkeys = (uint32_t)(cur.b >> 32), k0 = (uint32_t)cur.b;
-                for (uint32_t k = t; k < nkeys; k += NT)  // the partitions that lie in this chunk
-                    if (slot_off[(uint64_t)k0 + k + 1] > slot_off[(uint64_t)k0 + k]) pm.pinfo[(uint64_t)k0 + k] = gb | ((unsigned long long)cid << PM_BASE_BITS);
-            }
             if (links) {
                 for (uint32_t i = t; i < lnk_bytes / 16; i += NT) ((uint4 *)lnk)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
                 lds_barrier();
@@ -616,6 +621,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
                     prev = 2 * rank_of(v & 0x3FFFu) + ((v & 0x4000u) ? 0u : 1u);
                 }
             }
+            if (r0 == 0 && t == 0) issue_place();  // (wcount > 0 in here)
 #pragma unroll 1
             for (uint32_t j = 0; j < seg_n; ++j) {
                 const uint32_t hv = (uint32_t)a0 & 0xFFFFu;
@@ -681,7 +687,20 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
                     y = rec_roll_rc<NW>(y, K, b);
                 }
             }
+            if (r0 == 0 && t == 0) publish_place();
             lds_barrier();
+            const unsigned long long gb = s_gbase;
+            const bool skip = s_skip != 0;
+            if constexpr (PM) {
+                if (r0 == 0 && !dirty && !skip) {  // (wcount > 0 in here) the chunk's group words, its descriptor, and its partitions' words
+                    const uint32_t cid = s_cid;
+                    pm.meta[(size_t)cid * NT + t] = pre | (occ << 16);
+                    if (t == 0) pm.cinfo[cid] = gb | ((unsigned long long)wcount << PM_BASE_BITS);
+                    const uint32_t nkeys = (uint32_t)(cur.b >> 32), k0 = (uint32_t)cur.b;
+                    for (uint32_t k = t; k < nkeys; k += NT)  // the partitions that lie in this chunk
+                        if (slot_off[(uint64_t)k0 + k + 1] > slot_off[(uint64_t)k0 + k]) pm.pinfo[(uint64_t)k0 + k] = gb | ((unsigned long long)cid << PM_BASE_BITS);
+                }
+            }
             if (!skip) {
                 const uint32_t nr = min(R, wcount - r0);
                 Rec<NW> *dst = out + gb + r0;

@@ -14,6 +14,7 @@
 // A graph whose gathered structure exceeds one GPU's HBM needs the distributed walks, which only dist.py drives today.
 #pragma once
 #include <sys/prctl.h>
+#include "rank_watchdog.hpp"
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <signal.h>
@@ -69,6 +70,7 @@ struct GbOptions {
 };
 
 #define GM_MARK(what)                                                                              \
+    smxtool::RankWatch::mark(what);                                                                \
     if (getenv("SMX_DEBUG")) {                                                                    \
         fprintf(stderr, "[rank %d] %s\n", c.rank, what);                                          \
         fflush(stderr);                                                                            \
@@ -265,11 +267,14 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
     RankComm c;
     c.rank = rank;
     c.world = world;
+    smxtool::RankWatch::arm(rank);
+    smxtool::RankWatch::mark("smx_create");
     smx_ctx *ctx = nullptr;
     if (int rc = smx_create(&ctx, rank, 0)) {
         fprintf(stderr, "[rank %d] no usable MI355X device %d (smx_create -> %d)\n", rank, rank, rc);
         return rc;
     }
+    smxtool::RankWatch::mark("communicator: ncclGetUniqueId / ncclCommInitRank");
     if (int rc = comm_init(c, idfile)) return rc;
     GM_MARK("communicator up")
     // input
@@ -470,14 +475,14 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
     // The work is done and every collective has completed; what follows only gives resources back. Should that not finish (a
     // communicator teardown that waits for ever has been seen on other stacks), the rank leaves with success after a grace period
     // that lets the other ranks finish theirs.
-    fflush(stdout);  // (_exit does not flush: the report lines must not be lost with a teardown that hangs when stdout is a pipe)
-    fflush(stderr);
-    signal(SIGALRM, [](int) { _exit(0); });
-    alarm(30);
+    smxtool::RankWatch::teardown_begins();
+    smxtool::RankWatch::mark("teardown: ncclCommDestroy");
     ncclCommDestroy(c.comm);
+    smxtool::RankWatch::mark("teardown: hipStreamDestroy");
     (void)hipStreamDestroy(c.stream);
+    smxtool::RankWatch::mark("teardown: smx_destroy");
     smx_destroy(ctx);
-    alarm(0);
+    smxtool::RankWatch::done();
     GM_MARK("rank done")
     return 0;
 }

@@ -10,6 +10,7 @@
 #include <signal.h>
 #include <fcntl.h>
 #include <sys/prctl.h>
+#include "rank_watchdog.hpp"
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -50,6 +51,8 @@ namespace smxtool {
 
 inline int sharded_rank_main(int rank, int world, unsigned K, const std::string &workdir, const std::vector<std::string> &input) {
     smx_ctx *ctx = nullptr;
+    smxtool::RankWatch::arm(rank);
+    smxtool::RankWatch::mark("smx_create");
     if (int rc = smx_create(&ctx, rank, 0)) {
         fprintf(stderr, "[rank %d] no usable MI355X device %d (smx_create -> %d)\n", rank, rank, rc);
         return rc;
@@ -57,6 +60,7 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
     // communicator: rank 0 publishes the id through the work directory
     const std::string idfile = workdir + "/.smx_nccl_id";
     ncclUniqueId id;
+    smxtool::RankWatch::mark("communicator: ncclGetUniqueId / ncclCommInitRank");
     if (rank == 0) {
         MG_NCCL(ncclGetUniqueId(&id));
         const std::string tmp = idfile + ".tmp";
@@ -84,6 +88,7 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
     MG_NCCL(ncclCommInitRank(&comm, world, id, rank));
     hipStream_t stream;
     MG_HIP(hipStreamCreate(&stream));
+    smxtool::RankWatch::mark("communicator up: reading the input");
     // this rank's share of the input: whole files dealt out round-robin when there is at least one per rank (nothing is parsed twice);
     // otherwise (R1 / R2 on eight GPUs) every file is cut among all ranks (read_share.hpp: byte ranges of plain FASTQ, every world-th
     // read of anything else)
@@ -106,6 +111,7 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
             return rc;
         }
     }
+    smxtool::RankWatch::mark("input submitted: local extraction");
     const unsigned NB = 16, nw = (K + 31) / 32;  // 16 buckets: kmercount.cpp:220
     // records grouped by owner in a buffer of the library's pool, sized after the local pre-dedupe (not one record per k-mer instance)
     uint64_t *d_send = nullptr, *d_recv = nullptr, *d_cnt = nullptr, *d_all = nullptr;
@@ -119,6 +125,7 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
         d_send = (uint64_t *)const_cast<void *>(p);
     }
     // counts of every pair
+    smxtool::RankWatch::mark("extracted: all-gather of the counts");
     MG_HIP(hipMalloc((void **)&d_cnt, (size_t)world * 8));
     MG_HIP(hipMalloc((void **)&d_all, (size_t)world * world * 8));
     MG_HIP(hipMemcpy(d_cnt, counts.data(), (size_t)world * 8, hipMemcpyHostToDevice));
@@ -143,6 +150,7 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
     // the exchange: all pairs at once, every pair on its own xGMI link, in rounds of <= 1 GiB per pair (one transfer of tens of GB was
     // seen to stop short on this stack: dist.py, _a2a); the segment that stays here is a device copy (SMX_MGPU_SELF_RCCL=1 sends it
     // through ncclSend / ncclRecv as well: the one-rank tests exercise the RCCL calls that way)
+    smxtool::RankWatch::mark("exchange (grouped ncclSend / ncclRecv)");
     {
         const bool self_rccl = getenv("SMX_MGPU_SELF_RCCL") != nullptr;
         const uint64_t LIM = getenv("SMX_MGPU_ROUND_WORDS") ? (uint64_t)std::max(1LL, atoll(getenv("SMX_MGPU_ROUND_WORDS"))) : (uint64_t)1 << 27;  // words (env: test hook)
@@ -164,12 +172,14 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
             MG_HIP(hipMemcpyAsync(d_recv + roff[rank] * nw, d_send + soff[rank] * nw, (size_t)counts[rank] * nw * 8, hipMemcpyDeviceToDevice, stream));
     }
     MG_HIP(hipStreamSynchronize(stream));
+    smxtool::RankWatch::mark("exchanged: owner-side count");
     smx_extract_release(ctx);
     if (int rc = smx_count_records(ctx, K, NB, d_recv, n_recv)) {
         fprintf(stderr, "%s\n", smx_last_error(ctx));
         return rc;
     }
     // file offsets: records per rank
+    smxtool::RankWatch::mark("counted: all-gather of the file offsets, writing");
     uint64_t n_mine = 0;
     smx_count_info(ctx, &n_mine, nullptr, nullptr);
     const std::string out = workdir + "/final_kmers";
@@ -216,6 +226,7 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
         close(fd);
     }
     // everybody has written before rank 0 reports
+    smxtool::RankWatch::mark("written: last all-gather");
     MG_NCCL(ncclAllGather(d_cnt, d_all, 1, ncclUint64, comm, stream));
     MG_HIP(hipStreamSynchronize(stream));
     if (rank == 0) {
@@ -224,16 +235,17 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
         unlink(idfile.c_str());
     }
     // (the work is done: should giving the resources back not finish, the rank leaves with success after a grace period)
-    fflush(stdout);  // (_exit does not flush: the report lines must not be lost with a teardown that hangs when stdout is a pipe)
-    fflush(stderr);
-    signal(SIGALRM, [](int) { _exit(0); });
-    alarm(30);
+    smxtool::RankWatch::teardown_begins();
+    smxtool::RankWatch::mark("teardown: hipFree");
     (void)hipFree(d_cnt);
     (void)hipFree(d_all);
+    smxtool::RankWatch::mark("teardown: ncclCommDestroy");
     ncclCommDestroy(comm);
+    smxtool::RankWatch::mark("teardown: hipStreamDestroy");
     (void)hipStreamDestroy(stream);
+    smxtool::RankWatch::mark("teardown: smx_destroy");
     smx_destroy(ctx);
-    alarm(0);
+    smxtool::RankWatch::done();
     return 0;
 }
 

@@ -4,7 +4,7 @@ with everything it includes: C ABI, host pipeline, every gfx950 kernel as writte
 the fiber-based SIMT stand-in. The sources are used as they are except for what only an AMDGPU assembler understands:
   * inline `asm volatile("s_waitcnt ...")` (waits that order nothing in a sequential emulation) and the library's LDS barrier (s_barrier),
   * `extern __shared__ T name[];` (dynamic LDS: a pointer to the emulator's one LDS buffer),
-  * two clang builtins g++ lacks.
+  * two clang builtins g++ lacks, and the register class of empty optimizer-barrier asm statements ("+v" -> "+r").
 The transformed copies live under _build/src; nothing of this is ever loaded by spades_amd (the product has no CPU path)."""
 import os
 import re
@@ -23,6 +23,8 @@ def transform(text):
     text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)\\n\\ts_barrier" ::: "memory"\);', "EMU_LDS_BARRIER();", text)
     text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', "/* s_waitcnt: nothing to wait for here */;", text)
     text = text.replace("__builtin_amdgcn_wave_barrier();", "EMU_WAVE_BARRIER();")
+    # an EMPTY asm statement that only hides a value from the optimizer ("+v": a vector register on gfx950) — a general register here
+    text = re.sub(r'asm volatile\(""\s*:\s*"\+v"\((\w+)\)\);', r'__asm__ __volatile__("" : "+r"(\1));', text)
     text = re.sub(r"extern __shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_0-9 ]+?)\s+(\w+)\[\];", r"\1 *\2 = (\1 *)emu::g_ctx->lds;", text)
     text = text.replace("__builtin_rotateleft32", "emu_rotl32")
     assert "asm volatile" not in text and "extern __shared__" not in text, "an AMDGPU-only construct the transform does not know"

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.skipif(not HAVE_HEADERS, reason="the hosts include the 
 
 def _build_shim():
     srcs = [os.path.join(SHIM_DIR, "shim.cpp")] + [os.path.join(ROOT, "spades_amd", "tools", f) for f in
-                                                   ("gbuilder_mgpu.hpp", "kmercount_mgpu.hpp", "read_input.hpp", "read_share.hpp", "fastq_split.hpp", "bgzf_reader.hpp")]
+                                                   ("gbuilder_mgpu.hpp", "kmercount_mgpu.hpp", "read_input.hpp", "read_share.hpp", "fastq_split.hpp", "bgzf_reader.hpp", "rank_watchdog.hpp")]
     if os.path.exists(SHIM) and all(os.path.getmtime(SHIM) >= os.path.getmtime(s) for s in srcs):
         return
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", SHIM + ".tmp", srcs[0],

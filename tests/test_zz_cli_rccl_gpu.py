@@ -26,17 +26,27 @@ def _fastq(path, reads, gz=False):
 
 
 def _launch_ranks(argv, env=None, tries=3, timeout=90):
-    """One launch of a tool with --gpus N. In one of four GPU runs of this round a one-rank launch (of 60 in all) did not come back;
-    26 launches in a row under SMX_DEBUG did (profiles/r04/gbuilder_mgpu_one_rank_26_launches.log) and the place was never seen. Until
-    it is found a launch that exceeds the timeout is repeated (the tool's ranks die with it) and reported as a warning, so that a stuck
-    launch costs this tier a minute and a half, not the rest of its tests. A non-zero exit code is never retried."""
+    """One launch of a tool with --gpus N. In one of four GPU runs of round 4 a one-rank launch (of 60 in all) did not come back; 26 launches in
+    a row under SMX_DEBUG did, and the place was never seen. Round 5: the ranks watch themselves (tools/rank_watchdog.hpp, SMX_MGPU_WATCHDOG): a
+    phase without progress for 60 s prints the rank, its last milestone and a backtrace of the blocked thread and leaves with code 75. Such a
+    launch is still repeated — a stuck launch must not cost the tier the rest of its tests — but the warning now carries the place.
+    Any other non-zero exit code is never retried."""
+    import tempfile
     import warnings
+    env = dict(env if env is not None else os.environ, SMX_MGPU_WATCHDOG="60")
     for t in range(tries):
-        try:
-            subprocess.run(argv, stdout=subprocess.DEVNULL, env=env, timeout=timeout, check=True)
-            return
-        except subprocess.TimeoutExpired:
-            warnings.warn(f"launch {t + 1} of {' '.join(argv[:1] + argv[-4:])} did not finish in {timeout} s")
+        with tempfile.TemporaryFile("w+") as err:
+            try:
+                r = subprocess.run(argv, stdout=subprocess.DEVNULL, stderr=err, env=env, timeout=timeout)
+                if r.returncode == 0:
+                    return
+                err.seek(0)
+                text = err.read()
+                assert r.returncode == 75, f"{argv} -> {r.returncode}\n{text[-2000:]}"
+                warnings.warn(f"launch {t + 1} of {' '.join(argv[:1] + argv[-4:])}: a rank's watchdog fired\n{text[-3000:]}")
+            except subprocess.TimeoutExpired:
+                err.seek(0)
+                warnings.warn(f"launch {t + 1} of {' '.join(argv[:1] + argv[-4:])} did not finish in {timeout} s\n{err.read()[-3000:]}")
     raise AssertionError(f"{tries} launches in a row did not finish: {argv}")
 
 
