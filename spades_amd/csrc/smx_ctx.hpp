@@ -592,6 +592,18 @@ size_t arena_avail(smx_ctx *ctx) {
     return std::min(dev, ctx->budget > ctx->arena_live ? ctx->budget - ctx->arena_live : (size_t)0);
 }
 
+// largest free block of the arena (diagnostics: SMX_DEBUG lines that tell a full arena from a fragmented one)
+size_t arena_largest_free(smx_ctx *ctx) {
+    size_t mx = 0;
+    if (ctx->arena.vmm) {
+        for (auto &b : ctx->arena.free_blocks) mx = std::max(mx, b.second);
+        mx = std::max(mx, ctx->arena.hi > ctx->arena.lo ? ctx->arena.hi - ctx->arena.lo : (size_t)0);  // (what can still be mapped between the two marks)
+    } else {
+        for (auto &b : ctx->arena_free) mx = std::max(mx, b.second);
+    }
+    return mx;
+}
+
 // fallback: a cache of hipMalloc'ed blocks, best fit with at most 2x waste
 void *arena_get_malloc(smx_ctx *ctx, size_t bytes) {
     size_t best = (size_t)-1, bi = 0;

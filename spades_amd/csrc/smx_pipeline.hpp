@@ -1064,6 +1064,9 @@ retry_with_more_ranges:
         goto retry_with_more_ranges;
     }
     arena_put(ctx, d_cnt);
+    if (getenv("SMX_DEBUG"))
+        fprintf(stderr, "[smx] two strands: %llu canonical records, reverse complements sorted in %u bucket range(s)%s; %.1f GB obtainable after them, largest free block %.1f GB\n",
+                (unsigned long long)t.nc, H, rc ? " (failed)" : "", (double)arena_avail(ctx) / 1e9, (double)arena_largest_free(ctx) / 1e9);
     if (rc) return bail(rc);
     t.nr = nr_total;
     ctx->bucket_off.assign((size_t)B + 1, 0);
