@@ -175,9 +175,21 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
             if (threadIdx.x == 0) atomicAdd(err, 1u);
             continue;
         }
+        // (the byte and the link word of the thread's NEXT record are asked for before this one is worked on: a chunk gives a thread ~4
+        // records, and with one load -> use -> store chain after the other the phase was latency, round-5 ticks: 574 of a chunk's 1100)
+        unsigned m_nx = 0;
+        uint32_t ll_nx = 0;
+        if (threadIdx.x < n) {
+            m_nx = mask[base + threadIdx.x];
+            ll_nx = llink[base + threadIdx.x];
+        }
         for (uint32_t r = threadIdx.x; r < n; r += BLK) {
-            const unsigned m = mask[base + r];
-            const uint32_t ll = llink[base + r];
+            const unsigned m = m_nx;
+            const uint32_t ll = ll_nx;
+            if (r + BLK < n) {
+                m_nx = mask[base + r + BLK];
+                ll_nx = llink[base + r + BLK];
+            }
             bits += __popc(m);
             const bool junction = mask_junction(m);
             node_t e[2];
