@@ -1423,6 +1423,14 @@ static int write_gfa_device(smx_ctx *ctx, const char *path, const char *flavour)
         for (void *p : mine) arena_put(ctx, p);
         return code;
     };
+    // (a device error leaves through done() as well: HIPCHK's plain return would keep this call's blocks out of the arena — ADVICE r4)
+#define GFACHK(call)                                                                                                                    \
+    do {                                                                                                                                \
+        hipError_t e_ = (call);                                                                                                         \
+        if (e_ != hipSuccess)                                                                                                           \
+            return done(fail(ctx, e_ == hipErrorOutOfMemory ? SMX_MEMORY_LIMIT_EXCEEDED : SMX_DEVICE_ERROR, "%s failed: %s (%s:%d)", #call, \
+                             hipGetErrorString(e_), __FILE__, __LINE__));                                                               \
+    } while (0)
     auto take = [&](auto **p, size_t n) {
         const int rc = dalloc(ctx, p, std::max<size_t>(n, 1), false);
         if (rc == 0) mine.push_back((void *)*p);
@@ -1465,28 +1473,28 @@ static int write_gfa_device(smx_ctx *ctx, const char *path, const char *flavour)
             ctx->err.clear();
             return done(1);
         }
-        HIPCHK(hipMemcpyAsync(d_taglen, tl.data(), ne * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(d_tagoff, to.data(), (ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(d_pool, pool.data(), pool.size(), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        GFACHK(hipMemcpyAsync(d_taglen, tl.data(), ne * 4, hipMemcpyHostToDevice, ctx->stream));
+        GFACHK(hipMemcpyAsync(d_tagoff, to.data(), (ne + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        GFACHK(hipMemcpyAsync(d_pool, pool.data(), pool.size(), hipMemcpyHostToDevice, ctx->stream));
+        GFACHK(hipStreamSynchronize(ctx->stream));
     }
     const unsigned g1 = (unsigned)std::min<uint64_t>((ne + BLK - 1) / BLK, 256 * 16), g2 = (unsigned)std::min<uint64_t>((nv + BLK - 1) / BLK, 256 * 16);
     hipLaunchKernelGGL(k_gfa_s_len, dim3(g1), dim3(BLK), 0, ctx->stream, (const unsigned long long *)ctx->g_elen, ne, (const uint32_t *)d_taglen, soff);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(d_nl, 0, 8, ctx->stream));
+    GFACHK(hipGetLastError());
+    GFACHK(hipMemsetAsync(d_nl, 0, 8, ctx->stream));
     if (nv) {
         hipLaunchKernelGGL((k_gfa_l<false>), dim3(std::max(g2, 1u)), dim3(BLK), 0, ctx->stream, (const Rec<2> *)ctx->g_lrecs, ctx->g_nlrec, ctx->g_lsh,
                            (const unsigned long long *)ctx->g_vstart, nv, (const uint8_t *)ctx->g_eself, ctx->g_k, loff, d_nl, (const unsigned long long *)nullptr, (char *)nullptr);
-        HIPCHK(hipGetLastError());
+        GFACHK(hipGetLastError());
     }
     if (int rc = scan_u64(ctx, soff, soff, ne)) return done(rc);
     if (nv)
         if (int rc = scan_u64(ctx, loff, loff, nv)) return done(rc);
     unsigned long long ts = 0, tl_ = 0, nlinks = 0;
-    HIPCHK(hipMemcpyAsync(&ts, soff + ne, 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (nv) HIPCHK(hipMemcpyAsync(&tl_, loff + nv, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&nlinks, d_nl, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    GFACHK(hipMemcpyAsync(&ts, soff + ne, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (nv) GFACHK(hipMemcpyAsync(&tl_, loff + nv, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GFACHK(hipMemcpyAsync(&nlinks, d_nl, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GFACHK(hipStreamSynchronize(ctx->stream));
     free_temps(ctx);  // (the scans' scratch)
     const size_t total = (size_t)ts + (size_t)tl_;
     char *text;
@@ -1496,14 +1504,14 @@ static int write_gfa_device(smx_ctx *ctx, const char *path, const char *flavour)
     }
     hipLaunchKernelGGL(k_gfa_s_write, dim3(std::max(g1, 1u)), dim3(BLK), 0, ctx->stream, (const uint64_t *)ctx->g_uwords, (const unsigned long long *)ctx->g_eoffw,
                        (const unsigned long long *)ctx->g_elen, ne, (const unsigned long long *)soff, (const char *)d_pool, (const unsigned long long *)d_tagoff, text);
-    HIPCHK(hipGetLastError());
+    GFACHK(hipGetLastError());
     if (nv) {
         hipLaunchKernelGGL((k_gfa_l<true>), dim3(std::max(g2, 1u)), dim3(BLK), 0, ctx->stream, (const Rec<2> *)ctx->g_lrecs, ctx->g_nlrec, ctx->g_lsh,
                            (const unsigned long long *)ctx->g_vstart, nv, (const uint8_t *)ctx->g_eself, ctx->g_k, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
                            (const unsigned long long *)loff, text + ts);
-        HIPCHK(hipGetLastError());
+        GFACHK(hipGetLastError());
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    GFACHK(hipStreamSynchronize(ctx->stream));
     // to the file: the header, then the text through a ring of page-locked buffers; every buffer is written by several pwrite threads
     const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);  // (read access too: a tmpfs output is filled through a shared mapping)
     if (fd < 0) return done(fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path));
@@ -1522,6 +1530,7 @@ static int write_gfa_device(smx_ctx *ctx, const char *path, const char *flavour)
     if (!ok) return done(fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path));
     return done(SMX_OK);
 }
+#undef GFACHK
 
 int smx_graph_write_gfa(smx_ctx *ctx, const char *path, const char *flavour_version) {
     if (!ctx || !path) return SMX_INVALID_PARAMETER;

@@ -1010,20 +1010,26 @@ retry_with_more_ranges:
         const uint64_t cap = H == 1 ? t.nc : std::min<uint64_t>(t.nc, (uint64_t)((double)t.nc * (double)(b1 - b0) / (double)B * 1.02) + (1u << 20));
         Rec<NW> *raw;
         if ((rc = dalloc(ctx, &raw, cap + 1))) break;
-        HIPCHK(hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
+        if (hipMemsetAsync(d_cnt, 0, 8, ctx->stream) != hipSuccess) {  // (device errors inside the range loop leave through `bail` like every other failure here: HIPCHK's plain return kept t.c and the finished ranges out of the arena — ADVICE r4)
+            rc = fail(ctx, SMX_DEVICE_ERROR, "two-strand count: counter reset failed");
+            break;
+        }
         tbegin(ctx, "ts_rc");
         if (t.nc) {
             // (a range's count is not known before the pass: a first pass with a null destination is not needed — the bound above holds
             // unless the hash is badly skewed, which the count below catches)
             hipLaunchKernelGGL((k_ts_rc<NW>), dim3((unsigned)std::min<uint64_t>((t.nc + BLK * 16 - 1) / (BLK * 16), 256 * 16)), dim3(BLK), 0, ctx->stream, (const void *)t.c,
                                t.nc, K, (void *)raw, d_cnt, B, b0, b1, (uint64_t)cap);
-            HIPCHK(hipGetLastError());
+            if (hipGetLastError() != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "two-strand count: k_ts_rc launch failed");
         }
         tend(ctx);
+        if (rc) break;
         unsigned long long nr = t.nc;
         if (!((K & 1u) && H == 1)) {
-            HIPCHK(hipMemcpyAsync(&nr, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (hipMemcpyAsync(&nr, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                rc = fail(ctx, SMX_DEVICE_ERROR, "two-strand count: reading the range's count failed");
+                break;
+            }
         }
         if (nr > cap) {  // (the kernel wrote past its block: never expected — the result cannot be trusted)
             rc = fail(ctx, SMX_DEVICE_ERROR, "two-strand count: %llu reverse complements in a bucket range planned for %llu", nr, (unsigned long long)cap);
