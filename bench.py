@@ -410,7 +410,21 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # librccl prints a version banner ("RCCL version : ...", five lines) to STDOUT when its first communicator comes up; rank 0's stdout
+        # is the ONE JSON line of the contract, so file descriptor 1 points at stderr while the communicator is made (init + a first barrier)
+        sys.stdout.flush()
+        saved_fd1 = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            import ctypes
+            ctypes.CDLL(None).fflush(None)  # (the banner sits in the C stdio buffer: it must leave while descriptor 1 is still stderr)
+            os.dup2(saved_fd1, 1)
+            os.close(saved_fd1)
         if dist.get_world_size() != world:
             raise SystemExit(f"RCCL reports world size {dist.get_world_size()}, expected {world}")
 
@@ -887,7 +901,7 @@ def main():
     if sharded and rank == 0:
         # the N = 1 default line is another workload (config 3: upload + count + construction); the figure to divide an N-rank value by
         # is this same sharded step on ONE rank, measured with --gpus 1 --force-sharded and committed under profiles/
-        ref = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, "bench_sharded_1rank_100M.json") for r_ in ("r04", "r03", "r02")) if os.path.exists(p_)),
+        ref = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, "bench_sharded_1rank_100M.json") for r_ in ("r05", "r04", "r03", "r02")) if os.path.exists(p_)),
                    os.path.join(ROOT, "profiles", "r04", "bench_sharded_1rank_100M.json"))
         try:
             r1 = json.load(open(ref))

@@ -1308,7 +1308,7 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
                         }
                     }
                 }
-                if ((rc = spill(t.c, t.nc, t.boff_c))) {  // (spill releases the block it was given once it has been read; on a failure before that it is ours)
+                if ((rc = spill(t.c, t.nc, t.boff_c))) {  // (spill releases the block it was given on every path: only the segments are still ours)
                     drop_view(0, false);
                     drop_runs();
                     return cleanup(rc);

@@ -1,4 +1,4 @@
-"""CPU: the bench line this round recorded on the GPU box (profiles/r04/bench_config3.json, printed by `python bench.py`) carries every
+"""CPU: the bench line this round recorded on the GPU box (the latest profiles/rNN/bench_config3.json, printed by `python bench.py`) carries every
 field of the driver's contract and its numbers agree with each other."""
 import glob
 import json
@@ -31,6 +31,12 @@ def test_recorded_bench_line_has_the_contract_fields():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["bit_identical_to_reference_output"] is True
     # value = whole-job reads per second of the timed steps
     assert abs(d["value"] - d["config"]["reads_per_gpu"] / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
+    # round 5: `value` is measured on reads resident in HBM; the same step with the upload inside is reported beside it and is the slower one
+    if "pcie_inclusive" in d:
+        p = d["pcie_inclusive"]
+        assert d["config"]["h2d_in_timed_region"] is False and p["unit"] == d["unit"]
+        assert 0 < p["value"] < d["value"] and p["ms_per_step"] > d["ms_per_step"]
+        assert abs(p["value"] - d["config"]["reads_per_gpu"] / p["ms_per_step"] / 1e3) < 0.01 * p["value"]
     # the dominant kernel is the longest single-kernel stage of the line and is priced on bytes of its own
     dk = d["dominant_kernel"]
     assert dk["ms"] == max(v for k, v in r["stages_ms"].items()) and 0 < dk["frac"] < 1
