@@ -156,6 +156,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "device_gfa")) ctx->opt_device_gfa = value;
     else if (!strcmp(key, "keep_perfect_loops")) ctx->opt_keep_loops = value;
     else if (!strcmp(key, "device_loops")) ctx->opt_device_loops = value;
+    else if (!strcmp(key, "nx_route")) ctx->opt_nx_route = value;
     else if (!strcmp(key, "skm_nkey_log2")) ctx->opt_skm_nkey_log2 = value;
     else if (!strcmp(key, "derive_batches")) ctx->opt_derive_batches = value;
     else if (!strcmp(key, "keep_kpo")) ctx->opt_keep_kpo = value;

@@ -69,6 +69,7 @@ void clear_graph(smx_ctx *ctx) {
     ctx->dw_ready = false;
     ctx->g_sharded_file = false;
     ctx->g_pm = false;
+    ctx->g_pm_nx = false;
     ctx->pm_view_pending = false;
     ctx->g_kmers = nullptr;
     ctx->g_mask = nullptr;
@@ -695,7 +696,11 @@ int device_loops(smx_ctx *ctx, unsigned k, bool pm, const unsigned long long *ll
     if (int rc = dalloc(ctx, &llen, L)) return rc;
     if (int rc = dalloc(ctx, &cnt, 2)) return rc;
     HIPCHK(hipMemsetAsync(cnt, 0, 16, ctx->stream));
-    if (pm)
+    const bool ext = pm && !ctx->g_pm_nx;  // the partition-major records carry their mask byte — unless the k-mer leaves it no room (nx: plain k-mers)
+    if (pm && !ext)
+        hipLaunchKernelGGL((k_lp_leaders<NW, false, true>), dim3(grid_for(L)), dim3(BLK), 0, ctx->stream, llist, L, tab, (const void *)ctx->g_kmers, (uint32_t)ctx->g_B,
+                           (unsigned long long)(2 * D0 + 2), lead, llen, cnt);
+    else if (pm)
         hipLaunchKernelGGL((k_lp_leaders<NW, true, true>), dim3(grid_for(L)), dim3(BLK), 0, ctx->stream, llist, L, tab, (const void *)ctx->g_kmers, (uint32_t)ctx->g_B,
                            (unsigned long long)(2 * D0 + 2), lead, llen, cnt);
     else
@@ -728,7 +733,8 @@ int device_loops(smx_ctx *ctx, unsigned k, bool pm, const unsigned long long *ll
         HIPCHK(hipStreamSynchronize(ctx->stream));
         std::vector<uint64_t> hk;
         if (int rc = d2h(ctx, hk, lk, (size_t)nl * NW)) return rc;
-        for (uint64_t i = 0; i < nl; ++i) hk[(size_t)i * NW + NW - 1] >>= smx::EXT_BITS;
+        if (ext)
+            for (uint64_t i = 0; i < nl; ++i) hk[(size_t)i * NW + NW - 1] >>= smx::EXT_BITS;
         std::vector<uint32_t> bk(nl);
         for (uint64_t i = 0; i < nl; ++i) bk[i] = pm_host_bucket(&hk[(size_t)i * NW], NW, ctx->g_B);
         std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
@@ -753,7 +759,7 @@ int device_loops(smx_ctx *ctx, unsigned k, bool pm, const unsigned long long *ll
     HIPCHK(hipMemcpy(llen, hlen.data(), nl * 8, hipMemcpyHostToDevice));
     unsigned long long *meas;
     if (int rc = dalloc(ctx, &meas, 4 * nl)) return rc;
-    if (pm)
+    if (ext)
         hipLaunchKernelGGL((k_lp_measure<NW, true>), dim3(grid_for(nl)), dim3(BLK), 0, ctx->stream, (const unsigned long long *)lead, (const unsigned long long *)llen, nl, tab,
                            (const void *)ctx->g_kmers, meas);
     else
@@ -813,7 +819,7 @@ int device_loops(smx_ctx *ctx, unsigned k, bool pm, const unsigned long long *ll
     cp(dnn, nnt.data(), nle * 8, hipMemcpyHostToDevice);
     cp(dof, offw.data(), nle * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        if (pm)
+        if (ext)
             hipLaunchKernelGGL((k_lp_write<NW, true>), dim3(grid_for(nle)), dim3(BLK), 0, ctx->stream, (const node_t *)dea, (const node_t *)deb, (const unsigned long long *)dnn,
                                (const unsigned long long *)dof, nle, tab, (const void *)ctx->g_kmers, k, uw2, es2 + nkept, ee2 + nkept, sf2 + nkept);
         else
@@ -1030,13 +1036,15 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             hipLaunchKernelGGL((k_pm_junc_write<NW>), dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const void *)ctx->g_kmers,
                                (const unsigned long long *)tjoff, D0, (void *)jrecs, jrank_of);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL((k_pm_cand_counts_node<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, nj, coff);
+            const bool nx = pm->ix.xs == 0;  // plain k-mer records: the bytes of the junction k-mers come from the graph's mask array (smx_pm.hip)
+            hipLaunchKernelGGL((k_pm_cand_counts_node<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, nj, coff,
+                               nx ? (const uint8_t *)ctx->g_mask : (const uint8_t *)nullptr, (const unsigned long long *)jrank_of);
             HIPCHK(hipGetLastError());
             if (int rc = scan_u64(ctx, coff, coff, nj)) return rc;
             tend(ctx);
             {
                 Prefix pf(ctx, "jsort:");
-                ctx->ext_mode = true;
+                ctx->ext_mode = !nx;
                 const int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, ctx->g_B, jrecs, nj, nullptr, /*recs_reusable=*/false, false, /*distinct_hint=*/true);
                 ctx->ext_mode = false;
                 if (rc) return rc;
@@ -1047,26 +1055,37 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             ctx->d_result_buf = ctx->d_result = nullptr;  // stays in the temp list
             ctx->n_records = 0;
             if (nj2 != nj) return fail(ctx, SMX_DEVICE_ERROR, "junction k-mers: %llu after the sort, %llu before", (unsigned long long)nj2, (unsigned long long)nj);
-            if (int rc = dalloc(ctx, &jk, nj + 1)) return rc;
+            if (nx) jk = const_cast<Rec<NW> *>(jsorted);  // (the sorted records ARE the k-mers)
+            else if (int rc = dalloc(ctx, &jk, nj + 1)) return rc;
             if (int rc = dalloc(ctx, &jm, nj + 16)) return rc;
             if (int rc = dalloc(ctx, &jstats, 3)) return rc;
             if (int rc = dalloc(ctx, &jcnt, nj + 1)) return rc;
             if (int rc = dalloc(ctx, &candoff, nj + 2)) return rc;
             HIPCHK(hipMemsetAsync(jstats, 0, 24, ctx->stream));
             tbegin(ctx, "junction_order");
-            hipLaunchKernelGGL((k_ext_split<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jsorted, nj, k, (void *)jk, jm, jstats);
-            HIPCHK(hipGetLastError());
+            if (!nx) {
+                hipLaunchKernelGGL((k_ext_split<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jsorted, nj, k, (void *)jk, jm, jstats);
+                HIPCHK(hipGetLastError());
+            }
             smx::RankDir jix{};
             if (int rc = build_rank_dir<NW>(ctx, jk, nj, jboff, ctx->g_B, k, jix)) return rc;
+            if (nx) {  // the bytes reach the sorted order through the rank lookups themselves (k_pm_jrank_nx1), then the counts, then the numbers
+                hipLaunchKernelGGL((k_pm_jrank_nx1<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, nj, (const void *)jk, jix,
+                                   (const uint8_t *)ctx->g_mask, (const unsigned long long *)jrank_of, qbase, jm, d_err);
+            }
             hipLaunchKernelGGL(k_pm_cand_counts, dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const uint8_t *)jm, nj, jcnt);
             if (int rc = scan_u64(ctx, jcnt, candoff, nj)) {
                 drop_rank_dir(ctx, jix);
                 return rc;
             }
-            hipLaunchKernelGGL((k_pm_jrank<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, nj, (const void *)jk, jix,
-                               (const unsigned long long *)candoff, qbase, d_err);
+            if (nx)
+                hipLaunchKernelGGL(k_pm_jrank_nx2, dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, nj, (const unsigned long long *)candoff, qbase);
+            else
+                hipLaunchKernelGGL((k_pm_jrank<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, nj, (const void *)jk, jix,
+                                   (const unsigned long long *)candoff, qbase, d_err);
             hipLaunchKernelGGL((k_pm_cand_expand<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, (const unsigned long long *)jrank_of, nj,
-                               (const unsigned long long *)coff, (const unsigned long long *)qbase, cand, qidx);
+                               (const unsigned long long *)coff, (const unsigned long long *)qbase, cand, qidx,
+                               nx ? (const uint8_t *)ctx->g_mask : (const uint8_t *)nullptr);
             unsigned long long ctot = 0;
             hipError_t e1 = hipGetLastError();
             if (e1 == hipSuccess) e1 = hipMemcpyAsync(&ctot, candoff + nj, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -1088,7 +1107,8 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         tbegin(ctx, "keep");
         if (pm) {
             hipLaunchKernelGGL((k_pm_keep<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (const unsigned long long *)qidx, (uint64_t)C,
-                               (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len, (const node_t *)first, flags, vq, counters + 1);
+                               (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len, (const node_t *)first, flags, vq, counters + 1,
+                               pm->ix.xs);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_pm_unpack, dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)vq, (uint64_t)C, kw, one);  // kw / one: indexed by q
         } else {
@@ -1121,7 +1141,8 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             if (int rc = dalloc(ctx, &erec, nkept + 1)) return rc;
             hipLaunchKernelGGL((k_pm_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (const unsigned long long *)qidx,
                                (uint64_t)C, (const void *)ctx->g_kmers, (const node_t *)tab, pm->jmp, k, (const unsigned long long *)len, (const node_t *)first,
-                               (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw, (const unsigned long long *)one, ctx->g_uwords, erec);
+                               (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw, (const unsigned long long *)one, ctx->g_uwords, erec,
+                               pm->ix.xs);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_pm_edges, dim3(grid_for(nkept)), dim3(BLK), 0, ctx->stream, (const ulonglong4 *)erec, (uint64_t)nkept, ctx->g_eoffw, ctx->g_elen,
                                ctx->g_estart, ctx->g_eend, ctx->g_eself);
@@ -1190,7 +1211,8 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             std::vector<uint64_t> order(nloopk);
             for (uint64_t i = 0; i < nloopk; ++i) order[i] = i;
             if (pm) {  // EXT records in partition-major order: drop the byte, then k-mer-file order = (bucket, words) on the host
-                for (uint64_t i = 0; i < nloopk; ++i) hk[(size_t)i * NW + NW - 1] >>= smx::EXT_BITS;
+                if (!ctx->g_pm_nx)
+                    for (uint64_t i = 0; i < nloopk; ++i) hk[(size_t)i * NW + NW - 1] >>= smx::EXT_BITS;
                 std::vector<uint32_t> bk(nloopk);
                 for (uint64_t i = 0; i < nloopk; ++i) bk[i] = pm_host_bucket(&hk[(size_t)i * NW], NW, ctx->g_B);
                 std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {

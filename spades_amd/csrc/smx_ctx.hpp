@@ -48,6 +48,7 @@ struct Arena {  // one virtual range, physically backed up to `mapped`
 // sorted tail of the k-mers of cut partitions.
 struct PmState {
     bool active = false;  // the dedupe stage in flight writes partition-major output (set by the route, like smx_ctx::ext_mode)
+    bool nx = false;      // ... with PLAIN k-mer records (no room for the byte in the last word): the bytes go to `mask` alone, those of cut partitions' survivors too
     unsigned long long *pinfo = nullptr, *cinfo = nullptr;
     uint32_t *meta = nullptr, *overflow = nullptr, *llink = nullptr;
     unsigned long long *pals = nullptr;
@@ -97,9 +98,11 @@ struct smx_ctx {
     PmState pm;               // partition-major construction route
     uint64_t g_route_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // smx_graph_route_stats of the last build
     bool g_pm = false;        // g_kmers holds EXT records in partition-major order (no sorted k-mer file yet: made on demand)
+    bool g_pm_nx = false;     // ... plain k-mer records instead (the k-mer leaves the last word no 8 spare bits): the bytes live in g_mask alone
     bool pm_view_pending = false;  // the count-result view (smx_copy_final_kmers, smx_bucket_sizes, ...) stands for the k-mer file of that
                                    // graph, not made yet; any later count owns the view again (clear_result)
     int64_t opt_pm_route = -1;  // construction without the sort of the k-mers: -1 where it applies, 0 never, 1 = -1
+    int64_t opt_nx_route = 1;   // ... also for k whose record has no 8 spare bits, on plain k-mer records (0: those k take the (k+1)-mer route as until round 5)
     bool ext_mode = false;    // the count in flight carries extension bytes in its records (EXT layout, smx_device.hpp): set by the construction
     void *x_owned = nullptr;  // output of smx_extract_partition_owned (released by the next extract / smx_extract_release)
     void *x_recv = nullptr;   // smx_exchange_buffer: receive side of the exchange, consumed by smx_count_records

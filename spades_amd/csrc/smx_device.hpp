@@ -156,6 +156,13 @@ __host__ __device__ __forceinline__ Rec<NW> rec_pure(Rec<NW> x) {
     return x;
 }
 __host__ __device__ inline bool ext_layout_fits(unsigned K, int nw) { return 2 * K + EXT_BITS <= 64u * (unsigned)nw; }
+// ... and where the record has no 8 spare bits (k = 29, 31, 61, 63, 93, 95, 125, 127) the partition-major route keeps the byte in its mask
+// array alone ("nx": records are the plain k-mers). Code that serves both takes the shift as a value: EXT_BITS, or 0.
+template <int NW>
+__host__ __device__ __forceinline__ Rec<NW> rec_pure_xs(Rec<NW> x, unsigned xs) {
+    x.w[NW - 1] >>= xs;
+    return x;
+}
 
 __device__ __forceinline__ uint32_t bucket_of(uint64_t hash, uint32_t num_buckets) {
     return num_buckets == 1 ? 0u : (uint32_t)__umul64hi(hash, (uint64_t)num_buckets);

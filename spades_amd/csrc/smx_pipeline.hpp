@@ -715,8 +715,10 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     const uint32_t T = 16 * NT;
     const uint32_t scap = std::min<uint32_t>(std::min<uint32_t>(SKM_SCAP, NT), ctx->opt_skm_scap > 0 ? (uint32_t)ctx->opt_skm_scap : SKM_SCAP);
     const size_t lds = (size_t)scap * SW * 8 + (size_t)T * 4 + (size_t)NT * 4 + (size_t)NT * 4 + 2 * (size_t)scap + 48;
+    const bool nx = ctx->pm.active && ctx->pm.nx;  // partition-major output with PLAIN k-mer records: the bytes go to the mask array alone (k without 8 spare record bits)
     const bool ext = ctx->ext_mode;  // the survivors carry their extension byte (EXT layout)
-    const bool pmode = ext && ctx->pm.active;  // ... and leave in partition-major order with their side arrays (smx_pm.hpp)
+    const bool pmode = (ext || nx) && ctx->pm.active;  // ... and leave in partition-major order with their side arrays (smx_pm.hpp)
+    if (ext && nx) return fail(ctx, SMX_INVALID_PARAMETER, "the EXT layout and plain partition-major records exclude each other");
     if (ext && !ext_layout_fits(K, NW)) return fail(ctx, SMX_INVALID_PARAMETER, "K=%u leaves no room for the extension byte", K);
     const uint32_t nitems = SKM_NKEY / SKM_KEYS_PER_ITEM;
     unsigned long long *prof = nullptr;
@@ -857,7 +859,8 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
             else if (NT == 512) launch(std::integral_constant<int, 512>{});
             else launch(std::integral_constant<int, 1024>{});
         };
-        if (pmode) go(std::integral_constant<int, 2>{});
+        if (pmode && nx) go(std::integral_constant<int, 3>{});
+        else if (pmode) go(std::integral_constant<int, 2>{});
         else if (ext) go(std::integral_constant<int, 1>{});
         else go(std::integral_constant<int, 0>{});
         if (rc2) return rc2;
@@ -891,6 +894,29 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         const unsigned DB = SKM_DIRTY_BUCKETS;
         if (int rc = run_count<NW>(ctx, K, SMX_MODE_ALL, DB, *out + (out_cap - nn[1]), nn[1])) return rc;
         std::vector<uint64_t> dboff = ctx->bucket_off;
+        uint32_t *nx_words = nullptr;  // nx: the bytes of the sorted-unique survivors, gathered from their copies (4 per word)
+        if (nx && ctx->n_records) {
+            // The copies (plain k-mers at the far end of *out, their bytes at the same places of the mask array) are still there: run_count
+            // sorted a copy. Every copy ORs its byte into the place of its k-mer in the sorted-unique array (k_nx_dirty_masks).
+            const uint64_t nd = ctx->n_records;
+            unsigned long long *d_boff;
+            uint32_t *d_nxerr;
+            if (int rc = dalloc(ctx, &nx_words, nd / 4 + 2)) return rc;
+            if (int rc = dalloc(ctx, &d_boff, DB + 1)) return rc;
+            if (int rc = dalloc(ctx, &d_nxerr, 1)) return rc;
+            std::vector<unsigned long long> hb(dboff.begin(), dboff.end());
+            HIPCHK(hipMemsetAsync(nx_words, 0, (size_t)(nd / 4 + 2) * 4, ctx->stream));
+            HIPCHK(hipMemsetAsync(d_nxerr, 0, 4, ctx->stream));
+            HIPCHK(hipMemcpyAsync(d_boff, hb.data(), (size_t)(DB + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL((k_nx_dirty_masks<NW>), dim3((unsigned)std::min<uint64_t>((nn[1] + BLK - 1) / BLK, 256 * 16)), dim3(BLK), 0, ctx->stream,
+                               (const void *)(*out + (out_cap - nn[1])), (const uint8_t *)ctx->pm.mask + (out_cap - nn[1]), (uint64_t)nn[1], (const void *)ctx->d_result_buf,
+                               (const unsigned long long *)d_boff, DB, nx_words, d_nxerr);
+            HIPCHK(hipGetLastError());
+            uint32_t nxerr = 0;
+            HIPCHK(hipMemcpyAsync(&nxerr, d_nxerr, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));  // (hb goes out of scope)
+            if (nxerr) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication: %u survivors of cut partitions are missing from their own sorted set", nxerr);
+        }
         if (ext && ctx->n_records && ctx->opt_ext_presort != 0) {
             // copies of a k-mer that left different chunks with different extension bytes are neighbours now: one record, bytes ORed
             const uint64_t nd = ctx->n_records, ntiles = (nd + XM_TILE - 1) / XM_TILE;
@@ -930,6 +956,8 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
             ctx->pm.dirty_boff = dboff;
         }
         HIPCHK(hipMemcpyAsync(*out + nn[0], ctx->d_result_buf, ctx->n_records * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream));
+        if (nx_words)  // (their bytes behind the clean winners' — the copies' places at the far end are not read again)
+            HIPCHK(hipMemcpyAsync(ctx->pm.mask + nn[0], nx_words, ctx->n_records, hipMemcpyDeviceToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         n += ctx->n_records;
         ctx->d_result_buf = ctx->d_result = nullptr;  // stays in the temp list

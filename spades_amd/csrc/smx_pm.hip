@@ -27,6 +27,8 @@ struct PmIndex {
     uint64_t nclean;
     const void *dk;                   // dirty region without the bytes
     RankDir ddir;                     // its rank directory (one bucket)
+    unsigned xs;                      // EXT_BITS: the records carry their InOutMask byte (EXT layout); 0: plain k-mers, the byte lives in `mask` alone ("nx", k without 8 spare record bits)
+    const uint8_t *mask;              // [records] InOutMask bytes (what an nx graph reads instead of the record's low byte)
 };
 
 struct PmWalk {  // what graph_from_masks (smx_construct.hpp) needs beyond the node table on this route
@@ -60,14 +62,14 @@ __device__ __forceinline__ uint32_t pm_partition(const Rec<NW> &y, const PmIndex
 
 // probe of one chunk's hash table through its group words (gm: ngroups words, in LDS or HBM); y = canonical k-mer without byte
 template <int NW>
-__device__ __forceinline__ node_t pm_probe(const Rec<NW> *__restrict__ recs, const uint32_t *gm, uint32_t T, uint64_t base, const Rec<NW> &y, uint32_t h32) {
+__device__ __forceinline__ node_t pm_probe(const Rec<NW> *__restrict__ recs, const uint32_t *gm, uint32_t T, uint64_t base, const Rec<NW> &y, uint32_t h32, unsigned xs = EXT_BITS) {
     uint32_t h = h32 & (T - 1);
     for (uint32_t it = 0; it < T; ++it) {
         const uint32_t g = gm[h >> 4];
         const uint32_t occ = g >> 16, bit = h & 15u;
         if (!((occ >> bit) & 1u)) return NODE_NONE;
         const uint64_t idx = base + (g & 0xFFFFu) + __popc(occ & ((1u << bit) - 1u));
-        if (rec_eq<NW>(rec_pure<NW>(recs[idx]), y)) return idx;
+        if (rec_eq<NW>(rec_pure_xs<NW>(recs[idx], xs), y)) return idx;
         h = (h + 1) & (T - 1);
     }
     return NODE_NONE;
@@ -81,7 +83,7 @@ __device__ __forceinline__ node_t pm_find(const PmIndex &ix, const Rec<NW> &y) {
         const node_t r = kmer_rank<NW, false>((const Rec<NW> *)ix.dk, ix.ddir, y);
         return r == NODE_NONE ? NODE_NONE : ix.nclean + r;
     }
-    return pm_probe<NW>((const Rec<NW> *)ix.recs, ix.meta + (size_t)(pi >> PM_BASE_BITS) * ix.ngroups, ix.T, pi & PM_BASE_MASK, y, rec_hash32<NW>(y));
+    return pm_probe<NW>((const Rec<NW> *)ix.recs, ix.meta + (size_t)(pi >> PM_BASE_BITS) * ix.ngroups, ix.T, pi & PM_BASE_MASK, y, rec_hash32<NW>(y), ix.xs);
 }
 // the same for a successor of a k-mer of the sorted tail: its partition was cut, and a path seldom leaves a cut partition at once — the
 // tail's own directory first (hash + directory word + record, no minimizer scan), the partition table only when it is not there
@@ -91,8 +93,8 @@ __device__ __forceinline__ node_t pm_find_from_tail(const PmIndex &ix, const Rec
     return r != NODE_NONE ? ix.nclean + r : pm_find<NW>(ix, y);
 }
 template <int NW>
-__device__ __forceinline__ Rec<NW> pm_node_kmer(const Rec<NW> *__restrict__ recs, node_t node, unsigned k) {  // oriented k-mer of a node
-    const Rec<NW> x = rec_pure<NW>(recs[node >> 1]);
+__device__ __forceinline__ Rec<NW> pm_node_kmer(const Rec<NW> *__restrict__ recs, node_t node, unsigned k, unsigned xs = EXT_BITS) {  // oriented k-mer of a node
+    const Rec<NW> x = rec_pure_xs<NW>(recs[node >> 1], xs);
     return (node & 1) ? rec_rc<NW>(x, k) : x;
 }
 
@@ -286,10 +288,10 @@ __global__ void __launch_bounds__(BLK) k_pm_remote(PmIndex ix, const unsigned lo
             for (uint32_t i = lane; i < n; i += 64) {
                 const node_t node = 2 * base + my[i];
                 const Rec<NW> raw = recs[node >> 1];
-                const unsigned m = (unsigned)(raw.w[NW - 1] & 0xFFu), o = (unsigned)(node & 1);
+                const unsigned m = ix.xs ? (unsigned)(raw.w[NW - 1] & 0xFFu) : (unsigned)ix.mask[node >> 1], o = (unsigned)(node & 1);
                 const unsigned mo = (o ? brev8(m) : m) & 15u;
                 unsigned yo;
-                const Rec<NW> y = pm_succ_kmer<NW>(rec_pure<NW>(raw), k, o, mo, yo);
+                const Rec<NW> y = pm_succ_kmer<NW>(rec_pure_xs<NW>(raw, ix.xs), k, o, mo, yo);
                 const node_t ry = pm_find<NW>(ix, y);
                 node_t e = (node_t)mo << TAB_OUT_SHIFT;
                 if (ry == NODE_NONE) atomicAdd(err, 1u);
@@ -309,8 +311,8 @@ __global__ void __launch_bounds__(BLK) k_pm_tab_dirty(PmIndex ix, uint64_t nd, u
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < nd; i += (uint64_t)gridDim.x * BLK) {
         const uint64_t r = ix.nclean + i;
         const Rec<NW> raw = recs[r];
-        const Rec<NW> x = rec_pure<NW>(raw);
-        const unsigned m = (unsigned)(raw.w[NW - 1] & 0xFFu);
+        const Rec<NW> x = rec_pure_xs<NW>(raw, ix.xs);
+        const unsigned m = ix.xs ? (unsigned)(raw.w[NW - 1] & 0xFFu) : (unsigned)ix.mask[r];
         bits += __popc(m);
         const unsigned x0 = rec_nucl<NW>(x, 0), xl = rec_nucl<NW>(x, k - 1);
         if (((m >> (3 - x0)) & 1) && range_is_rc_palindrome<NW>(x, 1, k - 1)) ++pals;
@@ -352,6 +354,18 @@ __global__ void k_pm_dirty_split(const void *recs_, uint64_t nclean, uint64_t nd
     }
 }
 
+// nx graph -> sorted k-mer file (pm_materialize_file): the plain records were sorted into the file; every k-mer of the old (partition-major) array
+// takes its byte to its place there
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_nx_file_masks(const void *old_, const uint8_t *old_mask, uint64_t n, const void *file_, RankDir dir, uint8_t *mask, uint32_t *err) {
+    const Rec<NW> *old = (const Rec<NW> *)old_, *file = (const Rec<NW> *)file_;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        const node_t r = kmer_rank<NW, false>(file, dir, old[i]);
+        if (r == NODE_NONE) atomicAdd(err, 1u);
+        else mask[r] = old_mask[i];
+    }
+}
+
 // ---- the reference's order of the start de-edges ------------------------------------------------------------------------------
 // Junction k-mers (EXT records, byte included) compacted in node order; tiles as k_cand_tiles (which also counts them per tile).
 template <int NW>
@@ -377,10 +391,11 @@ __global__ void __launch_bounds__(BLK) k_pm_junc_write(const uint8_t *mask, cons
 }
 // start de-edges of the junction k-mers in node order (the byte of the EXT record is the mask)
 template <int NW>
-__global__ void k_pm_cand_counts_node(const void *jn_, uint64_t nj, unsigned long long *cnt) {
+__global__ void k_pm_cand_counts_node(const void *jn_, uint64_t nj, unsigned long long *cnt, const uint8_t *mask /* nx: the graph's mask array, else nullptr */,
+                                      const unsigned long long *jrank_of) {
     const Rec<NW> *jn = (const Rec<NW> *)jn_;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nj; i += (uint64_t)gridDim.x * blockDim.x)
-        cnt[i] = cand_of_mask((unsigned)(jn[i].w[NW - 1] & 0xFFu));
+        cnt[i] = cand_of_mask(mask ? (unsigned)mask[jrank_of[i]] : (unsigned)(jn[i].w[NW - 1] & 0xFFu));
 }
 // start de-edges of every sorted junction k-mer (the reference's enumeration: its position in the file, then the de-edge)
 __global__ void k_pm_cand_counts(const uint8_t *jm, uint64_t nj, unsigned long long *cnt) {
@@ -399,16 +414,38 @@ __global__ void __launch_bounds__(BLK) k_pm_jrank(const void *jn_, uint64_t nj, 
         qbase[j] = jr == NODE_NONE ? 0ull : candoff[jr];
     }
 }
+// The same for an nx graph (plain k-mer records; the bytes are in the graph's mask array), in two steps, because the sorted junction file carries no
+// bytes from which the de-edges of the reference's order could be counted first: (1) every junction k-mer (node order) finds its place jr in the
+// sorted file, leaves it in qbase and puts ITS byte there (jm[jr]); then the caller counts and scans jm into candoff; (2) qbase[j] = candoff[jr].
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_pm_jrank_nx1(const void *jn_, uint64_t nj, const void *jk_, RankDir jix, const uint8_t *mask, const unsigned long long *jrank_of,
+                                                      unsigned long long *qbase, uint8_t *jm, uint32_t *err) {
+    const Rec<NW> *jn = (const Rec<NW> *)jn_;
+    const Rec<NW> *jk = (const Rec<NW> *)jk_;
+    for (uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x; j < nj; j += (uint64_t)gridDim.x * BLK) {
+        const node_t jr = kmer_rank<NW, false>(jk, jix, jn[j]);
+        if (jr == NODE_NONE) atomicAdd(err, 1u);
+        else jm[jr] = mask[jrank_of[j]];
+        qbase[j] = jr;
+    }
+}
+__global__ void k_pm_jrank_nx2(uint64_t nj, const unsigned long long *candoff, unsigned long long *qbase) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long jr = qbase[j];
+        qbase[j] = jr == NODE_NONE ? 0ull : candoff[jr];
+    }
+}
 // The start de-edges in node order (what k_cand_expand lists from the masks) with q[o] = their number in the reference's order: dense
 // over the junction k-mers — coff: first de-edge of the junction in node order, qbase: in the reference's order; then out bits of the
 // k-mer, out bits of its reverse complement (AddStartDeEdges, debruijn_graph_constructor.hpp:203-226).
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_pm_cand_expand(const void *jn_, const unsigned long long *jrank_of, uint64_t nj, const unsigned long long *coff,
-                                                        const unsigned long long *qbase, unsigned long long *cand, unsigned long long *q) {
+                                                        const unsigned long long *qbase, unsigned long long *cand, unsigned long long *q,
+                                                        const uint8_t *mask /* nx: the graph's mask array, else nullptr */) {
     const Rec<NW> *jn = (const Rec<NW> *)jn_;
     for (uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x; j < nj; j += (uint64_t)gridDim.x * BLK) {
-        const unsigned m = (unsigned)(jn[j].w[NW - 1] & 0xFFu);
         const unsigned long long r = jrank_of[j];
+        const unsigned m = mask ? (unsigned)mask[r] : (unsigned)(jn[j].w[NW - 1] & 0xFFu);
         unsigned long long o = coff[j], qq = qbase[j];
         for (unsigned cc = 0; cc < 4; ++cc)
             if (m & (1u << cc)) {
@@ -456,7 +493,7 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
     const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         const unsigned long long cd = cand[i];
-        const Rec<NW> x = pm_node_kmer<NW>(recs, cd >> 2, k);
+        const Rec<NW> x = pm_node_kmer<NW>(recs, cd >> 2, k, ix.xs);
         unsigned yo;
         const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, (unsigned)(cd & 3)), k, yo);
         // the first k-mer of the path: in the junction's own chunk 19 times in 20 (no minimizer scan, group word and record next to
@@ -466,7 +503,7 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
         if (rj < ix.nclean) {
             uint64_t cbase;
             const uint32_t cid = pm_chunk_of(cinfo, cob, nchunks, rj, cbase);
-            ry = pm_probe<NW>(recs, ix.meta + (size_t)cid * ix.ngroups, ix.T, cbase, y, rec_hash32<NW>(y));
+            ry = pm_probe<NW>(recs, ix.meta + (size_t)cid * ix.ngroups, ix.T, cbase, y, rec_hash32<NW>(y), ix.xs);
         }
         if (ry == NODE_NONE) ry = rj < ix.nclean ? pm_find<NW>(ix, y) : pm_find_from_tail<NW>(ix, y);
         if (ry == NODE_NONE) {
@@ -503,7 +540,7 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
         // equal (a hairpin: k_pm_keep walks it); flags: bit 0 keep, bit 2 undecided
         uint8_t fl = 0;
         if (node != NODE_NONE) {
-            const int cmp = rec_lex_cmp<NW>(x, pm_node_kmer<NW>(recs, node ^ 1, k));
+            const int cmp = rec_lex_cmp<NW>(x, pm_node_kmer<NW>(recs, node ^ 1, k, ix.xs));
             fl = cmp > 0 ? 1 : (cmp == 0 ? 4 : 0);
         }
         flags[i] = fl;
@@ -514,7 +551,7 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_pm_keep(const unsigned long long *cand, const unsigned long long *q, uint64_t C, const void *recs_, const node_t *succ,
                                                  unsigned k, const unsigned long long *len, const node_t *first, uint8_t *flags, unsigned long long *vq,
-                                                 unsigned long long *interior) {
+                                                 unsigned long long *interior, unsigned xs) {
     __shared__ unsigned long long scratch[BLK / 64 + 2];
     const Rec<NW> *recs = (const Rec<NW> *)recs_;
     unsigned long long inner = 0;
@@ -530,7 +567,7 @@ __global__ void __launch_bounds__(BLK) k_pm_keep(const unsigned long long *cand,
                 prev = a;
                 a = succ[a] & TAB_NODE_MASK;
             }
-            const unsigned c2 = 3u - rec_nucl<NW>(pm_node_kmer<NW>(recs, prev, k), 0);
+            const unsigned c2 = 3u - rec_nucl<NW>(pm_node_kmer<NW>(recs, prev, k, xs), 0);
             const unsigned c1 = (unsigned)(cd & 3);
             int cmp = c1 < c2 ? -1 : (c1 > c2 ? 1 : 0);
             a = first[i];
@@ -599,14 +636,14 @@ template <int NW>
 __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long *cand, const unsigned long long *q, uint64_t C, const void *recs_, const node_t *succ,
                                                        const uint32_t *jmp, unsigned k, const unsigned long long *len, const node_t *first, const node_t *last,
                                                        const uint8_t *flags, const unsigned long long *woffq, const unsigned long long *eidxq, uint64_t *words,
-                                                       ulonglong4 *erec /* [edges]: word offset, length, start node, end node | self << 63 */) {
+                                                       ulonglong4 *erec /* [edges]: word offset, length, start node, end node | self << 63 */, unsigned xs) {
     const Rec<NW> *recs = (const Rec<NW> *)recs_;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         if (!(flags[i] & 1)) continue;
         const unsigned long long qi = q[i];
         const unsigned long long cd = cand[i], n = len[i], e = eidxq[qi], wo = woffq[qi];
         const unsigned c = (unsigned)(cd & 3);
-        const Rec<NW> x = pm_node_kmer<NW>(recs, cd >> 2, k);
+        const Rec<NW> x = pm_node_kmer<NW>(recs, cd >> 2, k, xs);
         PmBitOut bo;
         bo.dst = words + wo;
 #pragma unroll
@@ -625,7 +662,7 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long 
             const node_t far = (node_t)((long long)node + (long long)(int16_t)(j & 0xFFFFu));
             if (s) {
                 if (s <= k && p + s <= n) {
-                    const Rec<NW> t = rec_shr_bits<NW>(pm_node_kmer<NW>(recs, far, k), 2 * (k - s));
+                    const Rec<NW> t = rec_shr_bits<NW>(pm_node_kmer<NW>(recs, far, k, xs), 2 * (k - s));
                     unsigned rem = 2 * s;
 #pragma unroll
                     for (int w = 0; w < NW; ++w)

@@ -60,13 +60,20 @@ inline uint32_t pm_host_bucket(const uint64_t *w, int nw, uint32_t B) {
 // another route); anything else: an error.
 template <int NW>
 int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
-    if (ctx->opt_pm_route == 0 || ctx->opt_ext_route == 0 || !ext_layout_fits(k, NW) || ctx->chunks.empty() || ctx->opt_derive_batches != 0 ||
+    if (ctx->opt_pm_route == 0 || ctx->opt_ext_route == 0 || ctx->chunks.empty() || ctx->opt_derive_batches != 0 ||
         ctx->opt_ext_presort == 0 || ctx->opt_early_at || ctx->opt_early_tip_bound > 0 || ctx->opt_batch_records > 0)
         return SMX_ROUTE_NA;
+    // k = 29, 31, 61, 63, 93, 95, 125, 127 leave the last record word no room for the InOutMask byte (EXT layout): the route then runs on PLAIN k-mer
+    // records ("nx") — the byte of every k-mer lives in the mask array the route keeps anyway, the junction k-mers are sorted without it and get it
+    // back by their rank lookups, the survivors of cut partitions gather theirs by a search in their own sorted set (round 5; option nx_route = 0:
+    // such k take the (k+1)-mer route as before)
+    const bool nx = !ext_layout_fits(k, NW);
+    if (nx && ctx->opt_nx_route == 0) return SMX_ROUTE_NA;
     const size_t W = sizeof(Rec<NW>);
     auto bail = [&](int rc) {  // leave nothing behind
         ctx->ext_mode = false;
         ctx->pm.active = false;
+        ctx->pm.nx = false;
         (void)hipStreamSynchronize(ctx->stream);
         for (auto &t : ctx->timings) {
             (void)hipEventDestroy(t.e0);
@@ -104,8 +111,9 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         ReadSel sel;
         sel.masks = &masks;
         sel.nrec = nwin;
-        ctx->ext_mode = true;
+        ctx->ext_mode = !nx;
         ctx->pm.active = true;
+        ctx->pm.nx = nx;
         rc = run_prededupe<NW>(ctx, k, sel, nwin, &recs, &n, out_cap);
         ctx->ext_mode = false;
         ctx->pm.active = false;
@@ -119,6 +127,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     free_temps(ctx, recs);
     ctx->g_kmers = recs;
     ctx->g_pm = true;
+    ctx->g_pm_nx = nx;
     ctx->g_nkmers = n;
     ctx->n_instances = nwin;
     arena_shrink(ctx, recs, (size_t)std::max<uint64_t>(n, 1) * W);
@@ -147,9 +156,14 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         Rec<NW> *dk;
         if ((rc = dalloc(ctx, &dk, P.ndirty, false))) return bail(rc);
         P.dk = dk;
-        hipLaunchKernelGGL((k_pm_dirty_split<NW>), dim3(grid_for(P.ndirty)), dim3(BLK), 0, ctx->stream, (const void *)recs, (uint64_t)P.nclean, (uint64_t)P.ndirty,
-                           (void *)dk, ctx->g_mask);
-        if (hipGetLastError() != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "k_pm_dirty_split launch failed"));
+        if (nx) {  // plain k-mers already, their bytes in the mask array already (run_prededupe): the directory's copy is a copy
+            if (hipMemcpyAsync(dk, recs + P.nclean, (size_t)P.ndirty * W, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                return bail(fail(ctx, SMX_DEVICE_ERROR, "copy of the sorted tail failed"));
+        } else {
+            hipLaunchKernelGGL((k_pm_dirty_split<NW>), dim3(grid_for(P.ndirty)), dim3(BLK), 0, ctx->stream, (const void *)recs, (uint64_t)P.nclean, (uint64_t)P.ndirty,
+                               (void *)dk, ctx->g_mask);
+            if (hipGetLastError() != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "k_pm_dirty_split launch failed"));
+        }
         if (P.dirty_boff.size() != (size_t)P.dirty_B + 1 || P.dirty_boff.back() != P.ndirty)
             return bail(fail(ctx, SMX_DEVICE_ERROR, "bucket offsets of the sorted tail do not add up (%llu of %llu)",
                              (unsigned long long)(P.dirty_boff.empty() ? 0 : P.dirty_boff.back()), (unsigned long long)P.ndirty));
@@ -171,6 +185,8 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     pw.ix.nclean = P.nclean;
     pw.ix.dk = P.dk;
     pw.ix.ddir = P.ddir;
+    pw.ix.xs = nx ? 0u : EXT_BITS;
+    pw.ix.mask = ctx->g_mask;
     uint32_t *d_err, *jmp;
     node_t *tab;
     unsigned long long *stats;
@@ -285,19 +301,76 @@ int pm_materialize_file(smx_ctx *ctx, bool for_view) {
     void *src = ctx->g_kmers;
     uint8_t *old_mask = ctx->g_mask;
     const uint64_t nkpo = ctx->g_nkpo;
+    const bool nx = ctx->g_pm_nx;
     ctx->g_kmers = nullptr;
     ctx->g_mask = nullptr;
     ctx->g_pm = false;
+    ctx->g_pm_nx = false;
     pm_release(ctx);  // no lookups on the old numbering from here on
-    arena_put(ctx, old_mask);
+    if (!nx) arena_put(ctx, old_mask);
     ctx->d_result = ctx->d_result_buf = nullptr;
-    ctx->ext_mode = true;
-    int rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, src, D0, nullptr, /*recs_reusable=*/true, false, /*distinct_hint=*/true);
-    ctx->ext_mode = false;
-    if (rc == 0) {
-        if (ctx->d_result_buf != src) arena_put(ctx, src);
-        src = nullptr;
-        rc = ext_result_to_file<NW>(ctx, k, B, /*whole=*/true);
+    int rc;
+    if (!nx) {
+        ctx->ext_mode = true;
+        rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, src, D0, nullptr, /*recs_reusable=*/true, false, /*distinct_hint=*/true);
+        ctx->ext_mode = false;
+        if (rc == 0) {
+            if (ctx->d_result_buf != src) arena_put(ctx, src);
+            src = nullptr;
+            rc = ext_result_to_file<NW>(ctx, k, B, /*whole=*/true);
+        }
+    } else {
+        // Plain records, the bytes beside them: a COPY goes through the sort (the old array stays), the file's rank directory is built, and every
+        // k-mer of the old array takes its byte to its place in the file (k_nx_file_masks). Costs one more copy of the records than the EXT
+        // layout needs; an input for which that does not fit gets the memory-limit code here.
+        rc = run_count<NW>(ctx, k, SMX_MODE_ALL, B, src, D0, nullptr, /*recs_reusable=*/false, false, /*distinct_hint=*/true);
+        uint8_t *new_mask = nullptr;
+        Rec<NW> *file = nullptr;
+        smx::RankDir dir{};
+        if (rc == 0 && ctx->n_records != D0) rc = fail(ctx, SMX_DEVICE_ERROR, "k-mer file: %llu records after the sort, %llu k-mers in the graph", (unsigned long long)ctx->n_records, (unsigned long long)D0);
+        const size_t mask_bytes = (size_t)((D0 + 7) / 8 * 8 + 8);
+        if (rc == 0) rc = dalloc(ctx, &file, D0 + 1, false);
+        if (rc == 0) rc = dalloc(ctx, &new_mask, mask_bytes, false);
+        uint32_t *d_e = nullptr;
+        if (rc == 0) rc = dalloc(ctx, &d_e, 1);
+        if (rc == 0) {
+            const std::vector<uint64_t> boff = ctx->bucket_off;
+            hipError_t e = hipMemcpyAsync(file, ctx->d_result_buf, (size_t)D0 * sizeof(Rec<NW>), hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(new_mask, 0, mask_bytes, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_e, 0, 4, ctx->stream);
+            if (e != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "k-mer file of a plain-record graph: %s", hipGetErrorString(e));
+            if (rc == 0) rc = build_rank_dir<NW>(ctx, file, D0, boff, B, k, dir);
+            if (rc == 0) {
+                hipLaunchKernelGGL((k_nx_file_masks<NW>), dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, (const void *)src, (const uint8_t *)old_mask, D0, (const void *)file, dir,
+                                   new_mask, d_e);
+                uint32_t he = 0;
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipMemcpyAsync(&he, d_e, 4, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "k-mer file of a plain-record graph: %s", hipGetErrorString(e));
+                else if (he) rc = fail(ctx, SMX_DEVICE_ERROR, "k-mer file of a plain-record graph: %u k-mers are missing from their own sorted file", he);
+            }
+            drop_rank_dir(ctx, dir);
+            if (rc == 0) {
+                ctx->g_kmers = file;
+                ctx->g_mask = new_mask;
+                file = nullptr;
+                new_mask = nullptr;
+                ctx->g_kboff = boff;
+                ctx->g_nkmers = D0;
+                ctx->n_records = D0;
+                ctx->bucket_off = boff;
+                ctx->K = k;
+                ctx->nw = NW;
+                ctx->num_buckets = B;
+            }
+        }
+        arena_put(ctx, file);
+        arena_put(ctx, new_mask);
+        arena_put(ctx, old_mask);
+        if (ctx->d_result_buf && ctx->d_result_buf != src) {  // the sorted copy (a temporary of run_count)
+            ctx->d_result_buf = ctx->d_result = nullptr;
+        }
     }
     if (src) arena_put(ctx, src);
     (void)hipStreamSynchronize(ctx->stream);

@@ -320,14 +320,15 @@ __device__ __forceinline__ Rec<NW> rec_roll_rc(const Rec<NW> &y, unsigned K, uin
 
 // LDS (dynamic): sl[scap * SW] u64 | tab[T] u32 | grp[NT] u32 | segl[NT] u16 | seglast[NT] u16 | nbv[scap -> x4] u8 | cl[scap] u8
 // NT threads = segments per chunk at most; T = 16 * NT table slots (thread g owns occupancy group g); scap <= min(NT, 512) slots.
-// MODE: 0 plain, 1 EXT, 2 EXT + partition-major output (see the head of this file).
+// MODE: 0 plain, 1 EXT, 2 EXT + partition-major output (see the head of this file), 3 partition-major output with PLAIN k-mer records ("nx": k without
+// 8 spare bits in the last record word — the byte a winner gathered goes to the mask array alone, for the winners of cut partitions too).
 template <int NW, int MODE, int NT>
 __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__restrict__ slots, const unsigned long long *__restrict__ slot_off, unsigned K,
                                                     const SkmChunk *__restrict__ chunks, uint32_t nlist, uint32_t scap, void *out_, unsigned long long out_cap,
                                                     unsigned long long clean_cap, unsigned long long dirty_cap, unsigned long long *out_count,
                                                     unsigned long long *dirty_count, unsigned long long *err, unsigned long long *prof, PmOut pm) {
     constexpr int SW = 2 * NW, SEG = SkmSeg<NW>::value, SB = SMX_SB;
-    constexpr bool EXT = MODE >= 1, PM = MODE == 2;
+    constexpr bool EXT = MODE >= 1, PM = MODE >= 2, NX = MODE == 3;
     constexpr uint32_t T = 16u * NT, EMPTY = 0xFFFFFFFFu;
     static_assert(SEG % SB == 0, "segments are worked through in sub-batches");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
@@ -649,6 +650,9 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
                     Rec<NW> cx;
 #pragma unroll
                     for (int i = 0; i < NW; ++i) cx.w[i] = fwd ? x.w[i] : y.w[i];
+                    if constexpr (NX) {
+                        if (dirty) stm[r] = (uint8_t)eb;  // (nx: the byte of a cut partition's winner travels in the mask array as well)
+                    }
                     if constexpr (PM) {
                         if (!dirty) {
                             stm[r] = (uint8_t)eb;
@@ -677,7 +681,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
                             }
                         }
                     }
-                    if constexpr (EXT) cx.w[NW - 1] = (cx.w[NW - 1] << EXT_BITS) | eb;
+                    if constexpr (EXT && !NX) cx.w[NW - 1] = (cx.w[NW - 1] << EXT_BITS) | eb;
                     stg[r] = cx;
                 }
                 {
@@ -706,7 +710,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
                 Rec<NW> *dst = out + gb + r0;
                 for (uint32_t i = t; i < nr; i += NT) dst[i] = stg[i];
                 if constexpr (PM) {
-                    if (!dirty) {
+                    if (!dirty || NX) {
                         uint8_t *md = pm.mask + gb + r0;
                         for (uint32_t i = t; i < nr; i += NT) md[i] = stm[i];
                     }
@@ -731,6 +735,30 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
     if constexpr (PM)
         if (npal) atomicAdd(pm.pals, (unsigned long long)npal);
 #undef SKM_T
+}
+
+// nx (MODE 3): the winners of cut partitions left the stage as plain k-mers with their bytes beside them; the k-mers have been sorted and made
+// unique since (bucket-major in DB hash buckets, `sorted`), and every copy's byte has to reach its k-mer: bucket of the copy, binary search in the
+// bucket's slice, atomic OR into a word array (4 bytes per word; cleared by the caller).
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_nx_dirty_masks(const void *copies_, const uint8_t *bytes, uint64_t n, const void *sorted_, const unsigned long long *boff, uint32_t DB,
+                                                        uint32_t *words, uint32_t *err) {
+    const Rec<NW> *copies = (const Rec<NW> *)copies_, *sorted = (const Rec<NW> *)sorted_;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        const Rec<NW> x = copies[i];
+        const uint32_t b = bucket_of(xxh3_rec<NW>(x), DB);
+        uint64_t lo = boff[b], hi = boff[b + 1];
+        while (lo < hi) {  // first record >= x
+            const uint64_t mid = (lo + hi) >> 1;
+            if (rec_less<NW>(sorted[mid], x)) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo >= boff[b + 1] || !rec_eq<NW>(sorted[lo], x)) {
+            atomicAdd(err, 1u);
+            continue;
+        }
+        atomicOr(&words[lo >> 2], (uint32_t)bytes[i] << (8u * (unsigned)(lo & 3u)));
+    }
 }
 
 }  // namespace smx

@@ -86,7 +86,9 @@ def test_gfa_equals_spades_gbuilder(case, tmp_path, route):
     took = "pm" if "pm_tab" in names else ("ext" if "kmers:ext_merge" in names else "kpo")
     nw = (g["k"] + 31) // 32
     fits = g["k"] >= 21 and 2 * g["k"] + 8 <= 64 * nw
-    assert took == (route if fits else "kpo")
+    # (round 5: where the byte has no room in the record — k = 127 here — the default route runs on plain records with the bytes beside them; the sorted
+    # route of the same count still needs the EXT layout and falls back to the (k+1)-mer file)
+    assert took == (route if fits else ("pm" if route == "pm" else "kpo"))
     out = str(tmp_path / "g.gfa")
     gb.write_gfa(out)
     assert info["n_unitigs"] == g["gfa_S_lines"]
