@@ -598,8 +598,16 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     node_rounds = _rounds_of(n2, WALK_CHUNK, dev)
     prev, rounds = -1, 0
     too_long = False
+    def chunks_of_nodes():
+        # (every pass over the node array goes chunk by chunk: an elementwise expression over all 2 x |shard| words makes temporaries of that size —
+        # 40 GiB each at the 2.7 G k-mers of a 62.5 M-read share, where the first run of this path at that size ran out of memory, round 5)
+        for c_ in range(node_rounds):
+            yield min(c_ * WALK_CHUNK, n2), min((c_ + 1) * WALK_CHUNK, n2)
+
     while True:
-        tot = is_open(word, flag).sum().reshape(1)
+        tot = torch.zeros(1, dtype=torch.int64, device=dev)
+        for a, b in chunks_of_nodes():
+            tot += is_open(word[a:b], flag[a:b]).sum()
         dist.all_reduce(tot)
         tot = int(tot.item())
         if tot == 0 or tot == prev:  # every round ends at least one k-mer of every open chain: what is left runs in circles
@@ -630,17 +638,25 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         if too_long:
             raise RuntimeError(f"a chain of 2^{HB} k-mers or more: beyond the packed hop count of the distributed walks")
     _guarded(dev, "chain lengths", check_hops)
-    left = is_open(word, flag).nonzero().squeeze(1)
+    left = [is_open(word[a:b], flag[a:b]).nonzero().squeeze(1) + a for a, b in chunks_of_nodes()]
+    left = torch.cat(left) if left else torch.empty(0, dtype=torch.int64, device=dev)
     loop_local = torch.unique(left >> 1) if left.numel() else torch.empty(0, dtype=torch.int64, device=dev)
     del left
-    done = ((flag & 1) != 0) & (word < 0)
+    done = torch.empty(n2, dtype=torch.bool, device=dev)
+    for a, b in chunks_of_nodes():
+        done[a:b] = ((flag[a:b] & 1) != 0) & (word[a:b] < 0)
 
     mark("doubling")
     # 3. every chain k-mer to the head of its chain. A node is a head when the reverse strand's node of its k-mer is a tail; the heads'
     #    bookkeeping (chain length, offset of its nucleotides, end node) is kept per HEAD (hidx: their local nodes, ascending), not per node
-    rev_tail = ((word & TBIT) != 0).view(-1, 2).flip(1).reshape(-1) if n2 else torch.zeros(0, dtype=torch.bool, device=dev)
-    hidx = (done & rev_tail).nonzero().squeeze(1)
-    del rev_tail
+    hidx = []
+    pair_chunk = max(2, WALK_CHUNK // 2 * 2)  # (whole k-mers per chunk: the two nodes of a k-mer are looked at together)
+    for a in range(0, n2, pair_chunk):
+        b = min(a + pair_chunk, n2)
+        rev_tail = ((word[a:b] & TBIT) != 0).view(-1, 2).flip(1).reshape(-1)
+        hidx.append((done[a:b] & rev_tail).nonzero().squeeze(1) + a)
+        del rev_tail
+    hidx = torch.cat(hidx) if hidx else torch.empty(0, dtype=torch.int64, device=dev)
     hw = word[hidx]
     hlen = torch.where((hw & TBIT) != 0, torch.zeros_like(hw), hw & HM) + 1  # k-mers of the chain (a head that is its own tail: 1)
     del hw
