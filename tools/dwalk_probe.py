@@ -30,7 +30,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    words, start, ln, codes = bench.synth_reads_device(1, genome, n_reads, dev, n_rate=0.001)
+    words, start, ln, codes = bench.synth_reads_device(int(os.environ.get("DWALK_SEED", "1")), genome, n_reads, dev, n_rate=0.001)  # (DWALK_SEED=1000: the bench's batch)
     del codes
     torch.cuda.synchronize()
     gb = GraphBuilder(k, T)
@@ -89,6 +89,8 @@ def main():
     fp1 = gb.fingerprint_portable()
     print("fingerprints:", fp0, fp1, flush=True)
     print("fingerprint walks:", fp1, flush=True)
+    import hashlib
+    print("fingerprint md5 (bench.py's graph_fingerprint):", hashlib.md5(b"".join(int(v).to_bytes(8, "little") for v in fp1)).hexdigest(), flush=True)
     print(f"distributed walks: {t_dw:.3f} s, {info['walk_rounds']} doubling rounds, {info['n_unitigs']} unitigs, {info['n_loops']} loops; "
           + (f"graph identical to the single-GPU build: {fp0 == fp1}" if fp0 is not None else "reference build in another process"), flush=True)
     print(f"torch peak memory: {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB; kmers_per_rank {info.get('kmers_per_rank')}", flush=True)
