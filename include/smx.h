@@ -61,6 +61,13 @@ int smx_trim(smx_ctx *ctx, size_t *bytes_returned);
  * work from the device's free memory (hipMemGetInfo) must add this — the arena only grows, so what the library released after a big
  * step is invisible to the device-level figure. No reference equivalent (the reference has no device). */
 int smx_arena_free_bytes(smx_ctx *ctx, size_t *bytes);
+/* A block of the context's device arena for the CALLER's own use (bytes, 256-byte aligned), and its return. For a neighbour whose working arrays
+ * must live next to what the library holds — the walk state of spades_amd.dist.distributed_walks, 9–10 B per oriented node of the rank's shard: the
+ * arena only grows and gives nothing back before smx_destroy, so after the library's big steps (the sharded count peaks at ~2x the shard) a framework
+ * allocator finds the device full although half of the arena is free. The block stays valid until smx_pool_free or smx_destroy; the library never
+ * reads or writes it. SMX_MEMORY_LIMIT_EXCEEDED when the arena (and the HBM budget) cannot hold it. No reference equivalent. */
+int smx_pool_alloc(smx_ctx *ctx, size_t bytes, void **d_block);
+int smx_pool_free(smx_ctx *ctx, void *d_block);
 const char *smx_last_error(const smx_ctx *ctx);
 const char *smx_version(void);
 /* Options. Behaviour switches of the reference's spades-core Construction stage (defaults reproduce spades-gbuilder):

@@ -43,6 +43,8 @@ def load():
         "smx_destroy": (None, [vp]),
         "smx_trim": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
         "smx_arena_free_bytes": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+        "smx_pool_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+        "smx_pool_free": (C.c_int, [vp, vp]),
         "smx_graph_clear": (C.c_int, [vp]),
         "smx_last_error": (C.c_char_p, [vp]),
         "smx_version": (C.c_char_p, []),

@@ -27,6 +27,7 @@
 #include <ctime>
 #include <cstdlib>
 #include <map>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -114,6 +115,8 @@ void smx_destroy(smx_ctx *ctx) {
     clear_graph(ctx);
     clear_result(ctx);
     free_temps(ctx);
+    for (void *p : ctx->pool_blocks) arena_put(ctx, p);  // (a caller's blocks it did not return: they end with the context)
+    ctx->pool_blocks.clear();
     arena_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -900,6 +903,27 @@ int smx_arena_free_bytes(smx_ctx *ctx, size_t *bytes) {
         for (auto &b : ctx->arena_free) cached += b.second;
     }
     *bytes = cached;
+    return SMX_OK;
+}
+
+int smx_pool_alloc(smx_ctx *ctx, size_t bytes, void **d_block) {
+    if (!ctx || !d_block) return SMX_INVALID_PARAMETER;
+    *d_block = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    void *p = arena_get(ctx, std::max<size_t>(bytes, 256), /*top=*/true);
+    if (!p) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "no room for a caller's block of %zu bytes in the device arena (%.1f GB obtainable)", bytes, (double)arena_avail(ctx) / 1e9);
+    ctx->pool_blocks.insert(p);
+    *d_block = p;
+    return SMX_OK;
+}
+int smx_pool_free(smx_ctx *ctx, void *d_block) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    if (!d_block) return SMX_OK;
+    auto it = ctx->pool_blocks.find(d_block);
+    if (it == ctx->pool_blocks.end()) return fail(ctx, SMX_INVALID_PARAMETER, "smx_pool_free: not a block smx_pool_alloc handed out");
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->pool_blocks.erase(it);
+    arena_put(ctx, d_block);
     return SMX_OK;
 }
 

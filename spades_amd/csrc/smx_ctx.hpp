@@ -104,6 +104,7 @@ struct smx_ctx {
     int64_t opt_pm_route = -1;  // construction without the sort of the k-mers: -1 where it applies, 0 never, 1 = -1
     int64_t opt_nx_route = 1;   // ... also for k whose record has no 8 spare bits, on plain k-mer records (0: those k take the (k+1)-mer route as until round 5)
     bool ext_mode = false;    // the count in flight carries extension bytes in its records (EXT layout, smx_device.hpp): set by the construction
+    std::set<void *> pool_blocks;  // blocks handed to the caller by smx_pool_alloc (returned at smx_destroy at the latest)
     void *x_owned = nullptr;  // output of smx_extract_partition_owned (released by the next extract / smx_extract_release)
     void *x_recv = nullptr;   // smx_exchange_buffer: receive side of the exchange, consumed by smx_count_records
     bool single_batch_only = false;  // count_reads: fail (memory limit) rather than cut the input into batches

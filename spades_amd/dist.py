@@ -142,6 +142,25 @@ class GpuEngine:
     def extract_release(self):
         _chk(self.ctx._h, self.ctx.lib.smx_extract_release(self.ctx._h))
 
+    def state(self, n: int, dtype, dev):
+        """a long-lived working array of the CALLER inside the library's device arena (smx_pool_alloc), as a tensor view: (tensor of n elements, handle for
+        state_free). The arena only grows: after the library's big steps a framework allocator finds the device full although half of the arena is free —
+        the walk state of distributed_walks (9-10 B per oriented node of the shard) lives where that room is. Not initialised."""
+        item = torch.empty(0, dtype=dtype).element_size()
+        words = (max(n, 1) * item + 7) // 8
+        ptr = C.c_void_p()
+        _chk(self.ctx._h, self.ctx.lib.smx_pool_alloc(self.ctx._h, words * 8, C.byref(ptr)))
+        t = torch.as_tensor(_DevView(ptr.value, words), device=dev)
+        if dtype != torch.int64:
+            t = t.view(torch.uint8)
+            if dtype != torch.uint8:
+                t = t.view(dtype)
+        return t[:n], ptr.value
+
+    def state_free(self, handle):
+        if handle:
+            _chk(self.ctx._h, self.ctx.lib.smx_pool_free(self.ctx._h, handle))
+
     def arena_free_bytes(self) -> int:
         return self.ctx.arena_free_bytes()
 
@@ -568,8 +587,25 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     FBIT, TBIT, IDM, HM = -(1 << 63), 1 << 62, (1 << (62 - HB)) - 1, (1 << HB) - 1
     if 2 * first[-1] > IDM:
         raise ValueError(f"{first[-1]} k-mers: node ids beyond {62 - HB} bits")
-    word = torch.zeros(n2, dtype=torch.int64, device=dev)
-    flag = torch.zeros(n2, dtype=torch.uint8, device=dev)
+    # (the arrays of the size of the shard's node set live in the library's arena where the engine offers that — GpuEngine.state: after the sharded
+    # count the arena holds ~2x the shard and gives nothing back, a 4.3 G-k-mer shard left torch 0 bytes of a 288 GB device, round 5 — and are torch's
+    # own on the CPU doubles)
+    _state = getattr(engine, "state", None)
+    _handles = []
+
+    def big(n, dtype, zero):
+        if _state is None:
+            return torch.zeros(n, dtype=dtype, device=dev) if zero else torch.empty(n, dtype=dtype, device=dev)
+        t, h = _state(n, dtype, dev)
+        _handles.append(h)
+        return t.zero_() if zero else t
+
+    def free_big(keep_last=0):  # (in allocation order; the views of what is freed must be gone)
+        while len(_handles) > keep_last:
+            engine.state_free(_handles.pop(0))
+
+    word = big(n2, torch.int64, True)
+    flag = big(n2, torch.uint8, True)
     # (range by range: the requests of WALK_CHUNK oriented nodes at a time — a k-mer record out and a node id back per request; all at once
     # the exchange buffers of a shard were 48 B per oriented node, the peak of the whole construction)
     for c in range(_rounds_of(n2, WALK_CHUNK, dev)):
@@ -642,7 +678,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     left = torch.cat(left) if left else torch.empty(0, dtype=torch.int64, device=dev)
     loop_local = torch.unique(left >> 1) if left.numel() else torch.empty(0, dtype=torch.int64, device=dev)
     del left
-    done = torch.empty(n2, dtype=torch.bool, device=dev)
+    done = big(n2, torch.bool, False)
     for a, b in chunks_of_nodes():
         done[a:b] = ((flag[a:b] & 1) != 0) & (word[a:b] < 0)
 
@@ -663,7 +699,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     hoff = torch.cumsum(hlen, 0) - hlen
     hend = torch.full_like(hlen, -1)
     total = int(hlen.sum().item()) if hidx.numel() else 0
-    bases = torch.zeros(max(total, 1), dtype=torch.uint8, device=dev)
+    bases = big(max(total, 1), torch.uint8, True)
     n_heads = hidx.numel()
 
     def head_slot(local_nodes):
@@ -721,6 +757,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
             raise RuntimeError("a chain whose end node never reached its head")
     _guarded(dev, "chain nucleotides at the heads", placed)
     del done, flag, word
+    free_big(keep_last=1)  # (the chain nucleotides stay until the chains have been fetched)
 
     mark("chain nucleotides to the heads")
     # 4. the chains behind this rank's start de-edges
@@ -765,6 +802,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     if my_bases.numel() == 0:
         my_bases = torch.zeros(1, dtype=torch.uint8, device=dev)
     del hidx, hlen, hoff, hend, bases, pieces
+    free_big()  # (word / flag / done / bases: views of arena blocks — nothing refers to them any more)
     # (no torch.cuda.empty_cache() here: VRAM that one allocator has just released is not safe for the next one to take at once on this
     # stack — arena_trim in csrc/smx_ctx.hpp has the measurements)
     _sync(dev)
