@@ -678,9 +678,8 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     left = torch.cat(left) if left else torch.empty(0, dtype=torch.int64, device=dev)
     loop_local = torch.unique(left >> 1) if left.numel() else torch.empty(0, dtype=torch.int64, device=dev)
     del left
-    done = big(n2, torch.bool, False)
-    for a, b in chunks_of_nodes():
-        done[a:b] = ((flag[a:b] & 1) != 0) & (word[a:b] < 0)
+    def done_of(a, b):  # finished chain k-mers among the nodes [a, b) (computed where it is needed: one byte per node less to hold)
+        return ((flag[a:b] & 1) != 0) & (word[a:b] < 0)
 
     mark("doubling")
     # 3. every chain k-mer to the head of its chain. A node is a head when the reverse strand's node of its k-mer is a tail; the heads'
@@ -690,7 +689,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     for a in range(0, n2, pair_chunk):
         b = min(a + pair_chunk, n2)
         rev_tail = ((word[a:b] & TBIT) != 0).view(-1, 2).flip(1).reshape(-1)
-        hidx.append((done[a:b] & rev_tail).nonzero().squeeze(1) + a)
+        hidx.append((done_of(a, b) & rev_tail).nonzero().squeeze(1) + a)
         del rev_tail
     hidx = torch.cat(hidx) if hidx else torch.empty(0, dtype=torch.int64, device=dev)
     hw = word[hidx]
@@ -715,7 +714,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     n_got_all, bad_head = 0, False
     for c in range(node_rounds):
         a, b = min(c * WALK_CHUNK, n2), min((c + 1) * WALK_CHUNK, n2)
-        xs = done[a:b].nonzero().squeeze(1) + a
+        xs = done_of(a, b).nonzero().squeeze(1) + a
         xr = xs ^ 1
         wr = word[xr]
         head = tail_of(xr + base, wr) ^ 1
@@ -756,7 +755,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         if n_heads and bool((hend < 0).any().item()):
             raise RuntimeError("a chain whose end node never reached its head")
     _guarded(dev, "chain nucleotides at the heads", placed)
-    del done, flag, word
+    del flag, word
     free_big(keep_last=1)  # (the chain nucleotides stay until the chains have been fetched)
 
     mark("chain nucleotides to the heads")
@@ -802,7 +801,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     if my_bases.numel() == 0:
         my_bases = torch.zeros(1, dtype=torch.uint8, device=dev)
     del hidx, hlen, hoff, hend, bases, pieces
-    free_big()  # (word / flag / done / bases: views of arena blocks — nothing refers to them any more)
+    free_big()  # (bases: a view of an arena block — nothing refers to it any more)
     # (no torch.cuda.empty_cache() here: VRAM that one allocator has just released is not safe for the next one to take at once on this
     # stack — arena_trim in csrc/smx_ctx.hpp has the measurements)
     _sync(dev)
