@@ -591,21 +591,23 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     # count the arena holds ~2x the shard and gives nothing back, a 4.3 G-k-mer shard left torch 0 bytes of a 288 GB device, round 5 — and are torch's
     # own on the CPU doubles)
     _state = getattr(engine, "state", None)
-    _handles = []
+    _handles = {}
 
-    def big(n, dtype, zero):
+    def big(name, n, dtype, zero):
         if _state is None:
             return torch.zeros(n, dtype=dtype, device=dev) if zero else torch.empty(n, dtype=dtype, device=dev)
         t, h = _state(n, dtype, dev)
-        _handles.append(h)
+        _handles[name] = h
         return t.zero_() if zero else t
 
-    def free_big(keep_last=0):  # (in allocation order; the views of what is freed must be gone)
-        while len(_handles) > keep_last:
-            engine.state_free(_handles.pop(0))
+    def free_big(*names):  # (the tensor views of what is freed must be gone)
+        for nm in names:
+            h = _handles.pop(nm, None)
+            if h:
+                engine.state_free(h)
 
-    word = big(n2, torch.int64, True)
-    flag = big(n2, torch.uint8, True)
+    word = big("word", n2, torch.int64, True)
+    flag = big("flag", n2, torch.uint8, True)
     # (range by range: the requests of WALK_CHUNK oriented nodes at a time — a k-mer record out and a node id back per request; all at once
     # the exchange buffers of a shard were 48 B per oriented node, the peak of the whole construction)
     for c in range(_rounds_of(n2, WALK_CHUNK, dev)):
@@ -698,7 +700,7 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
     hoff = torch.cumsum(hlen, 0) - hlen
     hend = torch.full_like(hlen, -1)
     total = int(hlen.sum().item()) if hidx.numel() else 0
-    bases = big(max(total, 1), torch.uint8, True)
+    bases = big("bases", max(total, 1), torch.uint8, True)
     n_heads = hidx.numel()
 
     def head_slot(local_nodes):
@@ -756,14 +758,15 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
             raise RuntimeError("a chain whose end node never reached its head")
     _guarded(dev, "chain nucleotides at the heads", placed)
     del flag, word
-    free_big(keep_last=1)  # (the chain nucleotides stay until the chains have been fetched)
+    free_big("word", "flag")  # (the chain nucleotides stay until the chains have been fetched)
 
     mark("chain nucleotides to the heads")
     # 4. the chains behind this rank's start de-edges
     q = (~c_fj).nonzero().squeeze(1)
-    steps = torch.zeros(n_cand, dtype=torch.int64, device=dev)
-    last = c_first.clone()
-    boff = torch.zeros(n_cand + 1, dtype=torch.int64, device=dev)
+    steps = big("steps", max(n_cand, 1), torch.int64, True)[:n_cand]
+    last = big("last", max(n_cand, 1), torch.int64, False)[:n_cand]
+    last.copy_(c_first)
+    boff = big("boff", n_cand + 1, torch.int64, True)
     pieces, have, headless = [], 0, False
     for c in range(_rounds_of(q.numel(), WALK_START_CHUNK, dev)):
         qc = q[c * WALK_START_CHUNK:(c + 1) * WALK_START_CHUNK]
@@ -797,11 +800,17 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         if headless:
             raise RuntimeError("a start de-edge leads to a k-mer that heads no chain")
     _guarded(dev, "chains behind the start de-edges", check_chains)
-    my_bases = torch.cat(pieces) if len(pieces) > 1 else (pieces[0] if pieces else torch.zeros(1, dtype=torch.uint8, device=dev))
-    if my_bases.numel() == 0:
-        my_bases = torch.zeros(1, dtype=torch.uint8, device=dev)
-    del hidx, hlen, hoff, hend, bases, pieces
-    free_big()  # (bases: a view of an arena block — nothing refers to it any more)
+    del hidx, hlen, hoff, hend, bases
+    free_big("bases")
+    # the fetched chains in one array (piece after piece into place: a torch.cat would hold them twice)
+    my_bases = big("my_bases", max(have, 1), torch.uint8, have == 0)
+    at = 0
+    while pieces:
+        pc = pieces.pop(0)
+        my_bases[at:at + pc.numel()] = pc
+        at += pc.numel()
+        del pc
+    del pieces
     # (no torch.cuda.empty_cache() here: VRAM that one allocator has just released is not safe for the next one to take at once on this
     # stack — arena_trim in csrc/smx_ctx.hpp has the measurements)
     _sync(dev)
@@ -810,6 +819,8 @@ def distributed_walks(engine, k: int, rank: int, world: int, dev, kmers_per_rank
         print(f"[dist] walks: rank {rank}: {n_cand} start de-edges, steps max {int(steps.max().item())} sum {int(steps.sum().item())}, "
               f"{my_bases.numel()} nucleotides fetched", flush=True)
     unitigs = _guarded(dev, "unitigs of the shard", engine.shard_unitigs, first[rank], steps, last, boff, my_bases, dev)
+    del steps, last, boff, my_bases
+    free_big("steps", "last", "boff", "my_bases")
     mark("unitigs")
     return unitigs, loop_local, rounds
 
