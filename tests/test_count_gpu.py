@@ -179,3 +179,30 @@ def test_trim_and_one_parked_arena_per_device():
         c.close()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < (8 << 30), "parked arenas pile up"
+
+
+def test_pool_blocks_for_the_callers_own_arrays():
+    """smx_pool_alloc / smx_pool_free (round 5): blocks of the context's device arena for a neighbour's working arrays (dist.distributed_walks keeps its per-node
+    state there). Distinct, aligned, returned once; a block that cannot be had is the memory-limit code; what the caller forgets ends with the context; a
+    count next to live blocks is still the oracle's."""
+    import ctypes as C
+    from oracle import oracle
+    from spades_amd import KMerDiskCounter, ReadKMerSplitter
+    from spades_amd.kmercount import Context
+    ctx = Context(hbm_budget=1 << 30)
+    lib, h = ctx.lib, ctx._h
+    a, b = C.c_void_p(), C.c_void_p()
+    assert lib.smx_pool_alloc(h, 1000, C.byref(a)) == 0 and lib.smx_pool_alloc(h, 5 << 20, C.byref(b)) == 0
+    assert a.value and b.value and a.value != b.value and a.value % 256 == 0 and b.value % 256 == 0
+    big = C.c_void_p(123)
+    assert lib.smx_pool_alloc(h, 8 << 30, C.byref(big)) == 68 and not big.value  # beyond the context's budget
+    reads = _synth(5, 3000, 300, 100)
+    sp = ReadKMerSplitter(21, "A", ctx)
+    sp.push_back_reads(reads)
+    st = KMerDiskCounter(None, sp).Count(16)
+    ref, rs = oracle.count(reads, 21, "A", 16)
+    assert (st.bucket_sizes() == rs).all() and (st.records() == ref).all()
+    assert lib.smx_pool_free(h, a) == 0
+    assert lib.smx_pool_free(h, a) == 67  # not (any more) a block of the pool
+    assert lib.smx_pool_free(h, None) == 0
+    ctx.close()  # (b goes with the context)
