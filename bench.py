@@ -355,10 +355,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=float, default=100e6, help="reads per GPU (weak scaling)")
+    ap.add_argument("--reads", type=float, default=None,
+                    help="reads per GPU (weak scaling); default: 100e6 at N = 1 (BASELINE config 3), 125e6 per GPU on the sharded path (BASELINE config 4: 1 B reads on 8 GPUs)")
     ap.add_argument("--k", type=int, default=55)
     ap.add_argument("--threads", type=int, default=16, help="the reference's -t that the output order reproduces: 10 x threads buckets")
-    ap.add_argument("--genome", type=float, default=500e6)
+    ap.add_argument("--genome", type=float, default=None,
+                    help="genome bases per GPU's reads; default 500e6 at N = 1 (30x), 625e6 on the sharded path (config 4: 5 Gbp over 8 GPUs, 30x)")
     ap.add_argument("--n-rate", type=float, default=0.001)
     ap.add_argument("--count-only", action="store_true", help="N=1: time the (k+1)-mer count alone (no construction)")
     ap.add_argument("--cpu-sample", type=float, default=20e6,
@@ -391,8 +393,21 @@ def main():
                     help="N>1 (or --force-sharded): after the timed steps, ONE construction over the ranks on this many reads per GPU (extra key; 0 disables)")
     ap.add_argument("--distributed-walks", type=float, default=2e6,
                     help="... and ONE more with the k-mer file left sharded (spades_amd.dist.distributed_walks) on this many reads per GPU (0 disables)")
-    ap.add_argument("--force-sharded", action="store_true", help="exercise the N>1 code path (extract/all-to-all/owner count) at any world size")
+    ap.add_argument("--force-sharded", "--scaling", dest="force_sharded", action="store_true",
+                    help="the N>1 step (extract / all-to-all / owner count on BASELINE config 4's per-GPU share: 125 M reads of the metagenome mix, seed 3) at "
+                         "any world size: `--gpus 1 --scaling` is the one-rank point of the scaling curve")
+    ap.add_argument("--iid", action="store_true", help="sharded path: the iid genome of config 3 instead of config 4's metagenome mix")
+    ap.add_argument("--scaling-reference", type=float, default=125e6,
+                    help="N=1 default line, extra: the N>1 step (config 4's per-GPU share) on this one GPU after the headline — the figure an N-rank `value` "
+                         "divides by; 0 disables")
     args = ap.parse_args()
+    sharded_cli = args.gpus > 1 or args.force_sharded or int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if args.reads is None:
+        args.reads = 125e6 if sharded_cli else 100e6
+    if args.genome is None:
+        args.genome = args.reads * L / 30.0
+    if sharded_cli and not args.iid:
+        args.skew = True  # metagenome mix (>= 1000 genomes, log-normal abundance)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
@@ -406,8 +421,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
-    if sharded:
-        import torch.distributed as dist
+    import torch.distributed as dist
+
+    def init_process_group():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         # librccl prints a version banner ("RCCL version : ...", five lines) to STDOUT when its first communicator comes up; rank 0's stdout
@@ -428,6 +444,9 @@ def main():
         if dist.get_world_size() != world:
             raise SystemExit(f"RCCL reports world size {dist.get_world_size()}, expected {world}")
 
+    if sharded:
+        init_process_group()
+
     if os.environ.get("SMX_BENCH_LIB"):  # A/B runs of kernel variants on one box: another build of the library (tools/ab/*.so), same host code
         from spades_amd import _lib as _smx_lib
         _smx_lib.LIB_PATH = os.path.abspath(os.environ["SMX_BENCH_LIB"])
@@ -441,7 +460,11 @@ def main():
     K1, nb = k + 1, 10 * T
     nw = (K1 + 31) // 32
     W = 8 * nw
-    words, start, ln, codes = synth_reads_device(1000 + rank, int(args.genome), n_reads, dev, n_rate=args.n_rate, skew=args.skew)
+    # read seeds: config 3 keeps the batch of rounds 1-5 (1000); the sharded path is SURVEY §8d's config 4 (seed 3): every rank draws ITS reads
+    # (seed 3000 + rank) from its own 1/world of the 5 Gbp mix (genome seed 3 + rank: different genomes on different ranks, as a metagenome
+    # sample split over ranks would be)
+    words, start, ln, codes = synth_reads_device((3000 if sharded else 1000) + rank, int(args.genome), n_reads, dev, n_rate=args.n_rate, skew=args.skew,
+                                                 genome_seed=(3 + rank) if sharded else 2)
     n_sample = int(min(args.cpu_sample, n_reads)) // 32 * 32
     if args.no_cpu_baseline:
         n_sample = 0
@@ -455,6 +478,17 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     hw, hs, hl = h_words.numpy().view("uint64"), h_start.numpy().view("uint64"), h_len.numpy().view("uint32")
+    # N = 1 default line: the per-GPU share of the N > 1 workload (BASELINE config 4: 125 M reads of the metagenome mix, seed 3) is generated
+    # NOW — later the library's arena holds most of the device — and waits in page-locked host memory for the `scaling_reference` leg
+    ref_reads = None
+    if rank == 0 and world == 1 and not sharded and not args.count_only and args.scaling_reference > 0:
+        n_ref = int(args.scaling_reference) // 32 * 32
+        w2, s2, l2, c2 = synth_reads_device(3000, int(n_ref * L / 30.0), n_ref, dev, n_rate=args.n_rate, skew=True, genome_seed=3)
+        del c2
+        ref_reads = (n_ref, w2.cpu().pin_memory(), s2.cpu().pin_memory(), l2.cpu().pin_memory())
+        del w2, s2, l2
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     # the end-to-end extra runs the CLI tools as processes of their own: before this process takes its device arena
     e2e_res = end_to_end(sample[:n_e2e], k, T) if n_e2e else None
 
@@ -632,6 +666,9 @@ def main():
         "value": round(value, 3), "unit": "M reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
+        # (BENCH_r01..r04 timed the step WITH the H2D copy inside: compare their `value` with this line's pcie_inclusive.value)
+        "value_definition": ("reads resident in HBM when the timed region starts (rounds 5+; rounds 1-4: the same step with the upload from page-locked host memory "
+                             "inside = this line's pcie_inclusive.value)") if not sharded else "per-GPU reads resident in HBM; all ranks' reads / max-over-ranks time",
         "config": {"workload": (f"BASELINE config 3: synthetic {n_reads / 1e6:g} M PE150 reads (genome {args.genome / 1e6:g} Mbp " +
                                 ("in 1000 genomes with log-normal abundances, 30% repeats, 1% low complexity" if args.skew else "iid") + ", 1% subst., "
                                 f"{args.n_rate * 100:g}% N), k={k}, packed reads resident in HBM: " +
@@ -641,7 +678,10 @@ def main():
                                 f"({nb} buckets = -t {T})" + ("" if args.count_only else " + de Bruijn construction (" +
                                 ("successor table, " if ext_route else "k-mer file, extension masks, ") +
                                 "unitigs in the reference's order, link records + vertices; graph resident in HBM; GFA identical to spades-gbuilder's)")) if not sharded else
-                               (f"BASELINE config 4 shape: {n_reads / 1e6:g} M PE150 reads per GPU, k={k}: sharded count of the canonical {K1}-mers "
+                               (f"BASELINE config 4: {n_reads * world / 1e6:g} M PE150 reads = {n_reads / 1e6:g} M per GPU on {world} GPU(s) (weak scaling: "
+                                f"1 B reads at 8), " + (f"metagenome mix ({args.genome * world / 1e9:.3g} Gbp in {1000 * world} genomes, log-normal abundances, 30% repeats, "
+                                "1% low complexity; seed 3)" if args.skew else f"iid genome ({args.genome / 1e6:g} Mbp per GPU)") +
+                                f", 1% subst., {args.n_rate * 100:g}% N, k={k}: sharded count of the canonical {K1}-mers "
                                 f"({nb} buckets, bucket-range owners, one RCCL all-to-all); inputs resident in HBM; no construction in the N>1 step"),
                    "reads_per_gpu": n_reads, "k": k, "num_buckets": nb, "kmer_instances": int(inst), "distinct_kpomers": int(D1),
                    "route": (("k-mers + masks from one count of the reads, never sorted: nodes numbered by minimizer partition" if pm_route else
@@ -665,6 +705,26 @@ def main():
             # rank directory = the k-mer file read once; node table = k-mers + masks read, up to 2 successor records of W bytes looked up
             # and 2 entries of 8 B written per k-mer; walks, unitigs and links as above
             b_con = D0 * W + (D0 * (W + 1) + 2 * D0 * W + 2 * D0 * 8) + 1.5 * 2 * D0 * 9 + nbases / 4 + 4 * 2 * ne * 16
+        b_con_formula = "route 1/2 formula (DESIGN.md §4b): rank directory + node table with up to two successor records per k-mer + walks + unitigs + links"
+        try:
+            rs0 = gb.route_stats()
+        except Exception:  # noqa: BLE001
+            rs0 = {}
+        if pm_route and rs0:
+            # Route 0 builds no rank directory over a k-mer file and looks 5 % of the successors up, not all of them: its bytes are the sum of
+            # what each of ITS kernels must move (the per-kernel rows of `dominant_kernel` below / DESIGN.md §6) — VERDICT r5 weak 5: the route-1
+            # formula priced 491 GB where the rows sum to ~370.
+            nj_, nc_ = rs0.get("junction_kmers", 0), rs0.get("start_de_edges", 0)
+            b_tab = D0 * (1 + 4) + 2 * D0 * 8 + 2 * D0 * 4
+            b_rem = 2 * D0 * 8 + 0.1 * 2 * D0 * (W + 8 + 4 + W + 8)
+            b_junc = 2 * D0 + nj_ * (2 * W + 8) + 3 * nj_ * W + nj_ * (2 * W + 1) + nj_ * (W + 24) + nc_ * 16  # masks scanned twice; junction records gathered, sorted (w + r + w), split, looked up; de-edges listed
+            b_wlen = nc_ * (8 + 2 * W + 4 + 3 * (4 + 16) + W + 8 * 3 + 1)
+            b_keep = nc_ * (8 + 8 + 8 + 1 + 8) + 4 * nc_ * 16  # keep pass + the two scans of the kept words / edge indices
+            b_wwr = ne * (8 * 6 + W + 3 * (4 + W + 16) + 32) + nbases / 4
+            b_links = 4 * 2 * ne * 16
+            b_con = b_tab + b_rem + b_junc + b_wlen + b_keep + b_wwr + b_links
+            b_con_formula = ("route 0, sum of its kernels' own bytes: successor table %.1f + successors outside their chunk %.1f + junction order %.1f + walk lengths %.1f + "
+                             "keep %.1f + walk write %.1f + links %.1f GB" % tuple(v / 1e9 for v in (b_tab, b_rem, b_junc, b_wlen, b_keep, b_wwr, b_links)))
         out["construct"] = {"n_kpomers": int(D1), "n_kmers": int(D0), "n_unitigs": int(ne), "n_vertices": int(info["n_vertices"]),
                             "unitig_bases": int(nbases),
                             "roofline": {"bound": "hbm", "achieved": round(b_con / max(construct_ms, 1e-9) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
@@ -672,7 +732,8 @@ def main():
                                          "traffic": pmc_split["construct"] if pmc_rows else None,
                                          "kernel": ("construction (rank directory, successor table, walks, link records)" if ext_route else
                                                     "construction (k-mer file, rank directory, masks + successors, walks, link records)") + ": sum of its stage kernels",
-                                         "algorithmic_bytes_per_step": int(b_con), "kernel_ms_per_step": round(construct_ms, 3)}}
+                                         "algorithmic_bytes_per_step": int(b_con), "algorithmic_bytes_are": b_con_formula,
+                                         "kernel_ms_per_step": round(construct_ms, 3)}}
         try:
             out["construct"]["route_stats"] = gb.route_stats()
         except Exception as e:  # noqa: BLE001
@@ -723,6 +784,23 @@ def main():
                                                                       "(smx_graph_fingerprint_portable: independent of the k-mer numbering, equal between routes)")
             except Exception as e:  # noqa: BLE001 — a check, never the measurement
                 out["construct"]["checks"]["graph_fingerprint"] = f"unavailable: {e}"
+        if info is not None and pm_route:
+            # What SURVEY §8(d)'s end point "sorted-unique bucket arrays resident in HBM" costs behind route 0: the step ends with
+            # the graph and the k-mers in minimizer-partition order; the reference's product of counting — the bucket-major sorted file — is made the
+            # first time an accessor asks for it (pm_materialize_file). Timed here once, on the graph of the last timed step, by asking for the
+            # bucket sizes (no copy to the host); `value` + this = the rate of a step that ends at the file.
+            try:
+                torch.cuda.synchronize()
+                t_f = time.perf_counter()
+                sizes_f = gb.ctx.bucket_sizes(nb)
+                torch.cuda.synchronize()
+                dt_f = (time.perf_counter() - t_f) * 1e3
+                out["kmer_file_on_demand"] = {"ms": round(dt_f, 1), "records": int(sum(sizes_f)), "buckets": nb,
+                                              "what": "pm_materialize_file on the resident graph of the last timed step: partition-major records -> sort pipeline -> k-mer file + InOutMask bytes in "
+                                                      "k-mer-file order (smx_bucket_sizes as the trigger; nothing leaves the device)",
+                                              "M_reads_per_s_count_construct_and_file": round(n_reads / ((ms_per_step + dt_f) / 1e3) / 1e6, 2)}
+            except Exception as e:  # noqa: BLE001 — an extra, never the measurement
+                out["kmer_file_on_demand"] = {"error": str(e)[:300]}
         if e2e_res is not None:
             out["end_to_end"] = e2e_res
         if not args.no_cpu_baseline and n_sample:
@@ -808,11 +886,54 @@ def main():
                                          "M_reads_per_s": round(ne_ / dta / 1e6, 2), "ms_per_step": round(dta * 1e3, 3), "kernel_ms": round(tma, 3),
                                          "kmer_instances": int(ia), "distinct_kmers": int(da), "result_held_as_two_strands": sta.device_ptr() == 0,
                                          "roofline_frac": round(ba / max(tma, 1e-9) / 1e6 / 8000.0, 4)}
+                if sta.device_ptr() == 0:
+                    # a result held as two strands leaves the per-bucket merge (k_ts_merge, 137 GB at 100 M reads) to the accessors: the figure above
+                    # stops before it. Here every bucket is merged, one after the other, into ONE device block of the largest
+                    # bucket's size (what a bucket-by-bucket consumer — the CLI writer, an index builder — does): count + merge = the whole file made once.
+                    bs_ = sta.bucket_sizes()
+                    blk_ = torch.empty(int(bs_.max()) * ((k + 31) // 32) + 8, dtype=torch.int64, device=dev)
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    for b_ in range(16):
+                        sta.bucket_to_device(b_, blk_.data_ptr())
+                    torch.cuda.synchronize()
+                    dtm = time.perf_counter() - t2
+                    del blk_
+                    out["kmercount_mode"].update({"merge_all_buckets_ms": round(dtm * 1e3, 3),
+                                                  "M_reads_per_s_through_the_merge": round(ne_ / (dta + dtm) / 1e6, 2),
+                                                  "roofline_frac_through_the_merge": round((ba + 2 * da * Wa) / max(tma + dtm * 1e3, 1e-9) / 1e6 / 8000.0, 4)})
                 spa.clear()
                 del w2, s2, l2
             except Exception as e:  # noqa: BLE001 — an extra, never the measurement
                 out["kmercount_mode"] = {"error": str(e)[:300]}
             ctx.set_option("single_batch", 0)
+        if ref_reads is not None:
+            # The one-rank point of the scaling curve: the N > 1 step (extract + grouping by owner, ONE RCCL all-to-all — with itself here —, owner-side
+            # count) on BASELINE config 4's per-GPU share. An N-rank `value` divides by THIS figure, not by the headline above (config 3: count +
+            # construction of another input). Same code path as `bench.py --gpus 1 --scaling`.
+            try:
+                n_ref, w2h, s2h, l2h = ref_reads
+                ctx.graph_clear()
+                gb.reads.clear()
+                ctx.set_option("async_upload", 0)
+                gb.reads.push_back_packed(w2h.numpy().view("uint64")[:-8], s2h.numpy().view("uint64"), l2h.numpy().view("uint32"))
+                init_process_group()
+                eng_r = smx_dist.GpuEngine(ctx, "B")
+                st_r = smx_dist.sharded_count(eng_r, K1, nb, 0, 1, dev)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for _ in range(args.steps):
+                    st_r = smx_dist.sharded_count(eng_r, K1, nb, 0, 1, dev)
+                torch.cuda.synchronize()
+                dtr = (time.perf_counter() - t3) / args.steps
+                out["scaling_reference"] = {"value": round(n_ref / dtr / 1e6, 3), "unit": "M reads/s", "ms_per_step": round(dtr * 1e3, 3), "n_gpus": 1,
+                                            "workload": f"the N > 1 step on ONE rank: BASELINE config 4's per-GPU share ({n_ref / 1e6:g} M PE150 reads of the metagenome mix, seed 3), "
+                                                        f"k={k}, sharded count of the canonical {K1}-mers ({nb} buckets), one RCCL all-to-all with itself; inputs resident in HBM",
+                                            "phase_ms": {k_: round(v_, 1) for k_, v_ in st_r["phase_ms"].items()}, "distinct": int(st_r["distinct"]),
+                                            "use": "divide the `value` of `bench.py --gpus N` (N > 1, same per-GPU workload) by N x this for the scaling efficiency"}
+                dist.destroy_process_group()
+            except Exception as e:  # noqa: BLE001 — an extra, never the measurement
+                out["scaling_reference"] = {"error": str(e)[:300]}
     if sharded:
         # per-rank figures of the last step, gathered on rank 0: records sent / received, distinct records owned, phase times
         st = last["st"]
@@ -901,15 +1022,19 @@ def main():
     if sharded and rank == 0:
         # the N = 1 default line is another workload (config 3: upload + count + construction); the figure to divide an N-rank value by
         # is this same sharded step on ONE rank, measured with --gpus 1 --force-sharded and committed under profiles/
-        ref = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, "bench_sharded_1rank_100M.json") for r_ in ("r05", "r04", "r03", "r02")) if os.path.exists(p_)),
-                   os.path.join(ROOT, "profiles", "r04", "bench_sharded_1rank_100M.json"))
-        try:
-            r1 = json.load(open(ref))
-            if r1["config"]["reads_per_gpu"] == n_reads and r1["config"]["k"] == k and r1["config"]["num_buckets"] == nb:
-                out["same_step_on_one_rank"] = {"value": r1["value"], "unit": r1["unit"], "ms_per_step": r1["ms_per_step"],
-                                                "source": os.path.relpath(ref, ROOT) + " (bench.py --gpus 1 --force-sharded)"}
-        except (OSError, ValueError, KeyError):
-            pass
+        # (recorded: profiles/r06/bench_config4_share_1rank.json = `bench.py --gpus 1 --scaling`; the N = 1 default line measures it live as `scaling_reference`)
+        cands = [os.path.join(ROOT, "profiles", "r06", "bench_config4_share_1rank.json")] + \
+                [os.path.join(ROOT, "profiles", r_, "bench_sharded_1rank_100M.json") for r_ in ("r05", "r04", "r03", "r02")]
+        for ref in cands:
+            try:
+                r1 = json.load(open(ref))
+                if (r1["config"]["reads_per_gpu"] == n_reads and r1["config"]["k"] == k and r1["config"]["num_buckets"] == nb and
+                        ("metagenome mix" in r1["config"]["workload"]) == bool(args.skew)):
+                    out["same_step_on_one_rank"] = {"value": r1["value"], "unit": r1["unit"], "ms_per_step": r1["ms_per_step"],
+                                                    "source": os.path.relpath(ref, ROOT) + " (bench.py --gpus 1 --scaling)"}
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
     if rank == 0:
         import ctypes
         ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: out before the result line, not after it

@@ -61,6 +61,12 @@ int smx_trim(smx_ctx *ctx, size_t *bytes_returned);
  * work from the device's free memory (hipMemGetInfo) must add this — the arena only grows, so what the library released after a big
  * step is invisible to the device-level figure. No reference equivalent (the reference has no device). */
 int smx_arena_free_bytes(smx_ctx *ctx, size_t *bytes);
+/* Returns at once; a helper thread of the context backs `bottom_bytes` of the arena's temporary region and `top_bytes` of its long-lived region
+ * with physical memory (512 MiB chunks, ~17 ms per GiB on this stack) while the caller goes on — a tool that builds ONE graph per process calls
+ * it before it reads its input, so that the mapping its first build would pay for (1.25 s of a 1.39 s "build graph" at 20 M reads) overlaps the
+ * parse. A hint, never a promise: the helper stops where the device runs short, leaves a context with an HBM budget alone, and any call that needs
+ * memory meanwhile maps what it needs itself. The reference's counterpart is the page cache warming up under `-tmp-dir`: no API there. */
+int smx_prewarm(smx_ctx *ctx, size_t bottom_bytes, size_t top_bytes);
 /* A block of the context's device arena for the CALLER's own use (bytes, 256-byte aligned), and its return. For a neighbour whose working arrays
  * must live next to what the library holds — the walk state of spades_amd.dist.distributed_walks, 9–10 B per oriented node of the rank's shard: the
  * arena only grows and gives nothing back before smx_destroy, so after the library's big steps (the sharded count peaks at ~2x the shard) a framework
@@ -179,6 +185,10 @@ int smx_write_final_kmers(const smx_ctx *ctx, const char *path);
 const void *smx_device_kmers(const smx_ctx *ctx);
 /* device-to-device copy of the same array into caller-owned HBM (e.g. a torch tensor about to enter a collective) */
 int smx_copy_kmers_device(const smx_ctx *ctx, void *d_dst);
+/* ... and of ONE bucket (KMerDiskStorage::bucket(i), kmer_index_builder.hpp:180-190) into caller-owned HBM of smx_bucket_sizes()[bucket] records: what
+ * a consumer that works bucket by bucket — the reference's index builder does, kmer_index_builder.hpp:470-500 — reads instead of the whole file;
+ * a both-strands result that is held as two strands (smx_device_kmers() == NULL) is merged straight into the block, bucket by bucket. */
+int smx_copy_bucket_device(const smx_ctx *ctx, unsigned bucket, void *d_dst);
 
 /* ---- multi-GPU sharding ---------------------------------------------------
  * Bucket ownership is a contiguous bucket range per rank. smx_extract_partition runs the

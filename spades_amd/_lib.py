@@ -43,6 +43,7 @@ def load():
         "smx_destroy": (None, [vp]),
         "smx_trim": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
         "smx_arena_free_bytes": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+        "smx_prewarm": (C.c_int, [vp, C.c_size_t, C.c_size_t]),
         "smx_pool_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
         "smx_pool_free": (C.c_int, [vp, vp]),
         "smx_graph_clear": (C.c_int, [vp]),
@@ -65,6 +66,7 @@ def load():
         "smx_build_graph_from_kmers": (C.c_int, [vp, C.c_uint, C.c_uint, vp, vp, C.c_uint64, u64p, C.c_uint64]),
         "smx_graph_set_kpomers": (C.c_int, [vp, vp, C.c_uint64, u64p]),
         "smx_copy_kmers_device": (C.c_int, [vp, vp]),
+        "smx_copy_bucket_device": (C.c_int, [vp, C.c_uint, vp]),
         "smx_submit_fastq_text": (C.c_int, [vp, C.c_char_p, C.c_uint64, C.c_int, u64p, u64p]),
         "smx_pinned_alloc": (vp, [C.c_size_t]),
         "smx_pinned_free": (None, [vp]),

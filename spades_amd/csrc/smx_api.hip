@@ -894,8 +894,15 @@ static int build_graph_impl(smx_ctx *ctx, unsigned k, unsigned num_buckets, cons
     return rc;
 }
 
+int smx_prewarm(smx_ctx *ctx, size_t bottom_bytes, size_t top_bytes) {
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    arena_prewarm_start(ctx, bottom_bytes, top_bytes);
+    return SMX_OK;
+}
+
 int smx_arena_free_bytes(smx_ctx *ctx, size_t *bytes) {
     if (!ctx || !bytes) return SMX_INVALID_PARAMETER;
+    std::lock_guard<std::recursive_mutex> lk(ctx->arena_mu);
     size_t cached = 0;
     if (ctx->arena.vmm) {
         for (auto &b : ctx->arena.free_blocks) cached += b.second;
@@ -921,7 +928,9 @@ int smx_pool_free(smx_ctx *ctx, void *d_block) {
     if (!d_block) return SMX_OK;
     auto it = ctx->pool_blocks.find(d_block);
     if (it == ctx->pool_blocks.end()) return fail(ctx, SMX_INVALID_PARAMETER, "smx_pool_free: not a block smx_pool_alloc handed out");
-    (void)hipStreamSynchronize(ctx->stream);
+    // the block was the CALLER's to write, on streams the library knows nothing about (torch's, RCCL's): all of the device's work ends before
+    // the arena may hand the memory to somebody else (a stream-only wait made a free with work in flight a silent overwrite)
+    (void)hipDeviceSynchronize();
     ctx->pool_blocks.erase(it);
     arena_put(ctx, d_block);
     return SMX_OK;
@@ -1283,11 +1292,21 @@ int smx_graph_set_kpomers(smx_ctx *ctx, const void *d_kpomers, uint64_t n, const
     if (!ctx || !ctx->g_ready || !bucket_sizes) return SMX_INVALID_PARAMETER;
     if (n && !d_kpomers) return SMX_INVALID_PARAMETER;
     HIPCHK(hipSetDevice(ctx->device));
+    {   // (checked before anything of the context changes: a refused call leaves the graph's bookkeeping as it was)
+        uint64_t sum = 0;
+        for (unsigned b = 0; b < ctx->g_B; ++b) sum += bucket_sizes[b];
+        if (sum != n) return fail(ctx, SMX_INVALID_PARAMETER, "bucket sizes do not add up to the number of (k+1)-mers");
+    }
     drop_kpo(ctx);
-    if (!ctx->g_nkpo_total) ctx->g_nkpo_total = ctx->g_nkpo;  // (a shard of the file is about to stand for it: smx_graph_info keeps reporting the whole count — smx_graph_set_coverage puts it back)
+    // A SHARD of the file is about to stand for it (fewer records than the graph's (k+1)-mer count): smx_graph_info keeps reporting the whole
+    // count and smx_graph_set_coverage puts it back. A file of the full size is a replacement, not a shard: it ends any latch.
+    if (n < (ctx->g_nkpo_total ? ctx->g_nkpo_total : ctx->g_nkpo)) {
+        if (!ctx->g_nkpo_total) ctx->g_nkpo_total = ctx->g_nkpo;
+    } else {
+        ctx->g_nkpo_total = 0;
+    }
     ctx->g_kpoboff.assign(ctx->g_B + 1, 0);
     for (unsigned b = 0; b < ctx->g_B; ++b) ctx->g_kpoboff[b + 1] = ctx->g_kpoboff[b] + bucket_sizes[b];
-    if (ctx->g_kpoboff[ctx->g_B] != n) return fail(ctx, SMX_INVALID_PARAMETER, "bucket sizes do not add up to the number of (k+1)-mers");
     ctx->g_nkpo = n;
     if (n == 0) return SMX_OK;
     if (int rc = dalloc(ctx, (uint64_t **)&ctx->g_kpo, (size_t)n * ctx->g_nw, false)) return rc;
@@ -1313,6 +1332,26 @@ int smx_graph_set_coverage(smx_ctx *ctx, const uint32_t *raw_coverage, uint64_t 
         ctx->g_nkpo = ctx->g_nkpo_total;
         ctx->g_nkpo_total = 0;
     }
+    return SMX_OK;
+}
+
+// one bucket of the result into caller-owned HBM (a two-strand result merges the bucket's strands straight into the block)
+int smx_copy_bucket_device(const smx_ctx *cctx, unsigned bucket, void *d_dst) {
+    smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
+    if (!ctx) return SMX_INVALID_PARAMETER;
+    if (int rc = ensure_kmer_file(ctx)) return rc;
+    if (bucket >= ctx->num_buckets) return fail(ctx, SMX_INVALID_PARAMETER, "bucket %u out of range", bucket);
+    const uint64_t o = ctx->bucket_off[bucket], n = ctx->bucket_off[bucket + 1] - o;
+    if (n == 0) return SMX_OK;
+    if (!d_dst) return SMX_INVALID_PARAMETER;
+    if (ctx->result_on_host) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the result was spilled to host memory (it does not fit the HBM budget)");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->ts.active) {
+        if (int rc = ts_merge_bucket_any(ctx, bucket, d_dst)) return rc;
+    } else {
+        HIPCHK(hipMemcpyAsync(d_dst, (const char *)ctx->d_result + o * (size_t)ctx->nw * 8, n * (size_t)ctx->nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return SMX_OK;
 }
 

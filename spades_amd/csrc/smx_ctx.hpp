@@ -1,7 +1,9 @@
 // spades_amd/csrc/smx_ctx.hpp — the context behind the C ABI: resident read chunks, result view, options, grow-only device
 // arena, temp bookkeeping, stage timers (included by smx_api.hip; one translation unit).
 #pragma once
+#include <atomic>
 #include <mutex>
+#include <thread>
 
 namespace {
 
@@ -66,6 +68,13 @@ struct PmState {
 struct smx_ctx {
     int device = 0;
     Arena arena;
+    // the arena is shared with ONE helper: the prewarm thread (smx_prewarm) maps chunks ahead of the calls that will need them while the
+    // caller's thread reads its input; every entry of the allocator takes this lock, the helper holds it for one chunk at a time
+    std::recursive_mutex arena_mu;
+    std::thread prewarm_thr;
+    std::atomic<bool> prewarm_stop{false};
+    double arena_map_s = 0, arena_prewarm_s = 0;          // wall time inside hipMemCreate / hipMemMap / hipMemSetAccess: all of it, the helper's share
+    size_t arena_map_bytes = 0, arena_prewarm_bytes = 0;  // ... and the bytes mapped
     size_t budget = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // uploads of asynchronous submissions
@@ -310,8 +319,18 @@ bool arena_vmm_init(smx_ctx *ctx) {
     return true;
 }
 // back the chunks [c0, c1) with physical memory
+double wall_now();
 bool arena_map_chunks(smx_ctx *ctx, size_t c0, size_t c1) {
     Arena &A = ctx->arena;
+    struct MapTimer {
+        smx_ctx *c;
+        double t0;
+        size_t bytes;
+        ~MapTimer() {
+            c->arena_map_s += wall_now() - t0;
+            c->arena_map_bytes += bytes;
+        }
+    } map_timer{ctx, wall_now(), (c1 - c0) * A.gran};
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -411,6 +430,48 @@ bool arena_grow(smx_ctx *ctx, size_t want, bool top) {
     return true;
 }
 
+// smx_prewarm: map `bottom` bytes above the bottom mark and `top` bytes below the top mark on a helper thread, one chunk per lock hold (a
+// caller that needs a block meanwhile waits for at most one chunk, ~9 ms, and maps what it needs itself). Mapping costs ~17 ms per GiB and a
+// process pays it once per address: a tool that builds ONE graph pays it inside its first build — 1.25 s for the 74 GiB of a 20 M-read
+// construction — unless it happens while the tool is still reading its input. Nothing is promised: the helper stops
+// where the device runs short, and a context with an HBM budget is left alone.
+void arena_prewarm_join(smx_ctx *ctx) {
+    ctx->prewarm_stop = true;
+    if (ctx->prewarm_thr.joinable()) ctx->prewarm_thr.join();
+    ctx->prewarm_stop = false;
+}
+void arena_prewarm_start(smx_ctx *ctx, size_t bottom, size_t top) {
+    arena_prewarm_join(ctx);
+    if (ctx->budget || (bottom == 0 && top == 0)) return;
+    ctx->prewarm_thr = std::thread([ctx, bottom, top]() {
+        if (hipSetDevice(ctx->device) != hipSuccess) return;
+        size_t done_b = 0, done_t = 0;
+        while (!ctx->prewarm_stop && (done_b < bottom || done_t < top)) {
+            std::lock_guard<std::recursive_mutex> lk(ctx->arena_mu);
+            if (!arena_vmm_init(ctx)) return;
+            Arena &A = ctx->arena;
+            const bool at_top = done_t < top && (done_b >= bottom || done_t * (bottom + 1) <= done_b * (top + 1));
+            if (A.lo + A.gran > A.hi) return;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < A.gran + total_b / 10) return;  // (the builds themselves stop at 5 %)
+            const double t0 = wall_now();
+            if (!at_top) {
+                if (!arena_map_chunks(ctx, A.lo / A.gran, A.lo / A.gran + 1)) return;
+                arena_add_free(A, A.lo, A.gran);
+                A.lo += A.gran;
+                done_b += A.gran;
+            } else {
+                if (!arena_map_chunks(ctx, A.hi / A.gran - 1, A.hi / A.gran)) return;
+                A.hi -= A.gran;
+                arena_add_free(A, A.hi, A.gran);
+                done_t += A.gran;
+            }
+            ctx->arena_prewarm_s += wall_now() - t0;
+            ctx->arena_prewarm_bytes += A.gran;
+        }
+    });
+}
+
 void *arena_get_malloc(smx_ctx *ctx, size_t bytes);
 void arena_put_malloc(smx_ctx *ctx, void *p);
 
@@ -478,6 +539,7 @@ void *arena_take(smx_ctx *ctx, size_t bytes, size_t r0, size_t r1, bool descendi
 // top = long-lived block (top region, highest address first); otherwise a temporary (bottom region, lowest address first).
 // Each kind spills into the other region's free blocks only when its own region cannot grow any more.
 void *arena_get(smx_ctx *ctx, size_t bytes, bool top = false) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->arena_mu);
     if (!arena_vmm_init(ctx)) return arena_get_malloc(ctx, bytes);
     Arena &A = ctx->arena;
     bytes = (bytes + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN;
@@ -497,6 +559,7 @@ void *arena_get(smx_ctx *ctx, size_t bytes, bool top = false) {
 }
 void arena_put(smx_ctx *ctx, void *p) {
     if (!p) return;
+    std::lock_guard<std::recursive_mutex> lk(ctx->arena_mu);
     Arena &A = ctx->arena;
     if (!A.vmm) {
         arena_put_malloc(ctx, p);
@@ -511,6 +574,7 @@ void arena_put(smx_ctx *ctx, void *p) {
 }
 // a live block gives its tail back (a result buffer sized for the worst case)
 void arena_shrink(smx_ctx *ctx, void *p, size_t bytes) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->arena_mu);
     Arena &A = ctx->arena;
     if (!p || !A.vmm) return;
     auto it = A.live.find(p);
@@ -524,6 +588,12 @@ void arena_shrink(smx_ctx *ctx, void *p, size_t bytes) {
 }
 // give the memory back to the device (smx_destroy: every block has been returned by then)
 void arena_release(smx_ctx *ctx) {
+    arena_prewarm_join(ctx);
+    if (getenv("SMX_DEBUG") && ctx->arena.vmm)
+        fprintf(stderr, "[smx] arena: %.1f GiB mapped in %.3f s (%.1f ms/GiB; the prewarm helper: %.1f GiB in %.3f s); bottom mark %.1f GiB, top region %.1f GiB of %.1f reserved\n",
+                (double)ctx->arena_map_bytes / (1 << 30), ctx->arena_map_s, ctx->arena_map_bytes ? ctx->arena_map_s * 1e3 / ((double)ctx->arena_map_bytes / (1 << 30)) : 0.0,
+                (double)ctx->arena_prewarm_bytes / (1 << 30), ctx->arena_prewarm_s, (double)ctx->arena.lo / (1 << 30),
+                (double)(ctx->arena.reserved - ctx->arena.hi) / (1 << 30), (double)ctx->arena.reserved / (1 << 30));
     Arena &A = ctx->arena;
     if (A.vmm) {
         if (!A.live.empty()) {  // somebody still holds a block (a bug of the caller's bookkeeping): the range cannot go, say so
@@ -568,6 +638,7 @@ void arena_release(smx_ctx *ctx) {
 // released pages first, sees nothing wrong. Until that window is understood the arena only grows; memory goes back at smx_destroy
 // (parked arenas: at most one per device). The hipMalloc fallback (SMX_ARENA=malloc) frees its cache. Returns the bytes released.
 size_t arena_trim(smx_ctx *ctx) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->arena_mu);
     Arena &A = ctx->arena;
     if (A.vmm) return 0;
     size_t freed = 0;
@@ -582,6 +653,7 @@ size_t arena_trim(smx_ctx *ctx) {
 // HBM still obtainable for new allocations (bytes): free blocks of the arena + what can still be mapped between its two marks, as
 // far as the device has it, or what is left of the caller's budget
 size_t arena_avail(smx_ctx *ctx) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->arena_mu);
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     size_t cached = 0;
@@ -598,6 +670,7 @@ size_t arena_avail(smx_ctx *ctx) {
 
 // largest free block of the arena (diagnostics: SMX_DEBUG lines that tell a full arena from a fragmented one)
 size_t arena_largest_free(smx_ctx *ctx) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->arena_mu);
     size_t mx = 0;
     if (ctx->arena.vmm) {
         for (auto &b : ctx->arena.free_blocks) mx = std::max(mx, b.second);

@@ -306,7 +306,9 @@ int pm_materialize_file(smx_ctx *ctx, bool for_view) {
     ctx->g_mask = nullptr;
     ctx->g_pm = false;
     ctx->g_pm_nx = false;
-    pm_release(ctx);  // no lookups on the old numbering from here on
+    // (EXT records are consumed by the sort: no lookups on the old numbering from here on. Plain records — nx — are only read: their side arrays
+    // stay until the file stands, so that a file that does not fit leaves the graph as it was)
+    if (!nx) pm_release(ctx);
     if (!nx) arena_put(ctx, old_mask);
     ctx->d_result = ctx->d_result_buf = nullptr;
     int rc;
@@ -329,6 +331,11 @@ int pm_materialize_file(smx_ctx *ctx, bool for_view) {
         smx::RankDir dir{};
         if (rc == 0 && ctx->n_records != D0) rc = fail(ctx, SMX_DEVICE_ERROR, "k-mer file: %llu records after the sort, %llu k-mers in the graph", (unsigned long long)ctx->n_records, (unsigned long long)D0);
         const size_t mask_bytes = (size_t)((D0 + 7) / 8 * 8 + 8);
+        void *sorted = rc == 0 ? ctx->d_result_buf : nullptr;
+        if (rc == 0) {  // the sort's other buffers go before the file's own block is asked for: old array + sorted copy + file at the peak, not four
+            (void)hipStreamSynchronize(ctx->stream);
+            free_temps(ctx, sorted);
+        }
         if (rc == 0) rc = dalloc(ctx, &file, D0 + 1, false);
         if (rc == 0) rc = dalloc(ctx, &new_mask, mask_bytes, false);
         uint32_t *d_e = nullptr;
@@ -367,10 +374,28 @@ int pm_materialize_file(smx_ctx *ctx, bool for_view) {
         }
         arena_put(ctx, file);
         arena_put(ctx, new_mask);
-        arena_put(ctx, old_mask);
-        if (ctx->d_result_buf && ctx->d_result_buf != src) {  // the sorted copy (a temporary of run_count)
-            ctx->d_result_buf = ctx->d_result = nullptr;
+        if (sorted) arena_put(ctx, sorted);  // the sorted copy (kept out of the temp list above)
+        ctx->d_result_buf = ctx->d_result = nullptr;
+        if (rc) {
+            // nothing of the graph was touched: the partition-major records, their bytes and the side arrays of the route are all there — the
+            // caller hears the error (normally the memory limit) and the graph stays what it was
+            (void)hipStreamSynchronize(ctx->stream);
+            for (auto &t : ctx->timings) {
+                (void)hipEventDestroy(t.e0);
+                (void)hipEventDestroy(t.e1);
+            }
+            ctx->timings.clear();
+            free_temps(ctx);
+            ctx->g_kmers = src;
+            ctx->g_mask = old_mask;
+            ctx->g_pm = true;
+            ctx->g_pm_nx = true;
+            ctx->g_nkpo = nkpo;
+            restore_view();
+            return rc;
         }
+        arena_put(ctx, old_mask);
+        pm_release(ctx);
     }
     if (src) arena_put(ctx, src);
     (void)hipStreamSynchronize(ctx->stream);

@@ -57,6 +57,16 @@ class Context:
         """smx_graph_clear: the graph of the last smx_build_graph gives its HBM back; reads stay resident"""
         _chk(self._h, self.lib.smx_graph_clear(self._h))
 
+    def bucket_sizes(self, num_buckets: int):
+        """smx_bucket_sizes of the context's count-result view (after a construction on the default route: makes the sorted k-mer file first)"""
+        sizes = (C.c_uint64 * num_buckets)()
+        _chk(self._h, self.lib.smx_bucket_sizes(self._h, sizes))
+        return [int(v) for v in sizes]
+
+    def prewarm(self, bottom_bytes: int, top_bytes: int) -> None:
+        """smx_prewarm: the arena's helper thread maps that much physical memory while the caller goes on"""
+        _chk(self._h, self.lib.smx_prewarm(self._h, bottom_bytes, top_bytes))
+
     def arena_free_bytes(self) -> int:
         """smx_arena_free_bytes: HBM the context holds but does not use right now (invisible to hipMemGetInfo: the arena only grows)"""
         n = C.c_size_t()
@@ -196,6 +206,10 @@ class KMerDiskStorage:
 
     def device_ptr(self) -> int:
         return int(self.ctx.lib.smx_device_kmers(self.ctx._h) or 0)
+
+    def bucket_to_device(self, i: int, d_dst: int) -> None:
+        """bucket i into caller-owned HBM of bucket_size(i) records (a result held as two strands is merged into the block)"""
+        _chk(self.ctx._h, self.ctx.lib.smx_copy_bucket_device(self.ctx._h, i, C.c_void_p(d_dst)))
 
     def merge(self):  # KMerDiskStorage::merge, kmer_index_builder.hpp:190-203
         if self.workdir is None:

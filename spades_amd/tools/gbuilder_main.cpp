@@ -108,6 +108,7 @@ int main(int argc, char **argv) {
         } else {
             files.push_back(file);
         }
+        smxtool::prewarm_for_inputs(ctx, files, 6.0, 6.0);
         for (const auto &fn : files) {
             rc = smxtool::submit_file(ctx, fn);
             if (rc) break;

@@ -189,6 +189,7 @@ inline int exchange(RankComm &c, smx_ctx *ctx, const uint64_t *d_send, const std
             if (f > e) GM_NCCL(ncclRecv(*d_recv + e, f - e, ncclUint64, p, c.comm, c.stream));
         }
         GM_NCCL(ncclGroupEnd());
+        smxtool::RankWatch::tick();
     }
     if (!self_rccl && counts[c.rank])
         GM_HIP(hipMemcpyAsync(*d_recv + roff[c.rank] * wpr, d_send + soff[c.rank] * wpr, (size_t)counts[c.rank] * wpr * 8, hipMemcpyDeviceToDevice, c.stream));
@@ -223,6 +224,7 @@ inline int gather_shards(RankComm &c, const void *d_mine, const std::vector<uint
             if (dest && f > e) GM_NCCL(ncclRecv((char *)*d_full + off[p] * unit + e, f - e, ncclUint8, p, c.comm, c.stream));
         }
         GM_NCCL(ncclGroupEnd());
+        smxtool::RankWatch::tick();
     }
     GM_HIP(hipStreamSynchronize(c.stream));
     return 0;
@@ -242,6 +244,7 @@ inline int bcast_from(RankComm &c, int root, void *d_buf, uint64_t bytes) {
             GM_NCCL(ncclRecv((char *)d_buf + a, n, ncclUint8, root, c.comm, c.stream));
         }
         GM_NCCL(ncclGroupEnd());
+        smxtool::RankWatch::tick();
     }
     GM_HIP(hipStreamSynchronize(c.stream));
     return 0;

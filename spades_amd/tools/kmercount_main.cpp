@@ -91,6 +91,7 @@ int main(int argc, char **argv) {
         // one host thread per input file (up to 8 at a time): reading / inflating is the slow part of the ingest and R1/R2 files are
         // independent streams; the library calls are serialised
         STAGE("device init")
+        smxtool::prewarm_for_inputs(ctx, input, 6.0, 6.0);
         std::mutex mu;
         std::vector<int> rcs(input.size(), 0);
         std::vector<std::string> errs(input.size());

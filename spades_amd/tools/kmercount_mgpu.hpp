@@ -167,6 +167,7 @@ inline int sharded_rank_main(int rank, int world, unsigned K, const std::string 
                 if (f > e) MG_NCCL(ncclRecv(d_recv + e, f - e, ncclUint64, p, comm, stream));
             }
             MG_NCCL(ncclGroupEnd());
+        smxtool::RankWatch::tick();
         }
         if (!self_rccl && counts[rank])
             MG_HIP(hipMemcpyAsync(d_recv + roff[rank] * nw, d_send + soff[rank] * nw, (size_t)counts[rank] * nw * 8, hipMemcpyDeviceToDevice, stream));

@@ -51,7 +51,11 @@ struct RankWatch {
     }
     static void arm(int r) {
         rank() = r;
-        if (const char *e = getenv("SMX_MGPU_WATCHDOG")) seconds() = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 0;
+        if (const char *e = getenv("SMX_MGPU_WATCHDOG")) {  // seconds per phase; anything that is not a positive number of at most a day leaves it off
+            char *end = nullptr;
+            const long v = strtol(e, &end, 10);
+            seconds() = (end != e && *end == 0 && v > 0 && v <= 86400) ? (unsigned)v : 0;
+        }
         void *bt[4];
         (void)backtrace(bt, 4);  // loads what backtrace() needs outside the signal handler
         signal(SIGALRM, on_alarm);
@@ -59,6 +63,11 @@ struct RankWatch {
     }
     static void mark(const char *what) {
         where() = what;
+        if (seconds() && !in_teardown()) alarm(seconds());
+    }
+    // progress INSIDE a long phase (a file of many GB being read and submitted piece by piece, the rounds of an exchange): the alarm is re-armed
+    // without a new milestone, so that the watchdog's period bounds the time without progress, not the length of a healthy phase
+    static void tick() {
         if (seconds() && !in_teardown()) alarm(seconds());
     }
     static void teardown_begins() {

@@ -2,6 +2,7 @@
 // The reference keeps parsing on the CPU too (kseq + zlib-ng: common/io/reads/parser.cpp); only sequences are used here.
 // Reads are handed to the library in ASCII; smx_submit_reads_ascii applies the longest-ACGT-run rule.
 #pragma once
+#include <sys/stat.h>
 #include "../../include/smx.h"
 #include "bgzf_reader.hpp"
 #include <zlib.h>
@@ -247,6 +248,25 @@ inline size_t read_plain(FILE *f, char *dst, size_t n) {
 // cannot be opened; throws std::string on malformed input.
 // mu (optional): serialises the library calls when several files are read by several host threads (a context is used by one
 // thread at a time; reading and inflating — the slow part — run in parallel).
+// The device arena maps its physical memory the first time an address is used (~17 ms per GiB): a tool that builds one graph or makes one
+// count per process would pay that inside its first stage. Asked for here, it happens on the library's helper thread while the input is read.
+// The figures: bytes of arena per byte of (uncompressed) input text that a construction / a both-strands count at 30x ends up using, split
+// between the temporary and the long-lived region as measured on the MI355X (SMX_PREWARM_X="bottom,top" overrides them; 0,0 turns it off).
+inline void prewarm_for_inputs(smx_ctx *ctx, const std::vector<std::string> &files, double bottom_x, double top_x) {
+    if (const char *e = getenv("SMX_PREWARM_X")) {
+        if (sscanf(e, "%lf,%lf", &bottom_x, &top_x) != 2) return;
+    }
+    double bytes = 0;
+    for (const std::string &f : files) {
+        struct stat st;
+        if (stat(f.c_str(), &st) != 0) continue;
+        const bool gz = f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0;
+        bytes += (double)st.st_size * (gz ? 4.0 : 1.0);
+    }
+    if (bytes <= 0) return;
+    (void)smx_prewarm(ctx, (size_t)(bytes * bottom_x), (size_t)(bytes * top_x));
+}
+
 inline int submit_file(smx_ctx *ctx, const std::string &path, std::mutex *mu = nullptr) {
     auto locked = [&](auto &&fn) {
         if (!mu) return fn();

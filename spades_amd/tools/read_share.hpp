@@ -11,6 +11,7 @@
 #include "../../include/smx.h"
 #include "fastq_split.hpp"
 #include "read_input.hpp"
+#include "rank_watchdog.hpp"
 
 namespace smxtool {
 
@@ -46,6 +47,7 @@ inline int submit_fastq_range(smx_ctx *ctx, const std::string &path, long long b
         const bool last = pos >= end;
         uint64_t n = 0, used = 0;
         rc = smx_submit_fastq_text(ctx, buf, have, last ? 1 : 0, &n, &used);
+        RankWatch::tick();
         if (rc) break;
         if (used == 0 && !last && have == chunk_bytes) {  // a single record larger than the chunk
             rc = SMX_INVALID_INPUT_FORMAT;
@@ -88,6 +90,7 @@ inline int submit_bgzf_range(smx_ctx *ctx, const BgzfText &bz, long long begin, 
         const bool last = pos >= end;
         uint64_t n = 0, used = 0;
         rc = smx_submit_fastq_text(ctx, buf, have, last ? 1 : 0, &n, &used);
+        RankWatch::tick();
         if (rc) break;
         if (used == 0 && !last && have == chunk_bytes) {  // a single record larger than the chunk
             rc = SMX_INVALID_INPUT_FORMAT;
@@ -138,6 +141,7 @@ inline int submit_share(smx_ctx *ctx, const std::string &path, unsigned part, un
         batch.add(s);
         if (batch.bases.size() > ((size_t)1 << 30) && !rc) {
             rc = smx_submit_reads_ascii(ctx, batch.bases.data(), batch.off.data(), batch.size());
+            RankWatch::tick();
             batch.clear();
         }
     });

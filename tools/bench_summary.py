@@ -2,6 +2,9 @@
 """one-screen summary of a bench.py JSON line"""
 import json, sys
 d = json.load(open(sys.argv[1]))
+# rounds 1-4 reported the upload-inclusive rate as `value`; since round 5 that figure is pcie_inclusive.value (value_definition in the line)
+like_r4 = (d.get("pcie_inclusive") or {}).get("value", d["value"] if d.get("config", {}).get("h2d_in_timed_region", True) else None)
+print("comparable with BENCH_r01..r04 `value` (upload inside the step):", like_r4)
 print("value", d["value"], "ms/step", d["ms_per_step"], d.get("step_breakdown_ms"), "pcie_inclusive", (d.get("pcie_inclusive") or {}).get("value"), (d.get("pcie_inclusive") or {}).get("ms_per_step"))
 st = d["roofline"]["stages_ms"]
 con = ("rank_dir", "fill_masks", "candidates", "walk_len", "keep", "walk_write", "succ")

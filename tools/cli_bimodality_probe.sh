@@ -1,0 +1,47 @@
+#!/bin/bash
+# "build graph" of spades-gbuilder-mi355x was 1.387 s on the driver's box and 0.131 s in the builder's run of the same 20 M-read leg.
+# Fresh processes, one after the other, with the arena's own account of its mapping time (SMX_DEBUG: "[smx] arena: ... mapped in ... s") —
+# with the prewarm helper (default) and without it (SMX_PREWARM_X=0,0). usage: cli_bimodality_probe.sh <reads, default 20000000>
+set -u
+N=${1:-20000000}
+cd "$(dirname "$0")/.."
+D=$(mktemp -d -p /dev/shm)
+python - "$N" "$D/r.fq" <<'PY'
+import sys, numpy as np
+sys.path.insert(0, "tests")
+n, path = int(sys.argv[1]), sys.argv[2]
+rng = np.random.default_rng(5)
+G = n * 150 // 30
+genome = rng.integers(0, 4, G, dtype=np.uint8)
+lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+with open(path, "wb") as f:
+    for c0 in range(0, n, 1 << 20):
+        m = min(1 << 20, n - c0)
+        p = rng.integers(0, G - 150, m)
+        blk = genome[p[:, None] + np.arange(150)[None, :]]
+        err = rng.random(blk.shape) < 0.01
+        blk = np.where(err, (blk + rng.integers(1, 4, blk.shape, dtype=np.uint8)) % 4, blk)
+        rec = np.empty((m, 12 + 150 + 3 + 150 + 1), dtype=np.uint8)
+        rec[:, 0], rec[:, 1] = ord("@"), ord("r")
+        rec[:, 2:11] = np.frombuffer("".join(np.char.zfill(np.arange(c0, c0 + m).astype(str), 9)).encode(), dtype=np.uint8).reshape(m, 9)
+        rec[:, 11] = 10
+        rec[:, 12:162] = lut[blk]
+        rec[:, 162], rec[:, 163], rec[:, 164] = 10, ord("+"), 10
+        rec[:, 165:315] = ord("I")
+        rec[:, 315] = 10
+        rec.tofile(f)
+PY
+ls -la "$D/r.fq"
+for mode in "default" "0,0" "default" "0,0" "default" "0,0"; do
+  echo "=== spades-gbuilder-mi355x, prewarm: $mode"
+  if [ "$mode" = "default" ]; then unset SMX_PREWARM_X; else export SMX_PREWARM_X=$mode; fi
+  /usr/bin/time -f "wall %e s" env SMX_DEBUG=1 spades_amd/tools/spades-gbuilder-mi355x "$D/r.fq" "$D/o.gfa" -k 55 -t 16 --gfa 2>&1 | grep -E "^\[tool\]|arena:|wall|g:" 
+  rm -f "$D/o.gfa"
+done
+for mode in "default" "0,0" "default" "0,0"; do
+  echo "=== spades-kmercount-mi355x, prewarm: $mode"
+  if [ "$mode" = "default" ]; then unset SMX_PREWARM_X; else export SMX_PREWARM_X=$mode; fi
+  /usr/bin/time -f "wall %e s" env SMX_DEBUG=1 spades_amd/tools/spades-kmercount-mi355x -k 55 -w "$D" "$D/r.fq" 2>&1 | grep -E "^\[tool\]|arena:|wall"
+  rm -f "$D/final_kmers"
+done
+rm -rf "$D"
