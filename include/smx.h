@@ -289,6 +289,32 @@ int smx_graph_shard_ext_stats(const smx_ctx *ctx, uint64_t *stats /* [2] */);
  *      in k-mer-file order with GLOBAL ranks) -> link records, vertices, every writer and smx_graph_fill_coverage as after
  *      smx_build_graph. That graph has no k-mer file: smx_graph_copy_kmers / smx_graph_fingerprint refuse. */
 int smx_shard_walk_counts(smx_ctx *ctx, uint64_t *n_chain_requests, uint64_t *n_start_requests);
+/* Steps 1-4 behind ONE call (round 6): the caller brings its collectives, the library does everything else on the device — successor
+ * lookups range by range, pointer doubling, chain nucleotides to the heads of their chains, the chains of this rank's start de-edges,
+ * assembly. The library still never touches a communicator: spades-gbuilder-mi355x --gpus N hands in grouped ncclSend / ncclRecv
+ * (tools/gbuilder_mgpu.hpp), spades_amd.dist torch.distributed; an MPI host would hand in MPI_Alltoallv. Role model in the reference tree:
+ * hpcspades/mpi/stages/construction_mpi.cpp:303-412 (the construction's phases over processes, collectives between them).
+ * Callbacks return 0 or non-zero (the call then fails with SMX_DEVICE_ERROR); they are called on the caller's thread, between kernels: the
+ * library's stream is idle when one is entered, and the data a callback moved must be complete when it returns.
+ *   exchange_counts: send_counts[world] of this rank -> recv_counts[p] = what rank p's send_counts[this rank] was (an all-to-all of one word
+ *                    per pair; all ones in any entry = that rank has failed: every rank then leaves the call together);
+ *   alltoallv:       segments of `unit_bytes`-byte elements between DEVICE buffers, grouped by rank in rank order on both sides
+ *                    (send_counts / recv_counts in elements; the segment a rank keeps is copied like any other);
+ *   allreduce_u64:   n host words reduced over all ranks in place, op 0 = sum, 1 = max.
+ * kmers_per_rank[world]: k-mers of every rank's shard (smx_graph_shard_info on each, all-gathered). On success info[4] = this rank's kept
+ * unitigs, their 2-bit words, its k-mers on perfect loops, doubling rounds; the unitigs wait for smx_shard_unitigs_copy, the loop k-mers'
+ * local ranks (ascending) for smx_shard_walk_loops. Collective: every rank calls it; a rank-local failure reaches every rank at its next
+ * collective and all return non-zero. Options "walk_chunk" / "walk_start_chunk" (oriented nodes / start de-edges per exchange round,
+ * default 2^26 / 2^22) bound the temporaries; "walk_hop_bits" (24) is the width of a node's step counter. */
+typedef struct smx_collectives {
+    void *user;
+    unsigned rank, world;
+    int (*exchange_counts)(void *user, const uint64_t *send_counts, uint64_t *recv_counts);
+    int (*alltoallv)(void *user, const void *d_send, const uint64_t *send_counts, void *d_recv, const uint64_t *recv_counts, unsigned unit_bytes);
+    int (*allreduce_u64)(void *user, uint64_t *values, unsigned n, int op);
+} smx_collectives;
+int smx_shard_walks(smx_ctx *ctx, const uint64_t *kmers_per_rank /* [world] */, const smx_collectives *coll, uint64_t *info /* [4] */);
+int smx_shard_walk_loops(const smx_ctx *ctx, uint64_t *d_local_ranks);
 int smx_shard_walk_requests(smx_ctx *ctx, int starts, unsigned world, void *d_records, uint64_t *d_tags, uint64_t *counts /* [world] */);
 /* ... the same for the items [first_item, first_item + n_items) only (oriented nodes 2 * local rank + orientation, or start de-edges in
  * k-mer-file order): at most one request per item, so buffers of n_items records / tags suffice — a caller that walks a shard of

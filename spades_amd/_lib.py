@@ -93,6 +93,8 @@ def load():
         "smx_shard_walk_requests": (C.c_int, [vp, C.c_int, C.c_uint, vp, u64p, u64p]),
         "smx_shard_walk_requests_range": (C.c_int, [vp, C.c_int, C.c_uint, C.c_uint64, C.c_uint64, vp, u64p, u64p]),
         "smx_shard_walk_starts": (C.c_int, [vp, u64p]),
+        "smx_shard_walks": (C.c_int, [vp, u64p, vp, u64p]),
+        "smx_shard_walk_loops": (C.c_int, [vp, u64p]),
         "smx_shard_lookup": (C.c_int, [vp, vp, C.c_uint64, u64p]),
         "smx_shard_gather_kmers": (C.c_int, [vp, u64p, C.c_uint64, vp, C.POINTER(C.c_uint8)]),
         "smx_shard_unitigs": (C.c_int, [vp, C.c_uint64, u64p, u64p, u64p, C.POINTER(C.c_uint8), u64p, u64p]),

@@ -163,6 +163,10 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "skm_nkey_log2")) ctx->opt_skm_nkey_log2 = value;
     else if (!strcmp(key, "derive_batches")) ctx->opt_derive_batches = value;
     else if (!strcmp(key, "keep_kpo")) ctx->opt_keep_kpo = value;
+    else if (!strcmp(key, "walk_chunk")) ctx->opt_walk_chunk = value;
+    else if (!strcmp(key, "walk_start_chunk")) ctx->opt_walk_start_chunk = value;
+    else if (!strcmp(key, "walk_hop_bits")) ctx->opt_walk_hop_bits = value;
+    else if (!strcmp(key, "walk_fail_at")) ctx->opt_walk_fail_at = value;
     else if (!strcmp(key, "verify_lookups")) ctx->opt_verify_lookups = value;
     else if (!strcmp(key, "spill")) ctx->opt_spill = value;
     else if (!strcmp(key, "spill_merge_max")) ctx->opt_spill_merge_max = value;
@@ -1173,6 +1177,32 @@ int smx_shard_walk_counts(smx_ctx *ctx, uint64_t *n_chain_requests, uint64_t *n_
     *n_chain_requests = ctx->dw_nchain;
     *n_start_requests = ctx->dw_ncand;
     return rc;
+}
+
+int smx_shard_walks(smx_ctx *ctx, const uint64_t *kmers_per_rank, const smx_collectives *coll, uint64_t *info) {
+    if (int rc = dw_check_shard(ctx)) return rc;
+    if (!kmers_per_rank || !coll || !info) return fail(ctx, SMX_INVALID_PARAMETER, "smx_shard_walks: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    info[0] = info[1] = info[2] = info[3] = 0;
+    int rc;
+    switch (ctx->g_nw) {
+        case 1: rc = dw_walks<1>(ctx, kmers_per_rank, coll, info); break;
+        case 2: rc = dw_walks<2>(ctx, kmers_per_rank, coll, info); break;
+        case 3: rc = dw_walks<3>(ctx, kmers_per_rank, coll, info); break;
+        default: rc = dw_walks<4>(ctx, kmers_per_rank, coll, info); break;
+    }
+    return finish_call(ctx, rc, false);
+}
+
+int smx_shard_walk_loops(const smx_ctx *cctx, uint64_t *d_local_ranks) {
+    smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
+    if (!ctx || !ctx->dw_ready) return SMX_INVALID_PARAMETER;
+    if (ctx->dw_nloops == 0) return SMX_OK;
+    if (!d_local_ranks || !ctx->dw_loops) return SMX_INVALID_PARAMETER;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(d_local_ranks, ctx->dw_loops, ctx->dw_nloops * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SMX_OK;
 }
 
 int smx_shard_walk_requests_range(smx_ctx *ctx, int starts, unsigned world, uint64_t first_item, uint64_t n_items, void *d_records, uint64_t *d_tags,

@@ -65,6 +65,9 @@ void clear_graph(smx_ctx *ctx) {
     pm_release(ctx);
     arena_put(ctx, ctx->dw_cand);
     ctx->dw_cand = nullptr;
+    arena_put(ctx, ctx->dw_loops);
+    ctx->dw_loops = nullptr;
+    ctx->dw_nloops = 0;
     ctx->dw_ncand = ctx->dw_nchain = 0;
     ctx->dw_ready = false;
     ctx->g_sharded_file = false;

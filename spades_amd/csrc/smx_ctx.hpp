@@ -175,6 +175,11 @@ struct smx_ctx {
     unsigned long long *dw_cand = nullptr;
     uint64_t dw_ncand = 0, dw_nchain = 0;
     bool dw_ready = false;
+    unsigned long long *dw_loops = nullptr;  // after smx_shard_walks: local ranks of the shard's k-mers on perfect loops, ascending
+    uint64_t dw_nloops = 0;
+    int64_t opt_walk_chunk = 0, opt_walk_start_chunk = 0;  // smx_shard_walks: oriented nodes / start de-edges per exchange round (0: 2^26 / 2^22; tests make them small)
+    int64_t opt_walk_fail_at = 0;                          // test hook: this rank's local step fails in that phase (1..5) of smx_shard_walks
+    int64_t opt_walk_hop_bits = 24;                        // ... bits of a node's word that count the steps to its pointer (tests: chains at the limit)
     bool g_sharded_file = false;  // the graph was built from gathered unitigs: no k-mer file, no masks on this rank (smx_build_graph_from_unitigs)
     // the graph itself, resident in HBM (unitigs 2-bit packed, word-aligned starts; edges in the reference's enumeration order)
     uint64_t *g_uwords = nullptr;                          // [g_nuwords + 8]

@@ -154,4 +154,346 @@ __global__ void k_dw_words_of(const unsigned long long *elen, uint64_t ne, unsig
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += (uint64_t)gridDim.x * blockDim.x) w[i] = (elen[i] + 31) / 32;
 }
 
+
+// ---- the plumbing between the k-mer steps, on the device (round 6) -------------------------------------------------------------------
+// Until round 5 the routing by owner, the pointer doubling and the ragged fetch of the chains were torch tensor code in spades_amd/dist.py
+// (at::native sort / searchsorted / index kernels: 19.8 s for one rank's share of BASELINE config 4). They are these kernels now, driven by
+// dw_walks (smx_dwalk.hpp) with the caller's collectives between them — from C++ (tools/gbuilder_mgpu.hpp: grouped ncclSend / ncclRecv) or
+// Python (dist.py: torch.distributed). Role model in the reference tree: hpcspades/mpi/stages/construction_mpi.cpp:303-412 (construction
+// phases spread over processes); the algorithm is SURVEY.md §8(e)'s "bulk-synchronous pointer-jumping rounds with an all-to-all per round".
+//
+// State of a local oriented node: ONE packed word + one byte (as dist.py had it since round 4):
+//   word  F << 63 | T << 62 | id << HB | hops     F: the end of the chain is known; T: this node IS the end (its successor is a junction
+//         open:      id = pointer, hops = steps to it      k-mer); id: 62 - HB bits; hops: HB bits (24: a chain of 16.7 M k-mers or more is refused)
+//         tail (T):  id = the junction node behind it
+//         finished:  id = the tail of its chain, hops = steps to the tail
+//   byte  bit 0 chain k-mer (non-junction), bit 1 its successor is a junction k-mer, bits 2-3 its outgoing nucleotide
+struct DwBits {
+    unsigned hb;
+    unsigned long long idm, hm;
+};
+constexpr unsigned long long DW_F = 1ull << 63, DW_T = 1ull << 62;
+constexpr unsigned DW_MAX_WORLD = 64;
+struct DwOwners {  // bound[p] = first global node of rank p + 1: owner_of(node) = the first p with node < bound[p]
+    unsigned long long bound[DW_MAX_WORLD];
+    unsigned world;
+};
+struct DwSegs {  // send-order segments of an exchange: segment p = [off[p], off[p + 1]) went to / came from rank p; add[p]: what its answers are relative to
+    unsigned long long off[DW_MAX_WORLD + 1];
+    unsigned long long add[DW_MAX_WORLD];
+    unsigned world;
+};
+__device__ __forceinline__ uint32_t dw_owner_of(const DwOwners &o, unsigned long long node) {
+    uint32_t p = 0;
+    while (p + 1 < o.world && node >= o.bound[p]) ++p;
+    return p;
+}
+__device__ __forceinline__ bool dw_open(unsigned long long w, uint8_t f) { return (f & 1) && !(w & DW_F); }
+__device__ __forceinline__ bool dw_done(unsigned long long w, uint8_t f) { return (f & 1) && (w & DW_F); }
+
+// One workgroup round of the two-pass grouping by owner: every thread brings up to NM messages; PASS 0 adds the workgroup's counts per owner
+// to hist, PASS 1 takes the workgroup's place from the cursors (initialised with the exclusive scan of hist) and returns every message's
+// slot in the send order. lds: [world] counts + [world] bases. Contains barriers: call from all threads.
+template <int NM>
+__device__ __forceinline__ void dw_group(unsigned long long *lcnt, unsigned long long *lbase, uint32_t world, const bool (&has)[NM], const uint32_t (&ow)[NM],
+                                         unsigned long long *hist_or_cursor, unsigned long long (&slot)[NM]) {
+    for (uint32_t t = threadIdx.x; t < world; t += BLK) lcnt[t] = 0;
+    __syncthreads();
+    unsigned long long at[NM];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) at[j] = has[j] ? atomicAdd(&lcnt[ow[j]], 1ull) : 0ull;
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < world; t += BLK)
+        if (lcnt[t]) lbase[t] = atomicAdd(&hist_or_cursor[t], lcnt[t]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NM; ++j) slot[j] = has[j] ? lbase[ow[j]] + at[j] : 0ull;
+    __syncthreads();
+}
+
+// answers of the owners to the successor requests (k_dw_requests -> all-to-all -> k_dw_lookup -> all-to-all back), in send order:
+// chain requests set the node's word and byte, start requests the first node of the de-edge and whether that is a junction k-mer
+template <bool CAND>
+__global__ void __launch_bounds__(BLK) k_dw_apply_succ(const unsigned long long *__restrict__ tags, const unsigned long long *__restrict__ back, uint64_t n, DwSegs sg,
+                                                       DwBits b, unsigned long long *word, uint8_t *flag, unsigned long long *c_first, uint8_t *c_fj, uint32_t *err) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        uint32_t p = 0;
+        while (p + 1 < sg.world && i >= sg.off[p + 1]) ++p;
+        const unsigned long long r = back[i], tag = tags[i];
+        if (r == ~0ull) {  // the successor k-mer is in no shard: the k-mer file and the masks disagree
+            atomicAdd(err, 1u);
+            continue;
+        }
+        const unsigned long long junc = r & 1ull, node = ((((r >> 1) + sg.add[p]) << 1) | ((tag >> 2) & 1ull)), item = tag >> DW_TAG_SHIFT;
+        if (CAND) {
+            c_first[item] = node;
+            c_fj[item] = (uint8_t)junc;
+        } else {
+            word[item] = junc ? ((node << b.hb) | DW_F | DW_T) : ((node << b.hb) | 1ull);
+            flag[item] = (uint8_t)(1u | (unsigned)(junc << 1) | ((unsigned)(tag & 3) << 2));
+        }
+    }
+}
+__global__ void __launch_bounds__(BLK) k_dw_count_open(const unsigned long long *__restrict__ word, const uint8_t *__restrict__ flag, uint64_t n2, unsigned long long *out) {
+    __shared__ unsigned long long scratch[BLK / 64 + 2];
+    unsigned long long c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * BLK) c += dw_open(word[i], flag[i]) ? 1 : 0;
+    unsigned long long tot;
+    block_excl_scan<unsigned long long>(c, scratch, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(out, tot);
+}
+// doubling: the open nodes of [a, a + n) ask the owners of their pointers for those nodes' words; q[slot] = pointer, tag[slot] = asking node
+template <int PASS>
+__global__ void __launch_bounds__(BLK) k_dw_open_req(const unsigned long long *__restrict__ word, const uint8_t *__restrict__ flag, uint64_t a, uint64_t n, DwBits b,
+                                                     DwOwners ow, unsigned long long *hist_or_cursor, unsigned long long *q, unsigned long long *tag) {
+    extern __shared__ unsigned long long lds_dw[];
+    for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n; base += (uint64_t)gridDim.x * BLK) {
+        const uint64_t i = a + base + threadIdx.x;
+        bool has[1] = {false};
+        uint32_t o[1] = {0};
+        unsigned long long tg = 0, slot[1];
+        if (base + threadIdx.x < n) {
+            const unsigned long long w = word[i];
+            if (dw_open(w, flag[i])) {
+                has[0] = true;
+                tg = (w >> b.hb) & b.idm;
+                o[0] = dw_owner_of(ow, tg);
+            }
+        }
+        dw_group<1>(lds_dw, lds_dw + ow.world, ow.world, has, o, hist_or_cursor, slot);
+        if (PASS == 1 && has[0]) {
+            q[slot[0]] = tg;
+            tag[slot[0]] = i;
+        }
+    }
+}
+// owner side: the words of the nodes that were asked for (global ids -> local)
+__global__ void __launch_bounds__(BLK) k_dw_gather_words(const unsigned long long *__restrict__ q, uint64_t n, unsigned long long my_base, uint64_t n2,
+                                                         const unsigned long long *__restrict__ word, unsigned long long *rows, uint32_t *err) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        const unsigned long long loc = q[i] - my_base;
+        if (loc >= n2) {
+            atomicAdd(err, 1u);
+            rows[i] = DW_F | DW_T;
+        } else {
+            rows[i] = word[loc];
+        }
+    }
+}
+// one doubling step of the asking nodes: wp = word of the pointer. A pointer only ever moves ahead along its chain, so a word of this round
+// or of the one before is equally good. Only a node that FINISHES can have a chain length to overflow (a node on a perfect loop never
+// finishes and doubles its count every round): open nodes saturate at HM — sticky — and a node that finishes with HM or more is refused.
+__global__ void __launch_bounds__(BLK) k_dw_double_apply(const unsigned long long *__restrict__ tag, const unsigned long long *__restrict__ wp_, uint64_t n, DwBits b,
+                                                         unsigned long long *word, uint32_t *too_long) {
+    for (uint64_t s = (uint64_t)blockIdx.x * BLK + threadIdx.x; s < n; s += (uint64_t)gridDim.x * BLK) {
+        const unsigned long long node = tag[s], mw = word[node], wp = wp_[s];
+        const unsigned long long tg = (mw >> b.hb) & b.idm;
+        const bool p_tail = (wp & DW_T) != 0, p_fin = (wp & DW_F) != 0;
+        unsigned long long hops = (mw & b.hm) + (p_tail ? 0ull : (wp & b.hm));
+        if (p_fin && hops >= b.hm) atomicAdd(too_long, 1u);
+        if (hops > b.hm) hops = b.hm;
+        const unsigned long long nid = p_tail ? tg : ((wp >> b.hb) & b.idm);
+        word[node] = (p_fin ? DW_F : 0ull) | (nid << b.hb) | hops;
+    }
+}
+// k-mers that never finished (perfect loops): tiles of CAND_TILE local ranks — counts, a scan over the tiles, ascending list
+template <int PASS>
+__global__ void __launch_bounds__(BLK) k_dw_loops(const unsigned long long *__restrict__ word, const uint8_t *__restrict__ flag, uint64_t D0, unsigned long long *tcnt_or_off,
+                                                  unsigned long long *list) {
+    __shared__ uint32_t scratch[BLK / 64 + 2];
+    const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
+    uint32_t c = 0, fl = 0;
+    for (int j = 0; j < CAND_PER; ++j) {
+        const uint64_t r = r0 + j;
+        if (r < D0 && (dw_open(word[2 * r], flag[2 * r]) || dw_open(word[2 * r + 1], flag[2 * r + 1]))) {
+            fl |= 1u << j;
+            ++c;
+        }
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<uint32_t>(c, scratch, &tot);
+    if (PASS == 0) {
+        if (threadIdx.x == 0) tcnt_or_off[blockIdx.x] = tot;
+    } else {
+        unsigned long long o = tcnt_or_off[blockIdx.x] + ex;
+        for (int j = 0; j < CAND_PER; ++j)
+            if (fl & (1u << j)) list[o++] = r0 + j;
+    }
+}
+// heads of the chains: a finished chain k-mer whose reverse-strand node is a tail. One bit per node and the number of heads before every
+// 64 nodes (hpre, after the caller's scan): slot of a head = hpre[node / 64] + popcount of the lower bits — no search, 16 B per 64 nodes.
+__global__ void __launch_bounds__(BLK) k_dw_head_bits(const unsigned long long *__restrict__ word, const uint8_t *__restrict__ flag, uint64_t n2, uint64_t nwords,
+                                                      unsigned long long *hbits, unsigned long long *hcnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t w = (uint64_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6); w < nwords; w += (uint64_t)gridDim.x * (BLK / 64)) {
+        const uint64_t nd = w * 64 + lane;
+        const bool h = nd < n2 && dw_done(word[nd], flag[nd]) && (word[nd ^ 1] & DW_T);
+        const unsigned long long bal = __ballot(h);
+        if (lane == 0) {
+            hbits[w] = bal;
+            hcnt[w] = (unsigned long long)__popcll(bal);
+        }
+    }
+}
+__device__ __forceinline__ bool dw_head_slot(const unsigned long long *__restrict__ hbits, const unsigned long long *__restrict__ hpre, unsigned long long loc, uint64_t n2,
+                                             unsigned long long &slot) {
+    if (loc >= n2) return false;
+    const unsigned long long bal = hbits[loc >> 6], bit = loc & 63ull;
+    if (!((bal >> bit) & 1ull)) return false;
+    slot = hpre[loc >> 6] + (unsigned long long)__popcll(bal & ((1ull << bit) - 1ull));
+    return true;
+}
+// k-mers of every chain (a head that is its own tail: 1), in head order; the caller scans them into the chains' places
+__global__ void __launch_bounds__(BLK) k_dw_head_len(const unsigned long long *__restrict__ word, const unsigned long long *__restrict__ hbits,
+                                                     const unsigned long long *__restrict__ hpre, uint64_t n2, DwBits b, unsigned long long *hlen) {
+    for (uint64_t nd = (uint64_t)blockIdx.x * BLK + threadIdx.x; nd < n2; nd += (uint64_t)gridDim.x * BLK) {
+        unsigned long long slot;
+        if (!dw_head_slot(hbits, hpre, nd, n2, slot)) continue;
+        const unsigned long long hw = word[nd];
+        hlen[slot] = ((hw & DW_T) ? 0ull : (hw & b.hm)) + 1ull;
+    }
+}
+// every finished chain k-mer x of [a, a + n) to the head of its chain: x is hops(x^1) steps behind the head tail(x^1)^1 (the reverse strand
+// went through the same doubling) — message (head, steps << 2 | outgoing nucleotide); a tail also tells which junction node ends the chain:
+// (head, -(end node) - 1)
+template <int PASS>
+__global__ void __launch_bounds__(BLK) k_dw_head_msgs(const unsigned long long *__restrict__ word, const uint8_t *__restrict__ flag, uint64_t a, uint64_t n,
+                                                      unsigned long long my_base, DwBits b, DwOwners ow, unsigned long long *hist_or_cursor, ulonglong2 *msg) {
+    extern __shared__ unsigned long long lds_dw[];
+    for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n; base += (uint64_t)gridDim.x * BLK) {
+        const uint64_t xs = a + base + threadIdx.x;
+        bool has[2] = {false, false};
+        uint32_t o[2] = {0, 0};
+        unsigned long long head = 0, pay0 = 0, pay1 = 0, slot[2];
+        if (base + threadIdx.x < n) {
+            const unsigned long long ws = word[xs];
+            const uint8_t f = flag[xs];
+            if (dw_done(ws, f)) {
+                const unsigned long long xr = xs ^ 1ull, wr = word[xr];
+                head = ((wr & DW_T) ? (xr + my_base) : ((wr >> b.hb) & b.idm)) ^ 1ull;
+                const unsigned long long back = (wr & DW_T) ? 0ull : (wr & b.hm);
+                pay0 = (back << 2) | ((unsigned long long)(f >> 2) & 3ull);
+                has[0] = true;
+                o[0] = o[1] = dw_owner_of(ow, head);
+                if (ws & DW_T) {
+                    has[1] = true;
+                    pay1 = ~((ws >> b.hb) & b.idm);  // = -(end) - 1
+                }
+            }
+        }
+        dw_group<2>(lds_dw, lds_dw + ow.world, ow.world, has, o, hist_or_cursor, slot);
+        if (PASS == 1) {
+            if (has[0]) msg[slot[0]] = make_ulonglong2(head, pay0);
+            if (has[1]) msg[slot[1]] = make_ulonglong2(head, pay1);
+        }
+    }
+}
+// owner of the heads: every message to its place. stats[0] += nucleotides placed, [1] += messages for a node that heads no chain or beyond its chain
+__global__ void __launch_bounds__(BLK) k_dw_place(const ulonglong2 *__restrict__ msg, uint64_t n, unsigned long long my_base, uint64_t n2,
+                                                  const unsigned long long *__restrict__ hbits, const unsigned long long *__restrict__ hpre,
+                                                  const unsigned long long *__restrict__ hoff, unsigned long long *hend, uint8_t *bases, unsigned long long *stats) {
+    __shared__ unsigned long long scratch[BLK / 64 + 2];
+    unsigned long long placed = 0, bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        const ulonglong2 m = msg[i];
+        unsigned long long slot;
+        if (!dw_head_slot(hbits, hpre, m.x - my_base, n2, slot)) {
+            ++bad;
+            continue;
+        }
+        if ((long long)m.y < 0) {
+            hend[slot] = ~m.y;
+        } else {
+            const unsigned long long pos = hoff[slot] + (m.y >> 2);
+            if (pos >= hoff[slot + 1]) {
+                ++bad;
+                continue;
+            }
+            bases[pos] = (uint8_t)(m.y & 3ull);
+            ++placed;
+        }
+    }
+    unsigned long long tot;
+    block_excl_scan<unsigned long long>(placed, scratch, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(&stats[0], tot);
+    block_excl_scan<unsigned long long>(bad, scratch, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(&stats[1], tot);
+}
+__global__ void __launch_bounds__(BLK) k_dw_count_unset(const unsigned long long *__restrict__ hend, uint64_t n, unsigned long long *out) {
+    __shared__ unsigned long long scratch[BLK / 64 + 2];
+    unsigned long long c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) c += hend[i] == ~0ull ? 1 : 0;
+    unsigned long long tot;
+    block_excl_scan<unsigned long long>(c, scratch, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd(out, tot);
+}
+// the start de-edges of [a, a + n) whose first node is a chain k-mer ask the owner of that node — the head of a chain — for the chain
+template <int PASS>
+__global__ void __launch_bounds__(BLK) k_dw_start_asks(const unsigned long long *__restrict__ c_first, const uint8_t *__restrict__ c_fj, uint64_t a, uint64_t n,
+                                                       DwOwners ow, unsigned long long *hist_or_cursor, unsigned long long *q, unsigned long long *tag) {
+    extern __shared__ unsigned long long lds_dw[];
+    for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n; base += (uint64_t)gridDim.x * BLK) {
+        const uint64_t i = a + base + threadIdx.x;
+        bool has[1] = {false};
+        uint32_t o[1] = {0};
+        unsigned long long tg = 0, slot[1];
+        if (base + threadIdx.x < n && !c_fj[i]) {
+            has[0] = true;
+            tg = c_first[i];
+            o[0] = dw_owner_of(ow, tg);
+        }
+        dw_group<1>(lds_dw, lds_dw + ow.world, ow.world, has, o, hist_or_cursor, slot);
+        if (PASS == 1 && has[0]) {
+            q[slot[0]] = tg;
+            tag[slot[0]] = i;
+        }
+    }
+}
+// owner of the heads: (length, end node) of the chain behind every asked node, its slot and its length once more for the scan of the bases
+__global__ void __launch_bounds__(BLK) k_dw_answer(const unsigned long long *__restrict__ asks, uint64_t n, unsigned long long my_base, uint64_t n2,
+                                                   const unsigned long long *__restrict__ hbits, const unsigned long long *__restrict__ hpre,
+                                                   const unsigned long long *__restrict__ hoff, const unsigned long long *__restrict__ hend, ulonglong2 *rows,
+                                                   unsigned long long *slots, unsigned long long *lens, uint32_t *err) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        unsigned long long slot = 0, len = 0, end = ~0ull;
+        if (dw_head_slot(hbits, hpre, asks[i] - my_base, n2, slot)) {
+            len = hoff[slot + 1] - hoff[slot];
+            end = hend[slot];
+        } else {
+            atomicAdd(err, 1u);  // a start de-edge leads to a k-mer that heads no chain
+        }
+        if (rows) rows[i] = make_ulonglong2(len, end);
+        if (slots) slots[i] = slot;
+        if (lens) lens[i] = len;
+    }
+}
+__global__ void __launch_bounds__(BLK) k_dw_place_rows(const unsigned long long *__restrict__ tag, const ulonglong2 *__restrict__ rows, uint64_t n, unsigned long long *steps,
+                                                       unsigned long long *last, uint32_t *err) {
+    for (uint64_t s = (uint64_t)blockIdx.x * BLK + threadIdx.x; s < n; s += (uint64_t)gridDim.x * BLK) {
+        const ulonglong2 r = rows[s];
+        if (r.x == 0) atomicAdd(err, 1u);
+        steps[tag[s]] = r.x;
+        last[tag[s]] = r.y;
+    }
+}
+// the nucleotides of the asked chains, one after the other in the order of the asks (off = scan of their lengths)
+__global__ void __launch_bounds__(BLK) k_dw_ragged_copy(const unsigned long long *__restrict__ slots, const unsigned long long *__restrict__ off, uint64_t n,
+                                                        const unsigned long long *__restrict__ hoff, const uint8_t *__restrict__ bases, uint8_t *flat) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLK) {
+        const unsigned long long o = off[i], len = off[i + 1] - o, src = hoff[slots[i]];
+        for (unsigned long long j = 0; j < len; ++j) flat[o + j] = bases[src + j];
+    }
+}
+__global__ void __launch_bounds__(BLK) k_dw_lens_of(const unsigned long long *__restrict__ tag, uint64_t n, const unsigned long long *__restrict__ steps, unsigned long long *lens) {
+    for (uint64_t s = (uint64_t)blockIdx.x * BLK + threadIdx.x; s < n; s += (uint64_t)gridDim.x * BLK) lens[s] = steps[tag[s]];
+}
+// ... and on the asking side from the order of the asks to the places of the start de-edges (boff: scan of steps in de-edge order)
+__global__ void __launch_bounds__(BLK) k_dw_scatter_bases(const unsigned long long *__restrict__ tag, const unsigned long long *__restrict__ off, uint64_t n,
+                                                          const unsigned long long *__restrict__ boff, const uint8_t *__restrict__ mine, uint8_t *my_bases) {
+    for (uint64_t s = (uint64_t)blockIdx.x * BLK + threadIdx.x; s < n; s += (uint64_t)gridDim.x * BLK) {
+        const unsigned long long o = off[s], len = off[s + 1] - o, dst = boff[tag[s]];
+        for (unsigned long long j = 0; j < len; ++j) my_bases[dst + j] = mine[o + j];
+    }
+}
+
 }  // namespace smx

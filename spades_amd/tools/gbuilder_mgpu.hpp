@@ -11,7 +11,11 @@
 //   (k+1)-mer file at a time (never the whole file on a rank) and sums the raw edge coverages (ncclAllReduce) —
 //   smx_build_graph_from_kmers; rank 0 writes the output.
 // Exchanges are grouped ncclSend / ncclRecv between all pairs (xGMI is point to point: every pair has its own link, no ring).
-// A graph whose gathered structure exceeds one GPU's HBM needs the distributed walks, which only dist.py drives today.
+// A graph whose gathered structure exceeds the HBM of the rank that would build it (BASELINE configs 4 and 5) takes the DISTRIBUTED WALKS
+// instead (round 6; SMX_MGPU_WALKS=distributed forces them, =gathered refuses such a graph with the memory-limit code as rounds 4-5 did): the
+// k-mer file stays sharded, smx_shard_walks does lookups / pointer doubling / chain fetch on the device with THIS host's collectives between
+// its kernels (walk_collectives below), only the unitigs (2 bits per base + 25 B each: ~3 % of the k-mer file) and the k-mers of perfect loops
+// are gathered, and smx_build_graph_from_unitigs derives link records and vertices. Same GFA, byte for byte.
 #pragma once
 #include <sys/prctl.h>
 #include "rank_watchdog.hpp"
@@ -80,6 +84,8 @@ struct RankComm {
     int rank = 0, world = 1;
     ncclComm_t comm{};
     hipStream_t stream{};
+    uint64_t *d_scratch = nullptr;  // device words for the small collectives (counts, flags): allocated once, not per call
+    size_t scratch_words = 0;
 };
 
 // words per pair and round of an exchange (1 GiB; SMX_MGPU_ROUND_WORDS: a test hook that makes small inputs take several rounds)
@@ -120,16 +126,24 @@ inline int comm_init(RankComm &c, const std::string &idfile) {
 }
 
 // every rank's `n` words -> all[world * n] on every rank
+inline int scratch_words(RankComm &c, size_t words) {
+    if (words <= c.scratch_words) return 0;
+    if (c.d_scratch) (void)hipFree(c.d_scratch);
+    c.d_scratch = nullptr;
+    c.scratch_words = 0;
+    const size_t want = std::max<size_t>(words, 4096);
+    GM_HIP(hipMalloc((void **)&c.d_scratch, want * 8));
+    c.scratch_words = want;
+    return 0;
+}
 inline int all_gather_words(RankComm &c, const uint64_t *mine, size_t n, std::vector<uint64_t> &all) {
-    uint64_t *d_in = nullptr;
-    GM_HIP(hipMalloc((void **)&d_in, n * (size_t)(c.world + 1) * 8));
-    uint64_t *d_out = d_in + n;
+    if (int rc = scratch_words(c, n * (size_t)(c.world + 1))) return rc;
+    uint64_t *d_in = c.d_scratch, *d_out = d_in + n;
     GM_HIP(hipMemcpy(d_in, mine, n * 8, hipMemcpyHostToDevice));
     GM_NCCL(ncclAllGather(d_in, d_out, n, ncclUint64, c.comm, c.stream));
     GM_HIP(hipStreamSynchronize(c.stream));
     all.resize(n * (size_t)c.world);
     GM_HIP(hipMemcpy(all.data(), d_out, all.size() * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(d_in);
     return 0;
 }
 
@@ -247,6 +261,138 @@ inline int bcast_from(RankComm &c, int root, void *d_buf, uint64_t bytes) {
         smxtool::RankWatch::tick();
     }
     GM_HIP(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+// ---- the collectives smx_shard_walks asks its caller for (include/smx.h: smx_collectives) ------------------------------------------------------
+// exchange_counts: one all-gather of every rank's row of counts (world words each), this rank reads its column;
+// alltoallv: grouped ncclSend / ncclRecv between all pairs, in rounds of <= 1 GiB per pair (both ends of a pair know that pair's size, so they
+//   cut it into the same pieces: no agreement on a global number of rounds is needed), the segment that stays here as a device copy;
+// allreduce_u64: ncclAllReduce of the few words on the scratch block.
+struct WalkColl {
+    RankComm *c;
+};
+inline int walk_cb_counts(void *user, const uint64_t *send_counts, uint64_t *recv_counts) {
+    RankComm &c = *((WalkColl *)user)->c;
+    std::vector<uint64_t> all;
+    if (int rc = all_gather_words(c, send_counts, (size_t)c.world, all)) return rc;
+    for (int p = 0; p < c.world; ++p) recv_counts[p] = all[(size_t)p * c.world + c.rank];
+    smxtool::RankWatch::tick();
+    return 0;
+}
+inline int walk_cb_alltoallv(void *user, const void *d_send, const uint64_t *send_counts, void *d_recv, const uint64_t *recv_counts, unsigned unit) {
+    RankComm &c = *((WalkColl *)user)->c;
+    const bool self_rccl = getenv("SMX_MGPU_SELF_RCCL") != nullptr;
+    const uint64_t LIM = round_limit_words() * 8;  // bytes per pair and round
+    std::vector<uint64_t> soff(c.world + 1, 0), roff(c.world + 1, 0);
+    uint64_t mx = 0;
+    for (int p = 0; p < c.world; ++p) {
+        soff[p + 1] = soff[p] + send_counts[p] * unit;
+        roff[p + 1] = roff[p] + recv_counts[p] * unit;
+        if (p != c.rank || self_rccl) mx = std::max<uint64_t>(mx, std::max(send_counts[p], recv_counts[p]) * unit);
+    }
+    const uint64_t rounds = (mx + LIM - 1) / LIM;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        GM_NCCL(ncclGroupStart());
+        for (int p = 0; p < c.world; ++p) {
+            if (p == c.rank && !self_rccl) continue;
+            const uint64_t a = std::min(soff[p] + r * LIM, soff[p + 1]), b = std::min(a + LIM, soff[p + 1]);
+            const uint64_t e = std::min(roff[p] + r * LIM, roff[p + 1]), f = std::min(e + LIM, roff[p + 1]);
+            if (b > a) GM_NCCL(ncclSend((const char *)d_send + a, b - a, ncclUint8, p, c.comm, c.stream));
+            if (f > e) GM_NCCL(ncclRecv((char *)d_recv + e, f - e, ncclUint8, p, c.comm, c.stream));
+        }
+        GM_NCCL(ncclGroupEnd());
+        smxtool::RankWatch::tick();
+    }
+    if (!self_rccl && send_counts[c.rank])
+        GM_HIP(hipMemcpyAsync((char *)d_recv + roff[c.rank], (const char *)d_send + soff[c.rank], (size_t)send_counts[c.rank] * unit, hipMemcpyDeviceToDevice, c.stream));
+    GM_HIP(hipStreamSynchronize(c.stream));
+    return 0;
+}
+inline int walk_cb_allreduce(void *user, uint64_t *values, unsigned n, int op) {
+    RankComm &c = *((WalkColl *)user)->c;
+    if (int rc = scratch_words(c, n)) return rc;
+    GM_HIP(hipMemcpy(c.d_scratch, values, (size_t)n * 8, hipMemcpyHostToDevice));
+    GM_NCCL(ncclAllReduce(c.d_scratch, c.d_scratch, n, ncclUint64, op == 1 ? ncclMax : ncclSum, c.comm, c.stream));
+    GM_HIP(hipStreamSynchronize(c.stream));
+    GM_HIP(hipMemcpy(values, c.d_scratch, (size_t)n * 8, hipMemcpyDeviceToHost));
+    smxtool::RankWatch::tick();
+    return 0;
+}
+
+// The graph from the DISTRIBUTED walks: this rank's shard of {k-mer file, masks} is in the context; afterwards the ranks that build (rank 0, or
+// every rank with -c) hold the whole graph — link records and vertices from the gathered unitigs — and no rank ever held more than its bucket
+// range of the k-mer file.
+inline int graph_by_distributed_walks(RankComm &c, smx_ctx *ctx, unsigned k, unsigned nb, const std::vector<uint64_t> &kmers_per, uint64_t total_kmers,
+                                      uint64_t n_kpo_all, bool to_all, bool builds) {
+    const unsigned nwk = (k + 31) / 32;
+    WalkColl wc{&c};
+    smx_collectives co{};
+    co.user = &wc;
+    co.rank = (unsigned)c.rank;
+    co.world = (unsigned)c.world;
+    co.exchange_counts = walk_cb_counts;
+    co.alltoallv = walk_cb_alltoallv;
+    co.allreduce_u64 = walk_cb_allreduce;
+    uint64_t winfo[4] = {0, 0, 0, 0};
+    GM_MARK("distributed walks: smx_shard_walks")
+    GM_SMX(smx_shard_walks(ctx, kmers_per.data(), &co, winfo));  // (a failure on any rank comes back on every rank: nobody is left in a collective)
+    const uint64_t ne = winfo[0], nwd = winfo[1], nl = winfo[2];
+    if (c.rank == 0 && getenv("SMX_DEBUG")) fprintf(stderr, "[rank 0] distributed walks: %llu doubling rounds\n", (unsigned long long)winfo[3]);
+    uint64_t me2[3] = {ne, nwd, nl};
+    std::vector<uint64_t> every2;
+    if (int rc = all_gather_words(c, me2, 3, every2)) return rc;
+    std::vector<uint64_t> ne_r(c.world), nwd_r(c.world), nl_r(c.world), first(c.world + 1, 0);
+    uint64_t ne_all = 0, nwd_all = 0, nl_all = 0;
+    for (int p = 0; p < c.world; ++p) {
+        ne_all += (ne_r[p] = every2[(size_t)p * 3]);
+        nwd_all += (nwd_r[p] = every2[(size_t)p * 3 + 1]);
+        nl_all += (nl_r[p] = every2[(size_t)p * 3 + 2]);
+        first[p + 1] = first[p] + kmers_per[p];
+    }
+    uint64_t *d_words = nullptr, *d_len = nullptr, *d_st = nullptr, *d_en = nullptr, *d_loops = nullptr, *d_lk = nullptr;
+    uint8_t *d_sf = nullptr, *d_lm = nullptr;
+    GM_HIP(hipMalloc((void **)&d_words, std::max<size_t>((size_t)nwd * 8, 8)));
+    GM_HIP(hipMalloc((void **)&d_len, std::max<size_t>((size_t)ne * 8, 8)));
+    GM_HIP(hipMalloc((void **)&d_st, std::max<size_t>((size_t)ne * 8, 8)));
+    GM_HIP(hipMalloc((void **)&d_en, std::max<size_t>((size_t)ne * 8, 8)));
+    GM_HIP(hipMalloc((void **)&d_sf, std::max<size_t>((size_t)ne, 8)));
+    GM_HIP(hipMalloc((void **)&d_loops, std::max<size_t>((size_t)nl * 8, 8)));
+    GM_HIP(hipMalloc((void **)&d_lk, std::max<size_t>((size_t)nl * nwk * 8, 8)));
+    GM_HIP(hipMalloc((void **)&d_lm, std::max<size_t>((size_t)nl, 8)));
+    GM_SMX(smx_shard_unitigs_copy(ctx, d_words, d_len, d_st, d_en, d_sf));
+    GM_SMX(smx_shard_walk_loops(ctx, d_loops));
+    GM_SMX(smx_shard_gather_kmers(ctx, d_loops, nl, d_lk, d_lm));
+    void *g_words = nullptr, *g_len = nullptr, *g_st = nullptr, *g_en = nullptr, *g_sf = nullptr, *g_loops = nullptr, *g_lk = nullptr, *g_lm = nullptr;
+    GM_MARK("distributed walks: gather of the unitigs")
+    if (int rc = gather_shards(c, d_words, nwd_r, 8, to_all, &g_words)) return rc;
+    if (int rc = gather_shards(c, d_len, ne_r, 8, to_all, &g_len)) return rc;
+    if (int rc = gather_shards(c, d_st, ne_r, 8, to_all, &g_st)) return rc;
+    if (int rc = gather_shards(c, d_en, ne_r, 8, to_all, &g_en)) return rc;
+    if (int rc = gather_shards(c, d_sf, ne_r, 1, to_all, &g_sf)) return rc;
+    if (int rc = gather_shards(c, d_loops, nl_r, 8, to_all, &g_loops)) return rc;
+    if (int rc = gather_shards(c, d_lk, nl_r, (size_t)nwk * 8, to_all, &g_lk)) return rc;
+    if (int rc = gather_shards(c, d_lm, nl_r, 1, to_all, &g_lm)) return rc;
+    for (void *p : {(void *)d_words, (void *)d_len, (void *)d_st, (void *)d_en, (void *)d_sf, (void *)d_loops, (void *)d_lk, (void *)d_lm}) (void)hipFree(p);
+    if (builds) {
+        // the loop k-mers go in as host arrays in k-mer-file order with GLOBAL ranks (rank order is file order: the shards are bucket ranges)
+        std::vector<uint64_t> h_lr(std::max<uint64_t>(nl_all, 1)), h_lk(std::max<uint64_t>(nl_all * nwk, 1));
+        std::vector<uint8_t> h_lm(std::max<uint64_t>(nl_all, 1));
+        if (nl_all) {
+            GM_HIP(hipMemcpy(h_lr.data(), g_loops, (size_t)nl_all * 8, hipMemcpyDeviceToHost));
+            GM_HIP(hipMemcpy(h_lk.data(), g_lk, (size_t)nl_all * nwk * 8, hipMemcpyDeviceToHost));
+            GM_HIP(hipMemcpy(h_lm.data(), g_lm, (size_t)nl_all, hipMemcpyDeviceToHost));
+            uint64_t o = 0;
+            for (int p = 0; p < c.world; ++p)
+                for (uint64_t i = 0; i < nl_r[p]; ++i) h_lr[o++] += first[p];
+        }
+        GM_SMX(smx_build_graph_from_unitigs(ctx, k, nb, total_kmers, n_kpo_all, (const uint64_t *)g_words, nwd_all, (const uint64_t *)g_len, (const uint64_t *)g_st,
+                                            (const uint64_t *)g_en, (const uint8_t *)g_sf, ne_all, h_lr.data(), h_lk.data(), h_lm.data(), nl_all));
+    } else {
+        GM_SMX(smx_graph_clear(ctx));  // (this rank's shard has done its part)
+    }
+    for (void *p : {g_words, g_len, g_st, g_en, g_sf, g_loops, g_lk, g_lm})
+        if (p) (void)hipFree(p);
     return 0;
 }
 
@@ -388,27 +534,40 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
     }
     // gather {k-mers, masks} where a graph is built: everywhere with -c (every rank counts its own reads on it), else on rank 0
     const bool builds = cov || rank == 0;
+    bool distributed = false;
     {   // Does the gathered structure fit where it is built? The gathered copy and the library's own cost (8 * words + 1) B per k-mer of
-        // the WHOLE graph each, the successor table 16 B more (dist.py decides by the same figure). Every rank hears the answer, so
-        // all leave together with the reference's "memory limit" code instead of one rank failing inside an allocation.
+        // the WHOLE graph each, the successor table 16 B more (dist.py decides by the same figure). Every rank hears the answer: where it
+        // does not fit on some rank, ALL ranks take the distributed walks together (SMX_MGPU_WALKS=gathered: all leave with the reference's
+        // "memory limit" code instead, as rounds 4-5 did; =distributed: the walks whatever the size).
         size_t dev_free = 0, dev_total = 0, arena_free = 0;
         GM_HIP(hipMemGetInfo(&dev_free, &dev_total));
         (void)smx_arena_free_bytes(ctx, &arena_free);
         const double need = (double)total_kmers * (2.0 * (8.0 * nw + 1.0) + 16.0), have = (double)dev_free + (double)arena_free;
         uint64_t fits = (!builds || need <= have) ? 1 : 0;
         if (getenv("SMX_MGPU_ASSUME_FREE_BYTES")) fits = (!builds || need <= atof(getenv("SMX_MGPU_ASSUME_FREE_BYTES"))) ? 1 : 0;  // (test hook)
+        const char *wenv = getenv("SMX_MGPU_WALKS");
+        const bool force_d = wenv && !strcmp(wenv, "distributed"), force_g = wenv && !strcmp(wenv, "gathered");
         std::vector<uint64_t> all_fit;
         if (int rc = all_gather_words(c, &fits, 1, all_fit)) return rc;
-        for (int p = 0; p < world; ++p)
+        distributed = force_d;
+        for (int p = 0; p < world && !distributed; ++p)
             if (!all_fit[p]) {
-                if (rank == p || (rank == 0 && all_fit[0]))
-                    fprintf(stderr, "[rank %d] the graph's k-mers and masks (%llu k-mers, %.1f GB to build from) do not fit rank %d's free device memory%s: "
-                                    "this graph needs the distributed walks (python: spades_amd.dist.sharded_build_graph(walks=\"distributed\"))\n",
-                            rank, (unsigned long long)total_kmers, need / 1e9, p, rank == p ? "" : " (reported by that rank)");
-                return SMX_MEMORY_LIMIT_EXCEEDED;
+                if (force_g) {
+                    if (rank == p || (rank == 0 && all_fit[0]))
+                        fprintf(stderr, "[rank %d] the graph's k-mers and masks (%llu k-mers, %.1f GB to build from) do not fit rank %d's free device memory%s "
+                                        "and SMX_MGPU_WALKS=gathered forbids the distributed walks\n",
+                                rank, (unsigned long long)total_kmers, need / 1e9, p, rank == p ? "" : " (reported by that rank)");
+                    return SMX_MEMORY_LIMIT_EXCEEDED;
+                }
+                if (rank == 0)
+                    fprintf(stderr, "the graph's k-mers and masks (%llu k-mers, %.1f GB to build from) do not fit rank %d's free device memory: the k-mer file stays "
+                                    "sharded, unitigs by distributed walks\n", (unsigned long long)total_kmers, need / 1e9, p);
+                distributed = true;
             }
     }
-    {
+    if (distributed) {
+        if (int rc = graph_by_distributed_walks(c, ctx, k, nb, kmers_per, total_kmers, n_kpo_all, cov, builds)) return rc;
+    } else {
         uint64_t *d_my_k = nullptr;
         uint8_t *d_my_m = nullptr;
         GM_HIP(hipMalloc((void **)&d_my_k, std::max<size_t>((size_t)n_kmers * nw * 8, 8)));
@@ -425,7 +584,7 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
     }
     uint64_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (builds) GM_SMX(smx_graph_info(ctx, info));
-    GM_MARK("graph built from the gathered shards")
+    GM_MARK(distributed ? "graph built from the gathered unitigs (distributed walks)" : "graph built from the gathered shards")
     if (cov) {
         // The counters of the coverage pass are keyed by (k+1)-mer, and no rank may hold that whole file: shard by shard (dist.py does the
         // same) — the owner of a bucket range sends its shard to everybody, every rank installs it as a (k+1)-mer file of those buckets
@@ -483,6 +642,7 @@ inline int gb_rank_main(int rank, int world, const GbOptions &o, const std::stri
     ncclCommDestroy(c.comm);
     smxtool::RankWatch::mark("teardown: hipStreamDestroy");
     (void)hipStreamDestroy(c.stream);
+    if (c.d_scratch) (void)hipFree(c.d_scratch);
     smxtool::RankWatch::mark("teardown: smx_destroy");
     smx_destroy(ctx);
     smxtool::RankWatch::done();

@@ -54,8 +54,14 @@ if EMU:
         import numpy as np
         return np.ctypeslib.as_array((ctypes.c_int64 * n).from_address(p))
 
+    def _host_bytes(p, n):
+        import ctypes
+        import numpy as np
+        return np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(p))
+
     import spades_amd.dist as _smx_dist  # noqa: E402
     _smx_dist._DevView = _host_view
+    _smx_dist._DevBytes = _host_bytes
 
 
 def free_port():

@@ -130,6 +130,8 @@ ncclResult_t ncclAllGather(const void *in, void *out, size_t count, ncclDataType
     return fwd("ncclAllGather", 3, LL(in), LL(out), LL(count) * elem_bytes(t)) ? ncclInternalError : ncclSuccess;
 }
 ncclResult_t ncclAllReduce(const void *in, void *out, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t, hipStream_t) {
+    if (t == ncclUint64 && (op == ncclSum || op == ncclMax))  // the few words of the walks' collectives
+        return fwd("ncclAllReduceU64", 4, LL(in), LL(out), LL(count), LL(op == ncclMax ? 1 : 0)) ? ncclInternalError : ncclSuccess;
     if (t != ncclUint32 || op != ncclSum) return ncclInvalidArgument;
     return fwd("ncclAllReduceU32Sum", 3, LL(in), LL(out), LL(count)) ? ncclInternalError : ncclSuccess;
 }
@@ -185,6 +187,22 @@ int smx_graph_shard_info(const smx_ctx *, uint64_t *n, uint64_t *sizes) { return
 int smx_graph_shard_copy(const smx_ctx *, void *dk, void *dm) { return (int)fwd("smx_graph_shard_copy", 2, LL(dk), LL(dm)); }
 int smx_build_graph_from_kmers(smx_ctx *, unsigned k, unsigned nb, const void *dk, const void *dm, uint64_t n, const uint64_t *sizes, uint64_t n_kpo) {
     return (int)fwd("smx_build_graph_from_kmers", 7, LL(k), LL(nb), LL(dk), LL(dm), LL(n), LL(sizes), LL(n_kpo));
+}
+// distributed walks: the one call is answered by the test with its torch restatement of the algorithm (tests/dwalk_torch_double.py), which moves
+// its data through THIS host's collectives (the callbacks in *coll are the host's own functions: counts, grouped ncclSend / ncclRecv, all-reduce)
+int smx_shard_walks(smx_ctx *, const uint64_t *kmers_per_rank, const smx_collectives *coll, uint64_t *info) {
+    return (int)fwd("smx_shard_walks", 9, LL(kmers_per_rank), LL(coll->user), LL(coll->rank), LL(coll->world), LL(coll->exchange_counts), LL(coll->alltoallv),
+                    LL(coll->allreduce_u64), LL(info), LL(0));
+}
+int smx_shard_unitigs_copy(const smx_ctx *, uint64_t *w, uint64_t *ln, uint64_t *st, uint64_t *en, uint8_t *sf) {
+    return (int)fwd("smx_shard_unitigs_copy", 5, LL(w), LL(ln), LL(st), LL(en), LL(sf));
+}
+int smx_shard_walk_loops(const smx_ctx *, uint64_t *d) { return (int)fwd("smx_shard_walk_loops", 1, LL(d)); }
+int smx_shard_gather_kmers(smx_ctx *, const uint64_t *ranks, uint64_t n, void *dk, uint8_t *dm) { return (int)fwd("smx_shard_gather_kmers", 4, LL(ranks), LL(n), LL(dk), LL(dm)); }
+int smx_build_graph_from_unitigs(smx_ctx *, unsigned k, unsigned nb, uint64_t n_kmers, uint64_t n_kpo, const uint64_t *words, uint64_t n_words, const uint64_t *ln,
+                                 const uint64_t *st, const uint64_t *en, const uint8_t *sf, uint64_t ne, const uint64_t *lr, const uint64_t *lk, const uint8_t *lm, uint64_t nl) {
+    long long a[15] = {LL(k), LL(nb), LL(n_kmers), LL(n_kpo), LL(words), LL(n_words), LL(ln), LL(st), LL(en), LL(sf), LL(ne), LL(lr), LL(lk), LL(lm), LL(nl)};
+    return (int)fwd("smx_build_graph_from_unitigs", 1, LL(a));
 }
 int smx_graph_info(const smx_ctx *, uint64_t *info) { return (int)fwd("smx_graph_info", 1, LL(info)); }
 int smx_graph_set_kpomers(smx_ctx *, const void *d, uint64_t n, const uint64_t *sizes) { return (int)fwd("smx_graph_set_kpomers", 3, LL(d), LL(n), LL(sizes)); }

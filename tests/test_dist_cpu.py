@@ -417,7 +417,8 @@ def test_a_failing_rank_does_not_leave_the_others_waiting(fail_in, code, route, 
         assert all(x[1] == "failed" and x[2] == code for x in got)
 
 
-# ---- distributed walks: spades_amd.dist.distributed_walks on a CPU double of the shard primitives ----------------
+# ---- distributed walks: sharded_build_graph(walks="distributed") on a CPU double of smx_shard_walks (tests/dwalk_torch_double.py over
+# string-level primitives); the library's own implementation of that call runs at world 2-3 on the SIMT stand-in: tests/test_dist_gpu.py -------
 _TR = str.maketrans("ACGT", "TGCA")
 
 
@@ -461,6 +462,12 @@ class OracleWalkEngine(OracleGraphEngine):
     def _node_str(self, node):
         s = self.strs[node >> 1]
         return _rcs(s) if node & 1 else s
+
+    def shard_walks(self, k, rank, world, dev, kmers_per_rank):
+        """smx_shard_walks on this double: the algorithm restated on torch tensors (tests/dwalk_torch_double.py) between the string-level primitives
+        below — what the library does on the device behind that one call"""
+        import dwalk_torch_double as dbl
+        return dbl.torch_walks(self, k, rank, world, dev, kmers_per_rank)
 
     def walk_counts(self):
         """(requests of the chain k-mers, start de-edges) of this shard: smx_shard_walk_counts"""
@@ -579,10 +586,11 @@ def _walk_worker(rank, world, port, k, threads, q, reads_file, nreads, coverage,
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from spades_amd import dist as smx_dist
     smx_dist.XCHG_LIMIT = limit
+    import dwalk_torch_double as dbl
     if hop_bits:
-        smx_dist.WALK_HOP_BITS = hop_bits
+        dbl.WALK_HOP_BITS = hop_bits
     if limit < 1000:  # several chunks per doubling round / per fetch of the chains, uneven over the ranks
-        smx_dist.WALK_CHUNK, smx_dist.WALK_START_CHUNK = 97, 13
+        dbl.WALK_CHUNK, dbl.WALK_START_CHUNK = 97, 13
     reads = read_lines(reads_file)[:nreads]
     eng = OracleWalkEngine(reads[rank::world], reads)
     eng.nb = 10 * threads

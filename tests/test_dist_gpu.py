@@ -336,8 +336,9 @@ def _dwalk_rank(rank, world, port, k, t, seed, n_reads, genome, coverage, outdir
         reads = [lut[c].tobytes().decode() for c in codes[rank::world]]
         gb = GraphBuilder(k, t)
         gb.push_back_reads(reads)
-        if k == 21:  # several chunks per doubling round and per fetch of the chains
-            smx_dist.WALK_CHUNK, smx_dist.WALK_START_CHUNK = 1 << 14, 1 << 10
+        if k == 21:  # several rounds per lookup range, per doubling round and per fetch of the chains (uneven over the ranks)
+            gb.ctx.set_option("walk_chunk", 1 << 14)
+            gb.ctx.set_option("walk_start_chunk", 1 << 10)
         info = smx_dist.sharded_build_graph(smx_dist.GpuEngine(gb.ctx, "B"), k, t, rank, world, dev, coverage=coverage, walks=walks)
         gb.adopt(info)
         gb.write_gfa(os.path.join(outdir, f"rank{rank}.gfa"))
@@ -380,6 +381,66 @@ def test_distributed_walks_ranks_sharing_one_gpu(k, t, n_reads, genome, coverage
         info = eval(open(os.path.join(str(tmp_path), f"rank{r}.info")).read())
         assert sum(info["kmers_per_rank"]) == n_kmers and max(info["kmers_per_rank"]) < n_kmers  # the file was sharded
         assert all(u > 0 for u in info["unitigs_per_rank"])
+
+
+def _dwalk_failing_rank(rank, world, port, phase, outdir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import conftest
+    from spades_amd import dist as smx_dist
+    from spades_amd.gbuilder import GraphBuilder
+    from spades_amd.kmercount import SmxError
+    import synth
+    if conftest.EMU:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        codes = synth.synth_codes(99, 30000, 6000)
+        lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+        gb = GraphBuilder(21, 1)
+        gb.push_back_reads([lut[c].tobytes().decode() for c in codes[rank::world]])
+        gb.ctx.set_option("walk_chunk", 1 << 13)
+        if rank == world - 1:
+            gb.ctx.set_option("walk_fail_at", phase)  # (only this rank fails; the others must hear of it at their next collective)
+        code, text = 0, ""
+        try:
+            smx_dist.sharded_build_graph(smx_dist.GpuEngine(gb.ctx, "B"), 21, 1, rank, world, dev, walks="distributed")
+        except SmxError as e:
+            code, text = e.code, str(e)
+        with open(os.path.join(outdir, f"rank{rank}.err"), "w") as f:
+            f.write(repr((code, text)))
+        gb.ctx.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("phase", [1, 2, 4, 5])
+def test_a_rank_that_fails_inside_the_distributed_walks_ends_them_on_every_rank(phase, tmp_path):
+    """smx_shard_walks' failure protocol (csrc/smx_dwalk.hpp): a rank whose LOCAL step fails (test hook: the memory-limit code in the given phase
+    on the last rank) carries poison into its next collective, so every rank comes back from the call — the failing one with its own code, the
+    others with "another rank failed" — and nobody waits in a collective for a rank that is gone."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_dwalk_failing_rank, args=(r, world, port, phase, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0  # (not None: nobody hung)
+    errs = [eval(open(os.path.join(str(tmp_path), f"rank{r}.err")).read()) for r in range(world)]
+    assert errs[world - 1][0] == 68 and "test hook" in errs[world - 1][1]
+    assert all(e[0] == 70 and "another rank failed" in e[1] for e in errs[:world - 1])
 
 
 @pytest.mark.parametrize("k,t,n_reads,genome,world", [(21, 1, 6000, 30000, 2), (55, 2, 8000, 40000, 3)])

@@ -61,8 +61,8 @@ class ShimRank:
 
     def engine(self):
         if self.eng is None:
-            from test_dist_cpu import OracleEngine, OracleGraphEngine
-            self.eng = OracleGraphEngine(self.reads, self.all_reads) if self.mode == "B" else OracleEngine(self.reads, "A")
+            from test_dist_cpu import OracleEngine, OracleWalkEngine
+            self.eng = OracleWalkEngine(self.reads, self.all_reads) if self.mode == "B" else OracleEngine(self.reads, "A")
         return self.eng
 
     # ---- dispatch ----
@@ -111,6 +111,11 @@ class ShimRank:
         outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
         dist.all_gather(outs, mine)
         _u8(dst, nbytes * self.world)[:] = torch.cat(outs).numpy()
+
+    def f_ncclAllReduceU64(self, src, dst, count, is_max, *_):
+        t = torch.from_numpy(_u64(src, count).astype(np.int64))  # (values below 2^62, or all ones = -1 under max: the order is kept)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if is_max else dist.ReduceOp.SUM)
+        _u64(dst, count)[:] = t.numpy().view(np.uint64)
 
     def f_ncclAllReduceU32Sum(self, src, dst, count, *_):
         t = torch.from_numpy(_u32(src, count).astype(np.int64))
@@ -207,6 +212,7 @@ class ShimRank:
         assert (world, rank) == (self.world, self.rank)
         nk, sizes, bits, pals = self.engine().shard_from_ext(k, nb, world, rank, _i64_tensor(d, n * ((k + 31) // 32)), n)
         self.shard = dict(n=nk, sizes=sizes, bits=bits, pals=pals, nb=nb)
+        self.kk, self.eng.nb, self.shard_n = k, nb, nk
 
     def f_smx_graph_shard_ext_stats(self, p_st, *_):
         _u64(p_st, 2)[:] = [self.shard["bits"], self.shard["pals"]]
@@ -219,6 +225,7 @@ class ShimRank:
         assert (world, rank) == (self.world, self.rank)
         nk, sizes = self.engine().shard_build(k, nb, world, rank, _i64_tensor(d, n * ((k + 31) // 32 + 1)), n)
         self.shard = dict(n=nk, sizes=sizes, bits=0, pals=0, nb=nb)
+        self.kk, self.eng.nb, self.shard_n = k, nb, nk
 
     def f_smx_graph_shard_info(self, p_n, p_sizes, *_):
         _u64(p_n, 1)[0] = self.shard["n"]
@@ -233,6 +240,65 @@ class ShimRank:
     def f_smx_build_graph_from_kmers(self, k, nb, dk, dm, n, p_sizes, n_kpo, *_):
         nw = (k + 31) // 32
         self.info = self.engine().build_graph_from_kmers(k, nb, _i64_tensor(dk, n * nw), torch.from_numpy(_u8(dm, n)), n, [int(x) for x in _u64(p_sizes, nb)], n_kpo)
+
+    # ---- distributed walks: smx_shard_walks answered by the torch restatement, its data moved by the HOST's own collectives ----
+    def f_smx_shard_walks(self, p_per, user, rank, world, f_counts, f_a2a, f_allreduce, p_info, *_):
+        import dwalk_torch_double as dbl
+        assert (rank, world) == (self.rank, self.world)
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        xc = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, u64p, u64p)(f_counts)
+        a2av = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, u64p, ctypes.c_void_p, u64p, ctypes.c_uint)(f_a2a)
+        ar = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, u64p, ctypes.c_uint, ctypes.c_int)(f_allreduce)
+        per = [int(x) for x in _u64(p_per, world)]
+        eng = self.engine()
+        assert per[rank] == len(eng.shard_kmers)
+        self.walk_a2a = 0
+
+        def a2a(send, counts, rank_, world_, dev, alloc=None):
+            sc, rc = (ctypes.c_uint64 * world)(*[int(c) for c in counts]), (ctypes.c_uint64 * world)()
+            assert xc(user, sc, rc) == 0
+            rcounts = [int(c) for c in rc]
+            send = send.contiguous()
+            recv = torch.empty(max(sum(rcounts), 1), dtype=send.dtype)
+            assert a2av(user, send.data_ptr(), sc, recv.data_ptr(), rc, send.element_size()) == 0
+            self.walk_a2a += 1
+            return recv, rcounts
+
+        def all_reduce(t, op=dist.ReduceOp.SUM):
+            n = t.numel()
+            vals = (ctypes.c_uint64 * n)(*[int(v) for v in t.reshape(-1).tolist()])
+            assert ar(user, vals, n, 1 if op == dist.ReduceOp.MAX else 0) == 0
+            t.copy_(torch.tensor([int(v) for v in vals], dtype=t.dtype).reshape(t.shape))
+
+        if os.environ.get("SHIM_WALK_CHUNK"):
+            dbl.WALK_CHUNK, dbl.WALK_START_CHUNK = [int(v) for v in os.environ["SHIM_WALK_CHUNK"].split(",")]
+        self.walk = dbl.torch_walks(eng, self.kk, rank, world, torch.device("cpu"), per, a2a=a2a, all_reduce=all_reduce)
+        (w, ln, st, en, sf), loops, rounds = self.walk
+        _u64(p_info, 4)[:] = [ln.numel(), w.numel(), loops.numel(), rounds]
+
+    def f_smx_shard_unitigs_copy(self, pw, pl, ps, pe, pf, *_):
+        (w, ln, st, en, sf), _loops, _r = self.walk
+        for p_, t in ((pw, w), (pl, ln), (ps, st), (pe, en)):
+            _u64(p_, t.numel())[:] = t.numpy().view(np.uint64)
+        _u8(pf, sf.numel())[:] = sf.numpy()
+
+    def f_smx_shard_walk_loops(self, p, *_):
+        loops = self.walk[1]
+        _u64(p, loops.numel())[:] = loops.numpy().view(np.uint64)
+
+    def f_smx_shard_gather_kmers(self, p_ranks, n, dk, dm, *_):
+        km, mk = self.eng.shard_gather_kmers(torch.from_numpy(_u64(p_ranks, n).astype(np.int64)), self.kk, None)
+        if n:
+            nw = (self.kk + 31) // 32
+            _u64(dk, n * nw)[:] = km.numpy().view(np.uint64)[:n * nw]
+            _u8(dm, n)[:] = mk.numpy()[:n]
+
+    def f_smx_build_graph_from_unitigs(self, p_args, *_):
+        a = [int(v) for v in np.ctypeslib.as_array((ctypes.c_longlong * 15).from_address(p_args))]
+        k, nb, n_kmers, n_kpo, pw, n_words, pl, ps, pe, pf, ne, plr, plk, plm, nl = a
+        nw = (k + 31) // 32
+        self.info = self.eng.build_graph_from_unitigs(k, nb, n_kmers, n_kpo, _i64_tensor(pw, n_words), n_words, _i64_tensor(pl, ne), _i64_tensor(ps, ne), _i64_tensor(pe, ne),
+                                                      torch.from_numpy(_u8(pf, ne)), ne, _u64(plr, nl).copy(), _u64(plk, nl * nw).copy(), _u8(plm, nl).copy())
 
     def f_smx_graph_info(self, p_info, *_):
         i = self.info
@@ -276,7 +342,7 @@ def _worker(rank, world, port, tool, args, env, all_reads, q):
         rc = lib.mgpu_shim_run_gbuilder(rank, world, k, threads, int(coverage), 1, out.encode(), "\n".join(files).encode(), (out + ".id").encode())
         res = dict(rank=rank, rc=rc, reads=me.reads, written=me.written, built=me.info is not None,
                    cov=me.eng.cov.tobytes() if getattr(me.eng, "cov", None) is not None else None, p2p_ops=me.p2p_ops, p2p_bytes=me.p2p_bytes,
-                   shard=me.shard["n"] if me.shard else None, kpo=me.count["distinct"] if me.count else None, calls=me.calls, error=me.error)
+                   shard=getattr(me, "shard_n", None), kpo=me.count["distinct"] if me.count else None, calls=me.calls, error=me.error)
     else:
         K, workdir, files = args
         rc = lib.mgpu_shim_run_kmercount(rank, world, K, workdir.encode(), "\n".join(files).encode())
@@ -329,6 +395,13 @@ def _write_fastq(path, reads, final_newline=True):
     (2, 31, True, "fa", {}),  # (a k without room for the extension byte: the route by the sharded (k+1)-mer count)
     (3, 21, False, "fq.gz", {"SMX_MGPU_CHUNK": "4096", "SMX_IO_THREADS": "3"}),
     (2, 33, True, "fq.gz", {"TEST_BGZF_BLOCK": "65280", "SMX_MGPU_PARTS": "2"}),
+    # round 6: the k-mer file stays sharded — smx_shard_walks with the HOST's collectives (counts by all-gather, grouped ncclSend / ncclRecv in
+    # several rounds, all-reduce), unitigs + loop k-mers gathered, smx_build_graph_from_unitigs; -c shard by shard on a graph without a k-mer file
+    (2, 21, False, "fq", {"SMX_MGPU_WALKS": "distributed", "SMX_MGPU_ROUND_WORDS": "16", "SHIM_WALK_CHUNK": "97,13"}),
+    (3, 21, True, "fq", {"SMX_MGPU_WALKS": "distributed", "SMX_MGPU_ROUND_WORDS": "64", "SHIM_WALK_CHUNK": "301,29"}),
+    (3, 33, False, "fa", {"SMX_MGPU_WALKS": "distributed"}),
+    (2, 31, True, "fa", {"SMX_MGPU_WALKS": "distributed"}),  # (the shard by the (k+1)-mer route, then the walks)
+    (2, 21, False, "fq", {"SMX_MGPU_ASSUME_FREE_BYTES": "1000"}),  # the gathered structure "does not fit": all ranks take the walks by themselves
 ])
 def test_gbuilder_host_world_n(tmp_path, world, k, coverage, fmt, env):
     from oracle import oracle
@@ -357,6 +430,10 @@ def test_gbuilder_host_world_n(tmp_path, world, k, coverage, fmt, env):
         assert all("smx_submit_reads_ascii" in g["calls"] for g in got)
     # who builds and who writes: rank 0, and with -c every rank (its coverage pass needs the graph); the engine double asserted inside
     # build_graph_from_kmers that the gathered structure IS the reference's k-mer file and mask bytes and that the (k+1)-mer count fits
+    walks = env.get("SMX_MGPU_WALKS") == "distributed" or "SMX_MGPU_ASSUME_FREE_BYTES" in env
+    assert all(("smx_shard_walks" in g["calls"]) == walks and ("smx_build_graph_from_kmers" in g["calls"]) == (not walks and g["built"]) for g in got)
+    if walks:  # only unitigs and loop k-mers travelled to the builders: the engine double asserted that they ARE the reference's edge list and loops
+        assert all(("smx_build_graph_from_unitigs" in g["calls"]) == g["built"] and "smx_graph_shard_copy" not in g["calls"] for g in got)
     assert [g["built"] for g in got] == [True] + [coverage] * (world - 1)
     assert [g["written"] is not None for g in got] == [True] + [False] * (world - 1)
     ref = oracle.build_graph(reads, k, 10, coverage=True)
@@ -411,15 +488,15 @@ def test_kmercount_host_world_n(tmp_path, world, K, nfiles, env):
 
 
 def test_gbuilder_host_refuses_a_graph_that_does_not_fit(tmp_path):
-    """the gathered structure would not fit where the graph is built: EVERY rank leaves with the reference's memory-limit code (68), none
-    waits in a collective, nothing is written"""
+    """the gathered structure would not fit where the graph is built and the distributed walks are forbidden (SMX_MGPU_WALKS=gathered: the
+    behaviour of rounds 4-5): EVERY rank leaves with the reference's memory-limit code (68), none waits in a collective, nothing is written"""
     reads = [r for r in read_lines("reads_small.txt")[:120] if r]
     inp = str(tmp_path / "r.fq")
     _write_fastq(inp, reads)
     out = str(tmp_path / "g.gfa")
-    got = _run(2, "gbuilder", (21, 1, False, [inp], out), {"SMX_MGPU_ASSUME_FREE_BYTES": "1000"}, reads, 40500)
+    got = _run(2, "gbuilder", (21, 1, False, [inp], out), {"SMX_MGPU_ASSUME_FREE_BYTES": "1000", "SMX_MGPU_WALKS": "gathered"}, reads, 40500)
     assert [g["rc"] for g in got] == [68, 68] and not os.path.exists(out)
-    assert all("smx_build_graph_from_kmers" not in g["calls"] for g in got)
+    assert all("smx_build_graph_from_kmers" not in g["calls"] and "smx_shard_walks" not in g["calls"] for g in got)
 
 
 @pytest.mark.parametrize("coverage,inject,expect", [

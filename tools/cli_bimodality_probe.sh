@@ -35,13 +35,13 @@ ls -la "$D/r.fq"
 for mode in "default" "0,0" "default" "0,0" "default" "0,0"; do
   echo "=== spades-gbuilder-mi355x, prewarm: $mode"
   if [ "$mode" = "default" ]; then unset SMX_PREWARM_X; else export SMX_PREWARM_X=$mode; fi
-  /usr/bin/time -f "wall %e s" env SMX_DEBUG=1 spades_amd/tools/spades-gbuilder-mi355x "$D/r.fq" "$D/o.gfa" -k 55 -t 16 --gfa 2>&1 | grep -E "^\[tool\]|arena:|wall|g:" 
+  env SMX_DEBUG=1 spades_amd/tools/spades-gbuilder-mi355x "$D/r.fq" "$D/o.gfa" -k 55 -t 16 --gfa 2>&1 | grep -E "^\[tool\]|arena:|g:"
   rm -f "$D/o.gfa"
 done
 for mode in "default" "0,0" "default" "0,0"; do
   echo "=== spades-kmercount-mi355x, prewarm: $mode"
   if [ "$mode" = "default" ]; then unset SMX_PREWARM_X; else export SMX_PREWARM_X=$mode; fi
-  /usr/bin/time -f "wall %e s" env SMX_DEBUG=1 spades_amd/tools/spades-kmercount-mi355x -k 55 -w "$D" "$D/r.fq" 2>&1 | grep -E "^\[tool\]|arena:|wall"
+  env SMX_DEBUG=1 spades_amd/tools/spades-kmercount-mi355x -k 55 -w "$D" "$D/r.fq" 2>&1 | grep -E "^\[tool\]|arena:"
   rm -f "$D/final_kmers"
 done
 rm -rf "$D"
