@@ -44,4 +44,15 @@ for mode in "default" "0,0" "default" "0,0"; do
   env SMX_DEBUG=1 spades_amd/tools/spades-kmercount-mi355x -k 55 -w "$D" "$D/r.fq" 2>&1 | grep -E "^\[tool\]|arena:"
   rm -f "$D/final_kmers"
 done
+# the C++ multi-GPU host at one rank on the same input: gathered structure, then the k-mer file left sharded (smx_shard_walks over ncclSend / ncclRecv
+# with itself) — both must write the single-process GFA byte for byte
+env spades_amd/tools/spades-gbuilder-mi355x "$D/r.fq" "$D/ref.gfa" -k 55 -t 16 --gfa > /dev/null 2>&1
+for w in gathered distributed; do
+  echo "=== spades-gbuilder-mi355x --gpus 1, SMX_MGPU_WALKS=$w"
+  t0=$(date +%s.%N)
+  env SMX_DEBUG=1 SMX_MGPU_WALKS=$w SMX_MGPU_SELF_RCCL=1 SMX_MGPU_PARTS=4 SMX_MGPU_WATCHDOG=120 spades_amd/tools/spades-gbuilder-mi355x "$D/r.fq" "$D/o.gfa" -k 55 -t 16 --gfa --gpus 1 2>&1 | grep -E "walks:|rank 0\] (owner|distributed|graph built|output)|doubling" | tail -30
+  t1=$(date +%s.%N)
+  echo "wall $(echo "$t1 - $t0" | bc) s; identical to the single-process GFA: $(cmp -s "$D/ref.gfa" "$D/o.gfa" && echo yes || echo NO)"
+  rm -f "$D/o.gfa"
+done
 rm -rf "$D"
