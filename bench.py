@@ -740,6 +740,13 @@ def main():
             out["construct"]["route_stats"] = str(e)
         out["step_breakdown_ms"] = {"count_kernels": round(count_ms, 1), "construct_kernels": round(construct_ms, 1),
                                     "host": round(ms_per_step - count_ms - construct_ms, 1)}
+        if pm_route:
+            # round 6: the successor table (pm_tab, pm_remote: side stream) and the junction order (candidates .. junction_order: main stream) run side by
+            # side; their stage times are each stream's own, so count + construct may exceed the step and "host" is then what is left AFTER the overlap
+            side = stages.get("pm_tab", 0.0) + stages.get("pm_remote", 0.0)
+            main = sum(ms for n_, ms in stages.items() if n_ in ("candidates", "junctions", "junction_order") or n_.startswith("jsort:"))
+            out["step_breakdown_ms"]["side_by_side"] = {"successor_table_ms": round(side, 1), "junction_order_ms": round(main, 1),
+                                                        "note": "two streams: at most min(these) of the stage sum is hidden; construct.roofline prices the SUM (conservative)"}
         # The dominant single kernel of the step = the longest stage that is ONE kernel (HIP events on the library stream), priced on the
         # bytes that kernel must move (stated per kernel below); its measured HBM traffic is quoted from the recorded PMC table when
         # that table belongs to these sources.

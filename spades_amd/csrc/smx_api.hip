@@ -120,6 +120,7 @@ void smx_destroy(smx_ctx *ctx) {
     arena_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     delete ctx;
 }
 
@@ -163,6 +164,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "skm_nkey_log2")) ctx->opt_skm_nkey_log2 = value;
     else if (!strcmp(key, "derive_batches")) ctx->opt_derive_batches = value;
     else if (!strcmp(key, "keep_kpo")) ctx->opt_keep_kpo = value;
+    else if (!strcmp(key, "pm_overlap")) ctx->opt_pm_overlap = value;
     else if (!strcmp(key, "walk_chunk")) ctx->opt_walk_chunk = value;
     else if (!strcmp(key, "walk_start_chunk")) ctx->opt_walk_start_chunk = value;
     else if (!strcmp(key, "walk_hop_bits")) ctx->opt_walk_hop_bits = value;

@@ -7,6 +7,7 @@
 // writers format) is filled the first time something asks for it. Ranks and node ids are 64-bit (size_t in the reference,
 // debruijn_graph_constructor.hpp:399-406,506-567).
 #pragma once
+#include <functional>
 
 void pm_release(smx_ctx *ctx);  // smx_pm.hpp
 template <int NW>
@@ -855,7 +856,8 @@ int device_loops(smx_ctx *ctx, unsigned k, bool pm, const unsigned long long *ll
 // pm: the partition-major route (smx_pm.hpp) — g_kmers holds EXT records in the dedupe stage's order, tab is filled, walks cross chunks by
 // jump words, and the start de-edges are numbered through the sorted junction k-mers.
 template <int NW>
-int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint32_t *d_err, WallTrace &gwt, bool present = false, const PmWalk *pm = nullptr) {
+int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint32_t *d_err, WallTrace &gwt, bool present = false, const PmWalk *pm = nullptr,
+                     const std::function<int()> *tab_ready = nullptr /* pm: the node table is still being filled on the side stream; called before the first use of it */) {
     const uint64_t D0 = ctx->g_nkmers;
     const unsigned grid = grid_for(2 * D0);
     const smx::RankDir ixk = ctx->g_dir_kmers;
@@ -1098,6 +1100,8 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             if (e1 != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "numbering the start de-edges failed: %s", hipGetErrorString(e1));
             if (ctot != C) return fail(ctx, SMX_DEVICE_ERROR, "start de-edges: %llu by the sorted junction k-mers, %llu by the masks", ctot, C);
         }
+        if (tab_ready)
+            if (int rc = (*tab_ready)()) return rc;
         tbegin(ctx, "walk_len");
         if (pm)
             hipLaunchKernelGGL((k_pm_walk_len<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C, pm->ix, pm->cinfo, pm->cob,
@@ -1157,6 +1161,8 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         HIPCHK(hipGetLastError());
         tend(ctx);
     } else {
+        if (tab_ready)
+            if (int rc = (*tab_ready)()) return rc;
         if (int rc = dalloc(ctx, &ctx->g_uwords, 8, false)) return rc;
         if (int rc = dalloc(ctx, &ctx->g_eoffw, 1, false)) return rc;
         if (int rc = dalloc(ctx, &ctx->g_elen, 1, false)) return rc;

@@ -78,6 +78,8 @@ struct smx_ctx {
     size_t budget = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // uploads of asynchronous submissions
+    hipStream_t side_stream = nullptr;  // construction, route 0: the successor table (k_pm_tab, k_pm_remote) runs here while the junction k-mers are sorted on `stream`
+    int64_t opt_pm_overlap = 1;         // ... 0: one after the other on `stream` (rounds 3-5)
     int64_t opt_async_upload = 0;       // smx_submit_reads_packed returns before the copy is done (the host arrays stay valid until the reads are used)
     std::string err;
     std::vector<ReadChunk> chunks;

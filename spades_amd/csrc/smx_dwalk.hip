@@ -24,6 +24,7 @@ __device__ __forceinline__ uint32_t dw_owner(const Rec<NW> &canon, uint32_t B, u
     return (uint32_t)(((uint64_t)bucket_of(xxh3_rec<NW>(canon), B) * world) / B);
 }
 
+__device__ __forceinline__ unsigned long long dw_wave_count(unsigned long long *lcnt, bool has, uint32_t ow);
 // CAND = false: items are the 2 * D0 oriented nodes of the shard, those of junction k-mers ask nothing;
 // CAND = true: items are the start de-edges (k_cand_expand). PASS 0 counts per owner, PASS 1 places record + tag.
 template <int NW, bool CAND, int PASS>
@@ -63,10 +64,10 @@ __global__ void __launch_bounds__(BLK) k_dw_requests(const void *kmers_, const u
                 unsigned yo;
                 y = rec_canon<NW>(rec_shl<NW>(node_kmer<NW>(kmers, node, k), k, c), k, yo);
                 ow = dw_owner<NW>(y, B, world);
-                at = atomicAdd(&lcnt[ow], 1ull);
                 tag = ((unsigned long long)i << DW_TAG_SHIFT) | (CAND ? 8u : 0u) | (yo << 2) | c;
             }
         }
+        at = dw_wave_count(lcnt, asks, ow);  // (one LDS atomic per wave and owner)
         __syncthreads();
         for (uint32_t t = threadIdx.x; t < world; t += BLK)
             if (lcnt[t]) lbase[t] = atomicAdd(&hist_or_cursor[t], lcnt[t]);
@@ -191,6 +192,25 @@ __device__ __forceinline__ uint32_t dw_owner_of(const DwOwners &o, unsigned long
 __device__ __forceinline__ bool dw_open(unsigned long long w, uint8_t f) { return (f & 1) && !(w & DW_F); }
 __device__ __forceinline__ bool dw_done(unsigned long long w, uint8_t f) { return (f & 1) && (w & DW_F); }
 
+// A wave's lanes with a message take their places in the workgroup's counters owner by owner: ONE LDS atomic per (wave, owner) instead of one per
+// lane — with a few ranks nearly every lane of a workgroup hits the same handful of counters (world = 1: all 256 the same one; the first GPU run of
+// these kernels was measured on exactly that). Every lane of the wave calls it (ballots / shuffles outside divergent code); returns the lane's
+// place among the workgroup's messages to `ow`.
+__device__ __forceinline__ unsigned long long dw_wave_count(unsigned long long *lcnt, bool has, uint32_t ow) {
+    unsigned long long todo = __ballot(has), at = 0;
+    const unsigned lane = threadIdx.x & 63u;
+    while (todo) {
+        const int lead = __ffsll(todo) - 1;
+        const uint32_t o = (uint32_t)__shfl((int)ow, lead, 64);
+        const unsigned long long same = __ballot(has && ow == o) & todo;
+        unsigned long long base = 0;
+        if ((int)lane == lead) base = atomicAdd(&lcnt[o], (unsigned long long)__popcll(same));
+        base = __shfl(base, lead, 64);
+        if ((same >> lane) & 1ull) at = base + (unsigned long long)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return at;
+}
 // One workgroup round of the two-pass grouping by owner: every thread brings up to NM messages; PASS 0 adds the workgroup's counts per owner
 // to hist, PASS 1 takes the workgroup's place from the cursors (initialised with the exclusive scan of hist) and returns every message's
 // slot in the send order. lds: [world] counts + [world] bases. Contains barriers: call from all threads.
@@ -201,7 +221,7 @@ __device__ __forceinline__ void dw_group(unsigned long long *lcnt, unsigned long
     __syncthreads();
     unsigned long long at[NM];
 #pragma unroll
-    for (int j = 0; j < NM; ++j) at[j] = has[j] ? atomicAdd(&lcnt[ow[j]], 1ull) : 0ull;
+    for (int j = 0; j < NM; ++j) at[j] = dw_wave_count(lcnt, has[j], ow[j]);
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < world; t += BLK)
         if (lcnt[t]) lbase[t] = atomicAdd(&hist_or_cursor[t], lcnt[t]);

@@ -74,6 +74,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         ctx->ext_mode = false;
         ctx->pm.active = false;
         ctx->pm.nx = false;
+        if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
         (void)hipStreamSynchronize(ctx->stream);
         for (auto &t : ctx->timings) {
             (void)hipEventDestroy(t.e0);
@@ -217,6 +218,21 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         if ((rc = dalloc(ctx, &prof, 8))) return bail(rc);
         if (hipMemsetAsync(prof, 0, 64, ctx->stream) != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "counter reset failed"));
     }
+    // The successor table (k_pm_tab: HBM writes; k_pm_remote: random sectors, latency) and the reference's order of the start de-edges (the
+    // junction k-mers through the sort pipeline: streaming) need nothing from each other — both read the records and the mask bytes only. Round 6:
+    // the table is filled on a side stream while graph_from_masks sorts the junction k-mers on the main one; the host joins them before the
+    // first walk (tab_ready below). Their stage times then overlap: the sum of the stage times exceeds the step's wall clock by what was hidden.
+    const bool overlap = ctx->opt_pm_overlap != 0 && !getenv("SMX_DEBUG");
+    hipStream_t main_stream = ctx->stream;
+    if (overlap) {
+        if (!ctx->side_stream && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "side stream"));
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, main_stream) != hipSuccess ||
+            hipStreamWaitEvent(ctx->side_stream, ev, 0) != hipSuccess)
+            return bail(fail(ctx, SMX_DEVICE_ERROR, "side stream: %s", hipGetErrorString(hipGetLastError())));
+        (void)hipEventDestroy(ev);  // (released once it has completed)
+        ctx->stream = ctx->side_stream;  // tbegin / tend and the launches below take the context's stream
+    }
     tbegin(ctx, "pm_tab");
     if (P.nchunks)
         hipLaunchKernelGGL(k_pm_tab, dim3(std::min<uint32_t>(P.nchunks, 256 * 16)), dim3(BLK), lds, ctx->stream, (const unsigned long long *)P.cinfo, P.nchunks,
@@ -229,34 +245,48 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         hipLaunchKernelGGL((k_pm_remote<NW>), dim3((unsigned)std::min<uint64_t>((P.nchunks + PMR_CH - 1) / PMR_CH, 256 * 32)), dim3(BLK), 0, ctx->stream, pw.ix,
                            (const unsigned long long *)P.cinfo, P.nchunks, wpc, (const uint32_t *)rbits, k, tab, d_err);
     tend(ctx);
-    if (hipGetLastError() != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "k_pm_tab launch failed"));
-    unsigned long long hs[2] = {0, 0}, hpal = 0;
-    if (hipMemcpyAsync(hs, stats, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(&hpal, P.pals, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
-        return bail(fail(ctx, SMX_DEVICE_ERROR, "node table pass failed: %s", hipGetErrorString(hipGetLastError())));
-    hs[1] += hpal;  // palindromic (k+1)-mers: the clean winners' by the dedupe stage, the dirty region's by k_pm_tab_dirty
-    arena_put(ctx, P.llink);  // (only k_pm_tab reads the local links)
-    P.llink = nullptr;
-    if (prof) {
-        unsigned long long hp[8];
-        if (hipMemcpy(hp, prof, 64, hipMemcpyDeviceToHost) == hipSuccess)
-            fprintf(stderr, "[smx] pm_tab: %u chunks (%llu k-mers clean, %llu dirty); 100MHz ticks per chunk: stage %.1f, node table %.1f, chain heads %.1f, jumps %.1f; "
-                            "successors outside their chunk %llu, chain heads per chunk %.1f\n", P.nchunks, (unsigned long long)P.nclean, (unsigned long long)P.ndirty,
-                    hp[4] ? (double)hp[0] / hp[4] : 0.0, hp[4] ? (double)hp[1] / hp[4] : 0.0, hp[4] ? (double)hp[2] / hp[4] : 0.0, hp[4] ? (double)hp[3] / hp[4] : 0.0,
-                    hp[5], hp[4] ? (double)hp[6] / hp[4] : 0.0);
+    ctx->stream = main_stream;
+    if (hipGetLastError() != hipSuccess) {
+        if (overlap) (void)hipStreamSynchronize(ctx->side_stream);
+        return bail(fail(ctx, SMX_DEVICE_ERROR, "k_pm_tab launch failed"));
     }
-    if ((hs[0] + hs[1]) & 1) return bail(fail(ctx, SMX_DEVICE_ERROR, "odd number of extension bits (%llu + %llu palindromes)", hs[0], hs[1]));
-    ctx->g_ext_bits = hs[0];
-    ctx->g_ext_pals = hs[1];
-    ctx->g_nkpo = (hs[0] + hs[1]) / 2;
+    bool joined = false;
+    const std::function<int()> tab_ready = [&]() -> int {
+        if (joined) return 0;
+        joined = true;
+        unsigned long long hs[2] = {0, 0}, hpal = 0;
+        if ((overlap && hipStreamSynchronize(ctx->side_stream) != hipSuccess) || hipMemcpyAsync(hs, stats, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(&hpal, P.pals, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return fail(ctx, SMX_DEVICE_ERROR, "node table pass failed: %s", hipGetErrorString(hipGetLastError()));
+        hs[1] += hpal;  // palindromic (k+1)-mers: the clean winners' by the dedupe stage, the dirty region's by k_pm_tab_dirty
+        arena_put(ctx, P.llink);  // (only k_pm_tab reads the local links)
+        P.llink = nullptr;
+        if (prof) {
+            unsigned long long hp[8];
+            if (hipMemcpy(hp, prof, 64, hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[smx] pm_tab: %u chunks (%llu k-mers clean, %llu dirty); 100MHz ticks per chunk: stage %.1f, node table %.1f, chain heads %.1f, jumps %.1f; "
+                                "successors outside their chunk %llu, chain heads per chunk %.1f\n", P.nchunks, (unsigned long long)P.nclean, (unsigned long long)P.ndirty,
+                        hp[4] ? (double)hp[0] / hp[4] : 0.0, hp[4] ? (double)hp[1] / hp[4] : 0.0, hp[4] ? (double)hp[2] / hp[4] : 0.0, hp[4] ? (double)hp[3] / hp[4] : 0.0,
+                        hp[5], hp[4] ? (double)hp[6] / hp[4] : 0.0);
+        }
+        if ((hs[0] + hs[1]) & 1) return fail(ctx, SMX_DEVICE_ERROR, "odd number of extension bits (%llu + %llu palindromes)", hs[0], hs[1]);
+        ctx->g_ext_bits = hs[0];
+        ctx->g_ext_pals = hs[1];
+        ctx->g_nkpo = (hs[0] + hs[1]) / 2;
+        return 0;
+    };
     ctx->g_route_stats[0] = 0;
     ctx->g_route_stats[1] = P.nclean;
     ctx->g_route_stats[2] = P.ndirty;
     ctx->g_route_stats[3] = P.nchunks;
     ctx->g_route_stats[6] = P.nslots;
     ctx->g_route_stats[7] = P.nfolded;
-    rc = graph_from_masks<NW>(ctx, k, tab, /*tab_valid=*/true, d_err, gwt, /*present=*/true, &pw);
+    if (!overlap)
+        if ((rc = tab_ready())) return bail(rc);
+    rc = graph_from_masks<NW>(ctx, k, tab, /*tab_valid=*/true, d_err, gwt, /*present=*/true, &pw, &tab_ready);
+    if (overlap) (void)hipStreamSynchronize(ctx->side_stream);  // (an early way out of graph_from_masks: nothing of the table may still be in flight when its blocks go)
     if (rc) return bail(rc);
+    if ((rc = tab_ready())) return bail(rc);
     // the count-result view: the k-mer file is made when somebody asks for it (pm_materialize_file)
     ctx->d_result = ctx->d_result_buf = nullptr;
     ctx->n_records = D0;

@@ -366,7 +366,7 @@ class GpuEngine:
             sc, rc = [int(send_c[p]) * unit for p in range(world)], [int(recv_c[p]) * unit for p in range(world)]
             send = torch.as_tensor(_DevBytes(d_send, max(sum(sc), 1)), device=dev)
             recv = torch.as_tensor(_DevBytes(d_recv, max(sum(rc), 1)), device=dev)
-            _a2a_known(send, sc, recv, rc, rank, world, dev, limit=XCHG_LIMIT * 8)
+            _p2p_known(send, sc, recv, rc, rank, world, dev, XCHG_LIMIT * 8)
 
         def allreduce(_u, vals, n, op):
             t = torch.tensor([int(vals[i]) for i in range(n)], dtype=torch.int64, device=dev)
@@ -454,6 +454,46 @@ def _a2a_known(send: torch.Tensor, counts, recv: torch.Tensor, rcounts, rank: in
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
     if dev.type == "cuda":  # the library runs on its own stream: what was received must have landed before it reads it
+        torch.cuda.current_stream(dev).synchronize()
+
+
+def _p2p_known(send: torch.Tensor, counts, recv: torch.Tensor, rcounts, rank: int, world: int, dev, limit: int):
+    """the same movement by grouped point-to-point operations only: both ends of a pair know that pair's size and cut it into the same pieces of
+    `limit` elements, so no rank needs to agree with all the others on a number of rounds (no all-reduce per exchange — smx_shard_walks makes
+    thousands of small ones), and the segment that stays on this rank is a device copy, as in the C++ host (tools/gbuilder_mgpu.hpp)."""
+    soff, roff = [0], [0]
+    for c in counts:
+        soff.append(soff[-1] + c)
+    for c in rcounts:
+        roff.append(roff[-1] + c)
+    if counts[rank]:
+        recv[roff[rank]:roff[rank + 1]].copy_(send[soff[rank]:soff[rank + 1]])
+    staged = _staged(send)
+    r = 0
+    while True:
+        ops, keep = [], []
+        for p in range(world):
+            if p == rank:
+                continue
+            a, c = min(soff[p] + r * limit, soff[p + 1]), min(roff[p] + r * limit, roff[p + 1])
+            b, d = min(a + limit, soff[p + 1]), min(c + limit, roff[p + 1])
+            if b > a:
+                ops.append(dist.P2POp(dist.isend, send[a:b].cpu() if staged else send[a:b], p))
+            if d > c:
+                if staged:  # (ranks that share a GPU run on gloo: through host memory)
+                    h = torch.empty(d - c, dtype=recv.dtype)
+                    keep.append((c, d, h))
+                    ops.append(dist.P2POp(dist.irecv, h, p))
+                else:
+                    ops.append(dist.P2POp(dist.irecv, recv[c:d], p))
+        if not ops:
+            break
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for c, d, h in keep:
+            recv[c:d].copy_(h)
+        r += 1
+    if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()
 
 

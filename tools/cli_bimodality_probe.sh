@@ -52,7 +52,7 @@ for w in gathered distributed; do
   t0=$(date +%s.%N)
   env SMX_DEBUG=1 SMX_MGPU_WALKS=$w SMX_MGPU_SELF_RCCL=1 SMX_MGPU_PARTS=4 SMX_MGPU_WATCHDOG=120 spades_amd/tools/spades-gbuilder-mi355x "$D/r.fq" "$D/o.gfa" -k 55 -t 16 --gfa --gpus 1 2>&1 | grep -E "walks:|rank 0\] (owner|distributed|graph built|output)|doubling" | tail -30
   t1=$(date +%s.%N)
-  echo "wall $(echo "$t1 - $t0" | bc) s; identical to the single-process GFA: $(cmp -s "$D/ref.gfa" "$D/o.gfa" && echo yes || echo NO)"
+  echo "wall $(python3 -c "print(round($t1 - $t0, 2))") s; identical to the single-process GFA: $(cmp -s "$D/ref.gfa" "$D/o.gfa" && echo yes || echo NO)"
   rm -f "$D/o.gfa"
 done
 rm -rf "$D"
