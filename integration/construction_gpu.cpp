@@ -113,6 +113,12 @@ class GpuConstruction : public Construction::Phase {
         check(smx_set_option(ctx, "submit_contigs", 0));
         INFO("Counting (k+1)-mers, building the extension index and condensing the graph on the MI355X");
         check(smx_build_graph(ctx, k, 10 * nthreads));  // bucket count of kmer_extension_index_builder.hpp:75
+        {   // which of the library's routes the build took (with the default configuration — early_tip_clipper on — it is the one the bench measures)
+            uint64_t rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            check(smx_graph_route_stats(ctx, rs));
+            INFO("Construction route: " << (rs[0] == 0 ? "partition-major (k-mers never sorted)" : rs[0] == 1 ? "k-mers + masks from one count, sorted" : "(k+1)-mer file first")
+                 << ", " << rs[4] << " junction k-mers, " << rs[5] << " start de-edges");
+        }
         check(smx_graph_fill_coverage(ctx));            // PHMCoverageFiller, stages/construction.cpp:371-435
         uint64_t info[8];
         check(smx_graph_info(ctx, info));

@@ -74,6 +74,7 @@ void clear_graph(smx_ctx *ctx) {
     ctx->g_sharded_file = false;
     ctx->g_pm = false;
     ctx->g_pm_nx = false;
+    ctx->g_pm_clipped = false;
     ctx->pm_view_pending = false;
     ctx->g_kmers = nullptr;
     ctx->g_mask = nullptr;
@@ -851,30 +852,15 @@ int device_loops(smx_ctx *ctx, unsigned k, bool pm, const unsigned long long *ll
     return 0;
 }
 
-// Everything after the extension masks: early clippers (options), node table of the final masks, start de-edges, walks, perfect
-// loops, link records + vertices. tab: 2 * D0 + 2 entries; tab_valid: k_fill_tab has already filled it for the current masks.
-// pm: the partition-major route (smx_pm.hpp) — g_kmers holds EXT records in the dedupe stage's order, tab is filled, walks cross chunks by
-// jump words, and the start de-edges are numbered through the sorted junction k-mers.
-template <int NW>
-int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint32_t *d_err, WallTrace &gwt, bool present = false, const PmWalk *pm = nullptr,
-                     const std::function<int()> *tab_ready = nullptr /* pm: the node table is still being filled on the side stream; called before the first use of it */) {
-    const uint64_t D0 = ctx->g_nkmers;
+// The early clippers of spades-core's Construction stage on the extension masks (stages/construction.cpp:289-341), on either view of the graph
+// (IX: FileFind — sorted k-mer file + rank directory; PmFind — the partition-major records of route 0). resucc(&succ): the successor table of the
+// masks as they are NOW, in the format IX::next reads; *edited is set whenever a pass has changed the masks.
+template <int NW, class IX>
+int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err, const std::function<int(const node_t **)> &resucc, bool *edited) {
     const unsigned grid = grid_for(2 * D0);
-    const smx::RankDir ixk = ctx->g_dir_kmers;
-    struct Prefix {
-        smx_ctx *c;
-        Prefix(smx_ctx *c_, const char *p) : c(c_) { c->tprefix = p; }
-        ~Prefix() { c->tprefix.clear(); }
-    };
-    node_t *succ = nullptr;  // successor table of the early clippers (their own format, by lookup)
-    if (ctx->opt_early_at || ctx->opt_early_tip_bound > 0)
-        if (int rc = dalloc(ctx, &succ, 2 * D0)) return rc;
-    bool clipped = !tab_valid;
-
+    const node_t *succ = nullptr;
     // ---- 3a. early A/T remover (RNA pipelines: EarlyATClipper::run, stages/construction.cpp:317-326) --------------
-    ctx->g_at_edges = ctx->g_at_tip_kmers = 0;
     if (ctx->opt_early_at) {
-        clipped = true;
         const double ratio = 0.8;
         const uint32_t min_len = 10, max_len = 200;
         // math::ls(a, b) = !AlmostEquals(a, b) && a < b (4 ULPs, math/xmath.h:284-312): thresholds as the smallest count that is NOT ls
@@ -909,33 +895,33 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         HIPCHK(hipMemsetAsync(astats, 0, 32, ctx->stream));
         HIPCHK(hipMemcpyAsync(d_thr, h_thr.data(), h_thr.size() * 2, hipMemcpyHostToDevice, ctx->stream));
         tbegin(ctx, "early_at");
-        hipLaunchKernelGGL((k_at_edges_mark<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk,
-                           thr_edge, atflag, d_err);
+        hipLaunchKernelGGL((k_at_edges_mark<NW, IX>), dim3(grid), dim3(BLK), 0, ctx->stream, ix, (const uint8_t *)ctx->g_mask, D0, k, thr_edge, atflag, d_err);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL((k_at_edges_apply<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (uint32_t *)ctx->g_mask, D0, k, ixk,
-                           (const uint8_t *)atflag, astats, d_err);
+        hipLaunchKernelGGL((k_at_edges_apply<NW, IX>), dim3(grid), dim3(BLK), 0, ctx->stream, ix, (uint32_t *)ctx->g_mask, D0, k, (const uint8_t *)atflag, astats, d_err);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, succ, d_err);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL((k_at_tips_mark<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const node_t *)succ, D0, k, ixk, min_len, max_len, (const uint16_t *)d_thr, isolate, tipped, astats, d_err);
+        *edited = true;
+        if (int rc = resucc(&succ)) return rc;
+        hipLaunchKernelGGL((k_at_tips_mark<NW, IX>), dim3(grid), dim3(BLK), 0, ctx->stream, ix, (const uint8_t *)ctx->g_mask, succ, D0, k, min_len, max_len,
+                           (const uint16_t *)d_thr, isolate, tipped, astats, d_err);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_tip_apply, dim3(grid), dim3(BLK), 0, ctx->stream, ctx->g_mask, (const uint8_t *)isolate, D0);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL((k_tip_fix<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (uint32_t *)ctx->g_mask,
-                           (const uint8_t *)tipped, D0, k, ixk, d_err);
+        hipLaunchKernelGGL((k_tip_fix<NW, IX>), dim3(grid), dim3(BLK), 0, ctx->stream, ix, (uint32_t *)ctx->g_mask, (const uint8_t *)tipped, D0, k, d_err);
         HIPCHK(hipGetLastError());
+        *edited = true;
         tend(ctx);
         unsigned long long hs[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(hs, astats, 32, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         ctx->g_at_tip_kmers = hs[0];
         ctx->g_at_edges = hs[2];
+        for (void *p : {(void *)atflag, (void *)isolate, (void *)tipped}) {  // (16 B per k-mer of marks: gone before the walks ask for their arrays)
+            detach_temp(ctx, p);
+            arena_put(ctx, p);
+        }
     }
     // ---- 3b. early tip clipper (spades-core variant, off for spades-gbuilder) ---------------------
-    ctx->g_tip_kmers = ctx->g_tips = 0;
     if (ctx->opt_early_tip_bound > 0) {
-        clipped = true;
         uint8_t *isolate, *tipped;
         unsigned long long *tstats;
         if (int rc = dalloc(ctx, &isolate, D0 + 1)) return rc;
@@ -944,26 +930,82 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         HIPCHK(hipMemsetAsync(isolate, 0, D0 + 1, ctx->stream));
         HIPCHK(hipMemsetAsync(tipped, 0, 2 * D0 + 1, ctx->stream));
         HIPCHK(hipMemsetAsync(tstats, 0, 16, ctx->stream));
+        if (int rc = resucc(&succ)) return rc;
         tbegin(ctx, "early_tips");
-        hipLaunchKernelGGL((k_succ<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, D0, k, ixk, succ, d_err);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL((k_tip_mark<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const node_t *)succ, D0, k, ixk, (uint32_t)std::min<int64_t>(ctx->opt_early_tip_bound, 0x7FFFFFFF), isolate, tipped, tstats,
-                           d_err);
+        hipLaunchKernelGGL((k_tip_mark<NW, IX>), dim3(grid), dim3(BLK), 0, ctx->stream, ix, (const uint8_t *)ctx->g_mask, succ, D0, k,
+                           (uint32_t)std::min<int64_t>(ctx->opt_early_tip_bound, 0x7FFFFFFF), isolate, tipped, tstats, d_err);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_tip_apply, dim3(grid), dim3(BLK), 0, ctx->stream, ctx->g_mask, (const uint8_t *)isolate, D0);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL((k_tip_fix<NW>), dim3(grid), dim3(BLK), 0, ctx->stream, (const void *)ctx->g_kmers, (uint32_t *)ctx->g_mask,
-                           (const uint8_t *)tipped, D0, k, ixk, d_err);
+        hipLaunchKernelGGL((k_tip_fix<NW, IX>), dim3(grid), dim3(BLK), 0, ctx->stream, ix, (uint32_t *)ctx->g_mask, (const uint8_t *)tipped, D0, k, d_err);
         HIPCHK(hipGetLastError());
+        *edited = true;
         tend(ctx);
         unsigned long long hs[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(hs, tstats, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         ctx->g_tip_kmers = hs[0];
         ctx->g_tips = hs[1];
+        for (void *p : {(void *)isolate, (void *)tipped}) {
+            detach_temp(ctx, p);
+            arena_put(ctx, p);
+        }
     }
-    if (clipped) {  // the node table has to describe the clipped masks
+    return 0;
+}
+
+// Everything after the extension masks: early clippers (options), node table of the final masks, start de-edges, walks, perfect
+// loops, link records + vertices. tab: 2 * D0 + 2 entries; tab_valid: k_fill_tab has already filled it for the current masks.
+// pm: the partition-major route (smx_pm.hpp) — g_kmers holds EXT records in the dedupe stage's order, tab is filled, walks cross chunks by
+// jump words, and the start de-edges are numbered through the sorted junction k-mers.
+template <int NW>
+int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint32_t *d_err, WallTrace &gwt, bool present = false, const PmWalk *pm = nullptr,
+                     const std::function<int()> *tab_ready = nullptr /* pm: the node table is still being filled on the side stream; called before the first use of it */,
+                     const std::function<int()> *retab = nullptr /* pm with early clippers: makes the node table again from the masks as they are now */) {
+    bool masks_edited = false;
+    const uint64_t D0 = ctx->g_nkmers;
+    const unsigned grid = grid_for(2 * D0);
+    const smx::RankDir ixk = ctx->g_dir_kmers;
+    struct Prefix {
+        smx_ctx *c;
+        Prefix(smx_ctx *c_, const char *p) : c(c_) { c->tprefix = p; }
+        ~Prefix() { c->tprefix.clear(); }
+    };
+    bool clipped = !tab_valid;
+    ctx->g_at_edges = ctx->g_at_tip_kmers = 0;
+    ctx->g_tip_kmers = ctx->g_tips = 0;
+    if (ctx->opt_early_at || ctx->opt_early_tip_bound > 0) {
+        clipped = true;
+        if (pm) {
+            // route 0 (round 6): the clippers look k-mers up through the partition table and walk the route's own node table; whenever they have
+            // edited the masks, the table is made again (retab: k_pm_tab with the unclipped masks beside the clipped ones + k_pm_remote)
+            if (!retab) return fail(ctx, SMX_DEVICE_ERROR, "the early clippers on the partition-major route need a way to renew the node table");
+            PmFind<NW> ixp{pm->ix, pm->jmp};
+            const std::function<int(const node_t **)> resucc = [&](const node_t **s) -> int {
+                if (masks_edited)
+                    if (int rc = (*retab)()) return rc;
+                masks_edited = false;
+                *s = tab;
+                return 0;
+            };
+            if (int rc = early_clippers<NW>(ctx, k, ixp, D0, d_err, resucc, &masks_edited)) return rc;
+            if (masks_edited)
+                if (int rc = (*retab)()) return rc;
+            masks_edited = false;
+        } else {
+            node_t *succ = nullptr;  // successor table of the early clippers (their own format, by lookup)
+            if (int rc = dalloc(ctx, &succ, 2 * D0)) return rc;
+            FileFind<NW> ixf{(const Rec<NW> *)ctx->g_kmers, ixk};
+            const std::function<int(const node_t **)> resucc = [&](const node_t **s) -> int {
+                hipLaunchKernelGGL((k_succ<NW, FileFind<NW>>), dim3(grid), dim3(BLK), 0, ctx->stream, ixf, (const uint8_t *)ctx->g_mask, D0, k, succ, d_err);
+                HIPCHK(hipGetLastError());
+                *s = succ;
+                return 0;
+            };
+            if (int rc = early_clippers<NW>(ctx, k, ixf, D0, d_err, resucc, &masks_edited)) return rc;
+        }
+    }
+    if (clipped && !(pm && (ctx->opt_early_at || ctx->opt_early_tip_bound > 0))) {  // the node table has to describe the clipped masks (route 0 has renewed its own)
         tbegin(ctx, "succ");
         // (present: masks that came from the reads and were not clipped — every extension leads to a k-mer of the file)
         if (present && !ctx->opt_early_at && ctx->opt_early_tip_bound <= 0)
@@ -1042,8 +1084,9 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
                                (const unsigned long long *)tjoff, D0, (void *)jrecs, jrank_of);
             HIPCHK(hipGetLastError());
             const bool nx = pm->ix.xs == 0;  // plain k-mer records: the bytes of the junction k-mers come from the graph's mask array (smx_pm.hip)
+            const bool bym = pm->ix.bym != 0;  // ... and so they do where an early clipper has edited the masks since the records were written (EXT records, stale bytes)
             hipLaunchKernelGGL((k_pm_cand_counts_node<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, nj, coff,
-                               nx ? (const uint8_t *)ctx->g_mask : (const uint8_t *)nullptr, (const unsigned long long *)jrank_of);
+                               bym ? (const uint8_t *)ctx->g_mask : (const uint8_t *)nullptr, (const unsigned long long *)jrank_of);
             HIPCHK(hipGetLastError());
             if (int rc = scan_u64(ctx, coff, coff, nj)) return rc;
             tend(ctx);
@@ -1074,23 +1117,23 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             }
             smx::RankDir jix{};
             if (int rc = build_rank_dir<NW>(ctx, jk, nj, jboff, ctx->g_B, k, jix)) return rc;
-            if (nx) {  // the bytes reach the sorted order through the rank lookups themselves (k_pm_jrank_nx1), then the counts, then the numbers
+            if (bym) {  // the bytes reach the sorted order through the rank lookups themselves (k_pm_jrank_nx1), then the counts, then the numbers
                 hipLaunchKernelGGL((k_pm_jrank_nx1<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, nj, (const void *)jk, jix,
-                                   (const uint8_t *)ctx->g_mask, (const unsigned long long *)jrank_of, qbase, jm, d_err);
+                                   (const uint8_t *)ctx->g_mask, (const unsigned long long *)jrank_of, qbase, jm, d_err, pm->ix.xs);
             }
             hipLaunchKernelGGL(k_pm_cand_counts, dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const uint8_t *)jm, nj, jcnt);
             if (int rc = scan_u64(ctx, jcnt, candoff, nj)) {
                 drop_rank_dir(ctx, jix);
                 return rc;
             }
-            if (nx)
+            if (bym)
                 hipLaunchKernelGGL(k_pm_jrank_nx2, dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, nj, (const unsigned long long *)candoff, qbase);
             else
                 hipLaunchKernelGGL((k_pm_jrank<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, nj, (const void *)jk, jix,
                                    (const unsigned long long *)candoff, qbase, d_err);
             hipLaunchKernelGGL((k_pm_cand_expand<NW>), dim3(grid_for(nj)), dim3(BLK), 0, ctx->stream, (const void *)jrecs, (const unsigned long long *)jrank_of, nj,
                                (const unsigned long long *)coff, (const unsigned long long *)qbase, cand, qidx,
-                               nx ? (const uint8_t *)ctx->g_mask : (const uint8_t *)nullptr);
+                               bym ? (const uint8_t *)ctx->g_mask : (const uint8_t *)nullptr);
             unsigned long long ctot = 0;
             hipError_t e1 = hipGetLastError();
             if (e1 == hipSuccess) e1 = hipMemcpyAsync(&ctot, candoff + nj, 8, hipMemcpyDeviceToHost, ctx->stream);

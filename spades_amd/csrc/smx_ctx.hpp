@@ -79,7 +79,8 @@ struct smx_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // uploads of asynchronous submissions
     hipStream_t side_stream = nullptr;  // construction, route 0: the successor table (k_pm_tab, k_pm_remote) runs here while the junction k-mers are sorted on `stream`
-    int64_t opt_pm_overlap = 1;         // ... 0: one after the other on `stream` (rounds 3-5)
+    int64_t opt_pm_overlap = 0;         // ... 1: measured (profiles/r06/bench_config3_successor_table_on_side_stream.json): side by side both get slower by what the
+                                        // other takes (80 -> 92 ms, 48 -> 120 ms; step 470-479 ms either way) — both are bound by the fabric's random-sector rate
     int64_t opt_async_upload = 0;       // smx_submit_reads_packed returns before the copy is done (the host arrays stay valid until the reads are used)
     std::string err;
     std::vector<ReadChunk> chunks;
@@ -109,6 +110,7 @@ struct smx_ctx {
     PmState pm;               // partition-major construction route
     uint64_t g_route_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // smx_graph_route_stats of the last build
     bool g_pm = false;        // g_kmers holds EXT records in partition-major order (no sorted k-mer file yet: made on demand)
+    bool g_pm_clipped = false;  // ... EXT records whose bytes are the UNCLIPPED masks (an early clipper edited g_mask after they were written): synced before the file is made
     bool g_pm_nx = false;     // ... plain k-mer records instead (the k-mer leaves the last word no 8 spare bits): the bytes live in g_mask alone
     bool pm_view_pending = false;  // the count-result view (smx_copy_final_kmers, smx_bucket_sizes, ...) stands for the k-mer file of that
                                    // graph, not made yet; any later count owns the view again (clear_result)

@@ -264,11 +264,11 @@ int dw_walks(smx_ctx *ctx, const uint64_t *kmers_per_rank, const smx_collectives
                                             (unsigned long long)n_mine) : 0);
     DW_LOCAL(dw_prepare<NW>(ctx));
     const uint64_t n_cand = bad ? 0 : ctx->dw_ncand;
-    const uint64_t CH = (uint64_t)std::max<int64_t>(ctx->opt_walk_chunk > 0 ? ctx->opt_walk_chunk : ((int64_t)1 << 26), 2) & ~1ull;  // nodes per round (whole k-mers)
+    const uint64_t CH = (uint64_t)std::max<int64_t>(ctx->opt_walk_chunk > 0 ? ctx->opt_walk_chunk : ((int64_t)1 << 27), 2) & ~1ull;  // nodes per round (whole k-mers)
     const uint64_t SCH = (uint64_t)std::max<int64_t>(ctx->opt_walk_start_chunk > 0 ? ctx->opt_walk_start_chunk : ((int64_t)1 << 22), 1);
-    uint64_t rounds3[3] = {(n2 + CH - 1) / CH, (n_cand + CH - 1) / CH, (n_cand + SCH - 1) / SCH};
-    if (int rc = allred(rounds3, 3, 1)) return rc;
-    const uint64_t node_rounds = rounds3[0], cand_rounds = rounds3[1], start_rounds = rounds3[2];
+    uint64_t rounds3[4] = {(n2 + CH - 1) / CH, (n_cand + CH - 1) / CH, (n_cand + SCH - 1) / SCH, n2};
+    if (int rc = allred(rounds3, 4, 1)) return rc;
+    const uint64_t node_rounds = rounds3[0], cand_rounds = rounds3[1], start_rounds = rounds3[2], max_n2 = rounds3[3];
     const size_t lds = (size_t)world * 16;
 
     DwKeep keep{ctx, {}};
@@ -382,8 +382,20 @@ int dw_walks(smx_ctx *ctx, const uint64_t *kmers_per_rank, const smx_collectives
         ++rounds;
         if (rounds == 2) DW_HOOK(2);
         if (dbg) fprintf(stderr, "[smx] walks: round %llu: %llu open\n", (unsigned long long)rounds, (unsigned long long)tot);
-        for (uint64_t c = 0; c < node_rounds; ++c) {
-            const uint64_t a = std::min(c * CH, n2), n_it = std::min(CH, n2 - a);
+        // A round's exchanges carry the OPEN nodes only, and they thin out round by round (at 30x: 92 %, 86, 74, 50, 15, 0.5 % of the nodes): the
+        // node range of one exchange grows as they do, so that every exchange carries about the same load — a chunk of the last rounds is the whole
+        // shard, not 1 / 80 of it with a few thousand requests and a dozen host round trips each. Every rank derives the same ranges (tot and the
+        // largest shard are global figures).
+        uint64_t CHr = CH;
+        {
+            const long double frac = (long double)tot / (long double)std::max<uint64_t>(2 * first[world], 1);
+            const long double grow = frac > 0 ? 1.0L / frac : 1.0L;
+            CHr = (uint64_t)std::min<long double>((long double)CH * std::min<long double>(grow, 4096.0L), (long double)std::max<uint64_t>(max_n2, 2));
+            CHr = std::max<uint64_t>(CHr & ~1ull, 2);
+        }
+        const uint64_t rounds_r = std::max<uint64_t>((max_n2 + CHr - 1) / CHr, 1);
+        for (uint64_t c = 0; c < rounds_r; ++c) {
+            const uint64_t a = std::min(c * CHr, n2), n_it = std::min(CHr, n2 - a);
             unsigned long long *hist = nullptr, *cur = nullptr, *q = nullptr, *tag = nullptr, *qin = nullptr, *rows = nullptr, *wp = nullptr;
             std::vector<uint64_t> counts(world, 0), rcounts;
             DW_LOCAL(dalloc(ctx, &hist, world));

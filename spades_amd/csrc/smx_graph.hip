@@ -531,6 +531,30 @@ __global__ void k_ext_boff(const void *in_, uint64_t n, const unsigned long long
     new_off[b] = c;
 }
 
+// Where the early clippers find a k-mer: they need nothing of the k-mer file but "the k-mer with this index" and "the index of this canonical
+// k-mer, if the graph has it" — the order of the indices never reaches their result (marks per k-mer, bits per mask). FileFind: the sorted
+// k-mer file and its rank directory (routes 1 and 2); PmFind (smx_pm.hip): the partition-major records of route 0, looked up by minimizer
+// partition and chunk hash table (round 6: spades-core's default configuration — early_tip_clipper on — runs the route the bench measures).
+template <int NW>
+struct FileFind {
+    const Rec<NW> *kmers;
+    RankDir dir;
+    __device__ __forceinline__ Rec<NW> kmer(uint64_t r) const { return kmers[r]; }
+    __device__ __forceinline__ node_t find(const Rec<NW> &y) const { return kmer_rank<NW>(kmers, dir, y); }
+    // successor of a node of a NON-junction k-mer in the table the clippers walk (k_succ's format here)
+    __device__ __forceinline__ node_t next(const node_t *__restrict__ succ, node_t nd) const { return succ_node(succ[nd]); }
+    // FindForward (early_simplification.hpp:102-112): from nd along non-junction k-mers, at most until cnt == bound; returns the node it stops at
+    // (NODE_NONE: inconsistent index)
+    __device__ __forceinline__ node_t advance(const node_t *__restrict__ succ, const uint8_t *__restrict__ mask, node_t nd, uint32_t &cnt, uint32_t bound) const {
+        while (cnt < bound && !mask_junction(mask[nd >> 1])) {
+            ++cnt;
+            nd = succ_node(succ[nd]);
+            if (nd == NODE_NONE) break;  // (reported by k_succ: never walk off the array)
+        }
+        return nd;
+    }
+};
+
 // the node table of clipped masks (spades-core variants): extensions from the masks, successors by lookup
 // (PRESENT: the masks come from the reads themselves, every extension leads to a k-mer of the file)
 template <int NW, bool PRESENT = false>
@@ -554,10 +578,8 @@ __global__ void __launch_bounds__(BLK) k_tab_from_masks(const void *kmers_, cons
 
 // successor of every non-junction node by lookup: GetOutgoing(kwh, GetUniqueOutgoing), debruijn_graph_constructor.hpp:228-235.
 // Used after the early clippers changed the masks (the table k_fill_masks left behind describes the unclipped index).
-template <int NW>
-__global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t *mask, uint64_t D0, unsigned k,
-                                              RankDir ix, node_t *succ, uint32_t *err) {
-    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+template <int NW, class IX>
+__global__ void __launch_bounds__(BLK) k_succ(IX ix, const uint8_t *mask, uint64_t D0, unsigned k, node_t *succ, uint32_t *err) {
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
         const uint64_t r = node >> 1;
         const unsigned o = (unsigned)(node & 1);
@@ -567,12 +589,12 @@ __global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t 
             continue;
         }
         const unsigned mo = o ? brev8(m) : m;
-        Rec<NW> x = kmers[r];
+        Rec<NW> x = ix.kmer(r);
         if (o) x = rec_rc<NW>(x, k);
         unsigned yo;
         const unsigned c = __ffs(mo & 15) - 1;
         Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-        const node_t ry = kmer_rank<NW>(kmers, ix, y);
+        const node_t ry = ix.find(y);
         if (ry == NODE_NONE) atomicAdd(err, 1u);
         succ[node] = ry == NODE_NONE ? NODE_NONE : ((ry << 1) | yo | ((node_t)c << 62));
     }
@@ -586,18 +608,17 @@ __global__ void __launch_bounds__(BLK) k_succ(const void *kmers_, const uint8_t 
 // predecessors all the way back to ONE junction orientation, so no other junction ever walks them, and roots keep their phantom
 // extension bits until the clean-up pass (checked against the reference run with 1-4 threads: tests/golden/etc_*). Hence three
 // data-parallel passes: mark (reads the original masks), apply (IsolateVertex), fix (RemoveInconsistentForwardLinks, :21-36).
-template <int NW>
-__global__ void __launch_bounds__(BLK) k_tip_mark(const void *kmers_, const uint8_t *mask, const node_t *succ, uint64_t D0, unsigned k,
-                                                  RankDir ix, uint32_t bound, uint8_t *isolate, uint8_t *tipped, unsigned long long *stats,
+template <int NW, class IX>
+__global__ void __launch_bounds__(BLK) k_tip_mark(IX ix, const uint8_t *mask, const node_t *succ, uint64_t D0, unsigned k,
+                                                  uint32_t bound, uint8_t *isolate, uint8_t *tipped, unsigned long long *stats,
                                                   uint32_t *err) {
-    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
         const uint64_t r = node >> 1;
         const unsigned o = (unsigned)(node & 1);
         const unsigned m = mask[r];
         const unsigned mo = o ? brev8(m) : m;
         if (__popc(mo & 15) < 2) continue;
-        Rec<NW> x = kmers[r];
+        Rec<NW> x = ix.kmer(r);
         if (o) x = rec_rc<NW>(x, k);
         node_t first[4];
         uint32_t len[4];
@@ -609,7 +630,7 @@ __global__ void __launch_bounds__(BLK) k_tip_mark(const void *kmers_, const uint
             if (!(mo & (1u << c))) continue;
             unsigned yo;
             const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-            const node_t ry = kmer_rank<NW>(kmers, ix, y);
+            const node_t ry = ix.find(y);
             if (ry == NODE_NONE) {
                 atomicAdd(err, 1u);
                 continue;
@@ -617,11 +638,7 @@ __global__ void __launch_bounds__(BLK) k_tip_mark(const void *kmers_, const uint
             node_t nd = (ry << 1) | yo;
             uint32_t cnt = 0;
             first[c] = nd;
-            while (cnt < bound && !mask_junction(mask[nd >> 1])) {
-                ++cnt;
-                nd = succ_node(succ[nd]);
-                if (nd == NODE_NONE) break;  // inconsistent index (reported by k_succ): never walk off the array
-            }
+            nd = ix.advance(succ, mask, nd, cnt, bound);
             if (nd == NODE_NONE) {
                 len[c] = 0xFFFFFFFFu;
                 mx = 0xFFFFFFFFu;
@@ -640,7 +657,7 @@ __global__ void __launch_bounds__(BLK) k_tip_mark(const void *kmers_, const uint
             node_t nd = first[c];
             for (uint32_t i = 0; i + 1 < len[c]; ++i) {
                 isolate[nd >> 1] = 1;
-                nd = succ_node(succ[nd]);
+                nd = ix.next(succ, nd);
             }
             isolate[nd >> 1] = 1;
             any = true;
@@ -654,10 +671,8 @@ __global__ void k_tip_apply(uint8_t *mask, const uint8_t *isolate, uint64_t D0) 
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * blockDim.x)
         if (isolate[r]) mask[r] = 0;
 }
-template <int NW>
-__global__ void __launch_bounds__(BLK) k_tip_fix(const void *kmers_, uint32_t *mask32, const uint8_t *tipped, uint64_t D0, unsigned k, RankDir ix,
-                                                 uint32_t *err) {
-    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
+template <int NW, class IX>
+__global__ void __launch_bounds__(BLK) k_tip_fix(IX ix, uint32_t *mask32, const uint8_t *tipped, uint64_t D0, unsigned k, uint32_t *err) {
     const uint8_t *mask = (const uint8_t *)mask32;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
         if (!tipped[node]) continue;
@@ -665,14 +680,14 @@ __global__ void __launch_bounds__(BLK) k_tip_fix(const void *kmers_, uint32_t *m
         const unsigned o = (unsigned)(node & 1);
         const unsigned m = mask[r];
         const unsigned mo = o ? brev8(m) : m;
-        Rec<NW> x = kmers[r];
+        Rec<NW> x = ix.kmer(r);
         if (o) x = rec_rc<NW>(x, k);
         const unsigned firstn = rec_nucl<NW>(x, 0);
         for (unsigned c = 0; c < 4; ++c) {
             if (!(mo & (1u << c))) continue;
             unsigned yo;
             const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-            const node_t ry = kmer_rank<NW>(kmers, ix, y);
+            const node_t ry = ix.find(y);
             if (ry == NODE_NONE) {
                 atomicAdd(err, 1u);
                 continue;
@@ -713,10 +728,9 @@ __device__ __forceinline__ Rec<NW> rec_shr(const Rec<NW> &x, unsigned K, unsigne
 }
 // RemoveATEdges, :176-259, pass 1: edges of length 1 (the next k-mer is a junction or a dead end) leaving a low-complexity junction
 // k-mer (some nucleotide occurs >= thr_edge times; thr_edge = smallest count that is not math::ls than 0.8 k, computed on the host)
-template <int NW>
-__global__ void __launch_bounds__(BLK) k_at_edges_mark(const void *kmers_, const uint8_t *mask, uint64_t D0, unsigned k, RankDir ix,
+template <int NW, class IX>
+__global__ void __launch_bounds__(BLK) k_at_edges_mark(IX ix, const uint8_t *mask, uint64_t D0, unsigned k,
                                                        uint32_t thr_edge, uint8_t *atflag, uint32_t *err) {
-    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
         const uint64_t r = node >> 1;
         const unsigned o = (unsigned)(node & 1);
@@ -724,7 +738,7 @@ __global__ void __launch_bounds__(BLK) k_at_edges_mark(const void *kmers_, const
         if (!mask_junction(m)) continue;
         const unsigned mo = o ? brev8(m) : m;
         if ((mo & 15) == 0) continue;
-        Rec<NW> x = kmers[r];
+        Rec<NW> x = ix.kmer(r);
         if (o) x = rec_rc<NW>(x, k);
         unsigned cnt[4];
         rec_counts<NW>(x, k, cnt);
@@ -734,7 +748,7 @@ __global__ void __launch_bounds__(BLK) k_at_edges_mark(const void *kmers_, const
             if (!(mo & (1u << c))) continue;
             unsigned yo;
             const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-            const node_t ry = kmer_rank<NW>(kmers, ix, y);
+            const node_t ry = ix.find(y);
             if (ry == NODE_NONE) {
                 atomicAdd(err, 1u);
                 continue;
@@ -748,23 +762,22 @@ __global__ void __launch_bounds__(BLK) k_at_edges_mark(const void *kmers_, const
 }
 // pass 2: DeleteOutgoing(kh, c) + DeleteIncoming(next, kh[0]) for the marked edges (an edge marked from both of its ends clears
 // the same two bits twice)
-template <int NW>
-__global__ void __launch_bounds__(BLK) k_at_edges_apply(const void *kmers_, uint32_t *mask32, uint64_t D0, unsigned k, RankDir ix,
+template <int NW, class IX>
+__global__ void __launch_bounds__(BLK) k_at_edges_apply(IX ix, uint32_t *mask32, uint64_t D0, unsigned k,
                                                         const uint8_t *atflag, unsigned long long *stats, uint32_t *err) {
-    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
         const unsigned fl = atflag[node];
         if (!fl) continue;
         const uint64_t r = node >> 1;
         const unsigned o = (unsigned)(node & 1);
-        Rec<NW> x = kmers[r];
+        Rec<NW> x = ix.kmer(r);
         if (o) x = rec_rc<NW>(x, k);
         const unsigned firstn = rec_nucl<NW>(x, 0);
         for (unsigned c = 0; c < 4; ++c) {
             if (!(fl & (1u << c))) continue;
             unsigned yo;
             const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-            const node_t ry = kmer_rank<NW>(kmers, ix, y);
+            const node_t ry = ix.find(y);
             if (ry == NODE_NONE) {
                 atomicAdd(err, 1u);
                 continue;
@@ -779,18 +792,17 @@ __global__ void __launch_bounds__(BLK) k_at_edges_apply(const void *kmers_, uint
 // RemoveATTips, :262-338: from every dead end with a unique incoming extension walk back to the junction the tip hangs on (at most
 // max_len k-mers; succ[] of the opposite strand is the predecessor), count the last nucleotides of the tip k-mers (+ the root's up to
 // min_len), remove the tip if one nucleotide makes up >= thr_tip[max(n, min_len)] of them.
-template <int NW>
-__global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const uint8_t *mask, const node_t *succ, uint64_t D0, unsigned k,
-                                                      RankDir ix, uint32_t min_len, uint32_t max_len, const uint16_t *thr_tip,
+template <int NW, class IX>
+__global__ void __launch_bounds__(BLK) k_at_tips_mark(IX ix, const uint8_t *mask, const node_t *succ, uint64_t D0, unsigned k,
+                                                      uint32_t min_len, uint32_t max_len, const uint16_t *thr_tip,
                                                       uint8_t *isolate, uint8_t *tipped, unsigned long long *stats, uint32_t *err) {
-    const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
         const uint64_t r = node >> 1;
         const unsigned o = (unsigned)(node & 1);
         const unsigned m0 = mask[r];
         const unsigned mo0 = o ? brev8(m0) : m0;
         if ((mo0 & 15) != 0 || !uniq4((mo0 >> 4) & 15)) continue;  // start from tip ends
-        Rec<NW> x = kmers[r];
+        Rec<NW> x = ix.kmer(r);
         if (o) x = rec_rc<NW>(x, k);
         unsigned cnt[4] = {0, 0, 0, 0};
         uint32_t n = 0;
@@ -805,14 +817,14 @@ __global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const 
             if (n == 1) {  // the dead end is a junction k-mer: its predecessor comes from a lookup, the rest by pointer chasing
                 unsigned yo;
                 const Rec<NW> y = rec_canon<NW>(x, k, yo);
-                const node_t ry = kmer_rank<NW>(kmers, ix, y);
+                const node_t ry = ix.find(y);
                 if (ry == NODE_NONE) {
                     bad = true;
                     break;
                 }
                 nd = (ry << 1) | yo;
             } else {
-                const node_t sp = succ_node(succ[nd ^ 1]);
+                const node_t sp = ix.next(succ, nd ^ 1);
                 if (sp == NODE_NONE) {
                     bad = true;
                     break;
@@ -833,7 +845,7 @@ __global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const 
         // second walk: IsolateVertex on the n tip k-mers
         {
             node_t q = node;
-            Rec<NW> z = kmers[r];
+            Rec<NW> z = ix.kmer(r);
             if (o) z = rec_rc<NW>(z, k);
             unsigned mq = mo0;
             for (uint32_t i = 0; i < n; ++i) {
@@ -844,9 +856,9 @@ __global__ void __launch_bounds__(BLK) k_at_tips_mark(const void *kmers_, const 
                 if (i == 0) {
                     unsigned yo;
                     const Rec<NW> y = rec_canon<NW>(z, k, yo);
-                    q = (kmer_rank<NW>(kmers, ix, y) << 1) | yo;
+                    q = (ix.find(y) << 1) | yo;
                 } else {
-                    q = succ_node(succ[q ^ 1]) ^ 1;
+                    q = ix.next(succ, q ^ 1) ^ 1;
                 }
                 const unsigned mm = mask[q >> 1];
                 mq = (q & 1) ? brev8(mm) : mm;

@@ -29,7 +29,13 @@ struct PmIndex {
     RankDir ddir;                     // its rank directory (one bucket)
     unsigned xs;                      // EXT_BITS: the records carry their InOutMask byte (EXT layout); 0: plain k-mers, the byte lives in `mask` alone ("nx", k without 8 spare record bits)
     const uint8_t *mask;              // [records] InOutMask bytes (what an nx graph reads instead of the record's low byte)
+    unsigned bym;                     // 1: the bytes are read from `mask` whatever the records carry — plain records, or EXT records whose bytes an early
+                                      // clipper has left behind (it edits the mask array: the record bytes are the UNCLIPPED ones from then on)
 };
+template <int NW>
+__device__ __forceinline__ unsigned pm_byte(const PmIndex &ix, const Rec<NW> &raw, uint64_t r) {
+    return ix.bym ? (unsigned)ix.mask[r] : (unsigned)(raw.w[NW - 1] & 0xFFu);
+}
 
 struct PmWalk {  // what graph_from_masks (smx_construct.hpp) needs beyond the node table on this route
     PmIndex ix;
@@ -98,6 +104,37 @@ __device__ __forceinline__ Rec<NW> pm_node_kmer(const Rec<NW> *__restrict__ recs
     return (node & 1) ? rec_rc<NW>(x, k) : x;
 }
 
+// the early clippers' view of the graph on this route (FileFind in smx_graph.hip is the other one): index = place in the partition-major records
+template <int NW>
+struct PmFind {
+    PmIndex ix;
+    __device__ __forceinline__ Rec<NW> kmer(uint64_t r) const { return rec_pure_xs<NW>(((const Rec<NW> *)ix.recs)[r], ix.xs); }
+    __device__ __forceinline__ node_t find(const Rec<NW> &y) const { return pm_find<NW>(ix, y); }
+    // (the table the clippers walk IS the route's node table here: no second array of 16 B per k-mer next to it)
+    __device__ __forceinline__ node_t next(const node_t *__restrict__ tab, node_t nd) const { return tab[nd] & TAB_NODE_MASK; }
+    const uint32_t *jmp;  // the jump words of the node table (chains inside a chunk)
+    // FindForward with the route's jump words: a chain of s non-junction k-mers inside a chunk is crossed with one word, as the unitig walks
+    // cross it — exactly: the reference's loop takes a step while cnt < bound, so it reaches the far end of the chain iff cnt + s <= bound, and
+    // otherwise stops INSIDE it, on a non-junction k-mer (which is no dead end: the branch is "too long" whatever that node is). 95 steps are
+    // ~6 chunks: a dozen sectors instead of 95 dependent ones per branch.
+    __device__ __forceinline__ node_t advance(const node_t *__restrict__ tab, const uint8_t *__restrict__ mask, node_t nd, uint32_t &cnt, uint32_t bound) const {
+        while (cnt < bound && !mask_junction(mask[nd >> 1])) {
+            const uint32_t j = jmp[nd], s = j >> 16;
+            if (s) {
+                if (cnt + s > bound) {  // the loop would stop on an interior k-mer of this chain: any of them tells the caller "not a tip"
+                    cnt = bound;
+                    return nd;
+                }
+                cnt += s;
+                nd = (node_t)((long long)nd + (long long)(int16_t)(j & 0xFFFFu));
+                continue;
+            }
+            ++cnt;
+            nd = tab[nd] & TAB_NODE_MASK;
+        }
+        return nd;
+    }
+};
 // Jump words: jmp[node] = (delta to the last node of the chain that stays inside the node's chunk, 16 bits signed) | steps << 16.
 // A walk that enters a chunk reads ONE word to cross it (smx_pm_walk_len) instead of one node-table entry per k-mer.
 constexpr uint16_t PM_ADV_NONE = 0xFFFFu;
@@ -143,7 +180,8 @@ __device__ __forceinline__ unsigned pm_palindromes(const Rec<NW> &x, unsigned m,
 }
 __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t maxn, const uint8_t *__restrict__ mask,
                                                 const uint32_t *__restrict__ llink, node_t *tab, uint32_t *jmp, unsigned long long *stats, uint32_t *err,
-                                                unsigned long long *prof, uint32_t *rbits /* [nchunks * (maxn >> 4)]: bit nd of a chunk's words = node nd asks k_pm_remote */) {
+                                                unsigned long long *prof, uint32_t *rbits /* [nchunks * (maxn >> 4)]: bit nd of a chunk's words = node nd asks k_pm_remote */,
+                                                const uint8_t *__restrict__ mask_orig /* the masks the local links were made on, when an early clipper has edited `mask` since; else nullptr */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pm_lds[];
     uint32_t *jw = pm_lds;
     uint16_t *list = (uint16_t *)(jw + 2 * maxn);
@@ -179,18 +217,20 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
         }
         // (the byte and the link word of the thread's NEXT record are asked for before this one is worked on: a chunk gives a thread ~4
         // records, and with one load -> use -> store chain after the other the phase was latency, round-5 ticks: 574 of a chunk's 1100)
-        unsigned m_nx = 0;
+        unsigned m_nx = 0, mo_nx = 0;
         uint32_t ll_nx = 0;
         if (threadIdx.x < n) {
             m_nx = mask[base + threadIdx.x];
             ll_nx = llink[base + threadIdx.x];
+            if (mask_orig) mo_nx = mask_orig[base + threadIdx.x];
         }
         for (uint32_t r = threadIdx.x; r < n; r += BLK) {
-            const unsigned m = m_nx;
+            const unsigned m = m_nx, m_was = mask_orig ? mo_nx : m_nx;
             const uint32_t ll = ll_nx;
             if (r + BLK < n) {
                 m_nx = mask[base + r + BLK];
                 ll_nx = llink[base + r + BLK];
+                if (mask_orig) mo_nx = mask_orig[base + r + BLK];
             }
             bits += __popc(m);
             const bool junction = mask_junction(m);
@@ -202,7 +242,10 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
                 uint32_t w = 0xFFFFu;  // no local successor
                 e[o] = (node_t)mo << TAB_OUT_SHIFT;
                 if (uniq4(mo)) {
-                    if (l != 0xFFFFu && l < nn) {
+                    // (a local link is the neighbour in SOME read: it is the successor only where the k-mer had this one extension when the links were
+                    // made — an orientation that lost branches to a clipper since looks its remaining successor up like a remote one)
+                    const bool link_ok = uniq4((o ? brev8(m_was) : m_was) & 15u);
+                    if (l != 0xFFFFu && l < nn && link_ok) {
                         e[o] |= 2 * base + l;
                         if (!junction) {
                             w = l;
@@ -288,7 +331,7 @@ __global__ void __launch_bounds__(BLK) k_pm_remote(PmIndex ix, const unsigned lo
             for (uint32_t i = lane; i < n; i += 64) {
                 const node_t node = 2 * base + my[i];
                 const Rec<NW> raw = recs[node >> 1];
-                const unsigned m = ix.xs ? (unsigned)(raw.w[NW - 1] & 0xFFu) : (unsigned)ix.mask[node >> 1], o = (unsigned)(node & 1);
+                const unsigned m = pm_byte<NW>(ix, raw, node >> 1), o = (unsigned)(node & 1);
                 const unsigned mo = (o ? brev8(m) : m) & 15u;
                 unsigned yo;
                 const Rec<NW> y = pm_succ_kmer<NW>(rec_pure_xs<NW>(raw, ix.xs), k, o, mo, yo);
@@ -312,7 +355,7 @@ __global__ void __launch_bounds__(BLK) k_pm_tab_dirty(PmIndex ix, uint64_t nd, u
         const uint64_t r = ix.nclean + i;
         const Rec<NW> raw = recs[r];
         const Rec<NW> x = rec_pure_xs<NW>(raw, ix.xs);
-        const unsigned m = ix.xs ? (unsigned)(raw.w[NW - 1] & 0xFFu) : (unsigned)ix.mask[r];
+        const unsigned m = pm_byte<NW>(ix, raw, r);
         bits += __popc(m);
         const unsigned x0 = rec_nucl<NW>(x, 0), xl = rec_nucl<NW>(x, k - 1);
         if (((m >> (3 - x0)) & 1) && range_is_rc_palindrome<NW>(x, 1, k - 1)) ++pals;
@@ -351,6 +394,17 @@ __global__ void k_pm_dirty_split(const void *recs_, uint64_t nclean, uint64_t nd
         const Rec<NW> raw = recs[nclean + i];
         dk[i] = rec_pure<NW>(raw);
         mask[nclean + i] = (uint8_t)(raw.w[NW - 1] & 0xFFu);
+    }
+}
+
+// EXT records of a graph whose masks an early clipper has edited: the byte in the record follows the mask array again (before the records go
+// through the sort that makes the k-mer file: the file's masks are split off the records)
+template <int NW>
+__global__ void k_pm_sync_bytes(void *recs_, const uint8_t *__restrict__ mask, uint64_t n) {
+    Rec<NW> *recs = (Rec<NW> *)recs_;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t w = recs[i].w[NW - 1];
+        recs[i].w[NW - 1] = (w & ~0xFFull) | (uint64_t)mask[i];
     }
 }
 
@@ -419,11 +473,11 @@ __global__ void __launch_bounds__(BLK) k_pm_jrank(const void *jn_, uint64_t nj, 
 // sorted file, leaves it in qbase and puts ITS byte there (jm[jr]); then the caller counts and scans jm into candoff; (2) qbase[j] = candoff[jr].
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_pm_jrank_nx1(const void *jn_, uint64_t nj, const void *jk_, RankDir jix, const uint8_t *mask, const unsigned long long *jrank_of,
-                                                      unsigned long long *qbase, uint8_t *jm, uint32_t *err) {
+                                                      unsigned long long *qbase, uint8_t *jm, uint32_t *err, unsigned xs /* 0: jn holds plain k-mers; EXT_BITS: EXT records */) {
     const Rec<NW> *jn = (const Rec<NW> *)jn_;
     const Rec<NW> *jk = (const Rec<NW> *)jk_;
     for (uint64_t j = (uint64_t)blockIdx.x * BLK + threadIdx.x; j < nj; j += (uint64_t)gridDim.x * BLK) {
-        const node_t jr = kmer_rank<NW, false>(jk, jix, jn[j]);
+        const node_t jr = kmer_rank<NW, false>(jk, jix, rec_pure_xs<NW>(jn[j], xs));
         if (jr == NODE_NONE) atomicAdd(err, 1u);
         else jm[jr] = mask[jrank_of[j]];
         qbase[j] = jr;

@@ -61,8 +61,13 @@ inline uint32_t pm_host_bucket(const uint64_t *w, int nw, uint32_t B) {
 template <int NW>
 int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     if (ctx->opt_pm_route == 0 || ctx->opt_ext_route == 0 || ctx->chunks.empty() || ctx->opt_derive_batches != 0 ||
-        ctx->opt_ext_presort == 0 || ctx->opt_early_at || ctx->opt_early_tip_bound > 0 || ctx->opt_batch_records > 0)
+        ctx->opt_ext_presort == 0 || ctx->opt_batch_records > 0)
         return SMX_ROUTE_NA;
+    // spades-core's early clippers (construction.info: early_tip_clipper { enable true } — its default) edit the extension masks before the
+    // condensation. Until round 5 they sent the build to the sorted routes ("their lookups may miss"); pm_find answers exactly for absent
+    // k-mers too, so they run here (round 6): on the partition-major records, walking the route's own node table, which is made again from the
+    // clipped masks (graph_from_masks: early_clippers<PmFind>, retab below).
+    const bool clip = ctx->opt_early_at || ctx->opt_early_tip_bound > 0;
     // k = 29, 31, 61, 63, 93, 95, 125, 127 leave the last record word no room for the InOutMask byte (EXT layout): the route then runs on PLAIN k-mer
     // records ("nx") — the byte of every k-mer lives in the mask array the route keeps anyway, the junction k-mers are sorted without it and get it
     // back by their rank lookups, the survivors of cut partitions gather theirs by a search in their own sorted set (round 5; option nx_route = 0:
@@ -188,6 +193,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     pw.ix.ddir = P.ddir;
     pw.ix.xs = nx ? 0u : EXT_BITS;
     pw.ix.mask = ctx->g_mask;
+    pw.ix.bym = (nx || clip) ? 1u : 0u;  // (the mask array holds every k-mer's byte on this route either way; a clipper edits IT, not the records)
     uint32_t *d_err, *jmp;
     node_t *tab;
     unsigned long long *stats;
@@ -222,7 +228,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     // junction k-mers through the sort pipeline: streaming) need nothing from each other — both read the records and the mask bytes only. Round 6:
     // the table is filled on a side stream while graph_from_masks sorts the junction k-mers on the main one; the host joins them before the
     // first walk (tab_ready below). Their stage times then overlap: the sum of the stage times exceeds the step's wall clock by what was hidden.
-    const bool overlap = ctx->opt_pm_overlap != 0 && !getenv("SMX_DEBUG");
+    const bool overlap = ctx->opt_pm_overlap != 0 && !getenv("SMX_DEBUG") && !clip;
     hipStream_t main_stream = ctx->stream;
     if (overlap) {
         if (!ctx->side_stream && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "side stream"));
@@ -236,7 +242,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     tbegin(ctx, "pm_tab");
     if (P.nchunks)
         hipLaunchKernelGGL(k_pm_tab, dim3(std::min<uint32_t>(P.nchunks, 256 * 16)), dim3(BLK), lds, ctx->stream, (const unsigned long long *)P.cinfo, P.nchunks,
-                           maxn, (const uint8_t *)ctx->g_mask, (const uint32_t *)P.llink, tab, jmp, stats, d_err, prof, rbits);
+                           maxn, (const uint8_t *)ctx->g_mask, (const uint32_t *)P.llink, tab, jmp, stats, d_err, prof, rbits, (const uint8_t *)nullptr);
     if (P.ndirty)
         hipLaunchKernelGGL((k_pm_tab_dirty<NW>), dim3(grid_for(P.ndirty)), dim3(BLK), 0, ctx->stream, pw.ix, (uint64_t)P.ndirty, k, tab, jmp, stats, d_err);
     tend(ctx);
@@ -259,8 +265,10 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
             hipMemcpyAsync(&hpal, P.pals, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
             return fail(ctx, SMX_DEVICE_ERROR, "node table pass failed: %s", hipGetErrorString(hipGetLastError()));
         hs[1] += hpal;  // palindromic (k+1)-mers: the clean winners' by the dedupe stage, the dirty region's by k_pm_tab_dirty
-        arena_put(ctx, P.llink);  // (only k_pm_tab reads the local links)
-        P.llink = nullptr;
+        if (!clip) {  // (only k_pm_tab reads the local links — once, unless an early clipper makes it run again)
+            arena_put(ctx, P.llink);
+            P.llink = nullptr;
+        }
         if (prof) {
             unsigned long long hp[8];
             if (hipMemcpy(hp, prof, 64, hipMemcpyDeviceToHost) == hipSuccess)
@@ -283,10 +291,45 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     ctx->g_route_stats[7] = P.nfolded;
     if (!overlap)
         if ((rc = tab_ready())) return bail(rc);
-    rc = graph_from_masks<NW>(ctx, k, tab, /*tab_valid=*/true, d_err, gwt, /*present=*/true, &pw, &tab_ready);
+    // with early clippers: the masks as the reads gave them stay beside the array the clippers edit (a local link is a successor only where the
+    // k-mer had ONE extension when the links were made), and the node table can be made again from the edited masks
+    uint8_t *mask_orig = nullptr;
+    unsigned long long *stats2 = nullptr;
+    if (clip) {
+        if ((rc = dalloc(ctx, &mask_orig, (size_t)D0 + 16))) return bail(rc);
+        if ((rc = dalloc(ctx, &stats2, 2))) return bail(rc);
+        if (hipMemcpyAsync(mask_orig, ctx->g_mask, (size_t)D0 + 16, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+            return bail(fail(ctx, SMX_DEVICE_ERROR, "copy of the masks failed"));
+    }
+    const std::function<int()> retab = [&]() -> int {
+        if (hipMemsetAsync(rbits, 0, (size_t)std::max<uint32_t>(P.nchunks, 1) * wpc * 4, ctx->stream) != hipSuccess || hipMemsetAsync(stats2, 0, 16, ctx->stream) != hipSuccess)
+            return fail(ctx, SMX_DEVICE_ERROR, "counter reset failed");
+        tbegin(ctx, "pm_tab");
+        if (P.nchunks)
+            hipLaunchKernelGGL(k_pm_tab, dim3(std::min<uint32_t>(P.nchunks, 256 * 16)), dim3(BLK), lds, ctx->stream, (const unsigned long long *)P.cinfo, P.nchunks,
+                               maxn, (const uint8_t *)ctx->g_mask, (const uint32_t *)P.llink, tab, jmp, stats2, d_err, (unsigned long long *)nullptr, rbits,
+                               (const uint8_t *)mask_orig);
+        if (P.ndirty)
+            hipLaunchKernelGGL((k_pm_tab_dirty<NW>), dim3(grid_for(P.ndirty)), dim3(BLK), 0, ctx->stream, pw.ix, (uint64_t)P.ndirty, k, tab, jmp, stats2, d_err);
+        tend(ctx);
+        tbegin(ctx, "pm_remote");
+        if (P.nchunks)
+            hipLaunchKernelGGL((k_pm_remote<NW>), dim3((unsigned)std::min<uint64_t>((P.nchunks + PMR_CH - 1) / PMR_CH, 256 * 32)), dim3(BLK), 0, ctx->stream, pw.ix,
+                               (const unsigned long long *)P.cinfo, P.nchunks, wpc, (const uint32_t *)rbits, k, tab, d_err);
+        tend(ctx);
+        if (hipGetLastError() != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "k_pm_tab launch failed");
+        return 0;
+    };
+    rc = graph_from_masks<NW>(ctx, k, tab, /*tab_valid=*/true, d_err, gwt, /*present=*/true, &pw, &tab_ready, clip ? &retab : nullptr);
+    if (P.llink) {
+        (void)hipStreamSynchronize(ctx->stream);
+        arena_put(ctx, P.llink);
+        P.llink = nullptr;
+    }
     if (overlap) (void)hipStreamSynchronize(ctx->side_stream);  // (an early way out of graph_from_masks: nothing of the table may still be in flight when its blocks go)
     if (rc) return bail(rc);
     if ((rc = tab_ready())) return bail(rc);
+    ctx->g_pm_clipped = clip && !nx;
     // the count-result view: the k-mer file is made when somebody asks for it (pm_materialize_file)
     ctx->d_result = ctx->d_result_buf = nullptr;
     ctx->n_records = D0;
@@ -332,6 +375,11 @@ int pm_materialize_file(smx_ctx *ctx, bool for_view) {
     uint8_t *old_mask = ctx->g_mask;
     const uint64_t nkpo = ctx->g_nkpo;
     const bool nx = ctx->g_pm_nx;
+    const bool clipped = ctx->g_pm_clipped;
+    if (clipped && !nx) {
+        hipLaunchKernelGGL((k_pm_sync_bytes<NW>), dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, src, (const uint8_t *)old_mask, D0);
+        ctx->g_pm_clipped = false;
+    }
     ctx->g_kmers = nullptr;
     ctx->g_mask = nullptr;
     ctx->g_pm = false;
@@ -349,7 +397,7 @@ int pm_materialize_file(smx_ctx *ctx, bool for_view) {
         if (rc == 0) {
             if (ctx->d_result_buf != src) arena_put(ctx, src);
             src = nullptr;
-            rc = ext_result_to_file<NW>(ctx, k, B, /*whole=*/true);
+            rc = ext_result_to_file<NW>(ctx, k, B, /*whole=*/!clipped);  // (clipped masks need not pair up bit for bit: the (k+1)-mer count is the one the reads gave)
         }
     } else {
         // Plain records, the bytes beside them: a COPY goes through the sort (the old array stays), the file's rank directory is built, and every
