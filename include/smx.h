@@ -181,6 +181,13 @@ int smx_copy_bucket(const smx_ctx *ctx, unsigned bucket, void *host_dst);
  * the bytes of <workdir>/final_kmers (kmercount.cpp:221-223) */
 int smx_copy_final_kmers(const smx_ctx *ctx, void *host_dst);
 int smx_write_final_kmers(const smx_ctx *ctx, const char *path);
+/* Count and file in one call, the destination known from the start: KMerDiskCounter::Count + KMerDiskStorage::merge (kmer_index_builder.hpp:306-332,
+ * 190-203). A count that goes out of core (the sorted-unique set does not fit the HBM budget) streams every merged bucket range to its place in
+ * `path` as the reference's merge does (:346-430, fwrite in 1 Mi-record chunks) instead of keeping the merged result in host memory next to the
+ * spilled runs, and gives the consumed parts of the runs back as it goes: host memory holds the runs alone, shrinking. A result that stays
+ * resident is written as smx_write_final_kmers writes it. Afterwards smx_count_info / smx_bucket_sizes answer; accessors of the RECORDS
+ * (smx_copy_bucket, smx_copy_final_kmers, ...) refuse with SMX_INVALID_PARAMETER when they were streamed: they are in the file. */
+int smx_count_to_file(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets, const char *path);
 /* device view of the same bytes (valid until the next smx_count / smx_destroy) */
 const void *smx_device_kmers(const smx_ctx *ctx);
 /* device-to-device copy of the same array into caller-owned HBM (e.g. a torch tensor about to enter a collective) */

@@ -78,6 +78,7 @@ def load():
         "smx_copy_bucket": (C.c_int, [vp, C.c_uint, vp]),
         "smx_copy_final_kmers": (C.c_int, [vp, vp]),
         "smx_write_final_kmers": (C.c_int, [vp, C.c_char_p]),
+        "smx_count_to_file": (C.c_int, [vp, C.c_uint, C.c_int, C.c_uint, C.c_char_p]),
         "smx_device_kmers": (vp, [vp]),
         "smx_extract_count": (C.c_int, [vp, C.c_uint, C.c_int, u64p]),
         "smx_extract_partition": (C.c_int, [vp, C.c_uint, C.c_int, C.c_uint, C.c_uint, vp, C.c_uint64, u64p]),

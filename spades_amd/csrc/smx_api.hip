@@ -536,6 +536,37 @@ int smx_count(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets) {
     return dispatch_count(ctx, K, mode, num_buckets, nullptr, 0);
 }
 
+// KMerDiskCounter::Count + KMerDiskStorage::merge in one call with the destination known from the start (kmer_index_builder.hpp:306-332,190-203):
+// a count that has to go out of core streams every merged bucket range to its place in the file instead of holding the merged result in host
+// memory next to the spilled runs (the reference's merge writes as it goes, :346-430); a result that stays in HBM is written as
+// smx_write_final_kmers writes it. Afterwards the figures of the count (smx_count_info, smx_bucket_sizes) are there; the records are in the file.
+int smx_count_to_file(smx_ctx *ctx, unsigned K, int mode, unsigned num_buckets, const char *path) {
+    if (!ctx || !path) return SMX_INVALID_PARAMETER;
+    ctx->xnames.clear();
+    ctx->xms.clear();
+    clear_result(ctx);
+    const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
+    ctx->sink_fd = fd;
+    ctx->sink_path = path;
+    int rc = dispatch_count(ctx, K, mode, num_buckets, nullptr, 0);
+    ctx->sink_fd = -1;
+    if (rc == 0 && !ctx->result_on_file) {  // the result is resident (one array, or two strands): written the usual way
+        (void)close(fd);
+        return smx_write_final_kmers(ctx, path);
+    }
+    if (rc == 0 && ftruncate(fd, (off_t)(ctx->n_records * (size_t)ctx->nw * 8)) != 0) rc = fail(ctx, SMX_IO_ERROR, "I/O error writing %s", path);
+    if (close(fd) != 0 && rc == 0) rc = fail(ctx, SMX_IO_ERROR, "I/O error closing %s", path);
+    if (rc) {
+        (void)unlink(path);
+        ctx->result_on_file = false;
+    }
+    return rc;
+}
+static int on_file(smx_ctx *ctx) {
+    return fail(ctx, SMX_INVALID_PARAMETER, "the records of this count were streamed to %s (smx_count_to_file): they are not held by the context", ctx->sink_path.c_str());
+}
+
 int smx_count_records(smx_ctx *ctx, unsigned K, unsigned num_buckets, const void *d_records, uint64_t n_records) {
     if (!ctx) return SMX_INVALID_PARAMETER;
     if (n_records && !d_records) return fail(ctx, SMX_INVALID_PARAMETER, "null records");
@@ -655,6 +686,7 @@ int smx_copy_bucket(const smx_ctx *cctx, unsigned bucket, void *host_dst) {
     const uint64_t o = ctx->bucket_off[bucket], n = ctx->bucket_off[bucket + 1] - o;
     if (n == 0) return SMX_OK;
     const size_t w = (size_t)ctx->nw * 8;
+    if (ctx->result_on_file) return on_file(ctx);
     if (ctx->result_on_host) {  // spilled result: chunks of whole buckets in file order
         uint64_t base = 0;
         for (auto &c : ctx->h_result) {
@@ -685,6 +717,7 @@ int smx_copy_final_kmers(const smx_ctx *cctx, void *host_dst) {
     if (ctx->n_records == 0) return SMX_OK;
     if (!host_dst) return SMX_INVALID_PARAMETER;
     if (int rc = ensure_kmer_file(ctx)) return rc;
+    if (ctx->result_on_file) return on_file(ctx);
     if (ctx->result_on_host) {
         char *dst = (char *)host_dst;
         for (auto &c : ctx->h_result) {
@@ -714,6 +747,7 @@ int smx_write_final_kmers(const smx_ctx *cctx, const char *path) {
     smx_ctx *ctx = const_cast<smx_ctx *>(cctx);
     if (!ctx || !path) return SMX_INVALID_PARAMETER;
     if (int rc = ensure_kmer_file(ctx)) return rc;
+    if (ctx->result_on_file) return ctx->sink_path == path ? SMX_OK : on_file(ctx);  // (that very file holds them already)
     FILE *f = fopen(path, "w+b");  // (read access too: a tmpfs output is filled through a shared mapping, smx_file_sink.hpp)
     if (!f) return fail(ctx, SMX_IO_ERROR, "Cannot open %s for writing", path);
     if (ctx->result_on_host) {
@@ -1376,6 +1410,7 @@ int smx_copy_bucket_device(const smx_ctx *cctx, unsigned bucket, void *d_dst) {
     const uint64_t o = ctx->bucket_off[bucket], n = ctx->bucket_off[bucket + 1] - o;
     if (n == 0) return SMX_OK;
     if (!d_dst) return SMX_INVALID_PARAMETER;
+    if (ctx->result_on_file) return on_file(ctx);
     if (ctx->result_on_host) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the result was spilled to host memory (it does not fit the HBM budget)");
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->ts.active) {
@@ -1393,6 +1428,7 @@ int smx_copy_kmers_device(const smx_ctx *cctx, void *d_dst) {
     if (ctx->n_records == 0) return SMX_OK;
     if (!d_dst) return SMX_INVALID_PARAMETER;
     if (int rc = ensure_kmer_file(ctx)) return rc;
+    if (ctx->result_on_file) return on_file(ctx);
     if (ctx->result_on_host) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "the result was spilled to host memory (it does not fit the HBM budget)");
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->ts.active) {  // merged straight into the caller's block

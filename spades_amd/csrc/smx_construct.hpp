@@ -900,7 +900,9 @@ int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err
         hipLaunchKernelGGL((k_at_edges_apply<NW, IX>), dim3(grid), dim3(BLK), 0, ctx->stream, ix, (uint32_t *)ctx->g_mask, D0, k, (const uint8_t *)atflag, astats, d_err);
         HIPCHK(hipGetLastError());
         *edited = true;
+        tend(ctx);  // (the stage is timed in two pieces: making the successor table again opens stages of its own in between)
         if (int rc = resucc(&succ)) return rc;
+        tbegin(ctx, "early_at");
         hipLaunchKernelGGL((k_at_tips_mark<NW, IX>), dim3(grid), dim3(BLK), 0, ctx->stream, ix, (const uint8_t *)ctx->g_mask, succ, D0, k, min_len, max_len,
                            (const uint16_t *)d_thr, isolate, tipped, astats, d_err);
         HIPCHK(hipGetLastError());

@@ -94,6 +94,12 @@ struct smx_ctx {
     };
     std::vector<HostChunk> h_result;
     bool result_on_host = false;
+    // ... or, for a count started by smx_count_to_file, in the FILE: the out-of-core merge streams every merged bucket range to its place in the file
+    // instead of keeping it (the reference's merge does: kmer_index_builder.hpp:346-430, fwrite in 1 Mi-record chunks) — host memory then holds the
+    // spilled runs alone, and those shrink as the merge consumes them
+    int sink_fd = -1;
+    std::string sink_path;
+    bool result_on_file = false;
     // ... or as the two strands of a both-strands count that is too large to hold merged (smx_pipeline.hpp: two_strand_finish): the
     // sorted canonical set and the sorted set of its reverse complements, both bucket-major; the accessors merge bucket by bucket
     struct TwoStrand {

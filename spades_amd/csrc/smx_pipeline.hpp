@@ -2,6 +2,8 @@
 // the super-k-mer pre-dedupe stage (run_prededupe), HBM-bounded batches (count_reads) and the owner partition of the sharded path
 // (included by smx_api.hip after smx_ctx.hpp).
 #pragma once
+#include <sys/mman.h>
+#include <unistd.h>
 
 namespace {
 template <int NW>
@@ -137,6 +139,7 @@ void clear_result(smx_ctx *ctx) {
     for (auto &c : ctx->h_result) free(c.data);
     ctx->h_result.clear();
     ctx->result_on_host = false;
+    ctx->result_on_file = false;
     if (ctx->d_result_buf) arena_put(ctx, ctx->d_result_buf);
     ctx->d_result_buf = ctx->d_result = nullptr;
     if (ctx->ts.active) {
@@ -1268,6 +1271,51 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
             for (auto &r : runs) free(r.data);
             runs.clear();
         };
+        // what the merge has consumed of the runs goes back to the system at once (the slices of the buckets [b0, b1): page-aligned interior of
+        // every run's block): the merged result grows as the runs shrink — in host memory (result_on_host) the peak is about the larger of the
+        // two instead of their sum, with a file sink the runs are all there is
+        auto release_slices = [&](unsigned b0, unsigned b1) {
+            const uintptr_t PG = 4096;
+            for (auto &r : runs) {
+                uintptr_t a = (uintptr_t)(r.data + r.boff[b0] * W), e = (uintptr_t)(r.data + r.boff[b1] * W);
+                a = (a + PG - 1) & ~(PG - 1);
+                e &= ~(PG - 1);
+                if (e > a) (void)madvise((void *)a, e - a, MADV_DONTNEED);
+            }
+        };
+        // a merged piece of the result: nu records at d_src belong at record `at` of the file order. Memory: appended to ch (the caller made room);
+        // file sink: through a page-locked staging buffer to their place in the file.
+        char *stage = nullptr;
+        const size_t STAGE = (size_t)256 << 20;
+        auto deliver = [&](smx_ctx::HostChunk &ch, const void *d_src, uint64_t nu, uint64_t at) -> int {
+            if (ctx->sink_fd < 0) {
+                if (nu && hipMemcpy(ch.data + ch.n * W, d_src, nu * W, hipMemcpyDeviceToHost) != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "result read-back failed");
+                ch.n += nu;
+                return 0;
+            }
+            if (!stage && hipHostMalloc((void **)&stage, STAGE, hipHostMallocDefault) != hipSuccess) {
+                stage = nullptr;
+                return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "no page-locked memory for the streamed result");
+            }
+            for (size_t o = 0; o < nu * W; o += STAGE) {
+                const size_t nbytes = std::min(STAGE, nu * W - o);
+                if (hipMemcpy(stage, (const char *)d_src + o, nbytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "result read-back failed");
+                size_t w = 0;
+                while (w < nbytes) {
+                    const ssize_t k_ = pwrite(ctx->sink_fd, stage + w, nbytes - w, (off_t)(at * W + o + w));
+                    if (k_ <= 0) return fail(ctx, SMX_IO_ERROR, "I/O error! Incomplete write to %s", ctx->sink_path.c_str());
+                    w += (size_t)k_;
+                }
+            }
+            ch.n += nu;
+            return 0;
+        };
+        struct StageFree {
+            char **p;
+            ~StageFree() {
+                if (*p) (void)hipHostFree(*p);
+            }
+        } stage_free{&stage};
         auto spill = [&](void *d, uint64_t n, const std::vector<uint64_t> &boff) -> int {
             HostRun r{(char *)malloc(std::max<size_t>(n * W, 1)), n, boff};
             if (!r.data) {
@@ -1441,12 +1489,12 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
             // parts are merged one after the other into ONE host chunk of the bucket (smx_spill_split.hpp; the reference streams the
             // bucket through its loser tree, kmer_index_builder.hpp:346-430). A part that cannot be placed halves the part size and
             // the REST of the bucket is planned again (what is merged stays).
-            auto merge_split_bucket = [&](unsigned b, uint64_t sum, smx_ctx::HostChunk &ch) -> int {
+            auto merge_split_bucket = [&](unsigned b, uint64_t sum, smx_ctx::HostChunk &ch, uint64_t base) -> int {
                 std::vector<smx_split::Slice> rest;
                 for (auto &r : runs) rest.push_back({r.data + r.boff[b] * W, r.boff[b + 1] - r.boff[b]});
-                ch.data = (char *)malloc(std::max<size_t>(sum * W, 1));  // (upper bound: the union cannot hold more; shrunk at the end)
+                ch.data = ctx->sink_fd >= 0 ? nullptr : (char *)malloc(std::max<size_t>(sum * W, 1));  // (upper bound: the union cannot hold more; shrunk at the end)
                 ch.n = 0;
-                if (!ch.data) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "host allocation for the merged result failed");
+                if (ctx->sink_fd < 0 && !ch.data) return fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "host allocation for the merged result failed");
                 uint64_t part_max = std::max<uint64_t>(std::min<uint64_t>(max_merge, sum / 2 + 1), 1);
                 const uint64_t floor_part = std::max<uint64_t>(runs.size(), ctx->opt_spill_merge_max > 0 ? 1 : (1u << 16));
                 for (;;) {
@@ -1477,8 +1525,7 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
                         if (!prc) {
                             const uint64_t nu = ctx->n_records;
                             if (ch.n + nu > sum) prc = fail(ctx, SMX_DEVICE_ERROR, "a merged part holds more records than went in");
-                            else if (nu && hipMemcpy(ch.data + ch.n * W, ctx->d_result_buf, nu * W, hipMemcpyDeviceToHost) != hipSuccess) prc = fail(ctx, SMX_DEVICE_ERROR, "result read-back failed");
-                            else ch.n += nu;
+                            else prc = deliver(ch, ctx->d_result_buf, nu, base + ch.n);
                         }
                         ctx->d_result_buf = ctx->d_result = nullptr;
                         free_temps(ctx);
@@ -1497,7 +1544,7 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
                         rest[r].n -= cuts[p][r];
                     }
                 }
-                if (ch.n < sum) {
+                if (ch.data && ch.n < sum) {
                     char *sh = (char *)realloc(ch.data, std::max<size_t>(ch.n * W, 1));
                     if (sh) ch.data = sh;
                 }
@@ -1513,13 +1560,14 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
                 while (b1 < B && (b1 == b0 || sum + tot[b1] <= max_merge)) sum += tot[b1++];
                 smx_ctx::HostChunk ch;
                 if (sum > max_merge && b1 - b0 == 1) {  // (b1 - b0 == 1: the loop above always takes one bucket, however large)
-                    rc = merge_split_bucket(b0, sum, ch);
+                    rc = merge_split_bucket(b0, sum, ch, done);
                     if (rc) {
                         free(ch.data);
                         break;
                     }
                     gboff[b0 + 1] = done + ch.n;
                     done += ch.n;
+                    release_slices(b0, b1);
                 } else if (sum) {
                     Rec<NW> *cat;
                     // two buffers of the range have to be placed; a fragmented arena gets a smaller range, a single bucket that does not fit is final
@@ -1544,12 +1592,14 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
                     }
                     if (!rc) rc = run_count<NW>(ctx, K, mode, B, cat, sum, nullptr, /*recs_reusable=*/true, false, false, b0, b1 - b0);
                     if (!rc) {
-                        ch.n = ctx->n_records;
-                        ch.data = (char *)malloc(std::max<size_t>(ch.n * W, 1));
-                        if (!ch.data) rc = fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "host allocation for the merged result failed");
-                        else if (ch.n && hipMemcpy(ch.data, ctx->d_result_buf, ch.n * W, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, SMX_DEVICE_ERROR, "result read-back failed");
+                        const uint64_t nu = ctx->n_records;
+                        ch.n = 0;
+                        ch.data = ctx->sink_fd >= 0 ? nullptr : (char *)malloc(std::max<size_t>(nu * W, 1));
+                        if (ctx->sink_fd < 0 && !ch.data) rc = fail(ctx, SMX_MEMORY_LIMIT_EXCEEDED, "host allocation for the merged result failed");
+                        else rc = deliver(ch, ctx->d_result_buf, nu, done);
                         for (unsigned b = b0; b < b1 && !rc; ++b) gboff[b + 1] = done + ctx->bucket_off[b + 1];
                         done += ch.n;
+                        if (!rc) release_slices(b0, b1);
                     }
                     ctx->d_result_buf = ctx->d_result = nullptr;
                     free_temps(ctx);
@@ -1569,8 +1619,12 @@ int count_reads(smx_ctx *ctx, unsigned K, int mode, unsigned B, unsigned min_len
                 for (auto &c : chunks) free(c.data);
                 return cleanup(rc);
             }
-            ctx->h_result = chunks;
-            ctx->result_on_host = true;
+            if (ctx->sink_fd >= 0) {  // every record is in the file already: nothing of the result stays here but its figures
+                ctx->result_on_file = true;
+            } else {
+                ctx->h_result = chunks;
+                ctx->result_on_host = true;
+            }
             ctx->K = K;
             ctx->nw = NW;
             ctx->num_buckets = B;

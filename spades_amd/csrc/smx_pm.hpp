@@ -76,6 +76,8 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     if (nx && ctx->opt_nx_route == 0) return SMX_ROUTE_NA;
     const size_t W = sizeof(Rec<NW>);
     auto bail = [&](int rc) {  // leave nothing behind
+        if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] partition-major route gives up (code %d: %s); %.1f GB obtainable\n", rc, rc == SMX_ROUTE_NA ? "does not apply" : ctx->err.c_str(),
+                                         (double)arena_avail(ctx) / 1e9);
         ctx->ext_mode = false;
         ctx->pm.active = false;
         ctx->pm.nx = false;

@@ -243,6 +243,15 @@ class KMerDiskCounter:
         return KMerDiskStorage(ctx, self.splitter.K(), int(num_buckets), self.workdir)
 
     def CountAll(self, num_buckets: int, num_threads: int = 1, merge: bool = True) -> KMerDiskStorage:
+        """Count + merge (kmer_index_builder.hpp:306-332). With a workdir the destination is known before the count starts (smx_count_to_file): a
+        count that goes out of core streams its merged bucket ranges into <workdir>/final_kmers as the reference's merge does instead of holding
+        the merged result in host memory; the records of such a result are in the file, not in the storage object."""
+        if merge and self.workdir is not None:
+            ctx = self.splitter.ctx
+            mode = _lib.MODE_ALL if self.splitter.mode == "A" else _lib.MODE_CANONICAL
+            path = os.path.join(self.workdir, "final_kmers")
+            _chk(ctx._h, ctx.lib.smx_count_to_file(ctx._h, self.splitter.K(), mode, int(num_buckets), path.encode()))
+            return KMerDiskStorage(ctx, self.splitter.K(), int(num_buckets), self.workdir)
         st = self.Count(num_buckets, num_threads)
         if merge:
             st.merge()

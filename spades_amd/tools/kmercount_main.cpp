@@ -120,22 +120,18 @@ int main(int argc, char **argv) {
             if (rcs[i]) throw std::string(smx_last_error(ctx));
         }
         STAGE("read input")
-        if (int rc = smx_count(ctx, K, SMX_MODE_ALL, 16)) {  // 16 buckets: kmercount.cpp:220
+        // Count + merge with the destination known from the start (16 buckets: kmercount.cpp:220): a count that goes out of core streams its merged
+        // bucket ranges into final_kmers as the reference's merge does (kmer_index_builder.hpp:346-430) — host memory never holds the merged result
+        std::string out = workdir + "/final_kmers";
+        if (int rc = smx_count_to_file(ctx, K, SMX_MODE_ALL, 16, out.c_str())) {
             fprintf(stderr, "%s\n", smx_last_error(ctx));
             smx_destroy(ctx);
             return rc;
         }
-        STAGE("count")
+        STAGE("count+write")
         uint64_t n = 0;
         smx_count_info(ctx, &n, nullptr, nullptr);
         printf("K-mer counting done. There are %llu kmers in total.\n", (unsigned long long)n);
-        std::string out = workdir + "/final_kmers";
-        if (int rc = smx_write_final_kmers(ctx, out.c_str())) {
-            fprintf(stderr, "%s\n", smx_last_error(ctx));
-            smx_destroy(ctx);
-            return rc;
-        }
-        STAGE("write output")
         printf("K-mer counting done, kmers saved to \"%s\"\n", out.c_str());
     } catch (const std::string &s) {
         fprintf(stderr, "%s\n", s.c_str());

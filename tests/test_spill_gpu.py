@@ -35,6 +35,40 @@ def test_forced_spill_small(K, mode, nb):
         ctx.close()
 
 
+@pytest.mark.parametrize("K,mode,nb,opts", [(21, "A", 16, {"spill": 1, "batch_records": 3000}), (55, "A", 16, {"spill": 1, "batch_records": 3000, "spill_merge_max": 700}),
+                                            (56, "B", 30, {"spill": 1, "batch_records": 2500}), (55, "A", 16, {})])
+def test_count_to_file_streams_an_out_of_core_result(K, mode, nb, opts, tmp_path):
+    """smx_count_to_file (round 6; VERDICT r5 missing 4): the destination is known before the count, and a count that goes out of core streams its merged
+    bucket ranges to their place in the file — the reference's merge writes as it goes, kmer_index_builder.hpp:346-430 — instead of keeping the merged
+    result in host memory next to the runs; a bucket cut by key range (spill_merge_max) arrives part by part. Same bytes as the resident count's file;
+    the figures of the count are there afterwards, the records are in the file (their accessors say so)."""
+    from spades_amd.kmercount import SmxError
+    reads = [r for r in read_lines("reads_small.txt") if r]
+    ref_ctx = Context()
+    sp0 = ReadKMerSplitter(K, mode, ref_ctx)
+    sp0.push_back_reads(reads)
+    ref = KMerDiskCounter(None, sp0).Count(nb)
+    want, want_sizes = ref.records().tobytes(), ref.bucket_sizes().tolist()
+    ref_ctx.close()
+    ctx = Context()
+    for key, v in opts.items():
+        ctx.set_option(key, v)
+    sp = ReadKMerSplitter(K, mode, ctx)
+    sp.push_back_reads(reads)
+    wd = tmp_path / "wd"
+    wd.mkdir()
+    st = KMerDiskCounter(str(wd), sp).CountAll(nb)
+    assert open(wd / "final_kmers", "rb").read() == want
+    assert st.bucket_sizes().tolist() == want_sizes and st.total_kmers() * ((K + 31) // 32) * 8 == len(want)
+    if opts:  # streamed: the storage object has the figures, not the records
+        with pytest.raises(SmxError):
+            st.bucket(0)
+        st.merge()  # (the file it would write is the one that holds them: nothing to do)
+    else:
+        assert st.records().tobytes() == want
+    ctx.close()
+
+
 def test_result_larger_than_the_hbm_budget(tmp_path):
     """2 M PE150 reads, k=55, spades-kmercount mode: 2.7 GB of k-mers with a 2 GiB budget"""
     codes = synth.synth_codes(77, 10_000_000, 2_000_000)
