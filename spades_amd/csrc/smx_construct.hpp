@@ -934,9 +934,40 @@ int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err
         HIPCHK(hipMemsetAsync(tstats, 0, 16, ctx->stream));
         if (int rc = resucc(&succ)) return rc;
         tbegin(ctx, "early_tips");
-        hipLaunchKernelGGL((k_tip_mark<NW, IX>), dim3(grid), dim3(BLK), 0, ctx->stream, ix, (const uint8_t *)ctx->g_mask, succ, D0, k,
-                           (uint32_t)std::min<int64_t>(ctx->opt_early_tip_bound, 0x7FFFFFFF), isolate, tipped, tstats, d_err);
-        HIPCHK(hipGetLastError());
+        {   // the branches of the junction k-mers, listed densely (k_cand_tiles / k_cand_expand on the masks as they are now): one lane per branch
+            const uint64_t ntiles = (D0 + CAND_TILE - 1) / CAND_TILE;
+            unsigned long long *tcnt, *toff, *nj, *bcand;
+            uint32_t *blen;
+            node_t *bfirst;
+            if (int rc = dalloc(ctx, &tcnt, ntiles)) return rc;
+            if (int rc = dalloc(ctx, &toff, ntiles + 1)) return rc;
+            if (int rc = dalloc(ctx, &nj, CAND_NJ)) return rc;
+            HIPCHK(hipMemsetAsync(nj, 0, CAND_NJ * 8, ctx->stream));
+            hipLaunchKernelGGL(k_cand_tiles, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, D0, tcnt, nj, (unsigned long long *)nullptr);
+            HIPCHK(hipGetLastError());
+            if (int rc = scan_u64(ctx, tcnt, toff, ntiles)) return rc;
+            unsigned long long Cb = 0;
+            HIPCHK(hipMemcpyAsync(&Cb, toff + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (Cb) {
+                if (int rc = dalloc(ctx, &bcand, Cb)) return rc;
+                if (int rc = dalloc(ctx, &blen, Cb)) return rc;
+                if (int rc = dalloc(ctx, &bfirst, Cb)) return rc;
+                hipLaunchKernelGGL(k_cand_expand, dim3((unsigned)ntiles), dim3(BLK), 0, ctx->stream, (const uint8_t *)ctx->g_mask, (const unsigned long long *)toff, D0, bcand);
+                HIPCHK(hipGetLastError());
+                hipLaunchKernelGGL((k_tip_branch<NW, IX>), dim3(grid_for(Cb)), dim3(BLK), 0, ctx->stream, ix, (const uint8_t *)ctx->g_mask, succ, (const unsigned long long *)bcand,
+                                   (uint64_t)Cb, k, (uint32_t)std::min<int64_t>(ctx->opt_early_tip_bound, 0x7FFFFFFF), blen, bfirst, d_err);
+                HIPCHK(hipGetLastError());
+                hipLaunchKernelGGL((k_tip_decide<IX>), dim3(grid_for(Cb)), dim3(BLK), 0, ctx->stream, ix, succ, (const unsigned long long *)bcand, (uint64_t)Cb,
+                                   (const uint32_t *)blen, (const node_t *)bfirst, isolate, tipped, tstats);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                for (void *p : {(void *)bcand, (void *)blen, (void *)bfirst}) {
+                    detach_temp(ctx, p);
+                    arena_put(ctx, p);
+                }
+            }
+        }
         hipLaunchKernelGGL(k_tip_apply, dim3(grid), dim3(BLK), 0, ctx->stream, ctx->g_mask, (const uint8_t *)isolate, D0);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL((k_tip_fix<NW, IX>), dim3(grid), dim3(BLK), 0, ctx->stream, ix, (uint32_t *)ctx->g_mask, (const uint8_t *)tipped, D0, k, d_err);
@@ -963,7 +994,7 @@ int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err
 template <int NW>
 int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint32_t *d_err, WallTrace &gwt, bool present = false, const PmWalk *pm = nullptr,
                      const std::function<int()> *tab_ready = nullptr /* pm: the node table is still being filled on the side stream; called before the first use of it */,
-                     const std::function<int()> *retab = nullptr /* pm with early clippers: makes the node table again from the masks as they are now */) {
+                     const std::function<int(bool)> *retab = nullptr /* pm with early clippers: makes the node table again from the masks as they are now (true: for the last time) */) {
     bool masks_edited = false;
     const uint64_t D0 = ctx->g_nkmers;
     const unsigned grid = grid_for(2 * D0);
@@ -985,14 +1016,13 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             PmFind<NW> ixp{pm->ix, pm->jmp};
             const std::function<int(const node_t **)> resucc = [&](const node_t **s) -> int {
                 if (masks_edited)
-                    if (int rc = (*retab)()) return rc;
+                    if (int rc = (*retab)(false)) return rc;
                 masks_edited = false;
                 *s = tab;
                 return 0;
             };
             if (int rc = early_clippers<NW>(ctx, k, ixp, D0, d_err, resucc, &masks_edited)) return rc;
-            if (masks_edited)
-                if (int rc = (*retab)()) return rc;
+            if (int rc = (*retab)(true)) return rc;  // (the last time: what only this needs — local links, unclipped masks — goes before the walks ask for their arrays)
             masks_edited = false;
         } else {
             node_t *succ = nullptr;  // successor table of the early clippers (their own format, by lookup)

@@ -30,19 +30,22 @@ __device__ __forceinline__ unsigned long long dw_wave_count(unsigned long long *
 template <int NW, bool CAND, int PASS>
 __global__ void __launch_bounds__(BLK) k_dw_requests(const void *kmers_, const uint8_t *__restrict__ mask, const unsigned long long *__restrict__ cand,
                                                      uint64_t item0, uint64_t n_items, unsigned k, uint32_t B, uint32_t world,
-                                                     unsigned long long *hist_or_cursor, void *out_, unsigned long long *tags) {
-    extern __shared__ unsigned long long lds_dw[];  // [world] counts, then [world] bases
-    unsigned long long *lcnt = lds_dw, *lbase = lds_dw + world;
+                                                     unsigned long long *bc_or_off, void *out_, unsigned long long *tags) {
+    // Grouping by owner without one global atomic per workgroup round (21 M atomics on ONE address per pass of a 5.4 G-node shard: 240 ms each at the
+    // ~88 atomics / us one address takes — what the first measurement of these kernels at size spent its time on): PASS 0 counts in LDS over ALL the
+    // rounds of the workgroup and leaves bc[owner * gridDim + block]; the caller scans that array (owner-major: the scan IS the place of every
+    // (owner, block) in the send order); PASS 1 — same grid, same rounds — starts its LDS cursors there. No barrier inside the loop.
+    extern __shared__ unsigned long long lds_dw[];  // [world] counters (PASS 0) / cursors (PASS 1)
     const Rec<NW> *kmers = (const Rec<NW> *)kmers_;
     Rec<NW> *out = (Rec<NW> *)out_;
+    for (uint32_t t = threadIdx.x; t < world; t += BLK) lds_dw[t] = PASS == 0 ? 0ull : bc_or_off[(size_t)t * gridDim.x + blockIdx.x];
+    __syncthreads();
     for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n_items; base += (uint64_t)gridDim.x * BLK) {
-        for (uint32_t t = threadIdx.x; t < world; t += BLK) lcnt[t] = 0;
-        __syncthreads();
         const uint64_t i = item0 + base + threadIdx.x;  // (the items [item0, item0 + n_items): a caller may ask range by range)
         bool asks = false;
         Rec<NW> y;
         uint32_t ow = 0;
-        unsigned long long at = 0, tag = 0;
+        unsigned long long tag = 0;
         if (base + threadIdx.x < n_items) {
             node_t node;
             unsigned c = 0;
@@ -67,17 +70,15 @@ __global__ void __launch_bounds__(BLK) k_dw_requests(const void *kmers_, const u
                 tag = ((unsigned long long)i << DW_TAG_SHIFT) | (CAND ? 8u : 0u) | (yo << 2) | c;
             }
         }
-        at = dw_wave_count(lcnt, asks, ow);  // (one LDS atomic per wave and owner)
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < world; t += BLK)
-            if (lcnt[t]) lbase[t] = atomicAdd(&hist_or_cursor[t], lcnt[t]);
-        __syncthreads();
+        const unsigned long long at = dw_wave_count(lds_dw, asks, ow);  // (one LDS atomic per wave and owner)
         if (PASS == 1 && asks) {
-            out[lbase[ow] + at] = y;
-            tags[lbase[ow] + at] = tag;
+            out[at] = y;
+            tags[at] = tag;
         }
-        __syncthreads();
     }
+    __syncthreads();
+    if (PASS == 0)
+        for (uint32_t t = threadIdx.x; t < world; t += BLK) bc_or_off[(size_t)t * gridDim.x + blockIdx.x] = lds_dw[t];
 }
 
 // owner side: canonical k-mer -> local rank << 1 | (its mask makes it a junction k-mer); all ones = not in this shard
@@ -211,24 +212,19 @@ __device__ __forceinline__ unsigned long long dw_wave_count(unsigned long long *
     }
     return at;
 }
-// One workgroup round of the two-pass grouping by owner: every thread brings up to NM messages; PASS 0 adds the workgroup's counts per owner
-// to hist, PASS 1 takes the workgroup's place from the cursors (initialised with the exclusive scan of hist) and returns every message's
-// slot in the send order. lds: [world] counts + [world] bases. Contains barriers: call from all threads.
-template <int NM>
-__device__ __forceinline__ void dw_group(unsigned long long *lcnt, unsigned long long *lbase, uint32_t world, const bool (&has)[NM], const uint32_t (&ow)[NM],
-                                         unsigned long long *hist_or_cursor, unsigned long long (&slot)[NM]) {
-    for (uint32_t t = threadIdx.x; t < world; t += BLK) lcnt[t] = 0;
+// The grouping kernels below share k_dw_requests' scheme: PASS 0 leaves bc[owner * gridDim + block] (counts over all rounds of the workgroup), the
+// caller scans it, PASS 1 starts its LDS cursors at off[owner * gridDim + block] — one LDS atomic per wave and owner, no global atomic, no barrier in
+// the loop. dw_pass_begin / dw_pass_end are the two ends of that.
+template <int PASS>
+__device__ __forceinline__ void dw_pass_begin(unsigned long long *lctr, uint32_t world, const unsigned long long *bc_or_off) {
+    for (uint32_t t = threadIdx.x; t < world; t += BLK) lctr[t] = PASS == 0 ? 0ull : bc_or_off[(size_t)t * gridDim.x + blockIdx.x];
     __syncthreads();
-    unsigned long long at[NM];
-#pragma unroll
-    for (int j = 0; j < NM; ++j) at[j] = dw_wave_count(lcnt, has[j], ow[j]);
+}
+template <int PASS>
+__device__ __forceinline__ void dw_pass_end(const unsigned long long *lctr, uint32_t world, unsigned long long *bc_or_off) {
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < world; t += BLK)
-        if (lcnt[t]) lbase[t] = atomicAdd(&hist_or_cursor[t], lcnt[t]);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NM; ++j) slot[j] = has[j] ? lbase[ow[j]] + at[j] : 0ull;
-    __syncthreads();
+    if (PASS == 0)
+        for (uint32_t t = threadIdx.x; t < world; t += BLK) bc_or_off[(size_t)t * gridDim.x + blockIdx.x] = lctr[t];
 }
 
 // answers of the owners to the successor requests (k_dw_requests -> all-to-all -> k_dw_lookup -> all-to-all back), in send order:
@@ -265,27 +261,29 @@ __global__ void __launch_bounds__(BLK) k_dw_count_open(const unsigned long long 
 // doubling: the open nodes of [a, a + n) ask the owners of their pointers for those nodes' words; q[slot] = pointer, tag[slot] = asking node
 template <int PASS>
 __global__ void __launch_bounds__(BLK) k_dw_open_req(const unsigned long long *__restrict__ word, const uint8_t *__restrict__ flag, uint64_t a, uint64_t n, DwBits b,
-                                                     DwOwners ow, unsigned long long *hist_or_cursor, unsigned long long *q, unsigned long long *tag) {
+                                                     DwOwners ow, unsigned long long *bc_or_off, unsigned long long *q, unsigned long long *tag) {
     extern __shared__ unsigned long long lds_dw[];
+    dw_pass_begin<PASS>(lds_dw, ow.world, bc_or_off);
     for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n; base += (uint64_t)gridDim.x * BLK) {
         const uint64_t i = a + base + threadIdx.x;
-        bool has[1] = {false};
-        uint32_t o[1] = {0};
-        unsigned long long tg = 0, slot[1];
+        bool has = false;
+        uint32_t o = 0;
+        unsigned long long tg = 0;
         if (base + threadIdx.x < n) {
             const unsigned long long w = word[i];
             if (dw_open(w, flag[i])) {
-                has[0] = true;
+                has = true;
                 tg = (w >> b.hb) & b.idm;
-                o[0] = dw_owner_of(ow, tg);
+                o = dw_owner_of(ow, tg);
             }
         }
-        dw_group<1>(lds_dw, lds_dw + ow.world, ow.world, has, o, hist_or_cursor, slot);
-        if (PASS == 1 && has[0]) {
-            q[slot[0]] = tg;
-            tag[slot[0]] = i;
+        const unsigned long long at = dw_wave_count(lds_dw, has, o);
+        if (PASS == 1 && has) {
+            q[at] = tg;
+            tag[at] = i;
         }
     }
+    dw_pass_end<PASS>(lds_dw, ow.world, bc_or_off);
 }
 // owner side: the words of the nodes that were asked for (global ids -> local)
 __global__ void __launch_bounds__(BLK) k_dw_gather_words(const unsigned long long *__restrict__ q, uint64_t n, unsigned long long my_base, uint64_t n2,
@@ -378,13 +376,14 @@ __global__ void __launch_bounds__(BLK) k_dw_head_len(const unsigned long long *_
 // (head, -(end node) - 1)
 template <int PASS>
 __global__ void __launch_bounds__(BLK) k_dw_head_msgs(const unsigned long long *__restrict__ word, const uint8_t *__restrict__ flag, uint64_t a, uint64_t n,
-                                                      unsigned long long my_base, DwBits b, DwOwners ow, unsigned long long *hist_or_cursor, ulonglong2 *msg) {
+                                                      unsigned long long my_base, DwBits b, DwOwners ow, unsigned long long *bc_or_off, ulonglong2 *msg) {
     extern __shared__ unsigned long long lds_dw[];
+    dw_pass_begin<PASS>(lds_dw, ow.world, bc_or_off);
     for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n; base += (uint64_t)gridDim.x * BLK) {
         const uint64_t xs = a + base + threadIdx.x;
-        bool has[2] = {false, false};
-        uint32_t o[2] = {0, 0};
-        unsigned long long head = 0, pay0 = 0, pay1 = 0, slot[2];
+        bool has0 = false, has1 = false;
+        uint32_t o = 0;
+        unsigned long long head = 0, pay0 = 0, pay1 = 0;
         if (base + threadIdx.x < n) {
             const unsigned long long ws = word[xs];
             const uint8_t f = flag[xs];
@@ -393,20 +392,21 @@ __global__ void __launch_bounds__(BLK) k_dw_head_msgs(const unsigned long long *
                 head = ((wr & DW_T) ? (xr + my_base) : ((wr >> b.hb) & b.idm)) ^ 1ull;
                 const unsigned long long back = (wr & DW_T) ? 0ull : (wr & b.hm);
                 pay0 = (back << 2) | ((unsigned long long)(f >> 2) & 3ull);
-                has[0] = true;
-                o[0] = o[1] = dw_owner_of(ow, head);
+                has0 = true;
+                o = dw_owner_of(ow, head);
                 if (ws & DW_T) {
-                    has[1] = true;
+                    has1 = true;
                     pay1 = ~((ws >> b.hb) & b.idm);  // = -(end) - 1
                 }
             }
         }
-        dw_group<2>(lds_dw, lds_dw + ow.world, ow.world, has, o, hist_or_cursor, slot);
+        const unsigned long long at0 = dw_wave_count(lds_dw, has0, o), at1 = dw_wave_count(lds_dw, has1, o);
         if (PASS == 1) {
-            if (has[0]) msg[slot[0]] = make_ulonglong2(head, pay0);
-            if (has[1]) msg[slot[1]] = make_ulonglong2(head, pay1);
+            if (has0) msg[at0] = make_ulonglong2(head, pay0);
+            if (has1) msg[at1] = make_ulonglong2(head, pay1);
         }
     }
+    dw_pass_end<PASS>(lds_dw, ow.world, bc_or_off);
 }
 // owner of the heads: every message to its place. stats[0] += nucleotides placed, [1] += messages for a node that heads no chain or beyond its chain
 __global__ void __launch_bounds__(BLK) k_dw_place(const ulonglong2 *__restrict__ msg, uint64_t n, unsigned long long my_base, uint64_t n2,
@@ -450,24 +450,26 @@ __global__ void __launch_bounds__(BLK) k_dw_count_unset(const unsigned long long
 // the start de-edges of [a, a + n) whose first node is a chain k-mer ask the owner of that node — the head of a chain — for the chain
 template <int PASS>
 __global__ void __launch_bounds__(BLK) k_dw_start_asks(const unsigned long long *__restrict__ c_first, const uint8_t *__restrict__ c_fj, uint64_t a, uint64_t n,
-                                                       DwOwners ow, unsigned long long *hist_or_cursor, unsigned long long *q, unsigned long long *tag) {
+                                                       DwOwners ow, unsigned long long *bc_or_off, unsigned long long *q, unsigned long long *tag) {
     extern __shared__ unsigned long long lds_dw[];
+    dw_pass_begin<PASS>(lds_dw, ow.world, bc_or_off);
     for (uint64_t base = (uint64_t)blockIdx.x * BLK; base < n; base += (uint64_t)gridDim.x * BLK) {
         const uint64_t i = a + base + threadIdx.x;
-        bool has[1] = {false};
-        uint32_t o[1] = {0};
-        unsigned long long tg = 0, slot[1];
+        bool has = false;
+        uint32_t o = 0;
+        unsigned long long tg = 0;
         if (base + threadIdx.x < n && !c_fj[i]) {
-            has[0] = true;
+            has = true;
             tg = c_first[i];
-            o[0] = dw_owner_of(ow, tg);
+            o = dw_owner_of(ow, tg);
         }
-        dw_group<1>(lds_dw, lds_dw + ow.world, ow.world, has, o, hist_or_cursor, slot);
-        if (PASS == 1 && has[0]) {
-            q[slot[0]] = tg;
-            tag[slot[0]] = i;
+        const unsigned long long at = dw_wave_count(lds_dw, has, o);
+        if (PASS == 1 && has) {
+            q[at] = tg;
+            tag[at] = i;
         }
     }
+    dw_pass_end<PASS>(lds_dw, ow.world, bc_or_off);
 }
 // owner of the heads: (length, end node) of the chain behind every asked node, its slot and its length once more for the scan of the bases
 __global__ void __launch_bounds__(BLK) k_dw_answer(const unsigned long long *__restrict__ asks, uint64_t n, unsigned long long my_base, uint64_t n2,

@@ -46,6 +46,25 @@ int dw_prepare(smx_ctx *ctx) {
     return 0;
 }
 
+// Host side of the two-pass grouping of smx_dwalk.hip: launch(0, bc) counts per (owner, workgroup), the scan of bc (owner-major) is the place of every
+// (owner, workgroup) in the send order, launch(1, off) places. counts[p] = what goes to rank p. `grid` must be the grid of both launches.
+template <class Launch>
+int dw_two_pass(smx_ctx *ctx, unsigned world, unsigned grid, Launch &&launch, uint64_t *counts, unsigned long long **d_off) {
+    unsigned long long *bc, *off;
+    const size_t n = (size_t)world * grid;
+    if (int rc = dalloc(ctx, &bc, n)) return rc;
+    if (int rc = dalloc(ctx, &off, n + 1)) return rc;
+    launch(0, bc);
+    HIPCHK(hipGetLastError());
+    if (int rc = scan_u64(ctx, bc, off, n)) return rc;
+    std::vector<unsigned long long> h(world + 1);
+    for (unsigned p = 0; p <= world; ++p) HIPCHK(hipMemcpyAsync(&h[p], off + (size_t)p * grid, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (unsigned p = 0; p < world; ++p) counts[p] = h[p + 1] - h[p];
+    *d_off = off;
+    return 0;
+}
+
 // requests of the chain k-mers (cand = false) or of the start de-edges (cand = true), grouped by owner rank
 template <int NW>
 int dw_requests(smx_ctx *ctx, bool cand, unsigned world, void *d_recs, unsigned long long *d_tags, uint64_t *counts, uint64_t item0 = 0,
@@ -59,35 +78,25 @@ int dw_requests(smx_ctx *ctx, bool cand, unsigned world, void *d_recs, unsigned 
     const uint64_t expect = cand ? ctx->dw_ncand : ctx->dw_nchain;
     if (expect == 0 || n_items == 0) return 0;
     if (!d_recs || !d_tags) return fail(ctx, SMX_INVALID_PARAMETER, "null request buffers");
-    unsigned long long *hist, *off, *cur;
-    if (int rc = dalloc(ctx, &hist, world)) return rc;
-    if (int rc = dalloc(ctx, &off, world + 1)) return rc;
-    if (int rc = dalloc(ctx, &cur, world)) return rc;
-    HIPCHK(hipMemsetAsync(hist, 0, (size_t)world * 8, ctx->stream));
-    const size_t lds = (size_t)world * 16;
+    const size_t lds = (size_t)world * 8;
     const unsigned grid = grid_for(n_items, 4096);
     const unsigned k = ctx->g_k, B = ctx->g_B;
-    if (cand)
-        hipLaunchKernelGGL((k_dw_requests<NW, true, 0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const unsigned long long *)ctx->dw_cand, item0, n_items, k, B, world, hist, (void *)nullptr, (unsigned long long *)nullptr);
-    else
-        hipLaunchKernelGGL((k_dw_requests<NW, false, 0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const unsigned long long *)nullptr, item0, n_items, k, B, world, hist, (void *)nullptr, (unsigned long long *)nullptr);
+    auto launch = [&](int pass, unsigned long long *bc_or_off) {
+        void *o = pass ? d_recs : nullptr;
+        unsigned long long *t = pass ? d_tags : nullptr;
+        const unsigned long long *cd = cand ? (const unsigned long long *)ctx->dw_cand : (const unsigned long long *)nullptr;
+        if (cand && pass == 0) hipLaunchKernelGGL((k_dw_requests<NW, true, 0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, cd, item0, n_items, k, B, world, bc_or_off, o, t);
+        else if (cand) hipLaunchKernelGGL((k_dw_requests<NW, true, 1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, cd, item0, n_items, k, B, world, bc_or_off, o, t);
+        else if (pass == 0) hipLaunchKernelGGL((k_dw_requests<NW, false, 0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, cd, item0, n_items, k, B, world, bc_or_off, o, t);
+        else hipLaunchKernelGGL((k_dw_requests<NW, false, 1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask, cd, item0, n_items, k, B, world, bc_or_off, o, t);
+    };
+    unsigned long long *d_off = nullptr;
+    if (int rc = dw_two_pass(ctx, world, grid, launch, counts, &d_off)) return rc;
+    launch(1, d_off);
     HIPCHK(hipGetLastError());
-    if (int rc = scan_u64(ctx, hist, off, world)) return rc;
-    HIPCHK(hipMemcpyAsync(cur, off, (size_t)world * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    if (cand)
-        hipLaunchKernelGGL((k_dw_requests<NW, true, 1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const unsigned long long *)ctx->dw_cand, item0, n_items, k, B, world, cur, d_recs, d_tags);
-    else
-        hipLaunchKernelGGL((k_dw_requests<NW, false, 1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const void *)ctx->g_kmers, (const uint8_t *)ctx->g_mask,
-                           (const unsigned long long *)nullptr, item0, n_items, k, B, world, cur, d_recs, d_tags);
-    HIPCHK(hipGetLastError());
-    std::vector<unsigned long long> h(world);
-    HIPCHK(hipMemcpyAsync(h.data(), hist, (size_t)world * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     uint64_t tot = 0;
-    for (unsigned i = 0; i < world; ++i) tot += (counts[i] = h[i]);
+    for (unsigned i = 0; i < world; ++i) tot += counts[i];
     if (whole && tot != expect) return fail(ctx, SMX_DEVICE_ERROR, "%llu requests placed, %llu expected", (unsigned long long)tot, (unsigned long long)expect);
     return 0;
 }
@@ -269,7 +278,7 @@ int dw_walks(smx_ctx *ctx, const uint64_t *kmers_per_rank, const smx_collectives
     uint64_t rounds3[4] = {(n2 + CH - 1) / CH, (n_cand + CH - 1) / CH, (n_cand + SCH - 1) / SCH, n2};
     if (int rc = allred(rounds3, 4, 1)) return rc;
     const uint64_t node_rounds = rounds3[0], cand_rounds = rounds3[1], start_rounds = rounds3[2], max_n2 = rounds3[3];
-    const size_t lds = (size_t)world * 16;
+    const size_t lds = (size_t)world * 8;
 
     DwKeep keep{ctx, {}};
     unsigned long long *word = nullptr, *c_first = nullptr;
@@ -303,18 +312,6 @@ int dw_walks(smx_ctx *ctx, const uint64_t *kmers_per_rank, const smx_collectives
             sg.add[p] = add_first ? first[p] : 0;
         }
         return sg;
-    };
-    // group-by-owner in two passes of one kernel: hist -> scan -> cursors; returns the counts per owner
-    auto scan_hist = [&](unsigned long long *hist, unsigned long long *cur, std::vector<uint64_t> &counts) -> int {
-        unsigned long long *off;
-        if (int rc = dalloc(ctx, &off, world + 1)) return rc;
-        if (int rc = scan_u64(ctx, hist, off, world)) return rc;
-        HIPCHK(hipMemcpyAsync(cur, off, (size_t)world * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        std::vector<unsigned long long> h(world);
-        HIPCHK(hipMemcpyAsync(h.data(), hist, (size_t)world * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        counts.assign(h.begin(), h.end());
-        return 0;
     };
     auto sum = [](const std::vector<uint64_t> &v) {
         uint64_t t = 0;
@@ -396,22 +393,20 @@ int dw_walks(smx_ctx *ctx, const uint64_t *kmers_per_rank, const smx_collectives
         const uint64_t rounds_r = std::max<uint64_t>((max_n2 + CHr - 1) / CHr, 1);
         for (uint64_t c = 0; c < rounds_r; ++c) {
             const uint64_t a = std::min(c * CHr, n2), n_it = std::min(CHr, n2 - a);
-            unsigned long long *hist = nullptr, *cur = nullptr, *q = nullptr, *tag = nullptr, *qin = nullptr, *rows = nullptr, *wp = nullptr;
+            unsigned long long *d_off = nullptr, *q = nullptr, *tag = nullptr, *qin = nullptr, *rows = nullptr, *wp = nullptr;
             std::vector<uint64_t> counts(world, 0), rcounts;
-            DW_LOCAL(dalloc(ctx, &hist, world));
-            DW_LOCAL(dalloc(ctx, &cur, world));
-            DW_HIP(hipMemsetAsync(hist, 0, (size_t)world * 8, ctx->stream));
             const unsigned grid = grid_for(std::max<uint64_t>(n_it, 1), 4096);
-            if (!bad && n_it) hipLaunchKernelGGL((k_dw_open_req<0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)word, (const uint8_t *)flag, a, n_it, B, OW,
-                                                 hist, (unsigned long long *)nullptr, (unsigned long long *)nullptr);
-            DW_HIP(hipGetLastError());
-            DW_LOCAL(scan_hist(hist, cur, counts));
+            auto launch = [&](int pass, unsigned long long *bc_or_off) {
+                if (pass == 0) hipLaunchKernelGGL((k_dw_open_req<0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)word, (const uint8_t *)flag, a, n_it, B, OW,
+                                                  bc_or_off, (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+                else hipLaunchKernelGGL((k_dw_open_req<1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)word, (const uint8_t *)flag, a, n_it, B, OW, bc_or_off, q, tag);
+            };
+            DW_LOCAL(dw_two_pass(ctx, world, grid, launch, counts.data(), &d_off));
             const uint64_t n_send = bad ? 0 : sum(counts);
             DW_LOCAL(dalloc(ctx, &q, std::max<uint64_t>(n_send, 1)));
             DW_LOCAL(dalloc(ctx, &tag, std::max<uint64_t>(n_send, 1)));
             DW_LOCAL(dalloc(ctx, &wp, std::max<uint64_t>(n_send, 1)));
-            if (!bad && n_it) hipLaunchKernelGGL((k_dw_open_req<1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)word, (const uint8_t *)flag, a, n_it, B, OW,
-                                                 cur, q, tag);
+            if (!bad) launch(1, d_off);
             DW_HIP(hipGetLastError());
             if (int rc = xcounts(counts, rcounts)) return rc;
             const uint64_t n_recv = sum(rcounts);
@@ -509,21 +504,19 @@ int dw_walks(smx_ctx *ctx, const uint64_t *kmers_per_rank, const smx_collectives
     DW_HIP(hipMemsetAsync(d_stats, 0, 64, ctx->stream));
     for (uint64_t c = 0; c < node_rounds; ++c) {
         const uint64_t a = std::min(c * CH, n2), n_it = std::min(CH, n2 - a);
-        unsigned long long *hist = nullptr, *cur = nullptr;
+        unsigned long long *d_off = nullptr;
         ulonglong2 *msg = nullptr, *got = nullptr;
         std::vector<uint64_t> counts(world, 0), rcounts;
-        DW_LOCAL(dalloc(ctx, &hist, world));
-        DW_LOCAL(dalloc(ctx, &cur, world));
-        DW_HIP(hipMemsetAsync(hist, 0, (size_t)world * 8, ctx->stream));
         const unsigned grid = grid_for(std::max<uint64_t>(n_it, 1), 4096);
-        if (!bad && n_it) hipLaunchKernelGGL((k_dw_head_msgs<0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)word, (const uint8_t *)flag, a, n_it, my_base, B,
-                                             OW, hist, (ulonglong2 *)nullptr);
-        DW_HIP(hipGetLastError());
-        DW_LOCAL(scan_hist(hist, cur, counts));
+        auto launch = [&](int pass, unsigned long long *bc_or_off) {
+            if (pass == 0) hipLaunchKernelGGL((k_dw_head_msgs<0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)word, (const uint8_t *)flag, a, n_it, my_base, B, OW,
+                                              bc_or_off, (ulonglong2 *)nullptr);
+            else hipLaunchKernelGGL((k_dw_head_msgs<1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)word, (const uint8_t *)flag, a, n_it, my_base, B, OW, bc_or_off, msg);
+        };
+        DW_LOCAL(dw_two_pass(ctx, world, grid, launch, counts.data(), &d_off));
         const uint64_t n_send = bad ? 0 : sum(counts);
         DW_LOCAL(dalloc(ctx, &msg, std::max<uint64_t>(n_send, 1)));
-        if (!bad && n_it) hipLaunchKernelGGL((k_dw_head_msgs<1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)word, (const uint8_t *)flag, a, n_it, my_base, B,
-                                             OW, cur, msg);
+        if (!bad) launch(1, d_off);
         DW_HIP(hipGetLastError());
         if (int rc = xcounts(counts, rcounts)) return rc;
         const uint64_t n_recv = sum(rcounts);
@@ -575,21 +568,19 @@ int dw_walks(smx_ctx *ctx, const uint64_t *kmers_per_rank, const smx_collectives
         }
         for (uint64_t c = 0; c < start_rounds; ++c) {
             const uint64_t a = std::min(c * SCH, n_cand), n_it = std::min(SCH, n_cand - a);
-            unsigned long long *hist = nullptr, *cur = nullptr, *q = nullptr, *tag = nullptr, *asks = nullptr;
+            unsigned long long *d_off = nullptr, *q = nullptr, *tag = nullptr, *asks = nullptr;
             std::vector<uint64_t> counts(world, 0), rcounts;
-            DW_LOCAL(dalloc(ctx, &hist, world));
-            DW_LOCAL(dalloc(ctx, &cur, world));
-            DW_HIP(hipMemsetAsync(hist, 0, (size_t)world * 8, ctx->stream));
             const unsigned grid = grid_for(std::max<uint64_t>(n_it, 1), 4096);
-            if (!bad && n_it) hipLaunchKernelGGL((k_dw_start_asks<0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)c_first, (const uint8_t *)c_fj, a, n_it, OW, hist,
-                                                 (unsigned long long *)nullptr, (unsigned long long *)nullptr);
-            DW_HIP(hipGetLastError());
-            DW_LOCAL(scan_hist(hist, cur, counts));
+            auto launch = [&](int pass, unsigned long long *bc_or_off) {
+                if (pass == 0) hipLaunchKernelGGL((k_dw_start_asks<0>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)c_first, (const uint8_t *)c_fj, a, n_it, OW, bc_or_off,
+                                                  (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+                else hipLaunchKernelGGL((k_dw_start_asks<1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)c_first, (const uint8_t *)c_fj, a, n_it, OW, bc_or_off, q, tag);
+            };
+            DW_LOCAL(dw_two_pass(ctx, world, grid, launch, counts.data(), &d_off));
             const uint64_t n_send = bad ? 0 : sum(counts);
             DW_LOCAL(dalloc(ctx, &q, std::max<uint64_t>(n_send, 1)));
             DW_LOCAL(dalloc(ctx, &tag, std::max<uint64_t>(n_send, 1)));
-            if (!bad && n_it) hipLaunchKernelGGL((k_dw_start_asks<1>), dim3(grid), dim3(BLK), lds, ctx->stream, (const unsigned long long *)c_first, (const uint8_t *)c_fj, a, n_it, OW, cur,
-                                                 q, tag);
+            if (!bad) launch(1, d_off);
             DW_HIP(hipGetLastError());
             if (int rc = xcounts(counts, rcounts)) return rc;
             const uint64_t n_recv = sum(rcounts);

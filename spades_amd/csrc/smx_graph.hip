@@ -608,63 +608,74 @@ __global__ void __launch_bounds__(BLK) k_succ(IX ix, const uint8_t *mask, uint64
 // predecessors all the way back to ONE junction orientation, so no other junction ever walks them, and roots keep their phantom
 // extension bits until the clean-up pass (checked against the reference run with 1-4 threads: tests/golden/etc_*). Hence three
 // data-parallel passes: mark (reads the original masks), apply (IsolateVertex), fix (RemoveInconsistentForwardLinks, :21-36).
+// Round 6: one lane per BRANCH, not per oriented k-mer. 4 % of the k-mers branch, so a kernel over all nodes has two or three working lanes per wave,
+// each with a chain of ~25-95 dependent reads in front of it: latency times (nodes / 64) wave rounds — 1.75 s of a 2.9 s step at BASELINE config 3,
+// measured (profiles/r06/bench_config3_sorted_route_early_tip_clipper.json). The branches are listed densely first (cand: the start de-edges of the
+// junction k-mers as k_cand_expand lists them, (k-mer << 3 | orientation << 2 | nucleotide), the branches of one oriented k-mer side by side);
+// k_tip_branch measures every branch of an orientation with >= 2 of them (0: none there), k_tip_decide compares a branch with its <= 3 siblings
+// and isolates the tips that are shorter than the longest one.
+constexpr uint32_t TIP_INF = 0xFFFFFFFFu;
 template <int NW, class IX>
-__global__ void __launch_bounds__(BLK) k_tip_mark(IX ix, const uint8_t *mask, const node_t *succ, uint64_t D0, unsigned k,
-                                                  uint32_t bound, uint8_t *isolate, uint8_t *tipped, unsigned long long *stats,
-                                                  uint32_t *err) {
-    for (uint64_t node = (uint64_t)blockIdx.x * BLK + threadIdx.x; node < 2 * D0; node += (uint64_t)gridDim.x * BLK) {
-        const uint64_t r = node >> 1;
-        const unsigned o = (unsigned)(node & 1);
+__global__ void __launch_bounds__(BLK) k_tip_branch(IX ix, const uint8_t *mask, const node_t *succ, const unsigned long long *__restrict__ cand, uint64_t C, unsigned k,
+                                                    uint32_t bound, uint32_t *blen, node_t *bfirst, uint32_t *err) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
+        const unsigned long long cd = cand[i];
+        const uint64_t r = cd >> 3;
+        const unsigned o = (unsigned)(cd >> 2) & 1u, c = (unsigned)(cd & 3);
         const unsigned m = mask[r];
         const unsigned mo = o ? brev8(m) : m;
-        if (__popc(mo & 15) < 2) continue;
-        Rec<NW> x = ix.kmer(r);
-        if (o) x = rec_rc<NW>(x, k);
-        node_t first[4];
-        uint32_t len[4];
-        uint32_t mx = 0;
-#pragma unroll
-        for (unsigned c = 0; c < 4; ++c) {
-            first[c] = NODE_NONE;
-            len[c] = 0;  // 0 = no branch
-            if (!(mo & (1u << c))) continue;
+        uint32_t len = 0;  // 0 = no branch to judge
+        node_t first = NODE_NONE;
+        if (__popc(mo & 15) >= 2) {
+            Rec<NW> x = ix.kmer(r);
+            if (o) x = rec_rc<NW>(x, k);
             unsigned yo;
             const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
             const node_t ry = ix.find(y);
             if (ry == NODE_NONE) {
                 atomicAdd(err, 1u);
-                continue;
+            } else {
+                node_t nd = (ry << 1) | yo;
+                uint32_t cnt = 0;
+                first = nd;
+                nd = ix.advance(succ, mask, nd, cnt, bound);
+                if (nd == NODE_NONE) {
+                    len = TIP_INF;
+                } else {
+                    ++cnt;
+                    const unsigned ml = (nd & 1) ? brev8(mask[nd >> 1]) : mask[nd >> 1];
+                    const bool tip = uniq4((ml >> 4) & 15) && (ml & 15) == 0;
+                    len = tip ? cnt : TIP_INF;  // branching or too long: never removed, longer than any tip
+                }
             }
-            node_t nd = (ry << 1) | yo;
-            uint32_t cnt = 0;
-            first[c] = nd;
-            nd = ix.advance(succ, mask, nd, cnt, bound);
-            if (nd == NODE_NONE) {
-                len[c] = 0xFFFFFFFFu;
-                mx = 0xFFFFFFFFu;
-                continue;
-            }
-            ++cnt;
-            const unsigned ml = (nd & 1) ? brev8(mask[nd >> 1]) : mask[nd >> 1];
-            const bool tip = uniq4((ml >> 4) & 15) && (ml & 15) == 0;
-            len[c] = tip ? cnt : 0xFFFFFFFFu;  // branching or too long: never removed, longer than any tip
-            mx = max(mx, len[c]);
         }
-        bool any = false;
-#pragma unroll
-        for (unsigned c = 0; c < 4; ++c) {
-            if (len[c] == 0 || len[c] == 0xFFFFFFFFu || len[c] >= mx) continue;
-            node_t nd = first[c];
-            for (uint32_t i = 0; i + 1 < len[c]; ++i) {
-                isolate[nd >> 1] = 1;
-                nd = ix.next(succ, nd);
-            }
+        blen[i] = len;
+        bfirst[i] = first;
+    }
+}
+template <class IX>
+__global__ void __launch_bounds__(BLK) k_tip_decide(IX ix, const node_t *succ, const unsigned long long *__restrict__ cand, uint64_t C, const uint32_t *__restrict__ blen,
+                                                    const node_t *__restrict__ bfirst, uint8_t *isolate, uint8_t *tipped, unsigned long long *stats) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
+        const uint32_t len = blen[i];
+        if (len == 0 || len == TIP_INF) continue;
+        const unsigned long long key = cand[i] >> 2;  // the oriented k-mer the branch leaves
+        uint32_t mx = len;
+        for (int d = -3; d <= 3; ++d) {
+            const int64_t j = (int64_t)i + d;
+            if (d == 0 || j < 0 || j >= (int64_t)C) continue;
+            if ((cand[j] >> 2) == key) mx = max(mx, blen[j]);
+        }
+        if (len >= mx) continue;
+        node_t nd = bfirst[i];
+        for (uint32_t t = 0; t + 1 < len; ++t) {
             isolate[nd >> 1] = 1;
-            any = true;
-            atomicAdd(&stats[0], (unsigned long long)len[c]);
-            atomicAdd(&stats[1], 1ull);
+            nd = ix.next(succ, nd);
         }
-        if (any) tipped[node] = 1;
+        isolate[nd >> 1] = 1;
+        tipped[key] = 1;
+        atomicAdd(&stats[0], (unsigned long long)len);
+        atomicAdd(&stats[1], 1ull);
     }
 }
 __global__ void k_tip_apply(uint8_t *mask, const uint8_t *isolate, uint64_t D0) {

@@ -76,7 +76,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     if (nx && ctx->opt_nx_route == 0) return SMX_ROUTE_NA;
     const size_t W = sizeof(Rec<NW>);
     auto bail = [&](int rc) {  // leave nothing behind
-        if (getenv("SMX_DEBUG")) fprintf(stderr, "[smx] partition-major route gives up (code %d: %s); %.1f GB obtainable\n", rc, rc == SMX_ROUTE_NA ? "does not apply" : ctx->err.c_str(),
+        if (getenv("SMX_DEBUG") || getenv("SMX_DEBUG_BAIL")) fprintf(stderr, "[smx] partition-major route gives up (code %d: %s); %.1f GB obtainable\n", rc, rc == SMX_ROUTE_NA ? "does not apply" : ctx->err.c_str(),
                                          (double)arena_avail(ctx) / 1e9);
         ctx->ext_mode = false;
         ctx->pm.active = false;
@@ -303,7 +303,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         if (hipMemcpyAsync(mask_orig, ctx->g_mask, (size_t)D0 + 16, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
             return bail(fail(ctx, SMX_DEVICE_ERROR, "copy of the masks failed"));
     }
-    const std::function<int()> retab = [&]() -> int {
+    const std::function<int(bool)> retab = [&](bool last) -> int {
         if (hipMemsetAsync(rbits, 0, (size_t)std::max<uint32_t>(P.nchunks, 1) * wpc * 4, ctx->stream) != hipSuccess || hipMemsetAsync(stats2, 0, 16, ctx->stream) != hipSuccess)
             return fail(ctx, SMX_DEVICE_ERROR, "counter reset failed");
         tbegin(ctx, "pm_tab");
@@ -320,6 +320,17 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
                                (const unsigned long long *)P.cinfo, P.nchunks, wpc, (const uint32_t *)rbits, k, tab, d_err);
         tend(ctx);
         if (hipGetLastError() != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "k_pm_tab launch failed");
+        if (last) {  // 5 B per k-mer of local links and unclipped masks + the remote bits: back to the arena before the walks' arrays are asked for
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "node table pass failed: %s", hipGetErrorString(hipGetLastError()));
+            arena_put(ctx, P.llink);
+            P.llink = nullptr;
+            for (void *p : {(void *)mask_orig, (void *)rbits}) {
+                detach_temp(ctx, p);
+                arena_put(ctx, p);
+            }
+            mask_orig = nullptr;
+            rbits = nullptr;
+        }
         return 0;
     };
     rc = graph_from_masks<NW>(ctx, k, tab, /*tab_valid=*/true, d_err, gwt, /*present=*/true, &pw, &tab_ready, clip ? &retab : nullptr);

@@ -251,7 +251,9 @@ class KMerDiskCounter:
             mode = _lib.MODE_ALL if self.splitter.mode == "A" else _lib.MODE_CANONICAL
             path = os.path.join(self.workdir, "final_kmers")
             _chk(ctx._h, ctx.lib.smx_count_to_file(ctx._h, self.splitter.K(), mode, int(num_buckets), path.encode()))
-            return KMerDiskStorage(ctx, self.splitter.K(), int(num_buckets), self.workdir)
+            st = KMerDiskStorage(ctx, self.splitter.K(), int(num_buckets), self.workdir)
+            st._final = path
+            return st
         st = self.Count(num_buckets, num_threads)
         if merge:
             st.merge()
