@@ -618,7 +618,7 @@ def main():
     # FETCH x2 gfx950 correction). A table is a constant of ITS measurement: it is quoted only for the workload it was taken on and only
     # while the library sources are the ones it was taken on (first line of the CSV: their sha256) — otherwise traffic stays null.
     pmc_name = "config3_pm_pmc_hbm_traffic.csv" if pm_route else ("config3_sorted_pmc_hbm_traffic.csv" if ext_route else "config3_kpomer_pmc_hbm_traffic.csv")
-    pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, pmc_name) for r_ in ("r05", "r04", "r03")) if os.path.exists(p_)), os.path.join(ROOT, "profiles", "r05", pmc_name))
+    pmc = next((p_ for p_ in (os.path.join(ROOT, "profiles", r_, pmc_name) for r_ in ("r06", "r05", "r04", "r03")) if os.path.exists(p_)), os.path.join(ROOT, "profiles", "r06", pmc_name))
     pmc_rows, pmc_split, pmc_note = {}, None, None
     pmc_same = "these very sources: sha256 checked"
     if not sharded and not args.count_only and n_reads == 100_000_000 and k == 55 and T == 16 and os.path.exists(pmc):

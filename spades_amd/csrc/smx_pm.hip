@@ -385,6 +385,40 @@ __global__ void __launch_bounds__(BLK) k_pm_tab_dirty(PmIndex ix, uint64_t nd, u
         if (pals) atomicAdd(&stats[1], pals);
     }
 }
+// The node table after an early clipper has edited some masks — incrementally (round 6). A clipper only ever touches k-mers that END chains: the junction k-mer a
+// tip or an A/T edge hangs on, the dead end or junction at its other side, and the k-mers of removed tips (isolated: mask 0, no walk reaches them any more). Every jump
+// word therefore still describes a chain of unchanged non-junction k-mers, and only the entries of the EDITED k-mers are made again: the extension bits from the new
+// mask; the successor kept where the orientation had one extension before (it still has that one, or none), looked up through the partition table where it had several
+// and has one now. mask_was: the masks as of the last time the table was right; brought up to date here. (The full pass — k_pm_tab with the local links + k_pm_remote
+// over all chunks, 80 ms at config 3 — is what this replaces; option pm_full_retab = 1 still takes it.)
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_pm_retab_changed(PmIndex ix, uint8_t *mask_was, uint64_t D0, unsigned k, node_t *tab, uint32_t *err) {
+    const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
+    for (uint64_t r = (uint64_t)blockIdx.x * BLK + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * BLK) {
+        const unsigned mn = ix.mask[r], mw = mask_was[r];
+        if (mn == mw) continue;
+        mask_was[r] = (uint8_t)mn;
+        const Rec<NW> x = rec_pure_xs<NW>(recs[r], ix.xs);
+#pragma unroll
+        for (unsigned o = 0; o < 2; ++o) {
+            const unsigned on = (o ? brev8(mn) : mn) & 15u, ow = (o ? brev8(mw) : mw) & 15u;
+            node_t e = (node_t)on << TAB_OUT_SHIFT;
+            if (uniq4(on)) {
+                if (uniq4(ow)) {
+                    e |= tab[2 * r + o] & TAB_NODE_MASK;
+                } else {
+                    unsigned yo;
+                    const Rec<NW> y = pm_succ_kmer<NW>(x, k, o, on, yo);
+                    const node_t ry = r < ix.nclean ? pm_find<NW>(ix, y) : pm_find_from_tail<NW>(ix, y);
+                    if (ry == NODE_NONE) atomicAdd(err, 1u);
+                    else e |= (ry << 1) | yo;
+                }
+            }
+            tab[2 * r + o] = e;
+        }
+    }
+}
+
 // dirty region: k-mers without their bytes (what the rank directory indexes) + the bytes into the mask array
 template <int NW>
 __global__ void k_pm_dirty_split(const void *recs_, uint64_t nclean, uint64_t nd, void *dk_, uint8_t *mask) {

@@ -76,8 +76,16 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     if (nx && ctx->opt_nx_route == 0) return SMX_ROUTE_NA;
     const size_t W = sizeof(Rec<NW>);
     auto bail = [&](int rc) {  // leave nothing behind
-        if (getenv("SMX_DEBUG") || getenv("SMX_DEBUG_BAIL")) fprintf(stderr, "[smx] partition-major route gives up (code %d: %s); %.1f GB obtainable\n", rc, rc == SMX_ROUTE_NA ? "does not apply" : ctx->err.c_str(),
-                                         (double)arena_avail(ctx) / 1e9);
+        if (getenv("SMX_DEBUG") || getenv("SMX_DEBUG_BAIL")) {
+            fprintf(stderr, "[smx] partition-major route gives up (code %d: %s); %.1f GB obtainable; last stage begun: %s; live blocks of 1 GB and more:", rc,
+                    rc == SMX_ROUTE_NA ? "does not apply" : ctx->err.c_str(), (double)arena_avail(ctx) / 1e9, ctx->timings.empty() ? "-" : ctx->timings.back().name.c_str());
+            std::vector<size_t> big;
+            for (auto &b : ctx->arena.live)
+                if (b.second >= ((size_t)1 << 30)) big.push_back(b.second);
+            std::sort(big.rbegin(), big.rend());
+            for (size_t v : big) fprintf(stderr, " %.1f", (double)v / 1e9);
+            fprintf(stderr, "\n");
+        }
         ctx->ext_mode = false;
         ctx->pm.active = false;
         ctx->pm.nx = false;
@@ -267,7 +275,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
             hipMemcpyAsync(&hpal, P.pals, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
             return fail(ctx, SMX_DEVICE_ERROR, "node table pass failed: %s", hipGetErrorString(hipGetLastError()));
         hs[1] += hpal;  // palindromic (k+1)-mers: the clean winners' by the dedupe stage, the dirty region's by k_pm_tab_dirty
-        if (!clip) {  // (only k_pm_tab reads the local links — once, unless an early clipper makes it run again)
+        if (!clip || !ctx->opt_pm_full_retab) {  // (only k_pm_tab reads the local links — once, unless an early clipper makes the WHOLE table again: option pm_full_retab)
             arena_put(ctx, P.llink);
             P.llink = nullptr;
         }
@@ -304,6 +312,22 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
             return bail(fail(ctx, SMX_DEVICE_ERROR, "copy of the masks failed"));
     }
     const std::function<int(bool)> retab = [&](bool last) -> int {
+        if (!ctx->opt_pm_full_retab) {  // the entries of the edited k-mers only (k_pm_retab_changed)
+            tbegin(ctx, "pm_retab");
+            hipLaunchKernelGGL((k_pm_retab_changed<NW>), dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, pw.ix, mask_orig, (uint64_t)D0, k, tab, d_err);
+            tend(ctx);
+            if (hipGetLastError() != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "k_pm_retab_changed launch failed");
+            if (last) {
+                if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "node table pass failed: %s", hipGetErrorString(hipGetLastError()));
+                for (void *p : {(void *)mask_orig, (void *)rbits}) {
+                    detach_temp(ctx, p);
+                    arena_put(ctx, p);
+                }
+                mask_orig = nullptr;
+                rbits = nullptr;
+            }
+            return 0;
+        }
         if (hipMemsetAsync(rbits, 0, (size_t)std::max<uint32_t>(P.nchunks, 1) * wpc * 4, ctx->stream) != hipSuccess || hipMemsetAsync(stats2, 0, 16, ctx->stream) != hipSuccess)
             return fail(ctx, SMX_DEVICE_ERROR, "counter reset failed");
         tbegin(ctx, "pm_tab");
