@@ -1101,7 +1101,12 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             // The reference visits the junction k-mers in k-mer-file order (AddStartDeEdges, debruijn_graph_constructor.hpp:203-226): they
             // alone — n_junction of D0 k-mers — go through the sort pipeline (EXT records: the byte gives every k-mer its number of start
             // de-edges), and the de-edges of a k-mer are numbered from the prefix sum at its place in that file.
-            const uint64_t nj = n_junction;
+            // (the junction k-mers that have start de-edges: after an early tip clipper most k-mers of a 30x data set with 1 % errors are ISOLATED — junction
+            // k-mers by the mask rule, 2.6 G of 4.3 G at config 3 — and sorting those for nothing was 41 + 21 GB and most of the stage's time)
+            unsigned long long nj_ = 0;
+            HIPCHK(hipMemcpyAsync(&nj_, tjoff + ntiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            const uint64_t nj = nj_;
             if (int rc = dalloc(ctx, &qidx, C)) return rc;
             if (int rc = dalloc(ctx, &vq, C)) return rc;
             Rec<NW> *jrecs, *jk;

@@ -891,19 +891,21 @@ __global__ void __launch_bounds__(BLK) k_cand_tiles(const uint8_t *mask, uint64_
                                                     unsigned long long *tjcnt /* nullable: junction k-mers of every tile */) {
     __shared__ uint32_t scratch[BLK / 64 + 2];
     const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
-    uint32_t c = 0, j_ = 0;
+    uint32_t c = 0, j_ = 0, jz = 0;
     for (int j = 0; j < CAND_PER; ++j)
         if (r0 + j < D0) {
             const unsigned m = mask[r0 + j];
             c += cand_of_mask(m);
             j_ += mask_junction(m) ? 1u : 0u;
+            jz += m ? 0u : 1u;  // isolated k-mers (an early clipper removed their tip): junction k-mers by the mask rule, without a single de-edge
         }
-    uint32_t tot, jt;
+    uint32_t tot, jt, zt;
     block_excl_scan<uint32_t>(c, scratch, &tot);
     block_excl_scan<uint32_t>(j_, scratch, &jt);
+    block_excl_scan<uint32_t>(jz, scratch, &zt);
     if (threadIdx.x == 0) {
         tcnt[blockIdx.x] = tot;
-        if (tjcnt) tjcnt[blockIdx.x] = jt;
+        if (tjcnt) tjcnt[blockIdx.x] = jt - zt;  // (route 0 numbers the de-edges through the junction k-mers that HAVE some: smx_pm.hip, k_pm_junc_write)
         if (jt) atomicAdd(&njunction[blockIdx.x & (CAND_NJ - 1)], (unsigned long long)jt);  // spread: one address takes ~88 atomics/us
     }
 }

@@ -398,7 +398,10 @@ __global__ void __launch_bounds__(BLK) k_pm_retab_changed(PmIndex ix, uint8_t *m
         const unsigned mn = ix.mask[r], mw = mask_was[r];
         if (mn == mw) continue;
         mask_was[r] = (uint8_t)mn;
-        const Rec<NW> x = rec_pure_xs<NW>(recs[r], ix.xs);
+        if (mn == 0) {  // isolated (most edited k-mers are: the k-mers of removed tips): two empty entries, nothing to read
+            *reinterpret_cast<ulonglong2 *>(tab + 2 * r) = make_ulonglong2(0ull, 0ull);
+            continue;
+        }
 #pragma unroll
         for (unsigned o = 0; o < 2; ++o) {
             const unsigned on = (o ? brev8(mn) : mn) & 15u, ow = (o ? brev8(mw) : mw) & 15u;
@@ -408,6 +411,7 @@ __global__ void __launch_bounds__(BLK) k_pm_retab_changed(PmIndex ix, uint8_t *m
                     e |= tab[2 * r + o] & TAB_NODE_MASK;
                 } else {
                     unsigned yo;
+                    const Rec<NW> x = rec_pure_xs<NW>(recs[r], ix.xs);  // (only where a successor has to be looked up)
                     const Rec<NW> y = pm_succ_kmer<NW>(x, k, o, on, yo);
                     const node_t ry = r < ix.nclean ? pm_find<NW>(ix, y) : pm_find_from_tail<NW>(ix, y);
                     if (ry == NODE_NONE) atomicAdd(err, 1u);
@@ -465,7 +469,7 @@ __global__ void __launch_bounds__(BLK) k_pm_junc_write(const uint8_t *mask, cons
     const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
     uint32_t c = 0, fl = 0;
     for (int j = 0; j < CAND_PER; ++j)
-        if (r0 + j < D0 && mask_junction(mask[r0 + j])) {
+        if (r0 + j < D0 && mask[r0 + j] && mask_junction(mask[r0 + j])) {  // (a k-mer with mask 0 — isolated by an early clipper — starts nothing: not listed, as k_cand_tiles counts)
             fl |= 1u << j;
             ++c;
         }
