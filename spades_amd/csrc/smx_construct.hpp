@@ -924,13 +924,11 @@ int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err
     }
     // ---- 3b. early tip clipper (spades-core variant, off for spades-gbuilder) ---------------------
     if (ctx->opt_early_tip_bound > 0) {
-        uint8_t *isolate, *tipped;
+        uint8_t *isolate;
         unsigned long long *tstats;
         if (int rc = dalloc(ctx, &isolate, D0 + 1)) return rc;
-        if (int rc = dalloc(ctx, &tipped, 2 * D0 + 1)) return rc;
         if (int rc = dalloc(ctx, &tstats, 2)) return rc;
         HIPCHK(hipMemsetAsync(isolate, 0, D0 + 1, ctx->stream));
-        HIPCHK(hipMemsetAsync(tipped, 0, 2 * D0 + 1, ctx->stream));
         HIPCHK(hipMemsetAsync(tstats, 0, 16, ctx->stream));
         if (int rc = resucc(&succ)) return rc;
         tbegin(ctx, "early_tips");
@@ -959,7 +957,7 @@ int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err
                                    (uint64_t)Cb, k, (uint32_t)std::min<int64_t>(ctx->opt_early_tip_bound, 0x7FFFFFFF), blen, bfirst, d_err);
                 HIPCHK(hipGetLastError());
                 hipLaunchKernelGGL((k_tip_decide<IX>), dim3(grid_for(Cb)), dim3(BLK), 0, ctx->stream, ix, succ, (const unsigned long long *)bcand, (uint64_t)Cb,
-                                   (const uint32_t *)blen, (const node_t *)bfirst, isolate, tipped, tstats);
+                                   (const uint32_t *)blen, (const node_t *)bfirst, isolate, (uint32_t *)ctx->g_mask, tstats);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipStreamSynchronize(ctx->stream));
                 for (void *p : {(void *)bcand, (void *)blen, (void *)bfirst}) {
@@ -970,8 +968,6 @@ int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err
         }
         hipLaunchKernelGGL(k_tip_apply, dim3(grid), dim3(BLK), 0, ctx->stream, ctx->g_mask, (const uint8_t *)isolate, D0);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL((k_tip_fix<NW, IX>), dim3(grid), dim3(BLK), 0, ctx->stream, ix, (uint32_t *)ctx->g_mask, (const uint8_t *)tipped, D0, k, d_err);
-        HIPCHK(hipGetLastError());
         *edited = true;
         tend(ctx);
         unsigned long long hs[2] = {0, 0};
@@ -979,10 +975,8 @@ int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err
         HIPCHK(hipStreamSynchronize(ctx->stream));
         ctx->g_tip_kmers = hs[0];
         ctx->g_tips = hs[1];
-        for (void *p : {(void *)isolate, (void *)tipped}) {
-            detach_temp(ctx, p);
-            arena_put(ctx, p);
-        }
+        detach_temp(ctx, isolate);
+        arena_put(ctx, isolate);
     }
     return 0;
 }

@@ -653,9 +653,12 @@ __global__ void __launch_bounds__(BLK) k_tip_branch(IX ix, const uint8_t *mask, 
         bfirst[i] = first;
     }
 }
+// (The removed branch's own extension bit goes here as well — RemoveInconsistentForwardLinks, :21-36, deletes exactly the forward links of a tipped k-mer whose
+// target lost its backward link, i.e. whose first k-mer was isolated: the removed branches, and no others — a tip's k-mers have ONE way in. A pass over all oriented
+// k-mers looking for the few tipped ones (k_tip_fix, still what the A/T remover uses) was the longest kernel of the clipper: two or three working lanes per wave.)
 template <class IX>
 __global__ void __launch_bounds__(BLK) k_tip_decide(IX ix, const node_t *succ, const unsigned long long *__restrict__ cand, uint64_t C, const uint32_t *__restrict__ blen,
-                                                    const node_t *__restrict__ bfirst, uint8_t *isolate, uint8_t *tipped, unsigned long long *stats) {
+                                                    const node_t *__restrict__ bfirst, uint8_t *isolate, uint32_t *mask32, unsigned long long *stats) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         const uint32_t len = blen[i];
         if (len == 0 || len == TIP_INF) continue;
@@ -673,7 +676,11 @@ __global__ void __launch_bounds__(BLK) k_tip_decide(IX ix, const node_t *succ, c
             nd = ix.next(succ, nd);
         }
         isolate[nd >> 1] = 1;
-        tipped[key] = 1;
+        {
+            const uint64_t r = key >> 1;
+            const unsigned o = (unsigned)(key & 1), c = (unsigned)(cand[i] & 3);
+            atomicAnd(&mask32[r >> 2], ~((1u << (o ? 7 - c : c)) << ((r & 3) * 8)));  // DeleteOutgoing(kh, c), inout_mask.hpp:133-139
+        }
         atomicAdd(&stats[0], (unsigned long long)len);
         atomicAdd(&stats[1], 1ull);
     }

@@ -391,9 +391,36 @@ __global__ void __launch_bounds__(BLK) k_pm_tab_dirty(PmIndex ix, uint64_t nd, u
 // mask; the successor kept where the orientation had one extension before (it still has that one, or none), looked up through the partition table where it had several
 // and has one now. mask_was: the masks as of the last time the table was right; brought up to date here. (The full pass — k_pm_tab with the local links + k_pm_remote
 // over all chunks, 80 ms at config 3 — is what this replaces; option pm_full_retab = 1 still takes it.)
+// (The few orientations that need a lookup — 4 % of the edited k-mers: the roots of removed tips — are listed for a dense second kernel, k_pm_retab_lookups: left in
+// this one they were two or three working lanes per wave, each with the route's four dependent reads in front of it. A full list falls back to the lookup in place.)
 template <int NW>
-__global__ void __launch_bounds__(BLK) k_pm_retab_changed(PmIndex ix, uint8_t *mask_was, uint64_t D0, unsigned k, node_t *tab, uint32_t *err) {
+__device__ __forceinline__ node_t pm_retab_lookup(const PmIndex &ix, uint64_t r, unsigned o, unsigned on, unsigned k, uint32_t *err) {
     const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
+    unsigned yo;
+    const Rec<NW> x = rec_pure_xs<NW>(recs[r], ix.xs);
+    const Rec<NW> y = pm_succ_kmer<NW>(x, k, o, on, yo);
+    const node_t ry = r < ix.nclean ? pm_find<NW>(ix, y) : pm_find_from_tail<NW>(ix, y);
+    if (ry == NODE_NONE) {
+        atomicAdd(err, 1u);
+        return 0;
+    }
+    return (ry << 1) | yo;
+}
+constexpr unsigned PM_RL_SUB = 256;  // sub-lists, each with a counter of its own (64 B apart): ONE address takes ~88 atomics per microsecond
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_pm_retab_lookups(PmIndex ix, const unsigned long long *__restrict__ list, const unsigned long long *__restrict__ nlist, uint64_t subcap,
+                                                          unsigned k, node_t *tab, uint32_t *err) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < (uint64_t)PM_RL_SUB * subcap; i += (uint64_t)gridDim.x * BLK) {
+        const uint64_t sub = i / subcap, j = i % subcap;
+        if (j >= nlist[sub * 8]) continue;
+        const node_t node = list[i];
+        const node_t e = tab[node];  // (the extension bits are in place; the successor is what is missing)
+        tab[node] = (e & ~TAB_NODE_MASK) | pm_retab_lookup<NW>(ix, node >> 1, (unsigned)(node & 1), tab_out4(e), k, err);
+    }
+}
+template <int NW>
+__global__ void __launch_bounds__(BLK) k_pm_retab_changed(PmIndex ix, uint8_t *mask_was, uint64_t D0, unsigned k, node_t *tab, uint32_t *err,
+                                                          unsigned long long *list, unsigned long long *nlist /* [PM_RL_SUB * 8]: entries asked for, per sub-list */, uint64_t subcap) {
     for (uint64_t r = (uint64_t)blockIdx.x * BLK + threadIdx.x; r < D0; r += (uint64_t)gridDim.x * BLK) {
         const unsigned mn = ix.mask[r], mw = mask_was[r];
         if (mn == mw) continue;
@@ -410,12 +437,10 @@ __global__ void __launch_bounds__(BLK) k_pm_retab_changed(PmIndex ix, uint8_t *m
                 if (uniq4(ow)) {
                     e |= tab[2 * r + o] & TAB_NODE_MASK;
                 } else {
-                    unsigned yo;
-                    const Rec<NW> x = rec_pure_xs<NW>(recs[r], ix.xs);  // (only where a successor has to be looked up)
-                    const Rec<NW> y = pm_succ_kmer<NW>(x, k, o, on, yo);
-                    const node_t ry = r < ix.nclean ? pm_find<NW>(ix, y) : pm_find_from_tail<NW>(ix, y);
-                    if (ry == NODE_NONE) atomicAdd(err, 1u);
-                    else e |= (ry << 1) | yo;
+                    const uint64_t sub = blockIdx.x & (PM_RL_SUB - 1);
+                    const unsigned long long at = atomicAdd(&nlist[sub * 8], 1ull);
+                    if (at < subcap) list[sub * subcap + at] = 2 * r + o;
+                    else e |= pm_retab_lookup<NW>(ix, r, o, on, k, err);  // (that sub-list is full: in place)
                 }
             }
             tab[2 * r + o] = e;

@@ -313,10 +313,22 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     }
     const std::function<int(bool)> retab = [&](bool last) -> int {
         if (!ctx->opt_pm_full_retab) {  // the entries of the edited k-mers only (k_pm_retab_changed)
+            const uint64_t subcap = std::min<uint64_t>(std::max<uint64_t>(D0 / 8 / PM_RL_SUB, 64), (uint64_t)1 << 20);
+            unsigned long long *rlist = nullptr, *rn = nullptr;
+            if (int rc2 = dalloc(ctx, &rlist, subcap * PM_RL_SUB)) return rc2;
+            if (int rc2 = dalloc(ctx, &rn, (size_t)PM_RL_SUB * 8)) return rc2;
+            if (hipMemsetAsync(rn, 0, (size_t)PM_RL_SUB * 64, ctx->stream) != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "counter reset failed");
             tbegin(ctx, "pm_retab");
-            hipLaunchKernelGGL((k_pm_retab_changed<NW>), dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, pw.ix, mask_orig, (uint64_t)D0, k, tab, d_err);
+            hipLaunchKernelGGL((k_pm_retab_changed<NW>), dim3(grid_for(D0)), dim3(BLK), 0, ctx->stream, pw.ix, mask_orig, (uint64_t)D0, k, tab, d_err, rlist, rn, subcap);
+            hipLaunchKernelGGL((k_pm_retab_lookups<NW>), dim3(grid_for(subcap * PM_RL_SUB)), dim3(BLK), 0, ctx->stream, pw.ix, (const unsigned long long *)rlist,
+                               (const unsigned long long *)rn, subcap, k, tab, d_err);
             tend(ctx);
             if (hipGetLastError() != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "k_pm_retab_changed launch failed");
+            (void)hipStreamSynchronize(ctx->stream);
+            for (void *p : {(void *)rlist, (void *)rn}) {
+                detach_temp(ctx, p);
+                arena_put(ctx, p);
+            }
             if (last) {
                 if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "node table pass failed: %s", hipGetErrorString(hipGetLastError()));
                 for (void *p : {(void *)mask_orig, (void *)rbits}) {
