@@ -856,7 +856,8 @@ int device_loops(smx_ctx *ctx, unsigned k, bool pm, const unsigned long long *ll
 // (IX: FileFind — sorted k-mer file + rank directory; PmFind — the partition-major records of route 0). resucc(&succ): the successor table of the
 // masks as they are NOW, in the format IX::next reads; *edited is set whenever a pass has changed the masks.
 template <int NW, class IX>
-int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err, const std::function<int(const node_t **)> &resucc, bool *edited) {
+int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err, const std::function<int(const node_t **)> &resucc, bool *edited,
+                   const std::function<int(const uint8_t *, uint8_t *)> *marked_chains = nullptr /* route 0: isolates the chains whose heads the tip clipper marked */) {
     const unsigned grid = grid_for(2 * D0);
     const node_t *succ = nullptr;
     // ---- 3a. early A/T remover (RNA pipelines: EarlyATClipper::run, stages/construction.cpp:317-326) --------------
@@ -924,11 +925,15 @@ int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err
     }
     // ---- 3b. early tip clipper (spades-core variant, off for spades-gbuilder) ---------------------
     if (ctx->opt_early_tip_bound > 0) {
-        uint8_t *isolate;
+        uint8_t *isolate, *hmark = nullptr;
         unsigned long long *tstats;
         if (int rc = dalloc(ctx, &isolate, D0 + 1)) return rc;
         if (int rc = dalloc(ctx, &tstats, 2)) return rc;
         HIPCHK(hipMemsetAsync(isolate, 0, D0 + 1, ctx->stream));
+        if (marked_chains) {
+            if (int rc = dalloc(ctx, &hmark, 2 * D0 + 16)) return rc;
+            HIPCHK(hipMemsetAsync(hmark, 0, 2 * D0 + 16, ctx->stream));
+        }
         HIPCHK(hipMemsetAsync(tstats, 0, 16, ctx->stream));
         if (int rc = resucc(&succ)) return rc;
         tbegin(ctx, "early_tips");
@@ -957,8 +962,10 @@ int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err
                                    (uint64_t)Cb, k, (uint32_t)std::min<int64_t>(ctx->opt_early_tip_bound, 0x7FFFFFFF), blen, bfirst, d_err);
                 HIPCHK(hipGetLastError());
                 hipLaunchKernelGGL((k_tip_decide<IX>), dim3(grid_for(Cb)), dim3(BLK), 0, ctx->stream, ix, succ, (const unsigned long long *)bcand, (uint64_t)Cb,
-                                   (const uint32_t *)blen, (const node_t *)bfirst, isolate, (uint32_t *)ctx->g_mask, tstats);
+                                   (const uint32_t *)blen, (const node_t *)bfirst, isolate, hmark, (uint32_t *)ctx->g_mask, tstats);
                 HIPCHK(hipGetLastError());
+                if (marked_chains)
+                    if (int rc = (*marked_chains)(hmark, isolate)) return rc;
                 HIPCHK(hipStreamSynchronize(ctx->stream));
                 for (void *p : {(void *)bcand, (void *)blen, (void *)bfirst}) {
                     detach_temp(ctx, p);
@@ -977,6 +984,10 @@ int early_clippers(smx_ctx *ctx, unsigned k, IX ix, uint64_t D0, uint32_t *d_err
         ctx->g_tips = hs[1];
         detach_temp(ctx, isolate);
         arena_put(ctx, isolate);
+        if (hmark) {
+            detach_temp(ctx, hmark);
+            arena_put(ctx, hmark);
+        }
     }
     return 0;
 }
@@ -1015,7 +1026,17 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
                 *s = tab;
                 return 0;
             };
-            if (int rc = early_clippers<NW>(ctx, k, ixp, D0, d_err, resucc, &masks_edited)) return rc;
+            const uint32_t maxn = pm->ix.T / 2;
+            const size_t ilds = (size_t)maxn * 12 + 16;
+            if (int rc = set_lds(ctx, k_pm_isolate_chains, ilds)) return rc;
+            const std::function<int(const uint8_t *, uint8_t *)> marked_chains = [&](const uint8_t *hmark, uint8_t *isolate) -> int {
+                if (pm->nchunks)
+                    hipLaunchKernelGGL(k_pm_isolate_chains, dim3(std::min<uint32_t>(pm->nchunks, 256 * 16)), dim3(BLK), ilds, ctx->stream, pm->cinfo, pm->nchunks, maxn,
+                                       (const node_t *)tab, pm->jmp, hmark, isolate);
+                HIPCHK(hipGetLastError());
+                return 0;
+            };
+            if (int rc = early_clippers<NW>(ctx, k, ixp, D0, d_err, resucc, &masks_edited, &marked_chains)) return rc;
             if (int rc = (*retab)(true)) return rc;  // (the last time: what only this needs — local links, unclipped masks — goes before the walks ask for their arrays)
             masks_edited = false;
         } else {

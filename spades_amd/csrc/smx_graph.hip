@@ -553,6 +553,14 @@ struct FileFind {
         }
         return nd;
     }
+    // IsolateVertex on the len k-mers of a removed tip, from its first node on
+    __device__ __forceinline__ void isolate_tip(const node_t *__restrict__ succ, node_t nd, uint32_t len, uint8_t *isolate, uint8_t *) const {
+        for (uint32_t t = 0; t + 1 < len; ++t) {
+            isolate[nd >> 1] = 1;
+            nd = succ_node(succ[nd]);
+        }
+        isolate[nd >> 1] = 1;
+    }
 };
 
 // the node table of clipped masks (spades-core variants): extensions from the masks, successors by lookup
@@ -658,7 +666,7 @@ __global__ void __launch_bounds__(BLK) k_tip_branch(IX ix, const uint8_t *mask, 
 // k-mers looking for the few tipped ones (k_tip_fix, still what the A/T remover uses) was the longest kernel of the clipper: two or three working lanes per wave.)
 template <class IX>
 __global__ void __launch_bounds__(BLK) k_tip_decide(IX ix, const node_t *succ, const unsigned long long *__restrict__ cand, uint64_t C, const uint32_t *__restrict__ blen,
-                                                    const node_t *__restrict__ bfirst, uint8_t *isolate, uint32_t *mask32, unsigned long long *stats) {
+                                                    const node_t *__restrict__ bfirst, uint8_t *isolate, uint8_t *hmark, uint32_t *mask32, unsigned long long *stats) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         const uint32_t len = blen[i];
         if (len == 0 || len == TIP_INF) continue;
@@ -670,12 +678,7 @@ __global__ void __launch_bounds__(BLK) k_tip_decide(IX ix, const node_t *succ, c
             if ((cand[j] >> 2) == key) mx = max(mx, blen[j]);
         }
         if (len >= mx) continue;
-        node_t nd = bfirst[i];
-        for (uint32_t t = 0; t + 1 < len; ++t) {
-            isolate[nd >> 1] = 1;
-            nd = ix.next(succ, nd);
-        }
-        isolate[nd >> 1] = 1;
+        ix.isolate_tip(succ, bfirst[i], len, isolate, hmark);
         {
             const uint64_t r = key >> 1;
             const unsigned o = (unsigned)(key & 1), c = (unsigned)(cand[i] & 3);

@@ -134,7 +134,65 @@ struct PmFind {
         }
         return nd;
     }
+    // The k-mers of a removed tip. A lane that steps through them one by one has a dependent read per k-mer in front of it (150 ms of the clipper at
+    // config 3, measured); here it crosses a chunk with the jump word and only MARKS the head of the chain (hmark[head]: "isolate the s + 1 k-mers of this
+    // chain"): a chain of non-junction k-mers lies inside the tip as a whole (a tip ends at a dead end, which ends its chain). k_pm_isolate_chains then follows
+    // the marked chains chunk by chunk, in LDS. K-mers outside chains (no jump word: the sorted tail, single k-mers) are isolated here.
+    __device__ __forceinline__ void isolate_tip(const node_t *__restrict__ tab, node_t nd, uint32_t len, uint8_t *isolate, uint8_t *hmark) const {
+        uint32_t left = len;
+        while (left) {
+            const uint32_t j = jmp[nd], s = j >> 16;
+            if (s && s + 1 <= left) {
+                hmark[nd] = 1;
+                left -= s + 1;
+                nd = (node_t)((long long)nd + (long long)(int16_t)(j & 0xFFFFu));  // the far end: isolated with its chain
+            } else {
+                isolate[nd >> 1] = 1;
+                --left;
+            }
+            if (left) nd = tab[nd] & TAB_NODE_MASK;
+        }
+    }
 };
+
+// the marked chains of a chunk (PmFind::isolate_tip): the chunk's node-table entries are loaded into LDS once, every marked head is followed for the steps its jump
+// word counts. One workgroup per chunk; chunks without a mark cost their 2 bytes per k-mer of marks.
+__global__ void __launch_bounds__(BLK) k_pm_isolate_chains(const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t maxn, const node_t *__restrict__ tab,
+                                                           const uint32_t *__restrict__ jmp, const uint8_t *__restrict__ hmark, uint8_t *isolate) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t pm_lds[];
+    uint32_t *ls = pm_lds;                     // [2 * maxn] local successor of every node (0xFFFFFFFF: leaves the chunk)
+    uint16_t *list = (uint16_t *)(ls + 2 * maxn);  // marked heads
+    __shared__ uint32_t s_n;
+    for (uint32_t cid = blockIdx.x; cid < nchunks; cid += gridDim.x) {
+        const unsigned long long ci = cinfo[cid];
+        const uint64_t base = ci & PM_BASE_MASK;
+        const uint32_t nn = 2 * (uint32_t)(ci >> PM_BASE_BITS);
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        if (nn > 2 * maxn) continue;
+        for (uint32_t nd = threadIdx.x; nd < nn; nd += BLK)
+            if (hmark[2 * base + nd]) list[atomicAdd(&s_n, 1u)] = (uint16_t)nd;
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (!n) continue;
+        for (uint32_t nd = threadIdx.x; nd < nn; nd += BLK) {
+            const node_t t = tab[2 * base + nd] & TAB_NODE_MASK;
+            ls[nd] = (t >= 2 * base && t < 2 * base + nn) ? (uint32_t)(t - 2 * base) : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += BLK) {
+            uint32_t cur = list[i];
+            const uint32_t s = jmp[2 * base + cur] >> 16;
+            isolate[base + (cur >> 1)] = 1;
+            for (uint32_t t = 0; t < s && cur != 0xFFFFFFFFu; ++t) {
+                cur = ls[cur];
+                if (cur != 0xFFFFFFFFu) isolate[base + (cur >> 1)] = 1;
+            }
+        }
+    }
+}
+
 // Jump words: jmp[node] = (delta to the last node of the chain that stays inside the node's chunk, 16 bits signed) | steps << 16.
 // A walk that enters a chunk reads ONE word to cross it (smx_pm_walk_len) instead of one node-table entry per k-mer.
 constexpr uint16_t PM_ADV_NONE = 0xFFFFu;
