@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, eighth GPU call: early tip clipper on route 0 after the junction list lost its isolated k-mers (100 M and 20 M reads), per-kernel times of that step.
 #   gpurun --timeout 1800 -- 'bash tools/gpu_calls_r06/r6_call8.sh'
-out=gpurun_out/r6j; mkdir -p $out; exec > $out/log.txt 2>&1
+out=gpurun_out/r6k; mkdir -p $out; exec > $out/log.txt 2>&1
 set -x
 timeout 600 python -m pytest tests/test_pm_route_gpu.py tests/test_graph_gpu.py tests/test_integration_gpu.py -m gpu -q -p no:cacheprovider > $out/gpu_tests.log 2>&1; tail -4 $out/gpu_tests.log
 B="--no-cpu-baseline --extra-kmercount 0 --end-to-end 0 --scaling-reference 0 --steps 5"
