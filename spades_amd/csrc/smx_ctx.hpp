@@ -459,6 +459,16 @@ void arena_prewarm_join(smx_ctx *ctx) {
 void arena_prewarm_start(smx_ctx *ctx, size_t bottom, size_t top) {
     arena_prewarm_join(ctx);
     if (ctx->budget || (bottom == 0 && top == 0)) return;
+    {   // never more than half of the device ahead of need: a hint must not take what another allocator of the process (RCCL's buffers, a framework) will ask for
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+        const size_t cap = total_b / 2;
+        if (bottom + top > cap) {
+            const double f = (double)cap / (double)(bottom + top);
+            bottom = (size_t)((double)bottom * f);
+            top = (size_t)((double)top * f);
+        }
+    }
     ctx->prewarm_thr = std::thread([ctx, bottom, top]() {
         if (hipSetDevice(ctx->device) != hipSuccess) return;
         size_t done_b = 0, done_t = 0;
