@@ -397,6 +397,7 @@ def main():
                     help="the N>1 step (extract / all-to-all / owner count on BASELINE config 4's per-GPU share: 125 M reads of the metagenome mix, seed 3) at "
                          "any world size: `--gpus 1 --scaling` is the one-rank point of the scaling curve")
     ap.add_argument("--iid", action="store_true", help="sharded path: the iid genome of config 3 instead of config 4's metagenome mix")
+    ap.add_argument("--no-file-on-demand", action="store_true", help="skip the `kmer_file_on_demand` extra (profiling runs: its sort would be counted with the step's kernels)")
     ap.add_argument("--early-tip-extra", type=int, default=95,
                     help="N=1 default route, extra: the same step with spades-core's early tip clipper at this length bound (read length - k; 0 disables)")
     ap.add_argument("--scaling-reference", type=float, default=125e6,
@@ -793,7 +794,7 @@ def main():
                                                                       "(smx_graph_fingerprint_portable: independent of the k-mer numbering, equal between routes)")
             except Exception as e:  # noqa: BLE001 — a check, never the measurement
                 out["construct"]["checks"]["graph_fingerprint"] = f"unavailable: {e}"
-        if info is not None and pm_route:
+        if info is not None and pm_route and not args.no_file_on_demand:
             # What SURVEY §8(d)'s end point "sorted-unique bucket arrays resident in HBM" costs behind route 0: the step ends with
             # the graph and the k-mers in minimizer-partition order; the reference's product of counting — the bucket-major sorted file — is made the
             # first time an accessor asks for it (pm_materialize_file). Timed here once, on the graph of the last timed step, by asking for the

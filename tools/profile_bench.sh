@@ -8,7 +8,7 @@ set -u
 tag=${1:-r02}; shift || true
 root=$(pwd); out=$root/gpurun_out/prof_$tag; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-common="--no-cpu-baseline --extra-kmercount 0 --end-to-end 0 --scaling-reference 0 --early-tip-extra 0 $*"
+common="--no-cpu-baseline --extra-kmercount 0 --end-to-end 0 --scaling-reference 0 --early-tip-extra 0 --no-file-on-demand $*"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python "$root/bench.py" --steps 2 --warmup 0 $common > "$out/kt.bench.json" 2> "$out/kt.err"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/$c" -- python "$root/bench.py" --steps 1 --warmup 0 $common > "$out/$c.bench.json" 2> "$out/$c.err"

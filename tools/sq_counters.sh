@@ -4,7 +4,7 @@ set -u
 pat=${1:-k_skm_dedupe2}; shift || true
 root=$(pwd); O=$root/gpurun_out/sqpmc; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $root/bench.py --no-cpu-baseline --end-to-end 0 --extra-kmercount 0 --steps 1 --warmup 0 --reads 20e6 --genome 100e6 --scaling-reference 0 --early-tip-extra 0 $*"
+B="python $root/bench.py --no-cpu-baseline --end-to-end 0 --extra-kmercount 0 --steps 1 --warmup 0 --reads 20e6 --genome 100e6 --scaling-reference 0 --early-tip-extra 0 --no-file-on-demand $*"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
