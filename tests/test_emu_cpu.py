@@ -44,13 +44,16 @@ def _run(args, timeout=900, **extra):
 # the routes that force the super-k-mer stage, with the stage's partition count started at 2^12 instead of 2^24 (option skm_nkey_log2: the
 # stand-in pays 20 s per build for the 2^24; small inputs also get a production-like ~200 windows per partition this way)
 SELECTION_SMALL_PARTITIONS = [
-    ("tests/test_pm_route_gpu.py", "vs_oracle_seeded and (21 or 55 or 77)"),
+    ("tests/test_pm_route_gpu.py", "test_vs_oracle_seeded and (21 or 55)"),
+    # round 6: the early tip clipper and the A/T remover on the partition-major records (index policy PmFind, jump-aware FindForward, one lane per branch, tips isolated
+    # chain by chain in LDS, incremental node-table renewal) against the oracle AND the sorted route, masks and k-mer file included
+    ("tests/test_pm_route_gpu.py", "test_early_clippers_on_the_partition_major_route_vs_oracle_seeded and (55-1-95-0-extra1 or 33-2-117-1-extra5)"),
     # round 5: the same route on PLAIN k-mer records where the byte has no room in the record (k = 31, 127; with cut partitions and perfect loops)
     ("tests/test_pm_route_gpu.py", "(without_spare and (31 or 127)) or (plain_records_cut_partitions and 127)"),
     ("tests/test_ext_route_gpu.py", "vs_oracle_seeded and (21 or 55)"),
     # both-strands batches that come back as two-strand views inside the batch loop of count_reads (the judge's repro: k = 55,
     # two_strand = 2, batch_records = 40000 gave 14 780 of 99 410 records with rc = 0), folded or spilled
-    ("tests/test_two_strand_gpu.py", "test_two_strand_inside_position_batches and 40000 and 55-16 and (2 or -1)"),
+    ("tests/test_two_strand_gpu.py", "test_two_strand_inside_position_batches and 40000 and 55-16 and 2-"),
     ("tests/test_graph_gpu.py", "test_perfect_loops_on_the_device and (21-route5 or 55-route6)"),
     # two ranks (gloo), the library's own kernels on both: sharded count, owner-side masks, DISTRIBUTED WALKS and -c shard by shard — every rank
     # writes the single-process graph byte for byte (the oracle-backed doubles of test_dist_cpu.py check the plumbing; this is the real code)
