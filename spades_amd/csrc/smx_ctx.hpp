@@ -55,6 +55,11 @@ struct PmState {
     uint32_t *meta = nullptr, *overflow = nullptr, *llink = nullptr;
     unsigned long long *pals = nullptr;
     uint8_t *mask = nullptr;
+    // the node table of the clean chunks written by the dedupe stage itself (PmOut::tab, smx_superkmer.hip): asked for by the route (fuse_tab), allocated by
+    // run_prededupe at the output's capacity, taken over by pm_route
+    bool fuse_tab = false;
+    unsigned long long *tab = nullptr, *tab_stats = nullptr;
+    uint32_t *jmp = nullptr, *rbits = nullptr;
     uint32_t max_chunks = 0, nchunks = 0, T = 0, nkey = 0;
     unsigned m = 0, w = 0, pshift = 0;
     uint64_t nclean = 0, ndirty = 0;
@@ -79,6 +84,7 @@ struct smx_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // uploads of asynchronous submissions
     hipStream_t side_stream = nullptr;  // construction, route 0: the successor table (k_pm_tab, k_pm_remote) runs here while the junction k-mers are sorted on `stream`
+    int64_t opt_pm_fuse_tab = 1;        // route 0: 1 = the dedupe stage writes the node table of its chunks from LDS (no link array, no k_pm_tab pass over the clean chunks); 0 = k_pm_tab afterwards
     int64_t opt_pm_full_retab = 0;      // route 0 with early clippers: 1 = the whole node table is made again after an edit (k_pm_tab + k_pm_remote), 0 = the edited k-mers' entries only
     int64_t opt_pm_overlap = 0;         // ... 1: measured (profiles/r06/bench_config3_successor_table_on_side_stream.json): side by side both get slower by what the
                                         // other takes (80 -> 92 ms, 48 -> 120 ms; step 470-479 ms either way) — both are bound by the fabric's random-sector rate

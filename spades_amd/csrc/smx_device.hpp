@@ -21,6 +21,26 @@ struct Rec {
     uint64_t w[NW];
 };
 
+// Cache-policy experiments (A/B builds: hipcc -DSMX_NT_MASK=<bits>): a load or store tagged with bit B is non-temporal ("nt": streamed past
+// the L2 / Infinity Cache replacement) in a build whose mask has that bit, plain otherwise. Bits: 0 k_skm_permute slot stores, 1 its staged loads,
+// 2 (was: k_pm_tab's table / jump stores — adopted: nt by default, 37.0 -> 33.2 ms), 3 the walks' streamed lists, 4 k_pm_remote's entry store, 5 k_pm_walk_write's path
+// words and edge record, 6 the dedupe stage's record / byte copy-out, 7 its slot loads, 8 the scan's staging stores. Measured (profiles/r06/nontemporal_ab_*.log):
+// nt on SCATTERED stores is a loss (k_skm_permute 35 -> 65 ms, k_pm_walk_write 44 -> 59 ms), on the walks' streamed lists and k_pm_remote's store nothing.
+#ifndef SMX_NT_MASK
+#define SMX_NT_MASK 0
+#endif
+typedef unsigned long long smx_ull2 __attribute__((ext_vector_type(2)));
+template <int BIT, typename T>
+__device__ __forceinline__ void st_pol(T *p, T v) {
+    if constexpr ((SMX_NT_MASK >> BIT) & 1) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <int BIT, typename T>
+__device__ __forceinline__ T ld_pol(const T *p) {
+    if constexpr ((SMX_NT_MASK >> BIT) & 1) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
 __device__ __forceinline__ uint64_t rev2_64(uint64_t v) {  // reverse the order of the 32 2-bit groups
     v = __brevll(v);
     return ((v >> 1) & 0x5555555555555555ull) | ((v & 0x5555555555555555ull) << 1);

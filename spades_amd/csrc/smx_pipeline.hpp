@@ -830,9 +830,18 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         if (int rc = dalloc(ctx, &P.cinfo, P.max_chunks, false)) return rc;
         if (int rc = dalloc(ctx, &P.mask, out_cap + 16, false)) return rc;
         if (int rc = dalloc(ctx, &P.overflow, 1, false)) return rc;
-        if (int rc = dalloc(ctx, &P.llink, out_cap + 16, false)) return rc;
+        if (P.fuse_tab) {  // the stage writes the node table of its chunks itself (PmOut::tab): no link array
+            if (int rc = dalloc(ctx, &P.tab, 2 * (size_t)out_cap + 2, false)) return rc;
+            if (int rc = dalloc(ctx, &P.jmp, 2 * (size_t)out_cap + 2, false)) return rc;
+            if (int rc = dalloc(ctx, &P.rbits, (size_t)P.max_chunks * (T >> 5), false)) return rc;
+            if (int rc = dalloc(ctx, &P.tab_stats, 2, false)) return rc;
+            HIPCHK(hipMemsetAsync(P.rbits, 0, (size_t)P.max_chunks * (T >> 5) * 4, ctx->stream));
+            HIPCHK(hipMemsetAsync(P.tab_stats, 0, 16, ctx->stream));
+        } else {
+            if (int rc = dalloc(ctx, &P.llink, out_cap + 16, false)) return rc;
+            HIPCHK(hipMemsetAsync(P.llink, 0xFF, (size_t)(out_cap + 16) * 4, ctx->stream));
+        }
         if (int rc = dalloc(ctx, &P.pals, 1, false)) return rc;
-        HIPCHK(hipMemsetAsync(P.llink, 0xFF, (size_t)(out_cap + 16) * 4, ctx->stream));
         HIPCHK(hipMemsetAsync(P.pals, 0, 8, ctx->stream));
         HIPCHK(hipMemsetAsync(P.overflow, 0, 4, ctx->stream));
         pmo.pinfo = P.pinfo;
@@ -843,6 +852,10 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         pmo.pals = P.pals;
         pmo.max_chunks = P.max_chunks;
         pmo.overflow = P.overflow;
+        pmo.tab = P.tab;
+        pmo.jmp = P.jmp;
+        pmo.rbits = P.rbits;
+        pmo.tab_stats = P.tab_stats;
     }
     tbegin(ctx, "skm_dedupe");
     if (nlist) {
@@ -871,11 +884,11 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     }
     tend(ctx);
     if (prof) {
-        unsigned long long hp[7];
-        HIPCHK(hipMemcpy(hp, prof, 56, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[smx] dedupe chunks=%llu slots/chunk=%.1f; 100MHz ticks per chunk: stage + segment list %.1f, insert %.1f, occupancy + allocation %.1f, output + links %.1f\n",
+        unsigned long long hp[8];
+        HIPCHK(hipMemcpy(hp, prof, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[smx] dedupe chunks=%llu slots/chunk=%.1f; 100MHz ticks per chunk: stage + segment list %.1f, insert %.1f, occupancy + allocation %.1f, output + links %.1f, node table %.1f\n",
                 hp[4], hp[4] ? (double)hp[5] / hp[4] : 0.0, hp[4] ? (double)hp[0] / hp[4] : 0.0, hp[4] ? (double)hp[1] / hp[4] : 0.0,
-                hp[4] ? (double)hp[2] / hp[4] : 0.0, hp[4] ? (double)hp[3] / hp[4] : 0.0);
+                hp[4] ? (double)hp[2] / hp[4] : 0.0, hp[4] ? (double)hp[3] / hp[4] : 0.0, hp[4] ? (double)hp[7] / hp[4] : 0.0);
     }
     unsigned long long nn[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(nn, ocount, 24, hipMemcpyDeviceToHost, ctx->stream));

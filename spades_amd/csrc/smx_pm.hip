@@ -68,14 +68,19 @@ __device__ __forceinline__ uint32_t pm_partition(const Rec<NW> &y, const PmIndex
 
 // probe of one chunk's hash table through its group words (gm: ngroups words, in LDS or HBM); y = canonical k-mer without byte
 template <int NW>
-__device__ __forceinline__ node_t pm_probe(const Rec<NW> *__restrict__ recs, const uint32_t *gm, uint32_t T, uint64_t base, const Rec<NW> &y, uint32_t h32, unsigned xs = EXT_BITS) {
+__device__ __forceinline__ node_t pm_probe(const Rec<NW> *__restrict__ recs, const uint32_t *gm, uint32_t T, uint64_t base, const Rec<NW> &y, uint32_t h32, unsigned xs = EXT_BITS,
+                                           Rec<NW> *raw_out = nullptr /* the record as stored (EXT: with its byte) when found */) {
     uint32_t h = h32 & (T - 1);
     for (uint32_t it = 0; it < T; ++it) {
         const uint32_t g = gm[h >> 4];
         const uint32_t occ = g >> 16, bit = h & 15u;
         if (!((occ >> bit) & 1u)) return NODE_NONE;
         const uint64_t idx = base + (g & 0xFFFFu) + __popc(occ & ((1u << bit) - 1u));
-        if (rec_eq<NW>(rec_pure_xs<NW>(recs[idx], xs), y)) return idx;
+        const Rec<NW> raw = recs[idx];
+        if (rec_eq<NW>(rec_pure_xs<NW>(raw, xs), y)) {
+            if (raw_out) *raw_out = raw;
+            return idx;
+        }
         h = (h + 1) & (T - 1);
     }
     return NODE_NONE;
@@ -317,7 +322,7 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
                 }
                 jw[2 * r + o] = w;
             }
-            *reinterpret_cast<ulonglong2 *>(tab + 2 * (base + r)) = make_ulonglong2(e[0], e[1]);  // both orientations: one 16-byte store
+            __builtin_nontemporal_store(smx_ull2{e[0], e[1]}, reinterpret_cast<smx_ull2 *>(tab + 2 * (base + r)));  // both orientations: one 16-byte store, streamed (nt: 37.0 -> 33.2 ms)
         }
         __syncthreads();
         PM_T(1)
@@ -336,7 +341,7 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
         __syncthreads();
         for (uint32_t nd = threadIdx.x; nd < nn; nd += BLK) {
             const uint32_t v = jw[nd];
-            jmp[2 * base + nd] = (v & 0x80000000u) ? (v & 0x7FFFFFFFu) : 0u;
+            __builtin_nontemporal_store((v & 0x80000000u) ? (v & 0x7FFFFFFFu) : 0u, jmp + 2 * base + nd);
         }
         if (prof && threadIdx.x == 0) {
             pc[1] += nhead;
@@ -397,7 +402,7 @@ __global__ void __launch_bounds__(BLK) k_pm_remote(PmIndex ix, const unsigned lo
                 node_t e = (node_t)mo << TAB_OUT_SHIFT;
                 if (ry == NODE_NONE) atomicAdd(err, 1u);
                 else e |= (ry << 1) | yo;
-                tab[node] = e;
+                st_pol<4>(tab + node, e);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -667,7 +672,7 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
                                                      node_t *first, node_t *last, uint8_t *flags, uint32_t *err) {
     const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
-        const unsigned long long cd = cand[i];
+        const unsigned long long cd = ld_pol<3>(cand + i);
         const Rec<NW> x = pm_node_kmer<NW>(recs, cd >> 2, k, ix.xs);
         unsigned yo;
         const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, (unsigned)(cd & 3)), k, yo);
@@ -675,10 +680,13 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
         // what the neighbouring lanes read), else through the partition table
         node_t ry = NODE_NONE;
         const uint64_t rj = cd >> 3;
+        Rec<NW> yraw;
+        bool have_raw = false;
         if (rj < ix.nclean) {
             uint64_t cbase;
             const uint32_t cid = pm_chunk_of(cinfo, cob, nchunks, rj, cbase);
-            ry = pm_probe<NW>(recs, ix.meta + (size_t)cid * ix.ngroups, ix.T, cbase, y, rec_hash32<NW>(y), ix.xs);
+            ry = pm_probe<NW>(recs, ix.meta + (size_t)cid * ix.ngroups, ix.T, cbase, y, rec_hash32<NW>(y), ix.xs, &yraw);
+            have_raw = ry != NODE_NONE;
         }
         if (ry == NODE_NONE) ry = rj < ix.nclean ? pm_find<NW>(ix, y) : pm_find_from_tail<NW>(ix, y);
         if (ry == NODE_NONE) {
@@ -689,8 +697,20 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
             continue;
         }
         node_t node = (ry << 1) | yo;
-        first[i] = node;
+        const node_t first_node = node;
         uint64_t steps = 0;
+        // The first k-mer is a junction itself (an edge between two junctions: a third of the start de-edges where every few bases of the genome carry a
+        // branch): the byte of the record the probe just compared says so (EXT records, no clipper since), the path ends here and its last k-mer is at
+        // hand — no jump word, no node entry, no second record read (3 lines of 128 B instead of 6).
+        if (have_raw && ix.xs && !ix.bym && mask_junction((unsigned)(yraw.w[NW - 1] & 0xFFu))) {
+            st_pol<3>(last + i, node);
+            st_pol<3>(len + i, (unsigned long long)(k + 1));
+            st_pol<3>(first + i, node);
+            const Rec<NW> yk = rec_pure_xs<NW>(yraw, ix.xs);
+            const int cmp = rec_lex_cmp<NW>(x, ((node ^ 1) & 1) ? rec_rc<NW>(yk, k) : yk);
+            st_pol<3>(flags + i, (uint8_t)(cmp > 0 ? 1 : (cmp == 0 ? 4 : 0)));
+            continue;
+        }
         for (;;) {
             const uint32_t j = jmp[node];  // to the end of the chain inside this chunk: non-junction k-mers all the way, the last one may be a junction
             node = (node_t)((long long)node + (long long)(int16_t)(j & 0xFFFFu));
@@ -708,9 +728,9 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
             atomicAdd(err, 1u);
             node = NODE_NONE;
         }
-        last[i] = node;
-        len[i] = node == NODE_NONE ? 0 : k + 1 + steps;
-        if (node == NODE_NONE) first[i] = NODE_NONE;
+        st_pol<3>(last + i, node);
+        st_pol<3>(len + i, (unsigned long long)(node == NODE_NONE ? 0 : k + 1 + steps));
+        st_pol<3>(first + i, node == NODE_NONE ? NODE_NONE : first_node);
         // keep iff !(s < RC(s)): the start k-mer (in registers) against the reverse complement of the last one decides unless they are
         // equal (a hairpin: k_pm_keep walks it); flags: bit 0 keep, bit 2 undecided
         uint8_t fl = 0;
@@ -718,7 +738,7 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
             const int cmp = rec_lex_cmp<NW>(x, pm_node_kmer<NW>(recs, node ^ 1, k, ix.xs));
             fl = cmp > 0 ? 1 : (cmp == 0 ? 4 : 0);
         }
-        flags[i] = fl;
+        st_pol<3>(flags + i, fl);
     }
 }
 // The rest of k_keep: the hairpins k_pm_walk_len left undecided (flag bit 2) are compared nucleotide by nucleotide; then, for every
@@ -782,7 +802,7 @@ __device__ __forceinline__ void pm_put(PmBitOut &b, uint64_t v, unsigned nbits) 
     const unsigned off = (unsigned)(b.pos & 63);
     b.cur |= v << off;
     if (off + nbits >= 64) {
-        b.dst[b.pos >> 6] = b.cur;
+        st_pol<5>(b.dst + (b.pos >> 6), b.cur);
         b.cur = off ? (v >> (64 - off)) : 0ull;
     }
     b.pos += nbits;
@@ -814,9 +834,10 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long 
                                                        ulonglong4 *erec /* [edges]: word offset, length, start node, end node | self << 63 */, unsigned xs) {
     const Rec<NW> *recs = (const Rec<NW> *)recs_;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
-        if (!(flags[i] & 1)) continue;
-        const unsigned long long qi = q[i];
-        const unsigned long long cd = cand[i], n = len[i], e = eidxq[qi], wo = woffq[qi];
+        const uint8_t fl = ld_pol<3>(flags + i);
+        if (!(fl & 1)) continue;
+        const unsigned long long qi = ld_pol<3>(q + i);
+        const unsigned long long cd = ld_pol<3>(cand + i), n = ld_pol<3>(len + i), e = eidxq[qi], wo = woffq[qi];
         const unsigned c = (unsigned)(cd & 3);
         const Rec<NW> x = pm_node_kmer<NW>(recs, cd >> 2, k, xs);
         PmBitOut bo;
@@ -829,7 +850,7 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long 
             bo.dst[NW - 1] = bo.cur;
             bo.cur = 0;
         }
-        node_t node = first[i];
+        node_t node = ld_pol<3>(first + i);
         unsigned long long p = k + 1;
         while (p < n) {
             const uint32_t j = jmp[node];
@@ -862,8 +883,12 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long 
             node = en & TAB_NODE_MASK;
             ++p;
         }
-        if (bo.pos & 63) bo.dst[bo.pos >> 6] = bo.cur;
-        erec[e] = make_ulonglong4(wo, n, cd >> 2, last[i] | ((unsigned long long)((flags[i] >> 1) & 1) << 63));  // one 32-byte store; k_pm_edges spreads it
+        if (bo.pos & 63) st_pol<5>(bo.dst + (bo.pos >> 6), bo.cur);
+        {  // one 32-byte record; k_pm_edges spreads it
+            smx_ull2 *er = reinterpret_cast<smx_ull2 *>(erec + e);
+            st_pol<5>(er, smx_ull2{wo, n});
+            st_pol<5>(er + 1, smx_ull2{cd >> 2, ld_pol<3>(last + i) | ((unsigned long long)((fl >> 1) & 1) << 63)});
+        }
     }
 }
 __global__ void k_pm_edges(const ulonglong4 *erec, uint64_t ne, unsigned long long *eoffw, unsigned long long *elen, node_t *estart, node_t *eend, uint8_t *eself) {

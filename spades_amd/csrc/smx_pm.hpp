@@ -16,6 +16,10 @@ void pm_release(smx_ctx *ctx) {
     arena_put(ctx, P.mask);
     arena_put(ctx, P.llink);
     arena_put(ctx, P.pals);
+    arena_put(ctx, P.tab);
+    arena_put(ctx, P.jmp);
+    arena_put(ctx, P.rbits);
+    arena_put(ctx, P.tab_stats);
     arena_put(ctx, P.dk);
     arena_put(ctx, (void *)P.ddir.dir);
     arena_put(ctx, (void *)P.ddir.boff);
@@ -116,7 +120,9 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     {
         const double avail = (double)arena_avail(ctx);
         if (10.0 * (double)nwin > avail) return bail(SMX_ROUTE_NA);  // the stage alone would need batches
-        const double fit1 = (avail - 5.0 * (double)nwin) / ((double)W + 7.0);  // record + mask byte + local links + share of the group words
+        // record + mask byte + share of the group words + local links, or (fuse_tab) the node table and jump words the stage writes itself
+        const bool fuse = ctx->opt_pm_fuse_tab != 0 && !(clip && ctx->opt_pm_full_retab != 0);
+        const double fit1 = (avail - 5.0 * (double)nwin) / ((double)W + (fuse ? 3.0 + 16.0 + 8.0 : 7.0));
         const double fit2 = avail / ((double)W + 1.0 + 16.0 + 8.0 + 8.0);
         const double fit = std::max(std::min(fit1, fit2), 1.0);
         if (fit < (double)nwin) out_cap = (uint64_t)fit;
@@ -130,6 +136,8 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         ctx->ext_mode = !nx;
         ctx->pm.active = true;
         ctx->pm.nx = nx;
+        // (the whole table again after an early clipper — option pm_full_retab — is k_pm_tab on the edited masks: it needs the link array)
+        ctx->pm.fuse_tab = ctx->opt_pm_fuse_tab != 0 && !(clip && ctx->opt_pm_full_retab != 0);
         rc = run_prededupe<NW>(ctx, k, sel, nwin, &recs, &n, out_cap);
         ctx->ext_mode = false;
         ctx->pm.active = false;
@@ -150,7 +158,13 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     arena_shrink(ctx, P.meta, (size_t)std::max<uint32_t>(P.nchunks, 1) * (P.T >> 4) * 4);
     arena_shrink(ctx, P.cinfo, (size_t)std::max<uint32_t>(P.nchunks, 1) * 8);
     arena_shrink(ctx, P.mask, (size_t)n + 16);
-    arena_shrink(ctx, P.llink, ((size_t)n + 16) * 4);
+    if (P.llink) arena_shrink(ctx, P.llink, ((size_t)n + 16) * 4);
+    const bool fused = P.tab != nullptr;  // the dedupe stage wrote the node table of the clean chunks
+    if (fused) {
+        arena_shrink(ctx, P.tab, (2 * (size_t)n + 2) * 8);
+        arena_shrink(ctx, P.jmp, (2 * (size_t)n + 2) * 4);
+        arena_shrink(ctx, P.rbits, (size_t)std::max<uint32_t>(P.nchunks, 1) * (P.T >> 5) * 4);
+    }
     ctx->g_mask = P.mask;
     P.mask = nullptr;
     gwt.mark(ctx, "g:kmers+masks");
@@ -209,8 +223,17 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     unsigned long long *stats;
     if ((rc = dalloc(ctx, &d_err, 1))) return bail(rc);
     if ((rc = dalloc(ctx, &stats, 2))) return bail(rc);
-    if ((rc = dalloc(ctx, &tab, 2 * D0 + 2))) return bail(rc);
-    if ((rc = dalloc(ctx, &jmp, 2 * D0 + 2))) return bail(rc);
+    if (fused) {  // (temporaries of this build from here on, like the ones asked for below)
+        tab = P.tab;
+        jmp = P.jmp;
+        P.tab = nullptr;
+        P.jmp = nullptr;
+        ctx->temps.push_back(tab);
+        ctx->temps.push_back(jmp);
+    } else {
+        if ((rc = dalloc(ctx, &tab, 2 * D0 + 2))) return bail(rc);
+        if ((rc = dalloc(ctx, &jmp, 2 * D0 + 2))) return bail(rc);
+    }
     pw.jmp = jmp;
     uint32_t *cob;
     if ((rc = dalloc(ctx, &cob, (size_t)(D0 >> 8) + 2))) return bail(rc);
@@ -227,8 +250,14 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
     // per chunk maxn / 16 words: the nodes whose successor lies in another chunk (k_pm_tab marks, k_pm_remote looks up)
     const uint32_t wpc = maxn >> 4;
     uint32_t *rbits = nullptr;
-    if ((rc = dalloc(ctx, &rbits, (size_t)std::max<uint32_t>(P.nchunks, 1) * wpc))) return bail(rc);
-    if (hipMemsetAsync(rbits, 0, (size_t)std::max<uint32_t>(P.nchunks, 1) * wpc * 4, ctx->stream) != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "counter reset failed"));
+    if (fused) {
+        rbits = P.rbits;
+        P.rbits = nullptr;
+        ctx->temps.push_back(rbits);
+    } else {
+        if ((rc = dalloc(ctx, &rbits, (size_t)std::max<uint32_t>(P.nchunks, 1) * wpc))) return bail(rc);
+        if (hipMemsetAsync(rbits, 0, (size_t)std::max<uint32_t>(P.nchunks, 1) * wpc * 4, ctx->stream) != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "counter reset failed"));
+    }
     unsigned long long *prof = nullptr;
     if (getenv("SMX_DEBUG")) {
         if ((rc = dalloc(ctx, &prof, 8))) return bail(rc);
@@ -250,7 +279,9 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         ctx->stream = ctx->side_stream;  // tbegin / tend and the launches below take the context's stream
     }
     tbegin(ctx, "pm_tab");
-    if (P.nchunks)
+    if (fused) {  // the clean chunks' entries are there; their extension bits were counted by the stage
+        if (hipMemcpyAsync(stats, P.tab_stats, 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return bail(fail(ctx, SMX_DEVICE_ERROR, "counter copy failed"));
+    } else if (P.nchunks)
         hipLaunchKernelGGL(k_pm_tab, dim3(std::min<uint32_t>(P.nchunks, 256 * 16)), dim3(BLK), lds, ctx->stream, (const unsigned long long *)P.cinfo, P.nchunks,
                            maxn, (const uint8_t *)ctx->g_mask, (const uint32_t *)P.llink, tab, jmp, stats, d_err, prof, rbits, (const uint8_t *)nullptr);
     if (P.ndirty)

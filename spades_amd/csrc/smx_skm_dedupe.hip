@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
     uint8_t *nbv = (uint8_t *)(seglast + NT);  // per slot 8 bits: the bases seen before the run (bits 0-3, one bit per base) and behind it (4-7)
     uint8_t *cl = nbv + ((scap + 3u) & ~3u);
     __shared__ uint32_t scr[NT / 64 + 2];
-    __shared__ uint32_t s_skip, s_cid;
+    __shared__ uint32_t s_skip, s_cid, s_nhead;
     __shared__ unsigned long long s_gbase;
     Rec<NW> *out = (Rec<NW> *)out_;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -348,6 +348,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
     const uint32_t stage_bytes = scap * SW * 8 + T * 4;
     __shared__ unsigned long long s_pt[9];  // SMX_DEBUG: 100 MHz ticks per phase seen by thread 0 (in LDS: registers are dear here)
     unsigned npal = 0;
+    unsigned long long tbits = 0;  // extension bits of the winners whose node entries this thread wrote (fused node table)
 #define SKM_T(i)                                       \
     if (prof && t == 0) {                              \
         const unsigned long long t1 = wall_clock64();  \
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
         if (t < nt) {
             const uint64_t *p = slots + ((c.a & SKM_M40) + t) * SW;
 #pragma unroll
-            for (int i = 0; i < SW; ++i) pf[i] = p[i];
+            for (int i = 0; i < SW; ++i) pf[i] = ld_pol<7>(p + i);
         }
     };
     fetch_slots(d1);
@@ -593,16 +594,21 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
         // their table entries (and the reverse one between the other strands). A node with ONE outgoing extension has one successor,
         // whichever read shows it; where several reads disagree the node has several extensions and nobody reads the link. A thread
         // knows the pairs inside its segment, and the pair across the boundary to the segment before it from that segment's last entry.
-        bool links = false;
-        uint32_t lnk_bytes = 0;
+        bool links = false, fuse = false;
+        uint32_t lnk_bytes = 0, mk_bytes = 0;
         if constexpr (PM) {
             links = !dirty && wcount && (size_t)wcount * 8 <= (size_t)stage_bytes;  // (a chunk that does not fit the output any more — skip, known at the copy-out — stages its links for nothing)
             lnk_bytes = links ? ((wcount * 4 + 15u) & ~15u) : 0u;
+            // the node table of the chunk is written from here (PmOut::tab): the bytes of ALL its winners stay in LDS behind the links (mk), whatever the
+            // number of output rounds; the rounds stage their records behind them
+            fuse = links && pm.tab != nullptr;
+            mk_bytes = fuse ? ((wcount + 15u) & ~15u) : 0u;
         }
         uint16_t *lnk = (uint16_t *)lds64;
-        Rec<NW> *stg = (Rec<NW> *)((uint8_t *)lds64 + lnk_bytes);
-        const uint32_t R = ((stage_bytes - lnk_bytes) / (uint32_t)(sizeof(Rec<NW>) + 1)) & ~15u;  // records per output round
-        uint8_t *stm = (uint8_t *)(stg + R);
+        uint8_t *mk = (uint8_t *)lds64 + lnk_bytes;
+        Rec<NW> *stg = (Rec<NW> *)((uint8_t *)lds64 + lnk_bytes + mk_bytes);
+        const uint32_t R = fuse ? (((stage_bytes - lnk_bytes - mk_bytes) / (uint32_t)sizeof(Rec<NW>)) & ~15u)
+                                : (((stage_bytes - lnk_bytes) / (uint32_t)(sizeof(Rec<NW>) + 1)) & ~15u);  // records per output round
         if constexpr (PM) {
             if (links) {
                 for (uint32_t i = t; i < lnk_bytes / 16; i += NT) ((uint4 *)lnk)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -612,6 +618,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
         // ---- winners: to their place in table-slot order, staged through LDS in rounds of R records; links in the first round ----
         for (uint32_t r0 = 0; r0 < wcount; r0 += R) {
             if (r0) lds_barrier();
+            uint8_t *stm = fuse ? mk + r0 : (uint8_t *)(stg + R);  // the bytes of this round's records
             Rec<NW> x = x0, y = y0;
             uint32_t nxt = nxt0;
             uint64_t a0 = hp0, a1 = hp1, e0 = ebq;
@@ -708,13 +715,17 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
             if (!skip) {
                 const uint32_t nr = min(R, wcount - r0);
                 Rec<NW> *dst = out + gb + r0;
-                for (uint32_t i = t; i < nr; i += NT) dst[i] = stg[i];
+                for (uint32_t i = t; i < nr; i += NT) {
+                    const Rec<NW> v = stg[i];
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) st_pol<6>(&dst[i].w[j], v.w[j]);
+                }
                 if constexpr (PM) {
                     if (!dirty || NX) {
                         uint8_t *md = pm.mask + gb + r0;
-                        for (uint32_t i = t; i < nr; i += NT) md[i] = stm[i];
+                        for (uint32_t i = t; i < nr; i += NT) st_pol<6>(md + i, stm[i]);
                     }
-                    if (links && r0 == 0) {
+                    if (links && r0 == 0 && pm.llink != nullptr) {  // (no link array where this stage writes the node table itself)
                         uint32_t *gl = pm.llink + gb;
                         for (uint32_t i = t; i < wcount; i += NT) gl[i] = ((const uint32_t *)lnk)[i];
                     }
@@ -723,6 +734,69 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
         }
         lds_barrier();
         SKM_T(3)
+        if constexpr (PM) {
+            // ---- the chunk's node table (k_pm_tab of smx_pm.hip, from LDS): per node its outgoing extensions and, where there is exactly one, the successor by the
+            // local link or TAB_NODE_MASK + its bit in rbits (k_pm_remote looks it up); then the chains inside the chunk, once each from their heads: jump words.
+            // LDS: the links become the chain links in place (0xFFFF: the chain ends here) | mk | over the staged records (all copied out): head list, two bitmaps.
+            if (fuse && !s_skip) {
+                constexpr uint32_t WPC = T / 32;  // words of rbits per chunk (= maxn / 16, smx_pm.hpp)
+                const unsigned long long gb = s_gbase;
+                const uint32_t cid = s_cid, nn = 2 * wcount;
+                uint16_t *list = (uint16_t *)stg;
+                uint32_t *hp = (uint32_t *)((uint8_t *)stg + ((4 * wcount + 15u) & ~15u));  // (two nodes may share a successor: up to nn heads) bit nd: some local link leads to node nd
+                uint32_t *rm = hp + WPC;                                                    // bit nd: the successor of node nd is not in this chunk
+                uint32_t *lnk32 = (uint32_t *)lnk;
+                for (uint32_t i = t; i < 2 * WPC; i += NT) hp[i] = 0;
+                if (t == 0) s_nhead = 0;
+                lds_barrier();
+                for (uint32_t r = t; r < wcount; r += NT) {
+                    const unsigned m = mk[r];
+                    const uint32_t ll = lnk32[r];
+                    tbits += __popc(m);
+                    const bool junction = mask_junction(m);
+                    node_t e[2];
+                    uint32_t w2 = 0;
+#pragma unroll
+                    for (unsigned o = 0; o < 2; ++o) {
+                        const unsigned mo = (o ? brev8(m) : m) & 15u;
+                        const uint32_t l = o ? (ll >> 16) : (ll & 0xFFFFu);
+                        uint32_t w = 0xFFFFu;  // no local successor
+                        e[o] = (node_t)mo << TAB_OUT_SHIFT;
+                        if (uniq4(mo)) {
+                            if (l != 0xFFFFu && l < nn) {
+                                e[o] |= 2 * gb + l;
+                                if (!junction) {
+                                    w = l;
+                                    atomicOr(&hp[w >> 5], 1u << (w & 31u));
+                                }
+                            } else {  // not next to it in any super-k-mer of the chunk
+                                e[o] |= TAB_NODE_MASK;
+                                atomicOr(&rm[(2 * r + o) >> 5], 1u << ((2 * r + o) & 31u));
+                            }
+                        }
+                        w2 |= w << (16 * o);
+                    }
+                    lnk32[r] = w2;
+                    __builtin_nontemporal_store(smx_ull2{e[0], e[1]}, reinterpret_cast<smx_ull2 *>(pm.tab + 2 * (gb + r)));
+                }
+                lds_barrier();
+                for (uint32_t i = t; i < WPC; i += NT) pm.rbits[(size_t)cid * WPC + i] = rm[i];
+                for (uint32_t nd = t; nd < nn; nd += NT) {  // chain heads: a local successor, no local predecessor; every other node's jump word is 0
+                    if (lnk[nd] != 0xFFFFu && !((hp[nd >> 5] >> (nd & 31u)) & 1u)) list[atomicAdd(&s_nhead, 1u)] = (uint16_t)nd;
+                    else __builtin_nontemporal_store(0u, pm.jmp + 2 * gb + nd);
+                }
+                lds_barrier();
+                const uint32_t nhead = s_nhead;
+                for (uint32_t i = t; i < nhead; i += NT) {  // every chain once, from its head
+                    const uint32_t h = list[i];
+                    uint32_t cur = h, st = 0;
+                    for (uint32_t a; (a = lnk[cur]) != 0xFFFFu && st < nn; ++st) cur = a;
+                    __builtin_nontemporal_store(((cur - h) & 0xFFFFu) | (st << 16), pm.jmp + 2 * gb + h);
+                }
+                lds_barrier();  // (the next chunk's slots and table go over all of this)
+            }
+            SKM_T(7)
+        }
         if (prof && t == 0) {
             s_pt[4] += 1;
             s_pt[5] += ntake;
@@ -731,9 +805,15 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
     if (prof && t == 0)
     {
         for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], s_pt[i]);
+        atomicAdd(&prof[7], s_pt[7]);
     }
-    if constexpr (PM)
+    if constexpr (PM) {
         if (npal) atomicAdd(pm.pals, (unsigned long long)npal);
+        if (pm.tab != nullptr) {
+            for (int o = 32; o > 0; o >>= 1) tbits += __shfl_down(tbits, o, 64);
+            if (lane == 0 && tbits) atomicAdd(pm.tab_stats, tbits);
+        }
+    }
 #undef SKM_T
 }
 

@@ -16,6 +16,7 @@
 // contract (tests: goldens with the stage forced on).
 #pragma once
 #include "smx_device.hpp"
+#include "smx_graph.hip"  // node entries, mask_junction (the dedupe stage writes the node table of its chunks)
 
 namespace smx {
 
@@ -456,9 +457,9 @@ __global__ void __launch_bounds__(BLK, SMX_SCAN_WPE) k_skm_scan(SkmArgs a) {
                         vals[i] = v;
                     }
                 }
-                if constexpr (PHASE == 0) a.stage_part[stage0 + si] = (unsigned long long)key | ((rank & SKM_CNT_MASK) << 32);  // (dst != nullptr in phase 0 <=> the tile has staging entries)
+                if constexpr (PHASE == 0) st_pol<8>(a.stage_part + stage0 + si, (unsigned long long)key | ((rank & SKM_CNT_MASK) << 32));  // (dst != nullptr in phase 0 <=> the tile has staging entries)
 #pragma unroll
-                for (int i = 0; i < SW; ++i) dst[i] = vals[i];
+                for (int i = 0; i < SW; ++i) st_pol<8>((uint64_t *)dst + i, (uint64_t)vals[i]);
             }
         }
         __syncthreads();
@@ -476,14 +477,14 @@ __global__ void __launch_bounds__(BLK) k_skm_permute(const uint64_t *__restrict_
                                                      uint64_t n_stage, const unsigned long long *__restrict__ soff, uint64_t *slots) {
     constexpr int SW = 2 * NW;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n_stage; i += (uint64_t)gridDim.x * BLK) {
-        const unsigned long long pr = stage_part[i];
+        const unsigned long long pr = ld_pol<1>(stage_part + i);
         if (pr == ~0ull) continue;
         uint64_t v[SW];
 #pragma unroll
-        for (int t = 0; t < SW; ++t) v[t] = stage_slots[i * SW + t];
+        for (int t = 0; t < SW; ++t) v[t] = ld_pol<1>(stage_slots + i * SW + t);
         uint64_t *dst = slots + (soff[(uint32_t)pr] + (pr >> 32)) * SW;  // the place the counting pass reserved
 #pragma unroll
-        for (int t = 0; t < SW; ++t) dst[t] = v[t];
+        for (int t = 0; t < SW; ++t) st_pol<0>(dst + t, v[t]);
     }
 }
 
@@ -573,6 +574,13 @@ struct PmOut {
     unsigned long long *pals;   // palindromic (k+1)-mers among the extensions of the clean winners (k_ext_split's second figure)
     uint32_t max_chunks;
     uint32_t *overflow;         // set when a chunk got no room in meta / cinfo
+    // The node table of the clean chunks made by the dedupe stage itself (round 6; nullptr: k_pm_tab makes it from mask + llink afterwards): the
+    // chunk's bytes and local links are in LDS when its records leave, so the entries, the jump words and the remote bits of smx_pm.hip's k_pm_tab
+    // are written from there and the links never travel (4 B per k-mer written, cleared and read again otherwise).
+    unsigned long long *tab;    // [2 * out_cap + 2] node entries (smx_graph.hip: successor | outgoing extensions << TAB_OUT_SHIFT)
+    uint32_t *jmp;              // [2 * out_cap + 2] jump words of the chain heads, 0 elsewhere
+    uint32_t *rbits;            // [max_chunks * T / 32] per chunk: bit nd = node nd's successor lies outside the chunk (k_pm_remote looks it up)
+    unsigned long long *tab_stats;  // [0] += extension bits of the clean winners
 };
 constexpr unsigned PM_BASE_BITS = 40;
 constexpr unsigned long long PM_BASE_MASK = (1ull << PM_BASE_BITS) - 1;

@@ -4,7 +4,7 @@ with everything it includes: C ABI, host pipeline, every gfx950 kernel as writte
 the fiber-based SIMT stand-in. The sources are used as they are except for what only an AMDGPU assembler understands:
   * inline `asm volatile("s_waitcnt ...")` (waits that order nothing in a sequential emulation) and the library's LDS barrier (s_barrier),
   * `extern __shared__ T name[];` (dynamic LDS: a pointer to the emulator's one LDS buffer),
-  * two clang builtins g++ lacks, and the register class of empty optimizer-barrier asm statements ("+v" -> "+r").
+  * a few clang builtins / vector attributes g++ lacks, and the register class of empty optimizer-barrier asm statements ("+v" -> "+r").
 The transformed copies live under _build/src; nothing of this is ever loaded by spades_amd (the product has no CPU path)."""
 import os
 import re
@@ -27,6 +27,10 @@ def transform(text):
     text = re.sub(r'asm volatile\(""\s*:\s*"\+v"\((\w+)\)\);', r'__asm__ __volatile__("" : "+r"(\1));', text)
     text = re.sub(r"extern __shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_0-9 ]+?)\s+(\w+)\[\];", r"\1 *\2 = (\1 *)emu::g_ctx->lds;", text)
     text = text.replace("__builtin_rotateleft32", "emu_rotl32")
+    # clang's vector extension and its cache-policy builtins (non-temporal = a hint to the memory system: a plain access here)
+    text = text.replace("__attribute__((ext_vector_type(2)))", "__attribute__((vector_size(16)))")
+    text = re.sub(r"__builtin_nontemporal_store\(", "emu_nt_store(", text)
+    text = re.sub(r"__builtin_nontemporal_load\(", "emu_nt_load(", text)
     assert "asm volatile" not in text and "extern __shared__" not in text, "an AMDGPU-only construct the transform does not know"
     return text
 

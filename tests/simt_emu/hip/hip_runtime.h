@@ -389,6 +389,10 @@ static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
 static inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
+template <typename T>
+static inline void emu_nt_store(T v, T *p) { *p = v; }
+template <typename T>
+static inline T emu_nt_load(const T *p) { return *p; }
 static inline unsigned __brev(unsigned v) {
     v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
     v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
