@@ -603,14 +603,18 @@ def main():
         inst = int(icnt) if icnt else int((torch.from_numpy(h_len.numpy().astype("int64")) - K1 + 1).clamp(min=0).sum().item())
     # B_alg(count) = N*L/4 + 2*I*W + D*W (ext route: I = k-mer instances of the reads that hold a (k+1)-mer, D = distinct
     # k-mers; the extension byte rides in spare record bits)
+    # round 6: on route 0 the dedupe stage writes the node table of its chunks itself (option pm_fuse_tab, default; smx_skm_dedupe.hip): two 8-byte node entries and two
+    # 4-byte jump words per k-mer leave the COUNT pipeline's kernel, and the construction has no k_pm_tab pass — the bytes move with the work
+    fused_tab = pm_route and not any(kv.replace(" ", "") == "pm_fuse_tab=0" for kv in args.opt)
     if ext_route:
         inst_k = int((torch.from_numpy(h_len.numpy().astype("int64")) - k + 1).clamp(min=0).sum().item())
-        b_count = n_reads * L / 4 + 2 * inst_k * W + info["n_kmers"] * W
+        b_count = n_reads * L / 4 + 2 * inst_k * W + info["n_kmers"] * W + (info["n_kmers"] * 24 if fused_tab else 0)
     else:
         b_count = n_reads * L / 4 + 2 * inst * W + D1 * W
     roof_count = {"bound": "hbm", "achieved": round(b_count / max(count_ms, 1e-9) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                   "frac": round(b_count / max(count_ms, 1e-9) / 1e6 / 8000.0, 4), "traffic": None,
-                  "kernel": ("counting pipeline of the canonical k-mers with their extension masks" if ext_route else
+                  "kernel": (("counting pipeline of the canonical k-mers with their extension masks" + (" and the node table of the partition-major chunks (24 B per k-mer, "
+                              "written by the dedupe stage from LDS)" if fused_tab else "")) if ext_route else
                              "counting pipeline of the canonical (k+1)-mers") + " (sum of its stage kernels, HIP events on the library stream)",
                   "algorithmic_bytes_per_step": int(b_count), "kernel_ms_per_step": round(count_ms, 3)}
     dom = max(stages.items(), key=lambda x: x[1]) if stages else ("", 0.0)
@@ -718,7 +722,7 @@ def main():
             # what each of ITS kernels must move (the per-kernel rows of `dominant_kernel` below / DESIGN.md §6) — VERDICT r5 weak 5: the route-1
             # formula priced 491 GB where the rows sum to ~370.
             nj_, nc_ = rs0.get("junction_kmers", 0), rs0.get("start_de_edges", 0)
-            b_tab = D0 * (1 + 4) + 2 * D0 * 8 + 2 * D0 * 4
+            b_tab = 0 if fused_tab else D0 * (1 + 4) + 2 * D0 * 8 + 2 * D0 * 4  # (fused: written by the count pipeline's dedupe stage, priced there)
             b_rem = 2 * D0 * 8 + 0.1 * 2 * D0 * (W + 8 + 4 + W + 8)
             b_junc = 2 * D0 + nj_ * (2 * W + 8) + 3 * nj_ * W + nj_ * (2 * W + 1) + nj_ * (W + 24) + nc_ * 16  # masks scanned twice; junction records gathered, sorted (w + r + w), split, looked up; de-edges listed
             b_wlen = nc_ * (8 + 2 * W + 4 + 3 * (4 + 16) + W + 8 * 3 + 1)
@@ -757,7 +761,9 @@ def main():
         nslots, nchunks = rs.get("superkmer_slots", 0), rs.get("chunks", 0)
         n_cand = rs.get("start_de_edges", 0)
         single = {  # stage -> (kernel, substring of its name in the PMC table, algorithmic bytes, what they are)
-            "kmers:skm_dedupe": ("smx::k_skm_dedupe2", "k_skm_dedupe2", nslots * 8 * 2 * nw + D0 * (W + 1 + 4) + nchunks * 4 * 256,
+            "kmers:skm_dedupe": ("smx::k_skm_dedupe2", "k_skm_dedupe2", nslots * 8 * 2 * nw + D0 * (W + 1 + (24 if fused_tab else 4)) + nchunks * 4 * (512 if fused_tab else 256),
+                                 ("super-k-mer slots read once; per distinct k-mer its record, mask byte, two node-table entries and two jump words written; 2 KB of group words and "
+                                  "remote bits per chunk") if fused_tab else
                                  "super-k-mer slots read once; per distinct k-mer its record, mask byte and link word written; 1 KB of group words per chunk"),
             "kmers:skm_count": ("smx::k_skm_scan<0>", "k_skm_scan", n_reads * L / 4 + n_reads * 12 + nslots * (8 * 2 * nw + 8) + nslots * 16,
                                 "2-bit stream + window marks read; per super-k-mer a staged slot and its (partition, rank) word written, one 8-byte counter updated"),

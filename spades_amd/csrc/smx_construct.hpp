@@ -1097,12 +1097,17 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
     node_t *first = nullptr;
     uint8_t *flags = nullptr;
     if (C > 0) {
-        unsigned long long *kw, *one;
+        unsigned long long *kw = nullptr, *one = nullptr;
         node_t *last;
+        // route 0: word offset (35 bits: 2^35 words of unitigs are 275 GB) and edge index (29 bits) of a kept path come out of ONE scan side by side in one word
+        // where the start de-edges number less than 2^29 (option walk_pack = 0: two arrays, two scans, as on the sorted routes)
+        const unsigned pack_shift = (pm && ctx->opt_walk_pack != 0 && C < (1ull << 29)) ? 35u : 0u;
         if (int rc = dalloc(ctx, &cand, C)) return rc;
         if (int rc = dalloc(ctx, &len, C)) return rc;
-        if (int rc = dalloc(ctx, &kw, C + 1)) return rc;
-        if (int rc = dalloc(ctx, &one, C + 1)) return rc;
+        if (!pack_shift) {
+            if (int rc = dalloc(ctx, &kw, C + 1)) return rc;
+            if (int rc = dalloc(ctx, &one, C + 1)) return rc;
+        }
         if (int rc = dalloc(ctx, &first, C)) return rc;
         if (int rc = dalloc(ctx, &last, C)) return rc;
         if (int rc = dalloc(ctx, &flags, C)) return rc;
@@ -1123,7 +1128,7 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             HIPCHK(hipStreamSynchronize(ctx->stream));
             const uint64_t nj = nj_;
             if (int rc = dalloc(ctx, &qidx, C)) return rc;
-            if (int rc = dalloc(ctx, &vq, C)) return rc;
+            if (int rc = dalloc(ctx, &vq, C + 1)) return rc;
             Rec<NW> *jrecs, *jk;
             uint8_t *jm;
             unsigned long long *jstats, *jcnt, *candoff, *qbase, *jrank_of, *coff;
@@ -1210,9 +1215,9 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         if (pm) {
             hipLaunchKernelGGL((k_pm_keep<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (const unsigned long long *)qidx, (uint64_t)C,
                                (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len, (const node_t *)first, flags, vq, counters + 1,
-                               pm->ix.xs);
+                               pm->ix.xs, pack_shift);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(k_pm_unpack, dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)vq, (uint64_t)C, kw, one);  // kw / one: indexed by q
+            if (!pack_shift) hipLaunchKernelGGL(k_pm_unpack, dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)vq, (uint64_t)C, kw, one);  // kw / one: indexed by q
         } else {
             hipLaunchKernelGGL((k_keep<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (uint64_t)C,
                                (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len,
@@ -1220,14 +1225,23 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         }
         HIPCHK(hipGetLastError());
         // word offsets and edge indices of the kept paths (scans in place: kw -> woff, one -> eidx)
-        if (int rc = scan_u64(ctx, kw, kw, C)) return rc;
-        if (int rc = scan_u64(ctx, one, one, C)) return rc;
         unsigned long long tw = 0, nk = 0;
-        HIPCHK(hipMemcpyAsync(&tw, kw + C, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(&nk, one + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (pack_shift) {  // one scan: word offset and edge index of a kept path side by side in one word
+            if (int rc = scan_u64(ctx, vq, vq, C)) return rc;
+            HIPCHK(hipMemcpyAsync(&tw, vq + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            if (int rc = scan_u64(ctx, kw, kw, C)) return rc;
+            if (int rc = scan_u64(ctx, one, one, C)) return rc;
+            HIPCHK(hipMemcpyAsync(&tw, kw + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(&nk, one + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
         HIPCHK(hipMemcpyAsync(&interior, counters + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         tend(ctx);
+        if (pack_shift) {
+            nk = tw >> pack_shift;
+            tw &= (1ull << pack_shift) - 1;
+        }
         nkept = nk;
         ktotalw = tw;
         if (int rc = dalloc(ctx, &ctx->g_uwords, ktotalw + 8, false)) return rc;
@@ -1243,8 +1257,8 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             if (int rc = dalloc(ctx, &erec, nkept + 1)) return rc;
             hipLaunchKernelGGL((k_pm_walk_write<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (const unsigned long long *)qidx,
                                (uint64_t)C, (const void *)ctx->g_kmers, (const node_t *)tab, pm->jmp, k, (const unsigned long long *)len, (const node_t *)first,
-                               (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)kw, (const unsigned long long *)one, ctx->g_uwords, erec,
-                               pm->ix.xs);
+                               (const node_t *)last, (const uint8_t *)flags, (const unsigned long long *)(pack_shift ? vq : kw), (const unsigned long long *)one, ctx->g_uwords, erec,
+                               pm->ix.xs, pack_shift);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(k_pm_edges, dim3(grid_for(nkept)), dim3(BLK), 0, ctx->stream, (const ulonglong4 *)erec, (uint64_t)nkept, ctx->g_eoffw, ctx->g_elen,
                                ctx->g_estart, ctx->g_eend, ctx->g_eself);

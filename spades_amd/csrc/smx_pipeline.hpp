@@ -726,8 +726,8 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     const uint32_t nitems = SKM_NKEY / SKM_KEYS_PER_ITEM;
     unsigned long long *prof = nullptr;
     if (getenv("SMX_DEBUG")) {
-        if (int rc = dalloc(ctx, &prof, 8)) return rc;
-        HIPCHK(hipMemsetAsync(prof, 0, 64, ctx->stream));
+        if (int rc = dalloc(ctx, &prof, 16)) return rc;
+        HIPCHK(hipMemsetAsync(prof, 0, 128, ctx->stream));
     }
     // Oversized partitions (homopolymer / short-period runs: every window of such a run is a super-k-mer of its own and all share one
     // minimizer) are taken out of the items and cut into pieces of BIG_PIECE slots, each an item of a second launch.
@@ -884,11 +884,11 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     }
     tend(ctx);
     if (prof) {
-        unsigned long long hp[8];
-        HIPCHK(hipMemcpy(hp, prof, 64, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[smx] dedupe chunks=%llu slots/chunk=%.1f; 100MHz ticks per chunk: stage + segment list %.1f, insert %.1f, occupancy + allocation %.1f, output + links %.1f, node table %.1f\n",
+        unsigned long long hp[9];
+        HIPCHK(hipMemcpy(hp, prof, 72, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[smx] dedupe chunks=%llu slots/chunk=%.1f; 100MHz ticks per chunk: stage + segment list %.1f, insert %.1f, occupancy + allocation %.1f, output + links (+ node entries) %.1f, chain heads %.1f, chains %.1f\n",
                 hp[4], hp[4] ? (double)hp[5] / hp[4] : 0.0, hp[4] ? (double)hp[0] / hp[4] : 0.0, hp[4] ? (double)hp[1] / hp[4] : 0.0,
-                hp[4] ? (double)hp[2] / hp[4] : 0.0, hp[4] ? (double)hp[3] / hp[4] : 0.0, hp[4] ? (double)hp[7] / hp[4] : 0.0);
+                hp[4] ? (double)hp[2] / hp[4] : 0.0, hp[4] ? (double)hp[3] / hp[4] : 0.0, hp[4] ? (double)hp[7] / hp[4] : 0.0, hp[4] ? (double)hp[8] / hp[4] : 0.0);
     }
     unsigned long long nn[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(nn, ocount, 24, hipMemcpyDeviceToHost, ctx->stream));

@@ -746,7 +746,9 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_pm_keep(const unsigned long long *cand, const unsigned long long *q, uint64_t C, const void *recs_, const node_t *succ,
                                                  unsigned k, const unsigned long long *len, const node_t *first, uint8_t *flags, unsigned long long *vq,
-                                                 unsigned long long *interior, unsigned xs) {
+                                                 unsigned long long *interior, unsigned xs,
+                                                 unsigned pack_shift /* 0: vq = words << 1 | keep (k_pm_unpack + two scans follow); else vq = words | keep << pack_shift: ONE scan
+                                                                        gives a kept path its word offset and its edge index in one word (one line per path in k_pm_walk_write) */) {
     __shared__ unsigned long long scratch[BLK / 64 + 2];
     const Rec<NW> *recs = (const Rec<NW> *)recs_;
     unsigned long long inner = 0;
@@ -778,7 +780,7 @@ __global__ void __launch_bounds__(BLK) k_pm_keep(const unsigned long long *cand,
             flags[i] = fl;
         }
         const bool keep = fl & 1;
-        vq[q[i]] = keep ? ((((n + 31) / 32) << 1) | 1ull) : 0ull;
+        vq[q[i]] = !keep ? 0ull : (pack_shift ? (((n + 31) / 32) | (1ull << pack_shift)) : ((((n + 31) / 32) << 1) | 1ull));
         if (keep) inner += (fl & 2) ? (n - k - 1) / 2 : (n - k - 1);  // a self-conjugate path meets every rank twice
     }
     unsigned long long tot;
@@ -831,13 +833,23 @@ template <int NW>
 __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long *cand, const unsigned long long *q, uint64_t C, const void *recs_, const node_t *succ,
                                                        const uint32_t *jmp, unsigned k, const unsigned long long *len, const node_t *first, const node_t *last,
                                                        const uint8_t *flags, const unsigned long long *woffq, const unsigned long long *eidxq, uint64_t *words,
-                                                       ulonglong4 *erec /* [edges]: word offset, length, start node, end node | self << 63 */, unsigned xs) {
+                                                       ulonglong4 *erec /* [edges]: word offset, length, start node, end node | self << 63 */, unsigned xs,
+                                                       unsigned pack_shift /* != 0: woffq[q] = word offset | edge index << pack_shift (k_pm_keep), eidxq unused */) {
     const Rec<NW> *recs = (const Rec<NW> *)recs_;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         const uint8_t fl = ld_pol<3>(flags + i);
         if (!(fl & 1)) continue;
         const unsigned long long qi = ld_pol<3>(q + i);
-        const unsigned long long cd = ld_pol<3>(cand + i), n = ld_pol<3>(len + i), e = eidxq[qi], wo = woffq[qi];
+        const unsigned long long cd = ld_pol<3>(cand + i), n = ld_pol<3>(len + i);
+        unsigned long long e, wo;
+        if (pack_shift) {
+            const unsigned long long v = woffq[qi];
+            wo = v & ((1ull << pack_shift) - 1);
+            e = v >> pack_shift;
+        } else {
+            e = eidxq[qi];
+            wo = woffq[qi];
+        }
         const unsigned c = (unsigned)(cd & 3);
         const Rec<NW> x = pm_node_kmer<NW>(recs, cd >> 2, k, xs);
         PmBitOut bo;

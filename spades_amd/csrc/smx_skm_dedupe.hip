@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     // staging area of the output (over the slots and the table, both dead by then): records | mask bytes
     const uint32_t stage_bytes = scap * SW * 8 + T * 4;
-    __shared__ unsigned long long s_pt[9];  // SMX_DEBUG: 100 MHz ticks per phase seen by thread 0 (in LDS: registers are dear here)
+    __shared__ unsigned long long s_pt[10];  // SMX_DEBUG: 100 MHz ticks per phase seen by thread 0 (in LDS: registers are dear here)
     unsigned npal = 0;
     unsigned long long tbits = 0;  // extension bits of the winners whose node entries this thread wrote (fused node table)
 #define SKM_T(i)                                       \
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
         s_pt[6] = t1;                                  \
     }
     if (prof && t == 0) {
-        for (int i = 0; i < 9; ++i) s_pt[i] = 0;
+        for (int i = 0; i < 10; ++i) s_pt[i] = 0;
         s_pt[6] = wall_clock64();
     }
     const SkmChunk none{0, 0};
@@ -602,16 +602,23 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
             // the node table of the chunk is written from here (PmOut::tab): the bytes of ALL its winners stay in LDS behind the links (mk), whatever the
             // number of output rounds; the rounds stage their records behind them
             fuse = links && pm.tab != nullptr;
-            mk_bytes = fuse ? ((wcount + 15u) & ~15u) : 0u;
+            mk_bytes = fuse ? ((wcount + 15u) & ~15u) + 8u * (T / 32) : 0u;  // ... and two bitmaps of the chunk's nodes (hp, rm: see the node table below)
         }
+        constexpr uint32_t WPC = T / 32;  // words of a node bitmap = words of rbits per chunk (= maxn / 16, smx_pm.hpp)
         uint16_t *lnk = (uint16_t *)lds64;
         uint8_t *mk = (uint8_t *)lds64 + lnk_bytes;
+        uint32_t *hp = (uint32_t *)(mk + ((wcount + 15u) & ~15u));  // bit nd: some local link leads to node nd
+        uint32_t *rm = hp + WPC;                                     // bit nd: the successor of node nd is not in this chunk
         Rec<NW> *stg = (Rec<NW> *)((uint8_t *)lds64 + lnk_bytes + mk_bytes);
         const uint32_t R = fuse ? (((stage_bytes - lnk_bytes - mk_bytes) / (uint32_t)sizeof(Rec<NW>)) & ~15u)
                                 : (((stage_bytes - lnk_bytes) / (uint32_t)(sizeof(Rec<NW>) + 1)) & ~15u);  // records per output round
         if constexpr (PM) {
             if (links) {
                 for (uint32_t i = t; i < lnk_bytes / 16; i += NT) ((uint4 *)lnk)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                if (fuse) {
+                    for (uint32_t i = t; i < 2 * WPC; i += NT) hp[i] = 0;
+                    if (t == 0) s_nhead = 0;
+                }
                 lds_barrier();
             }
         }
@@ -729,63 +736,65 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
                         uint32_t *gl = pm.llink + gb;
                         for (uint32_t i = t; i < wcount; i += NT) gl[i] = ((const uint32_t *)lnk)[i];
                     }
+                    // ---- the chunk's node table (k_pm_tab of smx_pm.hip, from LDS), first half, beside the copy-out of the LAST round (every winner's byte is in mk by
+                    // now, the links since the first round): per node its outgoing extensions and, where there is exactly one, the successor by the local link or
+                    // TAB_NODE_MASK + its bit in rm (k_pm_remote looks it up). The links become the chain links in place (0xFFFF: the chain ends here).
+                    if (fuse && r0 + R >= wcount) {
+                        const uint32_t nn = 2 * wcount;
+                        uint32_t *lnk32 = (uint32_t *)lnk;
+                        for (uint32_t r = t; r < wcount; r += NT) {
+                            const unsigned m = mk[r];
+                            const uint32_t ll = lnk32[r];
+                            tbits += __popc(m);
+                            const bool junction = mask_junction(m);
+                            node_t e[2];
+                            uint32_t w2 = 0;
+#pragma unroll
+                            for (unsigned o = 0; o < 2; ++o) {
+                                const unsigned mo = (o ? brev8(m) : m) & 15u;
+                                const uint32_t l = o ? (ll >> 16) : (ll & 0xFFFFu);
+                                uint32_t w = 0xFFFFu;  // no local successor
+                                e[o] = (node_t)mo << TAB_OUT_SHIFT;
+                                if (uniq4(mo)) {
+                                    if (l != 0xFFFFu && l < nn) {
+                                        e[o] |= 2 * gb + l;
+                                        if (!junction) {
+                                            w = l;
+                                            atomicOr(&hp[w >> 5], 1u << (w & 31u));
+                                        }
+                                    } else {  // not next to it in any super-k-mer of the chunk
+                                        e[o] |= TAB_NODE_MASK;
+                                        atomicOr(&rm[(2 * r + o) >> 5], 1u << ((2 * r + o) & 31u));
+                                    }
+                                }
+                                w2 |= w << (16 * o);
+                            }
+                            lnk32[r] = w2;
+                            __builtin_nontemporal_store(smx_ull2{e[0], e[1]}, reinterpret_cast<smx_ull2 *>(pm.tab + 2 * (gb + r)));
+                        }
+                    }
                 }
             }
         }
         lds_barrier();
         SKM_T(3)
         if constexpr (PM) {
-            // ---- the chunk's node table (k_pm_tab of smx_pm.hip, from LDS): per node its outgoing extensions and, where there is exactly one, the successor by the
-            // local link or TAB_NODE_MASK + its bit in rbits (k_pm_remote looks it up); then the chains inside the chunk, once each from their heads: jump words.
-            // LDS: the links become the chain links in place (0xFFFF: the chain ends here) | mk | over the staged records (all copied out): head list, two bitmaps.
+            // ---- the chunk's node table, second half: the chains inside the chunk, once each from their heads (the nodes no local link leads to): jump words.
+            // LDS over the staged records (all copied out): the head list. (Tried and dropped, round 6: pointer jumping over all nodes instead of one thread per
+            // chain — to convergence, ~9 rounds of a dense pass + barrier: 13 us per chunk in here where this takes 5; 2 / 3 / 4 rounds in front of the walks: each
+            // round costs ~0.7 us and the walks get no shorter on the clock — profiles/r06/fused_node_table_pointer_jumping_ab.log, ..._chain_doubling_ab.log. Nor did
+            // it matter that the first half moved beside the copy-out, two barriers less: a chunk's time in here is its instructions and LDS round trips.)
             if (fuse && !s_skip) {
-                constexpr uint32_t WPC = T / 32;  // words of rbits per chunk (= maxn / 16, smx_pm.hpp)
                 const unsigned long long gb = s_gbase;
                 const uint32_t cid = s_cid, nn = 2 * wcount;
-                uint16_t *list = (uint16_t *)stg;
-                uint32_t *hp = (uint32_t *)((uint8_t *)stg + ((4 * wcount + 15u) & ~15u));  // (two nodes may share a successor: up to nn heads) bit nd: some local link leads to node nd
-                uint32_t *rm = hp + WPC;                                                    // bit nd: the successor of node nd is not in this chunk
-                uint32_t *lnk32 = (uint32_t *)lnk;
-                for (uint32_t i = t; i < 2 * WPC; i += NT) hp[i] = 0;
-                if (t == 0) s_nhead = 0;
-                lds_barrier();
-                for (uint32_t r = t; r < wcount; r += NT) {
-                    const unsigned m = mk[r];
-                    const uint32_t ll = lnk32[r];
-                    tbits += __popc(m);
-                    const bool junction = mask_junction(m);
-                    node_t e[2];
-                    uint32_t w2 = 0;
-#pragma unroll
-                    for (unsigned o = 0; o < 2; ++o) {
-                        const unsigned mo = (o ? brev8(m) : m) & 15u;
-                        const uint32_t l = o ? (ll >> 16) : (ll & 0xFFFFu);
-                        uint32_t w = 0xFFFFu;  // no local successor
-                        e[o] = (node_t)mo << TAB_OUT_SHIFT;
-                        if (uniq4(mo)) {
-                            if (l != 0xFFFFu && l < nn) {
-                                e[o] |= 2 * gb + l;
-                                if (!junction) {
-                                    w = l;
-                                    atomicOr(&hp[w >> 5], 1u << (w & 31u));
-                                }
-                            } else {  // not next to it in any super-k-mer of the chunk
-                                e[o] |= TAB_NODE_MASK;
-                                atomicOr(&rm[(2 * r + o) >> 5], 1u << ((2 * r + o) & 31u));
-                            }
-                        }
-                        w2 |= w << (16 * o);
-                    }
-                    lnk32[r] = w2;
-                    __builtin_nontemporal_store(smx_ull2{e[0], e[1]}, reinterpret_cast<smx_ull2 *>(pm.tab + 2 * (gb + r)));
-                }
-                lds_barrier();
+                uint16_t *list = (uint16_t *)stg;  // (two nodes may share a successor: up to nn heads)
                 for (uint32_t i = t; i < WPC; i += NT) pm.rbits[(size_t)cid * WPC + i] = rm[i];
                 for (uint32_t nd = t; nd < nn; nd += NT) {  // chain heads: a local successor, no local predecessor; every other node's jump word is 0
                     if (lnk[nd] != 0xFFFFu && !((hp[nd >> 5] >> (nd & 31u)) & 1u)) list[atomicAdd(&s_nhead, 1u)] = (uint16_t)nd;
                     else __builtin_nontemporal_store(0u, pm.jmp + 2 * gb + nd);
                 }
                 lds_barrier();
+                SKM_T(7)
                 const uint32_t nhead = s_nhead;
                 for (uint32_t i = t; i < nhead; i += NT) {  // every chain once, from its head
                     const uint32_t h = list[i];
@@ -795,7 +804,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
                 }
                 lds_barrier();  // (the next chunk's slots and table go over all of this)
             }
-            SKM_T(7)
+            SKM_T(8)
         }
         if (prof && t == 0) {
             s_pt[4] += 1;
@@ -806,6 +815,7 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
     {
         for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], s_pt[i]);
         atomicAdd(&prof[7], s_pt[7]);
+        atomicAdd(&prof[8], s_pt[8]);
     }
     if constexpr (PM) {
         if (npal) atomicAdd(pm.pals, (unsigned long long)npal);

@@ -56,7 +56,7 @@ def build(force=False):
         if f.endswith((".hip", ".hpp")):
             open(os.path.join(src, f), "w").write(transform(open(os.path.join(CSRC, f)).read()))
     cmd = ["g++", "-std=c++17", "-O1", "-g0", "-fPIC", "-shared", "-pthread", "-x", "c++", "-DEMU_DEFINE_SWITCH", "-Wno-unknown-pragmas", "-Wno-attributes",
-           "-fno-omit-frame-pointer", "-I", HERE, "-include", os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(src, "smx_api.hip"), "-o", LIB]
+           "-fno-omit-frame-pointer", *os.environ.get("EMU_CXXFLAGS", "").split(), "-I", HERE, "-include", os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(src, "smx_api.hip"), "-o", LIB]
     subprocess.check_call(cmd)
     return LIB
 

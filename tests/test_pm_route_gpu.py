@@ -93,6 +93,22 @@ def test_vs_oracle_seeded(k, tmp_path):
         assert _same_kmers(r, old) and r["info"] == old["info"]
 
 
+@pytest.mark.parametrize("opts", [{"pm_fuse_tab": 0}, {"walk_pack": 0}, {"pm_fuse_tab": 0, "walk_pack": 0, "skm_cap": 512}, {"skm_cap": 512}],
+                         ids=lambda o: "-".join(f"{k_}{v_}" for k_, v_ in o.items()))
+def test_node_table_by_the_dedupe_stage_or_afterwards(opts, tmp_path):
+    """round 6: the dedupe stage writes the node table of its chunks from LDS (pm_fuse_tab, default; 0 = link array + k_pm_tab afterwards), and the kept paths get
+    their word offset and edge index from one scan (walk_pack, default; 0 = two arrays, two scans): every combination gives the oracle's graph, record for record the
+    same as the default's — with a tiny chunk capacity too (many chunks, cut partitions, chains that end at a chunk's edge all the time)"""
+    from oracle import oracle
+    for k, threads in ((21, 1), (55, 2), (63, 1)):
+        reads = _synth(13 * k, 5000, 2500, 150, err=0.004) + ["ACGT" * 40] * 3 + ["AT" * 70] * 2 + ["A" * 140] * 4
+        ref = oracle.build_graph(reads, k, 10 * threads)
+        r = _build(reads, k, threads, tmp_path, dict(PM, **opts))
+        assert r["took_pm_route"] and r["unitigs"] == ref["unitigs"] and r["gfa"] == ref["gfa"], (k, opts)
+        d = _build(reads, k, threads, tmp_path, PM)
+        assert _same_kmers(r, d) and r["info"] == d["info"] and r["fp"] == d["fp"]
+
+
 @pytest.mark.parametrize("log2", [12, 13, 16])
 def test_partition_count_does_not_matter(log2, tmp_path):
     """option skm_nkey_log2: the super-k-mer stage starts from 2^12 … 2^16 minimizer partitions (2^16 is the default floor since round 5; 2^24 until then) — on
