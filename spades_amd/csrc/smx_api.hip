@@ -168,6 +168,7 @@ int smx_set_option(smx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "pm_full_retab")) ctx->opt_pm_full_retab = value;
     else if (!strcmp(key, "pm_fuse_tab")) ctx->opt_pm_fuse_tab = value;
     else if (!strcmp(key, "walk_pack")) ctx->opt_walk_pack = value;
+    else if (!strcmp(key, "pm_remote_mirror")) ctx->opt_pm_remote_mirror = value;
     else if (!strcmp(key, "walk_chunk")) ctx->opt_walk_chunk = value;
     else if (!strcmp(key, "walk_start_chunk")) ctx->opt_walk_start_chunk = value;
     else if (!strcmp(key, "walk_hop_bits")) ctx->opt_walk_hop_bits = value;

@@ -1213,6 +1213,7 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
         tend(ctx);
         tbegin(ctx, "keep");
         if (pm) {
+            HIPCHK(hipMemsetAsync(vq, 0, (size_t)(C + 1) * 8, ctx->stream));
             hipLaunchKernelGGL((k_pm_keep<NW>), dim3(cgrid), dim3(BLK), 0, ctx->stream, (const unsigned long long *)cand, (const unsigned long long *)qidx, (uint64_t)C,
                                (const void *)ctx->g_kmers, (const node_t *)tab, k, (const unsigned long long *)len, (const node_t *)first, flags, vq, counters + 1,
                                pm->ix.xs, pack_shift);

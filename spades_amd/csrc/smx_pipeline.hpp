@@ -677,6 +677,7 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     // one genomic locus at coverage 30 is ~46 slots = ~860 instances; deeper coverage grows it linearly. 2048 instances is the fastest
     // geometry (4 workgroups per CU; 1024: 17.7 ms, 4096: 14.0 ms, 2048: 9.6 ms at bench scale); larger only when the data need it.
     uint32_t cap = 2048;
+    double cut_frac = 0.0;  // share of the slots in partitions that the chosen capacity will cut (known where the capacity is chosen from the data)
     if (ctx->opt_skm_cap > 0) {
         cap = 512;
         while (cap < (uint32_t)std::min<int64_t>(ctx->opt_skm_cap, 8192)) cap <<= 1;
@@ -704,6 +705,7 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         for (uint32_t c = 2048, t = 0; c <= 8192 && !pick; c <<= 1, ++t)
             if ((double)hs[2 + t] <= 0.25 * (double)hs[0]) pick = c;
         cap = pick ? pick : 4096;
+        cut_frac = hs[0] ? (double)hs[2 + (cap == 2048 ? 0 : cap == 4096 ? 1 : 2)] / (double)hs[0] : 0.0;
         if (getenv("SMX_DEBUG"))
             fprintf(stderr, "[smx] prededupe: typical partition %.0f slots = %.0f instances; slots in partitions beyond 2048/4096/8192 instances: %.1f%% %.1f%% %.1f%% -> chunk capacity %u\n",
                     typical_slots, typical_inst, hs[0] ? 100.0 * hs[2] / hs[0] : 0.0, hs[0] ? 100.0 * hs[3] / hs[0] : 0.0, hs[0] ? 100.0 * hs[4] / hs[0] : 0.0, cap);
@@ -830,6 +832,10 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
         if (int rc = dalloc(ctx, &P.cinfo, P.max_chunks, false)) return rc;
         if (int rc = dalloc(ctx, &P.mask, out_cap + 16, false)) return rc;
         if (int rc = dalloc(ctx, &P.overflow, 1, false)) return rc;
+        // The node table written by this stage is allocated at the OUTPUT'S CAPACITY before the stage runs (24 B per record where the link array takes 4); the
+        // survivors of cut partitions then need a sort of their own next to it. Data that cut many partitions (skewed abundances, repeats: 20 % of the slots at
+        // bench scale) keep the link array and k_pm_tab — measured: with the table up front such a step lost the route to the memory plan (1 357 against 652 ms).
+        if (P.fuse_tab && cut_frac > 0.02) P.fuse_tab = false;
         if (P.fuse_tab) {  // the stage writes the node table of its chunks itself (PmOut::tab): no link array
             if (int rc = dalloc(ctx, &P.tab, 2 * (size_t)out_cap + 2, false)) return rc;
             if (int rc = dalloc(ctx, &P.jmp, 2 * (size_t)out_cap + 2, false)) return rc;
@@ -903,6 +909,10 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
     }
     if (nn[0] + nn[1] > nwin) return fail(ctx, SMX_DEVICE_ERROR, "pre-deduplication produced %llu records from %llu windows", nn[0] + nn[1], (unsigned long long)nwin);
     if (nn[0] + nn[1] > out_cap) return SMX_RETRY_SMALLER;
+    if (pmode && ctx->pm.tab) {  // the table was allocated for out_cap records: what lies beyond clean + cut survivors goes back before those are sorted
+        arena_shrink(ctx, ctx->pm.tab, (2 * (size_t)(nn[0] + nn[1]) + 2) * 8);
+        arena_shrink(ctx, ctx->pm.jmp, (2 * (size_t)(nn[0] + nn[1]) + 2) * 4);
+    }
     unsigned long long n = nn[0];
     if (nn[1]) {  // survivors of cut keys: sort + unique them on their own, then the whole array is exactly distinct
         // (hash buckets first, like every other count: the cut partitions are the low-complexity and the heavy ones, and by raw key alone

@@ -366,10 +366,17 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
 // a dense loop in which every lane has a lookup — minimizer scan of the successor k-mer, partition table, the other
 // chunk's group word, the record. (Left inside k_pm_tab's per-node loop, nearly every wave paid that path for its few misses: 62 of 80 us
 // per chunk. Round 3 found the marked nodes by scanning the whole node table: 69 GB read for 3 GB of answers.)
+// Round 6, `mode`: a de Bruijn edge u -> v that leaves its chunk is asked for from BOTH ends — u's successor v, and v^1's successor u^1 (the same (k+1)-mer read
+// the other way) — and each answer costs ~5 lines of 128 B (record, partition word, group word, found record, the entry's line): the kernel runs at the fabric's
+// request rate (tools/ubench_random_access.hip: 48 G lines/s whatever the bytes used). So the two ends share ONE lookup: mode 1 answers only for the end that reads
+// the (k+1)-mer in its smaller orientation (its k-mer <= the reverse complement of the successor, as integers — the other end sees the two swapped; equal: a
+// palindrome, both ends are one node) and also writes the entry of v^1 where that one waits for exactly this answer (one outgoing extension, successor pending: v has no
+// other predecessor, so it IS u^1); mode 2 then visits the listed nodes again and looks up what is still pending (the other end was a junction and never asked):
+// N/2 x 6 + N/2 x 1 lines instead of N x 5. mode 0: every listed node, no mirror (the whole table again after an early clipper).
 constexpr int PMR_CH = BLK / 64;
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_pm_remote(PmIndex ix, const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t wpc /* words of rbits per chunk */,
-                                                   const uint32_t *__restrict__ rbits, unsigned k, node_t *tab, uint32_t *err) {
+                                                   const uint32_t *__restrict__ rbits, unsigned k, node_t *tab, uint32_t *err, unsigned mode) {
     __shared__ uint16_t lst[PMR_CH][64 * 32];  // per wave: the marked local nodes of 64 words of its chunk
     const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -393,16 +400,34 @@ __global__ void __launch_bounds__(BLK) k_pm_remote(PmIndex ix, const unsigned lo
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             for (uint32_t i = lane; i < n; i += 64) {
                 const node_t node = 2 * base + my[i];
+                if (mode == 2 && (tab[node] & TAB_NODE_MASK) != TAB_NODE_MASK) continue;  // answered from the other end
                 const Rec<NW> raw = recs[node >> 1];
                 const unsigned m = pm_byte<NW>(ix, raw, node >> 1), o = (unsigned)(node & 1);
                 const unsigned mo = (o ? brev8(m) : m) & 15u;
                 unsigned yo;
-                const Rec<NW> y = pm_succ_kmer<NW>(rec_pure_xs<NW>(raw, ix.xs), k, o, mo, yo);
+                Rec<NW> y;
+                {
+                    const Rec<NW> x0 = rec_pure_xs<NW>(raw, ix.xs), x1 = rec_rc<NW>(x0, k);
+                    const Rec<NW> &fw = o ? x1 : x0, &bw = o ? x0 : x1;
+                    const unsigned c = __ffs(mo) - 1;
+                    const Rec<NW> z = rec_shl<NW>(fw, k, c), zr = rec_shr<NW>(bw, k, 3u - c);  // the successor as this node reads it, and its reverse complement
+                    if (mode == 1 && !rc_ge<NW>(zr, fw)) continue;  // the other end reads the (k+1)-mer in its smaller orientation: it answers for both
+                    const bool minimal = rc_ge<NW>(zr, z);
+                    yo = minimal ? 0u : 1u;
+                    y = minimal ? z : zr;
+                }
                 const node_t ry = pm_find<NW>(ix, y);
                 node_t e = (node_t)mo << TAB_OUT_SHIFT;
                 if (ry == NODE_NONE) atomicAdd(err, 1u);
                 else e |= (ry << 1) | yo;
                 st_pol<4>(tab + node, e);
+                if (mode == 1 && ry != NODE_NONE) {
+                    const node_t mn = ((ry << 1) | yo) ^ 1;  // v^1
+                    if (mn != node) {
+                        const node_t em = tab[mn];
+                        if (uniq4(tab_out4(em)) && (em & TAB_NODE_MASK) == TAB_NODE_MASK) tab[mn] = (em & ~TAB_NODE_MASK) | (node ^ 1);
+                    }
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -780,7 +805,8 @@ __global__ void __launch_bounds__(BLK) k_pm_keep(const unsigned long long *cand,
             flags[i] = fl;
         }
         const bool keep = fl & 1;
-        vq[q[i]] = !keep ? 0ull : (pack_shift ? (((n + 31) / 32) | (1ull << pack_shift)) : ((((n + 31) / 32) << 1) | 1ull));
+        // (vq was cleared: only the kept half of the de-edges touches its line — a scattered 8-byte store is a line of 128 B read and written)
+        if (keep) vq[q[i]] = pack_shift ? (((n + 31) / 32) | (1ull << pack_shift)) : ((((n + 31) / 32) << 1) | 1ull);
         if (keep) inner += (fl & 2) ? (n - k - 1) / 2 : (n - k - 1);  // a self-conjugate path meets every rank twice
     }
     unsigned long long tot;
@@ -863,7 +889,24 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long 
             bo.cur = 0;
         }
         node_t node = ld_pol<3>(first + i);
+        const node_t last_node = ld_pol<3>(last + i);
         unsigned long long p = k + 1;
+        // A path of at most 2k + 1 bases: what follows the start (k+1)-mer are the last n - k - 1 <= k bases of its LAST k-mer, whatever chunks the path crossed —
+        // one record instead of a jump word, a far record and a node entry per chunk (where every few bases of the genome carry a branch and an error's bubble is
+        // k + 1 edges long, that is nearly every path: 7.3 -> ~5 lines of 128 B per kept path).
+        if (n > p && n - p <= k) {
+            const unsigned s = (unsigned)(n - p);
+            const Rec<NW> t = rec_shr_bits<NW>(pm_node_kmer<NW>(recs, last_node, k, xs), 2 * (k - s));
+            unsigned rem = 2 * s;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if (rem) {
+                    const unsigned nb = rem < 64 ? rem : 64;
+                    pm_put(bo, t.w[w], nb);
+                    rem -= nb;
+                }
+            p = n;
+        }
         while (p < n) {
             const uint32_t j = jmp[node];
             const uint32_t s = j >> 16;
@@ -899,7 +942,7 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long 
         {  // one 32-byte record; k_pm_edges spreads it
             smx_ull2 *er = reinterpret_cast<smx_ull2 *>(erec + e);
             st_pol<5>(er, smx_ull2{wo, n});
-            st_pol<5>(er + 1, smx_ull2{cd >> 2, ld_pol<3>(last + i) | ((unsigned long long)((fl >> 1) & 1) << 63)});
+            st_pol<5>(er + 1, smx_ull2{cd >> 2, last_node | ((unsigned long long)((fl >> 1) & 1) << 63)});
         }
     }
 }

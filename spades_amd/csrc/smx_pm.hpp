@@ -288,9 +288,13 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         hipLaunchKernelGGL((k_pm_tab_dirty<NW>), dim3(grid_for(P.ndirty)), dim3(BLK), 0, ctx->stream, pw.ix, (uint64_t)P.ndirty, k, tab, jmp, stats, d_err);
     tend(ctx);
     tbegin(ctx, "pm_remote");
-    if (P.nchunks)
-        hipLaunchKernelGGL((k_pm_remote<NW>), dim3((unsigned)std::min<uint64_t>((P.nchunks + PMR_CH - 1) / PMR_CH, 256 * 32)), dim3(BLK), 0, ctx->stream, pw.ix,
-                           (const unsigned long long *)P.cinfo, P.nchunks, wpc, (const uint32_t *)rbits, k, tab, d_err);
+    if (P.nchunks) {
+        // (an edge that leaves its chunk is answered once for both of its ends, then what is still pending: see k_pm_remote; option pm_remote_mirror = 0: every end asks)
+        const bool mirror = ctx->opt_pm_remote_mirror != 0;
+        for (unsigned mode = mirror ? 1u : 0u; mode <= (mirror ? 2u : 0u); ++mode)
+            hipLaunchKernelGGL((k_pm_remote<NW>), dim3((unsigned)std::min<uint64_t>((P.nchunks + PMR_CH - 1) / PMR_CH, 256 * 32)), dim3(BLK), 0, ctx->stream, pw.ix,
+                               (const unsigned long long *)P.cinfo, P.nchunks, wpc, (const uint32_t *)rbits, k, tab, d_err, mode);
+    }
     tend(ctx);
     ctx->stream = main_stream;
     if (hipGetLastError() != hipSuccess) {
@@ -384,7 +388,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         tbegin(ctx, "pm_remote");
         if (P.nchunks)
             hipLaunchKernelGGL((k_pm_remote<NW>), dim3((unsigned)std::min<uint64_t>((P.nchunks + PMR_CH - 1) / PMR_CH, 256 * 32)), dim3(BLK), 0, ctx->stream, pw.ix,
-                               (const unsigned long long *)P.cinfo, P.nchunks, wpc, (const uint32_t *)rbits, k, tab, d_err);
+                               (const unsigned long long *)P.cinfo, P.nchunks, wpc, (const uint32_t *)rbits, k, tab, d_err, 0u);
         tend(ctx);
         if (hipGetLastError() != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "k_pm_tab launch failed");
         if (last) {  // 5 B per k-mer of local links and unclipped masks + the remote bits: back to the arena before the walks' arrays are asked for
