@@ -104,7 +104,11 @@ const char *smx_version(void);
  *   (k+1)-mer file), "pm_route" (-1 / 1: where "ext_route" applies and no early clipper is asked for, the construction does not sort
  *   the k-mers at all — nodes are numbered by minimizer partition, only the junction k-mers are put into k-mer-file order to number
  *   the unitigs, and the sorted k-mer file is made the first time smx_copy_final_kmers / smx_bucket_sizes / smx_graph_copy_kmers ask
- *   for it; 0: the k-mers are sorted first, as in the reference).
+ *   for it; 0: the k-mers are sorted first, as in the reference). The early clippers run on that route too since round 6 ("pm_full_retab" = 1: the whole
+ *   node table is made again after an edit instead of the edited k-mers' entries). "pm_fuse_tab" (1: the dedupe stage writes the node table of its chunks from
+ *   LDS; 0: link array + a pass of its own afterwards — what data that cut many partitions get either way), "walk_pack" (1: word offset and edge index of the
+ *   kept paths from one scan), "pm_remote_mirror" (1: a successor outside its chunk is looked up from one end of the edge for both), "pm_overlap" (1: the
+ *   successor table on a side stream beside the junction order) — measured variants of that route's kernels.
  * SMX_OPTS="key=value,..." in the environment applies options to every new context.
  *
  * HBM budget (smx_create): the context never holds more device memory than hbm_budget_bytes (0 = what the device has). A count whose

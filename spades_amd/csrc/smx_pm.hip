@@ -109,6 +109,7 @@ __device__ __forceinline__ Rec<NW> pm_node_kmer(const Rec<NW> *__restrict__ recs
     return (node & 1) ? rec_rc<NW>(x, k) : x;
 }
 
+__device__ __forceinline__ uint32_t pm_jump_steps(uint32_t j) { return (j >> 16) & 0x7FFFu; }  // (bit 31 of a jump word: its far end is a junction, see k_pm_tab)
 // the early clippers' view of the graph on this route (FileFind in smx_graph.hip is the other one): index = place in the partition-major records
 template <int NW>
 struct PmFind {
@@ -124,7 +125,7 @@ struct PmFind {
     // ~6 chunks: a dozen sectors instead of 95 dependent ones per branch.
     __device__ __forceinline__ node_t advance(const node_t *__restrict__ tab, const uint8_t *__restrict__ mask, node_t nd, uint32_t &cnt, uint32_t bound) const {
         while (cnt < bound && !mask_junction(mask[nd >> 1])) {
-            const uint32_t j = jmp[nd], s = j >> 16;
+            const uint32_t j = jmp[nd], s = pm_jump_steps(j);
             if (s) {
                 if (cnt + s > bound) {  // the loop would stop on an interior k-mer of this chain: any of them tells the caller "not a tip"
                     cnt = bound;
@@ -146,7 +147,7 @@ struct PmFind {
     __device__ __forceinline__ void isolate_tip(const node_t *__restrict__ tab, node_t nd, uint32_t len, uint8_t *isolate, uint8_t *hmark) const {
         uint32_t left = len;
         while (left) {
-            const uint32_t j = jmp[nd], s = j >> 16;
+            const uint32_t j = jmp[nd], s = pm_jump_steps(j);
             if (s && s + 1 <= left) {
                 hmark[nd] = 1;
                 left -= s + 1;
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(BLK) k_pm_isolate_chains(const unsigned long l
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += BLK) {
             uint32_t cur = list[i];
-            const uint32_t s = jmp[2 * base + cur] >> 16;
+            const uint32_t s = pm_jump_steps(jmp[2 * base + cur]);
             isolate[base + (cur >> 1)] = 1;
             for (uint32_t t = 0; t < s && cur != 0xFFFFFFFFu; ++t) {
                 cur = ls[cur];
@@ -198,7 +199,9 @@ __global__ void __launch_bounds__(BLK) k_pm_isolate_chains(const unsigned long l
     }
 }
 
-// Jump words: jmp[node] = (delta to the last node of the chain that stays inside the node's chunk, 16 bits signed) | steps << 16.
+// Jump words: jmp[node] = (delta to the last node of the chain that stays inside the node's chunk, 16 bits signed) | steps << 16 (15 bits) | bit 31: that last node
+// is a junction BY THE MASKS THE TABLE WAS MADE ON — a walk that reads the word need not read the far end's node entry to learn that its path ends there
+// (k_pm_walk_len; ignored where an early clipper has edited the masks since, PmIndex::bym).
 // A walk that enters a chunk reads ONE word to cross it (smx_pm_walk_len) instead of one node-table entry per k-mer.
 constexpr uint16_t PM_ADV_NONE = 0xFFFFu;
 
@@ -336,12 +339,13 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
             const uint32_t h = list[i];
             uint32_t cur = h, st = 0;
             for (uint32_t a; (a = jw[cur] & 0xFFFFu) != 0xFFFFu && st < nn; ++st) cur = a;
-            jw[h] = (((cur - h) & 0xFFFFu) | (st << 16)) | 0x80000000u;  // (bit 31 marks the word as a result; st <= nn < 2^15)
+            // (bit 31 marks the word as a result; st <= nn < 2^15; bit 30 here = the far end is a junction, moved to bit 31 of the word that is stored)
+            jw[h] = (((cur - h) & 0xFFFFu) | (st << 16)) | 0x80000000u | (mask_junction(mask[base + (cur >> 1)]) ? 0x40000000u : 0u);
         }
         __syncthreads();
         for (uint32_t nd = threadIdx.x; nd < nn; nd += BLK) {
             const uint32_t v = jw[nd];
-            __builtin_nontemporal_store((v & 0x80000000u) ? (v & 0x7FFFFFFFu) : 0u, jmp + 2 * base + nd);
+            __builtin_nontemporal_store((v & 0x80000000u) ? ((v & 0x3FFFFFFFu) | ((v & 0x40000000u) << 1)) : 0u, jmp + 2 * base + nd);
         }
         if (prof && threadIdx.x == 0) {
             pc[1] += nhead;
@@ -739,10 +743,12 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
         for (;;) {
             const uint32_t j = jmp[node];  // to the end of the chain inside this chunk: non-junction k-mers all the way, the last one may be a junction
             node = (node_t)((long long)node + (long long)(int16_t)(j & 0xFFFFu));
-            steps += j >> 16;
+            steps += pm_jump_steps(j);
             node_t nx;
             unsigned nuc;
-            if (node >= n_nodes || !tab_step(tab, node, nx, nuc)) break;  // a junction ends the path
+            if (node >= n_nodes) break;
+            if ((j >> 31) && !ix.bym) break;  // the word says so: the chain's last node is a junction — the path ends there, its node entry is not read
+            if (!tab_step(tab, node, nx, nuc)) break;  // a junction ends the path
             node = nx;
             if (++steps > n_nodes || node >= n_nodes) {  // cannot happen on a consistent index; never hang the GPU or leave the arrays
                 node = n_nodes;
@@ -909,7 +915,7 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_write(const unsigned long long 
         }
         while (p < n) {
             const uint32_t j = jmp[node];
-            const uint32_t s = j >> 16;
+            const uint32_t s = pm_jump_steps(j);
             const node_t far = (node_t)((long long)node + (long long)(int16_t)(j & 0xFFFFu));
             if (s) {
                 if (s <= k && p + s <= n) {

@@ -800,7 +800,8 @@ __global__ void __launch_bounds__(NT, SMX_WPE) k_skm_dedupe2(const uint64_t *__r
                     const uint32_t h = list[i];
                     uint32_t cur = h, st = 0;
                     for (uint32_t a; (a = lnk[cur]) != 0xFFFFu && st < nn; ++st) cur = a;
-                    __builtin_nontemporal_store(((cur - h) & 0xFFFFu) | (st << 16), pm.jmp + 2 * gb + h);
+                    // (bit 31: the chain's last node is a junction — k_pm_walk_len then ends its path there without reading that node's entry; smx_pm.hip)
+                    __builtin_nontemporal_store(((cur - h) & 0xFFFFu) | (st << 16) | (mask_junction(mk[cur >> 1]) ? 0x80000000u : 0u), pm.jmp + 2 * gb + h);
                 }
                 lds_barrier();  // (the next chunk's slots and table go over all of this)
             }
