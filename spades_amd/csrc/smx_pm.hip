@@ -702,8 +702,10 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
     const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
     for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < C; i += (uint64_t)gridDim.x * BLK) {
         const unsigned long long cd = ld_pol<3>(cand + i);
-        const Rec<NW> x = pm_node_kmer<NW>(recs, cd >> 2, k, ix.xs);
-        unsigned yo;
+        const Rec<NW> jraw = recs[cd >> 3];
+        const Rec<NW> jk = rec_pure_xs<NW>(jraw, ix.xs);
+        const Rec<NW> x = ((cd >> 2) & 1) ? rec_rc<NW>(jk, k) : jk;
+        unsigned yo = 0;
         const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, (unsigned)(cd & 3)), k, yo);
         // the first k-mer of the path: in the junction's own chunk 19 times in 20 (no minimizer scan, group word and record next to
         // what the neighbouring lanes read), else through the partition table
@@ -711,7 +713,20 @@ __global__ void __launch_bounds__(BLK) k_pm_walk_len(const unsigned long long *c
         const uint64_t rj = cd >> 3;
         Rec<NW> yraw;
         bool have_raw = false;
-        if (rj < ix.nclean) {
+        // ... unless this orientation of the junction k-mer has ONE outgoing extension (a join, a tip's start: a third of the start de-edges): its node entry
+        // holds that successor like any other node's (one line, shared with the entry of the other orientation, instead of a group word and a record)
+        node_t from_tab = NODE_NONE;
+        if (ix.xs && !ix.bym) {
+            const unsigned mj = (unsigned)(jraw.w[NW - 1] & 0xFFu);
+            if (uniq4((((cd >> 2) & 1) ? brev8(mj) : mj) & 15u)) {
+                const node_t e = tab[cd >> 2] & TAB_NODE_MASK;
+                if (e != TAB_NODE_MASK && e < n_nodes) from_tab = e;
+            }
+        }
+        if (from_tab != NODE_NONE) {
+            ry = from_tab >> 1;
+            yo = (unsigned)(from_tab & 1);
+        } else if (rj < ix.nclean) {
             uint64_t cbase;
             const uint32_t cid = pm_chunk_of(cinfo, cob, nchunks, rj, cbase);
             ry = pm_probe<NW>(recs, ix.meta + (size_t)cid * ix.ngroups, ix.T, cbase, y, rec_hash32<NW>(y), ix.xs, &yraw);
