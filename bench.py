@@ -725,9 +725,11 @@ def main():
             b_tab = 0 if fused_tab else D0 * (1 + 4) + 2 * D0 * 8 + 2 * D0 * 4  # (fused: written by the count pipeline's dedupe stage, priced there)
             b_rem = 2 * D0 * 8 + 0.1 * 2 * D0 * (W + 8 + 4 + W + 8)
             b_junc = 2 * D0 + nj_ * (2 * W + 8) + 3 * nj_ * W + nj_ * (2 * W + 1) + nj_ * (W + 24) + nc_ * 16  # masks scanned twice; junction records gathered, sorted (w + r + w), split, looked up; de-edges listed
-            b_wlen = nc_ * (8 + 2 * W + 4 + 3 * (4 + 16) + W + 8 * 3 + 1)
-            b_keep = nc_ * (8 + 8 + 8 + 1 + 8) + 4 * nc_ * 16  # keep pass + the two scans of the kept words / edge indices
-            b_wwr = ne * (8 * 6 + W + 3 * (4 + W + 16) + 32) + nbases / 4
+            # (round 6, second half: the walks need fewer bytes than round 5's — a jump word says when its chain ends at a junction, a path of <= 2k+1 bases is
+            # written from its start and its LAST record alone, one scan places the kept paths — and the formulas follow the kernels down, not the other way round)
+            b_wlen = nc_ * (8 + 2 * W + 4 + (4 + 8) + W + 8 * 3 + 1)  # de-edge word, junction record, group word + probed record, jump word + one node entry, last record, length / first / last / flag
+            b_keep = nc_ * (8 + 8 + 8 + 1) + nc_ * 8 + ne * 8 + 2 * nc_ * 8  # keep pass (the array of places cleared, the kept half written) + ONE scan of it
+            b_wwr = ne * (8 * 5 + W + W + 8 + 32) + nbases / 4  # bookkeeping words, start record, last record, place word, edge record; 2 bits per base
             b_links = 4 * 2 * ne * 16
             b_con = b_tab + b_rem + b_junc + b_wlen + b_keep + b_wwr + b_links
             b_con_formula = ("route 0, sum of its kernels' own bytes: successor table %.1f + successors outside their chunk %.1f + junction order %.1f + walk lengths %.1f + "
@@ -771,10 +773,10 @@ def main():
             "pm_tab": ("smx::k_pm_tab", "k_pm_tab", D0 * (1 + 4) + 2 * D0 * 8 + 2 * D0 * 4, "mask byte + link word read, two node-table entries and two jump words written per k-mer"),
             "pm_remote": ("smx::k_pm_remote", "k_pm_remote", 2 * D0 * 8 + 0.1 * 2 * D0 * (W + 8 + 4 + W + 8),
                           "node table scanned; per successor outside its chunk (~5 % of the nodes) the record, the partition word, a group word and the found record read, the entry written"),
-            "walk_len": ("smx::k_pm_walk_len", "k_pm_walk_len", n_cand * (8 + 2 * W + 4 + 3 * (4 + 16) + W + 8 * 3 + 1),
-                         "per start de-edge: its junction record, the first k-mer's group word and record, ~3 chunks crossed (jump word + node-table entry), the last record; length, first, last, flag written"),
-            "walk_write": ("smx::k_pm_walk_write", "k_pm_walk_write", ne * (8 * 6 + W + 3 * (4 + W + 16) + 32) + nbases / 4,
-                           "per kept path: its bookkeeping words, the start record, ~3 chunks crossed (jump word, far record, node-table entry), 2 bits per base and a 32-byte edge record written"),
+            "walk_len": ("smx::k_pm_walk_len", "k_pm_walk_len", n_cand * (8 + 2 * W + 4 + (4 + 8) + W + 8 * 3 + 1),
+                         "per start de-edge: its junction record, the first k-mer's group word and record, a jump word and one node-table entry, the last record; length, first, last, flag written"),
+            "walk_write": ("smx::k_pm_walk_write", "k_pm_walk_write", ne * (8 * 5 + W + W + 8 + 32) + nbases / 4,
+                           "per kept path: its bookkeeping words, the start record, the last record (a path of <= 2k+1 bases needs no other), its place word; 2 bits per base and a 32-byte edge record written"),
         }
         cand_st = [(st_, ms_) for st_, ms_ in stages.items() if st_ in single]
         if cand_st:
