@@ -906,20 +906,26 @@ constexpr int CAND_TILE = BLK * CAND_PER;
 __device__ __forceinline__ unsigned cand_of_mask(unsigned m) { return mask_junction(m) ? (unsigned)(__popc(m & 15) + __popc(m >> 4)) : 0u; }
 __global__ void __launch_bounds__(BLK) k_cand_tiles(const uint8_t *mask, uint64_t D0, unsigned long long *tcnt, unsigned long long *njunction,
                                                     unsigned long long *tjcnt /* nullable: junction k-mers of every tile */) {
-    __shared__ uint32_t scratch[BLK / 64 + 2];
+    __shared__ unsigned long long scratch[BLK / 64 + 2];
     const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
     uint32_t c = 0, j_ = 0, jz = 0;
+    static_assert(CAND_PER == 8, "a thread's masks are one 8-byte word");
+    // (the thread's 8 bytes as ONE load where all of them exist, and the three counts through ONE block scan — 21 bits each: a tile has 2048 k-mers of at most 8 de-edges)
+    uint64_t mm = 0;
+    if (r0 + CAND_PER <= D0) mm = *reinterpret_cast<const uint64_t *>(mask + r0);
+    else
+        for (int j = 0; j < CAND_PER; ++j)
+            if (r0 + j < D0) mm |= (uint64_t)mask[r0 + j] << (8 * j);
     for (int j = 0; j < CAND_PER; ++j)
         if (r0 + j < D0) {
-            const unsigned m = mask[r0 + j];
+            const unsigned m = (unsigned)(mm >> (8 * j)) & 0xFFu;
             c += cand_of_mask(m);
             j_ += mask_junction(m) ? 1u : 0u;
             jz += m ? 0u : 1u;  // isolated k-mers (an early clipper removed their tip): junction k-mers by the mask rule, without a single de-edge
         }
-    uint32_t tot, jt, zt;
-    block_excl_scan<uint32_t>(c, scratch, &tot);
-    block_excl_scan<uint32_t>(j_, scratch, &jt);
-    block_excl_scan<uint32_t>(jz, scratch, &zt);
+    unsigned long long all;
+    block_excl_scan<unsigned long long>((unsigned long long)c | ((unsigned long long)j_ << 21) | ((unsigned long long)jz << 42), scratch, &all);
+    const uint32_t tot = (uint32_t)(all & 0x1FFFFFu), jt = (uint32_t)((all >> 21) & 0x1FFFFFu), zt = (uint32_t)(all >> 42);
     if (threadIdx.x == 0) {
         tcnt[blockIdx.x] = tot;
         if (tjcnt) tjcnt[blockIdx.x] = jt - zt;  // (route 0 numbers the de-edges through the junction k-mers that HAVE some: smx_pm.hip, k_pm_junc_write)

@@ -585,11 +585,18 @@ __global__ void __launch_bounds__(BLK) k_pm_junc_write(const uint8_t *mask, cons
     Rec<NW> *out = (Rec<NW> *)out_;
     const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
     uint32_t c = 0, fl = 0;
-    for (int j = 0; j < CAND_PER; ++j)
-        if (r0 + j < D0 && mask[r0 + j] && mask_junction(mask[r0 + j])) {  // (a k-mer with mask 0 — isolated by an early clipper — starts nothing: not listed, as k_cand_tiles counts)
+    uint64_t mm = 0;  // (the thread's 8 bytes as one load where all of them exist)
+    if (r0 + CAND_PER <= D0) mm = *reinterpret_cast<const uint64_t *>(mask + r0);
+    else
+        for (int j = 0; j < CAND_PER; ++j)
+            if (r0 + j < D0) mm |= (uint64_t)mask[r0 + j] << (8 * j);
+    for (int j = 0; j < CAND_PER; ++j) {
+        const unsigned m = (unsigned)(mm >> (8 * j)) & 0xFFu;
+        if (r0 + j < D0 && m && mask_junction(m)) {  // (a k-mer with mask 0 — isolated by an early clipper — starts nothing: not listed, as k_cand_tiles counts)
             fl |= 1u << j;
             ++c;
         }
+    }
     uint32_t tot;
     unsigned long long o = tjoff[blockIdx.x] + block_excl_scan<uint32_t>(c, scratch, &tot);
     for (int j = 0; j < CAND_PER; ++j)
