@@ -14,6 +14,7 @@ c = b["construct"]
 rs = c["route_stats"]
 n_reads, L, nw, W = b["config"]["reads_per_gpu"], 150, 2, 16
 D0, nslots, nchunks, n_cand, ne, nbases = c["n_kmers"], rs["superkmer_slots"], rs["chunks"], rs["start_de_edges"], c["n_unitigs"], c["unitig_bases"]
+fused = st.get("pm_tab", 99.0) < 0.25 * st.get("pm_remote", 1.0)  # round 6: the dedupe stage wrote the node table of the clean chunks (pm_fuse_tab)
 pmc = {}
 for line in open(os.path.join(d, "config3_pm_pmc_hbm_traffic.csv")):
     f = line.strip().rsplit(",", 5)
@@ -25,13 +26,14 @@ for line in open(os.path.join(d, "config3_pm_pmc_hbm_traffic.csv")):
 rows = [  # stage, kernel substring in the PMC table, algorithmic bytes, unit the bytes are per, what bounds it (SQ counters)
     ("kmers:mark_windows", "k_mark_windows", n_reads * 12 + n_reads * L / 8 * 2, "12 B (start, len) per read in, 2 bits per position out", "HBM (streaming)"),
     ("kmers:skm_count", "k_skm_scan", n_reads * L / 4 + n_reads * 12 + nslots * (8 * 2 * nw + 8) + nslots * 16, "37.5 B per read in; 56 B per super-k-mer out (staged slot, partition word, counter)", "VALU issue + counting atomics"),
-    ("kmers:skm_scatter", "k_skm_permute", nslots * (2 * 8 * 2 * nw + 8 + 8), "80 B per super-k-mer (staged slot in, slot out, two words)", "random 32-B writes (64-B sectors)"),
+    ("kmers:skm_scatter", "k_skm_permute", nslots * (2 * 8 * 2 * nw + 8 + 8), "80 B per super-k-mer (staged slot in, slot out, two words)", "requests: one line for the partition's offset, one filled for the 32-B slot (~48 G lines/s)"),
     ("kmers:skm_plan", "k_skm_plan", nslots * 8 * 2 * nw + nchunks * 16, "32 B per slot in, 16 B per chunk out", "latency of the slot loads"),
-    ("kmers:skm_dedupe", "k_skm_dedupe2", nslots * 8 * 2 * nw + D0 * (W + 1 + 4) + nchunks * 4 * 256, "32 B per slot in; 21 B per distinct k-mer out; 1 KB per chunk", "VALU issue (LDS hash inserts)"),
-    ("pm_tab", "k_pm_tab", D0 * (1 + 4) + 2 * D0 * 8 + 2 * D0 * 4, "5 B per k-mer in, 24 B out (two node entries, two jump words)", "HBM writes"),
-    ("pm_remote", "k_pm_remote", 2 * D0 * 8 + 0.1 * 2 * D0 * (W + 8 + 4 + W + 8), "16 B per k-mer scanned + 52 B per successor outside its chunk (5 %)", "random 64-B sectors"),
-    ("walk_len", "k_pm_walk_len", n_cand * (8 + 2 * W + 4 + 3 * (4 + 16) + W + 8 * 3 + 1), "145 B per start de-edge (records, ~3 jump words + node entries, results)", "random 64-B sectors"),
-    ("walk_write", "k_pm_walk_write", ne * (8 * 6 + W + 3 * (4 + W + 16) + 32) + nbases / 4, "204 B per kept path + 2 bits per base", "random 64-B sectors"),
+    ("kmers:skm_dedupe", "k_skm_dedupe2", nslots * 8 * 2 * nw + D0 * (W + 1 + (24 if fused else 4)) + nchunks * 4 * (512 if fused else 256),
+     ("32 B per slot in; 41 B per distinct k-mer out (record, byte, two node entries, two jump words); 2 KB per chunk" if fused else "32 B per slot in; 21 B per distinct k-mer out; 1 KB per chunk"), "VALU issue + LDS round trips (hash inserts; the node table of the chunk)"),
+    ("pm_tab", "k_pm_tab", (0 if fused else D0 * (1 + 4) + 2 * D0 * 8 + 2 * D0 * 4), ("the cut partitions' tail only (k_pm_tab_dirty): the clean chunks' table leaves the dedupe stage" if fused else "5 B per k-mer in, 24 B out (two node entries, two jump words)"), "HBM writes"),
+    ("pm_remote", "k_pm_remote", 2 * D0 * 8 + 0.1 * 2 * D0 * (W + 8 + 4 + W + 8), "16 B per k-mer scanned + 52 B per successor outside its chunk (5 %)", "requests (~5 lines of 128 B per lookup at ~48 G lines/s)"),
+    ("walk_len", "k_pm_walk_len", n_cand * (8 + 2 * W + 4 + (4 + 8) + W + 8 * 3 + 1), "97 B per start de-edge (junction record, group word + probed record, jump word + node entry, last record, results)", "requests (~5.5 lines per start de-edge)"),
+    ("walk_write", "k_pm_walk_write", ne * (8 * 5 + W + W + 8 + 32) + nbases / 4, "112 B per kept path (bookkeeping, start and last record, place word, edge record) + 2 bits per base", "requests (~5 lines per kept path)"),
 ]
 tot_ms = b["ms_per_step"]
 print("| kernel | ms / step | % of step | algorithmic GB (per unit) | alg. GB/s (frac of 8 TB/s) | PMC fetch + write GB | moved GB/s | bound by |")
