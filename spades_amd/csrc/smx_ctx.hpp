@@ -85,7 +85,7 @@ struct smx_ctx {
     hipStream_t copy_stream = nullptr;  // uploads of asynchronous submissions
     hipStream_t side_stream = nullptr;  // construction, route 0: the successor table (k_pm_tab, k_pm_remote) runs here while the junction k-mers are sorted on `stream`
     int64_t opt_pm_fuse_tab = 1;        // route 0: 1 = the dedupe stage writes the node table of its chunks from LDS (no link array, no k_pm_tab pass over the clean chunks); 0 = k_pm_tab afterwards
-    int64_t opt_pm_remote_mirror = 0;   // route 0: 1 = a successor outside its chunk is looked up from one end of the edge for both (k_pm_remote modes 1 + 2), 0 = from each end (default: measured no gain, 46.3-48.3 against 44.7 ms — half-empty waves in the first pass, a second scan of the lists)
+    int64_t opt_pm_remote_mirror = 1;   // route 0: 1 = a successor outside its chunk is looked up from one end of the edge for both (k_pm_remote modes 1 + 2), 0 = from each end. (Measured: without the per-wave queue no gain — half-empty waves; with it 41.5-41.8 against 43.8-44.3 ms)
     int64_t opt_walk_pack = 1;          // route 0: 1 = word offset and edge index of the kept paths from one scan, packed in one word (smx_construct.hpp)
     int64_t opt_pm_full_retab = 0;      // route 0 with early clippers: 1 = the whole node table is made again after an edit (k_pm_tab + k_pm_remote), 0 = the edited k-mers' entries only
     int64_t opt_pm_overlap = 0;         // ... 1: measured (profiles/r06/bench_config3_successor_table_on_side_stream.json): side by side both get slower by what the

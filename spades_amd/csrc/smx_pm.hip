@@ -376,15 +376,45 @@ __global__ void __launch_bounds__(BLK) k_pm_tab(const unsigned long long *__rest
 // the (k+1)-mer in its smaller orientation (its k-mer <= the reverse complement of the successor, as integers — the other end sees the two swapped; equal: a
 // palindrome, both ends are one node) and also writes the entry of v^1 where that one waits for exactly this answer (one outgoing extension, successor pending: v has no
 // other predecessor, so it IS u^1); mode 2 then visits the listed nodes again and looks up what is still pending (the other end was a junction and never asked):
-// N/2 x 6 + N/2 x 1 lines instead of N x 5. mode 0: every listed node, no mirror (the whole table again after an early clipper).
+// N/2 x 6 + N/2 x 1 lines instead of N x 5 on paper; measured 41.5-41.8 against 43.8-44.3 ms once the lookups are worked off a queue (below; without it the first pass ran
+// half-empty waves and the second scanned full lists: no gain). mode 0: every listed node, no mirror (the whole table again after an early clipper; option pm_remote_mirror = 0).
 constexpr int PMR_CH = BLK / 64;
+// One lookup (lane `lane` of a full batch): the successor k-mer of `node` through the partition table, its entry written; mode 1: the other end's entry too.
+template <int NW>
+__device__ __forceinline__ void pm_remote_one(const PmIndex &ix, const Rec<NW> *__restrict__ recs, node_t node, unsigned k, node_t *tab, uint32_t *err, unsigned mode) {
+    const Rec<NW> raw = recs[node >> 1];
+    const unsigned m = pm_byte<NW>(ix, raw, node >> 1), o = (unsigned)(node & 1);
+    const unsigned mo = (o ? brev8(m) : m) & 15u;
+    unsigned yo;
+    const Rec<NW> y = pm_succ_kmer<NW>(rec_pure_xs<NW>(raw, ix.xs), k, o, mo, yo);
+    const node_t ry = pm_find<NW>(ix, y);
+    node_t e = (node_t)mo << TAB_OUT_SHIFT;
+    if (ry == NODE_NONE) atomicAdd(err, 1u);
+    else e |= (ry << 1) | yo;
+    st_pol<4>(tab + node, e);
+    if (mode == 1 && ry != NODE_NONE) {
+        const node_t mn = ((ry << 1) | yo) ^ 1;  // v^1
+        if (mn != node) {
+            const node_t em = tab[mn];
+            if (uniq4(tab_out4(em)) && (em & TAB_NODE_MASK) == TAB_NODE_MASK) tab[mn] = (em & ~TAB_NODE_MASK) | (node ^ 1);
+        }
+    }
+}
+// Round 6: the marked nodes of a chunk's window are ~46 (half of them in mode 1): handled window by window they left a quarter to two thirds of a wave's lanes
+// idle through five dependent memory round trips. The wave now QUEUES the nodes that need a lookup (mode 0: all; mode 1: the owning ends, their bit cleared in
+// rbits so that mode 2 lists the others only; mode 2: the listed nodes whose entry is still pending) and works the queue off 64 at a time, across windows and chunks.
 template <int NW>
 __global__ void __launch_bounds__(BLK) k_pm_remote(PmIndex ix, const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t wpc /* words of rbits per chunk */,
-                                                   const uint32_t *__restrict__ rbits, unsigned k, node_t *tab, uint32_t *err, unsigned mode) {
+                                                   uint32_t *rbits, unsigned k, node_t *tab, uint32_t *err, unsigned mode) {
     __shared__ uint16_t lst[PMR_CH][64 * 32];  // per wave: the marked local nodes of 64 words of its chunk
+    __shared__ unsigned long long qs[PMR_CH][128];  // per wave: nodes waiting for their lookup
+    __shared__ uint32_t wbs[PMR_CH][64];            // per wave (mode 1): the window's words without the owning ends
     const Rec<NW> *recs = (const Rec<NW> *)ix.recs;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint16_t *my = lst[wave];
+    unsigned long long *q = qs[wave];
+    uint32_t *wb = wbs[wave];
+    uint32_t qn = 0;  // (the same in every lane)
     for (uint32_t cid = blockIdx.x * PMR_CH + wave; cid < nchunks; cid += gridDim.x * PMR_CH) {  // (a wave per chunk: no workgroup barrier in here)
         const uint64_t base = cinfo[cid] & PM_BASE_MASK;
         for (uint32_t w0 = 0; w0 < wpc; w0 += 64) {
@@ -400,43 +430,46 @@ __global__ void __launch_bounds__(BLK) k_pm_remote(PmIndex ix, const unsigned lo
             const uint32_t n = __shfl(inc, 63, 64);
             uint32_t at = inc - cnt;
             for (uint32_t b = bits; b; b &= b - 1) my[at++] = (uint16_t)(w * 32u + (uint32_t)__ffs(b) - 1u);
+            if (mode == 1) wb[lane] = bits;
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            for (uint32_t i = lane; i < n; i += 64) {
-                const node_t node = 2 * base + my[i];
-                if (mode == 2 && (tab[node] & TAB_NODE_MASK) != TAB_NODE_MASK) continue;  // answered from the other end
-                const Rec<NW> raw = recs[node >> 1];
-                const unsigned m = pm_byte<NW>(ix, raw, node >> 1), o = (unsigned)(node & 1);
-                const unsigned mo = (o ? brev8(m) : m) & 15u;
-                unsigned yo;
-                Rec<NW> y;
-                {
+            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const uint32_t id = i < n ? my[i] : 0u;
+                const node_t node = 2 * base + id;
+                bool want = i < n;
+                if (want && mode == 2) want = (tab[node] & TAB_NODE_MASK) == TAB_NODE_MASK;  // (else: answered from the other end)
+                if (want && mode == 1) {
+                    // the end that reads the (k+1)-mer in its smaller orientation answers for both (see above)
+                    const Rec<NW> raw = recs[node >> 1];
+                    const unsigned m = pm_byte<NW>(ix, raw, node >> 1), o = (unsigned)(node & 1);
+                    const unsigned c = __ffs((o ? brev8(m) : m) & 15u) - 1;
                     const Rec<NW> x0 = rec_pure_xs<NW>(raw, ix.xs), x1 = rec_rc<NW>(x0, k);
-                    const Rec<NW> &fw = o ? x1 : x0, &bw = o ? x0 : x1;
-                    const unsigned c = __ffs(mo) - 1;
-                    const Rec<NW> z = rec_shl<NW>(fw, k, c), zr = rec_shr<NW>(bw, k, 3u - c);  // the successor as this node reads it, and its reverse complement
-                    if (mode == 1 && !rc_ge<NW>(zr, fw)) continue;  // the other end reads the (k+1)-mer in its smaller orientation: it answers for both
-                    const bool minimal = rc_ge<NW>(zr, z);
-                    yo = minimal ? 0u : 1u;
-                    y = minimal ? z : zr;
+                    want = rc_ge<NW>(rec_shr<NW>(o ? x0 : x1, k, 3u - c), o ? x1 : x0);
+                    if (want) atomicAnd(&wb[(id >> 5) - w0], ~(1u << (id & 31u)));
                 }
-                const node_t ry = pm_find<NW>(ix, y);
-                node_t e = (node_t)mo << TAB_OUT_SHIFT;
-                if (ry == NODE_NONE) atomicAdd(err, 1u);
-                else e |= (ry << 1) | yo;
-                st_pol<4>(tab + node, e);
-                if (mode == 1 && ry != NODE_NONE) {
-                    const node_t mn = ((ry << 1) | yo) ^ 1;  // v^1
-                    if (mn != node) {
-                        const node_t em = tab[mn];
-                        if (uniq4(tab_out4(em)) && (em & TAB_NODE_MASK) == TAB_NODE_MASK) tab[mn] = (em & ~TAB_NODE_MASK) | (node ^ 1);
-                    }
+                const unsigned long long wm = __ballot(want);
+                if (want) q[qn + __popcll(wm & ((1ull << lane) - 1ull))] = node;
+                qn += (uint32_t)__popcll(wm);
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (qn >= 64) {  // a full wave of lookups
+                    pm_remote_one<NW>(ix, recs, q[lane], k, tab, err, mode);
+                    const unsigned long long rest = lane + 64 < qn ? q[lane + 64] : 0ull;
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane + 64 < qn) q[lane] = rest;
+                    qn -= 64;
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
             }
+            if (mode == 1 && w < wpc && wb[lane] != bits) rbits[(size_t)cid * wpc + w] = wb[lane];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if (lane < qn) pm_remote_one<NW>(ix, recs, q[lane], k, tab, err, mode);  // what is left in the queue
 }
 // ... and of the dirty region: every successor through the partition table; no jumps (delta 0, 0 steps)
 template <int NW>

@@ -293,7 +293,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         const bool mirror = ctx->opt_pm_remote_mirror != 0;
         for (unsigned mode = mirror ? 1u : 0u; mode <= (mirror ? 2u : 0u); ++mode)
             hipLaunchKernelGGL((k_pm_remote<NW>), dim3((unsigned)std::min<uint64_t>((P.nchunks + PMR_CH - 1) / PMR_CH, 256 * 32)), dim3(BLK), 0, ctx->stream, pw.ix,
-                               (const unsigned long long *)P.cinfo, P.nchunks, wpc, (const uint32_t *)rbits, k, tab, d_err, mode);
+                               (const unsigned long long *)P.cinfo, P.nchunks, wpc, rbits, k, tab, d_err, mode);
     }
     tend(ctx);
     ctx->stream = main_stream;
@@ -388,7 +388,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         tbegin(ctx, "pm_remote");
         if (P.nchunks)
             hipLaunchKernelGGL((k_pm_remote<NW>), dim3((unsigned)std::min<uint64_t>((P.nchunks + PMR_CH - 1) / PMR_CH, 256 * 32)), dim3(BLK), 0, ctx->stream, pw.ix,
-                               (const unsigned long long *)P.cinfo, P.nchunks, wpc, (const uint32_t *)rbits, k, tab, d_err, 0u);
+                               (const unsigned long long *)P.cinfo, P.nchunks, wpc, rbits, k, tab, d_err, 0u);
         tend(ctx);
         if (hipGetLastError() != hipSuccess) return fail(ctx, SMX_DEVICE_ERROR, "k_pm_tab launch failed");
         if (last) {  // 5 B per k-mer of local links and unclipped masks + the remote bits: back to the arena before the walks' arrays are asked for

@@ -49,7 +49,7 @@ SELECTION_SMALL_PARTITIONS = [
     # chain by chain in LDS, incremental node-table renewal) against the oracle AND the sorted route, masks and k-mer file included
     ("tests/test_pm_route_gpu.py", "test_early_clippers_on_the_partition_major_route_vs_oracle_seeded and (55-1-95-0-extra1 or 33-2-117-1-extra5)"),
     # round 6: the node table written by the dedupe stage from LDS (default) against link array + k_pm_tab, one scan against two for the kept paths' places
-    ("tests/test_pm_route_gpu.py", "test_node_table_by_the_dedupe_stage_or_afterwards and pm_fuse_tab0-walk_pack0-pm_remote_mirror1-skm_cap512"),
+    ("tests/test_pm_route_gpu.py", "test_node_table_by_the_dedupe_stage_or_afterwards and pm_fuse_tab0-walk_pack0-pm_remote_mirror0-skm_cap512"),
     # round 5: the same route on PLAIN k-mer records where the byte has no room in the record (k = 31, 127; with cut partitions and perfect loops)
     ("tests/test_pm_route_gpu.py", "(without_spare and (31 or 127)) or (plain_records_cut_partitions and 127)"),
     ("tests/test_ext_route_gpu.py", "vs_oracle_seeded and (21 or 55)"),

@@ -93,12 +93,12 @@ def test_vs_oracle_seeded(k, tmp_path):
         assert _same_kmers(r, old) and r["info"] == old["info"]
 
 
-@pytest.mark.parametrize("opts", [{"pm_fuse_tab": 0}, {"walk_pack": 0}, {"pm_remote_mirror": 1}, {"pm_fuse_tab": 0, "walk_pack": 0, "pm_remote_mirror": 1, "skm_cap": 512}, {"skm_cap": 512}],
+@pytest.mark.parametrize("opts", [{"pm_fuse_tab": 0}, {"walk_pack": 0}, {"pm_remote_mirror": 0}, {"pm_fuse_tab": 0, "walk_pack": 0, "pm_remote_mirror": 0, "skm_cap": 512}, {"skm_cap": 512}],
                          ids=lambda o: "-".join(f"{k_}{v_}" for k_, v_ in o.items()))
 def test_node_table_by_the_dedupe_stage_or_afterwards(opts, tmp_path):
     """round 6: the dedupe stage writes the node table of its chunks from LDS (pm_fuse_tab, default; 0 = link array + k_pm_tab afterwards), and the kept paths get
     their word offset and edge index from one scan (walk_pack, default; 0 = two arrays, two scans), a successor outside its chunk is looked up from one end of the edge
-    for both (pm_remote_mirror = 1; default 0 = from each end: it measured no gain): every combination gives the oracle's graph, record for record the
+    for both (pm_remote_mirror, default; 0 = from each end): every combination gives the oracle's graph, record for record the
     same as the default's — with a tiny chunk capacity too (many chunks, cut partitions, chains that end at a chunk's edge all the time)"""
     from oracle import oracle
     for k, threads in ((21, 1), (55, 2), (63, 1)):
