@@ -140,6 +140,7 @@ struct PmFind {
         }
         return nd;
     }
+
     // The k-mers of a removed tip. A lane that steps through them one by one has a dependent read per k-mer in front of it (150 ms of the clipper at
     // config 3, measured); here it crosses a chunk with the jump word and only MARKS the head of the chain (hmark[head]: "isolate the s + 1 k-mers of this
     // chain"): a chain of non-junction k-mers lies inside the tip as a whole (a tip ends at a dead end, which ends its chain). k_pm_isolate_chains then follows
@@ -550,10 +551,10 @@ __global__ void __launch_bounds__(BLK) k_pm_retab_changed(PmIndex ix, uint8_t *m
         const unsigned mn = ix.mask[r], mw = mask_was[r];
         if (mn == mw) continue;
         mask_was[r] = (uint8_t)mn;
-        if (mn == 0) {  // isolated (most edited k-mers are: the k-mers of removed tips): two empty entries, nothing to read
-            *reinterpret_cast<ulonglong2 *>(tab + 2 * r) = make_ulonglong2(0ull, 0ull);
-            continue;
-        }
+        // isolated (most edited k-mers are: the k-mers of removed tips, 2.5 G of 4.3 G at bench scale): nothing leads to such a k-mer any more — the junction lost
+        // the branch bit, the rest of the tip is isolated with it — so its two entries are never read again and are LEFT as they were (writing 16 B of zeros for each
+        // was 40 GB of the 36 ms this pass took)
+        if (mn == 0) continue;
 #pragma unroll
         for (unsigned o = 0; o < 2; ++o) {
             const unsigned on = (o ? brev8(mn) : mn) & 15u, ow = (o ? brev8(mw) : mw) & 15u;
