@@ -1018,7 +1018,13 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             // route 0 (round 6): the clippers look k-mers up through the partition table and walk the route's own node table; whenever they have
             // edited the masks, the table is made again (retab: k_pm_tab with the unclipped masks beside the clipped ones + k_pm_remote)
             if (!retab) return fail(ctx, SMX_DEVICE_ERROR, "the early clippers on the partition-major route need a way to renew the node table");
-            PmFind<NW> ixp{pm->ix, pm->jmp};
+            PmFind<NW> ixp{};
+            ixp.ix = pm->ix;
+            ixp.jmp = pm->jmp;
+            ixp.cinfo = pm->cinfo;
+            ixp.cob = pm->cob;
+            ixp.nchunks = pm->nchunks;
+            ixp.bytes_ok = ctx->opt_early_at ? 0u : 1u;  // (the tip clipper is then the first to edit the mask array: its branch walks still see the records' own bytes)
             const std::function<int(const node_t **)> resucc = [&](const node_t **s) -> int {
                 if (masks_edited)
                     if (int rc = (*retab)(false)) return rc;
@@ -1032,7 +1038,7 @@ int graph_from_masks(smx_ctx *ctx, unsigned k, node_t *tab, bool tab_valid, uint
             const std::function<int(const uint8_t *, uint8_t *)> marked_chains = [&](const uint8_t *hmark, uint8_t *isolate) -> int {
                 if (pm->nchunks)
                     hipLaunchKernelGGL(k_pm_isolate_chains, dim3(std::min<uint32_t>(pm->nchunks, 256 * 16)), dim3(BLK), ilds, ctx->stream, pm->cinfo, pm->nchunks, maxn,
-                                       (const node_t *)tab, pm->jmp, hmark, isolate);
+                                       (const node_t *)tab, pm->jmp, hmark, isolate, (const uint32_t *)ctx->pm.llink);
                 HIPCHK(hipGetLastError());
                 return 0;
             };

@@ -58,6 +58,7 @@ struct PmState {
     // the node table of the clean chunks written by the dedupe stage itself (PmOut::tab, smx_superkmer.hip): asked for by the route (fuse_tab), allocated by
     // run_prededupe at the output's capacity, taken over by pm_route
     bool fuse_tab = false;
+    bool keep_links = false;  // ... and the local links are written all the same (an early clipper will isolate whole chains: k_pm_isolate_chains follows them, 4 B per k-mer)
     unsigned long long *tab = nullptr, *tab_stats = nullptr;
     uint32_t *jmp = nullptr, *rbits = nullptr;
     uint32_t max_chunks = 0, nchunks = 0, T = 0, nkey = 0;

@@ -541,11 +541,15 @@ struct FileFind {
     RankDir dir;
     __device__ __forceinline__ Rec<NW> kmer(uint64_t r) const { return kmers[r]; }
     __device__ __forceinline__ node_t find(const Rec<NW> &y) const { return kmer_rank<NW>(kmers, dir, y); }
+    __device__ __forceinline__ node_t find_from(const Rec<NW> &y, uint64_t, int &byte0) const {  // (PmFind knows a shorter way from the k-mer it comes from)
+        byte0 = -1;
+        return find(y);
+    }
     // successor of a node of a NON-junction k-mer in the table the clippers walk (k_succ's format here)
     __device__ __forceinline__ node_t next(const node_t *__restrict__ succ, node_t nd) const { return succ_node(succ[nd]); }
     // FindForward (early_simplification.hpp:102-112): from nd along non-junction k-mers, at most until cnt == bound; returns the node it stops at
     // (NODE_NONE: inconsistent index)
-    __device__ __forceinline__ node_t advance(const node_t *__restrict__ succ, const uint8_t *__restrict__ mask, node_t nd, uint32_t &cnt, uint32_t bound) const {
+    __device__ __forceinline__ node_t advance(const node_t *__restrict__ succ, const uint8_t *__restrict__ mask, node_t nd, uint32_t &cnt, uint32_t bound, int = -1) const {
         while (cnt < bound && !mask_junction(mask[nd >> 1])) {
             ++cnt;
             nd = succ_node(succ[nd]);
@@ -639,14 +643,15 @@ __global__ void __launch_bounds__(BLK) k_tip_branch(IX ix, const uint8_t *mask, 
             if (o) x = rec_rc<NW>(x, k);
             unsigned yo;
             const Rec<NW> y = rec_canon<NW>(rec_shl<NW>(x, k, c), k, yo);
-            const node_t ry = ix.find(y);
+            int byte0;
+            const node_t ry = ix.find_from(y, r, byte0);
             if (ry == NODE_NONE) {
                 atomicAdd(err, 1u);
             } else {
                 node_t nd = (ry << 1) | yo;
                 uint32_t cnt = 0;
                 first = nd;
-                nd = ix.advance(succ, mask, nd, cnt, bound);
+                nd = ix.advance(succ, mask, nd, cnt, bound, byte0);
                 if (nd == NODE_NONE) {
                     len = TIP_INF;
                 } else {

@@ -843,6 +843,8 @@ int run_prededupe(smx_ctx *ctx, unsigned K, const ReadSel &sel, uint64_t nwin, R
             if (int rc = dalloc(ctx, &P.tab_stats, 2, false)) return rc;
             HIPCHK(hipMemsetAsync(P.rbits, 0, (size_t)P.max_chunks * (T >> 5) * 4, ctx->stream));
             HIPCHK(hipMemsetAsync(P.tab_stats, 0, 16, ctx->stream));
+            if (P.keep_links)  // (every clean winner's word is written by its chunk: no preset; nobody reads the words of the sorted tail)
+                if (int rc = dalloc(ctx, &P.llink, out_cap + 16, false)) return rc;
         } else {
             if (int rc = dalloc(ctx, &P.llink, out_cap + 16, false)) return rc;
             HIPCHK(hipMemsetAsync(P.llink, 0xFF, (size_t)(out_cap + 16) * 4, ctx->stream));

@@ -109,6 +109,21 @@ __device__ __forceinline__ Rec<NW> pm_node_kmer(const Rec<NW> *__restrict__ recs
     return (node & 1) ? rec_rc<NW>(x, k) : x;
 }
 
+// chunk (id, base) of clean record r
+__device__ __forceinline__ uint32_t pm_chunk_of(const unsigned long long *__restrict__ cinfo, const uint32_t *__restrict__ cob, uint32_t nchunks, uint64_t r,
+                                                uint64_t &base) {
+    uint32_t c = cob[r >> 8];  // the chunk of record 256 * (r >> 8); r lies in it or in one of the next few
+    unsigned long long ci = cinfo[c];
+    while (c + 1 < nchunks) {
+        const unsigned long long nx = cinfo[c + 1];
+        if ((nx & PM_BASE_MASK) > r) break;
+        ci = nx;
+        ++c;
+    }
+    base = ci & PM_BASE_MASK;
+    return c;
+}
+
 __device__ __forceinline__ uint32_t pm_jump_steps(uint32_t j) { return (j >> 16) & 0x7FFFu; }  // (bit 31 of a jump word: its far end is a junction, see k_pm_tab)
 // the early clippers' view of the graph on this route (FileFind in smx_graph.hip is the other one): index = place in the partition-major records
 template <int NW>
@@ -116,6 +131,26 @@ struct PmFind {
     PmIndex ix;
     __device__ __forceinline__ Rec<NW> kmer(uint64_t r) const { return rec_pure_xs<NW>(((const Rec<NW> *)ix.recs)[r], ix.xs); }
     __device__ __forceinline__ node_t find(const Rec<NW> &y) const { return pm_find<NW>(ix, y); }
+    // the successor y of the k-mer at index r: in r's own chunk 19 times in 20 (no minimizer scan, no partition word: one line of 128 B less per branch), and the
+    // byte of the found record where the record bytes are still the graph's masks (bytes_ok: no clipper has edited the mask array yet) — else -1
+    const unsigned long long *cinfo = nullptr;
+    const uint32_t *cob = nullptr;
+    uint32_t nchunks = 0;
+    unsigned bytes_ok = 0;
+    __device__ __forceinline__ node_t find_from(const Rec<NW> &y, uint64_t r, int &byte0) const {
+        byte0 = -1;
+        if (cinfo && r < ix.nclean) {
+            uint64_t cbase;
+            const uint32_t cid = pm_chunk_of(cinfo, cob, nchunks, r, cbase);
+            Rec<NW> raw;
+            const node_t ry = pm_probe<NW>((const Rec<NW> *)ix.recs, ix.meta + (size_t)cid * ix.ngroups, ix.T, cbase, y, rec_hash32<NW>(y), ix.xs, &raw);
+            if (ry != NODE_NONE) {
+                if (bytes_ok && ix.xs) byte0 = (int)(raw.w[NW - 1] & 0xFFu);
+                return ry;
+            }
+        }
+        return pm_find<NW>(ix, y);
+    }
     // (the table the clippers walk IS the route's node table here: no second array of 16 B per k-mer next to it)
     __device__ __forceinline__ node_t next(const node_t *__restrict__ tab, node_t nd) const { return tab[nd] & TAB_NODE_MASK; }
     const uint32_t *jmp;  // the jump words of the node table (chains inside a chunk)
@@ -123,8 +158,11 @@ struct PmFind {
     // cross it — exactly: the reference's loop takes a step while cnt < bound, so it reaches the far end of the chain iff cnt + s <= bound, and
     // otherwise stops INSIDE it, on a non-junction k-mer (which is no dead end: the branch is "too long" whatever that node is). 95 steps are
     // ~6 chunks: a dozen sectors instead of 95 dependent ones per branch.
-    __device__ __forceinline__ node_t advance(const node_t *__restrict__ tab, const uint8_t *__restrict__ mask, node_t nd, uint32_t &cnt, uint32_t bound) const {
-        while (cnt < bound && !mask_junction(mask[nd >> 1])) {
+    __device__ __forceinline__ node_t advance(const node_t *__restrict__ tab, const uint8_t *__restrict__ mask, node_t nd, uint32_t &cnt, uint32_t bound, int byte0 = -1) const {
+        while (cnt < bound) {
+            const unsigned mb = byte0 >= 0 ? (unsigned)byte0 : (unsigned)mask[nd >> 1];  // (the first node's byte may come with its record: find_from)
+            byte0 = -1;
+            if (mask_junction(mb)) break;
             const uint32_t j = jmp[nd], s = pm_jump_steps(j);
             if (s) {
                 if (cnt + s > bound) {  // the loop would stop on an interior k-mer of this chain: any of them tells the caller "not a tip"
@@ -165,7 +203,9 @@ struct PmFind {
 // the marked chains of a chunk (PmFind::isolate_tip): the chunk's node-table entries are loaded into LDS once, every marked head is followed for the steps its jump
 // word counts. One workgroup per chunk; chunks without a mark cost their 2 bytes per k-mer of marks.
 __global__ void __launch_bounds__(BLK) k_pm_isolate_chains(const unsigned long long *__restrict__ cinfo, uint32_t nchunks, uint32_t maxn, const node_t *__restrict__ tab,
-                                                           const uint32_t *__restrict__ jmp, const uint8_t *__restrict__ hmark, uint8_t *isolate) {
+                                                           const uint32_t *__restrict__ jmp, const uint8_t *__restrict__ hmark, uint8_t *isolate,
+                                                           const uint32_t *__restrict__ llink /* the dedupe stage's local links where they were kept (4 B per k-mer instead of the
+                                                                                                 16 B of its two node entries: a chain IS a run of these links), else nullptr */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pm_lds[];
     uint32_t *ls = pm_lds;                     // [2 * maxn] local successor of every node (0xFFFFFFFF: leaves the chunk)
     uint16_t *list = (uint16_t *)(ls + 2 * maxn);  // marked heads
@@ -183,9 +223,17 @@ __global__ void __launch_bounds__(BLK) k_pm_isolate_chains(const unsigned long l
         __syncthreads();
         const uint32_t n = s_n;
         if (!n) continue;
-        for (uint32_t nd = threadIdx.x; nd < nn; nd += BLK) {
-            const node_t t = tab[2 * base + nd] & TAB_NODE_MASK;
-            ls[nd] = (t >= 2 * base && t < 2 * base + nn) ? (uint32_t)(t - 2 * base) : 0xFFFFFFFFu;
+        if (llink) {
+            for (uint32_t r = threadIdx.x; r < nn / 2; r += BLK) {
+                const uint32_t ll = llink[base + r], l0 = ll & 0xFFFFu, l1 = ll >> 16;
+                ls[2 * r] = l0 < nn ? l0 : 0xFFFFFFFFu;
+                ls[2 * r + 1] = l1 < nn ? l1 : 0xFFFFFFFFu;
+            }
+        } else {
+            for (uint32_t nd = threadIdx.x; nd < nn; nd += BLK) {
+                const node_t t = tab[2 * base + nd] & TAB_NODE_MASK;
+                ls[nd] = (t >= 2 * base && t < 2 * base + nn) ? (uint32_t)(t - 2 * base) : 0xFFFFFFFFu;
+            }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += BLK) {
@@ -719,21 +767,6 @@ __global__ void k_pm_cob(const unsigned long long *__restrict__ cinfo, uint32_t 
         for (uint64_t b = (base + 255) >> 8; (b << 8) < base + n; ++b) cob[b] = c;
     }
 }
-// chunk (id, base) of clean record r
-__device__ __forceinline__ uint32_t pm_chunk_of(const unsigned long long *__restrict__ cinfo, const uint32_t *__restrict__ cob, uint32_t nchunks, uint64_t r,
-                                                uint64_t &base) {
-    uint32_t c = cob[r >> 8];  // the chunk of record 256 * (r >> 8); r lies in it or in one of the next few
-    unsigned long long ci = cinfo[c];
-    while (c + 1 < nchunks) {
-        const unsigned long long nx = cinfo[c + 1];
-        if ((nx & PM_BASE_MASK) > r) break;
-        ci = nx;
-        ++c;
-    }
-    base = ci & PM_BASE_MASK;
-    return c;
-}
-
 // ---- walks ----------------------------------------------------------------------------------------------------------------------
 // k_walk_len on the partition-major numbering: the first node by pm_find, chunks crossed by their jump words
 template <int NW>

@@ -122,7 +122,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         if (10.0 * (double)nwin > avail) return bail(SMX_ROUTE_NA);  // the stage alone would need batches
         // record + mask byte + share of the group words + local links, or (fuse_tab) the node table and jump words the stage writes itself
         const bool fuse = ctx->opt_pm_fuse_tab != 0 && !(clip && ctx->opt_pm_full_retab != 0);
-        const double fit1 = (avail - 5.0 * (double)nwin) / ((double)W + (fuse ? 3.0 + 16.0 + 8.0 : 7.0));
+        const double fit1 = (avail - 5.0 * (double)nwin) / ((double)W + (fuse ? 3.0 + 16.0 + 8.0 + (clip ? 4.0 : 0.0) : 7.0));
         const double fit2 = avail / ((double)W + 1.0 + 16.0 + 8.0 + 8.0);
         const double fit = std::max(std::min(fit1, fit2), 1.0);
         if (fit < (double)nwin) out_cap = (uint64_t)fit;
@@ -138,6 +138,7 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
         ctx->pm.nx = nx;
         // (the whole table again after an early clipper — option pm_full_retab — is k_pm_tab on the edited masks: it needs the link array)
         ctx->pm.fuse_tab = ctx->opt_pm_fuse_tab != 0 && !(clip && ctx->opt_pm_full_retab != 0);
+        ctx->pm.keep_links = clip;
         rc = run_prededupe<NW>(ctx, k, sel, nwin, &recs, &n, out_cap);
         ctx->ext_mode = false;
         ctx->pm.active = false;
@@ -310,7 +311,8 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
             hipMemcpyAsync(&hpal, P.pals, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
             return fail(ctx, SMX_DEVICE_ERROR, "node table pass failed: %s", hipGetErrorString(hipGetLastError()));
         hs[1] += hpal;  // palindromic (k+1)-mers: the clean winners' by the dedupe stage, the dirty region's by k_pm_tab_dirty
-        if (!clip || !ctx->opt_pm_full_retab) {  // (only k_pm_tab reads the local links — once, unless an early clipper makes the WHOLE table again: option pm_full_retab)
+        if (!clip) {  // (k_pm_tab reads the local links once; with an early clipper they stay until the last renewal of the table: k_pm_isolate_chains follows them, and
+                      // option pm_full_retab makes the whole table again from them)
             arena_put(ctx, P.llink);
             P.llink = nullptr;
         }
@@ -372,6 +374,8 @@ int pm_route(smx_ctx *ctx, unsigned k, unsigned B, WallTrace &gwt) {
                 }
                 mask_orig = nullptr;
                 rbits = nullptr;
+                arena_put(ctx, P.llink);
+                P.llink = nullptr;
             }
             return 0;
         }
