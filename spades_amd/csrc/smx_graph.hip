@@ -941,14 +941,19 @@ __global__ void __launch_bounds__(BLK) k_cand_expand(const uint8_t *mask, const 
     __shared__ uint32_t scratch[BLK / 64 + 2];
     const uint64_t r0 = (uint64_t)blockIdx.x * CAND_TILE + (uint64_t)threadIdx.x * CAND_PER;
     uint32_t c = 0;
+    uint64_t mm = 0;  // (the thread's 8 bytes as one load where all of them exist — k_cand_tiles does the same; bytes past D0 stay 0 = not a junction with de-edges)
+    if (r0 + CAND_PER <= D0) mm = *reinterpret_cast<const uint64_t *>(mask + r0);
+    else
+        for (int j = 0; j < CAND_PER; ++j)
+            if (r0 + j < D0) mm |= (uint64_t)mask[r0 + j] << (8 * j);
     for (int j = 0; j < CAND_PER; ++j)
-        if (r0 + j < D0) c += cand_of_mask(mask[r0 + j]);
+        if (r0 + j < D0) c += cand_of_mask((unsigned)(mm >> (8 * j)) & 0xFFu);
     uint32_t tot;
     unsigned long long o = toff[blockIdx.x] + block_excl_scan<uint32_t>(c, scratch, &tot);
     for (int j = 0; j < CAND_PER; ++j) {
         const uint64_t r = r0 + j;
         if (r >= D0) break;
-        const unsigned m = mask[r];
+        const unsigned m = (unsigned)(mm >> (8 * j)) & 0xFFu;
         if (!mask_junction(m)) continue;
         for (unsigned cc = 0; cc < 4; ++cc)
             if (m & (1u << cc)) cand[o++] = (r << 3) | cc;

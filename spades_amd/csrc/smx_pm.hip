@@ -171,6 +171,16 @@ struct PmFind {
                 }
                 cnt += s;
                 nd = (node_t)((long long)nd + (long long)(int16_t)(j & 0xFFFFu));
+                if (bytes_ok) {
+                    // Bit 31 of the jump word still tells the truth (no clipper has edited the masks): set — the chain's last node is a junction, the loop would
+                    // read its byte and stop (the caller reads that byte anyway); clear — it is a non-junction k-mer whose successor lies in another chunk: the loop
+                    // would read its byte (no junction), its jump word (0: no chain starts at a chain's end) and step through its entry. One line instead of three.
+                    if (j >> 31) break;
+                    if (cnt < bound) {
+                        ++cnt;
+                        nd = tab[nd] & TAB_NODE_MASK;
+                    }
+                }
                 continue;
             }
             ++cnt;
