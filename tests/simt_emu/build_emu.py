@@ -35,8 +35,13 @@ def transform(text):
     return text
 
 
+FLAGS_STAMP = os.path.join(BUILD, "cxxflags.txt")  # what EMU_CXXFLAGS the library was built with (a sanitizer build must not be taken for the plain one)
+
+
 def stale():
     if not os.path.exists(LIB):
+        return True
+    if (open(FLAGS_STAMP).read() if os.path.exists(FLAGS_STAMP) else "") != os.environ.get("EMU_CXXFLAGS", ""):
         return True
     t = os.path.getmtime(LIB)
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))] + [os.path.join(ROOT, "include", "smx.h"),
@@ -58,6 +63,7 @@ def build(force=False):
     cmd = ["g++", "-std=c++17", "-O1", "-g0", "-fPIC", "-shared", "-pthread", "-x", "c++", "-DEMU_DEFINE_SWITCH", "-Wno-unknown-pragmas", "-Wno-attributes",
            "-fno-omit-frame-pointer", *os.environ.get("EMU_CXXFLAGS", "").split(), "-I", HERE, "-include", os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(src, "smx_api.hip"), "-o", LIB]
     subprocess.check_call(cmd)
+    open(FLAGS_STAMP, "w").write(os.environ.get("EMU_CXXFLAGS", ""))
     return LIB
 
 
